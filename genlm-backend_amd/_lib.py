@@ -1,0 +1,111 @@
+"""ctypes binding of libglb_hip.so (C ABI: include/glb.h).
+
+There is no fallback: if the shared object is missing or cannot be loaded this module raises, and
+every compute entry point raises when the HIP runtime sees no device.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libglb_hip.so")
+
+GLB_OK, GLB_EINVAL, GLB_EUNSUPPORTED, GLB_EHIP, GLB_ENOSPC = 0, 1, 2, 3, 4
+F32, BF16, F16 = 0, 1, 2
+MASK_NONE, MASK_BITS, MASK_F32 = 0, 1, 2
+RNG_NONE, RNG_PHILOX, RNG_NOISE = 0, 1, 2
+
+
+class GlbError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"glb error {code}: {msg}")
+        self.code = code
+
+
+class StepArgs(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("logits", C.c_void_p),
+        ("dtype", C.c_int32),
+        ("n_rows", C.c_int64),
+        ("vocab", C.c_int64),
+        ("ld", C.c_int64),
+        ("logit_scale", C.c_float),
+        ("n_particles", C.c_int64),
+        ("row_of", C.c_void_p),
+        ("mask_kind", C.c_int32),
+        ("mask", C.c_void_p),
+        ("mask_ld", C.c_int64),
+        ("n_masks", C.c_int64),
+        ("mask_id", C.c_void_p),
+        ("rng_mode", C.c_int32),
+        ("noise", C.c_void_p),
+        ("noise_ld", C.c_int64),
+        ("seed", C.c_uint64),
+        ("offset", C.c_uint64),
+        ("particle_base", C.c_int64),
+        ("out_logZ", C.c_void_p),
+        ("out_lse", C.c_void_p),
+        ("out_token", C.c_void_p),
+        ("variant", C.c_int32),
+    ]
+
+
+class MT19937(C.Structure):
+    _fields_ = [("mt", C.c_uint32 * 624), ("idx", C.c_int32)]
+
+
+# every symbol include/glb.h declares: name -> (restype, argtypes)
+_vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+SYMBOLS = {
+    "glb_version": (C.c_char_p, []),
+    "glb_abi_version": (C.c_int, []),
+    "glb_last_error": (C.c_int, [C.c_char_p, _sz]),
+    "glb_device_count": (C.c_int, []),
+    "glb_logprob_mask_sample": (C.c_int, [C.POINTER(StepArgs), _vp]),
+    "glb_log_softmax_rows": (C.c_int, [_vp, _i32, _i64, _i64, _i64, _f32, _vp, _i64, _vp, _vp]),
+    "glb_mask_f32_to_bits": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp]),
+    "glb_group_contexts_workspace": (_sz, [_i64]),
+    "glb_group_contexts": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "glb_match_prefixes": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "glb_gather_padded": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "glb_gather_kv_padded": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp]),
+    "glb_particles_advance": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "glb_normalize_weights": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
+    "glb_mt19937_seed": (None, [C.POINTER(MT19937), C.c_uint64]),
+    "glb_mt19937_exponential_f32": (C.c_int, [C.POINTER(MT19937), _vp, _i64]),
+    "glb_philox4x32_10": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libglb_hip.so and bind every symbol.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `make -C genlm-backend_amd/csrc -j8` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
+        fn.restype = res
+        fn.argtypes = args
+    if lib.glb_abi_version() != 1:
+        raise ImportError(f"libglb_hip.so ABI {lib.glb_abi_version()} != 1")
+    _lib = lib
+    return lib
+
+
+def last_error():
+    buf = C.create_string_buffer(512)
+    load().glb_last_error(buf, 512)
+    return buf.value.decode()
+
+
+def check(rc):
+    if rc != GLB_OK:
+        raise GlbError(rc, last_error())

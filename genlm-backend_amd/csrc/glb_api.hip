@@ -1,0 +1,649 @@
+// glb_api.hip — C ABI of libglb_hip.so (include/glb.h): argument validation, launch-geometry
+// selection, the small bookkeeping kernels of the hot path, and the host-side RNG helpers.
+// gfx950 only.  No entry point allocates, frees or synchronises.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/glb.h"
+#include "glb_row_kernel.hpp"
+
+namespace glb {
+// launchers exported by the nine glb_row_tu.hip translation units (dtype x mode)
+#define GLB_DECL(dt, mode) \
+  hipError_t launch_row_##dt##_##mode(const RowParams &p, int mask_kind, int geom, hipStream_t s);
+GLB_DECL(0, 0) GLB_DECL(0, 1) GLB_DECL(0, 2)
+GLB_DECL(1, 0) GLB_DECL(1, 1) GLB_DECL(1, 2)
+GLB_DECL(2, 0) GLB_DECL(2, 1) GLB_DECL(2, 2)
+#undef GLB_DECL
+}  // namespace glb
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+int hip_fail(hipError_t e, const char *what) {
+  return fail(GLB_EHIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+// geometry table shared with glb_row_tu.hip: id -> capacity in 16-byte vectors
+struct Geom { int id, threads, nvl; };
+const Geom kGeoms[] = {{1, 256, 4}, {2, 1024, 4}, {3, 1024, 8}, {4, 1024, 13}, {5, 1024, 16}};
+
+int pick_geom(int64_t vocab, int dtype, int variant) {
+  const int epv = dtype == GLB_F32 ? 4 : 8;
+  // worst case alignment pad is epv-1 leading elements
+  const int64_t nv_max = (vocab + (epv - 1) + epv - 1) / epv;
+  if (variant > 0) {
+    for (const Geom &g : kGeoms)
+      if (g.id == variant) return (int64_t)g.threads * g.nvl >= nv_max ? g.id : -1;
+    return -1;
+  }
+  for (const Geom &g : kGeoms)
+    if ((int64_t)g.threads * g.nvl >= nv_max) return g.id;
+  return 0;
+}
+
+hipError_t dispatch_row(int dtype, int mode, const glb::RowParams &p, int mask_kind, int geom,
+                        hipStream_t s) {
+  using namespace glb;
+  switch (dtype * 3 + mode) {
+    case 0: return launch_row_0_0(p, mask_kind, geom, s);
+    case 1: return launch_row_0_1(p, mask_kind, geom, s);
+    case 2: return launch_row_0_2(p, mask_kind, geom, s);
+    case 3: return launch_row_1_0(p, mask_kind, geom, s);
+    case 4: return launch_row_1_1(p, mask_kind, geom, s);
+    case 5: return launch_row_1_2(p, mask_kind, geom, s);
+    case 6: return launch_row_2_0(p, mask_kind, geom, s);
+    case 7: return launch_row_2_1(p, mask_kind, geom, s);
+    case 8: return launch_row_2_2(p, mask_kind, geom, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------------------
+// small kernels
+// ---------------------------------------------------------------------------------------------
+
+// one thread per output word: bit = (mask == 0); flags any value that is neither 0 nor -inf
+__global__ void mask_to_bits_kernel(const float *mask, int64_t n_masks, int64_t V, int64_t mask_ld,
+                                    uint32_t *bits, int64_t bits_ld, int32_t *nonbinary) {
+  const int64_t words = bits_ld;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n_masks * words) return;
+  const int64_t k = gid / words, w = gid % words;
+  const float *row = mask + k * mask_ld;
+  uint32_t out = 0;
+  bool nb = false;
+  for (int b = 0; b < 32; ++b) {
+    const int64_t j = w * 32 + b;
+    if (j < V) {
+      const float v = row[j];
+      if (v == 0.0f) out |= 1u << b;
+      else if (!(v == glb::kNegInf)) nb = true;
+    }
+  }
+  bits[k * bits_ld + w] = out;
+  if (nb && nonbinary) *nonbinary = 1;
+}
+
+__device__ inline uint64_t hash_ctx(const int32_t *t, int64_t len) {
+  uint64_t h = 0xcbf29ce484222325ull ^ (uint64_t)len;
+  for (int64_t i = 0; i < len; ++i) {
+    h ^= (uint32_t)t[i];
+    h *= 0x100000001b3ull;
+    h ^= h >> 29;
+  }
+  return h;
+}
+
+__device__ inline bool same_ctx(const int32_t *tok, const int64_t *off, int64_t i, int64_t j) {
+  const int64_t li = off[i + 1] - off[i];
+  if (off[j + 1] - off[j] != li) return false;
+  const int32_t *a = tok + off[i], *b = tok + off[j];
+  for (int64_t t = 0; t < li; ++t)
+    if (a[t] != b[t]) return false;
+  return true;
+}
+
+// Exact dedup in first-appearance order, one 1024-thread workgroup (n is a particle count, the
+// whole job is a few microseconds of integer work; a single workgroup needs no grid-level sync).
+// Open-addressing table keyed by full token comparison: the slot owner is whichever context won
+// the CAS, the group representative is the minimum index that reached the slot (order independent).
+__global__ __launch_bounds__(1024) void group_contexts_kernel(
+    const int32_t *tok, const int64_t *off, int32_t n, int32_t cap, int32_t *table,
+    int32_t *minidx, int32_t *slot_of, int32_t *gid_of, int32_t *out_group_of, int32_t *out_rep,
+    int32_t *out_n_groups) {
+  const int T = 1024, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ int32_t s_wave[16];
+  __shared__ int32_t s_carry;
+  for (int i = tid; i < cap; i += T) {
+    table[i] = -1;
+    minidx[i] = 0x7fffffff;
+  }
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += T) {
+    const uint64_t h = hash_ctx(tok + off[i], off[i + 1] - off[i]);
+    int32_t slot = (int32_t)(h & (uint64_t)(cap - 1));
+    for (;;) {
+      const int32_t owner = atomicCAS(&table[slot], -1, i);
+      if (owner == -1 || owner == i || same_ctx(tok, off, owner, i)) break;
+      slot = (slot + 1) & (cap - 1);
+    }
+    slot_of[i] = slot;
+    atomicMin(&minidx[slot], i);
+  }
+  __syncthreads();
+  // exclusive scan of is_rep flags in chunks of T -> group ids in first-appearance order
+  for (int base = 0; base < n; base += T) {
+    const int i = base + tid;
+    const int32_t flag = (i < n && minidx[slot_of[i]] == i) ? 1 : 0;
+    int32_t incl = flag;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int32_t t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int32_t wbase = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const int32_t v = s_wave[w];
+      if (w < wave) wbase += v;
+      total += v;
+    }
+    const int32_t carry = s_carry;
+    if (flag) {
+      const int32_t g = carry + wbase + incl - 1;
+      gid_of[i] = g;
+      out_rep[g] = i;
+    }
+    __syncthreads();
+    if (tid == 0) s_carry = carry + total;
+    __syncthreads();
+  }
+  if (tid == 0) *out_n_groups = s_carry;
+  for (int i = tid; i < n; i += T) out_group_of[i] = gid_of[minidx[slot_of[i]]];
+}
+
+__global__ void match_prefixes_kernel(const int32_t *tok, const int64_t *off, int64_t n,
+                                      const int32_t *ptok, const int64_t *poff, int64_t np,
+                                      int32_t *out_prefix, int32_t *out_base) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t li = off[i + 1] - off[i];
+  const int32_t *c = tok + off[i];
+  int32_t best = -1;
+  int64_t bl = 0;
+  for (int64_t k = 0; k < np; ++k) {
+    const int64_t lk = poff[k + 1] - poff[k];
+    if (lk >= li || lk <= bl) continue;
+    const int32_t *q = ptok + poff[k];
+    bool eq = true;
+    for (int64_t t = 0; t < lk; ++t)
+      if (q[t] != c[t]) {
+        eq = false;
+        break;
+      }
+    if (eq) {
+      best = (int32_t)k;
+      bl = lk;
+    }
+  }
+  out_prefix[i] = best;
+  out_base[i] = (int32_t)bl;
+}
+
+// one thread per attention-mask column (the widest output); ids / positions share the tail columns
+__global__ void gather_padded_kernel(const int32_t *tok, const int64_t *off, const int32_t *sel,
+                                     int64_t n_sel, const int32_t *base, int64_t pad_id,
+                                     int64_t p_max, int64_t l_max, int64_t *ids, int64_t *am,
+                                     int64_t *pos, int32_t *last) {
+  const int64_t width = p_max + l_max;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n_sel * width) return;
+  const int64_t u = gid / width, p = gid % width;
+  const int64_t s = sel ? sel[u] : u;
+  const int64_t b = base ? base[s] : 0;
+  int64_t len = off[s + 1] - off[s] - b;
+  len = len < 0 ? 0 : (len > l_max ? l_max : len);
+  if (p < p_max) {
+    am[gid] = p < b ? 1 : 0;
+  } else {
+    const int64_t t = p - p_max;
+    const bool in = t < len;
+    am[gid] = in ? 1 : 0;
+    ids[u * l_max + t] = in ? (int64_t)tok[off[s] + b + t] : pad_id;
+    pos[u * l_max + t] = in ? b + t : 0;
+    if (t == 0 && last) last[u] = (int32_t)(len - 1);
+  }
+}
+
+// 16-byte (or elem-wide fallback) copies of prefix KV slabs into the zero-padded batch tensor
+template <typename VT>
+__global__ void gather_kv_kernel(const void *const *slabs, const int32_t *slab_len,
+                                 const int32_t *prefix_of, int64_t n_rows, int64_t heads,
+                                 int64_t row_vecs, int64_t p_max, VT *out) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = n_rows * heads * p_max * row_vecs;
+  if (gid >= total) return;
+  const int64_t x = gid % row_vecs;
+  const int64_t pp = (gid / row_vecs) % p_max;
+  const int64_t h = (gid / (row_vecs * p_max)) % heads;
+  const int64_t u = gid / (row_vecs * p_max * heads);
+  const int32_t k = prefix_of[u];
+  VT v{};
+  if (k >= 0) {
+    const int64_t pl = slab_len[k];
+    if (pp < pl) v = reinterpret_cast<const VT *>(slabs[k])[(h * pl + pp) * row_vecs + x];
+  }
+  out[gid] = v;
+}
+
+__global__ void particles_advance_kernel(int32_t *ctx, int64_t ctx_ld, int32_t *len,
+                                         int32_t *active, float *lw, const float *logZ,
+                                         const int32_t *tok, int64_t n, int32_t eos,
+                                         int32_t max_len) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !active[i]) return;
+  lw[i] += logZ[i];
+  const int32_t t = tok[i];
+  if (t == eos || t < 0) {
+    active[i] = 0;
+  } else {
+    const int32_t l = len[i];
+    ctx[i * ctx_ld + l] = t;
+    len[i] = l + 1;
+    if (l + 1 >= max_len) active[i] = 0;
+  }
+}
+
+// README.md:108-110 on the gathered log-weight vector, one workgroup, GLB math
+__global__ __launch_bounds__(1024) void normalize_weights_kernel(const float *lw, int64_t n,
+                                                                 float *probs, float *stats) {
+  using namespace glb;
+  const int T = 1024, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ float s_m[16];
+  __shared__ uint64_t s_s[2][16];
+  __shared__ float s_lse;
+  float m = kNegInf;
+  for (int64_t i = tid; i < n; i += T) m = fmaxf(m, lw[i]);
+  m = wave_max(m);
+  if (lane == 0) s_m[wave] = m;
+  __syncthreads();
+  m = s_m[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) m = fmaxf(m, s_m[w]);
+  const float N = __builtin_rintf(m * kLog2e), N2 = __builtin_rintf((m + m) * kLog2e);
+  const float Nb = N + (float)kFixShift, Nb2 = N2 + (float)kFixShift;
+  uint64_t S = 0, S2 = 0;
+  for (int64_t i = tid; i < n; i += T) {
+    const float v = lw[i];
+    S += fix_term(v, Nb);
+    S2 += fix_term(v + v, Nb2);
+  }
+  S = wave_sum_u64(S);
+  S2 = wave_sum_u64(S2);
+  if (lane == 0) {
+    s_s[0][wave] = S;
+    s_s[1][wave] = S2;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    S = 0;
+    S2 = 0;
+    for (int w = 0; w < 16; ++w) {
+      S += s_s[0][w];
+      S2 += s_s[1][w];
+    }
+    const double lse = S ? log_fix(S, (int32_t)N - kFixFrac) : (double)kNegInf;
+    const double lse2 = S2 ? log_fix(S2, (int32_t)N2 - kFixFrac) : (double)kNegInf;
+    s_lse = (float)lse;
+    if (stats) {
+      stats[0] = (float)lse;
+      const float d = (float)(2.0 * lse - lse2);
+      if (!(d > kNegInf) || !(d < -kNegInf)) {
+        stats[1] = 0.0f;
+      } else {
+        float nf, P;
+        exp_parts(d, nf, P);
+        stats[1] = __builtin_ldexpf(P, (int)nf - 30);
+      }
+    }
+  }
+  __syncthreads();
+  if (probs) {
+    const float lsef = s_lse;
+    for (int64_t i = tid; i < n; i += T) {
+      const float d = lw[i] - lsef;
+      float o = 0.0f;
+      if (d > kNegInf) {
+        float nf, P;
+        exp_parts(d, nf, P);
+        o = (nf < -120.0f) ? 0.0f : __builtin_ldexpf(P, (int)nf - 30);
+      }
+      probs[i] = o;
+    }
+  }
+}
+
+inline unsigned blocks_for(int64_t n, int t) { return (unsigned)((n + t - 1) / t); }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *glb_version(void) { return "glb-hip 0.1.0 (gfx950)"; }
+int glb_abi_version(void) { return GLB_ABI_VERSION; }
+
+int glb_last_error(char *buf, size_t n) {
+  if (!buf || n == 0) return GLB_EINVAL;
+  snprintf(buf, n, "%s", g_err.c_str());
+  return GLB_OK;
+}
+
+int glb_device_count(void) {
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  return c;
+}
+
+int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
+  if (!a) return fail(GLB_EINVAL, "glb_logprob_mask_sample: null args");
+  if (a->struct_size != sizeof(glb_step_args))
+    return fail(GLB_EINVAL, "glb_step_args.struct_size %u != %zu (ABI mismatch)", a->struct_size,
+                sizeof(glb_step_args));
+  if (!a->logits) return fail(GLB_EINVAL, "logits is null");
+  if (a->dtype < GLB_F32 || a->dtype > GLB_F16) return fail(GLB_EINVAL, "bad dtype %d", a->dtype);
+  if (a->n_rows <= 0 || a->vocab <= 0 || a->n_particles <= 0)
+    return fail(GLB_EINVAL, "n_rows=%lld vocab=%lld n_particles=%lld must be positive",
+                (long long)a->n_rows, (long long)a->vocab, (long long)a->n_particles);
+  if (a->ld < a->vocab) return fail(GLB_EINVAL, "ld %lld < vocab %lld", (long long)a->ld, (long long)a->vocab);
+  if (a->vocab > 0x7fffff00ll || a->n_particles > 0x7fffffffll)
+    return fail(GLB_EINVAL, "vocab / n_particles exceed 31 bits");
+  const int es = a->dtype == GLB_F32 ? 4 : 2;
+  if (((uintptr_t)a->logits) % es) return fail(GLB_EINVAL, "logits pointer not element aligned");
+  if (!a->row_of && a->n_particles != a->n_rows)
+    return fail(GLB_EINVAL, "row_of is null but n_particles != n_rows");
+  if (a->mask_kind < GLB_MASK_NONE || a->mask_kind > GLB_MASK_F32)
+    return fail(GLB_EINVAL, "bad mask_kind %d", a->mask_kind);
+  if (a->mask_kind != GLB_MASK_NONE) {
+    if (!a->mask || a->n_masks <= 0) return fail(GLB_EINVAL, "mask table missing");
+    const int64_t need = a->mask_kind == GLB_MASK_BITS ? (a->vocab + 31) / 32 : a->vocab;
+    if (a->mask_ld < need) return fail(GLB_EINVAL, "mask_ld %lld < %lld", (long long)a->mask_ld, (long long)need);
+    if (!a->mask_id && a->n_masks != 1 && a->n_masks != a->n_particles)
+      return fail(GLB_EINVAL, "mask_id is null but n_masks is neither 1 nor n_particles");
+    if (((uintptr_t)a->mask) % 4) return fail(GLB_EINVAL, "mask pointer not 4-byte aligned");
+  }
+  if (a->rng_mode < GLB_RNG_NONE || a->rng_mode > GLB_RNG_NOISE)
+    return fail(GLB_EINVAL, "bad rng_mode %d", a->rng_mode);
+  if (a->rng_mode == GLB_RNG_NOISE && (!a->noise || a->noise_ld < a->vocab))
+    return fail(GLB_EINVAL, "noise tensor missing or noise_ld < vocab");
+  if (a->rng_mode != GLB_RNG_NONE && !a->out_token)
+    return fail(GLB_EINVAL, "rng_mode set but out_token is null");
+  if (!(a->logit_scale == a->logit_scale)) return fail(GLB_EINVAL, "logit_scale is NaN");
+
+  const int geom = pick_geom(a->vocab, a->dtype, a->variant);
+  if (geom < 0) return fail(GLB_EINVAL, "variant %d cannot hold vocab %lld", a->variant, (long long)a->vocab);
+  if (geom == 0)
+    return fail(GLB_EUNSUPPORTED, "vocab %lld too large for the register-resident row kernel",
+                (long long)a->vocab);
+
+  glb::RowParams p{};
+  p.logits = a->logits;
+  p.ld = a->ld;
+  p.V = (int32_t)a->vocab;
+  p.use_scale = a->logit_scale != 1.0f;
+  p.scale = a->logit_scale;
+  p.n_particles = (int32_t)a->n_particles;
+  p.row_of = a->row_of;
+  p.mask = a->mask;
+  p.mask_ld = a->mask_ld;
+  p.mask_id = a->mask_id;
+  p.n_masks = (int32_t)a->n_masks;
+  p.noise = a->noise;
+  p.noise_ld = a->noise_ld;
+  p.seed = a->seed;
+  p.offset = a->offset;
+  p.particle_base = a->particle_base;
+  p.out_logZ = a->out_logZ;
+  p.out_lse = a->out_lse;
+  p.out_token = a->out_token;
+  p.out_logprobs = nullptr;
+  p.out_ld = 0;
+  const hipError_t e = dispatch_row(a->dtype, a->rng_mode, p, a->mask_kind, geom, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "row_kernel launch");
+  return GLB_OK;
+}
+
+int glb_log_softmax_rows(const void *logits, int32_t dtype, int64_t n_rows, int64_t vocab,
+                         int64_t ld, float logit_scale, float *out, int64_t out_ld, float *out_lse,
+                         void *stream) {
+  if (!logits) return fail(GLB_EINVAL, "logits is null");
+  if (dtype < GLB_F32 || dtype > GLB_F16) return fail(GLB_EINVAL, "bad dtype %d", dtype);
+  if (n_rows <= 0 || vocab <= 0) return fail(GLB_EINVAL, "n_rows / vocab must be positive");
+  if (ld < vocab || (out && out_ld < vocab)) return fail(GLB_EINVAL, "ld / out_ld smaller than vocab");
+  if (!out && !out_lse) return fail(GLB_EINVAL, "no output requested");
+  if (vocab > 0x7fffff00ll || n_rows > 0x7fffffffll) return fail(GLB_EINVAL, "size exceeds 31 bits");
+  if (out && ((uintptr_t)out) % 4) return fail(GLB_EINVAL, "out pointer not 4-byte aligned");
+  const int geom = pick_geom(vocab, dtype, 0);
+  if (geom == 0)
+    return fail(GLB_EUNSUPPORTED, "vocab %lld too large for the register-resident row kernel", (long long)vocab);
+  glb::RowParams p{};
+  p.logits = logits;
+  p.ld = ld;
+  p.V = (int32_t)vocab;
+  p.use_scale = logit_scale != 1.0f;
+  p.scale = logit_scale;
+  p.n_particles = (int32_t)n_rows;
+  p.out_lse = out_lse;
+  p.out_logprobs = out;
+  p.out_ld = out_ld;
+  const hipError_t e = dispatch_row(dtype, glb::kModeStats, p, glb::kMaskNone, geom, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "row_kernel launch");
+  return GLB_OK;
+}
+
+int glb_mask_f32_to_bits(const float *mask, int64_t n_masks, int64_t vocab, int64_t mask_ld,
+                         uint32_t *out_bits, int64_t bits_ld, int32_t *out_nonbinary, void *stream) {
+  if (!mask || !out_bits) return fail(GLB_EINVAL, "null pointer");
+  if (n_masks <= 0 || vocab <= 0 || mask_ld < vocab || bits_ld < (vocab + 31) / 32)
+    return fail(GLB_EINVAL, "bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  if (out_nonbinary) {
+    const hipError_t e = hipMemsetAsync(out_nonbinary, 0, sizeof(int32_t), s);
+    if (e != hipSuccess) return hip_fail(e, "memset");
+  }
+  const int64_t total = n_masks * bits_ld;
+  hipLaunchKernelGGL(mask_to_bits_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, mask,
+                     n_masks, vocab, mask_ld, out_bits, bits_ld, out_nonbinary);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "mask_to_bits launch");
+  return GLB_OK;
+}
+
+static int64_t group_cap(int64_t n) {
+  int64_t cap = 64;
+  while (cap < 2 * n) cap <<= 1;
+  return cap;
+}
+
+size_t glb_group_contexts_workspace(int64_t n) {
+  if (n <= 0) return 0;
+  return (size_t)(2 * group_cap(n) + 2 * n) * sizeof(int32_t);
+}
+
+int glb_group_contexts(const int32_t *tokens, const int64_t *offsets, int64_t n,
+                       int32_t *out_group_of, int32_t *out_rep, int32_t *out_n_groups,
+                       void *workspace, size_t workspace_bytes, void *stream) {
+  if (!tokens || !offsets || !out_group_of || !out_rep || !out_n_groups || !workspace)
+    return fail(GLB_EINVAL, "null pointer");
+  if (n <= 0 || n > (1 << 28)) return fail(GLB_EINVAL, "n out of range");
+  if (workspace_bytes < glb_group_contexts_workspace(n))
+    return fail(GLB_ENOSPC, "workspace %zu < %zu bytes", workspace_bytes, glb_group_contexts_workspace(n));
+  const int64_t cap = group_cap(n);
+  int32_t *table = (int32_t *)workspace, *minidx = table + cap, *slot_of = minidx + cap,
+          *gid_of = slot_of + n;
+  hipLaunchKernelGGL(group_contexts_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, tokens,
+                     offsets, (int32_t)n, (int32_t)cap, table, minidx, slot_of, gid_of,
+                     out_group_of, out_rep, out_n_groups);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "group_contexts launch");
+  return GLB_OK;
+}
+
+int glb_match_prefixes(const int32_t *tokens, const int64_t *offsets, int64_t n,
+                       const int32_t *prefix_tokens, const int64_t *prefix_offsets,
+                       int64_t n_prefixes, int32_t *out_prefix, int32_t *out_base, void *stream) {
+  if (!tokens || !offsets || !out_prefix || !out_base) return fail(GLB_EINVAL, "null pointer");
+  if (n <= 0 || n_prefixes < 0) return fail(GLB_EINVAL, "bad sizes");
+  if (n_prefixes > 0 && (!prefix_tokens || !prefix_offsets)) return fail(GLB_EINVAL, "null prefix table");
+  hipLaunchKernelGGL(match_prefixes_kernel, dim3(blocks_for(n, 256)), dim3(256), 0,
+                     (hipStream_t)stream, tokens, offsets, n, prefix_tokens, prefix_offsets,
+                     n_prefixes, out_prefix, out_base);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "match_prefixes launch");
+  return GLB_OK;
+}
+
+int glb_gather_padded(const int32_t *tokens, const int64_t *offsets, const int32_t *sel,
+                      int64_t n_sel, const int32_t *base, int64_t pad_id, int64_t p_max,
+                      int64_t l_max, int64_t *out_input_ids, int64_t *out_attention_mask,
+                      int64_t *out_position_ids, int32_t *out_last_index, void *stream) {
+  if (!tokens || !offsets || !out_input_ids || !out_attention_mask || !out_position_ids)
+    return fail(GLB_EINVAL, "null pointer");
+  if (n_sel <= 0 || l_max <= 0 || p_max < 0) return fail(GLB_EINVAL, "bad sizes");
+  const int64_t total = n_sel * (p_max + l_max);
+  hipLaunchKernelGGL(gather_padded_kernel, dim3(blocks_for(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, tokens, offsets, sel, n_sel, base, pad_id, p_max, l_max,
+                     out_input_ids, out_attention_mask, out_position_ids, out_last_index);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "gather_padded launch");
+  return GLB_OK;
+}
+
+int glb_gather_kv_padded(const void *const *slabs, const int32_t *slab_len, int64_t n_prefixes,
+                         const int32_t *prefix_of, int64_t n_rows, int64_t heads, int64_t head_dim,
+                         int64_t p_max, int32_t elem_bytes, void *out, void *stream) {
+  if (!slabs || !slab_len || !prefix_of || !out) return fail(GLB_EINVAL, "null pointer");
+  if (n_prefixes <= 0 || n_rows <= 0 || heads <= 0 || head_dim <= 0 || p_max <= 0)
+    return fail(GLB_EINVAL, "bad sizes");
+  if (elem_bytes != 2 && elem_bytes != 4) return fail(GLB_EINVAL, "elem_bytes must be 2 or 4");
+  const int64_t rowb = head_dim * elem_bytes;
+  hipStream_t s = (hipStream_t)stream;
+  if (rowb % 16 == 0 && ((uintptr_t)out) % 16 == 0) {
+    const int64_t rv = rowb / 16, total = n_rows * heads * p_max * rv;
+    hipLaunchKernelGGL(gather_kv_kernel<uint4>, dim3(blocks_for(total, 256)), dim3(256), 0, s,
+                       slabs, slab_len, prefix_of, n_rows, heads, rv, p_max, (uint4 *)out);
+  } else if (elem_bytes == 4) {
+    const int64_t total = n_rows * heads * p_max * head_dim;
+    hipLaunchKernelGGL(gather_kv_kernel<uint32_t>, dim3(blocks_for(total, 256)), dim3(256), 0, s,
+                       slabs, slab_len, prefix_of, n_rows, heads, head_dim, p_max, (uint32_t *)out);
+  } else {
+    const int64_t total = n_rows * heads * p_max * head_dim;
+    hipLaunchKernelGGL(gather_kv_kernel<uint16_t>, dim3(blocks_for(total, 256)), dim3(256), 0, s,
+                       slabs, slab_len, prefix_of, n_rows, heads, head_dim, p_max, (uint16_t *)out);
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "gather_kv launch");
+  return GLB_OK;
+}
+
+int glb_particles_advance(int32_t *contexts, int64_t ctx_ld, int32_t *lengths, int32_t *active,
+                          float *log_weights, const float *logZ, const int32_t *token, int64_t n,
+                          int32_t eos_id, int32_t max_len, void *stream) {
+  if (!contexts || !lengths || !active || !log_weights || !logZ || !token)
+    return fail(GLB_EINVAL, "null pointer");
+  if (n <= 0 || ctx_ld <= 0 || max_len > ctx_ld) return fail(GLB_EINVAL, "bad sizes");
+  hipLaunchKernelGGL(particles_advance_kernel, dim3(blocks_for(n, 256)), dim3(256), 0,
+                     (hipStream_t)stream, contexts, ctx_ld, lengths, active, log_weights, logZ,
+                     token, n, eos_id, max_len);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "particles_advance launch");
+  return GLB_OK;
+}
+
+int glb_normalize_weights(const float *log_weights, int64_t n, float *out_probs, float *out_stats,
+                          void *stream) {
+  if (!log_weights || (!out_probs && !out_stats)) return fail(GLB_EINVAL, "null pointer");
+  if (n <= 0) return fail(GLB_EINVAL, "n must be positive");
+  hipLaunchKernelGGL(normalize_weights_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream,
+                     log_weights, n, out_probs, out_stats);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "normalize_weights launch");
+  return GLB_OK;
+}
+
+// ---- host RNG helpers --------------------------------------------------------------------------
+
+void glb_mt19937_seed(glb_mt19937 *st, uint64_t seed) {
+  st->mt[0] = (uint32_t)seed;
+  for (int i = 1; i < 624; ++i)
+    st->mt[i] = 1812433253u * (st->mt[i - 1] ^ (st->mt[i - 1] >> 30)) + (uint32_t)i;
+  st->idx = 624;
+}
+
+static inline void mt_refill(glb_mt19937 *st) {
+  uint32_t *mt = st->mt;
+  int i = 0;
+  for (; i < 624 - 397; ++i) {
+    const uint32_t y = (mt[i] & 0x80000000u) | (mt[i + 1] & 0x7fffffffu);
+    mt[i] = mt[i + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+  }
+  for (; i < 623; ++i) {
+    const uint32_t y = (mt[i] & 0x80000000u) | (mt[i + 1] & 0x7fffffffu);
+    mt[i] = mt[i - 227] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+  }
+  const uint32_t y = (mt[623] & 0x80000000u) | (mt[0] & 0x7fffffffu);
+  mt[623] = mt[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+  st->idx = 0;
+}
+
+static inline uint32_t mt_next(glb_mt19937 *st) {
+  if (st->idx >= 624) mt_refill(st);
+  uint32_t y = st->mt[st->idx++];
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
+}
+
+int glb_mt19937_exponential_f32(glb_mt19937 *st, float *out, int64_t n) {
+  if (!st || !out || n < 0) return fail(GLB_EINVAL, "bad arguments");
+  for (int64_t i = 0; i < n; ++i) {
+    const uint64_t hi = mt_next(st), lo = mt_next(st);
+    const uint64_t r = (hi << 32) | lo;
+    const double u = (double)(r & ((1ull << 53) - 1)) * (1.0 / 9007199254740992.0);
+    out[i] = (float)(-log1p(-u));
+  }
+  return GLB_OK;
+}
+
+void glb_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  glb::philox4x32_10(ctr, key, out);
+}
+
+}  // extern "C"

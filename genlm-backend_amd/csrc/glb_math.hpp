@@ -1,0 +1,127 @@
+// glb_math.hpp — "GLB math": the deterministic arithmetic contract of the hot path.
+//
+// Device restatement of the contract that oracle/glb_oracle.c states for the CPU.  Every floating
+// point step is a single IEEE-754 operation (mul, add, fma, rint, exact power-of-two scaling), the
+// file is compiled with -ffp-contract=off, and all sums are 64-bit integer sums, so results do not
+// depend on how a row is split over lanes, waves, workgroups or GPUs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace glb {
+
+constexpr float kLog2e = __builtin_bit_cast(float, 0x3FB8AA3Bu);  // 1.44269502
+constexpr float kLn2Hi = __builtin_bit_cast(float, 0x3F317200u);  // 0.693145752
+constexpr float kLn2Lo = __builtin_bit_cast(float, 0x35BFBE8Eu);  // 1.42860677e-06
+constexpr int kFixShift = 18;  // S = sum floor(P * 2^32 >> (18 + N - n)), 44 fractional bits
+constexpr int kFixFrac = 44;
+constexpr double kLn2D = 0.693147180559945309417232121458;
+constexpr float kNegInf = -__builtin_huge_valf();
+
+// degree-5 polynomial for e^r on |r| <= ln2/2 (max rel. error 2.6e-7), coefficients times 2^30
+constexpr float kS30 = 1073741824.0f;
+constexpr float kC0 = __builtin_bit_cast(float, 0x3f800000u) * kS30;
+constexpr float kC1 = __builtin_bit_cast(float, 0x3f800000u) * kS30;
+constexpr float kC2 = __builtin_bit_cast(float, 0x3effff2du) * kS30;
+constexpr float kC3 = __builtin_bit_cast(float, 0x3e2aaa6eu) * kS30;
+constexpr float kC4 = __builtin_bit_cast(float, 0x3d2b8604u) * kS30;
+constexpr float kC5 = __builtin_bit_cast(float, 0x3c0905d1u) * kS30;
+
+// e^x = 2^n * P / 2^30 ; returns n (integer valued float) and P (float in [0.70, 1.42] * 2^30)
+__device__ __forceinline__ void exp_parts(float x, float &nf, float &P) {
+  float t = x * kLog2e;
+  nf = __builtin_rintf(t);
+  float r = __builtin_fmaf(nf, -kLn2Hi, x);
+  r = __builtin_fmaf(nf, -kLn2Lo, r);
+  float p = kC5;
+  p = __builtin_fmaf(p, r, kC4);
+  p = __builtin_fmaf(p, r, kC3);
+  p = __builtin_fmaf(p, r, kC2);
+  p = __builtin_fmaf(p, r, kC1);
+  p = __builtin_fmaf(p, r, kC0);
+  P = p;
+}
+
+// fixed-point term of x relative to the row exponent N (N + 18 passed pre-added as Nb).
+// x == -inf contributes 0 (sf = +inf -> s = 63 -> pfix = 0).
+__device__ __forceinline__ uint64_t fix_term_from_parts(float nf, float P, float Nb) {
+  float sf = Nb - nf;
+  uint32_t s = (sf < 63.0f) ? (uint32_t)sf : 63u;
+  uint32_t pfix = (s < 63u) ? (uint32_t)P : 0u;
+  return ((uint64_t)pfix << 32) >> s;
+}
+
+__device__ __forceinline__ uint64_t fix_term(float x, float Nb) {
+  float nf, P;
+  exp_parts(x, nf, P);
+  return fix_term_from_parts(nf, P, Nb);
+}
+
+// ln(S * 2^k) for integer S > 0 (atanh series in double, fixed op order)
+__device__ inline double log_fix(uint64_t S, int32_t k) {
+  double d = __builtin_fma((double)(uint32_t)(S >> 32), 4294967296.0, (double)(uint32_t)S);
+  uint64_t bits = (uint64_t)__double_as_longlong(d);
+  int32_t e = (int32_t)((bits >> 52) & 0x7ff) - 1023;
+  bits = (bits & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
+  double m = __longlong_as_double((long long)bits);
+  if (m > 1.4142135623730951) {
+    m *= 0.5;
+    e += 1;
+  }
+  double z = (m - 1.0) / (m + 1.0);
+  double w = z * z;
+  double p = 1.0 / 21.0;
+  p = __builtin_fma(p, w, 1.0 / 19.0);
+  p = __builtin_fma(p, w, 1.0 / 17.0);
+  p = __builtin_fma(p, w, 1.0 / 15.0);
+  p = __builtin_fma(p, w, 1.0 / 13.0);
+  p = __builtin_fma(p, w, 1.0 / 11.0);
+  p = __builtin_fma(p, w, 1.0 / 9.0);
+  p = __builtin_fma(p, w, 1.0 / 7.0);
+  p = __builtin_fma(p, w, 1.0 / 5.0);
+  p = __builtin_fma(p, w, 1.0 / 3.0);
+  p = __builtin_fma(p, w, 1.0);
+  double lg = (2.0 * z) * p;
+  return __builtin_fma((double)(e + k), kLn2D, lg);
+}
+
+// Philox4x32-10 (Salmon et al., SC'11)
+__host__ __device__ inline void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2],
+                                              uint32_t out[4]) {
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// ---- wave64 helpers --------------------------------------------------------------------------
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int o) {
+  uint32_t lo = __shfl_xor((uint32_t)v, o, 64), hi = __shfl_xor((uint32_t)(v >> 32), o, 64);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int o) {
+  uint32_t lo = __shfl_up((uint32_t)v, o, 64), hi = __shfl_up((uint32_t)(v >> 32), o, 64);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += shfl_xor_u64(v, o);
+  return v;
+}
+
+}  // namespace glb

@@ -1,0 +1,462 @@
+// glb_row_kernel.hpp — the fused particle-step kernel (one workgroup per particle, logits row held
+// in VGPRs, single HBM pass).  gfx950 / wave64 only.
+//
+// Replaces, per particle (reference = genlm/genlm-backend):
+//   cache.py:96      logps  = log_softmax(logits_row)
+//   README.md:84-87  masked = logps + mask; logZ = logsumexp(masked); token = multinomial(exp(masked - logZ))
+//   base.py:136-141  the same draw with logits scaled by 1/temperature
+//
+// Layout: the row is addressed from its 16-byte-aligned-down start (`a` leading pad elements) in
+// 16-byte vectors of EPV elements.  Wave w owns the contiguous vectors [w*64*NVL, (w+1)*64*NVL);
+// its k-th load instruction reads vectors w*64*NVL + k*64 + lane (1 KiB contiguous per
+// wave-instruction).  All NVL loads of a lane are issued before the first use, so a 1024-thread
+// workgroup keeps the whole row (<= 256 KiB) in flight.  An aligned 16-byte vector that overlaps
+// the row by at least one byte lies in the same page as that byte, so loading it never faults;
+// elements outside [0, V) are replaced by -inf after the load.
+//
+// Phases: (1) row max / masked max -> exponents N; (2) fixed-point sums S_all, S_mask (GLB math,
+// glb_math.hpp) and, by mode, the exponential race or the per-tile partial sums for the inverse
+// CDF; (3) one lane turns the sums into lse / logZ in double and the draw is located by
+// wave -> tile -> lane -> element prefix search in vocabulary order.
+#pragma once
+#include "glb_math.hpp"
+
+namespace glb {
+
+enum { kDtF32 = 0, kDtBf16 = 1, kDtF16 = 2 };
+enum { kMaskNone = 0, kMaskBits = 1, kMaskF32 = 2 };
+enum { kModeStats = 0, kModePhilox = 1, kModeNoise = 2 };
+
+struct RowParams {
+  const void *logits;
+  int64_t ld;
+  int32_t V;
+  int32_t use_scale;
+  float scale;
+  int32_t n_particles;
+  const int32_t *row_of;
+  const void *mask;
+  int64_t mask_ld;
+  const int32_t *mask_id;
+  int32_t n_masks;
+  const float *noise;
+  int64_t noise_ld;
+  uint64_t seed, offset;
+  int64_t particle_base;
+  float *out_logZ;
+  float *out_lse;
+  int32_t *out_token;
+  float *out_logprobs;  // stats mode only: [n_particles, out_ld]
+  int64_t out_ld;
+};
+
+template <int DT>
+struct ElemTraits {
+  static constexpr int EPV = DT == kDtF32 ? 4 : 8;
+  static constexpr int ES = DT == kDtF32 ? 4 : 2;
+};
+
+// unpack one 16-byte vector into EPV floats
+template <int DT>
+__device__ __forceinline__ void unpack_vec(const uint4 &r, float *x) {
+  if constexpr (DT == kDtF32) {
+    x[0] = __uint_as_float(r.x);
+    x[1] = __uint_as_float(r.y);
+    x[2] = __uint_as_float(r.z);
+    x[3] = __uint_as_float(r.w);
+  } else if constexpr (DT == kDtBf16) {
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      x[2 * i] = __uint_as_float(w[i] << 16);
+      x[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  } else {
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      x[2 * i] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[i] & 0xffffu));
+      x[2 * i + 1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[i] >> 16));
+    }
+  }
+}
+
+// EPV mask bits for the elements j0 .. j0+EPV-1 of a packed bit row (bits of invalid elements are
+// don't-care: their x is -inf)
+template <int EPV>
+__device__ __forceinline__ uint32_t mask_nibble(const uint32_t *mrow, int32_t n_words, int32_t j0) {
+  const int32_t jb = j0 < 0 ? 0 : j0;
+  const int32_t d = jb - j0;
+  const int32_t wi = jb >> 5;
+  const int32_t w0 = wi < n_words ? wi : n_words - 1;
+  const int32_t w1 = wi + 1 < n_words ? wi + 1 : n_words - 1;
+  const uint64_t w64 = ((uint64_t)mrow[w1] << 32) | mrow[w0];
+  return (uint32_t)((w64 >> (jb & 31)) << d) & ((1u << EPV) - 1u);
+}
+
+template <int DT, int MASK, int MODE, int NVL, int T>
+__global__ __launch_bounds__(T) void row_kernel(const RowParams p) {
+  constexpr int EPV = ElemTraits<DT>::EPV;
+  constexpr int ES = ElemTraits<DT>::ES;
+  constexpr int W = T / 64;
+  constexpr int MBW = (NVL * EPV + 31) / 32;
+
+  __shared__ float s_max[2][W];
+  __shared__ uint64_t s_sum[2][W];
+  __shared__ float s_bestg[W];
+  __shared__ int32_t s_bestj[W];
+  __shared__ float s_lse;
+  // per-(tile, lane) masked partial sums for the inverse-CDF search (philox mode only)
+  __shared__ uint64_t s_asum[MODE == kModePhilox ? NVL * T : 1];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // XCD-aware particle assignment: blocks b, b+8, ... share an XCD (and its L2); give each XCD a
+  // contiguous particle range so particles that share a logits row (dedup fan-out) share an L2.
+  int pidx;
+  {
+    const int n = p.n_particles, b = blockIdx.x;
+    const int q = n >> 3, r = n & 7, xcd = b & 7, i = b >> 3;
+    pidx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+  }
+  const int row = p.row_of ? p.row_of[pidx] : pidx;
+  const int V = p.V;
+  const char *rowp = (const char *)p.logits + (int64_t)row * p.ld * ES;
+  const int a = (int)(((uintptr_t)rowp) & 15) / ES;
+  const char *base = rowp - a * ES;
+  const int nv = (V + a + EPV - 1) / EPV;
+  const int v0 = wave * (64 * NVL) + lane;
+
+  // ---- issue every load of the row ------------------------------------------------------------
+  uint4 raw[NVL];
+#pragma unroll
+  for (int k = 0; k < NVL; ++k) {
+    int v = v0 + k * 64;
+    v = v < nv ? v : nv - 1;
+    raw[k] = *reinterpret_cast<const uint4 *>(base + (int64_t)v * 16);
+  }
+
+  // mask bits of this lane's elements (issued behind the row loads; the table is L2 resident)
+  uint32_t mb[MBW];
+#pragma unroll
+  for (int i = 0; i < MBW; ++i) mb[i] = 0xffffffffu;
+  const float *mrow_f = nullptr;
+  if constexpr (MASK == kMaskBits) {
+    const int mi = p.mask_id ? p.mask_id[pidx] : (p.n_masks == 1 ? 0 : pidx);
+    const uint32_t *mrow = (const uint32_t *)p.mask + (int64_t)mi * p.mask_ld;
+    const int n_words = (V + 31) >> 5;
+#pragma unroll
+    for (int i = 0; i < MBW; ++i) mb[i] = 0;
+#pragma unroll
+    for (int k = 0; k < NVL; ++k) {
+      const int v = v0 + k * 64;
+      const uint32_t nib = mask_nibble<EPV>(mrow, n_words, v * EPV - a);
+      mb[(k * EPV) >> 5] |= nib << ((k * EPV) & 31);
+    }
+  } else if constexpr (MASK == kMaskF32) {
+    const int mi = p.mask_id ? p.mask_id[pidx] : (p.n_masks == 1 ? 0 : pidx);
+    mrow_f = (const float *)p.mask + (int64_t)mi * p.mask_ld;
+  }
+
+  // ---- invalidate out-of-row elements (in the packed registers: -inf bit patterns) ------------------
+#pragma unroll
+  for (int k = 0; k < NVL; ++k) {
+    const int tile_lo = wave * (64 * NVL) + k * 64;
+    if ((tile_lo == 0 && a > 0) || tile_lo + 64 >= nv) {
+      const int j0 = (v0 + k * 64) * EPV - a;
+      uint32_t w[4] = {raw[k].x, raw[k].y, raw[k].z, raw[k].w};
+#pragma unroll
+      for (int c = 0; c < EPV; ++c) {
+        if ((uint32_t)(j0 + c) >= (uint32_t)V) {
+          if constexpr (DT == kDtF32) w[c] = 0xff800000u;
+          else if constexpr (DT == kDtBf16)
+            w[c >> 1] = (c & 1) ? ((w[c >> 1] & 0x0000ffffu) | 0xff800000u)
+                                : ((w[c >> 1] & 0xffff0000u) | 0x0000ff80u);
+          else
+            w[c >> 1] = (c & 1) ? ((w[c >> 1] & 0x0000ffffu) | 0xfc000000u)
+                                : ((w[c >> 1] & 0xffff0000u) | 0x0000fc00u);
+        }
+      }
+      raw[k] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+
+  // ---- phase 1: maxima ------------------------------------------------------------------------
+  float m_all = kNegInf, m_msk = kNegInf;
+#pragma unroll
+  for (int k = 0; k < NVL; ++k) {
+    float xk[EPV];
+    unpack_vec<DT>(raw[k], xk);
+#pragma unroll
+    for (int c = 0; c < EPV; ++c) {
+      const float xv = p.use_scale ? xk[c] * p.scale : xk[c];
+      m_all = fmaxf(m_all, xv);
+      if constexpr (MASK == kMaskBits) {
+        const bool bit = (mb[(k * EPV + c) >> 5] >> ((k * EPV + c) & 31)) & 1u;
+        m_msk = fmaxf(m_msk, bit ? xv : kNegInf);
+      } else if constexpr (MASK == kMaskF32) {
+        int j = (v0 + k * 64) * EPV - a + c;
+        j = j < 0 ? 0 : (j >= V ? V - 1 : j);
+        m_msk = fmaxf(m_msk, xv + mrow_f[j]);
+      }
+    }
+  }
+  m_all = wave_max(m_all);
+  if constexpr (MASK != kMaskNone) m_msk = wave_max(m_msk);
+  if (lane == 0) {
+    s_max[0][wave] = m_all;
+    if constexpr (MASK != kMaskNone) s_max[1][wave] = m_msk;
+  }
+  __syncthreads();
+  m_all = s_max[0][0];
+#pragma unroll
+  for (int w = 1; w < W; ++w) m_all = fmaxf(m_all, s_max[0][w]);
+  if constexpr (MASK != kMaskNone) {
+    m_msk = s_max[1][0];
+#pragma unroll
+    for (int w = 1; w < W; ++w) m_msk = fmaxf(m_msk, s_max[1][w]);
+  } else {
+    m_msk = m_all;
+  }
+  const float N_all = __builtin_rintf(m_all * kLog2e);
+  const float N_msk = __builtin_rintf(m_msk * kLog2e);
+  const float Nb_all = N_all + (float)kFixShift, Nb_msk = N_msk + (float)kFixShift;
+
+  // ---- phase 2: fixed-point sums (+ race / per-tile partial sums) ----------------------------------
+  uint64_t s_all = 0, s_msk = 0;
+  float best_g = -1.0f;
+  int32_t best_j = 0x7fffffff;
+  const float *noise_row = nullptr;
+  if constexpr (MODE == kModeNoise) noise_row = p.noise + (int64_t)pidx * p.noise_ld;
+#pragma unroll
+  for (int k = 0; k < NVL; ++k) {
+    uint64_t ak = 0;
+    float xk[EPV];
+    unpack_vec<DT>(raw[k], xk);
+#pragma unroll
+    for (int c = 0; c < EPV; ++c) {
+      const float xv = p.use_scale ? xk[c] * p.scale : xk[c];
+      float nf, P;
+      exp_parts(xv, nf, P);
+      s_all += fix_term_from_parts(nf, P, Nb_all);
+      uint64_t qm;
+      float nfy = nf, Py = P, yv = xv;
+      if constexpr (MASK == kMaskNone) {
+        qm = 0;  // S_mask == S_all, taken after the loop
+        if constexpr (MODE == kModePhilox) qm = fix_term_from_parts(nf, P, Nb_all);
+      } else if constexpr (MASK == kMaskBits) {
+        const bool bit = (mb[(k * EPV + c) >> 5] >> ((k * EPV + c) & 31)) & 1u;
+        const uint64_t q2 = fix_term_from_parts(nf, P, Nb_msk);
+        qm = bit ? q2 : 0ull;
+        yv = bit ? xv : kNegInf;
+      } else {
+        int j = (v0 + k * 64) * EPV - a + c;
+        j = j < 0 ? 0 : (j >= V ? V - 1 : j);
+        yv = xv + mrow_f[j];
+        exp_parts(yv, nfy, Py);
+        qm = fix_term_from_parts(nfy, Py, Nb_msk);
+      }
+      s_msk += qm;
+      if constexpr (MODE == kModePhilox) ak += qm;
+      if constexpr (MODE == kModeNoise) {
+        const int jr = (v0 + k * 64) * EPV - a + c;
+        const int jc = jr < 0 ? 0 : (jr >= V ? V - 1 : jr);
+        const float E = noise_row[jc];
+        if (yv > kNegInf) {
+          const float df = nfy - N_msk;
+          const float e = (df < -100.0f) ? 0.0f : __builtin_ldexpf(Py, (int)df - 30);
+          const float g = e / E;
+          if (g > best_g) {
+            best_g = g;
+            best_j = jr;
+          }
+        }
+      }
+    }
+    if constexpr (MODE == kModePhilox) s_asum[k * T + tid] = ak;
+  }
+  if constexpr (MASK == kMaskNone) s_msk = s_all;
+
+  s_all = wave_sum_u64(s_all);
+  if constexpr (MASK != kMaskNone) s_msk = wave_sum_u64(s_msk);
+  else s_msk = s_all;
+  if constexpr (MODE == kModeNoise) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float og = __shfl_xor(best_g, o, 64);
+      const int32_t oj = __shfl_xor(best_j, o, 64);
+      if (og > best_g || (og == best_g && oj < best_j)) {
+        best_g = og;
+        best_j = oj;
+      }
+    }
+  }
+  if (lane == 0) {
+    s_sum[0][wave] = s_all;
+    s_sum[1][wave] = s_msk;
+    if constexpr (MODE == kModeNoise) {
+      s_bestg[wave] = best_g;
+      s_bestj[wave] = best_j;
+    }
+  }
+  __syncthreads();
+  uint64_t S_all = 0, S_msk = 0;
+#pragma unroll
+  for (int w = 0; w < W; ++w) {
+    S_all += s_sum[0][w];
+    S_msk += s_sum[1][w];
+  }
+
+  // ---- phase 3: lse / logZ ---------------------------------------------------------------------
+  if (tid == 0) {
+    const double lse_all = S_all ? log_fix(S_all, (int32_t)N_all - kFixFrac) : (double)kNegInf;
+    const double lse_msk = S_msk ? log_fix(S_msk, (int32_t)N_msk - kFixFrac) : (double)kNegInf;
+    if (p.out_lse) p.out_lse[pidx] = (float)lse_all;
+    if (p.out_logZ) p.out_logZ[pidx] = (float)(lse_msk - lse_all);
+    if constexpr (MODE == kModeStats) s_lse = (float)lse_all;
+    if constexpr (MODE == kModeNoise) {
+      if (p.out_token) {
+        float g = s_bestg[0];
+        int32_t j = s_bestj[0];
+#pragma unroll
+        for (int w = 1; w < W; ++w) {
+          const float og = s_bestg[w];
+          const int32_t oj = s_bestj[w];
+          if (og > g || (og == g && oj < j)) {
+            g = og;
+            j = oj;
+          }
+        }
+        p.out_token[pidx] = (S_msk != 0 && g >= 0.0f) ? j : -1;
+      }
+    }
+    if constexpr (MODE == kModePhilox) {
+      if (p.out_token && S_msk == 0) p.out_token[pidx] = -1;
+    }
+  }
+
+  if constexpr (MODE == kModeStats) {
+    if (p.out_logprobs) {
+      __syncthreads();
+      const float lse = s_lse;
+      float *orow = p.out_logprobs + (int64_t)pidx * p.out_ld;
+      const bool vec_ok = ((((uintptr_t)(orow - a)) & 15) == 0);
+#pragma unroll
+      for (int k = 0; k < NVL; ++k) {
+        const int v = v0 + k * 64;
+        const int j0 = v * EPV - a;
+        float xk[EPV];
+        unpack_vec<DT>(raw[k], xk);
+        if (p.use_scale) {
+#pragma unroll
+          for (int c = 0; c < EPV; ++c) xk[c] = xk[c] * p.scale;
+        }
+        if (v < nv) {
+          if (vec_ok && j0 >= 0 && j0 + EPV <= V) {
+#pragma unroll
+            for (int h = 0; h < EPV / 4; ++h) {
+              float4 o;
+              o.x = xk[4 * h + 0] - lse;
+              o.y = xk[4 * h + 1] - lse;
+              o.z = xk[4 * h + 2] - lse;
+              o.w = xk[4 * h + 3] - lse;
+              *reinterpret_cast<float4 *>(orow + j0 + 4 * h) = o;
+            }
+          } else {
+#pragma unroll
+            for (int c = 0; c < EPV; ++c)
+              if ((uint32_t)(j0 + c) < (uint32_t)V) orow[j0 + c] = xk[c] - lse;
+          }
+        }
+      }
+    }
+  }
+
+  // ---- inverse-CDF draw: wave -> tile -> lane -> element, vocabulary order ---------------------------
+  if constexpr (MODE == kModePhilox) {
+    if (p.out_token && S_msk != 0) {
+      const uint64_t gp = (uint64_t)(p.particle_base + pidx);
+      const uint32_t ctr[4] = {(uint32_t)gp, (uint32_t)(gp >> 32), (uint32_t)p.offset,
+                               (uint32_t)(p.offset >> 32)};
+      const uint32_t key[2] = {(uint32_t)p.seed, (uint32_t)(p.seed >> 32)};
+      uint32_t rnd[4];
+      philox4x32_10(ctr, key, rnd);
+      const uint64_t R = ((uint64_t)rnd[1] << 32) | rnd[0];
+      uint64_t Tw = __umul64hi(R, S_msk);  // uniform integer in [0, S_msk)
+      int wsel = W - 1;
+      {
+        uint64_t run = 0;
+        bool found = false;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+          const uint64_t cw = s_sum[1][w];
+          if (!found && Tw < run + cw) {
+            found = true;
+            wsel = w;
+            Tw -= run;
+          }
+          run += cw;
+        }
+      }
+      if (wave == wsel) {
+        uint64_t run = 0, asel = 0, Trem = 0;
+        int ksel = 0;
+        bool found = false;
+        for (int k = 0; k < NVL; ++k) {
+          const uint64_t ak = s_asum[k * T + tid];
+          const uint64_t ck = wave_sum_u64(ak);
+          if (!found && Tw < run + ck) {
+            found = true;
+            ksel = k;
+            asel = ak;
+            Trem = Tw - run;
+          }
+          run += ck;
+        }
+        uint64_t incl = asel;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint64_t t = shfl_up_u64(incl, o);
+          if (lane >= o) incl += t;
+        }
+        const unsigned long long ball = __ballot(incl > Trem);
+        const int lsel = __ffsll((long long)ball) - 1;
+        if (lane == lsel) {
+          uint64_t Tl = Trem - (incl - asel);
+          const int v = v0 + ksel * 64;  // < nv because its tile sum is non-zero
+          const uint4 rr = *reinterpret_cast<const uint4 *>(base + (int64_t)v * 16);
+          float xs[EPV];
+          unpack_vec<DT>(rr, xs);
+          const int j0 = v * EPV - a;
+          uint32_t nib = (1u << EPV) - 1u;
+          if constexpr (MASK == kMaskBits) {
+            const int mi = p.mask_id ? p.mask_id[pidx] : (p.n_masks == 1 ? 0 : pidx);
+            nib = mask_nibble<EPV>((const uint32_t *)p.mask + (int64_t)mi * p.mask_ld,
+                                   (V + 31) >> 5, j0);
+          }
+          int32_t tok = -1;
+#pragma unroll
+          for (int c = 0; c < EPV; ++c) {
+            float xv = xs[c];
+            if (p.use_scale) xv = xv * p.scale;
+            const int j = j0 + c;
+            bool ok = (uint32_t)j < (uint32_t)V;
+            if constexpr (MASK == kMaskBits) ok = ok && ((nib >> c) & 1u);
+            if constexpr (MASK == kMaskF32) {
+              const int jc = j < 0 ? 0 : (j >= V ? V - 1 : j);
+              xv = xv + mrow_f[jc];
+            }
+            const uint64_t q = ok ? fix_term(xv, Nb_msk) : 0ull;
+            if (tok < 0) {
+              if (Tl < q) tok = j;
+              else Tl -= q;
+            }
+          }
+          p.out_token[pidx] = tok;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace glb

@@ -1,0 +1,203 @@
+"""Tensor-level front-end of the HIP library: torch tensors in, torch tensors out, raw pointers and
+the current HIP stream across the C ABI (include/glb.h).  PyTorch only provides device memory and
+streams here.  Nothing in this module computes on the CPU; constructing `HipEngine` without a GPU
+raises.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (F32, BF16, F16, MASK_NONE, MASK_BITS, MASK_F32, RNG_NONE, RNG_PHILOX, RNG_NOISE,
+                   StepArgs, MT19937, check)
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class HostRng:
+    """torch-CPU-compatible MT19937 stream for GLB_RNG_NOISE (parity mode).
+
+    `exponential(n)` returns the float32 values `torch.empty(n).exponential_(1, generator=g)` yields
+    for a generator seeded with `seed` (README.md:87 / base.py:125-141 draw through it)."""
+
+    def __init__(self, seed):
+        self._lib = _lib.load()
+        self.state = MT19937()
+        self._lib.glb_mt19937_seed(C.byref(self.state), C.c_uint64(seed))
+
+    def exponential(self, n, out=None):
+        if out is None:
+            out = torch.empty(n, dtype=torch.float32, pin_memory=torch.cuda.is_available())
+        assert out.dtype == torch.float32 and out.is_contiguous() and out.device.type == "cpu"
+        check(self._lib.glb_mt19937_exponential_f32(C.byref(self.state), _ptr(out), n))
+        return out
+
+
+class HipEngine:
+    """All device work of the hot path for one GPU."""
+
+    def __init__(self, device=None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available() or self.lib.glb_device_count() <= 0:
+            raise RuntimeError(
+                "HipEngine needs a HIP device (MI355X / gfx950); none is visible and there is no CPU fallback"
+            )
+        self.device = torch.device(device if device is not None else "cuda:0")
+        if self.device.type != "cuda":
+            raise RuntimeError(f"HipEngine device must be a HIP device, got {self.device}")
+        self._ws = None
+
+    # ------------------------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _i32(self, n):
+        return torch.empty(n, dtype=torch.int32, device=self.device)
+
+    def _f32(self, n):
+        return torch.empty(n, dtype=torch.float32, device=self.device)
+
+    def _check_dev(self, *ts):
+        for t in ts:
+            if t is not None and (t.device != self.device or not t.is_contiguous()):
+                if t.device != self.device:
+                    raise ValueError(f"tensor on {t.device}, engine on {self.device}")
+                raise ValueError("tensor must be contiguous")
+
+    # ------------------------------------------------------------------------------------------
+    def step(self, logits, vocab=None, row_of=None, mask_kind=MASK_NONE, mask=None, mask_id=None,
+             rng_mode=RNG_NONE, noise=None, seed=0, offset=0, particle_base=0, logit_scale=1.0,
+             want_lse=True, variant=0, out=None):
+        """Fused particle step (glb_logprob_mask_sample).  Returns (logZ, lse, token) device tensors.
+
+        logits: [n_rows, ld] (last dim contiguous; rows may be strided), vocab <= ld.
+        """
+        if logits.dim() != 2 or logits.stride(1) != 1:
+            raise ValueError("logits must be 2-D with unit inner stride")
+        if logits.dtype not in _DT:
+            raise TypeError(f"unsupported logits dtype {logits.dtype}")
+        n_rows, width = logits.shape
+        ld = logits.stride(0) if n_rows > 1 else max(width, logits.stride(0))
+        V = width if vocab is None else vocab
+        n = n_rows if row_of is None else row_of.numel()
+        self._check_dev(row_of, mask, mask_id, noise)
+        if out is None:
+            logZ, lse, tok = self._f32(n), (self._f32(n) if want_lse else None), None
+            if rng_mode != RNG_NONE:
+                tok = self._i32(n)
+        else:
+            logZ, lse, tok = out
+        a = StepArgs()
+        a.struct_size = C.sizeof(StepArgs)
+        a.logits = logits.data_ptr()
+        a.dtype = _DT[logits.dtype]
+        a.n_rows, a.vocab, a.ld = n_rows, V, ld
+        a.logit_scale = logit_scale
+        a.n_particles = n
+        a.row_of = None if row_of is None else row_of.data_ptr()
+        a.mask_kind = mask_kind
+        if mask_kind != MASK_NONE:
+            if mask.dim() != 2 or mask.stride(1) != 1:
+                raise ValueError("mask must be 2-D")
+            want = torch.float32 if mask_kind == MASK_F32 else torch.int32
+            if mask.dtype != want:
+                raise TypeError(f"mask dtype {mask.dtype}, expected {want}")
+            a.mask = mask.data_ptr()
+            a.mask_ld = mask.stride(0) if mask.shape[0] > 1 else mask.shape[1]
+            a.n_masks = mask.shape[0]
+            a.mask_id = None if mask_id is None else mask_id.data_ptr()
+        a.rng_mode = rng_mode
+        if rng_mode == RNG_NOISE:
+            if noise.dim() != 2 or noise.dtype != torch.float32:
+                raise ValueError("noise must be float32 [n_particles, >=vocab]")
+            a.noise = noise.data_ptr()
+            a.noise_ld = noise.stride(0) if noise.shape[0] > 1 else noise.shape[1]
+        a.seed, a.offset, a.particle_base = seed, offset, particle_base
+        a.out_logZ = None if logZ is None else logZ.data_ptr()
+        a.out_lse = None if lse is None else lse.data_ptr()
+        a.out_token = None if tok is None else tok.data_ptr()
+        a.variant = variant
+        check(self.lib.glb_logprob_mask_sample(C.byref(a), self._stream()))
+        return logZ, lse, tok
+
+    def log_softmax_rows(self, logits, vocab=None, logit_scale=1.0, out=None, want_lse=False):
+        """out[r] = logits[r] - logsumexp(logits[r]) (glb_log_softmax_rows); float32 result."""
+        if logits.dim() != 2 or logits.stride(1) != 1:
+            raise ValueError("logits must be 2-D with unit inner stride")
+        n_rows, width = logits.shape
+        V = width if vocab is None else vocab
+        ld = logits.stride(0) if n_rows > 1 else max(width, logits.stride(0))
+        if out is None:
+            out = torch.empty((n_rows, V), dtype=torch.float32, device=self.device)
+        lse = self._f32(n_rows) if want_lse else None
+        out_ld = out.stride(0) if n_rows > 1 else max(V, out.stride(0))
+        check(self.lib.glb_log_softmax_rows(_ptr(logits), _DT[logits.dtype], n_rows, V, ld,
+                                            logit_scale, _ptr(out), out_ld, _ptr(lse), self._stream()))
+        return (out, lse) if want_lse else out
+
+    def mask_to_bits(self, mask):
+        """{0,-inf} float log-masks [K, V] -> packed int32 bit rows [K, ceil(V/32)] + non-binary flag."""
+        if mask.dim() == 1:
+            mask = mask[None]
+        mask = mask.to(self.device, torch.float32).contiguous()
+        K, V = mask.shape
+        W = (V + 31) // 32
+        bits = torch.empty((K, W), dtype=torch.int32, device=self.device)
+        flag = self._i32(1)
+        check(self.lib.glb_mask_f32_to_bits(_ptr(mask), K, V, V, _ptr(bits), W, _ptr(flag), self._stream()))
+        return bits, flag
+
+    # ------------------------------------------------------------------------------------------
+    def group_contexts(self, tokens, offsets):
+        """Exact dedup, first-appearance order.  Returns (group_of[n], rep[n], n_groups[1]) on device."""
+        n = offsets.numel() - 1
+        self._check_dev(tokens, offsets)
+        need = self.lib.glb_group_contexts_workspace(n)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(max(need, 1 << 16), dtype=torch.uint8, device=self.device)
+        group_of, rep, ng = self._i32(n), self._i32(n), self._i32(1)
+        check(self.lib.glb_group_contexts(_ptr(tokens), _ptr(offsets), n, _ptr(group_of), _ptr(rep),
+                                          _ptr(ng), _ptr(self._ws), self._ws.numel(), self._stream()))
+        return group_of, rep, ng
+
+    def match_prefixes(self, tokens, offsets, prefix_tokens, prefix_offsets):
+        n = offsets.numel() - 1
+        npre = 0 if prefix_offsets is None else prefix_offsets.numel() - 1
+        pref, base = self._i32(n), self._i32(n)
+        check(self.lib.glb_match_prefixes(_ptr(tokens), _ptr(offsets), n, _ptr(prefix_tokens),
+                                          _ptr(prefix_offsets), npre, _ptr(pref), _ptr(base), self._stream()))
+        return pref, base
+
+    def gather_padded(self, tokens, offsets, sel, n_sel, base, pad_id, p_max, l_max):
+        dev = self.device
+        ids = torch.empty((n_sel, l_max), dtype=torch.int64, device=dev)
+        am = torch.empty((n_sel, p_max + l_max), dtype=torch.int64, device=dev)
+        pos = torch.empty((n_sel, l_max), dtype=torch.int64, device=dev)
+        last = self._i32(n_sel)
+        check(self.lib.glb_gather_padded(_ptr(tokens), _ptr(offsets), _ptr(sel), n_sel, _ptr(base), pad_id,
+                                         p_max, l_max, _ptr(ids), _ptr(am), _ptr(pos), _ptr(last), self._stream()))
+        return ids, am, pos, last
+
+    def gather_kv_padded(self, slab_ptrs, slab_len, prefix_of, heads, head_dim, p_max, dtype):
+        """slab_ptrs: int64 device tensor of raw pointers to [heads, len_k, head_dim] slabs."""
+        n_rows = prefix_of.numel()
+        out = torch.empty((n_rows, heads, p_max, head_dim), dtype=dtype, device=self.device)
+        check(self.lib.glb_gather_kv_padded(_ptr(slab_ptrs), _ptr(slab_len), slab_len.numel(), _ptr(prefix_of),
+                                            n_rows, heads, head_dim, p_max, out.element_size(), _ptr(out),
+                                            self._stream()))
+        return out
+
+    def particles_advance(self, contexts, lengths, active, log_weights, logZ, token, eos_id, max_len):
+        n, ld = contexts.shape
+        check(self.lib.glb_particles_advance(_ptr(contexts), ld, _ptr(lengths), _ptr(active), _ptr(log_weights),
+                                             _ptr(logZ), _ptr(token), n, eos_id, max_len, self._stream()))
+
+    def normalize_weights(self, log_weights):
+        n = log_weights.numel()
+        probs, stats = self._f32(n), self._f32(2)
+        check(self.lib.glb_normalize_weights(_ptr(log_weights), n, _ptr(probs), _ptr(stats), self._stream()))
+        return probs, stats

@@ -1,0 +1,224 @@
+/*
+ * glb.h — C ABI of libglb_hip.so, the MI355X (gfx950) implementation of genlm-backend's
+ * autobatched next_token_logprobs hot path.
+ *
+ * Every entry point is `extern "C"`, takes plain device/host pointers and sizes, returns an
+ * int status (GLB_OK == 0) and never throws.  On failure a thread-local message is available
+ * through glb_last_error().  The library never allocates or frees caller memory: all buffers,
+ * including scratch, are caller-owned (torch-allocated in the Python host) and must stay valid
+ * until the passed HIP stream has reached the end of the call.  Kernels are enqueued on the
+ * caller's stream; no entry point synchronises the device unless its comment says so.
+ *
+ * Each entry point cites the reference (genlm/genlm-backend) code it replaces; paths are
+ * relative to the reference checkout.
+ *
+ * Arithmetic contract ("GLB math"): sums of exponentials are accumulated in
+ * 64-bit fixed point from a correctly-rounded-FMA polynomial exp, so logZ / lse / sampled token
+ * are bit-identical for any launch geometry, GPU count or row split, and are restated
+ * bit-for-bit by oracle/glb_oracle.c.
+ */
+#ifndef GLB_H
+#define GLB_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GLB_ABI_VERSION 1
+
+/* status codes */
+enum {
+  GLB_OK = 0,
+  GLB_EINVAL = 1,      /* bad argument (null pointer, zero size, bad enum, misaligned ld) */
+  GLB_EUNSUPPORTED = 2,/* valid request the build cannot serve (e.g. vocab too large for scratch) */
+  GLB_EHIP = 3,        /* HIP runtime error (message carries hipGetErrorString) */
+  GLB_ENOSPC = 4       /* caller-provided workspace too small */
+};
+
+/* element types of a logits matrix */
+enum { GLB_F32 = 0, GLB_BF16 = 1, GLB_F16 = 2 };
+
+/* mask kinds (README.md:57-70 builds two shared {0,-inf} masks; real grammars give per-row masks) */
+enum {
+  GLB_MASK_NONE = 0, /* no mask: logZ == 0 up to rounding, sample from the full distribution      */
+  GLB_MASK_BITS = 1, /* table [n_masks, mask_ld] of uint32 words, bit j%32 of word j/32 == 1 ⇔
+                        token j allowed (log-mask 0), 0 ⇔ forbidden (log-mask -inf)                */
+  GLB_MASK_F32 = 2   /* table [n_masks, mask_ld] of float additive log-masks (any value, -inf ok) */
+};
+
+/* RNG modes of the categorical draw */
+enum {
+  GLB_RNG_NONE = 0,   /* no draw (out_token untouched)                                            */
+  GLB_RNG_PHILOX = 1, /* in-kernel Philox4x32-10, one 64-bit uniform per particle, exact integer
+                         inverse-CDF in vocabulary order                                          */
+  GLB_RNG_NOISE = 2   /* parity mode: caller supplies Exp(1) noise E[n_particles, noise_ld] drawn
+                         the way torch.multinomial draws it on CPU; token = first argmax p_j/E_j
+                         (README.md:87, base.py:137-141)                                          */
+};
+
+const char *glb_version(void);
+int glb_abi_version(void);
+/* copies the calling thread's last error message (NUL-terminated, truncated to n) */
+int glb_last_error(char *buf, size_t n);
+/* number of visible HIP devices, or -1 when the runtime cannot initialise (no GPU) */
+int glb_device_count(void);
+
+/*
+ * Fused particle step.  Replaces, per particle,
+ *     logps  = log_softmax(logits_row)                      cache.py:96
+ *     masked = logps + mask                                 README.md:84
+ *     logZ   = masked.logsumexp(-1)                         README.md:85
+ *     token  = multinomial((masked - logZ).exp(), 1)        README.md:87   (base.py:136-141 with
+ *                                                           logit_scale = 1/temperature)
+ * in one pass over the logits row.  Particle i reads row row_of[i] (dedup fan-out of
+ * hf.py:214-220,285-288) and mask row mask_id[i].
+ */
+typedef struct glb_step_args {
+  uint32_t struct_size; /* sizeof(glb_step_args) — ABI guard */
+  /* logits of the unique contexts */
+  const void *logits; /* [n_rows, ld] device */
+  int32_t dtype;      /* GLB_F32 / GLB_BF16 / GLB_F16 */
+  int64_t n_rows;
+  int64_t vocab; /* V */
+  int64_t ld;    /* row pitch in elements, >= vocab */
+  float logit_scale; /* x' = fl(x * logit_scale) when != 1 (1/temperature of base.py:136) */
+  /* particles */
+  int64_t n_particles;
+  const int32_t *row_of; /* [n_particles] device, nullable ⇒ identity (needs n_particles == n_rows) */
+  /* mask */
+  int32_t mask_kind;
+  const void *mask;  /* [n_masks, mask_ld] device (uint32 words or float) */
+  int64_t mask_ld;   /* pitch in words (BITS, >= ceil(V/32)) or floats (F32, >= V) */
+  int64_t n_masks;
+  const int32_t *mask_id; /* [n_particles] device, nullable ⇒ identity (needs n_masks == n_particles)
+                             or, when n_masks == 1, everybody uses mask 0 */
+  /* rng */
+  int32_t rng_mode;
+  const float *noise; /* GLB_RNG_NOISE: [n_particles, noise_ld] device */
+  int64_t noise_ld;
+  uint64_t seed;          /* GLB_RNG_PHILOX key */
+  uint64_t offset;        /* GLB_RNG_PHILOX counter word (e.g. SIS step number) */
+  int64_t particle_base;  /* global index of particle 0 of this call (multi-GPU shards) */
+  /* outputs, each nullable */
+  float *out_logZ;   /* [n_particles] logsumexp(log_softmax(x)+mask) */
+  float *out_lse;    /* [n_particles] logsumexp(x) of the particle's row */
+  int32_t *out_token;/* [n_particles] sampled id, -1 when every token is masked out */
+  int32_t variant;   /* 0 = auto; otherwise forces a launch geometry (tuning / tests) */
+} glb_step_args;
+
+int glb_logprob_mask_sample(const glb_step_args *args, void *hip_stream);
+
+/*
+ * Materialise log-probabilities: out[r, j] = x[r, j] - logsumexp(x[r, :]).  Replaces the
+ * per-position torch.log_softmax of TokenTrie.extend_cache (cache.py:93-98) and
+ * next_token_logprobs_uncached (hf.py:422).  out_lse is optional.
+ */
+int glb_log_softmax_rows(const void *logits, int32_t dtype, int64_t n_rows, int64_t vocab,
+                         int64_t ld, float logit_scale, float *out_logprobs, int64_t out_ld,
+                         float *out_lse, void *hip_stream);
+
+/*
+ * Convert {0,-inf}-style float log-masks (README.md:60-66, `.log()` of a 0/1 tensor) to the
+ * packed GLB_MASK_BITS form: bit = (mask[j] == 0).  Values other than 0 / -inf set *out_nonbinary
+ * (device int32, optional) to 1 so the caller can fall back to GLB_MASK_F32.
+ */
+int glb_mask_f32_to_bits(const float *mask, int64_t n_masks, int64_t vocab, int64_t mask_ld,
+                         uint32_t *out_bits, int64_t bits_ld, int32_t *out_nonbinary,
+                         void *hip_stream);
+
+/*
+ * Context grouping: exact dedup of ragged token contexts, first-appearance order.  Replaces the
+ * dict keyed by tuple(prompt) of batch_evaluate_queries (hf.py:214-220).
+ *   tokens  [offsets[n]] int32 device, offsets [n+1] int64 device
+ *   out_group_of [n]   group id of every context (ids numbered by first appearance)
+ *   out_rep      [n]   out_rep[g] = smallest context index in group g (only [0, n_groups) valid)
+ *   out_n_groups [1]   device int32
+ * workspace: device scratch of at least glb_group_contexts_workspace(n) bytes.
+ */
+size_t glb_group_contexts_workspace(int64_t n);
+int glb_group_contexts(const int32_t *tokens, const int64_t *offsets, int64_t n,
+                       int32_t *out_group_of, int32_t *out_rep, int32_t *out_n_groups,
+                       void *workspace, size_t workspace_bytes, void *hip_stream);
+
+/*
+ * Cached-prefix match ("trie grouping"): for every context pick the longest cached prefix that
+ * is a proper prefix of it — the deepest KV-bearing trie node walk_cache returns (hf.py:314-344).
+ *   prefix_tokens [prefix_offsets[n_prefixes]] int32, prefix_offsets [n_prefixes+1] int64
+ *   out_prefix [n] int32 index of the chosen cached prefix or -1; out_base [n] int32 its length
+ *   (0 when none).  Ties on length resolve to the lowest prefix index.
+ */
+int glb_match_prefixes(const int32_t *tokens, const int64_t *offsets, int64_t n,
+                       const int32_t *prefix_tokens, const int64_t *prefix_offsets,
+                       int64_t n_prefixes, int32_t *out_prefix, int32_t *out_base,
+                       void *hip_stream);
+
+/*
+ * Ragged -> padded gather for the batched prefill.  Replaces Query.prompt_padded /
+ * attention_mask / position_ids and the three torch.tensor(...) builds of hf.py:55-70,232-246.
+ * For each selected context s = sel[u] (u < n_sel; sel nullable ⇒ identity) with cached-prefix
+ * length base[s] (nullable ⇒ 0):
+ *   input_ids[u, t]      = tokens[offsets[s] + base + t]        t <  len          else pad_id
+ *   position_ids[u, t]   = base + t                             t <  len          else 0
+ *   attention_mask[u, p] = 1 for p < base; 0 for base <= p < p_max;
+ *                          1 for p_max <= p < p_max + len; 0 afterwards           (hf.py:58-64)
+ *   last_index[u]        = len - 1        (row of the next-token logits, optional output)
+ * with len = offsets[s+1] - offsets[s] - base.  Outputs are int64 [n_sel, l_max] /
+ * [n_sel, p_max + l_max], matching what transformers expects.
+ */
+int glb_gather_padded(const int32_t *tokens, const int64_t *offsets, const int32_t *sel,
+                      int64_t n_sel, const int32_t *base, int64_t pad_id, int64_t p_max,
+                      int64_t l_max, int64_t *out_input_ids, int64_t *out_attention_mask,
+                      int64_t *out_position_ids, int32_t *out_last_index, void *hip_stream);
+
+/*
+ * Batched prefix-KV assembly.  Replaces Query.past_padded + the per-layer torch.cat of
+ * hf.py:33-53,247-271: out[u, h, p, :] = slab_k[h, p, :] for p < plen_k, zero up to p_max,
+ * where k = prefix_of[u] (k < 0 ⇒ all zeros).  `slabs` is a device array of n_prefixes device
+ * pointers to [heads, plen_k, head_dim] tensors of elem_bytes-wide elements (contiguous).
+ */
+int glb_gather_kv_padded(const void *const *slabs, const int32_t *slab_len, int64_t n_prefixes,
+                         const int32_t *prefix_of, int64_t n_rows, int64_t heads,
+                         int64_t head_dim, int64_t p_max, int32_t elem_bytes, void *out,
+                         void *hip_stream);
+
+/*
+ * Particle bookkeeping of the SIS loop (README.md:82-91): for every particle that is active,
+ *   log_weight += logZ; if token == eos_id (or token < 0) active = 0
+ *   else tokens[i, length[i]++] = token; and a context that reaches max_len is deactivated.
+ * `contexts` is the padded [n, ctx_ld] int32 matrix the ragged views are cut from.
+ */
+int glb_particles_advance(int32_t *contexts, int64_t ctx_ld, int32_t *lengths, int32_t *active,
+                          float *log_weights, const float *logZ, const int32_t *token, int64_t n,
+                          int32_t eos_id, int32_t max_len, void *hip_stream);
+
+/*
+ * Weight normalisation over the full particle population (README.md:108-110) on the all-gathered
+ * log-weight vector: out_probs = exp(lw - logsumexp(lw)); out_stats = {logsumexp(lw), ESS}.
+ * Deterministic (fixed-point sums), so every rank of a sharded run computes identical values.
+ */
+int glb_normalize_weights(const float *log_weights, int64_t n, float *out_probs, float *out_stats,
+                          void *hip_stream);
+
+/*
+ * Host helper for GLB_RNG_NOISE: fills out[0..n) with the float32 Exp(1) variates
+ * torch.empty(n).exponential_(1, generator) produces on CPU for a generator whose MT19937 state is
+ * `state` (seeded with glb_mt19937_seed).  Serial by construction (one 64-bit draw = two MT words per
+ * variate).  Host pointers only.
+ */
+typedef struct glb_mt19937 {
+  uint32_t mt[624];
+  int32_t idx;
+} glb_mt19937;
+void glb_mt19937_seed(glb_mt19937 *st, uint64_t seed);
+int glb_mt19937_exponential_f32(glb_mt19937 *st, float *out, int64_t n);
+
+/* Philox4x32-10 block function, exposed so hosts can reproduce the device draws. */
+void glb_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLB_H */

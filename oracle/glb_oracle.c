@@ -1,0 +1,545 @@
+/*
+ * glb_oracle.c — CPU ORACLE.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C restatement of the genlm-backend hot path (reference = genlm/genlm-backend) used as
+ * the checker for the HIP library.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this file's shared object; nothing under genlm-backend_amd/ does.
+ *
+ * Two layers live here:
+ *   (A) reference semantics in the reference's own arithmetic (float32 torch-CPU style), each
+ *       function citing the reference file:line it follows.  Pinned by the npz files under tests/golden,
+ *       which were produced by the reference itself / torch-CPU (oracle/make_goldens.py).
+ *   (B) the "GLB math" contract the HIP kernels implement: the same quantities
+ *       computed with a fixed polynomial exp + 64-bit fixed-point sums so that results are
+ *       bit-identical on any hardware.  Layer B is checked against layer A within 1e-4
+ *       (tests/test_oracle.py) and the HIP path is checked against layer B bit-for-bit.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -mfma).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_F32 0
+#define ORC_BF16 1
+#define ORC_F16 2
+#define ORC_MASK_NONE 0
+#define ORC_MASK_BITS 1
+#define ORC_MASK_F32 2
+#define ORC_RNG_NONE 0
+#define ORC_RNG_PHILOX 1
+#define ORC_RNG_NOISE 2
+
+/* ---------------------------------------------------------------- element loads */
+
+static float bf16_to_f32(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+static float f16_to_f32(uint16_t h) {
+  uint32_t sign = (uint32_t)(h >> 15) << 31;
+  uint32_t e = (h >> 10) & 0x1f, m = h & 0x3ff, u;
+  if (e == 0) {
+    if (m == 0) {
+      u = sign;
+    } else { /* subnormal half: value = m * 2^-24, exact in float */
+      float f = (float)m * 5.9604644775390625e-08f;
+      memcpy(&u, &f, 4);
+      u |= sign;
+    }
+  } else if (e == 31) {
+    u = sign | 0x7f800000u | (m << 13);
+  } else {
+    u = sign | ((e + 112) << 23) | (m << 13);
+  }
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+static float load_elem(const void *base, int dtype, int64_t idx) {
+  if (dtype == ORC_F32) return ((const float *)base)[idx];
+  if (dtype == ORC_BF16) return bf16_to_f32(((const uint16_t *)base)[idx]);
+  return f16_to_f32(((const uint16_t *)base)[idx]);
+}
+
+/* ---------------------------------------------------------------- GLB math (layer B) */
+
+/* exp split: e^x = 2^n * P(r),  n = rint(x*log2e),  r = x - n*ln2 (two-constant Cody-Waite),
+ * P = degree-5 polynomial evaluated by Horner with correctly rounded FMAs, pre-scaled by 2^30.
+ * Returns n (as float, integer valued) and Pfix = (uint32)P in [0.70*2^30, 1.42*2^30]. */
+#define GLB_LOG2E 1.44269502162933349609375f     /* 0x3FB8AA3B */
+#define GLB_LN2_HI 0.693145751953125f            /* 0x3F317200 */
+#define GLB_LN2_LO 1.42860676533018704503775e-06f /* 0x35BFBE8E */
+static const uint32_t GLB_EXP_C[6] = {0x3f800000u, 0x3f800000u, 0x3effff2du,
+                                      0x3e2aaa6eu, 0x3d2b8604u, 0x3c0905d1u};
+#define GLB_FIX_SHIFT 18 /* S has 44 fractional bits: 2^30 (Pfix) * 2^32 >> 18 */
+#define GLB_FIX_FRAC 44
+
+static float u2f(uint32_t u) {
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+static void glb_exp_parts(float x, float *nf_out, float *P_out) {
+  const float S30 = 1073741824.0f; /* 2^30, exact scaling of the coefficients */
+  float t = x * GLB_LOG2E;
+  float nf = rintf(t);
+  float r = fmaf(nf, -GLB_LN2_HI, x);
+  r = fmaf(nf, -GLB_LN2_LO, r);
+  float p = u2f(GLB_EXP_C[5]) * S30;
+  p = fmaf(p, r, u2f(GLB_EXP_C[4]) * S30);
+  p = fmaf(p, r, u2f(GLB_EXP_C[3]) * S30);
+  p = fmaf(p, r, u2f(GLB_EXP_C[2]) * S30);
+  p = fmaf(p, r, u2f(GLB_EXP_C[1]) * S30);
+  p = fmaf(p, r, u2f(GLB_EXP_C[0]) * S30);
+  *nf_out = nf;
+  *P_out = p;
+}
+
+/* fixed-point term of element x relative to row exponent Nf: floor(P*2^32 / 2^(18 + N - n)) */
+static uint64_t glb_fix_term(float x, float Nf) {
+  float nf, P;
+  if (!(x > -INFINITY)) return 0; /* -inf (and NaN) contribute nothing */
+  glb_exp_parts(x, &nf, &P);
+  float sf = (Nf + (float)GLB_FIX_SHIFT) - nf;
+  uint32_t s = (sf < 63.0f) ? (uint32_t)sf : 63u;
+  uint32_t pfix = (s < 63u) ? (uint32_t)P : 0u;
+  return ((uint64_t)pfix << 32) >> s;
+}
+
+/* natural log of S * 2^k for integer S > 0, in double, fixed op order (atanh series) */
+#define GLB_LN2_D 0.693147180559945309417232121458
+static double glb_log_fix(uint64_t S, int32_t k) {
+  double d = fma((double)(uint32_t)(S >> 32), 4294967296.0, (double)(uint32_t)S);
+  uint64_t bits;
+  memcpy(&bits, &d, 8);
+  int32_t e = (int32_t)((bits >> 52) & 0x7ff) - 1023;
+  bits = (bits & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
+  double m;
+  memcpy(&m, &bits, 8);
+  if (m > 1.4142135623730951) {
+    m *= 0.5;
+    e += 1;
+  }
+  double z = (m - 1.0) / (m + 1.0);
+  double w = z * z;
+  double p = 1.0 / 21.0;
+  p = fma(p, w, 1.0 / 19.0);
+  p = fma(p, w, 1.0 / 17.0);
+  p = fma(p, w, 1.0 / 15.0);
+  p = fma(p, w, 1.0 / 13.0);
+  p = fma(p, w, 1.0 / 11.0);
+  p = fma(p, w, 1.0 / 9.0);
+  p = fma(p, w, 1.0 / 7.0);
+  p = fma(p, w, 1.0 / 5.0);
+  p = fma(p, w, 1.0 / 3.0);
+  p = fma(p, w, 1.0);
+  double lg = (2.0 * z) * p;
+  return fma((double)(e + k), GLB_LN2_D, lg);
+}
+
+/* Philox4x32-10 (Salmon et al. 2011), the counter-based generator of GLB_RNG_PHILOX */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+static uint64_t mulhi64(uint64_t a, uint64_t b) {
+  return (uint64_t)(((unsigned __int128)a * b) >> 64);
+}
+
+/* per-row scratch of layer B */
+typedef struct {
+  float m_all, m_mask;     /* maxima (order independent) */
+  float N_all, N_mask;     /* rint(m*log2e) */
+  uint64_t S_all, S_mask;  /* fixed-point sums */
+} row_stats;
+
+static int mask_allows(const uint32_t *bits, int64_t j) {
+  return (int)((bits[j >> 5] >> (j & 31)) & 1u);
+}
+
+/*
+ * Layer B particle step (contract of glb_logprob_mask_sample, include/glb.h).
+ * Mirrors README.md:82-91 / cache.py:96 / base.py:136-141 semantics.
+ */
+int orc_step(const void *logits, int dtype, int64_t n_rows, int64_t V, int64_t ld,
+             float logit_scale, int64_t n_particles, const int32_t *row_of, int mask_kind,
+             const void *mask, int64_t mask_ld, int64_t n_masks, const int32_t *mask_id,
+             int rng_mode, const float *noise, int64_t noise_ld, uint64_t seed, uint64_t offset,
+             int64_t particle_base, float *out_logZ, float *out_lse, int32_t *out_token) {
+  float *x = (float *)malloc(sizeof(float) * (size_t)V);
+  float *y = (float *)malloc(sizeof(float) * (size_t)V);
+  if (!x || !y) return 4;
+  for (int64_t i = 0; i < n_particles; ++i) {
+    int64_t r = row_of ? row_of[i] : i;
+    if (r < 0 || r >= n_rows) { free(x); free(y); return 1; }
+    int64_t mi = 0;
+    if (mask_kind != ORC_MASK_NONE) mi = mask_id ? mask_id[i] : (n_masks == 1 ? 0 : i);
+    const uint32_t *mb = mask_kind == ORC_MASK_BITS ? (const uint32_t *)mask + mi * mask_ld : NULL;
+    const float *mf = mask_kind == ORC_MASK_F32 ? (const float *)mask + mi * mask_ld : NULL;
+    row_stats st;
+    st.m_all = -INFINITY;
+    st.m_mask = -INFINITY;
+    for (int64_t j = 0; j < V; ++j) {
+      float v = load_elem(logits, dtype, r * ld + j);
+      if (logit_scale != 1.0f) v = v * logit_scale;
+      x[j] = v;
+      float vm = v;
+      if (mb) vm = mask_allows(mb, j) ? v : -INFINITY;
+      if (mf) vm = v + mf[j];
+      y[j] = vm;
+      if (v > st.m_all) st.m_all = v;
+      if (vm > st.m_mask) st.m_mask = vm;
+    }
+    st.N_all = rintf(st.m_all * GLB_LOG2E);
+    st.N_mask = rintf(st.m_mask * GLB_LOG2E);
+    st.S_all = 0;
+    st.S_mask = 0;
+    for (int64_t j = 0; j < V; ++j) {
+      st.S_all += glb_fix_term(x[j], st.N_all);
+      st.S_mask += glb_fix_term(y[j], st.N_mask);
+    }
+    double lse_all = st.S_all ? glb_log_fix(st.S_all, (int32_t)st.N_all - GLB_FIX_FRAC) : -INFINITY;
+    double lse_mask = st.S_mask ? glb_log_fix(st.S_mask, (int32_t)st.N_mask - GLB_FIX_FRAC) : -INFINITY;
+    if (out_lse) out_lse[i] = (float)lse_all;
+    if (out_logZ) out_logZ[i] = (float)(lse_mask - lse_all);
+    if (rng_mode == ORC_RNG_NONE || !out_token) continue;
+    int32_t tok = -1;
+    if (st.S_mask != 0) {
+      if (rng_mode == ORC_RNG_PHILOX) {
+        uint64_t gp = (uint64_t)(particle_base + i);
+        uint32_t ctr[4] = {(uint32_t)gp, (uint32_t)(gp >> 32), (uint32_t)offset,
+                           (uint32_t)(offset >> 32)};
+        uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, rnd[4];
+        orc_philox4x32_10(ctr, key, rnd);
+        uint64_t R = ((uint64_t)rnd[1] << 32) | rnd[0];
+        uint64_t T = mulhi64(R, st.S_mask); /* uniform integer in [0, S_mask) */
+        uint64_t c = 0;
+        for (int64_t j = 0; j < V; ++j) {
+          c += glb_fix_term(y[j], st.N_mask);
+          if (c > T) { tok = (int32_t)j; break; }
+        }
+      } else { /* exponential race against caller noise: first argmax of e_j / E_j */
+        const float *E = noise + i * noise_ld;
+        float best = -1.0f;
+        for (int64_t j = 0; j < V; ++j) {
+          if (!(y[j] > -INFINITY)) continue;
+          float nf, P;
+          glb_exp_parts(y[j], &nf, &P);
+          float df = nf - st.N_mask; /* <= 0, integer valued */
+          float e = (df < -100.0f) ? 0.0f : ldexpf(P, (int)df - 30);
+          float g = e / E[j];
+          if (g > best) { best = g; tok = (int32_t)j; }
+        }
+      }
+    }
+    out_token[i] = tok;
+  }
+  free(x);
+  free(y);
+  return 0;
+}
+
+/* contract of glb_log_softmax_rows: out = x - (float)lse, lse from the fixed-point sum */
+int orc_log_softmax_rows(const void *logits, int dtype, int64_t n_rows, int64_t V, int64_t ld,
+                         float logit_scale, float *out, int64_t out_ld, float *out_lse) {
+  for (int64_t r = 0; r < n_rows; ++r) {
+    float m = -INFINITY;
+    for (int64_t j = 0; j < V; ++j) {
+      float v = load_elem(logits, dtype, r * ld + j);
+      if (logit_scale != 1.0f) v = v * logit_scale;
+      if (v > m) m = v;
+    }
+    float N = rintf(m * GLB_LOG2E);
+    uint64_t S = 0;
+    for (int64_t j = 0; j < V; ++j) {
+      float v = load_elem(logits, dtype, r * ld + j);
+      if (logit_scale != 1.0f) v = v * logit_scale;
+      S += glb_fix_term(v, N);
+    }
+    float lse = S ? (float)glb_log_fix(S, (int32_t)N - GLB_FIX_FRAC) : -INFINITY;
+    if (out_lse) out_lse[r] = lse;
+    if (out)
+      for (int64_t j = 0; j < V; ++j) {
+        float v = load_elem(logits, dtype, r * ld + j);
+        if (logit_scale != 1.0f) v = v * logit_scale;
+        out[r * out_ld + j] = v - lse;
+      }
+  }
+  return 0;
+}
+
+/* contract of glb_mask_f32_to_bits */
+int orc_mask_f32_to_bits(const float *mask, int64_t n_masks, int64_t V, int64_t mask_ld,
+                         uint32_t *out_bits, int64_t bits_ld, int32_t *out_nonbinary) {
+  int nb = 0;
+  for (int64_t k = 0; k < n_masks; ++k) {
+    for (int64_t w = 0; w < bits_ld; ++w) out_bits[k * bits_ld + w] = 0;
+    for (int64_t j = 0; j < V; ++j) {
+      float v = mask[k * mask_ld + j];
+      if (v == 0.0f) out_bits[k * bits_ld + (j >> 5)] |= 1u << (j & 31);
+      else if (!(v == -INFINITY)) nb = 1;
+    }
+  }
+  if (out_nonbinary) *out_nonbinary = nb;
+  return 0;
+}
+
+/* contract of glb_normalize_weights (README.md:108-110) in GLB math */
+int orc_normalize_weights(const float *lw, int64_t n, float *out_probs, float *out_stats) {
+  float m = -INFINITY;
+  for (int64_t i = 0; i < n; ++i)
+    if (lw[i] > m) m = lw[i];
+  float N = rintf(m * GLB_LOG2E);
+  float N2 = rintf((m + m) * GLB_LOG2E);
+  uint64_t S = 0, S2 = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    S += glb_fix_term(lw[i], N);
+    S2 += glb_fix_term(lw[i] + lw[i], N2);
+  }
+  double lse = S ? glb_log_fix(S, (int32_t)N - GLB_FIX_FRAC) : -INFINITY;
+  double lse2 = S2 ? glb_log_fix(S2, (int32_t)N2 - GLB_FIX_FRAC) : -INFINITY;
+  float lsef = (float)lse;
+  if (out_stats) {
+    out_stats[0] = lsef;
+    /* ESS = (sum w)^2 / sum w^2 = e^(2*lse - lse2) through the same exp split */
+    float d = (float)(2.0 * lse - lse2), nf, P;
+    if (!(d > -INFINITY) || !(d < INFINITY)) {
+      out_stats[1] = 0.0f;
+    } else {
+      glb_exp_parts(d, &nf, &P);
+      out_stats[1] = ldexpf(P, (int)nf - 30);
+    }
+  }
+  if (out_probs)
+    for (int64_t i = 0; i < n; ++i) {
+      /* probs = e^(lw - lse) through the same exp split, scaled back to float */
+      float d = lw[i] - lsef;
+      if (!(d > -INFINITY)) { out_probs[i] = 0.0f; continue; }
+      float nf, P;
+      glb_exp_parts(d, &nf, &P);
+      out_probs[i] = (nf < -120.0f) ? 0.0f : ldexpf(P, (int)nf - 30);
+    }
+  return 0;
+}
+
+/* ---------------------------------------------------------------- layer A: reference semantics */
+
+/* MT19937 as used by torch's CPUGeneratorImpl (at::mt19937; the reference reaches it through
+ * torch.multinomial in README.md:87 and base.py:137-141).  The algorithm is Matsumoto &
+ * Nishimura's published one; torch seeds it with init_genrand(seed & 0xffffffff). */
+typedef struct {
+  uint32_t mt[624];
+  int32_t idx;
+} orc_mt19937;
+
+void orc_mt19937_seed(orc_mt19937 *st, uint64_t seed) {
+  st->mt[0] = (uint32_t)seed;
+  for (int i = 1; i < 624; ++i)
+    st->mt[i] = 1812433253u * (st->mt[i - 1] ^ (st->mt[i - 1] >> 30)) + (uint32_t)i;
+  st->idx = 624;
+}
+
+static uint32_t orc_mt19937_next(orc_mt19937 *st) {
+  if (st->idx >= 624) {
+    uint32_t *mt = st->mt;
+    for (int i = 0; i < 624; ++i) {
+      uint32_t yv = (mt[i] & 0x80000000u) | (mt[(i + 1) % 624] & 0x7fffffffu);
+      mt[i] = mt[(i + 397) % 624] ^ (yv >> 1) ^ ((yv & 1u) ? 0x9908b0dfu : 0u);
+    }
+    st->idx = 0;
+  }
+  uint32_t yv = st->mt[st->idx++];
+  yv ^= yv >> 11;
+  yv ^= (yv << 7) & 0x9d2c5680u;
+  yv ^= (yv << 15) & 0xefc60000u;
+  yv ^= yv >> 18;
+  return yv;
+}
+
+/* torch.empty(n, dtype=float32).exponential_(1, generator) on CPU: each variate consumes one
+ * random64() = (first word << 32 | second word), u = (r & (2^53-1)) * 2^-53 as double,
+ * E = (float)(-log1p(-u)).  Verified bit-for-bit against torch 2.10 in tests/test_oracle.py. */
+int orc_mt19937_exponential_f32(orc_mt19937 *st, float *out, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) {
+    uint64_t hi = orc_mt19937_next(st), lo = orc_mt19937_next(st);
+    uint64_t r = (hi << 32) | lo;
+    double u = (double)(r & ((1ULL << 53) - 1)) * (1.0 / 9007199254740992.0);
+    out[i] = (float)(-log1p(-u));
+  }
+  return 0;
+}
+
+/* README.md:84-87 particle math in the reference's float32 arithmetic, given logps already
+ * normalised (the tensor next_token_logprobs returns):
+ *   masked = logps + mask; logZ = logsumexp(masked); p = exp(masked - logZ);
+ *   token = multinomial(p, 1) == first argmax p / E   (torch CPU fast path, n_sample == 1).
+ * logsumexp follows torch: max, exp(x - max) summed, log, + max (sum done in double here; torch
+ * sums in float with its own blocking, the difference is < 1e-6 and is covered by the 1e-4 bar). */
+int orc_ref_particle(const float *logps, const float *mask, int64_t V, const float *E,
+                     float *out_logZ, int32_t *out_token) {
+  float m = -INFINITY;
+  for (int64_t j = 0; j < V; ++j) {
+    float v = mask ? logps[j] + mask[j] : logps[j];
+    if (v > m) m = v;
+  }
+  float mm = isinf(m) ? 0.0f : m;
+  double s = 0;
+  for (int64_t j = 0; j < V; ++j) {
+    float v = mask ? logps[j] + mask[j] : logps[j];
+    s += (double)expf(v - mm);
+  }
+  float logZ = (float)log(s) + mm;
+  if (out_logZ) *out_logZ = logZ;
+  if (E && out_token) {
+    float best = -1.0f;
+    int32_t tok = -1;
+    for (int64_t j = 0; j < V; ++j) {
+      float v = mask ? logps[j] + mask[j] : logps[j];
+      float p = expf(v - logZ);
+      float g = p / E[j];
+      if (g > best) { best = g; tok = (int32_t)j; }
+    }
+    *out_token = tok;
+  }
+  return 0;
+}
+
+/* cache.py:96 — torch.log_softmax(row, 0) in float32: x - max - log(sum exp(x - max)) */
+int orc_ref_log_softmax(const float *x, int64_t V, float *out) {
+  float m = -INFINITY;
+  for (int64_t j = 0; j < V; ++j)
+    if (x[j] > m) m = x[j];
+  double s = 0;
+  for (int64_t j = 0; j < V; ++j) s += (double)expf(x[j] - m);
+  float ls = (float)log(s);
+  for (int64_t j = 0; j < V; ++j) out[j] = (x[j] - m) - ls;
+  return 0;
+}
+
+/* hf.py:214-220 — dedup by tuple(prompt), groups numbered in first-appearance order (dict order) */
+int orc_group_contexts(const int32_t *tokens, const int64_t *offsets, int64_t n,
+                       int32_t *out_group_of, int32_t *out_rep, int32_t *out_n_groups) {
+  int32_t ng = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t li = offsets[i + 1] - offsets[i];
+    int32_t g = -1;
+    for (int32_t k = 0; k < ng; ++k) {
+      int64_t r = out_rep[k];
+      if (offsets[r + 1] - offsets[r] == li &&
+          memcmp(tokens + offsets[r], tokens + offsets[i], (size_t)li * 4) == 0) {
+        g = k;
+        break;
+      }
+    }
+    if (g < 0) {
+      g = ng;
+      out_rep[ng++] = (int32_t)i;
+    }
+    out_group_of[i] = g;
+  }
+  *out_n_groups = ng;
+  return 0;
+}
+
+/* hf.py:314-344 walk_cache, restricted to what batching needs: deepest KV-bearing prefix that is
+ * a proper prefix of the context (KV is looked up *before* consuming the token at that depth,
+ * so a prefix as long as the whole context never qualifies). */
+int orc_match_prefixes(const int32_t *tokens, const int64_t *offsets, int64_t n,
+                       const int32_t *ptok, const int64_t *poff, int64_t np, int32_t *out_prefix,
+                       int32_t *out_base) {
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t li = offsets[i + 1] - offsets[i];
+    int32_t best = -1;
+    int64_t bl = 0;
+    for (int64_t k = 0; k < np; ++k) {
+      int64_t lk = poff[k + 1] - poff[k];
+      if (lk >= li || lk <= bl) continue;
+      if (lk > 0 && memcmp(ptok + poff[k], tokens + offsets[i], (size_t)lk * 4) == 0) {
+        best = (int32_t)k;
+        bl = lk;
+      }
+    }
+    out_prefix[i] = best;
+    out_base[i] = (int32_t)bl;
+  }
+  return 0;
+}
+
+/* hf.py:55-70,232-246 — Query.prompt_padded / attention_mask / position_ids for a batch */
+int orc_gather_padded(const int32_t *tokens, const int64_t *offsets, const int32_t *sel,
+                      int64_t n_sel, const int32_t *base, int64_t pad_id, int64_t p_max,
+                      int64_t l_max, int64_t *ids, int64_t *am, int64_t *pos, int32_t *last) {
+  for (int64_t u = 0; u < n_sel; ++u) {
+    int64_t s = sel ? sel[u] : u;
+    int64_t b = base ? base[s] : 0;
+    int64_t len = offsets[s + 1] - offsets[s] - b;
+    if (len < 0 || len > l_max || b > p_max) return 1;
+    for (int64_t t = 0; t < l_max; ++t) {
+      ids[u * l_max + t] = t < len ? tokens[offsets[s] + b + t] : pad_id;
+      pos[u * l_max + t] = t < len ? b + t : 0;
+    }
+    for (int64_t p = 0; p < p_max + l_max; ++p) {
+      int64_t v;
+      if (p < p_max) v = p < b;
+      else v = (p - p_max) < len;
+      am[u * (p_max + l_max) + p] = v;
+    }
+    if (last) last[u] = (int32_t)(len - 1);
+  }
+  return 0;
+}
+
+/* hf.py:33-53,247-271 — zero-pad each query's past on the sequence axis and stack on batch */
+int orc_gather_kv_padded(const void *const *slabs, const int32_t *slab_len, int64_t np,
+                         const int32_t *prefix_of, int64_t n_rows, int64_t heads, int64_t hd,
+                         int64_t p_max, int32_t eb, void *out) {
+  (void)np;
+  char *o = (char *)out;
+  size_t rowb = (size_t)hd * eb;
+  for (int64_t u = 0; u < n_rows; ++u) {
+    int32_t k = prefix_of[u];
+    for (int64_t h = 0; h < heads; ++h)
+      for (int64_t p = 0; p < p_max; ++p) {
+        char *dst = o + ((u * heads + h) * p_max + p) * rowb;
+        if (k >= 0 && p < slab_len[k])
+          memcpy(dst, (const char *)slabs[k] + (h * slab_len[k] + p) * rowb, rowb);
+        else
+          memset(dst, 0, rowb);
+      }
+  }
+  return 0;
+}
+
+/* README.md:82-91 bookkeeping after the draw */
+int orc_particles_advance(int32_t *ctx, int64_t ctx_ld, int32_t *len, int32_t *active,
+                          float *lw, const float *logZ, const int32_t *tok, int64_t n,
+                          int32_t eos, int32_t max_len) {
+  for (int64_t i = 0; i < n; ++i) {
+    if (!active[i]) continue;
+    lw[i] += logZ[i];
+    if (tok[i] == eos || tok[i] < 0) {
+      active[i] = 0;
+    } else {
+      ctx[i * ctx_ld + len[i]] = tok[i];
+      len[i] += 1;
+      if (len[i] >= max_len) active[i] = 0;
+    }
+  }
+  return 0;
+}

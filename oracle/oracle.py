@@ -1,0 +1,236 @@
+"""ctypes front-end of the CPU oracle (oracle/glb_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product package (genlm-backend_amd/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libglb_oracle.so")
+
+F32, BF16, F16 = 0, 1, 2
+MASK_NONE, MASK_BITS, MASK_F32 = 0, 1, 2
+RNG_NONE, RNG_PHILOX, RNG_NOISE = 0, 1, 2
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "glb_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+    return _lib
+
+
+def _p(a, ct=C.c_void_p):
+    if a is None:
+        return None
+    return a.ctypes.data_as(ct)
+
+
+def _dtype_code(a):
+    if a.dtype == np.float32:
+        return F32
+    if a.dtype == np.float16:
+        return F16
+    if a.dtype == np.uint16:  # raw bf16 bits
+        return BF16
+    raise TypeError(a.dtype)
+
+
+def f32_to_bf16_bits(x):
+    """round-to-nearest-even float32 -> bf16 bit pattern (uint16)"""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    r = ((u >> 16) & 1) + 0x7FFF
+    return ((u + r) >> 16).astype(np.uint16)
+
+
+def bf16_bits_to_f32(b):
+    return (b.astype(np.uint32) << 16).view(np.float32)
+
+
+def step(logits, row_of=None, mask_kind=MASK_NONE, mask=None, mask_id=None, rng_mode=RNG_NONE,
+         noise=None, seed=0, offset=0, particle_base=0, logit_scale=1.0, n_particles=None):
+    """Layer-B particle step.  Returns (logZ, lse, token)."""
+    logits = np.ascontiguousarray(logits)
+    n_rows, ld = logits.shape
+    V = ld
+    if row_of is not None:
+        row_of = np.ascontiguousarray(row_of, dtype=np.int32)
+        n = len(row_of)
+    else:
+        n = n_rows if n_particles is None else n_particles
+    n_masks, mask_ld = 0, 0
+    if mask_kind != MASK_NONE:
+        mask = np.ascontiguousarray(mask)
+        n_masks, mask_ld = mask.shape
+    if mask_id is not None:
+        mask_id = np.ascontiguousarray(mask_id, dtype=np.int32)
+    noise_ld = 0
+    if noise is not None:
+        noise = np.ascontiguousarray(noise, dtype=np.float32)
+        noise_ld = noise.shape[1]
+    logZ = np.empty(n, np.float32)
+    lse = np.empty(n, np.float32)
+    tok = np.full(n, -2, np.int32)
+    rc = lib().orc_step(
+        _p(logits), _dtype_code(logits), C.c_int64(n_rows), C.c_int64(V), C.c_int64(ld),
+        C.c_float(logit_scale), C.c_int64(n), _p(row_of), C.c_int(mask_kind), _p(mask),
+        C.c_int64(mask_ld), C.c_int64(n_masks), _p(mask_id), C.c_int(rng_mode), _p(noise),
+        C.c_int64(noise_ld), C.c_uint64(seed), C.c_uint64(offset), C.c_int64(particle_base),
+        _p(logZ), _p(lse), _p(tok))
+    if rc:
+        raise RuntimeError(f"orc_step rc={rc}")
+    return logZ, lse, tok
+
+
+def log_softmax_rows(logits, logit_scale=1.0):
+    logits = np.ascontiguousarray(logits)
+    n, V = logits.shape
+    out = np.empty((n, V), np.float32)
+    lse = np.empty(n, np.float32)
+    lib().orc_log_softmax_rows(_p(logits), _dtype_code(logits), C.c_int64(n), C.c_int64(V),
+                               C.c_int64(V), C.c_float(logit_scale), _p(out), C.c_int64(V), _p(lse))
+    return out, lse
+
+
+def mask_f32_to_bits(mask):
+    mask = np.ascontiguousarray(mask, dtype=np.float32)
+    k, V = mask.shape
+    W = (V + 31) // 32
+    bits = np.zeros((k, W), np.uint32)
+    nb = C.c_int32(0)
+    lib().orc_mask_f32_to_bits(_p(mask), C.c_int64(k), C.c_int64(V), C.c_int64(V), _p(bits),
+                               C.c_int64(W), C.byref(nb))
+    return bits, bool(nb.value)
+
+
+def normalize_weights(lw):
+    lw = np.ascontiguousarray(lw, dtype=np.float32)
+    probs = np.empty_like(lw)
+    stats = np.empty(2, np.float32)
+    lib().orc_normalize_weights(_p(lw), C.c_int64(len(lw)), _p(probs), _p(stats))
+    return probs, stats
+
+
+class MT19937(C.Structure):
+    _fields_ = [("mt", C.c_uint32 * 624), ("idx", C.c_int32)]
+
+
+def mt_exponential(seed, n, state=None):
+    """float32 Exp(1) variates exactly as torch CPU `exponential_` draws them."""
+    st = state or MT19937()
+    if state is None:
+        lib().orc_mt19937_seed(C.byref(st), C.c_uint64(seed))
+    out = np.empty(n, np.float32)
+    lib().orc_mt19937_exponential_f32(C.byref(st), _p(out), C.c_int64(n))
+    return out, st
+
+
+def philox(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib().orc_philox4x32_10(c, k, o)
+    return list(o)
+
+
+def ref_particle(logps, mask, E):
+    """Layer-A README.md:84-87 particle math in float32.  Returns (logZ, token)."""
+    logps = np.ascontiguousarray(logps, dtype=np.float32)
+    mask = None if mask is None else np.ascontiguousarray(mask, dtype=np.float32)
+    E = None if E is None else np.ascontiguousarray(E, dtype=np.float32)
+    z = C.c_float()
+    t = C.c_int32(-2)
+    lib().orc_ref_particle(_p(logps), _p(mask), C.c_int64(len(logps)), _p(E), C.byref(z), C.byref(t))
+    return z.value, t.value
+
+
+def ref_log_softmax(x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty_like(x)
+    lib().orc_ref_log_softmax(_p(x), C.c_int64(len(x)), _p(out))
+    return out
+
+
+def _ragged(contexts):
+    off = np.zeros(len(contexts) + 1, np.int64)
+    for i, c in enumerate(contexts):
+        off[i + 1] = off[i] + len(c)
+    tok = np.zeros(max(int(off[-1]), 1), np.int32)
+    for i, c in enumerate(contexts):
+        tok[off[i]:off[i + 1]] = c
+    return tok, off
+
+
+def group_contexts(contexts):
+    tok, off = _ragged(contexts)
+    n = len(contexts)
+    g = np.empty(n, np.int32)
+    rep = np.empty(max(n, 1), np.int32)
+    ng = C.c_int32()
+    lib().orc_group_contexts(_p(tok), _p(off), C.c_int64(n), _p(g), _p(rep), C.byref(ng))
+    return g, rep[:ng.value].copy(), ng.value
+
+
+def match_prefixes(contexts, prefixes):
+    tok, off = _ragged(contexts)
+    ptok, poff = _ragged(prefixes)
+    n = len(contexts)
+    pref = np.empty(n, np.int32)
+    base = np.empty(n, np.int32)
+    lib().orc_match_prefixes(_p(tok), _p(off), C.c_int64(n), _p(ptok), _p(poff),
+                             C.c_int64(len(prefixes)), _p(pref), _p(base))
+    return pref, base
+
+
+def gather_padded(contexts, sel, base, pad_id, p_max, l_max):
+    tok, off = _ragged(contexts)
+    sel_a = None if sel is None else np.ascontiguousarray(sel, dtype=np.int32)
+    base_a = None if base is None else np.ascontiguousarray(base, dtype=np.int32)
+    n_sel = len(contexts) if sel is None else len(sel)
+    ids = np.empty((n_sel, l_max), np.int64)
+    am = np.empty((n_sel, p_max + l_max), np.int64)
+    pos = np.empty((n_sel, l_max), np.int64)
+    last = np.empty(n_sel, np.int32)
+    rc = lib().orc_gather_padded(_p(tok), _p(off), _p(sel_a), C.c_int64(n_sel), _p(base_a),
+                                 C.c_int64(pad_id), C.c_int64(p_max), C.c_int64(l_max), _p(ids),
+                                 _p(am), _p(pos), _p(last))
+    if rc:
+        raise RuntimeError("orc_gather_padded")
+    return ids, am, pos, last
+
+
+def gather_kv_padded(slabs, prefix_of, p_max):
+    """slabs: list of [H, P_k, D] arrays; returns [U, H, p_max, D]."""
+    slabs = [np.ascontiguousarray(s) for s in slabs]
+    H, _, D = slabs[0].shape
+    eb = slabs[0].dtype.itemsize
+    ptrs = (C.c_void_p * len(slabs))(*[s.ctypes.data for s in slabs])
+    lens = np.array([s.shape[1] for s in slabs], np.int32)
+    prefix_of = np.ascontiguousarray(prefix_of, dtype=np.int32)
+    U = len(prefix_of)
+    out = np.empty((U, H, p_max, D), slabs[0].dtype)
+    lib().orc_gather_kv_padded(ptrs, _p(lens), C.c_int64(len(slabs)), _p(prefix_of), C.c_int64(U),
+                               C.c_int64(H), C.c_int64(D), C.c_int64(p_max), C.c_int32(eb), _p(out))
+    return out
+
+
+def particles_advance(ctx, lengths, active, lw, logZ, tok, eos, max_len):
+    n, ld = ctx.shape
+    lib().orc_particles_advance(_p(ctx), C.c_int64(ld), _p(lengths), _p(active), _p(lw),
+                                _p(np.ascontiguousarray(logZ, dtype=np.float32)),
+                                _p(np.ascontiguousarray(tok, dtype=np.int32)), C.c_int64(n),
+                                C.c_int32(eos), C.c_int32(max_len))
