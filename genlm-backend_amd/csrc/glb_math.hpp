@@ -45,9 +45,10 @@ __device__ __forceinline__ void exp_parts(float x, float &nf, float &P) {
 // fixed-point term of x relative to the row exponent N (N + 18 passed pre-added as Nb).
 // x == -inf contributes 0 (sf = +inf -> s = 63 -> pfix = 0).
 __device__ __forceinline__ uint64_t fix_term_from_parts(float nf, float P, float Nb) {
-  float sf = Nb - nf;
-  uint32_t s = (sf < 63.0f) ? (uint32_t)sf : 63u;
-  uint32_t pfix = (s < 63u) ? (uint32_t)P : 0u;
+  // s = min(Nb - n, 63) (NaN -> 63); P < 2^31 so a shift by 63 always yields 0, which makes the
+  // oracle's "pfix = 0 when s == 63" select redundant here (v_cvt_u32_f32 maps NaN to 0).
+  const uint32_t s = (uint32_t)fminf(Nb - nf, 63.0f);
+  const uint32_t pfix = (uint32_t)P;
   return ((uint64_t)pfix << 32) >> s;
 }
 
@@ -100,28 +101,57 @@ __host__ __device__ inline void philox4x32_10(const uint32_t ctr[4], const uint3
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// ---- wave64 helpers --------------------------------------------------------------------------
+// ---- wave64 helpers (DPP: no LDS traffic) ----------------------------------------------------------
+// dpp_ctrl encodings (GFX9): row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143
 
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint64_t dpp_u64_or0(uint64_t v) {
+  const uint32_t lo = dpp_u32<CTRL, ROW_MASK>(0u, (uint32_t)v);
+  const uint32_t hi = dpp_u32<CTRL, ROW_MASK>(0u, (uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// inclusive prefix sum over the 64 lanes (lane 63 ends up with the wave total)
+__device__ __forceinline__ uint64_t wave_scan_u64(uint64_t v) {
+  v += dpp_u64_or0<0x111, 0xf>(v);
+  v += dpp_u64_or0<0x112, 0xf>(v);
+  v += dpp_u64_or0<0x114, 0xf>(v);
+  v += dpp_u64_or0<0x118, 0xf>(v);
+  v += dpp_u64_or0<0x142, 0xa>(v);
+  v += dpp_u64_or0<0x143, 0xc>(v);
+  return v;
+}
+
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// wave total, broadcast to every lane (wave-uniform value)
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) { return readlane_u64(wave_scan_u64(v), 63); }
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_max_step(float v) {
+  const uint32_t ninf = 0xff800000u;
+  const float o = __uint_as_float(dpp_u32<CTRL, ROW_MASK>(ninf, __float_as_uint(v)));
+  return fmaxf(v, o);
+}
+
+// wave maximum, broadcast to every lane
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-
-__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int o) {
-  uint32_t lo = __shfl_xor((uint32_t)v, o, 64), hi = __shfl_xor((uint32_t)(v >> 32), o, 64);
-  return ((uint64_t)hi << 32) | lo;
-}
-
-__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int o) {
-  uint32_t lo = __shfl_up((uint32_t)v, o, 64), hi = __shfl_up((uint32_t)(v >> 32), o, 64);
-  return ((uint64_t)hi << 32) | lo;
-}
-
-__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += shfl_xor_u64(v, o);
-  return v;
+  v = dpp_max_step<0x111, 0xf>(v);
+  v = dpp_max_step<0x112, 0xf>(v);
+  v = dpp_max_step<0x114, 0xf>(v);
+  v = dpp_max_step<0x118, 0xf>(v);
+  v = dpp_max_step<0x142, 0xa>(v);
+  v = dpp_max_step<0x143, 0xc>(v);
+  return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
 }
 
 }  // namespace glb

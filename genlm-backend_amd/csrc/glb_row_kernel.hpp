@@ -19,6 +19,8 @@
 // CDF; (3) one lane turns the sums into lse / logZ in double and the draw is located by
 // wave -> tile -> lane -> element prefix search in vocabulary order.
 #pragma once
+#include <type_traits>
+
 #include "glb_math.hpp"
 
 namespace glb {
@@ -81,8 +83,9 @@ __device__ __forceinline__ void unpack_vec(const uint4 &r, float *x) {
   }
 }
 
-// EPV mask bits for the elements j0 .. j0+EPV-1 of a packed bit row (bits of invalid elements are
-// don't-care: their x is -inf)
+// Funnel-extract the EPV mask bits of elements j0 .. j0+EPV-1 from a packed bit row.  Bits of
+// elements outside [0, V) are don't-care (their x is -inf).  d = max(-j0, 0) only matters for the
+// first vector of a misaligned row.
 template <int EPV>
 __device__ __forceinline__ uint32_t mask_nibble(const uint32_t *mrow, int32_t n_words, int32_t j0) {
   const int32_t jb = j0 < 0 ? 0 : j0;
@@ -90,8 +93,21 @@ __device__ __forceinline__ uint32_t mask_nibble(const uint32_t *mrow, int32_t n_
   const int32_t wi = jb >> 5;
   const int32_t w0 = wi < n_words ? wi : n_words - 1;
   const int32_t w1 = wi + 1 < n_words ? wi + 1 : n_words - 1;
-  const uint64_t w64 = ((uint64_t)mrow[w1] << 32) | mrow[w0];
-  return (uint32_t)((w64 >> (jb & 31)) << d) & ((1u << EPV) - 1u);
+  const uint32_t lo = mrow[w0], hi = mrow[w1];
+  const uint32_t f = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(jb & 31));  // ({hi,lo} >> sh)[31:0]
+  return (f << d) & ((1u << EPV) - 1u);
+}
+
+// Zero-instruction barrier: the compiler may not reuse values derived from `r` before this point
+// (prevents it from carrying 4*NVL unpacked / scaled / bit-filled copies of the row across phases).
+__device__ __forceinline__ void opaque(uint4 &r) {
+  asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w));
+}
+__device__ __forceinline__ void opaque(uint32_t &r) { asm volatile("" : "+v"(r)); }
+
+// all-ones / all-zeros word from bit `pos` of w (v_bfe_i32)
+__device__ __forceinline__ uint32_t bit_fill(uint32_t w, int pos) {
+  return (uint32_t)(((int32_t)(w << (31 - pos))) >> 31);
 }
 
 template <int DT, int MASK, int MODE, int NVL, int T>
@@ -100,6 +116,8 @@ __global__ __launch_bounds__(T) void row_kernel(const RowParams p) {
   constexpr int ES = ElemTraits<DT>::ES;
   constexpr int W = T / 64;
   constexpr int MBW = (NVL * EPV + 31) / 32;
+  constexpr bool kPhilox = MODE == kModePhilox;
+  constexpr bool kNoise = MODE == kModeNoise;
 
   __shared__ float s_max[2][W];
   __shared__ uint64_t s_sum[2][W];
@@ -107,7 +125,7 @@ __global__ __launch_bounds__(T) void row_kernel(const RowParams p) {
   __shared__ int32_t s_bestj[W];
   __shared__ float s_lse;
   // per-(tile, lane) masked partial sums for the inverse-CDF search (philox mode only)
-  __shared__ uint64_t s_asum[MODE == kModePhilox ? NVL * T : 1];
+  __shared__ uint64_t s_asum[kPhilox ? NVL * T : 1];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -141,16 +159,17 @@ __global__ __launch_bounds__(T) void row_kernel(const RowParams p) {
 #pragma unroll
   for (int i = 0; i < MBW; ++i) mb[i] = 0xffffffffu;
   const float *mrow_f = nullptr;
+  const uint32_t *mrow_b = nullptr;
   if constexpr (MASK == kMaskBits) {
     const int mi = p.mask_id ? p.mask_id[pidx] : (p.n_masks == 1 ? 0 : pidx);
-    const uint32_t *mrow = (const uint32_t *)p.mask + (int64_t)mi * p.mask_ld;
+    mrow_b = (const uint32_t *)p.mask + (int64_t)mi * p.mask_ld;
     const int n_words = (V + 31) >> 5;
 #pragma unroll
     for (int i = 0; i < MBW; ++i) mb[i] = 0;
 #pragma unroll
     for (int k = 0; k < NVL; ++k) {
       const int v = v0 + k * 64;
-      const uint32_t nib = mask_nibble<EPV>(mrow, n_words, v * EPV - a);
+      const uint32_t nib = mask_nibble<EPV>(mrow_b, n_words, v * EPV - a);
       mb[(k * EPV) >> 5] |= nib << ((k * EPV) & 31);
     }
   } else if constexpr (MASK == kMaskF32) {
@@ -192,8 +211,10 @@ __global__ __launch_bounds__(T) void row_kernel(const RowParams p) {
       const float xv = p.use_scale ? xk[c] * p.scale : xk[c];
       m_all = fmaxf(m_all, xv);
       if constexpr (MASK == kMaskBits) {
-        const bool bit = (mb[(k * EPV + c) >> 5] >> ((k * EPV + c) & 31)) & 1u;
-        m_msk = fmaxf(m_msk, bit ? xv : kNegInf);
+        // allowed ? x : -inf  as one v_bfi_b32 on the bit pattern
+        const uint32_t fill = bit_fill(mb[(k * EPV + c) >> 5], (k * EPV + c) & 31);
+        const uint32_t sel = (__float_as_uint(xv) & fill) | (0xff800000u & ~fill);
+        m_msk = fmaxf(m_msk, __uint_as_float(sel));
       } else if constexpr (MASK == kMaskF32) {
         int j = (v0 + k * 64) * EPV - a + c;
         j = j < 0 ? 0 : (j >= V ? V - 1 : j);
@@ -221,13 +242,23 @@ __global__ __launch_bounds__(T) void row_kernel(const RowParams p) {
   const float N_all = __builtin_rintf(m_all * kLog2e);
   const float N_msk = __builtin_rintf(m_msk * kLog2e);
   const float Nb_all = N_all + (float)kFixShift, Nb_msk = N_msk + (float)kFixShift;
+  // When the masked maximum has the same exponent as the row maximum (the usual case: the top
+  // token is allowed) the masked terms are the unmasked terms gated by the mask bit.
+  const bool same_n = (N_all == N_msk);
 
   // ---- phase 2: fixed-point sums (+ race / per-tile partial sums) ----------------------------------
   uint64_t s_all = 0, s_msk = 0;
   float best_g = -1.0f;
   int32_t best_j = 0x7fffffff;
   const float *noise_row = nullptr;
-  if constexpr (MODE == kModeNoise) noise_row = p.noise + (int64_t)pidx * p.noise_ld;
+  if constexpr (kNoise) noise_row = p.noise + (int64_t)pidx * p.noise_ld;
+  // keep the compiler from carrying the per-element bit fills of phase 1 across the barrier (50+
+  // VGPRs): make the packed mask words opaque so the fills are re-derived from them in phase 2
+#pragma unroll
+  for (int i = 0; i < MBW; ++i) opaque(mb[i]);
+#pragma unroll
+  for (int k = 0; k < NVL; ++k) opaque(raw[k]);
+
 #pragma unroll
   for (int k = 0; k < NVL; ++k) {
     uint64_t ak = 0;
@@ -238,27 +269,25 @@ __global__ __launch_bounds__(T) void row_kernel(const RowParams p) {
       const float xv = p.use_scale ? xk[c] * p.scale : xk[c];
       float nf, P;
       exp_parts(xv, nf, P);
-      s_all += fix_term_from_parts(nf, P, Nb_all);
-      uint64_t qm;
+      const uint64_t q = fix_term_from_parts(nf, P, Nb_all);
+      s_all += q;
       float nfy = nf, Py = P, yv = xv;
       if constexpr (MASK == kMaskNone) {
-        qm = 0;  // S_mask == S_all, taken after the loop
-        if constexpr (MODE == kModePhilox) qm = fix_term_from_parts(nf, P, Nb_all);
+        if constexpr (kPhilox) ak += q;
       } else if constexpr (MASK == kMaskBits) {
-        const bool bit = (mb[(k * EPV + c) >> 5] >> ((k * EPV + c) & 31)) & 1u;
-        const uint64_t q2 = fix_term_from_parts(nf, P, Nb_msk);
-        qm = bit ? q2 : 0ull;
-        yv = bit ? xv : kNegInf;
+        // masked term == unmasked term gated by the mask bit when N_msk == N_all; the rare other
+        // case is redone below against N_msk
+        const uint32_t fill = bit_fill(mb[(k * EPV + c) >> 5], (k * EPV + c) & 31);
+        ak += q & (((uint64_t)fill << 32) | fill);
+        if constexpr (kNoise) yv = __uint_as_float((__float_as_uint(xv) & fill) | (0xff800000u & ~fill));
       } else {
         int j = (v0 + k * 64) * EPV - a + c;
         j = j < 0 ? 0 : (j >= V ? V - 1 : j);
         yv = xv + mrow_f[j];
         exp_parts(yv, nfy, Py);
-        qm = fix_term_from_parts(nfy, Py, Nb_msk);
+        ak += fix_term_from_parts(nfy, Py, Nb_msk);
       }
-      s_msk += qm;
-      if constexpr (MODE == kModePhilox) ak += qm;
-      if constexpr (MODE == kModeNoise) {
+      if constexpr (kNoise) {
         const int jr = (v0 + k * 64) * EPV - a + c;
         const int jc = jr < 0 ? 0 : (jr >= V ? V - 1 : jr);
         const float E = noise_row[jc];
@@ -273,14 +302,51 @@ __global__ __launch_bounds__(T) void row_kernel(const RowParams p) {
         }
       }
     }
-    if constexpr (MODE == kModePhilox) s_asum[k * T + tid] = ak;
+    s_msk += ak;
+    if constexpr (kPhilox) s_asum[k * T + tid] = ak;
+    // one vector at a time: without this the scheduler interleaves many vectors and spills
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if constexpr (MASK == kMaskBits) {
+    if (!same_n) {
+      // the allowed set's maximum sits in a lower binade than the row maximum: redo the masked
+      // sum against its own exponent (block-uniform, rare: the top token is forbidden)
+      // (re-reads the row - L2 / Infinity Cache - instead of keeping all of it live in VGPRs)
+      s_msk = 0;
+#pragma unroll 1
+      for (int k = 0; k < NVL; ++k) {
+        int v = v0 + k * 64;
+        const int j0 = v * EPV - a;
+        v = v < nv ? v : nv - 1;
+        const uint4 rk = *reinterpret_cast<const uint4 *>(base + (int64_t)v * 16);
+        const uint32_t nib = mask_nibble<EPV>(mrow_b, (V + 31) >> 5, j0);
+        uint64_t ak = 0;
+        float xk[EPV];
+        unpack_vec<DT>(rk, xk);
+#pragma unroll
+        for (int c = 0; c < EPV; ++c) {
+          const float xv = p.use_scale ? xk[c] * p.scale : xk[c];
+          const bool ok = ((uint32_t)(j0 + c) < (uint32_t)V) && ((nib >> c) & 1u);
+          ak += ok ? fix_term(xv, Nb_msk) : 0ull;
+        }
+        s_msk += ak;
+        if constexpr (kPhilox) s_asum[k * T + tid] = ak;
+      }
+    }
   }
   if constexpr (MASK == kMaskNone) s_msk = s_all;
 
-  s_all = wave_sum_u64(s_all);
-  if constexpr (MASK != kMaskNone) s_msk = wave_sum_u64(s_msk);
-  else s_msk = s_all;
-  if constexpr (MODE == kModeNoise) {
+  {
+    const uint64_t t_all = wave_scan_u64(s_all);
+    uint64_t t_msk = t_all;
+    if constexpr (MASK != kMaskNone) t_msk = wave_scan_u64(s_msk);
+    if (lane == 63) {
+      s_sum[0][wave] = t_all;
+      s_sum[1][wave] = t_msk;
+    }
+  }
+  if constexpr (kNoise) {
+    // wave argmax (max g, then min j) through LDS-free DPP would need 2 fields; 6 xor steps suffice
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const float og = __shfl_xor(best_g, o, 64);
@@ -290,11 +356,7 @@ __global__ __launch_bounds__(T) void row_kernel(const RowParams p) {
         best_j = oj;
       }
     }
-  }
-  if (lane == 0) {
-    s_sum[0][wave] = s_all;
-    s_sum[1][wave] = s_msk;
-    if constexpr (MODE == kModeNoise) {
+    if (lane == 0) {
       s_bestg[wave] = best_g;
       s_bestj[wave] = best_j;
     }
@@ -314,7 +376,7 @@ __global__ __launch_bounds__(T) void row_kernel(const RowParams p) {
     if (p.out_lse) p.out_lse[pidx] = (float)lse_all;
     if (p.out_logZ) p.out_logZ[pidx] = (float)(lse_msk - lse_all);
     if constexpr (MODE == kModeStats) s_lse = (float)lse_all;
-    if constexpr (MODE == kModeNoise) {
+    if constexpr (kNoise) {
       if (p.out_token) {
         float g = s_bestg[0];
         int32_t j = s_bestj[0];
@@ -330,7 +392,7 @@ __global__ __launch_bounds__(T) void row_kernel(const RowParams p) {
         p.out_token[pidx] = (S_msk != 0 && g >= 0.0f) ? j : -1;
       }
     }
-    if constexpr (MODE == kModePhilox) {
+    if constexpr (kPhilox) {
       if (p.out_token && S_msk == 0) p.out_token[pidx] = -1;
     }
   }
@@ -373,18 +435,27 @@ __global__ __launch_bounds__(T) void row_kernel(const RowParams p) {
   }
 
   // ---- inverse-CDF draw: wave -> tile -> lane -> element, vocabulary order ---------------------------
-  if constexpr (MODE == kModePhilox) {
+  if constexpr (kPhilox) {
     if (p.out_token && S_msk != 0) {
-      const uint64_t gp = (uint64_t)(p.particle_base + pidx);
-      const uint32_t ctr[4] = {(uint32_t)gp, (uint32_t)(gp >> 32), (uint32_t)p.offset,
-                               (uint32_t)(p.offset >> 32)};
-      const uint32_t key[2] = {(uint32_t)p.seed, (uint32_t)(p.seed >> 32)};
-      uint32_t rnd[4];
-      philox4x32_10(ctr, key, rnd);
-      const uint64_t R = ((uint64_t)rnd[1] << 32) | rnd[0];
-      uint64_t Tw = __umul64hi(R, S_msk);  // uniform integer in [0, S_msk)
+      // the draw is wave-uniform work: find the wave first, only that wave continues
+      uint64_t Tw = 0;
       int wsel = W - 1;
       {
+        const uint64_t gp = (uint64_t)(p.particle_base + pidx);
+        const uint32_t ctr[4] = {(uint32_t)gp, (uint32_t)(gp >> 32), (uint32_t)p.offset,
+                                 (uint32_t)(p.offset >> 32)};
+        const uint32_t key[2] = {(uint32_t)p.seed, (uint32_t)(p.seed >> 32)};
+        uint32_t rnd[4];
+        philox4x32_10(ctr, key, rnd);
+        const uint64_t R = ((uint64_t)rnd[1] << 32) | rnd[0];
+        Tw = __umul64hi(R, S_msk);  // uniform integer in [0, S_msk)
+        // Keep the search in VALU registers: hipcc (ROCm 7.2) lowers a wave-uniform `u64 < u64`
+        // feeding a select to v_cmp + s_cselect without materialising SCC (wrong wave picked).
+        {
+          uint32_t z = 0;
+          opaque(z);
+          Tw += z;
+        }
         uint64_t run = 0;
         bool found = false;
 #pragma unroll
@@ -399,41 +470,34 @@ __global__ __launch_bounds__(T) void row_kernel(const RowParams p) {
         }
       }
       if (wave == wsel) {
-        uint64_t run = 0, asel = 0, Trem = 0;
-        int ksel = 0;
-        bool found = false;
-        for (int k = 0; k < NVL; ++k) {
-          const uint64_t ak = s_asum[k * T + tid];
-          const uint64_t ck = wave_sum_u64(ak);
-          if (!found && Tw < run + ck) {
-            found = true;
-            ksel = k;
-            asel = ak;
-            Trem = Tw - run;
+        // binary search over this wave's tiles: sum of tiles [lo, mid) by lane-local adds + one scan
+        int lo = 0, hi = NVL;
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          uint64_t part = 0;
+          for (int k = lo; k < mid; ++k) part += s_asum[k * T + tid];
+          const uint64_t c = wave_sum_u64(part);
+          if (Tw < c) {
+            hi = mid;
+          } else {
+            Tw -= c;
+            lo = mid;
           }
-          run += ck;
         }
-        uint64_t incl = asel;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const uint64_t t = shfl_up_u64(incl, o);
-          if (lane >= o) incl += t;
-        }
-        const unsigned long long ball = __ballot(incl > Trem);
+        const int ksel = lo;
+        const uint64_t asel = s_asum[ksel * T + tid];
+        const uint64_t incl = wave_scan_u64(asel);
+        const unsigned long long ball = __ballot(incl > Tw);
         const int lsel = __ffsll((long long)ball) - 1;
         if (lane == lsel) {
-          uint64_t Tl = Trem - (incl - asel);
+          uint64_t Tl = Tw - (incl - asel);
           const int v = v0 + ksel * 64;  // < nv because its tile sum is non-zero
           const uint4 rr = *reinterpret_cast<const uint4 *>(base + (int64_t)v * 16);
           float xs[EPV];
           unpack_vec<DT>(rr, xs);
           const int j0 = v * EPV - a;
           uint32_t nib = (1u << EPV) - 1u;
-          if constexpr (MASK == kMaskBits) {
-            const int mi = p.mask_id ? p.mask_id[pidx] : (p.n_masks == 1 ? 0 : pidx);
-            nib = mask_nibble<EPV>((const uint32_t *)p.mask + (int64_t)mi * p.mask_ld,
-                                   (V + 31) >> 5, j0);
-          }
+          if constexpr (MASK == kMaskBits) nib = mask_nibble<EPV>(mrow_b, (V + 31) >> 5, j0);
           int32_t tok = -1;
 #pragma unroll
           for (int c = 0; c < EPV; ++c) {
