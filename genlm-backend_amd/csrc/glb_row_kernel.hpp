@@ -202,6 +202,8 @@ __global__ __launch_bounds__(T) void row_kernel(const RowParams p) {
 
   // ---- phase 1: maxima ------------------------------------------------------------------------
   float m_all = kNegInf, m_msk = kNegInf;
+  uint32_t v0a = (uint32_t)v0;  // per-phase opaque copies: element indices are re-derived, not kept live
+  opaque(v0a);
 #pragma unroll
   for (int k = 0; k < NVL; ++k) {
     float xk[EPV];
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(T) void row_kernel(const RowParams p) {
         const uint32_t sel = (__float_as_uint(xv) & fill) | (0xff800000u & ~fill);
         m_msk = fmaxf(m_msk, __uint_as_float(sel));
       } else if constexpr (MASK == kMaskF32) {
-        int j = (v0 + k * 64) * EPV - a + c;
+        int j = ((int)v0a + k * 64) * EPV - a + c;
         j = j < 0 ? 0 : (j >= V ? V - 1 : j);
         m_msk = fmaxf(m_msk, xv + mrow_f[j]);
       }
@@ -259,80 +261,69 @@ __global__ __launch_bounds__(T) void row_kernel(const RowParams p) {
 #pragma unroll
   for (int k = 0; k < NVL; ++k) opaque(raw[k]);
 
+  // Bit masks: the masked term equals the unmasked term gated by the mask bit whenever
+  // N_msk == N_all (the usual case).  Otherwise (top token forbidden, block-uniform and rare) the
+  // same loop body runs a second time against N_msk; only its masked sums are kept.
+  const int n_pass = (MASK == kMaskBits && !same_n) ? 2 : 1;
+#pragma unroll 1
+  for (int pass = 0; pass < n_pass; ++pass) {
+    const float Nb_cur = pass == 0 ? Nb_all : Nb_msk;
+    uint64_t acc = 0;
+    s_msk = 0;
+    // defeat loop-invariant hoisting of the per-element exp splits / bit fills (100+ VGPRs)
 #pragma unroll
-  for (int k = 0; k < NVL; ++k) {
-    uint64_t ak = 0;
-    float xk[EPV];
-    unpack_vec<DT>(raw[k], xk);
+    for (int i = 0; i < MBW; ++i) opaque(mb[i]);
 #pragma unroll
-    for (int c = 0; c < EPV; ++c) {
-      const float xv = p.use_scale ? xk[c] * p.scale : xk[c];
-      float nf, P;
-      exp_parts(xv, nf, P);
-      const uint64_t q = fix_term_from_parts(nf, P, Nb_all);
-      s_all += q;
-      float nfy = nf, Py = P, yv = xv;
-      if constexpr (MASK == kMaskNone) {
-        if constexpr (kPhilox) ak += q;
-      } else if constexpr (MASK == kMaskBits) {
-        // masked term == unmasked term gated by the mask bit when N_msk == N_all; the rare other
-        // case is redone below against N_msk
-        const uint32_t fill = bit_fill(mb[(k * EPV + c) >> 5], (k * EPV + c) & 31);
-        ak += q & (((uint64_t)fill << 32) | fill);
-        if constexpr (kNoise) yv = __uint_as_float((__float_as_uint(xv) & fill) | (0xff800000u & ~fill));
-      } else {
-        int j = (v0 + k * 64) * EPV - a + c;
-        j = j < 0 ? 0 : (j >= V ? V - 1 : j);
-        yv = xv + mrow_f[j];
-        exp_parts(yv, nfy, Py);
-        ak += fix_term_from_parts(nfy, Py, Nb_msk);
-      }
-      if constexpr (kNoise) {
-        const int jr = (v0 + k * 64) * EPV - a + c;
-        const int jc = jr < 0 ? 0 : (jr >= V ? V - 1 : jr);
-        const float E = noise_row[jc];
-        if (yv > kNegInf) {
-          const float df = nfy - N_msk;
-          const float e = (df < -100.0f) ? 0.0f : __builtin_ldexpf(Py, (int)df - 30);
-          const float g = e / E;
-          if (g > best_g) {
-            best_g = g;
-            best_j = jr;
+    for (int k = 0; k < NVL; ++k) opaque(raw[k]);
+    uint32_t v0b = (uint32_t)v0;
+    opaque(v0b);
+#pragma unroll
+    for (int k = 0; k < NVL; ++k) {
+      uint64_t ak = 0;
+      float xk[EPV];
+      unpack_vec<DT>(raw[k], xk);
+#pragma unroll
+      for (int c = 0; c < EPV; ++c) {
+        const float xv = p.use_scale ? xk[c] * p.scale : xk[c];
+        float nf, P;
+        exp_parts(xv, nf, P);
+        const uint64_t q = fix_term_from_parts(nf, P, Nb_cur);
+        acc += q;
+        float nfy = nf, Py = P, yv = xv;
+        if constexpr (MASK == kMaskNone) {
+          if constexpr (kPhilox) ak += q;
+        } else if constexpr (MASK == kMaskBits) {
+          const uint32_t fill = bit_fill(mb[(k * EPV + c) >> 5], (k * EPV + c) & 31);
+          ak += q & (((uint64_t)fill << 32) | fill);
+          if constexpr (kNoise) yv = __uint_as_float((__float_as_uint(xv) & fill) | (0xff800000u & ~fill));
+        } else {
+          int j = ((int)v0b + k * 64) * EPV - a + c;
+          j = j < 0 ? 0 : (j >= V ? V - 1 : j);
+          yv = xv + mrow_f[j];
+          exp_parts(yv, nfy, Py);
+          ak += fix_term_from_parts(nfy, Py, Nb_msk);
+        }
+        if constexpr (kNoise) {
+          const int jr = ((int)v0b + k * 64) * EPV - a + c;
+          const int jc = jr < 0 ? 0 : (jr >= V ? V - 1 : jr);
+          const float E = noise_row[jc];
+          if (yv > kNegInf && pass == n_pass - 1) {
+            const float df = nfy - N_msk;
+            const float e = (df < -100.0f) ? 0.0f : __builtin_ldexpf(Py, (int)df - 30);
+            const float g = e / E;
+            if (g > best_g) {
+              best_g = g;
+              best_j = jr;
+            }
           }
         }
       }
+      s_msk += ak;
+      if constexpr (kPhilox) s_asum[k * T + tid] = ak;
+      // one vector at a time: without this the scheduler interleaves many vectors and spills
+      __builtin_amdgcn_sched_barrier(0);
     }
-    s_msk += ak;
-    if constexpr (kPhilox) s_asum[k * T + tid] = ak;
-    // one vector at a time: without this the scheduler interleaves many vectors and spills
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if constexpr (MASK == kMaskBits) {
-    if (!same_n) {
-      // the allowed set's maximum sits in a lower binade than the row maximum: redo the masked
-      // sum against its own exponent (block-uniform, rare: the top token is forbidden)
-      // (re-reads the row - L2 / Infinity Cache - instead of keeping all of it live in VGPRs)
-      s_msk = 0;
-#pragma unroll 1
-      for (int k = 0; k < NVL; ++k) {
-        int v = v0 + k * 64;
-        const int j0 = v * EPV - a;
-        v = v < nv ? v : nv - 1;
-        const uint4 rk = *reinterpret_cast<const uint4 *>(base + (int64_t)v * 16);
-        const uint32_t nib = mask_nibble<EPV>(mrow_b, (V + 31) >> 5, j0);
-        uint64_t ak = 0;
-        float xk[EPV];
-        unpack_vec<DT>(rk, xk);
-#pragma unroll
-        for (int c = 0; c < EPV; ++c) {
-          const float xv = p.use_scale ? xk[c] * p.scale : xk[c];
-          const bool ok = ((uint32_t)(j0 + c) < (uint32_t)V) && ((nib >> c) & 1u);
-          ak += ok ? fix_term(xv, Nb_msk) : 0ull;
-        }
-        s_msk += ak;
-        if constexpr (kPhilox) s_asum[k * T + tid] = ak;
-      }
-    }
+    if (pass == 0) s_all = acc;
   }
   if constexpr (MASK == kMaskNone) s_msk = s_all;
 
