@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the genlm-backend hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload sis|kernel]
+
+One process per GPU (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ...`,
+RCCL through torch.distributed backend "nccl").  A step is one pass of the hot path over one batch
+of synthetic input that is already resident in HBM:
+
+  workload "sis"    (default) one sequential-importance-sampling step of 1024 particles per GPU on
+                    a GPT-2-small-shaped random-init model (README.md:82-98 of the reference):
+                    context dedup -> ragged-to-padded gather -> PyTorch-ROCm forward -> lm_head on
+                    the last position -> fused log-softmax + mask + logsumexp + sample kernel ->
+                    particle bookkeeping (-> RCCL all-gather of log-weights when N > 1).
+  workload "kernel" only the fused kernel on [1024, 50257] fp32 logits, rotating over 4 buffers so the
+                    256 MiB Infinity Cache cannot serve the rows.
+
+Rank 0 prints ONE JSON line.  `value` = particles per second over all GPUs (weak scaling: 1024
+particles per GPU).  `roofline` prices the fused kernel: algorithmic bytes per launch
+over its mean launch duration, measured with HIP events on the launch stream inside the timed
+region.  `cpu_baseline` times the reference-semantics CPU port (oracle/, test infrastructure) of
+the same particle step on a bounded sample, single thread, on this host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+V_GPT2 = 50257
+N_PARTICLES = 1024
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
+
+
+def algorithmic_bytes(B, V, elem_size, n_masks, mask_words):
+    """logits once + distinct mask bytes + 8 B of outputs per particle."""
+    return B * V * elem_size + n_masks * mask_words * 4 + B * 8
+
+
+def cpu_baseline(sample_rows, repeats, seed=1234):
+    """Reference-semantics particle step on the host (oracle layer A: cache.py:96 log_softmax,
+    README.md:84-87 mask + logsumexp + exp + multinomial incl. the serial MT19937 draws)."""
+    from oracle import oracle as O
+    from tests import synth
+
+    O.build()
+    x = synth.logits(seed, sample_rows, V_GPT2)
+    masks = synth.binary_masks(seed, 2, V_GPT2)
+    t0 = time.perf_counter()
+    done = 0
+    st = None
+    for _ in range(repeats):
+        for r in range(sample_rows):
+            lp = O.ref_log_softmax(x[r])
+            E, st = O.mt_exponential(seed, V_GPT2, st)
+            O.ref_particle(lp, masks[r % 2], E)
+            done += 1
+    dt = time.perf_counter() - t0
+    return {
+        "value": done / dt,
+        "unit": "particles/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{done} particle steps (V={V_GPT2}, fp32, shared mask, MT19937 multinomial) in {dt:.1f} s, "
+                  f"single thread; host has {os.cpu_count()} cores",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default=None, choices=["sis", "kernel"])
+    ap.add_argument("--cpu-sample", type=int, default=1024, help="rows of the CPU baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if args.gpus != 1 and world == 1:
+            raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import genlm_backend_amd  # noqa: F401
+    from genlm_backend_amd.engine import HipEngine
+
+    eng = HipEngine(dev)
+    workload = args.workload
+    if workload is None:
+        try:
+            from genlm_backend_amd import sis  # noqa: F401
+            workload = "sis"
+        except ImportError:
+            workload = "kernel"
+
+    if workload == "kernel":
+        runner = KernelWorkload(eng, dev, rank, world, dist)
+    else:
+        from genlm_backend_amd.sis import SisBenchWorkload
+
+        runner = SisBenchWorkload(eng, dev, rank, world, dist)
+
+    for i in range(args.warmup):
+        runner.step(i, timed=False)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        runner.step(args.warmup + i, timed=True)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    kern_us = runner.kernel_times_us()
+    if rank == 0:
+        total_particles = runner.particles_per_step * world * args.steps
+        ach = runner.kernel_bytes / (np.mean(kern_us) * 1e-6) / 1e9
+        out = {
+            "metric": "particles/sec (SIS particle steps; fused logprob+mask+logsumexp+sample kernel priced against HBM)",
+            "value": total_particles / dt,
+            "unit": "particles/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": runner.config(),
+            "roofline": {
+                "bound": "hbm",
+                "achieved": ach,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel": "glb::row_kernel (fused log-softmax + mask + logsumexp + sample)",
+                "bytes_per_launch": runner.kernel_bytes,
+                "us_per_launch_mean": float(np.mean(kern_us)),
+                "us_per_launch_median": float(np.median(kern_us)),
+                "launches_timed": len(kern_us),
+            },
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, 1)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+class KernelWorkload:
+    """Fused kernel only, [1024, 50257] fp32 logits, two shared {0,-inf} masks, in-kernel Philox."""
+
+    particles_per_step = N_PARTICLES
+
+    def __init__(self, eng, dev, rank, world, dist, nbuf=4):
+        self.eng, self.dev, self.rank, self.world, self.dist = eng, dev, rank, world, dist
+        g = torch.Generator(device=dev)
+        g.manual_seed(1234 + rank)
+        B, V = N_PARTICLES, V_GPT2
+        self.bufs = [torch.randn((B, V), device=dev, generator=g) * 3.0 for _ in range(nbuf)]
+        maskf = torch.where(torch.rand((2, V), device=dev, generator=g) < 1 / 3, float("-inf"), 0.0)
+        maskf[:, 0] = 0.0
+        self.bits, _ = eng.mask_to_bits(maskf)
+        self.mask_id = (torch.arange(B, device=dev) % 2).to(torch.int32)
+        self.out = (torch.empty(B, device=dev), torch.empty(B, device=dev),
+                    torch.empty(B, dtype=torch.int32, device=dev))
+        self.lw = torch.zeros(B, device=dev)
+        self.gathered = torch.empty(B * world, device=dev) if world > 1 else None
+        self.kernel_bytes = algorithmic_bytes(B, V, 4, 2, (V + 31) // 32)
+        self.events = []
+
+    def step(self, i, timed):
+        x = self.bufs[i % len(self.bufs)]
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        self.eng.step(x, mask_kind=1, mask=self.bits, mask_id=self.mask_id, rng_mode=1, seed=1234, offset=i,
+                      particle_base=self.rank * N_PARTICLES, out=self.out)
+        if timed:
+            e1.record()
+            self.events.append((e0, e1))
+        self.lw += self.out[0]
+        if self.world > 1:
+            self.dist.all_gather_into_tensor(self.gathered, self.lw)
+            self.eng.normalize_weights(self.gathered)
+
+    def kernel_times_us(self):
+        return np.array([a.elapsed_time(b) * 1e3 for a, b in self.events])
+
+    def config(self):
+        return {"workload": "fused kernel only: 1024 particles x gpt2 vocab 50257, fp32 logits [1024,50257] ld=V, "
+                            "2 shared bit masks, Philox draw, 4 rotating logits buffers",
+                "particles_per_gpu": N_PARTICLES, "vocab": V_GPT2, "rng": "philox"}
+
+
+if __name__ == "__main__":
+    main()
