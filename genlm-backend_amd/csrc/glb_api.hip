@@ -111,10 +111,11 @@ __device__ inline uint64_t hash_ctx(const int32_t *t, int64_t len) {
   return h;
 }
 
-__device__ inline bool same_ctx(const int32_t *tok, const int64_t *off, int64_t i, int64_t j) {
-  const int64_t li = off[i + 1] - off[i];
-  if (off[j + 1] - off[j] != li) return false;
-  const int32_t *a = tok + off[i], *b = tok + off[j];
+__device__ inline bool same_ctx(const int32_t *tok, const int64_t *st, const int32_t *len, int64_t i,
+                                int64_t j) {
+  const int64_t li = len[i];
+  if (len[j] != li) return false;
+  const int32_t *a = tok + st[i], *b = tok + st[j];
   for (int64_t t = 0; t < li; ++t)
     if (a[t] != b[t]) return false;
   return true;
@@ -125,7 +126,7 @@ __device__ inline bool same_ctx(const int32_t *tok, const int64_t *off, int64_t 
 // Open-addressing table keyed by full token comparison: the slot owner is whichever context won
 // the CAS, the group representative is the minimum index that reached the slot (order independent).
 __global__ __launch_bounds__(1024) void group_contexts_kernel(
-    const int32_t *tok, const int64_t *off, int32_t n, int32_t cap, int32_t *table,
+    const int32_t *tok, const int64_t *st, const int32_t *len, int32_t n, int32_t cap, int32_t *table,
     int32_t *minidx, int32_t *slot_of, int32_t *gid_of, int32_t *out_group_of, int32_t *out_rep,
     int32_t *out_n_groups) {
   const int T = 1024, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -138,11 +139,11 @@ __global__ __launch_bounds__(1024) void group_contexts_kernel(
   if (tid == 0) s_carry = 0;
   __syncthreads();
   for (int i = tid; i < n; i += T) {
-    const uint64_t h = hash_ctx(tok + off[i], off[i + 1] - off[i]);
+    const uint64_t h = hash_ctx(tok + st[i], len[i]);
     int32_t slot = (int32_t)(h & (uint64_t)(cap - 1));
     for (;;) {
       const int32_t owner = atomicCAS(&table[slot], -1, i);
-      if (owner == -1 || owner == i || same_ctx(tok, off, owner, i)) break;
+      if (owner == -1 || owner == i || same_ctx(tok, st, len, owner, i)) break;
       slot = (slot + 1) & (cap - 1);
     }
     slot_of[i] = slot;
@@ -182,19 +183,20 @@ __global__ __launch_bounds__(1024) void group_contexts_kernel(
   for (int i = tid; i < n; i += T) out_group_of[i] = gid_of[minidx[slot_of[i]]];
 }
 
-__global__ void match_prefixes_kernel(const int32_t *tok, const int64_t *off, int64_t n,
-                                      const int32_t *ptok, const int64_t *poff, int64_t np,
-                                      int32_t *out_prefix, int32_t *out_base) {
+__global__ void match_prefixes_kernel(const int32_t *tok, const int64_t *st, const int32_t *len,
+                                      int64_t n, const int32_t *ptok, const int64_t *pst,
+                                      const int32_t *plen, int64_t np, int32_t *out_prefix,
+                                      int32_t *out_base) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const int64_t li = off[i + 1] - off[i];
-  const int32_t *c = tok + off[i];
+  const int64_t li = len[i];
+  const int32_t *c = tok + st[i];
   int32_t best = -1;
   int64_t bl = 0;
   for (int64_t k = 0; k < np; ++k) {
-    const int64_t lk = poff[k + 1] - poff[k];
+    const int64_t lk = plen[k];
     if (lk >= li || lk <= bl) continue;
-    const int32_t *q = ptok + poff[k];
+    const int32_t *q = ptok + pst[k];
     bool eq = true;
     for (int64_t t = 0; t < lk; ++t)
       if (q[t] != c[t]) {
@@ -211,8 +213,8 @@ __global__ void match_prefixes_kernel(const int32_t *tok, const int64_t *off, in
 }
 
 // one thread per attention-mask column (the widest output); ids / positions share the tail columns
-__global__ void gather_padded_kernel(const int32_t *tok, const int64_t *off, const int32_t *sel,
-                                     int64_t n_sel, const int32_t *base, int64_t pad_id,
+__global__ void gather_padded_kernel(const int32_t *tok, const int64_t *st, const int32_t *lens,
+                                     const int32_t *sel, int64_t n_sel, const int32_t *base, int64_t pad_id,
                                      int64_t p_max, int64_t l_max, int64_t *ids, int64_t *am,
                                      int64_t *pos, int32_t *last) {
   const int64_t width = p_max + l_max;
@@ -221,7 +223,7 @@ __global__ void gather_padded_kernel(const int32_t *tok, const int64_t *off, con
   const int64_t u = gid / width, p = gid % width;
   const int64_t s = sel ? sel[u] : u;
   const int64_t b = base ? base[s] : 0;
-  int64_t len = off[s + 1] - off[s] - b;
+  int64_t len = (int64_t)lens[s] - b;
   len = len < 0 ? 0 : (len > l_max ? l_max : len);
   if (p < p_max) {
     am[gid] = p < b ? 1 : 0;
@@ -229,7 +231,7 @@ __global__ void gather_padded_kernel(const int32_t *tok, const int64_t *off, con
     const int64_t t = p - p_max;
     const bool in = t < len;
     am[gid] = in ? 1 : 0;
-    ids[u * l_max + t] = in ? (int64_t)tok[off[s] + b + t] : pad_id;
+    ids[u * l_max + t] = in ? (int64_t)tok[st[s] + b + t] : pad_id;
     pos[u * l_max + t] = in ? b + t : 0;
     if (t == 0 && last) last[u] = (int32_t)(len - 1);
   }
@@ -495,10 +497,10 @@ size_t glb_group_contexts_workspace(int64_t n) {
   return (size_t)(2 * group_cap(n) + 2 * n) * sizeof(int32_t);
 }
 
-int glb_group_contexts(const int32_t *tokens, const int64_t *offsets, int64_t n,
-                       int32_t *out_group_of, int32_t *out_rep, int32_t *out_n_groups,
+int glb_group_contexts(const int32_t *tokens, const int64_t *starts, const int32_t *lengths,
+                       int64_t n, int32_t *out_group_of, int32_t *out_rep, int32_t *out_n_groups,
                        void *workspace, size_t workspace_bytes, void *stream) {
-  if (!tokens || !offsets || !out_group_of || !out_rep || !out_n_groups || !workspace)
+  if (!tokens || !starts || !lengths || !out_group_of || !out_rep || !out_n_groups || !workspace)
     return fail(GLB_EINVAL, "null pointer");
   if (n <= 0 || n > (1 << 28)) return fail(GLB_EINVAL, "n out of range");
   if (workspace_bytes < glb_group_contexts_workspace(n))
@@ -507,37 +509,39 @@ int glb_group_contexts(const int32_t *tokens, const int64_t *offsets, int64_t n,
   int32_t *table = (int32_t *)workspace, *minidx = table + cap, *slot_of = minidx + cap,
           *gid_of = slot_of + n;
   hipLaunchKernelGGL(group_contexts_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, tokens,
-                     offsets, (int32_t)n, (int32_t)cap, table, minidx, slot_of, gid_of,
+                     starts, lengths, (int32_t)n, (int32_t)cap, table, minidx, slot_of, gid_of,
                      out_group_of, out_rep, out_n_groups);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "group_contexts launch");
   return GLB_OK;
 }
 
-int glb_match_prefixes(const int32_t *tokens, const int64_t *offsets, int64_t n,
-                       const int32_t *prefix_tokens, const int64_t *prefix_offsets,
-                       int64_t n_prefixes, int32_t *out_prefix, int32_t *out_base, void *stream) {
-  if (!tokens || !offsets || !out_prefix || !out_base) return fail(GLB_EINVAL, "null pointer");
+int glb_match_prefixes(const int32_t *tokens, const int64_t *starts, const int32_t *lengths,
+                       int64_t n, const int32_t *prefix_tokens, const int64_t *prefix_starts,
+                       const int32_t *prefix_lengths, int64_t n_prefixes, int32_t *out_prefix,
+                       int32_t *out_base, void *stream) {
+  if (!tokens || !starts || !lengths || !out_prefix || !out_base) return fail(GLB_EINVAL, "null pointer");
   if (n <= 0 || n_prefixes < 0) return fail(GLB_EINVAL, "bad sizes");
-  if (n_prefixes > 0 && (!prefix_tokens || !prefix_offsets)) return fail(GLB_EINVAL, "null prefix table");
+  if (n_prefixes > 0 && (!prefix_tokens || !prefix_starts || !prefix_lengths))
+    return fail(GLB_EINVAL, "null prefix table");
   hipLaunchKernelGGL(match_prefixes_kernel, dim3(blocks_for(n, 256)), dim3(256), 0,
-                     (hipStream_t)stream, tokens, offsets, n, prefix_tokens, prefix_offsets,
-                     n_prefixes, out_prefix, out_base);
+                     (hipStream_t)stream, tokens, starts, lengths, n, prefix_tokens, prefix_starts,
+                     prefix_lengths, n_prefixes, out_prefix, out_base);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "match_prefixes launch");
   return GLB_OK;
 }
 
-int glb_gather_padded(const int32_t *tokens, const int64_t *offsets, const int32_t *sel,
-                      int64_t n_sel, const int32_t *base, int64_t pad_id, int64_t p_max,
+int glb_gather_padded(const int32_t *tokens, const int64_t *starts, const int32_t *lengths,
+                      const int32_t *sel, int64_t n_sel, const int32_t *base, int64_t pad_id, int64_t p_max,
                       int64_t l_max, int64_t *out_input_ids, int64_t *out_attention_mask,
                       int64_t *out_position_ids, int32_t *out_last_index, void *stream) {
-  if (!tokens || !offsets || !out_input_ids || !out_attention_mask || !out_position_ids)
+  if (!tokens || !starts || !lengths || !out_input_ids || !out_attention_mask || !out_position_ids)
     return fail(GLB_EINVAL, "null pointer");
   if (n_sel <= 0 || l_max <= 0 || p_max < 0) return fail(GLB_EINVAL, "bad sizes");
   const int64_t total = n_sel * (p_max + l_max);
   hipLaunchKernelGGL(gather_padded_kernel, dim3(blocks_for(total, 256)), dim3(256), 0,
-                     (hipStream_t)stream, tokens, offsets, sel, n_sel, base, pad_id, p_max, l_max,
+                     (hipStream_t)stream, tokens, starts, lengths, sel, n_sel, base, pad_id, p_max, l_max,
                      out_input_ids, out_attention_mask, out_position_ids, out_last_index);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "gather_padded launch");

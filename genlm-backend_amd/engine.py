@@ -152,34 +152,36 @@ class HipEngine:
         return bits, flag
 
     # ------------------------------------------------------------------------------------------
-    def group_contexts(self, tokens, offsets):
+    def group_contexts(self, tokens, starts, lengths):
         """Exact dedup, first-appearance order.  Returns (group_of[n], rep[n], n_groups[1]) on device."""
-        n = offsets.numel() - 1
-        self._check_dev(tokens, offsets)
+        n = lengths.numel()
+        self._check_dev(tokens, starts, lengths)
         need = self.lib.glb_group_contexts_workspace(n)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(max(need, 1 << 16), dtype=torch.uint8, device=self.device)
         group_of, rep, ng = self._i32(n), self._i32(n), self._i32(1)
-        check(self.lib.glb_group_contexts(_ptr(tokens), _ptr(offsets), n, _ptr(group_of), _ptr(rep),
+        check(self.lib.glb_group_contexts(_ptr(tokens), _ptr(starts), _ptr(lengths), n, _ptr(group_of), _ptr(rep),
                                           _ptr(ng), _ptr(self._ws), self._ws.numel(), self._stream()))
         return group_of, rep, ng
 
-    def match_prefixes(self, tokens, offsets, prefix_tokens, prefix_offsets):
-        n = offsets.numel() - 1
-        npre = 0 if prefix_offsets is None else prefix_offsets.numel() - 1
+    def match_prefixes(self, tokens, starts, lengths, prefix_tokens, prefix_starts, prefix_lengths):
+        n = lengths.numel()
+        npre = 0 if prefix_lengths is None else prefix_lengths.numel()
         pref, base = self._i32(n), self._i32(n)
-        check(self.lib.glb_match_prefixes(_ptr(tokens), _ptr(offsets), n, _ptr(prefix_tokens),
-                                          _ptr(prefix_offsets), npre, _ptr(pref), _ptr(base), self._stream()))
+        check(self.lib.glb_match_prefixes(_ptr(tokens), _ptr(starts), _ptr(lengths), n, _ptr(prefix_tokens),
+                                          _ptr(prefix_starts), _ptr(prefix_lengths), npre, _ptr(pref), _ptr(base),
+                                          self._stream()))
         return pref, base
 
-    def gather_padded(self, tokens, offsets, sel, n_sel, base, pad_id, p_max, l_max):
+    def gather_padded(self, tokens, starts, lengths, sel, n_sel, base, pad_id, p_max, l_max):
         dev = self.device
         ids = torch.empty((n_sel, l_max), dtype=torch.int64, device=dev)
         am = torch.empty((n_sel, p_max + l_max), dtype=torch.int64, device=dev)
         pos = torch.empty((n_sel, l_max), dtype=torch.int64, device=dev)
         last = self._i32(n_sel)
-        check(self.lib.glb_gather_padded(_ptr(tokens), _ptr(offsets), _ptr(sel), n_sel, _ptr(base), pad_id,
-                                         p_max, l_max, _ptr(ids), _ptr(am), _ptr(pos), _ptr(last), self._stream()))
+        check(self.lib.glb_gather_padded(_ptr(tokens), _ptr(starts), _ptr(lengths), _ptr(sel), n_sel, _ptr(base),
+                                         pad_id, p_max, l_max, _ptr(ids), _ptr(am), _ptr(pos), _ptr(last),
+                                         self._stream()))
         return ids, am, pos, last
 
     def gather_kv_padded(self, slab_ptrs, slab_len, prefix_of, heads, head_dim, p_max, dtype):

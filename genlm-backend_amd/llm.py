@@ -1,0 +1,527 @@
+"""AsyncLM interface and the MI355X backend behind it.
+
+Mirrors, name for name, the surface of the reference that the hot path exposes:
+  * `AsyncLM`                       genlm/backend/llm/base.py:9-179
+  * `AsyncAmdLM` (= AsyncTransformer of genlm/backend/llm/hf.py:73-422 with the per-step work moved
+    to the HIP library): `from_name`, `next_token_logprobs[_sync|_uncached]`,
+    `batch_next_token_logprobs[_sync]`, `sample`, `batch_sample`, `cache_kv`, `clear_cache`,
+    `clear_kv_cache`, `reset_async_queries`, `walk_cache`, `add_query`, `batch_evaluate_queries`,
+    attributes `model tokenizer device cache queries batch_size timeout timer byte_vocab str_vocab`
+  * `load_model_by_name`            genlm/backend/llm/__init__.py:10-43 (extra backend value "amd")
+plus one addition the reference leaves to user code (README.md:82-91): `next_token_step`, the fused
+log-softmax + mask + logsumexp + categorical draw, autobatched through the same queue.
+
+All device arithmetic after the transformer's final hidden state goes through `HipEngine`
+(C ABI, include/glb.h).  There is no CPU fallback: without the built library and a HIP device the
+constructor raises.
+"""
+import asyncio
+from abc import ABC, abstractmethod
+
+import numpy as np
+import torch
+
+from .cache import KVPrefix, TokenTrie
+from .tokenization import decode_vocab
+
+MASK_NONE, MASK_BITS, MASK_F32 = 0, 1, 2
+RNG_NONE, RNG_PHILOX, RNG_NOISE = 0, 1, 2
+
+
+class AsyncLM(ABC):
+    """base.py:9-179."""
+
+    def __init__(self, tokenizer):
+        self.tokenizer = tokenizer
+        self.byte_vocab, self.str_vocab = decode_vocab(self.tokenizer)
+
+    @abstractmethod
+    async def next_token_logprobs(self, token_ids):
+        pass
+
+    @abstractmethod
+    def next_token_logprobs_sync(self, token_ids):
+        pass
+
+    async def batch_next_token_logprobs(self, token_ids_list):
+        """base.py:47-60"""
+        logprobs = await asyncio.gather(*[self.next_token_logprobs(t) for t in token_ids_list])
+        return torch.stack(logprobs)
+
+    def batch_next_token_logprobs_sync(self, token_ids_list):
+        """base.py:62-73"""
+        return torch.stack([self.next_token_logprobs_sync(t) for t in token_ids_list])
+
+    def add_new_lora(self, lora_path, lora_name):
+        raise NotImplementedError("add_new_lora must be implemented by subclasses")
+
+    def set_lora(self, lora_path, lora_name):
+        raise NotImplementedError("set_lora must be implemented by subclasses")
+
+    def clear_lora(self):
+        raise NotImplementedError("clear_lora must be implemented by subclasses")
+
+    def clear_cache(self):
+        pass
+
+    def _draw(self, logprobs, temperature, generator_state):
+        """One categorical draw from softmax(logprobs / temperature); subclasses override."""
+        probs = torch.softmax(logprobs / temperature, dim=-1)
+        return torch.multinomial(probs.cpu(), num_samples=1, generator=generator_state).item()
+
+    def _make_generator(self, seed):
+        if seed is None:
+            return None
+        g = torch.Generator()
+        g.manual_seed(seed)
+        return g
+
+    async def sample(self, prompt_token_ids, max_tokens, eos_token_ids, temperature=1.0, seed=None):
+        """base.py:110-146"""
+        gen = self._make_generator(seed)
+        generated = []
+        for _ in range(max_tokens):
+            logprobs = await self.next_token_logprobs(prompt_token_ids + generated)
+            tok = self._draw(logprobs, temperature, gen)
+            if tok in eos_token_ids:
+                break
+            generated.append(tok)
+        return generated
+
+    async def batch_sample(self, prompt_token_ids_list, max_tokens, eos_token_ids, temperature=1.0, seed=None):
+        """base.py:148-179 (every sequence gets its own generator seeded with `seed`)"""
+        return await asyncio.gather(*[
+            self.sample(prompt_token_ids=p, max_tokens=max_tokens, eos_token_ids=eos_token_ids,
+                        temperature=temperature, seed=seed)
+            for p in prompt_token_ids_list
+        ])
+
+
+class Query:
+    """A pending request (hf.py:14-70).  Padding, masks and position ids are no longer built per query in
+    Python: the gather kernel produces them for the whole batch (glb_gather_padded)."""
+
+    __slots__ = ("prompt", "future", "past", "past_len", "first_new", "kind", "mask_id")
+
+    def __init__(self, prompt, future, past=None, first_new=0, kind="logprobs", mask_id=0):
+        self.prompt = prompt
+        self.future = future
+        self.past = past
+        self.past_len = len(past) if past is not None else 0
+        self.first_new = first_new  # first prompt position whose next-token row the caller needs
+        self.kind = kind            # "logprobs" | "step"
+        self.mask_id = mask_id
+
+
+class AsyncAmdLM(AsyncLM):
+    """Autobatching wrapper around a HuggingFace causal LM on one MI355X (hf.py:73-422)."""
+
+    @classmethod
+    def from_name(cls, model_id, bitsandbytes_opts=None, hf_opts=None, **kwargs):
+        """hf.py:80-112.  bitsandbytes is a CUDA-only dependency and is rejected."""
+        from transformers import AutoModelForCausalLM, AutoTokenizer
+
+        if bitsandbytes_opts:
+            raise NotImplementedError("bitsandbytes quantisation is CUDA-only; not available on MI355X")
+        _hf_opts = {"torch_dtype": "auto"}
+        if hf_opts:
+            _hf_opts.update(hf_opts)
+        device = _hf_opts.pop("device", None) or _hf_opts.pop("device_map", None) or "cuda:0"
+        if device == "auto":
+            device = "cuda:0"
+        tok = AutoTokenizer.from_pretrained(model_id)
+        mod = AutoModelForCausalLM.from_pretrained(model_id, **_hf_opts).to(device)
+        return cls(mod, tok, **kwargs)
+
+    @classmethod
+    def from_config(cls, config, tokenizer, device="cuda:0", dtype=torch.float32, seed=0, **kwargs):
+        """Random-init model of a given architecture (no hub access needed; synthetic benchmarks/tests)."""
+        from transformers import AutoModelForCausalLM
+
+        torch.manual_seed(seed)
+        mod = AutoModelForCausalLM.from_config(config).to(dtype).to(device)
+        return cls(mod, tokenizer, **kwargs)
+
+    @torch.no_grad()
+    def __init__(self, hf_model, hf_tokenizer, batch_size=20, timeout=0.02, engine=None):
+        self.model = hf_model
+        self.tokenizer = hf_tokenizer
+        self.device = hf_model.device
+        if engine is None:
+            from .engine import HipEngine  # raises without the library / a HIP device
+
+            engine = HipEngine(self.device)
+        self.engine = engine
+        self.cache = TokenTrie()
+        self.queries = []
+        self.batch_size = batch_size
+        self.timeout = timeout
+        self.timer = None
+        self.model.eval()
+        self._lm_head = self.model.get_output_embeddings()
+        self._body = self.model.base_model
+        # fused-step state
+        self._mask_kind = MASK_NONE
+        self._masks = None
+        self._rng_mode = RNG_PHILOX
+        self._rng_seed = 0
+        self._host_rng = None
+        self._batch_counter = 0
+        self.stats = {"batches": 0, "queries": 0, "unique": 0, "rows": 0}
+        if hf_tokenizer is not None:
+            super().__init__(tokenizer=self.tokenizer)
+        else:  # model-only use (synthetic benchmarks): no vocabulary to decode
+            self.byte_vocab, self.str_vocab = None, None
+
+    # ---- cache management (hf.py:142-164) ---------------------------------------------------------
+    def clear_cache(self):
+        self.cache = TokenTrie()
+
+    def clear_kv_cache(self):
+        self.cache.clear_kv_cache()
+
+    def reset_async_queries(self):
+        self.queries = []
+
+    @torch.no_grad()
+    def cache_kv(self, prompt_tokens):
+        """hf.py:155-164: run the prompt once, cache every position's log-probs and keep the KV states
+        on the prompt's last node so later queries only feed their new tokens."""
+        ids = torch.tensor([prompt_tokens], device=self.device)
+        out = self._body(input_ids=ids, use_cache=True)
+        logits = self._lm_head(out.last_hidden_state[0])
+        node = self.cache.extend_cache(0, prompt_tokens, logits, 0, engine=self.engine)
+        node.past_key_values = KVPrefix.from_hf_cache(out.past_key_values)
+
+    # ---- LoRA hooks (hf.py:166-200): weight management is outside the hot path ---------------------
+    def add_new_lora(self, lora_path, lora_name="lora_1"):
+        raise NotImplementedError("LoRA adapters are out of scope for the MI355X hot-path backend")
+
+    def set_lora(self, lora_path=None, lora_name="lora_1"):
+        raise NotImplementedError("LoRA adapters are out of scope for the MI355X hot-path backend")
+
+    def clear_lora(self):
+        raise NotImplementedError("LoRA adapters are out of scope for the MI355X hot-path backend")
+
+    # ---- fused-step configuration -------------------------------------------------------------------
+    def register_masks(self, masks):
+        """masks: float tensor [K, V] (or list of [V]) of additive log-masks (README.md:57-70).  {0,-inf}
+        masks are packed to bit rows on the device; anything else is kept as float."""
+        if isinstance(masks, (list, tuple)):
+            masks = torch.stack([m.to(torch.float32) for m in masks])
+        masks = masks.to(self.device, torch.float32).contiguous()
+        bits, flag = self.engine.mask_to_bits(masks)
+        if int(flag.item()) == 0:
+            self._mask_kind, self._masks = MASK_BITS, bits
+        else:
+            self._mask_kind, self._masks = MASK_F32, masks
+        return masks.shape[0]
+
+    def set_rng(self, mode="philox", seed=0):
+        """"philox": in-kernel counter RNG (fast).  "torch": parity with the reference's CPU
+        torch.multinomial under torch.manual_seed(seed) (README.md:87): exponentials are drawn on the
+        host from the same MT19937 stream, in the reference's particle order."""
+        if mode == "philox":
+            self._rng_mode, self._rng_seed, self._host_rng = RNG_PHILOX, int(seed), None
+        elif mode == "torch":
+            from .engine import HostRng
+
+            self._rng_mode, self._rng_seed, self._host_rng = RNG_NOISE, int(seed), HostRng(int(seed))
+        else:
+            raise ValueError(f"unknown rng mode {mode!r}")
+        self._batch_counter = 0
+
+    # ---- the batched evaluation (hf.py:202-288) -------------------------------------------------------
+    @torch.no_grad()
+    def batch_evaluate_queries(self):
+        queries, self.queries = self.queries, []
+        if len(queries) == 0:
+            return
+        try:
+            self._evaluate(queries)
+        except Exception as e:  # vllm.py:396-400 behaviour: nobody is left waiting
+            stranded = [q.future for q in queries if q.future is not None and not q.future.done()]
+            for f in stranded:
+                f.set_exception(e)
+            if not stranded:
+                raise
+
+    def _evaluate(self, queries):
+        eng, dev = self.engine, self.device
+        n = len(queries)
+        # -- flatten: context i = [prefix slot, past_len, prompt...]; two header words make the dedup key
+        #    (hf.py:216 keys on the prompt only; adding the prefix identity cannot merge unequal requests)
+        prefixes, prefix_slot = [], {}
+        lens = np.empty(n, np.int32)
+        for i, q in enumerate(queries):
+            lens[i] = len(q.prompt) + 2
+        starts = np.zeros(n, np.int64)
+        if n > 1:
+            starts[1:] = np.cumsum(lens[:-1])
+        flat = np.empty(int(lens.sum()), np.int32)
+        for i, q in enumerate(queries):
+            slot = 0
+            if q.past is not None:
+                key = id(q.past)
+                if key not in prefix_slot:
+                    prefix_slot[key] = len(prefixes) + 1
+                    prefixes.append(q.past)
+                slot = prefix_slot[key]
+            s = starts[i]
+            flat[s] = slot
+            flat[s + 1] = q.past_len
+            flat[s + 2:s + lens[i]] = q.prompt
+        tok_d = torch.from_numpy(flat).to(dev)
+        st_d = torch.from_numpy(starts).to(dev)
+        ln_d = torch.from_numpy(lens).to(dev)
+
+        # -- shared-prefix dedup on the device, first-appearance order (glb_group_contexts)
+        group_of_d, rep_d, ng_d = eng.group_contexts(tok_d, st_d, ln_d)
+        U = int(ng_d.item())
+        group_of = group_of_d.cpu().numpy()
+        rep = rep_d[:U].cpu().numpy()
+        uniq = [queries[r] for r in rep]
+        members = [[] for _ in range(U)]
+        for i, g in enumerate(group_of):
+            members[g].append(queries[i])
+
+        p_max = max(q.past_len for q in uniq)
+        l_max = max(len(q.prompt) for q in uniq)
+        pad_id = getattr(self.tokenizer, "pad_token_id", None) if self.tokenizer is not None else None
+        pad_id = 0 if pad_id is None else pad_id
+
+        # -- ragged -> padded gather (glb_gather_padded).  starts/lengths are shifted so that
+        #    tokens[start + base + t] is prompt token t, with base = past_len.
+        past_len = np.array([q.past_len for q in queries], np.int32)
+        base_d = torch.from_numpy(past_len).to(dev)
+        st_adj = st_d + 2 - base_d.to(torch.int64)
+        ln_adj = ln_d - 2 + base_d
+        ids, am, pos, _last = eng.gather_padded(tok_d, st_adj, ln_adj, rep_d, U, base_d, pad_id, p_max, l_max)
+
+        # -- batched prefix KV (glb_gather_kv_padded), one launch per layer and K/V
+        cache = None
+        if p_max > 0:
+            from transformers import DynamicCache
+
+            slot_of_u = np.array([prefix_slot[id(q.past)] - 1 if q.past is not None else -1 for q in uniq], np.int32)
+            slot_d = torch.from_numpy(slot_of_u).to(dev)
+            plen_d = torch.tensor([len(p) for p in prefixes], dtype=torch.int32, device=dev)
+            p0 = prefixes[0]
+            data = []
+            for layer in range(len(p0.layers)):
+                kv = []
+                for j in range(2):
+                    ptrs = torch.tensor([p.layers[layer][j].data_ptr() for p in prefixes], dtype=torch.int64, device=dev)
+                    kv.append(eng.gather_kv_padded(ptrs, plen_d, slot_d, p0.heads, p0.head_dim, p_max, p0.dtype))
+                data.append(tuple(kv))
+            cache = DynamicCache(ddp_cache_data=data)
+
+        # -- transformer body (PyTorch-ROCm; the only MFMA work on the path)
+        hidden = self._body(input_ids=ids, attention_mask=am, position_ids=pos, past_key_values=cache,
+                            use_cache=cache is not None).last_hidden_state  # [U, l_max, d]
+
+        # -- which (unique, position) rows are needed: log-prob queries want every new position,
+        #    step queries only the last one
+        row_u, row_t, lp_rows, step_row = [], [], {}, {}
+        for u, q in enumerate(uniq):
+            L = len(q.prompt)
+            lp_first = min((m.first_new for m in members[u] if m.kind == "logprobs"), default=None)
+            if lp_first is not None:
+                lp_rows[u] = (len(row_u), lp_first)
+                for t in range(lp_first, L):
+                    row_u.append(u)
+                    row_t.append(t)
+                step_row[u] = len(row_u) - 1
+            elif any(m.kind == "step" for m in members[u]):
+                step_row[u] = len(row_u)
+                row_u.append(u)
+                row_t.append(L - 1)
+        ru = torch.tensor(row_u, dtype=torch.int64, device=dev)
+        rt = torch.tensor(row_t, dtype=torch.int64, device=dev)
+        logits = self._lm_head(hidden[ru, rt])  # [R, V] plain library GEMM on the gathered rows
+        V = logits.shape[-1]
+        R = logits.shape[0]
+
+        # -- log-prob rows in one launch (glb_log_softmax_rows; replaces cache.py:93-98)
+        lp_slab, slab_row = None, None
+        if lp_rows:
+            need = sorted(r for u, (r0, f) in lp_rows.items() for r in range(r0, r0 + len(uniq[u].prompt) - f))
+            if len(need) == R:
+                lp_slab = eng.log_softmax_rows(logits)
+            else:
+                idx = torch.tensor(need, dtype=torch.int64, device=dev)
+                lp_slab = eng.log_softmax_rows(logits[idx].contiguous())
+                slab_row = {r: i for i, r in enumerate(need)}
+
+        # -- fused step for every step query, in resolution order (group order, duplicates contiguous)
+        step_q = [(u, m) for u in range(U) for m in members[u] if m.kind == "step"]
+        step_out = None
+        if step_q:
+            row_of = torch.tensor([step_row[u] for u, _ in step_q], dtype=torch.int32, device=dev)
+            mask_id = torch.tensor([m.mask_id for _, m in step_q], dtype=torch.int32, device=dev)
+            kw = {}
+            if self._mask_kind != MASK_NONE:
+                kw = dict(mask_kind=self._mask_kind, mask=self._masks, mask_id=mask_id)
+            if self._rng_mode == RNG_NOISE:
+                noise = self._host_rng.exponential(len(step_q) * V).view(len(step_q), V).to(dev, non_blocking=True)
+                kw["noise"] = noise
+            logZ, _lse, tok = eng.step(logits, vocab=V, row_of=row_of, rng_mode=self._rng_mode, seed=self._rng_seed,
+                                       offset=self._batch_counter, want_lse=False, **kw)
+            step_out = (logZ.cpu().tolist(), tok.cpu().tolist())
+        self._batch_counter += 1
+        self.stats["batches"] += 1
+        self.stats["queries"] += n
+        self.stats["unique"] += U
+        self.stats["rows"] += R
+
+        # -- fan out (hf.py:285-288 order)
+        si = 0
+        for u in range(U):
+            rows = None
+            if u in lp_rows:
+                r0, first = lp_rows[u]
+                cnt = len(uniq[u].prompt) - first
+                if slab_row is None:
+                    rows = (lp_slab[r0:r0 + cnt], first)
+                else:
+                    s0 = slab_row[r0]
+                    rows = (lp_slab[s0:s0 + cnt], first)
+            for m in members[u]:
+                if m.kind == "step":
+                    res = (step_out[0][si], step_out[1][si])
+                    si += 1
+                else:
+                    res = rows
+                if m.future is not None and not m.future.done():
+                    m.future.set_result(res)
+
+    # ---- queueing (hf.py:290-312) -----------------------------------------------------------------------
+    @torch.no_grad()
+    def add_query(self, query, future, past, first_new=0, kind="logprobs", mask_id=0):
+        self.queries.append(Query(query, future, past, first_new=first_new, kind=kind, mask_id=mask_id))
+        if self.timer:
+            self.timer.cancel()
+            self.timer = None
+        if len(self.queries) >= self.batch_size:
+            self.batch_evaluate_queries()
+        else:
+            self.timer = asyncio.get_running_loop().call_later(self.timeout, lambda: self.batch_evaluate_queries())
+
+    def walk_cache(self, token_ids):
+        """hf.py:314-344: deepest matching node, tokens matched, deepest KV on the way and its depth."""
+        node = self.cache
+        next_token_index = 0
+        past = None
+        base = 0
+        while next_token_index < len(token_ids):
+            if node.past_key_values is not None:
+                past = node.past_key_values
+                base = next_token_index
+            if node.has_token(token_ids[next_token_index]):
+                node = node.get_token(token_ids[next_token_index])
+                next_token_index += 1
+            else:
+                break
+        return node, next_token_index, past, base
+
+    @torch.no_grad()
+    async def next_token_logprobs(self, token_ids):
+        """hf.py:346-373.  Returns a float32 [V] tensor on the model's device."""
+        if not token_ids:
+            raise ValueError("Token ids must not be empty")
+        node, next_token_index, past, base = self.walk_cache(token_ids)
+        if next_token_index == len(token_ids):
+            return node.logprobs
+        future = asyncio.get_running_loop().create_future()
+        self.add_query(token_ids[base:], future, past, first_new=next_token_index - base)
+        rows, first = await future
+        node = node.extend_cache_rows(next_token_index, token_ids, rows[next_token_index - base - first:],
+                                      next_token_index)
+        return node.logprobs
+
+    def _evaluate_one(self, prompt, past, first_new):
+        """Synchronous single-query evaluation through the same batched machinery."""
+
+        class _Slot:
+            def __init__(self):
+                self.value = None
+                self.exc = None
+
+            def done(self):
+                return self.value is not None or self.exc is not None
+
+            def set_result(self, v):
+                self.value = v
+
+            def set_exception(self, e):
+                self.exc = e
+
+        slot = _Slot()
+        self._evaluate([Query(prompt, slot, past, first_new=first_new)])
+        return slot.value
+
+    @torch.no_grad()
+    def next_token_logprobs_sync(self, token_ids):
+        """hf.py:375-402 (uses the walked KV prefix; the reference passes the matched node's, hf.py:396)."""
+        if not token_ids:
+            raise ValueError("Token ids must not be empty")
+        node, next_token_index, past, base = self.walk_cache(token_ids)
+        if next_token_index == len(token_ids):
+            return node.logprobs
+        rows, first = self._evaluate_one(token_ids[base:], past, next_token_index - base)
+        node = node.extend_cache_rows(next_token_index, token_ids, rows, next_token_index)
+        return node.logprobs
+
+    @torch.no_grad()
+    def next_token_logprobs_uncached(self, token_ids):
+        """hf.py:404-422: no KV, no output cache, no batching."""
+        if not token_ids:
+            raise ValueError("Token ids must not be empty")
+        ids = torch.tensor([token_ids], device=self.device)
+        h = self._body(input_ids=ids, use_cache=False).last_hidden_state[0, -1:]
+        return self.engine.log_softmax_rows(self._lm_head(h))[0]
+
+    # ---- fused particle step (README.md:82-91 moved behind the queue) ------------------------------------
+    @torch.no_grad()
+    async def next_token_step(self, token_ids, mask_id=0):
+        """Returns (logZ, token): logZ = logsumexp(next_token_logprobs + mask[mask_id]) and a categorical
+        draw from the masked, renormalised distribution; token is -1 if the mask forbids everything."""
+        if not token_ids:
+            raise ValueError("Token ids must not be empty")
+        _node, _n, past, base = self.walk_cache(token_ids)
+        future = asyncio.get_running_loop().create_future()
+        self.add_query(token_ids[base:], future, past, kind="step", mask_id=mask_id)
+        return await future
+
+    # ---- sampling (base.py:110-146) -------------------------------------------------------------------------
+    def _make_generator(self, seed):
+        if seed is None:
+            return None
+        from .engine import HostRng
+
+        return HostRng(seed)
+
+    def _draw(self, logprobs, temperature, generator_state):
+        """softmax(logprobs / T) -> one draw, on the device.  With a seed the draw reproduces
+        torch.multinomial(probs.cpu(), 1, generator=torch.Generator().manual_seed(seed)) (base.py:136-141);
+        without one it uses the in-kernel Philox stream keyed from torch's global generator."""
+        x = (logprobs / temperature).reshape(1, -1).contiguous()
+        if generator_state is not None:
+            noise = generator_state.exponential(x.shape[1]).view(1, -1).to(self.device)
+            _, _, tok = self.engine.step(x, rng_mode=RNG_NOISE, noise=noise, want_lse=False)
+        else:
+            seed = int(torch.randint(0, 2**62, (1,)).item())
+            _, _, tok = self.engine.step(x, rng_mode=RNG_PHILOX, seed=seed, want_lse=False)
+        return int(tok.item())
+
+
+def load_model_by_name(name, backend=None, llm_opts=None):
+    """llm/__init__.py:10-43.  `backend` may be None / "amd" / "hf" (all served by AsyncAmdLM on the
+    MI355X); the CUDA / Apple engines of the reference ("vllm", "sgl", "mlx") do not exist here."""
+    if llm_opts is None:
+        llm_opts = {}
+    if backend in (None, "amd", "hf"):
+        return AsyncAmdLM.from_name(name, **llm_opts)
+    if backend in ("vllm", "sgl", "mlx", "mock"):
+        raise ValueError(f"Backend {backend!r} is not part of the MI355X hot-path build")
+    raise ValueError(f"Invalid backend: {backend}")

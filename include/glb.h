@@ -130,46 +130,49 @@ int glb_mask_f32_to_bits(const float *mask, int64_t n_masks, int64_t vocab, int6
                          void *hip_stream);
 
 /*
+ * Ragged contexts are passed as (tokens, starts, lengths): context i is
+ * tokens[starts[i] .. starts[i] + lengths[i]), int32 token ids, int64 starts, int32 lengths, all on
+ * the device.  This covers both a CSR buffer and the rows of a padded [n, cap] particle matrix.
+ *
  * Context grouping: exact dedup of ragged token contexts, first-appearance order.  Replaces the
  * dict keyed by tuple(prompt) of batch_evaluate_queries (hf.py:214-220).
- *   tokens  [offsets[n]] int32 device, offsets [n+1] int64 device
  *   out_group_of [n]   group id of every context (ids numbered by first appearance)
  *   out_rep      [n]   out_rep[g] = smallest context index in group g (only [0, n_groups) valid)
  *   out_n_groups [1]   device int32
  * workspace: device scratch of at least glb_group_contexts_workspace(n) bytes.
  */
 size_t glb_group_contexts_workspace(int64_t n);
-int glb_group_contexts(const int32_t *tokens, const int64_t *offsets, int64_t n,
-                       int32_t *out_group_of, int32_t *out_rep, int32_t *out_n_groups,
+int glb_group_contexts(const int32_t *tokens, const int64_t *starts, const int32_t *lengths,
+                       int64_t n, int32_t *out_group_of, int32_t *out_rep, int32_t *out_n_groups,
                        void *workspace, size_t workspace_bytes, void *hip_stream);
 
 /*
  * Cached-prefix match ("trie grouping"): for every context pick the longest cached prefix that
  * is a proper prefix of it — the deepest KV-bearing trie node walk_cache returns (hf.py:314-344).
- *   prefix_tokens [prefix_offsets[n_prefixes]] int32, prefix_offsets [n_prefixes+1] int64
+ *   cached prefixes in the same (tokens, starts, lengths) form
  *   out_prefix [n] int32 index of the chosen cached prefix or -1; out_base [n] int32 its length
  *   (0 when none).  Ties on length resolve to the lowest prefix index.
  */
-int glb_match_prefixes(const int32_t *tokens, const int64_t *offsets, int64_t n,
-                       const int32_t *prefix_tokens, const int64_t *prefix_offsets,
-                       int64_t n_prefixes, int32_t *out_prefix, int32_t *out_base,
-                       void *hip_stream);
+int glb_match_prefixes(const int32_t *tokens, const int64_t *starts, const int32_t *lengths,
+                       int64_t n, const int32_t *prefix_tokens, const int64_t *prefix_starts,
+                       const int32_t *prefix_lengths, int64_t n_prefixes, int32_t *out_prefix,
+                       int32_t *out_base, void *hip_stream);
 
 /*
  * Ragged -> padded gather for the batched prefill.  Replaces Query.prompt_padded /
  * attention_mask / position_ids and the three torch.tensor(...) builds of hf.py:55-70,232-246.
  * For each selected context s = sel[u] (u < n_sel; sel nullable ⇒ identity) with cached-prefix
  * length base[s] (nullable ⇒ 0):
- *   input_ids[u, t]      = tokens[offsets[s] + base + t]        t <  len          else pad_id
+ *   input_ids[u, t]      = tokens[starts[s] + base + t]         t <  len          else pad_id
  *   position_ids[u, t]   = base + t                             t <  len          else 0
  *   attention_mask[u, p] = 1 for p < base; 0 for base <= p < p_max;
  *                          1 for p_max <= p < p_max + len; 0 afterwards           (hf.py:58-64)
  *   last_index[u]        = len - 1        (row of the next-token logits, optional output)
- * with len = offsets[s+1] - offsets[s] - base.  Outputs are int64 [n_sel, l_max] /
+ * with len = lengths[s] - base.  Outputs are int64 [n_sel, l_max] /
  * [n_sel, p_max + l_max], matching what transformers expects.
  */
-int glb_gather_padded(const int32_t *tokens, const int64_t *offsets, const int32_t *sel,
-                      int64_t n_sel, const int32_t *base, int64_t pad_id, int64_t p_max,
+int glb_gather_padded(const int32_t *tokens, const int64_t *starts, const int32_t *lengths,
+                      const int32_t *sel, int64_t n_sel, const int32_t *base, int64_t pad_id, int64_t p_max,
                       int64_t l_max, int64_t *out_input_ids, int64_t *out_attention_mask,
                       int64_t *out_position_ids, int32_t *out_last_index, void *hip_stream);
 

@@ -433,16 +433,16 @@ int orc_ref_log_softmax(const float *x, int64_t V, float *out) {
 }
 
 /* hf.py:214-220 — dedup by tuple(prompt), groups numbered in first-appearance order (dict order) */
-int orc_group_contexts(const int32_t *tokens, const int64_t *offsets, int64_t n,
-                       int32_t *out_group_of, int32_t *out_rep, int32_t *out_n_groups) {
+int orc_group_contexts(const int32_t *tokens, const int64_t *starts, const int32_t *lengths,
+                       int64_t n, int32_t *out_group_of, int32_t *out_rep, int32_t *out_n_groups) {
   int32_t ng = 0;
   for (int64_t i = 0; i < n; ++i) {
-    int64_t li = offsets[i + 1] - offsets[i];
+    int64_t li = lengths[i];
     int32_t g = -1;
     for (int32_t k = 0; k < ng; ++k) {
       int64_t r = out_rep[k];
-      if (offsets[r + 1] - offsets[r] == li &&
-          memcmp(tokens + offsets[r], tokens + offsets[i], (size_t)li * 4) == 0) {
+      if (lengths[r] == li &&
+          memcmp(tokens + starts[r], tokens + starts[i], (size_t)li * 4) == 0) {
         g = k;
         break;
       }
@@ -460,17 +460,17 @@ int orc_group_contexts(const int32_t *tokens, const int64_t *offsets, int64_t n,
 /* hf.py:314-344 walk_cache, restricted to what batching needs: deepest KV-bearing prefix that is
  * a proper prefix of the context (KV is looked up *before* consuming the token at that depth,
  * so a prefix as long as the whole context never qualifies). */
-int orc_match_prefixes(const int32_t *tokens, const int64_t *offsets, int64_t n,
-                       const int32_t *ptok, const int64_t *poff, int64_t np, int32_t *out_prefix,
-                       int32_t *out_base) {
+int orc_match_prefixes(const int32_t *tokens, const int64_t *starts, const int32_t *lengths,
+                       int64_t n, const int32_t *ptok, const int64_t *pst, const int32_t *plen,
+                       int64_t np, int32_t *out_prefix, int32_t *out_base) {
   for (int64_t i = 0; i < n; ++i) {
-    int64_t li = offsets[i + 1] - offsets[i];
+    int64_t li = lengths[i];
     int32_t best = -1;
     int64_t bl = 0;
     for (int64_t k = 0; k < np; ++k) {
-      int64_t lk = poff[k + 1] - poff[k];
+      int64_t lk = plen[k];
       if (lk >= li || lk <= bl) continue;
-      if (lk > 0 && memcmp(ptok + poff[k], tokens + offsets[i], (size_t)lk * 4) == 0) {
+      if (lk > 0 && memcmp(ptok + pst[k], tokens + starts[i], (size_t)lk * 4) == 0) {
         best = (int32_t)k;
         bl = lk;
       }
@@ -482,16 +482,16 @@ int orc_match_prefixes(const int32_t *tokens, const int64_t *offsets, int64_t n,
 }
 
 /* hf.py:55-70,232-246 — Query.prompt_padded / attention_mask / position_ids for a batch */
-int orc_gather_padded(const int32_t *tokens, const int64_t *offsets, const int32_t *sel,
-                      int64_t n_sel, const int32_t *base, int64_t pad_id, int64_t p_max,
+int orc_gather_padded(const int32_t *tokens, const int64_t *starts, const int32_t *lengths,
+                      const int32_t *sel, int64_t n_sel, const int32_t *base, int64_t pad_id, int64_t p_max,
                       int64_t l_max, int64_t *ids, int64_t *am, int64_t *pos, int32_t *last) {
   for (int64_t u = 0; u < n_sel; ++u) {
     int64_t s = sel ? sel[u] : u;
     int64_t b = base ? base[s] : 0;
-    int64_t len = offsets[s + 1] - offsets[s] - b;
+    int64_t len = (int64_t)lengths[s] - b;
     if (len < 0 || len > l_max || b > p_max) return 1;
     for (int64_t t = 0; t < l_max; ++t) {
-      ids[u * l_max + t] = t < len ? tokens[offsets[s] + b + t] : pad_id;
+      ids[u * l_max + t] = t < len ? tokens[starts[s] + b + t] : pad_id;
       pos[u * l_max + t] = t < len ? b + t : 0;
     }
     for (int64_t p = 0; p < p_max + l_max; ++p) {

@@ -165,39 +165,41 @@ def ref_log_softmax(x):
     return out
 
 
-def _ragged(contexts):
-    off = np.zeros(len(contexts) + 1, np.int64)
+def ragged(contexts):
+    """list of token lists -> (tokens int32, starts int64, lengths int32)"""
+    lens = np.array([len(c) for c in contexts], np.int32)
+    starts = np.zeros(len(contexts), np.int64)
+    if len(contexts) > 1:
+        starts[1:] = np.cumsum(lens[:-1])
+    tok = np.zeros(max(int(lens.sum()), 1), np.int32)
     for i, c in enumerate(contexts):
-        off[i + 1] = off[i] + len(c)
-    tok = np.zeros(max(int(off[-1]), 1), np.int32)
-    for i, c in enumerate(contexts):
-        tok[off[i]:off[i + 1]] = c
-    return tok, off
+        tok[starts[i]:starts[i] + lens[i]] = c
+    return tok, starts, lens
 
 
 def group_contexts(contexts):
-    tok, off = _ragged(contexts)
+    tok, st, ln = ragged(contexts)
     n = len(contexts)
     g = np.empty(n, np.int32)
     rep = np.empty(max(n, 1), np.int32)
     ng = C.c_int32()
-    lib().orc_group_contexts(_p(tok), _p(off), C.c_int64(n), _p(g), _p(rep), C.byref(ng))
+    lib().orc_group_contexts(_p(tok), _p(st), _p(ln), C.c_int64(n), _p(g), _p(rep), C.byref(ng))
     return g, rep[:ng.value].copy(), ng.value
 
 
 def match_prefixes(contexts, prefixes):
-    tok, off = _ragged(contexts)
-    ptok, poff = _ragged(prefixes)
+    tok, st, ln = ragged(contexts)
+    ptok, pst, pln = ragged(prefixes)
     n = len(contexts)
     pref = np.empty(n, np.int32)
     base = np.empty(n, np.int32)
-    lib().orc_match_prefixes(_p(tok), _p(off), C.c_int64(n), _p(ptok), _p(poff),
+    lib().orc_match_prefixes(_p(tok), _p(st), _p(ln), C.c_int64(n), _p(ptok), _p(pst), _p(pln),
                              C.c_int64(len(prefixes)), _p(pref), _p(base))
     return pref, base
 
 
 def gather_padded(contexts, sel, base, pad_id, p_max, l_max):
-    tok, off = _ragged(contexts)
+    tok, st, ln = ragged(contexts)
     sel_a = None if sel is None else np.ascontiguousarray(sel, dtype=np.int32)
     base_a = None if base is None else np.ascontiguousarray(base, dtype=np.int32)
     n_sel = len(contexts) if sel is None else len(sel)
@@ -205,7 +207,7 @@ def gather_padded(contexts, sel, base, pad_id, p_max, l_max):
     am = np.empty((n_sel, p_max + l_max), np.int64)
     pos = np.empty((n_sel, l_max), np.int64)
     last = np.empty(n_sel, np.int32)
-    rc = lib().orc_gather_padded(_p(tok), _p(off), _p(sel_a), C.c_int64(n_sel), _p(base_a),
+    rc = lib().orc_gather_padded(_p(tok), _p(st), _p(ln), _p(sel_a), C.c_int64(n_sel), _p(base_a),
                                  C.c_int64(pad_id), C.c_int64(p_max), C.c_int64(l_max), _p(ids),
                                  _p(am), _p(pos), _p(last))
     if rc:

@@ -1,0 +1,115 @@
+"""Test double for `HipEngine` built on the CPU oracle, so the host logic (queueing, dedup order,
+trie, sharding) is testable without a GPU.  TEST INFRASTRUCTURE: lives under tests/, is never
+imported by the product package."""
+import numpy as np
+import torch
+
+from oracle import oracle as O
+
+
+def _np(t):
+    return None if t is None else t.detach().cpu().contiguous().numpy()
+
+
+def _logits_np(t):
+    if t.dtype == torch.bfloat16:
+        return t.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+    return t.detach().cpu().contiguous().numpy()
+
+
+class CpuOracleEngine:
+    device = torch.device("cpu")
+
+    def step(self, logits, vocab=None, row_of=None, mask_kind=0, mask=None, mask_id=None, rng_mode=0, noise=None,
+             seed=0, offset=0, particle_base=0, logit_scale=1.0, want_lse=True, variant=0, out=None):
+        V = logits.shape[1] if vocab is None else vocab
+        x = _logits_np(logits[:, :V])
+        m = _np(mask)
+        if mask_kind == 1:
+            m = m.view(np.uint32)
+        logZ, lse, tok = O.step(x, row_of=_np(row_of), mask_kind=mask_kind, mask=m, mask_id=_np(mask_id),
+                                rng_mode=rng_mode, noise=_np(noise), seed=seed, offset=offset,
+                                particle_base=particle_base, logit_scale=logit_scale)
+        res = (torch.from_numpy(logZ), torch.from_numpy(lse) if want_lse else None,
+               torch.from_numpy(tok) if rng_mode else None)
+        if out is not None:
+            for o, r in zip(out, res):
+                if o is not None and r is not None:
+                    o.copy_(r)
+            return out
+        return res
+
+    def log_softmax_rows(self, logits, vocab=None, logit_scale=1.0, out=None, want_lse=False):
+        V = logits.shape[1] if vocab is None else vocab
+        lp, lse = O.log_softmax_rows(_logits_np(logits[:, :V]), logit_scale)
+        lp = torch.from_numpy(lp)
+        if out is not None:
+            out.copy_(lp)
+            lp = out
+        return (lp, torch.from_numpy(lse)) if want_lse else lp
+
+    def mask_to_bits(self, mask):
+        if mask.dim() == 1:
+            mask = mask[None]
+        bits, nb = O.mask_f32_to_bits(_np(mask.to(torch.float32)))
+        return torch.from_numpy(bits.view(np.int32)), torch.tensor([int(nb)], dtype=torch.int32)
+
+    @staticmethod
+    def _ctxs(tokens, starts, lengths):
+        t, s, l = _np(tokens), _np(starts), _np(lengths)
+        return [list(t[s[i]:s[i] + l[i]]) for i in range(len(l))]
+
+    def group_contexts(self, tokens, starts, lengths):
+        g, rep, ng = O.group_contexts(self._ctxs(tokens, starts, lengths))
+        rep_full = np.zeros(len(g), np.int32)
+        rep_full[:ng] = rep
+        return torch.from_numpy(g), torch.from_numpy(rep_full), torch.tensor([ng], dtype=torch.int32)
+
+    def match_prefixes(self, tokens, starts, lengths, ptok, pst, pln):
+        pre = [] if pln is None else self._ctxs(ptok, pst, pln)
+        p, b = O.match_prefixes(self._ctxs(tokens, starts, lengths), pre)
+        return torch.from_numpy(p), torch.from_numpy(b)
+
+    def gather_padded(self, tokens, starts, lengths, sel, n_sel, base, pad_id, p_max, l_max):
+        t, s, l = _np(tokens), _np(starts), _np(lengths)
+        b = _np(base)
+        sel_np = np.arange(n_sel) if sel is None else _np(sel)[:n_sel]
+        ids = np.full((n_sel, l_max), pad_id, np.int64)
+        am = np.zeros((n_sel, p_max + l_max), np.int64)
+        pos = np.zeros((n_sel, l_max), np.int64)
+        last = np.zeros(n_sel, np.int32)
+        for u, c in enumerate(sel_np):
+            bb = 0 if b is None else int(b[c])
+            ln = int(l[c]) - bb
+            ids[u, :ln] = t[s[c] + bb:s[c] + bb + ln]
+            pos[u, :ln] = np.arange(bb, bb + ln)
+            am[u, :bb] = 1
+            am[u, p_max:p_max + ln] = 1
+            last[u] = ln - 1
+        return torch.from_numpy(ids), torch.from_numpy(am), torch.from_numpy(pos), torch.from_numpy(last)
+
+    def gather_kv_padded(self, slab_ptrs, slab_len, prefix_of, heads, head_dim, p_max, dtype):
+        import ctypes as C
+
+        ptrs = [int(p) for p in slab_ptrs.tolist()]
+        arr = (C.c_void_p * len(ptrs))(*ptrs)
+        n_rows = prefix_of.numel()
+        out = torch.empty((n_rows, heads, p_max, head_dim), dtype=dtype)
+        sl, po = _np(slab_len), _np(prefix_of)
+        O.lib().orc_gather_kv_padded(arr, sl.ctypes.data_as(C.c_void_p), C.c_int64(len(ptrs)),
+                                     po.ctypes.data_as(C.c_void_p), C.c_int64(n_rows), C.c_int64(heads),
+                                     C.c_int64(head_dim), C.c_int64(p_max), C.c_int32(out.element_size()),
+                                     C.c_void_p(out.data_ptr()))
+        return out
+
+    def particles_advance(self, contexts, lengths, active, log_weights, logZ, token, eos_id, max_len):
+        c, l, a, w = _np(contexts), _np(lengths), _np(active), _np(log_weights)
+        O.particles_advance(c, l, a, w, _np(logZ), _np(token), eos_id, max_len)
+        contexts.copy_(torch.from_numpy(c))
+        lengths.copy_(torch.from_numpy(l))
+        active.copy_(torch.from_numpy(a))
+        log_weights.copy_(torch.from_numpy(w))
+
+    def normalize_weights(self, log_weights):
+        p, s = O.normalize_weights(_np(log_weights))
+        return torch.from_numpy(p), torch.from_numpy(s)
