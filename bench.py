@@ -43,32 +43,56 @@ def algorithmic_bytes(B, V, elem_size, n_masks, mask_words):
     return B * V * elem_size + n_masks * mask_words * 4 + B * 8
 
 
-def cpu_baseline(sample_rows, repeats, seed=1234):
-    """Reference-semantics particle step on the host (oracle layer A: cache.py:96 log_softmax,
-    README.md:84-87 mask + logsumexp + exp + multinomial incl. the serial MT19937 draws)."""
+def cpu_baseline(workload, sample_rows, seed=1234):
+    """The same work on this host's cores, in the reference's arithmetic (oracle layer A = port of
+    cache.py:96 log_softmax and README.md:84-87 mask + logsumexp + exp + multinomial incl. its serial
+    MT19937 draws; for "sis" preceded by the torch-CPU forward hf.py:275-281 runs, full-vocabulary logits
+    for every position as the reference computes them).  Bounded sample, scaled to particles/s."""
     from oracle import oracle as O
     from tests import synth
 
     O.build()
-    x = synth.logits(seed, sample_rows, V_GPT2)
     masks = synth.binary_masks(seed, 2, V_GPT2)
+    threads = 1
+    t_fwd = 0.0
+    if workload == "sis":
+        from transformers import GPT2Config, GPT2LMHeadModel
+
+        rows = min(sample_rows, 64)
+        torch.manual_seed(seed)
+        model = GPT2LMHeadModel(GPT2Config()).eval()
+        ids = torch.randint(0, V_GPT2, (rows, 13))  # mid-loop context length: prompt 8 + 5 generated
+        threads = torch.get_num_threads()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            logits = model(ids).logits  # [rows, 13, V], all positions (hf.py:275-281)
+        t_fwd = time.perf_counter() - t0
+        x = logits[:, -1].contiguous().numpy()
+        repeats = 1
+    else:
+        rows = sample_rows
+        x = synth.logits(seed, rows, V_GPT2)
+        repeats = 8
     t0 = time.perf_counter()
-    done = 0
     st = None
+    done = 0
     for _ in range(repeats):
-        for r in range(sample_rows):
+        for r in range(rows):
             lp = O.ref_log_softmax(x[r])
             E, st = O.mt_exponential(seed, V_GPT2, st)
             O.ref_particle(lp, masks[r % 2], E)
             done += 1
-    dt = time.perf_counter() - t0
+    t_part = time.perf_counter() - t0
+    dt = t_fwd * repeats + t_part
+    what = (f"torch-CPU gpt2-small forward [{rows}x13 tokens, all-position logits] {t_fwd:.1f} s on {threads} threads + "
+            if workload == "sis" else "")
     return {
         "value": done / dt,
         "unit": "particles/s",
-        "cores": 1,
+        "cores": threads,
         "kind": "port",
-        "sample": f"{done} particle steps (V={V_GPT2}, fp32, shared mask, MT19937 multinomial) in {dt:.1f} s, "
-                  f"single thread; host has {os.cpu_count()} cores",
+        "sample": f"{done} particle steps: {what}per-particle log_softmax + mask + logsumexp + MT19937 multinomial "
+                  f"(V={V_GPT2}, fp32) {t_part:.1f} s single-threaded; host has {os.cpu_count()} cores",
     }
 
 
@@ -169,7 +193,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, 1)
+            out["cpu_baseline"] = cpu_baseline(workload, args.cpu_sample)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
