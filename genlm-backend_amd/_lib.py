@@ -47,6 +47,8 @@ class StepArgs(C.Structure):
         ("out_lse", C.c_void_p),
         ("out_token", C.c_void_p),
         ("variant", C.c_int32),
+        ("workspace", C.c_void_p),
+        ("workspace_bytes", C.c_size_t),
     ]
 
 
@@ -61,6 +63,7 @@ SYMBOLS = {
     "glb_abi_version": (C.c_int, []),
     "glb_last_error": (C.c_int, [C.c_char_p, _sz]),
     "glb_device_count": (C.c_int, []),
+    "glb_step_workspace_bytes": (_sz, [_i64]),
     "glb_logprob_mask_sample": (C.c_int, [C.POINTER(StepArgs), _vp]),
     "glb_log_softmax_rows": (C.c_int, [_vp, _i32, _i64, _i64, _i64, _f32, _vp, _i64, _vp, _vp]),
     "glb_mask_f32_to_bits": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp]),

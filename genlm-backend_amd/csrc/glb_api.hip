@@ -58,6 +58,34 @@ int pick_geom(int64_t vocab, int dtype, int variant) {
   return 0;
 }
 
+// persistent-kernel geometries (glb_row_tu.hip): id, NVL at 512 threads; capacity = 512 * NVL vectors
+struct Geom2 { int id, nvl; bool f32; };
+const Geom2 kGeoms2[] = {{22, 16, true}, {21, 25, true}, {22, 16, false}, {23, 32, false}};
+
+int pick_geom2(int64_t vocab, int dtype, int variant) {
+  const int epv = dtype == GLB_F32 ? 4 : 8;
+  const int64_t nv_max = (vocab + (epv - 1) + epv - 1) / epv;
+  for (const Geom2 &g : kGeoms2) {
+    if (g.f32 != (dtype == GLB_F32)) continue;
+    if (variant > 0 && g.id != variant) continue;
+    if ((int64_t)512 * g.nvl >= nv_max) return g.id;
+  }
+  return 0;
+}
+
+int num_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      cus = v;
+    else
+      cus = 256;
+  }
+  return cus;
+}
+
 hipError_t dispatch_row(int dtype, int mode, const glb::RowParams &p, int mask_kind, int geom,
                         hipStream_t s) {
   using namespace glb;
@@ -372,6 +400,11 @@ int glb_device_count(void) {
   return c;
 }
 
+size_t glb_step_workspace_bytes(int64_t n_particles) {
+  if (n_particles <= 0) return 0;
+  return (size_t)n_particles * (64 * sizeof(uint64_t) + sizeof(float)) + 16;
+}
+
 int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
   if (!a) return fail(GLB_EINVAL, "glb_logprob_mask_sample: null args");
   if (a->struct_size != sizeof(glb_step_args))
@@ -407,11 +440,30 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
     return fail(GLB_EINVAL, "rng_mode set but out_token is null");
   if (!(a->logit_scale == a->logit_scale)) return fail(GLB_EINVAL, "logit_scale is NaN");
 
-  const int geom = pick_geom(a->vocab, a->dtype, a->variant);
-  if (geom < 0) return fail(GLB_EINVAL, "variant %d cannot hold vocab %lld", a->variant, (long long)a->vocab);
-  if (geom == 0)
-    return fail(GLB_EUNSUPPORTED, "vocab %lld too large for the register-resident row kernel",
-                (long long)a->vocab);
+  // persistent pipelined kernel when the caller lent a workspace and the mode allows it
+  int geom = 0;
+  const bool v2_ok = a->workspace && a->mask_kind != GLB_MASK_F32 && a->rng_mode != GLB_RNG_NOISE &&
+                     (a->variant == 0 || a->variant >= 21);
+  if (v2_ok) {
+    if (a->workspace_bytes < glb_step_workspace_bytes(a->n_particles))
+      return fail(GLB_ENOSPC, "workspace %zu < %zu bytes", a->workspace_bytes,
+                  glb_step_workspace_bytes(a->n_particles));
+    if (((uintptr_t)a->workspace) % 16) return fail(GLB_EINVAL, "workspace not 16-byte aligned");
+    const int g2 = pick_geom2(a->vocab, a->dtype, a->variant);
+    if (g2) {
+      const int64_t grid = a->n_particles < num_cus() ? a->n_particles : num_cus();
+      geom = g2 | ((int)grid << 8);
+    }
+  }
+  if (a->variant >= 21 && geom == 0)
+    return fail(GLB_EINVAL, "variant %d needs a workspace, mask none/bits and rng none/philox", a->variant);
+  if (geom == 0) {
+    geom = pick_geom(a->vocab, a->dtype, a->variant);
+    if (geom < 0) return fail(GLB_EINVAL, "variant %d cannot hold vocab %lld", a->variant, (long long)a->vocab);
+    if (geom == 0)
+      return fail(GLB_EUNSUPPORTED, "vocab %lld too large for the register-resident row kernel",
+                  (long long)a->vocab);
+  }
 
   glb::RowParams p{};
   p.logits = a->logits;
@@ -435,6 +487,10 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
   p.out_token = a->out_token;
   p.out_logprobs = nullptr;
   p.out_ld = 0;
+  if (a->workspace) {
+    p.chunk_sums = (uint64_t *)a->workspace;
+    p.chunk_nmsk = (float *)((char *)a->workspace + (size_t)a->n_particles * 64 * sizeof(uint64_t));
+  }
   const hipError_t e = dispatch_row(a->dtype, a->rng_mode, p, a->mask_kind, geom, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "row_kernel launch");
   return GLB_OK;

@@ -50,6 +50,10 @@ struct RowParams {
   int32_t *out_token;
   float *out_logprobs;  // stats mode only: [n_particles, out_ld]
   int64_t out_ld;
+  // v2 + locate_kernel: per-particle chunk totals [n_particles, n_chunks] and masked exponent N_msk
+  uint64_t *chunk_sums;
+  float *chunk_nmsk;
+  int32_t n_chunks, chunk_vecs;
 };
 
 template <int DT>
@@ -104,6 +108,15 @@ __device__ __forceinline__ void opaque(uint4 &r) {
   asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w));
 }
 __device__ __forceinline__ void opaque(uint32_t &r) { asm volatile("" : "+v"(r)); }
+
+__device__ __forceinline__ void opaque(uint64_t &r) { asm volatile("" : "+v"(r)); }
+
+// q gated by an all-ones / all-zeros word, half by half (a 64-bit `q & splat(fill)` is turned into a
+// 64-bit multiply by 0x100000001 by instcombine)
+__device__ __forceinline__ uint64_t mask_u64(uint64_t q, uint32_t fill) {
+  const uint32_t lo = (uint32_t)q & fill, hi = (uint32_t)(q >> 32) & fill;
+  return ((uint64_t)hi << 32) | lo;
+}
 
 // all-ones / all-zeros word from bit `pos` of w (v_bfe_i32)
 __device__ __forceinline__ uint32_t bit_fill(uint32_t w, int pos) {
@@ -294,7 +307,7 @@ __global__ __launch_bounds__(T) void row_kernel(const RowParams p) {
           if constexpr (kPhilox) ak += q;
         } else if constexpr (MASK == kMaskBits) {
           const uint32_t fill = bit_fill(mb[(k * EPV + c) >> 5], (k * EPV + c) & 31);
-          ak += q & (((uint64_t)fill << 32) | fill);
+          ak += mask_u64(q, fill);
           if constexpr (kNoise) yv = __uint_as_float((__float_as_uint(xv) & fill) | (0xff800000u & ~fill));
         } else {
           int j = ((int)v0b + k * 64) * EPV - a + c;

@@ -1,0 +1,463 @@
+// glb_row_kernel_v2.hpp — persistent, software-pipelined variant of the fused particle-step kernel.
+//
+// v1 (glb_row_kernel.hpp) runs one 1024-thread workgroup per particle with the row in VGPRs; only
+// one such workgroup fits a CU, so a row's HBM load never overlaps another row's arithmetic and the
+// kernel stops at ~27 % of the HBM roofline.  v2 keeps ONE workgroup per CU for the whole launch and
+// streams rows through it: while row i is reduced from registers, row i+1 is already in flight —
+// NL of its NVL vectors per lane by LDS-DMA (`global_load_lds_dwordx4`: no VGPRs, each wave fills its
+// own 1 KiB-per-instruction slots and later reads back only what it wrote, so no barrier guards the
+// staging area), ND by ordinary loads into spare registers, the mask bit row by LDS-DMA too.
+//
+// What had to change for that (gfx950 / ROCm 7.2, see cdna_hip_programming.md §5 "Pipelining across
+// barriers"): no `__syncthreads()` (its fence drains vmcnt), no use of an ordinary load's result and
+// no compiler-visible LDS read while a DMA is in flight.  Barriers are raw `s_barrier`, the
+// cross-wave scratch is accessed with inline-asm `ds_*`, the one `s_waitcnt vmcnt(0)` per row is
+// explicit, and the inverse-CDF draw is finished by a second, tiny kernel (locate_kernel) from per-chunk
+// wave totals this kernel leaves in a workspace: it re-reads one 4-5 KiB chunk of one row per particle.
+//
+// Arithmetic is GLB math exactly as in v1: results are bit-identical to v1 and to the oracle.
+#pragma once
+#include "glb_row_kernel.hpp"
+
+namespace glb {
+
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
+__device__ __forceinline__ void lds_write_b32(uint32_t addr, uint32_t v) {
+  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_write_b64(uint32_t addr, uint64_t v) {
+  asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_read_b32_wait(uint32_t addr) {
+  uint32_t v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+__device__ __forceinline__ uint64_t lds_read_b64_wait(uint32_t addr) {
+  uint64_t v;
+  asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+// all LDS writes of this wave done, then workgroup barrier — never touches vmcnt
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
+// max over the first 16 lanes of each row of 16 (DPP), result broadcast from lane 15
+__device__ __forceinline__ float row16_max_bcast(float v) {
+  v = dpp_max_step<0x111, 0xf>(v);
+  v = dpp_max_step<0x112, 0xf>(v);
+  v = dpp_max_step<0x114, 0xf>(v);
+  v = dpp_max_step<0x118, 0xf>(v);
+  return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 15));
+}
+// inclusive prefix sum within each row of 16 lanes
+__device__ __forceinline__ uint64_t row16_scan_u64(uint64_t v) {
+  v += dpp_u64_or0<0x111, 0xf>(v);
+  v += dpp_u64_or0<0x112, 0xf>(v);
+  v += dpp_u64_or0<0x114, 0xf>(v);
+  v += dpp_u64_or0<0x118, 0xf>(v);
+  return v;
+}
+
+template <int DT, int MASK, int MODE, int NVL, int NL, int ND, int T>
+__global__ __launch_bounds__(T) void row_kernel_v2(const RowParams p) {
+  constexpr int W = T / 64;
+  static_assert(NVL <= 35 && W <= 16, "cross-wave scratch is reduced inside one DPP row of 16 lanes");
+  constexpr int EPV = ElemTraits<DT>::EPV;
+  constexpr int ES = ElemTraits<DT>::ES;
+  constexpr int NX = NVL - NL - ND;  // vectors loaded late (after the row is consumed), exposed
+  constexpr int MBW = (NVL * EPV + 31) / 32;
+  constexpr bool kPhilox = MODE == kModePhilox;
+  constexpr bool kBits = MASK == kMaskBits;
+  static_assert(NX >= 0 && MASK != kMaskF32 && MODE != kModeNoise, "v2 covers mask none/bits, stats/philox");
+  // one LDS object (a second one makes hipcc drain vmcnt before LDS reads): [stage | mask row | scratch]
+  constexpr int STAGE_V = NL * T;                                   // uint4 slots
+  constexpr int MASK_V = kBits ? (((NVL * T * EPV / 8 + 15) / 16 + 2) + 63) / 64 * 64 : 0;  // whole 1 KiB chunks
+  constexpr int GS = (NVL % 5 == 0) ? 5 : 4;                        // tiles per chunk of the draw's search
+  constexpr int NG = NVL / GS;                                      // chunks per wave
+  static_assert(NVL % GS == 0, "chunks must tile a wave's vectors exactly (locate_kernel indexes them linearly)");
+  constexpr int SCR_V = 24;                                         // 2x16 floats, 2x16 u64
+  __shared__ uint4 s_lds[STAGE_V + MASK_V + SCR_V];
+  uint4 *s_stage = s_lds;
+  const uint32_t *s_mask = reinterpret_cast<const uint32_t *>(s_lds + STAGE_V);
+  const uint32_t scr = lds_addr(s_lds + STAGE_V + MASK_V);  // byte address of the scratch area
+  const uint32_t scr_max = scr, scr_sum = scr + 128;  // [2][16] f32, [2][16] u64
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int V = p.V;
+  const int n = p.n_particles, G = gridDim.x;
+  const int v0 = wave * (64 * NVL) + lane;
+
+  // row bookkeeping for "virtual block" vb (same XCD-aware particle order as v1)
+  auto particle_of = [&](int vb) {
+    const int q = n >> 3, r = n & 7, xcd = vb & 7, i = vb >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+  };
+  struct RowRef {
+    const char *base;  // 16-byte aligned-down row start
+    int a, nv;         // leading pad elements, vectors covering the row
+    const uint32_t *mrow16;  // 16-byte aligned-down mask row
+    int am, mvec;            // leading pad words, 16-byte vectors covering the mask row
+    int pidx;
+  };
+  auto row_ref = [&](int vb) {
+    RowRef r;
+    r.pidx = particle_of(vb);
+    const int row = p.row_of ? p.row_of[r.pidx] : r.pidx;
+    const char *rowp = (const char *)p.logits + (int64_t)row * p.ld * ES;
+    r.a = (int)(((uintptr_t)rowp) & 15) / ES;
+    r.base = rowp - r.a * ES;
+    r.nv = (V + r.a + EPV - 1) / EPV;
+    r.mrow16 = nullptr;
+    r.am = 0;
+    r.mvec = 0;
+    if constexpr (kBits) {
+      const int mi = p.mask_id ? p.mask_id[r.pidx] : (p.n_masks == 1 ? 0 : r.pidx);
+      const char *mp = (const char *)p.mask + (int64_t)mi * p.mask_ld * 4;
+      r.am = (int)(((uintptr_t)mp) & 15) / 4;
+      r.mrow16 = (const uint32_t *)(mp - r.am * 4);
+      r.mvec = (((V + 31) >> 5) + r.am + 3) >> 2;
+    }
+    return r;
+  };
+
+  uint4 raw[NVL];
+  uint4 nxt[ND > 0 ? ND : 1];
+  uint32_t mb[MBW];
+
+  // issue the whole prefetch of a row: NL vectors per lane by LDS-DMA, ND into `nxt`, the mask row by DMA
+  auto prefetch = [&](const RowRef &r) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      int v = v0 + k * 64;
+      v = v < r.nv ? v : r.nv - 1;
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(r.base + (int64_t)v * 16),
+                                       (lds_ptr_t)(s_stage + (wave * NL + k) * 64), 16, 0, 0);
+    }
+    if constexpr (kBits) {
+      for (int m = wave; m * 64 < r.mvec; m += W) {  // chunk m = mask vectors [64m, 64m+64)
+        int mv = m * 64 + lane;
+        mv = mv < r.mvec ? mv : r.mvec - 1;
+        __builtin_amdgcn_global_load_lds(
+            (const void __attribute__((address_space(1))) *)((const char *)r.mrow16 + (int64_t)mv * 16),
+            (lds_ptr_t)(s_lds + STAGE_V + m * 64), 16, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < ND; ++k) {
+      int v = v0 + (NL + k) * 64;
+      v = v < r.nv ? v : r.nv - 1;
+      nxt[k] = *reinterpret_cast<const uint4 *>(r.base + (int64_t)v * 16);
+    }
+  };
+
+  // after the explicit vmcnt(0) (+ barrier for the mask row): staged data -> registers, late vectors,
+  // mask nibbles, invalidation of out-of-row elements
+  auto land = [&](const RowRef &r) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) raw[k] = s_stage[(wave * NL + k) * 64 + lane];
+#pragma unroll
+    for (int k = 0; k < ND; ++k) raw[NL + k] = nxt[k];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      int v = v0 + (NL + ND + k) * 64;
+      v = v < r.nv ? v : r.nv - 1;
+      raw[NL + ND + k] = *reinterpret_cast<const uint4 *>(r.base + (int64_t)v * 16);
+    }
+    // late vectors must have landed before the next prefetch is issued: hipcc would otherwise wait
+    // vmcnt(0) at their first use and drain the DMA with them
+    if constexpr (NX > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < MBW; ++i) mb[i] = kBits ? 0u : 0xffffffffu;
+    if constexpr (kBits) {
+      const int last_w = r.mvec * 4 - 1;  // last staged word
+#pragma unroll
+      for (int k = 0; k < NVL; ++k) {
+        const int j0 = (v0 + k * 64) * EPV - r.a;
+        const int jb = j0 < 0 ? 0 : j0;
+        const int d = jb - j0;
+        int wi = (jb >> 5) + r.am;
+        const int w0 = wi < last_w ? wi : last_w, w1 = wi + 1 < last_w ? wi + 1 : last_w;
+        const uint32_t f = __builtin_amdgcn_alignbit(s_mask[w1], s_mask[w0], (uint32_t)(jb & 31));
+        mb[(k * EPV) >> 5] |= ((f << d) & ((1u << EPV) - 1u)) << ((k * EPV) & 31);
+        if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the words in flight
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NVL; ++k) {
+      const int tile_lo = wave * (64 * NVL) + k * 64;
+      if ((tile_lo == 0 && r.a > 0) || tile_lo + 64 >= r.nv) {
+        const int j0 = (v0 + k * 64) * EPV - r.a;
+        uint32_t w[4] = {raw[k].x, raw[k].y, raw[k].z, raw[k].w};
+#pragma unroll
+        for (int c = 0; c < EPV; ++c) {
+          if ((uint32_t)(j0 + c) >= (uint32_t)V) {
+            if constexpr (DT == kDtF32) w[c] = 0xff800000u;
+            else if constexpr (DT == kDtBf16)
+              w[c >> 1] = (c & 1) ? ((w[c >> 1] & 0x0000ffffu) | 0xff800000u) : ((w[c >> 1] & 0xffff0000u) | 0x0000ff80u);
+            else
+              w[c >> 1] = (c & 1) ? ((w[c >> 1] & 0x0000ffffu) | 0xfc000000u) : ((w[c >> 1] & 0xffff0000u) | 0x0000fc00u);
+          }
+        }
+        raw[k] = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+    }
+  };
+
+  // ---- prologue: first row straight to registers (nothing to overlap with yet) ---------------------
+  int vb = blockIdx.x;
+  if (vb >= n) return;
+  RowRef cur = row_ref(vb);
+  prefetch(cur);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (kBits) lds_barrier();
+  land(cur);
+
+  for (;;) {
+    const int vb_next = vb + G;
+    const bool has_next = vb_next < n;
+    RowRef nxr = cur;
+    // every read of the staging area / mask row by this wave has returned before the DMA refills them;
+    // the mask row is shared, so all waves must be past `land`
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (kBits) __builtin_amdgcn_s_barrier();
+    if (has_next) {
+      nxr = row_ref(vb_next);
+      prefetch(nxr);
+    }
+
+    // ---- phase 1: maxima ----------------------------------------------------------------------
+    float m_all = kNegInf, m_msk = kNegInf;
+#pragma unroll
+    for (int k = 0; k < NVL; ++k) {
+      float xk[EPV];
+      unpack_vec<DT>(raw[k], xk);
+#pragma unroll
+      for (int c = 0; c < EPV; ++c) {
+        const float xv = p.use_scale ? xk[c] * p.scale : xk[c];
+        m_all = fmaxf(m_all, xv);
+        if constexpr (kBits) {
+          const uint32_t fill = bit_fill(mb[(k * EPV + c) >> 5], (k * EPV + c) & 31);
+          m_msk = fmaxf(m_msk, __uint_as_float((__float_as_uint(xv) & fill) | (0xff800000u & ~fill)));
+        }
+      }
+    }
+    m_all = wave_max(m_all);
+    if constexpr (kBits) m_msk = wave_max(m_msk);
+    if (lane == 0) {
+      lds_write_b32(scr_max + wave * 4, __float_as_uint(m_all));
+      if constexpr (kBits) lds_write_b32(scr_max + 64 + wave * 4, __float_as_uint(m_msk));
+    }
+    lds_barrier();
+    const int wl = lane & 15;            // lane wl of every DPP row stands for wave wl
+    const int wr = wl < W ? wl : W - 1;  // rows of 16 lanes but only W waves: the rest duplicate the last
+    m_all = row16_max_bcast(__uint_as_float(lds_read_b32_wait(scr_max + wr * 4)));
+    if constexpr (kBits) m_msk = row16_max_bcast(__uint_as_float(lds_read_b32_wait(scr_max + 64 + wr * 4)));
+    else m_msk = m_all;
+    const float N_all = __builtin_rintf(m_all * kLog2e);
+    const float N_msk = __builtin_rintf(m_msk * kLog2e);
+    const float Nb_all = N_all + (float)kFixShift, Nb_msk = N_msk + (float)kFixShift;
+    const bool same_n = (N_all == N_msk);
+
+    // ---- phase 2: fixed-point sums -----------------------------------------------------------------
+    uint64_t s_all = 0, s_msk = 0;
+    uint64_t ag[kPhilox ? NG : 1];  // per-lane masked sums of the chunks (GS tiles each)
+    const int n_pass = (kBits && !same_n) ? 2 : 1;
+#pragma unroll 1
+    for (int pass = 0; pass < n_pass; ++pass) {
+      const float Nb_cur = pass == 0 ? Nb_all : Nb_msk;
+      uint64_t acc = 0;
+      s_msk = 0;
+      if constexpr (kPhilox) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) ag[g] = 0;
+      }
+#pragma unroll
+      for (int i = 0; i < MBW; ++i) opaque(mb[i]);
+#pragma unroll
+      for (int k = 0; k < NVL; ++k) opaque(raw[k]);
+#pragma unroll
+      for (int k = 0; k < NVL; ++k) {
+        uint64_t ak = 0;
+        float xk[EPV];
+        unpack_vec<DT>(raw[k], xk);
+#pragma unroll
+        for (int c = 0; c < EPV; ++c) {
+          const float xv = p.use_scale ? xk[c] * p.scale : xk[c];
+          float nf, P;
+          exp_parts(xv, nf, P);
+          const uint64_t q = fix_term_from_parts(nf, P, Nb_cur);
+          acc += q;
+          if constexpr (kBits) {
+            const uint32_t fill = bit_fill(mb[(k * EPV + c) >> 5], (k * EPV + c) & 31);
+            ak += mask_u64(q, fill);
+          } else if constexpr (kPhilox) {
+            ak += q;
+          }
+        }
+        s_msk += ak;
+        if constexpr (kPhilox) {
+          ag[k / GS] += ak;
+          if (k % GS == GS - 1 || k == NVL - 1) opaque(ag[k / GS]);
+        }
+        // pin both running sums here: otherwise the masked adds are reassociated and sunk below the
+        // loop, which keeps every q of the row alive (200 VGPRs)
+        opaque(s_msk);
+        opaque(acc);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (pass == 0) s_all = acc;
+    }
+    if constexpr (!kBits) s_msk = s_all;
+    {
+      const uint64_t t_all = wave_scan_u64(s_all);
+      uint64_t t_msk = t_all;
+      if constexpr (kBits) t_msk = wave_scan_u64(s_msk);
+      if (lane == 63) {
+        lds_write_b64(scr_sum + wave * 8, t_all);
+        lds_write_b64(scr_sum + 128 + wave * 8, t_msk);
+      }
+      if constexpr (kPhilox) {
+        // wave totals of every chunk -> workspace; locate_kernel finishes the draw from them
+        uint64_t *crow = p.chunk_sums + (int64_t)cur.pidx * (W * NG) + wave * NG;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const uint64_t tg = wave_scan_u64(ag[g]);
+          if (lane == 63) crow[g] = tg;
+        }
+      }
+    }
+    lds_barrier();
+    // lane l (mod 16) holds wave l's totals; a 16-lane scan gives totals and the per-wave prefix at once
+    const uint64_t cw_all = wl < W ? lds_read_b64_wait(scr_sum + wr * 8) : 0ull;
+    const uint64_t cw_msk = wl < W ? lds_read_b64_wait(scr_sum + 128 + wr * 8) : 0ull;
+    const uint64_t in_all = row16_scan_u64(cw_all), in_msk = row16_scan_u64(cw_msk);
+    const uint64_t S_all = readlane_u64(in_all, 15), S_msk = readlane_u64(in_msk, 15);
+
+    // ---- phase 3: lse / logZ, draw -------------------------------------------------------------------
+    const int pidx = cur.pidx;
+    if (tid == 0) {
+      const double lse_all = S_all ? log_fix(S_all, (int32_t)N_all - kFixFrac) : (double)kNegInf;
+      const double lse_msk = S_msk ? log_fix(S_msk, (int32_t)N_msk - kFixFrac) : (double)kNegInf;
+      if (p.out_lse) p.out_lse[pidx] = (float)lse_all;
+      if (p.out_logZ) p.out_logZ[pidx] = (float)(lse_msk - lse_all);
+    }
+    if constexpr (kPhilox) {
+      if (tid == 0) p.chunk_nmsk[pidx] = N_msk;
+    }
+
+    if (!has_next) break;
+    // ---- next row: everything prefetched has landed ---------------------------------------------------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (kBits) lds_barrier();  // the mask row was DMA'd by other waves
+    cur = nxr;
+    vb = vb_next;
+    land(cur);
+  }
+}
+
+
+// Second half of the Philox draw for v2: one wave per particle.  From the chunk totals the fused
+// kernel left in the workspace it picks the chunk (64-lane scan), re-reads that chunk's 4-5 KiB of
+// the row, recomputes the per-lane tile sums against the stored exponent and walks
+// tile -> lane -> element exactly as v1 does in-kernel.  Same integers, same token.
+template <int DT, int MASK>
+__global__ __launch_bounds__(256) void locate_kernel(const RowParams p) {
+  constexpr int EPV = ElemTraits<DT>::EPV;
+  constexpr int ES = ElemTraits<DT>::ES;
+  const int lane = threadIdx.x & 63;
+  const int pidx = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pidx >= p.n_particles) return;
+  const int V = p.V;
+  const int row = p.row_of ? p.row_of[pidx] : pidx;
+  const char *rowp = (const char *)p.logits + (int64_t)row * p.ld * ES;
+  const int a = (int)(((uintptr_t)rowp) & 15) / ES;
+  const char *base = rowp - a * ES;
+  const int nv = (V + a + EPV - 1) / EPV;
+  const uint32_t *mrow = nullptr;
+  if constexpr (MASK == kMaskBits) {
+    const int mi = p.mask_id ? p.mask_id[pidx] : (p.n_masks == 1 ? 0 : pidx);
+    mrow = (const uint32_t *)p.mask + (int64_t)mi * p.mask_ld;
+  }
+  const uint64_t cs = lane < p.n_chunks ? p.chunk_sums[(int64_t)pidx * p.n_chunks + lane] : 0ull;
+  const uint64_t incl_c = wave_scan_u64(cs);
+  const uint64_t S = readlane_u64(incl_c, 63);
+  if (S == 0) {
+    if (lane == 0) p.out_token[pidx] = -1;
+    return;
+  }
+  const uint64_t gp = (uint64_t)(p.particle_base + pidx);
+  const uint32_t ctr[4] = {(uint32_t)gp, (uint32_t)(gp >> 32), (uint32_t)p.offset, (uint32_t)(p.offset >> 32)};
+  const uint32_t key[2] = {(uint32_t)p.seed, (uint32_t)(p.seed >> 32)};
+  uint32_t rnd[4];
+  philox4x32_10(ctr, key, rnd);
+  uint64_t Tc = __umul64hi(((uint64_t)rnd[1] << 32) | rnd[0], S);
+  {
+    uint32_t z = 0;
+    opaque(z);  // VALU compare (uniform u64 `<` miscompile, see v1)
+    Tc += z;
+  }
+  const int csel = __ffsll((long long)__ballot(incl_c > Tc)) - 1;
+  Tc -= readlane_u64(incl_c - cs, csel);
+  const float Nb = p.chunk_nmsk[pidx] + (float)kFixShift;
+  const int tiles = p.chunk_vecs >> 6;
+  uint64_t run = 0, asel = 0;
+  uint4 rsel = make_uint4(0, 0, 0, 0);
+  uint32_t nsel = 0;
+  int j0sel = 0;
+  bool found = false;
+  for (int j = 0; j < tiles; ++j) {
+    const int v = csel * p.chunk_vecs + j * 64 + lane;
+    const int vc = v < nv ? v : nv - 1;
+    const uint4 rk = *reinterpret_cast<const uint4 *>(base + (int64_t)vc * 16);
+    const int j0 = v * EPV - a;
+    uint32_t nib = (1u << EPV) - 1u;
+    if constexpr (MASK == kMaskBits) nib = mask_nibble<EPV>(mrow, (V + 31) >> 5, j0);
+    float xs[EPV];
+    unpack_vec<DT>(rk, xs);
+    uint64_t aj = 0;
+#pragma unroll
+    for (int c = 0; c < EPV; ++c) {
+      const float xv = p.use_scale ? xs[c] * p.scale : xs[c];
+      const bool ok = ((uint32_t)(j0 + c) < (uint32_t)V) && ((nib >> c) & 1u);
+      aj += ok ? fix_term(xv, Nb) : 0ull;
+    }
+    const uint64_t cj = wave_sum_u64(aj);
+    if (!found && Tc < run + cj) {
+      found = true;
+      Tc -= run;
+      asel = aj;
+      rsel = rk;
+      nsel = nib;
+      j0sel = j0;
+    }
+    run += cj;
+  }
+  const uint64_t incl = wave_scan_u64(asel);
+  const int lsel = __ffsll((long long)__ballot(incl > Tc)) - 1;
+  if (lane == lsel) {
+    uint64_t Tl = Tc - (incl - asel);
+    float xs[EPV];
+    unpack_vec<DT>(rsel, xs);
+    int32_t tok = -1;
+#pragma unroll
+    for (int c = 0; c < EPV; ++c) {
+      const float xv = p.use_scale ? xs[c] * p.scale : xs[c];
+      const bool ok = ((uint32_t)(j0sel + c) < (uint32_t)V) && ((nsel >> c) & 1u);
+      const uint64_t q = ok ? fix_term(xv, Nb) : 0ull;
+      if (tok < 0) {
+        if (Tl < q) tok = j0sel + c;
+        else Tl -= q;
+      }
+    }
+    p.out_token[pidx] = tok;
+  }
+}
+
+}  // namespace glb

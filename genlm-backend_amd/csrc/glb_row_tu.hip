@@ -1,7 +1,7 @@
 // glb_row_tu.hip — one translation unit per (element type, draw mode); compiled with
 // -DGLB_DT=<0|1|2> -DGLB_MODE=<0|1|2>.  Instantiates the row kernel for every mask kind and launch
 // geometry and exports one launcher that glb_api.hip dispatches to.
-#include "glb_row_kernel.hpp"
+#include "glb_row_kernel_v2.hpp"
 
 #ifndef GLB_DT
 #error "GLB_DT not defined"
@@ -32,11 +32,56 @@ static hipError_t launch_geom(const RowParams &p, int geom, hipStream_t s) {
   }
 }
 
+// persistent pipelined variant (glb_row_kernel_v2.hpp): 512 threads (2 waves / SIMD, 256 VGPRs),
+// ids -> (NVL, NL, ND):  21:(25,19,6) fp32 gpt2-sized rows   22:(16,16,0)   23:(32,17,11) 16-bit 128k rows
+#if GLB_MODE != 2
+template <int MASK, int NVL, int NL, int ND>
+static hipError_t launch2(const RowParams &p0, int grid, hipStream_t s) {
+  RowParams p = p0;
+  constexpr int GS = (NVL % 5 == 0) ? 5 : 4;
+  p.n_chunks = 8 * (NVL / GS);
+  p.chunk_vecs = GS * 64;
+  hipLaunchKernelGGL((row_kernel_v2<GLB_DT, MASK, GLB_MODE, NVL, NL, ND, 512>), dim3(grid), dim3(512), 0, s, p);
+  hipError_t e = hipGetLastError();
+#if GLB_MODE == 1
+  if (e == hipSuccess && p.out_token) {
+    hipLaunchKernelGGL((locate_kernel<GLB_DT, MASK>), dim3((p.n_particles + 3) / 4), dim3(256), 0, s, p);
+    e = hipGetLastError();
+  }
+#endif
+  return e;
+}
+
+template <int MASK>
+static hipError_t launch_geom2(const RowParams &p, int geom, int grid, hipStream_t s) {
+  switch (geom) {
+#if GLB_DT == 0
+    case 21: return launch2<MASK, 25, 19, 6>(p, grid, s);
+#else
+    case 23: return launch2<MASK, 32, 17, 11>(p, grid, s);
+#endif
+    case 22: return launch2<MASK, 16, 16, 0>(p, grid, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+#endif
+
 #define GLB_CAT_(a, b, c) a##b##_##c
 #define GLB_CAT(a, b, c) GLB_CAT_(a, b, c)
 
 hipError_t GLB_CAT(launch_row_, GLB_DT, GLB_MODE)(const RowParams &p, int mask_kind, int geom,
                                                   hipStream_t s) {
+#if GLB_MODE != 2
+  if ((geom & 0xff) >= 21) {
+    const int grid = geom >> 8;  // persistent grid size rides in the upper bits
+    const int g = geom & 0xff;
+    switch (mask_kind) {
+      case kMaskNone: return launch_geom2<kMaskNone>(p, g, grid, s);
+      case kMaskBits: return launch_geom2<kMaskBits>(p, g, grid, s);
+      default: return hipErrorInvalidValue;
+    }
+  }
+#endif
   switch (mask_kind) {
     case kMaskNone: return launch_geom<kMaskNone>(p, geom, s);
     case kMaskBits: return launch_geom<kMaskBits>(p, geom, s);

@@ -50,6 +50,7 @@ class HipEngine:
         if self.device.type != "cuda":
             raise RuntimeError(f"HipEngine device must be a HIP device, got {self.device}")
         self._ws = None
+        self._step_ws = None
 
     # ------------------------------------------------------------------------------------------
     def _stream(self):
@@ -120,7 +121,13 @@ class HipEngine:
         a.out_logZ = None if logZ is None else logZ.data_ptr()
         a.out_lse = None if lse is None else lse.data_ptr()
         a.out_token = None if tok is None else tok.data_ptr()
-        a.variant = variant
+        a.variant = max(variant, 0)  # variant -1: auto geometry of the one-workgroup-per-particle kernel
+        if variant == 0 or variant >= 21:  # lend scratch: enables the persistent pipelined kernel
+            need = self.lib.glb_step_workspace_bytes(n)
+            if self._step_ws is None or self._step_ws.numel() < need:
+                self._step_ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=self.device)
+            a.workspace = self._step_ws.data_ptr()
+            a.workspace_bytes = self._step_ws.numel()
         check(self.lib.glb_logprob_mask_sample(C.byref(a), self._stream()))
         return logZ, lse, tok
 

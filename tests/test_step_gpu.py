@@ -116,3 +116,45 @@ def test_log_softmax_rows(engine, oracle):
         assert np.array_equal(_np(lse).view(np.uint32), lse_o.view(np.uint32))
         ref = torch.log_softmax(torch.from_numpy(x), -1).numpy()
         assert np.abs(_np(got) - ref).max() < 1e-4  # north_star tolerance vs the reference op (cache.py:96)
+
+
+V2_CASES = [
+    # (n_particles, n_rows, V, dtype, variant)   variant: 21 fp32 <= 51196, 22 small rows, 23 16-bit <= 131064
+    (700, 300, 50257, "f32", 21),
+    (513, 513, 50257, "f32", 0),
+    (300, 300, 30001, "f32", 22),
+    (300, 100, 128256, "bf16", 23),
+    (260, 260, 65001, "f16", 22),
+    (9, 9, 1000, "f32", 22),
+]
+
+
+@pytest.mark.parametrize("N,U,V,dtype,variant", V2_CASES)
+@pytest.mark.parametrize("mask_kind", ["none", "bits"])
+def test_persistent_kernel_bit_exact(engine, oracle, N, U, V, dtype, variant, mask_kind):
+    """The persistent pipelined kernel + locate kernel give the same bits as the oracle (and so as v1):
+    more particles than CUs so every workgroup streams several rows, shared rows, unaligned rows."""
+    O = oracle
+    x_np, x_t = _mk(O, U, V, dtype, seed=V + U)
+    dev = engine.device
+    row_of = (np.arange(N) * 7 % U).astype(np.int32)
+    K = 3
+    masks = synth.binary_masks(V + 1, K, V)
+    masks[2, 50:] = -np.inf  # a mask whose allowed set sits far below the row maximum for most rows
+    mid = (np.arange(N) % K).astype(np.int32)
+    kw_o, kw_g = {}, {}
+    if mask_kind == "bits":
+        bits, _ = O.mask_f32_to_bits(masks)
+        kw_o = dict(mask_kind=O.MASK_BITS, mask=bits, mask_id=mid)
+        kw_g = dict(mask_kind=1, mask=_bits_dev(bits, dev), mask_id=torch.from_numpy(mid).to(dev))
+    logZ_o, lse_o, tok_o = O.step(x_np, row_of=row_of, rng_mode=O.RNG_PHILOX, seed=77, offset=5, particle_base=3, **kw_o)
+    logZ, lse, tok = engine.step(x_t.to(dev), row_of=torch.from_numpy(row_of).to(dev), rng_mode=1, seed=77, offset=5,
+                                 particle_base=3, variant=variant, **kw_g)
+    torch.cuda.synchronize()
+    assert np.array_equal(_np(tok), tok_o)
+    assert np.array_equal(_np(logZ).view(np.uint32), logZ_o.view(np.uint32))
+    assert np.array_equal(_np(lse).view(np.uint32), lse_o.view(np.uint32))
+    # and the one-workgroup-per-particle kernel agrees
+    logZ1, lse1, tok1 = engine.step(x_t.to(dev), row_of=torch.from_numpy(row_of).to(dev), rng_mode=1, seed=77,
+                                    offset=5, particle_base=3, variant=-1, **kw_g)
+    assert torch.equal(tok, tok1) and torch.equal(logZ, logZ1) and torch.equal(lse, lse1)
