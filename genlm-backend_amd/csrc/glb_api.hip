@@ -402,7 +402,7 @@ int glb_device_count(void) {
 
 size_t glb_step_workspace_bytes(int64_t n_particles) {
   if (n_particles <= 0) return 0;
-  return (size_t)n_particles * (64 * sizeof(uint64_t) + sizeof(float)) + 16;
+  return (size_t)n_particles * (66 * sizeof(uint64_t) + 2 * sizeof(float)) + 16;
 }
 
 int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
@@ -489,7 +489,8 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
   p.out_ld = 0;
   if (a->workspace) {
     p.chunk_sums = (uint64_t *)a->workspace;
-    p.chunk_nmsk = (float *)((char *)a->workspace + (size_t)a->n_particles * 64 * sizeof(uint64_t));
+    p.row_sums = p.chunk_sums + (size_t)a->n_particles * 64;
+    p.row_exps = (float *)(p.row_sums + (size_t)a->n_particles * 2);
   }
   const hipError_t e = dispatch_row(a->dtype, a->rng_mode, p, a->mask_kind, geom, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "row_kernel launch");

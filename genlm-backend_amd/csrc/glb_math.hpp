@@ -58,6 +58,73 @@ __device__ __forceinline__ uint64_t fix_term(float x, float Nb) {
   return fix_term_from_parts(nf, P, Nb);
 }
 
+// Four independent exp splits + fixed-point operands, hand-interleaved.  hipcc emits each element's
+// 13-instruction dependency chain back to back (every instruction waits on the previous one: half of
+// the issue slots of a 2-wave/SIMD kernel are stalls); here the four chains advance in lock step.
+// Same instructions, same roundings as exp_parts + fix_term_from_parts:
+//   pf[c] = (uint32) P(x_c),  sh[c] = (uint32) min(Nb - n(x_c), 63),  term = ((uint64)pf << 32) >> sh.
+__device__ __forceinline__ void exp_fix4(float x0, float x1, float x2, float x3, float Nb,
+                                         uint32_t (&pf)[4], uint32_t (&sh)[4]) {
+  float r0, r1, r2, r3;
+  const float c4 = kC4, nhi = -kLn2Hi, nlo = -kLn2Lo;
+  asm volatile(
+      "v_mul_f32 %0, 0x3fb8aa3b, %12\n\t"
+      "v_mul_f32 %1, 0x3fb8aa3b, %13\n\t"
+      "v_mul_f32 %2, 0x3fb8aa3b, %14\n\t"
+      "v_mul_f32 %3, 0x3fb8aa3b, %15\n\t"
+      "v_rndne_f32 %4, %0\n\t"
+      "v_rndne_f32 %5, %1\n\t"
+      "v_rndne_f32 %6, %2\n\t"
+      "v_rndne_f32 %7, %3\n\t"
+      "v_fma_f32 %8, %4, %18, %12\n\t"
+      "v_fma_f32 %9, %5, %18, %13\n\t"
+      "v_fma_f32 %10, %6, %18, %14\n\t"
+      "v_fma_f32 %11, %7, %18, %15\n\t"
+      "v_fma_f32 %8, %4, %19, %8\n\t"
+      "v_fma_f32 %9, %5, %19, %9\n\t"
+      "v_fma_f32 %10, %6, %19, %10\n\t"
+      "v_fma_f32 %11, %7, %19, %11\n\t"
+      "v_fmamk_f32 %0, %8, 0x4b0905d1, %17\n\t"
+      "v_fmamk_f32 %1, %9, 0x4b0905d1, %17\n\t"
+      "v_fmamk_f32 %2, %10, 0x4b0905d1, %17\n\t"
+      "v_fmamk_f32 %3, %11, 0x4b0905d1, %17\n\t"
+      "v_fmaak_f32 %0, %0, %8, 0x4d2aaa6e\n\t"
+      "v_fmaak_f32 %1, %1, %9, 0x4d2aaa6e\n\t"
+      "v_fmaak_f32 %2, %2, %10, 0x4d2aaa6e\n\t"
+      "v_fmaak_f32 %3, %3, %11, 0x4d2aaa6e\n\t"
+      "v_fmaak_f32 %0, %0, %8, 0x4dffff2d\n\t"
+      "v_fmaak_f32 %1, %1, %9, 0x4dffff2d\n\t"
+      "v_fmaak_f32 %2, %2, %10, 0x4dffff2d\n\t"
+      "v_fmaak_f32 %3, %3, %11, 0x4dffff2d\n\t"
+      "v_fmaak_f32 %0, %0, %8, 0x4e800000\n\t"
+      "v_fmaak_f32 %1, %1, %9, 0x4e800000\n\t"
+      "v_fmaak_f32 %2, %2, %10, 0x4e800000\n\t"
+      "v_fmaak_f32 %3, %3, %11, 0x4e800000\n\t"
+      "v_fmaak_f32 %0, %0, %8, 0x4e800000\n\t"
+      "v_fmaak_f32 %1, %1, %9, 0x4e800000\n\t"
+      "v_fmaak_f32 %2, %2, %10, 0x4e800000\n\t"
+      "v_fmaak_f32 %3, %3, %11, 0x4e800000\n\t"
+      "v_sub_f32 %4, %16, %4\n\t"
+      "v_sub_f32 %5, %16, %5\n\t"
+      "v_sub_f32 %6, %16, %6\n\t"
+      "v_sub_f32 %7, %16, %7\n\t"
+      "v_min_f32 %4, 0x427c0000, %4\n\t"
+      "v_min_f32 %5, 0x427c0000, %5\n\t"
+      "v_min_f32 %6, 0x427c0000, %6\n\t"
+      "v_min_f32 %7, 0x427c0000, %7\n\t"
+      "v_cvt_u32_f32 %4, %4\n\t"
+      "v_cvt_u32_f32 %5, %5\n\t"
+      "v_cvt_u32_f32 %6, %6\n\t"
+      "v_cvt_u32_f32 %7, %7\n\t"
+      "v_cvt_u32_f32 %0, %0\n\t"
+      "v_cvt_u32_f32 %1, %1\n\t"
+      "v_cvt_u32_f32 %2, %2\n\t"
+      "v_cvt_u32_f32 %3, %3"
+      : "=&v"(pf[0]), "=&v"(pf[1]), "=&v"(pf[2]), "=&v"(pf[3]), "=&v"(sh[0]), "=&v"(sh[1]), "=&v"(sh[2]),
+        "=&v"(sh[3]), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+      : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(Nb), "v"(c4), "s"(nhi), "s"(nlo));
+}
+
 // ln(S * 2^k) for integer S > 0 (atanh series in double, fixed op order)
 __device__ inline double log_fix(uint64_t S, int32_t k) {
   double d = __builtin_fma((double)(uint32_t)(S >> 32), 4294967296.0, (double)(uint32_t)S);

@@ -52,7 +52,8 @@ struct RowParams {
   int64_t out_ld;
   // v2 + locate_kernel: per-particle chunk totals [n_particles, n_chunks] and masked exponent N_msk
   uint64_t *chunk_sums;
-  float *chunk_nmsk;
+  uint64_t *row_sums;  // [n_particles][2]  S_all, S_mask
+  float *row_exps;     // [n_particles][2]  N_all, N_mask
   int32_t n_chunks, chunk_vecs;
 };
 

@@ -23,6 +23,13 @@ namespace glb {
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 
+// 1 KiB of -inf per element type: vectors past the end of a row are fetched from here instead of being
+// patched after the load (f32 | bf16 | f16 bit patterns)
+__device__ const uint32_t g_neg_inf_page[3][256] = {
+    {0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u},
+    {0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u},
+    {0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u}};
+
 __device__ __forceinline__ uint32_t lds_addr(const void *p) {
   return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
 }
@@ -65,7 +72,7 @@ __device__ __forceinline__ uint64_t row16_scan_u64(uint64_t v) {
   return v;
 }
 
-template <int DT, int MASK, int MODE, int NVL, int NL, int ND, int T>
+template <int DT, int MASK, int MODE, int NVL, int NL, int ND, int T, bool SCALED>
 __global__ __launch_bounds__(T) void row_kernel_v2(const RowParams p) {
   constexpr int W = T / 64;
   static_assert(NVL <= 35 && W <= 16, "cross-wave scratch is reduced inside one DPP row of 16 lanes");
@@ -127,34 +134,44 @@ __global__ __launch_bounds__(T) void row_kernel_v2(const RowParams p) {
     return r;
   };
 
+  const char *ninf = (const char *)g_neg_inf_page[DT];
   uint4 raw[NVL];
   uint4 nxt[ND > 0 ? ND : 1];
   uint32_t mb[MBW];
 
-  // issue the whole prefetch of a row: NL vectors per lane by LDS-DMA, ND into `nxt`, the mask row by DMA
-  auto prefetch = [&](const RowRef &r) {
-#pragma unroll
-    for (int k = 0; k < NL; ++k) {
-      int v = v0 + k * 64;
-      v = v < r.nv ? v : r.nv - 1;
-      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(r.base + (int64_t)v * 16),
+  // Prefetch of a row, one slot at a time.  Issuing all of a row's loads at once blocks the issuing
+  // waves for most of the transfer (the CU's memory queue holds far less than 200 KB of requests:
+  // measured 6-10k cycles at issue, 0.4k at the final vmcnt wait), so the slots are issued from inside
+  // phase 2, one per tile of arithmetic: slot k < NL by LDS-DMA into this wave's staging slot, the next
+  // ND into `nxt`, plus this wave's chunks of the mask bit row.
+  uint32_t lane_off = (uint32_t)v0 * 16u;  // byte offset of this lane's first vector; re-opaqued per row so
+                                           // the 2*NVL slot addresses are not hoisted out of the row loop
+  auto prefetch_slot = [&](const RowRef &r, int k) {
+    const uint32_t off = lane_off + (uint32_t)k * 1024u;
+    const char *src = off < (uint32_t)r.nv * 16u ? r.base + off : ninf + lane * 16;  // past the row: -inf page
+    if (k < NL) {
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)src,
                                        (lds_ptr_t)(s_stage + (wave * NL + k) * 64), 16, 0, 0);
+    } else if (k < NL + ND) {
+      nxt[k - NL] = *reinterpret_cast<const uint4 *>(src);
     }
     if constexpr (kBits) {
-      for (int m = wave; m * 64 < r.mvec; m += W) {  // chunk m = mask vectors [64m, 64m+64)
-        int mv = m * 64 + lane;
-        mv = mv < r.mvec ? mv : r.mvec - 1;
-        __builtin_amdgcn_global_load_lds(
-            (const void __attribute__((address_space(1))) *)((const char *)r.mrow16 + (int64_t)mv * 16),
-            (lds_ptr_t)(s_lds + STAGE_V + m * 64), 16, 0, 0);
+      constexpr int MCH = (MASK_V / 64 + W - 1) / W;  // mask chunks per wave
+      if (k < MCH) {
+        const int m = wave + k * W;  // chunk m = mask vectors [64m, 64m+64)
+        if (m * 64 < r.mvec) {
+          int mv = m * 64 + lane;
+          mv = mv < r.mvec ? mv : r.mvec - 1;
+          __builtin_amdgcn_global_load_lds(
+              (const void __attribute__((address_space(1))) *)((const char *)r.mrow16 + (int64_t)mv * 16),
+              (lds_ptr_t)(s_lds + STAGE_V + m * 64), 16, 0, 0);
+        }
       }
     }
+  };
+  auto prefetch = [&](const RowRef &r) {
 #pragma unroll
-    for (int k = 0; k < ND; ++k) {
-      int v = v0 + (NL + k) * 64;
-      v = v < r.nv ? v : r.nv - 1;
-      nxt[k] = *reinterpret_cast<const uint4 *>(r.base + (int64_t)v * 16);
-    }
+    for (int k = 0; k < NVL; ++k) prefetch_slot(r, k);
   };
 
   // after the explicit vmcnt(0) (+ barrier for the mask row): staged data -> registers, late vectors,
@@ -166,48 +183,48 @@ __global__ __launch_bounds__(T) void row_kernel_v2(const RowParams p) {
     for (int k = 0; k < ND; ++k) raw[NL + k] = nxt[k];
 #pragma unroll
     for (int k = 0; k < NX; ++k) {
-      int v = v0 + (NL + ND + k) * 64;
-      v = v < r.nv ? v : r.nv - 1;
-      raw[NL + ND + k] = *reinterpret_cast<const uint4 *>(r.base + (int64_t)v * 16);
+      const int v = v0 + (NL + ND + k) * 64;
+      raw[NL + ND + k] = *reinterpret_cast<const uint4 *>(v < r.nv ? r.base + (int64_t)v * 16 : ninf + lane * 16);
     }
     // late vectors must have landed before the next prefetch is issued: hipcc would otherwise wait
     // vmcnt(0) at their first use and drain the DMA with them
     if constexpr (NX > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int j00 = v0 * EPV - r.a;  // element index of this lane's first element (may be -a..-1)
 #pragma unroll
     for (int i = 0; i < MBW; ++i) mb[i] = kBits ? 0u : 0xffffffffu;
     if constexpr (kBits) {
-      const int last_w = r.mvec * 4 - 1;  // last staged word
+      // tile k's EPV bits start at bit j00 + 64*EPV*k of the staged mask row: a fixed shift and a word
+      // index that advances by 2*EPV per tile.  Words outside the staged row (index -1, or past the end)
+      // are harmless LDS reads: they only feed bits of elements that are -inf anyway.
+      const uint32_t shb = (uint32_t)(j00 & 31);
+      const uint32_t *mw = s_mask + ((j00 >> 5) + r.am);
 #pragma unroll
       for (int k = 0; k < NVL; ++k) {
-        const int j0 = (v0 + k * 64) * EPV - r.a;
-        const int jb = j0 < 0 ? 0 : j0;
-        const int d = jb - j0;
-        int wi = (jb >> 5) + r.am;
-        const int w0 = wi < last_w ? wi : last_w, w1 = wi + 1 < last_w ? wi + 1 : last_w;
-        const uint32_t f = __builtin_amdgcn_alignbit(s_mask[w1], s_mask[w0], (uint32_t)(jb & 31));
-        mb[(k * EPV) >> 5] |= ((f << d) & ((1u << EPV) - 1u)) << ((k * EPV) & 31);
-        if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the words in flight
+        const uint32_t f = __builtin_amdgcn_alignbit(mw[k * 2 * EPV + 1], mw[k * 2 * EPV], shb);
+        mb[(k * EPV) >> 5] |= (f & ((1u << EPV) - 1u)) << ((k * EPV) & 31);
       }
     }
+    // only two vectors of a row can be partly outside it: the first (leading pad) and the last
+    auto patch = [&](uint4 &rk, int first_valid, int n_valid) {  // keep elements [first_valid, n_valid)
+      uint32_t w[4] = {rk.x, rk.y, rk.z, rk.w};
 #pragma unroll
-    for (int k = 0; k < NVL; ++k) {
-      const int tile_lo = wave * (64 * NVL) + k * 64;
-      if ((tile_lo == 0 && r.a > 0) || tile_lo + 64 >= r.nv) {
-        const int j0 = (v0 + k * 64) * EPV - r.a;
-        uint32_t w[4] = {raw[k].x, raw[k].y, raw[k].z, raw[k].w};
-#pragma unroll
-        for (int c = 0; c < EPV; ++c) {
-          if ((uint32_t)(j0 + c) >= (uint32_t)V) {
-            if constexpr (DT == kDtF32) w[c] = 0xff800000u;
-            else if constexpr (DT == kDtBf16)
-              w[c >> 1] = (c & 1) ? ((w[c >> 1] & 0x0000ffffu) | 0xff800000u) : ((w[c >> 1] & 0xffff0000u) | 0x0000ff80u);
-            else
-              w[c >> 1] = (c & 1) ? ((w[c >> 1] & 0x0000ffffu) | 0xfc000000u) : ((w[c >> 1] & 0xffff0000u) | 0x0000fc00u);
-          }
+      for (int c = 0; c < EPV; ++c) {
+        if (c < first_valid || c >= n_valid) {
+          if constexpr (DT == kDtF32) w[c] = 0xff800000u;
+          else if constexpr (DT == kDtBf16)
+            w[c >> 1] = (c & 1) ? ((w[c >> 1] & 0x0000ffffu) | 0xff800000u) : ((w[c >> 1] & 0xffff0000u) | 0x0000ff80u);
+          else
+            w[c >> 1] = (c & 1) ? ((w[c >> 1] & 0x0000ffffu) | 0xfc000000u) : ((w[c >> 1] & 0xffff0000u) | 0x0000fc00u);
         }
-        raw[k] = make_uint4(w[0], w[1], w[2], w[3]);
       }
-    }
+      rk = make_uint4(w[0], w[1], w[2], w[3]);
+    };
+    if (tid == 0 && r.a > 0) patch(raw[0], r.a, EPV);
+    const int vlast = r.nv - 1;                      // last vector of the row
+    const int klast = (vlast - wave * (64 * NVL)) >> 6;  // its tile in this wave (if it is this wave's)
+#pragma unroll
+    for (int k = 0; k < NVL; ++k)
+      if (k == klast && v0 + k * 64 == vlast) patch(raw[k], (vlast == 0) ? r.a : 0, V + r.a - vlast * EPV);
   };
 
   // ---- prologue: first row straight to registers (nothing to overlap with yet) ---------------------
@@ -223,14 +240,8 @@ __global__ __launch_bounds__(T) void row_kernel_v2(const RowParams p) {
     const int vb_next = vb + G;
     const bool has_next = vb_next < n;
     RowRef nxr = cur;
-    // every read of the staging area / mask row by this wave has returned before the DMA refills them;
-    // the mask row is shared, so all waves must be past `land`
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if constexpr (kBits) __builtin_amdgcn_s_barrier();
-    if (has_next) {
-      nxr = row_ref(vb_next);
-      prefetch(nxr);
-    }
+    if (has_next) nxr = row_ref(vb_next);
+    opaque(lane_off);
 
     // ---- phase 1: maxima ----------------------------------------------------------------------
     float m_all = kNegInf, m_msk = kNegInf;
@@ -240,7 +251,7 @@ __global__ __launch_bounds__(T) void row_kernel_v2(const RowParams p) {
       unpack_vec<DT>(raw[k], xk);
 #pragma unroll
       for (int c = 0; c < EPV; ++c) {
-        const float xv = p.use_scale ? xk[c] * p.scale : xk[c];
+        const float xv = SCALED ? xk[c] * p.scale : xk[c];
         m_all = fmaxf(m_all, xv);
         if constexpr (kBits) {
           const uint32_t fill = bit_fill(mb[(k * EPV + c) >> 5], (k * EPV + c) & 31);
@@ -287,18 +298,25 @@ __global__ __launch_bounds__(T) void row_kernel_v2(const RowParams p) {
         uint64_t ak = 0;
         float xk[EPV];
         unpack_vec<DT>(raw[k], xk);
+        if constexpr (SCALED) {
 #pragma unroll
-        for (int c = 0; c < EPV; ++c) {
-          const float xv = p.use_scale ? xk[c] * p.scale : xk[c];
-          float nf, P;
-          exp_parts(xv, nf, P);
-          const uint64_t q = fix_term_from_parts(nf, P, Nb_cur);
-          acc += q;
-          if constexpr (kBits) {
-            const uint32_t fill = bit_fill(mb[(k * EPV + c) >> 5], (k * EPV + c) & 31);
-            ak += mask_u64(q, fill);
-          } else if constexpr (kPhilox) {
-            ak += q;
+          for (int c = 0; c < EPV; ++c) xk[c] = xk[c] * p.scale;
+        }
+#pragma unroll
+        for (int h = 0; h < EPV / 4; ++h) {
+          uint32_t pf[4], sh[4];
+          exp_fix4(xk[4 * h], xk[4 * h + 1], xk[4 * h + 2], xk[4 * h + 3], Nb_cur, pf, sh);
+#pragma unroll
+          for (int c4 = 0; c4 < 4; ++c4) {
+            const int c = 4 * h + c4;
+            const uint64_t q = ((uint64_t)pf[c4] << 32) >> sh[c4];
+            acc += q;
+            if constexpr (kBits) {
+              const uint32_t fill = bit_fill(mb[(k * EPV + c) >> 5], (k * EPV + c) & 31);
+              ak += mask_u64(q, fill);
+            } else if constexpr (kPhilox) {
+              ak += q;
+            }
           }
         }
         s_msk += ak;
@@ -310,7 +328,10 @@ __global__ __launch_bounds__(T) void row_kernel_v2(const RowParams p) {
         // loop, which keeps every q of the row alive (200 VGPRs)
         opaque(s_msk);
         opaque(acc);
-        __builtin_amdgcn_sched_barrier(0);
+        // next row's slot k goes out now: this wave's staging slot k was emptied by `land`, and every wave
+        // is past `land` (barrier after phase 1), so the shared mask row may be refilled too
+        if (has_next && pass == 0) prefetch_slot(nxr, k);
+        __builtin_amdgcn_sched_barrier(0);  // one vector at a time (register pressure)
       }
       if (pass == 0) s_all = acc;
     }
@@ -340,16 +361,14 @@ __global__ __launch_bounds__(T) void row_kernel_v2(const RowParams p) {
     const uint64_t in_all = row16_scan_u64(cw_all), in_msk = row16_scan_u64(cw_msk);
     const uint64_t S_all = readlane_u64(in_all, 15), S_msk = readlane_u64(in_msk, 15);
 
-    // ---- phase 3: lse / logZ, draw -------------------------------------------------------------------
-    const int pidx = cur.pidx;
+    // ---- phase 3 is not here: the sums and exponents go to the workspace and finish_kernel /
+    //      locate_kernel turn them into lse / logZ (double-precision log) and the token.  In-kernel it
+    //      cost 1.2k cycles per row on one lane and its hoisted double constants spilled.
     if (tid == 0) {
-      const double lse_all = S_all ? log_fix(S_all, (int32_t)N_all - kFixFrac) : (double)kNegInf;
-      const double lse_msk = S_msk ? log_fix(S_msk, (int32_t)N_msk - kFixFrac) : (double)kNegInf;
-      if (p.out_lse) p.out_lse[pidx] = (float)lse_all;
-      if (p.out_logZ) p.out_logZ[pidx] = (float)(lse_msk - lse_all);
-    }
-    if constexpr (kPhilox) {
-      if (tid == 0) p.chunk_nmsk[pidx] = N_msk;
+      p.row_sums[2 * cur.pidx] = S_all;
+      p.row_sums[2 * cur.pidx + 1] = S_msk;
+      p.row_exps[2 * cur.pidx] = N_all;
+      p.row_exps[2 * cur.pidx + 1] = N_msk;
     }
 
     if (!has_next) break;
@@ -362,6 +381,22 @@ __global__ __launch_bounds__(T) void row_kernel_v2(const RowParams p) {
   }
 }
 
+
+// lse / logZ of one particle from the sums the persistent kernel parked in the workspace
+__device__ __forceinline__ void finish_row(const RowParams &p, int pidx) {
+  const uint64_t S_all = p.row_sums[2 * pidx], S_msk = p.row_sums[2 * pidx + 1];
+  const float N_all = p.row_exps[2 * pidx], N_msk = p.row_exps[2 * pidx + 1];
+  const double lse_all = S_all ? log_fix(S_all, (int32_t)N_all - kFixFrac) : (double)kNegInf;
+  const double lse_msk = S_msk ? log_fix(S_msk, (int32_t)N_msk - kFixFrac) : (double)kNegInf;
+  if (p.out_lse) p.out_lse[pidx] = (float)lse_all;
+  if (p.out_logZ) p.out_logZ[pidx] = (float)(lse_msk - lse_all);
+}
+
+template <int UNUSED>
+__global__ void finish_kernel(const RowParams p) {
+  const int pidx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pidx < p.n_particles) finish_row(p, pidx);
+}
 
 // Second half of the Philox draw for v2: one wave per particle.  From the chunk totals the fused
 // kernel left in the workspace it picks the chunk (64-lane scan), re-reads that chunk's 4-5 KiB of
@@ -388,6 +423,7 @@ __global__ __launch_bounds__(256) void locate_kernel(const RowParams p) {
   const uint64_t cs = lane < p.n_chunks ? p.chunk_sums[(int64_t)pidx * p.n_chunks + lane] : 0ull;
   const uint64_t incl_c = wave_scan_u64(cs);
   const uint64_t S = readlane_u64(incl_c, 63);
+  if (lane == 0) finish_row(p, pidx);
   if (S == 0) {
     if (lane == 0) p.out_token[pidx] = -1;
     return;
@@ -405,7 +441,7 @@ __global__ __launch_bounds__(256) void locate_kernel(const RowParams p) {
   }
   const int csel = __ffsll((long long)__ballot(incl_c > Tc)) - 1;
   Tc -= readlane_u64(incl_c - cs, csel);
-  const float Nb = p.chunk_nmsk[pidx] + (float)kFixShift;
+  const float Nb = p.row_exps[2 * pidx + 1] + (float)kFixShift;
   const int tiles = p.chunk_vecs >> 6;
   uint64_t run = 0, asel = 0;
   uint4 rsel = make_uint4(0, 0, 0, 0);

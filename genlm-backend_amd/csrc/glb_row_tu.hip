@@ -41,11 +41,19 @@ static hipError_t launch2(const RowParams &p0, int grid, hipStream_t s) {
   constexpr int GS = (NVL % 5 == 0) ? 5 : 4;
   p.n_chunks = 8 * (NVL / GS);
   p.chunk_vecs = GS * 64;
-  hipLaunchKernelGGL((row_kernel_v2<GLB_DT, MASK, GLB_MODE, NVL, NL, ND, 512>), dim3(grid), dim3(512), 0, s, p);
+  if (p.use_scale)
+    hipLaunchKernelGGL((row_kernel_v2<GLB_DT, MASK, GLB_MODE, NVL, NL, ND, 512, true>), dim3(grid), dim3(512), 0, s, p);
+  else
+    hipLaunchKernelGGL((row_kernel_v2<GLB_DT, MASK, GLB_MODE, NVL, NL, ND, 512, false>), dim3(grid), dim3(512), 0, s, p);
   hipError_t e = hipGetLastError();
 #if GLB_MODE == 1
-  if (e == hipSuccess && p.out_token) {
+  if (e == hipSuccess) {
     hipLaunchKernelGGL((locate_kernel<GLB_DT, MASK>), dim3((p.n_particles + 3) / 4), dim3(256), 0, s, p);
+    e = hipGetLastError();
+  }
+#else
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(finish_kernel<0>, dim3((p.n_particles + 255) / 256), dim3(256), 0, s, p);
     e = hipGetLastError();
   }
 #endif
