@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -451,7 +452,11 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
     if (((uintptr_t)a->workspace) % 16) return fail(GLB_EINVAL, "workspace not 16-byte aligned");
     const int g2 = pick_geom2(a->vocab, a->dtype, a->variant);
     if (g2) {
-      const int64_t grid = a->n_particles < num_cus() ? a->n_particles : num_cus();
+      int64_t grid = a->n_particles < num_cus() ? a->n_particles : num_cus();
+      if (const char *g = getenv("GLB_V2_GRID")) {  // tuning knob: persistent workgroups to launch
+        const int64_t want = atoll(g);
+        if (want > 0 && want < grid) grid = want;
+      }
       geom = g2 | ((int)grid << 8);
     }
   }

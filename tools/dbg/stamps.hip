@@ -14,9 +14,11 @@ int main() {
   hipMemcpy(x + h.size(), h.data(), h.size() * 4, hipMemcpyHostToDevice);
   float *lz, *ls; hipMalloc(&lz, B * 4); hipMalloc(&ls, B * 4);
   glb::RowParams p{}; p.logits = x; p.ld = V; p.V = V; p.n_particles = B; p.out_logZ = lz; p.out_lse = ls;
+  uint64_t* ws; hipMalloc(&ws, (size_t)B * 70 * 8); p.chunk_sums = ws; p.row_sums = ws + (size_t)B * 64; p.row_exps = (float*)(ws + (size_t)B * 66); p.n_chunks = 40; p.chunk_vecs = 320;
+  uint32_t* mk; int W32 = (V + 31) / 32; hipMalloc(&mk, (size_t)2 * W32 * 4); hipMemset(mk, 0xB7, (size_t)2 * W32 * 4); p.mask = mk; p.mask_ld = W32; p.n_masks = 1;
   for (int it = 0; it < 6; ++it) {
     p.logits = x + (it & 1) * h.size();
-    hipLaunchKernelGGL((glb::row_kernel_v2<0, 0, 0, 25, 19, 6, 512, false>), dim3(256), dim3(512), 0, 0, p);
+    hipLaunchKernelGGL((glb::row_kernel_v2<0, MASKK, MODEE, 25, 19, 6, 512, false>), dim3(256), dim3(512), 0, 0, p);
   }
   hipDeviceSynchronize();
   std::vector<unsigned long long> st(256 * 64);
