@@ -11,7 +11,7 @@
 #include <string>
 
 #include "../../include/glb.h"
-#include "glb_row_kernel.hpp"
+#include "glb_row_kernel_v3.hpp"
 
 namespace glb {
 // launchers exported by the nine glb_row_tu.hip translation units (dtype x mode)
@@ -21,6 +21,10 @@ GLB_DECL(0, 0) GLB_DECL(0, 1) GLB_DECL(0, 2)
 GLB_DECL(1, 0) GLB_DECL(1, 1) GLB_DECL(1, 2)
 GLB_DECL(2, 0) GLB_DECL(2, 1) GLB_DECL(2, 2)
 #undef GLB_DECL
+#define GLB_DECL3(dt, mode) \
+  hipError_t launch_row3_##dt##_##mode(const V3Params &q, int mask_kind, int geom, hipStream_t s);
+GLB_DECL3(0, 0) GLB_DECL3(0, 1) GLB_DECL3(1, 0) GLB_DECL3(1, 1) GLB_DECL3(2, 0) GLB_DECL3(2, 1)
+#undef GLB_DECL3
 }  // namespace glb
 
 namespace {
@@ -378,6 +382,30 @@ inline unsigned blocks_for(int64_t n, int t) { return (unsigned)((n + t - 1) / t
 
 }  // namespace
 
+static void fill_row_params(glb::RowParams &p, const glb_step_args *a) {
+  p.logits = a->logits;
+  p.ld = a->ld;
+  p.V = (int32_t)a->vocab;
+  p.use_scale = a->logit_scale != 1.0f;
+  p.scale = a->logit_scale;
+  p.n_particles = (int32_t)a->n_particles;
+  p.row_of = a->row_of;
+  p.mask = a->mask;
+  p.mask_ld = a->mask_ld;
+  p.mask_id = a->mask_id;
+  p.n_masks = (int32_t)a->n_masks;
+  p.noise = a->noise;
+  p.noise_ld = a->noise_ld;
+  p.seed = a->seed;
+  p.offset = a->offset;
+  p.particle_base = a->particle_base;
+  p.out_logZ = a->out_logZ;
+  p.out_lse = a->out_lse;
+  p.out_token = a->out_token;
+  p.out_logprobs = nullptr;
+  p.out_ld = 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
@@ -403,7 +431,8 @@ int glb_device_count(void) {
 
 size_t glb_step_workspace_bytes(int64_t n_particles) {
   if (n_particles <= 0) return 0;
-  return (size_t)n_particles * (66 * sizeof(uint64_t) + 2 * sizeof(float)) + 16;
+  // max over the v2 layout (66 u64 + 2 f32 per particle) and the v3 layout (8 + 64 u64 + 2 f32, + timeout)
+  return (size_t)n_particles * (72 * sizeof(uint64_t) + 2 * sizeof(float)) + 64;
 }
 
 int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
@@ -445,11 +474,46 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
   int geom = 0;
   const bool v2_ok = a->workspace && a->mask_kind != GLB_MASK_F32 && a->rng_mode != GLB_RNG_NOISE &&
                      (a->variant == 0 || a->variant >= 21);
+  // (the workspace must have been zeroed once by the caller: the split-row kernel's granules live in it)
   if (v2_ok) {
     if (a->workspace_bytes < glb_step_workspace_bytes(a->n_particles))
       return fail(GLB_ENOSPC, "workspace %zu < %zu bytes", a->workspace_bytes,
                   glb_step_workspace_bytes(a->n_particles));
     if (((uintptr_t)a->workspace) % 16) return fail(GLB_EINVAL, "workspace not 16-byte aligned");
+    // cooperative split-row kernel: needs enough particles to fill its 4-stage pipeline
+    const int epv3 = a->dtype == GLB_F32 ? 4 : 8;
+    const int64_t nv_max3 = (a->vocab + 2 * (epv3 - 1)) / epv3;
+    const int64_t q_max3 = (nv_max3 + 3) / 4;
+    int g3 = 0;
+    if (q_max3 <= 512 * 7) g3 = 31;
+    else if (q_max3 <= 512 * 8) g3 = 32;
+    const bool want3 = a->variant == 31 || a->variant == 32 || (a->variant == 0 && a->n_particles >= 2 * num_cus());
+    if (want3 && g3 && (a->variant == 0 || a->variant == g3 || (a->variant == 32 && g3 == 31))) {
+      if (a->variant == 32) g3 = 32;
+      glb::V3Params q{};
+      fill_row_params(q.rp, a);
+      char *w = (char *)a->workspace;
+      q.xch = (unsigned long long *)w;
+      q.wave_sums = (uint64_t *)(w + (size_t)a->n_particles * 8 * sizeof(uint64_t));
+      q.row_exps = (float *)(w + (size_t)a->n_particles * 72 * sizeof(uint64_t));
+      q.timeout = (unsigned int *)(w + (size_t)a->n_particles * (72 * sizeof(uint64_t) + 2 * sizeof(float)));
+      int ncl = num_cus() / 4;
+      if (ncl > a->n_particles) ncl = (int)a->n_particles;
+      q.n_clusters = ncl;
+      hipError_t e3 = hipErrorInvalidValue;
+      switch (a->dtype * 2 + (a->rng_mode == GLB_RNG_PHILOX ? 1 : 0)) {
+        case 0: e3 = glb::launch_row3_0_0(q, a->mask_kind, g3, (hipStream_t)stream); break;
+        case 1: e3 = glb::launch_row3_0_1(q, a->mask_kind, g3, (hipStream_t)stream); break;
+        case 2: e3 = glb::launch_row3_1_0(q, a->mask_kind, g3, (hipStream_t)stream); break;
+        case 3: e3 = glb::launch_row3_1_1(q, a->mask_kind, g3, (hipStream_t)stream); break;
+        case 4: e3 = glb::launch_row3_2_0(q, a->mask_kind, g3, (hipStream_t)stream); break;
+        case 5: e3 = glb::launch_row3_2_1(q, a->mask_kind, g3, (hipStream_t)stream); break;
+      }
+      if (e3 != hipSuccess) return hip_fail(e3, "row_kernel_v3 launch");
+      return GLB_OK;
+    }
+    if (a->variant == 31 || a->variant == 32)
+      return fail(GLB_EINVAL, "variant %d cannot hold vocab %lld", a->variant, (long long)a->vocab);
     const int g2 = pick_geom2(a->vocab, a->dtype, a->variant);
     if (g2) {
       int64_t grid = a->n_particles < num_cus() ? a->n_particles : num_cus();
@@ -471,27 +535,7 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
   }
 
   glb::RowParams p{};
-  p.logits = a->logits;
-  p.ld = a->ld;
-  p.V = (int32_t)a->vocab;
-  p.use_scale = a->logit_scale != 1.0f;
-  p.scale = a->logit_scale;
-  p.n_particles = (int32_t)a->n_particles;
-  p.row_of = a->row_of;
-  p.mask = a->mask;
-  p.mask_ld = a->mask_ld;
-  p.mask_id = a->mask_id;
-  p.n_masks = (int32_t)a->n_masks;
-  p.noise = a->noise;
-  p.noise_ld = a->noise_ld;
-  p.seed = a->seed;
-  p.offset = a->offset;
-  p.particle_base = a->particle_base;
-  p.out_logZ = a->out_logZ;
-  p.out_lse = a->out_lse;
-  p.out_token = a->out_token;
-  p.out_logprobs = nullptr;
-  p.out_ld = 0;
+  fill_row_params(p, a);
   if (a->workspace) {
     p.chunk_sums = (uint64_t *)a->workspace;
     p.row_sums = p.chunk_sums + (size_t)a->n_particles * 64;

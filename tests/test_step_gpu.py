@@ -120,8 +120,14 @@ def test_log_softmax_rows(engine, oracle):
 
 V2_CASES = [
     # (n_particles, n_rows, V, dtype, variant)   variant: 21 fp32 <= 51196, 22 small rows, 23 16-bit <= 131064
+    #                                             31 / 32: cooperative split-row kernel (4 workgroups per row)
     (700, 300, 50257, "f32", 21),
-    (513, 513, 50257, "f32", 0),
+    (700, 300, 50257, "f32", 31),
+    (1024, 1024, 50257, "f32", 0),
+    (300, 100, 128256, "bf16", 32),
+    (9, 9, 1000, "f32", 31),
+    (130, 40, 65001, "f16", 31),
+    (513, 513, 50257, "f32", 21),
     (300, 300, 30001, "f32", 22),
     (300, 100, 128256, "bf16", 23),
     (260, 260, 65001, "f16", 22),
