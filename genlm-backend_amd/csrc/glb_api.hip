@@ -487,7 +487,8 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
     int g3 = 0;
     if (q_max3 <= 512 * 7) g3 = 31;
     else if (q_max3 <= 512 * 8) g3 = 32;
-    const bool want3 = a->variant == 31 || a->variant == 32 || (a->variant == 0 && a->n_particles >= 2 * num_cus());
+    // measured slower than v2 at 1024 x 50257 (fixed per-item latencies are paid 4x as often): opt-in only
+    const bool want3 = a->variant == 31 || a->variant == 32;
     if (want3 && g3 && (a->variant == 0 || a->variant == g3 || (a->variant == 32 && g3 == 31))) {
       if (a->variant == 32) g3 = 32;
       glb::V3Params q{};
@@ -514,7 +515,10 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
     }
     if (a->variant == 31 || a->variant == 32)
       return fail(GLB_EINVAL, "variant %d cannot hold vocab %lld", a->variant, (long long)a->vocab);
-    const int g2 = pick_geom2(a->vocab, a->dtype, a->variant);
+    int g2 = pick_geom2(a->vocab, a->dtype, a->variant);
+    // auto: the persistent kernel only pays off with >= 3 rows per CU and rows that need the big geometry
+    // (measured: 1024 x 50257 fp32 91 vs 96 us, 2048 rows 147 vs 163 us; 512 x 128256 bf16 118 vs 92 us)
+    if (a->variant == 0 && !(g2 == 21 && a->n_particles >= 3 * (int64_t)num_cus())) g2 = 0;
     if (g2) {
       int64_t grid = a->n_particles < num_cus() ? a->n_particles : num_cus();
       if (const char *g = getenv("GLB_V2_GRID")) {  // tuning knob: persistent workgroups to launch

@@ -130,6 +130,7 @@ __global__ __launch_bounds__(T) void row_kernel(const RowParams p) {
   constexpr int ES = ElemTraits<DT>::ES;
   constexpr int W = T / 64;
   constexpr int MBW = (NVL * EPV + 31) / 32;
+  constexpr bool kPhiloxMode = MODE == kModePhilox;
   constexpr bool kPhilox = MODE == kModePhilox;
   constexpr bool kNoise = MODE == kModeNoise;
 
@@ -291,6 +292,40 @@ __global__ __launch_bounds__(T) void row_kernel(const RowParams p) {
     for (int k = 0; k < NVL; ++k) opaque(raw[k]);
     uint32_t v0b = (uint32_t)v0;
     opaque(v0b);
+    if constexpr (MASK != kMaskF32 && MODE != kModeNoise) {
+      // hand-interleaved exp split (glb_math.hpp exp_fix4): same roundings, 4 chains in lock step
+#pragma unroll
+      for (int k = 0; k < NVL; ++k) {
+        uint64_t ak = 0;
+        float xk[EPV];
+        unpack_vec<DT>(raw[k], xk);
+        if (p.use_scale) {
+#pragma unroll
+          for (int c = 0; c < EPV; ++c) xk[c] = xk[c] * p.scale;
+        }
+#pragma unroll
+        for (int h = 0; h < EPV / 4; ++h) {
+          uint32_t pf[4], sh[4];
+          exp_fix4(xk[4 * h], xk[4 * h + 1], xk[4 * h + 2], xk[4 * h + 3], Nb_cur, pf, sh);
+#pragma unroll
+          for (int c4 = 0; c4 < 4; ++c4) {
+            const int c = 4 * h + c4;
+            const uint64_t q = ((uint64_t)pf[c4] << 32) >> sh[c4];
+            acc += q;
+            if constexpr (MASK == kMaskBits) {
+              ak += mask_u64(q, bit_fill(mb[(k * EPV + c) >> 5], (k * EPV + c) & 31));
+            } else if constexpr (kPhiloxMode) {
+              ak += q;
+            }
+          }
+        }
+        s_msk += ak;
+        if constexpr (kPhiloxMode) s_asum[k * T + tid] = ak;
+        opaque(s_msk);
+        opaque(acc);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
 #pragma unroll
     for (int k = 0; k < NVL; ++k) {
       uint64_t ak = 0;
@@ -336,6 +371,7 @@ __global__ __launch_bounds__(T) void row_kernel(const RowParams p) {
       if constexpr (kPhilox) s_asum[k * T + tid] = ak;
       // one vector at a time: without this the scheduler interleaves many vectors and spills
       __builtin_amdgcn_sched_barrier(0);
+    }
     }
     if (pass == 0) s_all = acc;
   }
