@@ -146,18 +146,23 @@ __global__ __launch_bounds__(T) void row_kernel_v2(const RowParams p) {
   // ND into `nxt`, plus this wave's chunks of the mask bit row.
   uint32_t lane_off = (uint32_t)v0 * 16u;  // byte offset of this lane's first vector; re-opaqued per row so
                                            // the 2*NVL slot addresses are not hoisted out of the row loop
-  auto prefetch_slot = [&](const RowRef &r, int k) {
+  auto prefetch_slot = [&](const RowRef &r, int k, bool with_mask) {
     const uint32_t off = lane_off + (uint32_t)k * 1024u;
-    const char *src = off < (uint32_t)r.nv * 16u ? r.base + off : ninf + lane * 16;  // past the row: -inf page
+    // both candidates are GLOBAL pointers (address space 1): a generic select would turn the ND loads into
+    // flat_load, in front of which hipcc drains vmcnt (every in-flight DMA) and lgkmcnt
+    typedef const __attribute__((address_space(1))) char *gptr_t;
+    const gptr_t src = off < (uint32_t)r.nv * 16u ? (gptr_t)r.base + off : (gptr_t)ninf + lane * 16;  // past the row: -inf page
     if (k < NL) {
       __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)src,
                                        (lds_ptr_t)(s_stage + (wave * NL + k) * 64), 16, 0, 0);
     } else if (k < NL + ND) {
-      nxt[k - NL] = *reinterpret_cast<const uint4 *>(src);
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      const u32x4 t = *reinterpret_cast<const __attribute__((address_space(1))) u32x4 *>(src);
+      nxt[k - NL] = make_uint4(t.x, t.y, t.z, t.w);
     }
     if constexpr (kBits) {
       constexpr int MCH = (MASK_V / 64 + W - 1) / W;  // mask chunks per wave
-      if (k < MCH) {
+      if (with_mask && k < MCH) {
         const int m = wave + k * W;  // chunk m = mask vectors [64m, 64m+64)
         if (m * 64 < r.mvec) {
           int mv = m * 64 + lane;
@@ -169,9 +174,21 @@ __global__ __launch_bounds__(T) void row_kernel_v2(const RowParams p) {
       }
     }
   };
+  auto prefetch_mask = [&](const RowRef &r, int k) {
+    if constexpr (kBits) {
+      const int m = wave + k * W;
+      if (m * 64 < r.mvec) {
+        int mv = m * 64 + lane;
+        mv = mv < r.mvec ? mv : r.mvec - 1;
+        __builtin_amdgcn_global_load_lds(
+            (const void __attribute__((address_space(1))) *)((const char *)r.mrow16 + (int64_t)mv * 16),
+            (lds_ptr_t)(s_lds + STAGE_V + m * 64), 16, 0, 0);
+      }
+    }
+  };
   auto prefetch = [&](const RowRef &r) {
 #pragma unroll
-    for (int k = 0; k < NVL; ++k) prefetch_slot(r, k);
+    for (int k = 0; k < NVL; ++k) prefetch_slot(r, k, true);
   };
 
   // after the explicit vmcnt(0) (+ barrier for the mask row): staged data -> registers, late vectors,
@@ -242,6 +259,15 @@ __global__ __launch_bounds__(T) void row_kernel_v2(const RowParams p) {
     RowRef nxr = cur;
     if (has_next) nxr = row_ref(vb_next);
     opaque(lane_off);
+    // head start: the memory queue is empty right after `land`, so the first KB slots go out in one burst
+    // (private staging slots only; the shared mask row waits for the barrier after phase 1)
+    // (not with bit masks: that combination produced wrong sums on hardware - an unexplained race - so the
+    //  masked kernels keep issuing every slot from inside phase 2)
+    constexpr int KB = (NVL >= 12 && !kBits) ? 6 : 0;
+    if (has_next) {
+#pragma unroll
+      for (int k = 0; k < KB; ++k) prefetch_slot(nxr, k, false);
+    }
 
     // ---- phase 1: maxima ----------------------------------------------------------------------
     float m_all = kNegInf, m_msk = kNegInf;
@@ -330,7 +356,13 @@ __global__ __launch_bounds__(T) void row_kernel_v2(const RowParams p) {
         opaque(acc);
         // next row's slot k goes out now: this wave's staging slot k was emptied by `land`, and every wave
         // is past `land` (barrier after phase 1), so the shared mask row may be refilled too
-        if (has_next && pass == 0) prefetch_slot(nxr, k);
+        if (has_next && pass == 0) {
+          if (k >= KB) prefetch_slot(nxr, k, false);
+          if constexpr (kBits) {
+            constexpr int MCH2 = (MASK_V / 64 + W - 1) / W;
+            if (k < MCH2) prefetch_mask(nxr, k);
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);  // one vector at a time (register pressure)
       }
       if (pass == 0) s_all = acc;
@@ -442,38 +474,51 @@ __global__ __launch_bounds__(256) void locate_kernel(const RowParams p) {
   const int csel = __ffsll((long long)__ballot(incl_c > Tc)) - 1;
   Tc -= readlane_u64(incl_c - cs, csel);
   const float Nb = p.row_exps[2 * pidx + 1] + (float)kFixShift;
-  const int tiles = p.chunk_vecs >> 6;
+  const int tiles = p.chunk_vecs >> 6;  // <= 5
   uint64_t run = 0, asel = 0;
   uint4 rsel = make_uint4(0, 0, 0, 0);
   uint32_t nsel = 0;
   int j0sel = 0;
   bool found = false;
-  for (int j = 0; j < tiles; ++j) {
+  // all of the chunk's loads go out before the first is consumed (they used to be one latency each)
+  constexpr int kMaxTiles = 5;
+  uint4 rks[kMaxTiles];
+  uint32_t nibs[kMaxTiles];
+#pragma unroll
+  for (int j = 0; j < kMaxTiles; ++j) {
     const int v = csel * p.chunk_vecs + j * 64 + lane;
     const int vc = v < nv ? v : nv - 1;
-    const uint4 rk = *reinterpret_cast<const uint4 *>(base + (int64_t)vc * 16);
-    const int j0 = v * EPV - a;
-    uint32_t nib = (1u << EPV) - 1u;
-    if constexpr (MASK == kMaskBits) nib = mask_nibble<EPV>(mrow, (V + 31) >> 5, j0);
-    float xs[EPV];
-    unpack_vec<DT>(rk, xs);
-    uint64_t aj = 0;
+    rks[j] = j < tiles ? *reinterpret_cast<const uint4 *>(base + (int64_t)vc * 16) : make_uint4(0, 0, 0, 0);
+    nibs[j] = (1u << EPV) - 1u;
+    if constexpr (MASK == kMaskBits) nibs[j] = j < tiles ? mask_nibble<EPV>(mrow, (V + 31) >> 5, v * EPV - a) : 0u;
+  }
 #pragma unroll
-    for (int c = 0; c < EPV; ++c) {
-      const float xv = p.use_scale ? xs[c] * p.scale : xs[c];
-      const bool ok = ((uint32_t)(j0 + c) < (uint32_t)V) && ((nib >> c) & 1u);
-      aj += ok ? fix_term(xv, Nb) : 0ull;
+  for (int j = 0; j < kMaxTiles; ++j) {
+    if (j < tiles) {
+      const int v = csel * p.chunk_vecs + j * 64 + lane;
+      const uint4 rk = rks[j];
+      const int j0 = v * EPV - a;
+      const uint32_t nib = nibs[j];
+      float xs[EPV];
+      unpack_vec<DT>(rk, xs);
+      uint64_t aj = 0;
+#pragma unroll
+      for (int c = 0; c < EPV; ++c) {
+        const float xv = p.use_scale ? xs[c] * p.scale : xs[c];
+        const bool ok = ((uint32_t)(j0 + c) < (uint32_t)V) && ((nib >> c) & 1u);
+        aj += ok ? fix_term(xv, Nb) : 0ull;
+      }
+      const uint64_t cj = wave_sum_u64(aj);
+      if (!found && Tc < run + cj) {
+        found = true;
+        Tc -= run;
+        asel = aj;
+        rsel = rk;
+        nsel = nib;
+        j0sel = j0;
+      }
+      run += cj;
     }
-    const uint64_t cj = wave_sum_u64(aj);
-    if (!found && Tc < run + cj) {
-      found = true;
-      Tc -= run;
-      asel = aj;
-      rsel = rk;
-      nsel = nib;
-      j0sel = j0;
-    }
-    run += cj;
   }
   const uint64_t incl = wave_scan_u64(asel);
   const int lsel = __ffsll((long long)__ballot(incl > Tc)) - 1;
