@@ -292,7 +292,9 @@ __global__ __launch_bounds__(T) void row_kernel(const RowParams p) {
     for (int k = 0; k < NVL; ++k) opaque(raw[k]);
     uint32_t v0b = (uint32_t)v0;
     opaque(v0b);
-    if constexpr (MASK != kMaskF32 && MODE != kModeNoise) {
+    // (measured: with 4 waves per SIMD the hand-interleaved exp_fix4 is SLOWER here - 105.7 vs 95.8 us on the
+    //  1024 x 50257 masked case; the hardware already hides the dependent chains.  Kept for reference.)
+    if constexpr (false && MASK != kMaskF32 && MODE != kModeNoise) {
       // hand-interleaved exp split (glb_math.hpp exp_fix4): same roundings, 4 chains in lock step
 #pragma unroll
       for (int k = 0; k < NVL; ++k) {
