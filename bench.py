@@ -58,7 +58,7 @@ def cpu_baseline(workload, sample_rows, seed=1234):
     if workload == "sis":
         from transformers import GPT2Config, GPT2LMHeadModel
 
-        rows = min(sample_rows, 64)
+        rows = min(sample_rows, 512)
         torch.manual_seed(seed)
         model = GPT2LMHeadModel(GPT2Config()).eval()
         ids = torch.randint(0, V_GPT2, (rows, 13))  # mid-loop context length: prompt 8 + 5 generated
