@@ -56,7 +56,7 @@ int pick_geom(int64_t vocab, int dtype, int variant) {
   if (variant > 0) {
     for (const Geom &g : kGeoms)
       if (g.id == variant) return (int64_t)g.threads * g.nvl >= nv_max ? g.id : -1;
-    return -1;
+    return variant == 99 ? 0 : -1;
   }
   for (const Geom &g : kGeoms)
     if ((int64_t)g.threads * g.nvl >= nv_max) return g.id;
@@ -473,7 +473,7 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
   // persistent pipelined kernel when the caller lent a workspace and the mode allows it
   int geom = 0;
   const bool v2_ok = a->workspace && a->mask_kind != GLB_MASK_F32 && a->rng_mode != GLB_RNG_NOISE &&
-                     (a->variant == 0 || a->variant >= 21);
+                     (a->variant == 0 || (a->variant >= 21 && a->variant != 99));
   // (the workspace must have been zeroed once by the caller: the split-row kernel's granules live in it)
   if (v2_ok) {
     if (a->workspace_bytes < glb_step_workspace_bytes(a->n_particles))
@@ -528,14 +528,18 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
       geom = g2 | ((int)grid << 8);
     }
   }
-  if (a->variant >= 21 && geom == 0)
+  if (a->variant >= 21 && a->variant != 99 && geom == 0)
     return fail(GLB_EINVAL, "variant %d needs a workspace, mask none/bits and rng none/philox", a->variant);
   if (geom == 0) {
     geom = pick_geom(a->vocab, a->dtype, a->variant);
     if (geom < 0) return fail(GLB_EINVAL, "variant %d cannot hold vocab %lld", a->variant, (long long)a->vocab);
-    if (geom == 0)
-      return fail(GLB_EUNSUPPORTED, "vocab %lld too large for the register-resident row kernel",
-                  (long long)a->vocab);
+    if (geom == 0 || a->variant == 99) {
+      // rows beyond the register-resident capacity: streaming multi-pass kernel (mask none/bits, no noise mode)
+      if (a->mask_kind == GLB_MASK_F32 || a->rng_mode == GLB_RNG_NOISE)
+        return fail(GLB_EUNSUPPORTED, "vocab %lld needs the streaming kernel, which supports mask none/bits and "
+                    "rng none/philox only", (long long)a->vocab);
+      geom = 99;
+    }
   }
 
   glb::RowParams p{};
@@ -560,9 +564,8 @@ int glb_log_softmax_rows(const void *logits, int32_t dtype, int64_t n_rows, int6
   if (!out && !out_lse) return fail(GLB_EINVAL, "no output requested");
   if (vocab > 0x7fffff00ll || n_rows > 0x7fffffffll) return fail(GLB_EINVAL, "size exceeds 31 bits");
   if (out && ((uintptr_t)out) % 4) return fail(GLB_EINVAL, "out pointer not 4-byte aligned");
-  const int geom = pick_geom(vocab, dtype, 0);
-  if (geom == 0)
-    return fail(GLB_EUNSUPPORTED, "vocab %lld too large for the register-resident row kernel", (long long)vocab);
+  int geom = pick_geom(vocab, dtype, 0);
+  if (geom == 0) geom = 99;  // streaming multi-pass kernel
   glb::RowParams p{};
   p.logits = logits;
   p.ld = ld;

@@ -84,17 +84,32 @@ __global__ __launch_bounds__(512) void row_kernel_v3(const V3Params q) {
 
   uint4 buf[4][NVI];
   uint32_t mbits[4][MW];
+  uint32_t mwords[2][NVI][2];  // the two mask words each tile's bits straddle, fetched with the tile (items s, s-1)
   const char *ninf = (const char *)g_neg_inf_page[DT];
 
   // one load of item `it` (tile k) into buffer B
-  auto load_tile = [&](const Item &it, uint4 (&b)[NVI], int k) {
+  typedef const __attribute__((address_space(1))) char *gptr_t;
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  auto load_tile = [&](const Item &it, uint4 (&b)[NVI], uint32_t (&mw)[NVI][2], int k) {
     const int v = it.vlo + v_item + k * 64;
-    const char *src = v < it.vhi ? it.base + (int64_t)v * 16 : ninf + lane * 16;
-    b[k] = *reinterpret_cast<const uint4 *>(src);
+    const gptr_t src = v < it.vhi ? (gptr_t)it.base + (int64_t)v * 16 : (gptr_t)ninf + lane * 16;
+    const u32x4 t = *reinterpret_cast<const __attribute__((address_space(1))) u32x4 *>(src);
+    b[k] = make_uint4(t.x, t.y, t.z, t.w);
+    if constexpr (kBits) {
+      // words holding bits j0 .. j0+EPV-1 (clamped; bits of out-of-row elements are don't-care)
+      const int j0 = v * EPV - it.a;
+      const int jb = j0 < 0 ? 0 : j0;
+      const int n_words = (V + 31) >> 5;
+      const int wi = jb >> 5;
+      const int w0 = wi < n_words ? wi : n_words - 1, w1 = wi + 1 < n_words ? wi + 1 : n_words - 1;
+      const __attribute__((address_space(1))) uint32_t *mr = (const __attribute__((address_space(1))) uint32_t *)it.mrow;
+      mw[k][0] = mr[w0];
+      mw[k][1] = mr[w1];
+    }
   };
 
   // edge patching (first / last vector of the ROW) + mask bits of the lane's NVI tiles
-  auto prepare = [&](const Item &it, uint4 (&b)[NVI], uint32_t (&mb)[MW]) {
+  auto prepare = [&](const Item &it, uint4 (&b)[NVI], const uint32_t (&mw)[NVI][2], uint32_t (&mb)[MW]) {
     auto patch = [&](uint4 &rk, int first_valid, int n_valid) {
       uint32_t w[4] = {rk.x, rk.y, rk.z, rk.w};
 #pragma unroll
@@ -119,11 +134,12 @@ __global__ __launch_bounds__(512) void row_kernel_v3(const V3Params q) {
 #pragma unroll
     for (int i = 0; i < MW; ++i) mb[i] = kBits ? 0u : 0xffffffffu;
     if constexpr (kBits) {
-      const int n_words = (V + 31) >> 5;
 #pragma unroll
       for (int k = 0; k < NVI; ++k) {
         const int j0 = (it.vlo + v_item + k * 64) * EPV - it.a;
-        mb[(k * EPV) >> 5] |= mask_nibble<EPV>(it.mrow, n_words, j0) << ((k * EPV) & 31);
+        const int jb = j0 < 0 ? 0 : j0;
+        const uint32_t f = __builtin_amdgcn_alignbit(mw[k][1], mw[k][0], (uint32_t)(jb & 31));
+        mb[(k * EPV) >> 5] |= ((f << (jb - j0)) & ((1u << EPV) - 1u)) << ((k * EPV) & 31);
       }
     }
   };
@@ -156,6 +172,7 @@ __global__ __launch_bounds__(512) void row_kernel_v3(const V3Params q) {
 
   // ---- software pipeline over steps ---------------------------------------------------------------------
   Item it_load, it_max, it_wait, it_sum;  // items of stage load / max / granules in flight / sums
+  Item it_pre = item_of(0);               // descriptor of the next item to load, fetched a step early
   unsigned long long gran = 0;            // this lane's granule of it_wait (lanes 0..7 of every wave)
 
   auto step = [&](auto S_tag, int s) {
@@ -165,7 +182,8 @@ __global__ __launch_bounds__(512) void row_kernel_v3(const V3Params q) {
     uint4(&b_sum)[NVI] = buf[(S + 1) & 3];
     const bool do_load = s < R, do_max = s >= 1 && s - 1 < R, do_wait = s >= 2 && s - 2 < R,
                do_sum = s >= 3 && s - 3 < R;
-    if (do_load) it_load = item_of(s);
+    if (do_load) it_load = it_pre;
+    if (s + 1 < R) it_pre = item_of(s + 1);  // its scalar loads overlap this step
 
     // (a) cluster-wide exponents of the item whose sums are due: granules were requested last step
     float N_all = 0.f, N_msk = 0.f;
@@ -184,11 +202,14 @@ __global__ __launch_bounds__(512) void row_kernel_v3(const V3Params q) {
         }
         __builtin_amdgcn_s_sleep(2);
       }
-      float mv = lane < 8 ? __uint_as_float((uint32_t)gran) : kNegInf;
       // lanes 0-3: members' row maxima, lanes 4-7: masked maxima
-      mv = fmaxf(mv, __shfl_xor(mv, 1, 64));
-      mv = fmaxf(mv, __shfl_xor(mv, 2, 64));
-      const float g_all = __shfl(mv, 0, 64), g_msk = __shfl(mv, 4, 64);
+      const uint32_t gv = (uint32_t)gran;
+      float g_all = kNegInf, g_msk = kNegInf;
+#pragma unroll
+      for (int m2 = 0; m2 < 4; ++m2) {
+        g_all = fmaxf(g_all, __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)gv, m2)));
+        g_msk = fmaxf(g_msk, __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)gv, 4 + m2)));
+      }
       N_all = __builtin_rintf(g_all * kLog2e);
       N_msk = __builtin_rintf(g_msk * kLog2e);
       if (member == 0 && tid == 0) {
@@ -225,7 +246,7 @@ __global__ __launch_bounds__(512) void row_kernel_v3(const V3Params q) {
         }
         opaque(acc);
         opaque(accm);
-        if (do_load) load_tile(it_load, b_load, k);
+        if (do_load) load_tile(it_load, b_load, mwords[S & 1], k);
         __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (kBits) {
@@ -255,12 +276,12 @@ __global__ __launch_bounds__(512) void row_kernel_v3(const V3Params q) {
       }
     } else if (do_load) {
 #pragma unroll
-      for (int k = 0; k < NVI; ++k) load_tile(it_load, b_load, k);
+      for (int k = 0; k < NVI; ++k) load_tile(it_load, b_load, mwords[S & 1], k);
     }
 
     // (c) local maxima of item s-1 -> granules
     if (do_max) {
-      prepare(it_max, b_max, mbits[(S + 3) & 3]);
+      prepare(it_max, b_max, mwords[(S + 1) & 1], mbits[(S + 3) & 3]);
       float m_all, m_msk;
       local_max(b_max, mbits[(S + 3) & 3], m_all, m_msk);
       if (lane == 0) {

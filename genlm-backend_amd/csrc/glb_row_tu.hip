@@ -2,6 +2,7 @@
 // -DGLB_DT=<0|1|2> -DGLB_MODE=<0|1|2>.  Instantiates the row kernel for every mask kind and launch
 // geometry and exports one launcher that glb_api.hip dispatches to.
 #include "glb_row_kernel_v3.hpp"
+#include "glb_row_stream.hpp"
 
 #ifndef GLB_DT
 #error "GLB_DT not defined"
@@ -107,6 +108,15 @@ hipError_t GLB_CAT3(launch_row3_, GLB_DT, GLB_MODE)(const V3Params &q, int mask_
 hipError_t GLB_CAT(launch_row_, GLB_DT, GLB_MODE)(const RowParams &p, int mask_kind, int geom,
                                                   hipStream_t s) {
 #if GLB_MODE != 2
+  if (geom == 99) {  // streaming fallback for rows beyond the register-resident capacity
+    if (mask_kind == kMaskNone)
+      hipLaunchKernelGGL((row_stream_kernel<GLB_DT, kMaskNone, GLB_MODE>), dim3(p.n_particles), dim3(1024), 0, s, p);
+    else if (mask_kind == kMaskBits)
+      hipLaunchKernelGGL((row_stream_kernel<GLB_DT, kMaskBits, GLB_MODE>), dim3(p.n_particles), dim3(1024), 0, s, p);
+    else
+      return hipErrorInvalidValue;
+    return hipGetLastError();
+  }
   if ((geom & 0xff) >= 21) {
     const int grid = geom >> 8;  // persistent grid size rides in the upper bits
     const int g = geom & 0xff;

@@ -164,3 +164,30 @@ def test_persistent_kernel_bit_exact(engine, oracle, N, U, V, dtype, variant, ma
     logZ1, lse1, tok1 = engine.step(x_t.to(dev), row_of=torch.from_numpy(row_of).to(dev), rng_mode=1, seed=77,
                                     offset=5, particle_base=3, variant=-1, **kw_g)
     assert torch.equal(tok, tok1) and torch.equal(logZ, logZ1) and torch.equal(lse, lse1)
+
+
+@pytest.mark.parametrize("B,V,dtype", [(5, 70001, "f32"), (3, 262144, "bf16"), (4, 151936, "f16"), (6, 1000, "f32")])
+@pytest.mark.parametrize("mask_kind", ["none", "bits"])
+def test_streaming_fallback_bit_exact(engine, oracle, B, V, dtype, mask_kind):
+    """Rows longer than the register-resident capacity (and, forced by variant 99, short ones) take the
+    streaming multi-pass kernel: same bits."""
+    O = oracle
+    x_np, x_t = _mk(O, B, V, dtype, seed=V)
+    dev = engine.device
+    masks = synth.binary_masks(V, 2, V)
+    mid = (np.arange(B) % 2).astype(np.int32)
+    kw_o, kw_g = {}, {}
+    if mask_kind == "bits":
+        bits, _ = O.mask_f32_to_bits(masks)
+        kw_o = dict(mask_kind=O.MASK_BITS, mask=bits, mask_id=mid)
+        kw_g = dict(mask_kind=1, mask=_bits_dev(bits, dev), mask_id=torch.from_numpy(mid).to(dev))
+    logZ_o, lse_o, tok_o = O.step(x_np, rng_mode=O.RNG_PHILOX, seed=5, offset=2, **kw_o)
+    logZ, lse, tok = engine.step(x_t.to(dev), rng_mode=1, seed=5, offset=2, variant=99 if V < 65000 else 0, **kw_g)
+    torch.cuda.synchronize()
+    assert np.array_equal(_np(tok), tok_o)
+    assert np.array_equal(_np(logZ).view(np.uint32), logZ_o.view(np.uint32))
+    assert np.array_equal(_np(lse).view(np.uint32), lse_o.view(np.uint32))
+    if dtype == "f32":
+        want, _ = O.log_softmax_rows(x_np)
+        got = engine.log_softmax_rows(x_t.to(dev))
+        assert np.array_equal(_np(got).view(np.uint32), want.view(np.uint32))
