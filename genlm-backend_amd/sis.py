@@ -23,6 +23,30 @@ RNG_PHILOX, RNG_NOISE = 1, 2
 
 
 # ------------------------------------------------------------------------------------------------
+# mask builders (README.md:57-70)
+# ------------------------------------------------------------------------------------------------
+def make_masks(llm, max_token_length):
+    """The two shared log-masks of the README example, registered with the backend as mask 0 and 1:
+       mask 0 (`valid_ids.log()`): 0 for EOS and for tokens of at most `max_token_length` bytes, -inf otherwise;
+       mask 1 (`eos_one_hot.log()`): 0 for EOS only.
+    `mask_selector(context)` of `make_masking_function` picks 1 once `len(context) >= max_tokens`."""
+    eos_id = llm.tokenizer.eos_token_id
+    V = len(llm.byte_vocab)
+    valid = torch.tensor([tid == eos_id or len(tok) <= max_token_length for tid, tok in enumerate(llm.byte_vocab)],
+                         dtype=torch.float).log()
+    eos_one_hot = torch.nn.functional.one_hot(torch.tensor(eos_id), V).log()
+    masks = torch.stack([valid, eos_one_hot.to(torch.float)])
+    llm.register_masks(masks)
+    return masks
+
+
+def make_masking_function(llm, max_token_length, max_tokens):
+    """README.md:57-70 shaped for the fused API: returns the mask *index* for a context."""
+    make_masks(llm, max_token_length)
+    return lambda context: 1 if len(context) >= max_tokens else 0
+
+
+# ------------------------------------------------------------------------------------------------
 # README-shaped driver (asyncio, one coroutine per particle)
 # ------------------------------------------------------------------------------------------------
 class Particle:
