@@ -11,7 +11,7 @@
 #include <string>
 
 #include "../../include/glb.h"
-#include "glb_row_kernel_v3.hpp"
+#include "glb_row_kernel.hpp"
 
 namespace glb {
 // launchers exported by the nine glb_row_tu.hip translation units (dtype x mode)
@@ -21,10 +21,6 @@ GLB_DECL(0, 0) GLB_DECL(0, 1) GLB_DECL(0, 2)
 GLB_DECL(1, 0) GLB_DECL(1, 1) GLB_DECL(1, 2)
 GLB_DECL(2, 0) GLB_DECL(2, 1) GLB_DECL(2, 2)
 #undef GLB_DECL
-#define GLB_DECL3(dt, mode) \
-  hipError_t launch_row3_##dt##_##mode(const V3Params &q, int mask_kind, int geom, hipStream_t s);
-GLB_DECL3(0, 0) GLB_DECL3(0, 1) GLB_DECL3(1, 0) GLB_DECL3(1, 1) GLB_DECL3(2, 0) GLB_DECL3(2, 1)
-#undef GLB_DECL3
 }  // namespace glb
 
 namespace {
@@ -431,7 +427,7 @@ int glb_device_count(void) {
 
 size_t glb_step_workspace_bytes(int64_t n_particles) {
   if (n_particles <= 0) return 0;
-  // max over the v2 layout (66 u64 + 2 f32 per particle) and the v3 layout (8 + 64 u64 + 2 f32, + timeout)
+  // 64 chunk sums + 2 row sums (u64) and 2 exponents (f32) per particle, with headroom
   return (size_t)n_particles * (72 * sizeof(uint64_t) + 2 * sizeof(float)) + 64;
 }
 
@@ -474,47 +470,11 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
   int geom = 0;
   const bool v2_ok = a->workspace && a->mask_kind != GLB_MASK_F32 && a->rng_mode != GLB_RNG_NOISE &&
                      (a->variant == 0 || (a->variant >= 21 && a->variant != 99));
-  // (the workspace must have been zeroed once by the caller: the split-row kernel's granules live in it)
   if (v2_ok) {
     if (a->workspace_bytes < glb_step_workspace_bytes(a->n_particles))
       return fail(GLB_ENOSPC, "workspace %zu < %zu bytes", a->workspace_bytes,
                   glb_step_workspace_bytes(a->n_particles));
     if (((uintptr_t)a->workspace) % 16) return fail(GLB_EINVAL, "workspace not 16-byte aligned");
-    // cooperative split-row kernel: needs enough particles to fill its 4-stage pipeline
-    const int epv3 = a->dtype == GLB_F32 ? 4 : 8;
-    const int64_t nv_max3 = (a->vocab + 2 * (epv3 - 1)) / epv3;
-    const int64_t q_max3 = (nv_max3 + 3) / 4;
-    int g3 = 0;
-    if (q_max3 <= 512 * 7) g3 = 31;
-    else if (q_max3 <= 512 * 8) g3 = 32;
-    // measured slower than v2 at 1024 x 50257 (fixed per-item latencies are paid 4x as often): opt-in only
-    const bool want3 = a->variant == 31 || a->variant == 32;
-    if (want3 && g3 && (a->variant == 0 || a->variant == g3 || (a->variant == 32 && g3 == 31))) {
-      if (a->variant == 32) g3 = 32;
-      glb::V3Params q{};
-      fill_row_params(q.rp, a);
-      char *w = (char *)a->workspace;
-      q.xch = (unsigned long long *)w;
-      q.wave_sums = (uint64_t *)(w + (size_t)a->n_particles * 8 * sizeof(uint64_t));
-      q.row_exps = (float *)(w + (size_t)a->n_particles * 72 * sizeof(uint64_t));
-      q.timeout = (unsigned int *)(w + (size_t)a->n_particles * (72 * sizeof(uint64_t) + 2 * sizeof(float)));
-      int ncl = num_cus() / 4;
-      if (ncl > a->n_particles) ncl = (int)a->n_particles;
-      q.n_clusters = ncl;
-      hipError_t e3 = hipErrorInvalidValue;
-      switch (a->dtype * 2 + (a->rng_mode == GLB_RNG_PHILOX ? 1 : 0)) {
-        case 0: e3 = glb::launch_row3_0_0(q, a->mask_kind, g3, (hipStream_t)stream); break;
-        case 1: e3 = glb::launch_row3_0_1(q, a->mask_kind, g3, (hipStream_t)stream); break;
-        case 2: e3 = glb::launch_row3_1_0(q, a->mask_kind, g3, (hipStream_t)stream); break;
-        case 3: e3 = glb::launch_row3_1_1(q, a->mask_kind, g3, (hipStream_t)stream); break;
-        case 4: e3 = glb::launch_row3_2_0(q, a->mask_kind, g3, (hipStream_t)stream); break;
-        case 5: e3 = glb::launch_row3_2_1(q, a->mask_kind, g3, (hipStream_t)stream); break;
-      }
-      if (e3 != hipSuccess) return hip_fail(e3, "row_kernel_v3 launch");
-      return GLB_OK;
-    }
-    if (a->variant == 31 || a->variant == 32)
-      return fail(GLB_EINVAL, "variant %d cannot hold vocab %lld", a->variant, (long long)a->vocab);
     int g2 = pick_geom2(a->vocab, a->dtype, a->variant);
     // auto: the persistent kernel only pays off with >= 3 rows per CU and rows that need the big geometry
     // (measured: 1024 x 50257 fp32 91 vs 96 us, 2048 rows 147 vs 163 us; 512 x 128256 bf16 118 vs 92 us)

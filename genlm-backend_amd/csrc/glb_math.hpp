@@ -15,6 +15,8 @@ constexpr float kLn2Hi = __builtin_bit_cast(float, 0x3F317200u);  // 0.693145752
 constexpr float kLn2Lo = __builtin_bit_cast(float, 0x35BFBE8Eu);  // 1.42860677e-06
 constexpr int kFixShift = 18;  // S = sum floor(P * 2^32 >> (18 + N - n)), 44 fractional bits
 constexpr int kFixFrac = 44;
+// masked sums stay on the row's scale unless that leaves them fewer than 37 significant bits
+constexpr uint64_t kLowMass = 1ull << 37;
 constexpr double kLn2D = 0.693147180559945309417232121458;
 constexpr float kNegInf = -__builtin_huge_valf();
 

@@ -111,6 +111,7 @@ __device__ __forceinline__ void opaque(uint4 &r) {
 __device__ __forceinline__ void opaque(uint32_t &r) { asm volatile("" : "+v"(r)); }
 
 __device__ __forceinline__ void opaque(uint64_t &r) { asm volatile("" : "+v"(r)); }
+__device__ __forceinline__ void opaque(float &r) { asm volatile("" : "+v"(r)); }
 
 // q gated by an all-ones / all-zeros word, half by half (a 64-bit `q & splat(fill)` is turned into a
 // 64-bit multiply by 0x100000001 by instcombine)
@@ -259,75 +260,34 @@ __global__ __launch_bounds__(T) void row_kernel(const RowParams p) {
   const float N_all = __builtin_rintf(m_all * kLog2e);
   const float N_msk = __builtin_rintf(m_msk * kLog2e);
   const float Nb_all = N_all + (float)kFixShift, Nb_msk = N_msk + (float)kFixShift;
-  // When the masked maximum has the same exponent as the row maximum (the usual case: the top
-  // token is allowed) the masked terms are the unmasked terms gated by the mask bit.
-  const bool same_n = (N_all == N_msk);
+  // Masked sums (GLB math): on the row's scale N_all - there the masked term of a bit mask is the
+  // unmasked term gated by the mask bit - unless the masked maximum lies above it (additive masks only)
+  // or the result keeps fewer than 37 bits (allowed mass < 2^-7 of the row; block-uniform, rare): then
+  // the loop body runs a second time on the masked maximum's own scale N_msk.
+  const bool over = (MASK == kMaskF32) && (N_msk > N_all);
+  float Nb_m = over ? Nb_msk : Nb_all;  // scale of the masked terms in this pass
+  float N_fin = over ? N_msk : N_all;   // ... and of the masked sum finally kept
 
   // ---- phase 2: fixed-point sums (+ race / per-tile partial sums) ----------------------------------
-  uint64_t s_all = 0, s_msk = 0;
+  uint64_t S_all = 0, S_msk = 0;
   float best_g = -1.0f;
   int32_t best_j = 0x7fffffff;
   const float *noise_row = nullptr;
   if constexpr (kNoise) noise_row = p.noise + (int64_t)pidx * p.noise_ld;
-  // keep the compiler from carrying the per-element bit fills of phase 1 across the barrier (50+
-  // VGPRs): make the packed mask words opaque so the fills are re-derived from them in phase 2
-#pragma unroll
-  for (int i = 0; i < MBW; ++i) opaque(mb[i]);
-#pragma unroll
-  for (int k = 0; k < NVL; ++k) opaque(raw[k]);
-
-  // Bit masks: the masked term equals the unmasked term gated by the mask bit whenever
-  // N_msk == N_all (the usual case).  Otherwise (top token forbidden, block-uniform and rare) the
-  // same loop body runs a second time against N_msk; only its masked sums are kept.
-  const int n_pass = (MASK == kMaskBits && !same_n) ? 2 : 1;
 #pragma unroll 1
-  for (int pass = 0; pass < n_pass; ++pass) {
-    const float Nb_cur = pass == 0 ? Nb_all : Nb_msk;
-    uint64_t acc = 0;
-    s_msk = 0;
-    // defeat loop-invariant hoisting of the per-element exp splits / bit fills (100+ VGPRs)
+  for (int pass = 0;; ++pass) {
+    const float Nb_q = (MASK == kMaskF32) ? Nb_all : Nb_m;
+    uint64_t acc = 0, s_msk = 0;
+    // defeat loop-invariant hoisting of the per-element exp splits / bit fills (100+ VGPRs), and keep the
+    // compiler from carrying the per-element bit fills of phase 1 across the barrier (50+ VGPRs)
 #pragma unroll
     for (int i = 0; i < MBW; ++i) opaque(mb[i]);
 #pragma unroll
     for (int k = 0; k < NVL; ++k) opaque(raw[k]);
     uint32_t v0b = (uint32_t)v0;
     opaque(v0b);
-    // (measured: with 4 waves per SIMD the hand-interleaved exp_fix4 is SLOWER here - 105.7 vs 95.8 us on the
-    //  1024 x 50257 masked case; the hardware already hides the dependent chains.  Kept for reference.)
-    if constexpr (false && MASK != kMaskF32 && MODE != kModeNoise) {
-      // hand-interleaved exp split (glb_math.hpp exp_fix4): same roundings, 4 chains in lock step
-#pragma unroll
-      for (int k = 0; k < NVL; ++k) {
-        uint64_t ak = 0;
-        float xk[EPV];
-        unpack_vec<DT>(raw[k], xk);
-        if (p.use_scale) {
-#pragma unroll
-          for (int c = 0; c < EPV; ++c) xk[c] = xk[c] * p.scale;
-        }
-#pragma unroll
-        for (int h = 0; h < EPV / 4; ++h) {
-          uint32_t pf[4], sh[4];
-          exp_fix4(xk[4 * h], xk[4 * h + 1], xk[4 * h + 2], xk[4 * h + 3], Nb_cur, pf, sh);
-#pragma unroll
-          for (int c4 = 0; c4 < 4; ++c4) {
-            const int c = 4 * h + c4;
-            const uint64_t q = ((uint64_t)pf[c4] << 32) >> sh[c4];
-            acc += q;
-            if constexpr (MASK == kMaskBits) {
-              ak += mask_u64(q, bit_fill(mb[(k * EPV + c) >> 5], (k * EPV + c) & 31));
-            } else if constexpr (kPhiloxMode) {
-              ak += q;
-            }
-          }
-        }
-        s_msk += ak;
-        if constexpr (kPhiloxMode) s_asum[k * T + tid] = ak;
-        opaque(s_msk);
-        opaque(acc);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {
+    // (measured: with 4 waves per SIMD the hand-interleaved exp_fix4 of glb_math.hpp is SLOWER here - 105.7
+    //  vs 95.8 us on the 1024 x 50257 masked case; the hardware already hides the dependent chains.)
 #pragma unroll
     for (int k = 0; k < NVL; ++k) {
       uint64_t ak = 0;
@@ -338,7 +298,7 @@ __global__ __launch_bounds__(T) void row_kernel(const RowParams p) {
         const float xv = p.use_scale ? xk[c] * p.scale : xk[c];
         float nf, P;
         exp_parts(xv, nf, P);
-        const uint64_t q = fix_term_from_parts(nf, P, Nb_cur);
+        const uint64_t q = fix_term_from_parts(nf, P, Nb_q);
         acc += q;
         float nfy = nf, Py = P, yv = xv;
         if constexpr (MASK == kMaskNone) {
@@ -352,13 +312,13 @@ __global__ __launch_bounds__(T) void row_kernel(const RowParams p) {
           j = j < 0 ? 0 : (j >= V ? V - 1 : j);
           yv = xv + mrow_f[j];
           exp_parts(yv, nfy, Py);
-          ak += fix_term_from_parts(nfy, Py, Nb_msk);
+          ak += fix_term_from_parts(nfy, Py, Nb_m);
         }
         if constexpr (kNoise) {
           const int jr = ((int)v0b + k * 64) * EPV - a + c;
           const int jc = jr < 0 ? 0 : (jr >= V ? V - 1 : jr);
           const float E = noise_row[jc];
-          if (yv > kNegInf && pass == n_pass - 1) {
+          if (yv > kNegInf && pass == 0) {  // the race is always run against the masked maximum's exponent
             const float df = nfy - N_msk;
             const float e = (df < -100.0f) ? 0.0f : __builtin_ldexpf(Py, (int)df - 30);
             const float g = e / E;
@@ -374,48 +334,57 @@ __global__ __launch_bounds__(T) void row_kernel(const RowParams p) {
       // one vector at a time: without this the scheduler interleaves many vectors and spills
       __builtin_amdgcn_sched_barrier(0);
     }
-    }
-    if (pass == 0) s_all = acc;
-  }
-  if constexpr (MASK == kMaskNone) s_msk = s_all;
-
-  {
-    const uint64_t t_all = wave_scan_u64(s_all);
-    uint64_t t_msk = t_all;
-    if constexpr (MASK != kMaskNone) t_msk = wave_scan_u64(s_msk);
-    if (lane == 63) {
-      s_sum[0][wave] = t_all;
-      s_sum[1][wave] = t_msk;
-    }
-  }
-  if constexpr (kNoise) {
-    // wave argmax (max g, then min j) through LDS-free DPP would need 2 fields; 6 xor steps suffice
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float og = __shfl_xor(best_g, o, 64);
-      const int32_t oj = __shfl_xor(best_j, o, 64);
-      if (og > best_g || (og == best_g && oj < best_j)) {
-        best_g = og;
-        best_j = oj;
+    if constexpr (MASK == kMaskNone) s_msk = acc;
+    {
+      const uint64_t t_all = wave_scan_u64(acc);
+      uint64_t t_msk = t_all;
+      if constexpr (MASK != kMaskNone) t_msk = wave_scan_u64(s_msk);
+      if (lane == 63) {
+        s_sum[0][wave] = t_all;
+        s_sum[1][wave] = t_msk;
       }
     }
-    if (lane == 0) {
-      s_bestg[wave] = best_g;
-      s_bestj[wave] = best_j;
-    }
-  }
-  __syncthreads();
-  uint64_t S_all = 0, S_msk = 0;
+    if constexpr (kNoise) {
+      if (pass == 0) {
+        // wave argmax (max g, then min j) through LDS-free DPP would need 2 fields; 6 xor steps suffice
 #pragma unroll
-  for (int w = 0; w < W; ++w) {
-    S_all += s_sum[0][w];
-    S_msk += s_sum[1][w];
+        for (int o = 32; o > 0; o >>= 1) {
+          const float og = __shfl_xor(best_g, o, 64);
+          const int32_t oj = __shfl_xor(best_j, o, 64);
+          if (og > best_g || (og == best_g && oj < best_j)) {
+            best_g = og;
+            best_j = oj;
+          }
+        }
+        if (lane == 0) {
+          s_bestg[wave] = best_g;
+          s_bestj[wave] = best_j;
+        }
+      }
+    }
+    __syncthreads();
+    uint64_t Sa = 0, Sm = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      Sa += s_sum[0][w];
+      Sm += s_sum[1][w];
+    }
+    if (pass == 0) S_all = Sa;
+    S_msk = Sm;
+    N_fin = (pass == 0 && !over) ? N_all : N_msk;
+    if constexpr (MASK == kMaskNone) break;
+    uint32_t top = (uint32_t)(Sm >> 37);  // sums stay below 2^62
+    opaque(top);                          // VALU compare (uniform u64 `<` miscompile, see the draw below)
+    if (pass == 1 || over || top != 0u || !(m_msk > kNegInf)) break;
+    __syncthreads();  // s_sum is rewritten by the second pass
+    Nb_m = Nb_msk;
   }
+  const float Nb_fin = N_fin + (float)kFixShift;
 
   // ---- phase 3: lse / logZ ---------------------------------------------------------------------
   if (tid == 0) {
     const double lse_all = S_all ? log_fix(S_all, (int32_t)N_all - kFixFrac) : (double)kNegInf;
-    const double lse_msk = S_msk ? log_fix(S_msk, (int32_t)N_msk - kFixFrac) : (double)kNegInf;
+    const double lse_msk = S_msk ? log_fix(S_msk, (int32_t)N_fin - kFixFrac) : (double)kNegInf;
     if (p.out_lse) p.out_lse[pidx] = (float)lse_all;
     if (p.out_logZ) p.out_logZ[pidx] = (float)(lse_msk - lse_all);
     if constexpr (MODE == kModeStats) s_lse = (float)lse_all;
@@ -553,7 +522,7 @@ __global__ __launch_bounds__(T) void row_kernel(const RowParams p) {
               const int jc = j < 0 ? 0 : (j >= V ? V - 1 : j);
               xv = xv + mrow_f[jc];
             }
-            const uint64_t q = ok ? fix_term(xv, Nb_msk) : 0ull;
+            const uint64_t q = ok ? fix_term(xv, Nb_fin) : 0ull;
             if (tok < 0) {
               if (Tl < q) tok = j;
               else Tl -= q;

@@ -269,48 +269,34 @@ __global__ __launch_bounds__(T) void row_kernel_v2(const RowParams p) {
       for (int k = 0; k < KB; ++k) prefetch_slot(nxr, k, false);
     }
 
-    // ---- phase 1: maxima ----------------------------------------------------------------------
-    float m_all = kNegInf, m_msk = kNegInf;
+    // ---- phase 1: row maximum (the masked maximum is only needed on the rare low-mass path below) -----
+    float m_all = kNegInf;
 #pragma unroll
     for (int k = 0; k < NVL; ++k) {
       float xk[EPV];
       unpack_vec<DT>(raw[k], xk);
 #pragma unroll
-      for (int c = 0; c < EPV; ++c) {
-        const float xv = SCALED ? xk[c] * p.scale : xk[c];
-        m_all = fmaxf(m_all, xv);
-        if constexpr (kBits) {
-          const uint32_t fill = bit_fill(mb[(k * EPV + c) >> 5], (k * EPV + c) & 31);
-          m_msk = fmaxf(m_msk, __uint_as_float((__float_as_uint(xv) & fill) | (0xff800000u & ~fill)));
-        }
-      }
+      for (int c = 0; c < EPV; ++c) m_all = fmaxf(m_all, SCALED ? xk[c] * p.scale : xk[c]);
     }
     m_all = wave_max(m_all);
-    if constexpr (kBits) m_msk = wave_max(m_msk);
-    if (lane == 0) {
-      lds_write_b32(scr_max + wave * 4, __float_as_uint(m_all));
-      if constexpr (kBits) lds_write_b32(scr_max + 64 + wave * 4, __float_as_uint(m_msk));
-    }
+    if (lane == 0) lds_write_b32(scr_max + wave * 4, __float_as_uint(m_all));
     lds_barrier();
     const int wl = lane & 15;            // lane wl of every DPP row stands for wave wl
     const int wr = wl < W ? wl : W - 1;  // rows of 16 lanes but only W waves: the rest duplicate the last
     m_all = row16_max_bcast(__uint_as_float(lds_read_b32_wait(scr_max + wr * 4)));
-    if constexpr (kBits) m_msk = row16_max_bcast(__uint_as_float(lds_read_b32_wait(scr_max + 64 + wr * 4)));
-    else m_msk = m_all;
     const float N_all = __builtin_rintf(m_all * kLog2e);
-    const float N_msk = __builtin_rintf(m_msk * kLog2e);
-    const float Nb_all = N_all + (float)kFixShift, Nb_msk = N_msk + (float)kFixShift;
-    const bool same_n = (N_all == N_msk);
+    float N_msk = N_all;
 
     // ---- phase 2: fixed-point sums -----------------------------------------------------------------
-    uint64_t s_all = 0, s_msk = 0;
+    // Pass 0 takes both sums on the row's scale N_all: one exponential per element, the masked term is
+    // the unmasked term gated by the mask bit.  Only if that leaves the masked sum fewer than 37 bits
+    // (allowed mass < 2^-7 of the row: workgroup-uniform, rare) pass 1 redoes it on the masked maximum's scale.
+    uint64_t S_all = 0, S_msk = 0;
     uint64_t ag[kPhilox ? NG : 1];  // per-lane masked sums of the chunks (GS tiles each)
-    const int n_pass = (kBits && !same_n) ? 2 : 1;
+    float Nb_cur = N_all + (float)kFixShift;
 #pragma unroll 1
-    for (int pass = 0; pass < n_pass; ++pass) {
-      const float Nb_cur = pass == 0 ? Nb_all : Nb_msk;
-      uint64_t acc = 0;
-      s_msk = 0;
+    for (int pass = 0;; ++pass) {
+      uint64_t acc = 0, s_msk = 0;
       if constexpr (kPhilox) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) ag[g] = 0;
@@ -365,33 +351,64 @@ __global__ __launch_bounds__(T) void row_kernel_v2(const RowParams p) {
         }
         __builtin_amdgcn_sched_barrier(0);  // one vector at a time (register pressure)
       }
-      if (pass == 0) s_all = acc;
-    }
-    if constexpr (!kBits) s_msk = s_all;
-    {
-      const uint64_t t_all = wave_scan_u64(s_all);
-      uint64_t t_msk = t_all;
-      if constexpr (kBits) t_msk = wave_scan_u64(s_msk);
-      if (lane == 63) {
-        lds_write_b64(scr_sum + wave * 8, t_all);
-        lds_write_b64(scr_sum + 128 + wave * 8, t_msk);
-      }
-      if constexpr (kPhilox) {
-        // wave totals of every chunk -> workspace; locate_kernel finishes the draw from them
-        uint64_t *crow = p.chunk_sums + (int64_t)cur.pidx * (W * NG) + wave * NG;
+      if constexpr (!kBits) s_msk = acc;
+      {
+        const uint64_t t_all = wave_scan_u64(acc);
+        uint64_t t_msk = t_all;
+        if constexpr (kBits) t_msk = wave_scan_u64(s_msk);
+        if (lane == 63) {
+          lds_write_b64(scr_sum + wave * 8, t_all);
+          lds_write_b64(scr_sum + 128 + wave * 8, t_msk);
+        }
+        if constexpr (kPhilox) {
+          // wave totals of every chunk -> workspace; locate_kernel finishes the draw from them
+          uint64_t *crow = p.chunk_sums + (int64_t)cur.pidx * (W * NG) + wave * NG;
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-          const uint64_t tg = wave_scan_u64(ag[g]);
-          if (lane == 63) crow[g] = tg;
+          for (int g = 0; g < NG; ++g) {
+            const uint64_t tg = wave_scan_u64(ag[g]);
+            if (lane == 63) crow[g] = tg;
+          }
         }
       }
+      lds_barrier();
+      // lane l (mod 16) holds wave l's totals; a 16-lane scan gives the totals
+      const uint64_t cw_all = wl < W ? lds_read_b64_wait(scr_sum + wr * 8) : 0ull;
+      const uint64_t cw_msk = wl < W ? lds_read_b64_wait(scr_sum + 128 + wr * 8) : 0ull;
+      const uint64_t in_all = row16_scan_u64(cw_all), in_msk = row16_scan_u64(cw_msk);
+      if (pass == 0) S_all = readlane_u64(in_all, 15);
+      S_msk = readlane_u64(in_msk, 15);
+      if constexpr (!kBits) break;
+      uint32_t top = (uint32_t)(S_msk >> 37);  // sums stay below 2^62
+      opaque(top);  // VALU compare (uniform u64 `<` miscompile, see v1)
+      const bool low = (top == 0u);
+      if (pass == 1 || !low) break;
+      // ---- rare: the allowed tokens hold < 2^-7 of the row's mass; redo the masked sum on their own scale ----
+      float m_msk = kNegInf;
+#pragma unroll
+      for (int i = 0; i < MBW; ++i) opaque(mb[i]);
+#pragma unroll
+      for (int k = 0; k < NVL; ++k) opaque(raw[k]);
+#pragma unroll
+      for (int k = 0; k < NVL; ++k) {
+        float xk[EPV];
+        unpack_vec<DT>(raw[k], xk);
+#pragma unroll
+        for (int c = 0; c < EPV; ++c) {
+          const float xv = SCALED ? xk[c] * p.scale : xk[c];
+          const uint32_t fill = bit_fill(mb[(k * EPV + c) >> 5], (k * EPV + c) & 31);
+          m_msk = fmaxf(m_msk, __uint_as_float((__float_as_uint(xv) & fill) | (0xff800000u & ~fill)));
+        }
+        opaque(m_msk);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      m_msk = wave_max(m_msk);
+      if (lane == 0) lds_write_b32(scr_max + 64 + wave * 4, __float_as_uint(m_msk));
+      lds_barrier();
+      m_msk = row16_max_bcast(__uint_as_float(lds_read_b32_wait(scr_max + 64 + wr * 4)));
+      if (!(m_msk > kNegInf)) break;  // nothing allowed: S_msk is 0
+      N_msk = __builtin_rintf(m_msk * kLog2e);
+      Nb_cur = N_msk + (float)kFixShift;
     }
-    lds_barrier();
-    // lane l (mod 16) holds wave l's totals; a 16-lane scan gives totals and the per-wave prefix at once
-    const uint64_t cw_all = wl < W ? lds_read_b64_wait(scr_sum + wr * 8) : 0ull;
-    const uint64_t cw_msk = wl < W ? lds_read_b64_wait(scr_sum + 128 + wr * 8) : 0ull;
-    const uint64_t in_all = row16_scan_u64(cw_all), in_msk = row16_scan_u64(cw_msk);
-    const uint64_t S_all = readlane_u64(in_all, 15), S_msk = readlane_u64(in_msk, 15);
 
     // ---- phase 3 is not here: the sums and exponents go to the workspace and finish_kernel /
     //      locate_kernel turn them into lse / logZ (double-precision log) and the token.  In-kernel it

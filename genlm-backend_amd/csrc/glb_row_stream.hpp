@@ -80,8 +80,11 @@ __global__ __launch_bounds__(1024) void row_stream_kernel(const RowParams p) {
   const float N_all = __builtin_rintf(m_all * kLog2e), N_msk = __builtin_rintf(m_msk * kLog2e);
   const float Nb_all = N_all + (float)kFixShift, Nb_msk = N_msk + (float)kFixShift;
 
-  // pass 2: fixed-point sums
-  uint64_t s_all = 0, s_msk = 0;
+  // pass 2: fixed-point sums.  GLB math keeps the masked sum on the row's scale N_all unless that leaves it
+  // fewer than 37 bits; a streaming kernel cannot cheaply come back, so when the two exponents differ it takes
+  // the masked sum on both scales in the same pass and chooses afterwards.
+  const bool two_scales = (N_msk != N_all);  // bit masks: N_msk <= N_all
+  uint64_t s_all = 0, s_cmn = 0, s_own = 0;
   for (int v = v_lo + lane; v < v_hi; v += 64) {
     float x[EPV];
     uint32_t nib;
@@ -90,24 +93,39 @@ __global__ __launch_bounds__(1024) void row_stream_kernel(const RowParams p) {
     for (int c = 0; c < EPV; ++c) {
       // (explicit guard: x was SET to -inf above, and the float->uint conversion of the resulting NaN is
       //  something the compiler may fold to anything; the other kernels carry -inf as opaque bit patterns)
-      s_all += (x[c] > kNegInf) ? fix_term(x[c], Nb_all) : 0ull;
-      s_msk += ((nib >> c) & 1u) ? fix_term(x[c], Nb_msk) : 0ull;
+      const uint64_t q = (x[c] > kNegInf) ? fix_term(x[c], Nb_all) : 0ull;
+      s_all += q;
+      const bool ok = ((nib >> c) & 1u) && (x[c] > kNegInf);
+      s_cmn += ok ? q : 0ull;
+      if (two_scales) s_own += ok ? fix_term(x[c], Nb_msk) : 0ull;
     }
   }
-  const uint64_t t_all = wave_sum_u64(s_all), t_msk = wave_sum_u64(s_msk);
+  const uint64_t t_all = wave_sum_u64(s_all), t_cmn = wave_sum_u64(s_cmn), t_own = wave_sum_u64(s_own);
   if (lane == 0) {
     s_sum[0][wave] = t_all;
-    s_sum[1][wave] = t_msk;
+    s_sum[1][wave] = t_cmn;
+    s_pre[wave] = t_own;
   }
   __syncthreads();
-  uint64_t S_all = 0, S_msk = 0;
+  uint64_t S_all = 0, S_cmn = 0, S_own = 0;
   for (int w = 0; w < W; ++w) {
     S_all += s_sum[0][w];
-    S_msk += s_sum[1][w];
+    S_cmn += s_sum[1][w];
+    S_own += s_pre[w];
   }
+  uint32_t top = (uint32_t)(S_cmn >> 37);
+  opaque(top);  // VALU compare (uniform u64 `<` miscompile, see v1)
+  const bool own = two_scales && top == 0u && (m_msk > kNegInf);
+  const uint64_t S_msk = own ? S_own : S_cmn;
+  const float N_fin = own ? N_msk : N_all;
+  const float Nb_fin = N_fin + (float)kFixShift;
+  // the draw walks the waves' sums on the chosen scale
+  __syncthreads();
+  if (own && lane == 0) s_sum[1][wave] = t_own;
+  __syncthreads();
   if (tid == 0) {
     const double lse_all = S_all ? log_fix(S_all, (int32_t)N_all - kFixFrac) : (double)kNegInf;
-    const double lse_msk = S_msk ? log_fix(S_msk, (int32_t)N_msk - kFixFrac) : (double)kNegInf;
+    const double lse_msk = S_msk ? log_fix(S_msk, (int32_t)N_fin - kFixFrac) : (double)kNegInf;
     if (p.out_lse) p.out_lse[pidx] = (float)lse_all;
     if (p.out_logZ) p.out_logZ[pidx] = (float)(lse_msk - lse_all);
     s_lse = (float)lse_all;
@@ -168,7 +186,7 @@ __global__ __launch_bounds__(1024) void row_stream_kernel(const RowParams p) {
             elems(v, x, nib);
 #pragma unroll
             for (int c = 0; c < EPV; ++c) {
-              q[c] = ((nib >> c) & 1u) ? fix_term(x[c], Nb_msk) : 0ull;
+              q[c] = ((nib >> c) & 1u) ? fix_term(x[c], Nb_fin) : 0ull;
               aj += q[c];
             }
           } else {

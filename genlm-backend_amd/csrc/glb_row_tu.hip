@@ -1,7 +1,7 @@
 // glb_row_tu.hip — one translation unit per (element type, draw mode); compiled with
 // -DGLB_DT=<0|1|2> -DGLB_MODE=<0|1|2>.  Instantiates the row kernel for every mask kind and launch
 // geometry and exports one launcher that glb_api.hip dispatches to.
-#include "glb_row_kernel_v3.hpp"
+#include "glb_row_kernel_v2.hpp"
 #include "glb_row_stream.hpp"
 
 #ifndef GLB_DT
@@ -78,29 +78,6 @@ static hipError_t launch_geom2(const RowParams &p, int geom, int grid, hipStream
 }
 #endif
 
-// cooperative split-row variant (glb_row_kernel_v3.hpp): ids -> NVI (vectors per lane per quarter-row)
-//   31: NVI=7 (fp32 rows up to 57 336; 16-bit up to 114 672)   32: NVI=8 (16-bit 128k rows, fp32 65 528)
-#if GLB_MODE != 2
-template <int MASK, int NVI>
-static hipError_t launch3(const V3Params &q, hipStream_t s) {
-  const int grid = q.n_clusters * kClusterSize;
-  if (q.rp.use_scale)
-    hipLaunchKernelGGL((row_kernel_v3<GLB_DT, MASK, NVI, true>), dim3(grid), dim3(512), 0, s, q);
-  else
-    hipLaunchKernelGGL((row_kernel_v3<GLB_DT, MASK, NVI, false>), dim3(grid), dim3(512), 0, s, q);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((locate_kernel_v3<GLB_DT, MASK, GLB_MODE == 1>), dim3((q.rp.n_particles + 3) / 4), dim3(256), 0,
-                     s, q, NVI);
-  return hipGetLastError();
-}
-
-hipError_t GLB_CAT3(launch_row3_, GLB_DT, GLB_MODE)(const V3Params &q, int mask_kind, int geom, hipStream_t s) {
-  if (mask_kind == kMaskNone) return geom == 31 ? launch3<kMaskNone, 7>(q, s) : launch3<kMaskNone, 8>(q, s);
-  if (mask_kind == kMaskBits) return geom == 31 ? launch3<kMaskBits, 7>(q, s) : launch3<kMaskBits, 8>(q, s);
-  return hipErrorInvalidValue;
-}
-#endif
 
 #define GLB_CAT_(a, b, c) a##b##_##c
 #define GLB_CAT(a, b, c) GLB_CAT_(a, b, c)

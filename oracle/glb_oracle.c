@@ -79,6 +79,8 @@ static const uint32_t GLB_EXP_C[6] = {0x3f800000u, 0x3f800000u, 0x3effff2du,
                                       0x3e2aaa6eu, 0x3d2b8604u, 0x3c0905d1u};
 #define GLB_FIX_SHIFT 18 /* S has 44 fractional bits: 2^30 (Pfix) * 2^32 >> 18 */
 #define GLB_FIX_FRAC 44
+/* masked sums are taken on the row's own scale unless that leaves them fewer than 37 significant bits */
+#define GLB_LOW_MASS (1ull << 37)
 
 static float u2f(uint32_t u) {
   float f;
@@ -207,13 +209,26 @@ int orc_step(const void *logits, int dtype, int64_t n_rows, int64_t V, int64_t l
       if (vm > st.m_mask) st.m_mask = vm;
     }
     st.N_all = rintf(st.m_all * GLB_LOG2E);
-    st.N_mask = rintf(st.m_mask * GLB_LOG2E);
+    const float N_k = rintf(st.m_mask * GLB_LOG2E); /* exponent of the masked maximum (race scale) */
     st.S_all = 0;
+    for (int64_t j = 0; j < V; ++j) st.S_all += glb_fix_term(x[j], st.N_all);
+    /* Masked sum: on the row's scale N_all (one exponential per element serves both sums) when the
+       masked maximum does not exceed it and the result keeps >= 37 bits; otherwise on the masked
+       maximum's own scale N_k. */
+    st.N_mask = N_k;
     st.S_mask = 0;
-    for (int64_t j = 0; j < V; ++j) {
-      st.S_all += glb_fix_term(x[j], st.N_all);
-      st.S_mask += glb_fix_term(y[j], st.N_mask);
+    int own_scale = 1;
+    if (N_k <= st.N_all) {
+      uint64_t S_c = 0;
+      for (int64_t j = 0; j < V; ++j) S_c += glb_fix_term(y[j], st.N_all);
+      if (S_c >= GLB_LOW_MASS) {
+        st.S_mask = S_c;
+        st.N_mask = st.N_all;
+        own_scale = 0;
+      }
     }
+    if (own_scale)
+      for (int64_t j = 0; j < V; ++j) st.S_mask += glb_fix_term(y[j], st.N_mask);
     double lse_all = st.S_all ? glb_log_fix(st.S_all, (int32_t)st.N_all - GLB_FIX_FRAC) : -INFINITY;
     double lse_mask = st.S_mask ? glb_log_fix(st.S_mask, (int32_t)st.N_mask - GLB_FIX_FRAC) : -INFINITY;
     if (out_lse) out_lse[i] = (float)lse_all;
@@ -241,7 +256,7 @@ int orc_step(const void *logits, int dtype, int64_t n_rows, int64_t V, int64_t l
           if (!(y[j] > -INFINITY)) continue;
           float nf, P;
           glb_exp_parts(y[j], &nf, &P);
-          float df = nf - st.N_mask; /* <= 0, integer valued */
+          float df = nf - N_k; /* <= 0, integer valued */
           float e = (df < -100.0f) ? 0.0f : ldexpf(P, (int)df - 30);
           float g = e / E[j];
           if (g > best) { best = g; tok = (int32_t)j; }

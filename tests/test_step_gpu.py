@@ -120,13 +120,9 @@ def test_log_softmax_rows(engine, oracle):
 
 V2_CASES = [
     # (n_particles, n_rows, V, dtype, variant)   variant: 21 fp32 <= 51196, 22 small rows, 23 16-bit <= 131064
-    #                                             31 / 32: cooperative split-row kernel (4 workgroups per row)
     (700, 300, 50257, "f32", 21),
-    (700, 300, 50257, "f32", 31),
     (1024, 1024, 50257, "f32", 0),
-    (300, 100, 128256, "bf16", 32),
-    (9, 9, 1000, "f32", 31),
-    (130, 40, 65001, "f16", 31),
+    (130, 40, 65001, "f16", 23),
     (513, 513, 50257, "f32", 21),
     (300, 300, 30001, "f32", 22),
     (300, 100, 128256, "bf16", 23),
@@ -144,9 +140,12 @@ def test_persistent_kernel_bit_exact(engine, oracle, N, U, V, dtype, variant, ma
     x_np, x_t = _mk(O, U, V, dtype, seed=V + U)
     dev = engine.device
     row_of = (np.arange(N) * 7 % U).astype(np.int32)
-    K = 3
+    K = 5
     masks = synth.binary_masks(V + 1, K, V)
-    masks[2, 50:] = -np.inf  # a mask whose allowed set sits far below the row maximum for most rows
+    masks[2, 50:] = -np.inf  # allowed set far below the row maximum for most rows: masked sum on its own scale
+    masks[3, :] = -np.inf    # nothing allowed: logZ = -inf, token -1
+    masks[4, :] = -np.inf    # a few hundred allowed tokens: mass around the 2^-7 switch of the masked-sum scale
+    masks[4, 7::V // 300] = 0.0
     mid = (np.arange(N) % K).astype(np.int32)
     kw_o, kw_g = {}, {}
     if mask_kind == "bits":

@@ -11,14 +11,14 @@ import genlm_backend_amd  # noqa: E402
 from genlm_backend_amd.engine import HipEngine  # noqa: E402
 
 
-def run(eng, B, V, dtype, mask_kind, rng_mode, nbuf, iters, variant=0, ld=None):
+def run(eng, B, V, dtype, mask_kind, rng_mode, nbuf, iters, variant=0, ld=None, pforbid=1 / 3):
     dev = eng.device
     ld = ld or V
     g = torch.Generator(device=dev)
     g.manual_seed(0)
     bufs = [(torch.randn((B, ld), device=dev, generator=g) * 3).to(dtype) for _ in range(nbuf)]
     K = 2
-    maskf = torch.where(torch.rand((K, V), device=dev, generator=g) < 1 / 3, float("-inf"), 0.0)
+    maskf = torch.where(torch.rand((K, V), device=dev, generator=g) < pforbid, float("-inf"), 0.0)
     bits, _ = eng.mask_to_bits(maskf)
     mid = (torch.arange(B, device=dev) % K).to(torch.int32)
     kw = {}
@@ -54,9 +54,16 @@ if __name__ == "__main__":
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--nbuf", type=int, default=4)
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--pforbid", action="store_true", help="sweep the forbidden fraction of the masks")
     a = ap.parse_args()
     eng = HipEngine("cuda:0")
     f32, bf16 = torch.float32, torch.bfloat16
+    if a.pforbid:
+        for pf in (1 / 3, 0.05, 0.0001):
+            print("pforbid", pf)
+            run(eng, 1024, 50257, f32, 1, 1, a.nbuf, a.iters, pforbid=pf)
+            run(eng, 1024, 50257, f32, 1, 0, a.nbuf, a.iters, pforbid=pf)
+        sys.exit(0)
     run(eng, 1024, 50257, f32, 1, 1, a.nbuf, a.iters)
     run(eng, 1024, 50257, f32, 0, 1, a.nbuf, a.iters)
     run(eng, 1024, 50257, f32, 0, 0, a.nbuf, a.iters)
