@@ -12,8 +12,8 @@
 // barriers"): no `__syncthreads()` (its fence drains vmcnt), no use of an ordinary load's result and
 // no compiler-visible LDS read while a DMA is in flight.  Barriers are raw `s_barrier`, the
 // cross-wave scratch is accessed with inline-asm `ds_*`, the one `s_waitcnt vmcnt(0)` per row is
-// explicit, and the inverse-CDF draw is finished by a second, tiny kernel (locate_kernel) from per-chunk
-// wave totals this kernel leaves in a workspace: it re-reads one 4-5 KiB chunk of one row per particle.
+// explicit, and the inverse-CDF draw is finished after the streaming loop (locate_row, one wave per row) from
+// per-chunk wave totals the loop leaves in a workspace: it re-reads one 4-5 KiB chunk of one row per particle.
 //
 // Arithmetic is GLB math exactly as in v1: results are bit-identical to v1 and to the oracle.
 #pragma once
@@ -71,6 +71,149 @@ __device__ __forceinline__ uint64_t row16_scan_u64(uint64_t v) {
   v += dpp_u64_or0<0x118, 0xf>(v);
   return v;
 }
+
+// ---- per-particle epilogue (run by the tail of the persistent kernel, one wave per particle) ----------
+// The workspace words were written by other waves of this workgroup with plain stores (complete: vmcnt(0) +
+// barrier); agent-scope loads keep the reads out of any stale vector-L1 line.
+__device__ __forceinline__ uint64_t ld_agent(const uint64_t *q) {
+  return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_agent(const float *q) {
+  return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// lse / logZ of one particle from its fixed-point sums (double-precision log: one lane)
+__device__ __forceinline__ void finish_row(const RowParams &p, int pidx) {
+  const uint64_t S_all = ld_agent(p.row_sums + 2 * pidx), S_msk = ld_agent(p.row_sums + 2 * pidx + 1);
+  const float N_all = ld_agent(p.row_exps + 2 * pidx), N_msk = ld_agent(p.row_exps + 2 * pidx + 1);
+  const double lse_all = S_all ? log_fix(S_all, (int32_t)N_all - kFixFrac) : (double)kNegInf;
+  const double lse_msk = S_msk ? log_fix(S_msk, (int32_t)N_msk - kFixFrac) : (double)kNegInf;
+  if (p.out_lse) p.out_lse[pidx] = (float)lse_all;
+  if (p.out_logZ) p.out_logZ[pidx] = (float)(lse_msk - lse_all);
+}
+
+// Second half of the Philox draw, one wave per particle.  From the chunk totals the streaming loop left in the
+// workspace it picks the chunk (64-lane scan), re-reads that chunk's 4-5 KiB of the row (L2 / Infinity Cache),
+// recomputes the per-lane tile sums against the stored exponent and walks tile -> lane -> element in
+// vocabulary order.  Same integers as the one-workgroup-per-particle kernel, same token.
+template <int DT, int MASK>
+__device__ __forceinline__ void locate_row(const RowParams &p, int pidx, int lane) {
+  constexpr int EPV = ElemTraits<DT>::EPV;
+  constexpr int ES = ElemTraits<DT>::ES;
+  const int V = p.V;
+  const int row = p.row_of ? p.row_of[pidx] : pidx;
+  const char *rowp = (const char *)p.logits + (int64_t)row * p.ld * ES;
+  const int a = (int)(((uintptr_t)rowp) & 15) / ES;
+  const char *base = rowp - a * ES;
+  const int nv = (V + a + EPV - 1) / EPV;
+  const uint32_t *mrow = nullptr;
+  if constexpr (MASK == kMaskBits) {
+    const int mi = p.mask_id ? p.mask_id[pidx] : (p.n_masks == 1 ? 0 : pidx);
+    mrow = (const uint32_t *)p.mask + (int64_t)mi * p.mask_ld;
+  }
+  const uint64_t cs = lane < p.n_chunks ? ld_agent(p.chunk_sums + (int64_t)pidx * p.n_chunks + lane) : 0ull;
+  const uint64_t incl_c = wave_scan_u64(cs);
+  const uint64_t S = readlane_u64(incl_c, 63);
+  if (lane == 0) finish_row(p, pidx);
+  if (S == 0) {
+    if (lane == 0) p.out_token[pidx] = -1;
+    return;
+  }
+  const uint64_t gp = (uint64_t)(p.particle_base + pidx);
+  const uint32_t ctr[4] = {(uint32_t)gp, (uint32_t)(gp >> 32), (uint32_t)p.offset, (uint32_t)(p.offset >> 32)};
+  const uint32_t key[2] = {(uint32_t)p.seed, (uint32_t)(p.seed >> 32)};
+  uint32_t rnd[4];
+  philox4x32_10(ctr, key, rnd);
+  uint64_t Tc = __umul64hi(((uint64_t)rnd[1] << 32) | rnd[0], S);
+  {
+    uint32_t z = 0;
+    opaque(z);  // VALU compare (uniform u64 `<` miscompile, see v1)
+    Tc += z;
+  }
+  const int csel = __ffsll((long long)__ballot(incl_c > Tc)) - 1;
+  Tc -= readlane_u64(incl_c - cs, csel);
+  const float Nb = ld_agent(p.row_exps + 2 * pidx + 1) + (float)kFixShift;
+  const int tiles = p.chunk_vecs >> 6;  // <= 5
+  uint64_t run = 0, asel = 0;
+  uint4 rsel = make_uint4(0, 0, 0, 0);
+  uint32_t nsel = 0;
+  int j0sel = 0;
+  bool found = false;
+  // all of the chunk's loads go out before the first is consumed
+  constexpr int kMaxTiles = 5;
+  uint4 rks[kMaxTiles];
+  uint32_t nibs[kMaxTiles];
+#pragma unroll
+  for (int j = 0; j < kMaxTiles; ++j) {
+    const int v = csel * p.chunk_vecs + j * 64 + lane;
+    const int vc = v < nv ? v : nv - 1;
+    rks[j] = j < tiles ? *reinterpret_cast<const uint4 *>(base + (int64_t)vc * 16) : make_uint4(0, 0, 0, 0);
+    nibs[j] = (1u << EPV) - 1u;
+    if constexpr (MASK == kMaskBits) nibs[j] = j < tiles ? mask_nibble<EPV>(mrow, (V + 31) >> 5, v * EPV - a) : 0u;
+  }
+#pragma unroll
+  for (int j = 0; j < kMaxTiles; ++j) {
+    if (j < tiles) {
+      const int v = csel * p.chunk_vecs + j * 64 + lane;
+      const uint4 rk = rks[j];
+      const int j0 = v * EPV - a;
+      const uint32_t nib = nibs[j];
+      float xs[EPV];
+      unpack_vec<DT>(rk, xs);
+      uint64_t aj = 0;
+#pragma unroll
+      for (int c = 0; c < EPV; ++c) {
+        const float xv = p.use_scale ? xs[c] * p.scale : xs[c];
+        const bool ok = ((uint32_t)(j0 + c) < (uint32_t)V) && ((nib >> c) & 1u);
+        aj += ok ? fix_term(xv, Nb) : 0ull;
+      }
+      const uint64_t cj = wave_sum_u64(aj);
+      if (!found && Tc < run + cj) {
+        found = true;
+        Tc -= run;
+        asel = aj;
+        rsel = rk;
+        nsel = nib;
+        j0sel = j0;
+      }
+      run += cj;
+    }
+  }
+  const uint64_t incl = wave_scan_u64(asel);
+  const int lsel = __ffsll((long long)__ballot(incl > Tc)) - 1;
+  if (lane == lsel) {
+    uint64_t Tl = Tc - (incl - asel);
+    float xs[EPV];
+    unpack_vec<DT>(rsel, xs);
+    int32_t tok = -1;
+#pragma unroll
+    for (int c = 0; c < EPV; ++c) {
+      const float xv = p.use_scale ? xs[c] * p.scale : xs[c];
+      const bool ok = ((uint32_t)(j0sel + c) < (uint32_t)V) && ((nsel >> c) & 1u);
+      const uint64_t q = ok ? fix_term(xv, Nb) : 0ull;
+      if (tok < 0) {
+        if (Tl < q) tok = j0sel + c;
+        else Tl -= q;
+      }
+    }
+    p.out_token[pidx] = tok;
+  }
+}
+
+// tuning aid (tools/dbg/stamps.hip): shader-clock stamps of the first and last wave at the phase boundaries
+#ifdef GLB_STAMPS
+__device__ unsigned long long g_stamps[256 * 2 * 64];
+__device__ unsigned long long g_realtime[256 * 2];
+__device__ int g_skew_cycles = 0;   // experiment: odd workgroups start this many cycles late
+#define GLB_STAMP()                                                                                        \
+  do {                                                                                                     \
+    if (lane == 0 && (wave == 0 || wave == W - 1) && stamp_i < 64 && blockIdx.x < 256)                     \
+      g_stamps[(blockIdx.x * 2 + (wave != 0)) * 64 + stamp_i] = __builtin_amdgcn_s_memtime();              \
+    ++stamp_i;                                                                                             \
+  } while (0)
+#else
+#define GLB_STAMP() do { } while (0)
+#endif
 
 template <int DT, int MASK, int MODE, int NVL, int NL, int ND, int T, bool SCALED>
 __global__ __launch_bounds__(T) void row_kernel_v2(const RowParams p) {
@@ -247,11 +390,25 @@ __global__ __launch_bounds__(T) void row_kernel_v2(const RowParams p) {
   // ---- prologue: first row straight to registers (nothing to overlap with yet) ---------------------
   int vb = blockIdx.x;
   if (vb >= n) return;
+#ifdef GLB_STAMPS
+  int stamp_i = 0;
+  if (tid == 0 && blockIdx.x < 256) g_realtime[blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef GLB_STAMPS
+  if ((blockIdx.x >> 3) & 1) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)g_skew_cycles) __builtin_amdgcn_s_sleep(8);
+  }
+#endif
+  GLB_STAMP();  // 0: start
   RowRef cur = row_ref(vb);
   prefetch(cur);
+  GLB_STAMP();  // 1: first row's loads issued
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if constexpr (kBits) lds_barrier();
+  GLB_STAMP();  // 2: ... arrived
   land(cur);
+  GLB_STAMP();  // 3: landed        then per row: +1 phase 1, +2 phase 2 body, +3 reduce, [+4 wait, +5 landed]
 
   for (;;) {
     const int vb_next = vb + G;
@@ -286,6 +443,7 @@ __global__ __launch_bounds__(T) void row_kernel_v2(const RowParams p) {
     m_all = row16_max_bcast(__uint_as_float(lds_read_b32_wait(scr_max + wr * 4)));
     const float N_all = __builtin_rintf(m_all * kLog2e);
     float N_msk = N_all;
+    GLB_STAMP();
 
     // ---- phase 2: fixed-point sums -----------------------------------------------------------------
     // Pass 0 takes both sums on the row's scale N_all: one exponential per element, the masked term is
@@ -352,6 +510,7 @@ __global__ __launch_bounds__(T) void row_kernel_v2(const RowParams p) {
         __builtin_amdgcn_sched_barrier(0);  // one vector at a time (register pressure)
       }
       if constexpr (!kBits) s_msk = acc;
+      if (pass == 0) GLB_STAMP();
       {
         const uint64_t t_all = wave_scan_u64(acc);
         uint64_t t_msk = t_all;
@@ -420,142 +579,34 @@ __global__ __launch_bounds__(T) void row_kernel_v2(const RowParams p) {
       p.row_exps[2 * cur.pidx + 1] = N_msk;
     }
 
+    GLB_STAMP();
     if (!has_next) break;
     // ---- next row: everything prefetched has landed ---------------------------------------------------
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (kBits) lds_barrier();  // the mask row was DMA'd by other waves
+    GLB_STAMP();
     cur = nxr;
     vb = vb_next;
     land(cur);
+    GLB_STAMP();
   }
-}
-
-
-// lse / logZ of one particle from the sums the persistent kernel parked in the workspace
-__device__ __forceinline__ void finish_row(const RowParams &p, int pidx) {
-  const uint64_t S_all = p.row_sums[2 * pidx], S_msk = p.row_sums[2 * pidx + 1];
-  const float N_all = p.row_exps[2 * pidx], N_msk = p.row_exps[2 * pidx + 1];
-  const double lse_all = S_all ? log_fix(S_all, (int32_t)N_all - kFixFrac) : (double)kNegInf;
-  const double lse_msk = S_msk ? log_fix(S_msk, (int32_t)N_msk - kFixFrac) : (double)kNegInf;
-  if (p.out_lse) p.out_lse[pidx] = (float)lse_all;
-  if (p.out_logZ) p.out_logZ[pidx] = (float)(lse_msk - lse_all);
-}
-
-template <int UNUSED>
-__global__ void finish_kernel(const RowParams p) {
-  const int pidx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pidx < p.n_particles) finish_row(p, pidx);
-}
-
-// Second half of the Philox draw for v2: one wave per particle.  From the chunk totals the fused
-// kernel left in the workspace it picks the chunk (64-lane scan), re-reads that chunk's 4-5 KiB of
-// the row, recomputes the per-lane tile sums against the stored exponent and walks
-// tile -> lane -> element exactly as v1 does in-kernel.  Same integers, same token.
-template <int DT, int MASK>
-__global__ __launch_bounds__(256) void locate_kernel(const RowParams p) {
-  constexpr int EPV = ElemTraits<DT>::EPV;
-  constexpr int ES = ElemTraits<DT>::ES;
-  const int lane = threadIdx.x & 63;
-  const int pidx = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (pidx >= p.n_particles) return;
-  const int V = p.V;
-  const int row = p.row_of ? p.row_of[pidx] : pidx;
-  const char *rowp = (const char *)p.logits + (int64_t)row * p.ld * ES;
-  const int a = (int)(((uintptr_t)rowp) & 15) / ES;
-  const char *base = rowp - a * ES;
-  const int nv = (V + a + EPV - 1) / EPV;
-  const uint32_t *mrow = nullptr;
-  if constexpr (MASK == kMaskBits) {
-    const int mi = p.mask_id ? p.mask_id[pidx] : (p.n_masks == 1 ? 0 : pidx);
-    mrow = (const uint32_t *)p.mask + (int64_t)mi * p.mask_ld;
-  }
-  const uint64_t cs = lane < p.n_chunks ? p.chunk_sums[(int64_t)pidx * p.n_chunks + lane] : 0ull;
-  const uint64_t incl_c = wave_scan_u64(cs);
-  const uint64_t S = readlane_u64(incl_c, 63);
-  if (lane == 0) finish_row(p, pidx);
-  if (S == 0) {
-    if (lane == 0) p.out_token[pidx] = -1;
-    return;
-  }
-  const uint64_t gp = (uint64_t)(p.particle_base + pidx);
-  const uint32_t ctr[4] = {(uint32_t)gp, (uint32_t)(gp >> 32), (uint32_t)p.offset, (uint32_t)(p.offset >> 32)};
-  const uint32_t key[2] = {(uint32_t)p.seed, (uint32_t)(p.seed >> 32)};
-  uint32_t rnd[4];
-  philox4x32_10(ctr, key, rnd);
-  uint64_t Tc = __umul64hi(((uint64_t)rnd[1] << 32) | rnd[0], S);
-  {
-    uint32_t z = 0;
-    opaque(z);  // VALU compare (uniform u64 `<` miscompile, see v1)
-    Tc += z;
-  }
-  const int csel = __ffsll((long long)__ballot(incl_c > Tc)) - 1;
-  Tc -= readlane_u64(incl_c - cs, csel);
-  const float Nb = p.row_exps[2 * pidx + 1] + (float)kFixShift;
-  const int tiles = p.chunk_vecs >> 6;  // <= 5
-  uint64_t run = 0, asel = 0;
-  uint4 rsel = make_uint4(0, 0, 0, 0);
-  uint32_t nsel = 0;
-  int j0sel = 0;
-  bool found = false;
-  // all of the chunk's loads go out before the first is consumed (they used to be one latency each)
-  constexpr int kMaxTiles = 5;
-  uint4 rks[kMaxTiles];
-  uint32_t nibs[kMaxTiles];
-#pragma unroll
-  for (int j = 0; j < kMaxTiles; ++j) {
-    const int v = csel * p.chunk_vecs + j * 64 + lane;
-    const int vc = v < nv ? v : nv - 1;
-    rks[j] = j < tiles ? *reinterpret_cast<const uint4 *>(base + (int64_t)vc * 16) : make_uint4(0, 0, 0, 0);
-    nibs[j] = (1u << EPV) - 1u;
-    if constexpr (MASK == kMaskBits) nibs[j] = j < tiles ? mask_nibble<EPV>(mrow, (V + 31) >> 5, v * EPV - a) : 0u;
-  }
-#pragma unroll
-  for (int j = 0; j < kMaxTiles; ++j) {
-    if (j < tiles) {
-      const int v = csel * p.chunk_vecs + j * 64 + lane;
-      const uint4 rk = rks[j];
-      const int j0 = v * EPV - a;
-      const uint32_t nib = nibs[j];
-      float xs[EPV];
-      unpack_vec<DT>(rk, xs);
-      uint64_t aj = 0;
-#pragma unroll
-      for (int c = 0; c < EPV; ++c) {
-        const float xv = p.use_scale ? xs[c] * p.scale : xs[c];
-        const bool ok = ((uint32_t)(j0 + c) < (uint32_t)V) && ((nib >> c) & 1u);
-        aj += ok ? fix_term(xv, Nb) : 0ull;
-      }
-      const uint64_t cj = wave_sum_u64(aj);
-      if (!found && Tc < run + cj) {
-        found = true;
-        Tc -= run;
-        asel = aj;
-        rsel = rk;
-        nsel = nib;
-        j0sel = j0;
-      }
-      run += cj;
+  // ---- tail: lse / logZ (and the token) of every row this workgroup streamed, one wave per row ----------
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's workspace stores have reached L2
+  lds_barrier();
+  for (int vr = blockIdx.x + wave * G; vr < n; vr += W * G) {
+    const int pidx = particle_of(vr);
+    if constexpr (kPhilox) {
+      if (p.out_token) locate_row<DT, MASK>(p, pidx, lane);
+      else if (lane == 0) finish_row(p, pidx);
+    } else {
+      if (lane == 0) finish_row(p, pidx);
     }
   }
-  const uint64_t incl = wave_scan_u64(asel);
-  const int lsel = __ffsll((long long)__ballot(incl > Tc)) - 1;
-  if (lane == lsel) {
-    uint64_t Tl = Tc - (incl - asel);
-    float xs[EPV];
-    unpack_vec<DT>(rsel, xs);
-    int32_t tok = -1;
-#pragma unroll
-    for (int c = 0; c < EPV; ++c) {
-      const float xv = p.use_scale ? xs[c] * p.scale : xs[c];
-      const bool ok = ((uint32_t)(j0sel + c) < (uint32_t)V) && ((nsel >> c) & 1u);
-      const uint64_t q = ok ? fix_term(xv, Nb) : 0ull;
-      if (tok < 0) {
-        if (Tl < q) tok = j0sel + c;
-        else Tl -= q;
-      }
-    }
-    p.out_token[pidx] = tok;
-  }
+  GLB_STAMP();
+#ifdef GLB_STAMPS
+  if (tid == 0 && blockIdx.x < 256) g_realtime[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
+
 
 }  // namespace glb

@@ -2,6 +2,7 @@
 // -DGLB_DT=<0|1|2> -DGLB_MODE=<0|1|2>.  Instantiates the row kernel for every mask kind and launch
 // geometry and exports one launcher that glb_api.hip dispatches to.
 #include "glb_row_kernel_v2.hpp"
+#include "glb_row_kernel_v4.hpp"
 #include "glb_row_stream.hpp"
 
 #ifndef GLB_DT
@@ -50,18 +51,21 @@ static hipError_t launch2(const RowParams &p0, int grid, hipStream_t s) {
   else
     hipLaunchKernelGGL((row_kernel_v2<GLB_DT, MASK, GLB_MODE, NVL, NL, ND, 512, false>), dim3(grid), dim3(512), 0, s, p);
   hipError_t e = hipGetLastError();
-#if GLB_MODE == 1
-  if (e == hipSuccess) {
-    hipLaunchKernelGGL((locate_kernel<GLB_DT, MASK>), dim3((p.n_particles + 3) / 4), dim3(256), 0, s, p);
-    e = hipGetLastError();
-  }
-#else
-  if (e == hipSuccess) {
-    hipLaunchKernelGGL(finish_kernel<0>, dim3((p.n_particles + 255) / 256), dim3(256), 0, s, p);
-    e = hipGetLastError();
-  }
-#endif
   return e;
+}
+
+// in-place register prefetch variant (glb_row_kernel_v4.hpp): ids 41/42/43 = the geometries of 21/22/23
+template <int MASK, int NVL>
+static hipError_t launch4(const RowParams &p0, int grid, hipStream_t s) {
+  RowParams p = p0;
+  constexpr int GS = (NVL % 5 == 0) ? 5 : 4;
+  p.n_chunks = 8 * (NVL / GS);
+  p.chunk_vecs = GS * 64;
+  if (p.use_scale)
+    hipLaunchKernelGGL((row_kernel_v4<GLB_DT, MASK, GLB_MODE, NVL, 512, true>), dim3(grid), dim3(512), 0, s, p);
+  else
+    hipLaunchKernelGGL((row_kernel_v4<GLB_DT, MASK, GLB_MODE, NVL, 512, false>), dim3(grid), dim3(512), 0, s, p);
+  return hipGetLastError();
 }
 
 template <int MASK>
@@ -73,6 +77,12 @@ static hipError_t launch_geom2(const RowParams &p, int geom, int grid, hipStream
     case 23: return launch2<MASK, 32, 17, 11>(p, grid, s);
 #endif
     case 22: return launch2<MASK, 16, 16, 0>(p, grid, s);
+#if GLB_DT == 0
+    case 41: return launch4<MASK, 25>(p, grid, s);
+#else
+    case 43: return launch4<MASK, 32>(p, grid, s);
+#endif
+    case 42: return launch4<MASK, 16>(p, grid, s);
     default: return hipErrorInvalidValue;
   }
 }

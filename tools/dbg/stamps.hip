@@ -1,38 +1,71 @@
-// diagnostic: run row_kernel_v2 (fp32, no mask, stats) with s_memtime stamps and print per-phase cycles
+// diagnostic: run row_kernel_v2 (fp32 gpt2 rows) with shader-clock stamps and print per-phase cycles.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DMASKK=1 -DMODEE=1 tools/dbg/stamps.hip -o tools/dbg/stamps_11
 #define GLB_STAMPS 1
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdio>
 #include <vector>
-#include <algorithm>
 #include "../../genlm-backend_amd/csrc/glb_row_kernel_v2.hpp"
 int main() {
   const int B = 1024, V = 50257;
-  float *x; hipMalloc(&x, (size_t)B * V * 4 * 2);
+  float *x;
+  hipMalloc(&x, (size_t)B * V * 4 * 2);
   std::vector<float> h((size_t)B * V);
   for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) % 1000) * 0.01f - 5.f;
   hipMemcpy(x, h.data(), h.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(x + h.size(), h.data(), h.size() * 4, hipMemcpyHostToDevice);
-  float *lz, *ls; hipMalloc(&lz, B * 4); hipMalloc(&ls, B * 4);
-  glb::RowParams p{}; p.logits = x; p.ld = V; p.V = V; p.n_particles = B; p.out_logZ = lz; p.out_lse = ls;
-  uint64_t* ws; hipMalloc(&ws, (size_t)B * 70 * 8); p.chunk_sums = ws; p.row_sums = ws + (size_t)B * 64; p.row_exps = (float*)(ws + (size_t)B * 66); p.n_chunks = 40; p.chunk_vecs = 320;
-  uint32_t* mk; int W32 = (V + 31) / 32; hipMalloc(&mk, (size_t)2 * W32 * 4); hipMemset(mk, 0xB7, (size_t)2 * W32 * 4); p.mask = mk; p.mask_ld = W32; p.n_masks = 1;
+  float *lz, *ls;
+  hipMalloc(&lz, B * 4);
+  hipMalloc(&ls, B * 4);
+  glb::RowParams p{};
+  p.logits = x; p.ld = V; p.V = V; p.n_particles = B; p.out_logZ = lz; p.out_lse = ls;
+  uint64_t *ws;
+  hipMalloc(&ws, (size_t)B * 70 * 8);
+  p.chunk_sums = ws; p.row_sums = ws + (size_t)B * 64; p.row_exps = (float *)(ws + (size_t)B * 66);
+  p.n_chunks = 40; p.chunk_vecs = 320;
+  uint32_t *mk;
+  int W32 = (V + 31) / 32;
+  hipMalloc(&mk, (size_t)2 * W32 * 4);
+  hipMemset(mk, 0xB7, (size_t)2 * W32 * 4);
+  p.mask = mk; p.mask_ld = W32; p.n_masks = 1;
+  for (int skew : {0}) {
+  hipMemcpyToSymbol(HIP_SYMBOL(glb::g_skew_cycles), &skew, 4);
   for (int it = 0; it < 6; ++it) {
     p.logits = x + (it & 1) * h.size();
     hipLaunchKernelGGL((glb::row_kernel_v2<0, MASKK, MODEE, 25, 19, 6, 512, false>), dim3(256), dim3(512), 0, 0, p);
   }
   hipDeviceSynchronize();
-  std::vector<unsigned long long> st(256 * 64);
+  std::vector<unsigned long long> st(256 * 2 * 64), rt(512);
   hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(glb::g_stamps), st.size() * 8);
-  // print for a few WGs the deltas
-  for (int wg : {0, 1, 100, 255}) {
-    printf("WG %d:", wg);
-    unsigned long long t0 = st[wg * 64];
-    for (int i = 1; i < 64 && st[wg * 64 + i]; ++i) printf(" %llu", (st[wg * 64 + i] - st[wg * 64 + i - 1]));
-    printf("  total %llu\n", st[wg*64+ (int)(std::find(st.begin()+wg*64+1, st.begin()+wg*64+64, 0ull)-(st.begin()+wg*64)) -1] - t0);
+  hipMemcpyFromSymbol(rt.data(), HIP_SYMBOL(glb::g_realtime), rt.size() * 8);
+  const char *names[] = {"issue0", "arrive0", "land0"};
+  for (int wg : {0, 8}) { if (skew != 0 && skew != 10000) break;
+    for (int wv = 0; wv < 2; ++wv) {
+      const unsigned long long *s = &st[(wg * 2 + wv) * 64];
+      printf("WG %3d wave %s:", wg, wv ? "last " : "first");
+      int i = 1;
+      for (; i < 4 && s[i]; ++i) printf(" %s %llu", names[i - 1], s[i] - s[i - 1]);
+      int row = 0;
+      while (i < 64 && s[i]) {
+        printf(" | row%d ph1 %llu", row, s[i] - s[i - 1]); ++i;
+        if (i < 64 && s[i]) { printf(" ph2 %llu", s[i] - s[i - 1]); ++i; }
+        if (i < 64 && s[i]) { printf(" red %llu", s[i] - s[i - 1]); ++i; }
+        if (i < 64 && s[i]) { printf(" wait %llu", s[i] - s[i - 1]); ++i; }
+        if (i < 64 && s[i]) { printf(" land %llu", s[i] - s[i - 1]); ++i; }
+        ++row;
+      }
+      printf("  total %llu cyc", s[i - 1] - s[0]);
+      if (!wv) printf("  realtime %llu ticks (100 MHz) -> %.2f GHz", rt[wg * 2 + 1] - rt[wg * 2],
+                      (double)(s[i - 1] - s[0]) / (double)(rt[wg * 2 + 1] - rt[wg * 2]) * 0.1);
+      printf("\n");
+    }
   }
-  // global: min start, max end
   unsigned long long mn = ~0ull, mx = 0;
-  for (int wg = 0; wg < 256; ++wg) { mn = std::min(mn, st[wg*64]); for (int i = 0; i < 64; ++i) mx = std::max(mx, st[wg*64+i]); }
-  printf("span %llu cycles\n", mx - mn);
+  for (int wg = 0; wg < 256; ++wg) {
+    mn = std::min(mn, rt[wg * 2]);
+    mx = std::max(mx, rt[wg * 2 + 1]);
+  }
+  printf("skew %d: span %.2f us\n", skew, (double)(mx - mn) * 0.01);
+  }
   return 0;
 }

@@ -55,6 +55,7 @@ if __name__ == "__main__":
     ap.add_argument("--nbuf", type=int, default=4)
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--pforbid", action="store_true", help="sweep the forbidden fraction of the masks")
+    ap.add_argument("--variant", type=int, default=0)
     a = ap.parse_args()
     eng = HipEngine("cuda:0")
     f32, bf16 = torch.float32, torch.bfloat16
@@ -64,10 +65,10 @@ if __name__ == "__main__":
             run(eng, 1024, 50257, f32, 1, 1, a.nbuf, a.iters, pforbid=pf)
             run(eng, 1024, 50257, f32, 1, 0, a.nbuf, a.iters, pforbid=pf)
         sys.exit(0)
-    run(eng, 1024, 50257, f32, 1, 1, a.nbuf, a.iters)
-    run(eng, 1024, 50257, f32, 0, 1, a.nbuf, a.iters)
-    run(eng, 1024, 50257, f32, 0, 0, a.nbuf, a.iters)
-    run(eng, 1024, 50257, f32, 1, 1, a.nbuf, a.iters, ld=50304)
+    run(eng, 1024, 50257, f32, 1, 1, a.nbuf, a.iters, variant=a.variant)
+    run(eng, 1024, 50257, f32, 0, 1, a.nbuf, a.iters, variant=a.variant)
+    run(eng, 1024, 50257, f32, 0, 0, a.nbuf, a.iters, variant=a.variant)
+    run(eng, 1024, 50257, f32, 1, 1, a.nbuf, a.iters, ld=50304, variant=a.variant)
     if not a.quick:
         run(eng, 1024, 50257, f32, 1, 2, a.nbuf, a.iters)
         run(eng, 1024, 50257, f32, 2, 1, a.nbuf, a.iters)
