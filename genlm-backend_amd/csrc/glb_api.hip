@@ -475,13 +475,10 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
       return fail(GLB_ENOSPC, "workspace %zu < %zu bytes", a->workspace_bytes,
                   glb_step_workspace_bytes(a->n_particles));
     if (((uintptr_t)a->workspace) % 16) return fail(GLB_EINVAL, "workspace not 16-byte aligned");
-    // variants 41-43 = the in-place register prefetch kernel on the geometries of 21-23
-    const bool want4 = a->variant >= 41 && a->variant <= 43;
-    int g2 = pick_geom2(a->vocab, a->dtype, want4 ? a->variant - 20 : a->variant);
+    int g2 = pick_geom2(a->vocab, a->dtype, a->variant);
     // auto: the persistent kernel only pays off with >= 3 rows per CU and rows that need the big geometry
     // (measured: 1024 x 50257 fp32 91 vs 96 us, 2048 rows 147 vs 163 us; 512 x 128256 bf16 118 vs 92 us)
     if (a->variant == 0 && !(g2 == 21 && a->n_particles >= 3 * (int64_t)num_cus())) g2 = 0;
-    if (g2 && want4) g2 += 20;
     if (g2) {
       int64_t grid = a->n_particles < num_cus() ? a->n_particles : num_cus();
       if (const char *g = getenv("GLB_V2_GRID")) {  // tuning knob: persistent workgroups to launch

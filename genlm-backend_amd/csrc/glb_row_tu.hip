@@ -1,8 +1,7 @@
 // glb_row_tu.hip — one translation unit per (element type, draw mode); compiled with
 // -DGLB_DT=<0|1|2> -DGLB_MODE=<0|1|2>.  Instantiates the row kernel for every mask kind and launch
 // geometry and exports one launcher that glb_api.hip dispatches to.
-#include "glb_row_kernel_v2.hpp"
-#include "glb_row_kernel_v4.hpp"
+#include "glb_row_persist.hpp"
 #include "glb_row_stream.hpp"
 
 #ifndef GLB_DT
@@ -38,33 +37,18 @@ static hipError_t launch_geom(const RowParams &p, int geom, hipStream_t s) {
 }
 
 // persistent pipelined variant (glb_row_kernel_v2.hpp): 512 threads (2 waves / SIMD, 256 VGPRs),
-// ids -> (NVL, NL, ND):  21:(25,19,6) fp32 gpt2-sized rows   22:(16,16,0)   23:(32,17,11) 16-bit 128k rows
+// persistent kernel (glb_row_persist.hpp), 512 threads; ids -> NVL:  21: 25 (fp32 gpt2-sized rows)   22: 16   23: 32 (16-bit 128k rows)
 #if GLB_MODE != 2
-template <int MASK, int NVL, int NL, int ND>
+template <int MASK, int NVL>
 static hipError_t launch2(const RowParams &p0, int grid, hipStream_t s) {
   RowParams p = p0;
   constexpr int GS = (NVL % 5 == 0) ? 5 : 4;
   p.n_chunks = 8 * (NVL / GS);
   p.chunk_vecs = GS * 64;
   if (p.use_scale)
-    hipLaunchKernelGGL((row_kernel_v2<GLB_DT, MASK, GLB_MODE, NVL, NL, ND, 512, true>), dim3(grid), dim3(512), 0, s, p);
+    hipLaunchKernelGGL((row_kernel_persist<GLB_DT, MASK, GLB_MODE, NVL, 512, true>), dim3(grid), dim3(512), 0, s, p);
   else
-    hipLaunchKernelGGL((row_kernel_v2<GLB_DT, MASK, GLB_MODE, NVL, NL, ND, 512, false>), dim3(grid), dim3(512), 0, s, p);
-  hipError_t e = hipGetLastError();
-  return e;
-}
-
-// in-place register prefetch variant (glb_row_kernel_v4.hpp): ids 41/42/43 = the geometries of 21/22/23
-template <int MASK, int NVL>
-static hipError_t launch4(const RowParams &p0, int grid, hipStream_t s) {
-  RowParams p = p0;
-  constexpr int GS = (NVL % 5 == 0) ? 5 : 4;
-  p.n_chunks = 8 * (NVL / GS);
-  p.chunk_vecs = GS * 64;
-  if (p.use_scale)
-    hipLaunchKernelGGL((row_kernel_v4<GLB_DT, MASK, GLB_MODE, NVL, 512, true>), dim3(grid), dim3(512), 0, s, p);
-  else
-    hipLaunchKernelGGL((row_kernel_v4<GLB_DT, MASK, GLB_MODE, NVL, 512, false>), dim3(grid), dim3(512), 0, s, p);
+    hipLaunchKernelGGL((row_kernel_persist<GLB_DT, MASK, GLB_MODE, NVL, 512, false>), dim3(grid), dim3(512), 0, s, p);
   return hipGetLastError();
 }
 
@@ -72,17 +56,11 @@ template <int MASK>
 static hipError_t launch_geom2(const RowParams &p, int geom, int grid, hipStream_t s) {
   switch (geom) {
 #if GLB_DT == 0
-    case 21: return launch2<MASK, 25, 19, 6>(p, grid, s);
+    case 21: return launch2<MASK, 25>(p, grid, s);
 #else
-    case 23: return launch2<MASK, 32, 17, 11>(p, grid, s);
+    case 23: return launch2<MASK, 32>(p, grid, s);
 #endif
-    case 22: return launch2<MASK, 16, 16, 0>(p, grid, s);
-#if GLB_DT == 0
-    case 41: return launch4<MASK, 25>(p, grid, s);
-#else
-    case 43: return launch4<MASK, 32>(p, grid, s);
-#endif
-    case 42: return launch4<MASK, 16>(p, grid, s);
+    case 22: return launch2<MASK, 16>(p, grid, s);
     default: return hipErrorInvalidValue;
   }
 }

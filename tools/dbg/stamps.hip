@@ -5,15 +5,15 @@
 #include <algorithm>
 #include <cstdio>
 #include <vector>
-#include "../../genlm-backend_amd/csrc/glb_row_kernel_v2.hpp"
+#include "../../genlm-backend_amd/csrc/glb_row_persist.hpp"
 int main() {
   const int B = 1024, V = 50257;
   float *x;
-  hipMalloc(&x, (size_t)B * V * 4 * 2);
+  hipMalloc(&x, (size_t)B * V * 4 * 4);
   std::vector<float> h((size_t)B * V);
   for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) % 1000) * 0.01f - 5.f;
   hipMemcpy(x, h.data(), h.size() * 4, hipMemcpyHostToDevice);
-  hipMemcpy(x + h.size(), h.data(), h.size() * 4, hipMemcpyHostToDevice);
+  for (int c = 1; c < 4; ++c) hipMemcpy(x + c * h.size(), h.data(), h.size() * 4, hipMemcpyHostToDevice);
   float *lz, *ls;
   hipMalloc(&lz, B * 4);
   hipMalloc(&ls, B * 4);
@@ -28,30 +28,40 @@ int main() {
   hipMalloc(&mk, (size_t)2 * W32 * 4);
   hipMemset(mk, 0xB7, (size_t)2 * W32 * 4);
   p.mask = mk; p.mask_ld = W32; p.n_masks = 1;
+  int32_t *tok;
+  hipMalloc(&tok, B * 4);
+  p.out_token = tok; p.seed = 5;
   for (int skew : {0}) {
-  hipMemcpyToSymbol(HIP_SYMBOL(glb::g_skew_cycles), &skew, 4);
-  for (int it = 0; it < 6; ++it) {
-    p.logits = x + (it & 1) * h.size();
-    hipLaunchKernelGGL((glb::row_kernel_v2<0, MASKK, MODEE, 25, 19, 6, 512, false>), dim3(256), dim3(512), 0, 0, p);
+  for (int it = 0; it < 8; ++it) {
+    p.logits = x + (it & 3) * h.size();
+    hipLaunchKernelGGL((glb::row_kernel_persist<0, MASKK, MODEE, 25, 512, false>), dim3(256), dim3(512), 0, 0, p);
   }
   hipDeviceSynchronize();
   std::vector<unsigned long long> st(256 * 2 * 64), rt(512);
   hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(glb::g_stamps), st.size() * 8);
   hipMemcpyFromSymbol(rt.data(), HIP_SYMBOL(glb::g_realtime), rt.size() * 8);
   const char *names[] = {"issue0", "arrive0", "land0"};
-  for (int wg : {0, 8}) { if (skew != 0 && skew != 10000) break;
+  for (int wg : {0}) { if (skew != 0 && skew != 10000) break;
     for (int wv = 0; wv < 2; ++wv) {
       const unsigned long long *s = &st[(wg * 2 + wv) * 64];
       printf("WG %3d wave %s:", wg, wv ? "last " : "first");
       int i = 1;
+#ifdef V4
+      for (; i < 2 && s[i]; ++i) printf(" first row issued+mask %llu", s[i] - s[i - 1]);
+#else
       for (; i < 4 && s[i]; ++i) printf(" %s %llu", names[i - 1], s[i] - s[i - 1]);
+#endif
       int row = 0;
       while (i < 64 && s[i]) {
         printf(" | row%d ph1 %llu", row, s[i] - s[i - 1]); ++i;
         if (i < 64 && s[i]) { printf(" ph2 %llu", s[i] - s[i - 1]); ++i; }
         if (i < 64 && s[i]) { printf(" red %llu", s[i] - s[i - 1]); ++i; }
+#ifdef V4
+        if (i < 64 && s[i]) { printf(" bits/tail %llu", s[i] - s[i - 1]); ++i; }
+#else
         if (i < 64 && s[i]) { printf(" wait %llu", s[i] - s[i - 1]); ++i; }
         if (i < 64 && s[i]) { printf(" land %llu", s[i] - s[i - 1]); ++i; }
+#endif
         ++row;
       }
       printf("  total %llu cyc", s[i - 1] - s[0]);
@@ -60,6 +70,23 @@ int main() {
       printf("\n");
     }
   }
+#ifdef V4
+  {  // averages over all workgroups: stamps 0 start, 1 prologue, then per row ph1 ph2 red bits (last row: tail)
+    for (int wv = 0; wv < 2; ++wv) {
+      double sum[32] = {0};
+      for (int wg = 0; wg < 256; ++wg) {
+        const unsigned long long *q = &st[(wg * 2 + wv) * 64];
+        for (int i = 1; i < 22; ++i) sum[i] += (double)(q[i] - q[i - 1]);
+      }
+      printf("AVG wave %s: prologue %.0f |", wv ? "last " : "first", sum[1] / 256);
+      for (int r = 0; r < 4; ++r)
+        printf(" row%d ph1 %.0f ph2 %.0f red %.0f %s %.0f |", r, sum[2 + 4 * r] / 256, sum[3 + 4 * r] / 256,
+               sum[4 + 4 * r] / 256, r == 3 ? "tail" : "bits", sum[5 + 4 * r] / 256);
+      printf("\n   tail: drain+barrier %.0f fix %.0f select+tiles %.0f exchange %.0f final %.0f\n", sum[17] / 256,
+             sum[18] / 256, sum[19] / 256, sum[20] / 256, sum[21] / 256);
+    }
+  }
+#endif
   unsigned long long mn = ~0ull, mx = 0;
   for (int wg = 0; wg < 256; ++wg) {
     mn = std::min(mn, rt[wg * 2]);
