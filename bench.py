@@ -161,6 +161,17 @@ def main():
         dt = float(t.item())
 
     kern_us = runner.kernel_times_us()
+    # HBM bytes per launch of the fused kernel from the rocprofv3 PMC passes of this same command (collected
+    # with tools/profile_round.sh - counters cannot be read from inside the process); kernel workload only
+    traffic = None
+    if workload == "kernel":
+        try:
+            prof = sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*", "kernel_workload_pmc_traffic_v*.json")))
+            if prof:
+                t = json.load(open(prof[-1]))
+                traffic = t["hbm_read_bytes_per_launch_corrected"] + t["hbm_write_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            traffic = None
     if rank == 0:
         total_particles = runner.particles_per_step * world * args.steps
         ach = runner.kernel_bytes / (np.mean(kern_us) * 1e-6) / 1e9
@@ -184,8 +195,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS,
-                "traffic": None,
-                "kernel": "glb::row_kernel (fused log-softmax + mask + logsumexp + sample)",
+                "traffic": traffic,
+                "kernel": "glb::row_kernel_persist (fused log-softmax + mask + logsumexp + sample; lse/logZ/token finished in its tail)",
                 "bytes_per_launch": runner.kernel_bytes,
                 "us_per_launch_mean": float(np.mean(kern_us)),
                 "us_per_launch_median": float(np.median(kern_us)),

@@ -321,7 +321,7 @@ __global__ __launch_bounds__(1024) void normalize_weights_kernel(const float *lw
   m = s_m[0];
 #pragma unroll
   for (int w = 1; w < 16; ++w) m = fmaxf(m, s_m[w]);
-  const float N = __builtin_rintf(m * kLog2e), N2 = __builtin_rintf((m + m) * kLog2e);
+  const float N = exp_n(m), N2 = exp_n(m + m);
   const float Nb = N + (float)kFixShift, Nb2 = N2 + (float)kFixShift;
   uint64_t S = 0, S2 = 0;
   for (int64_t i = tid; i < n; i += T) {

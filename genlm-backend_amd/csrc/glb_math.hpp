@@ -11,8 +11,8 @@
 namespace glb {
 
 constexpr float kLog2e = __builtin_bit_cast(float, 0x3FB8AA3Bu);  // 1.44269502
-constexpr float kLn2Hi = __builtin_bit_cast(float, 0x3F317200u);  // 0.693145752
-constexpr float kLn2Lo = __builtin_bit_cast(float, 0x35BFBE8Eu);  // 1.42860677e-06
+constexpr float kMagic = 12582912.0f;  // 1.5 * 2^23 (0x4B400000): x + kMagic has rint(x) in its low mantissa bits
+constexpr uint32_t kMagicBits = 0x4B400000u;
 constexpr int kFixShift = 18;  // S = sum floor(P * 2^32 >> (18 + N - n)), 44 fractional bits
 constexpr int kFixFrac = 44;
 // masked sums stay on the row's scale unless that leaves them fewer than 37 significant bits
@@ -20,37 +20,50 @@ constexpr uint64_t kLowMass = 1ull << 37;
 constexpr double kLn2D = 0.693147180559945309417232121458;
 constexpr float kNegInf = -__builtin_huge_valf();
 
-// degree-5 polynomial for e^r on |r| <= ln2/2 (max rel. error 2.6e-7), coefficients times 2^30
-constexpr float kS30 = 1073741824.0f;
-constexpr float kC0 = __builtin_bit_cast(float, 0x3f800000u) * kS30;
-constexpr float kC1 = __builtin_bit_cast(float, 0x3f800000u) * kS30;
-constexpr float kC2 = __builtin_bit_cast(float, 0x3effff2du) * kS30;
-constexpr float kC3 = __builtin_bit_cast(float, 0x3e2aaa6eu) * kS30;
-constexpr float kC4 = __builtin_bit_cast(float, 0x3d2b8604u) * kS30;
-constexpr float kC5 = __builtin_bit_cast(float, 0x3c0905d1u) * kS30;
+// degree-5 minimax polynomial for 2^f on |f| <= 1/2 (max rel. error 1.6e-7 as evaluated in fp32 Horner
+// form), coefficients times 2^30; the constant term is exactly 2^30
+constexpr float kC0 = __builtin_bit_cast(float, 0x4e800000u);
+constexpr float kC1 = __builtin_bit_cast(float, 0x4e317216u);
+constexpr float kC2 = __builtin_bit_cast(float, 0x4d75fcd9u);
+constexpr float kC3 = __builtin_bit_cast(float, 0x4c635b16u);
+constexpr float kC4 = __builtin_bit_cast(float, 0x4b1e7722u);
+constexpr float kC5 = __builtin_bit_cast(float, 0x49adfe07u);
 
-// e^x = 2^n * P / 2^30 ; returns n (integer valued float) and P (float in [0.70, 1.42] * 2^30)
+// binary exponent of e^x: n = x * log2(e) rounded to the nearest integer in ONE rounding (the fma adds the
+// magic constant before rounding), returned as an integer-valued float.  Valid for |x * log2 e| < 2^22.
+__device__ __forceinline__ float exp_n(float x) { return __builtin_fmaf(x, kLog2e, kMagic) - kMagic; }
+
+// e^x = 2^n * P / 2^30 ; returns n (integer valued float) and P (float in [0.7071, 1.4143] * 2^30):
+// f = x * log2(e) - n in one fma (|f| <= 1/2), P = 2^30 * 2^f by Horner.  Accuracy: the product uses the fp32
+// value of log2(e), i.e. e^(x (1 + 1.4e-8)) - as if the logit carried a quarter-ulp error.
 __device__ __forceinline__ void exp_parts(float x, float &nf, float &P) {
-  float t = x * kLog2e;
-  nf = __builtin_rintf(t);
-  float r = __builtin_fmaf(nf, -kLn2Hi, x);
-  r = __builtin_fmaf(nf, -kLn2Lo, r);
+  const float tm = __builtin_fmaf(x, kLog2e, kMagic);
+  const float neg_n = kMagic - tm;
+  nf = tm - kMagic;
+  const float f = __builtin_fmaf(x, kLog2e, neg_n);
   float p = kC5;
-  p = __builtin_fmaf(p, r, kC4);
-  p = __builtin_fmaf(p, r, kC3);
-  p = __builtin_fmaf(p, r, kC2);
-  p = __builtin_fmaf(p, r, kC1);
-  p = __builtin_fmaf(p, r, kC0);
+  p = __builtin_fmaf(p, f, kC4);
+  p = __builtin_fmaf(p, f, kC3);
+  p = __builtin_fmaf(p, f, kC2);
+  p = __builtin_fmaf(p, f, kC1);
+  p = __builtin_fmaf(p, f, kC0);
   P = p;
 }
 
+// float -> uint32 as the hardware does it (v_cvt_u32_f32: NaN and negatives -> 0, >= 2^32 -> 0xffffffff); spelled
+// as an instruction because a C cast of NaN is undefined and gets folded
+__device__ __forceinline__ uint32_t cvt_u32_sat(float v) {
+  uint32_t r;
+  asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(v));
+  return r;
+}
+
 // fixed-point term of x relative to the row exponent N (N + 18 passed pre-added as Nb).
-// x == -inf contributes 0 (sf = +inf -> s = 63 -> pfix = 0).
+// x == -inf contributes 0 (f is NaN -> P is NaN -> pfix = 0).
 __device__ __forceinline__ uint64_t fix_term_from_parts(float nf, float P, float Nb) {
-  // s = min(Nb - n, 63) (NaN -> 63); P < 2^31 so a shift by 63 always yields 0, which makes the
-  // oracle's "pfix = 0 when s == 63" select redundant here (v_cvt_u32_f32 maps NaN to 0).
-  const uint32_t s = (uint32_t)fminf(Nb - nf, 63.0f);
-  const uint32_t pfix = (uint32_t)P;
+  // s = min(Nb - n, 63) (NaN -> 63); P < 2^31 so a shift by 63 always yields 0
+  const uint32_t s = cvt_u32_sat(fminf(Nb - nf, 63.0f));
+  const uint32_t pfix = cvt_u32_sat(P);
   return ((uint64_t)pfix << 32) >> s;
 }
 
@@ -60,71 +73,64 @@ __device__ __forceinline__ uint64_t fix_term(float x, float Nb) {
   return fix_term_from_parts(nf, P, Nb);
 }
 
-// Four independent exp splits + fixed-point operands, hand-interleaved.  hipcc emits each element's
-// 13-instruction dependency chain back to back (every instruction waits on the previous one: half of
-// the issue slots of a 2-wave/SIMD kernel are stalls); here the four chains advance in lock step.
-// Same instructions, same roundings as exp_parts + fix_term_from_parts:
-//   pf[c] = (uint32) P(x_c),  sh[c] = (uint32) min(Nb - n(x_c), 63),  term = ((uint64)pf << 32) >> sh.
+// Four independent exp splits + fixed-point operands, hand-interleaved (the four dependency chains advance in
+// lock step) and with the shift taken in the integer domain: n sits in the low mantissa bits of
+// tm = fma(x, log2e, magic), so  sh = min(bits(Nb + magic) - bits(tm), 63)  is two integer instructions instead
+// of subtract / min / convert.  Same values as exp_parts + fix_term_from_parts for |x * log2 e| < 2^22:
+//   pf[c] = (uint32) P(x_c),  sh[c] = min(Nb - n(x_c), 63),  term = ((uint64)pf << 32) >> sh.
 __device__ __forceinline__ void exp_fix4(float x0, float x1, float x2, float x3, float Nb,
                                          uint32_t (&pf)[4], uint32_t (&sh)[4]) {
   float r0, r1, r2, r3;
-  const float c4 = kC4, nhi = -kLn2Hi, nlo = -kLn2Lo;
+  const float c4 = kC4, l2e = kLog2e, magic = kMagic;
+  const uint32_t nbi = __float_as_uint(Nb + kMagic);
   asm volatile(
-      "v_mul_f32 %0, 0x3fb8aa3b, %12\n\t"
-      "v_mul_f32 %1, 0x3fb8aa3b, %13\n\t"
-      "v_mul_f32 %2, 0x3fb8aa3b, %14\n\t"
-      "v_mul_f32 %3, 0x3fb8aa3b, %15\n\t"
-      "v_rndne_f32 %4, %0\n\t"
-      "v_rndne_f32 %5, %1\n\t"
-      "v_rndne_f32 %6, %2\n\t"
-      "v_rndne_f32 %7, %3\n\t"
-      "v_fma_f32 %8, %4, %18, %12\n\t"
-      "v_fma_f32 %9, %5, %18, %13\n\t"
-      "v_fma_f32 %10, %6, %18, %14\n\t"
-      "v_fma_f32 %11, %7, %18, %15\n\t"
-      "v_fma_f32 %8, %4, %19, %8\n\t"
-      "v_fma_f32 %9, %5, %19, %9\n\t"
-      "v_fma_f32 %10, %6, %19, %10\n\t"
-      "v_fma_f32 %11, %7, %19, %11\n\t"
-      "v_fmamk_f32 %0, %8, 0x4b0905d1, %17\n\t"
-      "v_fmamk_f32 %1, %9, 0x4b0905d1, %17\n\t"
-      "v_fmamk_f32 %2, %10, 0x4b0905d1, %17\n\t"
-      "v_fmamk_f32 %3, %11, 0x4b0905d1, %17\n\t"
-      "v_fmaak_f32 %0, %0, %8, 0x4d2aaa6e\n\t"
-      "v_fmaak_f32 %1, %1, %9, 0x4d2aaa6e\n\t"
-      "v_fmaak_f32 %2, %2, %10, 0x4d2aaa6e\n\t"
-      "v_fmaak_f32 %3, %3, %11, 0x4d2aaa6e\n\t"
-      "v_fmaak_f32 %0, %0, %8, 0x4dffff2d\n\t"
-      "v_fmaak_f32 %1, %1, %9, 0x4dffff2d\n\t"
-      "v_fmaak_f32 %2, %2, %10, 0x4dffff2d\n\t"
-      "v_fmaak_f32 %3, %3, %11, 0x4dffff2d\n\t"
+      "v_fmaak_f32 %4, %18, %12, 0x4b400000\n\t"
+      "v_fmaak_f32 %5, %18, %13, 0x4b400000\n\t"
+      "v_fmaak_f32 %6, %18, %14, 0x4b400000\n\t"
+      "v_fmaak_f32 %7, %18, %15, 0x4b400000\n\t"
+      "v_sub_f32 %8, %19, %4\n\t"
+      "v_sub_f32 %9, %19, %5\n\t"
+      "v_sub_f32 %10, %19, %6\n\t"
+      "v_sub_f32 %11, %19, %7\n\t"
+      "v_fmac_f32 %8, %18, %12\n\t"
+      "v_fmac_f32 %9, %18, %13\n\t"
+      "v_fmac_f32 %10, %18, %14\n\t"
+      "v_fmac_f32 %11, %18, %15\n\t"
+      "v_fmamk_f32 %0, %8, 0x49adfe07, %17\n\t"
+      "v_fmamk_f32 %1, %9, 0x49adfe07, %17\n\t"
+      "v_fmamk_f32 %2, %10, 0x49adfe07, %17\n\t"
+      "v_fmamk_f32 %3, %11, 0x49adfe07, %17\n\t"
+      "v_fmaak_f32 %0, %0, %8, 0x4c635b16\n\t"
+      "v_fmaak_f32 %1, %1, %9, 0x4c635b16\n\t"
+      "v_fmaak_f32 %2, %2, %10, 0x4c635b16\n\t"
+      "v_fmaak_f32 %3, %3, %11, 0x4c635b16\n\t"
+      "v_fmaak_f32 %0, %0, %8, 0x4d75fcd9\n\t"
+      "v_fmaak_f32 %1, %1, %9, 0x4d75fcd9\n\t"
+      "v_fmaak_f32 %2, %2, %10, 0x4d75fcd9\n\t"
+      "v_fmaak_f32 %3, %3, %11, 0x4d75fcd9\n\t"
+      "v_fmaak_f32 %0, %0, %8, 0x4e317216\n\t"
+      "v_fmaak_f32 %1, %1, %9, 0x4e317216\n\t"
+      "v_fmaak_f32 %2, %2, %10, 0x4e317216\n\t"
+      "v_fmaak_f32 %3, %3, %11, 0x4e317216\n\t"
       "v_fmaak_f32 %0, %0, %8, 0x4e800000\n\t"
       "v_fmaak_f32 %1, %1, %9, 0x4e800000\n\t"
       "v_fmaak_f32 %2, %2, %10, 0x4e800000\n\t"
       "v_fmaak_f32 %3, %3, %11, 0x4e800000\n\t"
-      "v_fmaak_f32 %0, %0, %8, 0x4e800000\n\t"
-      "v_fmaak_f32 %1, %1, %9, 0x4e800000\n\t"
-      "v_fmaak_f32 %2, %2, %10, 0x4e800000\n\t"
-      "v_fmaak_f32 %3, %3, %11, 0x4e800000\n\t"
-      "v_sub_f32 %4, %16, %4\n\t"
-      "v_sub_f32 %5, %16, %5\n\t"
-      "v_sub_f32 %6, %16, %6\n\t"
-      "v_sub_f32 %7, %16, %7\n\t"
-      "v_min_f32 %4, 0x427c0000, %4\n\t"
-      "v_min_f32 %5, 0x427c0000, %5\n\t"
-      "v_min_f32 %6, 0x427c0000, %6\n\t"
-      "v_min_f32 %7, 0x427c0000, %7\n\t"
-      "v_cvt_u32_f32 %4, %4\n\t"
-      "v_cvt_u32_f32 %5, %5\n\t"
-      "v_cvt_u32_f32 %6, %6\n\t"
-      "v_cvt_u32_f32 %7, %7\n\t"
+      "v_sub_u32 %4, %16, %4\n\t"
+      "v_sub_u32 %5, %16, %5\n\t"
+      "v_sub_u32 %6, %16, %6\n\t"
+      "v_sub_u32 %7, %16, %7\n\t"
+      "v_min_u32 %4, 63, %4\n\t"
+      "v_min_u32 %5, 63, %5\n\t"
+      "v_min_u32 %6, 63, %6\n\t"
+      "v_min_u32 %7, 63, %7\n\t"
       "v_cvt_u32_f32 %0, %0\n\t"
       "v_cvt_u32_f32 %1, %1\n\t"
       "v_cvt_u32_f32 %2, %2\n\t"
       "v_cvt_u32_f32 %3, %3"
       : "=&v"(pf[0]), "=&v"(pf[1]), "=&v"(pf[2]), "=&v"(pf[3]), "=&v"(sh[0]), "=&v"(sh[1]), "=&v"(sh[2]),
         "=&v"(sh[3]), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
-      : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(Nb), "v"(c4), "s"(nhi), "s"(nlo));
+      : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(nbi), "v"(c4), "v"(l2e), "s"(magic));  // (a literal and an SGPR cannot share an instruction on gfx9)
 }
 
 // ln(S * 2^k) for integer S > 0 (atanh series in double, fixed op order)

@@ -257,8 +257,8 @@ __global__ __launch_bounds__(T) void row_kernel(const RowParams p) {
   } else {
     m_msk = m_all;
   }
-  const float N_all = __builtin_rintf(m_all * kLog2e);
-  const float N_msk = __builtin_rintf(m_msk * kLog2e);
+  const float N_all = exp_n(m_all);
+  const float N_msk = exp_n(m_msk);
   const float Nb_all = N_all + (float)kFixShift, Nb_msk = N_msk + (float)kFixShift;
   // Masked sums (GLB math): on the row's scale N_all - there the masked term of a bit mask is the
   // unmasked term gated by the mask bit - unless the masked maximum lies above it (additive masks only)

@@ -50,6 +50,16 @@ __device__ __forceinline__ uint4 gload16(gptr_t src) {  // global_load_dwordx4 (
   return make_uint4(t.x, t.y, t.z, t.w);
 }
 
+// Uniform read of one input index through the scalar cache.  hipcc will not use s_load here by itself (the
+// kernel also stores to global memory, so it cannot prove the array unclobbered) and its vector load of a
+// uniform address comes with `s_waitcnt vmcnt(0)`: at the top of a row that drains every prefetched tile.
+__device__ __forceinline__ int32_t sload_i32(const int32_t *base, int idx) {
+  int32_t v;
+  const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane(idx) * 4u;
+  asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(base), "s"(off) : "memory");
+  return v;
+}
+
 // ---- LDS scratch by inline asm + raw barrier (nothing here touches vmcnt) ---------------------------------
 __device__ __forceinline__ uint32_t lds_addr(const void *p) {
   return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
@@ -126,6 +136,10 @@ __device__ unsigned long long g_realtime[256 * 2];
 #define GLB_STAMP() do { } while (0)
 #endif
 
+// (Tried and removed: a second register buffer holding the first 8-12 tiles of row r+2, requested right after the
+//  sums pass of row r so that the memory queue is also fed during the reductions.  hipcc's counted waits for the
+//  in-place tiles do not look past those younger loads - the maximum pass ended up waiting for the look-ahead
+//  tiles too - and the kernel got slower: 60.5 / 96.8 us for 8 / 12 tiles against 57.8.)
 template <int DT, int MASK, int MODE, int NVL, int T, bool SCALED>
 __global__ __launch_bounds__(T) void row_kernel_persist(const RowParams p) {
   constexpr int W = T / 64;
@@ -174,7 +188,7 @@ __global__ __launch_bounds__(T) void row_kernel_persist(const RowParams p) {
   auto row_ref = [&](int vb) {
     RowRef r;
     r.pidx = particle_of(vb);
-    const int row = p.row_of ? p.row_of[r.pidx] : r.pidx;
+    const int row = p.row_of ? sload_i32(p.row_of, r.pidx) : r.pidx;
     const char *rowp = (const char *)p.logits + (int64_t)row * p.ld * ES;
     r.a = (int)(((uintptr_t)rowp) & 15) / ES;
     r.base = (gptr_t)(rowp - r.a * ES);
@@ -183,7 +197,7 @@ __global__ __launch_bounds__(T) void row_kernel_persist(const RowParams p) {
     r.am = 0;
     r.mvec = 1;
     if constexpr (kBits) {
-      const int mi = p.mask_id ? p.mask_id[r.pidx] : (p.n_masks == 1 ? 0 : r.pidx);
+      const int mi = p.mask_id ? sload_i32(p.mask_id, r.pidx) : (p.n_masks == 1 ? 0 : r.pidx);
       const char *mp = (const char *)p.mask + (int64_t)mi * p.mask_ld * 4;
       r.am = (int)(((uintptr_t)mp) & 15) / 4;
       r.mrow16 = (gptr_t)(mp - r.am * 4);
@@ -298,7 +312,7 @@ __global__ __launch_bounds__(T) void row_kernel_persist(const RowParams p) {
     if (lane == 0) lds_write_b32(scr_max + wave * 4, __float_as_uint(m_all));
     lds_barrier();
     m_all = row16_max_bcast(__uint_as_float(lds_read_b32_wait(scr_max + wr * 4)));
-    const float N_all = __builtin_rintf(m_all * kLog2e);
+    const float N_all = exp_n(m_all);
     const float Nb_all = N_all + (float)kFixShift;
     GLB_STAMP();
 
@@ -501,7 +515,7 @@ __global__ __launch_bounds__(T) void row_kernel_persist(const RowParams p) {
       mk = row16_max_bcast(__uint_as_float(lds_read_b32_wait(scr_max + wr * 4)));
       lds_barrier();  // scratch is reused by the next flagged row
       if (!(mk > kNegInf)) continue;  // nothing allowed (workgroup-uniform): the sums on the row's scale are 0
-      const float N_k = __builtin_rintf(mk * kLog2e);
+      const float N_k = exp_n(mk);
       const float Nb = N_k + (float)kFixShift;
       uint64_t s_w = 0;
 #pragma unroll 1

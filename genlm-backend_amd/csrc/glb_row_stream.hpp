@@ -77,7 +77,7 @@ __global__ __launch_bounds__(1024) void row_stream_kernel(const RowParams p) {
     m_all = fmaxf(m_all, s_max[0][w]);
     m_msk = fmaxf(m_msk, s_max[1][w]);
   }
-  const float N_all = __builtin_rintf(m_all * kLog2e), N_msk = __builtin_rintf(m_msk * kLog2e);
+  const float N_all = exp_n(m_all), N_msk = exp_n(m_msk);
   const float Nb_all = N_all + (float)kFixShift, Nb_msk = N_msk + (float)kFixShift;
 
   // pass 2: fixed-point sums.  GLB math keeps the masked sum on the row's scale N_all unless that leaves it

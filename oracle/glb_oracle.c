@@ -69,14 +69,16 @@ static float load_elem(const void *base, int dtype, int64_t idx) {
 
 /* ---------------------------------------------------------------- GLB math (layer B) */
 
-/* exp split: e^x = 2^n * P(r),  n = rint(x*log2e),  r = x - n*ln2 (two-constant Cody-Waite),
- * P = degree-5 polynomial evaluated by Horner with correctly rounded FMAs, pre-scaled by 2^30.
- * Returns n (as float, integer valued) and Pfix = (uint32)P in [0.70*2^30, 1.42*2^30]. */
-#define GLB_LOG2E 1.44269502162933349609375f     /* 0x3FB8AA3B */
-#define GLB_LN2_HI 0.693145751953125f            /* 0x3F317200 */
-#define GLB_LN2_LO 1.42860676533018704503775e-06f /* 0x35BFBE8E */
-static const uint32_t GLB_EXP_C[6] = {0x3f800000u, 0x3f800000u, 0x3effff2du,
-                                      0x3e2aaa6eu, 0x3d2b8604u, 0x3c0905d1u};
+/* exp split: e^x = 2^n * 2^f,  n = x*log2e rounded to nearest in ONE rounding (the fma adds the magic
+ * constant 1.5*2^23 before rounding, so n sits in the low mantissa bits of the result),  f = x*log2e - n
+ * in one fma (|f| <= 1/2),  P = 2^30 * 2^f by a degree-5 minimax polynomial in Horner form with correctly
+ * rounded FMAs.  Returns n (as float, integer valued) and P in [0.7071*2^30, 1.4143*2^30].
+ * Valid for |x*log2e| < 2^22 (|x| < 2.9e6); the product uses the fp32 value of log2(e), i.e. the result is
+ * e^(x(1+1.4e-8)). */
+#define GLB_LOG2E 1.44269502162933349609375f /* 0x3FB8AA3B */
+#define GLB_MAGIC 12582912.0f                /* 0x4B400000 = 1.5 * 2^23 */
+static const uint32_t GLB_EXP_C[6] = {0x4e800000u, 0x4e317216u, 0x4d75fcd9u,
+                                      0x4c635b16u, 0x4b1e7722u, 0x49adfe07u}; /* times 2^30 */
 #define GLB_FIX_SHIFT 18 /* S has 44 fractional bits: 2^30 (Pfix) * 2^32 >> 18 */
 #define GLB_FIX_FRAC 44
 /* masked sums are taken on the row's own scale unless that leaves them fewer than 37 significant bits */
@@ -88,20 +90,28 @@ static float u2f(uint32_t u) {
   return f;
 }
 
+/* binary exponent of e^x as an integer-valued float (row maxima, log-weights) */
+static float glb_exp_n(float x) { return fmaf(x, GLB_LOG2E, GLB_MAGIC) - GLB_MAGIC; }
+
 static void glb_exp_parts(float x, float *nf_out, float *P_out) {
-  const float S30 = 1073741824.0f; /* 2^30, exact scaling of the coefficients */
-  float t = x * GLB_LOG2E;
-  float nf = rintf(t);
-  float r = fmaf(nf, -GLB_LN2_HI, x);
-  r = fmaf(nf, -GLB_LN2_LO, r);
-  float p = u2f(GLB_EXP_C[5]) * S30;
-  p = fmaf(p, r, u2f(GLB_EXP_C[4]) * S30);
-  p = fmaf(p, r, u2f(GLB_EXP_C[3]) * S30);
-  p = fmaf(p, r, u2f(GLB_EXP_C[2]) * S30);
-  p = fmaf(p, r, u2f(GLB_EXP_C[1]) * S30);
-  p = fmaf(p, r, u2f(GLB_EXP_C[0]) * S30);
-  *nf_out = nf;
+  float tm = fmaf(x, GLB_LOG2E, GLB_MAGIC);
+  float neg_n = GLB_MAGIC - tm;
+  float f = fmaf(x, GLB_LOG2E, neg_n);
+  float p = u2f(GLB_EXP_C[5]);
+  p = fmaf(p, f, u2f(GLB_EXP_C[4]));
+  p = fmaf(p, f, u2f(GLB_EXP_C[3]));
+  p = fmaf(p, f, u2f(GLB_EXP_C[2]));
+  p = fmaf(p, f, u2f(GLB_EXP_C[1]));
+  p = fmaf(p, f, u2f(GLB_EXP_C[0]));
+  *nf_out = tm - GLB_MAGIC;
   *P_out = p;
+}
+
+/* float -> uint32 as v_cvt_u32_f32 does it: NaN and negatives -> 0, >= 2^32 -> 0xffffffff, else truncate */
+static uint32_t cvt_u32_sat(float v) {
+  if (!(v > 0.0f)) return 0u;
+  if (v >= 4294967296.0f) return 0xffffffffu;
+  return (uint32_t)v;
 }
 
 /* fixed-point term of element x relative to row exponent Nf: floor(P*2^32 / 2^(18 + N - n)) */
@@ -110,8 +120,8 @@ static uint64_t glb_fix_term(float x, float Nf) {
   if (!(x > -INFINITY)) return 0; /* -inf (and NaN) contribute nothing */
   glb_exp_parts(x, &nf, &P);
   float sf = (Nf + (float)GLB_FIX_SHIFT) - nf;
-  uint32_t s = (sf < 63.0f) ? (uint32_t)sf : 63u;
-  uint32_t pfix = (s < 63u) ? (uint32_t)P : 0u;
+  uint32_t s = cvt_u32_sat(fminf(sf, 63.0f)); /* fminf(NaN, 63) = 63 */
+  uint32_t pfix = cvt_u32_sat(P);
   return ((uint64_t)pfix << 32) >> s;
 }
 
@@ -208,8 +218,8 @@ int orc_step(const void *logits, int dtype, int64_t n_rows, int64_t V, int64_t l
       if (v > st.m_all) st.m_all = v;
       if (vm > st.m_mask) st.m_mask = vm;
     }
-    st.N_all = rintf(st.m_all * GLB_LOG2E);
-    const float N_k = rintf(st.m_mask * GLB_LOG2E); /* exponent of the masked maximum (race scale) */
+    st.N_all = glb_exp_n(st.m_all);
+    const float N_k = glb_exp_n(st.m_mask); /* exponent of the masked maximum (race scale) */
     st.S_all = 0;
     for (int64_t j = 0; j < V; ++j) st.S_all += glb_fix_term(x[j], st.N_all);
     /* Masked sum: on the row's scale N_all (one exponential per element serves both sums) when the
@@ -280,7 +290,7 @@ int orc_log_softmax_rows(const void *logits, int dtype, int64_t n_rows, int64_t 
       if (logit_scale != 1.0f) v = v * logit_scale;
       if (v > m) m = v;
     }
-    float N = rintf(m * GLB_LOG2E);
+    float N = glb_exp_n(m);
     uint64_t S = 0;
     for (int64_t j = 0; j < V; ++j) {
       float v = load_elem(logits, dtype, r * ld + j);
@@ -320,8 +330,8 @@ int orc_normalize_weights(const float *lw, int64_t n, float *out_probs, float *o
   float m = -INFINITY;
   for (int64_t i = 0; i < n; ++i)
     if (lw[i] > m) m = lw[i];
-  float N = rintf(m * GLB_LOG2E);
-  float N2 = rintf((m + m) * GLB_LOG2E);
+  float N = glb_exp_n(m);
+  float N2 = glb_exp_n(m + m);
   uint64_t S = 0, S2 = 0;
   for (int64_t i = 0; i < n; ++i) {
     S += glb_fix_term(lw[i], N);
