@@ -125,7 +125,7 @@ class HipEngine:
         if variant == 0 or variant >= 21:  # lend scratch: enables the persistent pipelined kernel
             need = self.lib.glb_step_workspace_bytes(n)
             if self._step_ws is None or self._step_ws.numel() < need:
-                self._step_ws = torch.zeros(max(need, 1 << 20), dtype=torch.uint8, device=self.device)  # zeroed once: holds the split-row kernel's granules
+                self._step_ws = torch.zeros(max(need, 1 << 20), dtype=torch.uint8, device=self.device)  # scratch of the persistent kernel
             a.workspace = self._step_ws.data_ptr()
             a.workspace_bytes = self._step_ws.numel()
         check(self.lib.glb_logprob_mask_sample(C.byref(a), self._stream()))
