@@ -60,14 +60,13 @@ int pick_geom(int64_t vocab, int dtype, int variant) {
 }
 
 // persistent-kernel geometries (glb_row_tu.hip): id, NVL at 512 threads; capacity = 512 * NVL vectors
-struct Geom2 { int id, nvl; bool f32; };
-const Geom2 kGeoms2[] = {{22, 16, true}, {21, 25, true}, {22, 16, false}, {23, 32, false}};
+struct Geom2 { int id, nvl; };
+const Geom2 kGeoms2[] = {{24, 8}, {22, 16}, {21, 25}, {23, 32}, {25, 40}};
 
 int pick_geom2(int64_t vocab, int dtype, int variant) {
   const int epv = dtype == GLB_F32 ? 4 : 8;
   const int64_t nv_max = (vocab + (epv - 1) + epv - 1) / epv;
   for (const Geom2 &g : kGeoms2) {
-    if (g.f32 != (dtype == GLB_F32)) continue;
     if (variant > 0 && g.id != variant) continue;
     if ((int64_t)512 * g.nvl >= nv_max) return g.id;
   }
@@ -476,9 +475,9 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
                   glb_step_workspace_bytes(a->n_particles));
     if (((uintptr_t)a->workspace) % 16) return fail(GLB_EINVAL, "workspace not 16-byte aligned");
     int g2 = pick_geom2(a->vocab, a->dtype, a->variant);
-    // auto: the persistent kernel only pays off with >= 3 rows per CU and rows that need the big geometry
-    // (measured: 1024 x 50257 fp32 91 vs 96 us, 2048 rows 147 vs 163 us; 512 x 128256 bf16 118 vs 92 us)
-    if (a->variant == 0 && !(g2 == 21 && a->n_particles >= 3 * (int64_t)num_cus())) g2 = 0;
+    // auto: the persistent kernel pays off from about 1.25 rows per CU (measured, tools/kdispatch.py: 512 x 50257
+    // fp32 36 vs 46 us, 1024: 58 vs 81, 2048: 99 vs 152; 512 x 128256 bf16 61 vs 71; at one row per CU they tie)
+    if (a->variant == 0 && a->n_particles * 4 < 5 * (int64_t)num_cus()) g2 = 0;
     if (g2) {
       int64_t grid = a->n_particles < num_cus() ? a->n_particles : num_cus();
       if (const char *g = getenv("GLB_V2_GRID")) {  // tuning knob: persistent workgroups to launch

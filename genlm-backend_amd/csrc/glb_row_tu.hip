@@ -37,7 +37,8 @@ static hipError_t launch_geom(const RowParams &p, int geom, hipStream_t s) {
 }
 
 // persistent pipelined variant (glb_row_kernel_v2.hpp): 512 threads (2 waves / SIMD, 256 VGPRs),
-// persistent kernel (glb_row_persist.hpp), 512 threads; ids -> NVL:  21: 25 (fp32 gpt2-sized rows)   22: 16   23: 32 (16-bit 128k rows)
+// persistent kernel (glb_row_persist.hpp), 512 threads; ids -> NVL (capacity 512*NVL 16-byte vectors per row):
+//   24: 8   22: 16   21: 25 (fp32 gpt2-sized rows)   23: 32 (16-bit 128k rows)   25: 40 (16-bit 152k rows, fp32 up to 81 912)
 #if GLB_MODE != 2
 template <int MASK, int NVL>
 static hipError_t launch2(const RowParams &p0, int grid, hipStream_t s) {
@@ -55,12 +56,11 @@ static hipError_t launch2(const RowParams &p0, int grid, hipStream_t s) {
 template <int MASK>
 static hipError_t launch_geom2(const RowParams &p, int geom, int grid, hipStream_t s) {
   switch (geom) {
-#if GLB_DT == 0
-    case 21: return launch2<MASK, 25>(p, grid, s);
-#else
-    case 23: return launch2<MASK, 32>(p, grid, s);
-#endif
+    case 24: return launch2<MASK, 8>(p, grid, s);
     case 22: return launch2<MASK, 16>(p, grid, s);
+    case 21: return launch2<MASK, 25>(p, grid, s);
+    case 23: return launch2<MASK, 32>(p, grid, s);
+    case 25: return launch2<MASK, 40>(p, grid, s);
     default: return hipErrorInvalidValue;
   }
 }

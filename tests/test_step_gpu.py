@@ -119,7 +119,7 @@ def test_log_softmax_rows(engine, oracle):
 
 
 V2_CASES = [
-    # (n_particles, n_rows, V, dtype, variant)   variant: 21 fp32 <= 51196, 22 small rows, 23 16-bit <= 131064
+    # (n_particles, n_rows, V, dtype, variant)   variant: persistent geometries 24/22/21/23/25 hold 4096/8192/12800/16384/20480 16-byte vectors
     (700, 300, 50257, "f32", 21),
     (1024, 1024, 50257, "f32", 0),
     (130, 40, 65001, "f16", 23),
@@ -130,6 +130,12 @@ V2_CASES = [
     (9, 9, 1000, "f32", 22),
     (1024, 1024, 50257, "f32", 21),
     (2300, 500, 50257, "f32", 21),   # 9 rows per workgroup: one wave per row in the tail
+    (700, 300, 16001, "f32", 24),
+    (700, 300, 32000, "bf16", 24),
+    (400, 150, 151936, "bf16", 25),
+    (400, 150, 70001, "f32", 25),
+    (600, 600, 128256, "bf16", 0),   # auto: persistent geometry 23
+    (400, 400, 100003, "f16", 0),
 ]
 
 
