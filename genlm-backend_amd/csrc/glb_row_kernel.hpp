@@ -318,15 +318,14 @@ __global__ __launch_bounds__(T) void row_kernel(const RowParams p) {
           const int jr = ((int)v0b + k * 64) * EPV - a + c;
           const int jc = jr < 0 ? 0 : (jr >= V ? V - 1 : jr);
           const float E = noise_row[jc];
-          if (yv > kNegInf && pass == 0) {  // the race is always run against the masked maximum's exponent
-            const float df = nfy - N_msk;
-            const float e = (df < -100.0f) ? 0.0f : __builtin_ldexpf(Py, (int)df - 30);
-            const float g = e / E;
-            if (g > best_g) {
-              best_g = g;
-              best_j = jr;
-            }
-          }
+          // the race is always run against the masked maximum's exponent (branch-free: selects, not lane branches)
+          const bool live = (yv > kNegInf) && pass == 0;
+          const float df = live ? nfy - N_msk : 0.0f;
+          const float e = (df < -100.0f) ? 0.0f : __builtin_ldexpf(Py, (int)df - 30);
+          const float g = live ? e / E : -1.0f;
+          const bool better = g > best_g;
+          best_g = better ? g : best_g;
+          best_j = better ? jr : best_j;
         }
       }
       s_msk += ak;

@@ -12,14 +12,15 @@
 // every prefetched tile): barriers are raw `s_barrier` behind an explicit `s_waitcnt lgkmcnt(0)`, and the
 // cross-wave scratch is accessed with inline-asm `ds_*`.
 //
-// The loop only takes the sums on the row's scale (GLB math: one exponential serves both sums).  Rows whose
-// masked sum came out below 2^37 - allowed mass below 2^-7 of the row, rare - are redone from memory on
-// the masked maximum's own scale by the whole workgroup after the loop (fix_row; the row's registers were
-// already being refilled when the sum became known).  Then every row gets its lse / logZ (finish_row) and
-// its token (locate): from per-chunk wave totals the loop left in the workspace, a wave - or a pair of
-// waves, when the workgroup streamed at most four rows - picks the chunk, re-reads that chunk's 4-5 KiB of
-// the row (L2 / Infinity Cache), recomputes the tile sums against the stored exponent and walks
-// tile -> lane -> element in vocabulary order.  Same integers as the one-workgroup-per-particle kernel.
+// The loop only takes the sums on the row's scale (GLB math: one exponential serves both sums).  The draw rides
+// along: the sums pass parks every lane's masked sum per tile (or pair of tiles) in LDS; once the row's total is
+// known every wave derives the same Philox target, the wave that owns it binary-searches its tiles in LDS,
+// re-requests the one vector (or two) per lane it lands in, and finishes - recompute, lane, element, in
+// vocabulary order - after the next row's maximum pass, when those vectors have arrived behind the prefetched
+// tiles.  Same integers as the one-workgroup-per-particle kernel.  Rows whose masked sum came out below 2^37 -
+// allowed mass below 2^-7 of the row, rare - are redone from memory on the masked maximum's own scale by the
+// whole workgroup after the loop, together with their draw (the row's registers were already being refilled when
+// the sum became known).  Last, one lane per row turns the sums into lse / logZ (double-precision log).
 //
 // (An earlier version staged the next row in LDS by LDS-DMA, `global_load_lds_dwordx4`, and copied it to
 //  registers at the row switch: 24.5k cycles per row against 22.3k here, with 90 more VGPRs; see DESIGN.md.)
@@ -143,29 +144,28 @@ __device__ unsigned long long g_realtime[256 * 2];
 template <int DT, int MASK, int MODE, int NVL, int T, bool SCALED>
 __global__ __launch_bounds__(T) void row_kernel_persist(const RowParams p) {
   constexpr int W = T / 64;
-  static_assert(W <= 16 && W % 2 == 0, "cross-wave scratch is reduced inside one DPP row of 16 lanes");
+  static_assert(W <= 16, "cross-wave scratch is reduced inside one DPP row of 16 lanes");
   constexpr int EPV = ElemTraits<DT>::EPV;
   constexpr int ES = ElemTraits<DT>::ES;
   constexpr int MBW = (NVL * EPV + 31) / 32;
   constexpr bool kPhilox = MODE == kModePhilox;
   constexpr bool kBits = MASK == kMaskBits;
   static_assert(MASK != kMaskF32 && MODE != kModeNoise, "persistent kernel: mask none/bits, stats/philox");
-  constexpr int GS = (NVL % 5 == 0) ? 5 : 4;  // tiles per chunk of the draw's search
-  constexpr int NG = NVL / GS;                // chunks per wave
-  static_assert(NVL % GS == 0, "chunks must tile a wave's vectors exactly (the draw indexes them linearly)");
-  // LDS: [pad | mask row A | mask row B | scratch]; a mask row covers NVL*T*EPV bits plus alignment slack
+  // The draw works from per-lane masked sums of groups of GT tiles, parked in LDS by the sums pass: the owning
+  // wave binary-searches the groups, then re-reads and recomputes only the GT tiles of one group.
+  constexpr int GT = NVL > 25 ? 2 : 1;
+  static_assert(NVL % GT == 0 && NVL / GT <= 32, "tile groups must tile a wave's vectors exactly");
+  constexpr int NGR = NVL / GT;
+  // LDS: [pad | mask row A | mask row B | scratch | group sums]; a mask row covers NVL*T*EPV bits plus slack
   constexpr int MROW_V = kBits ? (NVL * T * EPV / 8 + 15) / 16 + 2 : 0;  // uint4 per buffer
   constexpr int MPT = kBits ? (MROW_V + T - 1) / T : 1;                  // mask vectors staged per thread
-  constexpr int SCR_V = 24;                                              // 2x16 floats, 2x16 u64
-  // the tail's inputs of the first RING rows of this workgroup stay in LDS as well (chunk totals, masked
-  // exponent): reading them back from the workspace costs an L2 round trip per dependent step
-  constexpr int RING = 16;
-  constexpr int RING_V = kPhilox ? (RING * (W * NG + 1) * 8 + 15) / 16 : 0;
-  __shared__ uint4 s_lds[1 + 2 * MROW_V + SCR_V + RING_V];
+  constexpr int SCR_V = 24 + 16;                                         // 2x16 floats, 2x16 u64, 32 u64 group totals
+  constexpr int GSUM_V = kPhilox ? NGR * T / 2 : 0;                      // [NGR][T] u64
+  static_assert((1 + 2 * MROW_V + SCR_V + GSUM_V) * 16 <= 160 * 1024, "LDS budget");
+  __shared__ uint4 s_lds[1 + 2 * MROW_V + SCR_V + GSUM_V];
   const uint32_t scr = lds_addr(s_lds + 1 + 2 * MROW_V);
-  const uint32_t scr_max = scr, scr_sum = scr + 128;
-  const uint32_t ring = scr + SCR_V * 16;            // [RING][W*NG] u64 chunk totals
-  const uint32_t ring_n = ring + RING * W * NG * 8;  // [RING] f32 masked exponent (8-byte slots)
+  const uint32_t scr_max = scr, scr_sum = scr + 128, scr_tot = scr + 384;
+  uint64_t *const s_gsum = reinterpret_cast<uint64_t *>(s_lds + 1 + 2 * MROW_V + SCR_V);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int V = p.V;
@@ -173,6 +173,7 @@ __global__ __launch_bounds__(T) void row_kernel_persist(const RowParams p) {
   const int v0 = wave * (64 * NVL) + lane;
   const int wl = lane & 15;            // lane wl of every DPP row stands for wave wl
   const int wr = wl < W ? wl : W - 1;  // rows of 16 lanes but only W waves: the rest duplicate the last
+  const int n_words = (V + 31) >> 5;
 
   auto particle_of = [&](int vb) {  // XCD-aware particle order (same as the one-workgroup-per-particle kernel)
     const int q = n >> 3, r = n & 7, xcd = vb & 7, i = vb >> 3;
@@ -259,10 +260,116 @@ __global__ __launch_bounds__(T) void row_kernel_persist(const RowParams p) {
     }
     rk = make_uint4(w[0], w[1], w[2], w[3]);
   };
+  // allowed terms of one vector (first element j0, mask bits nib) against exponent Nb: per-lane sum and terms
+  auto vec_terms = [&](const uint4 &rk, uint32_t nib, int j0, float Nb, uint64_t(&q)[EPV]) {
+    float xs[EPV];
+    unpack_vec<DT>(rk, xs);
+    uint64_t s = 0;
+#pragma unroll
+    for (int c = 0; c < EPV; ++c) {
+      const float xv = SCALED ? xs[c] * p.scale : xs[c];
+      const bool ok = ((uint32_t)(j0 + c) < (uint32_t)V) && ((nib >> c) & 1u);
+      q[c] = ok ? fix_term(xv, Nb) : 0ull;
+      s += q[c];
+    }
+    return s;
+  };
+  auto philox_target = [&](int pidx, uint64_t S) {  // uniform integer in [0, S), kept in VGPRs
+    const uint64_t gp = (uint64_t)(p.particle_base + pidx);
+    const uint32_t ctr[4] = {(uint32_t)gp, (uint32_t)(gp >> 32), (uint32_t)p.offset, (uint32_t)(p.offset >> 32)};
+    const uint32_t key[2] = {(uint32_t)p.seed, (uint32_t)(p.seed >> 32)};
+    uint32_t rnd[4];
+    philox4x32_10(ctr, key, rnd);
+    uint64_t Tc = __umul64hi(((uint64_t)rnd[1] << 32) | rnd[0], S);
+    uint32_t z = 0;
+    opaque(z);  // VALU compares (hipcc lowers a wave-uniform u64 `<` feeding a select to v_cmp + s_cselect w/o SCC)
+    return Tc + z;
+  };
 
   uint4 raw[NVL];
   uint4 mreg[MPT];
   uint32_t mb[MBW];
+
+  // The draw of row r is spread over the next two rows so that none of it sits in front of a barrier:
+  //   (1) after row r's totals are known every wave derives the Philox target and the owning wave, and the
+  //       waves share out the owning wave's tile groups: group totals (64-lane sums of the LDS entries) -> LDS;
+  //   (2) after the next barrier the owning wave scans the <= 32 group totals, picks the group and re-requests its
+  //       GT vectors per lane (+ mask bits) - they queue behind nothing but row r+1's first tiles;
+  //   (3) in row r+2's maximum pass, which mostly waits for memory, it recomputes those vectors and walks
+  //       tile -> lane -> element in vocabulary order.
+  struct DrawJob {  // wave-uniform
+    bool live;
+    int owner, pidx, a, nv;
+    gptr_t base;
+    const uint32_t *mrow;
+    float Nb;
+    uint64_t target;
+  };
+  DrawJob job{};
+  job.live = false;
+  bool pend = false;  // wave-uniform: stage (2) done, (3) outstanding
+  uint4 pend_rk[GT];
+  uint32_t pend_nib[GT];
+  uint64_t pend_T = 0;
+  float pend_Nb = 0.f;
+  int pend_j0 = 0, pend_pidx = 0;
+  auto pick_group = [&]() {  // stage (2)
+    if (!job.live) return;
+    job.live = false;
+    if (wave != job.owner) return;
+    const uint64_t t = lane < NGR ? lds_read_b64_wait(scr_tot + (uint32_t)lane * 8u) : 0ull;
+    const uint64_t incl = wave_scan_u64(t);
+    uint64_t Tc = job.target;
+    const int gsel = __ffsll((long long)__ballot(incl > Tc)) - 1;
+    Tc -= readlane_u64(incl - t, gsel);
+    pend = true;
+    pend_T = Tc;
+    pend_Nb = job.Nb;
+    pend_pidx = job.pidx;
+    pend_j0 = (v0 + gsel * GT * 64) * EPV - job.a;
+#pragma unroll
+    for (int g = 0; g < GT; ++g) {
+      const int v = v0 + (gsel * GT + g) * 64;
+      pend_rk[g] = gload16(job.base + (int64_t)(v < job.nv ? v : job.nv - 1) * 16);
+      pend_nib[g] = (1u << EPV) - 1u;
+      if constexpr (kBits) pend_nib[g] = mask_nibble<EPV>(job.mrow, n_words, v * EPV - job.a);
+    }
+  };
+  auto finish_draw = [&]() {
+    if (!pend) return;
+    pend = false;
+    uint64_t Tc = pend_T;
+    uint64_t aj[GT], cj[GT], q[GT][EPV];
+#pragma unroll
+    for (int g = 0; g < GT; ++g) {
+      aj[g] = vec_terms(pend_rk[g], pend_nib[g], pend_j0 + g * 64 * EPV, pend_Nb, q[g]);
+      cj[g] = GT > 1 ? wave_sum_u64(aj[g]) : 0ull;
+    }
+    int gsel = 0;
+    if constexpr (GT > 1) {
+      if (!(Tc < cj[0])) {
+        Tc -= cj[0];
+        gsel = 1;
+      }
+    }
+    const uint64_t asel = gsel ? aj[GT - 1] : aj[0];
+    const uint64_t incl = wave_scan_u64(asel);
+    const int lsel = __ffsll((long long)__ballot(incl > Tc)) - 1;
+    if (lane == lsel) {
+      uint64_t Tl = Tc - (incl - asel);
+      const int j0 = pend_j0 + gsel * 64 * EPV;
+      int32_t tok = -1;
+#pragma unroll
+      for (int c = 0; c < EPV; ++c) {
+        const uint64_t qc = gsel ? q[GT - 1][c] : q[0][c];
+        if (tok < 0) {
+          if (Tl < qc) tok = j0 + c;
+          else Tl -= qc;
+        }
+      }
+      p.out_token[pend_pidx] = tok;
+    }
+  };
 
   int vb = blockIdx.x;
   if (vb >= n) return;
@@ -308,6 +415,7 @@ __global__ __launch_bounds__(T) void row_kernel_persist(const RowParams p) {
         for (int c = 0; c < EPV; ++c) m_all = fmaxf(m_all, SCALED ? xk[c] * p.scale : xk[c]);
       }
     }
+    if constexpr (kPhilox) finish_draw();  // stage (3) of the row before the previous one
     m_all = wave_max(m_all);
     if (lane == 0) lds_write_b32(scr_max + wave * 4, __float_as_uint(m_all));
     lds_barrier();
@@ -315,15 +423,11 @@ __global__ __launch_bounds__(T) void row_kernel_persist(const RowParams p) {
     const float N_all = exp_n(m_all);
     const float Nb_all = N_all + (float)kFixShift;
     GLB_STAMP();
+    if constexpr (kPhilox) pick_group();  // stage (2) of the previous row (its group totals are behind the barrier)
 
     // ---- phase 2: both fixed-point sums on the row's scale; tile k of the next row is requested as soon
     //      as tile k of this one has been consumed --------------------------------------------------------
-    uint64_t acc = 0, s_msk = 0;
-    uint64_t ag[kPhilox ? NG : 1];  // per-lane masked sums of the chunks (GS tiles each)
-    if constexpr (kPhilox) {
-#pragma unroll
-      for (int g = 0; g < NG; ++g) ag[g] = 0;
-    }
+    uint64_t acc = 0, s_msk = 0, grp = 0, prev = 0;
 #pragma unroll
     for (int i = 0; i < MBW; ++i) opaque(mb[i]);
 #pragma unroll
@@ -354,15 +458,16 @@ __global__ __launch_bounds__(T) void row_kernel_persist(const RowParams p) {
       }
       if constexpr (kBits) {
         s_msk += ak;
-        if constexpr (kPhilox) ag[k / GS] += ak;
+        grp += ak;
       }
       if constexpr (kPhilox) {
-        if (k % GS == GS - 1 || k == NVL - 1) {
-          if constexpr (!kBits) {  // unmasked: a chunk's sum is the difference of the running sum at its ends
-            ag[k / GS] = acc - s_msk;
-            s_msk = acc;
+        if (k % GT == GT - 1) {  // this lane's masked sum of the tile group -> LDS, for the draw
+          if constexpr (!kBits) {  // unmasked: difference of the running sum at the group's ends
+            grp = acc - prev;
+            prev = acc;
           }
-          opaque(ag[k / GS]);
+          s_gsum[(k / GT) * T + tid] = grp;
+          grp = 0;
         }
       }
       // pin the running sums here: otherwise the adds are reassociated and sunk below the loop, which keeps
@@ -382,18 +487,6 @@ __global__ __launch_bounds__(T) void row_kernel_persist(const RowParams p) {
         lds_write_b64(scr_sum + wave * 8, t_all);
         lds_write_b64(scr_sum + 128 + wave * 8, t_msk);
       }
-      if constexpr (kPhilox) {
-        // wave totals of every chunk -> workspace; the tail finishes the draw from them
-        uint64_t *crow = p.chunk_sums + (int64_t)cur.pidx * (W * NG) + wave * NG;
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-          const uint64_t tg = wave_scan_u64(ag[g]);
-          if (lane == 63) {
-            crow[g] = tg;
-            if (ri < RING) lds_write_b64(ring + (uint32_t)((ri * W + wave) * NG + g) * 8u, tg);
-          }
-        }
-      }
     }
     if (has_next) stage_mask(mreg, buf ^ 1);  // the other buffer: nobody reads it until after this barrier
     lds_barrier();
@@ -408,14 +501,35 @@ __global__ __launch_bounds__(T) void row_kernel_persist(const RowParams p) {
         p.row_sums[2 * cur.pidx + 1] = S_msk;  // below 2^37: redone on its own scale in the tail
         p.row_exps[2 * cur.pidx] = N_all;
         p.row_exps[2 * cur.pidx + 1] = N_all;
-        if constexpr (kPhilox) {
-          if (ri < RING) lds_write_b32(ring_n + (uint32_t)ri * 8u, __float_as_uint(N_all));
-        }
       }
+      bool low = false;
       if constexpr (kBits) {
         uint32_t top = (uint32_t)(S_msk >> 37);  // sums stay below 2^62
         opaque(top);  // VALU compare (uniform u64 `<` miscompile, see the one-workgroup-per-particle kernel)
-        if (top == 0u && ri < 64) low_rows |= 1ull << ri;
+        low = top == 0u;
+        if (low && ri < 64) low_rows |= 1ull << ri;
+      }
+      if constexpr (kPhilox) {
+        // ---- the draw: every wave derives the same target; the wave that owns it searches its tile groups in
+        //      LDS, re-requests the GT vectors of the group it lands in and carries on (finish_draw) ----------
+        if (p.out_token && !low) {  // low-mass rows (incl. nothing allowed) are drawn in the tail
+          uint64_t Tc = philox_target(cur.pidx, S_msk);
+          const int owner = __ffsll((long long)(__ballot(in_msk > Tc) & 0xffffull)) - 1;  // lanes 0..15 <-> waves
+          Tc -= readlane_u64(in_msk - cw_msk, owner);
+          for (int g = wave; g < NGR; g += W) {
+            const uint64_t tg = wave_sum_u64(s_gsum[g * T + owner * 64 + lane]);
+            if (lane == 0) lds_write_b64(scr_tot + (uint32_t)g * 8u, tg);
+          }
+          job.live = true;
+          job.owner = owner;
+          job.pidx = cur.pidx;
+          job.a = cur.a;
+          job.nv = cur.nv;
+          job.base = cur.base;
+          job.mrow = kBits ? reinterpret_cast<const uint32_t *>((const char *)cur.mrow16) + cur.am : nullptr;
+          job.Nb = Nb_all;
+          job.target = Tc;
+        }
       }
     }
     GLB_STAMP();
@@ -429,6 +543,12 @@ __global__ __launch_bounds__(T) void row_kernel_persist(const RowParams p) {
   }
 
   // =================================== tail ===============================================================
+  if constexpr (kPhilox) {
+    finish_draw();  // stage (3) of the last row but one
+    lds_barrier();  // the last row's group totals
+    pick_group();   // its stage (2) ...
+    finish_draw();  // ... and (3)
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's workspace stores have reached L2
   lds_barrier();
   GLB_STAMP();
@@ -453,21 +573,6 @@ __global__ __launch_bounds__(T) void row_kernel_persist(const RowParams p) {
     }
     return r;
   };
-  const int n_words = (V + 31) >> 5;
-  // allowed terms of one vector against exponent Nb: per-lane sum (and the terms themselves on request)
-  auto vec_terms = [&](const TailRow &r, const uint4 &rk, uint32_t nib, int j0, float Nb, uint64_t(&q)[EPV]) {
-    float xs[EPV];
-    unpack_vec<DT>(rk, xs);
-    uint64_t s = 0;
-#pragma unroll
-    for (int c = 0; c < EPV; ++c) {
-      const float xv = SCALED ? xs[c] * p.scale : xs[c];
-      const bool ok = ((uint32_t)(j0 + c) < (uint32_t)V) && ((nib >> c) & 1u);
-      q[c] = ok ? fix_term(xv, Nb) : 0ull;
-      s += q[c];
-    }
-    return s;
-  };
 
   const int n_mine = (n - 1 - (int)blockIdx.x) / G + 1;  // rows blockIdx.x, +G, +2G, ...
   bool any_low = false;
@@ -478,7 +583,7 @@ __global__ __launch_bounds__(T) void row_kernel_persist(const RowParams p) {
   }
   if (kBits && any_low) {
     // ---- rows whose allowed tokens hold < 2^-7 of the mass: masked sum again, on the masked maximum's own
-    //      scale, from memory, by the whole workgroup (same chunk layout as the loop) --------------------------
+    //      scale, from memory, by the whole workgroup; then their draw, by the owning wave walking its tiles ----
 #pragma unroll 1
     for (int i = 0, vr = blockIdx.x; vr < n; ++i, vr += G) {
       if (i < 64) {
@@ -514,189 +619,86 @@ __global__ __launch_bounds__(T) void row_kernel_persist(const RowParams p) {
       lds_barrier();
       mk = row16_max_bcast(__uint_as_float(lds_read_b32_wait(scr_max + wr * 4)));
       lds_barrier();  // scratch is reused by the next flagged row
-      if (!(mk > kNegInf)) continue;  // nothing allowed (workgroup-uniform): the sums on the row's scale are 0
+      if (!(mk > kNegInf)) {  // nothing allowed (workgroup-uniform): the sums on the row's scale are 0 already
+        if (kPhilox && p.out_token && tid == 0) p.out_token[pidx] = -1;
+        continue;
+      }
       const float N_k = exp_n(mk);
       const float Nb = N_k + (float)kFixShift;
-      uint64_t s_w = 0;
+      uint64_t a_w = 0;
 #pragma unroll 1
-      for (int g = 0; g < NG; ++g) {
-        uint64_t a_g = 0;
-#pragma unroll 1
-        for (int t = 0; t < GS; ++t) {
-          const int v = v0 + (g * GS + t) * 64;
-          if (v < r.nv) {
-            const uint4 rk = *reinterpret_cast<const uint4 *>(r.base + (int64_t)v * 16);
-            const int j0 = v * EPV - r.a;
-            uint64_t q[EPV];
-            a_g += vec_terms(r, rk, mask_nibble<EPV>(r.mrow, n_words, j0), j0, Nb, q);
-          }
+      for (int k = 0; k < NVL; ++k) {
+        const int v = v0 + k * 64;
+        if (v < r.nv) {
+          const uint4 rk = *reinterpret_cast<const uint4 *>(r.base + (int64_t)v * 16);
+          const int j0 = v * EPV - r.a;
+          uint64_t q[EPV];
+          a_w += vec_terms(rk, mask_nibble<EPV>(r.mrow, n_words, j0), j0, Nb, q);
         }
-        const uint64_t tg = wave_sum_u64(a_g);
-        if (lane == 0) {
-          p.chunk_sums[(int64_t)pidx * (W * NG) + wave * NG + g] = tg;
-          if constexpr (kPhilox) {
-            if (i < RING) lds_write_b64(ring + (uint32_t)((i * W + wave) * NG + g) * 8u, tg);
-          }
-        }
-        s_w += tg;
       }
+      const uint64_t s_w = wave_sum_u64(a_w);
       if (lane == 0) lds_write_b64(scr_sum + wave * 8, s_w);
       lds_barrier();
       const uint64_t cw = wl < W ? lds_read_b64_wait(scr_sum + wr * 8) : 0ull;
-      const uint64_t S = readlane_u64(row16_scan_u64(cw), 15);
+      const uint64_t in_w = row16_scan_u64(cw);
+      const uint64_t S = readlane_u64(in_w, 15);
       if (tid == 0) {
         p.row_sums[2 * pidx + 1] = S;
         p.row_exps[2 * pidx + 1] = N_k;
-        if constexpr (kPhilox) {
-          if (i < RING) lds_write_b32(ring_n + (uint32_t)i * 8u, __float_as_uint(N_k));
+      }
+      if (kPhilox && p.out_token) {
+        if (S == 0) {
+          if (tid == 0) p.out_token[pidx] = -1;
+        } else {
+          uint64_t Tc = philox_target(pidx, S);
+          const int owner = __ffsll((long long)(__ballot(in_w > Tc) & 0xffffull)) - 1;
+          Tc -= readlane_u64(in_w - cw, owner);
+          if (wave == owner) {  // tile by tile until the running sum passes the target
+            bool done = false;
+#pragma unroll 1
+            for (int k = 0; k < NVL && !done; ++k) {
+              const int v = v0 + k * 64;
+              const int j0 = v * EPV - r.a;
+              uint64_t q[EPV], aj = 0;
+#pragma unroll
+              for (int c = 0; c < EPV; ++c) q[c] = 0;
+              if (v < r.nv) {
+                const uint4 rk = *reinterpret_cast<const uint4 *>(r.base + (int64_t)v * 16);
+                aj = vec_terms(rk, mask_nibble<EPV>(r.mrow, n_words, j0), j0, Nb, q);
+              }
+              const uint64_t incl = wave_scan_u64(aj);
+              const uint64_t tile = readlane_u64(incl, 63);
+              if (Tc < tile) {
+                const int lsel = __ffsll((long long)__ballot(incl > Tc)) - 1;
+                if (lane == lsel) {
+                  uint64_t Tl = Tc - (incl - aj);
+                  int32_t tok = -1;
+#pragma unroll
+                  for (int c = 0; c < EPV; ++c) {
+                    if (tok < 0) {
+                      if (Tl < q[c]) tok = j0 + c;
+                      else Tl -= q[c];
+                    }
+                  }
+                  p.out_token[pidx] = tok;
+                }
+                done = true;
+              } else {
+                Tc -= tile;
+              }
+            }
+          }
         }
       }
-      lds_barrier();
+      lds_barrier();  // scratch is reused by the next flagged row
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
   }
   GLB_STAMP();
 
-  // ---- lse / logZ and the token of every row this workgroup streamed -----------------------------------------
-  if (!(kPhilox && p.out_token)) {
-    for (int i = tid; i < n_mine; i += T) finish_row(p, particle_of(blockIdx.x + i * G));
-  } else {
-    // With at most W/2 rows a PAIR of waves shares a row's draw: both pick the chunk, the even wave takes its
-    // first tiles, the odd wave the rest (and the double-precision logs); one LDS word tells the odd wave where
-    // its tiles start in the chunk's running sum.  Otherwise one wave per row.
-    const bool paired = n_mine <= W / 2;
-    const int slot = paired ? (wave >> 1) : wave, half = paired ? (wave & 1) : 0;
-    const int step = paired ? W / 2 : W;
-    const int tiles = p.chunk_vecs >> 6;  // <= 5
-    const int t_split = paired ? (tiles + 1) / 2 : tiles;
-    constexpr int kMaxTiles = 5;
-    for (int i0 = 0; i0 < n_mine; i0 += step) {  // workgroup-uniform trip count (barrier inside)
-      const int i = i0 + slot;
-      const bool live = i < n_mine;
-      const int pidx = live ? particle_of(blockIdx.x + i * G) : 0;
-      uint64_t Tc = 0, run = 0, asel = 0, qsel[EPV];
-      uint64_t cj[kMaxTiles], aj[kMaxTiles];
-      uint4 rks[kMaxTiles];
-      uint32_t nibs[kMaxTiles];
-      int j0sel = 0;
-      bool found = false, empty = true;
-      int t_lo = 0, t_hi = 0;
-      float Nb = 0.f;
-      TailRow r{};
-      int csel = 0;
-      if (live) {
-        r = tail_row(pidx);
-        uint64_t cs = 0;
-        if (lane < W * NG)
-          cs = i < RING ? lds_read_b64_wait(ring + (uint32_t)(i * W * NG + lane) * 8u)
-                        : ld_agent(p.chunk_sums + (int64_t)pidx * (W * NG) + lane);
-        const uint64_t incl_c = wave_scan_u64(cs);
-        const uint64_t S = readlane_u64(incl_c, 63);
-        empty = (S == 0);
-        if (!empty) {
-          const uint64_t gp = (uint64_t)(p.particle_base + pidx);
-          const uint32_t ctr[4] = {(uint32_t)gp, (uint32_t)(gp >> 32), (uint32_t)p.offset, (uint32_t)(p.offset >> 32)};
-          const uint32_t key[2] = {(uint32_t)p.seed, (uint32_t)(p.seed >> 32)};
-          uint32_t rnd[4];
-          philox4x32_10(ctr, key, rnd);
-          Tc = __umul64hi(((uint64_t)rnd[1] << 32) | rnd[0], S);  // uniform integer in [0, S)
-          {
-            uint32_t z = 0;
-            opaque(z);  // VALU compare (uniform u64 `<` miscompile)
-            Tc += z;
-          }
-          csel = __ffsll((long long)__ballot(incl_c > Tc)) - 1;
-          Tc -= readlane_u64(incl_c - cs, csel);
-          Nb = (i < RING ? __uint_as_float(lds_read_b32_wait(ring_n + (uint32_t)i * 8u))
-                         : ld_agent(p.row_exps + 2 * pidx + 1)) + (float)kFixShift;
-          t_lo = half ? t_split : 0;
-          t_hi = half ? tiles : t_split;
-          // all of this wave's tile loads go out before the first is consumed
-#pragma unroll
-          for (int j = 0; j < kMaxTiles; ++j) {
-            const int v = csel * p.chunk_vecs + j * 64 + lane;
-            const int vc = v < r.nv ? v : r.nv - 1;
-            const bool mine = j >= t_lo && j < t_hi;
-            rks[j] = mine ? *reinterpret_cast<const uint4 *>(r.base + (int64_t)vc * 16) : make_uint4(0, 0, 0, 0);
-            nibs[j] = (1u << EPV) - 1u;
-            if constexpr (kBits) nibs[j] = mine ? mask_nibble<EPV>(r.mrow, n_words, v * EPV - r.a) : 0u;
-          }
-#pragma unroll
-          for (int j = 0; j < kMaxTiles; ++j) {
-            aj[j] = 0;
-            cj[j] = 0;
-            if (j >= t_lo && j < t_hi) {
-              const int v = csel * p.chunk_vecs + j * 64 + lane;
-              uint64_t q[EPV];
-              aj[j] = vec_terms(r, rks[j], nibs[j], v * EPV - r.a, Nb, q);
-              cj[j] = wave_sum_u64(aj[j]);
-            }
-          }
-        }
-      }
-      GLB_STAMP();
-      if (paired) {  // even wave -> odd wave: total of the even wave's tiles
-        if (live && !empty && half == 0 && lane == 0) {
-          uint64_t r0 = 0;
-#pragma unroll
-          for (int j = 0; j < kMaxTiles; ++j) r0 += cj[j];
-          lds_write_b64(scr_sum + slot * 8, r0);
-        }
-        lds_barrier();
-        if (live && !empty && half == 1) run = lds_read_b64_wait(scr_sum + slot * 8);
-        lds_barrier();  // the slot is rewritten in the next round
-      }
-      GLB_STAMP();
-      if (live) {
-        if (half == (paired ? 1 : 0) && lane == 0) finish_row(p, pidx);
-        if (empty) {
-          if (half == 0 && lane == 0) p.out_token[pidx] = -1;
-        } else {
-          int jsel = 0;
-#pragma unroll
-          for (int j = 0; j < kMaxTiles; ++j) {
-            if (j >= t_lo && j < t_hi) {
-              if (!found && Tc >= run && Tc - run < cj[j]) {
-                found = true;
-                Tc -= run;
-                asel = aj[j];
-                jsel = j;
-              }
-              run += cj[j];
-            }
-          }
-          if (found) {  // wave-uniform
-            const uint64_t incl = wave_scan_u64(asel);
-            const int lsel = __ffsll((long long)__ballot(incl > Tc)) - 1;
-            if (lane == lsel) {
-              uint64_t Tl = Tc - (incl - asel);
-              uint4 rsel = rks[0];
-              uint32_t nsel = nibs[0];
-#pragma unroll
-              for (int j = 1; j < kMaxTiles; ++j)
-                if (j == jsel) {
-                  rsel = rks[j];
-                  nsel = nibs[j];
-                }
-              const int v = csel * p.chunk_vecs + jsel * 64 + lane;
-              j0sel = v * EPV - r.a;
-              vec_terms(r, rsel, nsel, j0sel, Nb, qsel);
-              int32_t tok = -1;
-#pragma unroll
-              for (int c = 0; c < EPV; ++c) {
-                if (tok < 0) {
-                  if (Tl < qsel[c]) tok = j0sel + c;
-                  else Tl -= qsel[c];
-                }
-              }
-              p.out_token[pidx] = tok;
-            }
-          }
-        }
-      }
-    }
-  }
+  // ---- lse / logZ of every row this workgroup streamed (double-precision logs: one lane per row) ------------
+  for (int i = tid; i < n_mine; i += T) finish_row(p, particle_of(blockIdx.x + i * G));
   GLB_STAMP();
 #ifdef GLB_STAMPS
   if (tid == 0 && blockIdx.x < 256) g_realtime[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime();
