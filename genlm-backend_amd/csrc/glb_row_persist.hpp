@@ -154,17 +154,18 @@ __global__ __launch_bounds__(T) void row_kernel_persist(const RowParams p) {
   // The draw works from per-lane masked sums of groups of GT tiles, parked in LDS by the sums pass: the owning
   // wave binary-searches the groups, then re-reads and recomputes only the GT tiles of one group.
   constexpr int GT = NVL > 25 ? 2 : 1;
-  static_assert(NVL % GT == 0 && NVL / GT <= 32, "tile groups must tile a wave's vectors exactly");
+  static_assert(NVL % GT == 0 && NVL / GT <= 4 * W, "tile groups must tile a wave's vectors exactly");
   constexpr int NGR = NVL / GT;
   // LDS: [pad | mask row A | mask row B | scratch | group sums]; a mask row covers NVL*T*EPV bits plus slack
   constexpr int MROW_V = kBits ? (NVL * T * EPV / 8 + 15) / 16 + 2 : 0;  // uint4 per buffer
   constexpr int MPT = kBits ? (MROW_V + T - 1) / T : 1;                  // mask vectors staged per thread
-  constexpr int SCR_V = 24 + 16;                                         // 2x16 floats, 2x16 u64, 32 u64 group totals
+  constexpr int MAXR = 64;                                               // rows whose input indices are tabled in LDS
+  constexpr int SCR_V = 24 + 16 + MAXR / 2;                              // 2x16 floats, 2x16 u64, 32 u64 group totals, index table
   constexpr int GSUM_V = kPhilox ? NGR * T / 2 : 0;                      // [NGR][T] u64
   static_assert((1 + 2 * MROW_V + SCR_V + GSUM_V) * 16 <= 160 * 1024, "LDS budget");
   __shared__ uint4 s_lds[1 + 2 * MROW_V + SCR_V + GSUM_V];
   const uint32_t scr = lds_addr(s_lds + 1 + 2 * MROW_V);
-  const uint32_t scr_max = scr, scr_sum = scr + 128, scr_tot = scr + 384;
+  const uint32_t scr_max = scr, scr_sum = scr + 128, scr_tot = scr + 384, scr_idx = scr + 640;
   uint64_t *const s_gsum = reinterpret_cast<uint64_t *>(s_lds + 1 + 2 * MROW_V + SCR_V);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -186,10 +187,20 @@ __global__ __launch_bounds__(T) void row_kernel_persist(const RowParams p) {
     int am, mvec;   // leading pad words, 16-byte vectors covering the mask row
     int pidx;
   };
-  auto row_ref = [&](int vb) {
+  // (row_of, mask_id) of the workgroup's first MAXR rows are fetched once, up front, into LDS: a scalar load at
+  // the top of every row stalls the wave for its full latency
+  auto row_ref = [&](int vb, int i) {
     RowRef r;
     r.pidx = particle_of(vb);
-    const int row = p.row_of ? sload_i32(p.row_of, r.pidx) : r.pidx;
+    int row, mi;
+    if (i > 0 && i < MAXR) {
+      const uint64_t e = lds_read_b64_wait(scr_idx + (uint32_t)i * 8u);
+      row = __builtin_amdgcn_readfirstlane((int)(uint32_t)e);
+      mi = __builtin_amdgcn_readfirstlane((int)(uint32_t)(e >> 32));
+    } else {
+      row = p.row_of ? sload_i32(p.row_of, r.pidx) : r.pidx;
+      mi = !kBits ? 0 : (p.mask_id ? sload_i32(p.mask_id, r.pidx) : (p.n_masks == 1 ? 0 : r.pidx));
+    }
     const char *rowp = (const char *)p.logits + (int64_t)row * p.ld * ES;
     r.a = (int)(((uintptr_t)rowp) & 15) / ES;
     r.base = (gptr_t)(rowp - r.a * ES);
@@ -198,7 +209,6 @@ __global__ __launch_bounds__(T) void row_kernel_persist(const RowParams p) {
     r.am = 0;
     r.mvec = 1;
     if constexpr (kBits) {
-      const int mi = p.mask_id ? sload_i32(p.mask_id, r.pidx) : (p.n_masks == 1 ? 0 : r.pidx);
       const char *mp = (const char *)p.mask + (int64_t)mi * p.mask_ld * 4;
       r.am = (int)(((uintptr_t)mp) & 15) / 4;
       r.mrow16 = (gptr_t)(mp - r.am * 4);
@@ -274,13 +284,16 @@ __global__ __launch_bounds__(T) void row_kernel_persist(const RowParams p) {
     }
     return s;
   };
-  auto philox_target = [&](int pidx, uint64_t S) {  // uniform integer in [0, S), kept in VGPRs
+  auto philox_bits = [&](int pidx) {  // the particle's 64 random bits (independent of the row's sums)
     const uint64_t gp = (uint64_t)(p.particle_base + pidx);
     const uint32_t ctr[4] = {(uint32_t)gp, (uint32_t)(gp >> 32), (uint32_t)p.offset, (uint32_t)(p.offset >> 32)};
     const uint32_t key[2] = {(uint32_t)p.seed, (uint32_t)(p.seed >> 32)};
     uint32_t rnd[4];
     philox4x32_10(ctr, key, rnd);
-    uint64_t Tc = __umul64hi(((uint64_t)rnd[1] << 32) | rnd[0], S);
+    return ((uint64_t)rnd[1] << 32) | rnd[0];
+  };
+  auto target_of = [&](uint64_t R, uint64_t S) {  // uniform integer in [0, S), kept in VGPRs
+    uint64_t Tc = __umul64hi(R, S);
     uint32_t z = 0;
     opaque(z);  // VALU compares (hipcc lowers a wave-uniform u64 `<` feeding a select to v_cmp + s_cselect w/o SCC)
     return Tc + z;
@@ -378,15 +391,24 @@ __global__ __launch_bounds__(T) void row_kernel_persist(const RowParams p) {
   if (tid == 0 && blockIdx.x < 256) g_realtime[blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime();
 #endif
   GLB_STAMP();
-  RowRef cur = row_ref(vb);
+  RowRef cur = row_ref(vb, 0);
   int buf = 0;
   int ri = 0;             // index of the current row among this workgroup's rows
   uint64_t low_rows = 0;  // bit i: row i (< 64) needs its masked sum redone on its own scale (workgroup-uniform)
+  uint64_t tab_e = 0;  // this thread's entry of the index table (requested ahead of the tiles, written behind them)
+  const bool tab_mine = tid > 0 && tid < MAXR && tid < (n - 1 - (int)blockIdx.x) / G + 1;
+  if (tab_mine) {
+    const int pi = particle_of(blockIdx.x + tid * G);
+    const uint32_t row = (uint32_t)(p.row_of ? p.row_of[pi] : pi);
+    const uint32_t mi = !kBits ? 0u : (uint32_t)(p.mask_id ? p.mask_id[pi] : (p.n_masks == 1 ? 0 : pi));
+    tab_e = ((uint64_t)mi << 32) | row;
+  }
   load_mask(cur, mreg);
 #pragma unroll
   for (int k = 0; k < NVL; ++k) raw[k] = load_tile(cur, k);
+  if (tab_mine) lds_write_b64(scr_idx + (uint32_t)tid * 8u, tab_e);
   stage_mask(mreg, 0);
-  if constexpr (kBits) lds_barrier();
+  lds_barrier();
   build_bits(cur, 0, mb);
   GLB_STAMP();
 
@@ -395,10 +417,13 @@ __global__ __launch_bounds__(T) void row_kernel_persist(const RowParams p) {
     const bool has_next = vb_next < n;
     RowRef nxr = cur;
     if (has_next) {
-      nxr = row_ref(vb_next);
+      nxr = row_ref(vb_next, ri + 1);
       load_mask(nxr, mreg);  // lands long before the row tiles issued behind it
     }
     opaque(lane_off);
+    // stage (3) of the row before the previous one: its vectors were requested ahead of all of this row's tiles,
+    // so they are here, and the arithmetic runs while the tail of the prefetch is still arriving
+    if constexpr (kPhilox) finish_draw();
 
     // ---- phase 1: row maximum (tiles are consumed in the order their loads were issued) ---------------
     float m_all = kNegInf;
@@ -415,7 +440,6 @@ __global__ __launch_bounds__(T) void row_kernel_persist(const RowParams p) {
         for (int c = 0; c < EPV; ++c) m_all = fmaxf(m_all, SCALED ? xk[c] * p.scale : xk[c]);
       }
     }
-    if constexpr (kPhilox) finish_draw();  // stage (3) of the row before the previous one
     m_all = wave_max(m_all);
     if (lane == 0) lds_write_b32(scr_max + wave * 4, __float_as_uint(m_all));
     lds_barrier();
@@ -423,7 +447,11 @@ __global__ __launch_bounds__(T) void row_kernel_persist(const RowParams p) {
     const float N_all = exp_n(m_all);
     const float Nb_all = N_all + (float)kFixShift;
     GLB_STAMP();
-    if constexpr (kPhilox) pick_group();  // stage (2) of the previous row (its group totals are behind the barrier)
+    uint64_t R_cur = 0;
+    if constexpr (kPhilox) {
+      pick_group();  // stage (2) of the previous row (its group totals are behind the barrier)
+      if (p.out_token) R_cur = philox_bits(cur.pidx);  // here, where the SIMD's other wave fills the issue slots
+    }
 
     // ---- phase 2: both fixed-point sums on the row's scale; tile k of the next row is requested as soon
     //      as tile k of this one has been consumed --------------------------------------------------------
@@ -513,12 +541,18 @@ __global__ __launch_bounds__(T) void row_kernel_persist(const RowParams p) {
         // ---- the draw: every wave derives the same target; the wave that owns it searches its tile groups in
         //      LDS, re-requests the GT vectors of the group it lands in and carries on (finish_draw) ----------
         if (p.out_token && !low) {  // low-mass rows (incl. nothing allowed) are drawn in the tail
-          uint64_t Tc = philox_target(cur.pidx, S_msk);
+          uint64_t Tc = target_of(R_cur, S_msk);
           const int owner = __ffsll((long long)(__ballot(in_msk > Tc) & 0xffffull)) - 1;  // lanes 0..15 <-> waves
           Tc -= readlane_u64(in_msk - cw_msk, owner);
-          for (int g = wave; g < NGR; g += W) {
-            const uint64_t tg = wave_sum_u64(s_gsum[g * T + owner * 64 + lane]);
-            if (lane == 0) lds_write_b64(scr_tot + (uint32_t)g * 8u, tg);
+          {  // group totals of the owning wave's entries: 16 lanes x 4 entries per group, 4 groups per wave
+            const int g = wave * 4 + (lane >> 4);
+            uint64_t v = 0;
+            if (g < NGR) {
+              const uint64_t *src = s_gsum + g * T + owner * 64 + (lane & 15) * 4;
+              v = (src[0] + src[1]) + (src[2] + src[3]);
+            }
+            const uint64_t tot = row16_scan_u64(v);
+            if (g < NGR && (lane & 15) == 15) lds_write_b64(scr_tot + (uint32_t)g * 8u, tot);
           }
           job.live = true;
           job.owner = owner;
@@ -650,7 +684,7 @@ __global__ __launch_bounds__(T) void row_kernel_persist(const RowParams p) {
         if (S == 0) {
           if (tid == 0) p.out_token[pidx] = -1;
         } else {
-          uint64_t Tc = philox_target(pidx, S);
+          uint64_t Tc = target_of(philox_bits(pidx), S);
           const int owner = __ffsll((long long)(__ballot(in_w > Tc) & 0xffffull)) - 1;
           Tc -= readlane_u64(in_w - cw, owner);
           if (wave == owner) {  // tile by tile until the running sum passes the target
