@@ -426,8 +426,8 @@ int glb_device_count(void) {
 
 size_t glb_step_workspace_bytes(int64_t n_particles) {
   if (n_particles <= 0) return 0;
-  // 64 chunk sums + 2 row sums (u64) and 2 exponents (f32) per particle, with headroom
-  return (size_t)n_particles * (72 * sizeof(uint64_t) + 2 * sizeof(float)) + 64;
+  // 2 row sums (u64) and 2 exponents (f32) per particle, with headroom
+  return (size_t)n_particles * (4 * sizeof(uint64_t)) + 256;
 }
 
 int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
@@ -504,8 +504,7 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
   glb::RowParams p{};
   fill_row_params(p, a);
   if (a->workspace) {
-    p.chunk_sums = (uint64_t *)a->workspace;
-    p.row_sums = p.chunk_sums + (size_t)a->n_particles * 64;
+    p.row_sums = (uint64_t *)a->workspace;
     p.row_exps = (float *)(p.row_sums + (size_t)a->n_particles * 2);
   }
   const hipError_t e = dispatch_row(a->dtype, a->rng_mode, p, a->mask_kind, geom, (hipStream_t)stream);

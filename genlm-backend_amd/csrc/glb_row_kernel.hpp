@@ -50,11 +50,9 @@ struct RowParams {
   int32_t *out_token;
   float *out_logprobs;  // stats mode only: [n_particles, out_ld]
   int64_t out_ld;
-  // v2 + locate_kernel: per-particle chunk totals [n_particles, n_chunks] and masked exponent N_msk
-  uint64_t *chunk_sums;
+  // persistent kernel: per-particle sums and exponents parked between its streaming loop and its tail
   uint64_t *row_sums;  // [n_particles][2]  S_all, S_mask
   float *row_exps;     // [n_particles][2]  N_all, N_mask
-  int32_t n_chunks, chunk_vecs;
 };
 
 template <int DT>

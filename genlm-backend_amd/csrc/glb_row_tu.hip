@@ -42,10 +42,7 @@ static hipError_t launch_geom(const RowParams &p, int geom, hipStream_t s) {
 #if GLB_MODE != 2
 template <int MASK, int NVL>
 static hipError_t launch2(const RowParams &p0, int grid, hipStream_t s) {
-  RowParams p = p0;
-  constexpr int GS = (NVL % 5 == 0) ? 5 : 4;
-  p.n_chunks = 8 * (NVL / GS);
-  p.chunk_vecs = GS * 64;
+  const RowParams &p = p0;
   if (p.use_scale)
     hipLaunchKernelGGL((row_kernel_persist<GLB_DT, MASK, GLB_MODE, NVL, 512, true>), dim3(grid), dim3(512), 0, s, p);
   else

@@ -198,3 +198,53 @@ def test_streaming_fallback_bit_exact(engine, oracle, B, V, dtype, mask_kind):
         want, _ = O.log_softmax_rows(x_np)
         got = engine.log_softmax_rows(x_t.to(dev))
         assert np.array_equal(_np(got).view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("variant,N,U,V,dtype", [(21, 600, 200, 50257, "f32"), (-1, 40, 20, 50257, "f32"),
+                                                  (23, 400, 100, 128256, "bf16"), (99, 6, 6, 9000, "f16")])
+def test_logit_scale_and_stats_mode(engine, oracle, variant, N, U, V, dtype):
+    """Temperature scaling (base.py:136-141: logits / T before the softmax) and the statistics-only mode, on
+    the persistent, the one-workgroup-per-particle and the streaming kernel."""
+    O = oracle
+    x_np, x_t = _mk(O, U, V, dtype, seed=V + 7)
+    dev = engine.device
+    row_of = (np.arange(N) * 5 % U).astype(np.int32)
+    masks = synth.binary_masks(V + 3, 2, V)
+    bits, _ = O.mask_f32_to_bits(masks)
+    mid = (np.arange(N) % 2).astype(np.int32)
+    kw_o = dict(mask_kind=O.MASK_BITS, mask=bits, mask_id=mid)
+    kw_g = dict(mask_kind=1, mask=_bits_dev(bits, dev), mask_id=torch.from_numpy(mid).to(dev))
+    rd = torch.from_numpy(row_of).to(dev)
+    for scale in (1.0, 0.7, 1.9):
+        logZ_o, lse_o, tok_o = O.step(x_np, row_of=row_of, rng_mode=O.RNG_PHILOX, seed=9, offset=1, logit_scale=scale, **kw_o)
+        logZ, lse, tok = engine.step(x_t.to(dev), row_of=rd, rng_mode=1, seed=9, offset=1, logit_scale=scale,
+                                     variant=variant, **kw_g)
+        assert np.array_equal(_np(tok), tok_o)
+        assert np.array_equal(_np(logZ).view(np.uint32), logZ_o.view(np.uint32))
+        assert np.array_equal(_np(lse).view(np.uint32), lse_o.view(np.uint32))
+        logZ, lse, tok = engine.step(x_t.to(dev), row_of=rd, rng_mode=0, logit_scale=scale, variant=variant, **kw_g)
+        assert tok is None
+        assert np.array_equal(_np(logZ).view(np.uint32), logZ_o.view(np.uint32))
+        assert np.array_equal(_np(lse).view(np.uint32), lse_o.view(np.uint32))
+
+
+def test_many_rows_per_workgroup(engine, oracle):
+    """More than 64 rows per persistent workgroup: the index table and the low-mass bitmap overflow into their
+    fallbacks (scalar index loads, workspace lookups)."""
+    O = oracle
+    N, U, V = 20000, 300, 1000
+    x_np, x_t = _mk(O, U, V, "f32", seed=99)
+    dev = engine.device
+    row_of = (np.arange(N) * 11 % U).astype(np.int32)
+    masks = synth.binary_masks(V + 5, 3, V)
+    masks[1, 7:] = -np.inf   # low mass: own-scale redo in the tail
+    masks[2, :] = -np.inf    # nothing allowed
+    bits, _ = O.mask_f32_to_bits(masks)
+    mid = (np.arange(N) % 3).astype(np.int32)
+    logZ_o, lse_o, tok_o = O.step(x_np, row_of=row_of, rng_mode=O.RNG_PHILOX, seed=4, offset=2, mask_kind=O.MASK_BITS,
+                                  mask=bits, mask_id=mid)
+    logZ, lse, tok = engine.step(x_t.to(dev), row_of=torch.from_numpy(row_of).to(dev), rng_mode=1, seed=4, offset=2,
+                                 mask_kind=1, mask=_bits_dev(bits, dev), mask_id=torch.from_numpy(mid).to(dev), variant=24)
+    assert np.array_equal(_np(tok), tok_o)
+    assert np.array_equal(_np(logZ).view(np.uint32), logZ_o.view(np.uint32))
+    assert np.array_equal(_np(lse).view(np.uint32), lse_o.view(np.uint32))

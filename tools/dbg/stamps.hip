@@ -21,8 +21,7 @@ int main() {
   p.logits = x; p.ld = V; p.V = V; p.n_particles = B; p.out_logZ = lz; p.out_lse = ls;
   uint64_t *ws;
   hipMalloc(&ws, (size_t)B * 70 * 8);
-  p.chunk_sums = ws; p.row_sums = ws + (size_t)B * 64; p.row_exps = (float *)(ws + (size_t)B * 66);
-  p.n_chunks = 40; p.chunk_vecs = 320;
+  p.row_sums = ws; p.row_exps = (float *)(ws + (size_t)B * 2);
   uint32_t *mk;
   int W32 = (V + 31) / 32;
   hipMalloc(&mk, (size_t)2 * W32 * 4);
@@ -76,14 +75,14 @@ int main() {
       double sum[32] = {0};
       for (int wg = 0; wg < 256; ++wg) {
         const unsigned long long *q = &st[(wg * 2 + wv) * 64];
-        for (int i = 1; i < 22; ++i) sum[i] += (double)(q[i] - q[i - 1]);
+        for (int i = 1; i < 20; ++i) sum[i] += (double)(q[i] - q[i - 1]);
       }
       printf("AVG wave %s: prologue %.0f |", wv ? "last " : "first", sum[1] / 256);
       for (int r = 0; r < 4; ++r)
         printf(" row%d ph1 %.0f ph2 %.0f red %.0f %s %.0f |", r, sum[2 + 4 * r] / 256, sum[3 + 4 * r] / 256,
                sum[4 + 4 * r] / 256, r == 3 ? "tail" : "bits", sum[5 + 4 * r] / 256);
-      printf("\n   tail: drain+barrier %.0f fix %.0f select+tiles %.0f exchange %.0f final %.0f\n", sum[17] / 256,
-             sum[18] / 256, sum[19] / 256, sum[20] / 256, sum[21] / 256);
+      printf("\n   tail: last draw + drain %.0f, own-scale redo %.0f, lse/logZ %.0f\n", sum[17] / 256, sum[18] / 256,
+             sum[19] / 256);
     }
   }
 #endif
