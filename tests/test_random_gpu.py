@@ -1,0 +1,109 @@
+"""Randomised parity sweep of the fused step (HIP through the C ABI vs the oracle, bit for bit): odd vocabulary
+sizes down to 1, padded and misaligned rows, every element type, mask kind, draw mode and kernel family."""
+import numpy as np
+import pytest
+import torch
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+V_POOL = [1, 2, 3, 5, 31, 32, 33, 127, 255, 1000, 4097, 8191, 16380, 16381, 32765, 32769, 50257, 65528, 65529, 70001]
+GEOM_CAP = {24: 4096, 22: 8192, 21: 12800, 23: 16384, 25: 20480}  # 16-byte vectors per row
+
+
+def _case(rng):
+    V = int(rng.choice(V_POOL)) if rng.random() < 0.7 else int(rng.integers(1, 60000))
+    dtype = str(rng.choice(["f32", "bf16", "f16"]))
+    U = int(rng.integers(1, 24))
+    budget = 3_000_000 // max(V, 1)
+    N = int(np.clip(rng.integers(1, 3 * U + 2), 1, max(budget, 1)))
+    if rng.random() < 0.25:
+        N = int(min(max(budget, 1), rng.integers(300, 700)))  # enough particles for the persistent kernel's auto path
+    pad = int(rng.integers(0, 10))
+    off = int(rng.integers(0, 8))
+    mask_kind = str(rng.choice(["none", "bits", "bits", "f32"]))
+    rng_mode = str(rng.choice(["philox", "philox", "none", "noise"]))
+    if rng_mode == "noise" and N * V > 400_000:
+        rng_mode = "philox"
+    epv = 4 if dtype == "f32" else 8
+    nv = (V + 2 * (epv - 1)) // epv
+    variants = [0, -1]
+    if mask_kind != "f32" and rng_mode != "noise":
+        variants += [99] + [g for g, cap in GEOM_CAP.items() if cap >= nv]
+    variant = int(rng.choice(variants))
+    scale = float(rng.choice([1.0, 1.0, 0.5, 1.7]))
+    return dict(V=V, dtype=dtype, U=U, N=N, pad=pad, off=off, mask_kind=mask_kind, rng_mode=rng_mode, variant=variant,
+                scale=scale, seed=int(rng.integers(0, 2**31)), K=int(rng.integers(1, 5)))
+
+
+CASES = [_case(np.random.default_rng(1000 + i)) for i in range(64)]
+
+
+@pytest.mark.parametrize("c", CASES, ids=lambda c: f"V{c['V']}-{c['dtype']}-N{c['N']}-{c['mask_kind']}-{c['rng_mode']}-v{c['variant']}")
+def test_random_case(engine, oracle, c):
+    O = oracle
+    dev = engine.device
+    V, U, N = c["V"], c["U"], c["N"]
+    rs = np.random.default_rng(c["seed"])
+    x = synth.logits(c["seed"] % 100000, U, V)
+    x[rs.random((U, V)) < 0.01] = -np.inf  # a few -inf logits (banned upstream)
+    tdt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[c["dtype"]]
+    xt = torch.from_numpy(x).to(tdt)
+    if c["dtype"] == "f32":
+        x_np = x
+    elif c["dtype"] == "bf16":
+        x_np = xt.view(torch.int16).numpy().view(np.uint16)
+    else:
+        x_np = xt.numpy()
+    ld = V + c["pad"]
+    flat = torch.full((c["off"] + U * ld + 8,), 123.0, dtype=tdt)
+    view = flat[c["off"]:c["off"] + U * ld].view(U, ld)
+    view[:, :V] = xt
+    x_d = flat.to(dev)[c["off"]:c["off"] + U * ld].view(U, ld)[:, :V]
+    row_of = rs.integers(0, U, N).astype(np.int32) if not (N == U and rs.random() < 0.5) else None
+    K = c["K"]
+    kw_o, kw_g = {}, {}
+    if c["mask_kind"] != "none":
+        masks = synth.binary_masks(c["seed"] % 9999, K, V)
+        if K > 1:
+            masks[K - 1, :] = -np.inf
+            masks[K - 1, rs.integers(0, V, max(1, V // 500))] = 0.0  # nearly everything forbidden: low allowed mass
+        mid = rs.integers(0, K, N).astype(np.int32)
+        if c["mask_kind"] == "bits":
+            bits, _ = O.mask_f32_to_bits(masks)
+            kw_o = dict(mask_kind=O.MASK_BITS, mask=bits, mask_id=mid)
+            kw_g = dict(mask_kind=1, mask=torch.from_numpy(bits.view(np.int32)).to(dev), mask_id=torch.from_numpy(mid).to(dev))
+        else:
+            mf = masks.copy()
+            fin = np.isfinite(mf)
+            mf[fin] = rs.standard_normal(int(fin.sum())).astype(np.float32) * 2.0  # additive, some positive
+            kw_o = dict(mask_kind=O.MASK_F32, mask=mf, mask_id=mid)
+            kw_g = dict(mask_kind=2, mask=torch.from_numpy(mf).to(dev), mask_id=torch.from_numpy(mid).to(dev))
+    mode = {"none": O.RNG_NONE, "philox": O.RNG_PHILOX, "noise": O.RNG_NOISE}[c["rng_mode"]]
+    if c["rng_mode"] == "noise":
+        E, _ = O.mt_exponential(c["seed"] % 1000, N * V)
+        E = E.reshape(N, V)
+        kw_o["noise"] = E
+        kw_g["noise"] = torch.from_numpy(E).to(dev)
+    seed, offset, base = c["seed"], c["seed"] % 17, c["seed"] % 1000
+    logZ_o, lse_o, tok_o = O.step(x_np, row_of=row_of, rng_mode=mode, seed=seed, offset=offset, particle_base=base,
+                                  logit_scale=c["scale"], n_particles=N if row_of is None else None, **kw_o)
+    call = lambda: engine.step(x_d, vocab=V, row_of=None if row_of is None else torch.from_numpy(row_of).to(dev),
+                               rng_mode={"none": 0, "philox": 1, "noise": 2}[c["rng_mode"]], seed=seed, offset=offset,
+                               particle_base=base, logit_scale=c["scale"], variant=c["variant"], **kw_g)
+    epv = 4 if c["dtype"] == "f32" else 8
+    if (c["mask_kind"] == "f32" or c["rng_mode"] == "noise") and (V + 2 * (epv - 1)) // epv > 16384:
+        # additive float masks and parity-noise draws exist only in the register-resident one-workgroup-per-particle
+        # kernel: longer rows are refused loudly (GLB_EUNSUPPORTED), never computed some other way
+        from genlm_backend_amd._lib import GlbError
+        with pytest.raises(GlbError):
+            call()
+        return
+    logZ, lse, tok = call()
+    torch.cuda.synchronize()
+    got_logZ, got_lse = logZ.cpu().numpy(), lse.cpu().numpy()
+    assert np.array_equal(got_lse.view(np.uint32), lse_o.view(np.uint32)), "lse"
+    assert np.array_equal(got_logZ.view(np.uint32), logZ_o.view(np.uint32)), "logZ"
+    if c["rng_mode"] != "none":
+        assert np.array_equal(tok.cpu().numpy(), tok_o), "token"
