@@ -100,7 +100,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default=None, choices=["sis", "kernel"])
     ap.add_argument("--cpu-sample", type=int, default=1024, help="rows of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
