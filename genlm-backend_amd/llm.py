@@ -142,6 +142,15 @@ class AsyncAmdLM(AsyncLM):
         mod = AutoModelForCausalLM.from_config(config).to(dtype).to(device)
         return cls(mod, tokenizer, **kwargs)
 
+    @staticmethod
+    def _fuse_activations(model):
+        """transformers spells GPT-2's `gelu_new` as eight elementwise torch ops (a fifth of the forward's GPU time at
+        1024 x 13 tokens); `torch.nn.GELU(approximate="tanh")` is the same function in one kernel."""
+        for mod in model.modules():
+            for name, child in list(mod.named_children()):
+                if type(child).__name__ == "NewGELUActivation":
+                    setattr(mod, name, torch.nn.GELU(approximate="tanh"))
+
     @torch.no_grad()
     def __init__(self, hf_model, hf_tokenizer, batch_size=20, timeout=0.02, engine=None):
         self.model = hf_model
@@ -158,6 +167,7 @@ class AsyncAmdLM(AsyncLM):
         self.timeout = timeout
         self.timer = None
         self.model.eval()
+        self._fuse_activations(self.model)
         self._lm_head = self.model.get_output_embeddings()
         self._body = self.model.base_model
         # fused-step state
