@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--workload", default=None, choices=["sis", "kernel"])
     ap.add_argument("--cpu-sample", type=int, default=1024, help="rows of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--prefix-kv", action="store_true",
+                    help="sis workload with the prompt's KV cached (hf.py:155-164 cache_kv; BASELINE config 3)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -139,7 +141,7 @@ def main():
     else:
         from genlm_backend_amd.sis import SisBenchWorkload
 
-        runner = SisBenchWorkload(eng, dev, rank, world, dist)
+        runner = SisBenchWorkload(eng, dev, rank, world, dist, prefix_kv=args.prefix_kv)
 
     for i in range(args.warmup):
         runner.step(i, timed=False)

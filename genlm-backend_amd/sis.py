@@ -252,7 +252,7 @@ class SisBenchWorkload:
 
     particles_per_step = 1024
 
-    def __init__(self, eng, dev, rank, world, dist, n_particles=1024, max_tokens=10):
+    def __init__(self, eng, dev, rank, world, dist, n_particles=1024, max_tokens=10, prefix_kv=False):
         from transformers import GPT2Config
 
         from .llm import AsyncAmdLM
@@ -271,7 +271,8 @@ class SisBenchWorkload:
         self.V, self.N, self.max_tokens = V, n_particles, max_tokens
         self.particles_per_step = n_particles
         self.sis = DeviceSIS(self.llm, n_particles, list(range(100, 108)), max_tokens, cfg.eos_token_id,
-                             seed=1234 + rank, rank=rank, world=world, dist=dist)
+                             seed=1234 + rank, rank=rank, world=world, dist=dist, use_prefix_kv=prefix_kv)
+        self.prefix_kv = prefix_kv
         self.kernel_bytes = None
         self._events = []
         self._bytes = []
@@ -304,6 +305,7 @@ class SisBenchWorkload:
 
     def config(self):
         return {"workload": "SIS step: 1024 particles/GPU, gpt2-small shape (random init, fp32), prompt len 8, <=10 new "
-                            "tokens, 2 shared bit masks, device-resident population, Philox draws",
+                            "tokens, 2 shared bit masks, device-resident population, Philox draws"
+                            + (", prompt KV cached (cache_kv semantics, BASELINE config 3)" if self.prefix_kv else ""),
                 "particles_per_gpu": self.N, "vocab": self.V, "rng": "philox",
                 "mean_unique_contexts_per_step": float(np.mean(self.unique_hist)) if self.unique_hist else None}
