@@ -139,8 +139,11 @@ __device__ unsigned long long g_realtime[256 * 2];
 
 // (Tried and removed: a second register buffer holding the first 8-12 tiles of row r+2, requested right after the
 //  sums pass of row r so that the memory queue is also fed during the reductions.  hipcc's counted waits for the
-//  in-place tiles do not look past those younger loads - the maximum pass ended up waiting for the look-ahead
-//  tiles too - and the kernel got slower: 60.5 / 96.8 us for 8 / 12 tiles against 57.8.)
+//  in-place tiles only count loads that are issued on every path as "younger", so with conditional requests the
+//  maximum pass waited for the look-ahead tiles too (60.5 / 96.8 us for 8 / 12 tiles against 57.8); made
+//  unconditional (rows that do not exist read the -inf page) the waits came out right and it was still slower,
+//  66 us against 58: the CU's memory queue is not starved during the reductions, the extra requests only delay
+//  the next row's own tiles.)
 template <int DT, int MASK, int MODE, int NVL, int T, bool SCALED>
 __global__ __launch_bounds__(T) void row_kernel_persist(const RowParams p) {
   constexpr int W = T / 64;
