@@ -346,8 +346,8 @@ class AsyncAmdLM(AsyncLM):
                 step_row[u] = len(row_u)
                 row_u.append(u)
                 row_t.append(L - 1)
-        ru = torch.tensor(row_u, dtype=torch.int64, device=dev)
-        rt = torch.tensor(row_t, dtype=torch.int64, device=dev)
+        ru = torch.from_numpy(np.asarray(row_u, np.int64)).to(dev)
+        rt = torch.from_numpy(np.asarray(row_t, np.int64)).to(dev)
         logits = self._lm_head(hidden[ru, rt])  # [R, V] plain library GEMM on the gathered rows
         V = logits.shape[-1]
         R = logits.shape[0]
@@ -359,7 +359,7 @@ class AsyncAmdLM(AsyncLM):
             if len(need) == R:
                 lp_slab = eng.log_softmax_rows(logits)
             else:
-                idx = torch.tensor(need, dtype=torch.int64, device=dev)
+                idx = torch.from_numpy(np.asarray(need, np.int64)).to(dev)
                 lp_slab = eng.log_softmax_rows(logits[idx].contiguous())
                 slab_row = {r: i for i, r in enumerate(need)}
 
@@ -367,8 +367,8 @@ class AsyncAmdLM(AsyncLM):
         step_q = [(u, m) for u in range(U) for m in members[u] if m.kind == "step"]
         step_out = None
         if step_q:
-            row_of = torch.tensor([step_row[u] for u, _ in step_q], dtype=torch.int32, device=dev)
-            mask_id = torch.tensor([m.mask_id for _, m in step_q], dtype=torch.int32, device=dev)
+            row_of = torch.from_numpy(np.fromiter((step_row[u] for u, _ in step_q), np.int32, len(step_q))).to(dev)
+            mask_id = torch.from_numpy(np.fromiter((m.mask_id for _, m in step_q), np.int32, len(step_q))).to(dev)
             kw = {}
             if self._mask_kind != MASK_NONE:
                 kw = dict(mask_kind=self._mask_kind, mask=self._masks, mask_id=mask_id)
@@ -406,16 +406,32 @@ class AsyncAmdLM(AsyncLM):
                     m.future.set_result(res)
 
     # ---- queueing (hf.py:290-312) -----------------------------------------------------------------------
-    @torch.no_grad()
     def add_query(self, query, future, past, first_new=0, kind="logprobs", mask_id=0):
+        """hf.py:290-312: queue the request; evaluate when the batch is full or `timeout` after the LAST request.
+        (The reference cancels and re-arms its timer on every request; here one timer re-checks a moving deadline,
+        which fires at the same moment without 2 x batch_size timer operations per batch.)"""
         self.queries.append(Query(query, future, past, first_new=first_new, kind=kind, mask_id=mask_id))
-        if self.timer:
-            self.timer.cancel()
-            self.timer = None
         if len(self.queries) >= self.batch_size:
+            if self.timer:
+                self.timer.cancel()
+                self.timer = None
             self.batch_evaluate_queries()
         else:
-            self.timer = asyncio.get_running_loop().call_later(self.timeout, lambda: self.batch_evaluate_queries())
+            loop = asyncio.get_running_loop()
+            self._deadline = loop.time() + self.timeout
+            if self.timer is None:
+                self.timer = loop.call_later(self.timeout, self._on_timer)
+
+    def _on_timer(self):
+        self.timer = None
+        if not self.queries:
+            return
+        loop = asyncio.get_running_loop()
+        remaining = self._deadline - loop.time()
+        if remaining > 1e-4:
+            self.timer = loop.call_later(remaining, self._on_timer)
+        else:
+            self.batch_evaluate_queries()
 
     def walk_cache(self, token_ids):
         """hf.py:314-344: deepest matching node, tokens matched, deepest KV on the way and its depth."""
@@ -434,7 +450,6 @@ class AsyncAmdLM(AsyncLM):
                 break
         return node, next_token_index, past, base
 
-    @torch.no_grad()
     async def next_token_logprobs(self, token_ids):
         """hf.py:346-373.  Returns a float32 [V] tensor on the model's device."""
         if not token_ids:
@@ -492,7 +507,6 @@ class AsyncAmdLM(AsyncLM):
         return self.engine.log_softmax_rows(self._lm_head(h))[0]
 
     # ---- fused particle step (README.md:82-91 moved behind the queue) ------------------------------------
-    @torch.no_grad()
     async def next_token_step(self, token_ids, mask_id=0):
         """Returns (logZ, token): logZ = logsumexp(next_token_logprobs + mask[mask_id]) and a categorical
         draw from the masked, renormalised distribution; token is -1 if the mask forbids everything."""
