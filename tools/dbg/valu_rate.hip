@@ -68,6 +68,14 @@ BENCH(add_co_only, "v_add_co_u32 %0, vcc, %0, %4\n v_add_co_u32 %1, vcc, %1, %5\
 BENCH(mul_u24, "v_mul_u32_u24 %0, %0, %16\n v_mul_u32_u24 %1, %1, %16\n v_mul_u32_u24 %2, %2, %16\n v_mul_u32_u24 %3, %3, %16\n")
 BENCH(pk_fma, "v_pk_fma_f32 %8, %8, %9, %10\n v_pk_fma_f32 %9, %9, %10, %11\n v_pk_fma_f32 %10, %10, %11, %8\n v_pk_fma_f32 %11, %11, %8, %9\n")
 
+BENCH(cvt_f64_f32, "v_cvt_f64_f32 %8, %12\n v_cvt_f64_f32 %9, %13\n v_cvt_f64_f32 %10, %14\n v_cvt_f64_f32 %11, %15\n")
+BENCH(ldexp_f64, "v_ldexp_f64 %8, %8, %16\n v_ldexp_f64 %9, %9, %16\n v_ldexp_f64 %10, %10, %16\n v_ldexp_f64 %11, %11, %16\n")
+BENCH(floor_f64, "v_floor_f64 %8, %8\n v_floor_f64 %9, %9\n v_floor_f64 %10, %10\n v_floor_f64 %11, %11\n")
+BENCH(trunc_f64, "v_trunc_f64 %8, %8\n v_trunc_f64 %9, %9\n v_trunc_f64 %10, %10\n v_trunc_f64 %11, %11\n")
+BENCH(fma_f64, "v_fma_f64 %8, %8, %9, %10\n v_fma_f64 %9, %9, %10, %11\n v_fma_f64 %10, %10, %11, %8\n v_fma_f64 %11, %11, %8, %9\n")
+BENCH(cvt_f64_u32, "v_cvt_f64_u32 %8, %0\n v_cvt_f64_u32 %9, %1\n v_cvt_f64_u32 %10, %2\n v_cvt_f64_u32 %11, %3\n")
+BENCH(mul_f64, "v_mul_f64 %8, %8, %9\n v_mul_f64 %9, %9, %10\n v_mul_f64 %10, %10, %11\n v_mul_f64 %11, %11, %8\n")
+
 #define RUN(NAME)                                                                                           \
   for (int th : {512}) {                                                                         \
     hipLaunchKernelGGL(k_##NAME, dim3(1), dim3(th), 0, 0, d, iters);                                        \
@@ -88,5 +96,6 @@ int main() {
   RUN(ldexp) RUN(exp) RUN(add_f64)
   RUN(min_u32) RUN(sub_u32) RUN(max_f32) RUN(sub_f32) RUN(mul_f32) RUN(add_f32) RUN(fmac_f32) RUN(fmaak) RUN(cvt_i32) RUN(ashr_i32) RUN(or_b32)
   RUN(bfi) RUN(and_or) RUN(add3) RUN(med3_u32) RUN(cmp_lt) RUN(add_co_only) RUN(mul_u24) RUN(pk_fma)
+  RUN(cvt_f64_f32) RUN(ldexp_f64) RUN(floor_f64) RUN(trunc_f64) RUN(fma_f64) RUN(cvt_f64_u32) RUN(mul_f64)
   return 0;
 }
