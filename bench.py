@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--workload", default=None, choices=["sis", "kernel"])
     ap.add_argument("--cpu-sample", type=int, default=1024, help="rows of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--particle-kv", action="store_true",
+                    help="sis workload with device-resident per-particle KV (beyond the reference: one token per particle per step)")
     ap.add_argument("--prefix-kv", action="store_true",
                     help="sis workload with the prompt's KV cached (hf.py:155-164 cache_kv; BASELINE config 3)")
     args = ap.parse_args()
@@ -141,7 +143,7 @@ def main():
     else:
         from genlm_backend_amd.sis import SisBenchWorkload
 
-        runner = SisBenchWorkload(eng, dev, rank, world, dist, prefix_kv=args.prefix_kv)
+        runner = SisBenchWorkload(eng, dev, rank, world, dist, prefix_kv=args.prefix_kv, particle_kv=args.particle_kv)
 
     for i in range(args.warmup):
         runner.step(i, timed=False)

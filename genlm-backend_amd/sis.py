@@ -87,7 +87,7 @@ class DeviceSIS:
     tokens were generated and masks[1] afterwards (README.md:57-70's masking function)."""
 
     def __init__(self, llm, n_particles, prompt_ids, max_tokens, eos_id, seed=0, rng="philox", rank=0, world=1,
-                 dist=None, use_prefix_kv=False):
+                 dist=None, use_prefix_kv=False, use_particle_kv=False):
         self.llm, self.eng, self.dev = llm, llm.engine, llm.device
         self.N, self.max_tokens, self.eos_id = n_particles, max_tokens, eos_id
         self.rank, self.world, self.dist = rank, world, dist
@@ -113,6 +113,14 @@ class DeviceSIS:
         if use_prefix_kv:
             distinct = sorted({tuple(p) for p in prompts})
             self._build_prefixes(distinct)
+        # Device-resident per-particle KV (beyond the reference, which re-encodes every context every step,
+        # hf.py:202-288): step 0 encodes the distinct prompts once and fans their KV out to the particles; every
+        # later step feeds ONE token per particle against its own KV rows.  Needs equal prompt lengths.
+        self.particle_kv = bool(use_particle_kv)
+        if self.particle_kv:
+            assert len({len(p) for p in prompts}) == 1, "per-particle KV needs prompts of one length"
+            assert not use_prefix_kv
+        self.pkv = None
         self.reset()
 
     @torch.no_grad()
@@ -141,12 +149,59 @@ class DeviceSIS:
         self.max_len_now = self.max_prompt
         self.last_stats = None
         self.kernel_events = []
+        self.pkv = None
 
     # -------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def _step_particle_kv(self, time_kernel):
+        """Steps t >= 1 with per-particle KV: one new token per particle, no dedup, logits row i = particle i."""
+        from transformers import DynamicCache
+
+        eng, llm, dev, N = self.eng, self.llm, self.dev, self.N
+        n_active = int(self.active.sum().item())  # the step's only D2H sync
+        cache_len = self.max_prompt + self.t - 1  # every particle's KV holds prompt + t - 1 tokens
+        rows = torch.arange(N, device=dev)
+        # active particles feed their newest token; finished ones a dummy (their rows are ignored afterwards)
+        newest = self.contexts[rows, (self.lengths - 1).clamp_min(0).long()]
+        ids = torch.where(self.active > 0, newest, torch.zeros_like(newest)).view(N, 1).long()
+        pos = torch.full((N, 1), cache_len, dtype=torch.long, device=dev)
+        out = llm._body(input_ids=ids, position_ids=pos, past_key_values=self.pkv, use_cache=True)
+        self.pkv = out.past_key_values
+        logits = llm._lm_head(out.last_hidden_state[:, 0])  # [N, V]
+        return self._finish_step(logits, None, N, n_active, time_kernel, l_max=1)
+
+    def _finish_step(self, logits, group_of, U, n_active, time_kernel, l_max):
+        eng, llm, N = self.eng, self.llm, self.N
+        V = logits.shape[-1]
+        mask_id = ((self.lengths - self.prompt_len) >= self.max_tokens).to(torch.int32)
+        kw = {}
+        if llm._mask_kind != 0:
+            kw = dict(mask_kind=llm._mask_kind, mask=llm._masks, mask_id=mask_id)
+        if self.rng_mode == RNG_NOISE:
+            kw["noise"] = self._parity_noise(group_of if group_of is not None else torch.arange(N, device=self.dev), V)
+        if time_kernel:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        logZ, _, tok = eng.step(logits, vocab=V, row_of=group_of, rng_mode=self.rng_mode, seed=self.seed,
+                                offset=self.t, particle_base=self.rank * N, want_lse=False, **kw)
+        if time_kernel:
+            e1.record()
+            self.kernel_events.append((e0, e1))
+        eng.particles_advance(self.contexts, self.lengths, self.active, self.log_weights, logZ, tok, self.eos_id,
+                              self.cap)
+        self.t += 1
+        self.max_len_now = min(self.max_len_now + 1, self.cap)
+        self.last_stats = dict(n_unique=U, n_active=n_active, l_max=l_max, n_rows=U)
+        if self.world > 1:
+            self.all_weights = self.gather_weights()
+        return U, n_active
+
     @torch.no_grad()
     def step(self, time_kernel=False):
         """One SIS step for every active particle.  Returns (n_unique, n_active_before)."""
         eng, llm, dev, N = self.eng, self.llm, self.dev, self.N
+        if self.particle_kv and self.t > 0:
+            return self._step_particle_kv(time_kernel)
         ctx_flat = self.contexts.view(-1)
         # finished particles still occupy a row: give them their 1-token stub so they dedup to one group
         lengths_eff = torch.where(self.active > 0, self.lengths, torch.ones_like(self.lengths))
@@ -172,33 +227,19 @@ class DeviceSIS:
             data = [tuple(eng.gather_kv_padded(P["ptrs"][l][j], P["lengths"], pref_u, kv0.heads, kv0.head_dim, p_max,
                                                kv0.dtype) for j in range(2)) for l in range(len(kv0.layers))]
             cache = DynamicCache(ddp_cache_data=data)
-        hidden = llm._body(input_ids=ids, attention_mask=am, position_ids=pos, past_key_values=cache,
-                           use_cache=cache is not None).last_hidden_state
+        want_kv = self.particle_kv  # step 0: keep the prompts' KV and fan it out to the particles
+        out = llm._body(input_ids=ids, attention_mask=None if want_kv else am, position_ids=pos, past_key_values=cache,
+                        use_cache=(cache is not None) or want_kv)
+        hidden = out.last_hidden_state
+        if want_kv:
+            from transformers import DynamicCache
+
+            g = group_of.long()
+            self.pkv = DynamicCache(ddp_cache_data=[(ly.keys.index_select(0, g), ly.values.index_select(0, g))
+                                                    for ly in out.past_key_values.layers])
         h_last = hidden[torch.arange(U, device=dev), last.long()]
         logits = llm._lm_head(h_last)  # [U, V]
-        V = logits.shape[-1]
-        mask_id = ((self.lengths - self.prompt_len) >= self.max_tokens).to(torch.int32)
-        kw = {}
-        if llm._mask_kind != 0:
-            kw = dict(mask_kind=llm._mask_kind, mask=llm._masks, mask_id=mask_id)
-        if self.rng_mode == RNG_NOISE:
-            kw["noise"] = self._parity_noise(group_of, V)
-        if time_kernel:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        logZ, _, tok = eng.step(logits, vocab=V, row_of=group_of, rng_mode=self.rng_mode, seed=self.seed,
-                                offset=self.t, particle_base=self.rank * N, want_lse=False, **kw)
-        if time_kernel:
-            e1.record()
-            self.kernel_events.append((e0, e1))
-        eng.particles_advance(self.contexts, self.lengths, self.active, self.log_weights, logZ, tok, self.eos_id,
-                              self.cap)
-        self.t += 1
-        self.max_len_now = min(self.max_len_now + 1, self.cap)
-        self.last_stats = dict(n_unique=U, n_active=n_active, l_max=l_max, n_rows=U)
-        if self.world > 1:
-            self.all_weights = self.gather_weights()
-        return U, n_active
+        return self._finish_step(logits, group_of, U, n_active, time_kernel, l_max)
 
     def _parity_noise(self, group_of, V):
         """Exp(1) rows in the order the reference's particles reach torch.multinomial: by dedup group
@@ -252,7 +293,7 @@ class SisBenchWorkload:
 
     particles_per_step = 1024
 
-    def __init__(self, eng, dev, rank, world, dist, n_particles=1024, max_tokens=10, prefix_kv=False):
+    def __init__(self, eng, dev, rank, world, dist, n_particles=1024, max_tokens=10, prefix_kv=False, particle_kv=False):
         from transformers import GPT2Config
 
         from .llm import AsyncAmdLM
@@ -271,8 +312,10 @@ class SisBenchWorkload:
         self.V, self.N, self.max_tokens = V, n_particles, max_tokens
         self.particles_per_step = n_particles
         self.sis = DeviceSIS(self.llm, n_particles, list(range(100, 108)), max_tokens, cfg.eos_token_id,
-                             seed=1234 + rank, rank=rank, world=world, dist=dist, use_prefix_kv=prefix_kv)
+                             seed=1234 + rank, rank=rank, world=world, dist=dist, use_prefix_kv=prefix_kv,
+                             use_particle_kv=particle_kv)
         self.prefix_kv = prefix_kv
+        self.particle_kv = particle_kv
         self.kernel_bytes = None
         self._events = []
         self._bytes = []
@@ -306,6 +349,8 @@ class SisBenchWorkload:
     def config(self):
         return {"workload": "SIS step: 1024 particles/GPU, gpt2-small shape (random init, fp32), prompt len 8, <=10 new "
                             "tokens, 2 shared bit masks, device-resident population, Philox draws"
-                            + (", prompt KV cached (cache_kv semantics, BASELINE config 3)" if self.prefix_kv else ""),
+                            + (", prompt KV cached (cache_kv semantics, BASELINE config 3)" if self.prefix_kv else "")
+                            + (", device-resident per-particle KV (one new token per particle per step; NOT the "
+                               "reference's re-encode-every-step algorithm)" if self.particle_kv else ""),
                 "particles_per_gpu": self.N, "vocab": self.V, "rng": "philox",
                 "mean_unique_contexts_per_step": float(np.mean(self.unique_hist)) if self.unique_hist else None}

@@ -167,8 +167,9 @@ def test_backend_sis_on_gpu_matches_reference(llm):
     m.register_masks(torch.from_numpy(gold["sis_masks"]))
     prompt = [int(t) for t in gold["sis_prompt"]]
     want_ctx = [_strip(r) for r in gold["sis_contexts"]]
-    for use_kv in (False, True):
-        sis = DeviceSIS(m, 16, prompt, max_tokens=10, eos_id=0, seed=1234, rng="torch", use_prefix_kv=use_kv)
+    for kw in (dict(), dict(use_prefix_kv=True), dict(use_particle_kv=True)):
+        # prompt KV cached (cache_kv semantics) / device-resident per-particle KV: same tokens, same weights
+        sis = DeviceSIS(m, 16, prompt, max_tokens=10, eos_id=0, seed=1234, rng="torch", **kw)
         sis.run()
         ctx, lw = sis.results()
         assert [list(map(int, c)) for c in ctx] == want_ctx
