@@ -36,7 +36,6 @@ static hipError_t launch_geom(const RowParams &p, int geom, hipStream_t s) {
   }
 }
 
-// persistent pipelined variant (glb_row_kernel_v2.hpp): 512 threads (2 waves / SIMD, 256 VGPRs),
 // persistent kernel (glb_row_persist.hpp), 512 threads; ids -> NVL (capacity 512*NVL 16-byte vectors per row):
 //   24: 8   22: 16   21: 25 (fp32 gpt2-sized rows)   23: 32 (16-bit 128k rows)   25: 40 (16-bit 152k rows, fp32 up to 81 912)
 #if GLB_MODE != 2

@@ -1,5 +1,5 @@
-// diagnostic: run row_kernel_v2 (fp32 gpt2 rows) with shader-clock stamps and print per-phase cycles.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DMASKK=1 -DMODEE=1 tools/dbg/stamps.hip -o tools/dbg/stamps_11
+// diagnostic: run row_kernel_persist (fp32 gpt2 rows) with shader-clock stamps and print per-phase cycles.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DV4 -DMASKK=1 -DMODEE=1 tools/dbg/stamps.hip -o tools/dbg/stamps_11
 #define GLB_STAMPS 1
 #include <hip/hip_runtime.h>
 #include <algorithm>
