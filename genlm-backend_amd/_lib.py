@@ -9,9 +9,10 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libglb_hip.so")
 
+ABI_VERSION = 2
 GLB_OK, GLB_EINVAL, GLB_EUNSUPPORTED, GLB_EHIP, GLB_ENOSPC = 0, 1, 2, 3, 4
 F32, BF16, F16 = 0, 1, 2
-MASK_NONE, MASK_BITS, MASK_F32 = 0, 1, 2
+MASK_NONE, MASK_BITS, MASK_F32, MASK_PREPARED = 0, 1, 2, 3
 RNG_NONE, RNG_PHILOX, RNG_NOISE = 0, 1, 2
 
 
@@ -37,6 +38,7 @@ class StepArgs(C.Structure):
         ("mask_ld", C.c_int64),
         ("n_masks", C.c_int64),
         ("mask_id", C.c_void_p),
+        ("row_mask_id", C.c_void_p),
         ("rng_mode", C.c_int32),
         ("noise", C.c_void_p),
         ("noise_ld", C.c_int64),
@@ -46,7 +48,7 @@ class StepArgs(C.Structure):
         ("out_logZ", C.c_void_p),
         ("out_lse", C.c_void_p),
         ("out_token", C.c_void_p),
-        ("variant", C.c_int32),
+        ("reserved", C.c_int32),
         ("workspace", C.c_void_p),
         ("workspace_bytes", C.c_size_t),
     ]
@@ -63,9 +65,12 @@ SYMBOLS = {
     "glb_abi_version": (C.c_int, []),
     "glb_last_error": (C.c_int, [C.c_char_p, _sz]),
     "glb_device_count": (C.c_int, []),
-    "glb_step_workspace_bytes": (_sz, [_i64]),
+    "glb_step_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "glb_logprob_mask_sample": (C.c_int, [C.POINTER(StepArgs), _vp]),
-    "glb_log_softmax_rows": (C.c_int, [_vp, _i32, _i64, _i64, _i64, _f32, _vp, _i64, _vp, _vp]),
+    "glb_mask_prepared_bytes": (_sz, [_i64, _i64]),
+    "glb_mask_prepare": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _vp, _sz, _vp]),
+    "glb_log_softmax_workspace_bytes": (_sz, [_i64, _i64]),
+    "glb_log_softmax_rows": (C.c_int, [_vp, _i32, _i64, _i64, _i64, _f32, _vp, _i64, _vp, _vp, _sz, _vp]),
     "glb_mask_f32_to_bits": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp]),
     "glb_group_contexts_workspace": (_sz, [_i64]),
     "glb_group_contexts": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -97,8 +102,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
         fn.restype = res
         fn.argtypes = args
-    if lib.glb_abi_version() != 1:
-        raise ImportError(f"libglb_hip.so ABI {lib.glb_abi_version()} != 1")
+    if lib.glb_abi_version() != ABI_VERSION:
+        raise ImportError(f"libglb_hip.so ABI {lib.glb_abi_version()} != {ABI_VERSION}")
     _lib = lib
     return lib
 

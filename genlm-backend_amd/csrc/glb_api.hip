@@ -11,15 +11,16 @@
 #include <string>
 
 #include "../../include/glb.h"
-#include "glb_row_kernel.hpp"
+#include "glb_chunk.hpp"
 
 namespace glb {
-// launchers exported by the nine glb_row_tu.hip translation units (dtype x mode)
-#define GLB_DECL(dt, mode) \
-  hipError_t launch_row_##dt##_##mode(const RowParams &p, int mask_kind, int geom, hipStream_t s);
-GLB_DECL(0, 0) GLB_DECL(0, 1) GLB_DECL(0, 2)
-GLB_DECL(1, 0) GLB_DECL(1, 1) GLB_DECL(1, 2)
-GLB_DECL(2, 0) GLB_DECL(2, 1) GLB_DECL(2, 2)
+// launchers exported by the three glb_chunk_tu.hip translation units (one per element type)
+#define GLB_DECL(dt)                                                                                              \
+  hipError_t launch_stats_##dt(const StepParams &p, int mask_kind, bool scaled, hipStream_t s);                   \
+  hipError_t launch_finish_##dt(const StepParams &p, int mask_kind, int mode, hipStream_t s);                     \
+  hipError_t launch_logprob_rows_##dt(const void *logits, int64_t ld, int V, float scale, const float *lse,       \
+                                      float *out, int64_t out_ld, int n_rows, hipStream_t s);
+GLB_DECL(0) GLB_DECL(1) GLB_DECL(2)
 #undef GLB_DECL
 }  // namespace glb
 
@@ -41,66 +42,45 @@ int hip_fail(hipError_t e, const char *what) {
   return fail(GLB_EHIP, "%s: %s", what, hipGetErrorString(e));
 }
 
-// geometry table shared with glb_row_tu.hip: id -> capacity in 16-byte vectors
-struct Geom { int id, threads, nvl; };
-const Geom kGeoms[] = {{1, 256, 4}, {2, 1024, 4}, {3, 1024, 8}, {4, 1024, 13}, {5, 1024, 16}};
-
-int pick_geom(int64_t vocab, int dtype, int variant) {
-  const int epv = dtype == GLB_F32 ? 4 : 8;
-  // worst case alignment pad is epv-1 leading elements
-  const int64_t nv_max = (vocab + (epv - 1) + epv - 1) / epv;
-  if (variant > 0) {
-    for (const Geom &g : kGeoms)
-      if (g.id == variant) return (int64_t)g.threads * g.nvl >= nv_max ? g.id : -1;
-    return variant == 99 ? 0 : -1;
-  }
-  for (const Geom &g : kGeoms)
-    if ((int64_t)g.threads * g.nvl >= nv_max) return g.id;
-  return 0;
-}
-
-// persistent-kernel geometries (glb_row_tu.hip): id, NVL at 512 threads; capacity = 512 * NVL vectors
-struct Geom2 { int id, nvl; };
-const Geom2 kGeoms2[] = {{24, 8}, {22, 16}, {21, 25}, {23, 32}, {25, 40}};
-
-int pick_geom2(int64_t vocab, int dtype, int variant) {
-  const int epv = dtype == GLB_F32 ? 4 : 8;
-  const int64_t nv_max = (vocab + (epv - 1) + epv - 1) / epv;
-  for (const Geom2 &g : kGeoms2) {
-    if (variant > 0 && g.id != variant) continue;
-    if ((int64_t)512 * g.nvl >= nv_max) return g.id;
-  }
-  return 0;
-}
-
-int num_cus() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-      cus = v;
-    else
-      cus = 256;
-  }
-  return cus;
-}
-
-hipError_t dispatch_row(int dtype, int mode, const glb::RowParams &p, int mask_kind, int geom,
-                        hipStream_t s) {
-  using namespace glb;
-  switch (dtype * 3 + mode) {
-    case 0: return launch_row_0_0(p, mask_kind, geom, s);
-    case 1: return launch_row_0_1(p, mask_kind, geom, s);
-    case 2: return launch_row_0_2(p, mask_kind, geom, s);
-    case 3: return launch_row_1_0(p, mask_kind, geom, s);
-    case 4: return launch_row_1_1(p, mask_kind, geom, s);
-    case 5: return launch_row_1_2(p, mask_kind, geom, s);
-    case 6: return launch_row_2_0(p, mask_kind, geom, s);
-    case 7: return launch_row_2_1(p, mask_kind, geom, s);
-    case 8: return launch_row_2_2(p, mask_kind, geom, s);
+hipError_t launch_stats(int dtype, const glb::StepParams &p, int mask_kind, bool scaled, hipStream_t s) {
+  switch (dtype) {
+    case 0: return glb::launch_stats_0(p, mask_kind, scaled, s);
+    case 1: return glb::launch_stats_1(p, mask_kind, scaled, s);
+    case 2: return glb::launch_stats_2(p, mask_kind, scaled, s);
   }
   return hipErrorInvalidValue;
+}
+
+hipError_t launch_finish(int dtype, const glb::StepParams &p, int mask_kind, int mode, hipStream_t s) {
+  switch (dtype) {
+    case 0: return glb::launch_finish_0(p, mask_kind, mode, s);
+    case 1: return glb::launch_finish_1(p, mask_kind, mode, s);
+    case 2: return glb::launch_finish_2(p, mask_kind, mode, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+inline int64_t n_chunks(int64_t vocab) { return (vocab + glb::kChunk - 1) / glb::kChunk; }
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+// prepared masks: transposed lane words, then the sparse-id lists
+inline size_t prepared_words_bytes(int64_t n_masks, int64_t vocab) {
+  return align256((size_t)n_masks * (size_t)n_chunks(vocab) * 64 * sizeof(uint64_t));
+}
+inline size_t prepared_bytes(int64_t n_masks, int64_t vocab) {
+  return prepared_words_bytes(n_masks, vocab) + align256((size_t)n_masks * glb::kInfoWords * sizeof(int32_t));
+}
+
+hipError_t launch_mask_prepare(const uint32_t *bits, int64_t n_masks, int64_t vocab, int64_t mask_ld, int dtype,
+                               void *out, hipStream_t s) {
+  const int nch = (int)n_chunks(vocab);
+  uint64_t *mt = (uint64_t *)out;
+  int32_t *info = (int32_t *)((char *)out + prepared_words_bytes(n_masks, vocab));
+  const dim3 grid((unsigned)(nch + 1), (unsigned)n_masks), block(256);
+  if (dtype == GLB_F32)
+    hipLaunchKernelGGL((glb::mask_prepare_kernel<4>), grid, block, 0, s, bits, mask_ld, (int)vocab, nch, mt, info);
+  else
+    hipLaunchKernelGGL((glb::mask_prepare_kernel<8>), grid, block, 0, s, bits, mask_ld, (int)vocab, nch, mt, info);
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -377,36 +357,12 @@ inline unsigned blocks_for(int64_t n, int t) { return (unsigned)((n + t - 1) / t
 
 }  // namespace
 
-static void fill_row_params(glb::RowParams &p, const glb_step_args *a) {
-  p.logits = a->logits;
-  p.ld = a->ld;
-  p.V = (int32_t)a->vocab;
-  p.use_scale = a->logit_scale != 1.0f;
-  p.scale = a->logit_scale;
-  p.n_particles = (int32_t)a->n_particles;
-  p.row_of = a->row_of;
-  p.mask = a->mask;
-  p.mask_ld = a->mask_ld;
-  p.mask_id = a->mask_id;
-  p.n_masks = (int32_t)a->n_masks;
-  p.noise = a->noise;
-  p.noise_ld = a->noise_ld;
-  p.seed = a->seed;
-  p.offset = a->offset;
-  p.particle_base = a->particle_base;
-  p.out_logZ = a->out_logZ;
-  p.out_lse = a->out_lse;
-  p.out_token = a->out_token;
-  p.out_logprobs = nullptr;
-  p.out_ld = 0;
-}
-
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
 extern "C" {
 
-const char *glb_version(void) { return "glb-hip 0.1.0 (gfx950)"; }
+const char *glb_version(void) { return "glb-hip 0.2.0 (gfx950)"; }
 int glb_abi_version(void) { return GLB_ABI_VERSION; }
 
 int glb_last_error(char *buf, size_t n) {
@@ -424,10 +380,30 @@ int glb_device_count(void) {
   return c;
 }
 
-size_t glb_step_workspace_bytes(int64_t n_particles) {
-  if (n_particles <= 0) return 0;
-  // 2 row sums (u64) and 2 exponents (f32) per particle, with headroom
-  return (size_t)n_particles * (4 * sizeof(uint64_t)) + 256;
+size_t glb_step_workspace_bytes(int64_t n_particles, int64_t n_rows, int64_t vocab, int64_t n_masks) {
+  if (n_particles <= 0 || vocab <= 0) return 0;
+  const int64_t units = n_particles > n_rows ? n_particles : n_rows;
+  return align256((size_t)units * (size_t)n_chunks(vocab) * sizeof(glb::ChunkRec)) +
+         (n_masks > 0 ? prepared_bytes(n_masks, vocab) : 0) + 256;
+}
+
+size_t glb_mask_prepared_bytes(int64_t n_masks, int64_t vocab) {
+  if (n_masks <= 0 || vocab <= 0) return 0;
+  return prepared_bytes(n_masks, vocab);
+}
+
+int glb_mask_prepare(const uint32_t *mask_bits, int64_t n_masks, int64_t vocab, int64_t mask_ld, int32_t dtype,
+                     void *out_prepared, size_t out_bytes, void *stream) {
+  if (!mask_bits || !out_prepared) return fail(GLB_EINVAL, "null pointer");
+  if (n_masks <= 0 || vocab <= 0 || mask_ld < (vocab + 31) / 32) return fail(GLB_EINVAL, "bad sizes");
+  if (dtype < GLB_F32 || dtype > GLB_F16) return fail(GLB_EINVAL, "bad dtype %d", dtype);
+  if (vocab > 0x7fffff00ll || n_masks > 65535) return fail(GLB_EINVAL, "vocab / n_masks out of range");
+  if (out_bytes < prepared_bytes(n_masks, vocab))
+    return fail(GLB_ENOSPC, "prepared buffer %zu < %zu bytes", out_bytes, prepared_bytes(n_masks, vocab));
+  if (((uintptr_t)out_prepared) % 16 || ((uintptr_t)mask_bits) % 4) return fail(GLB_EINVAL, "misaligned pointer");
+  const hipError_t e = launch_mask_prepare(mask_bits, n_masks, vocab, mask_ld, dtype, out_prepared, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "mask_prepare launch");
+  return GLB_OK;
 }
 
 int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
@@ -441,21 +417,28 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
     return fail(GLB_EINVAL, "n_rows=%lld vocab=%lld n_particles=%lld must be positive",
                 (long long)a->n_rows, (long long)a->vocab, (long long)a->n_particles);
   if (a->ld < a->vocab) return fail(GLB_EINVAL, "ld %lld < vocab %lld", (long long)a->ld, (long long)a->vocab);
-  if (a->vocab > 0x7fffff00ll || a->n_particles > 0x7fffffffll)
-    return fail(GLB_EINVAL, "vocab / n_particles exceed 31 bits");
+  if (a->vocab > 0x7fffff00ll || a->n_particles > 0x7fffffffll || a->n_rows > 0x7fffffffll)
+    return fail(GLB_EINVAL, "vocab / n_particles / n_rows exceed 31 bits");
   const int es = a->dtype == GLB_F32 ? 4 : 2;
   if (((uintptr_t)a->logits) % es) return fail(GLB_EINVAL, "logits pointer not element aligned");
   if (!a->row_of && a->n_particles != a->n_rows)
     return fail(GLB_EINVAL, "row_of is null but n_particles != n_rows");
-  if (a->mask_kind < GLB_MASK_NONE || a->mask_kind > GLB_MASK_F32)
+  if (a->mask_kind < GLB_MASK_NONE || a->mask_kind > GLB_MASK_PREPARED)
     return fail(GLB_EINVAL, "bad mask_kind %d", a->mask_kind);
+  const bool by_row = a->mask_kind == GLB_MASK_NONE || a->row_mask_id != nullptr;  // reduce once per logits row
+  const int64_t n_units = by_row ? a->n_rows : a->n_particles;
   if (a->mask_kind != GLB_MASK_NONE) {
     if (!a->mask || a->n_masks <= 0) return fail(GLB_EINVAL, "mask table missing");
-    const int64_t need = a->mask_kind == GLB_MASK_BITS ? (a->vocab + 31) / 32 : a->vocab;
-    if (a->mask_ld < need) return fail(GLB_EINVAL, "mask_ld %lld < %lld", (long long)a->mask_ld, (long long)need);
-    if (!a->mask_id && a->n_masks != 1 && a->n_masks != a->n_particles)
-      return fail(GLB_EINVAL, "mask_id is null but n_masks is neither 1 nor n_particles");
-    if (((uintptr_t)a->mask) % 4) return fail(GLB_EINVAL, "mask pointer not 4-byte aligned");
+    if (a->mask_kind != GLB_MASK_PREPARED) {
+      const int64_t need = a->mask_kind == GLB_MASK_BITS ? (a->vocab + 31) / 32 : a->vocab;
+      if (a->mask_ld < need) return fail(GLB_EINVAL, "mask_ld %lld < %lld", (long long)a->mask_ld, (long long)need);
+    }
+    if (a->row_mask_id && a->mask_id) return fail(GLB_EINVAL, "give mask_id (per particle) or row_mask_id (per row), not both");
+    if (!a->row_mask_id && !a->mask_id && a->n_masks != 1 && a->n_masks != n_units)
+      return fail(GLB_EINVAL, "no mask ids given but n_masks is neither 1 nor the number of %s",
+                  by_row ? "rows" : "particles");
+    if (((uintptr_t)a->mask) % (a->mask_kind == GLB_MASK_PREPARED ? 16 : 4)) return fail(GLB_EINVAL, "mask pointer misaligned");
+    if (a->n_masks > 0x7fffffffll) return fail(GLB_EINVAL, "n_masks exceeds 31 bits");
   }
   if (a->rng_mode < GLB_RNG_NONE || a->rng_mode > GLB_RNG_NOISE)
     return fail(GLB_EINVAL, "bad rng_mode %d", a->rng_mode);
@@ -464,57 +447,74 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
   if (a->rng_mode != GLB_RNG_NONE && !a->out_token)
     return fail(GLB_EINVAL, "rng_mode set but out_token is null");
   if (!(a->logit_scale == a->logit_scale)) return fail(GLB_EINVAL, "logit_scale is NaN");
+  if (!a->workspace) return fail(GLB_EINVAL, "workspace is null (glb_step_workspace_bytes)");
+  if (((uintptr_t)a->workspace) % 32) return fail(GLB_EINVAL, "workspace not 32-byte aligned");
+  const bool own_prep = a->mask_kind == GLB_MASK_BITS;
+  const size_t recs_bytes = align256((size_t)n_units * (size_t)n_chunks(a->vocab) * sizeof(glb::ChunkRec));
+  const size_t need_ws = recs_bytes + (own_prep ? prepared_bytes(a->n_masks, a->vocab) : 0);
+  if (a->workspace_bytes < need_ws)
+    return fail(GLB_ENOSPC, "workspace %zu < %zu bytes", a->workspace_bytes, need_ws);
 
-  // persistent pipelined kernel when the caller lent a workspace and the mode allows it
-  int geom = 0;
-  const bool v2_ok = a->workspace && a->mask_kind != GLB_MASK_F32 && a->rng_mode != GLB_RNG_NOISE &&
-                     (a->variant == 0 || (a->variant >= 21 && a->variant != 99));
-  if (v2_ok) {
-    if (a->workspace_bytes < glb_step_workspace_bytes(a->n_particles))
-      return fail(GLB_ENOSPC, "workspace %zu < %zu bytes", a->workspace_bytes,
-                  glb_step_workspace_bytes(a->n_particles));
-    if (((uintptr_t)a->workspace) % 16) return fail(GLB_EINVAL, "workspace not 16-byte aligned");
-    int g2 = pick_geom2(a->vocab, a->dtype, a->variant);
-    // auto: the persistent kernel pays off from about 1.25 rows per CU (measured, tools/kdispatch.py: 512 x 50257
-    // fp32 36 vs 46 us, 1024: 58 vs 81, 2048: 99 vs 152; 512 x 128256 bf16 61 vs 71; at one row per CU they tie)
-    if (a->variant == 0 && a->n_particles * 4 < 5 * (int64_t)num_cus()) g2 = 0;
-    if (g2) {
-      int64_t grid = a->n_particles < num_cus() ? a->n_particles : num_cus();
-      if (const char *g = getenv("GLB_V2_GRID")) {  // tuning knob: persistent workgroups to launch
-        const int64_t want = atoll(g);
-        if (want > 0 && want < grid) grid = want;
-      }
-      geom = g2 | ((int)grid << 8);
+  hipStream_t s = (hipStream_t)stream;
+  glb::StepParams p{};
+  p.logits = a->logits;
+  p.ld = a->ld;
+  p.V = (int32_t)a->vocab;
+  p.nch = (int32_t)n_chunks(a->vocab);
+  p.scale = a->logit_scale;
+  p.n_particles = (int32_t)a->n_particles;
+  p.n_pairs = (int32_t)n_units;
+  p.n_masks = (int32_t)a->n_masks;
+  if (by_row) {
+    p.pair_row = nullptr;
+    p.pair_mask = a->row_mask_id;
+    p.pair_of = a->row_of;
+  } else {
+    p.pair_row = a->row_of;
+    p.pair_mask = a->mask_id;
+    p.pair_of = nullptr;
+  }
+  p.recs = (glb::ChunkRec *)a->workspace;
+  int kmask = glb::kMaskNone;
+  if (a->mask_kind == GLB_MASK_F32) {
+    kmask = glb::kMaskF32;
+    p.mask_f = (const float *)a->mask;
+    p.mask_ld = a->mask_ld;
+  } else if (a->mask_kind != GLB_MASK_NONE) {
+    kmask = glb::kMaskBits;
+    const char *prep = (const char *)a->mask;
+    if (own_prep) {  // transposed form + sparse lists into the workspace, on the same stream
+      char *dst = (char *)a->workspace + recs_bytes;
+      const hipError_t e = launch_mask_prepare((const uint32_t *)a->mask, a->n_masks, a->vocab, a->mask_ld, a->dtype, dst, s);
+      if (e != hipSuccess) return hip_fail(e, "mask_prepare launch");
+      prep = dst;
     }
+    p.mask_t = (const uint64_t *)prep;
+    p.mask_info = (const int32_t *)(prep + prepared_words_bytes(a->n_masks, a->vocab));
   }
-  if (a->variant >= 21 && a->variant != 99 && geom == 0)
-    return fail(GLB_EINVAL, "variant %d needs a workspace, mask none/bits and rng none/philox", a->variant);
-  if (geom == 0) {
-    geom = pick_geom(a->vocab, a->dtype, a->variant);
-    if (geom < 0) return fail(GLB_EINVAL, "variant %d cannot hold vocab %lld", a->variant, (long long)a->vocab);
-    if (geom == 0 || a->variant == 99) {
-      // rows beyond the register-resident capacity: streaming multi-pass kernel (mask none/bits, no noise mode)
-      if (a->mask_kind == GLB_MASK_F32 || a->rng_mode == GLB_RNG_NOISE)
-        return fail(GLB_EUNSUPPORTED, "vocab %lld needs the streaming kernel, which supports mask none/bits and "
-                    "rng none/philox only", (long long)a->vocab);
-      geom = 99;
-    }
-  }
-
-  glb::RowParams p{};
-  fill_row_params(p, a);
-  if (a->workspace) {
-    p.row_sums = (uint64_t *)a->workspace;
-    p.row_exps = (float *)(p.row_sums + (size_t)a->n_particles * 2);
-  }
-  const hipError_t e = dispatch_row(a->dtype, a->rng_mode, p, a->mask_kind, geom, (hipStream_t)stream);
-  if (e != hipSuccess) return hip_fail(e, "row_kernel launch");
+  p.noise = a->noise;
+  p.noise_ld = a->noise_ld;
+  p.seed = a->seed;
+  p.offset = a->offset;
+  p.particle_base = a->particle_base;
+  p.out_logZ = a->out_logZ;
+  p.out_lse = a->out_lse;
+  p.out_token = a->out_token;
+  hipError_t e = launch_stats(a->dtype, p, kmask, a->logit_scale != 1.0f, s);
+  if (e != hipSuccess) return hip_fail(e, "chunk_stats launch");
+  e = launch_finish(a->dtype, p, kmask, a->rng_mode, s);
+  if (e != hipSuccess) return hip_fail(e, "finish launch");
   return GLB_OK;
+}
+
+size_t glb_log_softmax_workspace_bytes(int64_t n_rows, int64_t vocab) {
+  if (n_rows <= 0 || vocab <= 0) return 0;
+  return align256((size_t)n_rows * (size_t)n_chunks(vocab) * sizeof(glb::ChunkRec)) + align256((size_t)n_rows * 4) + 256;
 }
 
 int glb_log_softmax_rows(const void *logits, int32_t dtype, int64_t n_rows, int64_t vocab,
                          int64_t ld, float logit_scale, float *out, int64_t out_ld, float *out_lse,
-                         void *stream) {
+                         void *workspace, size_t workspace_bytes, void *stream) {
   if (!logits) return fail(GLB_EINVAL, "logits is null");
   if (dtype < GLB_F32 || dtype > GLB_F16) return fail(GLB_EINVAL, "bad dtype %d", dtype);
   if (n_rows <= 0 || vocab <= 0) return fail(GLB_EINVAL, "n_rows / vocab must be positive");
@@ -522,20 +522,35 @@ int glb_log_softmax_rows(const void *logits, int32_t dtype, int64_t n_rows, int6
   if (!out && !out_lse) return fail(GLB_EINVAL, "no output requested");
   if (vocab > 0x7fffff00ll || n_rows > 0x7fffffffll) return fail(GLB_EINVAL, "size exceeds 31 bits");
   if (out && ((uintptr_t)out) % 4) return fail(GLB_EINVAL, "out pointer not 4-byte aligned");
-  int geom = pick_geom(vocab, dtype, 0);
-  if (geom == 0) geom = 99;  // streaming multi-pass kernel
-  glb::RowParams p{};
+  if (!(logit_scale == logit_scale)) return fail(GLB_EINVAL, "logit_scale is NaN");
+  if (!workspace || ((uintptr_t)workspace) % 32) return fail(GLB_EINVAL, "workspace null or not 32-byte aligned");
+  if (workspace_bytes < glb_log_softmax_workspace_bytes(n_rows, vocab))
+    return fail(GLB_ENOSPC, "workspace %zu < %zu bytes", workspace_bytes, glb_log_softmax_workspace_bytes(n_rows, vocab));
+  hipStream_t s = (hipStream_t)stream;
+  const size_t recs_bytes = align256((size_t)n_rows * (size_t)n_chunks(vocab) * sizeof(glb::ChunkRec));
+  float *lse = out_lse ? out_lse : (float *)((char *)workspace + recs_bytes);
+  glb::StepParams p{};
   p.logits = logits;
   p.ld = ld;
   p.V = (int32_t)vocab;
-  p.use_scale = logit_scale != 1.0f;
+  p.nch = (int32_t)n_chunks(vocab);
   p.scale = logit_scale;
   p.n_particles = (int32_t)n_rows;
-  p.out_lse = out_lse;
-  p.out_logprobs = out;
-  p.out_ld = out_ld;
-  const hipError_t e = dispatch_row(dtype, glb::kModeStats, p, glb::kMaskNone, geom, (hipStream_t)stream);
-  if (e != hipSuccess) return hip_fail(e, "row_kernel launch");
+  p.n_pairs = (int32_t)n_rows;
+  p.recs = (glb::ChunkRec *)workspace;
+  p.out_lse = lse;
+  hipError_t e = launch_stats(dtype, p, glb::kMaskNone, logit_scale != 1.0f, s);
+  if (e != hipSuccess) return hip_fail(e, "chunk_stats launch");
+  e = launch_finish(dtype, p, glb::kMaskNone, glb::kModeStats, s);
+  if (e != hipSuccess) return hip_fail(e, "finish launch");
+  if (out) {
+    switch (dtype) {
+      case 0: e = glb::launch_logprob_rows_0(logits, ld, (int)vocab, logit_scale, lse, out, out_ld, (int)n_rows, s); break;
+      case 1: e = glb::launch_logprob_rows_1(logits, ld, (int)vocab, logit_scale, lse, out, out_ld, (int)n_rows, s); break;
+      default: e = glb::launch_logprob_rows_2(logits, ld, (int)vocab, logit_scale, lse, out, out_ld, (int)n_rows, s); break;
+    }
+    if (e != hipSuccess) return hip_fail(e, "logprob_rows launch");
+  }
   return GLB_OK;
 }
 

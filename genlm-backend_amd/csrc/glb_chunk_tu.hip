@@ -1,0 +1,65 @@
+// glb_chunk_tu.hip — one translation unit per element type (-DGLB_DT=<0|1|2>): instantiates the chunked step
+// kernels for every mask kind / draw mode and exports the launchers glb_api.hip dispatches to.
+#include "glb_chunk.hpp"
+
+#ifndef GLB_DT
+#error "GLB_DT not defined"
+#endif
+
+namespace glb {
+
+#define GLB_CAT_(a, b) a##b
+#define GLB_CAT(a, b) GLB_CAT_(a, b)
+
+template <int MASK>
+static hipError_t stats1(const StepParams &p, bool scaled, hipStream_t s) {
+  const int64_t waves = (int64_t)p.n_pairs * p.nch;
+  const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+  if (scaled)
+    hipLaunchKernelGGL((chunk_stats_kernel<GLB_DT, MASK, true>), grid, block, 0, s, p);
+  else
+    hipLaunchKernelGGL((chunk_stats_kernel<GLB_DT, MASK, false>), grid, block, 0, s, p);
+  return hipGetLastError();
+}
+
+hipError_t GLB_CAT(launch_stats_, GLB_DT)(const StepParams &p, int mask_kind, bool scaled, hipStream_t s) {
+  switch (mask_kind) {
+    case kMaskNone: return stats1<kMaskNone>(p, scaled, s);
+    case kMaskBits: return stats1<kMaskBits>(p, scaled, s);
+    case kMaskF32: return stats1<kMaskF32>(p, scaled, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+template <int MASK>
+static hipError_t finish1(const StepParams &p, int mode, hipStream_t s) {
+  const dim3 grid((unsigned)(((int64_t)p.n_particles + 3) / 4)), block(256);
+  switch (mode) {
+    case kModeStats: hipLaunchKernelGGL((finish_kernel<GLB_DT, MASK, kModeStats>), grid, block, 0, s, p); break;
+    case kModePhilox: hipLaunchKernelGGL((finish_kernel<GLB_DT, MASK, kModePhilox>), grid, block, 0, s, p); break;
+    case kModeNoise: hipLaunchKernelGGL((finish_kernel<GLB_DT, MASK, kModeNoise>), grid, block, 0, s, p); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t GLB_CAT(launch_finish_, GLB_DT)(const StepParams &p, int mask_kind, int mode, hipStream_t s) {
+  switch (mask_kind) {
+    case kMaskNone: return finish1<kMaskNone>(p, mode, s);
+    case kMaskBits: return finish1<kMaskBits>(p, mode, s);
+    case kMaskF32: return finish1<kMaskF32>(p, mode, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+hipError_t GLB_CAT(launch_logprob_rows_, GLB_DT)(const void *logits, int64_t ld, int V, float scale,
+                                                  const float *lse, float *out, int64_t out_ld, int n_rows,
+                                                  hipStream_t s) {
+  constexpr int EPV = ElemTraits<GLB_DT>::EPV;
+  const int64_t total = (int64_t)n_rows * ((V + EPV - 1) / EPV);
+  hipLaunchKernelGGL((logprob_rows_kernel<GLB_DT>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, logits,
+                     ld, V, scale, lse, out, out_ld, n_rows);
+  return hipGetLastError();
+}
+
+}  // namespace glb

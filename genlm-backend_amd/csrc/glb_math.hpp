@@ -1,9 +1,13 @@
 // glb_math.hpp — "GLB math": the deterministic arithmetic contract of the hot path.
 //
 // Device restatement of the contract that oracle/glb_oracle.c states for the CPU.  Every floating
-// point step is a single IEEE-754 operation (mul, add, fma, rint, exact power-of-two scaling), the
-// file is compiled with -ffp-contract=off, and all sums are 64-bit integer sums, so results do not
+// point step is a single IEEE-754 operation (mul, add, fma, exact power-of-two scaling), the
+// file is compiled with -ffp-contract=off, and all sums are integer sums, so results do not
 // depend on how a row is split over lanes, waves, workgroups or GPUs.
+//
+// Two generations live here: the chunked contract of the particle step ("v2": chunk_term / term_q and the
+// round-toward-zero two-grid accumulation, below) and the row-scale fixed-point term of the first round
+// (exp_parts / fix_term), which glb_normalize_weights still uses for the short log-weight vector.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -71,66 +75,6 @@ __device__ __forceinline__ uint64_t fix_term(float x, float Nb) {
   float nf, P;
   exp_parts(x, nf, P);
   return fix_term_from_parts(nf, P, Nb);
-}
-
-// Four independent exp splits + fixed-point operands, hand-interleaved (the four dependency chains advance in
-// lock step) and with the shift taken in the integer domain: n sits in the low mantissa bits of
-// tm = fma(x, log2e, magic), so  sh = min(bits(Nb + magic) - bits(tm), 63)  is two integer instructions instead
-// of subtract / min / convert.  Same values as exp_parts + fix_term_from_parts for |x * log2 e| < 2^22:
-//   pf[c] = (uint32) P(x_c),  sh[c] = min(Nb - n(x_c), 63),  term = ((uint64)pf << 32) >> sh.
-__device__ __forceinline__ void exp_fix4(float x0, float x1, float x2, float x3, float Nb,
-                                         uint32_t (&pf)[4], uint32_t (&sh)[4]) {
-  float r0, r1, r2, r3;
-  const float c4 = kC4, l2e = kLog2e, magic = kMagic;
-  const uint32_t nbi = __float_as_uint(Nb + kMagic);
-  asm volatile(
-      "v_fmaak_f32 %4, %18, %12, 0x4b400000\n\t"
-      "v_fmaak_f32 %5, %18, %13, 0x4b400000\n\t"
-      "v_fmaak_f32 %6, %18, %14, 0x4b400000\n\t"
-      "v_fmaak_f32 %7, %18, %15, 0x4b400000\n\t"
-      "v_sub_f32 %8, %19, %4\n\t"
-      "v_sub_f32 %9, %19, %5\n\t"
-      "v_sub_f32 %10, %19, %6\n\t"
-      "v_sub_f32 %11, %19, %7\n\t"
-      "v_fmac_f32 %8, %18, %12\n\t"
-      "v_fmac_f32 %9, %18, %13\n\t"
-      "v_fmac_f32 %10, %18, %14\n\t"
-      "v_fmac_f32 %11, %18, %15\n\t"
-      "v_fmamk_f32 %0, %8, 0x49adfe07, %17\n\t"
-      "v_fmamk_f32 %1, %9, 0x49adfe07, %17\n\t"
-      "v_fmamk_f32 %2, %10, 0x49adfe07, %17\n\t"
-      "v_fmamk_f32 %3, %11, 0x49adfe07, %17\n\t"
-      "v_fmaak_f32 %0, %0, %8, 0x4c635b16\n\t"
-      "v_fmaak_f32 %1, %1, %9, 0x4c635b16\n\t"
-      "v_fmaak_f32 %2, %2, %10, 0x4c635b16\n\t"
-      "v_fmaak_f32 %3, %3, %11, 0x4c635b16\n\t"
-      "v_fmaak_f32 %0, %0, %8, 0x4d75fcd9\n\t"
-      "v_fmaak_f32 %1, %1, %9, 0x4d75fcd9\n\t"
-      "v_fmaak_f32 %2, %2, %10, 0x4d75fcd9\n\t"
-      "v_fmaak_f32 %3, %3, %11, 0x4d75fcd9\n\t"
-      "v_fmaak_f32 %0, %0, %8, 0x4e317216\n\t"
-      "v_fmaak_f32 %1, %1, %9, 0x4e317216\n\t"
-      "v_fmaak_f32 %2, %2, %10, 0x4e317216\n\t"
-      "v_fmaak_f32 %3, %3, %11, 0x4e317216\n\t"
-      "v_fmaak_f32 %0, %0, %8, 0x4e800000\n\t"
-      "v_fmaak_f32 %1, %1, %9, 0x4e800000\n\t"
-      "v_fmaak_f32 %2, %2, %10, 0x4e800000\n\t"
-      "v_fmaak_f32 %3, %3, %11, 0x4e800000\n\t"
-      "v_sub_u32 %4, %16, %4\n\t"
-      "v_sub_u32 %5, %16, %5\n\t"
-      "v_sub_u32 %6, %16, %6\n\t"
-      "v_sub_u32 %7, %16, %7\n\t"
-      "v_min_u32 %4, 63, %4\n\t"
-      "v_min_u32 %5, 63, %5\n\t"
-      "v_min_u32 %6, 63, %6\n\t"
-      "v_min_u32 %7, 63, %7\n\t"
-      "v_cvt_u32_f32 %0, %0\n\t"
-      "v_cvt_u32_f32 %1, %1\n\t"
-      "v_cvt_u32_f32 %2, %2\n\t"
-      "v_cvt_u32_f32 %3, %3"
-      : "=&v"(pf[0]), "=&v"(pf[1]), "=&v"(pf[2]), "=&v"(pf[3]), "=&v"(sh[0]), "=&v"(sh[1]), "=&v"(sh[2]),
-        "=&v"(sh[3]), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
-      : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(nbi), "v"(c4), "v"(l2e), "s"(magic));  // (a literal and an SGPR cannot share an instruction on gfx9)
 }
 
 // ln(S * 2^k) for integer S > 0 (atanh series in double, fixed op order)
@@ -227,6 +171,220 @@ __device__ __forceinline__ float wave_max(float v) {
   v = dpp_max_step<0x142, 0xa>(v);
   v = dpp_max_step<0x143, 0xc>(v);
   return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
+}
+
+
+// =====================================================================================================
+// Chunked contract of the particle step.  A row is cut into chunks of kChunk elements by
+// vocabulary index.  Chunk c has its own binary scale N_c = exp_n(max of the chunk); every element gives
+//     t = ldexp(P(f), n - N_c)    fp32, P = 2^(f-1) in [0.35, 0.71] (degree-5 Horner, result clamped to [0,1],
+//                                 NaN -> 0), so t <= 0.7072 and t = 0 for -inf / NaN
+//     q = floor(t * 2^36)         integer term, 36 fractional bits below 2^(N_c + 1)
+// and S_c = sum q.  The hot kernel never forms q: it adds t into fp32 accumulators in ROUND-TOWARD-ZERO mode on
+// two fixed grids - A on 2^-18 (A stays in [32, 64)), the exact remainder into B on 2^-36 (B in [2^-13, 2^-12)) -
+// which is the same integer sum: floor_36(t) = floor_18(t) + floor_36(t - floor_18(t)), every add exact.
+// A accumulator takes at most 32 terms (32 * 0.7072 < 32; remainders < 2^-18 each, 32 of them < 2^-13).
+// =====================================================================================================
+constexpr int kChunk = 4096;         // elements per chunk (64 per lane of one wave)
+constexpr int kFrac = 36;            // q = floor(t * 2^36)
+constexpr int kGridHi = 18;          // coarse grid 2^-18
+constexpr uint32_t kA0Bits = 0x42000000u;  // 32.0f: ulp 2^-18
+constexpr uint32_t kB0Bits = 0x39000000u;  // 2^-13: ulp 2^-36
+constexpr int kLowMassBits = 32;     // bit-masked sums below 2^32 (on the row's scale) are redone on their own scale
+// 2^(f-1) on |f| <= 1/2: the 2^30-scaled coefficients above times 2^-31 (exact)
+constexpr float kD0 = __builtin_bit_cast(float, 0x4e800000u - (31u << 23));
+constexpr float kD1 = __builtin_bit_cast(float, 0x4e317216u - (31u << 23));
+constexpr float kD2 = __builtin_bit_cast(float, 0x4d75fcd9u - (31u << 23));
+constexpr float kD3 = __builtin_bit_cast(float, 0x4c635b16u - (31u << 23));
+constexpr float kD4 = __builtin_bit_cast(float, 0x4b1e7722u - (31u << 23));
+constexpr float kD5 = __builtin_bit_cast(float, 0x49adfe07u - (31u << 23));
+
+// v_fma_f32 with the clamp modifier: result clamped to [0, 1], NaN -> 0 (DX10_CLAMP is on in HSA kernels)
+__device__ __forceinline__ float fma_clamp01(float a, float b, float c) {
+  float r;
+  asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+// t of one element against the chunk scale; magicN = kMagic - N_c (exact).  The exponent n - N_c sits in the
+// low mantissa bits of tm; out-of-range inputs (-inf, NaN, more than 2^22 binades away) end as t = 0 or as a
+// harmless finite value because P is clamped and v_ldexp_f32 saturates.
+__device__ __forceinline__ float chunk_term(float x, float magicN) {
+  const float tm = __builtin_fmaf(x, kLog2e, magicN);
+  const float negn = magicN - tm;
+  const int np = (int)(__float_as_uint(tm) - kMagicBits);
+  const float f = __builtin_fmaf(x, kLog2e, negn);
+  float p = kD5;
+  p = __builtin_fmaf(p, f, kD4);
+  p = __builtin_fmaf(p, f, kD3);
+  p = __builtin_fmaf(p, f, kD2);
+  p = __builtin_fmaf(p, f, kD1);
+  p = fma_clamp01(p, f, kD0);
+  return __builtin_amdgcn_ldexpf(p, np);
+}
+
+// the integer term itself (slow paths: draws, own-scale sums): floor(t * 2^36), t < 1
+__device__ __forceinline__ uint64_t term_q(float x, float magicN) {
+  const float t = chunk_term(x, magicN);
+  const float hi = __builtin_truncf(t * 262144.0f);             // floor(t * 2^18), exact
+  const float lo = __builtin_fmaf(hi, -0x1p-18f, t) * 0x1p36f;  // (t - hi * 2^-18) * 2^36, exact, < 2^18 (+ fraction)
+  uint32_t h, l;
+  asm("v_cvt_u32_f32 %0, %1" : "=v"(h) : "v"(hi));
+  asm("v_cvt_u32_f32 %0, %1" : "=v"(l) : "v"(lo));
+  return ((uint64_t)h << kGridHi) + l;
+}
+
+// Accumulate four terms in round-toward-zero mode: elements 0, 2 into set 0 (A0, B0), elements 1, 3 into set 1.
+// With MASKED, the lanes named by the 64-bit lane masks M0..M3 also add the same (coarse, remainder) pair into the
+// masked accumulators (exact adds on the same grids; EXEC is restored before the block ends).
+template <bool MASKED>
+__device__ __forceinline__ void rtz_acc4(float t0, float t1, float t2, float t3, float &A0, float &B0, float &A1,
+                                         float &B1, float &Am0, float &Bm0, float &Am1, float &Bm1, uint64_t M0,
+                                         uint64_t M1, uint64_t M2, uint64_t M3) {
+  float x0, x1, d0, d1, l0, l1;
+  if constexpr (MASKED) {
+    asm volatile(
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+        "v_add_f32 %8, %0, %14\n\t"
+        "v_add_f32 %9, %2, %15\n\t"
+        "v_sub_f32 %10, %8, %0\n\t"
+        "v_sub_f32 %11, %9, %2\n\t"
+        "v_sub_f32 %12, %14, %10\n\t"
+        "v_sub_f32 %13, %15, %11\n\t"
+        "v_add_f32 %1, %1, %12\n\t"
+        "v_add_f32 %3, %3, %13\n\t"
+        "s_mov_b64 exec, %18\n\t"
+        "v_add_f32 %4, %4, %10\n\t"
+        "v_add_f32 %5, %5, %12\n\t"
+        "s_mov_b64 exec, %19\n\t"
+        "v_add_f32 %6, %6, %11\n\t"
+        "v_add_f32 %7, %7, %13\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "v_add_f32 %0, %8, %16\n\t"
+        "v_add_f32 %2, %9, %17\n\t"
+        "v_sub_f32 %10, %0, %8\n\t"
+        "v_sub_f32 %11, %2, %9\n\t"
+        "v_sub_f32 %12, %16, %10\n\t"
+        "v_sub_f32 %13, %17, %11\n\t"
+        "v_add_f32 %1, %1, %12\n\t"
+        "v_add_f32 %3, %3, %13\n\t"
+        "s_mov_b64 exec, %20\n\t"
+        "v_add_f32 %4, %4, %10\n\t"
+        "v_add_f32 %5, %5, %12\n\t"
+        "s_mov_b64 exec, %21\n\t"
+        "v_add_f32 %6, %6, %11\n\t"
+        "v_add_f32 %7, %7, %13\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+        : "+v"(A0), "+v"(B0), "+v"(A1), "+v"(B1), "+v"(Am0), "+v"(Bm0), "+v"(Am1), "+v"(Bm1), "=&v"(x0), "=&v"(x1),
+          "=&v"(d0), "=&v"(d1), "=&v"(l0), "=&v"(l1)
+        : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "s"(M0), "s"(M1), "s"(M2), "s"(M3));
+  } else {
+    asm volatile(
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+        "v_add_f32 %4, %0, %10\n\t"
+        "v_add_f32 %5, %2, %11\n\t"
+        "v_sub_f32 %6, %4, %0\n\t"
+        "v_sub_f32 %7, %5, %2\n\t"
+        "v_sub_f32 %8, %10, %6\n\t"
+        "v_sub_f32 %9, %11, %7\n\t"
+        "v_add_f32 %1, %1, %8\n\t"
+        "v_add_f32 %3, %3, %9\n\t"
+        "v_add_f32 %0, %4, %12\n\t"
+        "v_add_f32 %2, %5, %13\n\t"
+        "v_sub_f32 %6, %0, %4\n\t"
+        "v_sub_f32 %7, %2, %5\n\t"
+        "v_sub_f32 %8, %12, %6\n\t"
+        "v_sub_f32 %9, %13, %7\n\t"
+        "v_add_f32 %1, %1, %8\n\t"
+        "v_add_f32 %3, %3, %9\n\t"
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+        : "+v"(A0), "+v"(B0), "+v"(A1), "+v"(B1), "=&v"(x0), "=&v"(x1), "=&v"(d0), "=&v"(d1), "=&v"(l0), "=&v"(l1)
+        : "v"(t0), "v"(t1), "v"(t2), "v"(t3));
+  }
+}
+
+// Masked (coarse, remainder) sums of four terms of ONE vector, each term split against the constant 32.0 (no running
+// accumulator: every lane may skip any element).  Am / Bm start at 32.0 / 2^-13 per vector and take at most 8 terms.
+template <bool MASKED>
+__device__ __forceinline__ void rtz_vec4(float t0, float t1, float t2, float t3, float &Am, float &Bm, uint64_t M0,
+                                         uint64_t M1, uint64_t M2, uint64_t M3) {
+  float x0, x1, d0, d1, l0, l1;
+  const float a0 = __uint_as_float(kA0Bits);
+  if constexpr (MASKED) {
+    asm volatile(
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+        "v_add_f32 %2, %8, %9\n\t"
+        "v_add_f32 %3, %8, %10\n\t"
+        "v_sub_f32 %4, %2, %8\n\t"
+        "v_sub_f32 %5, %3, %8\n\t"
+        "v_sub_f32 %6, %9, %4\n\t"
+        "v_sub_f32 %7, %10, %5\n\t"
+        "s_mov_b64 exec, %13\n\t"
+        "v_add_f32 %0, %0, %4\n\t"
+        "v_add_f32 %1, %1, %6\n\t"
+        "s_mov_b64 exec, %14\n\t"
+        "v_add_f32 %0, %0, %5\n\t"
+        "v_add_f32 %1, %1, %7\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "v_add_f32 %2, %8, %11\n\t"
+        "v_add_f32 %3, %8, %12\n\t"
+        "v_sub_f32 %4, %2, %8\n\t"
+        "v_sub_f32 %5, %3, %8\n\t"
+        "v_sub_f32 %6, %11, %4\n\t"
+        "v_sub_f32 %7, %12, %5\n\t"
+        "s_mov_b64 exec, %15\n\t"
+        "v_add_f32 %0, %0, %4\n\t"
+        "v_add_f32 %1, %1, %6\n\t"
+        "s_mov_b64 exec, %16\n\t"
+        "v_add_f32 %0, %0, %5\n\t"
+        "v_add_f32 %1, %1, %7\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+        : "+v"(Am), "+v"(Bm), "=&v"(x0), "=&v"(x1), "=&v"(d0), "=&v"(d1), "=&v"(l0), "=&v"(l1)
+        : "v"(a0), "v"(t0), "v"(t1), "v"(t2), "v"(t3), "s"(M0), "s"(M1), "s"(M2), "s"(M3));
+  } else {
+    asm volatile(
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+        "v_add_f32 %2, %8, %9\n\t"
+        "v_add_f32 %3, %8, %10\n\t"
+        "v_sub_f32 %4, %2, %8\n\t"
+        "v_sub_f32 %5, %3, %8\n\t"
+        "v_sub_f32 %6, %9, %4\n\t"
+        "v_sub_f32 %7, %10, %5\n\t"
+        "v_add_f32 %0, %0, %4\n\t"
+        "v_add_f32 %1, %1, %6\n\t"
+        "v_add_f32 %0, %0, %5\n\t"
+        "v_add_f32 %1, %1, %7\n\t"
+        "v_add_f32 %2, %8, %11\n\t"
+        "v_add_f32 %3, %8, %12\n\t"
+        "v_sub_f32 %4, %2, %8\n\t"
+        "v_sub_f32 %5, %3, %8\n\t"
+        "v_sub_f32 %6, %11, %4\n\t"
+        "v_sub_f32 %7, %12, %5\n\t"
+        "v_add_f32 %0, %0, %4\n\t"
+        "v_add_f32 %1, %1, %6\n\t"
+        "v_add_f32 %0, %0, %5\n\t"
+        "v_add_f32 %1, %1, %7\n\t"
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+        : "+v"(Am), "+v"(Bm), "=&v"(x0), "=&v"(x1), "=&v"(d0), "=&v"(d1), "=&v"(l0), "=&v"(l1)
+        : "v"(a0), "v"(t0), "v"(t1), "v"(t2), "v"(t3));
+  }
+}
+
+// zero-instruction barriers: the value is re-materialised in a VGPR here (keeps wave-uniform 64-bit compares out of
+// hipcc's scalar lowering, which loses SCC on ROCm 7.2)
+__device__ __forceinline__ void opaque_u32(uint32_t &r) { asm volatile("" : "+v"(r)); }
+
+// 32-bit wave sum by DPP; every lane of the result is NOT the total - lane 63 holds it
+__device__ __forceinline__ uint32_t wave_sum_u32_l63(uint32_t v) {
+  v += dpp_u32<0x111, 0xf>(0u, v);
+  v += dpp_u32<0x112, 0xf>(0u, v);
+  v += dpp_u32<0x114, 0xf>(0u, v);
+  v += dpp_u32<0x118, 0xf>(0u, v);
+  v += dpp_u32<0x142, 0xa>(0u, v);
+  v += dpp_u32<0x143, 0xc>(0u, v);
+  return v;
 }
 
 }  // namespace glb

@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (F32, BF16, F16, MASK_NONE, MASK_BITS, MASK_F32, RNG_NONE, RNG_PHILOX, RNG_NOISE,
+from ._lib import (F32, BF16, F16, MASK_NONE, MASK_BITS, MASK_F32, MASK_PREPARED, RNG_NONE, RNG_PHILOX, RNG_NOISE,
                    StepArgs, MT19937, check)
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
@@ -35,6 +35,13 @@ class HostRng:
         assert out.dtype == torch.float32 and out.is_contiguous() and out.device.type == "cpu"
         check(self._lib.glb_mt19937_exponential_f32(C.byref(self.state), _ptr(out), n))
         return out
+
+
+class PreparedMasks:
+    """Bit masks in the kernels' own layout (glb_mask_prepare): built once for masks that do not change."""
+
+    def __init__(self, blob, n_masks, vocab, dtype):
+        self.blob, self.n_masks, self.vocab, self.dtype = blob, n_masks, vocab, dtype
 
 
 class HipEngine:
@@ -70,12 +77,20 @@ class HipEngine:
                 raise ValueError("tensor must be contiguous")
 
     # ------------------------------------------------------------------------------------------
+    def _scratch(self, need):
+        if self._step_ws is None or self._step_ws.numel() < need:
+            self._step_ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=self.device)
+        return self._step_ws
+
     def step(self, logits, vocab=None, row_of=None, mask_kind=MASK_NONE, mask=None, mask_id=None,
              rng_mode=RNG_NONE, noise=None, seed=0, offset=0, particle_base=0, logit_scale=1.0,
-             want_lse=True, variant=0, out=None):
+             want_lse=True, variant=0, out=None, row_mask_id=None):
         """Fused particle step (glb_logprob_mask_sample).  Returns (logZ, lse, token) device tensors.
 
         logits: [n_rows, ld] (last dim contiguous; rows may be strided), vocab <= ld.
+        mask: int32 bit rows / float rows, or a `PreparedMasks` (prepare_masks).  `row_mask_id` gives the mask per
+        logits row (the mask is a function of the context): shared rows are then reduced once.
+        `variant` is accepted for source compatibility and ignored (one kernel family serves every shape).
         """
         if logits.dim() != 2 or logits.stride(1) != 1:
             raise ValueError("logits must be 2-D with unit inner stride")
@@ -85,7 +100,7 @@ class HipEngine:
         ld = logits.stride(0) if n_rows > 1 else max(width, logits.stride(0))
         V = width if vocab is None else vocab
         n = n_rows if row_of is None else row_of.numel()
-        self._check_dev(row_of, mask, mask_id, noise)
+        self._check_dev(row_of, mask_id, row_mask_id, noise)
         if out is None:
             logZ, lse, tok = self._f32(n), (self._f32(n) if want_lse else None), None
             if rng_mode != RNG_NONE:
@@ -100,17 +115,30 @@ class HipEngine:
         a.logit_scale = logit_scale
         a.n_particles = n
         a.row_of = None if row_of is None else row_of.data_ptr()
-        a.mask_kind = mask_kind
-        if mask_kind != MASK_NONE:
-            if mask.dim() != 2 or mask.stride(1) != 1:
-                raise ValueError("mask must be 2-D")
-            want = torch.float32 if mask_kind == MASK_F32 else torch.int32
-            if mask.dtype != want:
-                raise TypeError(f"mask dtype {mask.dtype}, expected {want}")
-            a.mask = mask.data_ptr()
-            a.mask_ld = mask.stride(0) if mask.shape[0] > 1 else mask.shape[1]
-            a.n_masks = mask.shape[0]
+        n_masks = 0
+        if isinstance(mask, PreparedMasks):
+            if mask.vocab != V or (mask.dtype == F32) != (_DT[logits.dtype] == F32):
+                raise ValueError("prepared masks were built for another vocabulary / element width")
+            a.mask_kind = MASK_PREPARED
+            a.mask = mask.blob.data_ptr()
+            a.mask_ld = 0
+            a.n_masks = mask.n_masks
+        else:
+            a.mask_kind = mask_kind
+            if mask_kind != MASK_NONE:
+                self._check_dev(mask)
+                if mask.dim() != 2 or mask.stride(1) != 1:
+                    raise ValueError("mask must be 2-D")
+                want = torch.float32 if mask_kind == MASK_F32 else torch.int32
+                if mask.dtype != want:
+                    raise TypeError(f"mask dtype {mask.dtype}, expected {want}")
+                a.mask = mask.data_ptr()
+                a.mask_ld = mask.stride(0) if mask.shape[0] > 1 else mask.shape[1]
+                a.n_masks = mask.shape[0]
+                n_masks = mask.shape[0] if mask_kind == MASK_BITS else 0
+        if a.mask_kind != MASK_NONE:
             a.mask_id = None if mask_id is None else mask_id.data_ptr()
+            a.row_mask_id = None if row_mask_id is None else row_mask_id.data_ptr()
         a.rng_mode = rng_mode
         if rng_mode == RNG_NOISE:
             if noise.dim() != 2 or noise.dtype != torch.float32:
@@ -121,15 +149,26 @@ class HipEngine:
         a.out_logZ = None if logZ is None else logZ.data_ptr()
         a.out_lse = None if lse is None else lse.data_ptr()
         a.out_token = None if tok is None else tok.data_ptr()
-        a.variant = max(variant, 0)  # variant -1: auto geometry of the one-workgroup-per-particle kernel
-        if variant == 0 or variant >= 21:  # lend scratch: enables the persistent pipelined kernel
-            need = self.lib.glb_step_workspace_bytes(n)
-            if self._step_ws is None or self._step_ws.numel() < need:
-                self._step_ws = torch.zeros(max(need, 1 << 20), dtype=torch.uint8, device=self.device)  # scratch of the persistent kernel
-            a.workspace = self._step_ws.data_ptr()
-            a.workspace_bytes = self._step_ws.numel()
+        ws = self._scratch(self.lib.glb_step_workspace_bytes(n, n_rows, V, n_masks))
+        a.workspace = ws.data_ptr()
+        a.workspace_bytes = ws.numel()
         check(self.lib.glb_logprob_mask_sample(C.byref(a), self._stream()))
         return logZ, lse, tok
+
+    def prepare_masks(self, bits, vocab, logits_dtype=torch.float32):
+        """int32 bit rows [K, >= ceil(V/32)] -> `PreparedMasks` for logits of `logits_dtype` (glb_mask_prepare)."""
+        if bits.dim() == 1:
+            bits = bits[None]
+        self._check_dev(bits)
+        if bits.dtype != torch.int32:
+            raise TypeError("bit masks must be int32 words")
+        K = bits.shape[0]
+        need = self.lib.glb_mask_prepared_bytes(K, vocab)
+        blob = torch.empty(need, dtype=torch.uint8, device=self.device)
+        dt = _DT[logits_dtype]
+        check(self.lib.glb_mask_prepare(_ptr(bits), K, vocab, bits.stride(0) if K > 1 else bits.shape[1], dt,
+                                        _ptr(blob), need, self._stream()))
+        return PreparedMasks(blob, K, vocab, dt)
 
     def log_softmax_rows(self, logits, vocab=None, logit_scale=1.0, out=None, want_lse=False):
         """out[r] = logits[r] - logsumexp(logits[r]) (glb_log_softmax_rows); float32 result."""
@@ -142,8 +181,9 @@ class HipEngine:
             out = torch.empty((n_rows, V), dtype=torch.float32, device=self.device)
         lse = self._f32(n_rows) if want_lse else None
         out_ld = out.stride(0) if n_rows > 1 else max(V, out.stride(0))
-        check(self.lib.glb_log_softmax_rows(_ptr(logits), _DT[logits.dtype], n_rows, V, ld,
-                                            logit_scale, _ptr(out), out_ld, _ptr(lse), self._stream()))
+        ws = self._scratch(self.lib.glb_log_softmax_workspace_bytes(n_rows, V))
+        check(self.lib.glb_log_softmax_rows(_ptr(logits), _DT[logits.dtype], n_rows, V, ld, logit_scale, _ptr(out),
+                                            out_ld, _ptr(lse), _ptr(ws), ws.numel(), self._stream()))
         return (out, lse) if want_lse else out
 
     def mask_to_bits(self, mask):

@@ -12,10 +12,10 @@
  * Each entry point cites the reference (genlm/genlm-backend) code it replaces; paths are
  * relative to the reference checkout.
  *
- * Arithmetic contract ("GLB math"): sums of exponentials are accumulated in
- * 64-bit fixed point from a correctly-rounded-FMA polynomial exp, so logZ / lse / sampled token
- * are bit-identical for any launch geometry, GPU count or row split, and are restated
- * bit-for-bit by oracle/glb_oracle.c.
+ * Arithmetic contract ("GLB math"): a logits row is a sequence of 4096-element chunks, each
+ * with its own binary scale; sums of exponentials are exact integer sums of floor(t * 2^36) terms from a
+ * correctly-rounded-FMA polynomial exp, so logZ / lse / sampled token are bit-identical for any launch
+ * geometry, GPU count or particle split, and are restated bit-for-bit by oracle/glb_oracle.c.
  */
 #ifndef GLB_H
 #define GLB_H
@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GLB_ABI_VERSION 1
+#define GLB_ABI_VERSION 2
 
 /* status codes */
 enum {
@@ -46,7 +46,10 @@ enum {
   GLB_MASK_NONE = 0, /* no mask: logZ == 0 up to rounding, sample from the full distribution      */
   GLB_MASK_BITS = 1, /* table [n_masks, mask_ld] of uint32 words, bit j%32 of word j/32 == 1 ⇔
                         token j allowed (log-mask 0), 0 ⇔ forbidden (log-mask -inf)                */
-  GLB_MASK_F32 = 2   /* table [n_masks, mask_ld] of float additive log-masks (any value, -inf ok) */
+  GLB_MASK_F32 = 2,  /* table [n_masks, mask_ld] of float additive log-masks (any value, -inf ok) */
+  GLB_MASK_PREPARED = 3 /* bit masks already brought into the kernels' layout by glb_mask_prepare (same
+                        meaning as GLB_MASK_BITS; saves one small launch per call for masks that are
+                        built once, like the two README masks)                                     */
 };
 
 /* RNG modes of the categorical draw */
@@ -74,7 +77,9 @@ int glb_device_count(void);
  *     token  = multinomial((masked - logZ).exp(), 1)        README.md:87   (base.py:136-141 with
  *                                                           logit_scale = 1/temperature)
  * in one pass over the logits row.  Particle i reads row row_of[i] (dedup fan-out of
- * hf.py:214-220,285-288) and mask row mask_id[i].
+ * hf.py:214-220,285-288) and mask row mask_id[i].  When the mask is a function of the context - as in
+ * the README, where it depends on len(context) only - pass the ids per logits ROW (row_mask_id) instead:
+ * a row shared by several particles is then reduced once and only the draw is done per particle.
  */
 typedef struct glb_step_args {
   uint32_t struct_size; /* sizeof(glb_step_args) — ABI guard */
@@ -95,6 +100,8 @@ typedef struct glb_step_args {
   int64_t n_masks;
   const int32_t *mask_id; /* [n_particles] device, nullable ⇒ identity (needs n_masks == n_particles)
                              or, when n_masks == 1, everybody uses mask 0 */
+  const int32_t *row_mask_id; /* [n_rows] device, nullable: mask ids per logits row instead of per particle
+                             (exclusive with mask_id); null ids ⇒ identity over rows / mask 0 as above */
   /* rng */
   int32_t rng_mode;
   const float *noise; /* GLB_RNG_NOISE: [n_particles, noise_ld] device */
@@ -106,25 +113,37 @@ typedef struct glb_step_args {
   float *out_logZ;   /* [n_particles] logsumexp(log_softmax(x)+mask) */
   float *out_lse;    /* [n_particles] logsumexp(x) of the particle's row */
   int32_t *out_token;/* [n_particles] sampled id, -1 when every token is masked out */
-  int32_t variant;   /* 0 = auto; otherwise forces a launch geometry (tuning / tests) */
-  /* optional device scratch of >= glb_step_workspace_bytes(n_particles) bytes (16-byte aligned).  With it
-     (and mask none/bits, rng none/philox) the persistent pipelined kernel is used; without it the
-     one-workgroup-per-particle kernel.  Results are bit-identical either way. */
+  int32_t reserved;  /* must be 0 */
+  /* device scratch of >= glb_step_workspace_bytes(...) bytes, 32-byte aligned: the per-chunk records the
+     reduction kernel hands to the per-particle kernel (and, for GLB_MASK_BITS, the prepared masks) */
   void *workspace;
   size_t workspace_bytes;
 } glb_step_args;
 
-size_t glb_step_workspace_bytes(int64_t n_particles);
+size_t glb_step_workspace_bytes(int64_t n_particles, int64_t n_rows, int64_t vocab, int64_t n_masks);
 int glb_logprob_mask_sample(const glb_step_args *args, void *hip_stream);
+
+/*
+ * Bring GLB_MASK_BITS rows into the layout the kernels read ([mask][chunk][vector][component] 64-bit lane
+ * words + a short id list for masks that allow at most 63 tokens, e.g. the README's EOS-only mask,
+ * README.md:62-66) once, for masks that do not change between steps.  `dtype` is the element type of the
+ * logits the masks will be used with (the lane layout differs between 4- and 2-byte elements).  Pass the
+ * result as `mask` with mask_kind = GLB_MASK_PREPARED and the same n_masks / vocab.
+ */
+size_t glb_mask_prepared_bytes(int64_t n_masks, int64_t vocab);
+int glb_mask_prepare(const uint32_t *mask_bits, int64_t n_masks, int64_t vocab, int64_t mask_ld, int32_t dtype,
+                     void *out_prepared, size_t out_bytes, void *hip_stream);
 
 /*
  * Materialise log-probabilities: out[r, j] = x[r, j] - logsumexp(x[r, :]).  Replaces the
  * per-position torch.log_softmax of TokenTrie.extend_cache (cache.py:93-98) and
- * next_token_logprobs_uncached (hf.py:422).  out_lse is optional.
+ * next_token_logprobs_uncached (hf.py:422).  out_lse is optional.  workspace: device scratch of at least
+ * glb_log_softmax_workspace_bytes(n_rows, vocab) bytes, 32-byte aligned.
  */
+size_t glb_log_softmax_workspace_bytes(int64_t n_rows, int64_t vocab);
 int glb_log_softmax_rows(const void *logits, int32_t dtype, int64_t n_rows, int64_t vocab,
                          int64_t ld, float logit_scale, float *out_logprobs, int64_t out_ld,
-                         float *out_lse, void *hip_stream);
+                         float *out_lse, void *workspace, size_t workspace_bytes, void *hip_stream);
 
 /*
  * Convert {0,-inf}-style float log-masks (README.md:60-66, `.log()` of a 0/1 tensor) to the

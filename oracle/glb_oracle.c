@@ -174,15 +174,87 @@ static uint64_t mulhi64(uint64_t a, uint64_t b) {
   return (uint64_t)(((unsigned __int128)a * b) >> 64);
 }
 
-/* per-row scratch of layer B */
-typedef struct {
-  float m_all, m_mask;     /* maxima (order independent) */
-  float N_all, N_mask;     /* rint(m*log2e) */
-  uint64_t S_all, S_mask;  /* fixed-point sums */
-} row_stats;
-
 static int mask_allows(const uint32_t *bits, int64_t j) {
   return (int)((bits[j >> 5] >> (j & 31)) & 1u);
+}
+
+/* ---------------------------------------------------------------- chunked contract of the particle step
+ *
+ * (device side: genlm-backend_amd/csrc/glb_math.hpp "chunk_term" and glb_chunk.hpp.)
+ * A row is cut into chunks of 4096 elements by vocabulary index.  Chunk c has its own binary scale
+ * N_c = glb_exp_n(max of the chunk).  Every element gives
+ *     t = ldexpf(P, n - N_c)     P = 2^(f-1) by the degree-5 Horner polynomial (coefficients of GLB_EXP_C times
+ *                                2^-31), clamped to [0, 1] with NaN -> 0
+ *     q = floor(t * 2^36)
+ * S_c = sum of q over the chunk, S_c^m = sum over the allowed elements.  The row scale is N = max N_c over the
+ * chunks with a non-zero sum, and the row sums are S = sum_c (S_c >> (N - N_c)).  sum_j e^(x_j) = 2^(N+1-36) S.
+ */
+#define GLB_CHUNK 4096
+#define GLB_FRAC 36
+#define GLB_LOW_MASS_BITS 32 /* bit-masked sums below 2^32 on the row's scale are redone on their own scale */
+
+static float glb_chunk_term(float x, float magicN) {
+  float tm = fmaf(x, GLB_LOG2E, magicN);
+  float negn = magicN - tm;
+  uint32_t tb;
+  memcpy(&tb, &tm, 4);
+  int32_t np = (int32_t)(tb - 0x4B400000u);
+  float f = fmaf(x, GLB_LOG2E, negn);
+  float p = u2f(GLB_EXP_C[5] - (31u << 23));
+  p = fmaf(p, f, u2f(GLB_EXP_C[4] - (31u << 23)));
+  p = fmaf(p, f, u2f(GLB_EXP_C[3] - (31u << 23)));
+  p = fmaf(p, f, u2f(GLB_EXP_C[2] - (31u << 23)));
+  p = fmaf(p, f, u2f(GLB_EXP_C[1] - (31u << 23)));
+  p = fmaf(p, f, u2f(GLB_EXP_C[0] - (31u << 23)));
+  if (!(p > 0.0f)) p = 0.0f; /* clamp modifier: NaN and negatives -> 0 */
+  if (p > 1.0f) p = 1.0f;
+  if (np < -300) np = -300; /* ldexpf takes any int; keep it in range for the libm call (result is 0 either way) */
+  if (np > 300) np = 300;
+  return ldexpf(p, np);
+}
+
+static uint64_t glb_term_q(float x, float magicN) {
+  float t = glb_chunk_term(x, magicN);
+  if (!(t > 0.0f)) return 0;
+  if (t >= 1.0f) t = 1.0f; /* never for in-range inputs */
+  return (uint64_t)floor(ldexp((double)t, GLB_FRAC));
+}
+
+typedef struct {
+  float N;      /* chunk scale (or -inf) */
+  uint64_t S;   /* chunk sum */
+} chunk_stat;
+
+/* statistics of y[0..V) by chunks; returns the number of chunks */
+static int64_t glb_chunk_stats(const float *y, int64_t V, chunk_stat *out) {
+  int64_t nch = (V + GLB_CHUNK - 1) / GLB_CHUNK;
+  for (int64_t c = 0; c < nch; ++c) {
+    int64_t lo = c * GLB_CHUNK, hi = lo + GLB_CHUNK < V ? lo + GLB_CHUNK : V;
+    float m = -INFINITY;
+    for (int64_t j = lo; j < hi; ++j)
+      if (y[j] > m) m = y[j];
+    out[c].N = glb_exp_n(m);
+    out[c].S = 0;
+    float magicN = GLB_MAGIC - out[c].N;
+    for (int64_t j = lo; j < hi; ++j) out[c].S += glb_term_q(y[j], magicN);
+  }
+  return nch;
+}
+
+/* bit-masked sums on the chunk scales of x: same terms, allowed elements only */
+static void glb_chunk_masked(const float *x, const uint32_t *mb, int64_t V, const chunk_stat *cs, uint64_t *Sm) {
+  int64_t nch = (V + GLB_CHUNK - 1) / GLB_CHUNK;
+  for (int64_t c = 0; c < nch; ++c) {
+    int64_t lo = c * GLB_CHUNK, hi = lo + GLB_CHUNK < V ? lo + GLB_CHUNK : V;
+    float magicN = GLB_MAGIC - cs[c].N;
+    Sm[c] = 0;
+    for (int64_t j = lo; j < hi; ++j)
+      if (mask_allows(mb, j)) Sm[c] += glb_term_q(x[j], magicN);
+  }
+}
+
+static uint64_t shr_sat(uint64_t v, float d) { /* d >= 0, integer valued */
+  return d < 64.0f ? v >> (uint32_t)d : 0;
 }
 
 /*
@@ -194,58 +266,80 @@ int orc_step(const void *logits, int dtype, int64_t n_rows, int64_t V, int64_t l
              const void *mask, int64_t mask_ld, int64_t n_masks, const int32_t *mask_id,
              int rng_mode, const float *noise, int64_t noise_ld, uint64_t seed, uint64_t offset,
              int64_t particle_base, float *out_logZ, float *out_lse, int32_t *out_token) {
+  int64_t nch = (V + GLB_CHUNK - 1) / GLB_CHUNK;
   float *x = (float *)malloc(sizeof(float) * (size_t)V);
   float *y = (float *)malloc(sizeof(float) * (size_t)V);
-  if (!x || !y) return 4;
+  chunk_stat *ca = (chunk_stat *)malloc(sizeof(chunk_stat) * (size_t)nch);
+  chunk_stat *cm = (chunk_stat *)malloc(sizeof(chunk_stat) * (size_t)nch);
+  uint64_t *Sm = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)nch);
+  if (!x || !y || !ca || !cm || !Sm) return 4;
   for (int64_t i = 0; i < n_particles; ++i) {
     int64_t r = row_of ? row_of[i] : i;
-    if (r < 0 || r >= n_rows) { free(x); free(y); return 1; }
+    if (r < 0 || r >= n_rows) { free(x); free(y); free(ca); free(cm); free(Sm); return 1; }
     int64_t mi = 0;
     if (mask_kind != ORC_MASK_NONE) mi = mask_id ? mask_id[i] : (n_masks == 1 ? 0 : i);
     const uint32_t *mb = mask_kind == ORC_MASK_BITS ? (const uint32_t *)mask + mi * mask_ld : NULL;
     const float *mf = mask_kind == ORC_MASK_F32 ? (const float *)mask + mi * mask_ld : NULL;
-    row_stats st;
-    st.m_all = -INFINITY;
-    st.m_mask = -INFINITY;
     for (int64_t j = 0; j < V; ++j) {
       float v = load_elem(logits, dtype, r * ld + j);
-      if (logit_scale != 1.0f) v = v * logit_scale;
+      v = v * logit_scale; /* x * 1.0f == x exactly */
       x[j] = v;
       float vm = v;
       if (mb) vm = mask_allows(mb, j) ? v : -INFINITY;
       if (mf) vm = v + mf[j];
       y[j] = vm;
-      if (v > st.m_all) st.m_all = v;
-      if (vm > st.m_mask) st.m_mask = vm;
     }
-    st.N_all = glb_exp_n(st.m_all);
-    const float N_k = glb_exp_n(st.m_mask); /* exponent of the masked maximum (race scale) */
-    st.S_all = 0;
-    for (int64_t j = 0; j < V; ++j) st.S_all += glb_fix_term(x[j], st.N_all);
-    /* Masked sum: on the row's scale N_all (one exponential per element serves both sums) when the
-       masked maximum does not exceed it and the result keeps >= 37 bits; otherwise on the masked
-       maximum's own scale N_k. */
-    st.N_mask = N_k;
-    st.S_mask = 0;
-    int own_scale = 1;
-    if (N_k <= st.N_all) {
-      uint64_t S_c = 0;
-      for (int64_t j = 0; j < V; ++j) S_c += glb_fix_term(y[j], st.N_all);
-      if (S_c >= GLB_LOW_MASS) {
-        st.S_mask = S_c;
-        st.N_mask = st.N_all;
-        own_scale = 0;
+    /* ---- all elements */
+    glb_chunk_stats(x, V, ca);
+    float N_all = -INFINITY;
+    for (int64_t c = 0; c < nch; ++c)
+      if (ca[c].S && ca[c].N > N_all) N_all = ca[c].N;
+    uint64_t S_all = 0;
+    for (int64_t c = 0; c < nch; ++c)
+      if (ca[c].S) S_all += shr_sat(ca[c].S, N_all - ca[c].N);
+    /* ---- allowed elements.  Bit masks: the same terms on the chunk scales of x (so one exponential per element
+     * serves both sums), unless that leaves the row-level sum below 2^32 (allowed mass under about 2^-4 of the
+     * row's largest term): then the masked values are summed on the masked maximum's own row scale.  Float
+     * masks: y = x + m has chunk scales of its own.  cm[c] holds the masked chunk (scale, sum) either way. */
+    float N_msk = N_all;
+    uint64_t S_msk = S_all;
+    int own = 0;
+    if (mb) {
+      glb_chunk_masked(x, mb, V, ca, Sm);
+      S_msk = 0;
+      for (int64_t c = 0; c < nch; ++c) {
+        cm[c].N = ca[c].N;
+        cm[c].S = Sm[c];
+        if (Sm[c]) S_msk += shr_sat(Sm[c], N_all - ca[c].N);
       }
+      if ((S_msk >> GLB_LOW_MASS_BITS) == 0) {
+        own = 1;
+        float mk = -INFINITY;
+        for (int64_t j = 0; j < V; ++j)
+          if (y[j] > mk) mk = y[j];
+        N_msk = glb_exp_n(mk);
+        S_msk = 0;
+        if (mk > -INFINITY)
+          for (int64_t j = 0; j < V; ++j) S_msk += glb_term_q(y[j], GLB_MAGIC - N_msk);
+      }
+    } else if (mf) {
+      glb_chunk_stats(y, V, cm);
+      N_msk = -INFINITY;
+      for (int64_t c = 0; c < nch; ++c)
+        if (cm[c].S && cm[c].N > N_msk) N_msk = cm[c].N;
+      S_msk = 0;
+      for (int64_t c = 0; c < nch; ++c)
+        if (cm[c].S) S_msk += shr_sat(cm[c].S, N_msk - cm[c].N);
+    } else {
+      for (int64_t c = 0; c < nch; ++c) cm[c] = ca[c];
     }
-    if (own_scale)
-      for (int64_t j = 0; j < V; ++j) st.S_mask += glb_fix_term(y[j], st.N_mask);
-    double lse_all = st.S_all ? glb_log_fix(st.S_all, (int32_t)st.N_all - GLB_FIX_FRAC) : -INFINITY;
-    double lse_mask = st.S_mask ? glb_log_fix(st.S_mask, (int32_t)st.N_mask - GLB_FIX_FRAC) : -INFINITY;
+    double lse_all = S_all ? glb_log_fix(S_all, (int32_t)N_all + 1 - GLB_FRAC) : -INFINITY;
+    double lse_mask = S_msk ? glb_log_fix(S_msk, (int32_t)N_msk + 1 - GLB_FRAC) : -INFINITY;
     if (out_lse) out_lse[i] = (float)lse_all;
     if (out_logZ) out_logZ[i] = (float)(lse_mask - lse_all);
     if (rng_mode == ORC_RNG_NONE || !out_token) continue;
     int32_t tok = -1;
-    if (st.S_mask != 0) {
+    if (S_msk != 0) {
       if (rng_mode == ORC_RNG_PHILOX) {
         uint64_t gp = (uint64_t)(particle_base + i);
         uint32_t ctr[4] = {(uint32_t)gp, (uint32_t)(gp >> 32), (uint32_t)offset,
@@ -253,21 +347,36 @@ int orc_step(const void *logits, int dtype, int64_t n_rows, int64_t V, int64_t l
         uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, rnd[4];
         orc_philox4x32_10(ctr, key, rnd);
         uint64_t R = ((uint64_t)rnd[1] << 32) | rnd[0];
-        uint64_t T = mulhi64(R, st.S_mask); /* uniform integer in [0, S_mask) */
-        uint64_t c = 0;
-        for (int64_t j = 0; j < V; ++j) {
-          c += glb_fix_term(y[j], st.N_mask);
-          if (c > T) { tok = (int32_t)j; break; }
+        uint64_t T = mulhi64(R, S_msk); /* uniform integer in [0, S_msk) */
+        if (own) { /* one scale for the whole row: plain inverse CDF in vocabulary order */
+          uint64_t c = 0;
+          for (int64_t j = 0; j < V; ++j) {
+            c += glb_term_q(y[j], GLB_MAGIC - N_msk);
+            if (c > T) { tok = (int32_t)j; break; }
+          }
+        } else { /* chunk by the shifted chunk sums, then the target moves onto the chunk's own scale */
+          for (int64_t c = 0; c < nch && tok < 0; ++c) {
+            if (!cm[c].S) continue;
+            float d = N_msk - cm[c].N;
+            uint64_t sm = shr_sat(cm[c].S, d);
+            if (T < sm) {
+              uint64_t Tc = T << (uint32_t)d, acc = 0;
+              int64_t lo = c * GLB_CHUNK, hi = lo + GLB_CHUNK < V ? lo + GLB_CHUNK : V;
+              for (int64_t j = lo; j < hi; ++j) {
+                acc += glb_term_q(y[j], GLB_MAGIC - cm[c].N);
+                if (acc > Tc) { tok = (int32_t)j; break; }
+              }
+              break;
+            }
+            T -= sm;
+          }
         }
-      } else { /* exponential race against caller noise: first argmax of e_j / E_j */
+      } else { /* exponential race against caller noise: first maximum of e_j / E_j, e_j on the masked row scale */
         const float *E = noise + i * noise_ld;
         float best = -1.0f;
         for (int64_t j = 0; j < V; ++j) {
           if (!(y[j] > -INFINITY)) continue;
-          float nf, P;
-          glb_exp_parts(y[j], &nf, &P);
-          float df = nf - N_k; /* <= 0, integer valued */
-          float e = (df < -100.0f) ? 0.0f : ldexpf(P, (int)df - 30);
+          float e = glb_chunk_term(y[j], GLB_MAGIC - N_msk);
           float g = e / E[j];
           if (g > best) { best = g; tok = (int32_t)j; }
         }
@@ -275,37 +384,32 @@ int orc_step(const void *logits, int dtype, int64_t n_rows, int64_t V, int64_t l
     }
     out_token[i] = tok;
   }
-  free(x);
-  free(y);
+  free(x); free(y); free(ca); free(cm); free(Sm);
   return 0;
 }
 
-/* contract of glb_log_softmax_rows: out = x - (float)lse, lse from the fixed-point sum */
+/* contract of glb_log_softmax_rows: out = x - (float)lse, lse from the chunked integer sums */
 int orc_log_softmax_rows(const void *logits, int dtype, int64_t n_rows, int64_t V, int64_t ld,
                          float logit_scale, float *out, int64_t out_ld, float *out_lse) {
+  int64_t nch = (V + GLB_CHUNK - 1) / GLB_CHUNK;
+  float *x = (float *)malloc(sizeof(float) * (size_t)V);
+  chunk_stat *ca = (chunk_stat *)malloc(sizeof(chunk_stat) * (size_t)nch);
+  if (!x || !ca) return 4;
   for (int64_t r = 0; r < n_rows; ++r) {
-    float m = -INFINITY;
-    for (int64_t j = 0; j < V; ++j) {
-      float v = load_elem(logits, dtype, r * ld + j);
-      if (logit_scale != 1.0f) v = v * logit_scale;
-      if (v > m) m = v;
-    }
-    float N = glb_exp_n(m);
+    for (int64_t j = 0; j < V; ++j) x[j] = load_elem(logits, dtype, r * ld + j) * logit_scale;
+    glb_chunk_stats(x, V, ca);
+    float N = -INFINITY;
+    for (int64_t c = 0; c < nch; ++c)
+      if (ca[c].S && ca[c].N > N) N = ca[c].N;
     uint64_t S = 0;
-    for (int64_t j = 0; j < V; ++j) {
-      float v = load_elem(logits, dtype, r * ld + j);
-      if (logit_scale != 1.0f) v = v * logit_scale;
-      S += glb_fix_term(v, N);
-    }
-    float lse = S ? (float)glb_log_fix(S, (int32_t)N - GLB_FIX_FRAC) : -INFINITY;
+    for (int64_t c = 0; c < nch; ++c)
+      if (ca[c].S) S += shr_sat(ca[c].S, N - ca[c].N);
+    float lse = S ? (float)glb_log_fix(S, (int32_t)N + 1 - GLB_FRAC) : -INFINITY;
     if (out_lse) out_lse[r] = lse;
     if (out)
-      for (int64_t j = 0; j < V; ++j) {
-        float v = load_elem(logits, dtype, r * ld + j);
-        if (logit_scale != 1.0f) v = v * logit_scale;
-        out[r * out_ld + j] = v - lse;
-      }
+      for (int64_t j = 0; j < V; ++j) out[r * out_ld + j] = x[j] - lse;
   }
+  free(x); free(ca);
   return 0;
 }
 

@@ -22,9 +22,9 @@ def test_library_exports_every_declared_symbol():
     raw = C.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert lib.glb_abi_version() == 1
+    assert lib.glb_abi_version() == 2
     assert b"gfx950" in lib.glb_version()
-    assert C.sizeof(_lib.StepArgs) == 208  # layout guard of glb_step_args
+    assert C.sizeof(_lib.StepArgs) == 216  # layout guard of glb_step_args
 
 
 def test_argument_errors_do_not_touch_the_gpu():
@@ -37,7 +37,11 @@ def test_argument_errors_do_not_touch_the_gpu():
     assert "struct_size" in _lib.last_error()
     a.struct_size = C.sizeof(_lib.StepArgs)
     assert lib.glb_logprob_mask_sample(C.byref(a), None) == _lib.GLB_EINVAL
-    assert lib.glb_log_softmax_rows(None, 0, 1, 1, 1, 1.0, None, 0, None, None) == _lib.GLB_EINVAL
+    assert lib.glb_log_softmax_rows(None, 0, 1, 1, 1, 1.0, None, 0, None, None, 0, None) == _lib.GLB_EINVAL
+    assert lib.glb_mask_prepare(None, 1, 64, 2, 0, None, 0, None) == _lib.GLB_EINVAL
+    assert lib.glb_step_workspace_bytes(1024, 1024, 50257, 2) >= 1024 * 13 * 32
+    assert lib.glb_mask_prepared_bytes(2, 50257) >= 2 * 13 * 512
+    assert lib.glb_log_softmax_workspace_bytes(8, 50257) >= 8 * 13 * 32
     assert lib.glb_group_contexts(None, None, None, 4, None, None, None, None, 0, None) == _lib.GLB_EINVAL
     assert lib.glb_group_contexts_workspace(1024) >= 1024 * 4 * 4
 

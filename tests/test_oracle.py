@@ -59,10 +59,13 @@ def test_layer_b_step_matches_torch_goldens(oracle, tag):
     lp, _ = O.log_softmax_rows(x_in)
     assert np.abs(lp[:, :64] - G[f"{tag}::lp32_head"]).max() < TOL
     assert np.abs(lp.astype(np.float64).sum(-1) - G[f"{tag}::lp32_rowsum"]).max() / V < 1e-5
-    # same masks as additive float rows give bit-identical results
+    # same masks as additive float rows: the masked sums are taken on scales of their own (float masks can raise
+    # values, bit masks only gate terms), so logZ agrees to rounding and the race picks the same tokens
     logZ2, _, tok2 = O.step(x_in, mask_kind=O.MASK_F32, mask=masks, mask_id=mid, rng_mode=O.RNG_NOISE,
                             noise=E.reshape(B, V))
-    assert np.array_equal(logZ, logZ2) and np.array_equal(tok, tok2)
+    fin = np.isfinite(logZ)
+    assert np.array_equal(fin, np.isfinite(logZ2)) and np.abs(logZ[fin] - logZ2[fin]).max() < 2e-6
+    assert np.array_equal(tok, tok2)
 
 
 def test_16bit_tokens_match_torch_on_upcast_logits(oracle):

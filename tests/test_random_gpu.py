@@ -1,5 +1,6 @@
 """Randomised parity sweep of the fused step (HIP through the C ABI vs the oracle, bit for bit): odd vocabulary
-sizes down to 1, padded and misaligned rows, every element type, mask kind, draw mode and kernel family."""
+sizes down to 1, padded and misaligned rows, every element type, mask kind, draw mode and mask hand-over form
+(bit rows per particle, prepared masks, mask ids per logits row = shared rows reduced once)."""
 import numpy as np
 import pytest
 import torch
@@ -9,7 +10,6 @@ from tests import synth
 pytestmark = pytest.mark.gpu
 
 V_POOL = [1, 2, 3, 5, 31, 32, 33, 127, 255, 1000, 4097, 8191, 16380, 16381, 32765, 32769, 50257, 65528, 65529, 70001]
-GEOM_CAP = {24: 4096, 22: 8192, 21: 12800, 23: 16384, 25: 20480}  # 16-byte vectors per row
 
 
 def _case(rng):
@@ -26,21 +26,16 @@ def _case(rng):
     rng_mode = str(rng.choice(["philox", "philox", "none", "noise"]))
     if rng_mode == "noise" and N * V > 400_000:
         rng_mode = "philox"
-    epv = 4 if dtype == "f32" else 8
-    nv = (V + 2 * (epv - 1)) // epv
-    variants = [0, -1]
-    if mask_kind != "f32" and rng_mode != "noise":
-        variants += [99] + [g for g, cap in GEOM_CAP.items() if cap >= nv]
-    variant = int(rng.choice(variants))
+    form = str(rng.choice(["particle", "prepared", "by_row"]))
     scale = float(rng.choice([1.0, 1.0, 0.5, 1.7]))
-    return dict(V=V, dtype=dtype, U=U, N=N, pad=pad, off=off, mask_kind=mask_kind, rng_mode=rng_mode, variant=variant,
+    return dict(V=V, dtype=dtype, U=U, N=N, pad=pad, off=off, mask_kind=mask_kind, rng_mode=rng_mode, form=form,
                 scale=scale, seed=int(rng.integers(0, 2**31)), K=int(rng.integers(1, 5)))
 
 
-CASES = [_case(np.random.default_rng(1000 + i)) for i in range(64)]
+CASES = [_case(np.random.default_rng(1000 + i)) for i in range(96)]
 
 
-@pytest.mark.parametrize("c", CASES, ids=lambda c: f"V{c['V']}-{c['dtype']}-N{c['N']}-{c['mask_kind']}-{c['rng_mode']}-v{c['variant']}")
+@pytest.mark.parametrize("c", CASES, ids=lambda c: f"V{c['V']}-{c['dtype']}-N{c['N']}-{c['mask_kind']}-{c['rng_mode']}-{c['form']}")
 def test_random_case(engine, oracle, c):
     O = oracle
     dev = engine.device
@@ -70,16 +65,27 @@ def test_random_case(engine, oracle, c):
             masks[K - 1, :] = -np.inf
             masks[K - 1, rs.integers(0, V, max(1, V // 500))] = 0.0  # nearly everything forbidden: low allowed mass
         mid = rs.integers(0, K, N).astype(np.int32)
+        by_row = c["form"] == "by_row"
+        if by_row:  # the mask is a function of the row: ids handed over per row, shared rows reduced once
+            mid_row = rs.integers(0, K, U).astype(np.int32)
+            mid = mid_row[row_of] if row_of is not None else mid_row[:N]
+            ids_g = dict(row_mask_id=torch.from_numpy(mid_row).to(dev))
+        else:
+            ids_g = dict(mask_id=torch.from_numpy(mid).to(dev))
         if c["mask_kind"] == "bits":
             bits, _ = O.mask_f32_to_bits(masks)
             kw_o = dict(mask_kind=O.MASK_BITS, mask=bits, mask_id=mid)
-            kw_g = dict(mask_kind=1, mask=torch.from_numpy(bits.view(np.int32)).to(dev), mask_id=torch.from_numpy(mid).to(dev))
+            bits_d = torch.from_numpy(bits.view(np.int32)).to(dev)
+            if c["form"] == "prepared":
+                kw_g = dict(mask=engine.prepare_masks(bits_d, V, tdt), **ids_g)
+            else:
+                kw_g = dict(mask_kind=1, mask=bits_d, **ids_g)
         else:
             mf = masks.copy()
             fin = np.isfinite(mf)
             mf[fin] = rs.standard_normal(int(fin.sum())).astype(np.float32) * 2.0  # additive, some positive
             kw_o = dict(mask_kind=O.MASK_F32, mask=mf, mask_id=mid)
-            kw_g = dict(mask_kind=2, mask=torch.from_numpy(mf).to(dev), mask_id=torch.from_numpy(mid).to(dev))
+            kw_g = dict(mask_kind=2, mask=torch.from_numpy(mf).to(dev), **ids_g)
     mode = {"none": O.RNG_NONE, "philox": O.RNG_PHILOX, "noise": O.RNG_NOISE}[c["rng_mode"]]
     if c["rng_mode"] == "noise":
         E, _ = O.mt_exponential(c["seed"] % 1000, N * V)
@@ -91,15 +97,7 @@ def test_random_case(engine, oracle, c):
                                   logit_scale=c["scale"], n_particles=N if row_of is None else None, **kw_o)
     call = lambda: engine.step(x_d, vocab=V, row_of=None if row_of is None else torch.from_numpy(row_of).to(dev),
                                rng_mode={"none": 0, "philox": 1, "noise": 2}[c["rng_mode"]], seed=seed, offset=offset,
-                               particle_base=base, logit_scale=c["scale"], variant=c["variant"], **kw_g)
-    epv = 4 if c["dtype"] == "f32" else 8
-    if (c["mask_kind"] == "f32" or c["rng_mode"] == "noise") and (V + 2 * (epv - 1)) // epv > 16384:
-        # additive float masks and parity-noise draws exist only in the register-resident one-workgroup-per-particle
-        # kernel: longer rows are refused loudly (GLB_EUNSUPPORTED), never computed some other way
-        from genlm_backend_amd._lib import GlbError
-        with pytest.raises(GlbError):
-            call()
-        return
+                               particle_base=base, logit_scale=c["scale"], **kw_g)
     logZ, lse, tok = call()
     torch.cuda.synchronize()
     got_logZ, got_lse = logZ.cpu().numpy(), lse.cpu().numpy()

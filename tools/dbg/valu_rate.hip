@@ -17,7 +17,7 @@
                    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7),         \
                      "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3)          \
                    : "v"(sh)                                                                                \
-                   : "vcc");                                                                                \
+                   : "vcc", "s10", "s11");                                                                                \
     }                                                                                                       \
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();                                             \
     if ((threadIdx.x & 63) == 0) out[threadIdx.x >> 6] = t1 - t0;                                           \
@@ -76,8 +76,20 @@ BENCH(fma_f64, "v_fma_f64 %8, %8, %9, %10\n v_fma_f64 %9, %9, %10, %11\n v_fma_f
 BENCH(cvt_f64_u32, "v_cvt_f64_u32 %8, %0\n v_cvt_f64_u32 %9, %1\n v_cvt_f64_u32 %10, %2\n v_cvt_f64_u32 %11, %3\n")
 BENCH(mul_f64, "v_mul_f64 %8, %8, %9\n v_mul_f64 %9, %9, %10\n v_mul_f64 %10, %10, %11\n v_mul_f64 %11, %11, %8\n")
 
+BENCH(fma_clamp, "v_fma_f32 %12, %12, %14, %15 clamp\n v_fma_f32 %13, %13, %14, %15 clamp\n v_fma_f32 %0, %0, %14, %15 clamp\n v_fma_f32 %1, %1, %14, %15 clamp\n")
+BENCH(max_i32, "v_max_i32 %0, %0, %16\n v_max_i32 %1, %1, %16\n v_max_i32 %2, %2, %16\n v_max_i32 %3, %3, %16\n")
+BENCH(exec_add, "s_mov_b64 exec, 0x5555\n v_add_f32 %12, %12, %14\n v_add_f32 %13, %13, %14\n s_mov_b64 exec, -1\n v_add_f32 %0, %0, %14\n v_add_f32 %1, %1, %14\n")
+BENCH(setreg_fma, "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n v_fma_f32 %12, %12, %14, %15\n v_fma_f32 %13, %13, %14, %15\n s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n v_fma_f32 %0, %0, %14, %15\n v_fma_f32 %1, %1, %14, %15\n")
+BENCH(cndmask_s, "v_cndmask_b32 %0, %4, %5, s[10:11]\n v_cndmask_b32 %1, %5, %6, s[10:11]\n v_cndmask_b32 %2, %6, %7, s[10:11]\n v_cndmask_b32 %3, %7, %4, s[10:11]\n")
+BENCH(lshl_b32, "v_lshlrev_b32 %0, 16, %0\n v_lshlrev_b32 %1, 16, %1\n v_lshlrev_b32 %2, 16, %2\n v_lshlrev_b32 %3, 16, %3\n")
+BENCH(add_dpp, "v_add_u32_dpp %0, %4, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %1, %5, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %2, %6, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %3, %7, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n")
+BENCH(fract, "v_fract_f32 %12, %12\n v_fract_f32 %13, %13\n v_fract_f32 %14, %14\n v_fract_f32 %15, %15\n")
+BENCH(and_sdwa, "v_and_b32_sdwa %0, %0, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n v_and_b32_sdwa %1, %1, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n v_and_b32_sdwa %2, %2, %6 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n v_and_b32_sdwa %3, %3, %7 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n")
+BENCH(pk_add, "v_pk_add_f32 %8, %8, %9\n v_pk_add_f32 %9, %9, %10\n v_pk_add_f32 %10, %10, %11\n v_pk_add_f32 %11, %11, %8\n")
+BENCH(mix8, "v_fma_f32 %12, %12, %14, %15\n v_add_u32 %0, %0, %16\n v_fma_f32 %13, %13, %14, %15\n v_and_b32 %1, %1, %16\n")
+
 #define RUN(NAME)                                                                                           \
-  for (int th : {512}) {                                                                         \
+  for (int th : {256, 512, 1024}) {                                                                         \
     hipLaunchKernelGGL(k_##NAME, dim3(1), dim3(th), 0, 0, d, iters);                                        \
     hipLaunchKernelGGL(k_##NAME, dim3(1), dim3(th), 0, 0, d, iters);                                        \
     hipDeviceSynchronize();                                                                                 \
@@ -96,6 +108,7 @@ int main() {
   RUN(ldexp) RUN(exp) RUN(add_f64)
   RUN(min_u32) RUN(sub_u32) RUN(max_f32) RUN(sub_f32) RUN(mul_f32) RUN(add_f32) RUN(fmac_f32) RUN(fmaak) RUN(cvt_i32) RUN(ashr_i32) RUN(or_b32)
   RUN(bfi) RUN(and_or) RUN(add3) RUN(med3_u32) RUN(cmp_lt) RUN(add_co_only) RUN(mul_u24) RUN(pk_fma)
+  RUN(fma_clamp) RUN(max_i32) RUN(exec_add) RUN(setreg_fma) RUN(cndmask_s) RUN(lshl_b32) RUN(add_dpp) RUN(fract) RUN(and_sdwa) RUN(pk_add) RUN(mix8)
   RUN(cvt_f64_f32) RUN(ldexp_f64) RUN(floor_f64) RUN(trunc_f64) RUN(fma_f64) RUN(cvt_f64_u32) RUN(mul_f64)
   return 0;
 }

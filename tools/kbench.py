@@ -24,6 +24,8 @@ def run(eng, B, V, dtype, mask_kind, rng_mode, nbuf, iters, variant=0, ld=None, 
     kw = {}
     if mask_kind == 1:
         kw = dict(mask_kind=1, mask=bits, mask_id=mid)
+    elif mask_kind == 3:  # prepared masks, ids per row
+        kw = dict(mask=eng.prepare_masks(bits, V, dtype), row_mask_id=mid)
     elif mask_kind == 2:
         kw = dict(mask_kind=2, mask=maskf.contiguous(), mask_id=mid)
     noise = None
@@ -42,7 +44,7 @@ def run(eng, B, V, dtype, mask_kind, rng_mode, nbuf, iters, variant=0, ld=None, 
     torch.cuda.synchronize()
     ts = np.array([a.elapsed_time(b) * 1e3 for a, b in evs])
     es = bufs[0].element_size()
-    byt = B * V * es + B * 8 + (K * ((V + 31) // 32) * 4 if mask_kind == 1 else 0) + (K * V * 4 if mask_kind == 2 else 0) + (B * V * 4 if rng_mode == 2 else 0)
+    byt = B * V * es + B * 8 + (K * ((V + 31) // 32) * 4 if mask_kind in (1, 3) else 0) + (K * V * 4 if mask_kind == 2 else 0) + (B * V * 4 if rng_mode == 2 else 0)
     med = np.median(ts)
     print(f"B={B} V={V} ld={ld} {str(dtype):15s} mask={mask_kind} rng={rng_mode} var={variant}: median {med:8.1f} us  min {ts.min():8.1f} us  "
           f"{byt / med / 1e6:7.3f} TB/s ({byt / med / 1e6 / 8 * 100:5.1f}% of 8 TB/s)  bytes={byt / 1e6:.1f} MB", flush=True)
@@ -65,6 +67,8 @@ if __name__ == "__main__":
             run(eng, 1024, 50257, f32, 1, 1, a.nbuf, a.iters, pforbid=pf)
             run(eng, 1024, 50257, f32, 1, 0, a.nbuf, a.iters, pforbid=pf)
         sys.exit(0)
+    run(eng, 1024, 50257, f32, 3, 1, a.nbuf, a.iters, variant=a.variant)
+    run(eng, 512, 128256, bf16, 3, 1, a.nbuf, a.iters)
     run(eng, 1024, 50257, f32, 1, 1, a.nbuf, a.iters, variant=a.variant)
     run(eng, 1024, 50257, f32, 0, 1, a.nbuf, a.iters, variant=a.variant)
     run(eng, 1024, 50257, f32, 0, 0, a.nbuf, a.iters, variant=a.variant)
