@@ -313,7 +313,7 @@ struct RowView {
     if constexpr (MASK == kMaskBits) {
 #pragma unroll
       for (int k = 0; k < EPV; ++k) {
-        const uint64_t w = mt[(int64_t)c * 64 + i * EPV + k];
+        const uint64_t w = as_const(mt)[(int64_t)c * 64 + i * EPV + k];
         if (!((w >> lane) & 1ull)) y[k] = kNegInf;
       }
     } else if constexpr (MASK == kMaskF32) {
@@ -369,21 +369,30 @@ __device__ __forceinline__ int32_t walk_vectors(const RowView<DT, MASK> &rv, int
   return -1;
 }
 
-// The draw inside one chunk: the chunk arrives in one burst (as in chunk_stats_kernel), every vector's allowed sum
-// is taken with the round-toward-zero adds, the vector holding the target is found by a scan over the <= 16 totals
-// and only that vector is walked element by element.
+// The draw inside one chunk, by the four waves of the particle's workgroup: wave w takes vectors w, w+4, ... of the
+// chunk (one burst of loads), sums their allowed terms with the round-toward-zero adds and parks the per-vector
+// totals in LDS; wave 0 then finds the vector holding the target by a scan over the <= 16 totals and walks only
+// that vector element by element.  Every wave must call this (it contains a workgroup barrier).
 template <int DT, int MASK>
-__device__ __forceinline__ int32_t draw_in_chunk(const RowView<DT, MASK> &rv, int c, int lane, float magicN,
-                                                 uint64_t T) {
-  constexpr int EPV = ElemTraits<DT>::EPV, NVC = ElemTraits<DT>::NVC;
+__device__ __forceinline__ int32_t draw_in_chunk(const RowView<DT, MASK> &rv, int c, int lane, int wave,
+                                                 float magicN, uint64_t T, uint64_t *s_tot) {
+  constexpr int EPV = ElemTraits<DT>::EPV, NVC = ElemTraits<DT>::NVC, NVW = NVC / 4;
   const int e_base = c * kChunk;
-  int nv_valid = (rv.V - e_base + 64 * EPV - 1) / (64 * EPV);
-  nv_valid = nv_valid < NVC ? nv_valid : NVC;
-  float x[64];
-  load_chunk<DT, true>(rv.rowp, e_base, rv.V, lane, rv.scale, x);
-  if constexpr (MASK == kMaskF32) {
+  const cu64_t mt = MASK == kMaskBits ? as_const(rv.mt + (int64_t)c * 64) : nullptr;
+  u32x4_t raw[NVW];
 #pragma unroll
-    for (int i = 0; i < NVC; ++i)
+  for (int j = 0; j < NVW; ++j) {
+    const int e0 = e_base + ((wave + 4 * j) * 64 + lane) * EPV;
+    raw[j] = load_vec_guarded<DT>(rv.rowp, e0 < rv.V ? e0 : rv.V, rv.V);
+  }
+#pragma unroll
+  for (int j = 0; j < NVW; ++j) {
+    const int i = wave + 4 * j;
+    float t[EPV];
+    unpack_vec<DT>(raw[j], t);
+#pragma unroll
+    for (int k = 0; k < EPV; ++k) t[k] *= rv.scale;
+    if constexpr (MASK == kMaskF32) {
 #pragma unroll
       for (int h = 0; h < EPV / 4; ++h) {
         const int e0 = e_base + (i * 64 + lane) * EPV + 4 * h;
@@ -391,36 +400,30 @@ __device__ __forceinline__ int32_t draw_in_chunk(const RowView<DT, MASK> &rv, in
         float mk[4];
         unpack_vec<kDtF32>(r, mk);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) x[i * EPV + 4 * h + k] += mk[k];
+        for (int k = 0; k < 4; ++k) t[4 * h + k] += mk[k];
       }
-  }
-  const cu64_t mt = MASK == kMaskBits ? as_const(rv.mt + (int64_t)c * 64) : nullptr;
-  uint64_t wv = 0;  // lane i: total of vector i
-#pragma unroll
-  for (int i = 0; i < NVC; ++i) {
-    if (i < nv_valid) {
-      float t[EPV];
-#pragma unroll
-      for (int k = 0; k < EPV; ++k) t[k] = chunk_term(x[i * EPV + k], magicN);
-      float Am = __uint_as_float(kA0Bits), Bm = __uint_as_float(kB0Bits);
-#pragma unroll
-      for (int h = 0; h < EPV / 4; ++h) {
-        uint64_t M0 = 0, M1 = 0, M2 = 0, M3 = 0;
-        if constexpr (MASK == kMaskBits) {
-          M0 = mt[i * EPV + 4 * h + 0];
-          M1 = mt[i * EPV + 4 * h + 1];
-          M2 = mt[i * EPV + 4 * h + 2];
-          M3 = mt[i * EPV + 4 * h + 3];
-        }
-        rtz_vec4<MASK == kMaskBits>(t[4 * h], t[4 * h + 1], t[4 * h + 2], t[4 * h + 3], Am, Bm, M0, M1, M2, M3);
-      }
-      const uint32_t pa = wave_sum_u32_l63(__float_as_uint(Am) - kA0Bits);
-      const uint32_t pb = wave_sum_u32_l63(__float_as_uint(Bm) - kB0Bits);
-      const uint64_t W = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)pa, 63) << kGridHi) +
-                         (uint32_t)__builtin_amdgcn_readlane((int)pb, 63);
-      wv = lane == i ? W : wv;
     }
+#pragma unroll
+    for (int k = 0; k < EPV; ++k) t[k] = chunk_term(t[k], magicN);
+    float Am = __uint_as_float(kA0Bits), Bm = __uint_as_float(kB0Bits);
+#pragma unroll
+    for (int h = 0; h < EPV / 4; ++h) {
+      uint64_t M0 = 0, M1 = 0, M2 = 0, M3 = 0;
+      if constexpr (MASK == kMaskBits) {
+        M0 = mt[i * EPV + 4 * h + 0];
+        M1 = mt[i * EPV + 4 * h + 1];
+        M2 = mt[i * EPV + 4 * h + 2];
+        M3 = mt[i * EPV + 4 * h + 3];
+      }
+      rtz_vec4<MASK == kMaskBits>(t[4 * h], t[4 * h + 1], t[4 * h + 2], t[4 * h + 3], Am, Bm, M0, M1, M2, M3);
+    }
+    const uint32_t pa = wave_sum_u32_l63(__float_as_uint(Am) - kA0Bits);
+    const uint32_t pb = wave_sum_u32_l63(__float_as_uint(Bm) - kB0Bits);
+    if (lane == 63) s_tot[i] = ((uint64_t)pa << kGridHi) + pb;
   }
+  __syncthreads();
+  if (wave != 0) return -1;
+  const uint64_t wv = lane < NVC ? s_tot[lane] : 0ull;
   const uint64_t incl = wave_scan_u64(wv);
   const int isel = first_lane_above(incl, T);
   if (isel < 0) return -1;
@@ -472,13 +475,15 @@ __device__ __forceinline__ float load_elem(const char *rowp, int j) {
 template <int DT, int MASK, int MODE>
 __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
   constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC;
-  const int lane = threadIdx.x & 63;
-  const int pidx = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
-  if (pidx >= p.n_particles) return;
+  __shared__ uint64_t s_tot[16];
+  __shared__ float s_bestg[4];
+  __shared__ int32_t s_bestj[4];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int pidx = blockIdx.x;  // one workgroup of four waves per particle
   const int nch = p.nch, V = p.V;
-  const int pr = p.pair_of ? p.pair_of[pidx] : pidx;
-  const int row = p.pair_row ? p.pair_row[pr] : pr;
-  const int mi = MASK == kMaskNone ? 0 : (p.pair_mask ? p.pair_mask[pr] : (p.n_masks == 1 ? 0 : pr));
+  const int pr = p.pair_of ? as_const(p.pair_of)[pidx] : pidx;
+  const int row = p.pair_row ? as_const(p.pair_row)[pr] : pr;
+  const int mi = MASK == kMaskNone ? 0 : (p.pair_mask ? as_const(p.pair_mask)[pr] : (p.n_masks == 1 ? 0 : pr));
   const ChunkRec *recs = p.recs + (int64_t)pr * nch;
 
   RowView<DT, MASK> rv;
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
   rv.mt = MASK == kMaskBits ? p.mask_t + (int64_t)mi * nch * 64 : nullptr;
   rv.mrow = MASK == kMaskF32 ? (const char *)(p.mask_f + (int64_t)mi * p.mask_ld) : nullptr;
 
-  // ---- fold the chunk records: row scales, then the sums shifted onto them (64 chunks per sweep) ----------
+  // ---- fold the chunk records (every wave, same values): row scales, then the sums shifted onto them ------------
   float N_all = kNegInf, N_msk = kNegInf;
   for (int c0 = 0; c0 < nch; c0 += 64) {
     const int c = c0 + lane;
@@ -517,12 +522,13 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
       }
     }
     S_all += wave_sum_u64(sa);
-    S_msk += wave_sum_u64(sm);
+    if constexpr (MASK != kMaskNone) S_msk += wave_sum_u64(sm);
   }
   if constexpr (MASK == kMaskNone) S_msk = S_all;
 
-  // ---- bit masks: allowed mass below 2^-4 of the row's largest term -> masked sum on its own scale ----------
-  bool own = false;       // wave-uniform
+  // ---- bit masks: allowed mass below 2^-4 of the row's largest term -> masked sum on its own scale (every wave
+  //      redundantly: rare, and the branch must be taken by all four for the barriers further down) -----------------
+  bool own = false;       // workgroup-uniform
   int sparse_n = -1;      // >= 0: the mask allows that many (<= 63) tokens, listed in mask_info
   float x_sp = kNegInf;   // sparse path: this lane's allowed logit
   int j_sp = -1;
@@ -555,8 +561,8 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
     }
   }
 
-  // ---- lse / logZ (sum of e^x = 2^(N + 1 - 36) * S) ------------------------------------------------------------
-  if (lane == 0) {
+  // ---- lse / logZ (sum of e^x = 2^(N + 1 - 36) * S): one lane of the last wave, beside the draw ---------------------
+  if (wave == 3 && lane == 0) {
     const double lse_all = S_all ? log_fix(S_all, (int32_t)N_all + 1 - kFrac) : (double)kNegInf;
     const double lse_msk = S_msk ? log_fix(S_msk, (int32_t)N_msk + 1 - kFrac) : (double)kNegInf;
     if (p.out_lse) p.out_lse[pidx] = (float)lse_all;
@@ -566,21 +572,23 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
   if (!p.out_token) return;
 
   int32_t tok = -1;
-  if (S_msk != 0) {
+  if (S_msk != 0) {  // workgroup-uniform from here on: every wave holds the same S_msk / own / N_msk
     if constexpr (MODE == kModePhilox) {
       uint64_t T = __umul64hi(philox_bits(p, pidx), S_msk);  // uniform integer in [0, S_msk)
       if (own) {
-        if (sparse_n >= 0) {
-          const uint64_t q = lane < sparse_n ? term_q(x_sp, kMagic - N_msk) : 0ull;
-          const uint64_t incl = wave_scan_u64(q);
-          const int lsel = first_lane_above(incl, T);
-          tok = __builtin_amdgcn_readlane(j_sp, lsel < 0 ? 0 : lsel);
-        } else {
-          for (int c = 0; c < nch && tok < 0; ++c) tok = walk_vectors(rv, c, 0, NVC, lane, kMagic - N_msk, T);
+        if (wave == 0) {
+          if (sparse_n >= 0) {
+            const uint64_t q = lane < sparse_n ? term_q(x_sp, kMagic - N_msk) : 0ull;
+            const uint64_t incl = wave_scan_u64(q);
+            const int lsel = first_lane_above(incl, T);
+            tok = __builtin_amdgcn_readlane(j_sp, lsel < 0 ? 0 : lsel);
+          } else {
+            for (int c = 0; c < nch && tok < 0; ++c) tok = walk_vectors(rv, c, 0, NVC, lane, kMagic - N_msk, T);
+          }
         }
       } else {
         // chunk: scan of the shifted chunk sums in vocabulary order; then the target is carried onto the chunk's
-        // own scale (T << shift stays below the chunk's unshifted sum) and the chunk is walked
+        // own scale (T << shift stays below the chunk's unshifted sum) and the chunk is searched
         int csel = -1;
         float Ncs = 0.f;
         for (int c0 = 0; c0 < nch && csel < 0; c0 += 64) {
@@ -612,19 +620,20 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
             T -= readlane_u64(incl, 63);
           }
         }
-        if (csel >= 0) tok = draw_in_chunk(rv, csel, lane, kMagic - Ncs, T);
+        if (csel >= 0) tok = draw_in_chunk(rv, csel, lane, wave, kMagic - Ncs, T, s_tot);
       }
     } else {
       // ---- parity mode: exponential race against the caller's noise, first maximum of e_j / E_j (README.md:87
-      //      through torch.multinomial's CPU algorithm).  e_j = ldexp(P, n_j - Nref + 1): any common scale gives the
-      //      same comparisons; the row scale keeps every allowed term that can win (the largest allowed term is
-      //      within 2^-4 of it unless `own`, and then Nref is the masked maximum's own exponent) ---------------------
+      //      through torch.multinomial's CPU algorithm).  e_j = ldexp(P, n_j - N_msk): any common scale gives the same
+      //      comparisons; the row scale keeps every allowed term that can win (the largest allowed term is within
+      //      2^-4 of it unless `own`, and then N_msk is the masked maximum's own exponent).  Vectors are dealt round
+      //      robin to the four waves; ties resolve to the smallest index at every level ------------------------------
       const float magicN = kMagic - N_msk;
       const float *E = p.noise + (int64_t)pidx * p.noise_ld;
       float best = -1.0f;
       int32_t bj = -1;
       for (int c = 0; c < nch; ++c)
-        for (int i = 0; i < NVC; ++i) {
+        for (int i = wave; i < NVC; i += 4) {
           if (c * kChunk + i * 64 * EPV >= V) break;
           float y[EPV];
           int e0;
@@ -640,7 +649,6 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
             bj = better ? j : bj;
           }
         }
-      // first maximum over the wave: largest g, ties to the smallest index
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
         const float og = __shfl_xor(best, o, 64);
@@ -649,10 +657,25 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
         best = take ? og : best;
         bj = take ? oj : bj;
       }
+      if (lane == 0) {
+        s_bestg[wave] = best;
+        s_bestj[wave] = bj;
+      }
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+          const float og = s_bestg[w];
+          const int32_t oj = s_bestj[w];
+          const bool take = og > best || (og == best && oj >= 0 && (bj < 0 || oj < bj));
+          best = take ? og : best;
+          bj = take ? oj : bj;
+        }
+      }
       tok = bj;
     }
   }
-  if (lane == 0) p.out_token[pidx] = tok;
+  if (wave == 0 && lane == 0) p.out_token[pidx] = tok;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -746,11 +769,13 @@ __global__ __launch_bounds__(256) void mask_prepare_kernel(const uint32_t *bits,
       tot += s_cnt[q];
     }
     int at = base + wb + incl - pc;
-    if (at < kInfoWords - 1) {
+    // single-sweep masks (V <= 131072): the total is known here, dense masks skip the id walk altogether
+    const bool may_list = nw > 256 * kTile || tot <= kInfoWords - 1;
+    if (may_list && at < kInfoWords - 1) {
 #pragma unroll
       for (int j = 0; j < kTile; ++j) {
         uint32_t v = word[j];
-        while (v) {
+        while (v && at < kInfoWords - 1) {
           const int bpos = __ffs(v) - 1;
           v &= v - 1;
           if (at < kInfoWords - 1) info[1 + at] = (w0 + tid * kTile + j) * 32 + bpos;

@@ -33,7 +33,7 @@ hipError_t GLB_CAT(launch_stats_, GLB_DT)(const StepParams &p, int mask_kind, bo
 
 template <int MASK>
 static hipError_t finish1(const StepParams &p, int mode, hipStream_t s) {
-  const dim3 grid((unsigned)(((int64_t)p.n_particles + 3) / 4)), block(256);
+  const dim3 grid((unsigned)p.n_particles), block(256);  // one workgroup (four waves) per particle
   switch (mode) {
     case kModeStats: hipLaunchKernelGGL((finish_kernel<GLB_DT, MASK, kModeStats>), grid, block, 0, s, p); break;
     case kModePhilox: hipLaunchKernelGGL((finish_kernel<GLB_DT, MASK, kModePhilox>), grid, block, 0, s, p); break;

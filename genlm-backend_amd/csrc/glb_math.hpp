@@ -177,7 +177,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // =====================================================================================================
 // Chunked contract of the particle step.  A row is cut into chunks of kChunk elements by
 // vocabulary index.  Chunk c has its own binary scale N_c = exp_n(max of the chunk); every element gives
-//     t = ldexp(P(f), n - N_c)    fp32, P = 2^(f-1) in [0.35, 0.71] (degree-5 Horner, result clamped to [0,1],
+//     t = ldexp(P(f), n - N_c)    fp32, P = 2^(f-1) in [0.35, 0.71] (degree-4 Horner, result clamped to [0,1],
 //                                 NaN -> 0), so t <= 0.7072 and t = 0 for -inf / NaN
 //     q = floor(t * 2^36)         integer term, 36 fractional bits below 2^(N_c + 1)
 // and S_c = sum q.  The hot kernel never forms q: it adds t into fp32 accumulators in ROUND-TOWARD-ZERO mode on
@@ -191,13 +191,13 @@ constexpr int kGridHi = 18;          // coarse grid 2^-18
 constexpr uint32_t kA0Bits = 0x42000000u;  // 32.0f: ulp 2^-18
 constexpr uint32_t kB0Bits = 0x39000000u;  // 2^-13: ulp 2^-36
 constexpr int kLowMassBits = 32;     // bit-masked sums below 2^32 (on the row's scale) are redone on their own scale
-// 2^(f-1) on |f| <= 1/2: the 2^30-scaled coefficients above times 2^-31 (exact)
-constexpr float kD0 = __builtin_bit_cast(float, 0x4e800000u - (31u << 23));
-constexpr float kD1 = __builtin_bit_cast(float, 0x4e317216u - (31u << 23));
-constexpr float kD2 = __builtin_bit_cast(float, 0x4d75fcd9u - (31u << 23));
-constexpr float kD3 = __builtin_bit_cast(float, 0x4c635b16u - (31u << 23));
-constexpr float kD4 = __builtin_bit_cast(float, 0x4b1e7722u - (31u << 23));
-constexpr float kD5 = __builtin_bit_cast(float, 0x49adfe07u - (31u << 23));
+// 2^(f-1) on |f| <= 1/2: degree-4 minimax polynomial (relative error, Remez; max 2.7e-6 as evaluated in fp32
+// Horner form, mean +4e-8), coefficients of 2^f with the exponent lowered by one
+constexpr float kD0 = __builtin_bit_cast(float, 0x3f7ffff4u - (1u << 23));
+constexpr float kD1 = __builtin_bit_cast(float, 0x3f31706eu - (1u << 23));
+constexpr float kD2 = __builtin_bit_cast(float, 0x3e76036du - (1u << 23));
+constexpr float kD3 = __builtin_bit_cast(float, 0x3d650a20u - (1u << 23));
+constexpr float kD4 = __builtin_bit_cast(float, 0x3c1ccbebu - (1u << 23));
 
 // v_fma_f32 with the clamp modifier: result clamped to [0, 1], NaN -> 0 (DX10_CLAMP is on in HSA kernels)
 __device__ __forceinline__ float fma_clamp01(float a, float b, float c) {
@@ -214,8 +214,7 @@ __device__ __forceinline__ float chunk_term(float x, float magicN) {
   const float negn = magicN - tm;
   const int np = (int)(__float_as_uint(tm) - kMagicBits);
   const float f = __builtin_fmaf(x, kLog2e, negn);
-  float p = kD5;
-  p = __builtin_fmaf(p, f, kD4);
+  float p = kD4;
   p = __builtin_fmaf(p, f, kD3);
   p = __builtin_fmaf(p, f, kD2);
   p = __builtin_fmaf(p, f, kD1);
@@ -243,41 +242,41 @@ __device__ __forceinline__ void rtz_acc4(float t0, float t1, float t2, float t3,
                                          uint64_t M1, uint64_t M2, uint64_t M3) {
   float x0, x1, d0, d1, l0, l1;
   if constexpr (MASKED) {
+    float d2, d3, l2, l3;
     asm volatile(
         "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
-        "v_add_f32 %8, %0, %14\n\t"
-        "v_add_f32 %9, %2, %15\n\t"
+        "v_add_f32 %8, %0, %18\n\t"
+        "v_add_f32 %9, %2, %19\n\t"
         "v_sub_f32 %10, %8, %0\n\t"
         "v_sub_f32 %11, %9, %2\n\t"
-        "v_sub_f32 %12, %14, %10\n\t"
-        "v_sub_f32 %13, %15, %11\n\t"
+        "v_sub_f32 %12, %18, %10\n\t"
+        "v_sub_f32 %13, %19, %11\n\t"
         "v_add_f32 %1, %1, %12\n\t"
         "v_add_f32 %3, %3, %13\n\t"
-        "s_mov_b64 exec, %18\n\t"
+        "v_add_f32 %0, %8, %20\n\t"
+        "v_add_f32 %2, %9, %21\n\t"
+        "v_sub_f32 %14, %0, %8\n\t"
+        "v_sub_f32 %15, %2, %9\n\t"
+        "v_sub_f32 %16, %20, %14\n\t"
+        "v_sub_f32 %17, %21, %15\n\t"
+        "v_add_f32 %1, %1, %16\n\t"
+        "v_add_f32 %3, %3, %17\n\t"
+        "s_mov_b64 exec, %22\n\t"
         "v_add_f32 %4, %4, %10\n\t"
         "v_add_f32 %5, %5, %12\n\t"
-        "s_mov_b64 exec, %19\n\t"
+        "s_mov_b64 exec, %23\n\t"
         "v_add_f32 %6, %6, %11\n\t"
         "v_add_f32 %7, %7, %13\n\t"
-        "s_mov_b64 exec, -1\n\t"
-        "v_add_f32 %0, %8, %16\n\t"
-        "v_add_f32 %2, %9, %17\n\t"
-        "v_sub_f32 %10, %0, %8\n\t"
-        "v_sub_f32 %11, %2, %9\n\t"
-        "v_sub_f32 %12, %16, %10\n\t"
-        "v_sub_f32 %13, %17, %11\n\t"
-        "v_add_f32 %1, %1, %12\n\t"
-        "v_add_f32 %3, %3, %13\n\t"
-        "s_mov_b64 exec, %20\n\t"
-        "v_add_f32 %4, %4, %10\n\t"
-        "v_add_f32 %5, %5, %12\n\t"
-        "s_mov_b64 exec, %21\n\t"
-        "v_add_f32 %6, %6, %11\n\t"
-        "v_add_f32 %7, %7, %13\n\t"
+        "s_mov_b64 exec, %24\n\t"
+        "v_add_f32 %4, %4, %14\n\t"
+        "v_add_f32 %5, %5, %16\n\t"
+        "s_mov_b64 exec, %25\n\t"
+        "v_add_f32 %6, %6, %15\n\t"
+        "v_add_f32 %7, %7, %17\n\t"
         "s_mov_b64 exec, -1\n\t"
         "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
         : "+v"(A0), "+v"(B0), "+v"(A1), "+v"(B1), "+v"(Am0), "+v"(Bm0), "+v"(Am1), "+v"(Bm1), "=&v"(x0), "=&v"(x1),
-          "=&v"(d0), "=&v"(d1), "=&v"(l0), "=&v"(l1)
+          "=&v"(d0), "=&v"(d1), "=&v"(l0), "=&v"(l1), "=&v"(d2), "=&v"(d3), "=&v"(l2), "=&v"(l3)
         : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "s"(M0), "s"(M1), "s"(M2), "s"(M3));
   } else {
     asm volatile(

@@ -173,6 +173,7 @@ class AsyncAmdLM(AsyncLM):
         # fused-step state
         self._mask_kind = MASK_NONE
         self._masks = None
+        self._masks_prepared = {}
         self._rng_mode = RNG_PHILOX
         self._rng_seed = 0
         self._host_rng = None
@@ -221,11 +222,25 @@ class AsyncAmdLM(AsyncLM):
             masks = torch.stack([m.to(torch.float32) for m in masks])
         masks = masks.to(self.device, torch.float32).contiguous()
         bits, flag = self.engine.mask_to_bits(masks)
+        self._masks_prepared = {}
         if int(flag.item()) == 0:
             self._mask_kind, self._masks = MASK_BITS, bits
+            self._mask_vocab = masks.shape[1]
         else:
             self._mask_kind, self._masks = MASK_F32, masks
         return masks.shape[0]
+
+    def step_masks(self, logits_dtype):
+        """Mask arguments of `HipEngine.step` for logits of `logits_dtype`: bit masks are brought into the kernels'
+        layout once per element width (glb_mask_prepare) and reused by every step."""
+        if self._mask_kind == MASK_NONE:
+            return {}
+        if self._mask_kind == MASK_F32:
+            return dict(mask_kind=MASK_F32, mask=self._masks)
+        wide = logits_dtype == torch.float32
+        if wide not in self._masks_prepared:
+            self._masks_prepared[wide] = self.engine.prepare_masks(self._masks, self._mask_vocab, logits_dtype)
+        return dict(mask=self._masks_prepared[wide])
 
     def set_rng(self, mode="philox", seed=0):
         """"philox": in-kernel counter RNG (fast).  "torch": parity with the reference's CPU
@@ -369,9 +384,9 @@ class AsyncAmdLM(AsyncLM):
         if step_q:
             row_of = torch.from_numpy(np.fromiter((step_row[u] for u, _ in step_q), np.int32, len(step_q))).to(dev)
             mask_id = torch.from_numpy(np.fromiter((m.mask_id for _, m in step_q), np.int32, len(step_q))).to(dev)
-            kw = {}
-            if self._mask_kind != MASK_NONE:
-                kw = dict(mask_kind=self._mask_kind, mask=self._masks, mask_id=mask_id)
+            kw = self.step_masks(logits.dtype)
+            if kw:
+                kw["mask_id"] = mask_id
             if self._rng_mode == RNG_NOISE:
                 noise = self._host_rng.exponential(len(step_q) * V).view(len(step_q), V).to(dev, non_blocking=True)
                 kw["noise"] = noise

@@ -102,6 +102,8 @@ class DeviceSIS:
         assert len(prompts) == n_particles
         self.prompt_len = torch.tensor([len(p) for p in prompts], dtype=torch.int32, device=self.dev)
         self.max_prompt = max(len(p) for p in prompts)
+        self._mask_by_row = len({len(p) for p in prompts}) == 1
+        self._rep = None
         self.cap = self.max_prompt + max_tokens + 1
         ctx = np.zeros((n_particles, self.cap), np.int32)
         for i, p in enumerate(prompts):
@@ -174,9 +176,17 @@ class DeviceSIS:
         eng, llm, N = self.eng, self.llm, self.N
         V = logits.shape[-1]
         mask_id = ((self.lengths - self.prompt_len) >= self.max_tokens).to(torch.int32)
-        kw = {}
-        if llm._mask_kind != 0:
-            kw = dict(mask_kind=llm._mask_kind, mask=llm._masks, mask_id=mask_id)
+        kw = llm.step_masks(logits.dtype)
+        if kw:
+            # The mask depends on the number of generated tokens only; with prompts of one length that makes it a
+            # function of the context, so identical contexts (one logits row) share it: ids go per ROW and a shared
+            # row is reduced once (hf.py:214-220 dedup carried through the particle math).
+            if self._mask_by_row and group_of is not None:
+                kw["row_mask_id"] = mask_id[self._rep[:U].long()].contiguous()
+            elif self._mask_by_row:
+                kw["row_mask_id"] = mask_id
+            else:
+                kw["mask_id"] = mask_id
         if self.rng_mode == RNG_NOISE:
             kw["noise"] = self._parity_noise(group_of if group_of is not None else torch.arange(N, device=self.dev), V)
         if time_kernel:
@@ -206,6 +216,7 @@ class DeviceSIS:
         # finished particles still occupy a row: give them their 1-token stub so they dedup to one group
         lengths_eff = torch.where(self.active > 0, self.lengths, torch.ones_like(self.lengths))
         group_of, rep, ng = eng.group_contexts(ctx_flat, self.starts, lengths_eff)
+        self._rep = rep
         head = torch.stack([ng[0], self.active.sum().to(torch.int32)]).cpu()  # the step's only D2H sync
         U, n_active = int(head[0]), int(head[1])
         base, p_max, cache = None, 0, None

@@ -183,12 +183,16 @@ static int mask_allows(const uint32_t *bits, int64_t j) {
  * (device side: genlm-backend_amd/csrc/glb_math.hpp "chunk_term" and glb_chunk.hpp.)
  * A row is cut into chunks of 4096 elements by vocabulary index.  Chunk c has its own binary scale
  * N_c = glb_exp_n(max of the chunk).  Every element gives
- *     t = ldexpf(P, n - N_c)     P = 2^(f-1) by the degree-5 Horner polynomial (coefficients of GLB_EXP_C times
- *                                2^-31), clamped to [0, 1] with NaN -> 0
+ *     t = ldexpf(P, n - N_c)     P = 2^(f-1) by a degree-4 Horner polynomial (GLB_EXP2_D), clamped to [0, 1]
+ *                                with NaN -> 0
  *     q = floor(t * 2^36)
  * S_c = sum of q over the chunk, S_c^m = sum over the allowed elements.  The row scale is N = max N_c over the
  * chunks with a non-zero sum, and the row sums are S = sum_c (S_c >> (N - N_c)).  sum_j e^(x_j) = 2^(N+1-36) S.
  */
+/* 2^(f-1) on |f| <= 1/2: degree-4 minimax polynomial (relative error; max 2.7e-6 as evaluated in fp32 Horner form):
+ * coefficients of 2^f with the exponent lowered by one */
+static const uint32_t GLB_EXP2_D[5] = {0x3f7ffff4u - (1u << 23), 0x3f31706eu - (1u << 23), 0x3e76036du - (1u << 23),
+                                       0x3d650a20u - (1u << 23), 0x3c1ccbebu - (1u << 23)};
 #define GLB_CHUNK 4096
 #define GLB_FRAC 36
 #define GLB_LOW_MASS_BITS 32 /* bit-masked sums below 2^32 on the row's scale are redone on their own scale */
@@ -200,12 +204,11 @@ static float glb_chunk_term(float x, float magicN) {
   memcpy(&tb, &tm, 4);
   int32_t np = (int32_t)(tb - 0x4B400000u);
   float f = fmaf(x, GLB_LOG2E, negn);
-  float p = u2f(GLB_EXP_C[5] - (31u << 23));
-  p = fmaf(p, f, u2f(GLB_EXP_C[4] - (31u << 23)));
-  p = fmaf(p, f, u2f(GLB_EXP_C[3] - (31u << 23)));
-  p = fmaf(p, f, u2f(GLB_EXP_C[2] - (31u << 23)));
-  p = fmaf(p, f, u2f(GLB_EXP_C[1] - (31u << 23)));
-  p = fmaf(p, f, u2f(GLB_EXP_C[0] - (31u << 23)));
+  float p = u2f(GLB_EXP2_D[4]);
+  p = fmaf(p, f, u2f(GLB_EXP2_D[3]));
+  p = fmaf(p, f, u2f(GLB_EXP2_D[2]));
+  p = fmaf(p, f, u2f(GLB_EXP2_D[1]));
+  p = fmaf(p, f, u2f(GLB_EXP2_D[0]));
   if (!(p > 0.0f)) p = 0.0f; /* clamp modifier: NaN and negatives -> 0 */
   if (p > 1.0f) p = 1.0f;
   if (np < -300) np = -300; /* ldexpf takes any int; keep it in range for the libm call (result is 0 either way) */

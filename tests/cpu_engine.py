@@ -17,16 +17,31 @@ def _logits_np(t):
     return t.detach().cpu().contiguous().numpy()
 
 
+class _Prepared:
+    """stand-in for engine.PreparedMasks: the oracle works on the plain bit rows"""
+
+    def __init__(self, bits):
+        self.bits = bits
+
+
 class CpuOracleEngine:
     device = torch.device("cpu")
 
+    def prepare_masks(self, bits, vocab, logits_dtype=torch.float32):
+        return _Prepared(bits)
+
     def step(self, logits, vocab=None, row_of=None, mask_kind=0, mask=None, mask_id=None, rng_mode=0, noise=None,
-             seed=0, offset=0, particle_base=0, logit_scale=1.0, want_lse=True, variant=0, out=None):
+             seed=0, offset=0, particle_base=0, logit_scale=1.0, want_lse=True, variant=0, out=None, row_mask_id=None):
         V = logits.shape[1] if vocab is None else vocab
         x = _logits_np(logits[:, :V])
+        if isinstance(mask, _Prepared):
+            mask, mask_kind = mask.bits, 1
         m = _np(mask)
         if mask_kind == 1:
             m = m.view(np.uint32)
+        if row_mask_id is not None:  # ids per logits row -> per particle for the oracle
+            rm = _np(row_mask_id)
+            mask_id = torch.from_numpy(rm if row_of is None else rm[_np(row_of)])
         logZ, lse, tok = O.step(x, row_of=_np(row_of), mask_kind=mask_kind, mask=m, mask_id=_np(mask_id),
                                 rng_mode=rng_mode, noise=_np(noise), seed=seed, offset=offset,
                                 particle_base=particle_base, logit_scale=logit_scale)
