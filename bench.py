@@ -1,29 +1,39 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the genlm-backend hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload sis|kernel]
+    python bench.py --gpus N --steps K --warmup W [--workload NAME]
 
-One process per GPU (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ...`,
-RCCL through torch.distributed backend "nccl").  A step is one pass of the hot path over one batch
-of synthetic input that is already resident in HBM:
+One process per GPU.  `python bench.py --gpus N` with N > 1 starts the N ranks itself: the parent process (which
+never touches the GPU) runs `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+... bench.py ...` as a child and relays rank 0's JSON line; launched through torch.distributed.run directly it
+reads RANK / LOCAL_RANK / WORLD_SIZE from the environment.  Ranks talk RCCL (torch.distributed backend "nccl").
 
-  workload "sis"    (default) one sequential-importance-sampling step of 1024 particles per GPU on
-                    a GPT-2-small-shaped random-init model (README.md:82-98 of the reference):
-                    context dedup -> ragged-to-padded gather -> PyTorch-ROCm forward -> lm_head on
-                    the last position -> fused log-softmax + mask + logsumexp + sample kernel ->
-                    particle bookkeeping (-> RCCL all-gather of log-weights when N > 1).
-  workload "kernel" only the fused kernel on [1024, 50257] fp32 logits, rotating over 4 buffers so the
-                    256 MiB Infinity Cache cannot serve the rows.
+A step is one pass of the hot path over one batch of synthetic input that is already resident in HBM:
 
-Rank 0 prints ONE JSON line.  `value` = particles per second over all GPUs (weak scaling: 1024
-particles per GPU).  `roofline` prices the fused kernel: algorithmic bytes per launch
-over its mean launch duration, measured with HIP events on the launch stream inside the timed
-region.  `cpu_baseline` times the reference-semantics CPU port (oracle/, test infrastructure) of
-the same particle step on a bounded sample, single thread, on this host.
+  sis           (default; BASELINE.json config 2) one sequential-importance-sampling step of 1024 particles per GPU
+                on a GPT-2-small-shaped random-init fp32 model (README.md:82-98 of the reference): context dedup ->
+                ragged-to-padded gather -> PyTorch-ROCm forward -> lm_head on the last position -> fused
+                log-softmax + mask + logsumexp + sample -> particle bookkeeping (-> RCCL all-gather of the
+                log-weights when N > 1).  --prefix-kv / --particle-kv select the KV variants (config 3 / beyond).
+  sis-llama     (config 4) the same step with a Llama-3.2-1B-shaped random-init bf16 model, V = 128256,
+                512 particles per GPU (4096 over 8 GPUs).
+  kernel        only the fused step on [1024, 50257] fp32 logits, rotating over 4 buffers so that the 256 MiB
+                Infinity Cache cannot serve the rows.
+  kernel-llama  (config 5) only the fused step on [512, 128256] bf16 logits, 4 rotating buffers.
+  api           the README loop itself: 1024 coroutines awaiting `AsyncAmdLM.next_token_step` (autobatched).
+  api-logprobs  `batch_next_token_logprobs` of 1024 contexts per step, log-prob rows materialised ([1024, V] fp32).
+  plumbing      CPU / gloo self-test of the multi-rank launch, barrier, all-gather and JSON relay (tests only; no
+                kernel is run and the line says so).
+
+Rank 0 prints ONE JSON line.  `value` = particles per second over all GPUs (weak scaling).  `roofline` prices the
+fused step: algorithmic bytes per call over the mean duration of its launches (chunk_stats_kernel +
+finish_kernel), measured with HIP events on the launch stream inside the timed region.  `cpu_baseline` times the
+reference-semantics CPU port (oracle/, test infrastructure) of the same work on a bounded sample on this host.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -33,67 +43,150 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-V_GPT2 = 50257
-N_PARTICLES = 1024
+V_GPT2, V_LLAMA = 50257, 128256
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
+METRIC = "particles/sec + logprob-kernel HBM GB/s (% of 8 TB/s), 1024 particles gpt2"
+WORKLOADS = ["sis", "sis-llama", "kernel", "kernel-llama", "api", "api-logprobs", "plumbing"]
 
 
-def algorithmic_bytes(B, V, elem_size, n_masks, mask_words):
-    """logits once + distinct mask bytes + 8 B of outputs per particle."""
-    return B * V * elem_size + n_masks * mask_words * 4 + B * 8
+def algorithmic_bytes(B, V, elem_size, n_masks, mask_words, n_particles=None):
+    """unique logits rows once + distinct mask bytes + 8 B of outputs per particle."""
+    return B * V * elem_size + n_masks * mask_words * 4 + (B if n_particles is None else n_particles) * 8
 
 
-def cpu_baseline(workload, sample_rows, seed=1234):
-    """The same work on this host's cores, in the reference's arithmetic (oracle layer A = port of
-    cache.py:96 log_softmax and README.md:84-87 mask + logsumexp + exp + multinomial incl. its serial
-    MT19937 draws; for "sis" preceded by the torch-CPU forward hf.py:275-281 runs, full-vocabulary logits
-    for every position as the reference computes them).  Bounded sample, scaled to particles/s."""
+# ------------------------------------------------------------------------------------------------------------
+# CPU baseline (oracle = test infrastructure; only this leg of bench.py touches it)
+# ------------------------------------------------------------------------------------------------------------
+def _cpu_particle_math(x, masks, seed, repeats):
     from oracle import oracle as O
-    from tests import synth
 
-    O.build()
-    masks = synth.binary_masks(seed, 2, V_GPT2)
-    threads = 1
-    t_fwd = 0.0
-    if workload == "sis":
-        from transformers import GPT2Config, GPT2LMHeadModel
-
-        rows = min(sample_rows, 512)
-        torch.manual_seed(seed)
-        model = GPT2LMHeadModel(GPT2Config()).eval()
-        ids = torch.randint(0, V_GPT2, (rows, 13))  # mid-loop context length: prompt 8 + 5 generated
-        threads = torch.get_num_threads()
-        t0 = time.perf_counter()
-        with torch.no_grad():
-            logits = model(ids).logits  # [rows, 13, V], all positions (hf.py:275-281)
-        t_fwd = time.perf_counter() - t0
-        x = logits[:, -1].contiguous().numpy()
-        repeats = 1
-    else:
-        rows = sample_rows
-        x = synth.logits(seed, rows, V_GPT2)
-        repeats = 8
+    V = x.shape[1]
     t0 = time.perf_counter()
     st = None
     done = 0
     for _ in range(repeats):
-        for r in range(rows):
+        for r in range(x.shape[0]):
             lp = O.ref_log_softmax(x[r])
-            E, st = O.mt_exponential(seed, V_GPT2, st)
-            O.ref_particle(lp, masks[r % 2], E)
+            E, st = O.mt_exponential(seed, V, st)
+            O.ref_particle(lp, masks[r % len(masks)], E)
             done += 1
-    t_part = time.perf_counter() - t0
-    dt = t_fwd * repeats + t_part
-    what = (f"torch-CPU gpt2-small forward [{rows}x13 tokens, all-position logits] {t_fwd:.1f} s on {threads} threads + "
-            if workload == "sis" else "")
+    return done, time.perf_counter() - t0
+
+
+def cpu_baseline(workload, sample_rows, seed=1234):
+    """The same work on this host's cores, in the reference's arithmetic (oracle layer A = port of cache.py:96
+    log_softmax and README.md:84-87 mask + logsumexp + exp + multinomial incl. its serial MT19937 draws; for the
+    SIS workloads preceded by the torch-CPU forward hf.py:275-281 runs - full-vocabulary logits for every position,
+    as the reference computes them).  Bounded sample, scaled to particles/s; the forward is timed at k = all cores
+    and at k = 1, the particle math is single-threaded as in the reference."""
+    from oracle import oracle as O
+    from tests import synth
+
+    O.build()
+    ncpu = os.cpu_count()
+    if workload in ("sis", "api", "api-logprobs"):
+        from transformers import GPT2Config, GPT2LMHeadModel
+
+        masks = synth.binary_masks(seed, 2, V_GPT2)
+        rows = min(sample_rows, 256)
+        torch.manual_seed(seed)
+        model = GPT2LMHeadModel(GPT2Config()).eval()
+        ids = torch.randint(0, V_GPT2, (rows, 13))  # mid-loop context length: prompt 8 + 5 generated
+        k_all = torch.get_num_threads()
+        fwd = {}
+        for k, nrow in ((k_all, rows), (1, 8)):
+            torch.set_num_threads(k)
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                logits = model(ids[:nrow]).logits  # [rows, 13, V], all positions (hf.py:275-281)
+            fwd[k] = (time.perf_counter() - t0) / nrow
+            if k == k_all:
+                x = logits[:, -1].contiguous().numpy()
+        torch.set_num_threads(k_all)
+        done, t_part = _cpu_particle_math(x, masks, seed, 1)
+        per_particle = t_part / done
+        v_all = 1.0 / (fwd[k_all] + per_particle)
+        v_1 = 1.0 / (fwd[1] + per_particle)
+        return {
+            "value": v_all, "unit": "particles/s", "cores": k_all, "kind": "port",
+            "value_k1": v_1,
+            "sample": f"torch-CPU gpt2-small forward over 13-token contexts, all-position logits: {rows} rows on "
+                      f"{k_all} threads ({fwd[k_all] * 1e3:.1f} ms/particle) and 8 rows on 1 thread "
+                      f"({fwd[1] * 1e3:.1f} ms/particle); + per-particle log_softmax + mask + logsumexp + MT19937 "
+                      f"multinomial (V={V_GPT2}, fp32) on {done} rows, single-threaded as in the reference "
+                      f"({per_particle * 1e3:.2f} ms/particle); value = k={k_all}, value_k1 = k=1; host has {ncpu} cores",
+        }
+    if workload == "sis-llama":
+        from transformers import LlamaForCausalLM
+
+        masks = synth.binary_masks(seed, 2, V_LLAMA)
+        rows = min(sample_rows, 32)
+        torch.manual_seed(seed)
+        model = LlamaForCausalLM(llama_1b_config()).to(torch.bfloat16).eval()
+        ids = torch.randint(0, V_LLAMA, (rows, 13))
+        k_all = torch.get_num_threads()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            logits = model(ids).logits
+        t_fwd = (time.perf_counter() - t0) / rows
+        x = logits[:, -1].float().contiguous().numpy()
+        done, t_part = _cpu_particle_math(x, masks, seed, 1)
+        return {
+            "value": 1.0 / (t_fwd + t_part / done), "unit": "particles/s", "cores": k_all, "kind": "port",
+            "sample": f"torch-CPU Llama-3.2-1B-shaped bf16 forward, {rows} rows x 13 tokens on {k_all} threads "
+                      f"({t_fwd * 1e3:.1f} ms/particle) + per-particle math on fp32-upcast rows (V={V_LLAMA}) "
+                      f"{t_part / done * 1e3:.2f} ms/particle single-threaded; host has {ncpu} cores",
+        }
+    # kernel-only analogues: per-particle math on synthetic rows
+    V = V_GPT2 if workload == "kernel" else V_LLAMA
+    rows = min(sample_rows, 1024 if workload == "kernel" else 256)
+    masks = synth.binary_masks(seed, 2, V)
+    x = synth.logits(seed, rows, V)
+    if workload == "kernel-llama":
+        x = torch.from_numpy(x).to(torch.bfloat16).float().numpy()  # bf16 values, upcast as the reference would see them
+    done, t_part = _cpu_particle_math(x, masks, seed, 8 if workload == "kernel" else 4)
     return {
-        "value": done / dt,
-        "unit": "particles/s",
-        "cores": threads,
-        "kind": "port",
-        "sample": f"{done} particle steps: {what}per-particle log_softmax + mask + logsumexp + MT19937 multinomial "
-                  f"(V={V_GPT2}, fp32) {t_part:.1f} s single-threaded; host has {os.cpu_count()} cores",
+        "value": done / t_part, "unit": "particles/s", "cores": 1, "kind": "port",
+        "sample": f"{done} particle steps of per-particle log_softmax + mask + logsumexp + MT19937 multinomial "
+                  f"(V={V}, {'fp32' if workload == 'kernel' else 'bf16 values in fp32'}) in {t_part:.1f} s, single "
+                  f"thread (the reference's draws are serial); host has {ncpu} cores",
     }
+
+
+def llama_1b_config():
+    from transformers import LlamaConfig
+
+    # Llama-3.2-1B architecture (16 layers, d 2048, 32 heads / 8 KV heads of 64, MLP 8192, tied embeddings, V 128256)
+    return LlamaConfig(vocab_size=V_LLAMA, hidden_size=2048, intermediate_size=8192, num_hidden_layers=16,
+                       num_attention_heads=32, num_key_value_heads=8, head_dim=64, max_position_embeddings=4096,
+                       rope_theta=500000.0, rms_norm_eps=1e-5, tie_word_embeddings=True, bos_token_id=128000,
+                       eos_token_id=128001)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# multi-rank launch: the parent never initialises HIP
+# ------------------------------------------------------------------------------------------------------------
+def spawn_ranks(n):
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if line is not None:
+        print(line, flush=True)
+    else:
+        sys.stdout.write(p.stdout)
+    sys.exit(p.returncode if p.returncode else (0 if line is not None else 1))
 
 
 def main():
@@ -101,28 +194,39 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default=None, choices=["sis", "kernel"])
-    ap.add_argument("--cpu-sample", type=int, default=1024, help="rows of the CPU baseline sample")
+    ap.add_argument("--workload", default="sis", choices=WORKLOADS)
+    ap.add_argument("--cpu-sample", type=int, default=1024, help="rows of the CPU baseline sample (upper bound)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--particle-kv", action="store_true",
-                    help="sis workload with device-resident per-particle KV (beyond the reference: one token per particle per step)")
+                    help="sis workloads with device-resident per-particle KV (beyond the reference: one token per particle per step)")
     ap.add_argument("--prefix-kv", action="store_true",
-                    help="sis workload with the prompt's KV cached (hf.py:155-164 cache_kv; BASELINE config 3)")
+                    help="sis workloads with the prompt's KV cached (hf.py:155-164 cache_kv; BASELINE config 3)")
+    ap.add_argument("--prompts", type=int, default=1, help="distinct shared prompts over the population (config 3: 1 / 8 / 64)")
+    ap.add_argument("--resample", action="store_true", help="systematic resampling after every step (replicated, deterministic)")
     args = ap.parse_args()
 
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        spawn_ranks(args.gpus)  # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(world_env or "1")
     if world != args.gpus:
-        if args.gpus != 1 and world == 1:
-            raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch `python bench.py --gpus N` (it starts its own "
+                         "ranks) or torch.distributed.run with --nproc-per-node equal to --gpus")
+    cpu_only = args.workload == "plumbing"
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if cpu_only:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if cpu_only:
+        return plumbing(args, rank, world, dist)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -131,19 +235,25 @@ def main():
 
     eng = HipEngine(dev)
     workload = args.workload
-    if workload is None:
-        try:
-            from genlm_backend_amd import sis  # noqa: F401
-            workload = "sis"
-        except ImportError:
-            workload = "kernel"
-
-    if workload == "kernel":
-        runner = KernelWorkload(eng, dev, rank, world, dist)
+    if workload in ("kernel", "kernel-llama"):
+        runner = KernelWorkload(eng, dev, rank, world, dist, llama=workload == "kernel-llama")
+    elif workload in ("api", "api-logprobs"):
+        runner = ApiWorkload(eng, dev, rank, world, dist, logprobs=workload == "api-logprobs")
     else:
         from genlm_backend_amd.sis import SisBenchWorkload
 
-        runner = SisBenchWorkload(eng, dev, rank, world, dist, prefix_kv=args.prefix_kv, particle_kv=args.particle_kv)
+        runner = SisBenchWorkload(eng, dev, rank, world, dist, prefix_kv=args.prefix_kv, particle_kv=args.particle_kv,
+                                  model="llama-3.2-1b" if workload == "sis-llama" else "gpt2",
+                                  n_particles=512 if workload == "sis-llama" else 1024, n_prompts=args.prompts,
+                                  resample=args.resample)
+
+    rccl_ranks = None
+    if dist is not None:  # one collective before the clock starts: proves every rank is on the RCCL communicator
+        probe = torch.full((1,), float(rank), device=dev)
+        got = torch.empty(world, device=dev)
+        dist.all_gather_into_tensor(got, probe)
+        assert got.cpu().tolist() == [float(r) for r in range(world)]
+        rccl_ranks = dist.get_world_size()
 
     for i in range(args.warmup):
         runner.step(i, timed=False)
@@ -165,22 +275,10 @@ def main():
         dt = float(t.item())
 
     kern_us = runner.kernel_times_us()
-    # HBM bytes per launch of the fused kernel from the rocprofv3 PMC passes of this same command (collected
-    # with tools/profile_round.sh - counters cannot be read from inside the process); kernel workload only
-    traffic = None
-    if workload == "kernel":
-        try:
-            prof = sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*", "kernel_workload_pmc_traffic_v*.json")))
-            if prof:
-                t = json.load(open(prof[-1]))
-                traffic = t["hbm_read_bytes_per_launch_corrected"] + t["hbm_write_bytes_per_launch"]
-        except (OSError, ValueError, KeyError):
-            traffic = None
     if rank == 0:
         total_particles = runner.particles_per_step * world * args.steps
-        ach = runner.kernel_bytes / (np.mean(kern_us) * 1e-6) / 1e9
         out = {
-            "metric": "particles/sec + logprob-kernel HBM GB/s (% of 8 TB/s), 1024 particles gpt2",
+            "metric": METRIC,
             "value": total_particles / dt,
             "unit": "particles/s",
             "n_gpus": world,
@@ -190,24 +288,28 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": runner.dtype_name,
             "data": "synthetic",
             "config": runner.config(),
-            "roofline": {
+        }
+        if rccl_ranks is not None:
+            out["rccl_ranks"] = rccl_ranks
+        if kern_us is not None and len(kern_us):
+            ach = runner.kernel_bytes / (np.mean(kern_us) * 1e-6) / 1e9
+            out["roofline"] = {
                 "bound": "hbm",
                 "achieved": ach,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS,
-                "traffic": traffic,
+                "traffic": pmc_traffic(workload),
                 "kernel": "glb::chunk_stats_kernel + glb::finish_kernel (fused log-softmax + mask + logsumexp + sample: "
                           "chunked streaming reduction, then lse / logZ / draw per particle); duration = both launches",
                 "bytes_per_launch": runner.kernel_bytes,
                 "us_per_launch_mean": float(np.mean(kern_us)),
                 "us_per_launch_median": float(np.median(kern_us)),
                 "launches_timed": len(kern_us),
-            },
-        }
+            }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(workload, args.cpu_sample)
         print(json.dumps(out), flush=True)
@@ -215,27 +317,81 @@ def main():
         dist.destroy_process_group()
 
 
+def pmc_traffic(workload):
+    """HBM bytes per fused call from the rocprofv3 PMC passes of this same command (FETCH_SIZE / WRITE_SIZE in
+    separate runs, corrected as MI355X_MICROARCH.md prescribes; collected with tools/profile_round.sh - counters
+    cannot be read from inside the process).  The newest summary under profiles/ for this workload, else null."""
+    import glob
+
+    try:
+        prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"{workload}_pmc_traffic*.json")))
+        if prof:
+            t = json.load(open(prof[-1]))
+            return t["hbm_read_bytes_per_launch_corrected"] + t["hbm_write_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
+def plumbing(args, rank, world, dist):
+    """Multi-rank skeleton on CPU / gloo: barrier, per-step all-gather of fake log-weights, max-over-ranks clock,
+    one JSON line from rank 0.  No kernel of the product runs here; the line is labelled accordingly."""
+    lw = torch.full((8,), float(rank))
+    gathered = torch.empty(8 * world)
+
+    def step():
+        if dist is not None:
+            dist.all_gather_into_tensor(gathered, lw)
+
+    for _ in range(args.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        assert gathered.view(world, 8)[:, 0].tolist() == [float(r) for r in range(world)]
+    if rank == 0:
+        print(json.dumps({"metric": "plumbing self-test (no kernel run; NOT a benchmark result)", "value": 8 * world * args.steps / dt,
+                          "unit": "fake particles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "none", "data": "synthetic",
+                          "config": {"workload": "plumbing self-test on CPU/gloo"},
+                          "rccl_ranks": world if dist is not None else None}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 class KernelWorkload:
-    """Fused kernel only, [1024, 50257] fp32 logits, two shared {0,-inf} masks, in-kernel Philox."""
+    """Fused step only: [1024, 50257] fp32 (or [512, 128256] bf16) logits, two shared {0,-inf} masks prepared once
+    (like the README's two masks), mask ids per row, in-kernel Philox."""
 
-    particles_per_step = N_PARTICLES
-
-    def __init__(self, eng, dev, rank, world, dist, nbuf=4):
+    def __init__(self, eng, dev, rank, world, dist, llama=False, nbuf=4):
         self.eng, self.dev, self.rank, self.world, self.dist = eng, dev, rank, world, dist
         g = torch.Generator(device=dev)
         g.manual_seed(1234 + rank)
-        B, V = N_PARTICLES, V_GPT2
-        self.bufs = [torch.randn((B, V), device=dev, generator=g) * 3.0 for _ in range(nbuf)]
+        B, V, dt = (512, V_LLAMA, torch.bfloat16) if llama else (1024, V_GPT2, torch.float32)
+        self.B, self.V, self.llama = B, V, llama
+        self.dtype_name = "bf16" if llama else "f32"
+        self.particles_per_step = B
+        self.bufs = [(torch.randn((B, V), device=dev, generator=g) * 3.0).to(dt) for _ in range(nbuf)]
         maskf = torch.where(torch.rand((2, V), device=dev, generator=g) < 1 / 3, float("-inf"), 0.0)
         maskf[:, 0] = 0.0
         self.bits, _ = eng.mask_to_bits(maskf)
-        self.masks = eng.prepare_masks(self.bits, V, torch.float32)  # built once, like the README's two masks
+        self.masks = eng.prepare_masks(self.bits, V, dt)
         self.mask_id = (torch.arange(B, device=dev) % 2).to(torch.int32)
         self.out = (torch.empty(B, device=dev), torch.empty(B, device=dev),
                     torch.empty(B, dtype=torch.int32, device=dev))
         self.lw = torch.zeros(B, device=dev)
         self.gathered = torch.empty(B * world, device=dev) if world > 1 else None
-        self.kernel_bytes = algorithmic_bytes(B, V, 4, 2, (V + 31) // 32)
+        self.kernel_bytes = algorithmic_bytes(B, V, 2 if llama else 4, 2, (V + 31) // 32)
         self.events = []
 
     def step(self, i, timed):
@@ -244,7 +400,7 @@ class KernelWorkload:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         self.eng.step(x, mask=self.masks, row_mask_id=self.mask_id, rng_mode=1, seed=1234, offset=i,
-                      particle_base=self.rank * N_PARTICLES, out=self.out)
+                      particle_base=self.rank * self.B, out=self.out)
         if timed:
             e1.record()
             self.events.append((e0, e1))
@@ -257,9 +413,93 @@ class KernelWorkload:
         return np.array([a.elapsed_time(b) * 1e3 for a, b in self.events])
 
     def config(self):
-        return {"workload": "fused kernel only: 1024 particles x gpt2 vocab 50257, fp32 logits [1024,50257] ld=V, "
-                            "2 shared bit masks, Philox draw, 4 rotating logits buffers",
-                "particles_per_gpu": N_PARTICLES, "vocab": V_GPT2, "rng": "philox"}
+        shape = "512 particles x Llama vocab 128256, bf16 logits [512,128256]" if self.llama else \
+            "1024 particles x gpt2 vocab 50257, fp32 logits [1024,50257]"
+        return {"workload": f"fused step only: {shape} ld=V, 2 shared bit masks (prepared once), Philox draw, "
+                            "4 rotating logits buffers",
+                "particles_per_gpu": self.B, "vocab": self.V, "rng": "philox"}
+
+
+class ApiWorkload:
+    """The reference's own API surface at 1024 particles on the GPT-2-small-shaped model.
+
+    api:          README.md:72-98 - one coroutine per particle awaiting `next_token_step(context, mask_id)`; a step is
+                  one `asyncio.gather` over the population (autobatched into one evaluation, batch_size = 1024).
+    api-logprobs: `batch_next_token_logprobs` (base.py:47-60) of 1024 distinct contexts: [1024, V] fp32 log-prob rows
+                  materialised on the device each step (trie cache cleared between steps so nothing is served from it)."""
+
+    dtype_name = "f32"
+
+    def __init__(self, eng, dev, rank, world, dist, logprobs=False, n_particles=1024, max_tokens=10):
+        import asyncio
+
+        from transformers import GPT2Config
+
+        from genlm_backend_amd.llm import AsyncAmdLM
+
+        self.asyncio = asyncio
+        cfg = GPT2Config()
+        self.llm = AsyncAmdLM.from_config(cfg, None, device=dev, dtype=torch.float32, seed=1234, engine=eng,
+                                          batch_size=n_particles, timeout=0.02)
+        V = cfg.vocab_size
+        g = torch.Generator(device=dev)
+        g.manual_seed(4321)
+        valid = torch.where(torch.rand(V, device=dev, generator=g) < 1 / 3, float("-inf"), 0.0)
+        valid[cfg.eos_token_id] = 0.0
+        eos1 = torch.full((V,), float("-inf"), device=dev)
+        eos1[cfg.eos_token_id] = 0.0
+        self.llm.register_masks(torch.stack([valid, eos1]))
+        self.llm.set_rng("philox", seed=1234 + rank)
+        self.N, self.V, self.max_tokens, self.eos = n_particles, V, max_tokens, cfg.eos_token_id
+        self.particles_per_step = n_particles
+        self.logprobs = logprobs
+        self.prompt = list(range(100, 108))
+        self.loop = asyncio.new_event_loop()
+        self.kernel_bytes = None
+        self.world, self.dist, self.dev = world, dist, dev
+        self.gathered = torch.empty(n_particles * world, device=dev) if world > 1 else None
+        self._reset()
+        rs = np.random.default_rng(7 + rank)
+        self.ctx_pool = [[int(t) for t in rs.integers(0, V, 13)] for _ in range(n_particles)]
+        for i in range(2):  # set-up: allocator growth, GEMM selection
+            self.step(i, False)
+        self._reset()
+
+    def _reset(self):
+        from genlm_backend_amd.sis import Particle
+
+        sel = lambda context: 1 if len(context) >= self.max_tokens else 0
+        self.particles = [Particle(self.llm, sel, self.prompt, self.eos) for _ in range(self.N)]
+        self.t = 0
+
+    def step(self, i, timed):
+        aio = self.asyncio
+        if self.logprobs:
+            self.llm.clear_cache()
+            rows = self.loop.run_until_complete(self.llm.batch_next_token_logprobs(self.ctx_pool))
+            assert rows.shape == (self.N, self.V)
+            return
+        if self.t >= self.max_tokens:
+            self._reset()
+
+        async def one_step():
+            await aio.gather(*[p.extend() for p in self.particles if p.active])
+
+        self.loop.run_until_complete(one_step())
+        self.t += 1
+        if self.world > 1:
+            lw = torch.tensor([p.log_weight for p in self.particles], dtype=torch.float32, device=self.dev)
+            self.dist.all_gather_into_tensor(self.gathered, lw)
+
+    def kernel_times_us(self):
+        return None
+
+    def config(self):
+        what = ("batch_next_token_logprobs of 1024 distinct 13-token contexts, [1024, V] fp32 log-prob rows materialised "
+                "on the device (base.py:47-60)") if self.logprobs else \
+            ("README loop: 1024 coroutines awaiting AsyncAmdLM.next_token_step, autobatched (batch_size 1024), prompt len 8, "
+             "<=10 new tokens, 2 shared bit masks, Philox draws (README.md:72-98)")
+        return {"workload": what + "; gpt2-small shape (random init, fp32)", "particles_per_gpu": self.N, "vocab": self.V}
 
 
 if __name__ == "__main__":

@@ -26,6 +26,9 @@ class KVPrefix:
     def __len__(self):
         return self.length
 
+    def nbytes(self):
+        return sum(k.numel() * k.element_size() + v.numel() * v.element_size() for k, v in self.layers)
+
 
 class TokenTrie:
     """cache.py:47-100.  `logprobs` is the next-token log-probability row after the path to this node."""

@@ -353,6 +353,114 @@ __global__ __launch_bounds__(1024) void normalize_weights_kernel(const float *lw
   }
 }
 
+// ---- device-resident particle state: KV slabs, resampling ---------------------------------------------------
+
+// slab[i, h, pos[i], :] = rows[i, h, :]  (one new token per particle; rows may be a strided view)
+template <typename VT>
+__global__ void kv_append_kernel(VT *slab, const VT *rows, const int32_t *pos, int64_t n_rows, int64_t heads,
+                                 int64_t cap, int64_t row_vecs, int64_t rows_stride_row, int64_t rows_stride_head) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n_rows * heads * row_vecs) return;
+  const int64_t x = gid % row_vecs, h = (gid / row_vecs) % heads, i = gid / (row_vecs * heads);
+  const int64_t p = pos[i];
+  if (p < 0 || p >= cap) return;
+  slab[((i * heads + h) * cap + p) * row_vecs + x] = rows[i * rows_stride_row + h * rows_stride_head + x];
+}
+
+// dst[t][i, h, p, :] = src[t][src_row_of[i], h, p, :] for p < len_of[i]; src_row_of[i] < 0 leaves row i alone.
+// One launch moves every layer's K and V (pointer tables): fan-out of prompt KV to particles, ancestor gather.
+template <typename VT>
+__global__ void kv_gather_rows_kernel(const VT *const *src, VT *const *dst, int64_t n_rows, int64_t heads,
+                                      int64_t row_vecs, int64_t src_cap, int64_t dst_cap, const int32_t *src_row_of,
+                                      const int32_t *len_of) {
+  const int t = blockIdx.y;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t per_row = heads * dst_cap * row_vecs;
+  if (gid >= n_rows * per_row) return;
+  const int64_t i = gid / per_row, r = gid % per_row;
+  const int64_t x = r % row_vecs, p = (r / row_vecs) % dst_cap, h = r / (row_vecs * dst_cap);
+  const int64_t sr = src_row_of[i];
+  if (sr < 0 || p >= len_of[i] || p >= src_cap) return;
+  dst[t][((i * heads + h) * dst_cap + p) * row_vecs + x] = src[t][((sr * heads + h) * src_cap + p) * row_vecs + x];
+}
+
+__global__ void gather_rows_i32_kernel(const int32_t *src, int64_t src_ld, const int32_t *row_of, int64_t n,
+                                       int64_t width, int32_t *dst, int64_t dst_ld) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n * width) return;
+  const int64_t i = gid / width, j = gid % width;
+  dst[i * dst_ld + j] = src[(int64_t)row_of[i] * src_ld + j];
+}
+
+// Systematic resampling on the gathered log-weight vector, one workgroup, integers only after the terms:
+//   q_i = fix_term(lw_i) on the vector's scale (as glb_normalize_weights), C_i = q_0 + .. + q_i, S = C_{n-1}
+//   U0 = mulhi64(R, S) with R the Philox block of (seed, offset);  S = n*a + b
+//   T_k = k*a + floor((U0 + k*b) / n)          (= floor((U0 + k*S) / n): the k-th point of the comb, exactly)
+//   ancestor_k = the smallest i with C_i > T_k
+// Same inputs give the same ancestors on every rank (the gathered weights are bit-identical).
+__global__ __launch_bounds__(1024) void resample_systematic_kernel(const float *lw, int64_t n, uint64_t seed,
+                                                                    uint64_t offset, int32_t *anc, uint64_t *cum,
+                                                                    float *stats) {
+  using namespace glb;
+  const int T = 1024, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ float s_m[16];
+  __shared__ uint64_t s_w[16];
+  __shared__ uint64_t s_carry;
+  float m = kNegInf;
+  for (int64_t i = tid; i < n; i += T) m = fmaxf(m, lw[i]);
+  m = wave_max(m);
+  if (lane == 0) s_m[wave] = m;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  m = s_m[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) m = fmaxf(m, s_m[w]);
+  const float N = exp_n(m), Nb = N + (float)kFixShift;
+  // inclusive scan of the terms in chunks of T
+  for (int64_t base = 0; base < n; base += T) {
+    const int64_t i = base + tid;
+    const uint64_t q = i < n ? fix_term(lw[i], Nb) : 0ull;
+    const uint64_t incl = wave_scan_u64(q);
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    uint64_t wb = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const uint64_t v = s_w[w];
+      if (w < wave) wb += v;
+      tot += v;
+    }
+    const uint64_t carry = s_carry;
+    if (i < n) cum[i] = carry + wb + incl;
+    __syncthreads();
+    if (tid == 0) s_carry = carry + tot;
+    __syncthreads();
+  }
+  const uint64_t S = s_carry;
+  if (stats && tid == 0) stats[0] = S ? (float)log_fix(S, (int32_t)N - kFixFrac) : kNegInf;
+  if (S == 0) {  // no mass at all: identity
+    for (int64_t k = tid; k < n; k += T) anc[k] = (int32_t)k;
+    return;
+  }
+  const uint32_t ctr[4] = {0xa5c3u, 0x5e5au, (uint32_t)offset, (uint32_t)(offset >> 32)};
+  const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  uint32_t rnd[4];
+  philox4x32_10(ctr, key, rnd);
+  const uint64_t R = ((uint64_t)rnd[1] << 32) | rnd[0];
+  const uint64_t U0 = __umul64hi(R, S);
+  const uint64_t un = (uint64_t)n, a = S / un, b = S % un;
+  for (int64_t k = tid; k < n; k += T) {
+    const uint64_t Tk = (uint64_t)k * a + (U0 + (uint64_t)k * b) / un;
+    int64_t lo = 0, hi = n - 1;  // smallest i with cum[i] > Tk (cum[n-1] = S > Tk)
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (cum[mid] > Tk) hi = mid;
+      else lo = mid + 1;
+    }
+    anc[k] = (int32_t)lo;
+  }
+}
+
 inline unsigned blocks_for(int64_t n, int t) { return (unsigned)((n + t - 1) / t); }
 
 }  // namespace
@@ -683,6 +791,92 @@ int glb_normalize_weights(const float *log_weights, int64_t n, float *out_probs,
                      log_weights, n, out_probs, out_stats);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "normalize_weights launch");
+  return GLB_OK;
+}
+
+int glb_kv_append(void *slab, const void *new_rows, const int32_t *pos, int64_t n_rows, int64_t heads, int64_t cap,
+                  int64_t head_dim, int64_t new_stride_row, int64_t new_stride_head, int32_t elem_bytes,
+                  void *stream) {
+  if (!slab || !new_rows || !pos) return fail(GLB_EINVAL, "null pointer");
+  if (n_rows <= 0 || heads <= 0 || cap <= 0 || head_dim <= 0) return fail(GLB_EINVAL, "bad sizes");
+  if (elem_bytes != 2 && elem_bytes != 4) return fail(GLB_EINVAL, "elem_bytes must be 2 or 4");
+  const int64_t rowb = head_dim * elem_bytes;
+  hipStream_t s = (hipStream_t)stream;
+  const bool wide = rowb % 16 == 0 && ((uintptr_t)slab) % 16 == 0 && ((uintptr_t)new_rows) % 16 == 0 &&
+                    (new_stride_row * elem_bytes) % 16 == 0 && (new_stride_head * elem_bytes) % 16 == 0;
+  if (wide) {
+    const int64_t rv = rowb / 16, total = n_rows * heads * rv;
+    hipLaunchKernelGGL(kv_append_kernel<uint4>, dim3(blocks_for(total, 256)), dim3(256), 0, s, (uint4 *)slab,
+                       (const uint4 *)new_rows, pos, n_rows, heads, cap, rv, new_stride_row * elem_bytes / 16,
+                       new_stride_head * elem_bytes / 16);
+  } else if (elem_bytes == 4) {
+    const int64_t total = n_rows * heads * head_dim;
+    hipLaunchKernelGGL(kv_append_kernel<uint32_t>, dim3(blocks_for(total, 256)), dim3(256), 0, s, (uint32_t *)slab,
+                       (const uint32_t *)new_rows, pos, n_rows, heads, cap, head_dim, new_stride_row, new_stride_head);
+  } else {
+    const int64_t total = n_rows * heads * head_dim;
+    hipLaunchKernelGGL(kv_append_kernel<uint16_t>, dim3(blocks_for(total, 256)), dim3(256), 0, s, (uint16_t *)slab,
+                       (const uint16_t *)new_rows, pos, n_rows, heads, cap, head_dim, new_stride_row, new_stride_head);
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "kv_append launch");
+  return GLB_OK;
+}
+
+int glb_kv_gather_rows(const void *const *src, void *const *dst, int64_t n_tensors, int64_t n_rows, int64_t heads,
+                       int64_t head_dim, int64_t src_cap, int64_t dst_cap, const int32_t *src_row_of,
+                       const int32_t *len_of, int32_t elem_bytes, void *stream) {
+  if (!src || !dst || !src_row_of || !len_of) return fail(GLB_EINVAL, "null pointer");
+  if (n_tensors <= 0 || n_tensors > 65535 || n_rows <= 0 || heads <= 0 || head_dim <= 0 || src_cap <= 0 || dst_cap <= 0)
+    return fail(GLB_EINVAL, "bad sizes");
+  if (elem_bytes != 2 && elem_bytes != 4) return fail(GLB_EINVAL, "elem_bytes must be 2 or 4");
+  const int64_t rowb = head_dim * elem_bytes;
+  hipStream_t s = (hipStream_t)stream;
+  if (rowb % 16 == 0) {  // slabs come from the allocator: 16-byte aligned
+    const int64_t rv = rowb / 16, total = n_rows * heads * dst_cap * rv;
+    hipLaunchKernelGGL(kv_gather_rows_kernel<uint4>, dim3(blocks_for(total, 256), (unsigned)n_tensors), dim3(256), 0, s,
+                       (const uint4 *const *)src, (uint4 *const *)dst, n_rows, heads, rv, src_cap, dst_cap,
+                       src_row_of, len_of);
+  } else if (elem_bytes == 4) {
+    const int64_t total = n_rows * heads * dst_cap * head_dim;
+    hipLaunchKernelGGL(kv_gather_rows_kernel<uint32_t>, dim3(blocks_for(total, 256), (unsigned)n_tensors), dim3(256), 0,
+                       s, (const uint32_t *const *)src, (uint32_t *const *)dst, n_rows, heads, head_dim, src_cap,
+                       dst_cap, src_row_of, len_of);
+  } else {
+    const int64_t total = n_rows * heads * dst_cap * head_dim;
+    hipLaunchKernelGGL(kv_gather_rows_kernel<uint16_t>, dim3(blocks_for(total, 256), (unsigned)n_tensors), dim3(256), 0,
+                       s, (const uint16_t *const *)src, (uint16_t *const *)dst, n_rows, heads, head_dim, src_cap,
+                       dst_cap, src_row_of, len_of);
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "kv_gather_rows launch");
+  return GLB_OK;
+}
+
+int glb_gather_rows_i32(const int32_t *src, int64_t src_ld, const int32_t *row_of, int64_t n, int64_t width,
+                        int32_t *dst, int64_t dst_ld, void *stream) {
+  if (!src || !row_of || !dst) return fail(GLB_EINVAL, "null pointer");
+  if (n <= 0 || width <= 0 || src_ld < width || dst_ld < width) return fail(GLB_EINVAL, "bad sizes");
+  hipLaunchKernelGGL(gather_rows_i32_kernel, dim3(blocks_for(n * width, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     src_ld, row_of, n, width, dst, dst_ld);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "gather_rows_i32 launch");
+  return GLB_OK;
+}
+
+size_t glb_resample_workspace(int64_t n) { return n > 0 ? (size_t)n * sizeof(uint64_t) : 0; }
+
+int glb_resample_systematic(const float *log_weights, int64_t n, uint64_t seed, uint64_t offset,
+                            int32_t *out_ancestors, float *out_stats, void *workspace, size_t workspace_bytes,
+                            void *stream) {
+  if (!log_weights || !out_ancestors || !workspace) return fail(GLB_EINVAL, "null pointer");
+  if (n <= 0 || n > (1 << 18)) return fail(GLB_EINVAL, "n must be in [1, 262144]");
+  if (workspace_bytes < glb_resample_workspace(n) || ((uintptr_t)workspace) % 8)
+    return fail(GLB_ENOSPC, "workspace too small or misaligned");
+  hipLaunchKernelGGL(resample_systematic_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, log_weights, n, seed,
+                     offset, out_ancestors, (uint64_t *)workspace, out_stats);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "resample launch");
   return GLB_OK;
 }
 

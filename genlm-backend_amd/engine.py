@@ -250,3 +250,45 @@ class HipEngine:
         probs, stats = self._f32(n), self._f32(2)
         check(self.lib.glb_normalize_weights(_ptr(log_weights), n, _ptr(probs), _ptr(stats), self._stream()))
         return probs, stats
+
+    # ---- device-resident particle state ------------------------------------------------------------------
+    def kv_append(self, slab, new_rows, pos):
+        """slab[i, h, pos[i], :] = new_rows[i, h, 0, :] (glb_kv_append).  slab [n, H, cap, Dh] contiguous; new_rows
+        [n, H, 1, Dh] with unit inner stride (usually a transposed view of the projection output)."""
+        n, H, cap, Dh = slab.shape
+        assert new_rows.shape == (n, H, 1, Dh) and new_rows.stride(3) == 1 and slab.is_contiguous()
+        check(self.lib.glb_kv_append(_ptr(slab), _ptr(new_rows), _ptr(pos), n, H, cap, Dh, new_rows.stride(0),
+                                     new_rows.stride(1), slab.element_size(), self._stream()))
+
+    def kv_gather_rows(self, srcs, dsts, src_row_of, len_of):
+        """dsts[t][i, h, p] = srcs[t][src_row_of[i], h, p] for p < len_of[i], for every tensor pair of the two lists
+        (all [rows, heads, cap, head_dim], contiguous) in ONE launch through device pointer tables
+        (glb_kv_gather_rows).  src_row_of[i] < 0 leaves row i untouched."""
+        s0, d0 = srcs[0], dsts[0]
+        assert all(t.is_contiguous() for t in srcs) and all(t.is_contiguous() for t in dsts)
+        sp = torch.tensor([t.data_ptr() for t in srcs], dtype=torch.int64, device=self.device)
+        dp = torch.tensor([t.data_ptr() for t in dsts], dtype=torch.int64, device=self.device)
+        check(self.lib.glb_kv_gather_rows(_ptr(sp), _ptr(dp), len(srcs), d0.shape[0], d0.shape[1], d0.shape[3],
+                                          s0.shape[2], d0.shape[2], _ptr(src_row_of), _ptr(len_of), d0.element_size(),
+                                          self._stream()))
+
+    def gather_rows_i32(self, src, row_of, out=None):
+        """out[i] = src[row_of[i]] for an int32 matrix (glb_gather_rows_i32)."""
+        n, width = row_of.numel(), src.shape[1]
+        if out is None:
+            out = torch.empty((n, width), dtype=torch.int32, device=self.device)
+        check(self.lib.glb_gather_rows_i32(_ptr(src), src.stride(0), _ptr(row_of), n, width, _ptr(out), out.stride(0),
+                                           self._stream()))
+        return out
+
+    def resample_systematic(self, log_weights, seed, offset):
+        """Ancestors of a systematic resampling step over `log_weights` (the gathered population), int32 [n]
+        (glb_resample_systematic); also returns logsumexp of the weights as a 1-element tensor."""
+        n = log_weights.numel()
+        need = self.lib.glb_resample_workspace(n)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(max(need, 1 << 16), dtype=torch.uint8, device=self.device)
+        anc, stats = self._i32(n), self._f32(1)
+        check(self.lib.glb_resample_systematic(_ptr(log_weights), n, seed, offset, _ptr(anc), _ptr(stats),
+                                               _ptr(self._ws), self._ws.numel(), self._stream()))
+        return anc, stats

@@ -1,0 +1,142 @@
+"""Device-resident KV state of the hot path.
+
+* `SlabKV` — per-particle KV in preallocated slabs `[n, heads, cap, head_dim]`, one pair per layer, handed to the
+  HuggingFace forward as a `Cache`.  The reference keeps KV as per-query tuples that are zero-padded and concatenated
+  for every batch (hf.py:33-53,247-271) or as per-token slices on trie nodes (cache.py:103-191, mlx.py:177-318); here a
+  particle owns row i of every slab, the new token's K/V is written in place at its own position (glb_kv_append:
+  ragged lengths, no torch.cat regrow) and a resampling step is one gather launch over all layers
+  (glb_kv_gather_rows) into the second slab set.
+* `PrefixLRU` — byte-budgeted least-recently-used store for the prompt prefixes `cache_kv` pins (hf.py:155-164);
+  the eviction policy of cache.py:103-191 (`DynamicTokenTrie`), applied to whole prefix slabs.
+"""
+from collections import OrderedDict
+
+import torch
+from transformers.cache_utils import Cache, CacheLayerMixin
+
+
+class _SlabLayer(CacheLayerMixin):
+    """One layer's K / V slabs.  `update` appends one token per row at `owner.pos` and returns the whole slabs; which
+    positions a row may attend to is the 2-D attention mask's business (`SlabKV.attention_mask`)."""
+
+    is_compileable = False
+    is_sliding = False
+
+    def __init__(self, owner, idx):
+        super().__init__()
+        self.owner, self.idx = owner, idx
+
+    def lazy_initialization(self, key_states, value_states):
+        o = self.owner
+        shape_k = (o.n, key_states.shape[1], o.cap, key_states.shape[-1])
+        shape_v = (o.n, value_states.shape[1], o.cap, value_states.shape[-1])
+        self.keys = torch.zeros(shape_k, dtype=key_states.dtype, device=key_states.device)
+        self.values = torch.zeros(shape_v, dtype=value_states.dtype, device=value_states.device)
+        self.is_initialized = True
+
+    def update(self, key_states, value_states, *args, **kwargs):
+        if not self.is_initialized:
+            self.lazy_initialization(key_states, value_states)
+        o = self.owner
+        if key_states.shape[0] != o.n or key_states.shape[-2] != 1:
+            raise ValueError("SlabKV takes one new token for every particle per forward")
+        o.engine.kv_append(self.keys, key_states, o.pos)
+        o.engine.kv_append(self.values, value_states, o.pos)
+        return self.keys, self.values
+
+    def get_mask_sizes(self, query_length):
+        return self.owner.cap, 0
+
+    def get_seq_length(self):
+        return self.owner.cap - 1  # the query sits "after" every slot: causality is expressed by the 2-D mask alone
+
+    def get_max_length(self):
+        return self.owner.cap
+
+
+class SlabKV(Cache):
+    def __init__(self, engine, n, cap, n_layers):
+        self.engine, self.n, self.cap = engine, n, cap
+        self.pos = None  # int32 [n] device: where this forward's token goes (= tokens already held by the row)
+        super().__init__(layers=[_SlabLayer(self, i) for i in range(n_layers)])
+        self._alt = None
+        self._ptrs = None
+
+    # ---- forward-side helpers ----------------------------------------------------------------------------------
+    def attention_mask(self, pos):
+        """[n, cap] 0/1: row i sees its `pos[i]` cached tokens and the one being appended at `pos[i]`."""
+        ar = torch.arange(self.cap, device=pos.device, dtype=pos.dtype)
+        return (ar[None, :] <= pos[:, None]).to(torch.int64)
+
+    # ---- slab plumbing ---------------------------------------------------------------------------------------------
+    def _alloc_like(self, prompt_layers):
+        for layer, (k, v) in zip(self.layers, prompt_layers):
+            if not layer.is_initialized:
+                layer.lazy_initialization(k[:1], v[:1])
+
+    def _tensors(self, which):
+        return [t for layer in which for t in (layer.keys, layer.values)]
+
+    def fill_rows(self, src_layers, src_row_of, len_of):
+        """Rows i with src_row_of[i] >= 0 take the first len_of[i] positions of row src_row_of[i] of `src_layers`
+        ([(K, V)] per layer, each [u, heads, l_src, head_dim], contiguous): fan-out of freshly encoded contexts."""
+        self._alloc_like(src_layers)
+        srcs = [t for kv in src_layers for t in kv]
+        self.engine.kv_gather_rows(srcs, self._tensors(self.layers), src_row_of, len_of)
+
+    def gather(self, src_row_of, len_of):
+        """Resampling: row i becomes a copy of row src_row_of[i] (first len_of[i] positions); rows with
+        src_row_of[i] < 0 are left to be refilled by the caller.  Works into the second slab set, then swaps."""
+        cur = self._tensors(self.layers)
+        if self._alt is None:
+            self._alt = [torch.zeros_like(t) for t in cur]
+        self.engine.kv_gather_rows(cur, self._alt, src_row_of, len_of)
+        for j, layer in enumerate(self.layers):
+            layer.keys, self._alt[2 * j] = self._alt[2 * j], layer.keys
+            layer.values, self._alt[2 * j + 1] = self._alt[2 * j + 1], layer.values
+
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in self._tensors(self.layers) if t is not None) * (2 if self._alt else 1)
+
+
+class PrefixLRU:
+    """Least-recently-used store of cached prompt prefixes under a byte budget.  Keys are trie nodes; evicting an entry
+    drops the node's `past_key_values` (the log-prob rows stay), so later queries fall back to re-encoding."""
+
+    def __init__(self, budget_bytes):
+        self.budget = int(budget_bytes)
+        self.used = 0
+        self._od = OrderedDict()
+        self.evictions = 0
+
+    def put(self, node, kv):
+        self.drop(node)
+        size = kv.nbytes()
+        node.past_key_values = kv
+        self._od[id(node)] = (node, size)
+        self.used += size
+        while self.used > self.budget and len(self._od) > 1:
+            _, (old, sz) = self._od.popitem(last=False)
+            old.past_key_values = None
+            self.used -= sz
+            self.evictions += 1
+
+    def touch(self, node):
+        key = id(node)
+        if key in self._od:
+            self._od.move_to_end(key)
+
+    def drop(self, node):
+        ent = self._od.pop(id(node), None)
+        if ent is not None:
+            self.used -= ent[1]
+            ent[0].past_key_values = None
+
+    def clear(self):
+        for node, _ in self._od.values():
+            node.past_key_values = None
+        self._od.clear()
+        self.used = 0
+
+    def __len__(self):
+        return len(self._od)

@@ -83,11 +83,21 @@ async def autobatched_sis(n_particles, llm, mask_selector, prompt_ids, eos_id):
 # device-resident driver
 # ------------------------------------------------------------------------------------------------
 class DeviceSIS:
-    """N particles over one prompt (or one prompt per particle), masks[0] while fewer than `max_tokens`
-    tokens were generated and masks[1] afterwards (README.md:57-70's masking function)."""
+    """N particles over one prompt (or one prompt per particle, any lengths), masks[0] while fewer than `max_tokens`
+    tokens were generated and masks[1] afterwards (README.md:57-70's masking function).
+
+    use_prefix_kv    the distinct prompts' KV is computed once (hf.py:155-164 `cache_kv`) and every step feeds only the
+                     generated tokens (the reference's algorithm with its prefix cache; BASELINE config 3).
+    use_particle_kv  beyond the reference: every particle owns a row of preallocated KV slabs (kv.SlabKV); step 0
+                     encodes the distinct prompts and fans their KV out, later steps feed ONE token per particle.
+    resample_ess     None: never resample (the reference's README loop).  Otherwise, after a step whose effective
+                     sample size is below `resample_ess * N_total`, the population is resampled systematically from
+                     the all-gathered log-weights; every rank computes the same ancestors (glb_resample_systematic),
+                     contexts and KV rows follow their ancestors, weights are reset to the population mean.
+    """
 
     def __init__(self, llm, n_particles, prompt_ids, max_tokens, eos_id, seed=0, rng="philox", rank=0, world=1,
-                 dist=None, use_prefix_kv=False, use_particle_kv=False):
+                 dist=None, use_prefix_kv=False, use_particle_kv=False, resample_ess=None):
         self.llm, self.eng, self.dev = llm, llm.engine, llm.device
         self.N, self.max_tokens, self.eos_id = n_particles, max_tokens, eos_id
         self.rank, self.world, self.dist = rank, world, dist
@@ -100,9 +110,20 @@ class DeviceSIS:
             self.host_rng = HostRng(seed)
         prompts = prompt_ids if isinstance(prompt_ids[0], (list, tuple)) else [prompt_ids] * n_particles
         assert len(prompts) == n_particles
-        self.prompt_len = torch.tensor([len(p) for p in prompts], dtype=torch.int32, device=self.dev)
+        self._prompt_len0 = torch.tensor([len(p) for p in prompts], dtype=torch.int32, device=self.dev)
         self.max_prompt = max(len(p) for p in prompts)
-        self._mask_by_row = len({len(p) for p in prompts}) == 1
+        if world > 1:  # one token-matrix width over all ranks: rows travel between ranks when resampling
+            mp_ = torch.tensor([self.max_prompt], dtype=torch.int64, device=self.dev)
+            dist.all_reduce(mp_, op=dist.ReduceOp.MAX)
+            self.max_prompt = int(mp_.item())
+        # the README mask is a function of the number of generated tokens; with prompts of ONE length (over all
+        # ranks, if particles can migrate) that makes it a function of the context, i.e. of the logits row
+        lens = {len(p) for p in prompts}
+        if world > 1 and resample_ess is not None:
+            mm = torch.tensor([min(lens), -max(lens)], dtype=torch.int64, device=self.dev)
+            dist.all_reduce(mm, op=dist.ReduceOp.MIN)
+            lens = {int(mm[0]), int(-mm[1])}
+        self._mask_by_row = len(lens) == 1
         self._rep = None
         self.cap = self.max_prompt + max_tokens + 1
         ctx = np.zeros((n_particles, self.cap), np.int32)
@@ -115,13 +136,11 @@ class DeviceSIS:
         if use_prefix_kv:
             distinct = sorted({tuple(p) for p in prompts})
             self._build_prefixes(distinct)
-        # Device-resident per-particle KV (beyond the reference, which re-encodes every context every step,
-        # hf.py:202-288): step 0 encodes the distinct prompts once and fans their KV out to the particles; every
-        # later step feeds ONE token per particle against its own KV rows.  Needs equal prompt lengths.
         self.particle_kv = bool(use_particle_kv)
         if self.particle_kv:
-            assert len({len(p) for p in prompts}) == 1, "per-particle KV needs prompts of one length"
             assert not use_prefix_kv
+        self.resample_ess = resample_ess
+        self.n_resamples = 0
         self.pkv = None
         self.reset()
 
@@ -144,6 +163,7 @@ class DeviceSIS:
 
     def reset(self):
         self.contexts = self._ctx0.clone()
+        self.prompt_len = self._prompt_len0.clone()
         self.lengths = self.prompt_len.clone()
         self.active = torch.ones(self.N, dtype=torch.int32, device=self.dev)
         self.log_weights = torch.zeros(self.N, dtype=torch.float32, device=self.dev)
@@ -152,27 +172,58 @@ class DeviceSIS:
         self.last_stats = None
         self.kernel_events = []
         self.pkv = None
+        self._kv_stale = None  # bool [N]: rows whose KV has to be rebuilt from the context (ancestor on another rank)
+        # active particles over all ranks as of the last exchange (device scalar; read with the step's one D2H copy)
+        self._global_active = torch.tensor(self.N * self.world, dtype=torch.int32, device=self.dev)
+        self.all_weights = None
 
     # -------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def _step_particle_kv(self, time_kernel):
-        """Steps t >= 1 with per-particle KV: one new token per particle, no dedup, logits row i = particle i."""
-        from transformers import DynamicCache
-
+    def _encode_into_slabs(self, rows):
+        """(Re)build the KV rows `rows` (int64 device indices, or None = all) from their contexts: the distinct contexts
+        are encoded once (dedup as in hf.py:214-220) and their KV fanned out with one gather launch."""
         eng, llm, dev, N = self.eng, self.llm, self.dev, self.N
-        n_active = int(self.active.sum().item())  # the step's only D2H sync
-        cache_len = self.max_prompt + self.t - 1  # every particle's KV holds prompt + t - 1 tokens
-        rows = torch.arange(N, device=dev)
-        # active particles feed their newest token; finished ones a dummy (their rows are ignored afterwards)
-        newest = self.contexts[rows, (self.lengths - 1).clamp_min(0).long()]
-        ids = torch.where(self.active > 0, newest, torch.zeros_like(newest)).view(N, 1).long()
-        pos = torch.full((N, 1), cache_len, dtype=torch.long, device=dev)
-        out = llm._body(input_ids=ids, position_ids=pos, past_key_values=self.pkv, use_cache=True)
-        self.pkv = out.past_key_values
-        logits = llm._lm_head(out.last_hidden_state[:, 0])  # [N, V]
-        return self._finish_step(logits, None, N, n_active, time_kernel, l_max=1)
+        ctx_flat = self.contexts.view(-1)
+        # a row's KV holds every token of its context but the newest one (that one is fed by the next forward); at
+        # t == 0 the whole prompt is encoded and its last position also yields the step's logits
+        kv_len = self.lengths if self.t == 0 else (self.lengths - 1).clamp_min(1)
+        want = torch.ones(N, dtype=torch.bool, device=dev) if rows is None else \
+            torch.zeros(N, dtype=torch.bool, device=dev).index_fill_(0, rows, True)
+        lens_eff = torch.where(want, kv_len, torch.ones_like(kv_len))  # rows not rebuilt collapse to a 1-token stub
+        group_of, rep, ng = eng.group_contexts(ctx_flat, self.starts, lens_eff)
+        U = int(ng.item())
+        l_max = int(lens_eff.max().item())
+        ids, am, pos, _ = eng.gather_padded(ctx_flat, self.starts, lens_eff, rep, U, None, 0, 0, l_max)
+        out = llm._body(input_ids=ids, attention_mask=am, position_ids=pos, use_cache=True)
+        src = [(ly.keys.contiguous(), ly.values.contiguous()) for ly in out.past_key_values.layers]
+        if self.pkv is None:
+            from .kv import SlabKV
 
-    def _finish_step(self, logits, group_of, U, n_active, time_kernel, l_max):
+            self.pkv = SlabKV(eng, N, self.cap, len(src))
+        src_row = torch.where(want, group_of, torch.full_like(group_of, -1))
+        self.pkv.fill_rows(src, src_row, lens_eff)
+        return out, group_of, rep, U
+
+    @torch.no_grad()
+    def _step_particle_kv(self, time_kernel):
+        """Steps t >= 1 with per-particle KV: one new token per particle (logits row i = particle i), ragged lengths."""
+        eng, llm, dev, N = self.eng, self.llm, self.dev, self.N
+        head = torch.stack([self.active.sum().to(torch.int32), self._global_active]).cpu()  # the step's one D2H copy
+        n_active, n_global = int(head[0]), int(head[1])
+        if self._kv_stale is not None:
+            self._encode_into_slabs(torch.nonzero(self._kv_stale).flatten())
+            self._kv_stale = None
+        rows = torch.arange(N, device=dev)
+        pos = (self.lengths - 1).clamp_min(0)  # tokens already in the row's KV = index of the newest token
+        newest = self.contexts[rows, pos.long()]
+        ids = torch.where(self.active > 0, newest, torch.zeros_like(newest)).view(N, 1).long()
+        self.pkv.pos = pos
+        out = llm._body(input_ids=ids, position_ids=pos.view(N, 1).long(), attention_mask=self.pkv.attention_mask(pos),
+                        past_key_values=self.pkv, use_cache=True)
+        logits = llm._lm_head(out.last_hidden_state[:, 0])  # [N, V]
+        return self._finish_step(logits, None, N, n_active, n_global, time_kernel, l_max=1)
+
+    def _finish_step(self, logits, group_of, U, n_active, n_global, time_kernel, l_max):
         eng, llm, N = self.eng, self.llm, self.N
         V = logits.shape[-1]
         mask_id = ((self.lengths - self.prompt_len) >= self.max_tokens).to(torch.int32)
@@ -202,23 +253,47 @@ class DeviceSIS:
         self.t += 1
         self.max_len_now = min(self.max_len_now + 1, self.cap)
         self.last_stats = dict(n_unique=U, n_active=n_active, l_max=l_max, n_rows=U)
+        self._exchange()
+        if self.resample_ess is not None:
+            self._maybe_resample()
+        return U, n_global
+
+    def _exchange(self):
+        """All-gather of the per-shard log-weights and active counts (RCCL over xGMI when the backend is nccl): every
+        rank then holds the population's weights (README.md:108-110 needs all of them) and knows whether anybody,
+        anywhere, is still generating - the loop's termination test is collective."""
+        count = self.active.sum().to(torch.float32).view(1)
         if self.world > 1:
-            self.all_weights = self.gather_weights()
-        return U, n_active
+            mine = torch.cat([self.log_weights, count])
+            out = torch.empty((self.world, self.N + 1), dtype=torch.float32, device=self.dev)
+            self.dist.all_gather_into_tensor(out.view(-1), mine)
+            self.all_weights = out[:, :self.N].reshape(-1)
+            self._global_active = out[:, self.N].sum().to(torch.int32)
+        else:
+            self.all_weights = self.log_weights
+            self._global_active = count[0].to(torch.int32)
 
     @torch.no_grad()
     def step(self, time_kernel=False):
-        """One SIS step for every active particle.  Returns (n_unique, n_active_before)."""
+        """One SIS step for every active particle.  Returns (n_unique, particles active over ALL ranks before it)."""
         eng, llm, dev, N = self.eng, self.llm, self.dev, self.N
         if self.particle_kv and self.t > 0:
             return self._step_particle_kv(time_kernel)
         ctx_flat = self.contexts.view(-1)
         # finished particles still occupy a row: give them their 1-token stub so they dedup to one group
         lengths_eff = torch.where(self.active > 0, self.lengths, torch.ones_like(self.lengths))
+        if self.particle_kv:  # step 0: encode the distinct prompts, keep their KV, fan it out to the particles
+            head = torch.stack([self.active.sum().to(torch.int32), self._global_active]).cpu()
+            n_active, n_global = int(head[0]), int(head[1])
+            out, group_of, rep, U = self._encode_into_slabs(None)
+            self._rep = rep
+            last = (self.lengths[rep[:U].long()] - 1).long()
+            h_last = out.last_hidden_state[torch.arange(U, device=dev), last]
+            return self._finish_step(llm._lm_head(h_last), group_of, U, n_active, n_global, time_kernel, self.max_len_now)
         group_of, rep, ng = eng.group_contexts(ctx_flat, self.starts, lengths_eff)
         self._rep = rep
-        head = torch.stack([ng[0], self.active.sum().to(torch.int32)]).cpu()  # the step's only D2H sync
-        U, n_active = int(head[0]), int(head[1])
+        head = torch.stack([ng[0], self.active.sum().to(torch.int32), self._global_active]).cpu()  # the step's one D2H copy
+        U, n_active, n_global = int(head[0]), int(head[1]), int(head[2])
         base, p_max, cache = None, 0, None
         # at t == 0 every context *is* its prompt, so no cached prefix is a proper prefix yet (hf.py:334-342)
         use_kv = self.prefixes is not None and self.t > 0
@@ -238,19 +313,11 @@ class DeviceSIS:
             data = [tuple(eng.gather_kv_padded(P["ptrs"][l][j], P["lengths"], pref_u, kv0.heads, kv0.head_dim, p_max,
                                                kv0.dtype) for j in range(2)) for l in range(len(kv0.layers))]
             cache = DynamicCache(ddp_cache_data=data)
-        want_kv = self.particle_kv  # step 0: keep the prompts' KV and fan it out to the particles
-        out = llm._body(input_ids=ids, attention_mask=None if want_kv else am, position_ids=pos, past_key_values=cache,
-                        use_cache=(cache is not None) or want_kv)
-        hidden = out.last_hidden_state
-        if want_kv:
-            from transformers import DynamicCache
-
-            g = group_of.long()
-            self.pkv = DynamicCache(ddp_cache_data=[(ly.keys.index_select(0, g), ly.values.index_select(0, g))
-                                                    for ly in out.past_key_values.layers])
-        h_last = hidden[torch.arange(U, device=dev), last.long()]
+        out = llm._body(input_ids=ids, attention_mask=am, position_ids=pos, past_key_values=cache,
+                        use_cache=cache is not None)
+        h_last = out.last_hidden_state[torch.arange(U, device=dev), last.long()]
         logits = llm._lm_head(h_last)  # [U, V]
-        return self._finish_step(logits, group_of, U, n_active, time_kernel, l_max)
+        return self._finish_step(logits, group_of, U, n_active, n_global, time_kernel, l_max)
 
     def _parity_noise(self, group_of, V):
         """Exp(1) rows in the order the reference's particles reach torch.multinomial: by dedup group
@@ -267,24 +334,67 @@ class DeviceSIS:
 
     # -------------------------------------------------------------------------------------------
     def gather_weights(self):
-        """All-gather of the per-shard log-weights (RCCL over xGMI when backend is nccl); every rank then
-        holds the population's weights and derives identical normalised weights / ESS."""
-        out = torch.empty(self.N * self.world, dtype=torch.float32, device=self.dev)
-        self.dist.all_gather_into_tensor(out, self.log_weights)
-        return out
+        """The population's log-weights as of the last step (all ranks hold the same vector)."""
+        if self.all_weights is None:
+            self._exchange()
+        return self.all_weights
 
     def normalized_weights(self):
-        lw = self.gather_weights() if self.world > 1 else self.log_weights
-        return self.eng.normalize_weights(lw)  # (probs, [logsumexp, ESS])  README.md:108-110
+        return self.eng.normalize_weights(self.gather_weights())  # (probs, [logsumexp, ESS])  README.md:108-110
+
+    @torch.no_grad()
+    def _maybe_resample(self):
+        n_total = self.N * self.world
+        if self.resample_ess < 1.0:  # adaptive: needs the ESS on the host (one scalar; identical on every rank)
+            _, stats = self.eng.normalize_weights(self.all_weights)
+            if float(stats[1].item()) >= self.resample_ess * n_total:
+                return
+        self.resample()
+
+    @torch.no_grad()
+    def resample(self):
+        """Systematic resampling of the whole population, replicated on every rank: identical gathered weights give
+        identical ancestors (integer comb, one Philox draw keyed by (seed, step)); slot i of rank r takes ancestor
+        anc[r*N + i].  Token matrices are all-gathered (N_total x cap int32) and gathered by ancestor; KV rows follow
+        a local ancestor with one gather launch and are rebuilt from the context when the ancestor lived elsewhere."""
+        eng, N, dev = self.eng, self.N, self.dev
+        n_total = N * self.world
+        anc, lse = eng.resample_systematic(self.all_weights, self.seed ^ 0x5eed5a11, self.t)
+        mine = anc[self.rank * N:(self.rank + 1) * N].contiguous()
+        meta = torch.stack([self.lengths, self.prompt_len, self.active], dim=1).contiguous()  # [N, 3] int32
+        if self.world > 1:
+            all_ctx = torch.empty((n_total, self.cap), dtype=torch.int32, device=dev)
+            all_meta = torch.empty((n_total, 3), dtype=torch.int32, device=dev)
+            self.dist.all_gather_into_tensor(all_ctx.view(-1), self.contexts.view(-1))
+            self.dist.all_gather_into_tensor(all_meta.view(-1), meta.view(-1))
+        else:
+            all_ctx, all_meta = self.contexts, meta
+        self.contexts = eng.gather_rows_i32(all_ctx, mine)
+        m = eng.gather_rows_i32(all_meta, mine)
+        self.lengths, self.prompt_len, self.active = m[:, 0].contiguous(), m[:, 1].contiguous(), m[:, 2].contiguous()
+        # equal weights: log of the population's mean weight
+        self.log_weights = (lse - float(np.log(n_total))).expand(N).contiguous()
+        if self.particle_kv and self.pkv is not None:
+            local = mine - self.rank * N
+            is_local = (local >= 0) & (local < N)
+            src = torch.where(is_local, local, torch.full_like(local, -1))
+            kv_len = (self.lengths - 1).clamp_min(0)
+            self.pkv.gather(src, kv_len)
+            stale = ~is_local
+            self._kv_stale = stale if bool(stale.any().item()) else None
+        self.n_resamples += 1
+        self._exchange()
 
     @torch.no_grad()
     def run(self, max_steps=None):
+        """README.md:94-98 `while any(p.active ...)`, with the test taken over ALL ranks: every rank runs the same number
+        of steps, so the per-step collectives stay matched even when one shard finishes early."""
         steps = 0
         limit = max_steps if max_steps is not None else self.max_tokens + 1
         while steps < limit:
-            _, n_active = self.step()
+            _, n_global = self.step()
             steps += 1
-            if n_active == 0:
+            if n_global == 0:  # nobody was active before this step: it was a no-op everywhere
                 break
         return steps
 
@@ -299,18 +409,32 @@ class DeviceSIS:
 # bench.py workload
 # ------------------------------------------------------------------------------------------------
 class SisBenchWorkload:
-    """1024 particles per GPU, GPT-2-small-shaped random-init fp32 model, prompt length 8, <= 10 new tokens,
-    two shared {0,-inf} masks (README.md:57-70 shape), in-kernel Philox draws.  BASELINE.json config 2."""
+    """N particles per GPU on a random-init model, prompt length 8, <= 10 new tokens, two shared {0,-inf} masks
+    (README.md:57-70 shape), in-kernel Philox draws.  model "gpt2": GPT-2-small shape, fp32, 1024 particles
+    (BASELINE.json config 2; with n_prompts / prefix_kv config 3).  model "llama-3.2-1b": Llama-3.2-1B shape, bf16,
+    V = 128256, 512 particles (config 4: 4096 over 8 GPUs)."""
 
-    particles_per_step = 1024
-
-    def __init__(self, eng, dev, rank, world, dist, n_particles=1024, max_tokens=10, prefix_kv=False, particle_kv=False):
-        from transformers import GPT2Config
-
+    def __init__(self, eng, dev, rank, world, dist, n_particles=1024, max_tokens=10, prefix_kv=False, particle_kv=False,
+                 model="gpt2", n_prompts=1, resample=False):
         from .llm import AsyncAmdLM
 
-        cfg = GPT2Config()  # gpt2 small: 12 layers, d=768, 12 heads, vocab 50257
-        self.llm = AsyncAmdLM.from_config(cfg, None, device=dev, dtype=torch.float32, seed=1234, engine=eng,
+        if model == "gpt2":
+            from transformers import GPT2Config
+
+            cfg, dtype = GPT2Config(), torch.float32  # gpt2 small: 12 layers, d=768, 12 heads, vocab 50257
+            self.model_name = "gpt2-small shape (random init, fp32)"
+        else:
+            from transformers import LlamaConfig
+
+            cfg = LlamaConfig(vocab_size=128256, hidden_size=2048, intermediate_size=8192, num_hidden_layers=16,
+                              num_attention_heads=32, num_key_value_heads=8, head_dim=64, max_position_embeddings=4096,
+                              rope_theta=500000.0, rms_norm_eps=1e-5, tie_word_embeddings=True, bos_token_id=128000,
+                              eos_token_id=128001)
+            dtype = torch.bfloat16
+            self.model_name = "Llama-3.2-1B shape (random init, bf16)"
+        self.dtype_name = "f32" if dtype == torch.float32 else "bf16"
+        self.elem = 4 if dtype == torch.float32 else 2
+        self.llm = AsyncAmdLM.from_config(cfg, None, device=dev, dtype=dtype, seed=1234, engine=eng,
                                           batch_size=n_particles)
         V = cfg.vocab_size
         g = torch.Generator(device=dev)
@@ -322,11 +446,16 @@ class SisBenchWorkload:
         self.llm.register_masks(torch.stack([valid, eos1]))
         self.V, self.N, self.max_tokens = V, n_particles, max_tokens
         self.particles_per_step = n_particles
-        self.sis = DeviceSIS(self.llm, n_particles, list(range(100, 108)), max_tokens, cfg.eos_token_id,
-                             seed=1234 + rank, rank=rank, world=world, dist=dist, use_prefix_kv=prefix_kv,
-                             use_particle_kv=particle_kv)
+        rs = np.random.default_rng(99)
+        base = [list(range(100, 108))] + [[int(t) for t in rs.integers(1000, 30000, 8)] for _ in range(n_prompts - 1)]
+        prompts = [base[i % n_prompts] for i in range(n_particles)] if n_prompts > 1 else base[0]
+        self.n_prompts = n_prompts
+        self.sis = DeviceSIS(self.llm, n_particles, prompts, max_tokens, cfg.eos_token_id,
+                             seed=1234, rank=rank, world=world, dist=dist, use_prefix_kv=prefix_kv,
+                             use_particle_kv=particle_kv, resample_ess=1.0 if resample else None)
         self.prefix_kv = prefix_kv
         self.particle_kv = particle_kv
+        self.resample = resample
         self.kernel_bytes = None
         self._events = []
         self._bytes = []
@@ -342,10 +471,10 @@ class SisBenchWorkload:
         if self.sis.t >= self.max_tokens:  # population finished: start the next 10-step loop
             self._collect()
             self.sis.reset()
-        U, n_active = self.sis.step(time_kernel=timed)
+        U, _ = self.sis.step(time_kernel=timed)
         if timed:
-            # algorithmic bytes of this launch: the unique logits rows once + mask bit rows + outputs
-            self._bytes.append(U * self.V * 4 + 2 * ((self.V + 31) // 32) * 4 + self.N * 8)
+            # algorithmic bytes of this call: the unique logits rows once + mask bit rows + outputs
+            self._bytes.append(U * self.V * self.elem + 2 * ((self.V + 31) // 32) * 4 + self.N * 8)
             self.unique_hist.append(U)
 
     def _collect(self):
@@ -358,10 +487,12 @@ class SisBenchWorkload:
         return np.array([a.elapsed_time(b) * 1e3 for a, b in self._events])
 
     def config(self):
-        return {"workload": "SIS step: 1024 particles/GPU, gpt2-small shape (random init, fp32), prompt len 8, <=10 new "
+        return {"workload": f"SIS step: {self.N} particles/GPU, {self.model_name}, prompt len 8, <=10 new "
                             "tokens, 2 shared bit masks, device-resident population, Philox draws"
+                            + (f", {self.n_prompts} distinct shared prompts" if self.n_prompts > 1 else "")
                             + (", prompt KV cached (cache_kv semantics, BASELINE config 3)" if self.prefix_kv else "")
-                            + (", device-resident per-particle KV (one new token per particle per step; NOT the "
-                               "reference's re-encode-every-step algorithm)" if self.particle_kv else ""),
+                            + (", device-resident per-particle KV slabs (one new token per particle per step; NOT the "
+                               "reference's re-encode-every-step algorithm)" if self.particle_kv else "")
+                            + (", systematic resampling after every step" if self.resample else ""),
                 "particles_per_gpu": self.N, "vocab": self.V, "rng": "philox",
                 "mean_unique_contexts_per_step": float(np.mean(self.unique_hist)) if self.unique_hist else None}

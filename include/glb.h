@@ -231,6 +231,41 @@ int glb_normalize_weights(const float *log_weights, int64_t n, float *out_probs,
                           void *hip_stream);
 
 /*
+ * Device-resident particle state (SURVEY.md §8 f1 / e): per-particle KV in preallocated slabs
+ * [n_rows, heads, cap, head_dim] (one per layer and K/V) instead of the reference's per-query tuples that are
+ * zero-padded and concatenated every batch (hf.py:33-53,247-271) or per-token trie slices (cache.py:103-191).
+ *
+ * glb_kv_append:      slab[i, h, pos[i], :] = new_rows[i, h, :]   - the new token's K or V of every particle;
+ *                     new_rows is addressed by element strides (it is usually a transposed view).
+ * glb_kv_gather_rows: dst[t][i, h, p, :] = src[t][src_row_of[i], h, p, :] for p < len_of[i], all n_tensors
+ *                     (layer, K|V) slabs in one launch through device arrays of device pointers.  Fans the KV of
+ *                     the distinct prompts out to the particles and gathers ancestors' KV after a resampling
+ *                     step; src_row_of[i] < 0 leaves row i untouched.  src and dst must not alias.
+ * glb_gather_rows_i32: dst[i, :width] = src[row_of[i], :width]   - the particles' token matrices.
+ */
+int glb_kv_append(void *slab, const void *new_rows, const int32_t *pos, int64_t n_rows, int64_t heads, int64_t cap,
+                  int64_t head_dim, int64_t new_stride_row, int64_t new_stride_head, int32_t elem_bytes,
+                  void *hip_stream);
+int glb_kv_gather_rows(const void *const *src, void *const *dst, int64_t n_tensors, int64_t n_rows, int64_t heads,
+                       int64_t head_dim, int64_t src_cap, int64_t dst_cap, const int32_t *src_row_of,
+                       const int32_t *len_of, int32_t elem_bytes, void *hip_stream);
+int glb_gather_rows_i32(const int32_t *src, int64_t src_ld, const int32_t *row_of, int64_t n, int64_t width,
+                        int32_t *dst, int64_t dst_ld, void *hip_stream);
+
+/*
+ * Systematic resampling of the whole population from the all-gathered log-weights (the step the all-gather of
+ * README.md:108-110's weights exists for; the reference itself stops at the normalised weights).  Exact integer
+ * comb over the fixed-point weights of glb_normalize_weights with one Philox draw keyed by (seed, offset):
+ * every rank that holds the same gathered vector computes the same ancestors.
+ *   out_ancestors [n] int32 (non-decreasing); out_stats [1] optional: logsumexp of the weights
+ *   workspace: glb_resample_workspace(n) bytes, 8-byte aligned.  n <= 262144.
+ */
+size_t glb_resample_workspace(int64_t n);
+int glb_resample_systematic(const float *log_weights, int64_t n, uint64_t seed, uint64_t offset,
+                            int32_t *out_ancestors, float *out_stats, void *workspace, size_t workspace_bytes,
+                            void *hip_stream);
+
+/*
  * Host helper for GLB_RNG_NOISE: fills out[0..n) with the float32 Exp(1) variates
  * torch.empty(n).exponential_(1, generator) produces on CPU for a generator whose MT19937 state is
  * `state` (seeded with glb_mt19937_seed).  Serial by construction (one 64-bit draw = two MT words per

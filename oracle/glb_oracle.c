@@ -470,6 +470,42 @@ int orc_normalize_weights(const float *lw, int64_t n, float *out_probs, float *o
   return 0;
 }
 
+/* contract of glb_resample_systematic: exact integer comb over the fixed-point weights (the
+ * reference itself ends at the normalised weights, README.md:108-110) */
+int orc_resample_systematic(const float *lw, int64_t n, uint64_t seed, uint64_t offset, int32_t *anc,
+                            float *out_stats) {
+  float m = -INFINITY;
+  for (int64_t i = 0; i < n; ++i)
+    if (lw[i] > m) m = lw[i];
+  float N = glb_exp_n(m);
+  uint64_t *cum = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)n);
+  if (!cum) return 4;
+  uint64_t S = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    S += glb_fix_term(lw[i], N);
+    cum[i] = S;
+  }
+  if (out_stats) out_stats[0] = S ? (float)glb_log_fix(S, (int32_t)N - GLB_FIX_FRAC) : -INFINITY;
+  if (S == 0) {
+    for (int64_t k = 0; k < n; ++k) anc[k] = (int32_t)k;
+    free(cum);
+    return 0;
+  }
+  uint32_t ctr[4] = {0xa5c3u, 0x5e5au, (uint32_t)offset, (uint32_t)(offset >> 32)};
+  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, rnd[4];
+  orc_philox4x32_10(ctr, key, rnd);
+  uint64_t R = ((uint64_t)rnd[1] << 32) | rnd[0];
+  uint64_t U0 = mulhi64(R, S), un = (uint64_t)n, a = S / un, b = S % un;
+  int64_t i = 0;
+  for (int64_t k = 0; k < n; ++k) { /* T_k is non-decreasing in k: one forward sweep */
+    uint64_t Tk = (uint64_t)k * a + (U0 + (uint64_t)k * b) / un;
+    while (cum[i] <= Tk) ++i;
+    anc[k] = (int32_t)i;
+  }
+  free(cum);
+  return 0;
+}
+
 /* ---------------------------------------------------------------- layer A: reference semantics */
 
 /* MT19937 as used by torch's CPUGeneratorImpl (at::mt19937; the reference reaches it through

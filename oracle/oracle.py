@@ -236,3 +236,15 @@ def particles_advance(ctx, lengths, active, lw, logZ, tok, eos, max_len):
                                 _p(np.ascontiguousarray(logZ, dtype=np.float32)),
                                 _p(np.ascontiguousarray(tok, dtype=np.int32)), C.c_int64(n),
                                 C.c_int32(eos), C.c_int32(max_len))
+
+
+def resample_systematic(log_weights, seed=0, offset=0):
+    """Layer-B systematic resampling: (ancestors int32 [n], logsumexp of the weights)."""
+    lw = np.ascontiguousarray(log_weights, dtype=np.float32)
+    n = len(lw)
+    anc = np.empty(n, np.int32)
+    stats = np.empty(1, np.float32)
+    rc = lib().orc_resample_systematic(_p(lw), C.c_int64(n), C.c_uint64(seed), C.c_uint64(offset), _p(anc), _p(stats))
+    if rc:
+        raise RuntimeError(f"orc_resample_systematic rc={rc}")
+    return anc, float(stats[0])

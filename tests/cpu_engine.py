@@ -128,3 +128,27 @@ class CpuOracleEngine:
     def normalize_weights(self, log_weights):
         p, s = O.normalize_weights(_np(log_weights))
         return torch.from_numpy(p), torch.from_numpy(s)
+
+    # ---- device-resident particle state (torch / oracle stand-ins) ---------------------------------------------
+    def kv_append(self, slab, new_rows, pos):
+        n = slab.shape[0]
+        slab[torch.arange(n), :, pos.long()] = new_rows[:, :, 0]
+
+    def kv_gather_rows(self, srcs, dsts, src_row_of, len_of):
+        sr, ln = _np(src_row_of), _np(len_of)
+        for s_, d_ in zip(srcs, dsts):
+            for i in range(d_.shape[0]):
+                if sr[i] >= 0:
+                    L = min(int(ln[i]), s_.shape[2], d_.shape[2])
+                    d_[i, :, :L] = s_[sr[i], :, :L]
+
+    def gather_rows_i32(self, src, row_of, out=None):
+        res = src[row_of.long()].contiguous()
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
+
+    def resample_systematic(self, log_weights, seed, offset):
+        anc, lse = O.resample_systematic(_np(log_weights), seed, offset)
+        return torch.from_numpy(anc), torch.tensor([lse], dtype=torch.float32)

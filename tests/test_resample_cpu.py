@@ -1,0 +1,166 @@
+"""Resampling and device-resident particle state on CPU (host logic over the oracle-backed engine double):
+the systematic comb against a float64 restatement, slab KV == re-encode == prefix KV on GPT-2- and Llama-shaped
+models with ragged prompts, and 1-rank == 2-rank (gloo) through several resampling steps, including a shard that
+finishes early."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_systematic_comb_matches_float64(oracle):
+    rs = np.random.default_rng(5)
+    for n in (1, 2, 7, 64, 1000, 4096):
+        lw = (rs.standard_normal(n) * 3).astype(np.float32)
+        lw[rs.random(n) < 0.1] = -np.inf
+        if not np.isfinite(lw).any():
+            lw[0] = 0.0
+        anc, lse = oracle.resample_systematic(lw, seed=11, offset=n)
+        assert (np.diff(anc) >= 0).all() and anc.min() >= 0 and anc.max() < n
+        w = np.exp(lw.astype(np.float64) - np.logaddexp.reduce(lw.astype(np.float64)))
+        counts = np.bincount(anc, minlength=n)
+        assert np.abs(counts - n * w).max() < 1.0 + 1e-6  # systematic resampling: every count within one of n*w
+        assert counts[~np.isfinite(lw)].sum() == 0
+        assert abs(lse - np.logaddexp.reduce(lw.astype(np.float64))) < 1e-5
+        # same weights, another draw: still a valid comb; same draw: same ancestors
+        assert np.array_equal(anc, oracle.resample_systematic(lw, seed=11, offset=n)[0])
+    anc, _ = oracle.resample_systematic(np.full(8, -np.inf, np.float32), 1, 1)
+    assert np.array_equal(anc, np.arange(8))  # no mass anywhere: identity
+
+
+class Tok:
+    pad_token_id = None
+    eos_token_id = 0
+
+
+def _tiny(kind, seed=0):
+    import genlm_backend_amd  # noqa: F401
+    from genlm_backend_amd.llm import AsyncAmdLM
+    from tests.cpu_engine import CpuOracleEngine
+    from transformers import GPT2Config, GPT2LMHeadModel, LlamaConfig, LlamaForCausalLM
+
+    torch.manual_seed(seed)
+    V = 300
+    if kind == "gpt2":
+        m = GPT2LMHeadModel(GPT2Config(vocab_size=V, n_positions=64, n_embd=32, n_layer=2, n_head=2, bos_token_id=0,
+                                       eos_token_id=0)).eval()
+    else:  # RoPE + grouped-query attention
+        m = LlamaForCausalLM(LlamaConfig(vocab_size=V, hidden_size=32, intermediate_size=64, num_hidden_layers=2,
+                                         num_attention_heads=4, num_key_value_heads=2, head_dim=8,
+                                         max_position_embeddings=64, bos_token_id=0, eos_token_id=0)).eval()
+    llm = AsyncAmdLM(m, None, batch_size=64, engine=CpuOracleEngine())
+    llm.tokenizer = Tok()
+    masks = torch.zeros(2, V)
+    masks[0, ::3] = float("-inf")
+    masks[0, 7:40] = float("-inf")  # uneven allowed mass across contexts -> uneven weights -> real resampling
+    masks[1, :] = float("-inf")
+    masks[1, 0] = 0
+    llm.register_masks(masks)
+    return llm
+
+
+PROMPTS = [[5, 6, 7, 8], [5, 6, 7, 8], [9, 10, 11], [12, 13, 14, 15, 16], [9, 10, 11], [20, 21], [5, 6, 7, 8], [33]]
+
+
+@pytest.mark.parametrize("kind", ["gpt2", "llama"])
+def test_slab_kv_equals_reencode_and_prefix_kv(kind):
+    from genlm_backend_amd.sis import DeviceSIS
+
+    llm = _tiny(kind)
+    res = {}
+    for mode in ("plain", "pkv", "prefix"):
+        s = DeviceSIS(llm, len(PROMPTS), PROMPTS, max_tokens=6, eos_id=0, seed=3, use_particle_kv=mode == "pkv",
+                      use_prefix_kv=mode == "prefix")
+        s.run()
+        res[mode] = s.results()
+    assert res["plain"][0] == res["pkv"][0] == res["prefix"][0]
+    assert np.abs(res["plain"][1] - res["pkv"][1]).max() < 1e-4
+    assert np.abs(res["plain"][1] - res["prefix"][1]).max() < 1e-4
+    # with resampling after every step the KV rows follow their ancestors
+    a = DeviceSIS(llm, len(PROMPTS), PROMPTS, max_tokens=6, eos_id=0, seed=3, use_particle_kv=True, resample_ess=1.0)
+    a.run()
+    b = DeviceSIS(llm, len(PROMPTS), PROMPTS, max_tokens=6, eos_id=0, seed=3, resample_ess=1.0)
+    b.run()
+    assert a.n_resamples >= 2 and a.results()[0] == b.results()[0]
+    assert np.abs(a.results()[1] - b.results()[1]).max() < 1e-4
+
+
+def _worker(rank, world, port, out_dir, kind, pkv):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from genlm_backend_amd.sis import DeviceSIS
+
+    llm = _tiny(kind)
+    n = len(PROMPTS) // world
+    mine = PROMPTS[rank * n:(rank + 1) * n]
+    sis = DeviceSIS(llm, n, mine, max_tokens=6, eos_id=0, seed=3, rank=rank, world=world, dist=dist,
+                    use_particle_kv=pkv, resample_ess=1.0)
+    steps = sis.run()
+    ctx, lw = sis.results()
+    width = 8
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), ctx=np.array([list(c) + [-1] * (width - len(c)) for c in ctx]),
+             lw=lw, all_lw=sis.all_weights.numpy(), steps=steps, n_res=sis.n_resamples)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("kind,pkv", [("gpt2", True), ("llama", False)])
+def test_two_ranks_equal_one_through_resampling(tmp_path, kind, pkv):
+    """Replicated deterministic resampling: two gloo ranks (4 particles each; ancestors cross the shard boundary, so
+    contexts travel and KV rows are rebuilt) end with the same tokens and weights as one process with all 8."""
+    world, port = 2, 29741 + os.getpid() % 200
+    mp.start_processes(_worker, args=(world, port, str(tmp_path), kind, pkv), nprocs=world, join=True,
+                       start_method="spawn")
+    r = [np.load(tmp_path / f"rank{i}.npz") for i in range(world)]
+    assert int(r[0]["steps"]) == int(r[1]["steps"]) and int(r[0]["n_res"]) >= 2
+    assert np.array_equal(r[0]["all_lw"], r[1]["all_lw"])
+    from genlm_backend_amd.sis import DeviceSIS
+
+    one = DeviceSIS(_tiny(kind), len(PROMPTS), PROMPTS, max_tokens=6, eos_id=0, seed=3, use_particle_kv=pkv,
+                    resample_ess=1.0)
+    one.run()
+    ctx, lw = one.results()
+    got = [[int(t) for t in row if t >= 0] for row in np.concatenate([r[0]["ctx"], r[1]["ctx"]])]
+    assert got == [list(map(int, c)) for c in ctx]
+    assert np.abs(lw - r[0]["all_lw"]).max() < 1e-4
+
+
+def _early_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from genlm_backend_amd.sis import DeviceSIS
+
+    llm = _tiny("gpt2")
+    # rank 0's particles may only emit EOS (mask 1 from the first step: max_tokens = 0 generated tokens allowed)
+    sis = DeviceSIS(llm, 4, PROMPTS[:4], max_tokens=0 if rank == 0 else 5, eos_id=0, seed=3, rank=rank, world=world,
+                    dist=dist)
+    sis.cap = max(sis.cap, 16)
+    steps = sis.run(max_steps=7)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), steps=steps, all_lw=sis.all_weights.numpy(),
+             active=int(sis.active.sum()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_shard_that_finishes_early_keeps_the_collectives_matched(tmp_path):
+    """One rank's particles all hit EOS at step 1 while the other rank keeps generating: both ranks run the same
+    number of steps (the loop's termination test is taken over all ranks), nothing hangs, weights agree."""
+    world, port = 2, 29941 + os.getpid() % 200
+    mp.start_processes(_early_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    r = [np.load(tmp_path / f"rank{i}.npz") for i in range(world)]
+    assert int(r[0]["steps"]) == int(r[1]["steps"]) > 2
+    assert int(r[0]["active"]) == 0
+    assert np.array_equal(r[0]["all_lw"], r[1]["all_lw"])
