@@ -20,7 +20,9 @@ A step is one pass of the hot path over one batch of synthetic input that is alr
   kernel        only the fused step on [1024, 50257] fp32 logits, rotating over 4 buffers so that the 256 MiB
                 Infinity Cache cannot serve the rows.
   kernel-llama  (config 5) only the fused step on [512, 128256] bf16 logits, 4 rotating buffers.
-  api           the README loop itself: 1024 coroutines awaiting `AsyncAmdLM.next_token_step` (autobatched).
+  api           the README loop through the backend's API, the population submitted as one batched call per step
+                (`AsyncAmdLM.batch_next_token_step`: contexts as Python lists in, logZ / tokens out).
+  api-coro      the README loop verbatim: 1024 coroutines awaiting `AsyncAmdLM.next_token_step` (autobatched).
   api-logprobs  `batch_next_token_logprobs` of 1024 contexts per step, log-prob rows materialised ([1024, V] fp32).
   plumbing      CPU / gloo self-test of the multi-rank launch, barrier, all-gather and JSON relay (tests only; no
                 kernel is run and the line says so).
@@ -46,7 +48,7 @@ sys.path.insert(0, ROOT)
 V_GPT2, V_LLAMA = 50257, 128256
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 METRIC = "particles/sec + logprob-kernel HBM GB/s (% of 8 TB/s), 1024 particles gpt2"
-WORKLOADS = ["sis", "sis-llama", "kernel", "kernel-llama", "api", "api-logprobs", "plumbing"]
+WORKLOADS = ["sis", "sis-llama", "kernel", "kernel-llama", "api", "api-coro", "api-logprobs", "plumbing"]
 
 
 def algorithmic_bytes(B, V, elem_size, n_masks, mask_words, n_particles=None):
@@ -84,7 +86,7 @@ def cpu_baseline(workload, sample_rows, seed=1234):
 
     O.build()
     ncpu = os.cpu_count()
-    if workload in ("sis", "api", "api-logprobs"):
+    if workload in ("sis", "api", "api-coro", "api-logprobs"):
         from transformers import GPT2Config, GPT2LMHeadModel
 
         masks = synth.binary_masks(seed, 2, V_GPT2)
@@ -237,8 +239,8 @@ def main():
     workload = args.workload
     if workload in ("kernel", "kernel-llama"):
         runner = KernelWorkload(eng, dev, rank, world, dist, llama=workload == "kernel-llama")
-    elif workload in ("api", "api-logprobs"):
-        runner = ApiWorkload(eng, dev, rank, world, dist, logprobs=workload == "api-logprobs")
+    elif workload in ("api", "api-coro", "api-logprobs"):
+        runner = ApiWorkload(eng, dev, rank, world, dist, logprobs=workload == "api-logprobs", coro=workload == "api-coro")
     else:
         from genlm_backend_amd.sis import SisBenchWorkload
 
@@ -430,7 +432,7 @@ class ApiWorkload:
 
     dtype_name = "f32"
 
-    def __init__(self, eng, dev, rank, world, dist, logprobs=False, n_particles=1024, max_tokens=10):
+    def __init__(self, eng, dev, rank, world, dist, logprobs=False, coro=False, n_particles=1024, max_tokens=10):
         import asyncio
 
         from transformers import GPT2Config
@@ -452,7 +454,7 @@ class ApiWorkload:
         self.llm.set_rng("philox", seed=1234 + rank)
         self.N, self.V, self.max_tokens, self.eos = n_particles, V, max_tokens, cfg.eos_token_id
         self.particles_per_step = n_particles
-        self.logprobs = logprobs
+        self.logprobs, self.coro = logprobs, coro
         self.prompt = list(range(100, 108))
         self.loop = asyncio.new_event_loop()
         self.kernel_bytes = None
@@ -482,10 +484,21 @@ class ApiWorkload:
         if self.t >= self.max_tokens:
             self._reset()
 
-        async def one_step():
-            await aio.gather(*[p.extend() for p in self.particles if p.active])
+        if self.coro:
+            async def one_step():
+                await aio.gather(*[p.extend() for p in self.particles if p.active])
 
-        self.loop.run_until_complete(one_step())
+            self.loop.run_until_complete(one_step())
+        else:  # README.md:82-91 for every active particle, lines 82-87 as one batched call
+            act = [p for p in self.particles if p.active]
+            logZ, tok = self.llm.batch_next_token_step_sync([p.prompt_ids + p.context for p in act],
+                                                            [p.mask_selector(p.context) for p in act])
+            for p, z, t in zip(act, logZ.tolist(), tok.tolist()):
+                p.log_weight += z
+                if t == p.eos_id or t < 0:
+                    p.active = False
+                else:
+                    p.context.append(t)
         self.t += 1
         if self.world > 1:
             lw = torch.tensor([p.log_weight for p in self.particles], dtype=torch.float32, device=self.dev)
@@ -497,8 +510,10 @@ class ApiWorkload:
     def config(self):
         what = ("batch_next_token_logprobs of 1024 distinct 13-token contexts, [1024, V] fp32 log-prob rows materialised "
                 "on the device (base.py:47-60)") if self.logprobs else \
-            ("README loop: 1024 coroutines awaiting AsyncAmdLM.next_token_step, autobatched (batch_size 1024), prompt len 8, "
-             "<=10 new tokens, 2 shared bit masks, Philox draws (README.md:72-98)")
+            (("README loop: 1024 coroutines awaiting AsyncAmdLM.next_token_step, autobatched (batch_size 1024)" if self.coro else
+              "README loop over 1024 Python-side particles, each step's requests submitted as one "
+              "AsyncAmdLM.batch_next_token_step call") + ", prompt len 8, <=10 new tokens, 2 shared bit masks, Philox draws "
+             "(README.md:72-98)")
         return {"workload": what + "; gpt2-small shape (random init, fp32)", "particles_per_gpu": self.N, "vocab": self.V}
 
 

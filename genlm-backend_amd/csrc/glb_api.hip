@@ -461,6 +461,44 @@ __global__ __launch_bounds__(1024) void resample_systematic_kernel(const float *
   }
 }
 
+// Token->byte trie masses (trie/base.py:346-393): one workgroup per weight row walks the trie bottom-up, one tree
+// level per barrier; a node's value is the sum (or max, floored at 0 as in the reference) of its children's values in
+// ascending child order, accumulated in double - the reference's sequential order, so the result does not depend on
+// the launch.  vals: per-row scratch [n_nodes] doubles.
+__global__ __launch_bounds__(1024) void trie_reduce_kernel(const float *ws, int64_t ld, int64_t n_rows, int32_t V,
+                                                            int32_t n_nodes, int32_t n_levels, const int32_t *leaf_node,
+                                                            const int32_t *level_start, const int32_t *level_nodes,
+                                                            const int32_t *child_ptr, const int32_t *child_idx, int op,
+                                                            int from_logprobs, double *vals_all, float *out,
+                                                            int64_t out_ld, int64_t row0) {
+  const int64_t r = row0 + blockIdx.x;
+  if (r >= n_rows) return;
+  const int T = blockDim.x, tid = threadIdx.x;
+  const float *w = ws + r * ld;
+  double *vals = vals_all + (int64_t)blockIdx.x * n_nodes;
+  for (int k = tid; k < V; k += T) {
+    const float v = w[k];
+    vals[leaf_node[k]] = from_logprobs ? (double)expf(v) : (double)v;
+  }
+  __syncthreads();
+  for (int d = 0; d < n_levels; ++d) {  // deepest level first
+    const int lo = level_start[d], hi = level_start[d + 1];
+    for (int i = lo + tid; i < hi; i += T) {
+      const int node = level_nodes[i];
+      double acc = 0.0;
+      const int c0 = child_ptr[node], c1 = child_ptr[node + 1];
+      if (op == 0)
+        for (int c = c0; c < c1; ++c) acc += vals[child_idx[c]];
+      else
+        for (int c = c0; c < c1; ++c) acc = fmax(acc, vals[child_idx[c]]);
+      vals[node] = acc;
+    }
+    __syncthreads();
+  }
+  float *o = out + r * out_ld;
+  for (int i = tid; i < n_nodes; i += T) o[i] = (float)vals[i];
+}
+
 inline unsigned blocks_for(int64_t n, int t) { return (unsigned)((n + t - 1) / t); }
 
 }  // namespace
@@ -877,6 +915,36 @@ int glb_resample_systematic(const float *log_weights, int64_t n, uint64_t seed, 
                      offset, out_ancestors, (uint64_t *)workspace, out_stats);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "resample launch");
+  return GLB_OK;
+}
+
+size_t glb_trie_workspace(int64_t n_rows, int64_t n_nodes) {
+  if (n_rows <= 0 || n_nodes <= 0) return 0;
+  const int64_t tile = n_rows < 512 ? n_rows : 512;  // rows in flight per launch
+  return (size_t)tile * (size_t)n_nodes * sizeof(double);
+}
+
+int glb_trie_reduce(const float *weights, int64_t ld, int64_t n_rows, int64_t vocab, int64_t n_nodes, int64_t n_levels,
+                    const int32_t *leaf_node, const int32_t *level_start, const int32_t *level_nodes,
+                    const int32_t *child_ptr, const int32_t *child_idx, int32_t op, int32_t from_logprobs, float *out,
+                    int64_t out_ld, void *workspace, size_t workspace_bytes, void *stream) {
+  if (!weights || !leaf_node || !level_start || !level_nodes || !child_ptr || !child_idx || !out || !workspace)
+    return fail(GLB_EINVAL, "null pointer");
+  if (n_rows <= 0 || vocab <= 0 || n_nodes <= vocab || n_levels <= 0 || ld < vocab || out_ld < n_nodes)
+    return fail(GLB_EINVAL, "bad sizes");
+  if (vocab > 0x7fffff00ll || n_nodes > 0x7fffff00ll) return fail(GLB_EINVAL, "size exceeds 31 bits");
+  if (op != GLB_TRIE_SUM && op != GLB_TRIE_MAX) return fail(GLB_EINVAL, "bad op %d", op);
+  if (workspace_bytes < glb_trie_workspace(n_rows, n_nodes) || ((uintptr_t)workspace) % 8)
+    return fail(GLB_ENOSPC, "workspace %zu < %zu bytes (or misaligned)", workspace_bytes, glb_trie_workspace(n_rows, n_nodes));
+  const int64_t tile = n_rows < 512 ? n_rows : 512;
+  for (int64_t r0 = 0; r0 < n_rows; r0 += tile) {
+    const int64_t nb = n_rows - r0 < tile ? n_rows - r0 : tile;
+    hipLaunchKernelGGL(trie_reduce_kernel, dim3((unsigned)nb), dim3(1024), 0, (hipStream_t)stream, weights, ld, n_rows,
+                       (int32_t)vocab, (int32_t)n_nodes, (int32_t)n_levels, leaf_node, level_start, level_nodes,
+                       child_ptr, child_idx, (int)op, (int)from_logprobs, (double *)workspace, out, out_ld, r0);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "trie_reduce launch");
+  }
   return GLB_OK;
 }
 

@@ -145,14 +145,50 @@ class AsyncAmdLM(AsyncLM):
     @staticmethod
     def _fuse_activations(model):
         """transformers spells GPT-2's `gelu_new` as eight elementwise torch ops (a fifth of the forward's GPU time at
-        1024 x 13 tokens); `torch.nn.GELU(approximate="tanh")` is the same function in one kernel."""
+        1024 x 13 tokens); `torch.nn.GELU(approximate="tanh")` is the same function in one kernel (same formula,
+        results agree to rounding, not bit for bit).  Returns the replaced modules so the change can be undone."""
+        replaced = []
         for mod in model.modules():
             for name, child in list(mod.named_children()):
-                if type(child).__name__ == "NewGELUActivation":
+                if isinstance(child, torch.nn.Module) and type(child).__name__ == "NewGELUActivation":
                     setattr(mod, name, torch.nn.GELU(approximate="tanh"))
+                    replaced.append((mod, name, child))
+        return replaced
+
+    def restore_activations(self):
+        """Undo `fuse_activations` on the wrapped HuggingFace model (it is patched in place)."""
+        for mod, name, child in self._replaced_activations:
+            setattr(mod, name, child)
+        self._replaced_activations = []
+
+    @staticmethod
+    def _post_head(config):
+        """What the model's own forward applies to `lm_head(hidden)` (the reference reads `model(...).logits`, hf.py:275):
+        Cohere `logit_scale`, Granite `logits_scaling`, Gemma-2 `final_logit_softcapping`.  Returned as
+        (multiplier, softcap); other families leave the head's output alone."""
+        mult, cap = 1.0, None
+        mt = getattr(config, "model_type", "")
+        if mt.startswith("cohere") and getattr(config, "logit_scale", None) is not None:
+            mult *= float(config.logit_scale)
+        if mt.startswith("granite") and getattr(config, "logits_scaling", None):
+            mult /= float(config.logits_scaling)
+        if getattr(config, "final_logit_softcapping", None):
+            cap = float(config.final_logit_softcapping)
+        return mult, cap
+
+    def _lm_head(self, hidden):
+        """Logits of the given hidden rows exactly as `model(...).logits` has them: output embedding, then the
+        family's post-head scaling / soft-capping."""
+        x = self._head(hidden)
+        if self._head_mult != 1.0:
+            x = x * self._head_mult
+        if self._head_cap is not None:
+            x = torch.tanh(x / self._head_cap) * self._head_cap
+        return x
 
     @torch.no_grad()
-    def __init__(self, hf_model, hf_tokenizer, batch_size=20, timeout=0.02, engine=None):
+    def __init__(self, hf_model, hf_tokenizer, batch_size=20, timeout=0.02, engine=None, fuse_activations=True,
+                 kv_budget_bytes=8 << 30):
         self.model = hf_model
         self.tokenizer = hf_tokenizer
         self.device = hf_model.device
@@ -167,9 +203,19 @@ class AsyncAmdLM(AsyncLM):
         self.timeout = timeout
         self.timer = None
         self.model.eval()
-        self._fuse_activations(self.model)
-        self._lm_head = self.model.get_output_embeddings()
+        # fuse_activations=True rewrites GPT-2's activation modules of `hf_model` IN PLACE (numerics: same formula,
+        # different rounding; `restore_activations()` undoes it); pass False to leave the model untouched
+        self._replaced_activations = self._fuse_activations(self.model) if fuse_activations else []
+        self._head = self.model.get_output_embeddings()
+        if self._head is None:
+            raise NotImplementedError(f"{type(hf_model).__name__} has no output embedding (get_output_embeddings() is None)")
+        self._head_mult, self._head_cap = self._post_head(self.model.config)
         self._body = self.model.base_model
+        from .kv import PrefixLRU
+
+        self._kv_lru = PrefixLRU(kv_budget_bytes)  # prompt prefixes pinned by cache_kv, least recently used out first
+        self._kv_tokens = {}  # id(trie node) -> the prefix's token ids (for the device prefix table)
+        self._ptab = None
         # fused-step state
         self._mask_kind = MASK_NONE
         self._masks = None
@@ -186,9 +232,12 @@ class AsyncAmdLM(AsyncLM):
 
     # ---- cache management (hf.py:142-164) ---------------------------------------------------------
     def clear_cache(self):
+        self._kv_lru.clear()
+        self._kv_tokens.clear()
         self.cache = TokenTrie()
 
     def clear_kv_cache(self):
+        self._kv_lru.clear()
         self.cache.clear_kv_cache()
 
     def reset_async_queries(self):
@@ -202,7 +251,10 @@ class AsyncAmdLM(AsyncLM):
         out = self._body(input_ids=ids, use_cache=True)
         logits = self._lm_head(out.last_hidden_state[0])
         node = self.cache.extend_cache(0, prompt_tokens, logits, 0, engine=self.engine)
-        node.past_key_values = KVPrefix.from_hf_cache(out.past_key_values)
+        # pinned under a byte budget: the least recently used prefix loses its KV (its log-prob rows stay), the policy
+        # of cache.py:103-191 applied to whole prefix slabs
+        self._kv_lru.put(node, KVPrefix.from_hf_cache(out.past_key_values))
+        self._kv_tokens[id(node)] = tuple(int(t) for t in prompt_tokens)
 
     # ---- LoRA hooks (hf.py:166-200): weight management is outside the hot path ---------------------
     def add_new_lora(self, lora_path, lora_name="lora_1"):
@@ -458,6 +510,7 @@ class AsyncAmdLM(AsyncLM):
             if node.past_key_values is not None:
                 past = node.past_key_values
                 base = next_token_index
+                self._kv_lru.touch(node)
             if node.has_token(token_ids[next_token_index]):
                 node = node.get_token(token_ids[next_token_index])
                 next_token_index += 1
@@ -531,6 +584,160 @@ class AsyncAmdLM(AsyncLM):
         future = asyncio.get_running_loop().create_future()
         self.add_query(token_ids[base:], future, past, kind="step", mask_id=mask_id)
         return await future
+
+    # ---- batched submit: a whole population per call (no per-query futures, no per-query Python) ----------------------
+    def _prefix_table(self):
+        """Device table of the prompts whose KV `cache_kv` holds (tokens / starts / lengths for glb_match_prefixes and
+        per-layer pointer tables for glb_gather_kv_padded); rebuilt when the set of cached prefixes changed."""
+        entries = [(node, self._kv_tokens.get(id(node))) for node, _ in self._kv_lru._od.values()]
+        entries = [(n, t) for n, t in entries if t is not None and n.past_key_values is not None]
+        key = tuple(id(n) for n, _ in entries)
+        if self._ptab is not None and self._ptab["key"] == key:
+            return self._ptab
+        if not entries:
+            self._ptab = dict(key=key, n=0)
+            return self._ptab
+        dev = self.device
+        kvs = [n.past_key_values for n, _ in entries]
+        lens = np.array([len(t) for _, t in entries], np.int32)
+        starts = np.zeros(len(entries), np.int64)
+        starts[1:] = np.cumsum(lens[:-1])
+        flat = np.concatenate([np.asarray(t, np.int32) for _, t in entries])
+        ptrs = [[torch.tensor([kv.layers[l][j].data_ptr() for kv in kvs], dtype=torch.int64, device=dev)
+                 for j in range(2)] for l in range(len(kvs[0].layers))]
+        self._ptab = dict(key=key, n=len(entries), kvs=kvs, tokens=torch.from_numpy(flat).to(dev),
+                          starts=torch.from_numpy(starts).to(dev), lengths=torch.from_numpy(lens).to(dev), ptrs=ptrs,
+                          p_max=int(lens.max()))
+        return self._ptab
+
+    @torch.no_grad()
+    def batch_next_token_step_sync(self, contexts, mask_ids=None):
+        """README.md:82-87 for a whole population in ONE call: for every context, logZ = logsumexp(next-token
+        log-probs + mask[mask_id]) and a draw from the masked, renormalised distribution (-1 if nothing is allowed).
+        Same pipeline as the queued `next_token_step` - dedup (hf.py:214-220), cached-prefix match (hf.py:334-342),
+        ragged-to-padded gather, forward, lm_head on the last position, fused step - but the ragged batch is built
+        once (three host arrays) and nothing is done per query in Python.  Returns (logZ float32 [n], token int32 [n])
+        as NumPy arrays."""
+        import itertools
+
+        eng, dev = self.engine, self.device
+        n = len(contexts)
+        if n == 0:
+            return np.zeros(0, np.float32), np.zeros(0, np.int32)
+        lens = np.fromiter(map(len, contexts), np.int32, n)
+        if int(lens.min()) == 0:
+            raise ValueError("Token ids must not be empty")
+        total = int(lens.sum())
+        flat = np.fromiter(itertools.chain.from_iterable(contexts), np.int32, total)
+        starts = np.zeros(n, np.int64)
+        starts[1:] = np.cumsum(lens[:-1])
+        tok_d = torch.from_numpy(flat).to(dev)
+        st_d = torch.from_numpy(starts).to(dev)
+        ln_d = torch.from_numpy(lens).to(dev)
+        group_of, rep, ng = eng.group_contexts(tok_d, st_d, ln_d)
+        P = self._prefix_table()
+        base, pref = None, None
+        mid_d = None
+        if self._mask_kind != MASK_NONE:
+            mid = np.zeros(n, np.int32) if mask_ids is None else np.ascontiguousarray(mask_ids, dtype=np.int32)
+            mid_d = torch.from_numpy(mid).to(dev)
+        head = [ng[0]]
+        if P["n"]:
+            pref, base = eng.match_prefixes(tok_d, st_d, ln_d, P["tokens"], P["starts"], P["lengths"])
+            head.append((ln_d - base).max().to(torch.int32))
+        if mid_d is not None:  # may the mask ids go per logits row? (they do when the mask is a function of the context)
+            row_mid = mid_d[rep.long().clamp(0, n - 1)]  # entries of `rep` past the group count are unspecified
+            head.append((row_mid[group_of.long()] == mid_d).all().to(torch.int32))
+        head = torch.stack(head).cpu().tolist()  # the call's one D2H copy before the forward
+        U = head[0]
+        l_max = head[1] if P["n"] else int(lens.max())
+        by_row = bool(head[-1]) if mid_d is not None else False
+        p_max = P["p_max"] if P["n"] else 0
+        pad_id = getattr(self.tokenizer, "pad_token_id", None) if self.tokenizer is not None else None
+        ids, am, pos, last = eng.gather_padded(tok_d, st_d, ln_d, rep, U, base, 0 if pad_id is None else pad_id, p_max, l_max)
+        cache = None
+        if P["n"]:
+            from transformers import DynamicCache
+
+            kv0 = P["kvs"][0]
+            pref_u = pref[rep[:U].long()].contiguous()
+            data = [tuple(eng.gather_kv_padded(P["ptrs"][l][j], P["lengths"], pref_u, kv0.heads, kv0.head_dim, p_max,
+                                               kv0.dtype) for j in range(2)) for l in range(len(kv0.layers))]
+            cache = DynamicCache(ddp_cache_data=data)
+        hidden = self._body(input_ids=ids, attention_mask=am, position_ids=pos, past_key_values=cache,
+                            use_cache=cache is not None).last_hidden_state
+        logits = self._lm_head(hidden[torch.arange(U, device=dev), last.long()])  # [U, V]
+        V = logits.shape[-1]
+        kw = self.step_masks(logits.dtype)
+        if kw:
+            if by_row:
+                kw["row_mask_id"] = row_mid[:U].contiguous()
+            else:
+                kw["mask_id"] = mid_d
+        if self._rng_mode == RNG_NOISE:
+            # Exp(1) rows in the reference's resolution order: by dedup group, duplicates contiguous (hf.py:285-288)
+            order = np.argsort(group_of.cpu().numpy(), kind="stable")
+            noise = torch.empty((n, V), dtype=torch.float32)
+            noise[torch.from_numpy(order)] = self._host_rng.exponential(n * V).view(n, V)
+            kw["noise"] = noise.to(dev, non_blocking=True)
+        logZ, _, tok = eng.step(logits, vocab=V, row_of=group_of, rng_mode=self._rng_mode, seed=self._rng_seed,
+                                offset=self._batch_counter, want_lse=False, **kw)
+        self._batch_counter += 1
+        self.stats["batches"] += 1
+        self.stats["queries"] += n
+        self.stats["unique"] += U
+        self.stats["rows"] += U
+        out = torch.stack([logZ, tok.to(torch.float32)]).cpu().numpy()  # token ids < 2^24: exact in float32
+        return out[0], out[1].astype(np.int32)
+
+    async def batch_next_token_step(self, contexts, mask_ids=None):
+        """Awaitable form of `batch_next_token_step_sync` (the evaluation itself blocks the loop, like
+        `batch_evaluate_queries` does in the reference, hf.py:307-308)."""
+        return self.batch_next_token_step_sync(contexts, mask_ids)
+
+    @torch.no_grad()
+    def _batch_logprobs(self, token_ids_list):
+        """`batch_next_token_logprobs` without one coroutine / future per context: cache walk per context, ONE batched
+        evaluation of the misses, trie update, rows stacked on the device."""
+
+        class _Slot:
+            __slots__ = ("value",)
+
+            def __init__(self):
+                self.value = None
+
+            def done(self):
+                return self.value is not None
+
+            def set_result(self, v):
+                self.value = v
+
+            def set_exception(self, e):
+                raise e
+
+        pending, nodes = [], [None] * len(token_ids_list)
+        for i, token_ids in enumerate(token_ids_list):
+            if not token_ids:
+                raise ValueError("Token ids must not be empty")
+            node, nti, past, base = self.walk_cache(token_ids)
+            if nti == len(token_ids):
+                nodes[i] = node
+            else:
+                pending.append((i, node, nti, base, Query(token_ids[base:], _Slot(), past, first_new=nti - base)))
+        if pending:
+            self._evaluate([q for *_, q in pending])
+            for i, node, nti, base, q in pending:
+                rows, first = q.future.value
+                nodes[i] = node.extend_cache_rows(nti, token_ids_list[i], rows[nti - base - first:], nti)
+        return torch.stack([nd.logprobs for nd in nodes])
+
+    async def batch_next_token_logprobs(self, token_ids_list):
+        """base.py:47-60 (one batched evaluation instead of a gather over per-context coroutines)"""
+        return self._batch_logprobs(token_ids_list)
+
+    def batch_next_token_logprobs_sync(self, token_ids_list):
+        """base.py:62-73"""
+        return self._batch_logprobs(token_ids_list)
 
     # ---- sampling (base.py:110-146) -------------------------------------------------------------------------
     def _make_generator(self, seed):

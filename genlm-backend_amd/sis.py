@@ -221,6 +221,10 @@ class DeviceSIS:
         out = llm._body(input_ids=ids, position_ids=pos.view(N, 1).long(), attention_mask=self.pkv.attention_mask(pos),
                         past_key_values=self.pkv, use_cache=True)
         logits = llm._lm_head(out.last_hidden_state[:, 0])  # [N, V]
+        self._noise_groups = None
+        if self.rng_mode == RNG_NOISE:  # parity draws follow the reference's resolution order: by dedup group
+            lengths_eff = torch.where(self.active > 0, self.lengths, torch.ones_like(self.lengths))
+            self._noise_groups, _, _ = eng.group_contexts(self.contexts.view(-1), self.starts, lengths_eff)
         return self._finish_step(logits, None, N, n_active, n_global, time_kernel, l_max=1)
 
     def _finish_step(self, logits, group_of, U, n_active, n_global, time_kernel, l_max):
@@ -239,7 +243,7 @@ class DeviceSIS:
             else:
                 kw["mask_id"] = mask_id
         if self.rng_mode == RNG_NOISE:
-            kw["noise"] = self._parity_noise(group_of if group_of is not None else torch.arange(N, device=self.dev), V)
+            kw["noise"] = self._parity_noise(group_of if group_of is not None else self._noise_groups, V)
         if time_kernel:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

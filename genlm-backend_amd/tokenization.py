@@ -88,6 +88,42 @@ def _added(tokenizer):
         return {}
 
 
+def default_char_table():
+    """The fallback character -> byte table: the GPT-2 byte-level alphabet plus the literal whitespace and the
+    SentencePiece space marker some fast tokenizers keep in their pieces (bytes.py:214-231)."""
+    table = gpt2_unicode_to_byte()
+    table.update({" ": 32, "\n": 10, "\r": 13, "\t": 9, "\u2581": 32})
+    return table
+
+
+_PROBE = "\u2019\u2022\u00b6\u2202\u0192\u02d9\u2206\u00a3\u0126\u7228\u0d60\u1158\u2230\u1368"
+
+
+def _table_is_usable(tokenizer, table):
+    """A character table is accepted only if (a) it covers every character of every ordinary piece of the vocabulary
+    and (b) a string of unusual code points survives tokenise -> pieces -> bytes (bytes.py:118-187's two checks)."""
+    special = set(_added(tokenizer).values())
+    try:
+        vocab = tokenizer.get_vocab()
+    except Exception:
+        return False
+    for piece in vocab:
+        if piece in special:
+            continue
+        for ch in piece:
+            if ch not in table:
+                return False
+    try:
+        ids = tokenizer(_PROBE, add_special_tokens=False)["input_ids"]
+        raw = b"".join(bytes(table[ch] for ch in tokenizer.convert_ids_to_tokens(i)) for i in ids)
+        bos = getattr(tokenizer, "bos_token", None)
+        if bos and raw.startswith(bos.encode()):
+            raw = raw[len(bos):]
+        return raw.decode() == _PROBE
+    except Exception:
+        return False
+
+
 def _via_char_table(tokenizer, table):
     added = _added(tokenizer)
     out = []
@@ -114,29 +150,56 @@ def _via_sentencepiece(tokenizer):
             raw = added[i].encode()
         else:
             raw = tokenizer.sp_model.id_to_piece(i).encode()
-            raw = re.sub(rb"<0x([0-9A-Fa-f]{2})>", lambda m: bytes.fromhex(m[1].decode()), raw)
-        out.append(raw.replace("▁".encode(), b" "))
+            raw = re.sub(rb"<0x(..)>", lambda m: bytes.fromhex(m[1].decode()), raw)
+        out.append(raw.replace("\u2581".encode(), b" "))
     return out
 
 
 def get_byte_vocab(tokenizer):
-    """list[bytes] indexed by token id."""
+    """list[bytes] indexed by token id (bytes.py:15-57): the tokenizer's own `byte_decoder` if it passes the checks,
+    else its SentencePiece model, else the default byte-level table (if THAT passes the checks)."""
     table = getattr(tokenizer, "byte_decoder", None)
-    if table:
-        try:
-            return _via_char_table(tokenizer, table)
-        except ByteVocabError:
-            pass
+    if table and _table_is_usable(tokenizer, table):
+        return _via_char_table(tokenizer, table)
     if hasattr(tokenizer, "sp_model"):
         return _via_sentencepiece(tokenizer)
-    return _via_char_table(tokenizer, gpt2_unicode_to_byte())
+    table = default_char_table()
+    if not _table_is_usable(tokenizer, table):
+        raise ByteVocabError("Could not decode vocabulary by falling back to GPT2 byte decoder.")
+    return _via_char_table(tokenizer, table)
+
+
+def _alternate_tokenizer(tokenizer, use_fast):
+    name = getattr(tokenizer, "name_or_path", None)
+    if not name:
+        return None
+    try:
+        from transformers import AutoTokenizer
+
+        return AutoTokenizer.from_pretrained(name, use_fast=use_fast)
+    except Exception:  # offline / in-memory tokenizers: there is no other flavour to load
+        return None
 
 
 def decode_vocab(tokenizer, byte2str_fallback="tokenizer"):
     """(byte_vocab: list[Token], str_vocab: list[str]); token id == list index."""
     if byte2str_fallback not in ("latin1", "tokenizer", "replace"):
         raise ValueError(f"Unknown byte2str_fallback strategy: {byte2str_fallback}")
-    raw = get_byte_vocab(tokenizer)
+    # vocab.py:31-49: prefer the slow flavour of a fast tokenizer, fall back to the fast one
+    raw = None
+    first = _alternate_tokenizer(tokenizer, use_fast=False) if getattr(tokenizer, "is_fast", False) else None
+    for cand in (first, tokenizer, _alternate_tokenizer(tokenizer, use_fast=True) if first is not None else None):
+        if cand is None:
+            continue
+        try:
+            raw = get_byte_vocab(cand)
+            tokenizer = cand
+            break
+        except ByteVocabError:
+            continue
+    if raw is None:
+        raise ValueError(f"Could not decode byte representation of token vocabuary from tokenizer "
+                         f"{getattr(tokenizer, 'name_or_path', '?')}")
     byte_vocab = [Token(i, b) for i, b in enumerate(raw)]
     str_vocab = []
     for i, b in enumerate(raw):

@@ -1,0 +1,151 @@
+"""Token -> byte trie with batched mass propagation on the MI355X.
+
+Counterpart of the reference's `TokenCharacterTrie` / `ParallelTokenCharacterTrie` (genlm/backend/trie/base.py:10-213,
+trie/parallel.py:33-145): a trie over the byte strings of the vocabulary with one extra leaf per token;
+`weight_sum` / `weight_max` give, for every node, the sum / maximum of the weights of the tokens below it.  The
+structure (node numbering, `children`, `word2leaf`, `leaf2word`, `node2prefix`, `jump`) is the reference's, so node ids
+mean the same thing; the propagation is one HIP launch for a whole batch of weight rows (glb_trie_reduce) instead of a
+numba loop per row (base.py:346-393) or a sparse matmul (parallel.py:92-145).
+"""
+import numpy as np
+import torch
+
+from .tokenization import Token
+
+
+class TokenByteTrie:
+    def __init__(self, decode, engine=None):
+        """decode: the vocabulary - `Token`s from `decode_vocab`, plain bytes, or other iterables of symbols; the weight
+        of token k is column k of a weight row.  engine: a `HipEngine` (needed for the weight_* methods)."""
+        self.decode = decode
+        self.engine = engine
+        # -- build: nodes in creation order, every node keeps its out-edges in insertion order; a token ends in a leaf
+        #    of its own hanging off the node of its last byte through the edge (None, k)          (base.py:13-62)
+        edges = [[]]          # per node: [(symbol, child)]
+        index = [{}]          # per node: symbol -> child
+        leaf_of, keys = [], []
+        for k, item in enumerate(decode):
+            if isinstance(item, Token):
+                word, key = item.byte_string, (item.byte_string, item.token_id)
+            else:
+                word, key = item, item
+            at = 0
+            for sym in word:
+                nxt = index[at].get(sym)
+                if nxt is None:
+                    nxt = len(edges)
+                    index[at][sym] = nxt
+                    edges[at].append((sym, nxt))
+                    edges.append([])
+                    index.append({})
+                at = nxt
+            leaf = len(edges)
+            edges[at].append(((None, k), leaf))
+            edges.append([])
+            index.append({})
+            leaf_of.append(leaf)
+            keys.append(key)
+        if len(set(keys)) != len(keys):
+            seen = set()
+            dup = next(x for x in keys if x in seen or seen.add(x))
+            raise ValueError(f"Duplicate word in vocabulary: {dup}")
+        # -- renumber in post-order (children before their parent, edges in insertion order; the root comes last), the
+        #    reference's memory-locality numbering (base.py:72-79,225-243)
+        n = len(edges)
+        new_id = np.empty(n, np.int64)
+        counter = 0
+        stack = [(0, 0)]
+        while stack:
+            node, i = stack.pop()
+            if i < len(edges[node]):
+                stack.append((node, i + 1))
+                stack.append((edges[node][i][1], 0))
+            else:
+                new_id[node] = counter
+                counter += 1
+        self.root = int(new_id[0])
+        self.children = [None] * n
+        for old in range(n):
+            self.children[new_id[old]] = {sym: int(new_id[c]) for sym, c in edges[old]}
+        self.word2leaf = {key: int(new_id[leaf]) for key, leaf in zip(keys, leaf_of)}
+        self.leaf2word = {v: k for k, v in self.word2leaf.items()}
+        self.idx_to_leaf = np.array([(k, new_id[leaf]) for k, leaf in enumerate(leaf_of)], dtype=np.int32).reshape(-1, 2)
+        self.jump = [np.array(sorted(c.values()), dtype=np.int32) for c in self.children]
+        # prefixes: parents have larger ids than their children, so a descending sweep sees a parent first
+        self.node2prefix = {self.root: []}
+        for x in range(n - 1, -1, -1):
+            for sym, y in self.children[x].items():
+                is_leaf_edge = isinstance(sym, tuple) and sym[0] is None
+                self.node2prefix[y] = self.node2prefix[x] if is_leaf_edge else self.node2prefix[x] + [sym]
+        self._flat = None
+        self._dev = None
+
+    def __len__(self):
+        return len(self.children)
+
+    # ---- flattened form for the kernel --------------------------------------------------------------------------
+    def flat(self):
+        """Host arrays of glb_trie_reduce: leaf of every token, internal nodes by level (level 0 = all children are
+        leaves; a node sits one level above its highest internal child) and the CSR of ascending children."""
+        if self._flat is None:
+            n = len(self.children)
+            counts = np.fromiter((len(j) for j in self.jump), np.int64, n)
+            child_ptr = np.zeros(n + 1, np.int64)
+            np.cumsum(counts, out=child_ptr[1:])
+            child_idx = np.concatenate(self.jump) if n else np.zeros(0, np.int32)
+            level = np.full(n, -1, np.int64)
+            for x in range(n):  # ascending ids = children first
+                if counts[x]:
+                    level[x] = 1 + max(-1, int(level[self.jump[x]].max()))
+            internal = np.nonzero(level >= 0)[0]
+            order = internal[np.argsort(level[internal], kind="stable")]
+            n_levels = int(level.max()) + 1
+            level_start = np.searchsorted(level[order], np.arange(n_levels + 1))
+            self._flat = dict(vocab=len(self.decode), n_nodes=n, n_levels=n_levels,
+                              leaf_node=self.idx_to_leaf[:, 1].astype(np.int32), level_start=level_start.astype(np.int32),
+                              level_nodes=order.astype(np.int32), child_ptr=child_ptr.astype(np.int32),
+                              child_idx=child_idx.astype(np.int32))
+        return self._flat
+
+    def device_arrays(self):
+        if self._dev is None:
+            if self.engine is None:
+                raise RuntimeError("TokenByteTrie needs a HipEngine to compute masses (there is no CPU path)")
+            f = self.flat()
+            dev = self.engine.device
+            self._dev = {k: (torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) else v) for k, v in f.items()}
+        return self._dev
+
+    # ---- masses -----------------------------------------------------------------------------------------------------
+    def _rows(self, ws):
+        if isinstance(ws, (list, tuple)):
+            ws = torch.stack([torch.as_tensor(w, dtype=torch.float32) for w in ws])
+        ws = torch.as_tensor(ws)
+        if ws.dim() == 1:
+            ws = ws[None]
+        if ws.shape[1] != len(self.decode):
+            raise ValueError(f"weight rows have {ws.shape[1]} columns, vocabulary has {len(self.decode)}")
+        return ws.to(self.engine.device, torch.float32).contiguous()
+
+    def batch_weight_sum_device(self, ws, from_logprobs=False):
+        """[B, V] weights (or log-probabilities) -> float32 [B, n_nodes] on the device."""
+        return self.engine.trie_reduce(self._rows(ws), self.device_arrays(), 0, from_logprobs)
+
+    def batch_weight_max_device(self, ws, from_logprobs=False):
+        return self.engine.trie_reduce(self._rows(ws), self.device_arrays(), 1, from_logprobs)
+
+    def batch_weight_sum(self, ws):
+        """base.py:196-205 / parallel.py:92-103: summed weights of every node for a batch of weight rows."""
+        return self.batch_weight_sum_device(ws).cpu().numpy()
+
+    def batch_weight_max(self, ws):
+        """base.py:207-216 / parallel.py:120-145"""
+        return self.batch_weight_max_device(ws).cpu().numpy()
+
+    def weight_sum(self, ws):
+        """base.py:147-169"""
+        return self.batch_weight_sum(self._rows(ws))[0]
+
+    def weight_max(self, ws):
+        """base.py:171-193"""
+        return self.batch_weight_max(self._rows(ws))[0]

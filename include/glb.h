@@ -266,6 +266,26 @@ int glb_resample_systematic(const float *log_weights, int64_t n, uint64_t seed, 
                             void *hip_stream);
 
 /*
+ * Token -> byte trie masses.  Replaces TokenCharacterTrie.weight_sum / weight_max and their batch_
+ * forms (trie/base.py:147-213 with the numba loops at :346-393; trie/parallel.py:92-145): for every node of the
+ * trie over the vocabulary's byte strings, the sum / maximum of the weights of the tokens below it, for a batch of
+ * weight rows at once.  The trie arrives flattened (built once per vocabulary on the host):
+ *   leaf_node   [vocab]        node id of token k's leaf
+ *   level_start [n_levels + 1] level_nodes[level_start[d] .. level_start[d+1]) = internal nodes d levels above the
+ *   level_nodes                deepest ones (children always sit in an earlier level or are leaves)
+ *   child_ptr   [n_nodes + 1], child_idx: CSR of every node's children, ascending (the reference's `jump`)
+ * out[r, node] = float(value); values are accumulated in double in child order (the reference's sequential
+ * algorithm, so results match it to the last float32 bit in practice).  from_logprobs != 0: weights = exp(row).
+ * GLB_TRIE_MAX floors internal nodes at 0 like the reference (:385).  workspace: glb_trie_workspace(...) bytes.
+ */
+enum { GLB_TRIE_SUM = 0, GLB_TRIE_MAX = 1 };
+size_t glb_trie_workspace(int64_t n_rows, int64_t n_nodes);
+int glb_trie_reduce(const float *weights, int64_t ld, int64_t n_rows, int64_t vocab, int64_t n_nodes, int64_t n_levels,
+                    const int32_t *leaf_node, const int32_t *level_start, const int32_t *level_nodes,
+                    const int32_t *child_ptr, const int32_t *child_idx, int32_t op, int32_t from_logprobs, float *out,
+                    int64_t out_ld, void *workspace, size_t workspace_bytes, void *hip_stream);
+
+/*
  * Host helper for GLB_RNG_NOISE: fills out[0..n) with the float32 Exp(1) variates
  * torch.empty(n).exponential_(1, generator) produces on CPU for a generator whose MT19937 state is
  * `state` (seeded with glb_mt19937_seed).  Serial by construction (one 64-bit draw = two MT words per

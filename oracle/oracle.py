@@ -248,3 +248,19 @@ def resample_systematic(log_weights, seed=0, offset=0):
     if rc:
         raise RuntimeError(f"orc_resample_systematic rc={rc}")
     return anc, float(stats[0])
+
+
+def trie_reduce(ws, flat, op=0, from_logprobs=False):
+    """Layer-B trie masses: ws [B, V] float32, flat = dict of the flattened trie arrays (genlm_backend_amd.trie)."""
+    ws = np.ascontiguousarray(ws, dtype=np.float32)
+    B, V = ws.shape
+    n_nodes = int(flat["n_nodes"])
+    out = np.empty((B, n_nodes), np.float32)
+    a = {k: np.ascontiguousarray(flat[k], dtype=np.int32) for k in ("leaf_node", "level_start", "level_nodes", "child_ptr", "child_idx")}
+    rc = lib().orc_trie_reduce(_p(ws), C.c_int64(V), C.c_int64(B), C.c_int64(V), C.c_int64(n_nodes),
+                               C.c_int64(len(a["level_start"]) - 1), _p(a["leaf_node"]), _p(a["level_start"]),
+                               _p(a["level_nodes"]), _p(a["child_ptr"]), _p(a["child_idx"]), C.c_int(op),
+                               C.c_int(1 if from_logprobs else 0), _p(out), C.c_int64(n_nodes))
+    if rc:
+        raise RuntimeError(f"orc_trie_reduce rc={rc}")
+    return out

@@ -187,3 +187,105 @@ def test_device_sis_matches_reference(llm, gold, use_kv):
     _check_sis(ctx, lw, gold)
     probs, stats = sis.normalized_weights()
     assert np.abs(probs.numpy() - gold["sis_probs"]).max() < 1e-5  # README.md:108-110
+
+
+def test_readme_sis_batched_submit_matches_reference(llm, gold):
+    """The README loop with each step's requests handed over as ONE `batch_next_token_step` call (no coroutine per
+    particle): same tokens and weights as the reference's run, with and without the prompt's KV cached."""
+    llm.register_masks(torch.from_numpy(gold["sis_masks"]))
+    prompt = [int(t) for t in gold["sis_prompt"]]
+    for with_kv in (False, True):
+        llm.clear_cache()
+        llm.set_rng("torch", 1234)
+        if with_kv:
+            llm.cache_kv(prompt)
+        ctxs, lw, active = [[] for _ in range(16)], np.zeros(16, np.float64), [True] * 16
+        steps = 0
+        while any(active):
+            idx = [i for i in range(16) if active[i]]
+            logZ, tok = llm.batch_next_token_step_sync([prompt + ctxs[i] for i in idx],
+                                                       [1 if len(ctxs[i]) >= 10 else 0 for i in idx])
+            for i, z, t in zip(idx, logZ, tok):
+                lw[i] += z
+                if t == 0 or t < 0:
+                    active[i] = False
+                else:
+                    ctxs[i].append(int(t))
+            steps += 1
+        _check_sis(ctxs, lw, gold)
+        assert steps == int(gold["sis_steps"][0])
+    with pytest.raises(ValueError):
+        llm.batch_next_token_step_sync([[1], []])
+
+
+def test_prefix_kv_is_evicted_least_recently_used_first(llm):
+    pres = [[5, 6, 7], [8, 9, 10, 11], [12, 13]]
+    llm.cache_kv(pres[0])
+    one = llm._kv_lru.used
+    llm._kv_lru.budget = int(one * 2.5)  # room for two three-token prefixes
+    llm.cache_kv(pres[1])
+    llm.walk_cache(pres[0] + [1])        # touch prefix 0: prefix 1 is now the least recently used
+    llm.cache_kv(pres[2])
+    assert llm._kv_lru.evictions >= 1
+    assert llm.walk_cache(pres[1] + [1])[2] is None          # evicted: falls back to re-encoding ...
+    assert llm.walk_cache(pres[0] + [1])[2] is not None      # ... the recently used ones stay
+    assert llm.walk_cache(pres[2] + [1])[2] is not None
+    got = asyncio.run(llm.batch_next_token_logprobs([pres[1] + [3], pres[0] + [3]]))
+    for p, row in zip((pres[1] + [3], pres[0] + [3]), got):
+        assert np.abs(row.numpy() - llm.next_token_logprobs_uncached(p).numpy()).max() < TOL
+
+
+@pytest.mark.parametrize("family", ["gemma2", "cohere", "granite"])
+def test_logits_include_the_models_post_head_transform(family):
+    """hf.py:275 reads `model(...).logits`: soft-capping (Gemma-2), logit_scale (Cohere) and logits_scaling (Granite)
+    are applied after the output embedding and must be part of the log-probs."""
+    import transformers as T
+
+    import genlm_backend_amd  # noqa: F401
+    from genlm_backend_amd.llm import AsyncAmdLM
+
+    torch.manual_seed(0)
+    common = dict(vocab_size=200, hidden_size=32, intermediate_size=64, num_hidden_layers=2, num_attention_heads=4,
+                  num_key_value_heads=2, max_position_embeddings=64, bos_token_id=1, eos_token_id=2, pad_token_id=0)
+    if family == "gemma2":
+        model = T.Gemma2ForCausalLM(T.Gemma2Config(head_dim=8, final_logit_softcapping=2.0, query_pre_attn_scalar=8, **common))
+    elif family == "cohere":
+        model = T.CohereForCausalLM(T.CohereConfig(logit_scale=0.25, **common))
+    else:
+        model = T.GraniteForCausalLM(T.GraniteConfig(logits_scaling=4.0, **common))
+    model = model.eval()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(3.0)  # make the logits large enough for the transform to matter
+    m = AsyncAmdLM(model, None, engine=CpuOracleEngine())
+    ids = [5, 17, 42, 9]
+    with torch.no_grad():
+        want = torch.log_softmax(model(torch.tensor([ids])).logits[0, -1].float(), -1).numpy()
+        plain = torch.log_softmax(model.get_output_embeddings()(model.base_model(torch.tensor([ids])).last_hidden_state)[0, -1], -1)
+    assert np.abs(plain.numpy() - want).max() > 1e-3  # the transform is not a no-op on this model
+    assert np.abs(m.next_token_logprobs_uncached(ids).numpy() - want).max() < TOL
+    assert np.abs(asyncio.run(m.next_token_logprobs(ids)).numpy() - want).max() < TOL
+
+
+def test_activation_fusion_is_optional_and_reversible(gold):
+    from transformers import GPT2Config, GPT2LMHeadModel
+
+    import genlm_backend_amd  # noqa: F401
+    from genlm_backend_amd.llm import AsyncAmdLM
+
+    cfg = ast.literal_eval(bytes(gold["config_json"]).decode())
+    model = GPT2LMHeadModel(GPT2Config(**cfg)).eval()
+    kinds = lambda: {type(c).__name__ for c in model.modules()}
+    before = kinds()
+    AsyncAmdLM(model, None, engine=CpuOracleEngine(), fuse_activations=False)
+    assert kinds() == before
+    m = AsyncAmdLM(model, None, engine=CpuOracleEngine())
+    if "NewGELUActivation" in before:
+        assert "NewGELUActivation" not in kinds()
+        ids = torch.tensor([[3, 1, 4, 1, 5]])
+        with torch.no_grad():
+            fused = model(ids).logits
+        m.restore_activations()
+        assert kinds() == before
+        with torch.no_grad():
+            assert (model(ids).logits - fused).abs().max() < 1e-4  # same function, different rounding

@@ -272,3 +272,112 @@ def test_device_sis_resampling_on_gpu(llm):
         runs.append(s.results())
     assert runs[0][0] == runs[1][0]
     assert np.abs(runs[0][1] - runs[1][1]).max() < 1e-4
+
+
+# ---- round-2 reference goldens on the GPU: trie masses, config 3, Llama-shaped model ------------------------------
+G2 = os.path.join(os.path.dirname(__file__), "golden", "ref_round2.npz")
+
+
+@pytest.mark.parametrize("tag", ["kat", "syn"])
+def test_trie_masses_on_gpu(engine, oracle, tag):
+    from genlm_backend_amd.tokenization import Token
+    from genlm_backend_amd.trie import TokenByteTrie
+
+    gold = np.load(G2)
+    words = bytes(gold[f"trie::{tag}::words"]).split(b"\x00")
+    trie = TokenByteTrie([Token(i, w) for i, w in enumerate(words)], engine=engine)
+    ws = gold[f"trie::{tag}::ws"]
+    for op, key, fn in ((0, "sum", trie.batch_weight_sum), (1, "max", trie.batch_weight_max)):
+        got = fn(torch.from_numpy(ws))
+        assert np.array_equal(got.view(np.uint32), oracle.trie_reduce(ws, trie.flat(), op).view(np.uint32))
+        assert np.abs(got - gold[f"trie::{tag}::{key}"]).max() < 1e-6  # the reference's own numbers
+    assert np.array_equal(trie.weight_sum(ws[0]), trie.batch_weight_sum(ws)[0])
+    lp = np.log(np.maximum(ws, 1e-30)).astype(np.float32)
+    got = trie.batch_weight_sum_device(torch.from_numpy(lp), from_logprobs=True).cpu().numpy()
+    assert np.abs(got - gold[f"trie::{tag}::sum"]).max() < 1e-5
+
+
+def test_trie_masses_large_vocabulary(engine, oracle):
+    """gpt2-sized vocabulary of synthetic byte strings, 64 weight rows: kernel == oracle bit for bit, root == row sum."""
+    from genlm_backend_amd.tokenization import Token
+    from genlm_backend_amd.trie import TokenByteTrie
+
+    rs = np.random.default_rng(0)
+    words, seen = [], set()
+    while len(words) < 50257:
+        w = bytes(rs.integers(97, 123, int(rs.integers(1, 9))).astype(np.uint8))
+        if w not in seen:
+            seen.add(w)
+            words.append(w)
+    trie = TokenByteTrie([Token(i, w) for i, w in enumerate(words)], engine=engine)
+    ws = rs.random((64, len(words))).astype(np.float32)
+    ws /= ws.sum(-1, keepdims=True)
+    got = trie.batch_weight_sum(torch.from_numpy(ws))
+    assert np.array_equal(got.view(np.uint32), oracle.trie_reduce(ws, trie.flat(), 0).view(np.uint32))
+    assert np.abs(got[:, trie.root] - 1.0).max() < 1e-6
+    gm = trie.batch_weight_max(torch.from_numpy(ws[:8]))
+    assert np.array_equal(gm.view(np.uint32), oracle.trie_reduce(ws[:8], trie.flat(), 1).view(np.uint32))
+
+
+@pytest.mark.parametrize("K,mode", [(1, "prefix"), (8, "plain"), (8, "pkv"), (64, "prefix"), (64, "pkv")])
+def test_config3_on_gpu_matches_reference(llm, K, mode):
+    """BASELINE config 3: K distinct ragged shared prompts, dedup + prefix / per-particle KV, tokens == reference."""
+    from genlm_backend_amd.sis import DeviceSIS
+
+    m, _ = llm
+    gold = np.load(G2)
+    m.register_masks(torch.from_numpy(gold["c3::masks"]))
+    prompts = [_strip(r) for r in gold[f"c3::K{K}::prompts"]]
+    per = [prompts[i % K] for i in range(64)]
+    sis = DeviceSIS(m, 64, per, max_tokens=6, eos_id=0, seed=4321 + K, rng="torch", use_prefix_kv=mode == "prefix",
+                    use_particle_kv=mode == "pkv")
+    sis.run()
+    ctx, lw = sis.results()
+    assert [list(map(int, c)) for c in ctx] == [_strip(r) for r in gold[f"c3::K{K}::contexts"]]
+    assert np.abs(lw - gold[f"c3::K{K}::log_weights"]).max() < TOL
+
+
+def test_llama_shaped_model_on_gpu_matches_reference(engine):
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    from genlm_backend_amd.llm import AsyncAmdLM
+    from genlm_backend_amd.sis import DeviceSIS
+
+    gold = np.load(G2)
+    cfg = ast.literal_eval(bytes(gold["llama::config_json"]).decode())
+    model = LlamaForCausalLM(LlamaConfig(**cfg)).eval()
+    model.load_state_dict({k[len("llama::w::"):]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("llama::w::")})
+    m = AsyncAmdLM(model.to(engine.device), None, batch_size=64, engine=engine)
+    m.tokenizer = Tok()
+    prompts = [_strip(r) for r in gold["llama::lp_prompts"]]
+    got = asyncio.run(m.batch_next_token_logprobs(prompts)).cpu().numpy()
+    assert np.abs(got - gold["llama::lp_values"]).max() < TOL
+    m.register_masks(torch.from_numpy(gold["llama::sis_masks"]))
+    p3 = [_strip(r) for r in gold["llama::sis_prompts"]]
+    per = [p3[i % 3] for i in range(24)]
+    for kw in (dict(), dict(use_prefix_kv=True), dict(use_particle_kv=True)):
+        sis = DeviceSIS(m, 24, per, max_tokens=6, eos_id=0, seed=999, rng="torch", **kw)
+        sis.run()
+        ctx, lw = sis.results()
+        assert [list(map(int, c)) for c in ctx] == [_strip(r) for r in gold["llama::sis_contexts"]]
+        assert np.abs(lw - gold["llama::sis_log_weights"]).max() < TOL
+
+
+def test_batched_submit_on_gpu_matches_reference(llm):
+    m, gold = llm
+    m.register_masks(torch.from_numpy(gold["sis_masks"]))
+    prompt = [int(t) for t in gold["sis_prompt"]]
+    m.set_rng("torch", 1234)
+    m.cache_kv(prompt)
+    ctxs, lw, active = [[] for _ in range(16)], np.zeros(16), [True] * 16
+    while any(active):
+        idx = [i for i in range(16) if active[i]]
+        logZ, tok = m.batch_next_token_step_sync([prompt + ctxs[i] for i in idx], [1 if len(ctxs[i]) >= 10 else 0 for i in idx])
+        for i, z, t in zip(idx, logZ, tok):
+            lw[i] += z
+            if t <= 0:
+                active[i] = False
+            else:
+                ctxs[i].append(int(t))
+    assert ctxs == [_strip(r) for r in gold["sis_contexts"]]
+    assert np.abs(lw - gold["sis_log_weights"]).max() < TOL

@@ -1,0 +1,217 @@
+"""Round-2 fixtures made by the REFERENCE (oracle/make_goldens_r2.py -> tests/golden/ref_round2.npz): the token->byte
+trie and its masses, byte vocabularies, BASELINE config 3 (K distinct ragged prompts, dedup + prefix KV) and a tiny
+Llama (RoPE, grouped-query attention) through the backend.  CPU: the HIP engine is the oracle-backed test double."""
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.cpu_engine import CpuOracleEngine
+
+GD = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(GD, "ref_round2.npz"))
+
+
+def _strip(row):
+    return [int(t) for t in row if t >= 0]
+
+
+# ------------------------------------------------------------------------------------------------ trie
+def _words(gold, tag):
+    return bytes(gold[f"trie::{tag}::words"]).split(b"\x00")
+
+
+@pytest.mark.parametrize("tag", ["kat", "syn"])
+def test_trie_structure_and_masses_match_reference(gold, oracle, tag):
+    import genlm_backend_amd  # noqa: F401
+    from genlm_backend_amd.tokenization import Token
+    from genlm_backend_amd.trie import TokenByteTrie
+
+    words = _words(gold, tag)
+    trie = TokenByteTrie([Token(i, w) for i, w in enumerate(words)])
+    # same node numbering, leaves, edges (in the reference's dict order) and prefixes
+    assert len(trie) == int(gold[f"trie::{tag}::n_nodes"][0]) and trie.root == int(gold[f"trie::{tag}::root"][0])
+    assert np.array_equal(trie.idx_to_leaf, gold[f"trie::{tag}::idx_to_leaf"])
+    tri = [(x, -1 - sym[1] if isinstance(sym, tuple) else int(sym), y) for x, ch in enumerate(trie.children)
+           for sym, y in ch.items()]
+    assert np.array_equal(np.array(tri, np.int64), gold[f"trie::{tag}::edges"])
+    assert [len(trie.node2prefix[i]) for i in range(len(trie))] == list(gold[f"trie::{tag}::prefix_len"])
+    assert trie.leaf2word[trie.word2leaf[(words[1], 1)]] == (words[1], 1)
+    # masses: the oracle's restatement of the kernel contract against the reference's own numbers
+    ws = gold[f"trie::{tag}::ws"]
+    for op, key in ((0, "sum"), (1, "max")):
+        got = oracle.trie_reduce(ws, trie.flat(), op)
+        assert np.abs(got - gold[f"trie::{tag}::{key}"]).max() < 1e-6
+    lp = np.log(np.maximum(ws, 1e-30)).astype(np.float32)
+    got = oracle.trie_reduce(lp, trie.flat(), 0, from_logprobs=True)
+    assert np.abs(got - gold[f"trie::{tag}::sum"]).max() < 1e-5
+    with pytest.raises(ValueError):
+        TokenByteTrie([Token(0, b"a"), Token(0, b"a")])
+
+
+def test_trie_known_answers(gold, oracle):
+    """tests/test_trie.py:26-85 of the reference, by prefix."""
+    from genlm_backend_amd.tokenization import Token
+    from genlm_backend_amd.trie import TokenByteTrie
+
+    trie = TokenByteTrie([Token(0, b"a"), Token(1, b"b"), Token(2, b"ab"), Token(3, b"<eos>")])
+    ws = np.array([[0.1, 0.2, 0.2, 0.5]], np.float32)
+    s, m = oracle.trie_reduce(ws, trie.flat(), 0)[0], oracle.trie_reduce(ws, trie.flat(), 1)[0]
+    leaf = {b"a": 0.1, b"b": 0.2, b"ab": 0.2, b"<eos>": 0.5}
+    want_s = {b"": 1, b"a": 0.3, b"b": 0.2, b"ab": 0.2, b"<": 0.5, b"<e": 0.5, b"<eo": 0.5, b"<eos": 0.5, b"<eos>": 0.5}
+    want_m = dict(want_s)
+    want_m.update({b"": 0.5, b"a": 0.2})
+    for node, prefix in trie.node2prefix.items():
+        p = bytes(prefix)
+        if node in trie.leaf2word:
+            assert np.isclose(s[node], leaf[p]) and np.isclose(m[node], leaf[p])
+        else:
+            assert np.isclose(s[node], want_s[p], rtol=1e-5) and np.isclose(m[node], want_m[p], rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ byte vocabulary
+def _split(gold, tag):
+    lens, raw = gold[f"bv::{tag}::lens"], bytes(gold[f"bv::{tag}::bytes"])
+    out, at = [], 0
+    for n in lens:
+        out.append(raw[at:at + int(n)])
+        at += int(n)
+    return out
+
+
+def test_byte_vocab_matches_reference_on_bpe_and_sentencepiece(gold):
+    import sentencepiece as spm
+    from tokenizers import Tokenizer
+    from transformers import PreTrainedTokenizerFast
+
+    import genlm_backend_amd  # noqa: F401
+    from genlm_backend_amd.tokenization import decode_vocab, get_byte_vocab
+
+    fast = PreTrainedTokenizerFast(tokenizer_object=Tokenizer.from_file(os.path.join(GD, "bpe_tokenizer.json")),
+                                   eos_token="<|endoftext|>")
+    assert get_byte_vocab(fast) == _split(gold, "bpe")
+    bv, sv = decode_vocab(fast)
+    assert [t.byte_string for t in bv] == _split(gold, "bpe") and len(sv) == len(bv)
+
+    class SpTok:  # the slice of a slow SentencePiece tokenizer the decoder reads
+        def __init__(self, path):
+            self.sp_model = spm.SentencePieceProcessor(model_file=path)
+            self._added = {"<extra_0>": self.sp_model.get_piece_size()}
+
+        def get_added_vocab(self):
+            return dict(self._added)
+
+        def __len__(self):
+            return self.sp_model.get_piece_size() + 1
+
+    assert get_byte_vocab(SpTok(os.path.join(GD, "spm_tiny.model"))) == _split(gold, "spm")
+
+
+def test_default_table_knows_whitespace_and_the_sentencepiece_space():
+    """Pieces of fast tokenizers without byte_decoder / sp_model may carry U+2581 and literal whitespace (Llama-2 /
+    Mistral / T5 style): the default table maps them (bytes.py:214-231).  A table that cannot reproduce the probe
+    string is refused (bytes.py:118-187), here as in the reference."""
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+
+    from genlm_backend_amd.tokenization import ByteVocabError, _via_char_table, default_char_table, get_byte_vocab
+
+    table = default_char_table()
+    assert table["\u2581"] == 32 and table[" "] == 32 and table["\n"] == 10 and table["\t"] == 9 and table["\r"] == 13
+    vocab = {"<unk>": 0, "\u2581the": 1, "\u2581": 2, "a b": 3, "x\n": 4}
+    tok = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+    tok.pre_tokenizer = pre_tokenizers.Whitespace()
+    fast = PreTrainedTokenizerFast(tokenizer_object=tok, unk_token="<unk>")
+    bv = _via_char_table(fast, table)
+    assert bv[1] == b" the" and bv[2] == b" " and bv[3] == b"a b" and bv[4] == b"x\n"
+    with pytest.raises(ByteVocabError):  # this toy vocabulary cannot spell the probe string: not a byte-level table
+        get_byte_vocab(fast)
+
+
+# ------------------------------------------------------------------------------------------------ config 3 / llama
+class Tok:
+    pad_token_id = None
+    eos_token_id = 0
+
+
+def _gpt2_tiny():
+    from transformers import GPT2Config, GPT2LMHeadModel
+
+    import genlm_backend_amd  # noqa: F401
+    from genlm_backend_amd.llm import AsyncAmdLM
+
+    g = np.load(os.path.join(GD, "ref_hotpath_tiny.npz"))
+    cfg = ast.literal_eval(bytes(g["config_json"]).decode())
+    model = GPT2LMHeadModel(GPT2Config(**cfg)).eval()
+    model.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w::")})
+    m = AsyncAmdLM(model, None, batch_size=128, engine=CpuOracleEngine())
+    m.tokenizer = Tok()
+    return m
+
+
+@pytest.mark.parametrize("K", [1, 8, 64])
+@pytest.mark.parametrize("mode", ["plain", "prefix", "pkv"])
+def test_config3_shared_ragged_prompts(gold, K, mode):
+    """BASELINE config 3: particles over K distinct shared prompts of ragged length; dedup + (prefix | per-particle) KV.
+    Tokens equal the reference's run, weights within 1e-4."""
+    from genlm_backend_amd.sis import DeviceSIS
+
+    m = _gpt2_tiny()
+    m.register_masks(torch.from_numpy(gold["c3::masks"]))
+    prompts = [_strip(r) for r in gold[f"c3::K{K}::prompts"]]
+    per = [prompts[i % K] for i in range(64)]
+    sis = DeviceSIS(m, 64, per, max_tokens=6, eos_id=0, seed=4321 + K, rng="torch", use_prefix_kv=mode == "prefix",
+                    use_particle_kv=mode == "pkv")
+    sis.run()
+    ctx, lw = sis.results()
+    assert [list(map(int, c)) for c in ctx] == [_strip(r) for r in gold[f"c3::K{K}::contexts"]]
+    assert np.abs(lw - gold[f"c3::K{K}::log_weights"]).max() < TOL
+    if K == 1:  # the reference's own cache_kv run agrees with its plain run
+        assert np.array_equal(gold["c3::K1::contexts_kv"], gold["c3::K1::contexts"])
+        assert np.abs(lw - gold["c3::K1::log_weights_kv"]).max() < TOL
+    assert m.stats["unique"] == 0  # DeviceSIS bypasses the queue; dedup happened on the "device"
+    assert sis.last_stats["n_unique"] <= 64
+
+
+def _llama_tiny(gold, engine=None, device="cpu"):
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    import genlm_backend_amd  # noqa: F401
+    from genlm_backend_amd.llm import AsyncAmdLM
+
+    cfg = ast.literal_eval(bytes(gold["llama::config_json"]).decode())
+    model = LlamaForCausalLM(LlamaConfig(**cfg)).eval()
+    model.load_state_dict({k[len("llama::w::"):]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("llama::w::")})
+    m = AsyncAmdLM(model.to(device), None, batch_size=64, engine=engine or CpuOracleEngine())
+    m.tokenizer = Tok()
+    return m
+
+
+def test_llama_shaped_model_matches_reference(gold):
+    """BASELINE config 4's model family (RoPE, grouped-query attention) through the backend: batched log-probs of
+    ragged prompts, and the SIS loop over three shared prompts with every KV variant."""
+    import asyncio
+
+    from genlm_backend_amd.sis import DeviceSIS
+
+    m = _llama_tiny(gold)
+    prompts = [_strip(r) for r in gold["llama::lp_prompts"]]
+    got = asyncio.run(m.batch_next_token_logprobs(prompts)).numpy()
+    assert np.abs(got - gold["llama::lp_values"]).max() < TOL
+    assert np.abs(got - gold["llama::lp_uncached"]).max() < TOL
+    m.register_masks(torch.from_numpy(gold["llama::sis_masks"]))
+    p3 = [_strip(r) for r in gold["llama::sis_prompts"]]
+    per = [p3[i % 3] for i in range(24)]
+    for kw in (dict(), dict(use_prefix_kv=True), dict(use_particle_kv=True)):
+        sis = DeviceSIS(m, 24, per, max_tokens=6, eos_id=0, seed=999, rng="torch", **kw)
+        sis.run()
+        ctx, lw = sis.results()
+        assert [list(map(int, c)) for c in ctx] == [_strip(r) for r in gold["llama::sis_contexts"]]
+        assert np.abs(lw - gold["llama::sis_log_weights"]).max() < TOL
