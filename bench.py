@@ -326,7 +326,7 @@ def pmc_traffic(workload):
     import glob
 
     try:
-        prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"{workload}_pmc_traffic*.json")))
+        prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"{workload}_pmc_traffic*.json")), key=os.path.getmtime)
         if prof:
             t = json.load(open(prof[-1]))
             return t["hbm_read_bytes_per_launch_corrected"] + t["hbm_write_bytes_per_launch"]

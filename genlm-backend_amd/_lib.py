@@ -48,6 +48,7 @@ class StepArgs(C.Structure):
         ("out_logZ", C.c_void_p),
         ("out_lse", C.c_void_p),
         ("out_token", C.c_void_p),
+        ("out_margin", C.c_void_p),
         ("reserved", C.c_int32),
         ("workspace", C.c_void_p),
         ("workspace_bytes", C.c_size_t),

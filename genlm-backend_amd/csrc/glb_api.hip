@@ -191,6 +191,107 @@ __global__ __launch_bounds__(1024) void group_contexts_kernel(
   for (int i = tid; i < n; i += T) out_group_of[i] = gid_of[minidx[slot_of[i]]];
 }
 
+// Exact dedup with the hash table in LDS (n <= 4096 contexts: every launch of the BASELINE configurations).  Same
+// result as group_contexts_kernel - groups numbered by first appearance, representative = smallest index - but
+// no global-memory atomics and no table in the workspace to clear: each thread keeps its contexts' slots in
+// registers, tokens are fetched with independent loads before they are hashed, and the only global traffic besides
+// the tokens is the output.  One workgroup: the whole job is a handful of memory latencies.
+template <int PER>
+__global__ __launch_bounds__(1024) void group_contexts_lds_kernel(const int32_t *tok, const int64_t *st,
+                                                                   const int32_t *len, int32_t n, int32_t cap,
+                                                                   int32_t *out_group_of, int32_t *out_rep,
+                                                                   int32_t *out_n_groups) {
+  extern __shared__ int32_t s_dyn[];
+  int32_t *s_table = s_dyn, *s_min = s_dyn + cap;
+  __shared__ int32_t s_wave[16];
+  const int T = 1024, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < cap; i += T) {
+    s_table[i] = -1;
+    s_min[i] = 0x7fffffff;
+  }
+  // thread t owns the PER consecutive contexts t*PER ..: one block scan then numbers the groups in index order
+  int32_t slot[PER], li[PER];
+  int64_t si[PER];
+  uint64_t h[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int i = tid * PER + k;
+    li[k] = i < n ? len[i] : 0;
+    si[k] = i < n ? st[i] : 0;
+    h[k] = 0xcbf29ce484222325ull ^ (uint64_t)li[k];
+  }
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int32_t *t = tok + si[k];
+    int j = 0;
+    for (; j + 4 <= li[k]; j += 4) {  // four independent loads per trip
+      const uint32_t a = (uint32_t)t[j], b = (uint32_t)t[j + 1], c = (uint32_t)t[j + 2], d = (uint32_t)t[j + 3];
+      h[k] ^= a; h[k] *= 0x100000001b3ull; h[k] ^= h[k] >> 29;
+      h[k] ^= b; h[k] *= 0x100000001b3ull; h[k] ^= h[k] >> 29;
+      h[k] ^= c; h[k] *= 0x100000001b3ull; h[k] ^= h[k] >> 29;
+      h[k] ^= d; h[k] *= 0x100000001b3ull; h[k] ^= h[k] >> 29;
+    }
+    for (; j < li[k]; ++j) {
+      h[k] ^= (uint32_t)t[j]; h[k] *= 0x100000001b3ull; h[k] ^= h[k] >> 29;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int i = tid * PER + k;
+    slot[k] = 0;
+    if (i < n) {
+      int32_t s = (int32_t)(h[k] & (uint64_t)(cap - 1));
+      for (;;) {
+        const int32_t owner = atomicCAS(&s_table[s], -1, i);
+        if (owner == -1 || owner == i || same_ctx(tok, st, len, owner, i)) break;
+        s = (s + 1) & (cap - 1);
+      }
+      slot[k] = s;
+      atomicMin(&s_min[s], i);
+    }
+  }
+  __syncthreads();
+  // group ids in first-appearance order: exclusive scan of the representative flags in index order
+  int32_t flag[PER], mine = 0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int i = tid * PER + k;
+    flag[k] = (i < n && s_min[slot[k]] == i) ? 1 : 0;
+    mine += flag[k];
+  }
+  int32_t incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int32_t t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  int32_t g = incl - mine, total = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    const int32_t v = s_wave[w];
+    if (w < wave) g += v;
+    total += v;
+  }
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    if (flag[k]) {
+      s_table[slot[k]] = g;  // the slot's owner is not needed any more: it now names the group
+      out_rep[g] = tid * PER + k;
+      ++g;
+    }
+  }
+  if (tid == 0) *out_n_groups = total;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int i = tid * PER + k;
+    if (i < n) out_group_of[i] = s_table[slot[k]];
+  }
+}
+
 __global__ void match_prefixes_kernel(const int32_t *tok, const int64_t *st, const int32_t *len,
                                       int64_t n, const int32_t *ptok, const int64_t *pst,
                                       const int32_t *plen, int64_t np, int32_t *out_prefix,
@@ -588,8 +689,8 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
   }
   if (a->rng_mode < GLB_RNG_NONE || a->rng_mode > GLB_RNG_NOISE)
     return fail(GLB_EINVAL, "bad rng_mode %d", a->rng_mode);
-  if (a->rng_mode == GLB_RNG_NOISE && (!a->noise || a->noise_ld < a->vocab))
-    return fail(GLB_EINVAL, "noise tensor missing or noise_ld < vocab");
+  if (a->rng_mode == GLB_RNG_NOISE && (!a->noise || (a->noise_ld < a->vocab && a->noise_ld != 0)))
+    return fail(GLB_EINVAL, "noise tensor missing or noise_ld < vocab (0 = one row shared by every particle)");
   if (a->rng_mode != GLB_RNG_NONE && !a->out_token)
     return fail(GLB_EINVAL, "rng_mode set but out_token is null");
   if (!(a->logit_scale == a->logit_scale)) return fail(GLB_EINVAL, "logit_scale is NaN");
@@ -646,6 +747,7 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
   p.out_logZ = a->out_logZ;
   p.out_lse = a->out_lse;
   p.out_token = a->out_token;
+  p.out_margin = a->rng_mode == GLB_RNG_NOISE ? a->out_margin : nullptr;
   hipError_t e = launch_stats(a->dtype, p, kmask, a->logit_scale != 1.0f, s);
   if (e != hipSuccess) return hip_fail(e, "chunk_stats launch");
   e = launch_finish(a->dtype, p, kmask, a->rng_mode, s);
@@ -738,6 +840,31 @@ int glb_group_contexts(const int32_t *tokens, const int64_t *starts, const int32
   if (workspace_bytes < glb_group_contexts_workspace(n))
     return fail(GLB_ENOSPC, "workspace %zu < %zu bytes", workspace_bytes, glb_group_contexts_workspace(n));
   const int64_t cap = group_cap(n);
+  if (n <= 8192) {  // table in LDS (2 * cap ints <= 128 KiB), slots in registers
+    const size_t lds = (size_t)cap * 2 * sizeof(int32_t);
+    if (n > 4096) {
+      static bool big_lds = false;  // more than 64 KiB of dynamic LDS has to be allowed once per process
+      if (!big_lds) {
+        if (hipFuncSetAttribute((const void *)group_contexts_lds_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                128 * 1024) != hipSuccess)
+          return hip_fail(hipGetLastError(), "hipFuncSetAttribute(group_contexts)");
+        big_lds = true;
+      }
+      hipLaunchKernelGGL(group_contexts_lds_kernel<8>, dim3(1), dim3(1024), lds, (hipStream_t)stream, tokens, starts,
+                         lengths, (int32_t)n, (int32_t)cap, out_group_of, out_rep, out_n_groups);
+    } else if (n <= 1024)
+      hipLaunchKernelGGL(group_contexts_lds_kernel<1>, dim3(1), dim3(1024), lds, (hipStream_t)stream, tokens, starts,
+                         lengths, (int32_t)n, (int32_t)cap, out_group_of, out_rep, out_n_groups);
+    else if (n <= 2048)
+      hipLaunchKernelGGL(group_contexts_lds_kernel<2>, dim3(1), dim3(1024), lds, (hipStream_t)stream, tokens, starts,
+                         lengths, (int32_t)n, (int32_t)cap, out_group_of, out_rep, out_n_groups);
+    else
+      hipLaunchKernelGGL(group_contexts_lds_kernel<4>, dim3(1), dim3(1024), lds, (hipStream_t)stream, tokens, starts,
+                         lengths, (int32_t)n, (int32_t)cap, out_group_of, out_rep, out_n_groups);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "group_contexts launch");
+    return GLB_OK;
+  }
   int32_t *table = (int32_t *)workspace, *minidx = table + cap, *slot_of = minidx + cap,
           *gid_of = slot_of + n;
   hipLaunchKernelGGL(group_contexts_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, tokens,

@@ -64,6 +64,7 @@ struct StepParams {
   int64_t particle_base;
   float *out_logZ, *out_lse;
   int32_t *out_token;
+  float *out_margin;  // parity mode: relative gap between the two largest e_j / E_j of the race
   ChunkRec *recs;  // [n_pairs][nch]
 };
 
@@ -476,7 +477,7 @@ template <int DT, int MASK, int MODE>
 __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
   constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC;
   __shared__ uint64_t s_tot[16];
-  __shared__ float s_bestg[4];
+  __shared__ float s_bestg[4], s_secg[4];
   __shared__ int32_t s_bestj[4];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int pidx = blockIdx.x;  // one workgroup of four waves per particle
@@ -630,7 +631,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
       //      robin to the four waves; ties resolve to the smallest index at every level ------------------------------
       const float magicN = kMagic - N_msk;
       const float *E = p.noise + (int64_t)pidx * p.noise_ld;
-      float best = -1.0f;
+      float best = -1.0f, sec = -1.0f;  // sec: runner-up of the race (for the reported margin)
       int32_t bj = -1;
       for (int c = 0; c < nch; ++c)
         for (int i = wave; i < NVC; i += 4) {
@@ -645,32 +646,38 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
             const float e = chunk_term(y[k], magicN);
             const float g = ok ? e / E[ok ? j : 0] : -1.0f;
             const bool better = g > best;  // strict: the first maximum in this lane's (increasing) order stays
+            sec = better ? best : fmaxf(sec, g);
             best = better ? g : best;
             bj = better ? j : bj;
           }
         }
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
-        const float og = __shfl_xor(best, o, 64);
+        const float og = __shfl_xor(best, o, 64), os = __shfl_xor(sec, o, 64);
         const int32_t oj = __shfl_xor(bj, o, 64);
         const bool take = og > best || (og == best && oj >= 0 && (bj < 0 || oj < bj));
+        sec = fmaxf(fmaxf(sec, os), take ? best : og);
         best = take ? og : best;
         bj = take ? oj : bj;
       }
       if (lane == 0) {
         s_bestg[wave] = best;
+        s_secg[wave] = sec;
         s_bestj[wave] = bj;
       }
       __syncthreads();
       if (wave == 0) {
 #pragma unroll
         for (int w = 1; w < 4; ++w) {
-          const float og = s_bestg[w];
+          const float og = s_bestg[w], os = s_secg[w];
           const int32_t oj = s_bestj[w];
           const bool take = og > best || (og == best && oj >= 0 && (bj < 0 || oj < bj));
+          sec = fmaxf(fmaxf(sec, os), take ? best : og);
           best = take ? og : best;
           bj = take ? oj : bj;
         }
+        // how far the draw is from a tie: (winner - runner-up) / winner; 1 when there is no runner-up
+        if (lane == 0 && p.out_margin) p.out_margin[pidx] = sec < 0.0f ? 1.0f : (best - sec) / best;
       }
       tok = bj;
     }

@@ -85,7 +85,7 @@ class HipEngine:
 
     def step(self, logits, vocab=None, row_of=None, mask_kind=MASK_NONE, mask=None, mask_id=None,
              rng_mode=RNG_NONE, noise=None, seed=0, offset=0, particle_base=0, logit_scale=1.0,
-             want_lse=True, variant=0, out=None, row_mask_id=None):
+             want_lse=True, variant=0, out=None, row_mask_id=None, out_margin=None):
         """Fused particle step (glb_logprob_mask_sample).  Returns (logZ, lse, token) device tensors.
 
         logits: [n_rows, ld] (last dim contiguous; rows may be strided), vocab <= ld.
@@ -145,11 +145,13 @@ class HipEngine:
             if noise.dim() != 2 or noise.dtype != torch.float32:
                 raise ValueError("noise must be float32 [n_particles, >=vocab]")
             a.noise = noise.data_ptr()
-            a.noise_ld = noise.stride(0) if noise.shape[0] > 1 else noise.shape[1]
+            # one row for everybody (batch_sample seeds every sequence alike): pitch 0
+            a.noise_ld = noise.stride(0) if noise.shape[0] > 1 else (0 if n > 1 else noise.shape[1])
         a.seed, a.offset, a.particle_base = seed, offset, particle_base
         a.out_logZ = None if logZ is None else logZ.data_ptr()
         a.out_lse = None if lse is None else lse.data_ptr()
         a.out_token = None if tok is None else tok.data_ptr()
+        a.out_margin = None if out_margin is None else out_margin.data_ptr()  # parity mode: tie margin of every draw
         ws = self._scratch(self.lib.glb_step_workspace_bytes(n, n_rows, V, n_masks))
         a.workspace = ws.data_ptr()
         a.workspace_bytes = ws.numel()

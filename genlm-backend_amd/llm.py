@@ -739,26 +739,31 @@ class AsyncAmdLM(AsyncLM):
         """base.py:62-73"""
         return self._batch_logprobs(token_ids_list)
 
-    # ---- sampling (base.py:110-146) -------------------------------------------------------------------------
-    def _make_generator(self, seed):
-        if seed is None:
-            return None
-        from .engine import HostRng
+    # ---- sampling (base.py:110-179): a device-resident multi-token loop -----------------------------------------------
+    @torch.no_grad()
+    def batch_sample_sync(self, prompt_token_ids_list, max_tokens, eos_token_ids, temperature=1.0, seed=None):
+        """base.py:148-179.  All sequences advance together on the device (sis.DeviceSampler): per-sequence KV slabs,
+        softmax(logits / temperature) -> one draw per sequence per forward by the fused step, stop on `eos_token_ids`.
+        With a seed every sequence reproduces torch.multinomial under its own torch.Generator().manual_seed(seed)
+        (base.py:125-141); without one the draws come from the in-kernel Philox stream."""
+        from .sis import DeviceSampler
 
-        return HostRng(seed)
+        if not prompt_token_ids_list:
+            return []
+        if any(len(p) == 0 for p in prompt_token_ids_list):
+            raise ValueError("Token ids must not be empty")
+        if max_tokens <= 0:
+            return [[] for _ in prompt_token_ids_list]
+        smp = DeviceSampler(self, prompt_token_ids_list, max_tokens, eos_token_ids, temperature, seed)
+        return [[int(t) for t in row] for row in smp.generate()]
 
-    def _draw(self, logprobs, temperature, generator_state):
-        """softmax(logprobs / T) -> one draw, on the device.  With a seed the draw reproduces
-        torch.multinomial(probs.cpu(), 1, generator=torch.Generator().manual_seed(seed)) (base.py:136-141);
-        without one it uses the in-kernel Philox stream keyed from torch's global generator."""
-        x = (logprobs / temperature).reshape(1, -1).contiguous()
-        if generator_state is not None:
-            noise = generator_state.exponential(x.shape[1]).view(1, -1).to(self.device)
-            _, _, tok = self.engine.step(x, rng_mode=RNG_NOISE, noise=noise, want_lse=False)
-        else:
-            seed = int(torch.randint(0, 2**62, (1,)).item())
-            _, _, tok = self.engine.step(x, rng_mode=RNG_PHILOX, seed=seed, want_lse=False)
-        return int(tok.item())
+    async def batch_sample(self, prompt_token_ids_list, max_tokens, eos_token_ids, temperature=1.0, seed=None):
+        """base.py:148-179"""
+        return self.batch_sample_sync(prompt_token_ids_list, max_tokens, eos_token_ids, temperature, seed)
+
+    async def sample(self, prompt_token_ids, max_tokens, eos_token_ids, temperature=1.0, seed=None):
+        """base.py:110-146"""
+        return self.batch_sample_sync([prompt_token_ids], max_tokens, eos_token_ids, temperature, seed)[0]
 
 
 def load_model_by_name(name, backend=None, llm_opts=None):

@@ -141,6 +141,7 @@ class DeviceSIS:
             assert not use_prefix_kv
         self.resample_ess = resample_ess
         self.n_resamples = 0
+        self.sync_every = 1  # per-particle-KV steps: how often the active counts are read back (one small D2H copy)
         self.pkv = None
         self.reset()
 
@@ -172,6 +173,7 @@ class DeviceSIS:
         self.last_stats = None
         self.kernel_events = []
         self.pkv = None
+        self._head_cache = None
         self._kv_stale = None  # bool [N]: rows whose KV has to be rebuilt from the context (ancestor on another rank)
         # active particles over all ranks as of the last exchange (device scalar; read with the step's one D2H copy)
         self._global_active = torch.tensor(self.N * self.world, dtype=torch.int32, device=self.dev)
@@ -208,8 +210,10 @@ class DeviceSIS:
     def _step_particle_kv(self, time_kernel):
         """Steps t >= 1 with per-particle KV: one new token per particle (logits row i = particle i), ragged lengths."""
         eng, llm, dev, N = self.eng, self.llm, self.dev, self.N
-        head = torch.stack([self.active.sum().to(torch.int32), self._global_active]).cpu()  # the step's one D2H copy
-        n_active, n_global = int(head[0]), int(head[1])
+        if self.t % self.sync_every == 0 or self._head_cache is None:
+            head = torch.stack([self.active.sum().to(torch.int32), self._global_active]).cpu()  # the step's one D2H copy
+            self._head_cache = (int(head[0]), int(head[1]))
+        n_active, n_global = self._head_cache
         if self._kv_stale is not None:
             self._encode_into_slabs(torch.nonzero(self._kv_stale).flatten())
             self._kv_stale = None
@@ -407,6 +411,63 @@ class DeviceSIS:
         ln = self.lengths.cpu().numpy()
         pl = self.prompt_len.cpu().numpy()
         return [list(ctx[i, pl[i]:ln[i]]) for i in range(self.N)], self.log_weights.cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------
+# multi-token sampling on the device (base.py:110-179)
+# ------------------------------------------------------------------------------------------------
+class DeviceSampler(DeviceSIS):
+    """`AsyncLM.sample` / `batch_sample` as a device-resident loop: the sequences are the "particles" (per-sequence KV
+    slabs, one new token per sequence per forward), the draw is the fused step with logit_scale = 1/temperature and no
+    mask, stopping tokens are a set.  Seeded: every sequence draws from its own generator seeded alike (base.py:125-127),
+    i.e. step t of every sequence races against the SAME Exp(1) row - one host-generated row per step, shared by pitch 0.
+    Nothing is read back per token: the active count is fetched every `sync_every` steps."""
+
+    def __init__(self, llm, prompts, max_tokens, eos_token_ids, temperature=1.0, seed=None, sync_every=4):
+        super().__init__(llm, len(prompts), [list(p) for p in prompts], max_tokens, eos_id=-1,
+                         seed=0 if seed is None else int(seed), rng="philox", use_particle_kv=True)
+        self.sync_every = max(1, int(sync_every))
+        self.temperature = float(temperature)
+        self.eos = torch.tensor(sorted(set(int(t) for t in eos_token_ids)), dtype=torch.int32, device=self.dev)
+        self.noise_rng = None
+        if seed is not None:
+            from .engine import HostRng
+
+            self.noise_rng = HostRng(int(seed))
+        else:  # unseeded: in-kernel Philox keyed from torch's global generator
+            self.seed = int(torch.randint(0, 2**62, (1,)).item())
+
+    def _finish_step(self, logits, group_of, U, n_active, n_global, time_kernel, l_max):
+        eng, N, dev = self.eng, self.N, self.dev
+        V = logits.shape[-1]
+        kw = {}
+        mode = RNG_PHILOX
+        if self.noise_rng is not None:
+            mode = RNG_NOISE
+            kw["noise"] = self.noise_rng.exponential(V).view(1, V).to(dev, non_blocking=True)
+        _, _, tok = eng.step(logits, vocab=V, row_of=group_of, rng_mode=mode, seed=self.seed, offset=self.t,
+                             logit_scale=1.0 / self.temperature, want_lse=False, **kw)
+        act = self.active > 0
+        stop = act & (torch.isin(tok, self.eos) | (tok < 0) | (self.lengths - self.prompt_len >= self.max_tokens))
+        keep = act & ~stop
+        rows = torch.arange(N, device=dev)
+        at = self.lengths.long().clamp_max(self.cap - 1)
+        self.contexts[rows, at] = torch.where(keep, tok, self.contexts[rows, at])
+        self.lengths = self.lengths + keep.to(torch.int32)
+        self.active = (keep & (self.lengths - self.prompt_len < self.max_tokens)).to(torch.int32)
+        self.t += 1
+        self.max_len_now = min(self.max_len_now + 1, self.cap)
+        self._exchange()
+        return U, n_global
+
+    def generate(self):
+        steps = 0
+        while steps < self.max_tokens:
+            _, n_global = self.step()
+            steps += 1
+            if n_global == 0:
+                break
+        return self.results()[0]
 
 
 # ------------------------------------------------------------------------------------------------

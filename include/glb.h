@@ -105,7 +105,8 @@ typedef struct glb_step_args {
   /* rng */
   int32_t rng_mode;
   const float *noise; /* GLB_RNG_NOISE: [n_particles, noise_ld] device */
-  int64_t noise_ld;
+  int64_t noise_ld;   /* >= vocab, or 0: ONE row shared by every particle (base.py:148-179 seeds every sequence of a
+                         batch_sample call alike) */
   uint64_t seed;          /* GLB_RNG_PHILOX key */
   uint64_t offset;        /* GLB_RNG_PHILOX counter word (e.g. SIS step number) */
   int64_t particle_base;  /* global index of particle 0 of this call (multi-GPU shards) */
@@ -113,6 +114,8 @@ typedef struct glb_step_args {
   float *out_logZ;   /* [n_particles] logsumexp(log_softmax(x)+mask) */
   float *out_lse;    /* [n_particles] logsumexp(x) of the particle's row */
   int32_t *out_token;/* [n_particles] sampled id, -1 when every token is masked out */
+  float *out_margin; /* [n_particles] GLB_RNG_NOISE only: (winner - runner-up) / winner of the race e_j / E_j, i.e. how
+                        far the draw is from a tie that float rounding could flip (1 if there is no runner-up) */
   int32_t reserved;  /* must be 0 */
   /* device scratch of >= glb_step_workspace_bytes(...) bytes, 32-byte aligned: the per-chunk records the
      reduction kernel hands to the per-particle kernel (and, for GLB_MASK_BITS, the prepared masks) */

@@ -268,7 +268,7 @@ int orc_step(const void *logits, int dtype, int64_t n_rows, int64_t V, int64_t l
              float logit_scale, int64_t n_particles, const int32_t *row_of, int mask_kind,
              const void *mask, int64_t mask_ld, int64_t n_masks, const int32_t *mask_id,
              int rng_mode, const float *noise, int64_t noise_ld, uint64_t seed, uint64_t offset,
-             int64_t particle_base, float *out_logZ, float *out_lse, int32_t *out_token) {
+             int64_t particle_base, float *out_logZ, float *out_lse, int32_t *out_token, float *out_margin) {
   int64_t nch = (V + GLB_CHUNK - 1) / GLB_CHUNK;
   float *x = (float *)malloc(sizeof(float) * (size_t)V);
   float *y = (float *)malloc(sizeof(float) * (size_t)V);
@@ -376,13 +376,15 @@ int orc_step(const void *logits, int dtype, int64_t n_rows, int64_t V, int64_t l
         }
       } else { /* exponential race against caller noise: first maximum of e_j / E_j, e_j on the masked row scale */
         const float *E = noise + i * noise_ld;
-        float best = -1.0f;
+        float best = -1.0f, sec = -1.0f;
         for (int64_t j = 0; j < V; ++j) {
           if (!(y[j] > -INFINITY)) continue;
           float e = glb_chunk_term(y[j], GLB_MAGIC - N_msk);
           float g = e / E[j];
-          if (g > best) { best = g; tok = (int32_t)j; }
+          if (g > best) { sec = best; best = g; tok = (int32_t)j; }
+          else if (g > sec) sec = g;
         }
+        if (out_margin) out_margin[i] = sec < 0.0f ? 1.0f : (best - sec) / best;
       }
     }
     out_token[i] = tok;

@@ -18,6 +18,7 @@ What is pinned:
              WITHOUT cache_kv for K > 1: the reference's dedup key is the token suffix after the cached prefix
              (hf.py:214-220, the ":216 XXX" note), so two particles of different cached prompts that generated the same
              tokens would be merged into one forward row; with one cached prompt (K = 1) cache_kv is exercised too.
+  parity1024::*  torch-CPU log_softmax + mask + logsumexp + multinomial at the full headline size (1024 x 50257 fp32)
   llama::*   a tiny LlamaConfig (RoPE, grouped-query attention) through the reference's hf path: batched log-probs of
              ragged prompts, the uncached values, and a README SIS loop.
 """
@@ -238,6 +239,29 @@ def golden_llama(out):
     out["llama::sis_masks"] = torch.stack(MG.make_masks(V)).numpy()
 
 
+def golden_parity_full(out):
+    """torch-CPU results of the reference's per-particle op sequence (cache.py:96, README.md:84-87) at the FULL headline
+    size, 1024 x 50257 fp32 (tests/synth.py logits, two masks): sampled ids, logZ and the exponential race's margins."""
+    from tests import synth
+
+    B, V = 1024, 50257
+    x = torch.from_numpy(synth.logits(21, B, V))
+    masks = torch.from_numpy(synth.binary_masks(21, 2, V))
+    mid = torch.arange(B) % 2
+    masked = torch.log_softmax(x, -1) + masks[mid]
+    logZ = masked.logsumexp(-1)
+    g = torch.Generator()
+    g.manual_seed(2024)
+    p = (masked - logZ[:, None]).exp()
+    tok = torch.multinomial(p, 1, generator=g).flatten()
+    g.manual_seed(2024)
+    q = torch.empty(B, V).exponential_(1, generator=g)
+    top2 = (p / q).topk(2, -1).values
+    out["parity1024::logZ"] = logZ.numpy()
+    out["parity1024::token"] = tok.numpy().astype(np.int32)
+    out["parity1024::margin"] = ((top2[:, 0] - top2[:, 1]) / top2[:, 0]).numpy()
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     MG.install_shims()
@@ -246,5 +270,6 @@ if __name__ == "__main__":
     golden_byte_vocab(out)
     golden_config3(out)
     golden_llama(out)
+    golden_parity_full(out)
     np.savez_compressed(os.path.join(OUT, "ref_round2.npz"), **out)
     print("ref_round2.npz:", {k: v.shape for k, v in out.items() if "::w::" not in k})

@@ -62,8 +62,8 @@ def bf16_bits_to_f32(b):
 
 
 def step(logits, row_of=None, mask_kind=MASK_NONE, mask=None, mask_id=None, rng_mode=RNG_NONE,
-         noise=None, seed=0, offset=0, particle_base=0, logit_scale=1.0, n_particles=None):
-    """Layer-B particle step.  Returns (logZ, lse, token)."""
+         noise=None, seed=0, offset=0, particle_base=0, logit_scale=1.0, n_particles=None, want_margin=False):
+    """Layer-B particle step.  Returns (logZ, lse, token) [+ the race's tie margin with want_margin]."""
     logits = np.ascontiguousarray(logits)
     n_rows, ld = logits.shape
     V = ld
@@ -85,15 +85,16 @@ def step(logits, row_of=None, mask_kind=MASK_NONE, mask=None, mask_id=None, rng_
     logZ = np.empty(n, np.float32)
     lse = np.empty(n, np.float32)
     tok = np.full(n, -2, np.int32)
+    margin = np.ones(n, np.float32) if want_margin else None
     rc = lib().orc_step(
         _p(logits), _dtype_code(logits), C.c_int64(n_rows), C.c_int64(V), C.c_int64(ld),
         C.c_float(logit_scale), C.c_int64(n), _p(row_of), C.c_int(mask_kind), _p(mask),
         C.c_int64(mask_ld), C.c_int64(n_masks), _p(mask_id), C.c_int(rng_mode), _p(noise),
         C.c_int64(noise_ld), C.c_uint64(seed), C.c_uint64(offset), C.c_int64(particle_base),
-        _p(logZ), _p(lse), _p(tok))
+        _p(logZ), _p(lse), _p(tok), _p(margin))
     if rc:
         raise RuntimeError(f"orc_step rc={rc}")
-    return logZ, lse, tok
+    return (logZ, lse, tok, margin) if want_margin else (logZ, lse, tok)
 
 
 def log_softmax_rows(logits, logit_scale=1.0):

@@ -39,6 +39,9 @@ class CpuOracleEngine:
         m = _np(mask)
         if mask_kind == 1:
             m = m.view(np.uint32)
+        if noise is not None and noise.shape[0] == 1:  # one noise row shared by every particle
+            n_p = logits.shape[0] if row_of is None else row_of.numel()
+            noise = noise.expand(n_p, noise.shape[1])
         if row_mask_id is not None:  # ids per logits row -> per particle for the oracle
             rm = _np(row_mask_id)
             mask_id = torch.from_numpy(rm if row_of is None else rm[_np(row_of)])

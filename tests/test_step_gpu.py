@@ -248,3 +248,33 @@ def test_many_rows_per_workgroup(engine, oracle):
     assert np.array_equal(_np(tok), tok_o)
     assert np.array_equal(_np(logZ).view(np.uint32), logZ_o.view(np.uint32))
     assert np.array_equal(_np(lse).view(np.uint32), lse_o.view(np.uint32))
+
+
+def test_parity_mode_at_the_headline_size(engine, oracle):
+    """1024 x 50257 fp32 in parity RNG mode against torch-CPU's log_softmax + mask + logsumexp + multinomial
+    (tests/golden/ref_round2.npz, parity1024::*): every sampled id identical, logZ within 1e-4, and the kernel's own
+    report of how close each draw was to a tie agrees with torch's race."""
+    import os
+
+    from genlm_backend_amd.engine import HostRng
+
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_round2.npz"))
+    B, V = 1024, 50257
+    dev = engine.device
+    x = synth.logits(21, B, V)
+    masks = synth.binary_masks(21, 2, V)
+    bits, _ = oracle.mask_f32_to_bits(masks)
+    mid = (np.arange(B) % 2).astype(np.int32)
+    noise = HostRng(2024).exponential(B * V).view(B, V).to(dev)
+    margin = torch.empty(B, device=dev)
+    logZ, lse, tok = engine.step(torch.from_numpy(x).to(dev), mask_kind=1, mask=_bits_dev(bits, dev),
+                                 mask_id=torch.from_numpy(mid).to(dev), rng_mode=2, noise=noise, out_margin=margin)
+    torch.cuda.synchronize()
+    assert np.array_equal(_np(tok), gold["parity1024::token"])
+    assert np.abs(_np(logZ) - gold["parity1024::logZ"]).max() < 1e-4
+    assert gold["parity1024::margin"].min() > 1e-4  # none of the golden draws was a near tie ...
+    assert np.abs(_np(margin) - gold["parity1024::margin"]).max() < 1e-3  # ... and the kernel reports the same margins
+    # first rows against the oracle, margins included, bit for bit
+    z_o, l_o, t_o, m_o = oracle.step(x[:8], mask_kind=oracle.MASK_BITS, mask=bits, mask_id=mid[:8], rng_mode=oracle.RNG_NOISE,
+                                     noise=noise[:8].cpu().numpy(), want_margin=True)
+    assert np.array_equal(_np(tok)[:8], t_o) and np.array_equal(_np(margin)[:8].view(np.uint32), m_o.view(np.uint32))

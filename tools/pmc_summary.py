@@ -1,6 +1,6 @@
-"""Condense rocprofv3 outputs under <dir> into the files committed under profiles/: per-kernel stats CSVs
-(first lines) and the HBM traffic of the fused kernel per launch (FETCH_SIZE x2 on gfx950, see
-MI355X_MICROARCH.md; counters are in KB)."""
+"""Condense the rocprofv3 outputs of tools/profile_round.sh under <dir> into the files committed under profiles/:
+per-kernel stats CSVs (first lines) and, per workload, the HBM traffic of one fused call = chunk_stats_kernel +
+finish_kernel (FETCH_SIZE x2 on gfx950 as MI355X_MICROARCH.md prescribes; WRITE_SIZE as read; counters are in KB)."""
 import csv
 import glob
 import json
@@ -8,6 +8,8 @@ import os
 import sys
 
 root = sys.argv[1]
+ALGO = {"kernel": 1024 * 50257 * 4 + 2 * 1571 * 4 + 1024 * 8, "kernel-llama": 512 * 128256 * 2 + 2 * 4008 * 4 + 512 * 8}
+KERNELS = ("glb::chunk_stats_kernel", "glb::finish_kernel")
 
 
 def first(pattern):
@@ -15,34 +17,37 @@ def first(pattern):
     return g[0] if g else None
 
 
-out = {}
-for tag, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
-    f = first(f"{sub}/**/*counter_collection.csv")
-    if not f:
+for wl in ("kernel", "kernel-llama"):
+    out = {}
+    for tag, sub in (("FETCH_SIZE", f"pmc_fetch_{wl}"), ("WRITE_SIZE", f"pmc_write_{wl}")):
+        f = first(f"{sub}/**/*counter_collection.csv")
+        if not f:
+            continue
+        per = {}
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if row.get("Counter_Name") != tag:
+                    continue
+                name = row["Kernel_Name"].split("<")[0].replace("void ", "")
+                if name in KERNELS:
+                    per.setdefault(name, []).append(float(row["Counter_Value"]))
+        for k, v in per.items():
+            out[f"{k}:{tag}"] = {"launches": len(v), "mean_raw_KB": sum(v) / len(v)}
+    if not out:
         continue
-    per = {}
-    with open(f) as fh:
-        for row in csv.DictReader(fh):
-            if row.get("Counter_Name") != tag:
-                continue
-            name = row["Kernel_Name"].split("<")[0].replace("void ", "")
-            if not name.startswith("glb::"):
-                continue
-            per.setdefault(name, []).append(float(row["Counter_Value"]))
-    for k, v in per.items():
-        out[f"{k}:{tag}"] = {"launches": len(v), "mean_raw_KB": sum(v) / len(v)}
-fetch = sum(v["mean_raw_KB"] for k, v in out.items() if k.endswith("FETCH_SIZE") and "row_kernel" in k)
-write = sum(v["mean_raw_KB"] for k, v in out.items() if k.endswith("WRITE_SIZE") and "row_kernel" in k)
-out["hbm_read_bytes_per_launch_corrected"] = fetch * 1024 * 2
-out["hbm_write_bytes_per_launch"] = write * 1024
-out["note"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python3 bench.py --workload kernel "
-               "--steps 20 --warmup 2 --no-cpu`; FETCH_SIZE doubled per MI355X_MICROARCH.md; algorithmic bytes per launch = "
-               "205873432")
-json.dump(out, open(os.path.join(root, "kernel_workload_pmc_traffic.json"), "w"), indent=1)
-for tag, sub in (("kernel", "kstats"), ("sis", "sstats")):
-    f = first(f"{sub}/**/*kernel_stats.csv")
+    fetch = sum(v["mean_raw_KB"] for k, v in out.items() if k.endswith("FETCH_SIZE"))
+    write = sum(v["mean_raw_KB"] for k, v in out.items() if k.endswith("WRITE_SIZE"))
+    out["hbm_read_bytes_per_launch_corrected"] = fetch * 1024 * 2
+    out["hbm_write_bytes_per_launch"] = write * 1024
+    out["algorithmic_bytes_per_launch"] = ALGO[wl]
+    out["note"] = (f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python3 bench.py --workload {wl} "
+                   "--steps 20 --warmup 2 --no-cpu`; one fused call = chunk_stats_kernel + finish_kernel; FETCH_SIZE doubled "
+                   "per MI355X_MICROARCH.md (gfx950 tallies 128-B read requests at 64 B)")
+    json.dump(out, open(os.path.join(root, f"{wl}_pmc_traffic.json"), "w"), indent=1)
+    print(wl, json.dumps(out, indent=1))
+for tag in ("kernel", "kernel-llama", "sis", "sis-llama"):
+    f = first(f"kstats_{tag}/**/*kernel_stats.csv")
     if f:
         lines = open(f).read().splitlines()
-        keep = [lines[0]] + [ln for ln in lines[1:] if len(ln) < 600][:25]
-        open(os.path.join(root, f"{tag}_workload_kernel_stats.csv"), "w").write("\n".join(keep) + "\n")
-print(json.dumps(out, indent=1))
+        keep = [lines[0]] + [ln for ln in lines[1:] if len(ln) < 700][:25]
+        open(os.path.join(root, f"{tag}_kernel_stats.csv"), "w").write("\n".join(keep) + "\n")

@@ -1,17 +1,33 @@
 #!/bin/bash
-# Runs on the GPU box (through gpurun): rocprofv3 kernel statistics of both bench workloads and the HBM traffic
-# counters of the fused kernel (separate --pmc passes, as MI355X_MICROARCH.md prescribes).  Output: gpurun_out/prof/
+# Runs on the GPU box (through gpurun): bench lines of every workload, rocprofv3 kernel statistics of the kernel and SIS
+# workloads and the HBM traffic counters of the fused step (separate --pmc passes, as MI355X_MICROARCH.md prescribes).
+# Output: gpurun_out/prof/ (copy what is to be judged into profiles/rNN/).
 set -e
-cd "${GRAFT_REPO_ROOT:-/root/repo}"
+R="${GRAFT_REPO_ROOT:-/root/repo}"
+cd /tmp
 export TMPDIR=/tmp
-O=gpurun_out/prof
+O=$R/gpurun_out/prof
 rm -rf $O && mkdir -p $O
-python3 bench.py --workload kernel --steps 200 --warmup 10 > $O/bench_kernel.json
-python3 bench.py --workload sis --steps 50 --warmup 5 > $O/bench_sis.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats -o k -- python3 bench.py --workload kernel --steps 100 --warmup 5 --no-cpu > $O/k_stats.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/sstats -o s -- python3 bench.py --workload sis --steps 30 --warmup 3 --no-cpu > $O/s_stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 bench.py --workload kernel --steps 20 --warmup 2 --no-cpu > $O/pmc_f.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 bench.py --workload kernel --steps 20 --warmup 2 --no-cpu > $O/pmc_w.log 2>&1
-python3 tools/pmc_summary.py $O
+for w in kernel kernel-llama; do
+  python3 $R/bench.py --workload $w --steps 200 --warmup 10 > $O/bench_$w.json 2> $O/bench_$w.err
+done
+python3 $R/bench.py --workload sis --steps 50 --warmup 10 > $O/bench_sis.json 2> $O/bench_sis.err
+python3 $R/bench.py --workload sis-llama --steps 30 --warmup 5 > $O/bench_sis-llama.json 2> $O/bench_sis-llama.err
+for w in "api" "api-coro" "api-logprobs"; do
+  python3 $R/bench.py --workload $w --steps 20 --warmup 3 --no-cpu > $O/bench_$w.json 2> $O/bench_$w.err
+done
+python3 $R/bench.py --workload sis --prefix-kv --prompts 8 --steps 30 --warmup 5 --no-cpu > $O/bench_sis_prefixkv_k8.json 2>> $O/bench_sis.err
+python3 $R/bench.py --workload sis --prefix-kv --prompts 64 --steps 30 --warmup 5 --no-cpu > $O/bench_sis_prefixkv_k64.json 2>> $O/bench_sis.err
+python3 $R/bench.py --workload sis --particle-kv --steps 30 --warmup 5 --no-cpu > $O/bench_sis_particlekv.json 2>> $O/bench_sis.err
+python3 $R/bench.py --workload sis --particle-kv --resample --steps 30 --warmup 5 --no-cpu > $O/bench_sis_particlekv_resample.json 2>> $O/bench_sis.err
+for w in kernel kernel-llama; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_$w -o k -- python3 $R/bench.py --workload $w --steps 100 --warmup 5 --no-cpu > $O/kstats_$w.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$w -o f -- python3 $R/bench.py --workload $w --steps 20 --warmup 2 --no-cpu > $O/pmc_f_$w.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$w -o w -- python3 $R/bench.py --workload $w --steps 20 --warmup 2 --no-cpu > $O/pmc_w_$w.log 2>&1
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_sis -o s -- python3 $R/bench.py --workload sis --steps 30 --warmup 3 --no-cpu > $O/kstats_sis.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_sis-llama -o s -- python3 $R/bench.py --workload sis-llama --steps 20 --warmup 3 --no-cpu > $O/kstats_sis-llama.log 2>&1
+python3 $R/tools/pmc_summary.py $O > $O/pmc_summary.log
 find $O -name "*.db" -delete 2>/dev/null || true
-ls -R $O | head -40
+find $O -name "*kernel_trace.csv" -delete 2>/dev/null || true
+ls $O
