@@ -222,8 +222,11 @@ __device__ __forceinline__ float chunk_max(const float (&x)[64]) {
 // ---------------------------------------------------------------------------------------------------------
 // chunk statistics: one wave per (reduction unit, chunk)
 // ---------------------------------------------------------------------------------------------------------
+#ifndef GLB_K1_MINW
+#define GLB_K1_MINW 1
+#endif
 template <int DT, int MASK, bool SCALED>
-__global__ __launch_bounds__(256) void chunk_stats_kernel(const StepParams p) {
+__global__ __launch_bounds__(256, GLB_K1_MINW) void chunk_stats_kernel(const StepParams p) {
   constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC;
   const int lane = threadIdx.x & 63;
   const int item = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
