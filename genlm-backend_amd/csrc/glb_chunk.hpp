@@ -175,16 +175,18 @@ __device__ __forceinline__ void store_rec(ChunkRec *dst, float Nc, uint32_t pA, 
   o[1] = b;
 }
 
-// sums of one chunk held in x[64]: returns the lane-63 totals of the four payload words
-template <int DT, bool MASKED>
+// sums of one chunk held in x[64]: returns the lane-63 totals of the four payload words.  (v0, VSTEP): this wave's
+// vectors are v0, v0 + VSTEP, ... (one wave per chunk: 0, 1; four waves per chunk: wave, 4) and x holds them densely.
+template <int DT, bool MASKED, int VSTEP = 1>
 __device__ __forceinline__ void chunk_sums(const float (&x)[64], float magicN, int nv_valid, cu64_t mt,
-                                           uint32_t &pA, uint32_t &pB, uint32_t &pAm, uint32_t &pBm) {
-  constexpr int EPV = ElemTraits<DT>::EPV, NVC = ElemTraits<DT>::NVC;
+                                           uint32_t &pA, uint32_t &pB, uint32_t &pAm, uint32_t &pBm, int v0 = 0) {
+  constexpr int EPV = ElemTraits<DT>::EPV, NVC = ElemTraits<DT>::NVC / VSTEP;
   float A0 = __uint_as_float(kA0Bits), A1 = A0, Am0 = A0, Am1 = A0;
   float B0 = __uint_as_float(kB0Bits), B1 = B0, Bm0 = B0, Bm1 = B0;
 #pragma unroll
   for (int i = 0; i < NVC; ++i) {
-    if (i < nv_valid) {  // wave-uniform: vectors wholly past the row end are skipped
+    const int vi = v0 + i * VSTEP;  // the vector's index inside the chunk
+    if (vi < nv_valid) {  // wave-uniform: vectors wholly past the row end are skipped
       float t[EPV];
 #pragma unroll
       for (int k = 0; k < EPV; ++k) t[k] = chunk_term(x[i * EPV + k], magicN);
@@ -192,10 +194,10 @@ __device__ __forceinline__ void chunk_sums(const float (&x)[64], float magicN, i
       for (int h = 0; h < EPV / 4; ++h) {
         uint64_t M0 = 0, M1 = 0, M2 = 0, M3 = 0;
         if constexpr (MASKED) {
-          M0 = mt[i * EPV + 4 * h + 0];
-          M1 = mt[i * EPV + 4 * h + 1];
-          M2 = mt[i * EPV + 4 * h + 2];
-          M3 = mt[i * EPV + 4 * h + 3];
+          M0 = mt[vi * EPV + 4 * h + 0];
+          M1 = mt[vi * EPV + 4 * h + 1];
+          M2 = mt[vi * EPV + 4 * h + 2];
+          M3 = mt[vi * EPV + 4 * h + 3];
         }
         rtz_acc4<MASKED>(t[4 * h], t[4 * h + 1], t[4 * h + 2], t[4 * h + 3], A0, B0, A1, B1, Am0, Bm0, Am1, Bm1,
                          M0, M1, M2, M3);
@@ -278,6 +280,71 @@ __global__ __launch_bounds__(256, GLB_K1_MINW) void chunk_stats_kernel(const Ste
     }
   }
   if (lane == 63) store_rec(p.recs + (int64_t)pr * nch + c, Nc, pA, pB, pAm, pBm, Nm);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// chunk statistics for launches that cannot fill the chip (a single shared row at SIS step 0, a lone API query):
+// one WORKGROUP of four waves per (unit, chunk); wave w takes vectors w, w+4, ... of the chunk, the chunk maximum and
+// the four payload sums are combined through LDS.  Same records as chunk_stats_kernel (integer sums do not care how
+// the elements were dealt out); a wave alone on its SIMD issues one instruction every ~5 cycles, so a quarter of the
+// elements per wave is what shortens the launch.  Bit masks / no mask only (float masks use the one-wave kernel).
+// ---------------------------------------------------------------------------------------------------------
+template <int DT, int MASK, bool SCALED>
+__global__ __launch_bounds__(256) void chunk_stats_small_kernel(const StepParams p) {
+  constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC, NVW = NVC / 4;
+  static_assert(MASK != kMaskF32, "float masks take the one-wave-per-chunk kernel");
+  __shared__ float s_max[4];
+  __shared__ uint32_t s_pay[4][4];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int item = blockIdx.x, nch = p.nch;
+  const int pr = item / nch, c = item - pr * nch;
+  const int row = p.pair_row ? as_const(p.pair_row)[pr] : pr;
+  const char *rowp = (const char *)p.logits + (int64_t)row * p.ld * ES;
+  const int V = p.V, e_base = c * kChunk;
+  int nv_valid = (V - e_base + 64 * EPV - 1) / (64 * EPV);
+  nv_valid = nv_valid < NVC ? nv_valid : NVC;
+  float x[64];
+#pragma unroll
+  for (int j = 0; j < 64; ++j) x[j] = kNegInf;
+#pragma unroll
+  for (int j = 0; j < NVW; ++j) {
+    const int e0 = e_base + ((wave + 4 * j) * 64 + lane) * EPV;
+    const u32x4_t r = load_vec_guarded<DT>(rowp, e0 < V ? e0 : V, V);
+    unpack_vec<DT>(r, &x[j * EPV]);
+    if constexpr (SCALED) {
+#pragma unroll
+      for (int k = 0; k < EPV; ++k) x[j * EPV + k] *= p.scale;
+    }
+  }
+  float m = kNegInf;
+#pragma unroll
+  for (int j = 0; j < NVW * EPV; j += 2) m = max3(m, x[j], x[j + 1]);
+  m = wave_max(m);
+  if (lane == 0) s_max[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+  const float Nc = exp_n(m);
+  uint32_t pA, pB, pAm, pBm;
+  if constexpr (MASK == kMaskBits) {
+    const int mi = p.pair_mask ? as_const(p.pair_mask)[pr] : (p.n_masks == 1 ? 0 : pr);
+    const cu64_t mt = as_const(p.mask_t + ((int64_t)mi * nch + c) * 64);
+    chunk_sums<DT, true, 4>(x, kMagic - Nc, nv_valid, mt, pA, pB, pAm, pBm, wave);
+  } else {
+    chunk_sums<DT, false, 4>(x, kMagic - Nc, nv_valid, nullptr, pA, pB, pAm, pBm, wave);
+  }
+  if (lane == 63) {
+    s_pay[wave][0] = pA;
+    s_pay[wave][1] = pB;
+    s_pay[wave][2] = pAm;
+    s_pay[wave][3] = pBm;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = s_pay[0][k] + s_pay[1][k] + s_pay[2][k] + s_pay[3][k];
+    store_rec(p.recs + (int64_t)pr * nch + c, Nc, t[0], t[1], t[2], t[3], Nc);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -497,6 +564,10 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
   rv.mt = MASK == kMaskBits ? p.mask_t + (int64_t)mi * nch * 64 : nullptr;
   rv.mrow = MASK == kMaskF32 ? (const char *)(p.mask_f + (int64_t)mi * p.mask_ld) : nullptr;
 
+  // the particle's 64 random bits do not depend on the records: computed while the first loads are in flight
+  uint64_t R = 0;
+  if constexpr (MODE == kModePhilox) R = philox_bits(p, pidx);
+
   // ---- fold the chunk records (every wave, same values): row scales, then the sums shifted onto them ------------
   float N_all = kNegInf, N_msk = kNegInf;
   for (int c0 = 0; c0 < nch; c0 += 64) {
@@ -578,7 +649,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
   int32_t tok = -1;
   if (S_msk != 0) {  // workgroup-uniform from here on: every wave holds the same S_msk / own / N_msk
     if constexpr (MODE == kModePhilox) {
-      uint64_t T = __umul64hi(philox_bits(p, pidx), S_msk);  // uniform integer in [0, S_msk)
+      uint64_t T = __umul64hi(R, S_msk);  // uniform integer in [0, S_msk)
       if (own) {
         if (wave == 0) {
           if (sparse_n >= 0) {

@@ -11,9 +11,23 @@ namespace glb {
 #define GLB_CAT_(a, b) a##b
 #define GLB_CAT(a, b) GLB_CAT_(a, b)
 
+// launches with fewer items than this use four waves per chunk (the chip has 1024 SIMDs; below about one wave per
+// two SIMDs the per-wave latency is the launch time)
+constexpr int64_t kSmallLaunchItems = 512;
+
 template <int MASK>
 static hipError_t stats1(const StepParams &p, bool scaled, hipStream_t s) {
   const int64_t waves = (int64_t)p.n_pairs * p.nch;
+  if constexpr (MASK != kMaskF32) {
+    if (waves <= kSmallLaunchItems) {
+      const dim3 grid((unsigned)waves), block(256);
+      if (scaled)
+        hipLaunchKernelGGL((chunk_stats_small_kernel<GLB_DT, MASK, true>), grid, block, 0, s, p);
+      else
+        hipLaunchKernelGGL((chunk_stats_small_kernel<GLB_DT, MASK, false>), grid, block, 0, s, p);
+      return hipGetLastError();
+    }
+  }
   const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
   if (scaled)
     hipLaunchKernelGGL((chunk_stats_kernel<GLB_DT, MASK, true>), grid, block, 0, s, p);

@@ -119,7 +119,7 @@ def test_log_softmax_rows(engine, oracle):
 
 
 V2_CASES = [
-    # (n_particles, n_rows, V, dtype, variant)   variant: persistent geometries 24/22/21/23/25 hold 4096/8192/12800/16384/20480 16-byte vectors
+    # (n_particles, n_rows, V, dtype, form)   form 0: mask ids per particle, bit rows prepared per call; 21+: prepared masks
     (700, 300, 50257, "f32", 21),
     (1024, 1024, 50257, "f32", 0),
     (130, 40, 65001, "f16", 23),
@@ -141,9 +141,10 @@ V2_CASES = [
 
 @pytest.mark.parametrize("N,U,V,dtype,variant", V2_CASES)
 @pytest.mark.parametrize("mask_kind", ["none", "bits"])
-def test_persistent_kernel_bit_exact(engine, oracle, N, U, V, dtype, variant, mask_kind):
-    """The persistent pipelined kernel + locate kernel give the same bits as the oracle (and so as v1):
-    more particles than CUs so every workgroup streams several rows, shared rows, unaligned rows."""
+def test_large_populations_bit_exact(engine, oracle, N, U, V, dtype, variant, mask_kind):
+    """Large populations (more waves than the chip holds at once), shared rows, unaligned rows, low-mass and empty
+    masks: the chunked reduction + per-particle finish give the same bits as the oracle, whichever way the masks
+    are handed over."""
     O = oracle
     x_np, x_t = _mk(O, U, V, dtype, seed=V + U)
     dev = engine.device
@@ -162,22 +163,24 @@ def test_persistent_kernel_bit_exact(engine, oracle, N, U, V, dtype, variant, ma
         kw_g = dict(mask_kind=1, mask=_bits_dev(bits, dev), mask_id=torch.from_numpy(mid).to(dev))
     logZ_o, lse_o, tok_o = O.step(x_np, row_of=row_of, rng_mode=O.RNG_PHILOX, seed=77, offset=5, particle_base=3, **kw_o)
     logZ, lse, tok = engine.step(x_t.to(dev), row_of=torch.from_numpy(row_of).to(dev), rng_mode=1, seed=77, offset=5,
-                                 particle_base=3, variant=variant, **kw_g)
+                                 particle_base=3, **kw_g)
     torch.cuda.synchronize()
     assert np.array_equal(_np(tok), tok_o)
     assert np.array_equal(_np(logZ).view(np.uint32), logZ_o.view(np.uint32))
     assert np.array_equal(_np(lse).view(np.uint32), lse_o.view(np.uint32))
-    # and the one-workgroup-per-particle kernel agrees
-    logZ1, lse1, tok1 = engine.step(x_t.to(dev), row_of=torch.from_numpy(row_of).to(dev), rng_mode=1, seed=77,
-                                    offset=5, particle_base=3, variant=-1, **kw_g)
-    assert torch.equal(tok, tok1) and torch.equal(logZ, logZ1) and torch.equal(lse, lse1)
+    if mask_kind == "bits" and variant:  # the same masks prepared once (GLB_MASK_PREPARED)
+        tdt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[dtype]
+        kw_p = dict(mask=engine.prepare_masks(kw_g["mask"], V, tdt), mask_id=kw_g["mask_id"])
+        logZ1, lse1, tok1 = engine.step(x_t.to(dev), row_of=torch.from_numpy(row_of).to(dev), rng_mode=1, seed=77,
+                                        offset=5, particle_base=3, **kw_p)
+        assert torch.equal(tok, tok1) and torch.equal(logZ, logZ1) and torch.equal(lse, lse1)
 
 
 @pytest.mark.parametrize("B,V,dtype", [(5, 70001, "f32"), (3, 262144, "bf16"), (4, 151936, "f16"), (6, 1000, "f32")])
 @pytest.mark.parametrize("mask_kind", ["none", "bits"])
 def test_streaming_fallback_bit_exact(engine, oracle, B, V, dtype, mask_kind):
-    """Rows longer than the register-resident capacity (and, forced by variant 99, short ones) take the
-    streaming multi-pass kernel: same bits."""
+    """Very long rows (up to 262144 columns: more than 64 chunks per row, the finish kernel's second sweep) and short
+    ones: same bits as the oracle."""
     O = oracle
     x_np, x_t = _mk(O, B, V, dtype, seed=V)
     dev = engine.device
@@ -189,7 +192,7 @@ def test_streaming_fallback_bit_exact(engine, oracle, B, V, dtype, mask_kind):
         kw_o = dict(mask_kind=O.MASK_BITS, mask=bits, mask_id=mid)
         kw_g = dict(mask_kind=1, mask=_bits_dev(bits, dev), mask_id=torch.from_numpy(mid).to(dev))
     logZ_o, lse_o, tok_o = O.step(x_np, rng_mode=O.RNG_PHILOX, seed=5, offset=2, **kw_o)
-    logZ, lse, tok = engine.step(x_t.to(dev), rng_mode=1, seed=5, offset=2, variant=99 if V < 65000 else 0, **kw_g)
+    logZ, lse, tok = engine.step(x_t.to(dev), rng_mode=1, seed=5, offset=2, **kw_g)
     torch.cuda.synchronize()
     assert np.array_equal(_np(tok), tok_o)
     assert np.array_equal(_np(logZ).view(np.uint32), logZ_o.view(np.uint32))
@@ -203,8 +206,8 @@ def test_streaming_fallback_bit_exact(engine, oracle, B, V, dtype, mask_kind):
 @pytest.mark.parametrize("variant,N,U,V,dtype", [(21, 600, 200, 50257, "f32"), (-1, 40, 20, 50257, "f32"),
                                                   (23, 400, 100, 128256, "bf16"), (99, 6, 6, 9000, "f16")])
 def test_logit_scale_and_stats_mode(engine, oracle, variant, N, U, V, dtype):
-    """Temperature scaling (base.py:136-141: logits / T before the softmax) and the statistics-only mode, on
-    the persistent, the one-workgroup-per-particle and the streaming kernel."""
+    """Temperature scaling (base.py:136-141: logits / T before the softmax) and the statistics-only mode, for launches
+    on both sides of the four-waves-per-chunk threshold."""
     O = oracle
     x_np, x_t = _mk(O, U, V, dtype, seed=V + 7)
     dev = engine.device
@@ -218,19 +221,19 @@ def test_logit_scale_and_stats_mode(engine, oracle, variant, N, U, V, dtype):
     for scale in (1.0, 0.7, 1.9):
         logZ_o, lse_o, tok_o = O.step(x_np, row_of=row_of, rng_mode=O.RNG_PHILOX, seed=9, offset=1, logit_scale=scale, **kw_o)
         logZ, lse, tok = engine.step(x_t.to(dev), row_of=rd, rng_mode=1, seed=9, offset=1, logit_scale=scale,
-                                     variant=variant, **kw_g)
+                                     **kw_g)
         assert np.array_equal(_np(tok), tok_o)
         assert np.array_equal(_np(logZ).view(np.uint32), logZ_o.view(np.uint32))
         assert np.array_equal(_np(lse).view(np.uint32), lse_o.view(np.uint32))
-        logZ, lse, tok = engine.step(x_t.to(dev), row_of=rd, rng_mode=0, logit_scale=scale, variant=variant, **kw_g)
+        logZ, lse, tok = engine.step(x_t.to(dev), row_of=rd, rng_mode=0, logit_scale=scale, **kw_g)
         assert tok is None
         assert np.array_equal(_np(logZ).view(np.uint32), logZ_o.view(np.uint32))
         assert np.array_equal(_np(lse).view(np.uint32), lse_o.view(np.uint32))
 
 
 def test_many_rows_per_workgroup(engine, oracle):
-    """More than 64 rows per persistent workgroup: the index table and the low-mass bitmap overflow into their
-    fallbacks (scalar index loads, workspace lookups)."""
+    """20 000 particles over 300 shared rows with low-mass and empty masks (mask ids per particle: every particle is
+    its own reduction unit)."""
     O = oracle
     N, U, V = 20000, 300, 1000
     x_np, x_t = _mk(O, U, V, "f32", seed=99)
@@ -244,7 +247,7 @@ def test_many_rows_per_workgroup(engine, oracle):
     logZ_o, lse_o, tok_o = O.step(x_np, row_of=row_of, rng_mode=O.RNG_PHILOX, seed=4, offset=2, mask_kind=O.MASK_BITS,
                                   mask=bits, mask_id=mid)
     logZ, lse, tok = engine.step(x_t.to(dev), row_of=torch.from_numpy(row_of).to(dev), rng_mode=1, seed=4, offset=2,
-                                 mask_kind=1, mask=_bits_dev(bits, dev), mask_id=torch.from_numpy(mid).to(dev), variant=24)
+                                 mask_kind=1, mask=_bits_dev(bits, dev), mask_id=torch.from_numpy(mid).to(dev))
     assert np.array_equal(_np(tok), tok_o)
     assert np.array_equal(_np(logZ).view(np.uint32), logZ_o.view(np.uint32))
     assert np.array_equal(_np(lse).view(np.uint32), lse_o.view(np.uint32))
@@ -278,3 +281,24 @@ def test_parity_mode_at_the_headline_size(engine, oracle):
     z_o, l_o, t_o, m_o = oracle.step(x[:8], mask_kind=oracle.MASK_BITS, mask=bits, mask_id=mid[:8], rng_mode=oracle.RNG_NOISE,
                                      noise=noise[:8].cpu().numpy(), want_margin=True)
     assert np.array_equal(_np(tok)[:8], t_o) and np.array_equal(_np(margin)[:8].view(np.uint32), m_o.view(np.uint32))
+
+
+def test_parity_and_float_masks_at_llama_width_fp32(engine, oracle):
+    """fp32 rows of 128256 columns with parity-noise draws and additive float masks (round 1 refused both above 65528
+    columns): bit-identical to the oracle."""
+    O = oracle
+    N, V = 6, 128256
+    x_np, x_t = _mk(O, N, V, "f32", seed=31)
+    dev = engine.device
+    rs = np.random.default_rng(2)
+    mf = synth.binary_masks(5, 2, V)
+    fin = np.isfinite(mf)
+    mf[fin] = rs.standard_normal(int(fin.sum())).astype(np.float32)
+    mid = (np.arange(N) % 2).astype(np.int32)
+    E, _ = O.mt_exponential(5, N * V)
+    E = E.reshape(N, V)
+    z_o, l_o, t_o = O.step(x_np, mask_kind=O.MASK_F32, mask=mf, mask_id=mid, rng_mode=O.RNG_NOISE, noise=E)
+    z, l, t = engine.step(x_t.to(dev), mask_kind=2, mask=torch.from_numpy(mf).to(dev), mask_id=torch.from_numpy(mid).to(dev),
+                          rng_mode=2, noise=torch.from_numpy(E).to(dev))
+    assert np.array_equal(_np(t), t_o) and np.array_equal(_np(z).view(np.uint32), z_o.view(np.uint32))
+    assert np.array_equal(_np(l).view(np.uint32), l_o.view(np.uint32))
