@@ -19,7 +19,9 @@ namespace glb {
   hipError_t launch_stats_##dt(const StepParams &p, int mask_kind, bool scaled, hipStream_t s);                   \
   hipError_t launch_finish_##dt(const StepParams &p, int mask_kind, int mode, hipStream_t s);                     \
   hipError_t launch_logprob_rows_##dt(const void *logits, int64_t ld, int V, float scale, const float *lse,       \
-                                      float *out, int64_t out_ld, int n_rows, hipStream_t s);
+                                      float *out, int64_t out_ld, int n_rows, hipStream_t s);                      \
+  hipError_t launch_logprob_fused_##dt(const void *logits, int64_t ld, int V, int nch, float scale, float *out,   \
+                                       int64_t out_ld, float *out_lse, int n_rows, hipStream_t s);
 GLB_DECL(0) GLB_DECL(1) GLB_DECL(2)
 #undef GLB_DECL
 }  // namespace glb
@@ -775,6 +777,16 @@ int glb_log_softmax_rows(const void *logits, int32_t dtype, int64_t n_rows, int6
   if (workspace_bytes < glb_log_softmax_workspace_bytes(n_rows, vocab))
     return fail(GLB_ENOSPC, "workspace %zu < %zu bytes", workspace_bytes, glb_log_softmax_workspace_bytes(n_rows, vocab));
   hipStream_t s = (hipStream_t)stream;
+  if (n_rows >= 128 && n_chunks(vocab) <= 4096) {  // enough rows for one workgroup each: single launch, one HBM read
+    hipError_t e;
+    switch (dtype) {
+      case 0: e = glb::launch_logprob_fused_0(logits, ld, (int)vocab, (int)n_chunks(vocab), logit_scale, out, out_ld, out_lse, (int)n_rows, s); break;
+      case 1: e = glb::launch_logprob_fused_1(logits, ld, (int)vocab, (int)n_chunks(vocab), logit_scale, out, out_ld, out_lse, (int)n_rows, s); break;
+      default: e = glb::launch_logprob_fused_2(logits, ld, (int)vocab, (int)n_chunks(vocab), logit_scale, out, out_ld, out_lse, (int)n_rows, s); break;
+    }
+    if (e != hipSuccess) return hip_fail(e, "logprob_rows_fused launch");
+    return GLB_OK;
+  }
   const size_t recs_bytes = align256((size_t)n_rows * (size_t)n_chunks(vocab) * sizeof(glb::ChunkRec));
   float *lse = out_lse ? out_lse : (float *)((char *)workspace + recs_bytes);
   glb::StepParams p{};

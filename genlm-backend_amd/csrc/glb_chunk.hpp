@@ -792,6 +792,99 @@ __global__ __launch_bounds__(256) void logprob_rows_kernel(const void *logits, i
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// log-probability rows in one launch: one 1024-thread workgroup per row.  Wave w reduces chunks w, w+16, ... of the
+// row (same per-chunk arithmetic as chunk_stats_kernel, records kept in LDS), one wave folds them into lse, then every
+// wave writes x - lse for its chunks: straight from its registers when the row has at most 16 chunks (ONE: a wave
+// owns one chunk - gpt2-sized rows), else after streaming them again (read microseconds ago: L2 / Infinity Cache serve
+// most of it).  HBM traffic ~ V*s + 4V per row instead of 2*V*s + 4V of the three-launch path; used when there are
+// enough rows to fill the chip (the three-launch path spreads a few rows over the chip chunk by chunk).
+// ---------------------------------------------------------------------------------------------------------
+template <int DT, bool SCALED, bool ONE>
+__global__ __launch_bounds__(1024) void logprob_rows_fused_kernel(const void *logits, int64_t ld, int V, int nch,
+                                                                 float scale, float *out, int64_t out_ld,
+                                                                 float *out_lse) {
+  constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC;
+  extern __shared__ uint64_t s_rec[];  // [nch] chunk sums, then [nch] floats of chunk scales
+  float *s_N = reinterpret_cast<float *>(s_rec + nch);
+  __shared__ float s_lse;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int r = blockIdx.x;
+  const char *rowp = (const char *)logits + (int64_t)r * ld * ES;
+  float x[64];
+  for (int c = wave; c < nch; c += 16) {
+    const int e_base = c * kChunk;
+    int nv_valid = (V - e_base + 64 * EPV - 1) / (64 * EPV);
+    nv_valid = nv_valid < NVC ? nv_valid : NVC;
+    load_chunk<DT, SCALED>(rowp, e_base, V, lane, scale, x);
+    const float Nc = exp_n(chunk_max(x));
+    uint32_t pA, pB, pAm, pBm;
+    chunk_sums<DT, false>(x, kMagic - Nc, nv_valid, nullptr, pA, pB, pAm, pBm);
+    if (lane == 63) {
+      s_rec[c] = ((uint64_t)pA << kGridHi) + pB;
+      s_N[c] = Nc;
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float N = kNegInf;
+    for (int c = lane; c < nch; c += 64)
+      if (s_rec[c]) N = fmaxf(N, s_N[c]);
+    N = wave_max(N);
+    uint64_t S = 0;
+    for (int c0 = 0; c0 < nch; c0 += 64) {
+      const int c = c0 + lane;
+      uint64_t sa = 0;
+      if (c < nch && s_rec[c]) {
+        const float d = N - s_N[c];
+        sa = d < 64.0f ? s_rec[c] >> (uint32_t)d : 0ull;
+      }
+      S += wave_sum_u64(sa);
+    }
+    if (lane == 0) {
+      const float lse = S ? (float)log_fix(S, (int32_t)N + 1 - kFrac) : kNegInf;
+      s_lse = lse;
+      if (out_lse) out_lse[r] = lse;
+    }
+  }
+  __syncthreads();
+  if (!out) return;
+  const float l = s_lse;
+  float *orow = out + (int64_t)r * out_ld;
+  for (int c = wave; c < nch; c += 16) {
+    const int e_base = c * kChunk;
+#pragma unroll
+    for (int i = 0; i < NVC; ++i) {
+      const int e0 = e_base + (i * 64 + lane) * EPV;
+      if (e0 >= V) continue;
+      float y[EPV];
+      if constexpr (ONE) {  // the wave's only chunk is still in its registers (already scaled)
+#pragma unroll
+        for (int k = 0; k < EPV; ++k) y[k] = x[i * EPV + k];
+      } else {
+        unpack_vec<DT>(load_vec_guarded<DT>(rowp, e0, V), y);
+        if constexpr (SCALED) {
+#pragma unroll
+          for (int k = 0; k < EPV; ++k) y[k] *= scale;
+        }
+      }
+      if (e0 + EPV <= V) {
+#pragma unroll
+        for (int h = 0; h < EPV / 4; ++h) {
+          float4 v;
+          v.x = y[4 * h] - l;
+          v.y = y[4 * h + 1] - l;
+          v.z = y[4 * h + 2] - l;
+          v.w = y[4 * h + 3] - l;
+          *reinterpret_cast<float4 *>(orow + e0 + 4 * h) = v;
+        }
+      } else {
+        for (int k = 0; k < V - e0; ++k) orow[e0 + k] = y[k] - l;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // mask preparation: bit rows [n_masks, mask_ld] -> transposed lane words + sparse-id lists.
 // Block (k, c) with c < nch transposes chunk c of mask k; block (k, nch) counts mask k and lists its ids.
 // ---------------------------------------------------------------------------------------------------------

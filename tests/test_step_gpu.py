@@ -302,3 +302,23 @@ def test_parity_and_float_masks_at_llama_width_fp32(engine, oracle):
                           rng_mode=2, noise=torch.from_numpy(E).to(dev))
     assert np.array_equal(_np(t), t_o) and np.array_equal(_np(z).view(np.uint32), z_o.view(np.uint32))
     assert np.array_equal(_np(l).view(np.uint32), l_o.view(np.uint32))
+
+
+@pytest.mark.parametrize("B,V,dtype,scale", [(160, 50257, "f32", 1.0), (130, 128256, "bf16", 0.7), (128, 4099, "f16", 1.0),
+                                             (200, 70001, "f32", 1.3)])
+def test_log_softmax_rows_single_launch_path(engine, oracle, B, V, dtype, scale):
+    """128 rows and more take the one-workgroup-per-row kernel (one HBM read of the logits): same bits as the oracle
+    (and as the three-launch path, which smaller batches take)."""
+    O = oracle
+    x_np, x_t = _mk(O, B, V, dtype, seed=V + B)
+    dev = engine.device
+    ld = V + 3
+    buf = torch.zeros((B, ld), dtype=x_t.dtype)
+    buf[:, :V] = x_t
+    want, lse_o = O.log_softmax_rows(x_np, scale)
+    got, lse = engine.log_softmax_rows(buf.to(dev)[:, :V], vocab=V, logit_scale=scale, want_lse=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(_np(lse).view(np.uint32), lse_o.view(np.uint32))
+    assert np.array_equal(_np(got).view(np.uint32), want.view(np.uint32))
+    few, lse_few = engine.log_softmax_rows(buf.to(dev)[:5, :V], vocab=V, logit_scale=scale, want_lse=True)
+    assert torch.equal(few, got[:5]) and torch.equal(lse_few, lse[:5])
