@@ -442,8 +442,9 @@ __device__ __forceinline__ int32_t walk_vectors(const RowView<DT, MASK> &rv, int
 
 // The draw inside one chunk, by the four waves of the particle's workgroup: wave w takes vectors w, w+4, ... of the
 // chunk (one burst of loads), sums their allowed terms with the round-toward-zero adds and parks the per-vector
-// totals in LDS; wave 0 then finds the vector holding the target by a scan over the <= 16 totals and walks only
-// that vector element by element.  Every wave must call this (it contains a workgroup barrier).
+// totals in LDS; every wave then finds the vector holding the target by a scan over the <= 16 totals, and the wave
+// that loaded that vector walks it element by element straight from its registers.  Every wave must call this (it
+// contains a workgroup barrier); the owning wave returns the token, the others -1.
 template <int DT, int MASK>
 __device__ __forceinline__ int32_t draw_in_chunk(const RowView<DT, MASK> &rv, int c, int lane, int wave,
                                                  float magicN, uint64_t T, uint64_t *s_tot) {
@@ -456,13 +457,13 @@ __device__ __forceinline__ int32_t draw_in_chunk(const RowView<DT, MASK> &rv, in
     const int e0 = e_base + ((wave + 4 * j) * 64 + lane) * EPV;
     raw[j] = load_vec_guarded<DT>(rv.rowp, e0 < rv.V ? e0 : rv.V, rv.V);
   }
+  float y[NVW][EPV];  // this wave's (masked-by-value for float masks) logits, kept for the walk
 #pragma unroll
   for (int j = 0; j < NVW; ++j) {
     const int i = wave + 4 * j;
-    float t[EPV];
-    unpack_vec<DT>(raw[j], t);
+    unpack_vec<DT>(raw[j], y[j]);
 #pragma unroll
-    for (int k = 0; k < EPV; ++k) t[k] *= rv.scale;
+    for (int k = 0; k < EPV; ++k) y[j][k] *= rv.scale;
     if constexpr (MASK == kMaskF32) {
 #pragma unroll
       for (int h = 0; h < EPV / 4; ++h) {
@@ -471,11 +472,12 @@ __device__ __forceinline__ int32_t draw_in_chunk(const RowView<DT, MASK> &rv, in
         float mk[4];
         unpack_vec<kDtF32>(r, mk);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) t[4 * h + k] += mk[k];
+        for (int k = 0; k < 4; ++k) y[j][4 * h + k] += mk[k];
       }
     }
+    float t[EPV];
 #pragma unroll
-    for (int k = 0; k < EPV; ++k) t[k] = chunk_term(t[k], magicN);
+    for (int k = 0; k < EPV; ++k) t[k] = chunk_term(y[j][k], magicN);
     float Am = __uint_as_float(kA0Bits), Bm = __uint_as_float(kB0Bits);
 #pragma unroll
     for (int h = 0; h < EPV / 4; ++h) {
@@ -493,13 +495,38 @@ __device__ __forceinline__ int32_t draw_in_chunk(const RowView<DT, MASK> &rv, in
     if (lane == 63) s_tot[i] = ((uint64_t)pa << kGridHi) + pb;
   }
   __syncthreads();
-  if (wave != 0) return -1;
   const uint64_t wv = lane < NVC ? s_tot[lane] : 0ull;
   const uint64_t incl = wave_scan_u64(wv);
   const int isel = first_lane_above(incl, T);
-  if (isel < 0) return -1;
+  if (isel < 0 || (isel & 3) != wave) return -1;
   T -= readlane_u64(incl - wv, isel);
-  return walk_vectors(rv, c, isel, isel + 1, lane, magicN, T);
+  // walk vector isel = wave + 4 * jsel from the registers: lane -> element, in vocabulary order
+  const int jsel = isel >> 2;
+  uint64_t q[EPV], s = 0;
+#pragma unroll
+  for (int k = 0; k < EPV; ++k) {
+    float v = y[0][k];
+#pragma unroll
+    for (int j = 1; j < NVW; ++j) v = jsel == j ? y[j][k] : v;
+    const int e = e_base + (isel * 64 + lane) * EPV + k;
+    bool ok = e < rv.V;
+    if constexpr (MASK == kMaskBits) ok = ok && ((mt[isel * EPV + k] >> lane) & 1ull);
+    q[k] = ok ? term_q(v, magicN) : 0ull;
+    s += q[k];
+  }
+  const uint64_t inc2 = wave_scan_u64(s);
+  const int lsel = first_lane_above(inc2, T);
+  if (lsel < 0) return -1;
+  uint64_t Tl = T - (inc2 - s);
+  int32_t tok = -1;
+#pragma unroll
+  for (int k = 0; k < EPV; ++k) {
+    if (tok < 0) {
+      if (Tl < q[k]) tok = e_base + (isel * 64 + lane) * EPV + k;
+      else Tl -= q[k];
+    }
+  }
+  return __builtin_amdgcn_readlane(tok, lsel);
 }
 
 // masked maximum / sum of the whole row at a given scale (own-scale redo; rare)
@@ -647,6 +674,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
   if (!p.out_token) return;
 
   int32_t tok = -1;
+  bool writer = wave == 0;  // who stores the token: wave 0, except after a chunk draw (the wave owning the vector)
   if (S_msk != 0) {  // workgroup-uniform from here on: every wave holds the same S_msk / own / N_msk
     if constexpr (MODE == kModePhilox) {
       uint64_t T = __umul64hi(R, S_msk);  // uniform integer in [0, S_msk)
@@ -695,7 +723,14 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
             T -= readlane_u64(incl, 63);
           }
         }
-        if (csel >= 0) tok = draw_in_chunk(rv, csel, lane, wave, kMagic - Ncs, T, s_tot);
+        if (csel >= 0) {
+          // the wave that loaded the target's vector ends up with the token and stores it; -1 is put down first (it
+          // stays only if nobody finds the target, which consistent sums rule out) - the barrier inside the draw
+          // orders the two stores
+          if (wave == 0 && lane == 0) p.out_token[pidx] = -1;
+          tok = draw_in_chunk(rv, csel, lane, wave, kMagic - Ncs, T, s_tot);
+          writer = tok >= 0;
+        }
       }
     } else {
       // ---- parity mode: exponential race against the caller's noise, first maximum of e_j / E_j (README.md:87
@@ -756,7 +791,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
       tok = bj;
     }
   }
-  if (wave == 0 && lane == 0) p.out_token[pidx] = tok;
+  if (lane == 0 && writer) p.out_token[pidx] = tok;
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -43,6 +43,8 @@ def test_random_case(engine, oracle, c):
     rs = np.random.default_rng(c["seed"])
     x = synth.logits(c["seed"] % 100000, U, V)
     x[rs.random((U, V)) < 0.01] = -np.inf  # a few -inf logits (banned upstream)
+    if c["seed"] % 5 == 0:
+        x[rs.random((U, V)) < 0.002] = np.nan  # NaN logits count as absent (term 0), never as a maximum
     tdt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[c["dtype"]]
     xt = torch.from_numpy(x).to(tdt)
     if c["dtype"] == "f32":
