@@ -564,42 +564,37 @@ __global__ __launch_bounds__(1024) void resample_systematic_kernel(const float *
   }
 }
 
-// Token->byte trie masses (trie/base.py:346-393): one workgroup per weight row walks the trie bottom-up, one tree
-// level per barrier; a node's value is the sum (or max, floored at 0 as in the reference) of its children's values in
-// ascending child order, accumulated in double - the reference's sequential order, so the result does not depend on
-// the launch.  vals: per-row scratch [n_nodes] doubles.
-__global__ __launch_bounds__(1024) void trie_reduce_kernel(const float *ws, int64_t ld, int64_t n_rows, int32_t V,
-                                                            int32_t n_nodes, int32_t n_levels, const int32_t *leaf_node,
-                                                            const int32_t *level_start, const int32_t *level_nodes,
-                                                            const int32_t *child_ptr, const int32_t *child_idx, int op,
-                                                            int from_logprobs, double *vals_all, float *out,
-                                                            int64_t out_ld, int64_t row0) {
-  const int64_t r = row0 + blockIdx.x;
-  if (r >= n_rows) return;
-  const int T = blockDim.x, tid = threadIdx.x;
-  const float *w = ws + r * ld;
-  double *vals = vals_all + (int64_t)blockIdx.x * n_nodes;
-  for (int k = tid; k < V; k += T) {
-    const float v = w[k];
-    vals[leaf_node[k]] = from_logprobs ? (double)expf(v) : (double)v;
-  }
-  __syncthreads();
-  for (int d = 0; d < n_levels; ++d) {  // deepest level first
-    const int lo = level_start[d], hi = level_start[d + 1];
-    for (int i = lo + tid; i < hi; i += T) {
-      const int node = level_nodes[i];
-      double acc = 0.0;
-      const int c0 = child_ptr[node], c1 = child_ptr[node + 1];
-      if (op == 0)
-        for (int c = c0; c < c1; ++c) acc += vals[child_idx[c]];
-      else
-        for (int c = c0; c < c1; ++c) acc = fmax(acc, vals[child_idx[c]]);
-      vals[node] = acc;
-    }
-    __syncthreads();
-  }
+// Token->byte trie masses (trie/base.py:346-393), level-synchronous over ALL weight rows at once: one launch puts the
+// token weights on the leaves, then one launch per tree level (deepest first) gives every node of that level the sum
+// (or the maximum, floored at 0 as in the reference) of its children - taken in ascending child order and accumulated
+// in double, the reference's sequential order - and stores it as float32.  A thread is one (row, node); node ids are
+// post-order, so the children of neighbouring nodes are neighbours in memory.  Values live in the output itself: no
+// scratch, every output float written once and read once.
+__global__ void trie_leaves_kernel(const float *ws, int64_t ld, int64_t n_rows, int32_t V, const int32_t *leaf_node,
+                                   int from_logprobs, float *out, int64_t out_ld) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n_rows * V) return;
+  const int64_t r = gid / V, k = gid % V;
+  const float v = ws[r * ld + k];
+  out[r * out_ld + leaf_node[k]] = from_logprobs ? expf(v) : v;
+}
+
+__global__ void trie_level_kernel(int64_t n_rows, int32_t lo, int32_t hi, const int32_t *level_nodes,
+                                  const int32_t *child_ptr, const int32_t *child_idx, int op, float *out,
+                                  int64_t out_ld) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int32_t cnt = hi - lo;
+  if (gid >= n_rows * cnt) return;
+  const int64_t r = gid / cnt;
+  const int32_t node = level_nodes[lo + (int32_t)(gid % cnt)];
   float *o = out + r * out_ld;
-  for (int i = tid; i < n_nodes; i += T) o[i] = (float)vals[i];
+  double acc = 0.0;
+  const int c0 = child_ptr[node], c1 = child_ptr[node + 1];
+  if (op == 0)
+    for (int c = c0; c < c1; ++c) acc += (double)o[child_idx[c]];
+  else
+    for (int c = c0; c < c1; ++c) acc = fmax(acc, (double)o[child_idx[c]]);
+  o[node] = (float)acc;
 }
 
 inline unsigned blocks_for(int64_t n, int t) { return (unsigned)((n + t - 1) / t); }
@@ -1057,33 +1052,28 @@ int glb_resample_systematic(const float *log_weights, int64_t n, uint64_t seed, 
   return GLB_OK;
 }
 
-size_t glb_trie_workspace(int64_t n_rows, int64_t n_nodes) {
-  if (n_rows <= 0 || n_nodes <= 0) return 0;
-  const int64_t tile = n_rows < 512 ? n_rows : 512;  // rows in flight per launch
-  return (size_t)tile * (size_t)n_nodes * sizeof(double);
-}
-
 int glb_trie_reduce(const float *weights, int64_t ld, int64_t n_rows, int64_t vocab, int64_t n_nodes, int64_t n_levels,
-                    const int32_t *leaf_node, const int32_t *level_start, const int32_t *level_nodes,
+                    const int32_t *leaf_node, const int32_t *level_start_host, const int32_t *level_nodes,
                     const int32_t *child_ptr, const int32_t *child_idx, int32_t op, int32_t from_logprobs, float *out,
-                    int64_t out_ld, void *workspace, size_t workspace_bytes, void *stream) {
-  if (!weights || !leaf_node || !level_start || !level_nodes || !child_ptr || !child_idx || !out || !workspace)
+                    int64_t out_ld, void *stream) {
+  if (!weights || !leaf_node || !level_start_host || !level_nodes || !child_ptr || !child_idx || !out)
     return fail(GLB_EINVAL, "null pointer");
   if (n_rows <= 0 || vocab <= 0 || n_nodes <= vocab || n_levels <= 0 || ld < vocab || out_ld < n_nodes)
     return fail(GLB_EINVAL, "bad sizes");
   if (vocab > 0x7fffff00ll || n_nodes > 0x7fffff00ll) return fail(GLB_EINVAL, "size exceeds 31 bits");
   if (op != GLB_TRIE_SUM && op != GLB_TRIE_MAX) return fail(GLB_EINVAL, "bad op %d", op);
-  if (workspace_bytes < glb_trie_workspace(n_rows, n_nodes) || ((uintptr_t)workspace) % 8)
-    return fail(GLB_ENOSPC, "workspace %zu < %zu bytes (or misaligned)", workspace_bytes, glb_trie_workspace(n_rows, n_nodes));
-  const int64_t tile = n_rows < 512 ? n_rows : 512;
-  for (int64_t r0 = 0; r0 < n_rows; r0 += tile) {
-    const int64_t nb = n_rows - r0 < tile ? n_rows - r0 : tile;
-    hipLaunchKernelGGL(trie_reduce_kernel, dim3((unsigned)nb), dim3(1024), 0, (hipStream_t)stream, weights, ld, n_rows,
-                       (int32_t)vocab, (int32_t)n_nodes, (int32_t)n_levels, leaf_node, level_start, level_nodes,
-                       child_ptr, child_idx, (int)op, (int)from_logprobs, (double *)workspace, out, out_ld, r0);
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "trie_reduce launch");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(trie_leaves_kernel, dim3(blocks_for(n_rows * vocab, 256)), dim3(256), 0, s, weights, ld, n_rows,
+                     (int32_t)vocab, leaf_node, (int)from_logprobs, out, out_ld);
+  for (int64_t d = 0; d < n_levels; ++d) {  // one launch per tree level, all rows
+    const int32_t lo = level_start_host[d], hi = level_start_host[d + 1];
+    if (hi < lo || hi > n_nodes) return fail(GLB_EINVAL, "level_start is not a monotone partition");
+    if (hi == lo) continue;
+    hipLaunchKernelGGL(trie_level_kernel, dim3(blocks_for(n_rows * (hi - lo), 256)), dim3(256), 0, s, n_rows, lo, hi,
+                       level_nodes, child_ptr, child_idx, (int)op, out, out_ld);
   }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "trie_reduce launch");
   return GLB_OK;
 }
 

@@ -58,7 +58,6 @@ class HipEngine:
             raise RuntimeError(f"HipEngine device must be a HIP device, got {self.device}")
         self._ws = None
         self._step_ws = None
-        self._trie_ws = None
 
     # ------------------------------------------------------------------------------------------
     def _stream(self):
@@ -299,19 +298,16 @@ class HipEngine:
     # ---- token -> byte trie masses ---------------------------------------------------------------------------
     def trie_reduce(self, ws, flat, op=0, from_logprobs=False, out=None):
         """out[r, node] = sum / max of the weights of the tokens below `node` (glb_trie_reduce).  ws: float32 [B, >=V]
-        device rows; flat: the trie's device arrays (trie.TokenByteTrie.device_arrays)."""
+        device rows; flat: the trie's arrays (trie.TokenByteTrie.device_arrays: device tensors + the host level table)."""
         if ws.dim() != 2 or ws.stride(1) != 1 or ws.dtype != torch.float32:
             raise ValueError("weights must be float32 [B, V] with unit inner stride")
         B = ws.shape[0]
         V, n_nodes = flat["vocab"], flat["n_nodes"]
         if out is None:
             out = torch.empty((B, n_nodes), dtype=torch.float32, device=self.device)
-        need = self.lib.glb_trie_workspace(B, n_nodes)
-        if self._trie_ws is None or self._trie_ws.numel() < need:
-            self._trie_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        ls = flat["level_start_host"]  # contiguous int32 NumPy array: it sizes the per-level launches
         check(self.lib.glb_trie_reduce(_ptr(ws), ws.stride(0) if B > 1 else max(V, ws.stride(0)), B, V, n_nodes,
-                                       flat["n_levels"], _ptr(flat["leaf_node"]), _ptr(flat["level_start"]),
+                                       flat["n_levels"], _ptr(flat["leaf_node"]), C.c_void_p(ls.ctypes.data),
                                        _ptr(flat["level_nodes"]), _ptr(flat["child_ptr"]), _ptr(flat["child_idx"]), op,
-                                       1 if from_logprobs else 0, _ptr(out), out.stride(0), _ptr(self._trie_ws),
-                                       self._trie_ws.numel(), self._stream()))
+                                       1 if from_logprobs else 0, _ptr(out), out.stride(0), self._stream()))
         return out

@@ -4,8 +4,8 @@ Counterpart of the reference's `TokenCharacterTrie` / `ParallelTokenCharacterTri
 trie/parallel.py:33-145): a trie over the byte strings of the vocabulary with one extra leaf per token;
 `weight_sum` / `weight_max` give, for every node, the sum / maximum of the weights of the tokens below it.  The
 structure (node numbering, `children`, `word2leaf`, `leaf2word`, `node2prefix`, `jump`) is the reference's, so node ids
-mean the same thing; the propagation is one HIP launch for a whole batch of weight rows (glb_trie_reduce) instead of a
-numba loop per row (base.py:346-393) or a sparse matmul (parallel.py:92-145).
+mean the same thing; the propagation runs for a whole batch of weight rows at once on the device (glb_trie_reduce: one launch per
+tree level) instead of a numba loop per row (base.py:346-393) or a sparse matmul (parallel.py:92-145).
 """
 import numpy as np
 import torch
@@ -114,6 +114,7 @@ class TokenByteTrie:
             f = self.flat()
             dev = self.engine.device
             self._dev = {k: (torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) else v) for k, v in f.items()}
+            self._dev["level_start_host"] = np.ascontiguousarray(f["level_start"], dtype=np.int32)
         return self._dev
 
     # ---- masses -----------------------------------------------------------------------------------------------------

@@ -273,20 +273,21 @@ int glb_resample_systematic(const float *log_weights, int64_t n, uint64_t seed, 
  * forms (trie/base.py:147-213 with the numba loops at :346-393; trie/parallel.py:92-145): for every node of the
  * trie over the vocabulary's byte strings, the sum / maximum of the weights of the tokens below it, for a batch of
  * weight rows at once.  The trie arrives flattened (built once per vocabulary on the host):
- *   leaf_node   [vocab]        node id of token k's leaf
- *   level_start [n_levels + 1] level_nodes[level_start[d] .. level_start[d+1]) = internal nodes d levels above the
- *   level_nodes                deepest ones (children always sit in an earlier level or are leaves)
- *   child_ptr   [n_nodes + 1], child_idx: CSR of every node's children, ascending (the reference's `jump`)
- * out[r, node] = float(value); values are accumulated in double in child order (the reference's sequential
- * algorithm, so results match it to the last float32 bit in practice).  from_logprobs != 0: weights = exp(row).
- * GLB_TRIE_MAX floors internal nodes at 0 like the reference (:385).  workspace: glb_trie_workspace(...) bytes.
+ *   leaf_node   [vocab]        device: node id of token k's leaf
+ *   level_start [n_levels + 1] HOST array (it sizes the launches): level_nodes[level_start[d] .. level_start[d+1]) are
+ *   level_nodes                the internal nodes d levels above the deepest ones (device); a node's children always sit
+ *                              in an earlier level or are leaves
+ *   child_ptr   [n_nodes + 1], child_idx: device CSR of every node's children, ascending (the reference's `jump`)
+ * out[r, node] = the value as float32; a node's children are added in ascending order in double and the result is
+ * rounded to float32 per node (the reference keeps doubles: agreement to ~1e-7 relative per level).
+ * from_logprobs != 0: weights = exp(row).  GLB_TRIE_MAX floors internal nodes at 0 like the reference (:385).
+ * One launch for the leaves + one per tree level, all rows each; no scratch.
  */
 enum { GLB_TRIE_SUM = 0, GLB_TRIE_MAX = 1 };
-size_t glb_trie_workspace(int64_t n_rows, int64_t n_nodes);
 int glb_trie_reduce(const float *weights, int64_t ld, int64_t n_rows, int64_t vocab, int64_t n_nodes, int64_t n_levels,
-                    const int32_t *leaf_node, const int32_t *level_start, const int32_t *level_nodes,
+                    const int32_t *leaf_node, const int32_t *level_start_host, const int32_t *level_nodes,
                     const int32_t *child_ptr, const int32_t *child_idx, int32_t op, int32_t from_logprobs, float *out,
-                    int64_t out_ld, void *workspace, size_t workspace_bytes, void *hip_stream);
+                    int64_t out_ld, void *hip_stream);
 
 /*
  * Host helper for GLB_RNG_NOISE: fills out[0..n) with the float32 Exp(1) variates

@@ -509,33 +509,31 @@ int orc_resample_systematic(const float *lw, int64_t n, uint64_t seed, uint64_t 
 }
 
 /* contract of glb_trie_reduce = trie/base.py:346-393 (the numba loops): leaves take the token weights, internal nodes
- * the sum (or the maximum, starting from 0) of their children in ascending child order, in double; float32 out */
+ * the sum (or the maximum, starting from 0) of their children in ascending child order, accumulated in double and
+ * stored as float32 per node (the reference keeps doubles throughout) */
 int orc_trie_reduce(const float *ws, int64_t ld, int64_t n_rows, int64_t V, int64_t n_nodes, int64_t n_levels,
                     const int32_t *leaf_node, const int32_t *level_start, const int32_t *level_nodes,
                     const int32_t *child_ptr, const int32_t *child_idx, int op, int from_logprobs, float *out,
                     int64_t out_ld) {
-  double *vals = (double *)malloc(sizeof(double) * (size_t)n_nodes);
-  if (!vals) return 4;
   for (int64_t r = 0; r < n_rows; ++r) {
-    for (int64_t i = 0; i < n_nodes; ++i) vals[i] = 0.0;
+    float *o = out + r * out_ld;
+    for (int64_t i = 0; i < n_nodes; ++i) o[i] = 0.0f;
     for (int64_t k = 0; k < V; ++k) {
       float v = ws[r * ld + k];
-      vals[leaf_node[k]] = from_logprobs ? (double)expf(v) : (double)v;
+      o[leaf_node[k]] = from_logprobs ? expf(v) : v;
     }
     for (int64_t d = 0; d < n_levels; ++d)
       for (int32_t i = level_start[d]; i < level_start[d + 1]; ++i) {
         int32_t node = level_nodes[i];
         double acc = 0.0;
         for (int32_t c = child_ptr[node]; c < child_ptr[node + 1]; ++c) {
-          double v = vals[child_idx[c]];
+          double v = (double)o[child_idx[c]];
           if (op == 0) acc += v;
           else if (v > acc) acc = v;
         }
-        vals[node] = acc;
+        o[node] = (float)acc;
       }
-    for (int64_t i = 0; i < n_nodes; ++i) out[r * out_ld + i] = (float)vals[i];
   }
-  free(vals);
   return 0;
 }
 

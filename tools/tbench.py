@@ -1,0 +1,28 @@
+"""Timing of glb_trie_reduce on a gpt2-sized synthetic vocabulary (HIP events around the engine call, median)."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import genlm_backend_amd
+from genlm_backend_amd.engine import HipEngine
+from genlm_backend_amd.tokenization import Token
+from genlm_backend_amd.trie import TokenByteTrie
+eng = HipEngine("cuda:0"); dev = eng.device
+rs = np.random.default_rng(0)
+words, seen = [], set()
+while len(words) < 50257:
+    w = bytes(rs.integers(97, 123, int(rs.integers(1, 9))).astype(np.uint8))
+    if w not in seen: seen.add(w); words.append(w)
+t0 = time.perf_counter(); trie = TokenByteTrie([Token(i, w) for i, w in enumerate(words)], engine=eng); f = trie.flat()
+print(f"build {time.perf_counter() - t0:.2f} s: {len(trie)} nodes, {f['n_levels']} levels")
+for B in (1, 64, 1024):
+    ws = torch.rand((B, len(words)), device=dev); ws /= ws.sum(-1, keepdim=True)
+    out = torch.empty((B, len(trie)), device=dev)
+    for op in (0, 1):
+        for _ in range(3): eng.trie_reduce(ws, trie.device_arrays(), op, out=out)
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+        for a, b in ev:
+            a.record(); eng.trie_reduce(ws, trie.device_arrays(), op, out=out); b.record()
+        torch.cuda.synchronize()
+        t = float(np.median([a.elapsed_time(b) * 1e3 for a, b in ev]))
+        print(f"trie_reduce op={op} B={B}: {t:9.1f} us  ({t / B:7.2f} us per row)", flush=True)
