@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libglb_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 GLB_OK, GLB_EINVAL, GLB_EUNSUPPORTED, GLB_EHIP, GLB_ENOSPC = 0, 1, 2, 3, 4
 F32, BF16, F16 = 0, 1, 2
 MASK_NONE, MASK_BITS, MASK_F32, MASK_PREPARED = 0, 1, 2, 3
@@ -49,7 +49,10 @@ class StepArgs(C.Structure):
         ("out_lse", C.c_void_p),
         ("out_token", C.c_void_p),
         ("out_margin", C.c_void_p),
-        ("reserved", C.c_int32),
+        ("path", C.c_int32),
+        ("row_members_start", C.c_void_p),
+        ("row_members", C.c_void_p),
+        ("row_members_max", C.c_int32),
         ("workspace", C.c_void_p),
         ("workspace_bytes", C.c_size_t),
     ]
@@ -68,6 +71,7 @@ SYMBOLS = {
     "glb_device_count": (C.c_int, []),
     "glb_step_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "glb_logprob_mask_sample": (C.c_int, [C.POINTER(StepArgs), _vp]),
+    "glb_row_members": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     "glb_mask_prepared_bytes": (_sz, [_i64, _i64]),
     "glb_mask_prepare": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _vp, _sz, _vp]),
     "glb_log_softmax_workspace_bytes": (_sz, [_i64, _i64]),

@@ -18,6 +18,8 @@ namespace glb {
 #define GLB_DECL(dt)                                                                                              \
   hipError_t launch_stats_##dt(const StepParams &p, int mask_kind, bool scaled, hipStream_t s);                   \
   hipError_t launch_finish_##dt(const StepParams &p, int mask_kind, int mode, hipStream_t s);                     \
+  hipError_t launch_row_step_##dt(const StepParams &p, int mask_kind, int mode, bool scaled, int waves,           \
+                                  hipStream_t s);                                                                  \
   hipError_t launch_logprob_rows_##dt(const void *logits, int64_t ld, int V, float scale, const float *lse,       \
                                       float *out, int64_t out_ld, int n_rows, hipStream_t s);                      \
   hipError_t launch_logprob_fused_##dt(const void *logits, int64_t ld, int V, int nch, float scale, float *out,   \
@@ -58,6 +60,16 @@ hipError_t launch_finish(int dtype, const glb::StepParams &p, int mask_kind, int
     case 0: return glb::launch_finish_0(p, mask_kind, mode, s);
     case 1: return glb::launch_finish_1(p, mask_kind, mode, s);
     case 2: return glb::launch_finish_2(p, mask_kind, mode, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_row_step(int dtype, const glb::StepParams &p, int mask_kind, int mode, bool scaled, int waves,
+                           hipStream_t s) {
+  switch (dtype) {
+    case 0: return glb::launch_row_step_0(p, mask_kind, mode, scaled, waves, s);
+    case 1: return glb::launch_row_step_1(p, mask_kind, mode, scaled, waves, s);
+    case 2: return glb::launch_row_step_2(p, mask_kind, mode, scaled, waves, s);
   }
   return hipErrorInvalidValue;
 }
@@ -599,6 +611,66 @@ __global__ void trie_level_kernel(int64_t n_rows, int32_t lo, int32_t hi, const 
 
 inline unsigned blocks_for(int64_t n, int t) { return (unsigned)((n + t - 1) / t); }
 
+// Inverse of row_of as a CSR by one workgroup: counts (global atomics into B[r + 2]), inclusive scan in place, then
+// every particle takes the next free slot of its row (atomic cursor B[r + 1], which ends as the start of row r + 1):
+// B[0 .. n_rows] finish as the offsets.  A handful of memory latencies for a few thousand particles.
+__global__ __launch_bounds__(1024) void row_members_kernel(const int32_t *row_of, int32_t n, int32_t n_rows,
+                                                            int32_t *B, int32_t *members, int32_t *out_max) {
+  __shared__ int32_t s_part[16];
+  __shared__ int32_t s_carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < n_rows + 2; i += 1024) B[i] = 0;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += 1024) {
+    const int r = row_of[i];
+    if (r >= 0 && r < n_rows) atomicAdd(&B[r + 2], 1);
+  }
+  __syncthreads();
+  int mx = 0;
+  for (int base = 0; base < n_rows; base += 1024) {
+    const int idx = base + tid;
+    const int v = idx < n_rows ? __hip_atomic_load(&B[idx + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    mx = v > mx ? v : mx;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_part[wave] = incl;
+    __syncthreads();
+    int off = s_carry;
+#pragma unroll
+    for (int w = 0; w < 16; ++w)
+      if (w < wave) off += s_part[w];
+    incl += off;
+    if (idx < n_rows) B[idx + 2] = incl;
+    __syncthreads();
+    if (tid == 1023) s_carry = incl;
+    __syncthreads();
+  }
+  if (out_max) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const int t = __shfl_xor(mx, o, 64);
+      mx = t > mx ? t : mx;
+    }
+    if (lane == 0) s_part[wave] = mx;
+    __syncthreads();
+    if (tid == 0) {
+      int m = 0;
+      for (int w = 0; w < 16; ++w) m = s_part[w] > m ? s_part[w] : m;
+      *out_max = m;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += 1024) {
+    const int r = row_of[i];
+    if (r >= 0 && r < n_rows) members[atomicAdd(&B[r + 1], 1)] = i;
+  }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -686,6 +758,12 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
   }
   if (a->rng_mode < GLB_RNG_NONE || a->rng_mode > GLB_RNG_NOISE)
     return fail(GLB_EINVAL, "bad rng_mode %d", a->rng_mode);
+  if (a->path < GLB_PATH_AUTO || a->path > GLB_PATH_ONE_LAUNCH) return fail(GLB_EINVAL, "bad path %d", a->path);
+  if ((a->row_members_start == nullptr) != (a->row_members == nullptr))
+    return fail(GLB_EINVAL, "row_members_start and row_members go together");
+  if (a->row_members && (!a->row_of || !by_row))
+    return fail(GLB_EINVAL, "row_members describes row_of of a per-row reduction (no per-particle mask ids)");
+  if (a->row_members_max < 0) return fail(GLB_EINVAL, "row_members_max is negative");
   if (a->rng_mode == GLB_RNG_NOISE && (!a->noise || (a->noise_ld < a->vocab && a->noise_ld != 0)))
     return fail(GLB_EINVAL, "noise tensor missing or noise_ld < vocab (0 = one row shared by every particle)");
   if (a->rng_mode != GLB_RNG_NONE && !a->out_token)
@@ -745,10 +823,49 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
   p.out_lse = a->out_lse;
   p.out_token = a->out_token;
   p.out_margin = a->rng_mode == GLB_RNG_NOISE ? a->out_margin : nullptr;
+  // One launch (a workgroup per reduction unit, records in LDS, in-chunk draws from the reducing wave's registers)
+  // when the unit -> particles direction is known and no unit carries more than a few particles; two launches
+  // (one wave per chunk, then one per particle) for everything else: float masks, parity mode, rows of more than 2^20
+  // elements, heavily shared rows (SIS step 0, freshly resampled populations), callers that give row_of only.
+  const bool members_known = !by_row || !a->row_of || (a->row_members_start && a->row_members);
+  const bool few_members = !by_row || !a->row_of ||
+                           (a->row_members_max > 0 && a->row_members_max <= glb::kFusedCap);
+  const bool one_launch_ok = kmask != glb::kMaskF32 && a->rng_mode != GLB_RNG_NOISE &&
+                             p.nch <= glb::kFusedMaxChunks && members_known;
+  if (a->path == GLB_PATH_ONE_LAUNCH && !one_launch_ok)
+    return fail(GLB_EUNSUPPORTED, "one-launch path asked for, but the call has float masks / parity noise / rows over "
+                                  "2^20 elements / row_of without row_members");
+  if (a->path == GLB_PATH_ONE_LAUNCH || (a->path == GLB_PATH_AUTO && one_launch_ok && few_members)) {
+    if (by_row && a->row_of) {
+      p.mem_start = a->row_members_start;
+      p.members = a->row_members;
+    }
+    // waves per workgroup: enough workgroups x waves to fill 1024 SIMDs four deep, at most one wave per chunk
+    static const int forced = [] { const char *e = getenv("GLB_ROW_WAVES"); return e ? atoi(e) : 0; }();
+    int waves = 4;
+    while (waves < 16 && n_units * waves * 2 <= 4096) waves *= 2;
+    while (waves > 1 && waves / 2 >= p.nch) waves /= 2;
+    if (forced >= 1 && forced <= 16) waves = forced;
+    const hipError_t e = launch_row_step(a->dtype, p, kmask, a->rng_mode, a->logit_scale != 1.0f, waves, s);
+    if (e != hipSuccess) return hip_fail(e, "row_step launch");
+    return GLB_OK;
+  }
   hipError_t e = launch_stats(a->dtype, p, kmask, a->logit_scale != 1.0f, s);
   if (e != hipSuccess) return hip_fail(e, "chunk_stats launch");
   e = launch_finish(a->dtype, p, kmask, a->rng_mode, s);
   if (e != hipSuccess) return hip_fail(e, "finish launch");
+  return GLB_OK;
+}
+
+int glb_row_members(const int32_t *row_of, int64_t n_particles, int64_t n_rows, int32_t *out_start,
+                    int32_t *out_members, int32_t *out_max, void *stream) {
+  if (!row_of || !out_start || !out_members) return fail(GLB_EINVAL, "null pointer");
+  if (n_particles <= 0 || n_rows <= 0 || n_particles > 0x7fffff00ll || n_rows > 0x7fffff00ll)
+    return fail(GLB_EINVAL, "bad sizes");
+  hipLaunchKernelGGL(row_members_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, row_of, (int32_t)n_particles,
+                     (int32_t)n_rows, out_start, out_members, out_max);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "row_members launch");
   return GLB_OK;
 }
 

@@ -54,6 +54,8 @@ struct StepParams {
   const int32_t *pair_row;   // [n_pairs] logits row of a reduction unit, null = identity
   const int32_t *pair_mask;  // [n_pairs] mask row, null = (n_masks == 1 ? 0 : identity)
   const int32_t *pair_of;    // [n_particles] reduction unit of a particle, null = identity
+  const int32_t *mem_start;  // [n_pairs + 1] row kernel: particles of a unit as a CSR, null = identity (one each)
+  const int32_t *members;    // [n_particles]
   const uint64_t *mask_t;    // transposed bit masks [n_masks][nch * 64]
   const int32_t *mask_info;  // [n_masks][kInfoWords]
   const float *mask_f;       // float masks [n_masks][mask_ld]
@@ -221,6 +223,83 @@ __device__ __forceinline__ float chunk_max(const float (&x)[64]) {
   return wave_max(m);
 }
 
+// y = x + (float mask row) for the wave's chunk (same lane layout as x)
+template <int DT>
+__device__ __forceinline__ void add_float_mask(const float (&x)[64], const char *mrow, int e_base, int V, int lane,
+                                               float (&y)[64]) {
+  constexpr int EPV = ElemTraits<DT>::EPV, NVC = ElemTraits<DT>::NVC;
+  if constexpr (EPV == 4) {
+    load_chunk<kDtF32, false>(mrow, e_base, V, lane, 1.0f, y);
+#pragma unroll
+    for (int j = 0; j < 64; ++j) y[j] = x[j] + y[j];
+  } else {
+    // 16-bit logits: lane holds 8 consecutive elements per vector, i.e. two 16-byte vectors of the float mask
+#pragma unroll
+    for (int i = 0; i < NVC; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int e0 = e_base + (i * 64 + lane) * 8 + 4 * h;
+        const u32x4_t r = load_vec_guarded<kDtF32>(mrow, e0, V);
+        float mk[4];
+        unpack_vec<kDtF32>(r, mk);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) y[i * 8 + 4 * h + k] = x[i * 8 + 4 * h + k] + mk[k];
+      }
+  }
+}
+
+// first lane whose inclusive scan exceeds T (wave-uniform T); -1 if none
+__device__ __forceinline__ int first_lane_above(uint64_t incl, uint64_t T) {
+  return __ffsll((long long)__ballot(incl > T)) - 1;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The draw inside one chunk, by the wave that holds it in x[64] (second stage of the Philox draw):
+// target T2 = floor(R2 * S_c / 2^64) against the chunk's allowed terms on the chunk's own scale, taken lane by lane
+// and inside a lane in register order (vector, component) - the order the wave holds them in, so nothing is loaded.
+// (inclA, inclB) are the per-lane inclusive scans of the allowed payload words chunk_sums returns; mword is the
+// transposed mask word of element `lane` of a lane's 64 (bit l = lane l allowed).  Stage 1 picks the lane from the
+// scan; that lane then parks its 64 values in LDS and every lane takes one of them: a second scan picks the element.
+// Returns the token id (wave-uniform) or -1 for an empty chunk.
+// ---------------------------------------------------------------------------------------------------------
+template <int DT, bool MASKED>
+__device__ __forceinline__ int32_t chunk_candidate(const float (&x)[64], float magicN, int e_base, int lane,
+                                                   uint32_t inclA, uint32_t inclB, uint64_t mword, uint64_t R2,
+                                                   float *s_tr) {
+  constexpr int EPV = ElemTraits<DT>::EPV;
+  const uint64_t incl = ((uint64_t)inclA << kGridHi) + inclB;
+  const uint64_t Sc = readlane_u64(incl, 63);
+  uint32_t nz = (uint32_t)Sc | (uint32_t)(Sc >> 32);
+  opaque_u32(nz);
+  if (nz == 0u) return -1;
+  const uint64_t T2 = __umul64hi(R2, Sc);  // uniform integer in [0, S_c)
+  const int lsel = first_lane_above(incl, T2);
+  const uint64_t before = readlane_u64(incl, lsel > 0 ? lsel - 1 : 0);
+  const uint64_t Tl = T2 - (lsel > 0 ? before : 0ull);
+  if (lane == lsel) {
+#pragma unroll
+    for (int j = 0; j < 64; j += 4)
+      *reinterpret_cast<u32x4_t *>(s_tr + j) = u32x4_t{__float_as_uint(x[j]), __float_as_uint(x[j + 1]),
+                                                       __float_as_uint(x[j + 2]), __float_as_uint(x[j + 3])};
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const float xv = s_tr[lane];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  uint32_t h, l;
+  term_q_parts(xv, magicN, h, l);
+  if constexpr (MASKED) {
+    if (!((mword >> lsel) & 1ull)) h = l = 0u;
+  }
+  const uint32_t sh = wave_sum_u32_l63(h), sl = wave_sum_u32_l63(l);  // inclusive scans; totals < 2^24 each
+  const uint64_t inc2 = ((uint64_t)sh << kGridHi) + sl;
+  const int jsel = first_lane_above(inc2, Tl);
+  if (jsel < 0) return -1;  // consistent sums rule this out
+  return e_base + ((jsel / EPV) * 64 + lsel) * EPV + (jsel % EPV);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // chunk statistics: one wave per (reduction unit, chunk)
 // ---------------------------------------------------------------------------------------------------------
@@ -256,24 +335,7 @@ __global__ __launch_bounds__(256, GLB_K1_MINW) void chunk_stats_kernel(const Ste
       const int mi = p.pair_mask ? as_const(p.pair_mask)[pr] : (p.n_masks == 1 ? 0 : pr);
       const char *mrow = (const char *)(p.mask_f + (int64_t)mi * p.mask_ld);
       float y[64];
-      if constexpr (EPV == 4) {
-        load_chunk<kDtF32, false>(mrow, e_base, V, lane, 1.0f, y);
-#pragma unroll
-        for (int j = 0; j < 64; ++j) y[j] = x[j] + y[j];
-      } else {
-        // 16-bit logits: lane holds 8 consecutive elements per vector, i.e. two 16-byte vectors of the float mask
-#pragma unroll
-        for (int i = 0; i < NVC; ++i)
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int e0 = e_base + (i * 64 + lane) * 8 + 4 * h;
-            const u32x4_t r = load_vec_guarded<kDtF32>(mrow, e0, V);
-            float mk[4];
-            unpack_vec<kDtF32>(r, mk);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) y[i * 8 + 4 * h + k] = x[i * 8 + 4 * h + k] + mk[k];
-          }
-      }
+      add_float_mask<DT>(x, mrow, e_base, V, lane, y);
       Nm = exp_n(chunk_max(y));
       uint32_t d0, d1;
       chunk_sums<DT, false>(y, kMagic - Nm, nv_valid, nullptr, pAm, pBm, d0, d1);
@@ -350,18 +412,16 @@ __global__ __launch_bounds__(256) void chunk_stats_small_kernel(const StepParams
 // ---------------------------------------------------------------------------------------------------------
 // finish: one wave per particle
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t philox_bits(const StepParams &p, int pidx) {
+// the particle's two 64-bit draws (chunk stage, in-chunk stage): Philox4x32-10 keyed by the call's seed, counter =
+// (global particle index, call offset)
+__device__ __forceinline__ void philox_pair(const StepParams &p, int pidx, uint64_t &R1, uint64_t &R2) {
   const uint64_t gp = (uint64_t)(p.particle_base + pidx);
   const uint32_t ctr[4] = {(uint32_t)gp, (uint32_t)(gp >> 32), (uint32_t)p.offset, (uint32_t)(p.offset >> 32)};
   const uint32_t key[2] = {(uint32_t)p.seed, (uint32_t)(p.seed >> 32)};
   uint32_t rnd[4];
   philox4x32_10(ctr, key, rnd);
-  return ((uint64_t)rnd[1] << 32) | rnd[0];
-}
-
-// first lane whose inclusive scan exceeds T (wave-uniform T); -1 if none
-__device__ __forceinline__ int first_lane_above(uint64_t incl, uint64_t T) {
-  return __ffsll((long long)__ballot(incl > T)) - 1;
+  R1 = ((uint64_t)rnd[1] << 32) | rnd[0];
+  R2 = ((uint64_t)rnd[3] << 32) | rnd[2];
 }
 
 // the row (or float-mask) view one particle works on
@@ -440,93 +500,33 @@ __device__ __forceinline__ int32_t walk_vectors(const RowView<DT, MASK> &rv, int
   return -1;
 }
 
-// The draw inside one chunk, by the four waves of the particle's workgroup: wave w takes vectors w, w+4, ... of the
-// chunk (one burst of loads), sums their allowed terms with the round-toward-zero adds and parks the per-vector
-// totals in LDS; every wave then finds the vector holding the target by a scan over the <= 16 totals, and the wave
-// that loaded that vector walks it element by element straight from its registers.  Every wave must call this (it
-// contains a workgroup barrier); the owning wave returns the token, the others -1.
+// The in-chunk draw for a particle whose chunk is not in registers any more (two-launch path; members of a shared row
+// beyond the ones the reducing wave drew for): one wave reloads chunk c, redoes its sums at the recorded scale Ncs and
+// draws exactly as the reducing wave would have (same functions, same order).
 template <int DT, int MASK>
-__device__ __forceinline__ int32_t draw_in_chunk(const RowView<DT, MASK> &rv, int c, int lane, int wave,
-                                                 float magicN, uint64_t T, uint64_t *s_tot) {
-  constexpr int EPV = ElemTraits<DT>::EPV, NVC = ElemTraits<DT>::NVC, NVW = NVC / 4;
+__device__ __forceinline__ int32_t draw_chunk_reload(const RowView<DT, MASK> &rv, int c, int lane, float Ncs,
+                                                     uint64_t R2, float *s_tr) {
+  constexpr int EPV = ElemTraits<DT>::EPV, NVC = ElemTraits<DT>::NVC;
   const int e_base = c * kChunk;
-  const cu64_t mt = MASK == kMaskBits ? as_const(rv.mt + (int64_t)c * 64) : nullptr;
-  u32x4_t raw[NVW];
-#pragma unroll
-  for (int j = 0; j < NVW; ++j) {
-    const int e0 = e_base + ((wave + 4 * j) * 64 + lane) * EPV;
-    raw[j] = load_vec_guarded<DT>(rv.rowp, e0 < rv.V ? e0 : rv.V, rv.V);
+  int nv_valid = (rv.V - e_base + 64 * EPV - 1) / (64 * EPV);
+  nv_valid = nv_valid < NVC ? nv_valid : NVC;
+  float x[64];
+  load_chunk<DT, true>(rv.rowp, e_base, rv.V, lane, rv.scale, x);
+  uint32_t pA, pB, pAm, pBm;
+  if constexpr (MASK == kMaskBits) {
+    const uint64_t *mtc = rv.mt + (int64_t)c * 64;
+    const uint64_t mw = mtc[lane];
+    chunk_sums<DT, true>(x, kMagic - Ncs, nv_valid, as_const(mtc), pA, pB, pAm, pBm);
+    return chunk_candidate<DT, true>(x, kMagic - Ncs, e_base, lane, pAm, pBm, mw, R2, s_tr);
+  } else if constexpr (MASK == kMaskF32) {
+    float y[64];
+    add_float_mask<DT>(x, rv.mrow, e_base, rv.V, lane, y);
+    chunk_sums<DT, false>(y, kMagic - Ncs, nv_valid, nullptr, pA, pB, pAm, pBm);
+    return chunk_candidate<DT, false>(y, kMagic - Ncs, e_base, lane, pA, pB, 0ull, R2, s_tr);
+  } else {
+    chunk_sums<DT, false>(x, kMagic - Ncs, nv_valid, nullptr, pA, pB, pAm, pBm);
+    return chunk_candidate<DT, false>(x, kMagic - Ncs, e_base, lane, pA, pB, 0ull, R2, s_tr);
   }
-  float y[NVW][EPV];  // this wave's (masked-by-value for float masks) logits, kept for the walk
-#pragma unroll
-  for (int j = 0; j < NVW; ++j) {
-    const int i = wave + 4 * j;
-    unpack_vec<DT>(raw[j], y[j]);
-#pragma unroll
-    for (int k = 0; k < EPV; ++k) y[j][k] *= rv.scale;
-    if constexpr (MASK == kMaskF32) {
-#pragma unroll
-      for (int h = 0; h < EPV / 4; ++h) {
-        const int e0 = e_base + (i * 64 + lane) * EPV + 4 * h;
-        const u32x4_t r = load_vec_guarded<kDtF32>(rv.mrow, e0 < rv.V ? e0 : rv.V, rv.V);
-        float mk[4];
-        unpack_vec<kDtF32>(r, mk);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) y[j][4 * h + k] += mk[k];
-      }
-    }
-    float t[EPV];
-#pragma unroll
-    for (int k = 0; k < EPV; ++k) t[k] = chunk_term(y[j][k], magicN);
-    float Am = __uint_as_float(kA0Bits), Bm = __uint_as_float(kB0Bits);
-#pragma unroll
-    for (int h = 0; h < EPV / 4; ++h) {
-      uint64_t M0 = 0, M1 = 0, M2 = 0, M3 = 0;
-      if constexpr (MASK == kMaskBits) {
-        M0 = mt[i * EPV + 4 * h + 0];
-        M1 = mt[i * EPV + 4 * h + 1];
-        M2 = mt[i * EPV + 4 * h + 2];
-        M3 = mt[i * EPV + 4 * h + 3];
-      }
-      rtz_vec4<MASK == kMaskBits>(t[4 * h], t[4 * h + 1], t[4 * h + 2], t[4 * h + 3], Am, Bm, M0, M1, M2, M3);
-    }
-    const uint32_t pa = wave_sum_u32_l63(__float_as_uint(Am) - kA0Bits);
-    const uint32_t pb = wave_sum_u32_l63(__float_as_uint(Bm) - kB0Bits);
-    if (lane == 63) s_tot[i] = ((uint64_t)pa << kGridHi) + pb;
-  }
-  __syncthreads();
-  const uint64_t wv = lane < NVC ? s_tot[lane] : 0ull;
-  const uint64_t incl = wave_scan_u64(wv);
-  const int isel = first_lane_above(incl, T);
-  if (isel < 0 || (isel & 3) != wave) return -1;
-  T -= readlane_u64(incl - wv, isel);
-  // walk vector isel = wave + 4 * jsel from the registers: lane -> element, in vocabulary order
-  const int jsel = isel >> 2;
-  uint64_t q[EPV], s = 0;
-#pragma unroll
-  for (int k = 0; k < EPV; ++k) {
-    float v = y[0][k];
-#pragma unroll
-    for (int j = 1; j < NVW; ++j) v = jsel == j ? y[j][k] : v;
-    const int e = e_base + (isel * 64 + lane) * EPV + k;
-    bool ok = e < rv.V;
-    if constexpr (MASK == kMaskBits) ok = ok && ((mt[isel * EPV + k] >> lane) & 1ull);
-    q[k] = ok ? term_q(v, magicN) : 0ull;
-    s += q[k];
-  }
-  const uint64_t inc2 = wave_scan_u64(s);
-  const int lsel = first_lane_above(inc2, T);
-  if (lsel < 0) return -1;
-  uint64_t Tl = T - (inc2 - s);
-  int32_t tok = -1;
-#pragma unroll
-  for (int k = 0; k < EPV; ++k) {
-    if (tok < 0) {
-      if (Tl < q[k]) tok = e_base + (isel * 64 + lane) * EPV + k;
-      else Tl -= q[k];
-    }
-  }
-  return __builtin_amdgcn_readlane(tok, lsel);
 }
 
 // masked maximum / sum of the whole row at a given scale (own-scale redo; rare)
@@ -570,37 +570,47 @@ __device__ __forceinline__ float load_elem(const char *rowp, int j) {
   return (float)__builtin_bit_cast(_Float16, (uint16_t)h);
 }
 
-template <int DT, int MASK, int MODE>
-__global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
-  constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC;
-  __shared__ uint64_t s_tot[16];
-  __shared__ float s_bestg[4], s_secg[4];
-  __shared__ int32_t s_bestj[4];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int pidx = blockIdx.x;  // one workgroup of four waves per particle
-  const int nch = p.nch, V = p.V;
-  const int pr = p.pair_of ? as_const(p.pair_of)[pidx] : pidx;
-  const int row = p.pair_row ? as_const(p.pair_row)[pr] : pr;
-  const int mi = MASK == kMaskNone ? 0 : (p.pair_mask ? as_const(p.pair_mask)[pr] : (p.n_masks == 1 ? 0 : pr));
-  const ChunkRec *recs = p.recs + (int64_t)pr * nch;
+// ---------------------------------------------------------------------------------------------------------
+// What one particle needs from the chunk records of its (row, mask) pair - shared by the two-launch finish kernel
+// (records in global memory) and the one-launch row kernel (records in LDS).  Every function here is executed by ONE
+// wave; all results are wave-uniform.
+// ---------------------------------------------------------------------------------------------------------
+struct RecsGlobal {
+  const ChunkRec *r;
+  __device__ __forceinline__ ChunkRec get(int c) const { return r[c]; }
+};
+struct RecsLds {  // words: Nc, pA, pB, pAm, pBm (no float masks on this path)
+  const uint32_t (*s)[5];
+  __device__ __forceinline__ ChunkRec get(int c) const {
+    ChunkRec r;
+    r.Nc = __uint_as_float(s[c][0]);
+    r.pA = s[c][1];
+    r.pB = s[c][2];
+    r.pAm = s[c][3];
+    r.pBm = s[c][4];
+    r.Nm = r.Nc;
+    return r;
+  }
+};
 
-  RowView<DT, MASK> rv;
-  rv.rowp = (const char *)p.logits + (int64_t)row * p.ld * ES;
-  rv.V = V;
-  rv.scale = p.scale;
-  rv.mt = MASK == kMaskBits ? p.mask_t + (int64_t)mi * nch * 64 : nullptr;
-  rv.mrow = MASK == kMaskF32 ? (const char *)(p.mask_f + (int64_t)mi * p.mask_ld) : nullptr;
+struct PairState {
+  float N_all, N_msk;     // row scales (all / allowed)
+  uint64_t S_all, S_msk;  // sums on them
+  bool own;               // bit masks: allowed sum redone on its own scale
+  int sparse_n;           // >= 0: the mask allows that many (<= 63) tokens, listed in mask_info
+  float x_sp;             // sparse path: this lane's allowed logit
+  int j_sp;
+};
 
-  // the particle's 64 random bits do not depend on the records: computed while the first loads are in flight
-  uint64_t R = 0;
-  if constexpr (MODE == kModePhilox) R = philox_bits(p, pidx);
-
-  // ---- fold the chunk records (every wave, same values): row scales, then the sums shifted onto them ------------
+// fold the chunk records: row scales, then the sums shifted onto them; then the low-mass rule for bit masks
+template <int DT, int MASK, class Recs>
+__device__ __forceinline__ void pair_fold(const StepParams &p, const Recs &recs, const RowView<DT, MASK> &rv, int mi,
+                                          int nch, int lane, PairState &st) {
   float N_all = kNegInf, N_msk = kNegInf;
   for (int c0 = 0; c0 < nch; c0 += 64) {
     const int c = c0 + lane;
     if (c < nch) {
-      const ChunkRec r = recs[c];
+      const ChunkRec r = recs.get(c);
       if (r.pA | r.pB) N_all = fmaxf(N_all, r.Nc);
       if (r.pAm | r.pBm) N_msk = fmaxf(N_msk, MASK == kMaskF32 ? r.Nm : r.Nc);
     }
@@ -612,7 +622,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
     const int c = c0 + lane;
     uint64_t sa = 0, sm = 0;
     if (c < nch) {
-      const ChunkRec r = recs[c];
+      const ChunkRec r = recs.get(c);
       const uint64_t a = ((uint64_t)r.pA << kGridHi) + r.pB, m = ((uint64_t)r.pAm << kGridHi) + r.pBm;
       if (a) {
         const float d = N_all - r.Nc;  // >= 0, integer valued
@@ -627,118 +637,157 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
     if constexpr (MASK != kMaskNone) S_msk += wave_sum_u64(sm);
   }
   if constexpr (MASK == kMaskNone) S_msk = S_all;
-
-  // ---- bit masks: allowed mass below 2^-4 of the row's largest term -> masked sum on its own scale (every wave
-  //      redundantly: rare, and the branch must be taken by all four for the barriers further down) -----------------
-  bool own = false;       // workgroup-uniform
-  int sparse_n = -1;      // >= 0: the mask allows that many (<= 63) tokens, listed in mask_info
-  float x_sp = kNegInf;   // sparse path: this lane's allowed logit
-  int j_sp = -1;
+  st.own = false;
+  st.sparse_n = -1;
+  st.x_sp = kNegInf;
+  st.j_sp = -1;
+  // bit masks: allowed mass below 2^-4 of the row's largest term -> masked sum on its own scale
   if constexpr (MASK == kMaskBits) {
     uint32_t top = (uint32_t)(S_msk >> kLowMassBits);
     opaque_u32(top);
     if (top == 0u) {
-      own = true;
+      st.own = true;
       const int32_t *info = p.mask_info + (int64_t)mi * kInfoWords;
       const int cnt = info[0];
       float mk;
       if (cnt <= kInfoWords - 1) {
-        sparse_n = cnt;
+        st.sparse_n = cnt;
         if (lane < cnt) {
-          j_sp = info[1 + lane];
-          x_sp = load_elem<DT>(rv.rowp, j_sp) * p.scale;
+          st.j_sp = info[1 + lane];
+          st.x_sp = load_elem<DT>(rv.rowp, st.j_sp) * p.scale;
         }
-        mk = wave_max(x_sp);
+        mk = wave_max(st.x_sp);
       } else {
         mk = row_masked_max(rv, nch, lane);
       }
       N_msk = exp_n(mk);
       if (!(mk > kNegInf)) {
         S_msk = 0;
-      } else if (sparse_n >= 0) {
-        S_msk = wave_sum_u64(lane < sparse_n ? term_q(x_sp, kMagic - N_msk) : 0ull);
+      } else if (st.sparse_n >= 0) {
+        S_msk = wave_sum_u64(lane < st.sparse_n ? term_q(st.x_sp, kMagic - N_msk) : 0ull);
       } else {
         S_msk = row_masked_sum(rv, nch, lane, kMagic - N_msk);
       }
     }
   }
+  st.N_all = N_all;
+  st.N_msk = N_msk;
+  st.S_all = S_all;
+  st.S_msk = S_msk;
+}
 
-  // ---- lse / logZ (sum of e^x = 2^(N + 1 - 36) * S): one lane of the last wave, beside the draw ---------------------
-  if (wave == 3 && lane == 0) {
-    const double lse_all = S_all ? log_fix(S_all, (int32_t)N_all + 1 - kFrac) : (double)kNegInf;
-    const double lse_msk = S_msk ? log_fix(S_msk, (int32_t)N_msk + 1 - kFrac) : (double)kNegInf;
-    if (p.out_lse) p.out_lse[pidx] = (float)lse_all;
-    if (p.out_logZ) p.out_logZ[pidx] = (float)(lse_msk - lse_all);
+// lse / logZ (sum of e^x = 2^(N + 1 - 36) * S) - call from one lane
+__device__ __forceinline__ void pair_logs(const PairState &st, float &lse, float &logZ) {
+  const double lse_all = st.S_all ? log_fix(st.S_all, (int32_t)st.N_all + 1 - kFrac) : (double)kNegInf;
+  const double lse_msk = st.S_msk ? log_fix(st.S_msk, (int32_t)st.N_msk + 1 - kFrac) : (double)kNegInf;
+  lse = (float)lse_all;
+  logZ = (float)(lse_msk - lse_all);
+}
+
+// The Philox draw of particle pidx.  Own-scale rows: one inverse CDF over the whole row in vocabulary order with the
+// first draw.  Otherwise two stages: the chunk by a scan of the shifted chunk sums (first draw); inside the chunk the
+// second draw - taken from `cand` (per-chunk results the reducing wave left behind, row kernel) or, when cand is
+// null, recomputed from a reload of that chunk.
+template <int DT, int MASK, class Recs>
+__device__ __forceinline__ int32_t pair_draw_philox(const StepParams &p, const Recs &recs, const RowView<DT, MASK> &rv,
+                                                    const PairState &st, int pidx, int nch, int lane,
+                                                    const int32_t *cand, float *s_tr) {
+  constexpr int NVC = ElemTraits<DT>::NVC;
+  uint32_t nz = (uint32_t)st.S_msk | (uint32_t)(st.S_msk >> 32);
+  opaque_u32(nz);
+  if (nz == 0u) return -1;
+  uint64_t R1, R2;
+  philox_pair(p, pidx, R1, R2);
+  uint64_t T = __umul64hi(R1, st.S_msk);  // uniform integer in [0, S_msk)
+  if (st.own) {
+    if (st.sparse_n >= 0) {
+      const uint64_t q = lane < st.sparse_n ? term_q(st.x_sp, kMagic - st.N_msk) : 0ull;
+      const uint64_t incl = wave_scan_u64(q);
+      const int lsel = first_lane_above(incl, T);
+      return __builtin_amdgcn_readlane(st.j_sp, lsel < 0 ? 0 : lsel);
+    }
+    int32_t tok = -1;
+    for (int c = 0; c < nch && tok < 0; ++c) tok = walk_vectors(rv, c, 0, NVC, lane, kMagic - st.N_msk, T);
+    return tok;
+  }
+  int csel = -1;
+  float Ncs = 0.f;
+  for (int c0 = 0; c0 < nch && csel < 0; c0 += 64) {
+    const int c = c0 + lane;
+    uint64_t sm = 0;
+    float Nc = kNegInf;
+    if (c < nch) {
+      const ChunkRec r = recs.get(c);
+      const uint64_t m = ((uint64_t)r.pAm << kGridHi) + r.pBm;
+      Nc = MASK == kMaskF32 ? r.Nm : r.Nc;
+      if (m) {
+        const float d = st.N_msk - Nc;
+        if (d < 64.0f) sm = m >> (uint32_t)d;
+      }
+    }
+    const uint64_t incl = wave_scan_u64(sm);
+    const int lsel = first_lane_above(incl, T);
+    if (lsel >= 0) {
+      csel = c0 + lsel;
+      Ncs = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(Nc), lsel));
+    } else {
+      T -= readlane_u64(incl, 63);
+    }
+  }
+  if (csel < 0) return -1;  // consistent sums rule this out
+  if (cand) return cand[csel];
+  return draw_chunk_reload(rv, csel, lane, Ncs, R2, s_tr);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// finish (two-launch path): one workgroup of four waves per particle.  Stats / Philox: wave 0 works alone (the other
+// three leave at once); parity mode deals the row's vectors to all four.
+// ---------------------------------------------------------------------------------------------------------
+template <int DT, int MASK, int MODE>
+__global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
+  constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC;
+  __shared__ float s_tr[64];
+  __shared__ float s_bestg[4], s_secg[4];
+  __shared__ int32_t s_bestj[4];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (MODE != kModeNoise && wave != 0) return;
+  const int pidx = blockIdx.x;
+  const int nch = p.nch, V = p.V;
+  const int pr = p.pair_of ? as_const(p.pair_of)[pidx] : pidx;
+  const int row = p.pair_row ? as_const(p.pair_row)[pr] : pr;
+  const int mi = MASK == kMaskNone ? 0 : (p.pair_mask ? as_const(p.pair_mask)[pr] : (p.n_masks == 1 ? 0 : pr));
+  const RecsGlobal recs{p.recs + (int64_t)pr * nch};
+
+  RowView<DT, MASK> rv;
+  rv.rowp = (const char *)p.logits + (int64_t)row * p.ld * ES;
+  rv.V = V;
+  rv.scale = p.scale;
+  rv.mt = MASK == kMaskBits ? p.mask_t + (int64_t)mi * nch * 64 : nullptr;
+  rv.mrow = MASK == kMaskF32 ? (const char *)(p.mask_f + (int64_t)mi * p.mask_ld) : nullptr;
+
+  PairState st;
+  pair_fold<DT, MASK>(p, recs, rv, mi, nch, lane, st);
+  if (wave == 0 && lane == 0) {
+    float lse, logZ;
+    pair_logs(st, lse, logZ);
+    if (p.out_lse) p.out_lse[pidx] = lse;
+    if (p.out_logZ) p.out_logZ[pidx] = logZ;
   }
   if constexpr (MODE == kModeStats) return;
   if (!p.out_token) return;
 
-  int32_t tok = -1;
-  bool writer = wave == 0;  // who stores the token: wave 0, except after a chunk draw (the wave owning the vector)
-  if (S_msk != 0) {  // workgroup-uniform from here on: every wave holds the same S_msk / own / N_msk
-    if constexpr (MODE == kModePhilox) {
-      uint64_t T = __umul64hi(R, S_msk);  // uniform integer in [0, S_msk)
-      if (own) {
-        if (wave == 0) {
-          if (sparse_n >= 0) {
-            const uint64_t q = lane < sparse_n ? term_q(x_sp, kMagic - N_msk) : 0ull;
-            const uint64_t incl = wave_scan_u64(q);
-            const int lsel = first_lane_above(incl, T);
-            tok = __builtin_amdgcn_readlane(j_sp, lsel < 0 ? 0 : lsel);
-          } else {
-            for (int c = 0; c < nch && tok < 0; ++c) tok = walk_vectors(rv, c, 0, NVC, lane, kMagic - N_msk, T);
-          }
-        }
-      } else {
-        // chunk: scan of the shifted chunk sums in vocabulary order; then the target is carried onto the chunk's
-        // own scale (T << shift stays below the chunk's unshifted sum) and the chunk is searched
-        int csel = -1;
-        float Ncs = 0.f;
-        for (int c0 = 0; c0 < nch && csel < 0; c0 += 64) {
-          const int c = c0 + lane;
-          uint64_t sm = 0;
-          float Nc = kNegInf;
-          uint32_t sh = 0;
-          if (c < nch) {
-            const ChunkRec r = recs[c];
-            const uint64_t m = ((uint64_t)r.pAm << kGridHi) + r.pBm;
-            Nc = MASK == kMaskF32 ? r.Nm : r.Nc;
-            if (m) {
-              const float d = N_msk - Nc;
-              if (d < 64.0f) {
-                sh = (uint32_t)d;
-                sm = m >> sh;
-              }
-            }
-          }
-          const uint64_t incl = wave_scan_u64(sm);
-          const int lsel = first_lane_above(incl, T);
-          if (lsel >= 0) {
-            csel = c0 + lsel;
-            const uint64_t before = readlane_u64(incl - sm, lsel);
-            const uint32_t shs = (uint32_t)__builtin_amdgcn_readlane((int)sh, lsel);
-            Ncs = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(Nc), lsel));
-            T = (T - before) << shs;
-          } else {
-            T -= readlane_u64(incl, 63);
-          }
-        }
-        if (csel >= 0) {
-          // the wave that loaded the target's vector ends up with the token and stores it; -1 is put down first (it
-          // stays only if nobody finds the target, which consistent sums rule out) - the barrier inside the draw
-          // orders the two stores
-          if (wave == 0 && lane == 0) p.out_token[pidx] = -1;
-          tok = draw_in_chunk(rv, csel, lane, wave, kMagic - Ncs, T, s_tot);
-          writer = tok >= 0;
-        }
-      }
-    } else {
-      // ---- parity mode: exponential race against the caller's noise, first maximum of e_j / E_j (README.md:87
-      //      through torch.multinomial's CPU algorithm).  e_j = ldexp(P, n_j - N_msk): any common scale gives the same
-      //      comparisons; the row scale keeps every allowed term that can win (the largest allowed term is within
-      //      2^-4 of it unless `own`, and then N_msk is the masked maximum's own exponent).  Vectors are dealt round
-      //      robin to the four waves; ties resolve to the smallest index at every level ------------------------------
-      const float magicN = kMagic - N_msk;
+  if constexpr (MODE == kModePhilox) {
+    const int32_t tok = pair_draw_philox<DT, MASK>(p, recs, rv, st, pidx, nch, lane, nullptr, s_tr);
+    if (lane == 0) p.out_token[pidx] = tok;
+  } else {
+    // ---- parity mode: exponential race against the caller's noise, first maximum of e_j / E_j (README.md:87
+    //      through torch.multinomial's CPU algorithm).  e_j = ldexp(P, n_j - N_msk): any common scale gives the same
+    //      comparisons; the row scale keeps every allowed term that can win (the largest allowed term is within
+    //      2^-4 of it unless `own`, and then N_msk is the masked maximum's own exponent).  Vectors are dealt round
+    //      robin to the four waves; ties resolve to the smallest index at every level ------------------------------
+    int32_t tok = -1;
+    if (st.S_msk != 0) {  // workgroup-uniform: every wave folded the same records
+      const float magicN = kMagic - st.N_msk;
       const float *E = p.noise + (int64_t)pidx * p.noise_ld;
       float best = -1.0f, sec = -1.0f;  // sec: runner-up of the race (for the reported margin)
       int32_t bj = -1;
@@ -790,8 +839,112 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
       }
       tok = bj;
     }
+    if (wave == 0 && lane == 0) p.out_token[pidx] = tok;
   }
-  if (lane == 0 && writer) p.out_token[pidx] = tok;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The whole step in ONE launch: a workgroup of W waves per (row, mask) pair.  Wave w reduces chunks w, w + W, ... of
+// the row exactly as chunk_stats_kernel does, leaves each chunk's record in LDS and - while the chunk is still in its
+// registers - the in-chunk draw of every particle of the pair (up to kFusedCap of them; further members reload).  After
+// one barrier the waves take the pair's particles round robin: fold the records, lse / logZ, chunk stage of the draw,
+// look up the token.  No records in global memory, no second launch, nothing re-read: the tail after the last byte of
+// a row has been streamed is a fold of <= 256 LDS records.  Stats / Philox modes, no mask or bit masks.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kFusedMaxChunks = 256;  // rows up to 2^20 elements
+constexpr int kFusedCap = 4;          // particles per pair whose in-chunk draws ride along with the reduction
+
+template <int DT, int MASK, bool SCALED, int MODE>
+__global__ __launch_bounds__(1024) void row_step_kernel(const StepParams p) {
+  constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC;
+  static_assert(MASK != kMaskF32 && MODE != kModeNoise, "float masks / parity mode take the two-launch path");
+  __shared__ uint32_t s_rec[kFusedMaxChunks][5];
+  __shared__ int32_t s_cand[kFusedCap][kFusedMaxChunks];
+  __shared__ __attribute__((aligned(16))) float s_tr[16][64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int W = (int)(blockDim.x >> 6);
+  const int pr = blockIdx.x, nch = p.nch, V = p.V;
+  int m0 = 0, cnt = 1;
+  if (p.mem_start) {
+    m0 = as_const(p.mem_start)[pr];
+    cnt = as_const(p.mem_start)[pr + 1] - m0;
+  }
+  if (cnt <= 0) return;  // a row nobody sits on (workgroup-uniform, before any barrier)
+  const int row = p.pair_row ? as_const(p.pair_row)[pr] : pr;
+  const int mi = MASK == kMaskNone ? 0 : (p.pair_mask ? as_const(p.pair_mask)[pr] : (p.n_masks == 1 ? 0 : pr));
+  const char *rowp = (const char *)p.logits + (int64_t)row * p.ld * ES;
+  const bool draw = MODE == kModePhilox && p.out_token != nullptr;
+  const int ncand = draw ? (cnt < kFusedCap ? cnt : kFusedCap) : 0;
+  uint64_t R2s[kFusedCap];
+#pragma unroll
+  for (int m = 0; m < kFusedCap; ++m) {
+    R2s[m] = 0;
+    if (m < ncand) {
+      uint64_t R1;
+      philox_pair(p, p.mem_start ? as_const(p.members)[m0 + m] : pr, R1, R2s[m]);
+    }
+  }
+
+  for (int c = wave; c < nch; c += W) {
+    const int e_base = c * kChunk;
+    int nv_valid = (V - e_base + 64 * EPV - 1) / (64 * EPV);
+    nv_valid = nv_valid < NVC ? nv_valid : NVC;
+    uint64_t mw = 0;
+    if constexpr (MASK == kMaskBits) {
+      if (ncand) mw = (p.mask_t + ((int64_t)mi * nch + c) * 64)[lane];
+    }
+    float x[64];
+    load_chunk<DT, SCALED>(rowp, e_base, V, lane, p.scale, x);
+    const float Nc = exp_n(chunk_max(x));
+    uint32_t pA, pB, pAm, pBm;
+    if constexpr (MASK == kMaskBits) {
+      const cu64_t mt = as_const(p.mask_t + ((int64_t)mi * nch + c) * 64);
+      chunk_sums<DT, true>(x, kMagic - Nc, nv_valid, mt, pA, pB, pAm, pBm);
+    } else {
+      chunk_sums<DT, false>(x, kMagic - Nc, nv_valid, nullptr, pA, pB, pAm, pBm);
+    }
+    if (lane == 63) {
+      s_rec[c][0] = __float_as_uint(Nc);
+      s_rec[c][1] = pA;
+      s_rec[c][2] = pB;
+      s_rec[c][3] = pAm;
+      s_rec[c][4] = pBm;
+    }
+#pragma unroll
+    for (int m = 0; m < kFusedCap; ++m) {
+      if (m < ncand) {
+        const int32_t tok =
+            chunk_candidate<DT, MASK == kMaskBits>(x, kMagic - Nc, e_base, lane, pAm, pBm, mw, R2s[m], s_tr[wave]);
+        if (lane == 0) s_cand[m][c] = tok;
+      }
+    }
+  }
+  __syncthreads();
+  if (wave >= cnt) return;
+
+  RowView<DT, MASK> rv;
+  rv.rowp = rowp;
+  rv.V = V;
+  rv.scale = p.scale;
+  rv.mt = MASK == kMaskBits ? p.mask_t + (int64_t)mi * nch * 64 : nullptr;
+  rv.mrow = nullptr;
+  const RecsLds recs{s_rec};
+  PairState st;
+  pair_fold<DT, MASK>(p, recs, rv, mi, nch, lane, st);
+  float lse = 0.f, logZ = 0.f;
+  if (lane == 0) pair_logs(st, lse, logZ);
+  for (int m = wave; m < cnt; m += W) {
+    const int pidx = p.mem_start ? as_const(p.members)[m0 + m] : pr;
+    if (lane == 0) {
+      if (p.out_lse) p.out_lse[pidx] = lse;
+      if (p.out_logZ) p.out_logZ[pidx] = logZ;
+    }
+    if (draw) {
+      const int32_t tok = pair_draw_philox<DT, MASK>(p, recs, rv, st, pidx, nch, lane,
+                                                     m < kFusedCap ? s_cand[m] : nullptr, s_tr[wave]);
+      if (lane == 0) p.out_token[pidx] = tok;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -47,7 +47,8 @@ hipError_t GLB_CAT(launch_stats_, GLB_DT)(const StepParams &p, int mask_kind, bo
 
 template <int MASK>
 static hipError_t finish1(const StepParams &p, int mode, hipStream_t s) {
-  const dim3 grid((unsigned)p.n_particles), block(256);  // one workgroup (four waves) per particle
+  // one workgroup per particle: one wave, four for the parity-mode race over the whole row
+  const dim3 grid((unsigned)p.n_particles), block(mode == kModeNoise ? 256 : 64);
   switch (mode) {
     case kModeStats: hipLaunchKernelGGL((finish_kernel<GLB_DT, MASK, kModeStats>), grid, block, 0, s, p); break;
     case kModePhilox: hipLaunchKernelGGL((finish_kernel<GLB_DT, MASK, kModePhilox>), grid, block, 0, s, p); break;
@@ -62,6 +63,32 @@ hipError_t GLB_CAT(launch_finish_, GLB_DT)(const StepParams &p, int mask_kind, i
     case kMaskNone: return finish1<kMaskNone>(p, mode, s);
     case kMaskBits: return finish1<kMaskBits>(p, mode, s);
     case kMaskF32: return finish1<kMaskF32>(p, mode, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+template <int MASK>
+static hipError_t row1(const StepParams &p, int mode, bool scaled, int waves, hipStream_t s) {
+  const dim3 grid((unsigned)p.n_pairs), block((unsigned)waves * 64);
+  if (mode == kModeStats) {
+    if (scaled) hipLaunchKernelGGL((row_step_kernel<GLB_DT, MASK, true, kModeStats>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((row_step_kernel<GLB_DT, MASK, false, kModeStats>), grid, block, 0, s, p);
+  } else if (mode == kModePhilox) {
+    if (scaled) hipLaunchKernelGGL((row_step_kernel<GLB_DT, MASK, true, kModePhilox>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((row_step_kernel<GLB_DT, MASK, false, kModePhilox>), grid, block, 0, s, p);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// the one-launch step (no mask / bit masks, stats / Philox); waves = waves per workgroup (1 .. 16)
+hipError_t GLB_CAT(launch_row_step_, GLB_DT)(const StepParams &p, int mask_kind, int mode, bool scaled, int waves,
+                                              hipStream_t s) {
+  if (waves < 1 || waves > 16 || p.nch > kFusedMaxChunks) return hipErrorInvalidValue;
+  switch (mask_kind) {
+    case kMaskNone: return row1<kMaskNone>(p, mode, scaled, waves, s);
+    case kMaskBits: return row1<kMaskBits>(p, mode, scaled, waves, s);
   }
   return hipErrorInvalidValue;
 }

@@ -223,13 +223,17 @@ __device__ __forceinline__ float chunk_term(float x, float magicN) {
 }
 
 // the integer term itself (slow paths: draws, own-scale sums): floor(t * 2^36), t < 1
-__device__ __forceinline__ uint64_t term_q(float x, float magicN) {
+// as two words: q = (h << 18) + l, h = floor(t * 2^18) < 2^18, l < 2^18
+__device__ __forceinline__ void term_q_parts(float x, float magicN, uint32_t &h, uint32_t &l) {
   const float t = chunk_term(x, magicN);
   const float hi = __builtin_truncf(t * 262144.0f);             // floor(t * 2^18), exact
   const float lo = __builtin_fmaf(hi, -0x1p-18f, t) * 0x1p36f;  // (t - hi * 2^-18) * 2^36, exact, < 2^18 (+ fraction)
-  uint32_t h, l;
   asm("v_cvt_u32_f32 %0, %1" : "=v"(h) : "v"(hi));
   asm("v_cvt_u32_f32 %0, %1" : "=v"(l) : "v"(lo));
+}
+__device__ __forceinline__ uint64_t term_q(float x, float magicN) {
+  uint32_t h, l;
+  term_q_parts(x, magicN, h, l);
   return ((uint64_t)h << kGridHi) + l;
 }
 

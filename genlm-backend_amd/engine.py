@@ -84,13 +84,15 @@ class HipEngine:
 
     def step(self, logits, vocab=None, row_of=None, mask_kind=MASK_NONE, mask=None, mask_id=None,
              rng_mode=RNG_NONE, noise=None, seed=0, offset=0, particle_base=0, logit_scale=1.0,
-             want_lse=True, variant=0, out=None, row_mask_id=None, out_margin=None):
+             want_lse=True, variant=0, out=None, row_mask_id=None, out_margin=None, path=0, row_members=None):
         """Fused particle step (glb_logprob_mask_sample).  Returns (logZ, lse, token) device tensors.
 
         logits: [n_rows, ld] (last dim contiguous; rows may be strided), vocab <= ld.
         mask: int32 bit rows / float rows, or a `PreparedMasks` (prepare_masks).  `row_mask_id` gives the mask per
         logits row (the mask is a function of the context): shared rows are then reduced once.
         `variant` is accepted for source compatibility and ignored (one kernel family serves every shape).
+        `row_members` = (start, members, max_per_row) from `row_members()` lets a per-row reduction with `row_of` run
+        as one launch; `path` forces the launch sequence (0 auto, 1 two launches, 2 one launch) - same results.
         """
         if logits.dim() != 2 or logits.stride(1) != 1:
             raise ValueError("logits must be 2-D with unit inner stride")
@@ -151,11 +153,29 @@ class HipEngine:
         a.out_lse = None if lse is None else lse.data_ptr()
         a.out_token = None if tok is None else tok.data_ptr()
         a.out_margin = None if out_margin is None else out_margin.data_ptr()  # parity mode: tie margin of every draw
+        a.path = path
+        if row_members is not None:
+            start, members, mx = row_members
+            self._check_dev(start, members)
+            if start.dtype != torch.int32 or members.dtype != torch.int32 or start.numel() < n_rows + 1 or members.numel() < n:
+                raise ValueError("row_members: int32 start [n_rows + 1] and members [n_particles]")
+            a.row_members_start, a.row_members, a.row_members_max = start.data_ptr(), members.data_ptr(), int(mx)
         ws = self._scratch(self.lib.glb_step_workspace_bytes(n, n_rows, V, n_masks))
         a.workspace = ws.data_ptr()
         a.workspace_bytes = ws.numel()
         check(self.lib.glb_logprob_mask_sample(C.byref(a), self._stream()))
         return logZ, lse, tok
+
+    def row_members(self, row_of, n_rows, out=None):
+        """Inverse of the fan-out map (glb_row_members): (start int32 [n_rows + 2], members int32 [n], max int32 [1])
+        device tensors; members of a row come in no particular order."""
+        self._check_dev(row_of)
+        if row_of.dtype != torch.int32 or row_of.dim() != 1 or not row_of.is_contiguous():
+            raise TypeError("row_of must be a contiguous int32 vector")
+        n = row_of.numel()
+        start, members, mx = out if out is not None else (self._i32(n_rows + 2), self._i32(n), self._i32(1))
+        check(self.lib.glb_row_members(_ptr(row_of), n, n_rows, _ptr(start), _ptr(members), _ptr(mx), self._stream()))
+        return start, members, mx
 
     def prepare_masks(self, bits, vocab, logits_dtype=torch.float32):
         """int32 bit rows [K, >= ceil(V/32)] -> `PreparedMasks` for logits of `logits_dtype` (glb_mask_prepare)."""

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GLB_ABI_VERSION 2
+#define GLB_ABI_VERSION 3
 
 /* status codes */
 enum {
@@ -55,11 +55,19 @@ enum {
 /* RNG modes of the categorical draw */
 enum {
   GLB_RNG_NONE = 0,   /* no draw (out_token untouched)                                            */
-  GLB_RNG_PHILOX = 1, /* in-kernel Philox4x32-10, one 64-bit uniform per particle, exact integer
-                         inverse-CDF in vocabulary order                                          */
+  GLB_RNG_PHILOX = 1, /* in-kernel Philox4x32-10, two 64-bit uniforms per particle: exact integer inverse
+                         CDF over the row's 4096-token chunks, then inside the chunk  */
   GLB_RNG_NOISE = 2   /* parity mode: caller supplies Exp(1) noise E[n_particles, noise_ld] drawn
                          the way torch.multinomial draws it on CPU; token = first argmax p_j/E_j
                          (README.md:87, base.py:137-141)                                          */
+};
+
+/* which launch sequence glb_logprob_mask_sample uses; results are the same bit for bit */
+enum {
+  GLB_PATH_AUTO = 0,
+  GLB_PATH_TWO_LAUNCH = 1, /* chunk records to the workspace, then one wave per particle */
+  GLB_PATH_ONE_LAUNCH = 2  /* a workgroup per row; GLB_EUNSUPPORTED for float masks, parity noise, rows over 2^20
+                              elements, or row_of without row_members */
 };
 
 const char *glb_version(void);
@@ -116,7 +124,14 @@ typedef struct glb_step_args {
   int32_t *out_token;/* [n_particles] sampled id, -1 when every token is masked out */
   float *out_margin; /* [n_particles] GLB_RNG_NOISE only: (winner - runner-up) / winner of the race e_j / E_j, i.e. how
                         far the draw is from a tie that float rounding could flip (1 if there is no runner-up) */
-  int32_t reserved;  /* must be 0 */
+  int32_t path;      /* GLB_PATH_*: 0 = let the library choose */
+  /* Optional inverse of row_of for per-row reductions (row_of given; no mask or row_mask_id), from
+     glb_row_members: the particles on row r are row_members[row_members_start[r] .. row_members_start[r + 1]).
+     With it, and with row_members_max (an upper bound on the particles per row the caller knows of, 0 = unknown)
+     at most 4, the step runs as one launch; a wrong bound costs time, never correctness. */
+  const int32_t *row_members_start; /* [n_rows + 1] device, nullable */
+  const int32_t *row_members;       /* [n_particles] device, nullable */
+  int32_t row_members_max;
   /* device scratch of >= glb_step_workspace_bytes(...) bytes, 32-byte aligned: the per-chunk records the
      reduction kernel hands to the per-particle kernel (and, for GLB_MASK_BITS, the prepared masks) */
   void *workspace;
@@ -125,6 +140,16 @@ typedef struct glb_step_args {
 
 size_t glb_step_workspace_bytes(int64_t n_particles, int64_t n_rows, int64_t vocab, int64_t n_masks);
 int glb_logprob_mask_sample(const glb_step_args *args, void *hip_stream);
+
+/*
+ * Inverse of the fan-out map row_of (hf.py:285-288 hands every query of a group the group's result): the particles
+ * of each row as a CSR (members of a row in no particular order).
+ *   out_start   [n_rows + 2]  device int32; [0, n_rows] are the offsets (the extra word is scratch)
+ *   out_members [n_particles] device int32
+ *   out_max     [1]           device int32, optional: the largest number of particles on one row
+ */
+int glb_row_members(const int32_t *row_of, int64_t n_particles, int64_t n_rows, int32_t *out_start,
+                    int32_t *out_members, int32_t *out_max, void *hip_stream);
 
 /*
  * Bring GLB_MASK_BITS rows into the layout the kernels read ([mask][chunk][vector][component] 64-bit lane

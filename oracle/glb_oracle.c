@@ -350,6 +350,7 @@ int orc_step(const void *logits, int dtype, int64_t n_rows, int64_t V, int64_t l
         uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, rnd[4];
         orc_philox4x32_10(ctr, key, rnd);
         uint64_t R = ((uint64_t)rnd[1] << 32) | rnd[0];
+        uint64_t R2 = ((uint64_t)rnd[3] << 32) | rnd[2];
         uint64_t T = mulhi64(R, S_msk); /* uniform integer in [0, S_msk) */
         if (own) { /* one scale for the whole row: plain inverse CDF in vocabulary order */
           uint64_t c = 0;
@@ -357,18 +358,28 @@ int orc_step(const void *logits, int dtype, int64_t n_rows, int64_t V, int64_t l
             c += glb_term_q(y[j], GLB_MAGIC - N_msk);
             if (c > T) { tok = (int32_t)j; break; }
           }
-        } else { /* chunk by the shifted chunk sums, then the target moves onto the chunk's own scale */
+        } else {
+          /* two stages, two independent 64-bit draws: the chunk by the shifted chunk sums (first draw), then inside
+           * the chunk an inverse CDF on the chunk's own scale against its unshifted sum (second draw).  The order
+           * inside a chunk is the order the kernel holds it in: lane l of the wave owns elements
+           * (i * 64 + l) * EPV + k of the chunk, i = 0 .. 64/EPV - 1, k = 0 .. EPV - 1, EPV elements per 16-byte
+           * vector of the logits; terms are taken lane by lane, within a lane by (i, k).  Any fixed order gives the
+           * same distribution; this one lets the wave that reduced the chunk draw from its registers. */
+          const int epv = dtype == ORC_F32 ? 4 : 8, nvc = 64 / epv;
           for (int64_t c = 0; c < nch && tok < 0; ++c) {
             if (!cm[c].S) continue;
             float d = N_msk - cm[c].N;
             uint64_t sm = shr_sat(cm[c].S, d);
             if (T < sm) {
-              uint64_t Tc = T << (uint32_t)d, acc = 0;
-              int64_t lo = c * GLB_CHUNK, hi = lo + GLB_CHUNK < V ? lo + GLB_CHUNK : V;
-              for (int64_t j = lo; j < hi; ++j) {
-                acc += glb_term_q(y[j], GLB_MAGIC - cm[c].N);
-                if (acc > Tc) { tok = (int32_t)j; break; }
-              }
+              uint64_t Tc = mulhi64(R2, cm[c].S), acc = 0;
+              for (int l = 0; l < 64 && tok < 0; ++l)
+                for (int i = 0; i < nvc && tok < 0; ++i)
+                  for (int k = 0; k < epv; ++k) {
+                    int64_t j = c * GLB_CHUNK + ((int64_t)i * 64 + l) * epv + k;
+                    if (j >= V) continue;
+                    acc += glb_term_q(y[j], GLB_MAGIC - cm[c].N);
+                    if (acc > Tc) { tok = (int32_t)j; break; }
+                  }
               break;
             }
             T -= sm;
@@ -390,6 +401,29 @@ int orc_step(const void *logits, int dtype, int64_t n_rows, int64_t V, int64_t l
     out_token[i] = tok;
   }
   free(x); free(y); free(ca); free(cm); free(Sm);
+  return 0;
+}
+
+/* contract of glb_row_members (inverse of the fan-out of hf.py:285-288): CSR of the particles on every row; the kernel
+ * promises no order inside a row, this restatement lists them in increasing order (tests compare row by row as sets) */
+int orc_row_members(const int32_t *row_of, int64_t n, int64_t n_rows, int32_t *start, int32_t *members,
+                    int32_t *out_max) {
+  for (int64_t r = 0; r <= n_rows; ++r) start[r] = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    if (row_of[i] < 0 || row_of[i] >= n_rows) return 1;
+    start[row_of[i] + 1]++;
+  }
+  int32_t mx = 0;
+  for (int64_t r = 0; r < n_rows; ++r) {
+    if (start[r + 1] > mx) mx = start[r + 1];
+    start[r + 1] += start[r];
+  }
+  int32_t *cur = (int32_t *)malloc(sizeof(int32_t) * (size_t)n_rows);
+  if (!cur) return 4;
+  for (int64_t r = 0; r < n_rows; ++r) cur[r] = start[r];
+  for (int64_t i = 0; i < n; ++i) members[cur[row_of[i]]++] = (int32_t)i;
+  free(cur);
+  if (out_max) *out_max = mx;
   return 0;
 }
 

@@ -22,9 +22,9 @@ def test_library_exports_every_declared_symbol():
     raw = C.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert lib.glb_abi_version() == 2
+    assert lib.glb_abi_version() == 3
     assert b"gfx950" in lib.glb_version()
-    assert C.sizeof(_lib.StepArgs) == 224  # layout guard of glb_step_args
+    assert C.sizeof(_lib.StepArgs) == 248  # layout guard of glb_step_args
 
 
 def test_argument_errors_do_not_touch_the_gpu():

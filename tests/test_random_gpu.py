@@ -97,13 +97,34 @@ def test_random_case(engine, oracle, c):
     seed, offset, base = c["seed"], c["seed"] % 17, c["seed"] % 1000
     logZ_o, lse_o, tok_o = O.step(x_np, row_of=row_of, rng_mode=mode, seed=seed, offset=offset, particle_base=base,
                                   logit_scale=c["scale"], n_particles=N if row_of is None else None, **kw_o)
-    call = lambda: engine.step(x_d, vocab=V, row_of=None if row_of is None else torch.from_numpy(row_of).to(dev),
-                               rng_mode={"none": 0, "philox": 1, "noise": 2}[c["rng_mode"]], seed=seed, offset=offset,
-                               particle_base=base, logit_scale=c["scale"], **kw_g)
-    logZ, lse, tok = call()
-    torch.cuda.synchronize()
-    got_logZ, got_lse = logZ.cpu().numpy(), lse.cpu().numpy()
-    assert np.array_equal(got_lse.view(np.uint32), lse_o.view(np.uint32)), "lse"
-    assert np.array_equal(got_logZ.view(np.uint32), logZ_o.view(np.uint32)), "logZ"
-    if c["rng_mode"] != "none":
-        assert np.array_equal(tok.cpu().numpy(), tok_o), "token"
+    call = lambda **kw: engine.step(x_d, vocab=V, row_of=None if row_of is None else torch.from_numpy(row_of).to(dev),
+                                    rng_mode={"none": 0, "philox": 1, "noise": 2}[c["rng_mode"]], seed=seed,
+                                    offset=offset, particle_base=base, logit_scale=c["scale"], **kw_g, **kw)
+    def check(res, what):
+        logZ, lse, tok = res
+        torch.cuda.synchronize()
+        got_logZ, got_lse = logZ.cpu().numpy(), lse.cpu().numpy()
+        assert np.array_equal(got_lse.view(np.uint32), lse_o.view(np.uint32)), f"lse ({what})"
+        assert np.array_equal(got_logZ.view(np.uint32), logZ_o.view(np.uint32)), f"logZ ({what})"
+        if c["rng_mode"] != "none":
+            assert np.array_equal(tok.cpu().numpy(), tok_o), f"token ({what})"
+
+    check(call(), "auto")
+    # every launch sequence gives the same bits: two launches (records in the workspace), one launch (a workgroup per
+    # row), and for per-row reductions with a fan-out map the one-launch form with the inverse map handed over - also
+    # with a wrong bound on the particles per row (members past the cap redo their chunk instead of finding a result)
+    per_row = c["mask_kind"] == "none" or c["form"] == "by_row"
+    one_launch = c["mask_kind"] != "f32" and c["rng_mode"] != "noise"
+    check(call(path=1), "two launches")
+    if one_launch and not (per_row and row_of is not None):
+        check(call(path=2), "one launch")
+    if one_launch and per_row and row_of is not None:
+        ro_d = torch.from_numpy(row_of).to(dev)
+        start, members, mx = engine.row_members(ro_d, U)
+        st_o, mem_o, mx_o = O.row_members(row_of, U)
+        assert np.array_equal(start.cpu().numpy()[:U + 1], st_o) and int(mx.item()) == mx_o
+        got = members.cpu().numpy()
+        for r in range(U):
+            assert sorted(got[st_o[r]:st_o[r + 1]]) == list(mem_o[st_o[r]:st_o[r + 1]])
+        check(call(row_members=(start, members, mx_o)), "members, auto")
+        check(call(path=2, row_members=(start, members, 1)), "members, one launch")
