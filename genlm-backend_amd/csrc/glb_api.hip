@@ -76,24 +76,24 @@ hipError_t launch_row_step(int dtype, const glb::StepParams &p, int mask_kind, i
 
 inline int64_t n_chunks(int64_t vocab) { return (vocab + glb::kChunk - 1) / glb::kChunk; }
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
-// prepared masks: transposed lane words, then the sparse-id lists
+// prepared masks: transposed lane words, then one "allows anything" word per (mask, chunk)
 inline size_t prepared_words_bytes(int64_t n_masks, int64_t vocab) {
   return align256((size_t)n_masks * (size_t)n_chunks(vocab) * 64 * sizeof(uint64_t));
 }
 inline size_t prepared_bytes(int64_t n_masks, int64_t vocab) {
-  return prepared_words_bytes(n_masks, vocab) + align256((size_t)n_masks * glb::kInfoWords * sizeof(int32_t));
+  return prepared_words_bytes(n_masks, vocab) + align256((size_t)n_masks * (size_t)n_chunks(vocab) * sizeof(uint64_t));
 }
 
 hipError_t launch_mask_prepare(const uint32_t *bits, int64_t n_masks, int64_t vocab, int64_t mask_ld, int dtype,
                                void *out, hipStream_t s) {
   const int nch = (int)n_chunks(vocab);
   uint64_t *mt = (uint64_t *)out;
-  int32_t *info = (int32_t *)((char *)out + prepared_words_bytes(n_masks, vocab));
-  const dim3 grid((unsigned)(nch + 1), (unsigned)n_masks), block(256);
+  uint64_t *many = (uint64_t *)((char *)out + prepared_words_bytes(n_masks, vocab));
+  const dim3 grid((unsigned)nch, (unsigned)n_masks), block(256);
   if (dtype == GLB_F32)
-    hipLaunchKernelGGL((glb::mask_prepare_kernel<4>), grid, block, 0, s, bits, mask_ld, (int)vocab, nch, mt, info);
+    hipLaunchKernelGGL((glb::mask_prepare_kernel<4>), grid, block, 0, s, bits, mask_ld, (int)vocab, nch, mt, many);
   else
-    hipLaunchKernelGGL((glb::mask_prepare_kernel<8>), grid, block, 0, s, bits, mask_ld, (int)vocab, nch, mt, info);
+    hipLaunchKernelGGL((glb::mask_prepare_kernel<8>), grid, block, 0, s, bits, mask_ld, (int)vocab, nch, mt, many);
   return hipGetLastError();
 }
 
@@ -812,7 +812,7 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
       prep = dst;
     }
     p.mask_t = (const uint64_t *)prep;
-    p.mask_info = (const int32_t *)(prep + prepared_words_bytes(a->n_masks, a->vocab));
+    p.mask_any = (const uint64_t *)(prep + prepared_words_bytes(a->n_masks, a->vocab));
   }
   p.noise = a->noise;
   p.noise_ld = a->noise_ld;
@@ -832,10 +832,12 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
                            (a->row_members_max > 0 && a->row_members_max <= glb::kFusedCap);
   const bool one_launch_ok = kmask != glb::kMaskF32 && a->rng_mode != GLB_RNG_NOISE &&
                              p.nch <= glb::kFusedMaxChunks && members_known;
+  static const int env_path = [] { const char *e = getenv("GLB_PATH"); return e ? atoi(e) : 0; }();  // tuning aid
+  const int path = a->path != GLB_PATH_AUTO ? a->path : (env_path == 1 || (env_path == 2 && one_launch_ok) ? env_path : 0);
   if (a->path == GLB_PATH_ONE_LAUNCH && !one_launch_ok)
     return fail(GLB_EUNSUPPORTED, "one-launch path asked for, but the call has float masks / parity noise / rows over "
                                   "2^20 elements / row_of without row_members");
-  if (a->path == GLB_PATH_ONE_LAUNCH || (a->path == GLB_PATH_AUTO && one_launch_ok && few_members)) {
+  if (path == GLB_PATH_ONE_LAUNCH || (path == GLB_PATH_AUTO && one_launch_ok && few_members)) {
     if (by_row && a->row_of) {
       p.mem_start = a->row_members_start;
       p.members = a->row_members;

@@ -15,14 +15,14 @@
 //                        LDS, no barrier, no cross-wave dependency: the launch is pure streaming and the unit
 //                        of scheduling is 16 KiB, so any row count / row length fills the chip.  Rows shared by
 //                        several particles (dedup fan-out of hf.py:214-220,285-288) are reduced once.
-//   finish_kernel        one wave per PARTICLE: folds the <= 64 chunk records of its row into (N, S_all, S_mask),
-//                        lse / logZ by a double-precision log, then the draw: Philox target -> chunk (scan of the
-//                        chunk sums) -> vector -> lane -> element, recomputing only the one chunk it lands in.
-//                        Also the rare own-scale redo (allowed mass below 2^-4 of the row's largest term) and the
-//                        parity-mode exponential race.
+//   finish_kernel        one wave per PARTICLE: folds the chunk records of its row into (N, S_all, S_mask), lse / logZ
+//                        by a double-precision log, then the draw: first Philox word -> chunk (scan of the chunk
+//                        sums), second word -> element inside that chunk, which is reloaded and reduced again.
+//                        Also the parity-mode exponential race (four waves).
+//   row_step_kernel      the same step in ONE launch: a workgroup per row, records in LDS, in-chunk draws made by the
+//                        reducing wave while the chunk is in its registers.
 //   logprob_rows_kernel  x - lse for the API path that materialises log-probabilities (cache.py:93-98).
-// mask_prepare_kernel builds the transposed masks ([mask][chunk][vector][component] 64-bit lane words) and a
-// short list of allowed ids for sparse masks (the README's EOS-only mask, README.md:62-66).
+// mask_prepare_kernel builds the transposed masks ([mask][chunk][vector][component] 64-bit lane words).
 #pragma once
 #include <type_traits>
 
@@ -34,13 +34,12 @@ enum { kDtF32 = 0, kDtBf16 = 1, kDtF16 = 2 };
 enum { kMaskNone = 0, kMaskBits = 1, kMaskF32 = 2 };
 enum { kModeStats = 0, kModePhilox = 1, kModeNoise = 2 };
 
-constexpr int kInfoWords = 64;  // per mask: allowed-token count, then up to 63 ids (when count <= 63)
-
 struct ChunkRec {  // 32 bytes per (row|particle, chunk)
   float Nc;            // chunk scale exp_n(max); -inf for an empty chunk
   uint32_t pA, pB;     // S_c   = (pA << 18) + pB     all elements
-  uint32_t pAm, pBm;   // S_c^m = (pAm << 18) + pBm   allowed elements (bit masks: on Nc; float masks: on Nm)
-  float Nm;            // float masks: scale of the masked chunk exp_n(max(x + mask))
+  uint32_t pAm, pBm;   // S_c^m = (pAm << 18) + pBm   allowed elements, on the scale Nm
+  float Nm;            // bit masks: Nc, or the allowed maximum's own scale for a low-mass chunk; float masks:
+                       // exp_n(max(x + mask)); no mask: Nc
   uint32_t pad[2];
 };
 static_assert(sizeof(ChunkRec) == 32, "ChunkRec layout");
@@ -57,7 +56,7 @@ struct StepParams {
   const int32_t *mem_start;  // [n_pairs + 1] row kernel: particles of a unit as a CSR, null = identity (one each)
   const int32_t *members;    // [n_particles]
   const uint64_t *mask_t;    // transposed bit masks [n_masks][nch * 64]
-  const int32_t *mask_info;  // [n_masks][kInfoWords]
+  const uint64_t *mask_any;  // [n_masks][nch]: nonzero when the mask allows any token of the chunk
   const float *mask_f;       // float masks [n_masks][mask_ld]
   int64_t mask_ld;
   const float *noise;
@@ -179,33 +178,83 @@ __device__ __forceinline__ void store_rec(ChunkRec *dst, float Nc, uint32_t pA, 
 
 // sums of one chunk held in x[64]: returns the lane-63 totals of the four payload words.  (v0, VSTEP): this wave's
 // vectors are v0, v0 + VSTEP, ... (one wave per chunk: 0, 1; four waves per chunk: wave, 4) and x holds them densely.
-template <int DT, bool MASKED, int VSTEP = 1>
-__device__ __forceinline__ void chunk_sums(const float (&x)[64], float magicN, int nv_valid, cu64_t mt,
-                                           uint32_t &pA, uint32_t &pB, uint32_t &pAm, uint32_t &pBm, int v0 = 0) {
+// the first two groups of mask words of a chunk (8 words each), fetched by the caller before it waits for the chunk's
+// own loads and hands to chunk_sums
+struct MaskAhead {
+  uint64_t w[2][8];
+};
+template <int DT, int VSTEP = 1>
+__device__ __forceinline__ void mask_ahead(cu64_t mt, MaskAhead &ma, int v0 = 0) {
+  constexpr int EPV = ElemTraits<DT>::EPV, NVC = ElemTraits<DT>::NVC / VSTEP, VPG = 8 / EPV;
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      const int i = g * VPG + w / EPV;
+      ma.w[g][w] = i < NVC ? mt[(v0 + i * VSTEP) * EPV + (w % EPV)] : 0ull;
+    }
+}
+
+template <int DT, bool MASKED, int VSTEP, bool FULL>
+__device__ __forceinline__ void chunk_sums_body(const float (&x)[64], float magicN, int nv_valid, cu64_t mt, int v0,
+                                                const MaskAhead &ahead, float &A0, float &B0, float &A1, float &B1, float &Am0, float &Bm0,
+                                                float &Am1, float &Bm1) {
   constexpr int EPV = ElemTraits<DT>::EPV, NVC = ElemTraits<DT>::NVC / VSTEP;
-  float A0 = __uint_as_float(kA0Bits), A1 = A0, Am0 = A0, Am1 = A0;
-  float B0 = __uint_as_float(kB0Bits), B1 = B0, Bm0 = B0, Bm1 = B0;
+  // mask words travel in groups of 8 (one s_load_dwordx16) fetched two groups ahead of the adds that use them: a
+  // scalar load that misses the scalar cache takes longer than the ~40 VALU issues of one group
+  constexpr int GW = 8, VPG = GW / EPV > 0 ? GW / EPV : 1, NG = (NVC + VPG - 1) / VPG;  // vectors per group, groups
+  uint64_t Mq[3][GW] = {};
+  auto fetch = [&](int g, uint64_t (&dst)[GW]) {
 #pragma unroll
-  for (int i = 0; i < NVC; ++i) {
-    const int vi = v0 + i * VSTEP;  // the vector's index inside the chunk
-    if (vi < nv_valid) {  // wave-uniform: vectors wholly past the row end are skipped
-      float t[EPV];
+    for (int w = 0; w < GW; ++w) {
+      const int i = g * VPG + w / EPV;  // this wave's i-th vector
+      dst[w] = i < NVC ? mt[(v0 + i * VSTEP) * EPV + (w % EPV)] : 0ull;
+    }
+  };
+  if constexpr (MASKED) {
 #pragma unroll
-      for (int k = 0; k < EPV; ++k) t[k] = chunk_term(x[i * EPV + k], magicN);
+    for (int w = 0; w < GW; ++w) {
+      Mq[0][w] = ahead.w[0][w];
+      Mq[1][w] = ahead.w[1][w];
+    }
+  }
 #pragma unroll
-      for (int h = 0; h < EPV / 4; ++h) {
-        uint64_t M0 = 0, M1 = 0, M2 = 0, M3 = 0;
-        if constexpr (MASKED) {
-          M0 = mt[vi * EPV + 4 * h + 0];
-          M1 = mt[vi * EPV + 4 * h + 1];
-          M2 = mt[vi * EPV + 4 * h + 2];
-          M3 = mt[vi * EPV + 4 * h + 3];
+  for (int g = 0; g < NG; ++g) {
+    if constexpr (MASKED) {
+      if (g + 2 < NG) fetch(g + 2, Mq[(g + 2) % 3]);
+    }
+#pragma unroll
+    for (int iv = 0; iv < VPG; ++iv) {
+      const int i = g * VPG + iv;
+      if (i >= NVC) break;
+      const int vi = v0 + i * VSTEP;  // the vector's index inside the chunk
+      if (FULL || vi < nv_valid) {  // wave-uniform: vectors wholly past the row end are skipped
+        float t[EPV];
+#pragma unroll
+        for (int k = 0; k < EPV; ++k) t[k] = chunk_term(x[i * EPV + k], magicN);
+#pragma unroll
+        for (int h = 0; h < EPV / 4; ++h) {
+          const uint64_t *M = &Mq[g % 3][iv * EPV + 4 * h];
+          rtz_acc4<MASKED>(t[4 * h], t[4 * h + 1], t[4 * h + 2], t[4 * h + 3], A0, B0, A1, B1, Am0, Bm0, Am1, Bm1,
+                           M[0], M[1], M[2], M[3]);
         }
-        rtz_acc4<MASKED>(t[4 * h], t[4 * h + 1], t[4 * h + 2], t[4 * h + 3], A0, B0, A1, B1, Am0, Bm0, Am1, Bm1,
-                         M0, M1, M2, M3);
       }
     }
   }
+}
+
+template <int DT, bool MASKED, int VSTEP = 1>
+__device__ __forceinline__ void chunk_sums(const float (&x)[64], float magicN, int nv_valid, cu64_t mt,
+                                           const MaskAhead &ahead, uint32_t &pA, uint32_t &pB, uint32_t &pAm,
+                                           uint32_t &pBm, int v0 = 0) {
+  float A0 = __uint_as_float(kA0Bits), A1 = A0, Am0 = A0, Am1 = A0;
+  float B0 = __uint_as_float(kB0Bits), B1 = B0, Bm0 = B0, Bm1 = B0;
+  // a full chunk (all but the last of a row) runs as one straight block: the scheduler can then start the scalar loads
+  // of the mask words well ahead of the adds that use them; the last chunk tests every vector against the row end
+  if (nv_valid == ElemTraits<DT>::NVC)
+    chunk_sums_body<DT, MASKED, VSTEP, true>(x, magicN, nv_valid, mt, v0, ahead, A0, B0, A1, B1, Am0, Bm0, Am1, Bm1);
+  else
+    chunk_sums_body<DT, MASKED, VSTEP, false>(x, magicN, nv_valid, mt, v0, ahead, A0, B0, A1, B1, Am0, Bm0, Am1, Bm1);
   pA = wave_sum_u32_l63((__float_as_uint(A0) - kA0Bits) + (__float_as_uint(A1) - kA0Bits));
   pB = wave_sum_u32_l63((__float_as_uint(B0) - kB0Bits) + (__float_as_uint(B1) - kB0Bits));
   pAm = pA;
@@ -221,6 +270,36 @@ __device__ __forceinline__ float chunk_max(const float (&x)[64]) {
 #pragma unroll
   for (int j = 0; j < 64; j += 2) m = max3(m, x[j], x[j + 1]);
   return wave_max(m);
+}
+
+// Bit-masked chunk: both sums at the chunk scale Nc (one exponential per element); if the allowed sum comes out
+// below 2^32 although the mask allows something in this chunk (allows_any, from mask_prepare) - allowed mass under
+// about 2^-3.5 of the chunk's largest term, e.g. the one likely token is the forbidden one - the forbidden elements of x are overwritten with -inf and the allowed ones summed
+// again on their own maximum's scale (wave-uniform, rare, everything still in registers).  (pAm, pBm) are per-lane
+// inclusive scans as chunk_sums returns them, on the scale Nm; `redone` tells the caller x is now the masked chunk.
+template <int DT>
+__device__ __forceinline__ void chunk_reduce_bits(float (&x)[64], float Nc, int nv_valid, cu64_t mt,
+                                                  const MaskAhead &ma, uint64_t allows_any, int lane, uint32_t &pA,
+                                                  uint32_t &pB, uint32_t &pAm, uint32_t &pBm, float &Nm,
+                                                  bool &redone) {
+  chunk_sums<DT, true>(x, kMagic - Nc, nv_valid, mt, ma, pA, pB, pAm, pBm);
+  Nm = Nc;
+  redone = false;
+  const uint32_t ta = (uint32_t)__builtin_amdgcn_readlane((int)pAm, 63);
+  const uint32_t tb = (uint32_t)__builtin_amdgcn_readlane((int)pBm, 63);
+  const uint64_t Sm = ((uint64_t)ta << kGridHi) + tb;
+  uint32_t top = (uint32_t)(Sm >> kLowMassBits), any = (uint32_t)allows_any;
+  opaque_u32(top);
+  opaque_u32(any);
+  if (top == 0u && any != 0u) {
+#pragma unroll
+    for (int j = 0; j < 64; ++j)
+      if (!((mt[j] >> lane) & 1ull)) x[j] = kNegInf;
+    Nm = exp_n(chunk_max(x));
+    uint32_t d0, d1;
+    chunk_sums<DT, false>(x, kMagic - Nm, nv_valid, nullptr, MaskAhead{}, pAm, pBm, d0, d1);
+    redone = true;
+  }
 }
 
 // y = x + (float mask row) for the wave's chunk (same lane layout as x)
@@ -320,17 +399,25 @@ __global__ __launch_bounds__(256, GLB_K1_MINW) void chunk_stats_kernel(const Ste
   int nv_valid = (V - e_base + 64 * EPV - 1) / (64 * EPV);
   nv_valid = nv_valid < NVC ? nv_valid : NVC;
 
+  MaskAhead ma{};
+  cu64_t mt = nullptr;
+  uint64_t allows_any = 0;
+  if constexpr (MASK == kMaskBits) {
+    const int mi = p.pair_mask ? as_const(p.pair_mask)[pr] : (p.n_masks == 1 ? 0 : pr);
+    mt = as_const(p.mask_t + ((int64_t)mi * nch + c) * 64);
+    mask_ahead<DT>(mt, ma);
+    allows_any = as_const(p.mask_any)[(int64_t)mi * nch + c];
+  }
   float x[64];
   load_chunk<DT, SCALED>(rowp, e_base, V, lane, p.scale, x);
   const float Nc = exp_n(chunk_max(x));
   uint32_t pA, pB, pAm, pBm;
   float Nm = Nc;
   if constexpr (MASK == kMaskBits) {
-    const int mi = p.pair_mask ? as_const(p.pair_mask)[pr] : (p.n_masks == 1 ? 0 : pr);
-    const cu64_t mt = as_const(p.mask_t + ((int64_t)mi * nch + c) * 64);
-    chunk_sums<DT, true>(x, kMagic - Nc, nv_valid, mt, pA, pB, pAm, pBm);
+    bool redone;
+    chunk_reduce_bits<DT>(x, Nc, nv_valid, mt, ma, allows_any, lane, pA, pB, pAm, pBm, Nm, redone);
   } else {
-    chunk_sums<DT, false>(x, kMagic - Nc, nv_valid, nullptr, pA, pB, pAm, pBm);
+    chunk_sums<DT, false>(x, kMagic - Nc, nv_valid, nullptr, ma, pA, pB, pAm, pBm);
     if constexpr (MASK == kMaskF32) {  // general additive masks: y = x + m has its own maximum, scale and exp
       const int mi = p.pair_mask ? as_const(p.pair_mask)[pr] : (p.n_masks == 1 ? 0 : pr);
       const char *mrow = (const char *)(p.mask_f + (int64_t)mi * p.mask_ld);
@@ -338,7 +425,7 @@ __global__ __launch_bounds__(256, GLB_K1_MINW) void chunk_stats_kernel(const Ste
       add_float_mask<DT>(x, mrow, e_base, V, lane, y);
       Nm = exp_n(chunk_max(y));
       uint32_t d0, d1;
-      chunk_sums<DT, false>(y, kMagic - Nm, nv_valid, nullptr, pAm, pBm, d0, d1);
+      chunk_sums<DT, false>(y, kMagic - Nm, nv_valid, nullptr, ma, pAm, pBm, d0, d1);
     }
   }
   if (lane == 63) store_rec(p.recs + (int64_t)pr * nch + c, Nc, pA, pB, pAm, pBm, Nm);
@@ -390,9 +477,11 @@ __global__ __launch_bounds__(256) void chunk_stats_small_kernel(const StepParams
   if constexpr (MASK == kMaskBits) {
     const int mi = p.pair_mask ? as_const(p.pair_mask)[pr] : (p.n_masks == 1 ? 0 : pr);
     const cu64_t mt = as_const(p.mask_t + ((int64_t)mi * nch + c) * 64);
-    chunk_sums<DT, true, 4>(x, kMagic - Nc, nv_valid, mt, pA, pB, pAm, pBm, wave);
+    MaskAhead ma;
+    mask_ahead<DT, 4>(mt, ma, wave);
+    chunk_sums<DT, true, 4>(x, kMagic - Nc, nv_valid, mt, ma, pA, pB, pAm, pBm, wave);
   } else {
-    chunk_sums<DT, false, 4>(x, kMagic - Nc, nv_valid, nullptr, pA, pB, pAm, pBm, wave);
+    chunk_sums<DT, false, 4>(x, kMagic - Nc, nv_valid, nullptr, MaskAhead{}, pA, pB, pAm, pBm, wave);
   }
   if (lane == 63) {
     s_pay[wave][0] = pA;
@@ -401,12 +490,44 @@ __global__ __launch_bounds__(256) void chunk_stats_small_kernel(const StepParams
     s_pay[wave][3] = pBm;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t t[4];
+  uint32_t t[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) t[k] = s_pay[0][k] + s_pay[1][k] + s_pay[2][k] + s_pay[3][k];
-    store_rec(p.recs + (int64_t)pr * nch + c, Nc, t[0], t[1], t[2], t[3], Nc);
+  for (int k = 0; k < 4; ++k) t[k] = s_pay[0][k] + s_pay[1][k] + s_pay[2][k] + s_pay[3][k];
+  float Nm = Nc;
+  if constexpr (MASK == kMaskBits) {
+    // the low-mass rule of chunk_reduce_bits, with the chunk spread over four waves (workgroup-uniform branch)
+    const uint64_t Sm = ((uint64_t)t[2] << kGridHi) + t[3];
+    const int mi = p.pair_mask ? as_const(p.pair_mask)[pr] : (p.n_masks == 1 ? 0 : pr);
+    uint32_t top = (uint32_t)(Sm >> kLowMassBits), any = (uint32_t)as_const(p.mask_any)[(int64_t)mi * nch + c];
+    opaque_u32(top);
+    opaque_u32(any);
+    if (top == 0u && any != 0u) {
+      const cu64_t mt = as_const(p.mask_t + ((int64_t)mi * nch + c) * 64);
+#pragma unroll
+      for (int j = 0; j < NVW; ++j)
+#pragma unroll
+        for (int k = 0; k < EPV; ++k)
+          if (!((mt[(wave + 4 * j) * EPV + k] >> lane) & 1ull)) x[j * EPV + k] = kNegInf;
+      float mm = kNegInf;
+#pragma unroll
+      for (int j = 0; j < NVW * EPV; j += 2) mm = max3(mm, x[j], x[j + 1]);
+      mm = wave_max(mm);
+      __syncthreads();  // everybody has read s_max / s_pay
+      if (lane == 0) s_max[wave] = mm;
+      __syncthreads();
+      Nm = exp_n(fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3])));
+      uint32_t qa, qb, d0, d1;
+      chunk_sums<DT, false, 4>(x, kMagic - Nm, nv_valid, nullptr, MaskAhead{}, qa, qb, d0, d1, wave);
+      if (lane == 63) {
+        s_pay[wave][2] = qa;
+        s_pay[wave][3] = qb;
+      }
+      __syncthreads();
+      t[2] = s_pay[0][2] + s_pay[1][2] + s_pay[2][2] + s_pay[3][2];
+      t[3] = s_pay[0][3] + s_pay[1][3] + s_pay[2][3] + s_pay[3][3];
+    }
   }
+  if (threadIdx.x == 0) store_rec(p.recs + (int64_t)pr * nch + c, Nc, t[0], t[1], t[2], t[3], Nm);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -431,6 +552,7 @@ struct RowView {
   int V;
   float scale;
   const uint64_t *mt;   // transposed mask row (kMaskBits)
+  const uint64_t *many; // its per-chunk "allows anything" words
   const char *mrow;     // float mask row (kMaskF32)
   static constexpr int EPV = ElemTraits<DT>::EPV;
 
@@ -464,48 +586,12 @@ struct RowView {
   }
 };
 
-// Walk vectors [i_lo, i_hi) of chunk c in vocabulary order at the fixed scale magicN until the running sum of q
-// passes T.  Returns the token (wave-uniform) or -1; T is updated (minus everything walked past).
-template <int DT, int MASK>
-__device__ __forceinline__ int32_t walk_vectors(const RowView<DT, MASK> &rv, int c, int i_lo, int i_hi, int lane,
-                                                float magicN, uint64_t &T) {
-  constexpr int EPV = ElemTraits<DT>::EPV;
-  for (int i = i_lo; i < i_hi; ++i) {
-    if (c * kChunk + i * 64 * EPV >= rv.V) return -1;
-    float y[EPV];
-    int e0;
-    rv.vec(c, i, lane, y, e0);
-    uint64_t q[EPV], s = 0;
-#pragma unroll
-    for (int k = 0; k < EPV; ++k) {
-      q[k] = term_q(y[k], magicN);
-      s += q[k];
-    }
-    const uint64_t incl = wave_scan_u64(s);
-    const int lsel = first_lane_above(incl, T);
-    if (lsel >= 0) {
-      uint64_t Tl = T - (incl - s);
-      int32_t tok = -1;
-#pragma unroll
-      for (int k = 0; k < EPV; ++k) {
-        if (tok < 0) {
-          if (Tl < q[k]) tok = e0 + k;
-          else Tl -= q[k];
-        }
-      }
-      return __builtin_amdgcn_readlane(tok, lsel);
-    }
-    T -= readlane_u64(incl, 63);
-  }
-  return -1;
-}
-
 // The in-chunk draw for a particle whose chunk is not in registers any more (two-launch path; members of a shared row
-// beyond the ones the reducing wave drew for): one wave reloads chunk c, redoes its sums at the recorded scale Ncs and
-// draws exactly as the reducing wave would have (same functions, same order).
+// beyond the ones the reducing wave drew for): one wave reloads chunk c and goes through exactly what the reducing wave
+// did - maximum, sums, low-mass rule, draw - with the same functions, so the result is the same.
 template <int DT, int MASK>
-__device__ __forceinline__ int32_t draw_chunk_reload(const RowView<DT, MASK> &rv, int c, int lane, float Ncs,
-                                                     uint64_t R2, float *s_tr) {
+__device__ __forceinline__ int32_t draw_chunk_reload(const RowView<DT, MASK> &rv, int c, int lane, uint64_t R2,
+                                                     float *s_tr) {
   constexpr int EPV = ElemTraits<DT>::EPV, NVC = ElemTraits<DT>::NVC;
   const int e_base = c * kChunk;
   int nv_valid = (rv.V - e_base + 64 * EPV - 1) / (64 * EPV);
@@ -516,58 +602,26 @@ __device__ __forceinline__ int32_t draw_chunk_reload(const RowView<DT, MASK> &rv
   if constexpr (MASK == kMaskBits) {
     const uint64_t *mtc = rv.mt + (int64_t)c * 64;
     const uint64_t mw = mtc[lane];
-    chunk_sums<DT, true>(x, kMagic - Ncs, nv_valid, as_const(mtc), pA, pB, pAm, pBm);
-    return chunk_candidate<DT, true>(x, kMagic - Ncs, e_base, lane, pAm, pBm, mw, R2, s_tr);
+    MaskAhead ma;
+    mask_ahead<DT>(as_const(mtc), ma);
+    const float Nc = exp_n(chunk_max(x));
+    float Nm;
+    bool redone;
+    chunk_reduce_bits<DT>(x, Nc, nv_valid, as_const(mtc), ma, as_const(rv.many)[c], lane, pA, pB, pAm, pBm, Nm,
+                          redone);
+    if (redone) return chunk_candidate<DT, false>(x, kMagic - Nm, e_base, lane, pAm, pBm, 0ull, R2, s_tr);
+    return chunk_candidate<DT, true>(x, kMagic - Nc, e_base, lane, pAm, pBm, mw, R2, s_tr);
   } else if constexpr (MASK == kMaskF32) {
     float y[64];
     add_float_mask<DT>(x, rv.mrow, e_base, rv.V, lane, y);
-    chunk_sums<DT, false>(y, kMagic - Ncs, nv_valid, nullptr, pA, pB, pAm, pBm);
-    return chunk_candidate<DT, false>(y, kMagic - Ncs, e_base, lane, pA, pB, 0ull, R2, s_tr);
+    const float Nm = exp_n(chunk_max(y));
+    chunk_sums<DT, false>(y, kMagic - Nm, nv_valid, nullptr, MaskAhead{}, pA, pB, pAm, pBm);
+    return chunk_candidate<DT, false>(y, kMagic - Nm, e_base, lane, pA, pB, 0ull, R2, s_tr);
   } else {
-    chunk_sums<DT, false>(x, kMagic - Ncs, nv_valid, nullptr, pA, pB, pAm, pBm);
-    return chunk_candidate<DT, false>(x, kMagic - Ncs, e_base, lane, pA, pB, 0ull, R2, s_tr);
+    const float Nc = exp_n(chunk_max(x));
+    chunk_sums<DT, false>(x, kMagic - Nc, nv_valid, nullptr, MaskAhead{}, pA, pB, pAm, pBm);
+    return chunk_candidate<DT, false>(x, kMagic - Nc, e_base, lane, pA, pB, 0ull, R2, s_tr);
   }
-}
-
-// masked maximum / sum of the whole row at a given scale (own-scale redo; rare)
-template <int DT, int MASK>
-__device__ __forceinline__ float row_masked_max(const RowView<DT, MASK> &rv, int nch, int lane) {
-  constexpr int EPV = ElemTraits<DT>::EPV, NVC = ElemTraits<DT>::NVC;
-  float m = kNegInf;
-  for (int c = 0; c < nch; ++c)
-    for (int i = 0; i < NVC; ++i) {
-      if (c * kChunk + i * 64 * EPV >= rv.V) break;
-      float y[EPV];
-      int e0;
-      rv.vec(c, i, lane, y, e0);
-#pragma unroll
-      for (int k = 0; k < EPV; ++k) m = fmaxf(m, y[k]);
-    }
-  return wave_max(m);
-}
-template <int DT, int MASK>
-__device__ __forceinline__ uint64_t row_masked_sum(const RowView<DT, MASK> &rv, int nch, int lane, float magicN) {
-  constexpr int EPV = ElemTraits<DT>::EPV, NVC = ElemTraits<DT>::NVC;
-  uint64_t s = 0;
-  for (int c = 0; c < nch; ++c)
-    for (int i = 0; i < NVC; ++i) {
-      if (c * kChunk + i * 64 * EPV >= rv.V) break;
-      float y[EPV];
-      int e0;
-      rv.vec(c, i, lane, y, e0);
-#pragma unroll
-      for (int k = 0; k < EPV; ++k) s += term_q(y[k], magicN);
-    }
-  return wave_sum_u64(s);
-}
-
-// one element of the row, scaled (sparse-mask path)
-template <int DT>
-__device__ __forceinline__ float load_elem(const char *rowp, int j) {
-  if constexpr (DT == kDtF32) return *reinterpret_cast<const float *>(rowp + (int64_t)j * 4);
-  const uint32_t h = *reinterpret_cast<const uint16_t *>(rowp + (int64_t)j * 2);
-  if constexpr (DT == kDtBf16) return __uint_as_float(h << 16);
-  return (float)__builtin_bit_cast(_Float16, (uint16_t)h);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -579,8 +633,8 @@ struct RecsGlobal {
   const ChunkRec *r;
   __device__ __forceinline__ ChunkRec get(int c) const { return r[c]; }
 };
-struct RecsLds {  // words: Nc, pA, pB, pAm, pBm (no float masks on this path)
-  const uint32_t (*s)[5];
+struct RecsLds {  // words: Nc, pA, pB, pAm, pBm, Nm
+  const uint32_t (*s)[6];
   __device__ __forceinline__ ChunkRec get(int c) const {
     ChunkRec r;
     r.Nc = __uint_as_float(s[c][0]);
@@ -588,7 +642,7 @@ struct RecsLds {  // words: Nc, pA, pB, pAm, pBm (no float masks on this path)
     r.pB = s[c][2];
     r.pAm = s[c][3];
     r.pBm = s[c][4];
-    r.Nm = r.Nc;
+    r.Nm = __uint_as_float(s[c][5]);
     return r;
   }
 };
@@ -596,27 +650,22 @@ struct RecsLds {  // words: Nc, pA, pB, pAm, pBm (no float masks on this path)
 struct PairState {
   float N_all, N_msk;     // row scales (all / allowed)
   uint64_t S_all, S_msk;  // sums on them
-  bool own;               // bit masks: allowed sum redone on its own scale
-  int sparse_n;           // >= 0: the mask allows that many (<= 63) tokens, listed in mask_info
-  float x_sp;             // sparse path: this lane's allowed logit
-  int j_sp;
 };
 
-// fold the chunk records: row scales, then the sums shifted onto them; then the low-mass rule for bit masks
-template <int DT, int MASK, class Recs>
-__device__ __forceinline__ void pair_fold(const StepParams &p, const Recs &recs, const RowView<DT, MASK> &rv, int mi,
-                                          int nch, int lane, PairState &st) {
+// fold the chunk records: row scales (the largest chunk scale among non-empty chunks), then the sums shifted onto them
+template <int MASK, class Recs>
+__device__ __forceinline__ void pair_fold(const Recs &recs, int nch, int lane, PairState &st) {
   float N_all = kNegInf, N_msk = kNegInf;
   for (int c0 = 0; c0 < nch; c0 += 64) {
     const int c = c0 + lane;
     if (c < nch) {
       const ChunkRec r = recs.get(c);
       if (r.pA | r.pB) N_all = fmaxf(N_all, r.Nc);
-      if (r.pAm | r.pBm) N_msk = fmaxf(N_msk, MASK == kMaskF32 ? r.Nm : r.Nc);
+      if (r.pAm | r.pBm) N_msk = fmaxf(N_msk, r.Nm);
     }
   }
   N_all = wave_max(N_all);
-  N_msk = MASK == kMaskF32 ? wave_max(N_msk) : N_all;  // bit masks: allowed terms sit on the row's scale
+  N_msk = MASK == kMaskNone ? N_all : wave_max(N_msk);
   uint64_t S_all = 0, S_msk = 0;
   for (int c0 = 0; c0 < nch; c0 += 64) {
     const int c = c0 + lane;
@@ -629,7 +678,7 @@ __device__ __forceinline__ void pair_fold(const StepParams &p, const Recs &recs,
         sa = d < 64.0f ? a >> (uint32_t)d : 0ull;
       }
       if (m) {
-        const float d = N_msk - (MASK == kMaskF32 ? r.Nm : r.Nc);
+        const float d = N_msk - r.Nm;
         sm = d < 64.0f ? m >> (uint32_t)d : 0ull;
       }
     }
@@ -637,39 +686,6 @@ __device__ __forceinline__ void pair_fold(const StepParams &p, const Recs &recs,
     if constexpr (MASK != kMaskNone) S_msk += wave_sum_u64(sm);
   }
   if constexpr (MASK == kMaskNone) S_msk = S_all;
-  st.own = false;
-  st.sparse_n = -1;
-  st.x_sp = kNegInf;
-  st.j_sp = -1;
-  // bit masks: allowed mass below 2^-4 of the row's largest term -> masked sum on its own scale
-  if constexpr (MASK == kMaskBits) {
-    uint32_t top = (uint32_t)(S_msk >> kLowMassBits);
-    opaque_u32(top);
-    if (top == 0u) {
-      st.own = true;
-      const int32_t *info = p.mask_info + (int64_t)mi * kInfoWords;
-      const int cnt = info[0];
-      float mk;
-      if (cnt <= kInfoWords - 1) {
-        st.sparse_n = cnt;
-        if (lane < cnt) {
-          st.j_sp = info[1 + lane];
-          st.x_sp = load_elem<DT>(rv.rowp, st.j_sp) * p.scale;
-        }
-        mk = wave_max(st.x_sp);
-      } else {
-        mk = row_masked_max(rv, nch, lane);
-      }
-      N_msk = exp_n(mk);
-      if (!(mk > kNegInf)) {
-        S_msk = 0;
-      } else if (st.sparse_n >= 0) {
-        S_msk = wave_sum_u64(lane < st.sparse_n ? term_q(st.x_sp, kMagic - N_msk) : 0ull);
-      } else {
-        S_msk = row_masked_sum(rv, nch, lane, kMagic - N_msk);
-      }
-    }
-  }
   st.N_all = N_all;
   st.N_msk = N_msk;
   st.S_all = S_all;
@@ -684,59 +700,39 @@ __device__ __forceinline__ void pair_logs(const PairState &st, float &lse, float
   logZ = (float)(lse_msk - lse_all);
 }
 
-// The Philox draw of particle pidx.  Own-scale rows: one inverse CDF over the whole row in vocabulary order with the
-// first draw.  Otherwise two stages: the chunk by a scan of the shifted chunk sums (first draw); inside the chunk the
-// second draw - taken from `cand` (per-chunk results the reducing wave left behind, row kernel) or, when cand is
-// null, recomputed from a reload of that chunk.
+// The Philox draw of particle pidx, two stages: the chunk by a scan of the shifted chunk sums (first draw); inside the
+// chunk the second draw - taken from `cand` (per-chunk results the reducing wave left behind, row kernel) or, when
+// cand is null, recomputed from a reload of that chunk.
 template <int DT, int MASK, class Recs>
 __device__ __forceinline__ int32_t pair_draw_philox(const StepParams &p, const Recs &recs, const RowView<DT, MASK> &rv,
                                                     const PairState &st, int pidx, int nch, int lane,
                                                     const int32_t *cand, float *s_tr) {
-  constexpr int NVC = ElemTraits<DT>::NVC;
   uint32_t nz = (uint32_t)st.S_msk | (uint32_t)(st.S_msk >> 32);
   opaque_u32(nz);
   if (nz == 0u) return -1;
   uint64_t R1, R2;
   philox_pair(p, pidx, R1, R2);
   uint64_t T = __umul64hi(R1, st.S_msk);  // uniform integer in [0, S_msk)
-  if (st.own) {
-    if (st.sparse_n >= 0) {
-      const uint64_t q = lane < st.sparse_n ? term_q(st.x_sp, kMagic - st.N_msk) : 0ull;
-      const uint64_t incl = wave_scan_u64(q);
-      const int lsel = first_lane_above(incl, T);
-      return __builtin_amdgcn_readlane(st.j_sp, lsel < 0 ? 0 : lsel);
-    }
-    int32_t tok = -1;
-    for (int c = 0; c < nch && tok < 0; ++c) tok = walk_vectors(rv, c, 0, NVC, lane, kMagic - st.N_msk, T);
-    return tok;
-  }
   int csel = -1;
-  float Ncs = 0.f;
   for (int c0 = 0; c0 < nch && csel < 0; c0 += 64) {
     const int c = c0 + lane;
     uint64_t sm = 0;
-    float Nc = kNegInf;
     if (c < nch) {
       const ChunkRec r = recs.get(c);
       const uint64_t m = ((uint64_t)r.pAm << kGridHi) + r.pBm;
-      Nc = MASK == kMaskF32 ? r.Nm : r.Nc;
       if (m) {
-        const float d = st.N_msk - Nc;
+        const float d = st.N_msk - r.Nm;
         if (d < 64.0f) sm = m >> (uint32_t)d;
       }
     }
     const uint64_t incl = wave_scan_u64(sm);
     const int lsel = first_lane_above(incl, T);
-    if (lsel >= 0) {
-      csel = c0 + lsel;
-      Ncs = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(Nc), lsel));
-    } else {
-      T -= readlane_u64(incl, 63);
-    }
+    if (lsel >= 0) csel = c0 + lsel;
+    else T -= readlane_u64(incl, 63);
   }
   if (csel < 0) return -1;  // consistent sums rule this out
   if (cand) return cand[csel];
-  return draw_chunk_reload(rv, csel, lane, Ncs, R2, s_tr);
+  return draw_chunk_reload(rv, csel, lane, R2, s_tr);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -763,10 +759,11 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
   rv.V = V;
   rv.scale = p.scale;
   rv.mt = MASK == kMaskBits ? p.mask_t + (int64_t)mi * nch * 64 : nullptr;
+  rv.many = MASK == kMaskBits ? p.mask_any + (int64_t)mi * nch : nullptr;
   rv.mrow = MASK == kMaskF32 ? (const char *)(p.mask_f + (int64_t)mi * p.mask_ld) : nullptr;
 
   PairState st;
-  pair_fold<DT, MASK>(p, recs, rv, mi, nch, lane, st);
+  pair_fold<MASK>(recs, nch, lane, st);
   if (wave == 0 && lane == 0) {
     float lse, logZ;
     pair_logs(st, lse, logZ);
@@ -858,7 +855,7 @@ template <int DT, int MASK, bool SCALED, int MODE>
 __global__ __launch_bounds__(1024) void row_step_kernel(const StepParams p) {
   constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC;
   static_assert(MASK != kMaskF32 && MODE != kModeNoise, "float masks / parity mode take the two-launch path");
-  __shared__ uint32_t s_rec[kFusedMaxChunks][5];
+  __shared__ uint32_t s_rec[kFusedMaxChunks][6];
   __shared__ int32_t s_cand[kFusedCap][kFusedMaxChunks];
   __shared__ __attribute__((aligned(16))) float s_tr[16][64];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -889,32 +886,37 @@ __global__ __launch_bounds__(1024) void row_step_kernel(const StepParams p) {
     const int e_base = c * kChunk;
     int nv_valid = (V - e_base + 64 * EPV - 1) / (64 * EPV);
     nv_valid = nv_valid < NVC ? nv_valid : NVC;
-    uint64_t mw = 0;
+    uint64_t mw = 0, allows_any = 0;
+    MaskAhead ma{};
+    cu64_t mt = nullptr;
     if constexpr (MASK == kMaskBits) {
       if (ncand) mw = (p.mask_t + ((int64_t)mi * nch + c) * 64)[lane];
+      mt = as_const(p.mask_t + ((int64_t)mi * nch + c) * 64);
+      mask_ahead<DT>(mt, ma);
+      allows_any = as_const(p.mask_any)[(int64_t)mi * nch + c];
     }
     float x[64];
     load_chunk<DT, SCALED>(rowp, e_base, V, lane, p.scale, x);
     const float Nc = exp_n(chunk_max(x));
     uint32_t pA, pB, pAm, pBm;
-    if constexpr (MASK == kMaskBits) {
-      const cu64_t mt = as_const(p.mask_t + ((int64_t)mi * nch + c) * 64);
-      chunk_sums<DT, true>(x, kMagic - Nc, nv_valid, mt, pA, pB, pAm, pBm);
-    } else {
-      chunk_sums<DT, false>(x, kMagic - Nc, nv_valid, nullptr, pA, pB, pAm, pBm);
-    }
+    float Nm = Nc;
+    bool redone = false;
+    if constexpr (MASK == kMaskBits) chunk_reduce_bits<DT>(x, Nc, nv_valid, mt, ma, allows_any, lane, pA, pB, pAm, pBm, Nm, redone);
+    else chunk_sums<DT, false>(x, kMagic - Nc, nv_valid, nullptr, ma, pA, pB, pAm, pBm);
     if (lane == 63) {
       s_rec[c][0] = __float_as_uint(Nc);
       s_rec[c][1] = pA;
       s_rec[c][2] = pB;
       s_rec[c][3] = pAm;
       s_rec[c][4] = pBm;
+      s_rec[c][5] = __float_as_uint(Nm);
     }
+    if (redone) mw = ~0ull;  // x holds the masked chunk now: every finite element counts
 #pragma unroll
     for (int m = 0; m < kFusedCap; ++m) {
       if (m < ncand) {
         const int32_t tok =
-            chunk_candidate<DT, MASK == kMaskBits>(x, kMagic - Nc, e_base, lane, pAm, pBm, mw, R2s[m], s_tr[wave]);
+            chunk_candidate<DT, MASK == kMaskBits>(x, kMagic - Nm, e_base, lane, pAm, pBm, mw, R2s[m], s_tr[wave]);
         if (lane == 0) s_cand[m][c] = tok;
       }
     }
@@ -927,10 +929,11 @@ __global__ __launch_bounds__(1024) void row_step_kernel(const StepParams p) {
   rv.V = V;
   rv.scale = p.scale;
   rv.mt = MASK == kMaskBits ? p.mask_t + (int64_t)mi * nch * 64 : nullptr;
+  rv.many = MASK == kMaskBits ? p.mask_any + (int64_t)mi * nch : nullptr;
   rv.mrow = nullptr;
   const RecsLds recs{s_rec};
   PairState st;
-  pair_fold<DT, MASK>(p, recs, rv, mi, nch, lane, st);
+  pair_fold<MASK>(recs, nch, lane, st);
   float lse = 0.f, logZ = 0.f;
   if (lane == 0) pair_logs(st, lse, logZ);
   for (int m = wave; m < cnt; m += W) {
@@ -1006,7 +1009,7 @@ __global__ __launch_bounds__(1024) void logprob_rows_fused_kernel(const void *lo
     load_chunk<DT, SCALED>(rowp, e_base, V, lane, scale, x);
     const float Nc = exp_n(chunk_max(x));
     uint32_t pA, pB, pAm, pBm;
-    chunk_sums<DT, false>(x, kMagic - Nc, nv_valid, nullptr, pA, pB, pAm, pBm);
+    chunk_sums<DT, false>(x, kMagic - Nc, nv_valid, nullptr, MaskAhead{}, pA, pB, pAm, pBm);
     if (lane == 63) {
       s_rec[c] = ((uint64_t)pA << kGridHi) + pB;
       s_N[c] = Nc;
@@ -1073,82 +1076,32 @@ __global__ __launch_bounds__(1024) void logprob_rows_fused_kernel(const void *lo
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// mask preparation: bit rows [n_masks, mask_ld] -> transposed lane words + sparse-id lists.
-// Block (k, c) with c < nch transposes chunk c of mask k; block (k, nch) counts mask k and lists its ids.
+// mask preparation: bit rows [n_masks, mask_ld] -> transposed lane words.  Block (c, k) transposes chunk c of mask k.
 // ---------------------------------------------------------------------------------------------------------
 template <int EPV>
 __global__ __launch_bounds__(256) void mask_prepare_kernel(const uint32_t *bits, int64_t mask_ld, int V, int nch,
-                                                          uint64_t *mask_t, int32_t *mask_info) {
+                                                          uint64_t *mask_t, uint64_t *mask_any) {
+  __shared__ uint64_t s_any[4];
   const int k = blockIdx.y, c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t *row = bits + (int64_t)k * mask_ld;
-  if (c < nch) {
-    uint64_t *dst = mask_t + ((int64_t)k * nch + c) * 64;
-    bool on[16];
+  uint64_t *dst = mask_t + ((int64_t)k * nch + c) * 64;
+  bool on[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {  // word w = wave + 4j = vector (w / EPV), component (w % EPV); loads first
-      const int w = wave + 4 * j, i = w / EPV, kk = w % EPV;
-      const int e = c * kChunk + (i * 64 + lane) * EPV + kk;
-      on[j] = e < V && ((row[e < V ? e >> 5 : 0] >> (e & 31)) & 1u);
-    }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const uint64_t m = __ballot(on[j]);
-      if (lane == 0) dst[wave + 4 * j] = m;
-    }
-    return;
+  for (int j = 0; j < 16; ++j) {  // word w = wave + 4j = vector (w / EPV), component (w % EPV); loads first
+    const int w = wave + 4 * j, i = w / EPV, kk = w % EPV;
+    const int e = c * kChunk + (i * 64 + lane) * EPV + kk;
+    on[j] = e < V && ((row[e < V ? e >> 5 : 0] >> (e & 31)) & 1u);
   }
-  // count + ordered id list (ids only matter when the count is at most kInfoWords - 1).  All words of the row are
-  // requested before the first is used (one memory latency, not one per 256-word tile).
-  __shared__ int s_cnt[4];
-  int32_t *info = mask_info + (int64_t)k * kInfoWords;
-  const int nw = (V + 31) >> 5;
-  constexpr int kTile = 16;  // words per thread per sweep: 4096 words = 131072 tokens in one sweep
-  int base = 0;
-  for (int w0 = 0; w0 < nw; w0 += 256 * kTile) {
-    uint32_t word[kTile];
-    int pc = 0;
+  uint64_t any = 0;
 #pragma unroll
-    for (int j = 0; j < kTile; ++j) {  // thread t owns the contiguous words w0 + t*kTile .. + kTile - 1
-      const int w = w0 + tid * kTile + j;
-      uint32_t v = w < nw ? row[w] : 0u;
-      const int rem = V - w * 32;
-      if (w < nw && rem < 32) v &= (1u << rem) - 1u;
-      word[j] = v;
-      pc += __popc(v);
-    }
-    int incl = pc;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int t = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += t;
-    }
-    if (lane == 63) s_cnt[wave] = incl;
-    __syncthreads();
-    int wb = 0, tot = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (q < wave) wb += s_cnt[q];
-      tot += s_cnt[q];
-    }
-    int at = base + wb + incl - pc;
-    // single-sweep masks (V <= 131072): the total is known here, dense masks skip the id walk altogether
-    const bool may_list = nw > 256 * kTile || tot <= kInfoWords - 1;
-    if (may_list && at < kInfoWords - 1) {
-#pragma unroll
-      for (int j = 0; j < kTile; ++j) {
-        uint32_t v = word[j];
-        while (v && at < kInfoWords - 1) {
-          const int bpos = __ffs(v) - 1;
-          v &= v - 1;
-          if (at < kInfoWords - 1) info[1 + at] = (w0 + tid * kTile + j) * 32 + bpos;
-          ++at;
-        }
-      }
-    }
-    base += tot;
-    __syncthreads();
+  for (int j = 0; j < 16; ++j) {
+    const uint64_t m = __ballot(on[j]);
+    any |= m;
+    if (lane == 0) dst[wave + 4 * j] = m;
   }
-  if (tid == 0) info[0] = base;
+  if (lane == 0) s_any[wave] = any;
+  __syncthreads();
+  if (tid == 0) mask_any[(int64_t)k * nch + c] = (s_any[0] | s_any[1] | s_any[2] | s_any[3]) ? 1ull : 0ull;
 }
 
 }  // namespace glb

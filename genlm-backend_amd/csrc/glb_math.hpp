@@ -247,7 +247,7 @@ __device__ __forceinline__ void rtz_acc4(float t0, float t1, float t2, float t3,
   float x0, x1, d0, d1, l0, l1;
   if constexpr (MASKED) {
     float d2, d3, l2, l3;
-    asm volatile(
+    asm(
         "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
         "v_add_f32 %8, %0, %18\n\t"
         "v_add_f32 %9, %2, %19\n\t"
@@ -283,7 +283,7 @@ __device__ __forceinline__ void rtz_acc4(float t0, float t1, float t2, float t3,
           "=&v"(d0), "=&v"(d1), "=&v"(l0), "=&v"(l1), "=&v"(d2), "=&v"(d3), "=&v"(l2), "=&v"(l3)
         : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "s"(M0), "s"(M1), "s"(M2), "s"(M3));
   } else {
-    asm volatile(
+    asm(
         "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
         "v_add_f32 %4, %0, %10\n\t"
         "v_add_f32 %5, %2, %11\n\t"

@@ -153,8 +153,7 @@ int glb_row_members(const int32_t *row_of, int64_t n_particles, int64_t n_rows, 
 
 /*
  * Bring GLB_MASK_BITS rows into the layout the kernels read ([mask][chunk][vector][component] 64-bit lane
- * words + a short id list for masks that allow at most 63 tokens, e.g. the README's EOS-only mask,
- * README.md:62-66) once, for masks that do not change between steps.  `dtype` is the element type of the
+ * words) once, for masks that do not change between steps (the two README masks, README.md:57-70).  `dtype` is the element type of the
  * logits the masks will be used with (the lane layout differs between 4- and 2-byte elements).  Pass the
  * result as `mask` with mask_kind = GLB_MASK_PREPARED and the same n_masks / vocab.
  */

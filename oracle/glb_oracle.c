@@ -244,15 +244,35 @@ static int64_t glb_chunk_stats(const float *y, int64_t V, chunk_stat *out) {
   return nch;
 }
 
-/* bit-masked sums on the chunk scales of x: same terms, allowed elements only */
-static void glb_chunk_masked(const float *x, const uint32_t *mb, int64_t V, const chunk_stat *cs, uint64_t *Sm) {
+/* bit-masked chunk sums: the same terms as the unmasked sum (chunk scale of x, so one exponential per element serves
+ * both), allowed elements only - unless that leaves the sum of a chunk that allows anything at all below 2^32 (allowed
+ * mass under about 2^-3.5 of the chunk's largest term): such a chunk sums its allowed values again on their own
+ * maximum's scale.  out[c] = the
+ * (scale, sum) of the allowed part of chunk c. */
+static void glb_chunk_masked(const float *x, const uint32_t *mb, int64_t V, const chunk_stat *cs, chunk_stat *out) {
   int64_t nch = (V + GLB_CHUNK - 1) / GLB_CHUNK;
   for (int64_t c = 0; c < nch; ++c) {
     int64_t lo = c * GLB_CHUNK, hi = lo + GLB_CHUNK < V ? lo + GLB_CHUNK : V;
     float magicN = GLB_MAGIC - cs[c].N;
-    Sm[c] = 0;
+    uint64_t S = 0;
+    int any = 0;
     for (int64_t j = lo; j < hi; ++j)
-      if (mask_allows(mb, j)) Sm[c] += glb_term_q(x[j], magicN);
+      if (mask_allows(mb, j)) {
+        S += glb_term_q(x[j], magicN);
+        any = 1;
+      }
+    out[c].N = cs[c].N;
+    if (any && (S >> GLB_LOW_MASS_BITS) == 0) {
+      float mk = -INFINITY;
+      for (int64_t j = lo; j < hi; ++j)
+        if (mask_allows(mb, j) && x[j] > mk) mk = x[j];
+      out[c].N = glb_exp_n(mk);
+      magicN = GLB_MAGIC - out[c].N;
+      S = 0;
+      for (int64_t j = lo; j < hi; ++j)
+        if (mask_allows(mb, j)) S += glb_term_q(x[j], magicN);
+    }
+    out[c].S = S;
   }
 }
 
@@ -274,11 +294,10 @@ int orc_step(const void *logits, int dtype, int64_t n_rows, int64_t V, int64_t l
   float *y = (float *)malloc(sizeof(float) * (size_t)V);
   chunk_stat *ca = (chunk_stat *)malloc(sizeof(chunk_stat) * (size_t)nch);
   chunk_stat *cm = (chunk_stat *)malloc(sizeof(chunk_stat) * (size_t)nch);
-  uint64_t *Sm = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)nch);
-  if (!x || !y || !ca || !cm || !Sm) return 4;
+  if (!x || !y || !ca || !cm) return 4;
   for (int64_t i = 0; i < n_particles; ++i) {
     int64_t r = row_of ? row_of[i] : i;
-    if (r < 0 || r >= n_rows) { free(x); free(y); free(ca); free(cm); free(Sm); return 1; }
+    if (r < 0 || r >= n_rows) { free(x); free(y); free(ca); free(cm); return 1; }
     int64_t mi = 0;
     if (mask_kind != ORC_MASK_NONE) mi = mask_id ? mask_id[i] : (n_masks == 1 ? 0 : i);
     const uint32_t *mb = mask_kind == ORC_MASK_BITS ? (const uint32_t *)mask + mi * mask_ld : NULL;
@@ -300,41 +319,21 @@ int orc_step(const void *logits, int dtype, int64_t n_rows, int64_t V, int64_t l
     uint64_t S_all = 0;
     for (int64_t c = 0; c < nch; ++c)
       if (ca[c].S) S_all += shr_sat(ca[c].S, N_all - ca[c].N);
-    /* ---- allowed elements.  Bit masks: the same terms on the chunk scales of x (so one exponential per element
-     * serves both sums), unless that leaves the row-level sum below 2^32 (allowed mass under about 2^-4 of the
-     * row's largest term): then the masked values are summed on the masked maximum's own row scale.  Float
-     * masks: y = x + m has chunk scales of its own.  cm[c] holds the masked chunk (scale, sum) either way. */
+    /* ---- allowed elements: cm[c] = (scale, sum) of the allowed part of chunk c - bit masks: glb_chunk_masked; float
+     * masks: y = x + m has chunk scales of its own; no mask: the chunk itself.  Row level as for the full sum. */
     float N_msk = N_all;
     uint64_t S_msk = S_all;
-    int own = 0;
-    if (mb) {
-      glb_chunk_masked(x, mb, V, ca, Sm);
-      S_msk = 0;
-      for (int64_t c = 0; c < nch; ++c) {
-        cm[c].N = ca[c].N;
-        cm[c].S = Sm[c];
-        if (Sm[c]) S_msk += shr_sat(Sm[c], N_all - ca[c].N);
-      }
-      if ((S_msk >> GLB_LOW_MASS_BITS) == 0) {
-        own = 1;
-        float mk = -INFINITY;
-        for (int64_t j = 0; j < V; ++j)
-          if (y[j] > mk) mk = y[j];
-        N_msk = glb_exp_n(mk);
-        S_msk = 0;
-        if (mk > -INFINITY)
-          for (int64_t j = 0; j < V; ++j) S_msk += glb_term_q(y[j], GLB_MAGIC - N_msk);
-      }
-    } else if (mf) {
-      glb_chunk_stats(y, V, cm);
+    if (mb) glb_chunk_masked(x, mb, V, ca, cm);
+    else if (mf) glb_chunk_stats(y, V, cm);
+    else
+      for (int64_t c = 0; c < nch; ++c) cm[c] = ca[c];
+    if (mb || mf) {
       N_msk = -INFINITY;
       for (int64_t c = 0; c < nch; ++c)
         if (cm[c].S && cm[c].N > N_msk) N_msk = cm[c].N;
       S_msk = 0;
       for (int64_t c = 0; c < nch; ++c)
         if (cm[c].S) S_msk += shr_sat(cm[c].S, N_msk - cm[c].N);
-    } else {
-      for (int64_t c = 0; c < nch; ++c) cm[c] = ca[c];
     }
     double lse_all = S_all ? glb_log_fix(S_all, (int32_t)N_all + 1 - GLB_FRAC) : -INFINITY;
     double lse_mask = S_msk ? glb_log_fix(S_msk, (int32_t)N_msk + 1 - GLB_FRAC) : -INFINITY;
@@ -352,13 +351,7 @@ int orc_step(const void *logits, int dtype, int64_t n_rows, int64_t V, int64_t l
         uint64_t R = ((uint64_t)rnd[1] << 32) | rnd[0];
         uint64_t R2 = ((uint64_t)rnd[3] << 32) | rnd[2];
         uint64_t T = mulhi64(R, S_msk); /* uniform integer in [0, S_msk) */
-        if (own) { /* one scale for the whole row: plain inverse CDF in vocabulary order */
-          uint64_t c = 0;
-          for (int64_t j = 0; j < V; ++j) {
-            c += glb_term_q(y[j], GLB_MAGIC - N_msk);
-            if (c > T) { tok = (int32_t)j; break; }
-          }
-        } else {
+        {
           /* two stages, two independent 64-bit draws: the chunk by the shifted chunk sums (first draw), then inside
            * the chunk an inverse CDF on the chunk's own scale against its unshifted sum (second draw).  The order
            * inside a chunk is the order the kernel holds it in: lane l of the wave owns elements
@@ -400,7 +393,7 @@ int orc_step(const void *logits, int dtype, int64_t n_rows, int64_t V, int64_t l
     }
     out_token[i] = tok;
   }
-  free(x); free(y); free(ca); free(cm); free(Sm);
+  free(x); free(y); free(ca); free(cm);
   return 0;
 }
 
