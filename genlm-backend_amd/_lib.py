@@ -49,10 +49,9 @@ class StepArgs(C.Structure):
         ("out_lse", C.c_void_p),
         ("out_token", C.c_void_p),
         ("out_margin", C.c_void_p),
-        ("path", C.c_int32),
+        ("reserved", C.c_int32),
         ("row_members_start", C.c_void_p),
         ("row_members", C.c_void_p),
-        ("row_members_max", C.c_int32),
         ("workspace", C.c_void_p),
         ("workspace_bytes", C.c_size_t),
     ]

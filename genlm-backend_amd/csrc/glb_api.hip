@@ -16,10 +16,8 @@
 namespace glb {
 // launchers exported by the three glb_chunk_tu.hip translation units (one per element type)
 #define GLB_DECL(dt)                                                                                              \
-  hipError_t launch_stats_##dt(const StepParams &p, int mask_kind, bool scaled, hipStream_t s);                   \
+  hipError_t launch_stats_##dt(const StepParams &p, int mask_kind, bool scaled, bool draw, hipStream_t s);        \
   hipError_t launch_finish_##dt(const StepParams &p, int mask_kind, int mode, hipStream_t s);                     \
-  hipError_t launch_row_step_##dt(const StepParams &p, int mask_kind, int mode, bool scaled, int waves,           \
-                                  hipStream_t s);                                                                  \
   hipError_t launch_logprob_rows_##dt(const void *logits, int64_t ld, int V, float scale, const float *lse,       \
                                       float *out, int64_t out_ld, int n_rows, hipStream_t s);                      \
   hipError_t launch_logprob_fused_##dt(const void *logits, int64_t ld, int V, int nch, float scale, float *out,   \
@@ -46,11 +44,11 @@ int hip_fail(hipError_t e, const char *what) {
   return fail(GLB_EHIP, "%s: %s", what, hipGetErrorString(e));
 }
 
-hipError_t launch_stats(int dtype, const glb::StepParams &p, int mask_kind, bool scaled, hipStream_t s) {
+hipError_t launch_stats(int dtype, const glb::StepParams &p, int mask_kind, bool scaled, bool draw, hipStream_t s) {
   switch (dtype) {
-    case 0: return glb::launch_stats_0(p, mask_kind, scaled, s);
-    case 1: return glb::launch_stats_1(p, mask_kind, scaled, s);
-    case 2: return glb::launch_stats_2(p, mask_kind, scaled, s);
+    case 0: return glb::launch_stats_0(p, mask_kind, scaled, draw, s);
+    case 1: return glb::launch_stats_1(p, mask_kind, scaled, draw, s);
+    case 2: return glb::launch_stats_2(p, mask_kind, scaled, draw, s);
   }
   return hipErrorInvalidValue;
 }
@@ -64,16 +62,6 @@ hipError_t launch_finish(int dtype, const glb::StepParams &p, int mask_kind, int
   return hipErrorInvalidValue;
 }
 
-hipError_t launch_row_step(int dtype, const glb::StepParams &p, int mask_kind, int mode, bool scaled, int waves,
-                           hipStream_t s) {
-  switch (dtype) {
-    case 0: return glb::launch_row_step_0(p, mask_kind, mode, scaled, waves, s);
-    case 1: return glb::launch_row_step_1(p, mask_kind, mode, scaled, waves, s);
-    case 2: return glb::launch_row_step_2(p, mask_kind, mode, scaled, waves, s);
-  }
-  return hipErrorInvalidValue;
-}
-
 inline int64_t n_chunks(int64_t vocab) { return (vocab + glb::kChunk - 1) / glb::kChunk; }
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 // prepared masks: transposed lane words, then one "allows anything" word per (mask, chunk)
@@ -82,6 +70,17 @@ inline size_t prepared_words_bytes(int64_t n_masks, int64_t vocab) {
 }
 inline size_t prepared_bytes(int64_t n_masks, int64_t vocab) {
   return prepared_words_bytes(n_masks, vocab) + align256((size_t)n_masks * (size_t)n_chunks(vocab) * sizeof(uint64_t));
+}
+
+// step workspace: chunk records, in-chunk draws; then prepared masks
+inline size_t step_recs_bytes(int64_t units, int64_t vocab) {
+  return align256((size_t)units * (size_t)n_chunks(vocab) * sizeof(glb::ChunkRec));
+}
+inline size_t step_cands_bytes(int64_t units, int64_t vocab) {
+  return align256((size_t)units * (size_t)n_chunks(vocab) * glb::kDrawCap * sizeof(int32_t));
+}
+inline size_t step_fixed_bytes(int64_t units, int64_t vocab) {
+  return step_recs_bytes(units, vocab) + step_cands_bytes(units, vocab);
 }
 
 hipError_t launch_mask_prepare(const uint32_t *bits, int64_t n_masks, int64_t vocab, int64_t mask_ld, int dtype,
@@ -699,8 +698,7 @@ int glb_device_count(void) {
 size_t glb_step_workspace_bytes(int64_t n_particles, int64_t n_rows, int64_t vocab, int64_t n_masks) {
   if (n_particles <= 0 || vocab <= 0) return 0;
   const int64_t units = n_particles > n_rows ? n_particles : n_rows;
-  return align256((size_t)units * (size_t)n_chunks(vocab) * sizeof(glb::ChunkRec)) +
-         (n_masks > 0 ? prepared_bytes(n_masks, vocab) : 0) + 256;
+  return step_fixed_bytes(units, vocab) + (n_masks > 0 ? prepared_bytes(n_masks, vocab) : 0) + 256;
 }
 
 size_t glb_mask_prepared_bytes(int64_t n_masks, int64_t vocab) {
@@ -758,12 +756,11 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
   }
   if (a->rng_mode < GLB_RNG_NONE || a->rng_mode > GLB_RNG_NOISE)
     return fail(GLB_EINVAL, "bad rng_mode %d", a->rng_mode);
-  if (a->path < GLB_PATH_AUTO || a->path > GLB_PATH_ONE_LAUNCH) return fail(GLB_EINVAL, "bad path %d", a->path);
   if ((a->row_members_start == nullptr) != (a->row_members == nullptr))
     return fail(GLB_EINVAL, "row_members_start and row_members go together");
   if (a->row_members && (!a->row_of || !by_row))
     return fail(GLB_EINVAL, "row_members describes row_of of a per-row reduction (no per-particle mask ids)");
-  if (a->row_members_max < 0) return fail(GLB_EINVAL, "row_members_max is negative");
+  if (a->reserved != 0) return fail(GLB_EINVAL, "reserved must be 0");
   if (a->rng_mode == GLB_RNG_NOISE && (!a->noise || (a->noise_ld < a->vocab && a->noise_ld != 0)))
     return fail(GLB_EINVAL, "noise tensor missing or noise_ld < vocab (0 = one row shared by every particle)");
   if (a->rng_mode != GLB_RNG_NONE && !a->out_token)
@@ -772,8 +769,8 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
   if (!a->workspace) return fail(GLB_EINVAL, "workspace is null (glb_step_workspace_bytes)");
   if (((uintptr_t)a->workspace) % 32) return fail(GLB_EINVAL, "workspace not 32-byte aligned");
   const bool own_prep = a->mask_kind == GLB_MASK_BITS;
-  const size_t recs_bytes = align256((size_t)n_units * (size_t)n_chunks(a->vocab) * sizeof(glb::ChunkRec));
-  const size_t need_ws = recs_bytes + (own_prep ? prepared_bytes(a->n_masks, a->vocab) : 0);
+  const size_t fixed_bytes = step_fixed_bytes(n_units, a->vocab);
+  const size_t need_ws = fixed_bytes + (own_prep ? prepared_bytes(a->n_masks, a->vocab) : 0);
   if (a->workspace_bytes < need_ws)
     return fail(GLB_ENOSPC, "workspace %zu < %zu bytes", a->workspace_bytes, need_ws);
 
@@ -806,7 +803,7 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
     kmask = glb::kMaskBits;
     const char *prep = (const char *)a->mask;
     if (own_prep) {  // transposed form + sparse lists into the workspace, on the same stream
-      char *dst = (char *)a->workspace + recs_bytes;
+      char *dst = (char *)a->workspace + fixed_bytes;
       const hipError_t e = launch_mask_prepare((const uint32_t *)a->mask, a->n_masks, a->vocab, a->mask_ld, a->dtype, dst, s);
       if (e != hipSuccess) return hip_fail(e, "mask_prepare launch");
       prep = dst;
@@ -823,36 +820,20 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
   p.out_lse = a->out_lse;
   p.out_token = a->out_token;
   p.out_margin = a->rng_mode == GLB_RNG_NOISE ? a->out_margin : nullptr;
-  // One launch (a workgroup per reduction unit, records in LDS, in-chunk draws from the reducing wave's registers)
-  // when the unit -> particles direction is known and no unit carries more than a few particles; two launches
-  // (one wave per chunk, then one per particle) for everything else: float masks, parity mode, rows of more than 2^20
-  // elements, heavily shared rows (SIS step 0, freshly resampled populations), callers that give row_of only.
+  // The reducing waves make the in-chunk draws of each unit's first particles when they can know who those are: one
+  // particle per unit, or a per-row reduction whose fan-out map comes with its inverse (row_members).  Otherwise (and
+  // for launches too small to fill the chip, which take the four-waves-per-chunk kernel) every particle redoes its
+  // chunk in the second launch.
   const bool members_known = !by_row || !a->row_of || (a->row_members_start && a->row_members);
-  const bool few_members = !by_row || !a->row_of ||
-                           (a->row_members_max > 0 && a->row_members_max <= glb::kFusedCap);
-  const bool one_launch_ok = kmask != glb::kMaskF32 && a->rng_mode != GLB_RNG_NOISE &&
-                             p.nch <= glb::kFusedMaxChunks && members_known;
-  static const int env_path = [] { const char *e = getenv("GLB_PATH"); return e ? atoi(e) : 0; }();  // tuning aid
-  const int path = a->path != GLB_PATH_AUTO ? a->path : (env_path == 1 || (env_path == 2 && one_launch_ok) ? env_path : 0);
-  if (a->path == GLB_PATH_ONE_LAUNCH && !one_launch_ok)
-    return fail(GLB_EUNSUPPORTED, "one-launch path asked for, but the call has float masks / parity noise / rows over "
-                                  "2^20 elements / row_of without row_members");
-  if (path == GLB_PATH_ONE_LAUNCH || (path == GLB_PATH_AUTO && one_launch_ok && few_members)) {
+  const bool draw = a->rng_mode == GLB_RNG_PHILOX && members_known && (n_units * p.nch > 512 || kmask == glb::kMaskF32);
+  if (draw) {
+    p.cands = (int32_t *)((char *)a->workspace + step_recs_bytes(n_units, a->vocab));
     if (by_row && a->row_of) {
       p.mem_start = a->row_members_start;
       p.members = a->row_members;
     }
-    // waves per workgroup: enough workgroups x waves to fill 1024 SIMDs four deep, at most one wave per chunk
-    static const int forced = [] { const char *e = getenv("GLB_ROW_WAVES"); return e ? atoi(e) : 0; }();
-    int waves = 4;
-    while (waves < 16 && n_units * waves * 2 <= 4096) waves *= 2;
-    while (waves > 1 && waves / 2 >= p.nch) waves /= 2;
-    if (forced >= 1 && forced <= 16) waves = forced;
-    const hipError_t e = launch_row_step(a->dtype, p, kmask, a->rng_mode, a->logit_scale != 1.0f, waves, s);
-    if (e != hipSuccess) return hip_fail(e, "row_step launch");
-    return GLB_OK;
   }
-  hipError_t e = launch_stats(a->dtype, p, kmask, a->logit_scale != 1.0f, s);
+  hipError_t e = launch_stats(a->dtype, p, kmask, a->logit_scale != 1.0f, draw, s);
   if (e != hipSuccess) return hip_fail(e, "chunk_stats launch");
   e = launch_finish(a->dtype, p, kmask, a->rng_mode, s);
   if (e != hipSuccess) return hip_fail(e, "finish launch");
@@ -913,7 +894,7 @@ int glb_log_softmax_rows(const void *logits, int32_t dtype, int64_t n_rows, int6
   p.n_pairs = (int32_t)n_rows;
   p.recs = (glb::ChunkRec *)workspace;
   p.out_lse = lse;
-  hipError_t e = launch_stats(dtype, p, glb::kMaskNone, logit_scale != 1.0f, s);
+  hipError_t e = launch_stats(dtype, p, glb::kMaskNone, logit_scale != 1.0f, false, s);
   if (e != hipSuccess) return hip_fail(e, "chunk_stats launch");
   e = launch_finish(dtype, p, glb::kMaskNone, glb::kModeStats, s);
   if (e != hipSuccess) return hip_fail(e, "finish launch");

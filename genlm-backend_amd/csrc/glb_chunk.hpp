@@ -11,16 +11,16 @@
 //   chunk_stats_kernel   one WAVE per (row|particle, chunk): 16 KiB (fp32) / 8 KiB (16-bit) of the row in one
 //                        burst of global_load_dwordx4, chunk maximum by DPP, one polynomial exp per element,
 //                        both sums (all / allowed) by round-toward-zero fp32 adds on two grids, allowed lanes
-//                        selected by EXEC from a pre-transposed bit mask read through the scalar cache.  No
-//                        LDS, no barrier, no cross-wave dependency: the launch is pure streaming and the unit
-//                        of scheduling is 16 KiB, so any row count / row length fills the chip.  Rows shared by
+//                        selected by EXEC from a pre-transposed bit mask read through the scalar cache; then, still
+//                        from registers, the in-chunk stage of the Philox draw for the unit's first particles.  No
+//                        barrier, no cross-wave dependency: the launch is pure streaming and the unit of
+//                        scheduling is 16 KiB, so any row count / row length fills the chip.  Rows shared by
 //                        several particles (dedup fan-out of hf.py:214-220,285-288) are reduced once.
 //   finish_kernel        one wave per PARTICLE: folds the chunk records of its row into (N, S_all, S_mask), lse / logZ
-//                        by a double-precision log, then the draw: first Philox word -> chunk (scan of the chunk
-//                        sums), second word -> element inside that chunk, which is reloaded and reduced again.
-//                        Also the parity-mode exponential race (four waves).
-//   row_step_kernel      the same step in ONE launch: a workgroup per row, records in LDS, in-chunk draws made by the
-//                        reducing wave while the chunk is in its registers.
+//                        by a double-precision log, then the chunk stage of the draw (first Philox word against a
+//                        scan of the chunk sums) and a look-up of the token the reducing wave drew in that chunk
+//                        (second word); particles nobody drew for reload the chunk and reduce it again.  Also the
+//                        parity-mode exponential race (four waves).
 //   logprob_rows_kernel  x - lse for the API path that materialises log-probabilities (cache.py:93-98).
 // mask_prepare_kernel builds the transposed masks ([mask][chunk][vector][component] 64-bit lane words).
 #pragma once
@@ -53,8 +53,8 @@ struct StepParams {
   const int32_t *pair_row;   // [n_pairs] logits row of a reduction unit, null = identity
   const int32_t *pair_mask;  // [n_pairs] mask row, null = (n_masks == 1 ? 0 : identity)
   const int32_t *pair_of;    // [n_particles] reduction unit of a particle, null = identity
-  const int32_t *mem_start;  // [n_pairs + 1] row kernel: particles of a unit as a CSR, null = identity (one each)
-  const int32_t *members;    // [n_particles]
+  const int32_t *mem_start;  // [n_pairs + 1] particles of a unit as a CSR (inverse of pair_of); null with pair_of
+  const int32_t *members;    // [n_particles]    null = identity (one each), null with pair_of given = unknown
   const uint64_t *mask_t;    // transposed bit masks [n_masks][nch * 64]
   const uint64_t *mask_any;  // [n_masks][nch]: nonzero when the mask allows any token of the chunk
   const float *mask_f;       // float masks [n_masks][mask_ld]
@@ -67,6 +67,7 @@ struct StepParams {
   int32_t *out_token;
   float *out_margin;  // parity mode: relative gap between the two largest e_j / E_j of the race
   ChunkRec *recs;  // [n_pairs][nch]
+  int32_t *cands;  // [n_pairs][nch][kDrawCap]: in-chunk draws of a unit's first particles, made by the reducing wave
 };
 
 template <int DT>
@@ -302,6 +303,18 @@ __device__ __forceinline__ void chunk_reduce_bits(float (&x)[64], float Nc, int 
   }
 }
 
+// the particle's two 64-bit draws (chunk stage, in-chunk stage): Philox4x32-10 keyed by the call's seed, counter =
+// (global particle index, call offset)
+__device__ __forceinline__ void philox_pair(const StepParams &p, int pidx, uint64_t &R1, uint64_t &R2) {
+  const uint64_t gp = (uint64_t)(p.particle_base + pidx);
+  const uint32_t ctr[4] = {(uint32_t)gp, (uint32_t)(gp >> 32), (uint32_t)p.offset, (uint32_t)(p.offset >> 32)};
+  const uint32_t key[2] = {(uint32_t)p.seed, (uint32_t)(p.seed >> 32)};
+  uint32_t rnd[4];
+  philox4x32_10(ctr, key, rnd);
+  R1 = ((uint64_t)rnd[1] << 32) | rnd[0];
+  R2 = ((uint64_t)rnd[3] << 32) | rnd[2];
+}
+
 // y = x + (float mask row) for the wave's chunk (same lane layout as x)
 template <int DT>
 __device__ __forceinline__ void add_float_mask(const float (&x)[64], const char *mrow, int e_base, int V, int lane,
@@ -382,17 +395,34 @@ __device__ __forceinline__ int32_t chunk_candidate(const float (&x)[64], float m
 // ---------------------------------------------------------------------------------------------------------
 // chunk statistics: one wave per (reduction unit, chunk)
 // ---------------------------------------------------------------------------------------------------------
-#ifndef GLB_K1_MINW
-#define GLB_K1_MINW 1
-#endif
-template <int DT, int MASK, bool SCALED>
-__global__ __launch_bounds__(256, GLB_K1_MINW) void chunk_stats_kernel(const StepParams p) {
+constexpr int kDrawCap = 4;  // particles per unit whose in-chunk draws ride along with the reduction
+
+// DRAW: the call samples with Philox and the particles of a unit are known (identity, or the CSR mem_start / members):
+// while the chunk is in registers the wave also makes the in-chunk draw (second stage) of the unit's first kDrawCap
+// particles and leaves the tokens beside the record, so the per-particle kernel only has to pick a chunk and look the
+// token up; later members of a crowded unit, and callers that give row_of without its inverse, redo the chunk there.
+template <int DT, int MASK, bool SCALED, bool DRAW>
+__global__ __launch_bounds__(256) void chunk_stats_kernel(const StepParams p) {
   constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC;
-  const int lane = threadIdx.x & 63;
+  __shared__ __attribute__((aligned(16))) float s_tr_all[DRAW ? 4 : 1][64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int item = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
   const int nch = p.nch;
   if (item >= p.n_pairs * nch) return;  // whole waves only
+#ifdef GLB_K1_SCATTER  // experiment: neighbouring waves on different rows
+  const int c = item / p.n_pairs, pr = item - c * p.n_pairs;
+#else
   const int pr = item / nch, c = item - pr * nch;
+#endif
+  int m0 = pr, ncand = 0;
+  if constexpr (DRAW) {
+    ncand = 1;
+    if (p.mem_start) {
+      m0 = as_const(p.mem_start)[pr];
+      const int cnt = as_const(p.mem_start)[pr + 1] - m0;
+      ncand = cnt < kDrawCap ? cnt : kDrawCap;
+    }
+  }
   const int row = p.pair_row ? as_const(p.pair_row)[pr] : pr;
   const char *rowp = (const char *)p.logits + (int64_t)row * p.ld * ES;
   const int V = p.V, e_base = c * kChunk;
@@ -401,34 +431,61 @@ __global__ __launch_bounds__(256, GLB_K1_MINW) void chunk_stats_kernel(const Ste
 
   MaskAhead ma{};
   cu64_t mt = nullptr;
-  uint64_t allows_any = 0;
+  uint64_t allows_any = 0, mw = 0;
+  int mi = 0;
+  if constexpr (MASK != kMaskNone) mi = p.pair_mask ? as_const(p.pair_mask)[pr] : (p.n_masks == 1 ? 0 : pr);
   if constexpr (MASK == kMaskBits) {
-    const int mi = p.pair_mask ? as_const(p.pair_mask)[pr] : (p.n_masks == 1 ? 0 : pr);
     mt = as_const(p.mask_t + ((int64_t)mi * nch + c) * 64);
     mask_ahead<DT>(mt, ma);
     allows_any = as_const(p.mask_any)[(int64_t)mi * nch + c];
+    if (DRAW && ncand) mw = (p.mask_t + ((int64_t)mi * nch + c) * 64)[lane];
   }
   float x[64];
   load_chunk<DT, SCALED>(rowp, e_base, V, lane, p.scale, x);
   const float Nc = exp_n(chunk_max(x));
   uint32_t pA, pB, pAm, pBm;
   float Nm = Nc;
+  int32_t toks[kDrawCap] = {-1, -1, -1, -1};
+  auto draws = [&](const float (&v)[64], bool masked_words, uint32_t ia, uint32_t ib) {
+#pragma unroll
+    for (int m = 0; m < kDrawCap; ++m) {
+      if (m < ncand) {
+        uint64_t R1, R2;
+        philox_pair(p, p.mem_start ? as_const(p.members)[m0 + m] : pr, R1, R2);
+        toks[m] = masked_words ? chunk_candidate<DT, true>(v, kMagic - Nm, e_base, lane, ia, ib, mw, R2, s_tr_all[wave])
+                               : chunk_candidate<DT, false>(v, kMagic - Nm, e_base, lane, ia, ib, 0ull, R2, s_tr_all[wave]);
+      }
+    }
+  };
   if constexpr (MASK == kMaskBits) {
     bool redone;
     chunk_reduce_bits<DT>(x, Nc, nv_valid, mt, ma, allows_any, lane, pA, pB, pAm, pBm, Nm, redone);
+    if constexpr (DRAW) {
+      if (redone) mw = ~0ull;  // x holds the masked chunk now: every finite element counts
+      draws(x, true, pAm, pBm);
+    }
   } else {
     chunk_sums<DT, false>(x, kMagic - Nc, nv_valid, nullptr, ma, pA, pB, pAm, pBm);
     if constexpr (MASK == kMaskF32) {  // general additive masks: y = x + m has its own maximum, scale and exp
-      const int mi = p.pair_mask ? as_const(p.pair_mask)[pr] : (p.n_masks == 1 ? 0 : pr);
       const char *mrow = (const char *)(p.mask_f + (int64_t)mi * p.mask_ld);
       float y[64];
       add_float_mask<DT>(x, mrow, e_base, V, lane, y);
       Nm = exp_n(chunk_max(y));
       uint32_t d0, d1;
       chunk_sums<DT, false>(y, kMagic - Nm, nv_valid, nullptr, ma, pAm, pBm, d0, d1);
+      if constexpr (DRAW) draws(y, false, pAm, pBm);
+    } else {
+      if constexpr (DRAW) draws(x, false, pA, pB);
     }
   }
-  if (lane == 63) store_rec(p.recs + (int64_t)pr * nch + c, Nc, pA, pB, pAm, pBm, Nm);
+  if (lane == 63) {
+    store_rec(p.recs + (int64_t)pr * nch + c, Nc, pA, pB, pAm, pBm, Nm);
+    if constexpr (DRAW) {
+      if (ncand)
+        *reinterpret_cast<u32x4_t *>(p.cands + ((int64_t)pr * nch + c) * kDrawCap) =
+            u32x4_t{(uint32_t)toks[0], (uint32_t)toks[1], (uint32_t)toks[2], (uint32_t)toks[3]};
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -533,18 +590,6 @@ __global__ __launch_bounds__(256) void chunk_stats_small_kernel(const StepParams
 // ---------------------------------------------------------------------------------------------------------
 // finish: one wave per particle
 // ---------------------------------------------------------------------------------------------------------
-// the particle's two 64-bit draws (chunk stage, in-chunk stage): Philox4x32-10 keyed by the call's seed, counter =
-// (global particle index, call offset)
-__device__ __forceinline__ void philox_pair(const StepParams &p, int pidx, uint64_t &R1, uint64_t &R2) {
-  const uint64_t gp = (uint64_t)(p.particle_base + pidx);
-  const uint32_t ctr[4] = {(uint32_t)gp, (uint32_t)(gp >> 32), (uint32_t)p.offset, (uint32_t)(p.offset >> 32)};
-  const uint32_t key[2] = {(uint32_t)p.seed, (uint32_t)(p.seed >> 32)};
-  uint32_t rnd[4];
-  philox4x32_10(ctr, key, rnd);
-  R1 = ((uint64_t)rnd[1] << 32) | rnd[0];
-  R2 = ((uint64_t)rnd[3] << 32) | rnd[2];
-}
-
 // the row (or float-mask) view one particle works on
 template <int DT, int MASK>
 struct RowView {
@@ -633,20 +678,6 @@ struct RecsGlobal {
   const ChunkRec *r;
   __device__ __forceinline__ ChunkRec get(int c) const { return r[c]; }
 };
-struct RecsLds {  // words: Nc, pA, pB, pAm, pBm, Nm
-  const uint32_t (*s)[6];
-  __device__ __forceinline__ ChunkRec get(int c) const {
-    ChunkRec r;
-    r.Nc = __uint_as_float(s[c][0]);
-    r.pA = s[c][1];
-    r.pB = s[c][2];
-    r.pAm = s[c][3];
-    r.pBm = s[c][4];
-    r.Nm = __uint_as_float(s[c][5]);
-    return r;
-  }
-};
-
 struct PairState {
   float N_all, N_msk;     // row scales (all / allowed)
   uint64_t S_all, S_msk;  // sums on them
@@ -706,7 +737,7 @@ __device__ __forceinline__ void pair_logs(const PairState &st, float &lse, float
 template <int DT, int MASK, class Recs>
 __device__ __forceinline__ int32_t pair_draw_philox(const StepParams &p, const Recs &recs, const RowView<DT, MASK> &rv,
                                                     const PairState &st, int pidx, int nch, int lane,
-                                                    const int32_t *cand, float *s_tr) {
+                                                    const int32_t *cand, int cand_stride, float *s_tr) {
   uint32_t nz = (uint32_t)st.S_msk | (uint32_t)(st.S_msk >> 32);
   opaque_u32(nz);
   if (nz == 0u) return -1;
@@ -731,7 +762,7 @@ __device__ __forceinline__ int32_t pair_draw_philox(const StepParams &p, const R
     else T -= readlane_u64(incl, 63);
   }
   if (csel < 0) return -1;  // consistent sums rule this out
-  if (cand) return cand[csel];
+  if (cand) return cand[(int64_t)csel * cand_stride];
   return draw_chunk_reload(rv, csel, lane, R2, s_tr);
 }
 
@@ -774,7 +805,20 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
   if (!p.out_token) return;
 
   if constexpr (MODE == kModePhilox) {
-    const int32_t tok = pair_draw_philox<DT, MASK>(p, recs, rv, st, pidx, nch, lane, nullptr, s_tr);
+    // did the reducing waves draw for this particle?  (it is one of its unit's first kDrawCap members)
+    const int32_t *cand = nullptr;
+    if (p.cands) {
+      if (!p.pair_of) {
+        cand = p.cands + (int64_t)pr * nch * kDrawCap;
+      } else if (p.mem_start) {
+        const int m0 = as_const(p.mem_start)[pr];
+        int cnt = as_const(p.mem_start)[pr + 1] - m0;
+        cnt = cnt < kDrawCap ? cnt : kDrawCap;
+        for (int m = 0; m < cnt; ++m)
+          if (as_const(p.members)[m0 + m] == pidx) cand = p.cands + (int64_t)pr * nch * kDrawCap + m;
+      }
+    }
+    const int32_t tok = pair_draw_philox<DT, MASK>(p, recs, rv, st, pidx, nch, lane, cand, kDrawCap, s_tr);
     if (lane == 0) p.out_token[pidx] = tok;
   } else {
     // ---- parity mode: exponential race against the caller's noise, first maximum of e_j / E_j (README.md:87
@@ -837,116 +881,6 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
       tok = bj;
     }
     if (wave == 0 && lane == 0) p.out_token[pidx] = tok;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// The whole step in ONE launch: a workgroup of W waves per (row, mask) pair.  Wave w reduces chunks w, w + W, ... of
-// the row exactly as chunk_stats_kernel does, leaves each chunk's record in LDS and - while the chunk is still in its
-// registers - the in-chunk draw of every particle of the pair (up to kFusedCap of them; further members reload).  After
-// one barrier the waves take the pair's particles round robin: fold the records, lse / logZ, chunk stage of the draw,
-// look up the token.  No records in global memory, no second launch, nothing re-read: the tail after the last byte of
-// a row has been streamed is a fold of <= 256 LDS records.  Stats / Philox modes, no mask or bit masks.
-// ---------------------------------------------------------------------------------------------------------
-constexpr int kFusedMaxChunks = 256;  // rows up to 2^20 elements
-constexpr int kFusedCap = 4;          // particles per pair whose in-chunk draws ride along with the reduction
-
-template <int DT, int MASK, bool SCALED, int MODE>
-__global__ __launch_bounds__(1024) void row_step_kernel(const StepParams p) {
-  constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC;
-  static_assert(MASK != kMaskF32 && MODE != kModeNoise, "float masks / parity mode take the two-launch path");
-  __shared__ uint32_t s_rec[kFusedMaxChunks][6];
-  __shared__ int32_t s_cand[kFusedCap][kFusedMaxChunks];
-  __shared__ __attribute__((aligned(16))) float s_tr[16][64];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int W = (int)(blockDim.x >> 6);
-  const int pr = blockIdx.x, nch = p.nch, V = p.V;
-  int m0 = 0, cnt = 1;
-  if (p.mem_start) {
-    m0 = as_const(p.mem_start)[pr];
-    cnt = as_const(p.mem_start)[pr + 1] - m0;
-  }
-  if (cnt <= 0) return;  // a row nobody sits on (workgroup-uniform, before any barrier)
-  const int row = p.pair_row ? as_const(p.pair_row)[pr] : pr;
-  const int mi = MASK == kMaskNone ? 0 : (p.pair_mask ? as_const(p.pair_mask)[pr] : (p.n_masks == 1 ? 0 : pr));
-  const char *rowp = (const char *)p.logits + (int64_t)row * p.ld * ES;
-  const bool draw = MODE == kModePhilox && p.out_token != nullptr;
-  const int ncand = draw ? (cnt < kFusedCap ? cnt : kFusedCap) : 0;
-  uint64_t R2s[kFusedCap];
-#pragma unroll
-  for (int m = 0; m < kFusedCap; ++m) {
-    R2s[m] = 0;
-    if (m < ncand) {
-      uint64_t R1;
-      philox_pair(p, p.mem_start ? as_const(p.members)[m0 + m] : pr, R1, R2s[m]);
-    }
-  }
-
-  for (int c = wave; c < nch; c += W) {
-    const int e_base = c * kChunk;
-    int nv_valid = (V - e_base + 64 * EPV - 1) / (64 * EPV);
-    nv_valid = nv_valid < NVC ? nv_valid : NVC;
-    uint64_t mw = 0, allows_any = 0;
-    MaskAhead ma{};
-    cu64_t mt = nullptr;
-    if constexpr (MASK == kMaskBits) {
-      if (ncand) mw = (p.mask_t + ((int64_t)mi * nch + c) * 64)[lane];
-      mt = as_const(p.mask_t + ((int64_t)mi * nch + c) * 64);
-      mask_ahead<DT>(mt, ma);
-      allows_any = as_const(p.mask_any)[(int64_t)mi * nch + c];
-    }
-    float x[64];
-    load_chunk<DT, SCALED>(rowp, e_base, V, lane, p.scale, x);
-    const float Nc = exp_n(chunk_max(x));
-    uint32_t pA, pB, pAm, pBm;
-    float Nm = Nc;
-    bool redone = false;
-    if constexpr (MASK == kMaskBits) chunk_reduce_bits<DT>(x, Nc, nv_valid, mt, ma, allows_any, lane, pA, pB, pAm, pBm, Nm, redone);
-    else chunk_sums<DT, false>(x, kMagic - Nc, nv_valid, nullptr, ma, pA, pB, pAm, pBm);
-    if (lane == 63) {
-      s_rec[c][0] = __float_as_uint(Nc);
-      s_rec[c][1] = pA;
-      s_rec[c][2] = pB;
-      s_rec[c][3] = pAm;
-      s_rec[c][4] = pBm;
-      s_rec[c][5] = __float_as_uint(Nm);
-    }
-    if (redone) mw = ~0ull;  // x holds the masked chunk now: every finite element counts
-#pragma unroll
-    for (int m = 0; m < kFusedCap; ++m) {
-      if (m < ncand) {
-        const int32_t tok =
-            chunk_candidate<DT, MASK == kMaskBits>(x, kMagic - Nm, e_base, lane, pAm, pBm, mw, R2s[m], s_tr[wave]);
-        if (lane == 0) s_cand[m][c] = tok;
-      }
-    }
-  }
-  __syncthreads();
-  if (wave >= cnt) return;
-
-  RowView<DT, MASK> rv;
-  rv.rowp = rowp;
-  rv.V = V;
-  rv.scale = p.scale;
-  rv.mt = MASK == kMaskBits ? p.mask_t + (int64_t)mi * nch * 64 : nullptr;
-  rv.many = MASK == kMaskBits ? p.mask_any + (int64_t)mi * nch : nullptr;
-  rv.mrow = nullptr;
-  const RecsLds recs{s_rec};
-  PairState st;
-  pair_fold<MASK>(recs, nch, lane, st);
-  float lse = 0.f, logZ = 0.f;
-  if (lane == 0) pair_logs(st, lse, logZ);
-  for (int m = wave; m < cnt; m += W) {
-    const int pidx = p.mem_start ? as_const(p.members)[m0 + m] : pr;
-    if (lane == 0) {
-      if (p.out_lse) p.out_lse[pidx] = lse;
-      if (p.out_logZ) p.out_logZ[pidx] = logZ;
-    }
-    if (draw) {
-      const int32_t tok = pair_draw_philox<DT, MASK>(p, recs, rv, st, pidx, nch, lane,
-                                                     m < kFusedCap ? s_cand[m] : nullptr, s_tr[wave]);
-      if (lane == 0) p.out_token[pidx] = tok;
-    }
   }
 }
 

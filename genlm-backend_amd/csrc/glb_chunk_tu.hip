@@ -1,5 +1,7 @@
 // glb_chunk_tu.hip — one translation unit per element type (-DGLB_DT=<0|1|2>): instantiates the chunked step
 // kernels for every mask kind / draw mode and exports the launchers glb_api.hip dispatches to.
+#include <cstdlib>
+
 #include "glb_chunk.hpp"
 
 #ifndef GLB_DT
@@ -16,10 +18,10 @@ namespace glb {
 constexpr int64_t kSmallLaunchItems = 512;
 
 template <int MASK>
-static hipError_t stats1(const StepParams &p, bool scaled, hipStream_t s) {
+static hipError_t stats1(const StepParams &p, bool scaled, bool draw, hipStream_t s) {
   const int64_t waves = (int64_t)p.n_pairs * p.nch;
   if constexpr (MASK != kMaskF32) {
-    if (waves <= kSmallLaunchItems) {
+    if (waves <= kSmallLaunchItems && !draw) {
       const dim3 grid((unsigned)waves), block(256);
       if (scaled)
         hipLaunchKernelGGL((chunk_stats_small_kernel<GLB_DT, MASK, true>), grid, block, 0, s, p);
@@ -29,18 +31,23 @@ static hipError_t stats1(const StepParams &p, bool scaled, hipStream_t s) {
     }
   }
   const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
-  if (scaled)
-    hipLaunchKernelGGL((chunk_stats_kernel<GLB_DT, MASK, true>), grid, block, 0, s, p);
-  else
-    hipLaunchKernelGGL((chunk_stats_kernel<GLB_DT, MASK, false>), grid, block, 0, s, p);
+  static const size_t lds = [] { const char *e = getenv("GLB_K1_LDS"); return e ? (size_t)atoi(e) : 0; }();  // tuning aid: caps the waves per SIMD
+  if (draw) {
+    if (scaled) hipLaunchKernelGGL((chunk_stats_kernel<GLB_DT, MASK, true, true>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((chunk_stats_kernel<GLB_DT, MASK, false, true>), grid, block, lds, s, p);
+  } else {
+    if (scaled) hipLaunchKernelGGL((chunk_stats_kernel<GLB_DT, MASK, true, false>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((chunk_stats_kernel<GLB_DT, MASK, false, false>), grid, block, lds, s, p);
+  }
   return hipGetLastError();
 }
 
-hipError_t GLB_CAT(launch_stats_, GLB_DT)(const StepParams &p, int mask_kind, bool scaled, hipStream_t s) {
+// draw: the reducing waves also make the in-chunk draws of each unit's first particles (StepParams::cands)
+hipError_t GLB_CAT(launch_stats_, GLB_DT)(const StepParams &p, int mask_kind, bool scaled, bool draw, hipStream_t s) {
   switch (mask_kind) {
-    case kMaskNone: return stats1<kMaskNone>(p, scaled, s);
-    case kMaskBits: return stats1<kMaskBits>(p, scaled, s);
-    case kMaskF32: return stats1<kMaskF32>(p, scaled, s);
+    case kMaskNone: return stats1<kMaskNone>(p, scaled, draw, s);
+    case kMaskBits: return stats1<kMaskBits>(p, scaled, draw, s);
+    case kMaskF32: return stats1<kMaskF32>(p, scaled, draw, s);
   }
   return hipErrorInvalidValue;
 }
@@ -63,32 +70,6 @@ hipError_t GLB_CAT(launch_finish_, GLB_DT)(const StepParams &p, int mask_kind, i
     case kMaskNone: return finish1<kMaskNone>(p, mode, s);
     case kMaskBits: return finish1<kMaskBits>(p, mode, s);
     case kMaskF32: return finish1<kMaskF32>(p, mode, s);
-  }
-  return hipErrorInvalidValue;
-}
-
-template <int MASK>
-static hipError_t row1(const StepParams &p, int mode, bool scaled, int waves, hipStream_t s) {
-  const dim3 grid((unsigned)p.n_pairs), block((unsigned)waves * 64);
-  if (mode == kModeStats) {
-    if (scaled) hipLaunchKernelGGL((row_step_kernel<GLB_DT, MASK, true, kModeStats>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((row_step_kernel<GLB_DT, MASK, false, kModeStats>), grid, block, 0, s, p);
-  } else if (mode == kModePhilox) {
-    if (scaled) hipLaunchKernelGGL((row_step_kernel<GLB_DT, MASK, true, kModePhilox>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((row_step_kernel<GLB_DT, MASK, false, kModePhilox>), grid, block, 0, s, p);
-  } else {
-    return hipErrorInvalidValue;
-  }
-  return hipGetLastError();
-}
-
-// the one-launch step (no mask / bit masks, stats / Philox); waves = waves per workgroup (1 .. 16)
-hipError_t GLB_CAT(launch_row_step_, GLB_DT)(const StepParams &p, int mask_kind, int mode, bool scaled, int waves,
-                                              hipStream_t s) {
-  if (waves < 1 || waves > 16 || p.nch > kFusedMaxChunks) return hipErrorInvalidValue;
-  switch (mask_kind) {
-    case kMaskNone: return row1<kMaskNone>(p, mode, scaled, waves, s);
-    case kMaskBits: return row1<kMaskBits>(p, mode, scaled, waves, s);
   }
   return hipErrorInvalidValue;
 }

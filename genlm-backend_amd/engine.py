@@ -84,15 +84,16 @@ class HipEngine:
 
     def step(self, logits, vocab=None, row_of=None, mask_kind=MASK_NONE, mask=None, mask_id=None,
              rng_mode=RNG_NONE, noise=None, seed=0, offset=0, particle_base=0, logit_scale=1.0,
-             want_lse=True, variant=0, out=None, row_mask_id=None, out_margin=None, path=0, row_members=None):
+             want_lse=True, variant=0, out=None, row_mask_id=None, out_margin=None, row_members=None):
         """Fused particle step (glb_logprob_mask_sample).  Returns (logZ, lse, token) device tensors.
 
         logits: [n_rows, ld] (last dim contiguous; rows may be strided), vocab <= ld.
         mask: int32 bit rows / float rows, or a `PreparedMasks` (prepare_masks).  `row_mask_id` gives the mask per
         logits row (the mask is a function of the context): shared rows are then reduced once.
         `variant` is accepted for source compatibility and ignored (one kernel family serves every shape).
-        `row_members` = (start, members, max_per_row) from `row_members()` lets a per-row reduction with `row_of` run
-        as one launch; `path` forces the launch sequence (0 auto, 1 two launches, 2 one launch) - same results.
+        `row_members` = (start, members[, max]) from `row_members()`: the inverse of `row_of` for a per-row reduction
+        (no mask, or `row_mask_id`); with it the reducing waves also make the in-chunk draws and the per-particle
+        launch only looks tokens up.  Same results with or without.
         """
         if logits.dim() != 2 or logits.stride(1) != 1:
             raise ValueError("logits must be 2-D with unit inner stride")
@@ -153,13 +154,12 @@ class HipEngine:
         a.out_lse = None if lse is None else lse.data_ptr()
         a.out_token = None if tok is None else tok.data_ptr()
         a.out_margin = None if out_margin is None else out_margin.data_ptr()  # parity mode: tie margin of every draw
-        a.path = path
         if row_members is not None:
-            start, members, mx = row_members
+            start, members = row_members[0], row_members[1]
             self._check_dev(start, members)
             if start.dtype != torch.int32 or members.dtype != torch.int32 or start.numel() < n_rows + 1 or members.numel() < n:
                 raise ValueError("row_members: int32 start [n_rows + 1] and members [n_particles]")
-            a.row_members_start, a.row_members, a.row_members_max = start.data_ptr(), members.data_ptr(), int(mx)
+            a.row_members_start, a.row_members = start.data_ptr(), members.data_ptr()
         ws = self._scratch(self.lib.glb_step_workspace_bytes(n, n_rows, V, n_masks))
         a.workspace = ws.data_ptr()
         a.workspace_bytes = ws.numel()

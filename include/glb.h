@@ -62,14 +62,6 @@ enum {
                          (README.md:87, base.py:137-141)                                          */
 };
 
-/* which launch sequence glb_logprob_mask_sample uses; results are the same bit for bit */
-enum {
-  GLB_PATH_AUTO = 0,
-  GLB_PATH_TWO_LAUNCH = 1, /* chunk records to the workspace, then one wave per particle */
-  GLB_PATH_ONE_LAUNCH = 2  /* a workgroup per row; GLB_EUNSUPPORTED for float masks, parity noise, rows over 2^20
-                              elements, or row_of without row_members */
-};
-
 const char *glb_version(void);
 int glb_abi_version(void);
 /* copies the calling thread's last error message (NUL-terminated, truncated to n) */
@@ -124,16 +116,16 @@ typedef struct glb_step_args {
   int32_t *out_token;/* [n_particles] sampled id, -1 when every token is masked out */
   float *out_margin; /* [n_particles] GLB_RNG_NOISE only: (winner - runner-up) / winner of the race e_j / E_j, i.e. how
                         far the draw is from a tie that float rounding could flip (1 if there is no runner-up) */
-  int32_t path;      /* GLB_PATH_*: 0 = let the library choose */
+  int32_t reserved;  /* must be 0 */
   /* Optional inverse of row_of for per-row reductions (row_of given; no mask or row_mask_id), from
      glb_row_members: the particles on row r are row_members[row_members_start[r] .. row_members_start[r + 1]).
-     With it, and with row_members_max (an upper bound on the particles per row the caller knows of, 0 = unknown)
-     at most 4, the step runs as one launch; a wrong bound costs time, never correctness. */
+     With it the waves that reduce a row also make the in-chunk draws of the row's first four particles, and the
+     per-particle launch only looks the token up; without it every particle redoes the chunk it lands in.  Same
+     results either way. */
   const int32_t *row_members_start; /* [n_rows + 1] device, nullable */
   const int32_t *row_members;       /* [n_particles] device, nullable */
-  int32_t row_members_max;
-  /* device scratch of >= glb_step_workspace_bytes(...) bytes, 32-byte aligned: the per-chunk records the
-     reduction kernel hands to the per-particle kernel (and, for GLB_MASK_BITS, the prepared masks) */
+  /* device scratch of >= glb_step_workspace_bytes(...) bytes, 32-byte aligned: the per-chunk records and in-chunk
+     draws the reduction kernel hands to the per-particle kernel (and, for GLB_MASK_BITS, the prepared masks) */
   void *workspace;
   size_t workspace_bytes;
 } glb_step_args;

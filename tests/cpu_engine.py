@@ -32,7 +32,7 @@ class CpuOracleEngine:
 
     def step(self, logits, vocab=None, row_of=None, mask_kind=0, mask=None, mask_id=None, rng_mode=0, noise=None,
              seed=0, offset=0, particle_base=0, logit_scale=1.0, want_lse=True, variant=0, out=None, row_mask_id=None,
-             out_margin=None, path=0, row_members=None):
+             out_margin=None, row_members=None):
         V = logits.shape[1] if vocab is None else vocab
         x = _logits_np(logits[:, :V])
         if isinstance(mask, _Prepared):
