@@ -107,6 +107,10 @@ def load():
             f"{LIB_PATH} not found: build it with `make -C genlm-backend_amd/csrc -j8` "
             "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback."
         )
+    # torch first: it brings its own HIP runtime, and the runtime that is loaded first serves the process - loading
+    # this library (linked against /opt/rocm's) ahead of torch leaves torch.cuda unable to find the device
+    import torch  # noqa: F401
+
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the ABI is incomplete

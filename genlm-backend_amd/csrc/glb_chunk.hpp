@@ -732,12 +732,14 @@ __device__ __forceinline__ void pair_logs(const PairState &st, float &lse, float
 }
 
 // The Philox draw of particle pidx, two stages: the chunk by a scan of the shifted chunk sums (first draw); inside the
-// chunk the second draw - taken from `cand` (per-chunk results the reducing wave left behind, row kernel) or, when
-// cand is null, recomputed from a reload of that chunk.
+// chunk the second draw - taken from `cand` (per-chunk results the reducing waves left behind; for rows of up to 64
+// chunks lane c has already fetched chunk c's into my_cand) or, when cand is null, recomputed from a reload of that
+// chunk.
 template <int DT, int MASK, class Recs>
 __device__ __forceinline__ int32_t pair_draw_philox(const StepParams &p, const Recs &recs, const RowView<DT, MASK> &rv,
                                                     const PairState &st, int pidx, int nch, int lane,
-                                                    const int32_t *cand, int cand_stride, float *s_tr) {
+                                                    const int32_t *cand, int cand_stride, int32_t my_cand,
+                                                    float *s_tr) {
   uint32_t nz = (uint32_t)st.S_msk | (uint32_t)(st.S_msk >> 32);
   opaque_u32(nz);
   if (nz == 0u) return -1;
@@ -762,7 +764,10 @@ __device__ __forceinline__ int32_t pair_draw_philox(const StepParams &p, const R
     else T -= readlane_u64(incl, 63);
   }
   if (csel < 0) return -1;  // consistent sums rule this out
-  if (cand) return cand[(int64_t)csel * cand_stride];
+  if (cand) {
+    if (nch <= 64) return __builtin_amdgcn_readlane(my_cand, csel);
+    return cand[(int64_t)csel * cand_stride];
+  }
   return draw_chunk_reload(rv, csel, lane, R2, s_tr);
 }
 
@@ -793,6 +798,25 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
   rv.many = MASK == kMaskBits ? p.mask_any + (int64_t)mi * nch : nullptr;
   rv.mrow = MASK == kMaskF32 ? (const char *)(p.mask_f + (int64_t)mi * p.mask_ld) : nullptr;
 
+  // did the reducing waves draw for this particle (it is one of its unit's first kDrawCap members)?  Then lane c
+  // fetches chunk c's token beside the records (rows of up to 64 chunks): the look-up after the chunk scan is a lane
+  // read, not one more dependent load
+  const int32_t *cand = nullptr;
+  int32_t my_cand = -1;
+  if constexpr (MODE == kModePhilox) {
+    if (p.cands && p.out_token) {
+      if (!p.pair_of) {
+        cand = p.cands + (int64_t)pr * nch * kDrawCap;
+      } else if (p.mem_start) {
+        const int m0 = as_const(p.mem_start)[pr];
+        int cnt = as_const(p.mem_start)[pr + 1] - m0;
+        cnt = cnt < kDrawCap ? cnt : kDrawCap;
+        for (int m = 0; m < cnt; ++m)
+          if (as_const(p.members)[m0 + m] == pidx) cand = p.cands + (int64_t)pr * nch * kDrawCap + m;
+      }
+      if (cand && nch <= 64 && lane < nch) my_cand = cand[lane * kDrawCap];
+    }
+  }
   PairState st;
   pair_fold<MASK>(recs, nch, lane, st);
   if (wave == 0 && lane == 0) {
@@ -805,20 +829,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
   if (!p.out_token) return;
 
   if constexpr (MODE == kModePhilox) {
-    // did the reducing waves draw for this particle?  (it is one of its unit's first kDrawCap members)
-    const int32_t *cand = nullptr;
-    if (p.cands) {
-      if (!p.pair_of) {
-        cand = p.cands + (int64_t)pr * nch * kDrawCap;
-      } else if (p.mem_start) {
-        const int m0 = as_const(p.mem_start)[pr];
-        int cnt = as_const(p.mem_start)[pr + 1] - m0;
-        cnt = cnt < kDrawCap ? cnt : kDrawCap;
-        for (int m = 0; m < cnt; ++m)
-          if (as_const(p.members)[m0 + m] == pidx) cand = p.cands + (int64_t)pr * nch * kDrawCap + m;
-      }
-    }
-    const int32_t tok = pair_draw_philox<DT, MASK>(p, recs, rv, st, pidx, nch, lane, cand, kDrawCap, s_tr);
+    const int32_t tok = pair_draw_philox<DT, MASK>(p, recs, rv, st, pidx, nch, lane, cand, kDrawCap, my_cand, s_tr);
     if (lane == 0) p.out_token[pidx] = tok;
   } else {
     // ---- parity mode: exponential race against the caller's noise, first maximum of e_j / E_j (README.md:87
