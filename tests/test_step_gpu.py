@@ -322,3 +322,53 @@ def test_log_softmax_rows_single_launch_path(engine, oracle, B, V, dtype, scale)
     assert np.array_equal(_np(got).view(np.uint32), want.view(np.uint32))
     few, lse_few = engine.log_softmax_rows(buf.to(dev)[:5, :V], vocab=V, logit_scale=scale, want_lse=True)
     assert torch.equal(few, got[:5]) and torch.equal(lse_few, lse[:5])
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_peaked_rows_with_the_likely_token_forbidden(engine, oracle, dtype):
+    """Constrained decoding's everyday case: the model is sure of a token the mask forbids.  The allowed mass of that
+    chunk is then far below its largest term - down to underflowing to zero on the chunk's scale - and the chunk sums
+    its allowed values again on their own scale (per chunk, from registers); logZ must still match a float64
+    log-softmax, for every path (draws by the reducing waves, reload in the per-particle launch, shared rows)."""
+    O = oracle
+    dev = engine.device
+    V, U = 50257, 160
+    rs = np.random.default_rng(5)
+    x = (rs.standard_normal((U, V)) * 2).astype(np.float32)
+    hot = rs.integers(0, V, U)
+    gap = rs.choice([12.0, 25.0, 40.0, 70.0], U).astype(np.float32)  # 40 and 70 nats: terms below 2^-36 of the maximum
+    x[np.arange(U), hot] += gap
+    masks = np.zeros((U, V), np.float32)
+    masks[np.arange(U), hot] = -np.inf                       # forbid exactly the likely token
+    masks[:8, :] = -np.inf
+    masks[np.arange(8), (hot[:8] + 1) % V] = 0.0             # a few rows allow one single (unlikely) token
+    bits, _ = O.mask_f32_to_bits(masks)
+    tdt = {"f32": torch.float32, "bf16": torch.bfloat16}[dtype]
+    xt = torch.from_numpy(x).to(tdt)
+    x_np = x if dtype == "f32" else xt.view(torch.int16).numpy().view(np.uint16)
+    N = 2 * U
+    row_of = np.concatenate([np.arange(U), rs.integers(0, U, N - U)]).astype(np.int32)
+    logZ_o, lse_o, tok_o = O.step(x_np, row_of=row_of, mask_kind=O.MASK_BITS, mask=bits, mask_id=row_of,
+                                  rng_mode=O.RNG_PHILOX, seed=9, offset=2)
+    x_d, ro_d = xt.to(dev), torch.from_numpy(row_of).to(dev)
+    bits_d = torch.from_numpy(bits.view(np.int32)).to(dev)
+    rmid = torch.arange(U, dtype=torch.int32, device=dev)
+    calls = {
+        "per particle": dict(mask_kind=1, mask=bits_d, mask_id=ro_d),
+        "per row": dict(mask_kind=1, mask=bits_d, row_mask_id=rmid),
+        "per row, members": dict(mask=engine.prepare_masks(bits_d, V, tdt), row_mask_id=rmid,
+                                 row_members=engine.row_members(ro_d, U)),
+    }
+    for what, kw in calls.items():
+        logZ, lse, tok = engine.step(x_d, row_of=ro_d, rng_mode=1, seed=9, offset=2, **kw)
+        torch.cuda.synchronize()
+        assert np.array_equal(logZ.cpu().numpy().view(np.uint32), logZ_o.view(np.uint32)), what
+        assert np.array_equal(lse.cpu().numpy().view(np.uint32), lse_o.view(np.uint32)), what
+        assert np.array_equal(tok.cpu().numpy(), tok_o), what
+    # against float64: masked log-softmax mass (the reference's logsumexp(log_softmax(x) + mask), README.md:84-85)
+    xf = xt.to(torch.float64)[torch.from_numpy(row_of).long()]
+    lp = torch.log_softmax(xf, -1) + torch.from_numpy(masks).to(torch.float64)[torch.from_numpy(row_of).long()]
+    want = torch.logsumexp(lp, -1).numpy()
+    assert np.all(np.isfinite(logZ_o)) and np.abs(logZ_o - want).max() < 2e-4 * max(1.0, np.abs(want).max() / 10), \
+        np.abs(logZ_o - want).max()
+    assert np.all(masks[row_of, tok_o] == 0.0)

@@ -43,7 +43,7 @@ for wl in ("kernel", "kernel-llama", "sis"):
     out["hbm_write_bytes_per_launch"] = write * 1024
     out["algorithmic_bytes_per_launch"] = ALGO[wl]
     out["note"] = (f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python3 bench.py --workload {wl} "
-                   "--steps 20 --warmup 2 --no-cpu`; one fused call = chunk_stats_kernel + finish_kernel; FETCH_SIZE doubled "
+                   f"--steps 20 --warmup {0 if wl == 'sis' else 2} --no-cpu`; one fused call = chunk_stats_kernel + finish_kernel; FETCH_SIZE doubled "
                    "per MI355X_MICROARCH.md (gfx950 tallies 128-B read requests at 64 B)")
     json.dump(out, open(os.path.join(root, f"{wl}_pmc_traffic.json"), "w"), indent=1)
     print(wl, json.dumps(out, indent=1))
