@@ -326,7 +326,13 @@ def pmc_traffic(workload):
     import glob
 
     try:
-        prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"{workload}_pmc_traffic*.json")), key=os.path.getmtime)
+        def order(path):  # profiles/rNN/<workload>_pmc_traffic_vM.json: latest round, then latest version
+            import re
+
+            m = re.search(r"r(\d+)[/\\][^/\\]*?(?:_v(\d+))?\.json$", path)
+            return (int(m.group(1)), int(m.group(2) or 0)) if m else (-1, -1)
+
+        prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"{workload}_pmc_traffic*.json")), key=order)
         if prof:
             t = json.load(open(prof[-1]))
             return t["hbm_read_bytes_per_launch_corrected"] + t["hbm_write_bytes_per_launch"]

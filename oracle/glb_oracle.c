@@ -81,8 +81,6 @@ static const uint32_t GLB_EXP_C[6] = {0x4e800000u, 0x4e317216u, 0x4d75fcd9u,
                                       0x4c635b16u, 0x4b1e7722u, 0x49adfe07u}; /* times 2^30 */
 #define GLB_FIX_SHIFT 18 /* S has 44 fractional bits: 2^30 (Pfix) * 2^32 >> 18 */
 #define GLB_FIX_FRAC 44
-/* masked sums are taken on the row's own scale unless that leaves them fewer than 37 significant bits */
-#define GLB_LOW_MASS (1ull << 37)
 
 static float u2f(uint32_t u) {
   float f;
@@ -186,8 +184,10 @@ static int mask_allows(const uint32_t *bits, int64_t j) {
  *     t = ldexpf(P, n - N_c)     P = 2^(f-1) by a degree-4 Horner polynomial (GLB_EXP2_D), clamped to [0, 1]
  *                                with NaN -> 0
  *     q = floor(t * 2^36)
- * S_c = sum of q over the chunk, S_c^m = sum over the allowed elements.  The row scale is N = max N_c over the
- * chunks with a non-zero sum, and the row sums are S = sum_c (S_c >> (N - N_c)).  sum_j e^(x_j) = 2^(N+1-36) S.
+ * S_c = sum of q over the chunk, S_c^m = sum over the allowed elements (on N_c, or on the allowed maximum's own scale
+ * for a low-mass chunk: glb_chunk_masked).  The row scale is N = max N_c over the chunks with a non-zero sum, and the
+ * row sums are S = sum_c (S_c >> (N - N_c)); likewise for the allowed sums.  sum_j e^(x_j) = 2^(N+1-36) S.
+ * Philox draws take two stages (chunk, then element inside the chunk in the kernel's register order): orc_step.
  */
 /* 2^(f-1) on |f| <= 1/2: degree-4 minimax polynomial (relative error; max 2.7e-6 as evaluated in fp32 Horner form):
  * coefficients of 2^f with the exponent lowered by one */
@@ -195,7 +195,7 @@ static const uint32_t GLB_EXP2_D[5] = {0x3f7ffff4u - (1u << 23), 0x3f31706eu - (
                                        0x3d650a20u - (1u << 23), 0x3c1ccbebu - (1u << 23)};
 #define GLB_CHUNK 4096
 #define GLB_FRAC 36
-#define GLB_LOW_MASS_BITS 32 /* bit-masked sums below 2^32 on the row's scale are redone on their own scale */
+#define GLB_LOW_MASS_BITS 32 /* a chunk's bit-masked sum below 2^32 on the chunk's scale is redone on its own scale */
 
 static float glb_chunk_term(float x, float magicN) {
   float tm = fmaf(x, GLB_LOG2E, magicN);
