@@ -372,3 +372,38 @@ def test_peaked_rows_with_the_likely_token_forbidden(engine, oracle, dtype):
     assert np.all(np.isfinite(logZ_o)) and np.abs(logZ_o - want).max() < 2e-4 * max(1.0, np.abs(want).max() / 10), \
         np.abs(logZ_o - want).max()
     assert np.all(masks[row_of, tok_o] == 0.0)
+
+
+def test_philox_draws_follow_the_masked_distribution(engine):
+    """Statistics of the two-stage draw (chunk, then element inside the chunk in register order): token frequencies over
+    many particles match the masked softmax - through the per-particle reload path (200 000 particles on ONE shared
+    row) and through the draws made by the reducing waves (20 000 identical rows, one particle each)."""
+    dev = engine.device
+    V = 9000  # three chunks, the last one partial
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(V, generator=g) * 2.5
+    maskf = torch.where(torch.rand(V, generator=g) < 0.3, float("-inf"), 0.0)
+    p = torch.softmax((x + maskf).double(), 0).numpy()
+    bits, _ = engine.mask_to_bits(maskf[None].to(dev))
+    top = np.argsort(-p)[:60]
+
+    def check(tok, what):
+        tok = tok.cpu().numpy()
+        n = len(tok)
+        assert np.all(np.isfinite(maskf.numpy()[tok])), what  # only allowed tokens
+        cnt = np.bincount(tok, minlength=V)
+        z = (cnt[top] - n * p[top]) / np.sqrt(n * p[top] * (1 - p[top]))
+        assert np.abs(z).max() < 5.0, (what, np.abs(z).max())
+        # per chunk as well (stage 1 alone)
+        for c in range(3):
+            pc = p[c * 4096:(c + 1) * 4096].sum()
+            zc = (cnt[c * 4096:(c + 1) * 4096].sum() - n * pc) / np.sqrt(n * pc * (1 - pc))
+            assert abs(zc) < 5.0, (what, c, zc)
+
+    n1 = 200_000
+    _, _, tok = engine.step(x[None].to(dev), row_of=torch.zeros(n1, dtype=torch.int32, device=dev), mask_kind=1, mask=bits,
+                            rng_mode=1, seed=77, offset=1)
+    check(tok, "shared row")
+    n2 = 20_000
+    _, _, tok = engine.step(x[None].repeat(n2, 1).to(dev), mask_kind=1, mask=bits, rng_mode=1, seed=78, offset=1)
+    check(tok, "draws by the reducing waves")
