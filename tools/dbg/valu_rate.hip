@@ -88,6 +88,12 @@ BENCH(and_sdwa, "v_and_b32_sdwa %0, %0, %4 dst_sel:DWORD dst_unused:UNUSED_PAD s
 BENCH(pk_add, "v_pk_add_f32 %8, %8, %9\n v_pk_add_f32 %9, %9, %10\n v_pk_add_f32 %10, %10, %11\n v_pk_add_f32 %11, %11, %8\n")
 BENCH(mix8, "v_fma_f32 %12, %12, %14, %15\n v_add_u32 %0, %0, %16\n v_fma_f32 %13, %13, %14, %15\n v_and_b32 %1, %1, %16\n")
 
+BENCH(cvt_bf16, "v_cvt_f32_bf16 %12, %0\n v_cvt_f32_bf16 %13, %1\n v_cvt_f32_bf16 %14, %2\n v_cvt_f32_bf16 %15, %3\n")
+BENCH(cvt_bf16_hi, "v_cvt_f32_bf16_sdwa %12, %0 dst_sel:DWORD dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n v_cvt_f32_bf16_sdwa %13, %1 dst_sel:DWORD dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n v_cvt_f32_bf16_sdwa %14, %2 dst_sel:DWORD dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n v_cvt_f32_bf16_sdwa %15, %3 dst_sel:DWORD dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n")
+BENCH(pk_max_f16, "v_pk_max_f16 %0, %0, %4\n v_pk_max_f16 %1, %1, %5\n v_pk_max_f16 %2, %2, %6\n v_pk_max_f16 %3, %3, %7\n")
+BENCH(perm, "v_perm_b32 %0, %4, %5, %16\n v_perm_b32 %1, %5, %6, %16\n v_perm_b32 %2, %6, %7, %16\n v_perm_b32 %3, %7, %4, %16\n")
+BENCH(pk_max_i16, "v_pk_max_i16 %0, %0, %4\n v_pk_max_i16 %1, %1, %5\n v_pk_max_i16 %2, %2, %6\n v_pk_max_i16 %3, %3, %7\n")
+
 #define RUN(NAME)                                                                                           \
   for (int th : {256, 512, 1024}) {                                                                         \
     hipLaunchKernelGGL(k_##NAME, dim3(1), dim3(th), 0, 0, d, iters);                                        \
@@ -109,6 +115,7 @@ int main() {
   RUN(min_u32) RUN(sub_u32) RUN(max_f32) RUN(sub_f32) RUN(mul_f32) RUN(add_f32) RUN(fmac_f32) RUN(fmaak) RUN(cvt_i32) RUN(ashr_i32) RUN(or_b32)
   RUN(bfi) RUN(and_or) RUN(add3) RUN(med3_u32) RUN(cmp_lt) RUN(add_co_only) RUN(mul_u24) RUN(pk_fma)
   RUN(fma_clamp) RUN(max_i32) RUN(exec_add) RUN(setreg_fma) RUN(cndmask_s) RUN(lshl_b32) RUN(add_dpp) RUN(fract) RUN(and_sdwa) RUN(pk_add) RUN(mix8)
+  RUN(cvt_bf16) RUN(cvt_bf16_hi) RUN(pk_max_f16) RUN(pk_max_i16) RUN(perm)
   RUN(cvt_f64_f32) RUN(ldexp_f64) RUN(floor_f64) RUN(trunc_f64) RUN(fma_f64) RUN(cvt_f64_u32) RUN(mul_f64)
   return 0;
 }
