@@ -395,7 +395,7 @@ __device__ __forceinline__ int32_t chunk_candidate(const float (&x)[64], float m
 // ---------------------------------------------------------------------------------------------------------
 // chunk statistics: one wave per (reduction unit, chunk)
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kDrawCap = 4;  // particles per unit whose in-chunk draws ride along with the reduction
+constexpr int kDrawCap = 8;  // particles per unit whose in-chunk draws ride along with the reduction
 
 // DRAW: the call samples with Philox and the particles of a unit are known (identity, or the CSR mem_start / members):
 // while the chunk is in registers the wave also makes the in-chunk draw (second stage) of the unit's first kDrawCap
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void chunk_stats_kernel(const StepParams p) {
   const float Nc = exp_n(chunk_max(x));
   uint32_t pA, pB, pAm, pBm;
   float Nm = Nc;
-  int32_t toks[kDrawCap] = {-1, -1, -1, -1};
+  int32_t toks[kDrawCap] = {-1, -1, -1, -1, -1, -1, -1, -1};
   auto draws = [&](const float (&v)[64], bool masked_words, uint32_t ia, uint32_t ib) {
 #pragma unroll
     for (int m = 0; m < kDrawCap; ++m) {
@@ -477,9 +477,11 @@ __global__ __launch_bounds__(256) void chunk_stats_kernel(const StepParams p) {
   if (lane == 63) {
     store_rec(p.recs + (int64_t)pr * nch + c, Nc, pA, pB, pAm, pBm, Nm);
     if constexpr (DRAW) {
-      if (ncand)
-        *reinterpret_cast<u32x4_t *>(p.cands + ((int64_t)pr * nch + c) * kDrawCap) =
-            u32x4_t{(uint32_t)toks[0], (uint32_t)toks[1], (uint32_t)toks[2], (uint32_t)toks[3]};
+      if (ncand) {
+        u32x4_t *cd = reinterpret_cast<u32x4_t *>(p.cands + ((int64_t)pr * nch + c) * kDrawCap);
+        cd[0] = u32x4_t{(uint32_t)toks[0], (uint32_t)toks[1], (uint32_t)toks[2], (uint32_t)toks[3]};
+        if (ncand > 4) cd[1] = u32x4_t{(uint32_t)toks[4], (uint32_t)toks[5], (uint32_t)toks[6], (uint32_t)toks[7]};
+      }
     }
   }
 }

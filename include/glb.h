@@ -119,7 +119,7 @@ typedef struct glb_step_args {
   int32_t reserved;  /* must be 0 */
   /* Optional inverse of row_of for per-row reductions (row_of given; no mask or row_mask_id), from
      glb_row_members: the particles on row r are row_members[row_members_start[r] .. row_members_start[r + 1]).
-     With it the waves that reduce a row also make the in-chunk draws of the row's first four particles, and the
+     With it the waves that reduce a row also make the in-chunk draws of the row's first eight particles, and the
      per-particle launch only looks the token up; without it every particle redoes the chunk it lands in.  Same
      results either way. */
   const int32_t *row_members_start; /* [n_rows + 1] device, nullable */

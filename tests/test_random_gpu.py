@@ -111,7 +111,7 @@ def test_random_case(engine, oracle, c):
 
     check(call(), "auto")
     # a per-row reduction with a fan-out map gives the same bits when the inverse map is handed over (the reducing
-    # waves then make the in-chunk draws of each row's first four particles; later ones still redo their chunk)
+    # waves then make the in-chunk draws of each row's first eight particles; later ones still redo their chunk)
     per_row = c["mask_kind"] == "none" or c["form"] == "by_row"
     if per_row and row_of is not None:
         ro_d = torch.from_numpy(row_of).to(dev)
