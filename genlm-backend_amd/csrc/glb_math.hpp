@@ -223,7 +223,7 @@ __device__ __forceinline__ float chunk_term(float x, float magicN) {
 }
 
 // the integer term itself (slow paths: draws, own-scale sums): floor(t * 2^36), t < 1
-// as two words: q = (h << 18) + l, h = floor(t * 2^18) < 2^18, l < 2^18
+// the integer term itself (the draws), as two words: q = floor(t * 2^36) = (h << 18) + l, h = floor(t * 2^18), l < 2^18
 __device__ __forceinline__ void term_q_parts(float x, float magicN, uint32_t &h, uint32_t &l) {
   const float t = chunk_term(x, magicN);
   const float hi = __builtin_truncf(t * 262144.0f);             // floor(t * 2^18), exact
@@ -231,11 +231,7 @@ __device__ __forceinline__ void term_q_parts(float x, float magicN, uint32_t &h,
   asm("v_cvt_u32_f32 %0, %1" : "=v"(h) : "v"(hi));
   asm("v_cvt_u32_f32 %0, %1" : "=v"(l) : "v"(lo));
 }
-__device__ __forceinline__ uint64_t term_q(float x, float magicN) {
-  uint32_t h, l;
-  term_q_parts(x, magicN, h, l);
-  return ((uint64_t)h << kGridHi) + l;
-}
+
 
 // Accumulate four terms in round-toward-zero mode: elements 0, 2 into set 0 (A0, B0), elements 1, 3 into set 1.
 // With MASKED, the lanes named by the 64-bit lane masks M0..M3 also add the same (coarse, remainder) pair into the
@@ -304,74 +300,6 @@ __device__ __forceinline__ void rtz_acc4(float t0, float t1, float t2, float t3,
         "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
         : "+v"(A0), "+v"(B0), "+v"(A1), "+v"(B1), "=&v"(x0), "=&v"(x1), "=&v"(d0), "=&v"(d1), "=&v"(l0), "=&v"(l1)
         : "v"(t0), "v"(t1), "v"(t2), "v"(t3));
-  }
-}
-
-// Masked (coarse, remainder) sums of four terms of ONE vector, each term split against the constant 32.0 (no running
-// accumulator: every lane may skip any element).  Am / Bm start at 32.0 / 2^-13 per vector and take at most 8 terms.
-template <bool MASKED>
-__device__ __forceinline__ void rtz_vec4(float t0, float t1, float t2, float t3, float &Am, float &Bm, uint64_t M0,
-                                         uint64_t M1, uint64_t M2, uint64_t M3) {
-  float x0, x1, d0, d1, l0, l1;
-  const float a0 = __uint_as_float(kA0Bits);
-  if constexpr (MASKED) {
-    asm volatile(
-        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
-        "v_add_f32 %2, %8, %9\n\t"
-        "v_add_f32 %3, %8, %10\n\t"
-        "v_sub_f32 %4, %2, %8\n\t"
-        "v_sub_f32 %5, %3, %8\n\t"
-        "v_sub_f32 %6, %9, %4\n\t"
-        "v_sub_f32 %7, %10, %5\n\t"
-        "s_mov_b64 exec, %13\n\t"
-        "v_add_f32 %0, %0, %4\n\t"
-        "v_add_f32 %1, %1, %6\n\t"
-        "s_mov_b64 exec, %14\n\t"
-        "v_add_f32 %0, %0, %5\n\t"
-        "v_add_f32 %1, %1, %7\n\t"
-        "s_mov_b64 exec, -1\n\t"
-        "v_add_f32 %2, %8, %11\n\t"
-        "v_add_f32 %3, %8, %12\n\t"
-        "v_sub_f32 %4, %2, %8\n\t"
-        "v_sub_f32 %5, %3, %8\n\t"
-        "v_sub_f32 %6, %11, %4\n\t"
-        "v_sub_f32 %7, %12, %5\n\t"
-        "s_mov_b64 exec, %15\n\t"
-        "v_add_f32 %0, %0, %4\n\t"
-        "v_add_f32 %1, %1, %6\n\t"
-        "s_mov_b64 exec, %16\n\t"
-        "v_add_f32 %0, %0, %5\n\t"
-        "v_add_f32 %1, %1, %7\n\t"
-        "s_mov_b64 exec, -1\n\t"
-        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
-        : "+v"(Am), "+v"(Bm), "=&v"(x0), "=&v"(x1), "=&v"(d0), "=&v"(d1), "=&v"(l0), "=&v"(l1)
-        : "v"(a0), "v"(t0), "v"(t1), "v"(t2), "v"(t3), "s"(M0), "s"(M1), "s"(M2), "s"(M3));
-  } else {
-    asm volatile(
-        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
-        "v_add_f32 %2, %8, %9\n\t"
-        "v_add_f32 %3, %8, %10\n\t"
-        "v_sub_f32 %4, %2, %8\n\t"
-        "v_sub_f32 %5, %3, %8\n\t"
-        "v_sub_f32 %6, %9, %4\n\t"
-        "v_sub_f32 %7, %10, %5\n\t"
-        "v_add_f32 %0, %0, %4\n\t"
-        "v_add_f32 %1, %1, %6\n\t"
-        "v_add_f32 %0, %0, %5\n\t"
-        "v_add_f32 %1, %1, %7\n\t"
-        "v_add_f32 %2, %8, %11\n\t"
-        "v_add_f32 %3, %8, %12\n\t"
-        "v_sub_f32 %4, %2, %8\n\t"
-        "v_sub_f32 %5, %3, %8\n\t"
-        "v_sub_f32 %6, %11, %4\n\t"
-        "v_sub_f32 %7, %12, %5\n\t"
-        "v_add_f32 %0, %0, %4\n\t"
-        "v_add_f32 %1, %1, %6\n\t"
-        "v_add_f32 %0, %0, %5\n\t"
-        "v_add_f32 %1, %1, %7\n\t"
-        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
-        : "+v"(Am), "+v"(Bm), "=&v"(x0), "=&v"(x1), "=&v"(d0), "=&v"(d1), "=&v"(l0), "=&v"(l1)
-        : "v"(a0), "v"(t0), "v"(t1), "v"(t2), "v"(t3));
   }
 }
 

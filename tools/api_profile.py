@@ -6,7 +6,8 @@ import genlm_backend_amd
 from genlm_backend_amd.engine import HipEngine
 import bench
 eng = HipEngine("cuda:0")
-w = bench.ApiWorkload(eng, torch.device("cuda:0"), 0, 1, None, logprobs=len(sys.argv) > 1 and sys.argv[1] == "logprobs")
+w = bench.ApiWorkload(eng, torch.device("cuda:0"), 0, 1, None, logprobs=len(sys.argv) > 1 and sys.argv[1] == "logprobs",
+                      coro=len(sys.argv) > 1 and sys.argv[1] == "coro")
 for i in range(4):
     w.step(i, False)
 torch.cuda.synchronize()
