@@ -222,7 +222,6 @@ __device__ __forceinline__ float chunk_term(float x, float magicN) {
   return __builtin_amdgcn_ldexpf(p, np);
 }
 
-// the integer term itself (slow paths: draws, own-scale sums): floor(t * 2^36), t < 1
 // the integer term itself (the draws), as two words: q = floor(t * 2^36) = (h << 18) + l, h = floor(t * 2^18), l < 2^18
 __device__ __forceinline__ void term_q_parts(float x, float magicN, uint32_t &h, uint32_t &l) {
   const float t = chunk_term(x, magicN);
