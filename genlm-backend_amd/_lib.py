@@ -86,7 +86,9 @@ SYMBOLS = {
     "glb_kv_append": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
     "glb_kv_gather_rows": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _i32, _vp]),
     "glb_gather_rows_i32": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),
-    "glb_trie_reduce": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp]),
+    "glb_trie_workspace": (_sz, [_i64, _i64]),
+    "glb_trie_reduce": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _sz,
+                                  _vp]),
     "glb_resample_workspace": (_sz, [_i64]),
     "glb_resample_systematic": (C.c_int, [_vp, _i64, C.c_uint64, C.c_uint64, _vp, _vp, _vp, _sz, _vp]),
     "glb_mt19937_seed": (None, [C.POINTER(MT19937), C.c_uint64]),

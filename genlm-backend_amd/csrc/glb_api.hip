@@ -610,6 +610,76 @@ __global__ void trie_level_kernel(int64_t n_rows, int32_t lo, int32_t hi, const 
 
 inline unsigned blocks_for(int64_t n, int t) { return (unsigned)((n + t - 1) / t); }
 
+// ---- node-major trie propagation (batches of >= 32 rows) -----------------------------------------------------------
+// In the row-major output a node's children sit subtree sizes apart, so every child read of every row is a cache line
+// of its own.  With the values held node-major, scr[node][row], the rows of a node are contiguous: a level is one
+// coalesced sweep (each thread: one row of one node, its children's rows read from the same lines as its
+// neighbours'), the leaves go in through a 64 x 64 LDS transpose of the weight rows and the result comes out through
+// another one.  Same arithmetic per (row, node) as the row-major kernels: ascending children, double, float32 store.
+constexpr int kTrieTile = 64;
+constexpr int64_t kTrieNodeMajorRows = 32;  // below this the rows are too short a run to coalesce: row-major kernels
+
+__global__ __launch_bounds__(256) void trie_leaves_t_kernel(const float *ws, int64_t ld, int32_t n_rows, int32_t V,
+                                                             const int32_t *leaf_node, int from_logprobs, float *scr,
+                                                             int64_t pitch) {
+  __shared__ float tile[kTrieTile][kTrieTile + 1];
+  const int k0 = blockIdx.x * kTrieTile, r0 = blockIdx.y * kTrieTile;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+  for (int j = ty; j < kTrieTile; j += 4) {  // row r0 + j, token k0 + tx: coalesced over tokens
+    const int r = r0 + j, k = k0 + tx;
+    float v = 0.f;
+    if (r < n_rows && k < V) {
+      v = ws[(int64_t)r * ld + k];
+      if (from_logprobs) v = expf(v);
+    }
+    tile[j][tx] = v;
+  }
+  __syncthreads();
+  for (int j = ty; j < kTrieTile; j += 4) {  // token k0 + j, row r0 + tx: coalesced over rows
+    const int k = k0 + j, r = r0 + tx;
+    if (k < V && r < n_rows) scr[(int64_t)leaf_node[k] * pitch + r] = tile[tx][j];
+  }
+}
+
+// one workgroup per (node of the level, block of rows); a thread owns four consecutive rows (one 16-byte load per child)
+__global__ __launch_bounds__(256) void trie_level_t_kernel(int32_t rows4, int32_t lo, const int32_t *level_nodes,
+                                                            const int32_t *child_ptr, const int32_t *child_idx, int op,
+                                                            float4 *scr4) {
+  const int32_t node = level_nodes[lo + blockIdx.x];  // workgroup-uniform: scalar loads
+  const int32_t t = blockIdx.y * blockDim.x + threadIdx.x;
+  if (t >= rows4) return;
+  const int c0 = child_ptr[node], c1 = child_ptr[node + 1];
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  if (op == 0) {
+    for (int c = c0; c < c1; ++c) {
+      const float4 v = scr4[(int64_t)child_idx[c] * rows4 + t];
+      a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+    }
+  } else {
+    for (int c = c0; c < c1; ++c) {
+      const float4 v = scr4[(int64_t)child_idx[c] * rows4 + t];
+      a0 = fmax(a0, (double)v.x); a1 = fmax(a1, (double)v.y); a2 = fmax(a2, (double)v.z); a3 = fmax(a3, (double)v.w);
+    }
+  }
+  scr4[(int64_t)node * rows4 + t] = make_float4((float)a0, (float)a1, (float)a2, (float)a3);
+}
+
+__global__ __launch_bounds__(256) void trie_untranspose_kernel(const float *scr, int64_t pitch, int32_t n_rows,
+                                                                int32_t n_nodes, float *out, int64_t out_ld) {
+  __shared__ float tile[kTrieTile][kTrieTile + 1];
+  const int n0 = blockIdx.x * kTrieTile, r0 = blockIdx.y * kTrieTile;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int j = ty; j < kTrieTile; j += 4) {  // node n0 + j, row r0 + tx
+    const int nd = n0 + j, r = r0 + tx;
+    tile[j][tx] = (nd < n_nodes && r < n_rows) ? scr[(int64_t)nd * pitch + r] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < kTrieTile; j += 4) {  // row r0 + j, node n0 + tx
+    const int r = r0 + j, nd = n0 + tx;
+    if (r < n_rows && nd < n_nodes) out[(int64_t)r * out_ld + nd] = tile[tx][j];
+  }
+}
+
 // Inverse of row_of as a CSR by one workgroup: counts (global atomics into B[r + 2]), inclusive scan in place, then
 // every particle takes the next free slot of its row (atomic cursor B[r + 1], which ends as the start of row r + 1):
 // B[0 .. n_rows] finish as the offsets.  A handful of memory latencies for a few thousand particles.
@@ -1152,22 +1222,51 @@ int glb_resample_systematic(const float *log_weights, int64_t n, uint64_t seed, 
   return GLB_OK;
 }
 
+size_t glb_trie_workspace(int64_t n_rows, int64_t n_nodes) {
+  if (n_rows < kTrieNodeMajorRows || n_nodes <= 0) return 0;
+  return align256((size_t)n_nodes * (size_t)((n_rows + 63) & ~(int64_t)63) * sizeof(float));
+}
+
 int glb_trie_reduce(const float *weights, int64_t ld, int64_t n_rows, int64_t vocab, int64_t n_nodes, int64_t n_levels,
                     const int32_t *leaf_node, const int32_t *level_start_host, const int32_t *level_nodes,
                     const int32_t *child_ptr, const int32_t *child_idx, int32_t op, int32_t from_logprobs, float *out,
-                    int64_t out_ld, void *stream) {
+                    int64_t out_ld, void *workspace, size_t workspace_bytes, void *stream) {
   if (!weights || !leaf_node || !level_start_host || !level_nodes || !child_ptr || !child_idx || !out)
     return fail(GLB_EINVAL, "null pointer");
   if (n_rows <= 0 || vocab <= 0 || n_nodes <= vocab || n_levels <= 0 || ld < vocab || out_ld < n_nodes)
     return fail(GLB_EINVAL, "bad sizes");
-  if (vocab > 0x7fffff00ll || n_nodes > 0x7fffff00ll) return fail(GLB_EINVAL, "size exceeds 31 bits");
+  if (vocab > 0x7fffff00ll || n_nodes > 0x7fffff00ll || n_rows > 0x7fffff00ll) return fail(GLB_EINVAL, "size exceeds 31 bits");
   if (op != GLB_TRIE_SUM && op != GLB_TRIE_MAX) return fail(GLB_EINVAL, "bad op %d", op);
+  for (int64_t d = 0; d < n_levels; ++d)
+    if (level_start_host[d + 1] < level_start_host[d] || level_start_host[d + 1] > n_nodes)
+      return fail(GLB_EINVAL, "level_start is not a monotone partition");
   hipStream_t s = (hipStream_t)stream;
+  if (n_rows >= kTrieNodeMajorRows && workspace && workspace_bytes >= glb_trie_workspace(n_rows, n_nodes) &&
+      ((uintptr_t)workspace) % 16 == 0) {  // node-major values: every level is a coalesced sweep
+    float *scr = (float *)workspace;
+    const int64_t pitch = (n_rows + 63) & ~(int64_t)63;
+    const dim3 tg(blocks_for(vocab, kTrieTile), blocks_for(n_rows, kTrieTile));
+    hipLaunchKernelGGL(trie_leaves_t_kernel, tg, dim3(256), 0, s, weights, ld, (int32_t)n_rows, (int32_t)vocab, leaf_node,
+                       (int)from_logprobs, scr, pitch);
+    for (int64_t d = 0; d < n_levels; ++d) {
+      const int32_t lo = level_start_host[d], hi = level_start_host[d + 1];
+      if (hi == lo) continue;
+      const int32_t rows4 = (int32_t)(pitch / 4);  // the padding rows of scr are computed too (never read back)
+      const int bt = rows4 < 256 ? (rows4 + 63) & ~63 : 256;
+      hipLaunchKernelGGL(trie_level_t_kernel, dim3((unsigned)(hi - lo), blocks_for(rows4, bt)), dim3(bt), 0, s, rows4, lo,
+                         level_nodes, child_ptr, child_idx, (int)op, (float4 *)scr);
+    }
+    const dim3 ug(blocks_for(n_nodes, kTrieTile), blocks_for(n_rows, kTrieTile));
+    hipLaunchKernelGGL(trie_untranspose_kernel, ug, dim3(256), 0, s, scr, pitch, (int32_t)n_rows, (int32_t)n_nodes, out,
+                       out_ld);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "trie_reduce launch");
+    return GLB_OK;
+  }
   hipLaunchKernelGGL(trie_leaves_kernel, dim3(blocks_for(n_rows * vocab, 256)), dim3(256), 0, s, weights, ld, n_rows,
                      (int32_t)vocab, leaf_node, (int)from_logprobs, out, out_ld);
   for (int64_t d = 0; d < n_levels; ++d) {  // one launch per tree level, all rows
     const int32_t lo = level_start_host[d], hi = level_start_host[d + 1];
-    if (hi < lo || hi > n_nodes) return fail(GLB_EINVAL, "level_start is not a monotone partition");
     if (hi == lo) continue;
     hipLaunchKernelGGL(trie_level_kernel, dim3(blocks_for(n_rows * (hi - lo), 256)), dim3(256), 0, s, n_rows, lo, hi,
                        level_nodes, child_ptr, child_idx, (int)op, out, out_ld);

@@ -58,6 +58,7 @@ class HipEngine:
             raise RuntimeError(f"HipEngine device must be a HIP device, got {self.device}")
         self._ws = None
         self._step_ws = None
+        self._trie_ws = None
 
     # ------------------------------------------------------------------------------------------
     def _stream(self):
@@ -326,8 +327,12 @@ class HipEngine:
         if out is None:
             out = torch.empty((B, n_nodes), dtype=torch.float32, device=self.device)
         ls = flat["level_start_host"]  # contiguous int32 NumPy array: it sizes the per-level launches
+        need = self.lib.glb_trie_workspace(B, n_nodes)  # node-major scratch for batches of 32 rows and more
+        if need and (self._trie_ws is None or self._trie_ws.numel() < need):
+            self._trie_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         check(self.lib.glb_trie_reduce(_ptr(ws), ws.stride(0) if B > 1 else max(V, ws.stride(0)), B, V, n_nodes,
                                        flat["n_levels"], _ptr(flat["leaf_node"]), C.c_void_p(ls.ctypes.data),
                                        _ptr(flat["level_nodes"]), _ptr(flat["child_ptr"]), _ptr(flat["child_idx"]), op,
-                                       1 if from_logprobs else 0, _ptr(out), out.stride(0), self._stream()))
+                                       1 if from_logprobs else 0, _ptr(out), out.stride(0),
+                                       _ptr(self._trie_ws) if need else None, need, self._stream()))
         return out

@@ -297,13 +297,16 @@ int glb_resample_systematic(const float *log_weights, int64_t n, uint64_t seed, 
  * out[r, node] = the value as float32; a node's children are added in ascending order in double and the result is
  * rounded to float32 per node (the reference keeps doubles: agreement to ~1e-7 relative per level).
  * from_logprobs != 0: weights = exp(row).  GLB_TRIE_MAX floors internal nodes at 0 like the reference (:385).
- * One launch for the leaves + one per tree level, all rows each; no scratch.
+ * One launch for the leaves + one per tree level, all rows each.  Batches of 32 rows or more run on node-major
+ * values (coalesced levels) if the caller lends glb_trie_workspace(n_rows, n_nodes) bytes of device scratch (16-byte
+ * aligned; workspace may be null: the row-major kernels then serve any batch, a few times slower for large ones).
  */
 enum { GLB_TRIE_SUM = 0, GLB_TRIE_MAX = 1 };
+size_t glb_trie_workspace(int64_t n_rows, int64_t n_nodes);
 int glb_trie_reduce(const float *weights, int64_t ld, int64_t n_rows, int64_t vocab, int64_t n_nodes, int64_t n_levels,
                     const int32_t *leaf_node, const int32_t *level_start_host, const int32_t *level_nodes,
                     const int32_t *child_ptr, const int32_t *child_idx, int32_t op, int32_t from_logprobs, float *out,
-                    int64_t out_ld, void *hip_stream);
+                    int64_t out_ld, void *workspace, size_t workspace_bytes, void *hip_stream);
 
 /*
  * Host helper for GLB_RNG_NOISE: fills out[0..n) with the float32 Exp(1) variates

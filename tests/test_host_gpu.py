@@ -298,7 +298,9 @@ def test_trie_masses_on_gpu(engine, oracle, tag):
 
 
 def test_trie_masses_large_vocabulary(engine, oracle):
-    """gpt2-sized vocabulary of synthetic byte strings, 64 weight rows: kernel == oracle bit for bit, root == row sum."""
+    """gpt2-sized vocabulary of synthetic byte strings: kernel == oracle bit for bit, root == row sum - 70 rows (node-major
+    values, a row count that is not a multiple of the transpose tile), 40 and 8 rows for the maximum (node-major and
+    row-major kernels)."""
     from genlm_backend_amd.tokenization import Token
     from genlm_backend_amd.trie import TokenByteTrie
 
@@ -310,13 +312,15 @@ def test_trie_masses_large_vocabulary(engine, oracle):
             seen.add(w)
             words.append(w)
     trie = TokenByteTrie([Token(i, w) for i, w in enumerate(words)], engine=engine)
-    ws = rs.random((64, len(words))).astype(np.float32)
+    ws = rs.random((70, len(words))).astype(np.float32)
     ws /= ws.sum(-1, keepdims=True)
     got = trie.batch_weight_sum(torch.from_numpy(ws))
     assert np.array_equal(got.view(np.uint32), oracle.trie_reduce(ws, trie.flat(), 0).view(np.uint32))
     assert np.abs(got[:, trie.root] - 1.0).max() < 1e-6
-    gm = trie.batch_weight_max(torch.from_numpy(ws[:8]))
-    assert np.array_equal(gm.view(np.uint32), oracle.trie_reduce(ws[:8], trie.flat(), 1).view(np.uint32))
+    assert np.array_equal(trie.batch_weight_sum(torch.from_numpy(ws[:5])), got[:5])  # row-major kernels: same bits
+    for nb in (40, 8):
+        gm = trie.batch_weight_max(torch.from_numpy(ws[:nb]))
+        assert np.array_equal(gm.view(np.uint32), oracle.trie_reduce(ws[:nb], trie.flat(), 1).view(np.uint32))
 
 
 @pytest.mark.parametrize("K,mode", [(1, "prefix"), (8, "plain"), (8, "pkv"), (64, "prefix"), (64, "pkv")])
