@@ -407,3 +407,40 @@ def test_philox_draws_follow_the_masked_distribution(engine):
     n2 = 20_000
     _, _, tok = engine.step(x[None].repeat(n2, 1).to(dev), mask_kind=1, mask=bits, rng_mode=1, seed=78, offset=1)
     check(tok, "draws by the reducing waves")
+
+
+@pytest.mark.parametrize("B,V,dtype", [(1024, 50257, torch.float32), (512, 128256, torch.bfloat16)])
+def test_full_size_properties(engine, B, V, dtype):
+    """BASELINE configs 2 and 5 at full size through properties that need no oracle: complementary masks split the mass
+    (exp(logZ_A) + exp(logZ_B) = 1), an all-allowing mask gives logZ = 0 exactly, rows can be permuted and the call split
+    into shards (particle_base) without changing a bit, duplicate rows agree, every drawn token is allowed."""
+    dev = engine.device
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = (torch.randn((B, V), device=dev, generator=g) * 3).to(dtype)
+    x[5] = x[900 % B]  # a duplicate row
+    allow = torch.rand((1, V), device=dev, generator=g) < 0.4
+    maskf = torch.cat([torch.where(allow, 0.0, float("-inf")), torch.where(allow, float("-inf"), 0.0),
+                       torch.zeros((1, V), device=dev)])
+    bits, _ = engine.mask_to_bits(maskf)
+    prep = engine.prepare_masks(bits, V, dtype)
+    ids = lambda k: torch.full((B,), k, dtype=torch.int32, device=dev)
+    zA, lse, tokA = engine.step(x, mask=prep, row_mask_id=ids(0), rng_mode=1, seed=5, offset=9)
+    zB, _, tokB = engine.step(x, mask=prep, row_mask_id=ids(1), rng_mode=1, seed=5, offset=9)
+    z1, lse1, _ = engine.step(x, mask=prep, row_mask_id=ids(2), rng_mode=1, seed=5, offset=9)
+    torch.cuda.synchronize()
+    assert torch.all(z1 == 0.0) and torch.equal(lse1, lse)
+    assert (torch.logaddexp(zA.double(), zB.double())).abs().max().item() < 1e-5
+    assert torch.equal(lse[5], lse[900 % B]) and torch.equal(zA[5], zA[900 % B])
+    am = allow[0]
+    assert bool(am[tokA.long()].all()) and not bool(am[tokB.long()].any())
+    ref = torch.logsumexp(x.double(), -1)
+    assert (lse.double() - ref).abs().max().item() < 1e-4
+    # shards: two calls with particle_base == one call
+    h = B // 2
+    outs = [engine.step(x[s:s + h], mask=prep, row_mask_id=ids(0)[s:s + h], rng_mode=1, seed=5, offset=9, particle_base=s)
+            for s in (0, h)]
+    assert torch.equal(torch.cat([o[0] for o in outs]), zA) and torch.equal(torch.cat([o[2] for o in outs]), tokA)
+    # permutation of the rows: statistics follow bit for bit
+    perm = torch.randperm(B, device=dev, generator=g)
+    zP, lseP, _ = engine.step(x[perm].contiguous(), mask=prep, row_mask_id=ids(0), rng_mode=0)
+    assert torch.equal(zP, zA[perm]) and torch.equal(lseP, lse[perm])
