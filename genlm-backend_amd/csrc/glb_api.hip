@@ -142,6 +142,44 @@ __device__ inline bool same_ctx(const int32_t *tok, const int64_t *st, const int
   return true;
 }
 
+__device__ inline uint64_t ctx_hash_step(uint64_t h, uint32_t v) {
+  h ^= v;
+  h *= 0x100000001b3ull;
+  return h ^ (h >> 29);
+}
+
+// Hash of every context, one thread each, as many workgroups as it takes.  What bounds context hashing is cache lines
+// touched per load instruction (every lane reads another context: 64 lines per instruction whatever the width), so
+// four tokens come in one 16-byte load (element-aligned only, like the logits rows) and - the point of a kernel of
+// its own - the lines are spread over many CUs' L1s instead of one.
+__global__ __launch_bounds__(256) void hash_contexts_kernel(const int32_t *tok, const int64_t *st, const int32_t *len,
+                                                             int32_t n, uint64_t *out_hash) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t li = len[i];
+  const int32_t *t = tok + st[i];
+  uint64_t h = 0xcbf29ce484222325ull ^ (uint64_t)li;
+  int j = 0;
+  for (; j + 4 <= li; j += 4) {
+    const glb::u32x4_t w = *reinterpret_cast<const glb::u32x4_t *>(t + j);
+    h = ctx_hash_step(ctx_hash_step(ctx_hash_step(ctx_hash_step(h, w.x), w.y), w.z), w.w);
+  }
+  for (; j < li; ++j) h = ctx_hash_step(h, (uint32_t)t[j]);
+  out_hash[i] = h;
+}
+
+// token comparison with 16-byte loads (used after the hashes and lengths were found equal: true duplicates)
+__device__ inline bool same_tokens(const int32_t *a, const int32_t *b, int32_t li) {
+  int j = 0;
+  for (; j + 4 <= li; j += 4) {
+    const glb::u32x4_t x = *reinterpret_cast<const glb::u32x4_t *>(a + j), y = *reinterpret_cast<const glb::u32x4_t *>(b + j);
+    if (((x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w)) != 0u) return false;
+  }
+  for (; j < li; ++j)
+    if (a[j] != b[j]) return false;
+  return true;
+}
+
 // Exact dedup in first-appearance order, one 1024-thread workgroup (n is a particle count, the
 // whole job is a few microseconds of integer work; a single workgroup needs no grid-level sync).
 // Open-addressing table keyed by full token comparison: the slot owner is whichever context won
@@ -209,11 +247,13 @@ __global__ __launch_bounds__(1024) void group_contexts_kernel(
 // no global-memory atomics and no table in the workspace to clear: each thread keeps its contexts' slots in
 // registers, tokens are fetched with independent loads before they are hashed, and the only global traffic besides
 // the tokens is the output.  One workgroup: the whole job is a handful of memory latencies.
-template <int PER>
+// HASHED: the hashes come from hash_contexts_kernel (populations above 1024: the table phase then touches tokens only
+// to confirm true duplicates); otherwise the kernel hashes its contexts itself (one launch for small populations).
+template <int PER, bool HASHED>
 __global__ __launch_bounds__(1024) void group_contexts_lds_kernel(const int32_t *tok, const int64_t *st,
                                                                    const int32_t *len, int32_t n, int32_t cap,
                                                                    int32_t *out_group_of, int32_t *out_rep,
-                                                                   int32_t *out_n_groups) {
+                                                                   int32_t *out_n_groups, const uint64_t *hash_in) {
   extern __shared__ int32_t s_dyn[];
   int32_t *s_table = s_dyn, *s_min = s_dyn + cap;
   __shared__ int32_t s_wave[16];
@@ -233,8 +273,15 @@ __global__ __launch_bounds__(1024) void group_contexts_lds_kernel(const int32_t 
     si[k] = i < n ? st[i] : 0;
     h[k] = 0xcbf29ce484222325ull ^ (uint64_t)li[k];
   }
+  if constexpr (HASHED) {
 #pragma unroll
-  for (int k = 0; k < PER; ++k) {
+    for (int k = 0; k < PER; ++k) {
+      const int i = tid * PER + k;
+      if (i < n) h[k] = hash_in[i];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < (HASHED ? 0 : PER); ++k) {
     const int32_t *t = tok + si[k];
     int j = 0;
     for (; j + 4 <= li[k]; j += 4) {  // four independent loads per trip
@@ -257,7 +304,12 @@ __global__ __launch_bounds__(1024) void group_contexts_lds_kernel(const int32_t 
       int32_t s = (int32_t)(h[k] & (uint64_t)(cap - 1));
       for (;;) {
         const int32_t owner = atomicCAS(&s_table[s], -1, i);
-        if (owner == -1 || owner == i || same_ctx(tok, st, len, owner, i)) break;
+        if (owner == -1 || owner == i) break;
+        if constexpr (HASHED) {
+          if (hash_in[owner] == h[k] && len[owner] == li[k] && same_tokens(tok + si[k], tok + st[owner], li[k])) break;
+        } else {
+          if (same_ctx(tok, st, len, owner, i)) break;
+        }
         s = (s + 1) & (cap - 1);
       }
       slot[k] = s;
@@ -1005,7 +1057,7 @@ static int64_t group_cap(int64_t n) {
 
 size_t glb_group_contexts_workspace(int64_t n) {
   if (n <= 0) return 0;
-  return (size_t)(2 * group_cap(n) + 2 * n) * sizeof(int32_t);
+  return (size_t)(2 * group_cap(n) + 2 * n) * sizeof(int32_t) + (size_t)n * sizeof(uint64_t) + 8;
 }
 
 int glb_group_contexts(const int32_t *tokens, const int64_t *starts, const int32_t *lengths,
@@ -1019,25 +1071,32 @@ int glb_group_contexts(const int32_t *tokens, const int64_t *starts, const int32
   const int64_t cap = group_cap(n);
   if (n <= 8192) {  // table in LDS (2 * cap ints <= 128 KiB), slots in registers
     const size_t lds = (size_t)cap * 2 * sizeof(int32_t);
-    if (n > 4096) {
-      static bool big_lds = false;  // more than 64 KiB of dynamic LDS has to be allowed once per process
-      if (!big_lds) {
-        if (hipFuncSetAttribute((const void *)group_contexts_lds_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                128 * 1024) != hipSuccess)
-          return hip_fail(hipGetLastError(), "hipFuncSetAttribute(group_contexts)");
-        big_lds = true;
+    hipStream_t s = (hipStream_t)stream;
+    if (n <= 1024) {  // one launch, the workgroup hashes its own contexts
+      hipLaunchKernelGGL((group_contexts_lds_kernel<1, false>), dim3(1), dim3(1024), lds, s, tokens, starts, lengths,
+                         (int32_t)n, (int32_t)cap, out_group_of, out_rep, out_n_groups, (const uint64_t *)nullptr);
+    } else {  // hashes by as many workgroups as it takes (many L1s), then the table
+      uint64_t *hashes = (uint64_t *)((char *)workspace + (size_t)(2 * cap + 2 * n) * sizeof(int32_t));
+      hipLaunchKernelGGL(hash_contexts_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, tokens, starts, lengths,
+                         (int32_t)n, hashes);
+      if (n > 4096) {
+        static bool big_lds = false;  // more than 64 KiB of dynamic LDS has to be allowed once per process
+        if (!big_lds) {
+          if (hipFuncSetAttribute((const void *)group_contexts_lds_kernel<8, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+            return hip_fail(hipGetLastError(), "hipFuncSetAttribute(group_contexts)");
+          big_lds = true;
+        }
+        hipLaunchKernelGGL((group_contexts_lds_kernel<8, true>), dim3(1), dim3(1024), lds, s, tokens, starts, lengths,
+                           (int32_t)n, (int32_t)cap, out_group_of, out_rep, out_n_groups, hashes);
+      } else if (n <= 2048) {
+        hipLaunchKernelGGL((group_contexts_lds_kernel<2, true>), dim3(1), dim3(1024), lds, s, tokens, starts, lengths,
+                           (int32_t)n, (int32_t)cap, out_group_of, out_rep, out_n_groups, hashes);
+      } else {
+        hipLaunchKernelGGL((group_contexts_lds_kernel<4, true>), dim3(1), dim3(1024), lds, s, tokens, starts, lengths,
+                           (int32_t)n, (int32_t)cap, out_group_of, out_rep, out_n_groups, hashes);
       }
-      hipLaunchKernelGGL(group_contexts_lds_kernel<8>, dim3(1), dim3(1024), lds, (hipStream_t)stream, tokens, starts,
-                         lengths, (int32_t)n, (int32_t)cap, out_group_of, out_rep, out_n_groups);
-    } else if (n <= 1024)
-      hipLaunchKernelGGL(group_contexts_lds_kernel<1>, dim3(1), dim3(1024), lds, (hipStream_t)stream, tokens, starts,
-                         lengths, (int32_t)n, (int32_t)cap, out_group_of, out_rep, out_n_groups);
-    else if (n <= 2048)
-      hipLaunchKernelGGL(group_contexts_lds_kernel<2>, dim3(1), dim3(1024), lds, (hipStream_t)stream, tokens, starts,
-                         lengths, (int32_t)n, (int32_t)cap, out_group_of, out_rep, out_n_groups);
-    else
-      hipLaunchKernelGGL(group_contexts_lds_kernel<4>, dim3(1), dim3(1024), lds, (hipStream_t)stream, tokens, starts,
-                         lengths, (int32_t)n, (int32_t)cap, out_group_of, out_rep, out_n_groups);
+    }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "group_contexts launch");
     return GLB_OK;
