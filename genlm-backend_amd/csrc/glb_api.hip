@@ -743,9 +743,19 @@ __global__ __launch_bounds__(1024) void row_members_kernel(const int32_t *row_of
   for (int i = tid; i < n_rows + 2; i += 1024) B[i] = 0;
   if (tid == 0) s_carry = 0;
   __syncthreads();
-  for (int i = tid; i < n; i += 1024) {
-    const int r = row_of[i];
-    if (r >= 0 && r < n_rows) atomicAdd(&B[r + 2], 1);
+  // (a wave whose lanes all sit on one row - SIS step 0, a freshly resampled population - sends ONE atomic: 1024
+  //  particles on one counter are otherwise 1024 serialised round trips, 37 us)
+  for (int i0 = 0; i0 < n; i0 += 1024) {
+    const int i = i0 + tid;
+    const int r = i < n ? row_of[i] : -1;
+    const bool ok = r >= 0 && r < n_rows;
+    const int r0 = __builtin_amdgcn_readfirstlane(r);
+    const uint64_t okm = __ballot(ok), same = __ballot(ok && r == r0);
+    if (okm != 0 && same == okm) {
+      if (lane == __ffsll((long long)okm) - 1) atomicAdd(&B[r + 2], __popcll(okm));
+    } else if (ok) {
+      atomicAdd(&B[r + 2], 1);
+    }
   }
   __syncthreads();
   int mx = 0;
@@ -786,9 +796,21 @@ __global__ __launch_bounds__(1024) void row_members_kernel(const int32_t *row_of
     }
   }
   __syncthreads();
-  for (int i = tid; i < n; i += 1024) {
-    const int r = row_of[i];
-    if (r >= 0 && r < n_rows) members[atomicAdd(&B[r + 1], 1)] = i;
+  for (int i0 = 0; i0 < n; i0 += 1024) {
+    const int i = i0 + tid;
+    const int r = i < n ? row_of[i] : -1;
+    const bool ok = r >= 0 && r < n_rows;
+    const int r0 = __builtin_amdgcn_readfirstlane(r);
+    const uint64_t okm = __ballot(ok), same = __ballot(ok && r == r0);
+    if (okm != 0 && same == okm) {
+      const int leader = __ffsll((long long)okm) - 1;
+      int base = 0;
+      if (lane == leader) base = atomicAdd(&B[r + 1], __popcll(okm));
+      base = __builtin_amdgcn_readlane(base, leader);
+      if (ok) members[base + __popcll(okm & ((1ull << lane) - 1ull))] = i;
+    } else if (ok) {
+      members[atomicAdd(&B[r + 1], 1)] = i;
+    }
   }
 }
 

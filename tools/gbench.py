@@ -28,3 +28,5 @@ for n in (1024, 4096, 16384):
     bufs = (torch.empty(n + 2, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev),
             torch.empty(1, dtype=torch.int32, device=dev))
     print(f"row_members n={n}: {t(lambda: eng.row_members(ro, n, out=bufs)):.1f} us", flush=True)
+    z = torch.zeros(n, dtype=torch.int32, device=dev)
+    print(f"row_members n={n}, one row: {t(lambda: eng.row_members(z, n, out=bufs)):.1f} us", flush=True)
