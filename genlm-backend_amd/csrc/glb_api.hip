@@ -122,16 +122,6 @@ __global__ void mask_to_bits_kernel(const float *mask, int64_t n_masks, int64_t 
   if (nb && nonbinary) *nonbinary = 1;
 }
 
-__device__ inline uint64_t hash_ctx(const int32_t *t, int64_t len) {
-  uint64_t h = 0xcbf29ce484222325ull ^ (uint64_t)len;
-  for (int64_t i = 0; i < len; ++i) {
-    h ^= (uint32_t)t[i];
-    h *= 0x100000001b3ull;
-    h ^= h >> 29;
-  }
-  return h;
-}
-
 __device__ inline bool same_ctx(const int32_t *tok, const int64_t *st, const int32_t *len, int64_t i,
                                 int64_t j) {
   const int64_t li = len[i];
@@ -180,36 +170,61 @@ __device__ inline bool same_tokens(const int32_t *a, const int32_t *b, int32_t l
   return true;
 }
 
-// Exact dedup in first-appearance order, one 1024-thread workgroup (n is a particle count, the
-// whole job is a few microseconds of integer work; a single workgroup needs no grid-level sync).
-// Open-addressing table keyed by full token comparison: the slot owner is whichever context won
-// the CAS, the group representative is the minimum index that reached the slot (order independent).
-__global__ __launch_bounds__(1024) void group_contexts_kernel(
-    const int32_t *tok, const int64_t *st, const int32_t *len, int32_t n, int32_t cap, int32_t *table,
-    int32_t *minidx, int32_t *slot_of, int32_t *gid_of, int32_t *out_group_of, int32_t *out_rep,
-    int32_t *out_n_groups) {
-  const int T = 1024, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  __shared__ int32_t s_wave[16];
-  __shared__ int32_t s_carry;
-  for (int i = tid; i < cap; i += T) {
+// ---- populations above 8192 contexts: the table lives in the workspace and every phase but the numbering runs on as
+// many workgroups as it takes.  Who wins a slot depends on timing; the result does not (a group's representative is the
+// minimum index that reached its slot, ids follow first appearance).
+__global__ __launch_bounds__(256) void group_init_kernel(int32_t cap, int32_t *table, int32_t *minidx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cap) {
     table[i] = -1;
     minidx[i] = 0x7fffffff;
   }
-  if (tid == 0) s_carry = 0;
-  __syncthreads();
-  for (int i = tid; i < n; i += T) {
-    const uint64_t h = hash_ctx(tok + st[i], len[i]);
-    int32_t slot = (int32_t)(h & (uint64_t)(cap - 1));
+}
+
+__global__ __launch_bounds__(256) void group_insert_kernel(const int32_t *tok, const int64_t *st, const int32_t *len,
+                                                            int32_t n, int32_t cap, const uint64_t *hashes,
+                                                            int32_t *table, int32_t *minidx, int32_t *slot_of) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t h = hashes[i];
+  const int32_t li = len[i];
+  const int64_t si = st[i];
+  const int32_t *mine = tok + si;
+  // A wave whose contexts are all the same one (SIS step 0, a freshly resampled population) sends its first lane
+  // alone: 16 384 CAS + atomicMin on ONE address are otherwise 16 384 serialised round trips (0.4 ms).
+  const uint32_t h0l = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)h);
+  const uint32_t h0h = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(h >> 32));
+  const int32_t l0 = __builtin_amdgcn_readfirstlane(li);
+  const uint32_t s0l = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)si);
+  const uint32_t s0h = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)si >> 32));
+  const int64_t si0 = (int64_t)(((uint64_t)s0h << 32) | s0l);
+  const bool like_first = h == (((uint64_t)h0h << 32) | h0l) && li == l0 && (si == si0 || same_tokens(mine, tok + si0, li));
+  const uint64_t act = __ballot(true);
+  const bool all_same = __ballot(like_first) == act;
+  const int leader = __ffsll((long long)act) - 1, lane = threadIdx.x & 63;
+  int32_t slot = (int32_t)(h & (uint64_t)(cap - 1));
+  if (!all_same || lane == leader) {
     for (;;) {
       const int32_t owner = atomicCAS(&table[slot], -1, i);
-      if (owner == -1 || owner == i || same_ctx(tok, st, len, owner, i)) break;
+      if (owner == -1 || owner == i) break;
+      if (hashes[owner] == h && len[owner] == li && same_tokens(mine, tok + st[owner], li)) break;
       slot = (slot + 1) & (cap - 1);
     }
-    slot_of[i] = slot;
-    atomicMin(&minidx[slot], i);
+    atomicMin(&minidx[slot], i);  // the leader has the wave's smallest index
   }
+  if (all_same) slot = __builtin_amdgcn_readlane(slot, leader);
+  slot_of[i] = slot;
+}
+
+// group ids in first-appearance order: one workgroup scans the representative flags tile by tile
+__global__ __launch_bounds__(1024) void group_number_kernel(int32_t n, const int32_t *minidx, const int32_t *slot_of,
+                                                             int32_t *gid_of, int32_t *out_group_of, int32_t *out_rep,
+                                                             int32_t *out_n_groups) {
+  const int T = 1024, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ int32_t s_wave[16];
+  __shared__ int32_t s_carry;
+  if (tid == 0) s_carry = 0;
   __syncthreads();
-  // exclusive scan of is_rep flags in chunks of T -> group ids in first-appearance order
   for (int base = 0; base < n; base += T) {
     const int i = base + tid;
     const int32_t flag = (i < n && minidx[slot_of[i]] == i) ? 1 : 0;
@@ -242,11 +257,10 @@ __global__ __launch_bounds__(1024) void group_contexts_kernel(
   for (int i = tid; i < n; i += T) out_group_of[i] = gid_of[minidx[slot_of[i]]];
 }
 
-// Exact dedup with the hash table in LDS (n <= 4096 contexts: every launch of the BASELINE configurations).  Same
-// result as group_contexts_kernel - groups numbered by first appearance, representative = smallest index - but
-// no global-memory atomics and no table in the workspace to clear: each thread keeps its contexts' slots in
-// registers, tokens are fetched with independent loads before they are hashed, and the only global traffic besides
-// the tokens is the output.  One workgroup: the whole job is a handful of memory latencies.
+// Exact dedup with the hash table in LDS (n <= 8192 contexts: every launch of the BASELINE configurations): groups
+// numbered by first appearance, representative = smallest index; no global-memory atomics and no table in the
+// workspace to clear: each thread keeps its contexts' slots in registers, and the only global traffic besides the
+// tokens (or their hashes) is the output.  One workgroup: the whole job is a handful of memory latencies.
 // HASHED: the hashes come from hash_contexts_kernel (populations above 1024: the table phase then touches tokens only
 // to confirm true duplicates); otherwise the kernel hashes its contexts itself (one launch for small populations).
 template <int PER, bool HASHED>
@@ -1123,11 +1137,16 @@ int glb_group_contexts(const int32_t *tokens, const int64_t *starts, const int32
     if (e != hipSuccess) return hip_fail(e, "group_contexts launch");
     return GLB_OK;
   }
-  int32_t *table = (int32_t *)workspace, *minidx = table + cap, *slot_of = minidx + cap,
-          *gid_of = slot_of + n;
-  hipLaunchKernelGGL(group_contexts_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, tokens,
-                     starts, lengths, (int32_t)n, (int32_t)cap, table, minidx, slot_of, gid_of,
-                     out_group_of, out_rep, out_n_groups);
+  int32_t *table = (int32_t *)workspace, *minidx = table + cap, *slot_of = minidx + cap, *gid_of = slot_of + n;
+  uint64_t *hashes = (uint64_t *)(gid_of + n);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(group_init_kernel, dim3(blocks_for(cap, 256)), dim3(256), 0, s, (int32_t)cap, table, minidx);
+  hipLaunchKernelGGL(hash_contexts_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, tokens, starts, lengths, (int32_t)n,
+                     hashes);
+  hipLaunchKernelGGL(group_insert_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, tokens, starts, lengths, (int32_t)n,
+                     (int32_t)cap, hashes, table, minidx, slot_of);
+  hipLaunchKernelGGL(group_number_kernel, dim3(1), dim3(1024), 0, s, (int32_t)n, minidx, slot_of, gid_of, out_group_of,
+                     out_rep, out_n_groups);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "group_contexts launch");
   return GLB_OK;

@@ -19,7 +19,8 @@ def _dev(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
-@pytest.mark.parametrize("n,distinct", [(1, 1), (7, 3), (1024, 1), (1024, 37), (5000, 4000), (3000, 3000)])
+@pytest.mark.parametrize("n,distinct", [(1, 1), (7, 3), (1024, 1), (1024, 37), (5000, 4000), (3000, 3000), (2000, 1),
+                                        (9000, 2), (20000, 15000)])
 def test_group_contexts(engine, oracle, n, distinct):
     ctxs = synth.contexts(n + distinct, n, distinct, lo=0, hi=18)
     tok, st, ln = oracle.ragged(ctxs)
