@@ -841,24 +841,41 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
       const float *E = p.noise + (int64_t)pidx * p.noise_ld;
       float best = -1.0f, sec = -1.0f;  // sec: runner-up of the race (for the reported margin)
       int32_t bj = -1;
-      for (int c = 0; c < nch; ++c)
-        for (int i = wave; i < NVC; i += 4) {
-          if (c * kChunk + i * 64 * EPV >= V) break;
-          float y[EPV];
-          int e0;
-          rv.vec(c, i, lane, y, e0);
+      constexpr int NVW = NVC / 4;  // this wave's vectors of a chunk: all their loads (logits, mask, noise) go out first
+      for (int c = 0; c < nch; ++c) {
+        float y[NVW][EPV];
+        int e0[NVW];
+        u32x4_t en[NVW][EPV / 4];
+#pragma unroll
+        for (int jv = 0; jv < NVW; ++jv) {
+          const int i = wave + 4 * jv;
+          e0[jv] = V;
+          if (c * kChunk + i * 64 * EPV < V) {  // wave-uniform
+            rv.vec(c, i, lane, y[jv], e0[jv]);
+#pragma unroll
+            for (int h = 0; h < EPV / 4; ++h) {
+              const int eh = e0[jv] + 4 * h;
+              en[jv][h] = load_vec_guarded<kDtF32>((const char *)E, eh < V ? eh : V, V);
+            }
+          }
+        }
+#pragma unroll
+        for (int jv = 0; jv < NVW; ++jv) {
+          if (c * kChunk + (wave + 4 * jv) * 64 * EPV >= V) break;
 #pragma unroll
           for (int k = 0; k < EPV; ++k) {
-            const int j = e0 + k;
-            const bool ok = j < V && y[k] > kNegInf;
-            const float e = chunk_term(y[k], magicN);
-            const float g = ok ? e / E[ok ? j : 0] : -1.0f;
+            const int j = e0[jv] + k;
+            const bool ok = j < V && y[jv][k] > kNegInf;
+            const float e = chunk_term(y[jv][k], magicN);
+            const uint32_t eb = k % 4 == 0 ? en[jv][k / 4].x : (k % 4 == 1 ? en[jv][k / 4].y : (k % 4 == 2 ? en[jv][k / 4].z : en[jv][k / 4].w));
+            const float g = ok ? e / __uint_as_float(eb) : -1.0f;
             const bool better = g > best;  // strict: the first maximum in this lane's (increasing) order stays
             sec = better ? best : fmaxf(sec, g);
             best = better ? g : best;
             bj = better ? j : bj;
           }
         }
+      }
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
         const float og = __shfl_xor(best, o, 64), os = __shfl_xor(sec, o, 64);
