@@ -960,7 +960,7 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
   } else if (a->mask_kind != GLB_MASK_NONE) {
     kmask = glb::kMaskBits;
     const char *prep = (const char *)a->mask;
-    if (own_prep) {  // transposed form + sparse lists into the workspace, on the same stream
+    if (own_prep) {  // transposed form into the workspace, on the same stream
       char *dst = (char *)a->workspace + fixed_bytes;
       const hipError_t e = launch_mask_prepare((const uint32_t *)a->mask, a->n_masks, a->vocab, a->mask_ld, a->dtype, dst, s);
       if (e != hipSuccess) return hip_fail(e, "mask_prepare launch");

@@ -668,8 +668,7 @@ __device__ __forceinline__ int32_t draw_chunk_reload(const RowView<DT, MASK> &rv
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// What one particle needs from the chunk records of its (row, mask) pair - shared by the two-launch finish kernel
-// (records in global memory) and the one-launch row kernel (records in LDS).  Every function here is executed by ONE
+// What one particle needs from the chunk records of its (row, mask) pair.  Every function here is executed by ONE
 // wave; all results are wave-uniform.
 // ---------------------------------------------------------------------------------------------------------
 struct RecsGlobal {
@@ -770,8 +769,8 @@ __device__ __forceinline__ int32_t pair_draw_philox(const StepParams &p, const R
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// finish (two-launch path): one workgroup of four waves per particle.  Stats / Philox: wave 0 works alone (the other
-// three leave at once); parity mode deals the row's vectors to all four.
+// finish: one workgroup per particle - a single wave for the statistics / Philox modes (launched with 64 threads),
+// four waves for parity mode, which deals the row's vectors to all of them.
 // ---------------------------------------------------------------------------------------------------------
 template <int DT, int MASK, int MODE>
 __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
@@ -832,8 +831,8 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
   } else {
     // ---- parity mode: exponential race against the caller's noise, first maximum of e_j / E_j (README.md:87
     //      through torch.multinomial's CPU algorithm).  e_j = ldexp(P, n_j - N_msk): any common scale gives the same
-    //      comparisons; the row scale keeps every allowed term that can win (the largest allowed term is within
-    //      2^-4 of it unless `own`, and then N_msk is the masked maximum's own exponent).  Vectors are dealt round
+    //      comparisons; N_msk is the largest scale any chunk's allowed terms were summed on, so every allowed term that
+    //      can win is representable.  Vectors are dealt round
     //      robin to the four waves; ties resolve to the smallest index at every level ------------------------------
     int32_t tok = -1;
     if (st.S_msk != 0) {  // workgroup-uniform: every wave folded the same records

@@ -190,7 +190,7 @@ constexpr int kFrac = 36;            // q = floor(t * 2^36)
 constexpr int kGridHi = 18;          // coarse grid 2^-18
 constexpr uint32_t kA0Bits = 0x42000000u;  // 32.0f: ulp 2^-18
 constexpr uint32_t kB0Bits = 0x39000000u;  // 2^-13: ulp 2^-36
-constexpr int kLowMassBits = 32;     // bit-masked sums below 2^32 (on the row's scale) are redone on their own scale
+constexpr int kLowMassBits = 32;     // a chunk's bit-masked sum below 2^32 (on the chunk's scale) is redone on its own scale
 // 2^(f-1) on |f| <= 1/2: degree-4 minimax polynomial (relative error, Remez; max 2.7e-6 as evaluated in fp32
 // Horner form, mean +4e-8), coefficients of 2^f with the exponent lowered by one
 constexpr float kD0 = __builtin_bit_cast(float, 0x3f7ffff4u - (1u << 23));
