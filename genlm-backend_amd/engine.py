@@ -44,6 +44,27 @@ class PreparedMasks:
         self.blob, self.n_masks, self.vocab, self.dtype = blob, n_masks, vocab, dtype
 
 
+class StepPlan:
+    """A fused step whose argument block is already filled (HipEngine.step_plan)."""
+
+    __slots__ = ("eng", "args", "keep", "out", "_ref")
+
+    def __init__(self, eng, args, keep, out):
+        self.eng, self.args, self.keep, self.out = eng, args, keep, out
+        self._ref = C.byref(args)
+
+    def run(self, offset=None, seed=None):
+        a = self.args
+        if offset is not None:
+            a.offset = offset
+        if seed is not None:
+            a.seed = seed
+        if self.eng._step_ws is not self.keep[-1]:
+            raise RuntimeError("the engine's scratch buffer was reallocated since this plan was made: make a new plan")
+        check(self.eng.lib.glb_logprob_mask_sample(self._ref, self.eng._stream()))
+        return self.out
+
+
 class HipEngine:
     """All device work of the hot path for one GPU."""
 
@@ -85,7 +106,7 @@ class HipEngine:
 
     def step(self, logits, vocab=None, row_of=None, mask_kind=MASK_NONE, mask=None, mask_id=None,
              rng_mode=RNG_NONE, noise=None, seed=0, offset=0, particle_base=0, logit_scale=1.0,
-             want_lse=True, variant=0, out=None, row_mask_id=None, out_margin=None, row_members=None):
+             want_lse=True, variant=0, out=None, row_mask_id=None, out_margin=None, row_members=None, _plan=False):
         """Fused particle step (glb_logprob_mask_sample).  Returns (logZ, lse, token) device tensors.
 
         logits: [n_rows, ld] (last dim contiguous; rows may be strided), vocab <= ld.
@@ -164,8 +185,19 @@ class HipEngine:
         ws = self._scratch(self.lib.glb_step_workspace_bytes(n, n_rows, V, n_masks))
         a.workspace = ws.data_ptr()
         a.workspace_bytes = ws.numel()
+        if _plan:  # step_plan(): the filled argument block, the tensors it points into, the outputs
+            return StepPlan(self, a, (logits, row_of, mask, mask_id, row_mask_id, noise, out_margin, row_members, ws),
+                            (logZ, lse, tok))
         check(self.lib.glb_logprob_mask_sample(C.byref(a), self._stream()))
         return logZ, lse, tok
+
+    def step_plan(self, logits, **kw):
+        """`step()` with the host work done once: validates and fills the argument block, returns a `StepPlan` whose
+        `run(offset=..., seed=...)` only launches (a few microseconds of host time instead of a few tens - for loops
+        that call the same configuration again and again, e.g. `bench.py --workload kernel`).  The tensors must keep
+        their storage; the scratch buffer is the engine's, so a plan is valid until another, larger step reallocates
+        it (run() checks)."""
+        return self.step(logits, _plan=True, **kw)
 
     def row_members(self, row_of, n_rows, out=None):
         """Inverse of the fan-out map (glb_row_members): (start int32 [n_rows + 2], members int32 [n], max int32 [1])

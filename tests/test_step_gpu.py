@@ -444,3 +444,21 @@ def test_full_size_properties(engine, B, V, dtype):
     perm = torch.randperm(B, device=dev, generator=g)
     zP, lseP, _ = engine.step(x[perm].contiguous(), mask=prep, row_mask_id=ids(0), rng_mode=0)
     assert torch.equal(zP, zA[perm]) and torch.equal(lseP, lse[perm])
+
+
+def test_step_plan_equals_step(engine):
+    """A prepared call (argument block filled once) gives what step() gives, for every offset it is run with."""
+    dev = engine.device
+    g = torch.Generator(device=dev).manual_seed(1)
+    x = torch.randn((96, 9000), device=dev, generator=g)
+    bits, _ = engine.mask_to_bits(torch.where(torch.rand((2, 9000), device=dev, generator=g) < 0.3, float("-inf"), 0.0))
+    mid = (torch.arange(96, device=dev) % 2).to(torch.int32)
+    masks = engine.prepare_masks(bits, 9000)
+    out = (torch.empty(96, device=dev), torch.empty(96, device=dev), torch.empty(96, dtype=torch.int32, device=dev))
+    plan = engine.step_plan(x, mask=masks, row_mask_id=mid, rng_mode=1, seed=7, offset=0, out=out)
+    for off in (0, 3, 11):
+        want = engine.step(x, mask=masks, row_mask_id=mid, rng_mode=1, seed=7, offset=off)
+        got = plan.run(offset=off)
+        torch.cuda.synchronize()
+        for a, b in zip(want, got):
+            assert torch.equal(a, b)
