@@ -384,6 +384,9 @@ class AsyncAmdLM(AsyncLM):
             slot_d = torch.from_numpy(slot_of_u).to(dev)
             plen_d = torch.tensor([len(p) for p in prefixes], dtype=torch.int32, device=dev)
             p0 = prefixes[0]
+            for p in prefixes[1:]:  # one gather launch per layer serves every prefix: they must come from one model
+                if (p.heads, p.head_dim, p.dtype, len(p.layers)) != (p0.heads, p0.head_dim, p0.dtype, len(p0.layers)):
+                    raise ValueError("cached prefixes of different KV shapes in one batch")
             data = []
             for layer in range(len(p0.layers)):
                 kv = []
