@@ -77,7 +77,7 @@ inline size_t step_recs_bytes(int64_t units, int64_t vocab) {
   return align256((size_t)units * (size_t)n_chunks(vocab) * sizeof(glb::ChunkRec));
 }
 inline size_t step_cands_bytes(int64_t units, int64_t vocab) {
-  return align256((size_t)units * (size_t)n_chunks(vocab) * glb::kDrawCap * sizeof(int32_t));
+  return align256((size_t)units * (size_t)n_chunks(vocab) * glb::kDrawCap * sizeof(uint64_t));
 }
 inline size_t step_fixed_bytes(int64_t units, int64_t vocab) {
   return step_recs_bytes(units, vocab) + step_cands_bytes(units, vocab);

@@ -68,6 +68,7 @@ struct StepParams {
   float *out_margin;  // parity mode: relative gap between the two largest e_j / E_j of the race
   ChunkRec *recs;  // [n_pairs][nch]
   int32_t *cands;  // [n_pairs][nch][kDrawCap]: in-chunk draws of a unit's first particles, made by the reducing wave
+                   // (int32 tokens for fp32 logits, 64-bit lane picks for 16-bit logits)
 };
 
 template <int DT>
@@ -354,20 +355,37 @@ __device__ __forceinline__ int first_lane_above(uint64_t incl, uint64_t T) {
 // scan; that lane then parks its 64 values in LDS and every lane takes one of them: a second scan picks the element.
 // Returns the token id (wave-uniform) or -1 for an empty chunk.
 // ---------------------------------------------------------------------------------------------------------
+// stage 2a: the lane.  Packed result (lane << 56) | (target left inside that lane's terms); ~0 for an empty chunk.
+__device__ __forceinline__ uint64_t chunk_pick_lane(uint32_t inclA, uint32_t inclB, uint64_t R2) {
+  const uint64_t incl = ((uint64_t)inclA << kGridHi) + inclB;
+  const uint64_t Sc = readlane_u64(incl, 63);
+  uint32_t nz = (uint32_t)Sc | (uint32_t)(Sc >> 32);
+  opaque_u32(nz);
+  if (nz == 0u) return ~0ull;
+  const uint64_t T2 = __umul64hi(R2, Sc);  // uniform integer in [0, S_c)
+  const int lsel = first_lane_above(incl, T2);
+  const uint64_t before = readlane_u64(incl, lsel > 0 ? lsel - 1 : 0);
+  const uint64_t Tl = T2 - (lsel > 0 ? before : 0ull);  // < that lane's total < 2^42
+  return ((uint64_t)lsel << 56) | Tl;
+}
+
+// stage 2b, common end: every lane holds one of the chosen lane's 64 terms as (h, l); the element is the first whose
+// running sum passes Tl.  Returns its index 0..63 in the lane's register order, -1 if none (consistent sums rule it out).
+__device__ __forceinline__ int pick_in_lane(uint32_t h, uint32_t l, uint64_t Tl) {
+  const uint32_t sh = wave_sum_u32_l63(h), sl = wave_sum_u32_l63(l);  // inclusive scans; totals < 2^24 each
+  const uint64_t inc2 = ((uint64_t)sh << kGridHi) + sl;
+  return first_lane_above(inc2, Tl);
+}
+
 template <int DT, bool MASKED>
 __device__ __forceinline__ int32_t chunk_candidate(const float (&x)[64], float magicN, int e_base, int lane,
                                                    uint32_t inclA, uint32_t inclB, uint64_t mword, uint64_t R2,
                                                    float *s_tr) {
   constexpr int EPV = ElemTraits<DT>::EPV;
-  const uint64_t incl = ((uint64_t)inclA << kGridHi) + inclB;
-  const uint64_t Sc = readlane_u64(incl, 63);
-  uint32_t nz = (uint32_t)Sc | (uint32_t)(Sc >> 32);
-  opaque_u32(nz);
-  if (nz == 0u) return -1;
-  const uint64_t T2 = __umul64hi(R2, Sc);  // uniform integer in [0, S_c)
-  const int lsel = first_lane_above(incl, T2);
-  const uint64_t before = readlane_u64(incl, lsel > 0 ? lsel - 1 : 0);
-  const uint64_t Tl = T2 - (lsel > 0 ? before : 0ull);
+  const uint64_t pick = chunk_pick_lane(inclA, inclB, R2);
+  if (pick == ~0ull) return -1;
+  const int lsel = (int)(pick >> 56);
+  const uint64_t Tl = pick & ((1ull << 56) - 1ull);
   if (lane == lsel) {
 #pragma unroll
     for (int j = 0; j < 64; j += 4)
@@ -385,16 +403,16 @@ __device__ __forceinline__ int32_t chunk_candidate(const float (&x)[64], float m
   if constexpr (MASKED) {
     if (!((mword >> lsel) & 1ull)) h = l = 0u;
   }
-  const uint32_t sh = wave_sum_u32_l63(h), sl = wave_sum_u32_l63(l);  // inclusive scans; totals < 2^24 each
-  const uint64_t inc2 = ((uint64_t)sh << kGridHi) + sl;
-  const int jsel = first_lane_above(inc2, Tl);
-  if (jsel < 0) return -1;  // consistent sums rule this out
+  const int jsel = pick_in_lane(h, l, Tl);
+  if (jsel < 0) return -1;
   return e_base + ((jsel / EPV) * 64 + lsel) * EPV + (jsel % EPV);
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // chunk statistics: one wave per (reduction unit, chunk)
 // ---------------------------------------------------------------------------------------------------------
+template <int DT>
+constexpr bool kDrawDeferred = DT != kDtF32;
 constexpr int kDrawCap = 8;  // particles per unit whose in-chunk draws ride along with the reduction
 
 // DRAW: the call samples with Philox and the particles of a unit are known (identity, or the CSR mem_start / members):
@@ -404,7 +422,7 @@ constexpr int kDrawCap = 8;  // particles per unit whose in-chunk draws ride alo
 template <int DT, int MASK, bool SCALED, bool DRAW>
 __global__ __launch_bounds__(256) void chunk_stats_kernel(const StepParams p) {
   constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC;
-  __shared__ __attribute__((aligned(16))) float s_tr_all[DRAW ? 4 : 1][64];
+  __shared__ __attribute__((aligned(16))) float s_tr_all[DRAW && !kDrawDeferred<DT> ? 4 : 1][64];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int item = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
   const int nch = p.nch;
@@ -441,15 +459,25 @@ __global__ __launch_bounds__(256) void chunk_stats_kernel(const StepParams p) {
   const float Nc = exp_n(chunk_max(x));
   uint32_t pA, pB, pAm, pBm;
   float Nm = Nc;
+  // fp32: the whole in-chunk draw here (the reduction has VALU time to spare); 16-bit logits, whose reduction is
+  // issue-bound: only the lane pick, which costs a dozen instructions on sums the wave already holds - the element pick
+  // (one gathered load of that lane's 64 values) is left to the per-particle launch
+  constexpr bool kDefer = kDrawDeferred<DT>;
   int32_t toks[kDrawCap] = {-1, -1, -1, -1, -1, -1, -1, -1};
+  uint64_t picks[kDrawCap] = {};
   auto draws = [&](const float (&v)[64], bool masked_words, uint32_t ia, uint32_t ib) {
 #pragma unroll
     for (int m = 0; m < kDrawCap; ++m) {
       if (m < ncand) {
         uint64_t R1, R2;
         philox_pair(p, p.mem_start ? as_const(p.members)[m0 + m] : pr, R1, R2);
-        toks[m] = masked_words ? chunk_candidate<DT, true>(v, kMagic - Nm, e_base, lane, ia, ib, mw, R2, s_tr_all[wave])
-                               : chunk_candidate<DT, false>(v, kMagic - Nm, e_base, lane, ia, ib, 0ull, R2, s_tr_all[wave]);
+        if constexpr (kDefer) {
+          (void)v;
+          picks[m] = chunk_pick_lane(ia, ib, R2);
+        } else {
+          toks[m] = masked_words ? chunk_candidate<DT, true>(v, kMagic - Nm, e_base, lane, ia, ib, mw, R2, s_tr_all[wave])
+                                 : chunk_candidate<DT, false>(v, kMagic - Nm, e_base, lane, ia, ib, 0ull, R2, s_tr_all[wave]);
+        }
       }
     }
   };
@@ -478,9 +506,16 @@ __global__ __launch_bounds__(256) void chunk_stats_kernel(const StepParams p) {
     store_rec(p.recs + (int64_t)pr * nch + c, Nc, pA, pB, pAm, pBm, Nm);
     if constexpr (DRAW) {
       if (ncand) {
-        u32x4_t *cd = reinterpret_cast<u32x4_t *>(p.cands + ((int64_t)pr * nch + c) * kDrawCap);
-        cd[0] = u32x4_t{(uint32_t)toks[0], (uint32_t)toks[1], (uint32_t)toks[2], (uint32_t)toks[3]};
-        if (ncand > 4) cd[1] = u32x4_t{(uint32_t)toks[4], (uint32_t)toks[5], (uint32_t)toks[6], (uint32_t)toks[7]};
+        if constexpr (kDefer) {
+          uint64_t *cd = reinterpret_cast<uint64_t *>(p.cands) + ((int64_t)pr * nch + c) * kDrawCap;
+#pragma unroll
+          for (int m = 0; m < kDrawCap; ++m)
+            if (m < ncand) cd[m] = picks[m];
+        } else {
+          u32x4_t *cd = reinterpret_cast<u32x4_t *>(p.cands + ((int64_t)pr * nch + c) * kDrawCap);
+          cd[0] = u32x4_t{(uint32_t)toks[0], (uint32_t)toks[1], (uint32_t)toks[2], (uint32_t)toks[3]};
+          if (ncand > 4) cd[1] = u32x4_t{(uint32_t)toks[4], (uint32_t)toks[5], (uint32_t)toks[6], (uint32_t)toks[7]};
+        }
       }
     }
   }
@@ -629,6 +664,42 @@ struct RowView {
   }
 };
 
+// one element of the row (unscaled)
+template <int DT>
+__device__ __forceinline__ float load_elem(const char *rowp, int j) {
+  if constexpr (DT == kDtF32) return *reinterpret_cast<const float *>(rowp + (int64_t)j * 4);
+  const uint32_t h = *reinterpret_cast<const uint16_t *>(rowp + (int64_t)j * 2);
+  if constexpr (DT == kDtBf16) return __uint_as_float(h << 16);
+  return (float)__builtin_bit_cast(_Float16, (uint16_t)h);
+}
+
+// stage 2b from memory (16-bit logits: the reducing wave left only the lane pick): lane j loads the chosen lane's
+// j-th element - eight 16-byte runs a kilobyte apart -, applies scale and mask exactly as the reduction did, and the
+// scan of pick_in_lane names the element.  Nm: the scale the chunk's allowed terms were summed on (its record).
+template <int DT, int MASK>
+__device__ __forceinline__ int32_t chunk_pick_element_mem(const RowView<DT, MASK> &rv, int c, uint64_t pick, float Nm,
+                                                          int lane) {
+  constexpr int EPV = ElemTraits<DT>::EPV;
+  if (pick == ~0ull) return -1;
+  const int lsel = (int)(pick >> 56);
+  const uint64_t Tl = pick & ((1ull << 56) - 1ull);
+  const int e = c * kChunk + ((lane / EPV) * 64 + lsel) * EPV + (lane % EPV);
+  float y = kNegInf;
+  if (e < rv.V) {
+    y = load_elem<DT>(rv.rowp, e) * rv.scale;
+    if constexpr (MASK == kMaskBits) {
+      if (!((rv.mt[(int64_t)c * 64 + lane] >> lsel) & 1ull)) y = kNegInf;
+    } else if constexpr (MASK == kMaskF32) {
+      y = y + reinterpret_cast<const float *>(rv.mrow)[e];
+    }
+  }
+  uint32_t h, l;
+  term_q_parts(y, kMagic - Nm, h, l);
+  const int jsel = pick_in_lane(h, l, Tl);
+  if (jsel < 0) return -1;
+  return __builtin_amdgcn_readlane(e, jsel);
+}
+
 // The in-chunk draw for a particle whose chunk is not in registers any more (two-launch path; members of a shared row
 // beyond the ones the reducing wave drew for): one wave reloads chunk c and goes through exactly what the reducing wave
 // did - maximum, sums, low-mass rule, draw - with the same functions, so the result is the same.
@@ -736,7 +807,7 @@ template <int DT, int MASK, class Recs>
 __device__ __forceinline__ int32_t pair_draw_philox(const StepParams &p, const Recs &recs, const RowView<DT, MASK> &rv,
                                                     const PairState &st, int pidx, int nch, int lane,
                                                     const int32_t *cand, int cand_stride, int32_t my_cand,
-                                                    float *s_tr) {
+                                                    uint64_t my_pick, float *s_tr) {
   uint32_t nz = (uint32_t)st.S_msk | (uint32_t)(st.S_msk >> 32);
   opaque_u32(nz);
   if (nz == 0u) return -1;
@@ -744,12 +815,15 @@ __device__ __forceinline__ int32_t pair_draw_philox(const StepParams &p, const R
   philox_pair(p, pidx, R1, R2);
   uint64_t T = __umul64hi(R1, st.S_msk);  // uniform integer in [0, S_msk)
   int csel = -1;
+  float Nms = 0.f;  // the scale the chosen chunk's allowed terms sit on
   for (int c0 = 0; c0 < nch && csel < 0; c0 += 64) {
     const int c = c0 + lane;
     uint64_t sm = 0;
+    float Nm = kNegInf;
     if (c < nch) {
       const ChunkRec r = recs.get(c);
       const uint64_t m = ((uint64_t)r.pAm << kGridHi) + r.pBm;
+      Nm = r.Nm;
       if (m) {
         const float d = st.N_msk - r.Nm;
         if (d < 64.0f) sm = m >> (uint32_t)d;
@@ -757,13 +831,23 @@ __device__ __forceinline__ int32_t pair_draw_philox(const StepParams &p, const R
     }
     const uint64_t incl = wave_scan_u64(sm);
     const int lsel = first_lane_above(incl, T);
-    if (lsel >= 0) csel = c0 + lsel;
-    else T -= readlane_u64(incl, 63);
+    if (lsel >= 0) {
+      csel = c0 + lsel;
+      Nms = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(Nm), lsel));
+    } else {
+      T -= readlane_u64(incl, 63);
+    }
   }
   if (csel < 0) return -1;  // consistent sums rule this out
   if (cand) {
-    if (nch <= 64) return __builtin_amdgcn_readlane(my_cand, csel);
-    return cand[(int64_t)csel * cand_stride];
+    if constexpr (kDrawDeferred<DT>) {  // the reducing wave picked the lane; the element comes from one gathered load
+      const uint64_t pick = nch <= 64 ? readlane_u64(my_pick, csel)
+                                      : reinterpret_cast<const uint64_t *>(cand)[(int64_t)csel * cand_stride];
+      return chunk_pick_element_mem(rv, csel, pick, Nms, lane);
+    } else {
+      if (nch <= 64) return __builtin_amdgcn_readlane(my_cand, csel);
+      return cand[(int64_t)csel * cand_stride];
+    }
   }
   return draw_chunk_reload(rv, csel, lane, R2, s_tr);
 }
@@ -798,20 +882,31 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
   // did the reducing waves draw for this particle (it is one of its unit's first kDrawCap members)?  Then lane c
   // fetches chunk c's token beside the records (rows of up to 64 chunks): the look-up after the chunk scan is a lane
   // read, not one more dependent load
-  const int32_t *cand = nullptr;
+  const int32_t *cand = nullptr;  // this particle's entry of chunk 0 (int32 tokens, or 64-bit lane picks for 16-bit logits)
   int32_t my_cand = -1;
+  uint64_t my_pick = ~0ull;
   if constexpr (MODE == kModePhilox) {
     if (p.cands && p.out_token) {
+      int slot = -1;
       if (!p.pair_of) {
-        cand = p.cands + (int64_t)pr * nch * kDrawCap;
+        slot = 0;
       } else if (p.mem_start) {
         const int m0 = as_const(p.mem_start)[pr];
         int cnt = as_const(p.mem_start)[pr + 1] - m0;
         cnt = cnt < kDrawCap ? cnt : kDrawCap;
         for (int m = 0; m < cnt; ++m)
-          if (as_const(p.members)[m0 + m] == pidx) cand = p.cands + (int64_t)pr * nch * kDrawCap + m;
+          if (as_const(p.members)[m0 + m] == pidx) slot = m;
       }
-      if (cand && nch <= 64 && lane < nch) my_cand = cand[lane * kDrawCap];
+      if (slot >= 0) {
+        if constexpr (kDrawDeferred<DT>) {
+          const uint64_t *c64 = reinterpret_cast<const uint64_t *>(p.cands) + (int64_t)pr * nch * kDrawCap + slot;
+          cand = reinterpret_cast<const int32_t *>(c64);
+          if (nch <= 64 && lane < nch) my_pick = c64[lane * kDrawCap];
+        } else {
+          cand = p.cands + (int64_t)pr * nch * kDrawCap + slot;
+          if (nch <= 64 && lane < nch) my_cand = cand[lane * kDrawCap];
+        }
+      }
     }
   }
   PairState st;
@@ -826,7 +921,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
   if (!p.out_token) return;
 
   if constexpr (MODE == kModePhilox) {
-    const int32_t tok = pair_draw_philox<DT, MASK>(p, recs, rv, st, pidx, nch, lane, cand, kDrawCap, my_cand, s_tr);
+    const int32_t tok = pair_draw_philox<DT, MASK>(p, recs, rv, st, pidx, nch, lane, cand, kDrawCap, my_cand, my_pick, s_tr);
     if (lane == 0) p.out_token[pidx] = tok;
   } else {
     // ---- parity mode: exponential race against the caller's noise, first maximum of e_j / E_j (README.md:87
