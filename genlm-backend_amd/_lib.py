@@ -50,8 +50,6 @@ class StepArgs(C.Structure):
         ("out_token", C.c_void_p),
         ("out_margin", C.c_void_p),
         ("reserved", C.c_int32),
-        ("row_members_start", C.c_void_p),
-        ("row_members", C.c_void_p),
         ("workspace", C.c_void_p),
         ("workspace_bytes", C.c_size_t),
     ]
@@ -70,7 +68,6 @@ SYMBOLS = {
     "glb_device_count": (C.c_int, []),
     "glb_step_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "glb_logprob_mask_sample": (C.c_int, [C.POINTER(StepArgs), _vp]),
-    "glb_row_members": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     "glb_mask_prepared_bytes": (_sz, [_i64, _i64]),
     "glb_mask_prepare": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _vp, _sz, _vp]),
     "glb_log_softmax_workspace_bytes": (_sz, [_i64, _i64]),

@@ -16,7 +16,7 @@
 namespace glb {
 // launchers exported by the three glb_chunk_tu.hip translation units (one per element type)
 #define GLB_DECL(dt)                                                                                              \
-  hipError_t launch_stats_##dt(const StepParams &p, int mask_kind, bool scaled, bool draw, hipStream_t s);        \
+  hipError_t launch_stats_##dt(const StepParams &p, int mask_kind, bool scaled, bool lanes, hipStream_t s);        \
   hipError_t launch_finish_##dt(const StepParams &p, int mask_kind, int mode, hipStream_t s);                     \
   hipError_t launch_logprob_rows_##dt(const void *logits, int64_t ld, int V, float scale, const float *lse,       \
                                       float *out, int64_t out_ld, int n_rows, hipStream_t s);                      \
@@ -44,11 +44,11 @@ int hip_fail(hipError_t e, const char *what) {
   return fail(GLB_EHIP, "%s: %s", what, hipGetErrorString(e));
 }
 
-hipError_t launch_stats(int dtype, const glb::StepParams &p, int mask_kind, bool scaled, bool draw, hipStream_t s) {
+hipError_t launch_stats(int dtype, const glb::StepParams &p, int mask_kind, bool scaled, bool lanes, hipStream_t s) {
   switch (dtype) {
-    case 0: return glb::launch_stats_0(p, mask_kind, scaled, draw, s);
-    case 1: return glb::launch_stats_1(p, mask_kind, scaled, draw, s);
-    case 2: return glb::launch_stats_2(p, mask_kind, scaled, draw, s);
+    case 0: return glb::launch_stats_0(p, mask_kind, scaled, lanes, s);
+    case 1: return glb::launch_stats_1(p, mask_kind, scaled, lanes, s);
+    case 2: return glb::launch_stats_2(p, mask_kind, scaled, lanes, s);
   }
   return hipErrorInvalidValue;
 }
@@ -72,15 +72,15 @@ inline size_t prepared_bytes(int64_t n_masks, int64_t vocab) {
   return prepared_words_bytes(n_masks, vocab) + align256((size_t)n_masks * (size_t)n_chunks(vocab) * sizeof(uint64_t));
 }
 
-// step workspace: chunk records, in-chunk draws; then prepared masks
+// step workspace: chunk records, per-lane scans of every chunk (512 bytes each); then prepared masks
 inline size_t step_recs_bytes(int64_t units, int64_t vocab) {
   return align256((size_t)units * (size_t)n_chunks(vocab) * sizeof(glb::ChunkRec));
 }
-inline size_t step_cands_bytes(int64_t units, int64_t vocab) {
-  return align256((size_t)units * (size_t)n_chunks(vocab) * glb::kDrawCap * sizeof(uint64_t));
+inline size_t step_lanes_bytes(int64_t units, int64_t vocab) {
+  return align256((size_t)units * (size_t)n_chunks(vocab) * 64 * 2 * sizeof(uint32_t));
 }
 inline size_t step_fixed_bytes(int64_t units, int64_t vocab) {
-  return step_recs_bytes(units, vocab) + step_cands_bytes(units, vocab);
+  return step_recs_bytes(units, vocab) + step_lanes_bytes(units, vocab);
 }
 
 hipError_t launch_mask_prepare(const uint32_t *bits, int64_t n_masks, int64_t vocab, int64_t mask_ld, int dtype,
@@ -746,88 +746,6 @@ __global__ __launch_bounds__(256) void trie_untranspose_kernel(const float *scr,
   }
 }
 
-// Inverse of row_of as a CSR by one workgroup: counts (global atomics into B[r + 2]), inclusive scan in place, then
-// every particle takes the next free slot of its row (atomic cursor B[r + 1], which ends as the start of row r + 1):
-// B[0 .. n_rows] finish as the offsets.  A handful of memory latencies for a few thousand particles.
-__global__ __launch_bounds__(1024) void row_members_kernel(const int32_t *row_of, int32_t n, int32_t n_rows,
-                                                            int32_t *B, int32_t *members, int32_t *out_max) {
-  __shared__ int32_t s_part[16];
-  __shared__ int32_t s_carry;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < n_rows + 2; i += 1024) B[i] = 0;
-  if (tid == 0) s_carry = 0;
-  __syncthreads();
-  // (a wave whose lanes all sit on one row - SIS step 0, a freshly resampled population - sends ONE atomic: 1024
-  //  particles on one counter are otherwise 1024 serialised round trips, 37 us)
-  for (int i0 = 0; i0 < n; i0 += 1024) {
-    const int i = i0 + tid;
-    const int r = i < n ? row_of[i] : -1;
-    const bool ok = r >= 0 && r < n_rows;
-    const int r0 = __builtin_amdgcn_readfirstlane(r);
-    const uint64_t okm = __ballot(ok), same = __ballot(ok && r == r0);
-    if (okm != 0 && same == okm) {
-      if (lane == __ffsll((long long)okm) - 1) atomicAdd(&B[r + 2], __popcll(okm));
-    } else if (ok) {
-      atomicAdd(&B[r + 2], 1);
-    }
-  }
-  __syncthreads();
-  int mx = 0;
-  for (int base = 0; base < n_rows; base += 1024) {
-    const int idx = base + tid;
-    const int v = idx < n_rows ? __hip_atomic_load(&B[idx + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-    mx = v > mx ? v : mx;
-    int incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int t = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += t;
-    }
-    if (lane == 63) s_part[wave] = incl;
-    __syncthreads();
-    int off = s_carry;
-#pragma unroll
-    for (int w = 0; w < 16; ++w)
-      if (w < wave) off += s_part[w];
-    incl += off;
-    if (idx < n_rows) B[idx + 2] = incl;
-    __syncthreads();
-    if (tid == 1023) s_carry = incl;
-    __syncthreads();
-  }
-  if (out_max) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const int t = __shfl_xor(mx, o, 64);
-      mx = t > mx ? t : mx;
-    }
-    if (lane == 0) s_part[wave] = mx;
-    __syncthreads();
-    if (tid == 0) {
-      int m = 0;
-      for (int w = 0; w < 16; ++w) m = s_part[w] > m ? s_part[w] : m;
-      *out_max = m;
-    }
-  }
-  __syncthreads();
-  for (int i0 = 0; i0 < n; i0 += 1024) {
-    const int i = i0 + tid;
-    const int r = i < n ? row_of[i] : -1;
-    const bool ok = r >= 0 && r < n_rows;
-    const int r0 = __builtin_amdgcn_readfirstlane(r);
-    const uint64_t okm = __ballot(ok), same = __ballot(ok && r == r0);
-    if (okm != 0 && same == okm) {
-      const int leader = __ffsll((long long)okm) - 1;
-      int base = 0;
-      if (lane == leader) base = atomicAdd(&B[r + 1], __popcll(okm));
-      base = __builtin_amdgcn_readlane(base, leader);
-      if (ok) members[base + __popcll(okm & ((1ull << lane) - 1ull))] = i;
-    } else if (ok) {
-      members[atomicAdd(&B[r + 1], 1)] = i;
-    }
-  }
-}
-
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -914,10 +832,6 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
   }
   if (a->rng_mode < GLB_RNG_NONE || a->rng_mode > GLB_RNG_NOISE)
     return fail(GLB_EINVAL, "bad rng_mode %d", a->rng_mode);
-  if ((a->row_members_start == nullptr) != (a->row_members == nullptr))
-    return fail(GLB_EINVAL, "row_members_start and row_members go together");
-  if (a->row_members && (!a->row_of || !by_row))
-    return fail(GLB_EINVAL, "row_members describes row_of of a per-row reduction (no per-particle mask ids)");
   if (a->reserved != 0) return fail(GLB_EINVAL, "reserved must be 0");
   if (a->rng_mode == GLB_RNG_NOISE && (!a->noise || (a->noise_ld < a->vocab && a->noise_ld != 0)))
     return fail(GLB_EINVAL, "noise tensor missing or noise_ld < vocab (0 = one row shared by every particle)");
@@ -978,35 +892,14 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
   p.out_lse = a->out_lse;
   p.out_token = a->out_token;
   p.out_margin = a->rng_mode == GLB_RNG_NOISE ? a->out_margin : nullptr;
-  // The reducing waves make the in-chunk draws of each unit's first particles when they can know who those are: one
-  // particle per unit, or a per-row reduction whose fan-out map comes with its inverse (row_members).  Otherwise (and
-  // for launches too small to fill the chip, which take the four-waves-per-chunk kernel) every particle redoes its
-  // chunk in the second launch.
-  const bool members_known = !by_row || !a->row_of || (a->row_members_start && a->row_members);
-  const bool draw = a->rng_mode == GLB_RNG_PHILOX && members_known && (n_units * p.nch > 512 || kmask == glb::kMaskF32);
-  if (draw) {
-    p.cands = (int32_t *)((char *)a->workspace + step_recs_bytes(n_units, a->vocab));
-    if (by_row && a->row_of) {
-      p.mem_start = a->row_members_start;
-      p.members = a->row_members;
-    }
-  }
-  hipError_t e = launch_stats(a->dtype, p, kmask, a->logit_scale != 1.0f, draw, s);
+  // Philox draws: the reducing waves leave the per-lane scans of every chunk's allowed sums beside the records; the
+  // per-particle launch picks chunk, lane and element from them
+  const bool lanes = a->rng_mode == GLB_RNG_PHILOX;
+  if (lanes) p.lanes = (uint32_t *)((char *)a->workspace + step_recs_bytes(n_units, a->vocab));
+  hipError_t e = launch_stats(a->dtype, p, kmask, a->logit_scale != 1.0f, lanes, s);
   if (e != hipSuccess) return hip_fail(e, "chunk_stats launch");
   e = launch_finish(a->dtype, p, kmask, a->rng_mode, s);
   if (e != hipSuccess) return hip_fail(e, "finish launch");
-  return GLB_OK;
-}
-
-int glb_row_members(const int32_t *row_of, int64_t n_particles, int64_t n_rows, int32_t *out_start,
-                    int32_t *out_members, int32_t *out_max, void *stream) {
-  if (!row_of || !out_start || !out_members) return fail(GLB_EINVAL, "null pointer");
-  if (n_particles <= 0 || n_rows <= 0 || n_particles > 0x7fffff00ll || n_rows > 0x7fffff00ll)
-    return fail(GLB_EINVAL, "bad sizes");
-  hipLaunchKernelGGL(row_members_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, row_of, (int32_t)n_particles,
-                     (int32_t)n_rows, out_start, out_members, out_max);
-  const hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return hip_fail(e, "row_members launch");
   return GLB_OK;
 }
 

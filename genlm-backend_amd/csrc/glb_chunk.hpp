@@ -53,8 +53,6 @@ struct StepParams {
   const int32_t *pair_row;   // [n_pairs] logits row of a reduction unit, null = identity
   const int32_t *pair_mask;  // [n_pairs] mask row, null = (n_masks == 1 ? 0 : identity)
   const int32_t *pair_of;    // [n_particles] reduction unit of a particle, null = identity
-  const int32_t *mem_start;  // [n_pairs + 1] particles of a unit as a CSR (inverse of pair_of); null with pair_of
-  const int32_t *members;    // [n_particles]    null = identity (one each), null with pair_of given = unknown
   const uint64_t *mask_t;    // transposed bit masks [n_masks][nch * 64]
   const uint64_t *mask_any;  // [n_masks][nch]: nonzero when the mask allows any token of the chunk
   const float *mask_f;       // float masks [n_masks][mask_ld]
@@ -67,8 +65,8 @@ struct StepParams {
   int32_t *out_token;
   float *out_margin;  // parity mode: relative gap between the two largest e_j / E_j of the race
   ChunkRec *recs;  // [n_pairs][nch]
-  int32_t *cands;  // [n_pairs][nch][kDrawCap]: in-chunk draws of a unit's first particles, made by the reducing wave
-                   // (int32 tokens for fp32 logits, 64-bit lane picks for 16-bit logits)
+  uint32_t *lanes;  // [n_pairs][nch][64][2] (Philox draws): per-lane inclusive scans of the allowed payload words of
+                    // every chunk, as the reducing wave held them - what the per-particle launch picks the lane from
 };
 
 template <int DT>
@@ -347,13 +345,11 @@ __device__ __forceinline__ int first_lane_above(uint64_t incl, uint64_t T) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// The draw inside one chunk, by the wave that holds it in x[64] (second stage of the Philox draw):
-// target T2 = floor(R2 * S_c / 2^64) against the chunk's allowed terms on the chunk's own scale, taken lane by lane
-// and inside a lane in register order (vector, component) - the order the wave holds them in, so nothing is loaded.
-// (inclA, inclB) are the per-lane inclusive scans of the allowed payload words chunk_sums returns; mword is the
-// transposed mask word of element `lane` of a lane's 64 (bit l = lane l allowed).  Stage 1 picks the lane from the
-// scan; that lane then parks its 64 values in LDS and every lane takes one of them: a second scan picks the element.
-// Returns the token id (wave-uniform) or -1 for an empty chunk.
+// The draw inside one chunk (second stage of the Philox draw): target T2 = floor(R2 * S_c / 2^64) against
+// the chunk's allowed terms on the scale they were summed on, taken lane by lane and inside a lane in register order
+// (vector, component) - the order the reducing wave held them in.  The reducing wave leaves the per-lane inclusive
+// scans of its allowed payload words behind (512 bytes per chunk); the per-particle launch picks the lane from them
+// (stage 2a) and the element from one gathered load of that lane's 64 values (stage 2b).
 // ---------------------------------------------------------------------------------------------------------
 // stage 2a: the lane.  Packed result (lane << 56) | (target left inside that lane's terms); ~0 for an empty chunk.
 __device__ __forceinline__ uint64_t chunk_pick_lane(uint32_t inclA, uint32_t inclB, uint64_t R2) {
@@ -377,66 +373,19 @@ __device__ __forceinline__ int pick_in_lane(uint32_t h, uint32_t l, uint64_t Tl)
   return first_lane_above(inc2, Tl);
 }
 
-template <int DT, bool MASKED>
-__device__ __forceinline__ int32_t chunk_candidate(const float (&x)[64], float magicN, int e_base, int lane,
-                                                   uint32_t inclA, uint32_t inclB, uint64_t mword, uint64_t R2,
-                                                   float *s_tr) {
-  constexpr int EPV = ElemTraits<DT>::EPV;
-  const uint64_t pick = chunk_pick_lane(inclA, inclB, R2);
-  if (pick == ~0ull) return -1;
-  const int lsel = (int)(pick >> 56);
-  const uint64_t Tl = pick & ((1ull << 56) - 1ull);
-  if (lane == lsel) {
-#pragma unroll
-    for (int j = 0; j < 64; j += 4)
-      *reinterpret_cast<u32x4_t *>(s_tr + j) = u32x4_t{__float_as_uint(x[j]), __float_as_uint(x[j + 1]),
-                                                       __float_as_uint(x[j + 2]), __float_as_uint(x[j + 3])};
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  const float xv = s_tr[lane];
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  uint32_t h, l;
-  term_q_parts(xv, magicN, h, l);
-  if constexpr (MASKED) {
-    if (!((mword >> lsel) & 1ull)) h = l = 0u;
-  }
-  const int jsel = pick_in_lane(h, l, Tl);
-  if (jsel < 0) return -1;
-  return e_base + ((jsel / EPV) * 64 + lsel) * EPV + (jsel % EPV);
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // chunk statistics: one wave per (reduction unit, chunk)
 // ---------------------------------------------------------------------------------------------------------
-template <int DT>
-constexpr bool kDrawDeferred = DT != kDtF32;
-constexpr int kDrawCap = 8;  // particles per unit whose in-chunk draws ride along with the reduction
-
-// DRAW: the call samples with Philox and the particles of a unit are known (identity, or the CSR mem_start / members):
-// while the chunk is in registers the wave also makes the in-chunk draw (second stage) of the unit's first kDrawCap
-// particles and leaves the tokens beside the record, so the per-particle kernel only has to pick a chunk and look the
-// token up; later members of a crowded unit, and callers that give row_of without its inverse, redo the chunk there.
-template <int DT, int MASK, bool SCALED, bool DRAW>
-__global__ __launch_bounds__(256) void chunk_stats_kernel(const StepParams p) {
+// LANES (calls that draw with Philox): the wave also leaves the per-lane inclusive scans of its allowed payload words
+// in the workspace (8 bytes per lane, one coalesced 512-byte store) - the per-particle launch draws from them.
+template <int DT, int MASK, bool SCALED, bool LANES>
+__global__ __launch_bounds__(256, 5) void chunk_stats_kernel(const StepParams p) {
   constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC;
-  __shared__ __attribute__((aligned(16))) float s_tr_all[DRAW && !kDrawDeferred<DT> ? 4 : 1][64];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
   const int item = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
   const int nch = p.nch;
   if (item >= p.n_pairs * nch) return;  // whole waves only
   const int pr = item / nch, c = item - pr * nch;  // (dealt row-interleaved instead, the launch is 2.5 us slower)
-  int m0 = pr, ncand = 0;
-  if constexpr (DRAW) {
-    ncand = 1;
-    if (p.mem_start) {
-      m0 = as_const(p.mem_start)[pr];
-      const int cnt = as_const(p.mem_start)[pr + 1] - m0;
-      ncand = cnt < kDrawCap ? cnt : kDrawCap;
-    }
-  }
   const int row = p.pair_row ? as_const(p.pair_row)[pr] : pr;
   const char *rowp = (const char *)p.logits + (int64_t)row * p.ld * ES;
   const int V = p.V, e_base = c * kChunk;
@@ -445,49 +394,22 @@ __global__ __launch_bounds__(256) void chunk_stats_kernel(const StepParams p) {
 
   MaskAhead ma{};
   cu64_t mt = nullptr;
-  uint64_t allows_any = 0, mw = 0;
+  uint64_t allows_any = 0;
   int mi = 0;
   if constexpr (MASK != kMaskNone) mi = p.pair_mask ? as_const(p.pair_mask)[pr] : (p.n_masks == 1 ? 0 : pr);
   if constexpr (MASK == kMaskBits) {
     mt = as_const(p.mask_t + ((int64_t)mi * nch + c) * 64);
     mask_ahead<DT>(mt, ma);
     allows_any = as_const(p.mask_any)[(int64_t)mi * nch + c];
-    if (DRAW && ncand) mw = (p.mask_t + ((int64_t)mi * nch + c) * 64)[lane];
   }
   float x[64];
   load_chunk<DT, SCALED>(rowp, e_base, V, lane, p.scale, x);
   const float Nc = exp_n(chunk_max(x));
   uint32_t pA, pB, pAm, pBm;
   float Nm = Nc;
-  // fp32: the whole in-chunk draw here (the reduction has VALU time to spare); 16-bit logits, whose reduction is
-  // issue-bound: only the lane pick, which costs a dozen instructions on sums the wave already holds - the element pick
-  // (one gathered load of that lane's 64 values) is left to the per-particle launch
-  constexpr bool kDefer = kDrawDeferred<DT>;
-  int32_t toks[kDrawCap] = {-1, -1, -1, -1, -1, -1, -1, -1};
-  uint64_t picks[kDrawCap] = {};
-  auto draws = [&](const float (&v)[64], bool masked_words, uint32_t ia, uint32_t ib) {
-#pragma unroll
-    for (int m = 0; m < kDrawCap; ++m) {
-      if (m < ncand) {
-        uint64_t R1, R2;
-        philox_pair(p, p.mem_start ? as_const(p.members)[m0 + m] : pr, R1, R2);
-        if constexpr (kDefer) {
-          (void)v;
-          picks[m] = chunk_pick_lane(ia, ib, R2);
-        } else {
-          toks[m] = masked_words ? chunk_candidate<DT, true>(v, kMagic - Nm, e_base, lane, ia, ib, mw, R2, s_tr_all[wave])
-                                 : chunk_candidate<DT, false>(v, kMagic - Nm, e_base, lane, ia, ib, 0ull, R2, s_tr_all[wave]);
-        }
-      }
-    }
-  };
   if constexpr (MASK == kMaskBits) {
     bool redone;
     chunk_reduce_bits<DT>(x, Nc, nv_valid, mt, ma, allows_any, lane, pA, pB, pAm, pBm, Nm, redone);
-    if constexpr (DRAW) {
-      if (redone) mw = ~0ull;  // x holds the masked chunk now: every finite element counts
-      draws(x, true, pAm, pBm);
-    }
   } else {
     chunk_sums<DT, false>(x, kMagic - Nc, nv_valid, nullptr, ma, pA, pB, pAm, pBm);
     if constexpr (MASK == kMaskF32) {  // general additive masks: y = x + m has its own maximum, scale and exp
@@ -497,28 +419,13 @@ __global__ __launch_bounds__(256) void chunk_stats_kernel(const StepParams p) {
       Nm = exp_n(chunk_max(y));
       uint32_t d0, d1;
       chunk_sums<DT, false>(y, kMagic - Nm, nv_valid, nullptr, ma, pAm, pBm, d0, d1);
-      if constexpr (DRAW) draws(y, false, pAm, pBm);
-    } else {
-      if constexpr (DRAW) draws(x, false, pA, pB);
     }
   }
-  if (lane == 63) {
-    store_rec(p.recs + (int64_t)pr * nch + c, Nc, pA, pB, pAm, pBm, Nm);
-    if constexpr (DRAW) {
-      if (ncand) {
-        if constexpr (kDefer) {
-          uint64_t *cd = reinterpret_cast<uint64_t *>(p.cands) + ((int64_t)pr * nch + c) * kDrawCap;
-#pragma unroll
-          for (int m = 0; m < kDrawCap; ++m)
-            if (m < ncand) cd[m] = picks[m];
-        } else {
-          u32x4_t *cd = reinterpret_cast<u32x4_t *>(p.cands + ((int64_t)pr * nch + c) * kDrawCap);
-          cd[0] = u32x4_t{(uint32_t)toks[0], (uint32_t)toks[1], (uint32_t)toks[2], (uint32_t)toks[3]};
-          if (ncand > 4) cd[1] = u32x4_t{(uint32_t)toks[4], (uint32_t)toks[5], (uint32_t)toks[6], (uint32_t)toks[7]};
-        }
-      }
-    }
+  if constexpr (LANES) {
+    uint32_t *ls = p.lanes + (((int64_t)pr * nch + c) * 64 + lane) * 2;
+    *reinterpret_cast<uint64_t *>(ls) = ((uint64_t)pBm << 32) | pAm;
   }
+  if (lane == 63) store_rec(p.recs + (int64_t)pr * nch + c, Nc, pA, pB, pAm, pBm, Nm);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -528,12 +435,13 @@ __global__ __launch_bounds__(256) void chunk_stats_kernel(const StepParams p) {
 // the elements were dealt out); a wave alone on its SIMD issues one instruction every ~5 cycles, so a quarter of the
 // elements per wave is what shortens the launch.  Bit masks / no mask only (float masks use the one-wave kernel).
 // ---------------------------------------------------------------------------------------------------------
-template <int DT, int MASK, bool SCALED>
+template <int DT, int MASK, bool SCALED, bool LANES>
 __global__ __launch_bounds__(256) void chunk_stats_small_kernel(const StepParams p) {
   constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC, NVW = NVC / 4;
   static_assert(MASK != kMaskF32, "float masks take the one-wave-per-chunk kernel");
   __shared__ float s_max[4];
   __shared__ uint32_t s_pay[4][4];
+  __shared__ uint32_t s_lane[LANES ? 4 : 1][64][2];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int item = blockIdx.x, nch = p.nch;
   const int pr = item / nch, c = item - pr * nch;
@@ -584,6 +492,9 @@ __global__ __launch_bounds__(256) void chunk_stats_small_kernel(const StepParams
 #pragma unroll
   for (int k = 0; k < 4; ++k) t[k] = s_pay[0][k] + s_pay[1][k] + s_pay[2][k] + s_pay[3][k];
   float Nm = Nc;
+  uint32_t lastA = pAm, lastB = pBm;  // this wave's per-lane scans of the allowed words, as finally summed
+  (void)lastA;
+  (void)lastB;
   if constexpr (MASK == kMaskBits) {
     // the low-mass rule of chunk_reduce_bits, with the chunk spread over four waves (workgroup-uniform branch)
     const uint64_t Sm = ((uint64_t)t[2] << kGridHi) + t[3];
@@ -608,6 +519,8 @@ __global__ __launch_bounds__(256) void chunk_stats_small_kernel(const StepParams
       Nm = exp_n(fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3])));
       uint32_t qa, qb, d0, d1;
       chunk_sums<DT, false, 4>(x, kMagic - Nm, nv_valid, nullptr, MaskAhead{}, qa, qb, d0, d1, wave);
+      lastA = qa;
+      lastB = qb;
       if (lane == 63) {
         s_pay[wave][2] = qa;
         s_pay[wave][3] = qb;
@@ -618,6 +531,21 @@ __global__ __launch_bounds__(256) void chunk_stats_small_kernel(const StepParams
     }
   }
   if (threadIdx.x == 0) store_rec(p.recs + (int64_t)pr * nch + c, Nc, t[0], t[1], t[2], t[3], Nm);
+  if constexpr (LANES) {
+    // the per-lane scans of the allowed words over the WHOLE chunk: every wave's lanes hold scans over their quarter
+    // of the vectors; their own parts are summed per lane through LDS and scanned again by wave 0
+    const uint32_t ia = MASK == kMaskBits ? lastA : pA, ib = MASK == kMaskBits ? lastB : pB;
+    const uint32_t pa = __shfl_up(ia, 1, 64), pb = __shfl_up(ib, 1, 64);
+    s_lane[wave][lane][0] = ia - (lane ? pa : 0u);
+    s_lane[wave][lane][1] = ib - (lane ? pb : 0u);
+    __syncthreads();
+    if (wave == 0) {
+      const uint32_t a = s_lane[0][lane][0] + s_lane[1][lane][0] + s_lane[2][lane][0] + s_lane[3][lane][0];
+      const uint32_t b2 = s_lane[0][lane][1] + s_lane[1][lane][1] + s_lane[2][lane][1] + s_lane[3][lane][1];
+      const uint32_t sa = wave_sum_u32_l63(a), sb = wave_sum_u32_l63(b2);
+      *reinterpret_cast<uint64_t *>(p.lanes + (((int64_t)pr * nch + c) * 64 + lane) * 2) = ((uint64_t)sb << 32) | sa;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -673,9 +601,9 @@ __device__ __forceinline__ float load_elem(const char *rowp, int j) {
   return (float)__builtin_bit_cast(_Float16, (uint16_t)h);
 }
 
-// stage 2b from memory (16-bit logits: the reducing wave left only the lane pick): lane j loads the chosen lane's
-// j-th element - eight 16-byte runs a kilobyte apart -, applies scale and mask exactly as the reduction did, and the
-// scan of pick_in_lane names the element.  Nm: the scale the chunk's allowed terms were summed on (its record).
+// stage 2b: lane j loads the chosen lane's j-th element (eight or sixteen 16-byte runs a kilobyte apart), applies scale
+// and mask exactly as the reduction did, and the scan of pick_in_lane names the element.  Nm: the scale the chunk's
+// allowed terms were summed on (its record).
 template <int DT, int MASK>
 __device__ __forceinline__ int32_t chunk_pick_element_mem(const RowView<DT, MASK> &rv, int c, uint64_t pick, float Nm,
                                                           int lane) {
@@ -698,44 +626,6 @@ __device__ __forceinline__ int32_t chunk_pick_element_mem(const RowView<DT, MASK
   const int jsel = pick_in_lane(h, l, Tl);
   if (jsel < 0) return -1;
   return __builtin_amdgcn_readlane(e, jsel);
-}
-
-// The in-chunk draw for a particle whose chunk is not in registers any more (two-launch path; members of a shared row
-// beyond the ones the reducing wave drew for): one wave reloads chunk c and goes through exactly what the reducing wave
-// did - maximum, sums, low-mass rule, draw - with the same functions, so the result is the same.
-template <int DT, int MASK>
-__device__ __forceinline__ int32_t draw_chunk_reload(const RowView<DT, MASK> &rv, int c, int lane, uint64_t R2,
-                                                     float *s_tr) {
-  constexpr int EPV = ElemTraits<DT>::EPV, NVC = ElemTraits<DT>::NVC;
-  const int e_base = c * kChunk;
-  int nv_valid = (rv.V - e_base + 64 * EPV - 1) / (64 * EPV);
-  nv_valid = nv_valid < NVC ? nv_valid : NVC;
-  float x[64];
-  load_chunk<DT, true>(rv.rowp, e_base, rv.V, lane, rv.scale, x);
-  uint32_t pA, pB, pAm, pBm;
-  if constexpr (MASK == kMaskBits) {
-    const uint64_t *mtc = rv.mt + (int64_t)c * 64;
-    const uint64_t mw = mtc[lane];
-    MaskAhead ma;
-    mask_ahead<DT>(as_const(mtc), ma);
-    const float Nc = exp_n(chunk_max(x));
-    float Nm;
-    bool redone;
-    chunk_reduce_bits<DT>(x, Nc, nv_valid, as_const(mtc), ma, as_const(rv.many)[c], lane, pA, pB, pAm, pBm, Nm,
-                          redone);
-    if (redone) return chunk_candidate<DT, false>(x, kMagic - Nm, e_base, lane, pAm, pBm, 0ull, R2, s_tr);
-    return chunk_candidate<DT, true>(x, kMagic - Nc, e_base, lane, pAm, pBm, mw, R2, s_tr);
-  } else if constexpr (MASK == kMaskF32) {
-    float y[64];
-    add_float_mask<DT>(x, rv.mrow, e_base, rv.V, lane, y);
-    const float Nm = exp_n(chunk_max(y));
-    chunk_sums<DT, false>(y, kMagic - Nm, nv_valid, nullptr, MaskAhead{}, pA, pB, pAm, pBm);
-    return chunk_candidate<DT, false>(y, kMagic - Nm, e_base, lane, pA, pB, 0ull, R2, s_tr);
-  } else {
-    const float Nc = exp_n(chunk_max(x));
-    chunk_sums<DT, false>(x, kMagic - Nc, nv_valid, nullptr, MaskAhead{}, pA, pB, pAm, pBm);
-    return chunk_candidate<DT, false>(x, kMagic - Nc, e_base, lane, pA, pB, 0ull, R2, s_tr);
-  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -799,15 +689,13 @@ __device__ __forceinline__ void pair_logs(const PairState &st, float &lse, float
   logZ = (float)(lse_msk - lse_all);
 }
 
-// The Philox draw of particle pidx, two stages: the chunk by a scan of the shifted chunk sums (first draw); inside the
-// chunk the second draw - taken from `cand` (per-chunk results the reducing waves left behind; for rows of up to 64
-// chunks lane c has already fetched chunk c's into my_cand) or, when cand is null, recomputed from a reload of that
-// chunk.
+// The Philox draw of particle pidx: the chunk by a scan of the shifted chunk sums (first Philox word); inside the chunk,
+// with the second word, the lane from the per-lane scans the reducing wave left in the workspace, then the element from
+// a gathered load of that lane's 64 values.  Three dependent round trips after the records: 512 B, 1 KiB.
 template <int DT, int MASK, class Recs>
 __device__ __forceinline__ int32_t pair_draw_philox(const StepParams &p, const Recs &recs, const RowView<DT, MASK> &rv,
                                                     const PairState &st, int pidx, int nch, int lane,
-                                                    const int32_t *cand, int cand_stride, int32_t my_cand,
-                                                    uint64_t my_pick, float *s_tr) {
+                                                    const uint32_t *lanes) {
   uint32_t nz = (uint32_t)st.S_msk | (uint32_t)(st.S_msk >> 32);
   opaque_u32(nz);
   if (nz == 0u) return -1;
@@ -839,17 +727,9 @@ __device__ __forceinline__ int32_t pair_draw_philox(const StepParams &p, const R
     }
   }
   if (csel < 0) return -1;  // consistent sums rule this out
-  if (cand) {
-    if constexpr (kDrawDeferred<DT>) {  // the reducing wave picked the lane; the element comes from one gathered load
-      const uint64_t pick = nch <= 64 ? readlane_u64(my_pick, csel)
-                                      : reinterpret_cast<const uint64_t *>(cand)[(int64_t)csel * cand_stride];
-      return chunk_pick_element_mem(rv, csel, pick, Nms, lane);
-    } else {
-      if (nch <= 64) return __builtin_amdgcn_readlane(my_cand, csel);
-      return cand[(int64_t)csel * cand_stride];
-    }
-  }
-  return draw_chunk_reload(rv, csel, lane, R2, s_tr);
+  const uint64_t w = *reinterpret_cast<const uint64_t *>(lanes + ((int64_t)csel * 64 + lane) * 2);
+  const uint64_t pick = chunk_pick_lane((uint32_t)w, (uint32_t)(w >> 32), R2);
+  return chunk_pick_element_mem(rv, csel, pick, Nms, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -859,7 +739,6 @@ __device__ __forceinline__ int32_t pair_draw_philox(const StepParams &p, const R
 template <int DT, int MASK, int MODE>
 __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
   constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC;
-  __shared__ float s_tr[64];
   __shared__ float s_bestg[4], s_secg[4];
   __shared__ int32_t s_bestj[4];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -879,36 +758,6 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
   rv.many = MASK == kMaskBits ? p.mask_any + (int64_t)mi * nch : nullptr;
   rv.mrow = MASK == kMaskF32 ? (const char *)(p.mask_f + (int64_t)mi * p.mask_ld) : nullptr;
 
-  // did the reducing waves draw for this particle (it is one of its unit's first kDrawCap members)?  Then lane c
-  // fetches chunk c's token beside the records (rows of up to 64 chunks): the look-up after the chunk scan is a lane
-  // read, not one more dependent load
-  const int32_t *cand = nullptr;  // this particle's entry of chunk 0 (int32 tokens, or 64-bit lane picks for 16-bit logits)
-  int32_t my_cand = -1;
-  uint64_t my_pick = ~0ull;
-  if constexpr (MODE == kModePhilox) {
-    if (p.cands && p.out_token) {
-      int slot = -1;
-      if (!p.pair_of) {
-        slot = 0;
-      } else if (p.mem_start) {
-        const int m0 = as_const(p.mem_start)[pr];
-        int cnt = as_const(p.mem_start)[pr + 1] - m0;
-        cnt = cnt < kDrawCap ? cnt : kDrawCap;
-        for (int m = 0; m < cnt; ++m)
-          if (as_const(p.members)[m0 + m] == pidx) slot = m;
-      }
-      if (slot >= 0) {
-        if constexpr (kDrawDeferred<DT>) {
-          const uint64_t *c64 = reinterpret_cast<const uint64_t *>(p.cands) + (int64_t)pr * nch * kDrawCap + slot;
-          cand = reinterpret_cast<const int32_t *>(c64);
-          if (nch <= 64 && lane < nch) my_pick = c64[lane * kDrawCap];
-        } else {
-          cand = p.cands + (int64_t)pr * nch * kDrawCap + slot;
-          if (nch <= 64 && lane < nch) my_cand = cand[lane * kDrawCap];
-        }
-      }
-    }
-  }
   PairState st;
   pair_fold<MASK>(recs, nch, lane, st);
   if (wave == 0 && lane == 0) {
@@ -921,7 +770,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
   if (!p.out_token) return;
 
   if constexpr (MODE == kModePhilox) {
-    const int32_t tok = pair_draw_philox<DT, MASK>(p, recs, rv, st, pidx, nch, lane, cand, kDrawCap, my_cand, my_pick, s_tr);
+    const int32_t tok = pair_draw_philox<DT, MASK>(p, recs, rv, st, pidx, nch, lane, p.lanes + (int64_t)pr * nch * 128);
     if (lane == 0) p.out_token[pidx] = tok;
   } else {
     // ---- parity mode: exponential race against the caller's noise, first maximum of e_j / E_j (README.md:87

@@ -17,22 +17,26 @@ namespace glb {
 // two SIMDs the per-wave latency is the launch time)
 constexpr int64_t kSmallLaunchItems = 512;
 
+// lanes: the call draws with Philox - the reducing waves also store their per-lane scans (StepParams::lanes)
 template <int MASK>
-static hipError_t stats1(const StepParams &p, bool scaled, bool draw, hipStream_t s) {
+static hipError_t stats1(const StepParams &p, bool scaled, bool lanes, hipStream_t s) {
   const int64_t waves = (int64_t)p.n_pairs * p.nch;
   if constexpr (MASK != kMaskF32) {
-    if (waves <= kSmallLaunchItems && !draw) {
+    if (waves <= kSmallLaunchItems) {
       const dim3 grid((unsigned)waves), block(256);
-      if (scaled)
-        hipLaunchKernelGGL((chunk_stats_small_kernel<GLB_DT, MASK, true>), grid, block, 0, s, p);
-      else
-        hipLaunchKernelGGL((chunk_stats_small_kernel<GLB_DT, MASK, false>), grid, block, 0, s, p);
+      if (lanes) {
+        if (scaled) hipLaunchKernelGGL((chunk_stats_small_kernel<GLB_DT, MASK, true, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((chunk_stats_small_kernel<GLB_DT, MASK, false, true>), grid, block, 0, s, p);
+      } else {
+        if (scaled) hipLaunchKernelGGL((chunk_stats_small_kernel<GLB_DT, MASK, true, false>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((chunk_stats_small_kernel<GLB_DT, MASK, false, false>), grid, block, 0, s, p);
+      }
       return hipGetLastError();
     }
   }
   const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
   static const size_t lds = [] { const char *e = getenv("GLB_K1_LDS"); return e ? (size_t)atoi(e) : 0; }();  // tuning aid: caps the waves per SIMD
-  if (draw) {
+  if (lanes) {
     if (scaled) hipLaunchKernelGGL((chunk_stats_kernel<GLB_DT, MASK, true, true>), grid, block, lds, s, p);
     else hipLaunchKernelGGL((chunk_stats_kernel<GLB_DT, MASK, false, true>), grid, block, lds, s, p);
   } else {
@@ -42,12 +46,11 @@ static hipError_t stats1(const StepParams &p, bool scaled, bool draw, hipStream_
   return hipGetLastError();
 }
 
-// draw: the reducing waves also make the in-chunk draws of each unit's first particles (StepParams::cands)
-hipError_t GLB_CAT(launch_stats_, GLB_DT)(const StepParams &p, int mask_kind, bool scaled, bool draw, hipStream_t s) {
+hipError_t GLB_CAT(launch_stats_, GLB_DT)(const StepParams &p, int mask_kind, bool scaled, bool lanes, hipStream_t s) {
   switch (mask_kind) {
-    case kMaskNone: return stats1<kMaskNone>(p, scaled, draw, s);
-    case kMaskBits: return stats1<kMaskBits>(p, scaled, draw, s);
-    case kMaskF32: return stats1<kMaskF32>(p, scaled, draw, s);
+    case kMaskNone: return stats1<kMaskNone>(p, scaled, lanes, s);
+    case kMaskBits: return stats1<kMaskBits>(p, scaled, lanes, s);
+    case kMaskF32: return stats1<kMaskF32>(p, scaled, lanes, s);
   }
   return hipErrorInvalidValue;
 }

@@ -106,16 +106,13 @@ class HipEngine:
 
     def step(self, logits, vocab=None, row_of=None, mask_kind=MASK_NONE, mask=None, mask_id=None,
              rng_mode=RNG_NONE, noise=None, seed=0, offset=0, particle_base=0, logit_scale=1.0,
-             want_lse=True, variant=0, out=None, row_mask_id=None, out_margin=None, row_members=None, _plan=False):
+             want_lse=True, variant=0, out=None, row_mask_id=None, out_margin=None, _plan=False):
         """Fused particle step (glb_logprob_mask_sample).  Returns (logZ, lse, token) device tensors.
 
         logits: [n_rows, ld] (last dim contiguous; rows may be strided), vocab <= ld.
         mask: int32 bit rows / float rows, or a `PreparedMasks` (prepare_masks).  `row_mask_id` gives the mask per
         logits row (the mask is a function of the context): shared rows are then reduced once.
         `variant` is accepted for source compatibility and ignored (one kernel family serves every shape).
-        `row_members` = (start, members[, max]) from `row_members()`: the inverse of `row_of` for a per-row reduction
-        (no mask, or `row_mask_id`); with it the reducing waves also make the in-chunk draws and the per-particle
-        launch only looks tokens up.  Same results with or without.
         """
         if logits.dim() != 2 or logits.stride(1) != 1:
             raise ValueError("logits must be 2-D with unit inner stride")
@@ -176,17 +173,11 @@ class HipEngine:
         a.out_lse = None if lse is None else lse.data_ptr()
         a.out_token = None if tok is None else tok.data_ptr()
         a.out_margin = None if out_margin is None else out_margin.data_ptr()  # parity mode: tie margin of every draw
-        if row_members is not None:
-            start, members = row_members[0], row_members[1]
-            self._check_dev(start, members)
-            if start.dtype != torch.int32 or members.dtype != torch.int32 or start.numel() < n_rows + 1 or members.numel() < n:
-                raise ValueError("row_members: int32 start [n_rows + 1] and members [n_particles]")
-            a.row_members_start, a.row_members = start.data_ptr(), members.data_ptr()
         ws = self._scratch(self.lib.glb_step_workspace_bytes(n, n_rows, V, n_masks))
         a.workspace = ws.data_ptr()
         a.workspace_bytes = ws.numel()
         if _plan:  # step_plan(): the filled argument block, the tensors it points into, the outputs
-            return StepPlan(self, a, (logits, row_of, mask, mask_id, row_mask_id, noise, out_margin, row_members, ws),
+            return StepPlan(self, a, (logits, row_of, mask, mask_id, row_mask_id, noise, out_margin, ws),
                             (logZ, lse, tok))
         check(self.lib.glb_logprob_mask_sample(C.byref(a), self._stream()))
         return logZ, lse, tok
@@ -198,17 +189,6 @@ class HipEngine:
         their storage; the scratch buffer is the engine's, so a plan is valid until another, larger step reallocates
         it (run() checks)."""
         return self.step(logits, _plan=True, **kw)
-
-    def row_members(self, row_of, n_rows, out=None):
-        """Inverse of the fan-out map (glb_row_members): (start int32 [n_rows + 2], members int32 [n], max int32 [1])
-        device tensors; members of a row come in no particular order."""
-        self._check_dev(row_of)
-        if row_of.dtype != torch.int32 or row_of.dim() != 1 or not row_of.is_contiguous():
-            raise TypeError("row_of must be a contiguous int32 vector")
-        n = row_of.numel()
-        start, members, mx = out if out is not None else (self._i32(n_rows + 2), self._i32(n), self._i32(1))
-        check(self.lib.glb_row_members(_ptr(row_of), n, n_rows, _ptr(start), _ptr(members), _ptr(mx), self._stream()))
-        return start, members, mx
 
     def prepare_masks(self, bits, vocab, logits_dtype=torch.float32):
         """int32 bit rows [K, >= ceil(V/32)] -> `PreparedMasks` for logits of `logits_dtype` (glb_mask_prepare)."""

@@ -683,8 +683,6 @@ class AsyncAmdLM(AsyncLM):
             noise = torch.empty((n, V), dtype=torch.float32)
             noise[torch.from_numpy(order)] = self._host_rng.exponential(n * V).view(n, V)
             kw["noise"] = noise.to(dev, non_blocking=True)
-        elif "mask_id" not in kw:  # per-row reduction: the fan-out map's inverse lets the reducing waves draw as well
-            kw["row_members"] = eng.row_members(group_of, U)
         logZ, _, tok = eng.step(logits, vocab=V, row_of=group_of, rng_mode=self._rng_mode, seed=self._rng_seed,
                                 offset=self._batch_counter, want_lse=False, **kw)
         self._batch_counter += 1

@@ -231,12 +231,6 @@ class DeviceSIS:
             self._noise_groups, _, _ = eng.group_contexts(self.contexts.view(-1), self.starts, lengths_eff)
         return self._finish_step(logits, None, N, n_active, n_global, time_kernel, l_max=1)
 
-    def _row_members(self, group_of, U):
-        if getattr(self, "_members_buf", None) is None:
-            i32 = dict(dtype=torch.int32, device=self.dev)
-            self._members_buf = (torch.empty(self.N + 2, **i32), torch.empty(self.N, **i32), torch.empty(1, **i32))
-        return self.eng.row_members(group_of, U, out=self._members_buf)
-
     def _finish_step(self, logits, group_of, U, n_active, n_global, time_kernel, l_max):
         eng, llm, N = self.eng, self.llm, self.N
         V = logits.shape[-1]
@@ -254,10 +248,6 @@ class DeviceSIS:
                 kw["mask_id"] = mask_id
         if self.rng_mode == RNG_NOISE:
             kw["noise"] = self._parity_noise(group_of if group_of is not None else self._noise_groups, V)
-        elif group_of is not None and "mask_id" not in kw:
-            # a per-row reduction fans out through group_of: hand its inverse over as well, so that the waves reducing
-            # a row also make the in-chunk draws of the particles sitting on it (hf.py:285-288's fan-out, inverted)
-            kw["row_members"] = self._row_members(group_of, U)
         if time_kernel:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -455,8 +445,6 @@ class DeviceSampler(DeviceSIS):
         if self.noise_rng is not None:
             mode = RNG_NOISE
             kw["noise"] = self.noise_rng.exponential(V).view(1, V).to(dev, non_blocking=True)
-        elif group_of is not None:
-            kw["row_members"] = self._row_members(group_of, U)
         _, _, tok = eng.step(logits, vocab=V, row_of=group_of, rng_mode=mode, seed=self.seed, offset=self.t,
                              logit_scale=1.0 / self.temperature, want_lse=False, **kw)
         act = self.active > 0

@@ -79,7 +79,8 @@ int glb_device_count(void);
  * in one pass over the logits row.  Particle i reads row row_of[i] (dedup fan-out of
  * hf.py:214-220,285-288) and mask row mask_id[i].  When the mask is a function of the context - as in
  * the README, where it depends on len(context) only - pass the ids per logits ROW (row_mask_id) instead:
- * a row shared by several particles is then reduced once and only the draw is done per particle.
+ * a row shared by several particles is then reduced once and only the draw is done per particle (any number of
+ * particles per row: the reduction leaves what every draw needs, whoever makes it).
  */
 typedef struct glb_step_args {
   uint32_t struct_size; /* sizeof(glb_step_args) — ABI guard */
@@ -117,31 +118,15 @@ typedef struct glb_step_args {
   float *out_margin; /* [n_particles] GLB_RNG_NOISE only: (winner - runner-up) / winner of the race e_j / E_j, i.e. how
                         far the draw is from a tie that float rounding could flip (1 if there is no runner-up) */
   int32_t reserved;  /* must be 0 */
-  /* Optional inverse of row_of for per-row reductions (row_of given; no mask or row_mask_id), from
-     glb_row_members: the particles on row r are row_members[row_members_start[r] .. row_members_start[r + 1]).
-     With it the waves that reduce a row also make the in-chunk draws of the row's first eight particles, and the
-     per-particle launch only looks the token up; without it every particle redoes the chunk it lands in.  Same
-     results either way. */
-  const int32_t *row_members_start; /* [n_rows + 1] device, nullable */
-  const int32_t *row_members;       /* [n_particles] device, nullable */
-  /* device scratch of >= glb_step_workspace_bytes(...) bytes, 32-byte aligned: the per-chunk records and in-chunk
-     draws the reduction kernel hands to the per-particle kernel (and, for GLB_MASK_BITS, the prepared masks) */
+  /* device scratch of >= glb_step_workspace_bytes(...) bytes, 32-byte aligned: the per-chunk records and per-lane
+     scans (32 + 512 bytes per row and 4096-token chunk) the reduction kernel hands to the per-particle kernel (and, for
+     GLB_MASK_BITS, the prepared masks) */
   void *workspace;
   size_t workspace_bytes;
 } glb_step_args;
 
 size_t glb_step_workspace_bytes(int64_t n_particles, int64_t n_rows, int64_t vocab, int64_t n_masks);
 int glb_logprob_mask_sample(const glb_step_args *args, void *hip_stream);
-
-/*
- * Inverse of the fan-out map row_of (hf.py:285-288 hands every query of a group the group's result): the particles
- * of each row as a CSR (members of a row in no particular order).
- *   out_start   [n_rows + 2]  device int32; [0, n_rows] are the offsets (the extra word is scratch)
- *   out_members [n_particles] device int32
- *   out_max     [1]           device int32, optional: the largest number of particles on one row
- */
-int glb_row_members(const int32_t *row_of, int64_t n_particles, int64_t n_rows, int32_t *out_start,
-                    int32_t *out_members, int32_t *out_max, void *hip_stream);
 
 /*
  * Bring GLB_MASK_BITS rows into the layout the kernels read ([mask][chunk][vector][component] 64-bit lane

@@ -397,29 +397,6 @@ int orc_step(const void *logits, int dtype, int64_t n_rows, int64_t V, int64_t l
   return 0;
 }
 
-/* contract of glb_row_members (inverse of the fan-out of hf.py:285-288): CSR of the particles on every row; the kernel
- * promises no order inside a row, this restatement lists them in increasing order (tests compare row by row as sets) */
-int orc_row_members(const int32_t *row_of, int64_t n, int64_t n_rows, int32_t *start, int32_t *members,
-                    int32_t *out_max) {
-  for (int64_t r = 0; r <= n_rows; ++r) start[r] = 0;
-  for (int64_t i = 0; i < n; ++i) {
-    if (row_of[i] < 0 || row_of[i] >= n_rows) return 1;
-    start[row_of[i] + 1]++;
-  }
-  int32_t mx = 0;
-  for (int64_t r = 0; r < n_rows; ++r) {
-    if (start[r + 1] > mx) mx = start[r + 1];
-    start[r + 1] += start[r];
-  }
-  int32_t *cur = (int32_t *)malloc(sizeof(int32_t) * (size_t)n_rows);
-  if (!cur) return 4;
-  for (int64_t r = 0; r < n_rows; ++r) cur[r] = start[r];
-  for (int64_t i = 0; i < n; ++i) members[cur[row_of[i]]++] = (int32_t)i;
-  free(cur);
-  if (out_max) *out_max = mx;
-  return 0;
-}
-
 /* contract of glb_log_softmax_rows: out = x - (float)lse, lse from the chunked integer sums */
 int orc_log_softmax_rows(const void *logits, int dtype, int64_t n_rows, int64_t V, int64_t ld,
                          float logit_scale, float *out, int64_t out_ld, float *out_lse) {

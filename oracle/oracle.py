@@ -251,18 +251,6 @@ def resample_systematic(log_weights, seed=0, offset=0):
     return anc, float(stats[0])
 
 
-def row_members(row_of, n_rows):
-    """CSR inverse of row_of: (start int32 [n_rows + 1], members int32 [n] in increasing order per row, max per row)."""
-    ro = np.ascontiguousarray(row_of, dtype=np.int32)
-    start = np.empty(n_rows + 1, np.int32)
-    members = np.empty(len(ro), np.int32)
-    mx = np.zeros(1, np.int32)
-    rc = lib().orc_row_members(_p(ro), C.c_int64(len(ro)), C.c_int64(n_rows), _p(start), _p(members), _p(mx))
-    if rc:
-        raise RuntimeError(f"orc_row_members rc={rc}")
-    return start, members, int(mx[0])
-
-
 def trie_reduce(ws, flat, op=0, from_logprobs=False):
     """Layer-B trie masses: ws [B, V] float32, flat = dict of the flattened trie arrays (genlm_backend_amd.trie)."""
     ws = np.ascontiguousarray(ws, dtype=np.float32)

@@ -32,7 +32,7 @@ class CpuOracleEngine:
 
     def step(self, logits, vocab=None, row_of=None, mask_kind=0, mask=None, mask_id=None, rng_mode=0, noise=None,
              seed=0, offset=0, particle_base=0, logit_scale=1.0, want_lse=True, variant=0, out=None, row_mask_id=None,
-             out_margin=None, row_members=None):
+             out_margin=None):
         V = logits.shape[1] if vocab is None else vocab
         x = _logits_np(logits[:, :V])
         if isinstance(mask, _Prepared):
@@ -57,11 +57,6 @@ class CpuOracleEngine:
                     o.copy_(r)
             return out
         return res
-
-    def row_members(self, row_of, n_rows, out=None):
-        start, members, mx = O.row_members(_np(row_of), n_rows)
-        return (torch.from_numpy(np.concatenate([start, start[-1:]])), torch.from_numpy(members),
-                torch.tensor([mx], dtype=torch.int32))
 
     def log_softmax_rows(self, logits, vocab=None, logit_scale=1.0, out=None, want_lse=False):
         V = logits.shape[1] if vocab is None else vocab

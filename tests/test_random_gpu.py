@@ -112,15 +112,3 @@ def test_random_case(engine, oracle, c):
             assert np.array_equal(tok.cpu().numpy(), tok_o), f"token ({what})"
 
     check(call(), "auto")
-    # a per-row reduction with a fan-out map gives the same bits when the inverse map is handed over (the reducing
-    # waves then make the in-chunk draws of each row's first eight particles; later ones still redo their chunk)
-    per_row = c["mask_kind"] == "none" or c["form"] == "by_row"
-    if per_row and row_of is not None:
-        ro_d = torch.from_numpy(row_of).to(dev)
-        start, members, mx = engine.row_members(ro_d, U)
-        st_o, mem_o, mx_o = O.row_members(row_of, U)
-        assert np.array_equal(start.cpu().numpy()[:U + 1], st_o) and int(mx.item()) == mx_o
-        got = members.cpu().numpy()
-        for r in range(U):
-            assert sorted(got[st_o[r]:st_o[r + 1]]) == list(mem_o[st_o[r]:st_o[r + 1]])
-        check(call(row_members=(start, members)), "with row members")

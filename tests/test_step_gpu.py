@@ -329,7 +329,7 @@ def test_peaked_rows_with_the_likely_token_forbidden(engine, oracle, dtype):
     """Constrained decoding's everyday case: the model is sure of a token the mask forbids.  The allowed mass of that
     chunk is then far below its largest term - down to underflowing to zero on the chunk's scale - and the chunk sums
     its allowed values again on their own scale (per chunk, from registers); logZ must still match a float64
-    log-softmax, for every path (draws by the reducing waves, reload in the per-particle launch, shared rows)."""
+    log-softmax, for every mask hand-over form and shared rows."""
     O = oracle
     dev = engine.device
     V, U = 50257, 160
@@ -356,8 +356,7 @@ def test_peaked_rows_with_the_likely_token_forbidden(engine, oracle, dtype):
     calls = {
         "per particle": dict(mask_kind=1, mask=bits_d, mask_id=ro_d),
         "per row": dict(mask_kind=1, mask=bits_d, row_mask_id=rmid),
-        "per row, members": dict(mask=engine.prepare_masks(bits_d, V, tdt), row_mask_id=rmid,
-                                 row_members=engine.row_members(ro_d, U)),
+        "per row, prepared": dict(mask=engine.prepare_masks(bits_d, V, tdt), row_mask_id=rmid),
     }
     for what, kw in calls.items():
         logZ, lse, tok = engine.step(x_d, row_of=ro_d, rng_mode=1, seed=9, offset=2, **kw)

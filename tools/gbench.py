@@ -24,9 +24,3 @@ for n in (1024, 4096, 16384):
         tok = torch.from_numpy(mat.reshape(-1)).to(dev); st = (torch.arange(n, device=dev, dtype=torch.int64) * cap)
         ln = torch.full((n,), 13, dtype=torch.int32, device=dev)
         print(f"group_contexts n={n} distinct={distinct}: {t(lambda: eng.group_contexts(tok, st, ln)):.1f} us", flush=True)
-    ro = torch.from_numpy(rs.integers(0, max(n // 2, 1), n).astype(np.int32)).to(dev)
-    bufs = (torch.empty(n + 2, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev),
-            torch.empty(1, dtype=torch.int32, device=dev))
-    print(f"row_members n={n}: {t(lambda: eng.row_members(ro, n, out=bufs)):.1f} us", flush=True)
-    z = torch.zeros(n, dtype=torch.int32, device=dev)
-    print(f"row_members n={n}, one row: {t(lambda: eng.row_members(z, n, out=bufs)):.1f} us", flush=True)
