@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256, 5) void chunk_stats_kernel(const StepParams p)
   }
   if constexpr (LANES) {
     uint32_t *ls = p.lanes + (((int64_t)pr * nch + c) * 64 + lane) * 2;
-    *reinterpret_cast<uint64_t *>(ls) = ((uint64_t)pBm << 32) | pAm;
+    __builtin_nontemporal_store(((uint64_t)pBm << 32) | pAm, reinterpret_cast<uint64_t *>(ls));
   }
   if (lane == 63) store_rec(p.recs + (int64_t)pr * nch + c, Nc, pA, pB, pAm, pBm, Nm);
 }
