@@ -689,22 +689,28 @@ __device__ __forceinline__ void pair_logs(const PairState &st, float &lse, float
   logZ = (float)(lse_msk - lse_all);
 }
 
-// The Philox draw of particle pidx: the chunk by a scan of the shifted chunk sums (first Philox word); inside the chunk,
-// with the second word, the lane from the per-lane scans the reducing wave left in the workspace, then the element from
-// a gathered load of that lane's 64 values.  Three dependent round trips after the records: 512 B, 1 KiB.
-template <int DT, int MASK, class Recs>
-__device__ __forceinline__ int32_t pair_draw_philox(const StepParams &p, const Recs &recs, const RowView<DT, MASK> &rv,
-                                                    const PairState &st, int pidx, int nch, int lane,
-                                                    const uint32_t *lanes) {
+// The Philox draw of particle pidx, in two calls so that the caller can put other work between a load and its use:
+// pair_pick_chunk - the chunk by a scan of the shifted chunk sums (first Philox word), and the request for this lane's
+// scan word of that chunk (what the reducing wave left in the workspace); pair_pick_token - with the second word, the
+// lane from those scans, then the element from a gathered load of that lane's 64 values.
+struct ChunkPick {
+  int csel;       // -1: nothing to draw from
+  float Nms;      // the scale the chosen chunk's allowed terms sit on
+  uint64_t R2;    // second Philox word
+  uint64_t scan;  // this lane's (A, B) inclusive scan words of the chosen chunk
+};
+
+template <class Recs>
+__device__ __forceinline__ ChunkPick pair_pick_chunk(const StepParams &p, const Recs &recs, const PairState &st, int pidx,
+                                                     int nch, int lane, const uint32_t *lanes) {
+  ChunkPick k{-1, 0.f, 0ull, 0ull};
   uint32_t nz = (uint32_t)st.S_msk | (uint32_t)(st.S_msk >> 32);
   opaque_u32(nz);
-  if (nz == 0u) return -1;
-  uint64_t R1, R2;
-  philox_pair(p, pidx, R1, R2);
+  if (nz == 0u) return k;
+  uint64_t R1;
+  philox_pair(p, pidx, R1, k.R2);
   uint64_t T = __umul64hi(R1, st.S_msk);  // uniform integer in [0, S_msk)
-  int csel = -1;
-  float Nms = 0.f;  // the scale the chosen chunk's allowed terms sit on
-  for (int c0 = 0; c0 < nch && csel < 0; c0 += 64) {
+  for (int c0 = 0; c0 < nch && k.csel < 0; c0 += 64) {
     const int c = c0 + lane;
     uint64_t sm = 0;
     float Nm = kNegInf;
@@ -720,16 +726,21 @@ __device__ __forceinline__ int32_t pair_draw_philox(const StepParams &p, const R
     const uint64_t incl = wave_scan_u64(sm);
     const int lsel = first_lane_above(incl, T);
     if (lsel >= 0) {
-      csel = c0 + lsel;
-      Nms = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(Nm), lsel));
+      k.csel = c0 + lsel;
+      k.Nms = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(Nm), lsel));
     } else {
       T -= readlane_u64(incl, 63);
     }
   }
-  if (csel < 0) return -1;  // consistent sums rule this out
-  const uint64_t w = *reinterpret_cast<const uint64_t *>(lanes + ((int64_t)csel * 64 + lane) * 2);
-  const uint64_t pick = chunk_pick_lane((uint32_t)w, (uint32_t)(w >> 32), R2);
-  return chunk_pick_element_mem(rv, csel, pick, Nms, lane);
+  if (k.csel >= 0) k.scan = *reinterpret_cast<const uint64_t *>(lanes + ((int64_t)k.csel * 64 + lane) * 2);
+  return k;
+}
+
+template <int DT, int MASK>
+__device__ __forceinline__ int32_t pair_pick_token(const RowView<DT, MASK> &rv, const ChunkPick &k, int lane) {
+  if (k.csel < 0) return -1;  // (with a non-zero sum, consistent records rule this out)
+  const uint64_t pick = chunk_pick_lane((uint32_t)k.scan, (uint32_t)(k.scan >> 32), k.R2);
+  return chunk_pick_element_mem(rv, k.csel, pick, k.Nms, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -760,6 +771,10 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
 
   PairState st;
   pair_fold<MASK>(recs, nch, lane, st);
+  ChunkPick pick{-1, 0.f, 0ull, 0ull};
+  if constexpr (MODE == kModePhilox) {  // the chunk, and the request for its scan words: in flight during the logs
+    if (p.out_token) pick = pair_pick_chunk(p, recs, st, pidx, nch, lane, p.lanes + (int64_t)pr * nch * 128);
+  }
   if (wave == 0 && lane == 0) {
     float lse, logZ;
     pair_logs(st, lse, logZ);
@@ -770,7 +785,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
   if (!p.out_token) return;
 
   if constexpr (MODE == kModePhilox) {
-    const int32_t tok = pair_draw_philox<DT, MASK>(p, recs, rv, st, pidx, nch, lane, p.lanes + (int64_t)pr * nch * 128);
+    const int32_t tok = pair_pick_token<DT, MASK>(rv, pick, lane);
     if (lane == 0) p.out_token[pidx] = tok;
   } else {
     // ---- parity mode: exponential race against the caller's noise, first maximum of e_j / E_j (README.md:87
