@@ -421,9 +421,11 @@ __global__ __launch_bounds__(256, 5) void chunk_stats_kernel(const StepParams p)
       chunk_sums<DT, false>(y, kMagic - Nm, nv_valid, nullptr, ma, pAm, pBm, d0, d1);
     }
   }
-  if constexpr (LANES) {
-    uint32_t *ls = p.lanes + (((int64_t)pr * nch + c) * 64 + lane) * 2;
-    __builtin_nontemporal_store(((uint64_t)pBm << 32) | pAm, reinterpret_cast<uint64_t *>(ls));
+  if constexpr (LANES) {  // (a chunk without allowed mass is never drawn from: sparse masks skip most of these stores)
+    if ((__builtin_amdgcn_readlane((int)pAm, 63) | __builtin_amdgcn_readlane((int)pBm, 63)) != 0) {
+      uint32_t *ls = p.lanes + (((int64_t)pr * nch + c) * 64 + lane) * 2;
+      __builtin_nontemporal_store(((uint64_t)pBm << 32) | pAm, reinterpret_cast<uint64_t *>(ls));
+    }
   }
   if (lane == 63) store_rec(p.recs + (int64_t)pr * nch + c, Nc, pA, pB, pAm, pBm, Nm);
 }
