@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libglb_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 GLB_OK, GLB_EINVAL, GLB_EUNSUPPORTED, GLB_EHIP, GLB_ENOSPC = 0, 1, 2, 3, 4
 F32, BF16, F16 = 0, 1, 2
 MASK_NONE, MASK_BITS, MASK_F32, MASK_PREPARED = 0, 1, 2, 3
@@ -68,6 +68,8 @@ SYMBOLS = {
     "glb_device_count": (C.c_int, []),
     "glb_step_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "glb_logprob_mask_sample": (C.c_int, [C.POINTER(StepArgs), _vp]),
+    "glb_workspace_init": (C.c_int, [_vp, _sz, _vp]),
+    "glb_workspace_release": (C.c_int, [_vp]),
     "glb_mask_prepared_bytes": (_sz, [_i64, _i64]),
     "glb_mask_prepare": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _vp, _sz, _vp]),
     "glb_log_softmax_workspace_bytes": (_sz, [_i64, _i64]),

@@ -8,7 +8,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 
 #include "../../include/glb.h"
 #include "glb_chunk.hpp"
@@ -16,7 +18,8 @@
 namespace glb {
 // launchers exported by the three glb_chunk_tu.hip translation units (one per element type)
 #define GLB_DECL(dt)                                                                                              \
-  hipError_t launch_stats_##dt(const StepParams &p, int mask_kind, bool scaled, bool lanes, hipStream_t s);        \
+  hipError_t launch_stats_##dt(const StepParams &p, int mask_kind, bool scaled, hipStream_t s);                    \
+  hipError_t launch_fused_step_##dt(const StepParams &p, int mask_kind, int mode, bool scaled, hipStream_t s);     \
   hipError_t launch_finish_##dt(const StepParams &p, int mask_kind, int mode, hipStream_t s);                     \
   hipError_t launch_logprob_rows_##dt(const void *logits, int64_t ld, int V, float scale, const float *lse,       \
                                       float *out, int64_t out_ld, int n_rows, hipStream_t s);                      \
@@ -44,13 +47,45 @@ int hip_fail(hipError_t e, const char *what) {
   return fail(GLB_EHIP, "%s: %s", what, hipGetErrorString(e));
 }
 
-hipError_t launch_stats(int dtype, const glb::StepParams &p, int mask_kind, bool scaled, bool lanes, hipStream_t s) {
+hipError_t launch_stats(int dtype, const glb::StepParams &p, int mask_kind, bool scaled, hipStream_t s) {
   switch (dtype) {
-    case 0: return glb::launch_stats_0(p, mask_kind, scaled, lanes, s);
-    case 1: return glb::launch_stats_1(p, mask_kind, scaled, lanes, s);
-    case 2: return glb::launch_stats_2(p, mask_kind, scaled, lanes, s);
+    case 0: return glb::launch_stats_0(p, mask_kind, scaled, s);
+    case 1: return glb::launch_stats_1(p, mask_kind, scaled, s);
+    case 2: return glb::launch_stats_2(p, mask_kind, scaled, s);
   }
   return hipErrorInvalidValue;
+}
+
+hipError_t launch_fused_step(int dtype, const glb::StepParams &p, int mask_kind, int mode, bool scaled, hipStream_t s) {
+  switch (dtype) {
+    case 0: return glb::launch_fused_step_0(p, mask_kind, mode, scaled, s);
+    case 1: return glb::launch_fused_step_1(p, mask_kind, mode, scaled, s);
+    case 2: return glb::launch_fused_step_2(p, mask_kind, mode, scaled, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+// Step workspaces that glb_workspace_init has zeroed: the one-launch step tags its records with a per-workspace epoch
+// (1, 2, ...), so a stale record can never pass for a fresh one.  Everything else about a workspace stays the caller's.
+struct WsEntry {
+  uint32_t epoch;
+  size_t bytes;
+};
+std::mutex g_ws_mu;
+std::unordered_map<const void *, WsEntry> g_ws;
+
+// wave slots the finishing waves of a one-launch step may take: well under half of what the device holds at the
+// kernels' occupancy (5 waves per SIMD; 3 for float masks), so that they cannot starve the waves they wait for
+int fin_wave_cap(bool float_mask) {
+  static int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+      (void)hipGetLastError();
+      n = 64;
+    }
+    return n;
+  }();
+  return cus * (float_mask ? 4 : 8);
 }
 
 hipError_t launch_finish(int dtype, const glb::StepParams &p, int mask_kind, int mode, hipStream_t s) {
@@ -72,16 +107,11 @@ inline size_t prepared_bytes(int64_t n_masks, int64_t vocab) {
   return prepared_words_bytes(n_masks, vocab) + align256((size_t)n_masks * (size_t)n_chunks(vocab) * sizeof(uint64_t));
 }
 
-// step workspace: chunk records, per-lane scans of every chunk (512 bytes each); then prepared masks
+// step workspace: chunk records (64 bytes per unit and chunk); then prepared masks
 inline size_t step_recs_bytes(int64_t units, int64_t vocab) {
-  return align256((size_t)units * (size_t)n_chunks(vocab) * sizeof(glb::ChunkRec));
+  return align256((size_t)units * (size_t)n_chunks(vocab) * glb::kRecWords * sizeof(uint64_t));
 }
-inline size_t step_lanes_bytes(int64_t units, int64_t vocab) {
-  return align256((size_t)units * (size_t)n_chunks(vocab) * 64 * 2 * sizeof(uint32_t));
-}
-inline size_t step_fixed_bytes(int64_t units, int64_t vocab) {
-  return step_recs_bytes(units, vocab) + step_lanes_bytes(units, vocab);
-}
+inline size_t step_fixed_bytes(int64_t units, int64_t vocab) { return step_recs_bytes(units, vocab); }
 
 hipError_t launch_mask_prepare(const uint32_t *bits, int64_t n_masks, int64_t vocab, int64_t mask_ld, int dtype,
                                void *out, hipStream_t s) {
@@ -865,7 +895,7 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
     p.pair_mask = a->mask_id;
     p.pair_of = nullptr;
   }
-  p.recs = (glb::ChunkRec *)a->workspace;
+  p.recs = (uint64_t *)a->workspace;
   int kmask = glb::kMaskNone;
   if (a->mask_kind == GLB_MASK_F32) {
     kmask = glb::kMaskF32;
@@ -892,20 +922,70 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
   p.out_lse = a->out_lse;
   p.out_token = a->out_token;
   p.out_margin = a->rng_mode == GLB_RNG_NOISE ? a->out_margin : nullptr;
-  // Philox draws: the reducing waves leave the per-lane scans of every chunk's allowed sums beside the records; the
-  // per-particle launch picks chunk, lane and element from them
-  const bool lanes = a->rng_mode == GLB_RNG_PHILOX;
-  if (lanes) p.lanes = (uint32_t *)((char *)a->workspace + step_recs_bytes(n_units, a->vocab));
-  hipError_t e = launch_stats(a->dtype, p, kmask, a->logit_scale != 1.0f, lanes, s);
+  const bool scaled = a->logit_scale != 1.0f;
+  // One launch (stats waves, then finishing waves that sweep the tagged records) when the workspace was initialised,
+  // the stream is not being captured (the epoch is a launch argument), the draw is not the parity race and the
+  // launch is big enough to be dealt one wave per chunk; two launches otherwise.
+  const int64_t items = n_units * (int64_t)p.nch;
+  bool fused = a->rng_mode != GLB_RNG_NOISE && items > 512 && a->n_particles <= 16 * (int64_t)fin_wave_cap(kmask == glb::kMaskF32);
+  if (fused) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess) {
+      (void)hipGetLastError();
+      fused = false;
+    } else if (cs != hipStreamCaptureStatusNone) {
+      fused = false;
+    }
+  }
+  if (fused) {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    auto it = g_ws.find(a->workspace);
+    if (it == g_ws.end() || it->second.bytes < fixed_bytes) {
+      fused = false;
+    } else {
+      if (++it->second.epoch == 0u) {  // 2^32 calls on this workspace: start the tags over
+        const hipError_t e = hipMemsetAsync(a->workspace, 0, fixed_bytes, s);
+        if (e != hipSuccess) return hip_fail(e, "workspace re-zero");
+        it->second.epoch = 1u;
+      }
+      p.epoch = it->second.epoch;
+    }
+  }
+  if (fused) {
+    p.stats_blocks = (int32_t)((items + 3) / 4);
+    const int64_t cap = fin_wave_cap(kmask == glb::kMaskF32);
+    p.fin_waves = (int32_t)(a->n_particles < cap ? a->n_particles : cap);
+    const hipError_t e = launch_fused_step(a->dtype, p, kmask, a->rng_mode, scaled, s);
+    if (e != hipSuccess) return hip_fail(e, "fused_step launch");
+    return GLB_OK;
+  }
+  p.epoch = 0u;
+  hipError_t e = launch_stats(a->dtype, p, kmask, scaled, s);
   if (e != hipSuccess) return hip_fail(e, "chunk_stats launch");
   e = launch_finish(a->dtype, p, kmask, a->rng_mode, s);
   if (e != hipSuccess) return hip_fail(e, "finish launch");
   return GLB_OK;
 }
 
+int glb_workspace_init(void *workspace, size_t workspace_bytes, void *stream) {
+  if (!workspace || workspace_bytes == 0) return fail(GLB_EINVAL, "workspace is null or empty");
+  if (((uintptr_t)workspace) % 32) return fail(GLB_EINVAL, "workspace not 32-byte aligned");
+  const hipError_t e = hipMemsetAsync(workspace, 0, workspace_bytes, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "workspace zero");
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  g_ws[workspace] = WsEntry{0u, workspace_bytes};
+  return GLB_OK;
+}
+
+int glb_workspace_release(void *workspace) {
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  g_ws.erase(workspace);
+  return GLB_OK;
+}
+
 size_t glb_log_softmax_workspace_bytes(int64_t n_rows, int64_t vocab) {
   if (n_rows <= 0 || vocab <= 0) return 0;
-  return align256((size_t)n_rows * (size_t)n_chunks(vocab) * sizeof(glb::ChunkRec)) + align256((size_t)n_rows * 4) + 256;
+  return step_recs_bytes(n_rows, vocab) + align256((size_t)n_rows * 4) + 256;
 }
 
 int glb_log_softmax_rows(const void *logits, int32_t dtype, int64_t n_rows, int64_t vocab,
@@ -933,7 +1013,7 @@ int glb_log_softmax_rows(const void *logits, int32_t dtype, int64_t n_rows, int6
     if (e != hipSuccess) return hip_fail(e, "logprob_rows_fused launch");
     return GLB_OK;
   }
-  const size_t recs_bytes = align256((size_t)n_rows * (size_t)n_chunks(vocab) * sizeof(glb::ChunkRec));
+  const size_t recs_bytes = step_recs_bytes(n_rows, vocab);
   float *lse = out_lse ? out_lse : (float *)((char *)workspace + recs_bytes);
   glb::StepParams p{};
   p.logits = logits;
@@ -943,9 +1023,9 @@ int glb_log_softmax_rows(const void *logits, int32_t dtype, int64_t n_rows, int6
   p.scale = logit_scale;
   p.n_particles = (int32_t)n_rows;
   p.n_pairs = (int32_t)n_rows;
-  p.recs = (glb::ChunkRec *)workspace;
+  p.recs = (uint64_t *)workspace;
   p.out_lse = lse;
-  hipError_t e = launch_stats(dtype, p, glb::kMaskNone, logit_scale != 1.0f, false, s);
+  hipError_t e = launch_stats(dtype, p, glb::kMaskNone, logit_scale != 1.0f, s);
   if (e != hipSuccess) return hip_fail(e, "chunk_stats launch");
   e = launch_finish(dtype, p, glb::kMaskNone, glb::kModeStats, s);
   if (e != hipSuccess) return hip_fail(e, "finish launch");

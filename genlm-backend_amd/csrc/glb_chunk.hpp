@@ -6,21 +6,23 @@
 //   base.py:136-141  the same draw with logits scaled by 1/temperature
 //
 // Work is cut by the arithmetic contract, not by the launch geometry (glb_math.hpp): a row is a
-// sequence of 4096-element chunks, each with its own binary scale, and every sum is an integer sum.  Three
-// kernels:
-//   chunk_stats_kernel   one WAVE per (row|particle, chunk): 16 KiB (fp32) / 8 KiB (16-bit) of the row in one
-//                        burst of global_load_dwordx4, chunk maximum by DPP, one polynomial exp per element,
-//                        both sums (all / allowed) by round-toward-zero fp32 adds on two grids, allowed lanes
-//                        selected by EXEC from a pre-transposed bit mask read through the scalar cache; then, still
-//                        from registers, the in-chunk stage of the Philox draw for the unit's first particles.  No
-//                        barrier, no cross-wave dependency: the launch is pure streaming and the unit of
-//                        scheduling is 16 KiB, so any row count / row length fills the chip.  Rows shared by
-//                        several particles (dedup fan-out of hf.py:214-220,285-288) are reduced once.
-//   finish_kernel        one wave per PARTICLE: folds the chunk records of its row into (N, S_all, S_mask), lse / logZ
-//                        by a double-precision log, then the chunk stage of the draw (first Philox word against a
-//                        scan of the chunk sums) and a look-up of the token the reducing wave drew in that chunk
-//                        (second word); particles nobody drew for reload the chunk and reduce it again.  Also the
-//                        parity-mode exponential race (four waves).
+// sequence of 4096-element chunks, each with its own binary scale, summed per (lane, class) in float32 in a fixed
+// order and as integers above that.  Two ROLES, normally waves of ONE launch (fused_step_kernel):
+//   stats role    one WAVE per (row|particle, chunk): 16 KiB (fp32) / 8 KiB (16-bit) of the row in one burst of
+//                 global_load_dwordx4, chunk maximum by DPP, one polynomial exp per element, both sums (all / allowed)
+//                 by plain float32 adds, allowed lanes selected by EXEC from a pre-transposed bit mask read through the
+//                 scalar cache.  Out: one 64-byte record of six tagged 8-byte granules {value, epoch} written through
+//                 to memory - fire and forget: no barrier, no fence, no wait, no cross-wave dependency.  Rows shared
+//                 by several particles (dedup fan-out of hf.py:214-220,285-288) are reduced once.
+//   finish role   one wave per PARTICLE, dealt at the END of the grid: sweeps the granules of its row's records until
+//                 every tag carries this call's epoch (the data is the flag: MI355X guide, Guideline 16 form R2; bounded
+//                 spin), folds them into (N, S_all, S_mask), lse / logZ by a double-precision log, picks the chunk with
+//                 the first Philox word, reloads that one chunk (L2 / Infinity Cache: it was streamed microseconds ago),
+//                 sums it again exactly as the stats wave did and walks down the summation tree with the second word:
+//                 lane, class, element.
+// The same roles also exist as two plain launches (chunk_stats_kernel, finish_kernel): under stream capture (the
+// epoch is a launch argument), for populations beyond what the tail of one grid should hold, for workspaces nobody
+// initialised, and for the parity-mode exponential race (four waves per particle over the whole row).
 //   logprob_rows_kernel  x - lse for the API path that materialises log-probabilities (cache.py:93-98).
 // mask_prepare_kernel builds the transposed masks ([mask][chunk][vector][component] 64-bit lane words).
 #pragma once
@@ -34,15 +36,18 @@ enum { kDtF32 = 0, kDtBf16 = 1, kDtF16 = 2 };
 enum { kMaskNone = 0, kMaskBits = 1, kMaskF32 = 2 };
 enum { kModeStats = 0, kModePhilox = 1, kModeNoise = 2 };
 
-struct ChunkRec {  // 32 bytes per (row|particle, chunk)
+struct ChunkRec {  // one (row|particle, chunk) as the finish role holds it
   float Nc;            // chunk scale exp_n(max); -inf for an empty chunk
   uint32_t pA, pB;     // S_c   = (pA << 18) + pB     all elements
   uint32_t pAm, pBm;   // S_c^m = (pAm << 18) + pBm   allowed elements, on the scale Nm
   float Nm;            // bit masks: Nc, or the allowed maximum's own scale for a low-mass chunk; float masks:
                        // exp_n(max(x + mask)); no mask: Nc
-  uint32_t pad[2];
 };
-static_assert(sizeof(ChunkRec) == 32, "ChunkRec layout");
+// In memory a record is 64 bytes: six 8-byte granules {low word = value, high word = the call's epoch} in the order
+// Nc, pA, pB, pAm, pBm, Nm (+ 16 bytes of padding), each written by ONE agent-scope store and valid exactly when
+// its tag equals the epoch of the call - so a reader needs no flag, no fence and no ordering between the granules.
+constexpr int kRecWords = 8;
+constexpr uint64_t kSpinTicks = 200000000ull;  // finish role gives up after 2 s of s_memrealtime (100 MHz): token -2
 
 struct StepParams {
   const void *logits;
@@ -64,9 +69,10 @@ struct StepParams {
   float *out_logZ, *out_lse;
   int32_t *out_token;
   float *out_margin;  // parity mode: relative gap between the two largest e_j / E_j of the race
-  ChunkRec *recs;  // [n_pairs][nch]
-  uint32_t *lanes;  // [n_pairs][nch][64][2] (Philox draws): per-lane inclusive scans of the allowed payload words of
-                    // every chunk, as the reducing wave held them - what the per-particle launch picks the lane from
+  uint64_t *recs;     // [n_pairs][nch][kRecWords] granules
+  uint32_t epoch;     // tag of this call's granules (never 0 on the fused path; 0 = tags are not looked at)
+  int32_t stats_blocks;  // fused launch: blocks [0, stats_blocks) reduce, the rest finish
+  int32_t fin_waves;     // fused launch: finishing waves (wave f takes particles f, f + fin_waves, ...)
 };
 
 template <int DT>
@@ -168,18 +174,39 @@ __device__ __forceinline__ void load_chunk(const char *rowp, int e_base, int V, 
   }
 }
 
-__device__ __forceinline__ void store_rec(ChunkRec *dst, float Nc, uint32_t pA, uint32_t pB, uint32_t pAm,
-                                          uint32_t pBm, float Nm) {
-  u32x4_t a{__float_as_uint(Nc), pA, pB, pAm}, b{pBm, __float_as_uint(Nm), 0u, 0u};
-  u32x4_t *o = reinterpret_cast<u32x4_t *>(dst);
-  o[0] = a;
-  o[1] = b;
+// one record out: lanes 0..5 store one granule each (the values are wave-uniform)
+__device__ __forceinline__ void store_rec(uint64_t *dst, uint32_t epoch, int lane, float Nc, uint32_t pA, uint32_t pB,
+                                          uint32_t pAm, uint32_t pBm, float Nm) {
+  uint32_t v = __float_as_uint(Nc);
+  v = lane == 1 ? pA : v;
+  v = lane == 2 ? pB : v;
+  v = lane == 3 ? pAm : v;
+  v = lane == 4 ? pBm : v;
+  v = lane == 5 ? __float_as_uint(Nm) : v;
+  if (lane < 6)
+    __hip_atomic_store(dst + lane, ((uint64_t)epoch << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// sums of one chunk held in x[64]: returns the lane-63 totals of the four payload words.  (v0, VSTEP): this wave's
-// vectors are v0, v0 + VSTEP, ... (one wave per chunk: 0, 1; four waves per chunk: wave, 4) and x holds them densely.
+// one record in; true when every granule carries `epoch`
+__device__ __forceinline__ bool load_rec(const uint64_t *src, uint32_t epoch, ChunkRec &r) {
+  uint64_t g[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+    g[k] = __hip_atomic_load(const_cast<uint64_t *>(src) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) ok = ok && (uint32_t)(g[k] >> 32) == epoch;
+  r.Nc = __uint_as_float((uint32_t)g[0]);
+  r.pA = (uint32_t)g[1];
+  r.pB = (uint32_t)g[2];
+  r.pAm = (uint32_t)g[3];
+  r.pBm = (uint32_t)g[4];
+  r.Nm = __uint_as_float((uint32_t)g[5]);
+  return ok;
+}
+
 // the first two groups of mask words of a chunk (8 words each), fetched by the caller before it waits for the chunk's
-// own loads and hands to chunk_sums
+// own loads and handed to class_partials
 struct MaskAhead {
   uint64_t w[2][8];
 };
@@ -195,10 +222,13 @@ __device__ __forceinline__ void mask_ahead(cu64_t mt, MaskAhead &ma, int v0 = 0)
     }
 }
 
+// The (lane, class) partial sums of one chunk held in x[64] (glb_math.hpp): P[w] over all elements of class w, Pm[w]
+// over the allowed ones.  (v0, VSTEP): this wave's vectors are v0, v0 + VSTEP, ... and x holds them densely - one wave
+// per chunk: (0, 1), four classes per lane; four waves per chunk: (wave, 4), every vector of a wave is of class `wave`
+// and the sums land in P[0] / Pm[0].
 template <int DT, bool MASKED, int VSTEP, bool FULL>
-__device__ __forceinline__ void chunk_sums_body(const float (&x)[64], float magicN, int nv_valid, cu64_t mt, int v0,
-                                                const MaskAhead &ahead, float &A0, float &B0, float &A1, float &B1, float &Am0, float &Bm0,
-                                                float &Am1, float &Bm1) {
+__device__ __forceinline__ void class_partials_body(const float (&x)[64], float magicN, int nv_valid, cu64_t mt, int v0,
+                                                    const MaskAhead &ahead, float (&P)[4], float (&Pm)[4]) {
   constexpr int EPV = ElemTraits<DT>::EPV, NVC = ElemTraits<DT>::NVC / VSTEP;
   // mask words travel in groups of 8 (one s_load_dwordx16) fetched two groups ahead of the adds that use them: a
   // scalar load that misses the scalar cache takes longer than the ~40 VALU issues of one group
@@ -228,15 +258,20 @@ __device__ __forceinline__ void chunk_sums_body(const float (&x)[64], float magi
       const int i = g * VPG + iv;
       if (i >= NVC) break;
       const int vi = v0 + i * VSTEP;  // the vector's index inside the chunk
-      if (FULL || vi < nv_valid) {  // wave-uniform: vectors wholly past the row end are skipped
+      constexpr int kOne = VSTEP == 1 ? 3 : 0;
+      const int cls = i & kOne;       // (compile-time after unrolling)
+      if (FULL || vi < nv_valid) {  // wave-uniform: vectors wholly past the row end are skipped (they would add +0)
         float t[EPV];
 #pragma unroll
         for (int k = 0; k < EPV; ++k) t[k] = chunk_term(x[i * EPV + k], magicN);
 #pragma unroll
-        for (int h = 0; h < EPV / 4; ++h) {
-          const uint64_t *M = &Mq[g % 3][iv * EPV + 4 * h];
-          rtz_acc4<MASKED>(t[4 * h], t[4 * h + 1], t[4 * h + 2], t[4 * h + 3], A0, B0, A1, B1, Am0, Bm0, Am1, Bm1,
-                           M[0], M[1], M[2], M[3]);
+        for (int k = 0; k < EPV; ++k) P[cls] = P[cls] + t[k];
+        if constexpr (MASKED) {
+#pragma unroll
+          for (int h = 0; h < EPV / 4; ++h) {
+            const uint64_t *M = &Mq[g % 3][iv * EPV + 4 * h];
+            masked_add4(Pm[cls], t[4 * h], t[4 * h + 1], t[4 * h + 2], t[4 * h + 3], M[0], M[1], M[2], M[3]);
+          }
         }
       }
     }
@@ -244,26 +279,33 @@ __device__ __forceinline__ void chunk_sums_body(const float (&x)[64], float magi
 }
 
 template <int DT, bool MASKED, int VSTEP = 1>
-__device__ __forceinline__ void chunk_sums(const float (&x)[64], float magicN, int nv_valid, cu64_t mt,
-                                           const MaskAhead &ahead, uint32_t &pA, uint32_t &pB, uint32_t &pAm,
-                                           uint32_t &pBm, int v0 = 0) {
-  float A0 = __uint_as_float(kA0Bits), A1 = A0, Am0 = A0, Am1 = A0;
-  float B0 = __uint_as_float(kB0Bits), B1 = B0, Bm0 = B0, Bm1 = B0;
+__device__ __forceinline__ void class_partials(const float (&x)[64], float magicN, int nv_valid, cu64_t mt,
+                                               const MaskAhead &ahead, float (&P)[4], float (&Pm)[4], int v0 = 0) {
+#pragma unroll
+  for (int w = 0; w < 4; ++w) P[w] = Pm[w] = 0.0f;
   // a full chunk (all but the last of a row) runs as one straight block: the scheduler can then start the scalar loads
   // of the mask words well ahead of the adds that use them; the last chunk tests every vector against the row end
   if (nv_valid == ElemTraits<DT>::NVC)
-    chunk_sums_body<DT, MASKED, VSTEP, true>(x, magicN, nv_valid, mt, v0, ahead, A0, B0, A1, B1, Am0, Bm0, Am1, Bm1);
+    class_partials_body<DT, MASKED, VSTEP, true>(x, magicN, nv_valid, mt, v0, ahead, P, Pm);
   else
-    chunk_sums_body<DT, MASKED, VSTEP, false>(x, magicN, nv_valid, mt, v0, ahead, A0, B0, A1, B1, Am0, Bm0, Am1, Bm1);
-  pA = wave_sum_u32_l63((__float_as_uint(A0) - kA0Bits) + (__float_as_uint(A1) - kA0Bits));
-  pB = wave_sum_u32_l63((__float_as_uint(B0) - kB0Bits) + (__float_as_uint(B1) - kB0Bits));
-  pAm = pA;
-  pBm = pB;
-  if constexpr (MASKED) {
-    pAm = wave_sum_u32_l63((__float_as_uint(Am0) - kA0Bits) + (__float_as_uint(Am1) - kA0Bits));
-    pBm = wave_sum_u32_l63((__float_as_uint(Bm0) - kB0Bits) + (__float_as_uint(Bm1) - kB0Bits));
+    class_partials_body<DT, MASKED, VSTEP, false>(x, magicN, nv_valid, mt, v0, ahead, P, Pm);
+}
+
+// this lane's payload words: the sum over its NCLS class partials of floor(P * 2^36), h and l words apart
+template <int NCLS>
+__device__ __forceinline__ void lane_payload(const float (&P)[4], uint32_t &h, uint32_t &l) {
+  h = l = 0;
+#pragma unroll
+  for (int w = 0; w < NCLS; ++w) {
+    uint32_t hw, lw;
+    partial_q(P[w], hw, lw);
+    h += hw;
+    l += lw;
   }
 }
+
+// lane-63 value of a DPP scan, wave-uniform
+__device__ __forceinline__ uint32_t last_lane(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
 
 __device__ __forceinline__ float chunk_max(const float (&x)[64]) {
   float m = kNegInf;
@@ -274,31 +316,40 @@ __device__ __forceinline__ float chunk_max(const float (&x)[64]) {
 
 // Bit-masked chunk: both sums at the chunk scale Nc (one exponential per element); if the allowed sum comes out
 // below 2^32 although the mask allows something in this chunk (allows_any, from mask_prepare) - allowed mass under
-// about 2^-3.5 of the chunk's largest term, e.g. the one likely token is the forbidden one - the forbidden elements of x are overwritten with -inf and the allowed ones summed
-// again on their own maximum's scale (wave-uniform, rare, everything still in registers).  (pAm, pBm) are per-lane
-// inclusive scans as chunk_sums returns them, on the scale Nm; `redone` tells the caller x is now the masked chunk.
-template <int DT>
+// about 2^-3.5 of the chunk's largest term, e.g. the one likely token is the forbidden one - the chunk is loaded once
+// more (wave-uniform, rare, L1 / L2 serve it; not keeping x alive for this is what lets the common path run without
+// spills), its forbidden elements overwritten with -inf and the allowed ones summed again on their own maximum's
+// scale.  Out: the four wave totals (uniform) and Nm, the scale of the allowed pair.
+template <int DT, bool SCALED>
 __device__ __forceinline__ void chunk_reduce_bits(float (&x)[64], float Nc, int nv_valid, cu64_t mt,
-                                                  const MaskAhead &ma, uint64_t allows_any, int lane, uint32_t &pA,
-                                                  uint32_t &pB, uint32_t &pAm, uint32_t &pBm, float &Nm,
-                                                  bool &redone) {
-  chunk_sums<DT, true>(x, kMagic - Nc, nv_valid, mt, ma, pA, pB, pAm, pBm);
+                                                  const MaskAhead &ma, uint64_t allows_any, int lane, const char *rowp,
+                                                  int e_base, int V, float scale, uint32_t &pA, uint32_t &pB,
+                                                  uint32_t &pAm, uint32_t &pBm, float &Nm) {
+  float P[4], Pm[4];
+  class_partials<DT, true>(x, kMagic - Nc, nv_valid, mt, ma, P, Pm);
+  uint32_t h, l, hm, lm;
+  lane_payload<4>(P, h, l);
+  lane_payload<4>(Pm, hm, lm);
+  pA = last_lane(wave_sum_u32_l63(h));
+  pB = last_lane(wave_sum_u32_l63(l));
+  pAm = last_lane(wave_sum_u32_l63(hm));
+  pBm = last_lane(wave_sum_u32_l63(lm));
   Nm = Nc;
-  redone = false;
-  const uint32_t ta = (uint32_t)__builtin_amdgcn_readlane((int)pAm, 63);
-  const uint32_t tb = (uint32_t)__builtin_amdgcn_readlane((int)pBm, 63);
-  const uint64_t Sm = ((uint64_t)ta << kGridHi) + tb;
+  const uint64_t Sm = ((uint64_t)pAm << kGridHi) + pBm;
   uint32_t top = (uint32_t)(Sm >> kLowMassBits), any = (uint32_t)allows_any;
   opaque_u32(top);
   opaque_u32(any);
   if (top == 0u && any != 0u) {
+    float y[64];
+    load_chunk<DT, SCALED>(rowp, e_base, V, lane, scale, y);
 #pragma unroll
     for (int j = 0; j < 64; ++j)
-      if (!((mt[j] >> lane) & 1ull)) x[j] = kNegInf;
-    Nm = exp_n(chunk_max(x));
-    uint32_t d0, d1;
-    chunk_sums<DT, false>(x, kMagic - Nm, nv_valid, nullptr, MaskAhead{}, pAm, pBm, d0, d1);
-    redone = true;
+      if (!((mt[j] >> lane) & 1ull)) y[j] = kNegInf;
+    Nm = exp_n(chunk_max(y));
+    class_partials<DT, false>(y, kMagic - Nm, nv_valid, nullptr, MaskAhead{}, P, Pm);
+    lane_payload<4>(P, hm, lm);
+    pAm = last_lane(wave_sum_u32_l63(hm));
+    pBm = last_lane(wave_sum_u32_l63(lm));
   }
 }
 
@@ -346,12 +397,11 @@ __device__ __forceinline__ int first_lane_above(uint64_t incl, uint64_t T) {
 
 // ---------------------------------------------------------------------------------------------------------
 // The draw inside one chunk (second stage of the Philox draw): target T2 = floor(R2 * S_c / 2^64) against
-// the chunk's allowed terms on the scale they were summed on, taken lane by lane and inside a lane in register order
-// (vector, component) - the order the reducing wave held them in.  The reducing wave leaves the per-lane inclusive
-// scans of its allowed payload words behind (512 bytes per chunk); the per-particle launch picks the lane from them
-// (stage 2a) and the element from one gathered load of that lane's 64 values (stage 2b).
+// the chunk's allowed sums on the scale they were made on, walked down the summation tree: lane (inclusive scan of the
+// lane payloads), class (the lane's four class terms), element (running float32 sum of the class, the first whose
+// floor(c * 2^36) passes what is left of the target).
 // ---------------------------------------------------------------------------------------------------------
-// stage 2a: the lane.  Packed result (lane << 56) | (target left inside that lane's terms); ~0 for an empty chunk.
+// the lane.  Packed result (lane << 56) | (target left inside that lane's terms); ~0 for an empty chunk.
 __device__ __forceinline__ uint64_t chunk_pick_lane(uint32_t inclA, uint32_t inclB, uint64_t R2) {
   const uint64_t incl = ((uint64_t)inclA << kGridHi) + inclB;
   const uint64_t Sc = readlane_u64(incl, 63);
@@ -365,26 +415,69 @@ __device__ __forceinline__ uint64_t chunk_pick_lane(uint32_t inclA, uint32_t inc
   return ((uint64_t)lsel << 56) | Tl;
 }
 
-// stage 2b, common end: every lane holds one of the chosen lane's 64 terms as (h, l); the element is the first whose
-// running sum passes Tl.  Returns its index 0..63 in the lane's register order, -1 if none (consistent sums rule it out).
-__device__ __forceinline__ int pick_in_lane(uint32_t h, uint32_t l, uint64_t Tl) {
-  const uint32_t sh = wave_sum_u32_l63(h), sl = wave_sum_u32_l63(l);  // inclusive scans; totals < 2^24 each
-  const uint64_t inc2 = ((uint64_t)sh << kGridHi) + sl;
-  return first_lane_above(inc2, Tl);
+// class and element.  P[4]: this lane's class partials of the chunk on the scale magicN = kMagic - Nm; (lsel, Tl) from
+// chunk_pick_lane.  Lanes 0..3 pick the class from the chosen lane's four class terms; then lane L = 16 w + pos holds
+// the chosen lane's element (class w, position pos) - fetched with one gathered load (sixteen 16-byte runs a kilobyte
+// apart, lines this wave has just streamed), scaled and masked exactly as the sums took it - and every 16-lane row
+// rebuilds its class's running sum in order (15 dependent DPP adds: after step s the first s + 1 lanes of a row are
+// final).  Returns the element's index in the row, -1 if none (consistent sums rule it out).
+template <int DT, int MASK, class Mid>
+__device__ __forceinline__ int32_t lane_pick_element(const StepParams &p, const char *rowp, int mi, int c,
+                                                     const float (&P)[4], float magicN, int lsel, uint64_t Tl, int lane,
+                                                     Mid &&mid) {
+  constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES;
+  uint64_t qw = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    uint32_t h, l;
+    partial_q(P[w], h, l);
+    const uint32_t hs = (uint32_t)__builtin_amdgcn_readlane((int)h, lsel), ls = (uint32_t)__builtin_amdgcn_readlane((int)l, lsel);
+    qw = lane == w ? ((uint64_t)hs << kGridHi) + ls : qw;
+  }
+  const int w = lane >> 4, pos = lane & 15;
+  const int iv = (pos / EPV) * 4 + w, k = pos % EPV;  // vector and component of (class w, position pos)
+  const int e = c * kChunk + (iv * 64 + lsel) * EPV + k;
+  float y = kNegInf;
+  if (e < p.V) {
+    if constexpr (DT == kDtF32) {
+      y = *reinterpret_cast<const float *>(rowp + (int64_t)e * ES);
+    } else {
+      const uint32_t hb = *reinterpret_cast<const uint16_t *>(rowp + (int64_t)e * ES);
+      if constexpr (DT == kDtBf16) y = __uint_as_float(hb << 16);
+      else y = (float)__builtin_bit_cast(_Float16, (uint16_t)hb);
+    }
+    y = y * p.scale;
+    if constexpr (MASK == kMaskBits) {
+      if (!((p.mask_t[((int64_t)mi * p.nch + c) * 64 + iv * EPV + k] >> lsel) & 1ull)) y = kNegInf;
+    } else if constexpr (MASK == kMaskF32) {
+      y = y + p.mask_f[(int64_t)mi * p.mask_ld + e];
+    }
+  }
+  mid();  // (the caller's logarithms: work for the time the gathered load is in flight)
+  const uint64_t inclw = wave_scan_u64(qw);  // lanes 0..3: inclusive sums of the class terms; later lanes: the total
+  const int wsel = first_lane_above(inclw, Tl);
+  if (wsel < 0 || wsel > 3) return -1;
+  const uint64_t before = readlane_u64(inclw, wsel > 0 ? wsel - 1 : 0);
+  const uint64_t Tw = Tl - (wsel > 0 ? before : 0ull);
+  const float t = chunk_term(y, magicN);
+  float cs = t;
+#pragma unroll
+  for (int s2 = 1; s2 < 16; ++s2) cs = __uint_as_float(dpp_u32<0x111, 0xf>(0u, __float_as_uint(cs))) + t;
+  uint32_t h, l;
+  partial_q(cs, h, l);
+  const uint64_t qc = w == wsel ? ((uint64_t)h << kGridHi) + l : 0ull;
+  const int Lsel = first_lane_above(qc, Tw);
+  if (Lsel < 0) return -1;
+  return __builtin_amdgcn_readlane(e, Lsel);
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// chunk statistics: one wave per (reduction unit, chunk)
+// stats role: one wave per (reduction unit, chunk)
 // ---------------------------------------------------------------------------------------------------------
-// LANES (calls that draw with Philox): the wave also leaves the per-lane inclusive scans of its allowed payload words
-// in the workspace (8 bytes per lane, one coalesced 512-byte store) - the per-particle launch draws from them.
-template <int DT, int MASK, bool SCALED, bool LANES>
-__global__ __launch_bounds__(256, 5) void chunk_stats_kernel(const StepParams p) {
+template <int DT, int MASK, bool SCALED>
+__device__ __forceinline__ void stats_item(const StepParams &p, int item, int lane) {
   constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC;
-  const int lane = threadIdx.x & 63;
-  const int item = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
   const int nch = p.nch;
-  if (item >= p.n_pairs * nch) return;  // whole waves only
   const int pr = item / nch, c = item - pr * nch;  // (dealt row-interleaved instead, the launch is 2.5 us slower)
   const int row = p.pair_row ? as_const(p.pair_row)[pr] : pr;
   const char *rowp = (const char *)p.logits + (int64_t)row * p.ld * ES;
@@ -408,42 +501,56 @@ __global__ __launch_bounds__(256, 5) void chunk_stats_kernel(const StepParams p)
   uint32_t pA, pB, pAm, pBm;
   float Nm = Nc;
   if constexpr (MASK == kMaskBits) {
-    bool redone;
-    chunk_reduce_bits<DT>(x, Nc, nv_valid, mt, ma, allows_any, lane, pA, pB, pAm, pBm, Nm, redone);
+    chunk_reduce_bits<DT, SCALED>(x, Nc, nv_valid, mt, ma, allows_any, lane, rowp, e_base, V, p.scale, pA, pB, pAm, pBm, Nm);
   } else {
-    chunk_sums<DT, false>(x, kMagic - Nc, nv_valid, nullptr, ma, pA, pB, pAm, pBm);
+    float P[4], Pm[4];
+    uint32_t h, l;
+    class_partials<DT, false>(x, kMagic - Nc, nv_valid, nullptr, ma, P, Pm);
+    lane_payload<4>(P, h, l);
+    pA = pAm = last_lane(wave_sum_u32_l63(h));
+    pB = pBm = last_lane(wave_sum_u32_l63(l));
     if constexpr (MASK == kMaskF32) {  // general additive masks: y = x + m has its own maximum, scale and exp
       const char *mrow = (const char *)(p.mask_f + (int64_t)mi * p.mask_ld);
       float y[64];
       add_float_mask<DT>(x, mrow, e_base, V, lane, y);
       Nm = exp_n(chunk_max(y));
-      uint32_t d0, d1;
-      chunk_sums<DT, false>(y, kMagic - Nm, nv_valid, nullptr, ma, pAm, pBm, d0, d1);
+      class_partials<DT, false>(y, kMagic - Nm, nv_valid, nullptr, ma, P, Pm);
+      lane_payload<4>(P, h, l);
+      pAm = last_lane(wave_sum_u32_l63(h));
+      pBm = last_lane(wave_sum_u32_l63(l));
     }
   }
-  if constexpr (LANES) {  // (a chunk without allowed mass is never drawn from: sparse masks skip most of these stores)
-    if ((__builtin_amdgcn_readlane((int)pAm, 63) | __builtin_amdgcn_readlane((int)pBm, 63)) != 0) {
-      uint32_t *ls = p.lanes + (((int64_t)pr * nch + c) * 64 + lane) * 2;
-      __builtin_nontemporal_store(((uint64_t)pBm << 32) | pAm, reinterpret_cast<uint64_t *>(ls));
-    }
-  }
-  if (lane == 63) store_rec(p.recs + (int64_t)pr * nch + c, Nc, pA, pB, pAm, pBm, Nm);
+  store_rec(p.recs + ((int64_t)pr * nch + c) * kRecWords, p.epoch, lane, Nc, pA, pB, pAm, pBm, Nm);
+}
+
+// float masks hold x[64] and y[64]: three waves per SIMD leave them the registers (five spill 61 of them)
+template <int MASK>
+struct StatsWaves {
+  static constexpr int value = MASK == kMaskF32 ? 3 : 4;
+};
+
+template <int DT, int MASK, bool SCALED>
+__global__ __launch_bounds__(256, StatsWaves<MASK>::value) void chunk_stats_kernel(const StepParams p) {
+  const int lane = threadIdx.x & 63;
+  const int item = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+  if (item >= p.n_pairs * p.nch) return;  // whole waves only
+  stats_item<DT, MASK, SCALED>(p, item, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // chunk statistics for launches that cannot fill the chip (a single shared row at SIS step 0, a lone API query):
-// one WORKGROUP of four waves per (unit, chunk); wave w takes vectors w, w+4, ... of the chunk, the chunk maximum and
-// the four payload sums are combined through LDS.  Same records as chunk_stats_kernel (integer sums do not care how
-// the elements were dealt out); a wave alone on its SIMD issues one instruction every ~5 cycles, so a quarter of the
-// elements per wave is what shortens the launch.  Bit masks / no mask only (float masks use the one-wave kernel).
+// one WORKGROUP of four waves per (unit, chunk); wave w takes vectors w, w+4, ... of the chunk - exactly class w of
+// every lane - the chunk maximum and the four payload sums are combined through LDS.  Same records as the one-wave
+// form by construction: the (lane, class) partials are the same sums in the same order, only held by another wave.  A
+// wave alone on its SIMD issues one instruction every ~5 cycles, so a quarter of the elements per wave is what shortens
+// the launch.  Bit masks / no mask only (float masks use the one-wave kernel).
 // ---------------------------------------------------------------------------------------------------------
-template <int DT, int MASK, bool SCALED, bool LANES>
+template <int DT, int MASK, bool SCALED>
 __global__ __launch_bounds__(256) void chunk_stats_small_kernel(const StepParams p) {
   constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC, NVW = NVC / 4;
   static_assert(MASK != kMaskF32, "float masks take the one-wave-per-chunk kernel");
   __shared__ float s_max[4];
   __shared__ uint32_t s_pay[4][4];
-  __shared__ uint32_t s_lane[LANES ? 4 : 1][64][2];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int item = blockIdx.x, nch = p.nch;
   const int pr = item / nch, c = item - pr * nch;
@@ -473,30 +580,34 @@ __global__ __launch_bounds__(256) void chunk_stats_small_kernel(const StepParams
   __syncthreads();
   m = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
   const float Nc = exp_n(m);
-  uint32_t pA, pB, pAm, pBm;
+  float P[4], Pm[4];
+  uint32_t h, l, hm, lm;
   if constexpr (MASK == kMaskBits) {
     const int mi = p.pair_mask ? as_const(p.pair_mask)[pr] : (p.n_masks == 1 ? 0 : pr);
     const cu64_t mt = as_const(p.mask_t + ((int64_t)mi * nch + c) * 64);
     MaskAhead ma;
     mask_ahead<DT, 4>(mt, ma, wave);
-    chunk_sums<DT, true, 4>(x, kMagic - Nc, nv_valid, mt, ma, pA, pB, pAm, pBm, wave);
+    class_partials<DT, true, 4>(x, kMagic - Nc, nv_valid, mt, ma, P, Pm, wave);
+    lane_payload<1>(P, h, l);
+    lane_payload<1>(Pm, hm, lm);
   } else {
-    chunk_sums<DT, false, 4>(x, kMagic - Nc, nv_valid, nullptr, MaskAhead{}, pA, pB, pAm, pBm, wave);
+    class_partials<DT, false, 4>(x, kMagic - Nc, nv_valid, nullptr, MaskAhead{}, P, Pm, wave);
+    lane_payload<1>(P, h, l);
+    hm = h;
+    lm = l;
   }
+  const uint32_t wA = wave_sum_u32_l63(h), wB = wave_sum_u32_l63(l), wAm = wave_sum_u32_l63(hm), wBm = wave_sum_u32_l63(lm);
   if (lane == 63) {
-    s_pay[wave][0] = pA;
-    s_pay[wave][1] = pB;
-    s_pay[wave][2] = pAm;
-    s_pay[wave][3] = pBm;
+    s_pay[wave][0] = wA;
+    s_pay[wave][1] = wB;
+    s_pay[wave][2] = wAm;
+    s_pay[wave][3] = wBm;
   }
   __syncthreads();
   uint32_t t[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) t[k] = s_pay[0][k] + s_pay[1][k] + s_pay[2][k] + s_pay[3][k];
   float Nm = Nc;
-  uint32_t lastA = pAm, lastB = pBm;  // this wave's per-lane scans of the allowed words, as finally summed
-  (void)lastA;
-  (void)lastB;
   if constexpr (MASK == kMaskBits) {
     // the low-mass rule of chunk_reduce_bits, with the chunk spread over four waves (workgroup-uniform branch)
     const uint64_t Sm = ((uint64_t)t[2] << kGridHi) + t[3];
@@ -507,10 +618,16 @@ __global__ __launch_bounds__(256) void chunk_stats_small_kernel(const StepParams
     if (top == 0u && any != 0u) {
       const cu64_t mt = as_const(p.mask_t + ((int64_t)mi * nch + c) * 64);
 #pragma unroll
-      for (int j = 0; j < NVW; ++j)
+      for (int j = 0; j < NVW; ++j) {  // (loaded again: x is not kept alive for this rare branch)
+        const int e0 = e_base + ((wave + 4 * j) * 64 + lane) * EPV;
+        const u32x4_t r = load_vec_guarded<DT>(rowp, e0 < V ? e0 : V, V);
+        unpack_vec<DT>(r, &x[j * EPV]);
 #pragma unroll
-        for (int k = 0; k < EPV; ++k)
+        for (int k = 0; k < EPV; ++k) {
+          if constexpr (SCALED) x[j * EPV + k] *= p.scale;
           if (!((mt[(wave + 4 * j) * EPV + k] >> lane) & 1ull)) x[j * EPV + k] = kNegInf;
+        }
+      }
       float mm = kNegInf;
 #pragma unroll
       for (int j = 0; j < NVW * EPV; j += 2) mm = max3(mm, x[j], x[j + 1]);
@@ -519,10 +636,9 @@ __global__ __launch_bounds__(256) void chunk_stats_small_kernel(const StepParams
       if (lane == 0) s_max[wave] = mm;
       __syncthreads();
       Nm = exp_n(fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3])));
-      uint32_t qa, qb, d0, d1;
-      chunk_sums<DT, false, 4>(x, kMagic - Nm, nv_valid, nullptr, MaskAhead{}, qa, qb, d0, d1, wave);
-      lastA = qa;
-      lastB = qb;
+      class_partials<DT, false, 4>(x, kMagic - Nm, nv_valid, nullptr, MaskAhead{}, P, Pm, wave);
+      lane_payload<1>(P, hm, lm);
+      const uint32_t qa = wave_sum_u32_l63(hm), qb = wave_sum_u32_l63(lm);
       if (lane == 63) {
         s_pay[wave][2] = qa;
         s_pay[wave][3] = qb;
@@ -532,22 +648,7 @@ __global__ __launch_bounds__(256) void chunk_stats_small_kernel(const StepParams
       t[3] = s_pay[0][3] + s_pay[1][3] + s_pay[2][3] + s_pay[3][3];
     }
   }
-  if (threadIdx.x == 0) store_rec(p.recs + (int64_t)pr * nch + c, Nc, t[0], t[1], t[2], t[3], Nm);
-  if constexpr (LANES) {
-    // the per-lane scans of the allowed words over the WHOLE chunk: every wave's lanes hold scans over their quarter
-    // of the vectors; their own parts are summed per lane through LDS and scanned again by wave 0
-    const uint32_t ia = MASK == kMaskBits ? lastA : pA, ib = MASK == kMaskBits ? lastB : pB;
-    const uint32_t pa = __shfl_up(ia, 1, 64), pb = __shfl_up(ib, 1, 64);
-    s_lane[wave][lane][0] = ia - (lane ? pa : 0u);
-    s_lane[wave][lane][1] = ib - (lane ? pb : 0u);
-    __syncthreads();
-    if (wave == 0) {
-      const uint32_t a = s_lane[0][lane][0] + s_lane[1][lane][0] + s_lane[2][lane][0] + s_lane[3][lane][0];
-      const uint32_t b2 = s_lane[0][lane][1] + s_lane[1][lane][1] + s_lane[2][lane][1] + s_lane[3][lane][1];
-      const uint32_t sa = wave_sum_u32_l63(a), sb = wave_sum_u32_l63(b2);
-      *reinterpret_cast<uint64_t *>(p.lanes + (((int64_t)pr * nch + c) * 64 + lane) * 2) = ((uint64_t)sb << 32) | sa;
-    }
-  }
+  if (wave == 0) store_rec(p.recs + ((int64_t)pr * nch + c) * kRecWords, p.epoch, lane, Nc, t[0], t[1], t[2], t[3], Nm);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -594,57 +695,57 @@ struct RowView {
   }
 };
 
-// one element of the row (unscaled)
-template <int DT>
-__device__ __forceinline__ float load_elem(const char *rowp, int j) {
-  if constexpr (DT == kDtF32) return *reinterpret_cast<const float *>(rowp + (int64_t)j * 4);
-  const uint32_t h = *reinterpret_cast<const uint16_t *>(rowp + (int64_t)j * 2);
-  if constexpr (DT == kDtBf16) return __uint_as_float(h << 16);
-  return (float)__builtin_bit_cast(_Float16, (uint16_t)h);
-}
-
-// stage 2b: lane j loads the chosen lane's j-th element (eight or sixteen 16-byte runs a kilobyte apart), applies scale
-// and mask exactly as the reduction did, and the scan of pick_in_lane names the element.  Nm: the scale the chunk's
-// allowed terms were summed on (its record).
-template <int DT, int MASK>
-__device__ __forceinline__ int32_t chunk_pick_element_mem(const RowView<DT, MASK> &rv, int c, uint64_t pick, float Nm,
-                                                          int lane) {
-  constexpr int EPV = ElemTraits<DT>::EPV;
-  if (pick == ~0ull) return -1;
-  const int lsel = (int)(pick >> 56);
-  const uint64_t Tl = pick & ((1ull << 56) - 1ull);
-  const int e = c * kChunk + ((lane / EPV) * 64 + lsel) * EPV + (lane % EPV);
-  float y = kNegInf;
-  if (e < rv.V) {
-    y = load_elem<DT>(rv.rowp, e) * rv.scale;
-    if constexpr (MASK == kMaskBits) {
-      if (!((rv.mt[(int64_t)c * 64 + lane] >> lsel) & 1ull)) y = kNegInf;
-    } else if constexpr (MASK == kMaskF32) {
-      y = y + reinterpret_cast<const float *>(rv.mrow)[e];
-    }
-  }
-  uint32_t h, l;
-  term_q_parts(y, kMagic - Nm, h, l);
-  const int jsel = pick_in_lane(h, l, Tl);
-  if (jsel < 0) return -1;
-  return __builtin_amdgcn_readlane(e, jsel);
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // What one particle needs from the chunk records of its (row, mask) pair.  Every function here is executed by ONE
 // wave; all results are wave-uniform.
 // ---------------------------------------------------------------------------------------------------------
-struct RecsGlobal {
-  const ChunkRec *r;
-  __device__ __forceinline__ ChunkRec get(int c) const { return r[c]; }
+// the records of one reduction unit.  Rows of up to 64 chunks (V <= 262144) stay in registers after the sweep that
+// waited for them: lane c holds record c.
+struct Recs {
+  const uint64_t *base;
+  uint32_t epoch;
+  bool cached;
+  ChunkRec mine;
+  __device__ __forceinline__ ChunkRec get(int c) const {  // always called with c = c0 + lane
+    if (cached) return mine;
+    ChunkRec r;
+    load_rec(base + (int64_t)c * kRecWords, epoch, r);
+    return r;
+  }
 };
+
+// POLL: sweep the unit's granules until every tag is this call's epoch (the stats waves of the same launch are still
+// writing them; relaxed agent-scope loads, a short sleep between sweeps, a bounded wait).  Without POLL the records
+// come from an earlier launch on the stream and the tags are not looked at.
+template <bool POLL>
+__device__ __forceinline__ bool recs_acquire(Recs &R, int nch, int lane) {
+  R.cached = nch <= 64;
+  R.mine = ChunkRec{kNegInf, 0u, 0u, 0u, 0u, kNegInf};
+  uint64_t t0 = 0;
+  if constexpr (POLL) t0 = __builtin_amdgcn_s_memrealtime();
+  for (int c0 = 0; c0 < nch; c0 += 64) {
+    const int c = c0 + lane;
+    for (;;) {
+      bool ok = true;
+      ChunkRec r{kNegInf, 0u, 0u, 0u, 0u, kNegInf};
+      if (c < nch) ok = load_rec(R.base + (int64_t)c * kRecWords, R.epoch, r);
+      if (c0 == 0) R.mine = r;
+      if constexpr (!POLL) break;
+      if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+      __builtin_amdgcn_s_sleep(8);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > kSpinTicks) return false;
+    }
+  }
+  return true;
+}
+
 struct PairState {
   float N_all, N_msk;     // row scales (all / allowed)
   uint64_t S_all, S_msk;  // sums on them
 };
 
 // fold the chunk records: row scales (the largest chunk scale among non-empty chunks), then the sums shifted onto them
-template <int MASK, class Recs>
+template <int MASK>
 __device__ __forceinline__ void pair_fold(const Recs &recs, int nch, int lane, PairState &st) {
   float N_all = kNegInf, N_msk = kNegInf;
   for (int c0 = 0; c0 < nch; c0 += 64) {
@@ -691,21 +792,16 @@ __device__ __forceinline__ void pair_logs(const PairState &st, float &lse, float
   logZ = (float)(lse_msk - lse_all);
 }
 
-// The Philox draw of particle pidx, in two calls so that the caller can put other work between a load and its use:
-// pair_pick_chunk - the chunk by a scan of the shifted chunk sums (first Philox word), and the request for this lane's
-// scan word of that chunk (what the reducing wave left in the workspace); pair_pick_token - with the second word, the
-// lane from those scans, then the element from a gathered load of that lane's 64 values.
+// first stage of the Philox draw of particle pidx: the chunk, by a scan of the shifted chunk sums (first word)
 struct ChunkPick {
   int csel;       // -1: nothing to draw from
   float Nms;      // the scale the chosen chunk's allowed terms sit on
   uint64_t R2;    // second Philox word
-  uint64_t scan;  // this lane's (A, B) inclusive scan words of the chosen chunk
 };
 
-template <class Recs>
 __device__ __forceinline__ ChunkPick pair_pick_chunk(const StepParams &p, const Recs &recs, const PairState &st, int pidx,
-                                                     int nch, int lane, const uint32_t *lanes) {
-  ChunkPick k{-1, 0.f, 0ull, 0ull};
+                                                     int nch, int lane) {
+  ChunkPick k{-1, 0.f, 0ull};
   uint32_t nz = (uint32_t)st.S_msk | (uint32_t)(st.S_msk >> 32);
   opaque_u32(nz);
   if (nz == 0u) return k;
@@ -734,20 +830,124 @@ __device__ __forceinline__ ChunkPick pair_pick_chunk(const StepParams &p, const 
       T -= readlane_u64(incl, 63);
     }
   }
-  if (k.csel >= 0) k.scan = *reinterpret_cast<const uint64_t *>(lanes + ((int64_t)k.csel * 64 + lane) * 2);
   return k;
 }
 
-template <int DT, int MASK>
-__device__ __forceinline__ int32_t pair_pick_token(const RowView<DT, MASK> &rv, const ChunkPick &k, int lane) {
-  if (k.csel < 0) return -1;  // (with a non-zero sum, consistent records rule this out)
-  const uint64_t pick = chunk_pick_lane((uint32_t)k.scan, (uint32_t)(k.scan >> 32), k.R2);
-  return chunk_pick_element_mem(rv, k.csel, pick, k.Nms, lane);
+// second stage: the chosen chunk once more, exactly as the stats role summed its allowed part - same loads, same
+// terms, same (lane, class) order, on the scale the record names (for a chunk that was redone on its allowed
+// maximum's scale the forbidden terms may overflow to +inf in the unmasked partials, which nobody reads) - then lane,
+// class and element from the second word.  mid(): see lane_pick_element.
+template <int DT, int MASK, class Mid>
+__device__ __forceinline__ int32_t pair_pick_token(const StepParams &p, const char *rowp, int mi, const ChunkPick &k,
+                                                   int lane, Mid &&mid) {
+  constexpr int EPV = ElemTraits<DT>::EPV, NVC = ElemTraits<DT>::NVC;
+  const int V = p.V, c = __builtin_amdgcn_readfirstlane(k.csel), e_base = c * kChunk;  // (uniform, and provably so:
+  mi = __builtin_amdgcn_readfirstlane(mi);                                               //  the mask words go to SGPRs)
+  int nv_valid = (V - e_base + 64 * EPV - 1) / (64 * EPV);
+  nv_valid = nv_valid < NVC ? nv_valid : NVC;
+  const float magicN = kMagic - k.Nms;
+  float P[4], Pm[4];
+  if constexpr (MASK == kMaskBits) {
+    const cu64_t mt = as_const(p.mask_t + ((int64_t)mi * p.nch + c) * 64);
+    MaskAhead ma;
+    mask_ahead<DT>(mt, ma);
+    float x[64];
+    load_chunk<DT, true>(rowp, e_base, V, lane, p.scale, x);  // (x * 1.0f == x: the scaled form serves every call)
+    class_partials<DT, true>(x, magicN, nv_valid, mt, ma, Pm, P);  // P: the allowed elements' partials
+  } else {
+    float y[64];
+    load_chunk<DT, true>(rowp, e_base, V, lane, p.scale, y);
+    if constexpr (MASK == kMaskF32) {
+      float x[64];
+#pragma unroll
+      for (int j = 0; j < 64; ++j) x[j] = y[j];
+      add_float_mask<DT>(x, (const char *)(p.mask_f + (int64_t)mi * p.mask_ld), e_base, V, lane, y);
+    }
+    class_partials<DT, false>(y, magicN, nv_valid, nullptr, MaskAhead{}, P, Pm);
+  }
+  uint32_t h, l;
+  lane_payload<4>(P, h, l);
+  const uint64_t pick = chunk_pick_lane(wave_sum_u32_l63(h), wave_sum_u32_l63(l), k.R2);
+  if (pick == ~0ull) {
+    mid();
+    return -1;
+  }
+  const int lsel = __builtin_amdgcn_readfirstlane((int)(pick >> 56));
+  return lane_pick_element<DT, MASK>(p, rowp, mi, c, P, magicN, lsel, pick & ((1ull << 56) - 1ull), lane, mid);
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// finish: one workgroup per particle - a single wave for the statistics / Philox modes (launched with 64 threads),
-// four waves for parity mode, which deals the row's vectors to all of them.
+// finish role, statistics and Philox modes: one wave per particle
+// ---------------------------------------------------------------------------------------------------------
+template <int DT, int MASK, int MODE, bool POLL>
+__device__ __forceinline__ void finish_particle(const StepParams &p, int pidx, int lane) {
+  constexpr int ES = ElemTraits<DT>::ES;
+  const int nch = p.nch;
+  const int pr = p.pair_of ? as_const(p.pair_of)[pidx] : pidx;
+  const int row = p.pair_row ? as_const(p.pair_row)[pr] : pr;
+  const int mi = MASK == kMaskNone ? 0 : (p.pair_mask ? as_const(p.pair_mask)[pr] : (p.n_masks == 1 ? 0 : pr));
+  Recs recs;
+  recs.base = p.recs + (int64_t)pr * nch * kRecWords;
+  recs.epoch = p.epoch;
+  if (!recs_acquire<POLL>(recs, nch, lane)) {  // never in a healthy launch: say so in the outputs and leave
+    if (lane == 0) {
+      const float nan = __uint_as_float(0x7fc00000u);
+      if (p.out_lse) p.out_lse[pidx] = nan;
+      if (p.out_logZ) p.out_logZ[pidx] = nan;
+      if (p.out_token) p.out_token[pidx] = -2;
+    }
+    return;
+  }
+  PairState st;
+  pair_fold<MASK>(recs, nch, lane, st);
+  auto logs = [&]() {
+    if (lane == 0) {
+      float lse, logZ;
+      pair_logs(st, lse, logZ);
+      if (p.out_lse) p.out_lse[pidx] = lse;
+      if (p.out_logZ) p.out_logZ[pidx] = logZ;
+    }
+  };
+  if constexpr (MODE == kModePhilox) {
+    if (p.out_token) {
+      const ChunkPick pick = pair_pick_chunk(p, recs, st, pidx, nch, lane);
+      int32_t tok = -1;
+      if (pick.csel >= 0) {
+        const char *rowp = (const char *)p.logits + (int64_t)row * p.ld * ES;
+        tok = pair_pick_token<DT, MASK>(p, rowp, mi, pick, lane, logs);  // (calls logs() once, on every path)
+      } else {
+        logs();
+      }
+      if (lane == 0) p.out_token[pidx] = tok;
+      return;
+    }
+  }
+  logs();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The step in ONE launch: blocks [0, stats_blocks) are four stats waves each, the blocks behind them four finishing
+// waves each.  Workgroups are dispatched in index order, so finishing waves become resident when the last stats
+// waves have been placed; correctness needs no such order: a finishing wave only waits for stats waves, which wait for
+// nobody, and fin_waves is capped well below the chip's wave slots (glb_api.hip), so finishing waves can never keep a
+// stats wave from getting one.  Every wait is bounded (kSpinTicks).
+// ---------------------------------------------------------------------------------------------------------
+template <int DT, int MASK, bool SCALED, int MODE>
+__global__ __launch_bounds__(256, StatsWaves<MASK>::value) void fused_step_kernel(const StepParams p) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int blk = blockIdx.x;
+  if (blk < p.stats_blocks) {
+    const int item = blk * 4 + wave;
+    if (item < p.n_pairs * p.nch) stats_item<DT, MASK, SCALED>(p, item, lane);
+    return;
+  }
+  for (int pidx = (blk - p.stats_blocks) * 4 + wave; pidx < p.n_particles; pidx += p.fin_waves)
+    finish_particle<DT, MASK, MODE, true>(p, pidx, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// finish as a launch of its own: one workgroup per particle - a single wave for the statistics / Philox modes
+// (launched with 64 threads), four waves for parity mode, which deals the row's vectors to all of them.
 // ---------------------------------------------------------------------------------------------------------
 template <int DT, int MASK, int MODE>
 __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
@@ -755,13 +955,19 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
   __shared__ float s_bestg[4], s_secg[4];
   __shared__ int32_t s_bestj[4];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  if (MODE != kModeNoise && wave != 0) return;
   const int pidx = blockIdx.x;
+  if constexpr (MODE != kModeNoise) {
+    if (wave == 0) finish_particle<DT, MASK, MODE, false>(p, pidx, lane);
+    return;
+  }
   const int nch = p.nch, V = p.V;
   const int pr = p.pair_of ? as_const(p.pair_of)[pidx] : pidx;
   const int row = p.pair_row ? as_const(p.pair_row)[pr] : pr;
   const int mi = MASK == kMaskNone ? 0 : (p.pair_mask ? as_const(p.pair_mask)[pr] : (p.n_masks == 1 ? 0 : pr));
-  const RecsGlobal recs{p.recs + (int64_t)pr * nch};
+  Recs recs;
+  recs.base = p.recs + (int64_t)pr * nch * kRecWords;
+  recs.epoch = p.epoch;
+  recs_acquire<false>(recs, nch, lane);
 
   RowView<DT, MASK> rv;
   rv.rowp = (const char *)p.logits + (int64_t)row * p.ld * ES;
@@ -773,23 +979,14 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
 
   PairState st;
   pair_fold<MASK>(recs, nch, lane, st);
-  ChunkPick pick{-1, 0.f, 0ull, 0ull};
-  if constexpr (MODE == kModePhilox) {  // the chunk, and the request for its scan words: in flight during the logs
-    if (p.out_token) pick = pair_pick_chunk(p, recs, st, pidx, nch, lane, p.lanes + (int64_t)pr * nch * 128);
-  }
   if (wave == 0 && lane == 0) {
     float lse, logZ;
     pair_logs(st, lse, logZ);
     if (p.out_lse) p.out_lse[pidx] = lse;
     if (p.out_logZ) p.out_logZ[pidx] = logZ;
   }
-  if constexpr (MODE == kModeStats) return;
   if (!p.out_token) return;
-
-  if constexpr (MODE == kModePhilox) {
-    const int32_t tok = pair_pick_token<DT, MASK>(rv, pick, lane);
-    if (lane == 0) p.out_token[pidx] = tok;
-  } else {
+  {
     // ---- parity mode: exponential race against the caller's noise, first maximum of e_j / E_j (README.md:87
     //      through torch.multinomial's CPU algorithm).  e_j = ldexp(P, n_j - N_msk): any common scale gives the same
     //      comparisons; N_msk is the largest scale any chunk's allowed terms were summed on, so every allowed term that
@@ -928,8 +1125,11 @@ __global__ __launch_bounds__(1024) void logprob_rows_fused_kernel(const void *lo
     nv_valid = nv_valid < NVC ? nv_valid : NVC;
     load_chunk<DT, SCALED>(rowp, e_base, V, lane, scale, x);
     const float Nc = exp_n(chunk_max(x));
-    uint32_t pA, pB, pAm, pBm;
-    chunk_sums<DT, false>(x, kMagic - Nc, nv_valid, nullptr, MaskAhead{}, pA, pB, pAm, pBm);
+    float P[4], Pm[4];
+    uint32_t h, l;
+    class_partials<DT, false>(x, kMagic - Nc, nv_valid, nullptr, MaskAhead{}, P, Pm);
+    lane_payload<4>(P, h, l);
+    const uint32_t pA = wave_sum_u32_l63(h), pB = wave_sum_u32_l63(l);
     if (lane == 63) {
       s_rec[c] = ((uint64_t)pA << kGridHi) + pB;
       s_N[c] = Nc;

@@ -1,7 +1,5 @@
 // glb_chunk_tu.hip — one translation unit per element type (-DGLB_DT=<0|1|2>): instantiates the chunked step
 // kernels for every mask kind / draw mode and exports the launchers glb_api.hip dispatches to.
-#include <cstdlib>
-
 #include "glb_chunk.hpp"
 
 #ifndef GLB_DT
@@ -17,40 +15,53 @@ namespace glb {
 // two SIMDs the per-wave latency is the launch time)
 constexpr int64_t kSmallLaunchItems = 512;
 
-// lanes: the call draws with Philox - the reducing waves also store their per-lane scans (StepParams::lanes)
 template <int MASK>
-static hipError_t stats1(const StepParams &p, bool scaled, bool lanes, hipStream_t s) {
+static hipError_t stats1(const StepParams &p, bool scaled, hipStream_t s) {
   const int64_t waves = (int64_t)p.n_pairs * p.nch;
   if constexpr (MASK != kMaskF32) {
     if (waves <= kSmallLaunchItems) {
       const dim3 grid((unsigned)waves), block(256);
-      if (lanes) {
-        if (scaled) hipLaunchKernelGGL((chunk_stats_small_kernel<GLB_DT, MASK, true, true>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((chunk_stats_small_kernel<GLB_DT, MASK, false, true>), grid, block, 0, s, p);
-      } else {
-        if (scaled) hipLaunchKernelGGL((chunk_stats_small_kernel<GLB_DT, MASK, true, false>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((chunk_stats_small_kernel<GLB_DT, MASK, false, false>), grid, block, 0, s, p);
-      }
+      if (scaled) hipLaunchKernelGGL((chunk_stats_small_kernel<GLB_DT, MASK, true>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((chunk_stats_small_kernel<GLB_DT, MASK, false>), grid, block, 0, s, p);
       return hipGetLastError();
     }
   }
   const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
-  static const size_t lds = [] { const char *e = getenv("GLB_K1_LDS"); return e ? (size_t)atoi(e) : 0; }();  // tuning aid: caps the waves per SIMD
-  if (lanes) {
-    if (scaled) hipLaunchKernelGGL((chunk_stats_kernel<GLB_DT, MASK, true, true>), grid, block, lds, s, p);
-    else hipLaunchKernelGGL((chunk_stats_kernel<GLB_DT, MASK, false, true>), grid, block, lds, s, p);
-  } else {
-    if (scaled) hipLaunchKernelGGL((chunk_stats_kernel<GLB_DT, MASK, true, false>), grid, block, lds, s, p);
-    else hipLaunchKernelGGL((chunk_stats_kernel<GLB_DT, MASK, false, false>), grid, block, lds, s, p);
-  }
+  if (scaled) hipLaunchKernelGGL((chunk_stats_kernel<GLB_DT, MASK, true>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((chunk_stats_kernel<GLB_DT, MASK, false>), grid, block, 0, s, p);
   return hipGetLastError();
 }
 
-hipError_t GLB_CAT(launch_stats_, GLB_DT)(const StepParams &p, int mask_kind, bool scaled, bool lanes, hipStream_t s) {
+hipError_t GLB_CAT(launch_stats_, GLB_DT)(const StepParams &p, int mask_kind, bool scaled, hipStream_t s) {
   switch (mask_kind) {
-    case kMaskNone: return stats1<kMaskNone>(p, scaled, lanes, s);
-    case kMaskBits: return stats1<kMaskBits>(p, scaled, lanes, s);
-    case kMaskF32: return stats1<kMaskF32>(p, scaled, lanes, s);
+    case kMaskNone: return stats1<kMaskNone>(p, scaled, s);
+    case kMaskBits: return stats1<kMaskBits>(p, scaled, s);
+    case kMaskF32: return stats1<kMaskF32>(p, scaled, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+// the step in one launch (statistics / Philox modes): p.stats_blocks and p.fin_waves are set by the caller
+template <int MASK, int MODE>
+static hipError_t fused2(const StepParams &p, bool scaled, hipStream_t s) {
+  const dim3 grid((unsigned)(p.stats_blocks + (p.fin_waves + 3) / 4)), block(256);
+  if (scaled) hipLaunchKernelGGL((fused_step_kernel<GLB_DT, MASK, true, MODE>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((fused_step_kernel<GLB_DT, MASK, false, MODE>), grid, block, 0, s, p);
+  return hipGetLastError();
+}
+
+template <int MASK>
+static hipError_t fused1(const StepParams &p, int mode, bool scaled, hipStream_t s) {
+  if (mode == kModeStats) return fused2<MASK, kModeStats>(p, scaled, s);
+  if (mode == kModePhilox) return fused2<MASK, kModePhilox>(p, scaled, s);
+  return hipErrorInvalidValue;
+}
+
+hipError_t GLB_CAT(launch_fused_step_, GLB_DT)(const StepParams &p, int mask_kind, int mode, bool scaled, hipStream_t s) {
+  switch (mask_kind) {
+    case kMaskNone: return fused1<kMaskNone>(p, mode, scaled, s);
+    case kMaskBits: return fused1<kMaskBits>(p, mode, scaled, s);
+    case kMaskF32: return fused1<kMaskF32>(p, mode, scaled, s);
   }
   return hipErrorInvalidValue;
 }
@@ -88,23 +99,17 @@ hipError_t GLB_CAT(launch_logprob_rows_, GLB_DT)(const void *logits, int64_t ld,
 }
 
 template <bool SCALED>
-static void fused1(const void *logits, int64_t ld, int V, int nch, float scale, float *out, int64_t out_ld, float *out_lse,
+static void lsm_fused1(const void *logits, int64_t ld, int V, int nch, float scale, float *out, int64_t out_ld, float *out_lse,
                    int n_rows, hipStream_t s) {
   const size_t lds = (size_t)nch * (sizeof(uint64_t) + sizeof(float));
-  // (the keep-the-chunk-in-registers variant, ONE = true, needs 128 VGPRs at 16 waves per CU and spills: 132 vs 111 us
-  //  at 1024 x 50257 fp32 - measured; it stays instantiable for a smaller workgroup but is not dispatched)
-  if (nch <= 0)
-    hipLaunchKernelGGL((logprob_rows_fused_kernel<GLB_DT, SCALED, true>), dim3((unsigned)n_rows), dim3(1024), lds, s, logits,
-                       ld, V, nch, scale, out, out_ld, out_lse);
-  else
-    hipLaunchKernelGGL((logprob_rows_fused_kernel<GLB_DT, SCALED, false>), dim3((unsigned)n_rows), dim3(1024), lds, s, logits,
-                       ld, V, nch, scale, out, out_ld, out_lse);
+  hipLaunchKernelGGL((logprob_rows_fused_kernel<GLB_DT, SCALED, false>), dim3((unsigned)n_rows), dim3(1024), lds, s, logits,
+                     ld, V, nch, scale, out, out_ld, out_lse);
 }
 
 hipError_t GLB_CAT(launch_logprob_fused_, GLB_DT)(const void *logits, int64_t ld, int V, int nch, float scale, float *out,
                                                    int64_t out_ld, float *out_lse, int n_rows, hipStream_t s) {
-  if (scale != 1.0f) fused1<true>(logits, ld, V, nch, scale, out, out_ld, out_lse, n_rows, s);
-  else fused1<false>(logits, ld, V, nch, scale, out, out_ld, out_lse, n_rows, s);
+  if (scale != 1.0f) lsm_fused1<true>(logits, ld, V, nch, scale, out, out_ld, out_lse, n_rows, s);
+  else lsm_fused1<false>(logits, ld, V, nch, scale, out, out_ld, out_lse, n_rows, s);
   return hipGetLastError();
 }
 

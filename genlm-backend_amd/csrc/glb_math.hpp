@@ -2,12 +2,13 @@
 //
 // Device restatement of the contract that oracle/glb_oracle.c states for the CPU.  Every floating
 // point step is a single IEEE-754 operation (mul, add, fma, exact power-of-two scaling), the
-// file is compiled with -ffp-contract=off, and all sums are integer sums, so results do not
-// depend on how a row is split over lanes, waves, workgroups or GPUs.
+// file is compiled with -ffp-contract=off, float32 additions happen only inside one (lane, class) of a chunk in a
+// fixed order, and every sum above that level is an integer sum, so results do not depend on how rows are split
+// over waves, workgroups or GPUs.
 //
-// Two generations live here: the chunked contract of the particle step ("v2": chunk_term / term_q and the
-// round-toward-zero two-grid accumulation, below) and the row-scale fixed-point term of the first round
-// (exp_parts / fix_term), which glb_normalize_weights still uses for the short log-weight vector.
+// Two generations live here: the chunked contract of the particle step (chunk_term and the (lane, class) partial
+// sums, below) and the row-scale fixed-point term of the first round (exp_parts / fix_term), which
+// glb_normalize_weights still uses for the short log-weight vector.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -179,17 +180,18 @@ __device__ __forceinline__ float wave_max(float v) {
 // vocabulary index.  Chunk c has its own binary scale N_c = exp_n(max of the chunk); every element gives
 //     t = ldexp(P(f), n - N_c)    fp32, P = 2^(f-1) in [0.35, 0.71] (degree-4 Horner, result clamped to [0,1],
 //                                 NaN -> 0), so t <= 0.7072 and t = 0 for -inf / NaN
-//     q = floor(t * 2^36)         integer term, 36 fractional bits below 2^(N_c + 1)
-// and S_c = sum q.  The hot kernel never forms q: it adds t into fp32 accumulators in ROUND-TOWARD-ZERO mode on
-// two fixed grids - A on 2^-18 (A stays in [32, 64)), the exact remainder into B on 2^-36 (B in [2^-13, 2^-12)) -
-// which is the same integer sum: floor_36(t) = floor_18(t) + floor_36(t - floor_18(t)), every add exact.
-// A accumulator takes at most 32 terms (32 * 0.7072 < 32; remainders < 2^-18 each, 32 of them < 2^-13).
+// One wave holds a chunk: lane l owns elements (i * 64 + l) * EPV + k (EPV elements per 16-byte vector, vector i,
+// component k).  The unit of floating-point summation is one (lane, class w = i mod 4): its 16 terms are added in
+// fp32, round to nearest, one by one in (i, k) order from +0 (a masked sum skips forbidden elements = adds +0):
+//     P_(l,w) = ((t_0 + t_1) + t_2) + ...        q_(l,w) = floor(P_(l,w) * 2^36) = (h << 18) + l
+// Everything above is an integer sum (of the h and l words separately), so it does not matter which wave, workgroup
+// or GPU holds which (lane, class) - only the order inside one is fixed, and it is the order the loads deliver.
+// Three VALU instructions per element for both sums (one add, and under EXEC = allowed lanes a second one) where
+// round 2's exact per-element integer terms took six.
 // =====================================================================================================
 constexpr int kChunk = 4096;         // elements per chunk (64 per lane of one wave)
-constexpr int kFrac = 36;            // q = floor(t * 2^36)
-constexpr int kGridHi = 18;          // coarse grid 2^-18
-constexpr uint32_t kA0Bits = 0x42000000u;  // 32.0f: ulp 2^-18
-constexpr uint32_t kB0Bits = 0x39000000u;  // 2^-13: ulp 2^-36
+constexpr int kFrac = 36;            // q = floor(P * 2^36)
+constexpr int kGridHi = 18;          // q = (h << 18) + l
 constexpr int kLowMassBits = 32;     // a chunk's bit-masked sum below 2^32 (on the chunk's scale) is redone on its own scale
 // 2^(f-1) on |f| <= 1/2: degree-4 minimax polynomial (relative error, Remez; max 2.7e-6 as evaluated in fp32
 // Horner form, mean +4e-8), coefficients of 2^f with the exponent lowered by one
@@ -222,84 +224,33 @@ __device__ __forceinline__ float chunk_term(float x, float magicN) {
   return __builtin_amdgcn_ldexpf(p, np);
 }
 
-// the integer term itself (the draws), as two words: q = floor(t * 2^36) = (h << 18) + l, h = floor(t * 2^18), l < 2^18
-__device__ __forceinline__ void term_q_parts(float x, float magicN, uint32_t &h, uint32_t &l) {
-  const float t = chunk_term(x, magicN);
-  const float hi = __builtin_truncf(t * 262144.0f);             // floor(t * 2^18), exact
-  const float lo = __builtin_fmaf(hi, -0x1p-18f, t) * 0x1p36f;  // (t - hi * 2^-18) * 2^36, exact, < 2^18 (+ fraction)
+// floor(P * 2^36) of a (lane, class) partial sum as two words: h = floor(P * 2^18) < 2^22, l < 2^18.  Every step
+// exact: P < 16, so P * 2^18 < 2^22 truncates exactly, and P - h * 2^-18 < 2^-18 is a multiple of ulp(P) >= 2^-41.
+__device__ __forceinline__ void partial_q(float P, uint32_t &h, uint32_t &l) {
+  const float hi = __builtin_truncf(P * 262144.0f);
+  const float lo = __builtin_fmaf(hi, -0x1p-18f, P) * 0x1p36f;
   asm("v_cvt_u32_f32 %0, %1" : "=v"(h) : "v"(hi));
   asm("v_cvt_u32_f32 %0, %1" : "=v"(l) : "v"(lo));
 }
 
-
-// Accumulate four terms in round-toward-zero mode: elements 0, 2 into set 0 (A0, B0), elements 1, 3 into set 1.
-// With MASKED, the lanes named by the 64-bit lane masks M0..M3 also add the same (coarse, remainder) pair into the
-// masked accumulators (exact adds on the same grids; EXEC is restored before the block ends).
-template <bool MASKED>
-__device__ __forceinline__ void rtz_acc4(float t0, float t1, float t2, float t3, float &A0, float &B0, float &A1,
-                                         float &B1, float &Am0, float &Bm0, float &Am1, float &Bm1, uint64_t M0,
-                                         uint64_t M1, uint64_t M2, uint64_t M3) {
-  float x0, x1, d0, d1, l0, l1;
-  if constexpr (MASKED) {
-    float d2, d3, l2, l3;
-    asm(
-        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
-        "v_add_f32 %8, %0, %18\n\t"
-        "v_add_f32 %9, %2, %19\n\t"
-        "v_sub_f32 %10, %8, %0\n\t"
-        "v_sub_f32 %11, %9, %2\n\t"
-        "v_sub_f32 %12, %18, %10\n\t"
-        "v_sub_f32 %13, %19, %11\n\t"
-        "v_add_f32 %1, %1, %12\n\t"
-        "v_add_f32 %3, %3, %13\n\t"
-        "v_add_f32 %0, %8, %20\n\t"
-        "v_add_f32 %2, %9, %21\n\t"
-        "v_sub_f32 %14, %0, %8\n\t"
-        "v_sub_f32 %15, %2, %9\n\t"
-        "v_sub_f32 %16, %20, %14\n\t"
-        "v_sub_f32 %17, %21, %15\n\t"
-        "v_add_f32 %1, %1, %16\n\t"
-        "v_add_f32 %3, %3, %17\n\t"
-        "s_mov_b64 exec, %22\n\t"
-        "v_add_f32 %4, %4, %10\n\t"
-        "v_add_f32 %5, %5, %12\n\t"
-        "s_mov_b64 exec, %23\n\t"
-        "v_add_f32 %6, %6, %11\n\t"
-        "v_add_f32 %7, %7, %13\n\t"
-        "s_mov_b64 exec, %24\n\t"
-        "v_add_f32 %4, %4, %14\n\t"
-        "v_add_f32 %5, %5, %16\n\t"
-        "s_mov_b64 exec, %25\n\t"
-        "v_add_f32 %6, %6, %15\n\t"
-        "v_add_f32 %7, %7, %17\n\t"
-        "s_mov_b64 exec, -1\n\t"
-        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
-        : "+v"(A0), "+v"(B0), "+v"(A1), "+v"(B1), "+v"(Am0), "+v"(Bm0), "+v"(Am1), "+v"(Bm1), "=&v"(x0), "=&v"(x1),
-          "=&v"(d0), "=&v"(d1), "=&v"(l0), "=&v"(l1), "=&v"(d2), "=&v"(d3), "=&v"(l2), "=&v"(l3)
-        : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "s"(M0), "s"(M1), "s"(M2), "s"(M3));
-  } else {
-    asm(
-        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
-        "v_add_f32 %4, %0, %10\n\t"
-        "v_add_f32 %5, %2, %11\n\t"
-        "v_sub_f32 %6, %4, %0\n\t"
-        "v_sub_f32 %7, %5, %2\n\t"
-        "v_sub_f32 %8, %10, %6\n\t"
-        "v_sub_f32 %9, %11, %7\n\t"
-        "v_add_f32 %1, %1, %8\n\t"
-        "v_add_f32 %3, %3, %9\n\t"
-        "v_add_f32 %0, %4, %12\n\t"
-        "v_add_f32 %2, %5, %13\n\t"
-        "v_sub_f32 %6, %0, %4\n\t"
-        "v_sub_f32 %7, %2, %5\n\t"
-        "v_sub_f32 %8, %12, %6\n\t"
-        "v_sub_f32 %9, %13, %7\n\t"
-        "v_add_f32 %1, %1, %8\n\t"
-        "v_add_f32 %3, %3, %9\n\t"
-        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
-        : "+v"(A0), "+v"(B0), "+v"(A1), "+v"(B1), "=&v"(x0), "=&v"(x1), "=&v"(d0), "=&v"(d1), "=&v"(l0), "=&v"(l1)
-        : "v"(t0), "v"(t1), "v"(t2), "v"(t3));
-  }
+// Pm += t_k on the lanes named by the 64-bit lane masks M_k (k = 0..3, in this order: one dependent chain).  EXEC is
+// saved and restored, so the block is correct under any caller EXEC (lanes outside it stay untouched: M_k is ANDed in).
+__device__ __forceinline__ void masked_add4(float &Pm, float t0, float t1, float t2, float t3, uint64_t M0, uint64_t M1,
+                                            uint64_t M2, uint64_t M3) {
+  uint64_t saved;
+  asm("s_mov_b64 %1, exec\n\t"
+      "s_and_b64 exec, %1, %6\n\t"
+      "v_add_f32 %0, %0, %2\n\t"
+      "s_and_b64 exec, %1, %7\n\t"
+      "v_add_f32 %0, %0, %3\n\t"
+      "s_and_b64 exec, %1, %8\n\t"
+      "v_add_f32 %0, %0, %4\n\t"
+      "s_and_b64 exec, %1, %9\n\t"
+      "v_add_f32 %0, %0, %5\n\t"
+      "s_mov_b64 exec, %1"
+      : "+v"(Pm), "=&s"(saved)
+      : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "s"(M0), "s"(M1), "s"(M2), "s"(M3)
+      : "scc");
 }
 
 // zero-instruction barriers: the value is re-materialised in a VGPR here (keeps wave-uniform 64-bit compares out of

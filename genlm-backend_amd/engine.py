@@ -65,21 +65,53 @@ class StepPlan:
         return self.out
 
 
+class _OnDevice:
+    """The library's entry points, each run with the engine's device current.  HIP launches go to the calling thread's
+    current device; the engine's tensors and stream belong to `self.device`, so a caller that has another device
+    current (one process driving several GPUs) must not be able to send a launch to the wrong one."""
+
+    def __init__(self, lib, index):
+        self._lib, self._index = lib, index
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        index = self._index
+
+        def call(*args):
+            if torch.cuda.current_device() == index:
+                return fn(*args)
+            with torch.cuda.device(index):
+                return fn(*args)
+
+        setattr(self, name, call)  # resolved once per entry point
+        return call
+
+
 class HipEngine:
     """All device work of the hot path for one GPU."""
 
     def __init__(self, device=None):
-        self.lib = _lib.load()
-        if not torch.cuda.is_available() or self.lib.glb_device_count() <= 0:
+        lib = _lib.load()
+        if not torch.cuda.is_available() or lib.glb_device_count() <= 0:
             raise RuntimeError(
                 "HipEngine needs a HIP device (MI355X / gfx950); none is visible and there is no CPU fallback"
             )
         self.device = torch.device(device if device is not None else "cuda:0")
         if self.device.type != "cuda":
             raise RuntimeError(f"HipEngine device must be a HIP device, got {self.device}")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.lib = _OnDevice(lib, self.device.index)
         self._ws = None
         self._step_ws = None
         self._trie_ws = None
+
+    def __del__(self):
+        try:
+            if self._step_ws is not None:
+                self.lib.glb_workspace_release(_ptr(self._step_ws))
+        except Exception:  # interpreter shutdown
+            pass
 
     # ------------------------------------------------------------------------------------------
     def _stream(self):
@@ -100,8 +132,13 @@ class HipEngine:
 
     # ------------------------------------------------------------------------------------------
     def _scratch(self, need):
+        """The step's scratch buffer, zeroed and registered with the library (glb_workspace_init): calls that find their
+        workspace registered run as ONE launch."""
         if self._step_ws is None or self._step_ws.numel() < need:
+            if self._step_ws is not None:
+                self.lib.glb_workspace_release(_ptr(self._step_ws))
             self._step_ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=self.device)
+            check(self.lib.glb_workspace_init(_ptr(self._step_ws), self._step_ws.numel(), self._stream()))
         return self._step_ws
 
     def step(self, logits, vocab=None, row_of=None, mask_kind=MASK_NONE, mask=None, mask_id=None,

@@ -13,9 +13,10 @@
  * relative to the reference checkout.
  *
  * Arithmetic contract ("GLB math"): a logits row is a sequence of 4096-element chunks, each
- * with its own binary scale; sums of exponentials are exact integer sums of floor(t * 2^36) terms from a
- * correctly-rounded-FMA polynomial exp, so logZ / lse / sampled token are bit-identical for any launch
- * geometry, GPU count or particle split, and are restated bit-for-bit by oracle/glb_oracle.c.
+ * with its own binary scale; the terms of a correctly-rounded-FMA polynomial exp are added in float32 in a fixed
+ * order inside each of a chunk's 256 (lane, class) groups of 16 elements and as integers (floor(P * 2^36)) above
+ * that, so logZ / lse / sampled token are bit-identical for any launch geometry, GPU count or particle split,
+ * and are restated bit-for-bit by oracle/glb_oracle.c.
  */
 #ifndef GLB_H
 #define GLB_H
@@ -27,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GLB_ABI_VERSION 3
+#define GLB_ABI_VERSION 4
 
 /* status codes */
 enum {
@@ -56,7 +57,8 @@ enum {
 enum {
   GLB_RNG_NONE = 0,   /* no draw (out_token untouched)                                            */
   GLB_RNG_PHILOX = 1, /* in-kernel Philox4x32-10, two 64-bit uniforms per particle: exact integer inverse
-                         CDF over the row's 4096-token chunks, then inside the chunk  */
+                         CDF over the row's 4096-token chunks, then down the chunk's summation tree: lane,
+                         class, element                                              */
   GLB_RNG_NOISE = 2   /* parity mode: caller supplies Exp(1) noise E[n_particles, noise_ld] drawn
                          the way torch.multinomial draws it on CPU; token = first argmax p_j/E_j
                          (README.md:87, base.py:137-141)                                          */
@@ -114,19 +116,32 @@ typedef struct glb_step_args {
   /* outputs, each nullable */
   float *out_logZ;   /* [n_particles] logsumexp(log_softmax(x)+mask) */
   float *out_lse;    /* [n_particles] logsumexp(x) of the particle's row */
-  int32_t *out_token;/* [n_particles] sampled id, -1 when every token is masked out */
+  int32_t *out_token;/* [n_particles] sampled id, -1 when every token is masked out (-2, with NaN logZ / lse: a
+                        finishing wave gave up waiting for its row's records - a failed launch, never a result) */
   float *out_margin; /* [n_particles] GLB_RNG_NOISE only: (winner - runner-up) / winner of the race e_j / E_j, i.e. how
                         far the draw is from a tie that float rounding could flip (1 if there is no runner-up) */
   int32_t reserved;  /* must be 0 */
-  /* device scratch of >= glb_step_workspace_bytes(...) bytes, 32-byte aligned: the per-chunk records and per-lane
-     scans (32 + 512 bytes per row and 4096-token chunk) the reduction kernel hands to the per-particle kernel (and, for
-     GLB_MASK_BITS, the prepared masks) */
+  /* device scratch of >= glb_step_workspace_bytes(...) bytes, 32-byte aligned: the per-chunk records (64 bytes per
+     row and 4096-token chunk) the reducing waves hand to the per-particle waves (and, for GLB_MASK_BITS, the prepared
+     masks).  See glb_workspace_init. */
   void *workspace;
   size_t workspace_bytes;
 } glb_step_args;
 
 size_t glb_step_workspace_bytes(int64_t n_particles, int64_t n_rows, int64_t vocab, int64_t n_masks);
 int glb_logprob_mask_sample(const glb_step_args *args, void *hip_stream);
+
+/*
+ * A step workspace that was zeroed and registered with glb_workspace_init is served in ONE launch: the waves that
+ * reduce the rows tag every record with the call's epoch (counted per workspace by the library) and the waves that
+ * finish the particles, dealt at the end of the same grid, sweep the records of their row until all tags are fresh.
+ * Call it once after allocating the buffer (enqueues one memset on the stream), and glb_workspace_release before
+ * freeing it or handing the memory to anything else.  Workspaces nobody initialised, calls made while the stream is
+ * being captured into a graph, and GLB_RNG_NOISE calls take two launches - same results, bit for bit.  A workspace
+ * serves one call at a time (as before: it is scratch).
+ */
+int glb_workspace_init(void *workspace, size_t workspace_bytes, void *hip_stream);
+int glb_workspace_release(void *workspace);
 
 /*
  * Bring GLB_MASK_BITS rows into the layout the kernels read ([mask][chunk][vector][component] 64-bit lane

@@ -183,11 +183,17 @@ static int mask_allows(const uint32_t *bits, int64_t j) {
  * N_c = glb_exp_n(max of the chunk).  Every element gives
  *     t = ldexpf(P, n - N_c)     P = 2^(f-1) by a degree-4 Horner polynomial (GLB_EXP2_D), clamped to [0, 1]
  *                                with NaN -> 0
- *     q = floor(t * 2^36)
- * S_c = sum of q over the chunk, S_c^m = sum over the allowed elements (on N_c, or on the allowed maximum's own scale
- * for a low-mass chunk: glb_chunk_masked).  The row scale is N = max N_c over the chunks with a non-zero sum, and the
- * row sums are S = sum_c (S_c >> (N - N_c)); likewise for the allowed sums.  sum_j e^(x_j) = 2^(N+1-36) S.
- * Philox draws take two stages (chunk, then element inside the chunk in the kernel's register order): orc_step.
+ * A chunk is held by one wave the way the kernels load it: with EPV elements per 16-byte vector of the logits (4 for
+ * fp32, 8 for 16-bit types) lane l owns elements (i * 64 + l) * EPV + k of the chunk, vector i = 0 .. 64/EPV - 1,
+ * component k = 0 .. EPV - 1.  The 64 elements of a lane fall into four CLASSES w = i mod 4 of 16 elements each.
+ * The unit of floating-point summation is one (lane, class): its 16 terms are added in float32, round to nearest, one
+ * by one in (i, k) order, starting from +0 (masked sums skip forbidden elements, which is the same as adding +0):
+ *     P_(l,w) = (((t_0 + t_1) + t_2) + ...)          q_(l,w) = floor(P_(l,w) * 2^36)
+ * Everything above that level is integer: S_c = sum of the 256 q's of the chunk; S_c^m likewise over the allowed
+ * elements (on N_c, or on the allowed maximum's own scale for a low-mass chunk: glb_chunk_masked).  The row scale is
+ * N = max N_c over the chunks with a non-zero sum, and the row sums are S = sum_c (S_c >> (N - N_c)); likewise for
+ * the allowed sums.  sum_j e^(x_j) = 2^(N+1-36) S.  Philox draws take two stages (chunk, then lane / class / element
+ * inside the chunk): orc_step.
  */
 /* 2^(f-1) on |f| <= 1/2: degree-4 minimax polynomial (relative error; max 2.7e-6 as evaluated in fp32 Horner form):
  * coefficients of 2^f with the exponent lowered by one */
@@ -216,11 +222,39 @@ static float glb_chunk_term(float x, float magicN) {
   return ldexpf(p, np);
 }
 
-static uint64_t glb_term_q(float x, float magicN) {
-  float t = glb_chunk_term(x, magicN);
-  if (!(t > 0.0f)) return 0;
-  if (t >= 1.0f) t = 1.0f; /* never for in-range inputs */
-  return (uint64_t)floor(ldexp((double)t, GLB_FRAC));
+/* floor(P * 2^36) of a float32 partial sum (P < 16: sixteen terms of at most 0.7072 each) */
+static uint64_t glb_partial_q(float P) {
+  if (!(P > 0.0f)) return 0;
+  return (uint64_t)floor(ldexp((double)P, GLB_FRAC));
+}
+
+static int glb_epv(int dtype) { return dtype == ORC_F32 ? 4 : 8; }
+
+/* index in the row of element (lane l, class w, position pos) of the chunk starting at lo */
+static int64_t glb_lane_elem(int64_t lo, int epv, int l, int w, int pos) {
+  int i = (pos / epv) * 4 + w, k = pos % epv;
+  return lo + ((int64_t)i * 64 + l) * epv + k;
+}
+
+/* the 256 (lane, class) sums of the chunk starting at lo: q[l * 4 + w]; returns their total.  mb != NULL: only the
+ * elements the bit mask allows. */
+static uint64_t glb_chunk_sum(const float *y, int64_t lo, int64_t V, float magicN, int epv, const uint32_t *mb,
+                              uint64_t *q /* [256] or NULL */) {
+  uint64_t S = 0;
+  for (int l = 0; l < 64; ++l)
+    for (int w = 0; w < 4; ++w) {
+      float P = 0.0f;
+      for (int pos = 0; pos < 16; ++pos) {
+        int64_t j = glb_lane_elem(lo, epv, l, w, pos);
+        if (j >= V) continue;
+        if (mb && !mask_allows(mb, j)) continue;
+        P = P + glb_chunk_term(y[j], magicN);
+      }
+      uint64_t ql = glb_partial_q(P);
+      if (q) q[l * 4 + w] = ql;
+      S += ql;
+    }
+  return S;
 }
 
 typedef struct {
@@ -229,7 +263,7 @@ typedef struct {
 } chunk_stat;
 
 /* statistics of y[0..V) by chunks; returns the number of chunks */
-static int64_t glb_chunk_stats(const float *y, int64_t V, chunk_stat *out) {
+static int64_t glb_chunk_stats(const float *y, int64_t V, int epv, chunk_stat *out) {
   int64_t nch = (V + GLB_CHUNK - 1) / GLB_CHUNK;
   for (int64_t c = 0; c < nch; ++c) {
     int64_t lo = c * GLB_CHUNK, hi = lo + GLB_CHUNK < V ? lo + GLB_CHUNK : V;
@@ -237,9 +271,7 @@ static int64_t glb_chunk_stats(const float *y, int64_t V, chunk_stat *out) {
     for (int64_t j = lo; j < hi; ++j)
       if (y[j] > m) m = y[j];
     out[c].N = glb_exp_n(m);
-    out[c].S = 0;
-    float magicN = GLB_MAGIC - out[c].N;
-    for (int64_t j = lo; j < hi; ++j) out[c].S += glb_term_q(y[j], magicN);
+    out[c].S = glb_chunk_sum(y, lo, V, GLB_MAGIC - out[c].N, epv, NULL, NULL);
   }
   return nch;
 }
@@ -249,28 +281,21 @@ static int64_t glb_chunk_stats(const float *y, int64_t V, chunk_stat *out) {
  * mass under about 2^-3.5 of the chunk's largest term): such a chunk sums its allowed values again on their own
  * maximum's scale.  out[c] = the
  * (scale, sum) of the allowed part of chunk c. */
-static void glb_chunk_masked(const float *x, const uint32_t *mb, int64_t V, const chunk_stat *cs, chunk_stat *out) {
+static void glb_chunk_masked(const float *x, const uint32_t *mb, int64_t V, int epv, const chunk_stat *cs,
+                             chunk_stat *out) {
   int64_t nch = (V + GLB_CHUNK - 1) / GLB_CHUNK;
   for (int64_t c = 0; c < nch; ++c) {
     int64_t lo = c * GLB_CHUNK, hi = lo + GLB_CHUNK < V ? lo + GLB_CHUNK : V;
-    float magicN = GLB_MAGIC - cs[c].N;
-    uint64_t S = 0;
     int any = 0;
-    for (int64_t j = lo; j < hi; ++j)
-      if (mask_allows(mb, j)) {
-        S += glb_term_q(x[j], magicN);
-        any = 1;
-      }
+    for (int64_t j = lo; j < hi && !any; ++j) any = mask_allows(mb, j);
+    uint64_t S = glb_chunk_sum(x, lo, V, GLB_MAGIC - cs[c].N, epv, mb, NULL);
     out[c].N = cs[c].N;
     if (any && (S >> GLB_LOW_MASS_BITS) == 0) {
       float mk = -INFINITY;
       for (int64_t j = lo; j < hi; ++j)
         if (mask_allows(mb, j) && x[j] > mk) mk = x[j];
       out[c].N = glb_exp_n(mk);
-      magicN = GLB_MAGIC - out[c].N;
-      S = 0;
-      for (int64_t j = lo; j < hi; ++j)
-        if (mask_allows(mb, j)) S += glb_term_q(x[j], magicN);
+      S = glb_chunk_sum(x, lo, V, GLB_MAGIC - out[c].N, epv, mb, NULL);
     }
     out[c].S = S;
   }
@@ -290,6 +315,7 @@ int orc_step(const void *logits, int dtype, int64_t n_rows, int64_t V, int64_t l
              int rng_mode, const float *noise, int64_t noise_ld, uint64_t seed, uint64_t offset,
              int64_t particle_base, float *out_logZ, float *out_lse, int32_t *out_token, float *out_margin) {
   int64_t nch = (V + GLB_CHUNK - 1) / GLB_CHUNK;
+  const int epv = glb_epv(dtype);
   float *x = (float *)malloc(sizeof(float) * (size_t)V);
   float *y = (float *)malloc(sizeof(float) * (size_t)V);
   chunk_stat *ca = (chunk_stat *)malloc(sizeof(chunk_stat) * (size_t)nch);
@@ -312,7 +338,7 @@ int orc_step(const void *logits, int dtype, int64_t n_rows, int64_t V, int64_t l
       y[j] = vm;
     }
     /* ---- all elements */
-    glb_chunk_stats(x, V, ca);
+    glb_chunk_stats(x, V, epv, ca);
     float N_all = -INFINITY;
     for (int64_t c = 0; c < nch; ++c)
       if (ca[c].S && ca[c].N > N_all) N_all = ca[c].N;
@@ -323,8 +349,8 @@ int orc_step(const void *logits, int dtype, int64_t n_rows, int64_t V, int64_t l
      * masks: y = x + m has chunk scales of its own; no mask: the chunk itself.  Row level as for the full sum. */
     float N_msk = N_all;
     uint64_t S_msk = S_all;
-    if (mb) glb_chunk_masked(x, mb, V, ca, cm);
-    else if (mf) glb_chunk_stats(y, V, cm);
+    if (mb) glb_chunk_masked(x, mb, V, epv, ca, cm);
+    else if (mf) glb_chunk_stats(y, V, epv, cm);
     else
       for (int64_t c = 0; c < nch; ++c) cm[c] = ca[c];
     if (mb || mf) {
@@ -353,26 +379,37 @@ int orc_step(const void *logits, int dtype, int64_t n_rows, int64_t V, int64_t l
         uint64_t T = mulhi64(R, S_msk); /* uniform integer in [0, S_msk) */
         {
           /* two stages, two independent 64-bit draws: the chunk by the shifted chunk sums (first draw), then inside
-           * the chunk an inverse CDF on the chunk's own scale against its unshifted sum (second draw).  The order
-           * inside a chunk is the order the kernel holds it in: lane l of the wave owns elements
-           * (i * 64 + l) * EPV + k of the chunk, i = 0 .. 64/EPV - 1, k = 0 .. EPV - 1, EPV elements per 16-byte
-           * vector of the logits; terms are taken lane by lane, within a lane by (i, k).  Any fixed order gives the
-           * same distribution; this one lets the wave that reduced the chunk draw from its registers. */
-          const int epv = dtype == ORC_F32 ? 4 : 8, nvc = 64 / epv;
+           * the chunk an inverse CDF on the chunk's own scale against its unshifted sum (second draw), level by level
+           * down the summation tree of the contract: lane (sums of the four class terms, lanes in order), class, then
+           * the element by the running float32 sum of its class - the first whose floor(c * 2^36) passes what is left
+           * of the target.  Every level is an exact inverse CDF of the quantities the sums were made of. */
           for (int64_t c = 0; c < nch && tok < 0; ++c) {
             if (!cm[c].S) continue;
             float d = N_msk - cm[c].N;
             uint64_t sm = shr_sat(cm[c].S, d);
             if (T < sm) {
+              uint64_t q[256];
+              const float magicN = GLB_MAGIC - cm[c].N;
+              const int64_t lo = c * GLB_CHUNK;
+              glb_chunk_sum(y, lo, V, magicN, epv, NULL, q); /* y carries the mask: forbidden = -inf = term 0 */
               uint64_t Tc = mulhi64(R2, cm[c].S), acc = 0;
-              for (int l = 0; l < 64 && tok < 0; ++l)
-                for (int i = 0; i < nvc && tok < 0; ++i)
-                  for (int k = 0; k < epv; ++k) {
-                    int64_t j = c * GLB_CHUNK + ((int64_t)i * 64 + l) * epv + k;
+              for (int l = 0; l < 64 && tok < 0; ++l) {
+                uint64_t ql = q[l * 4] + q[l * 4 + 1] + q[l * 4 + 2] + q[l * 4 + 3];
+                if (acc + ql <= Tc) { acc += ql; continue; }
+                uint64_t Tl = Tc - acc;
+                for (int w = 0; w < 4 && tok < 0; ++w) {
+                  if (Tl >= q[l * 4 + w]) { Tl -= q[l * 4 + w]; continue; }
+                  float P = 0.0f;
+                  for (int pos = 0; pos < 16; ++pos) {
+                    int64_t j = glb_lane_elem(lo, epv, l, w, pos);
                     if (j >= V) continue;
-                    acc += glb_term_q(y[j], GLB_MAGIC - cm[c].N);
-                    if (acc > Tc) { tok = (int32_t)j; break; }
+                    P = P + glb_chunk_term(y[j], magicN);
+                    if (glb_partial_q(P) > Tl) { tok = (int32_t)j; break; }
                   }
+                  break;
+                }
+                break;
+              }
               break;
             }
             T -= sm;
@@ -406,7 +443,7 @@ int orc_log_softmax_rows(const void *logits, int dtype, int64_t n_rows, int64_t 
   if (!x || !ca) return 4;
   for (int64_t r = 0; r < n_rows; ++r) {
     for (int64_t j = 0; j < V; ++j) x[j] = load_elem(logits, dtype, r * ld + j) * logit_scale;
-    glb_chunk_stats(x, V, ca);
+    glb_chunk_stats(x, V, glb_epv(dtype), ca);
     float N = -INFINITY;
     for (int64_t c = 0; c < nch; ++c)
       if (ca[c].S && ca[c].N > N) N = ca[c].N;
