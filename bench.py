@@ -28,8 +28,9 @@ A step is one pass of the hot path over one batch of synthetic input that is alr
                 kernel is run and the line says so).
 
 Rank 0 prints ONE JSON line.  `value` = particles per second over all GPUs (weak scaling).  `roofline` prices the
-fused step: algorithmic bytes per call over the mean duration of its launches (chunk_stats_kernel +
-finish_kernel), measured with HIP events on the launch stream inside the timed region.  `cpu_baseline` times the
+fused step: algorithmic bytes per call over the mean duration of its launch (fused_step_kernel), measured
+inside the timed region with HIP events the launch carries as its own start / stop stamps, and - reported beside it -
+with events recorded around the call.  `cpu_baseline` times the
 reference-semantics CPU port (oracle/, test infrastructure) of the same work on a bounded sample on this host.
 """
 import argparse
@@ -298,18 +299,28 @@ def main():
             out["rccl_ranks"] = rccl_ranks
         if kern_us is not None and len(kern_us):
             ach = runner.kernel_bytes / (np.mean(kern_us) * 1e-6) / 1e9
+            outer = runner.outer_times_us()
             out["roofline"] = {
                 "bound": "hbm",
                 "achieved": ach,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS,
+                "frac_median": runner.kernel_bytes / (np.median(kern_us) * 1e-6) / 1e9 / HBM_PEAK_GBS,
                 "traffic": pmc_traffic(workload),
-                "kernel": "glb::chunk_stats_kernel + glb::finish_kernel (fused log-softmax + mask + logsumexp + sample: "
-                          "chunked streaming reduction, then lse / logZ / draw per particle); duration = both launches",
+                "kernel": "glb::fused_step_kernel (fused log-softmax + mask + logsumexp + sample in ONE launch: stats waves "
+                          "stream the rows chunk by chunk, finishing waves at the end of the grid fold the tagged records "
+                          "and draw); the few calls too small for it (one shared row: SIS step 0) run "
+                          "glb::chunk_stats_small_kernel + glb::finish_kernel and are timed first start to last stop",
+                "timing": "every fused call of the timed region, none left out: HIP events carried by the launch itself as "
+                          "its start / stop stamps (hipExtLaunchKernel through glb_logprob_mask_sample_timed) = the launch "
+                          "duration rocprofv3 reports; *_outer_events = the same calls between two hipEventRecord markers "
+                          "on the stream (adds the marker packets)",
                 "bytes_per_launch": runner.kernel_bytes,
                 "us_per_launch_mean": float(np.mean(kern_us)),
                 "us_per_launch_median": float(np.median(kern_us)),
+                "us_per_launch_outer_events_mean": float(np.mean(outer)) if len(outer) else None,
+                "frac_outer_events": (runner.kernel_bytes / (np.mean(outer) * 1e-6) / 1e9 / HBM_PEAK_GBS) if len(outer) else None,
                 "launches_timed": len(kern_us),
             }
         if world == 1 and not args.no_cpu:
@@ -401,6 +412,8 @@ class KernelWorkload:
         self.gathered = torch.empty(B * world, device=dev) if world > 1 else None
         self.kernel_bytes = algorithmic_bytes(B, V, 2 if llama else 4, 2, (V + 31) // 32)
         self.events = []
+        self.outer = []
+        self._pool = []
         # the argument block of every buffer's call is filled once: a step's host work is then a few microseconds, so
         # the host stays ahead of the GPU and the event interval holds no wait for the next launch packet
         self.plans = [eng.step_plan(x, mask=self.masks, row_mask_id=self.mask_id, rng_mode=1, seed=1234, offset=0,
@@ -409,12 +422,18 @@ class KernelWorkload:
     def step(self, i, timed):
         plan = self.plans[i % len(self.plans)]
         if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            # two clocks (see roofline.timing): events the launch carries as its own start / stop stamps, and a pair
+            # recorded around the call
+            if len(self._pool) < 2:
+                self._pool = self.eng.timing_events(128)
+            inner, (e0, e1) = self._pool.pop(), self._pool.pop()
             e0.record()
-        plan.run(offset=i)
-        if timed:
+            plan.run_timed(inner, offset=i)
             e1.record()
-            self.events.append((e0, e1))
+            self.events.append(inner)
+            self.outer.append((e0, e1))
+        else:
+            plan.run(offset=i)
         self.lw += self.out[0]
         if self.world > 1:
             self.dist.all_gather_into_tensor(self.gathered, self.lw)
@@ -422,6 +441,9 @@ class KernelWorkload:
 
     def kernel_times_us(self):
         return np.array([a.elapsed_time(b) * 1e3 for a, b in self.events])
+
+    def outer_times_us(self):
+        return np.array([a.elapsed_time(b) * 1e3 for a, b in self.outer])
 
     def config(self):
         shape = "512 particles x Llama vocab 128256, bf16 logits [512,128256]" if self.llama else \

@@ -68,6 +68,7 @@ SYMBOLS = {
     "glb_device_count": (C.c_int, []),
     "glb_step_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "glb_logprob_mask_sample": (C.c_int, [C.POINTER(StepArgs), _vp]),
+    "glb_logprob_mask_sample_timed": (C.c_int, [C.POINTER(StepArgs), _vp, _vp, _vp]),
     "glb_workspace_init": (C.c_int, [_vp, _sz, _vp]),
     "glb_workspace_release": (C.c_int, [_vp]),
     "glb_mask_prepared_bytes": (_sz, [_i64, _i64]),

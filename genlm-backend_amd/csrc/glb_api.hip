@@ -27,6 +27,7 @@ namespace glb {
                                        int64_t out_ld, float *out_lse, int n_rows, hipStream_t s);
 GLB_DECL(0) GLB_DECL(1) GLB_DECL(2)
 #undef GLB_DECL
+thread_local hipEvent_t g_step_ev_start = nullptr, g_step_ev_stop = nullptr;  // glb_logprob_mask_sample_timed
 }  // namespace glb
 
 namespace {
@@ -74,9 +75,7 @@ struct WsEntry {
 std::mutex g_ws_mu;
 std::unordered_map<const void *, WsEntry> g_ws;
 
-// wave slots the finishing waves of a one-launch step may take: well under half of what the device holds at the
-// kernels' occupancy (5 waves per SIMD; 3 for float masks), so that they cannot starve the waves they wait for
-int fin_wave_cap(bool float_mask) {
+int device_cus() {
   static int cus = [] {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
@@ -85,8 +84,13 @@ int fin_wave_cap(bool float_mask) {
     }
     return n;
   }();
-  return cus * (float_mask ? 4 : 8);
+  return cus;
 }
+
+// finishing waves a one-launch step may have: half of the wave slots the device holds at the kernels' occupancy (4
+// waves per SIMD; 3 with float masks), so that they can never keep the stats waves they wait for from a slot
+int fin_wave_cap(bool float_mask) { return device_cus() * (float_mask ? 6 : 8); }
+
 
 hipError_t launch_finish(int dtype, const glb::StepParams &p, int mask_kind, int mode, hipStream_t s) {
   switch (dtype) {
@@ -921,13 +925,19 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
   p.out_logZ = a->out_logZ;
   p.out_lse = a->out_lse;
   p.out_token = a->out_token;
+#ifdef GLB_STAMPS
+  p.out_margin = a->out_margin;
+#else
   p.out_margin = a->rng_mode == GLB_RNG_NOISE ? a->out_margin : nullptr;
+#endif
   const bool scaled = a->logit_scale != 1.0f;
   // One launch (stats waves, then finishing waves that sweep the tagged records) when the workspace was initialised,
   // the stream is not being captured (the epoch is a launch argument), the draw is not the parity race and the
-  // launch is big enough to be dealt one wave per chunk; two launches otherwise.
+  // launch is big enough to be dealt one wave per chunk (smaller ones: four waves per chunk, then the finish launch);
+  // two launches otherwise.
   const int64_t items = n_units * (int64_t)p.nch;
-  bool fused = a->rng_mode != GLB_RNG_NOISE && items > 512 && a->n_particles <= 16 * (int64_t)fin_wave_cap(kmask == glb::kMaskF32);
+  const bool fmask = kmask == glb::kMaskF32;
+  bool fused = a->rng_mode != GLB_RNG_NOISE && items > 512 && a->n_particles <= 16 * (int64_t)fin_wave_cap(fmask);
   if (fused) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cs) != hipSuccess) {
@@ -952,9 +962,9 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
     }
   }
   if (fused) {
-    p.stats_blocks = (int32_t)((items + 3) / 4);
-    const int64_t cap = fin_wave_cap(kmask == glb::kMaskF32);
-    p.fin_waves = (int32_t)(a->n_particles < cap ? a->n_particles : cap);
+    p.stats_blocks = (int32_t)items;
+    const int64_t cap = fin_wave_cap(fmask);
+    p.fin_blocks = (int32_t)(a->n_particles < cap ? a->n_particles : cap);
     const hipError_t e = launch_fused_step(a->dtype, p, kmask, a->rng_mode, scaled, s);
     if (e != hipSuccess) return hip_fail(e, "fused_step launch");
     return GLB_OK;
@@ -965,6 +975,14 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
   e = launch_finish(a->dtype, p, kmask, a->rng_mode, s);
   if (e != hipSuccess) return hip_fail(e, "finish launch");
   return GLB_OK;
+}
+
+int glb_logprob_mask_sample_timed(const glb_step_args *a, void *stream, void *start_event, void *stop_event) {
+  glb::g_step_ev_start = (hipEvent_t)start_event;
+  glb::g_step_ev_stop = (hipEvent_t)stop_event;
+  const int rc = glb_logprob_mask_sample(a, stream);
+  glb::g_step_ev_start = glb::g_step_ev_stop = nullptr;
+  return rc;
 }
 
 int glb_workspace_init(void *workspace, size_t workspace_bytes, void *stream) {

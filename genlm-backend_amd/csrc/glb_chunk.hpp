@@ -38,15 +38,19 @@ enum { kModeStats = 0, kModePhilox = 1, kModeNoise = 2 };
 
 struct ChunkRec {  // one (row|particle, chunk) as the finish role holds it
   float Nc;            // chunk scale exp_n(max); -inf for an empty chunk
+  float Nm;            // scale of the allowed sums - bit masks: Nc, or the allowed maximum's own scale for a low-mass
+                       // chunk; float masks: exp_n(max(x + mask)); no mask: Nc
   uint32_t pA, pB;     // S_c   = (pA << 18) + pB     all elements
-  uint32_t pAm, pBm;   // S_c^m = (pAm << 18) + pBm   allowed elements, on the scale Nm
-  float Nm;            // bit masks: Nc, or the allowed maximum's own scale for a low-mass chunk; float masks:
-                       // exp_n(max(x + mask)); no mask: Nc
+  uint32_t rA[4], rB[4];  // allowed elements on the scale Nm, by 16-lane row g of the wave that held the chunk (lanes
+                          // 16 g .. 16 g + 15: a quarter of the chunk): (rA[g] << 18) + rB[g]; S_c^m = their sum
+  uint32_t pAm, pBm;   // the sums of rA / rB (not stored)
 };
-// In memory a record is 64 bytes: six 8-byte granules {low word = value, high word = the call's epoch} in the order
-// Nc, pA, pB, pAm, pBm, Nm (+ 16 bytes of padding), each written by ONE agent-scope store and valid exactly when
-// its tag equals the epoch of the call - so a reader needs no flag, no fence and no ordering between the granules.
-constexpr int kRecWords = 8;
+// In memory a record is 128 bytes: twelve 8-byte granules {low word = value, high word = the call's epoch} in the
+// order Nc, Nm, pA, pB, rA[0..3], rB[0..3] (+ 32 bytes of padding), each written by ONE agent-scope store and valid
+// exactly when its tag equals the epoch of the call - so a reader needs no flag, no fence and no ordering between the
+// granules.  The row sums cost the reducing wave nothing (its DPP sums pass through them) and let a draw re-reduce a
+// quarter of a chunk instead of all of it.
+constexpr int kRecWords = 16;
 constexpr uint64_t kSpinTicks = 200000000ull;  // finish role gives up after 2 s of s_memrealtime (100 MHz): token -2
 
 struct StepParams {
@@ -71,8 +75,9 @@ struct StepParams {
   float *out_margin;  // parity mode: relative gap between the two largest e_j / E_j of the race
   uint64_t *recs;     // [n_pairs][nch][kRecWords] granules
   uint32_t epoch;     // tag of this call's granules (never 0 on the fused path; 0 = tags are not looked at)
-  int32_t stats_blocks;  // fused launch: blocks [0, stats_blocks) reduce, the rest finish
-  int32_t fin_waves;     // fused launch: finishing waves (wave f takes particles f, f + fin_waves, ...)
+  // fused launch (one-wave workgroups): blocks [0, stats_blocks) reduce one (unit, chunk) each, then fin_blocks
+  // finishing waves (wave f takes particles f, f + fin_blocks, ...)
+  int32_t stats_blocks, fin_blocks;
 };
 
 template <int DT>
@@ -174,34 +179,43 @@ __device__ __forceinline__ void load_chunk(const char *rowp, int e_base, int V, 
   }
 }
 
-// one record out: lanes 0..5 store one granule each (the values are wave-uniform)
-__device__ __forceinline__ void store_rec(uint64_t *dst, uint32_t epoch, int lane, float Nc, uint32_t pA, uint32_t pB,
-                                          uint32_t pAm, uint32_t pBm, float Nm) {
+// one record out: lanes 0..11 store one granule each (the values are wave-uniform)
+__device__ __forceinline__ void store_rec(uint64_t *dst, uint32_t epoch, int lane, float Nc, float Nm, uint32_t pA,
+                                          uint32_t pB, const uint32_t (&rA)[4], const uint32_t (&rB)[4]) {
   uint32_t v = __float_as_uint(Nc);
-  v = lane == 1 ? pA : v;
-  v = lane == 2 ? pB : v;
-  v = lane == 3 ? pAm : v;
-  v = lane == 4 ? pBm : v;
-  v = lane == 5 ? __float_as_uint(Nm) : v;
-  if (lane < 6)
+  v = lane == 1 ? __float_as_uint(Nm) : v;
+  v = lane == 2 ? pA : v;
+  v = lane == 3 ? pB : v;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    v = lane == 4 + g ? rA[g] : v;
+    v = lane == 8 + g ? rB[g] : v;
+  }
+  if (lane < 12)
     __hip_atomic_store(dst + lane, ((uint64_t)epoch << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // one record in; true when every granule carries `epoch`
 __device__ __forceinline__ bool load_rec(const uint64_t *src, uint32_t epoch, ChunkRec &r) {
-  uint64_t g[6];
+  uint64_t g[12];
 #pragma unroll
-  for (int k = 0; k < 6; ++k)
+  for (int k = 0; k < 12; ++k)
     g[k] = __hip_atomic_load(const_cast<uint64_t *>(src) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   bool ok = true;
 #pragma unroll
-  for (int k = 0; k < 6; ++k) ok = ok && (uint32_t)(g[k] >> 32) == epoch;
+  for (int k = 0; k < 12; ++k) ok = ok && (uint32_t)(g[k] >> 32) == epoch;
   r.Nc = __uint_as_float((uint32_t)g[0]);
-  r.pA = (uint32_t)g[1];
-  r.pB = (uint32_t)g[2];
-  r.pAm = (uint32_t)g[3];
-  r.pBm = (uint32_t)g[4];
-  r.Nm = __uint_as_float((uint32_t)g[5]);
+  r.Nm = __uint_as_float((uint32_t)g[1]);
+  r.pA = (uint32_t)g[2];
+  r.pB = (uint32_t)g[3];
+  r.pAm = r.pBm = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    r.rA[k] = (uint32_t)g[4 + k];
+    r.rB[k] = (uint32_t)g[8 + k];
+    r.pAm += r.rA[k];
+    r.pBm += r.rB[k];
+  }
   return ok;
 }
 
@@ -319,12 +333,12 @@ __device__ __forceinline__ float chunk_max(const float (&x)[64]) {
 // about 2^-3.5 of the chunk's largest term, e.g. the one likely token is the forbidden one - the chunk is loaded once
 // more (wave-uniform, rare, L1 / L2 serve it; not keeping x alive for this is what lets the common path run without
 // spills), its forbidden elements overwritten with -inf and the allowed ones summed again on their own maximum's
-// scale.  Out: the four wave totals (uniform) and Nm, the scale of the allowed pair.
+// scale.  Out (wave-uniform): the totals of all elements, the allowed elements' sums by 16-lane row, and their scale Nm.
 template <int DT, bool SCALED>
 __device__ __forceinline__ void chunk_reduce_bits(float (&x)[64], float Nc, int nv_valid, cu64_t mt,
                                                   const MaskAhead &ma, uint64_t allows_any, int lane, const char *rowp,
                                                   int e_base, int V, float scale, uint32_t &pA, uint32_t &pB,
-                                                  uint32_t &pAm, uint32_t &pBm, float &Nm) {
+                                                  uint32_t (&rA)[4], uint32_t (&rB)[4], float &Nm) {
   float P[4], Pm[4];
   class_partials<DT, true>(x, kMagic - Nc, nv_valid, mt, ma, P, Pm);
   uint32_t h, l, hm, lm;
@@ -332,10 +346,10 @@ __device__ __forceinline__ void chunk_reduce_bits(float (&x)[64], float Nc, int 
   lane_payload<4>(Pm, hm, lm);
   pA = last_lane(wave_sum_u32_l63(h));
   pB = last_lane(wave_sum_u32_l63(l));
-  pAm = last_lane(wave_sum_u32_l63(hm));
-  pBm = last_lane(wave_sum_u32_l63(lm));
+  row_sums_u32(hm, rA);
+  row_sums_u32(lm, rB);
   Nm = Nc;
-  const uint64_t Sm = ((uint64_t)pAm << kGridHi) + pBm;
+  const uint64_t Sm = ((uint64_t)(rA[0] + rA[1] + rA[2] + rA[3]) << kGridHi) + (rB[0] + rB[1] + rB[2] + rB[3]);
   uint32_t top = (uint32_t)(Sm >> kLowMassBits), any = (uint32_t)allows_any;
   opaque_u32(top);
   opaque_u32(any);
@@ -348,8 +362,8 @@ __device__ __forceinline__ void chunk_reduce_bits(float (&x)[64], float Nc, int 
     Nm = exp_n(chunk_max(y));
     class_partials<DT, false>(y, kMagic - Nm, nv_valid, nullptr, MaskAhead{}, P, Pm);
     lane_payload<4>(P, hm, lm);
-    pAm = last_lane(wave_sum_u32_l63(hm));
-    pBm = last_lane(wave_sum_u32_l63(lm));
+    row_sums_u32(hm, rA);
+    row_sums_u32(lm, rB);
   }
 }
 
@@ -415,62 +429,6 @@ __device__ __forceinline__ uint64_t chunk_pick_lane(uint32_t inclA, uint32_t inc
   return ((uint64_t)lsel << 56) | Tl;
 }
 
-// class and element.  P[4]: this lane's class partials of the chunk on the scale magicN = kMagic - Nm; (lsel, Tl) from
-// chunk_pick_lane.  Lanes 0..3 pick the class from the chosen lane's four class terms; then lane L = 16 w + pos holds
-// the chosen lane's element (class w, position pos) - fetched with one gathered load (sixteen 16-byte runs a kilobyte
-// apart, lines this wave has just streamed), scaled and masked exactly as the sums took it - and every 16-lane row
-// rebuilds its class's running sum in order (15 dependent DPP adds: after step s the first s + 1 lanes of a row are
-// final).  Returns the element's index in the row, -1 if none (consistent sums rule it out).
-template <int DT, int MASK, class Mid>
-__device__ __forceinline__ int32_t lane_pick_element(const StepParams &p, const char *rowp, int mi, int c,
-                                                     const float (&P)[4], float magicN, int lsel, uint64_t Tl, int lane,
-                                                     Mid &&mid) {
-  constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES;
-  uint64_t qw = 0;
-#pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    uint32_t h, l;
-    partial_q(P[w], h, l);
-    const uint32_t hs = (uint32_t)__builtin_amdgcn_readlane((int)h, lsel), ls = (uint32_t)__builtin_amdgcn_readlane((int)l, lsel);
-    qw = lane == w ? ((uint64_t)hs << kGridHi) + ls : qw;
-  }
-  const int w = lane >> 4, pos = lane & 15;
-  const int iv = (pos / EPV) * 4 + w, k = pos % EPV;  // vector and component of (class w, position pos)
-  const int e = c * kChunk + (iv * 64 + lsel) * EPV + k;
-  float y = kNegInf;
-  if (e < p.V) {
-    if constexpr (DT == kDtF32) {
-      y = *reinterpret_cast<const float *>(rowp + (int64_t)e * ES);
-    } else {
-      const uint32_t hb = *reinterpret_cast<const uint16_t *>(rowp + (int64_t)e * ES);
-      if constexpr (DT == kDtBf16) y = __uint_as_float(hb << 16);
-      else y = (float)__builtin_bit_cast(_Float16, (uint16_t)hb);
-    }
-    y = y * p.scale;
-    if constexpr (MASK == kMaskBits) {
-      if (!((p.mask_t[((int64_t)mi * p.nch + c) * 64 + iv * EPV + k] >> lsel) & 1ull)) y = kNegInf;
-    } else if constexpr (MASK == kMaskF32) {
-      y = y + p.mask_f[(int64_t)mi * p.mask_ld + e];
-    }
-  }
-  mid();  // (the caller's logarithms: work for the time the gathered load is in flight)
-  const uint64_t inclw = wave_scan_u64(qw);  // lanes 0..3: inclusive sums of the class terms; later lanes: the total
-  const int wsel = first_lane_above(inclw, Tl);
-  if (wsel < 0 || wsel > 3) return -1;
-  const uint64_t before = readlane_u64(inclw, wsel > 0 ? wsel - 1 : 0);
-  const uint64_t Tw = Tl - (wsel > 0 ? before : 0ull);
-  const float t = chunk_term(y, magicN);
-  float cs = t;
-#pragma unroll
-  for (int s2 = 1; s2 < 16; ++s2) cs = __uint_as_float(dpp_u32<0x111, 0xf>(0u, __float_as_uint(cs))) + t;
-  uint32_t h, l;
-  partial_q(cs, h, l);
-  const uint64_t qc = w == wsel ? ((uint64_t)h << kGridHi) + l : 0ull;
-  const int Lsel = first_lane_above(qc, Tw);
-  if (Lsel < 0) return -1;
-  return __builtin_amdgcn_readlane(e, Lsel);
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // stats role: one wave per (reduction unit, chunk)
 // ---------------------------------------------------------------------------------------------------------
@@ -478,6 +436,9 @@ template <int DT, int MASK, bool SCALED>
 __device__ __forceinline__ void stats_item(const StepParams &p, int item, int lane) {
   constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC;
   const int nch = p.nch;
+#ifdef GLB_STAMPS  // diagnostic build (tools/dbg/stamps.py): wave start / end times in the record's padding
+  const uint64_t stamp0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int pr = item / nch, c = item - pr * nch;  // (dealt row-interleaved instead, the launch is 2.5 us slower)
   const int row = p.pair_row ? as_const(p.pair_row)[pr] : pr;
   const char *rowp = (const char *)p.logits + (int64_t)row * p.ld * ES;
@@ -498,17 +459,19 @@ __device__ __forceinline__ void stats_item(const StepParams &p, int item, int la
   float x[64];
   load_chunk<DT, SCALED>(rowp, e_base, V, lane, p.scale, x);
   const float Nc = exp_n(chunk_max(x));
-  uint32_t pA, pB, pAm, pBm;
+  uint32_t pA, pB, rA[4], rB[4];
   float Nm = Nc;
   if constexpr (MASK == kMaskBits) {
-    chunk_reduce_bits<DT, SCALED>(x, Nc, nv_valid, mt, ma, allows_any, lane, rowp, e_base, V, p.scale, pA, pB, pAm, pBm, Nm);
+    chunk_reduce_bits<DT, SCALED>(x, Nc, nv_valid, mt, ma, allows_any, lane, rowp, e_base, V, p.scale, pA, pB, rA, rB, Nm);
   } else {
     float P[4], Pm[4];
     uint32_t h, l;
     class_partials<DT, false>(x, kMagic - Nc, nv_valid, nullptr, ma, P, Pm);
     lane_payload<4>(P, h, l);
-    pA = pAm = last_lane(wave_sum_u32_l63(h));
-    pB = pBm = last_lane(wave_sum_u32_l63(l));
+    row_sums_u32(h, rA);
+    row_sums_u32(l, rB);
+    pA = rA[0] + rA[1] + rA[2] + rA[3];
+    pB = rB[0] + rB[1] + rB[2] + rB[3];
     if constexpr (MASK == kMaskF32) {  // general additive masks: y = x + m has its own maximum, scale and exp
       const char *mrow = (const char *)(p.mask_f + (int64_t)mi * p.mask_ld);
       float y[64];
@@ -516,43 +479,40 @@ __device__ __forceinline__ void stats_item(const StepParams &p, int item, int la
       Nm = exp_n(chunk_max(y));
       class_partials<DT, false>(y, kMagic - Nm, nv_valid, nullptr, ma, P, Pm);
       lane_payload<4>(P, h, l);
-      pAm = last_lane(wave_sum_u32_l63(h));
-      pBm = last_lane(wave_sum_u32_l63(l));
+      row_sums_u32(h, rA);
+      row_sums_u32(l, rB);
     }
   }
-  store_rec(p.recs + ((int64_t)pr * nch + c) * kRecWords, p.epoch, lane, Nc, pA, pB, pAm, pBm, Nm);
-}
-
-// float masks hold x[64] and y[64]: three waves per SIMD leave them the registers (five spill 61 of them)
-template <int MASK>
-struct StatsWaves {
-  static constexpr int value = MASK == kMaskF32 ? 3 : 4;
-};
-
-template <int DT, int MASK, bool SCALED>
-__global__ __launch_bounds__(256, StatsWaves<MASK>::value) void chunk_stats_kernel(const StepParams p) {
-  const int lane = threadIdx.x & 63;
-  const int item = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
-  if (item >= p.n_pairs * p.nch) return;  // whole waves only
-  stats_item<DT, MASK, SCALED>(p, item, lane);
+  store_rec(p.recs + ((int64_t)pr * nch + c) * kRecWords, p.epoch, lane, Nc, Nm, pA, pB, rA, rB);
+#ifdef GLB_STAMPS
+  if (lane == 0) {
+    uint64_t *r = p.recs + ((int64_t)pr * nch + c) * kRecWords;
+    r[12] = stamp0;
+    r[13] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// chunk statistics for launches that cannot fill the chip (a single shared row at SIS step 0, a lone API query):
-// one WORKGROUP of four waves per (unit, chunk); wave w takes vectors w, w+4, ... of the chunk - exactly class w of
-// every lane - the chunk maximum and the four payload sums are combined through LDS.  Same records as the one-wave
-// form by construction: the (lane, class) partials are the same sums in the same order, only held by another wave.  A
-// wave alone on its SIMD issues one instruction every ~5 cycles, so a quarter of the elements per wave is what shortens
-// the launch.  Bit masks / no mask only (float masks use the one-wave kernel).
+// stats role in quarters, for launches that cannot fill the chip (a single shared row at SIS step 0, a lone API
+// query): one WORKGROUP of four waves per (unit, chunk); wave w takes vectors w, w+4, ... of the chunk - exactly class w
+// of every lane - the chunk maximum and the payload sums are combined through LDS.  Same records as the one-wave form by
+// construction: the (lane, class) partials are the same sums in the same order, only held by another wave.  A wave
+// alone on its SIMD issues one instruction every ~5 cycles, so a quarter of the elements per wave is what shortens the
+// launch.  (As the tail of a big launch the quarters gain nothing: tools/dbg/stamps.py)  Bit masks / no
+// mask only (float masks use the one-wave form).
 // ---------------------------------------------------------------------------------------------------------
 template <int DT, int MASK, bool SCALED>
 __global__ __launch_bounds__(256) void chunk_stats_small_kernel(const StepParams p) {
   constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC, NVW = NVC / 4;
-  static_assert(MASK != kMaskF32, "float masks take the one-wave-per-chunk kernel");
+  static_assert(MASK != kMaskF32, "float masks take the one-wave-per-chunk form");
   __shared__ float s_max[4];
-  __shared__ uint32_t s_pay[4][4];
+  __shared__ uint32_t s_pay[4][10];  // per wave: pA, pB, rA[4], rB[4]
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int item = blockIdx.x, nch = p.nch;
+#ifdef GLB_STAMPS
+  const uint64_t stamp0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int pr = item / nch, c = item - pr * nch;
   const int row = p.pair_row ? as_const(p.pair_row)[pr] : pr;
   const char *rowp = (const char *)p.logits + (int64_t)row * p.ld * ES;
@@ -596,21 +556,28 @@ __global__ __launch_bounds__(256) void chunk_stats_small_kernel(const StepParams
     hm = h;
     lm = l;
   }
-  const uint32_t wA = wave_sum_u32_l63(h), wB = wave_sum_u32_l63(l), wAm = wave_sum_u32_l63(hm), wBm = wave_sum_u32_l63(lm);
-  if (lane == 63) {
-    s_pay[wave][0] = wA;
-    s_pay[wave][1] = wB;
-    s_pay[wave][2] = wAm;
-    s_pay[wave][3] = wBm;
+  uint32_t rA[4], rB[4];
+  {
+    const uint32_t wA = wave_sum_u32_l63(h), wB = wave_sum_u32_l63(l);
+    row_sums_u32(hm, rA);
+    row_sums_u32(lm, rB);
+    if (lane == 63) {
+      s_pay[wave][0] = wA;
+      s_pay[wave][1] = wB;
+    }
+    if (lane < 4) {
+      s_pay[wave][2 + lane] = lane == 0 ? rA[0] : lane == 1 ? rA[1] : lane == 2 ? rA[2] : rA[3];
+      s_pay[wave][6 + lane] = lane == 0 ? rB[0] : lane == 1 ? rB[1] : lane == 2 ? rB[2] : rB[3];
+    }
   }
   __syncthreads();
-  uint32_t t[4];
+  uint32_t t[10];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) t[k] = s_pay[0][k] + s_pay[1][k] + s_pay[2][k] + s_pay[3][k];
+  for (int k = 0; k < 10; ++k) t[k] = s_pay[0][k] + s_pay[1][k] + s_pay[2][k] + s_pay[3][k];
   float Nm = Nc;
   if constexpr (MASK == kMaskBits) {
     // the low-mass rule of chunk_reduce_bits, with the chunk spread over four waves (workgroup-uniform branch)
-    const uint64_t Sm = ((uint64_t)t[2] << kGridHi) + t[3];
+    const uint64_t Sm = ((uint64_t)(t[2] + t[3] + t[4] + t[5]) << kGridHi) + (t[6] + t[7] + t[8] + t[9]);
     const int mi = p.pair_mask ? as_const(p.pair_mask)[pr] : (p.n_masks == 1 ? 0 : pr);
     uint32_t top = (uint32_t)(Sm >> kLowMassBits), any = (uint32_t)as_const(p.mask_any)[(int64_t)mi * nch + c];
     opaque_u32(top);
@@ -638,17 +605,28 @@ __global__ __launch_bounds__(256) void chunk_stats_small_kernel(const StepParams
       Nm = exp_n(fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3])));
       class_partials<DT, false, 4>(x, kMagic - Nm, nv_valid, nullptr, MaskAhead{}, P, Pm, wave);
       lane_payload<1>(P, hm, lm);
-      const uint32_t qa = wave_sum_u32_l63(hm), qb = wave_sum_u32_l63(lm);
-      if (lane == 63) {
-        s_pay[wave][2] = qa;
-        s_pay[wave][3] = qb;
+      row_sums_u32(hm, rA);
+      row_sums_u32(lm, rB);
+      if (lane < 4) {
+        s_pay[wave][2 + lane] = lane == 0 ? rA[0] : lane == 1 ? rA[1] : lane == 2 ? rA[2] : rA[3];
+        s_pay[wave][6 + lane] = lane == 0 ? rB[0] : lane == 1 ? rB[1] : lane == 2 ? rB[2] : rB[3];
       }
       __syncthreads();
-      t[2] = s_pay[0][2] + s_pay[1][2] + s_pay[2][2] + s_pay[3][2];
-      t[3] = s_pay[0][3] + s_pay[1][3] + s_pay[2][3] + s_pay[3][3];
+#pragma unroll
+      for (int k = 2; k < 10; ++k) t[k] = s_pay[0][k] + s_pay[1][k] + s_pay[2][k] + s_pay[3][k];
     }
   }
-  if (wave == 0) store_rec(p.recs + ((int64_t)pr * nch + c) * kRecWords, p.epoch, lane, Nc, t[0], t[1], t[2], t[3], Nm);
+  if (wave == 0) {
+    const uint32_t qa[4] = {t[2], t[3], t[4], t[5]}, qb[4] = {t[6], t[7], t[8], t[9]};
+    store_rec(p.recs + ((int64_t)pr * nch + c) * kRecWords, p.epoch, lane, Nc, Nm, t[0], t[1], qa, qb);
+  }
+#ifdef GLB_STAMPS
+  if (wave == 0 && lane == 0) {
+    uint64_t *r = p.recs + ((int64_t)pr * nch + c) * kRecWords;
+    r[12] = stamp0;
+    r[13] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -720,14 +698,14 @@ struct Recs {
 template <bool POLL>
 __device__ __forceinline__ bool recs_acquire(Recs &R, int nch, int lane) {
   R.cached = nch <= 64;
-  R.mine = ChunkRec{kNegInf, 0u, 0u, 0u, 0u, kNegInf};
+  R.mine = ChunkRec{kNegInf, kNegInf, 0u, 0u, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, 0u, 0u};
   uint64_t t0 = 0;
   if constexpr (POLL) t0 = __builtin_amdgcn_s_memrealtime();
   for (int c0 = 0; c0 < nch; c0 += 64) {
     const int c = c0 + lane;
     for (;;) {
       bool ok = true;
-      ChunkRec r{kNegInf, 0u, 0u, 0u, 0u, kNegInf};
+      ChunkRec r = ChunkRec{kNegInf, kNegInf, 0u, 0u, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, 0u, 0u};
       if (c < nch) ok = load_rec(R.base + (int64_t)c * kRecWords, R.epoch, r);
       if (c0 == 0) R.mine = r;
       if constexpr (!POLL) break;
@@ -794,28 +772,26 @@ __device__ __forceinline__ void pair_logs(const PairState &st, float &lse, float
 
 // first stage of the Philox draw of particle pidx: the chunk, by a scan of the shifted chunk sums (first word)
 struct ChunkPick {
-  int csel;       // -1: nothing to draw from
-  float Nms;      // the scale the chosen chunk's allowed terms sit on
-  uint64_t R2;    // second Philox word
+  int csel;        // -1: nothing to draw from
+  float Nms;       // the scale the chosen chunk's allowed terms sit on
+  uint64_t R2;     // second Philox word
+  uint64_t qg[4];  // the chosen chunk's allowed sums by 16-lane row
 };
 
-__device__ __forceinline__ ChunkPick pair_pick_chunk(const StepParams &p, const Recs &recs, const PairState &st, int pidx,
+__device__ __forceinline__ ChunkPick pair_pick_chunk(const Recs &recs, const PairState &st, uint64_t R1, uint64_t R2,
                                                      int nch, int lane) {
-  ChunkPick k{-1, 0.f, 0ull};
+  ChunkPick k{-1, 0.f, R2, {0ull, 0ull, 0ull, 0ull}};
   uint32_t nz = (uint32_t)st.S_msk | (uint32_t)(st.S_msk >> 32);
   opaque_u32(nz);
   if (nz == 0u) return k;
-  uint64_t R1;
-  philox_pair(p, pidx, R1, k.R2);
   uint64_t T = __umul64hi(R1, st.S_msk);  // uniform integer in [0, S_msk)
   for (int c0 = 0; c0 < nch && k.csel < 0; c0 += 64) {
     const int c = c0 + lane;
     uint64_t sm = 0;
-    float Nm = kNegInf;
+    ChunkRec r{kNegInf, kNegInf, 0u, 0u, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, 0u, 0u};
     if (c < nch) {
-      const ChunkRec r = recs.get(c);
+      r = recs.get(c);
       const uint64_t m = ((uint64_t)r.pAm << kGridHi) + r.pBm;
-      Nm = r.Nm;
       if (m) {
         const float d = st.N_msk - r.Nm;
         if (d < 64.0f) sm = m >> (uint32_t)d;
@@ -825,7 +801,11 @@ __device__ __forceinline__ ChunkPick pair_pick_chunk(const StepParams &p, const 
     const int lsel = first_lane_above(incl, T);
     if (lsel >= 0) {
       k.csel = c0 + lsel;
-      k.Nms = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(Nm), lsel));
+      k.Nms = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(r.Nm), lsel));
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        k.qg[g] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)r.rA[g], lsel) << kGridHi) +
+                  (uint32_t)__builtin_amdgcn_readlane((int)r.rB[g], lsel);
     } else {
       T -= readlane_u64(incl, 63);
     }
@@ -833,59 +813,52 @@ __device__ __forceinline__ ChunkPick pair_pick_chunk(const StepParams &p, const 
   return k;
 }
 
-// second stage: the chosen chunk once more, exactly as the stats role summed its allowed part - same loads, same
-// terms, same (lane, class) order, on the scale the record names (for a chunk that was redone on its allowed
-// maximum's scale the forbidden terms may overflow to +inf in the unmasked partials, which nobody reads) - then lane,
-// class and element from the second word.  mid(): see lane_pick_element.
-template <int DT, int MASK, class Mid>
-__device__ __forceinline__ int32_t pair_pick_token(const StepParams &p, const char *rowp, int mi, const ChunkPick &k,
-                                                   int lane, Mid &&mid) {
-  constexpr int EPV = ElemTraits<DT>::EPV, NVC = ElemTraits<DT>::NVC;
-  const int V = p.V, c = __builtin_amdgcn_readfirstlane(k.csel), e_base = c * kChunk;  // (uniform, and provably so:
-  mi = __builtin_amdgcn_readfirstlane(mi);                                               //  the mask words go to SGPRs)
-  int nv_valid = (V - e_base + 64 * EPV - 1) / (64 * EPV);
-  nv_valid = nv_valid < NVC ? nv_valid : NVC;
-  const float magicN = kMagic - k.Nms;
-  float P[4], Pm[4];
-  if constexpr (MASK == kMaskBits) {
-    const cu64_t mt = as_const(p.mask_t + ((int64_t)mi * p.nch + c) * 64);
-    MaskAhead ma;
-    mask_ahead<DT>(mt, ma);
-    float x[64];
-    load_chunk<DT, true>(rowp, e_base, V, lane, p.scale, x);  // (x * 1.0f == x: the scaled form serves every call)
-    class_partials<DT, true>(x, magicN, nv_valid, mt, ma, Pm, P);  // P: the allowed elements' partials
-  } else {
-    float y[64];
-    load_chunk<DT, true>(rowp, e_base, V, lane, p.scale, y);
-    if constexpr (MASK == kMaskF32) {
-      float x[64];
-#pragma unroll
-      for (int j = 0; j < 64; ++j) x[j] = y[j];
-      add_float_mask<DT>(x, (const char *)(p.mask_f + (int64_t)mi * p.mask_ld), e_base, V, lane, y);
-    }
-    class_partials<DT, false>(y, magicN, nv_valid, nullptr, MaskAhead{}, P, Pm);
+// ---------------------------------------------------------------------------------------------------------
+// finish role, statistics mode (no draw): one wave per particle
+// ---------------------------------------------------------------------------------------------------------
+template <int MASK, bool POLL>
+__device__ __forceinline__ void finish_stats(const StepParams &p, int pidx, int lane) {
+  const int nch = p.nch;
+  const int pr = p.pair_of ? as_const(p.pair_of)[pidx] : pidx;
+  Recs recs;
+  recs.base = p.recs + (int64_t)pr * nch * kRecWords;
+  recs.epoch = p.epoch;
+  float lse = __uint_as_float(0x7fc00000u), logZ = lse;  // (a wave that gave up waiting: NaN, never in a healthy launch)
+  if (recs_acquire<POLL>(recs, nch, lane)) {
+    PairState st;
+    pair_fold<MASK>(recs, nch, lane, st);
+    if (lane == 0) pair_logs(st, lse, logZ);
   }
-  uint32_t h, l;
-  lane_payload<4>(P, h, l);
-  const uint64_t pick = chunk_pick_lane(wave_sum_u32_l63(h), wave_sum_u32_l63(l), k.R2);
-  if (pick == ~0ull) {
-    mid();
-    return -1;
+  if (lane == 0) {
+    if (p.out_lse) p.out_lse[pidx] = lse;
+    if (p.out_logZ) p.out_logZ[pidx] = logZ;
   }
-  const int lsel = __builtin_amdgcn_readfirstlane((int)(pick >> 56));
-  return lane_pick_element<DT, MASK>(p, rowp, mi, c, P, magicN, lsel, pick & ((1ull << 56) - 1ull), lane, mid);
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// finish role, statistics and Philox modes: one wave per particle
+// finish role with a Philox draw: one wave per particle.  Sweeps the records of the particle's row until they are
+// complete (POLL), folds them, draws the chunk with the first Philox word and, with the second, walks down the chunk's
+// summation tree: 16-lane row (the record carries the four row sums), lane, class, element.  Only the chosen ROW is
+// reduced again - a quarter of the chunk, 4 KiB that L2 / Infinity Cache still hold: finishing lane L = 16 w + l takes
+// class w of the row's lane l (its 16 elements, in the order the stats wave added them), so every (lane, class) partial
+// is rebuilt bit for bit by one lane, the four classes of a lane are added with two lane exchanges, and the chosen
+// (lane, class)'s running sum is rebuilt in order by 15 dependent DPP adds.
+// Nothing per particle is ever written by the stats role: round 2 left 512 bytes of lane scans per chunk for this
+// step - 2 us of a read-bound launch.
 // ---------------------------------------------------------------------------------------------------------
-template <int DT, int MASK, int MODE, bool POLL>
-__device__ __forceinline__ void finish_particle(const StepParams &p, int pidx, int lane) {
-  constexpr int ES = ElemTraits<DT>::ES;
-  const int nch = p.nch;
+template <int DT, int MASK, bool POLL>
+__device__ __forceinline__ void finish_draw(const StepParams &p, int pidx, int lane) {
+  constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC, NVW = NVC / 4;
+  const int nch = p.nch, V = p.V;
   const int pr = p.pair_of ? as_const(p.pair_of)[pidx] : pidx;
   const int row = p.pair_row ? as_const(p.pair_row)[pr] : pr;
   const int mi = MASK == kMaskNone ? 0 : (p.pair_mask ? as_const(p.pair_mask)[pr] : (p.n_masks == 1 ? 0 : pr));
+#ifdef GLB_STAMPS  // diagnostic build: [start, records complete, token written] of every particle through out_margin
+  uint64_t *stamps = p.out_margin ? reinterpret_cast<uint64_t *>(p.out_margin) + (int64_t)pidx * 4 : nullptr;
+  if (stamps && lane == 0) stamps[0] = __builtin_amdgcn_s_memrealtime();
+#endif
+  uint64_t R1, R2;
+  philox_pair(p, pidx, R1, R2);  // (before the wait: the draws need nothing from the records)
   Recs recs;
   recs.base = p.recs + (int64_t)pr * nch * kRecWords;
   recs.epoch = p.epoch;
@@ -894,60 +867,162 @@ __device__ __forceinline__ void finish_particle(const StepParams &p, int pidx, i
       const float nan = __uint_as_float(0x7fc00000u);
       if (p.out_lse) p.out_lse[pidx] = nan;
       if (p.out_logZ) p.out_logZ[pidx] = nan;
-      if (p.out_token) p.out_token[pidx] = -2;
+      p.out_token[pidx] = -2;
     }
     return;
   }
+#ifdef GLB_STAMPS
+  if (stamps && lane == 0) stamps[1] = __builtin_amdgcn_s_memrealtime();
+#endif
   PairState st;
   pair_fold<MASK>(recs, nch, lane, st);
-  auto logs = [&]() {
-    if (lane == 0) {
+  const ChunkPick pick = pair_pick_chunk(recs, st, R1, R2, nch, lane);
+  int32_t tok = -1;
+  if (pick.csel >= 0) {
+    // ---- the row: lanes 0..3 hold the four row sums
+    const uint64_t qg = lane == 0 ? pick.qg[0] : lane == 1 ? pick.qg[1] : lane == 2 ? pick.qg[2] : lane == 3 ? pick.qg[3] : 0ull;
+    const uint64_t inclg = wave_scan_u64(qg);
+    const uint64_t Sc = readlane_u64(inclg, 63);
+    const uint64_t T2 = __umul64hi(pick.R2, Sc);  // uniform integer in [0, S_c)
+    const int gsel = first_lane_above(inclg, T2);  // 0..3 (S_c > 0: the chunk was drawn)
+    const uint64_t Tg = T2 - (gsel > 0 ? readlane_u64(inclg, gsel > 0 ? gsel - 1 : 0) : 0ull);
+    // ---- this lane's (row lane, class): 16 elements
+    const int c = pick.csel, e_base = c * kChunk;
+    const int w = lane >> 4, sl = 16 * gsel + (lane & 15);  // class, lane of the stats wave
+    const char *rowp = (const char *)p.logits + (int64_t)row * p.ld * ES;
+    const float magicN = kMagic - pick.Nms;
+    float y[16];
+#pragma unroll
+    for (int j = 0; j < NVW; ++j) {
+      const int iv = w + 4 * j;
+      const int e0 = e_base + (iv * 64 + sl) * EPV;
+      const u32x4_t r = load_vec_guarded<DT>(rowp, e0 < V ? e0 : V, V);
+      unpack_vec<DT>(r, &y[j * EPV]);
+#pragma unroll
+      for (int k = 0; k < EPV; ++k) y[j * EPV + k] *= p.scale;  // (x * 1.0f == x: the scaled form serves every call)
+      if constexpr (MASK == kMaskBits) {
+        const uint64_t *mw = p.mask_t + ((int64_t)mi * nch + c) * 64 + iv * EPV;
+#pragma unroll
+        for (int k = 0; k < EPV; ++k)
+          if (!((mw[k] >> sl) & 1ull)) y[j * EPV + k] = kNegInf;
+      } else if constexpr (MASK == kMaskF32) {
+        const char *mrow = (const char *)(p.mask_f + (int64_t)mi * p.mask_ld);
+#pragma unroll
+        for (int h = 0; h < EPV / 4; ++h) {
+          const int eh = e0 + 4 * h;
+          const u32x4_t mr = load_vec_guarded<kDtF32>(mrow, eh < V ? eh : V, V);
+          float mk[4];
+          unpack_vec<kDtF32>(mr, mk);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) y[j * EPV + 4 * h + k] = y[j * EPV + 4 * h + k] + mk[k];
+        }
+      }
+    }
+    if (lane == 0) {  // the logarithms: one lane's work for the time the loads are in flight
       float lse, logZ;
       pair_logs(st, lse, logZ);
       if (p.out_lse) p.out_lse[pidx] = lse;
       if (p.out_logZ) p.out_logZ[pidx] = logZ;
     }
-  };
-  if constexpr (MODE == kModePhilox) {
-    if (p.out_token) {
-      const ChunkPick pick = pair_pick_chunk(p, recs, st, pidx, nch, lane);
-      int32_t tok = -1;
-      if (pick.csel >= 0) {
-        const char *rowp = (const char *)p.logits + (int64_t)row * p.ld * ES;
-        tok = pair_pick_token<DT, MASK>(p, rowp, mi, pick, lane, logs);  // (calls logs() once, on every path)
-      } else {
-        logs();
-      }
-      if (lane == 0) p.out_token[pidx] = tok;
-      return;
+    float t[16], P = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      t[j] = chunk_term(y[j], magicN);
+      P = P + t[j];
     }
+    uint32_t h, l;
+    partial_q(P, h, l);
+    const uint64_t qown = ((uint64_t)h << kGridHi) + l;  // q of (row lane lane & 15, class w)
+    // ---- the lane of the row: lanes 0..15 get the sum over the four classes
+    uint32_t hs = h + (uint32_t)__shfl_xor((int)h, 16, 64), ls = l + (uint32_t)__shfl_xor((int)l, 16, 64);
+    hs += (uint32_t)__shfl_xor((int)hs, 32, 64);
+    ls += (uint32_t)__shfl_xor((int)ls, 32, 64);
+    const uint64_t ql = lane < 16 ? ((uint64_t)hs << kGridHi) + ls : 0ull;
+    const uint64_t incll = wave_scan_u64(ql);
+    const int lsel = first_lane_above(incll, Tg);
+    if (lsel >= 0 && lsel < 16) {
+      const uint64_t Tl = Tg - (lsel > 0 ? readlane_u64(incll, lsel > 0 ? lsel - 1 : 0) : 0ull);
+      // ---- the class: lanes 0..3 get the four class terms of row lane lsel
+      uint64_t qw = 0;
+#pragma unroll
+      for (int ww = 0; ww < 4; ++ww) {
+        const uint64_t q = readlane_u64(qown, lsel + 16 * ww);
+        qw = lane == ww ? q : qw;
+      }
+      const uint64_t inclw = wave_scan_u64(qw);
+      const int wsel = first_lane_above(inclw, Tl);
+      if (wsel >= 0 && wsel < 4) {
+        const uint64_t Tw = Tl - (wsel > 0 ? readlane_u64(inclw, wsel > 0 ? wsel - 1 : 0) : 0ull);
+        // ---- the element: lane pos < 16 gets term pos of finishing lane 16 wsel + lsel, then the running sum in order
+        const int Lsel = 16 * wsel + lsel;
+        float tv = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const float tj = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(t[j]), Lsel));
+          tv = (lane & 15) == j ? tj : tv;
+        }
+        float cs = tv;
+#pragma unroll
+        for (int s2 = 1; s2 < 16; ++s2) cs = __uint_as_float(dpp_u32<0x111, 0xf>(0u, __float_as_uint(cs))) + tv;
+        uint32_t hc, lc;
+        partial_q(cs, hc, lc);
+        const uint64_t qc = lane < 16 ? ((uint64_t)hc << kGridHi) + lc : 0ull;
+        const int psel = first_lane_above(qc, Tw);
+        if (psel >= 0) tok = e_base + ((wsel + 4 * (psel / EPV)) * 64 + 16 * gsel + lsel) * EPV + (psel % EPV);
+      }
+    }
+  } else if (lane == 0) {
+    float lse, logZ;
+    pair_logs(st, lse, logZ);
+    if (p.out_lse) p.out_lse[pidx] = lse;
+    if (p.out_logZ) p.out_logZ[pidx] = logZ;
   }
-  logs();
+  if (lane == 0) p.out_token[pidx] = tok;
+#ifdef GLB_STAMPS
+  if (stamps && lane == 0) stamps[2] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// The step in ONE launch: blocks [0, stats_blocks) are four stats waves each, the blocks behind them four finishing
-// waves each.  Workgroups are dispatched in index order, so finishing waves become resident when the last stats
-// waves have been placed; correctness needs no such order: a finishing wave only waits for stats waves, which wait for
-// nobody, and fin_waves is capped well below the chip's wave slots (glb_api.hip), so finishing waves can never keep a
-// stats wave from getting one.  Every wait is bounded (kSpinTicks).
+// The step in ONE launch of one-wave workgroups: blocks [0, stats_blocks) are stats waves, the blocks behind them
+// finishing waves.  (One wave per workgroup: a four-wave workgroup gives its slots back only when its slowest wave is
+// done - measured, 3 us of the fp32 launch and 5 us of the bf16 one.)  Workgroups are dispatched in index order, so
+// finishing waves become resident when the last stats waves have been placed; correctness needs no such order: a
+// finishing wave only waits for stats waves, which wait for nobody, and there are never more finishing waves than half
+// the chip's wave slots (glb_api.hip), so they cannot keep a stats wave from getting one.  Every wait is bounded
+// (kSpinTicks).
 // ---------------------------------------------------------------------------------------------------------
+// waves per SIMD the kernels are compiled for.  Float masks hold x[64] and y[64] in the stats role: three leave them
+// the registers.  16-bit rows are bound by VALU issue and gain from a fifth wave (96 registers fit without spills);
+// fp32 rows spill at five and stream as fast with four.
+template <int DT, int MASK>
+struct StatsWaves {
+  static constexpr int value = MASK == kMaskF32 ? 3 : (DT == kDtF32 ? 4 : 5);
+};
+
 template <int DT, int MASK, bool SCALED, int MODE>
-__global__ __launch_bounds__(256, StatsWaves<MASK>::value) void fused_step_kernel(const StepParams p) {
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+__global__ __launch_bounds__(64, (StatsWaves<DT, MASK>::value)) void fused_step_kernel(const StepParams p) {
+  const int lane = threadIdx.x;
   const int blk = blockIdx.x;
   if (blk < p.stats_blocks) {
-    const int item = blk * 4 + wave;
-    if (item < p.n_pairs * p.nch) stats_item<DT, MASK, SCALED>(p, item, lane);
+    stats_item<DT, MASK, SCALED>(p, blk, lane);
     return;
   }
-  for (int pidx = (blk - p.stats_blocks) * 4 + wave; pidx < p.n_particles; pidx += p.fin_waves)
-    finish_particle<DT, MASK, MODE, true>(p, pidx, lane);
+  for (int pidx = blk - p.stats_blocks; pidx < p.n_particles; pidx += p.fin_blocks) {
+    if constexpr (MODE == kModePhilox) finish_draw<DT, MASK, true>(p, pidx, lane);
+    else finish_stats<MASK, true>(p, pidx, lane);
+  }
+}
+
+template <int DT, int MASK, bool SCALED>
+__global__ __launch_bounds__(64, (StatsWaves<DT, MASK>::value)) void chunk_stats_kernel(const StepParams p) {
+  stats_item<DT, MASK, SCALED>(p, blockIdx.x, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// finish as a launch of its own: one workgroup per particle - a single wave for the statistics / Philox modes
-// (launched with 64 threads), four waves for parity mode, which deals the row's vectors to all of them.
+// finish as a launch of its own (records of an earlier launch, tags not looked at): one workgroup per particle - one
+// wave for the statistics / Philox modes (launched with 64 threads), four for parity mode, which deals the row's vectors
+// to all of them.
 // ---------------------------------------------------------------------------------------------------------
 template <int DT, int MASK, int MODE>
 __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
@@ -956,8 +1031,15 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
   __shared__ int32_t s_bestj[4];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int pidx = blockIdx.x;
-  if constexpr (MODE != kModeNoise) {
-    if (wave == 0) finish_particle<DT, MASK, MODE, false>(p, pidx, lane);
+  if constexpr (MODE == kModeStats) {
+    if (wave == 0) finish_stats<MASK, false>(p, pidx, lane);
+    return;
+  }
+  if constexpr (MODE == kModePhilox) {
+    if (wave == 0) {
+      if (p.out_token) finish_draw<DT, MASK, false>(p, pidx, lane);
+      else finish_stats<MASK, false>(p, pidx, lane);
+    }
     return;
   }
   const int nch = p.nch, V = p.V;

@@ -1,5 +1,7 @@
 // glb_chunk_tu.hip — one translation unit per element type (-DGLB_DT=<0|1|2>): instantiates the chunked step
 // kernels for every mask kind / draw mode and exports the launchers glb_api.hip dispatches to.
+#include <hip/hip_ext.h>
+
 #include "glb_chunk.hpp"
 
 #ifndef GLB_DT
@@ -11,6 +13,17 @@ namespace glb {
 #define GLB_CAT_(a, b) a##b
 #define GLB_CAT(a, b) GLB_CAT_(a, b)
 
+// glb_logprob_mask_sample_timed (glb_api.hip): HIP events that the step's first / last launch carries as its own start /
+// stop time stamps (hipExtLaunchKernel) - the launch duration as the profiler sees it, without marker packets
+extern thread_local hipEvent_t g_step_ev_start, g_step_ev_stop;
+
+template <class K>
+static void launch_k(K kernel, dim3 grid, dim3 block, hipStream_t s, const StepParams &p, bool first, bool last) {
+  hipEvent_t e0 = first ? g_step_ev_start : nullptr, e1 = last ? g_step_ev_stop : nullptr;
+  if (e0 || e1) hipExtLaunchKernelGGL(kernel, grid, block, 0, s, e0, e1, 0, p);
+  else hipLaunchKernelGGL(kernel, grid, block, 0, s, p);
+}
+
 // launches with fewer items than this use four waves per chunk (the chip has 1024 SIMDs; below about one wave per
 // two SIMDs the per-wave latency is the launch time)
 constexpr int64_t kSmallLaunchItems = 512;
@@ -21,14 +34,14 @@ static hipError_t stats1(const StepParams &p, bool scaled, hipStream_t s) {
   if constexpr (MASK != kMaskF32) {
     if (waves <= kSmallLaunchItems) {
       const dim3 grid((unsigned)waves), block(256);
-      if (scaled) hipLaunchKernelGGL((chunk_stats_small_kernel<GLB_DT, MASK, true>), grid, block, 0, s, p);
-      else hipLaunchKernelGGL((chunk_stats_small_kernel<GLB_DT, MASK, false>), grid, block, 0, s, p);
+      if (scaled) launch_k(chunk_stats_small_kernel<GLB_DT, MASK, true>, grid, block, s, p, true, false);
+      else launch_k(chunk_stats_small_kernel<GLB_DT, MASK, false>, grid, block, s, p, true, false);
       return hipGetLastError();
     }
   }
-  const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
-  if (scaled) hipLaunchKernelGGL((chunk_stats_kernel<GLB_DT, MASK, true>), grid, block, 0, s, p);
-  else hipLaunchKernelGGL((chunk_stats_kernel<GLB_DT, MASK, false>), grid, block, 0, s, p);
+  const dim3 grid((unsigned)waves), block(64);  // one-wave workgroups: every wave slot refills on its own
+  if (scaled) launch_k(chunk_stats_kernel<GLB_DT, MASK, true>, grid, block, s, p, true, false);
+  else launch_k(chunk_stats_kernel<GLB_DT, MASK, false>, grid, block, s, p, true, false);
   return hipGetLastError();
 }
 
@@ -41,12 +54,12 @@ hipError_t GLB_CAT(launch_stats_, GLB_DT)(const StepParams &p, int mask_kind, bo
   return hipErrorInvalidValue;
 }
 
-// the step in one launch (statistics / Philox modes): p.stats_blocks and p.fin_waves are set by the caller
+// the step in one launch (statistics / Philox modes): the caller has set the grid's two parts in p
 template <int MASK, int MODE>
 static hipError_t fused2(const StepParams &p, bool scaled, hipStream_t s) {
-  const dim3 grid((unsigned)(p.stats_blocks + (p.fin_waves + 3) / 4)), block(256);
-  if (scaled) hipLaunchKernelGGL((fused_step_kernel<GLB_DT, MASK, true, MODE>), grid, block, 0, s, p);
-  else hipLaunchKernelGGL((fused_step_kernel<GLB_DT, MASK, false, MODE>), grid, block, 0, s, p);
+  const dim3 grid((unsigned)(p.stats_blocks + p.fin_blocks)), block(64);
+  if (scaled) launch_k(fused_step_kernel<GLB_DT, MASK, true, MODE>, grid, block, s, p, true, true);
+  else launch_k(fused_step_kernel<GLB_DT, MASK, false, MODE>, grid, block, s, p, true, true);
   return hipGetLastError();
 }
 
@@ -71,9 +84,9 @@ static hipError_t finish1(const StepParams &p, int mode, hipStream_t s) {
   // one workgroup per particle: one wave, four for the parity-mode race over the whole row
   const dim3 grid((unsigned)p.n_particles), block(mode == kModeNoise ? 256 : 64);
   switch (mode) {
-    case kModeStats: hipLaunchKernelGGL((finish_kernel<GLB_DT, MASK, kModeStats>), grid, block, 0, s, p); break;
-    case kModePhilox: hipLaunchKernelGGL((finish_kernel<GLB_DT, MASK, kModePhilox>), grid, block, 0, s, p); break;
-    case kModeNoise: hipLaunchKernelGGL((finish_kernel<GLB_DT, MASK, kModeNoise>), grid, block, 0, s, p); break;
+    case kModeStats: launch_k(finish_kernel<GLB_DT, MASK, kModeStats>, grid, block, s, p, false, true); break;
+    case kModePhilox: launch_k(finish_kernel<GLB_DT, MASK, kModePhilox>, grid, block, s, p, false, true); break;
+    case kModeNoise: launch_k(finish_kernel<GLB_DT, MASK, kModeNoise>, grid, block, s, p, false, true); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -268,4 +268,17 @@ __device__ __forceinline__ uint32_t wave_sum_u32_l63(uint32_t v) {
   return v;
 }
 
+// sums of v over the four 16-lane rows of the wave (wave-uniform results): the first four steps of the DPP scan leave
+// every row's total in its last lane - what the full scan passes through anyway
+__device__ __forceinline__ void row_sums_u32(uint32_t v, uint32_t (&r)[4]) {
+  v += dpp_u32<0x111, 0xf>(0u, v);
+  v += dpp_u32<0x112, 0xf>(0u, v);
+  v += dpp_u32<0x114, 0xf>(0u, v);
+  v += dpp_u32<0x118, 0xf>(0u, v);
+  r[0] = (uint32_t)__builtin_amdgcn_readlane((int)v, 15);
+  r[1] = (uint32_t)__builtin_amdgcn_readlane((int)v, 31);
+  r[2] = (uint32_t)__builtin_amdgcn_readlane((int)v, 47);
+  r[3] = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 }  // namespace glb

@@ -64,6 +64,21 @@ class StepPlan:
         check(self.eng.lib.glb_logprob_mask_sample(self._ref, self.eng._stream()))
         return self.out
 
+    def run_timed(self, events, offset=None, seed=None):
+        """run() whose launch(es) carry `events` = (start, stop) - two recorded-once torch.cuda.Event(enable_timing=True)
+        - as their own start / stop stamps (glb_logprob_mask_sample_timed): start.elapsed_time(stop) is the duration of
+        the step's launches on the device."""
+        a = self.args
+        if offset is not None:
+            a.offset = offset
+        if seed is not None:
+            a.seed = seed
+        if self.eng._step_ws is not self.keep[-1]:
+            raise RuntimeError("the engine's scratch buffer was reallocated since this plan was made: make a new plan")
+        check(self.eng.lib.glb_logprob_mask_sample_timed(self._ref, self.eng._stream(), C.c_void_p(events[0].cuda_event),
+                                                         C.c_void_p(events[1].cuda_event)))
+        return self.out
+
 
 class _OnDevice:
     """The library's entry points, each run with the engine's device current.  HIP launches go to the calling thread's
@@ -143,7 +158,7 @@ class HipEngine:
 
     def step(self, logits, vocab=None, row_of=None, mask_kind=MASK_NONE, mask=None, mask_id=None,
              rng_mode=RNG_NONE, noise=None, seed=0, offset=0, particle_base=0, logit_scale=1.0,
-             want_lse=True, variant=0, out=None, row_mask_id=None, out_margin=None, _plan=False):
+             want_lse=True, variant=0, out=None, row_mask_id=None, out_margin=None, _plan=False, timing_events=None):
         """Fused particle step (glb_logprob_mask_sample).  Returns (logZ, lse, token) device tensors.
 
         logits: [n_rows, ld] (last dim contiguous; rows may be strided), vocab <= ld.
@@ -216,8 +231,24 @@ class HipEngine:
         if _plan:  # step_plan(): the filled argument block, the tensors it points into, the outputs
             return StepPlan(self, a, (logits, row_of, mask, mask_id, row_mask_id, noise, out_margin, ws),
                             (logZ, lse, tok))
-        check(self.lib.glb_logprob_mask_sample(C.byref(a), self._stream()))
+        if timing_events is not None:  # (start, stop) from timing_events(): the launches' own start / stop stamps
+            check(self.lib.glb_logprob_mask_sample_timed(C.byref(a), self._stream(), C.c_void_p(timing_events[0].cuda_event),
+                                                         C.c_void_p(timing_events[1].cuda_event)))
+        else:
+            check(self.lib.glb_logprob_mask_sample(C.byref(a), self._stream()))
         return logZ, lse, tok
+
+    def timing_events(self, n):
+        """n (start, stop) pairs of HIP events for `step(timing_events=...)` / `StepPlan.run_timed`: created and
+        recorded once here (torch makes the hipEvent_t on first record), so that using them later puts nothing but the
+        launch itself on the stream."""
+        with torch.cuda.device(self.device):
+            pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+            for a, b in pairs:
+                a.record()
+                b.record()
+            torch.cuda.current_stream(self.device).synchronize()
+        return pairs
 
     def step_plan(self, logits, **kw):
         """`step()` with the host work done once: validates and fills the argument block, returns a `StepPlan` whose

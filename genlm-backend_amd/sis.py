@@ -172,6 +172,8 @@ class DeviceSIS:
         self.max_len_now = self.max_prompt
         self.last_stats = None
         self.kernel_events = []
+        self.outer_events = []
+        self._event_pool = []
         self.pkv = None
         self._head_cache = None
         self._kv_stale = None  # bool [N]: rows whose KV has to be rebuilt from the context (ancestor on another rank)
@@ -249,13 +251,20 @@ class DeviceSIS:
         if self.rng_mode == RNG_NOISE:
             kw["noise"] = self._parity_noise(group_of if group_of is not None else self._noise_groups, V)
         if time_kernel:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            # two clocks on the fused call: HIP events the launch itself carries as its start / stop stamps (the launch
+            # duration, as rocprofv3 reports it), and a pair recorded around the call on the stream (adds the two marker
+            # packets and whatever the stream does between them)
+            if len(self._event_pool) < 2:
+                self._event_pool = eng.timing_events(64)
+            inner, (e0, e1) = self._event_pool.pop(), self._event_pool.pop()
             e0.record()
+            kw["timing_events"] = inner
         logZ, _, tok = eng.step(logits, vocab=V, row_of=group_of, rng_mode=self.rng_mode, seed=self.seed,
                                 offset=self.t, particle_base=self.rank * N, want_lse=False, **kw)
         if time_kernel:
             e1.record()
-            self.kernel_events.append((e0, e1))
+            self.kernel_events.append(inner)
+            self.outer_events.append((e0, e1))
         eng.particles_advance(self.contexts, self.lengths, self.active, self.log_weights, logZ, tok, self.eos_id,
                               self.cap)
         self.t += 1
@@ -523,6 +532,7 @@ class SisBenchWorkload:
         self.resample = resample
         self.kernel_bytes = None
         self._events = []
+        self._outer = []
         self._bytes = []
         self.unique_hist = []
         # set-up, not measurement: one untimed pass over the loop's ten batch shapes (context lengths 8..17) so that
@@ -544,12 +554,17 @@ class SisBenchWorkload:
 
     def _collect(self):
         self._events.extend(self.sis.kernel_events)
+        self._outer.extend(self.sis.outer_events)
         self.sis.kernel_events = []
+        self.sis.outer_events = []
 
     def kernel_times_us(self):
         self._collect()
         self.kernel_bytes = float(np.mean(self._bytes)) if self._bytes else 0.0
         return np.array([a.elapsed_time(b) * 1e3 for a, b in self._events])
+
+    def outer_times_us(self):
+        return np.array([a.elapsed_time(b) * 1e3 for a, b in self._outer])
 
     def config(self):
         return {"workload": f"SIS step: {self.N} particles/GPU, {self.model_name}, prompt len 8, <=10 new "

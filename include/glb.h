@@ -130,6 +130,13 @@ typedef struct glb_step_args {
 
 size_t glb_step_workspace_bytes(int64_t n_particles, int64_t n_rows, int64_t vocab, int64_t n_masks);
 int glb_logprob_mask_sample(const glb_step_args *args, void *hip_stream);
+/*
+ * The same call with two HIP events (hipEvent_t, created by the caller with timing enabled; either may be null) that
+ * the step's first launch carries as its start stamp and its last launch as its stop stamp (hipExtLaunchKernel):
+ * hipEventElapsedTime(start, stop) is then the duration of the step's launch(es) on the device - what a profiler
+ * reports for them - without the marker packets of hipEventRecord around the call.  For measurement (bench.py).
+ */
+int glb_logprob_mask_sample_timed(const glb_step_args *args, void *hip_stream, void *start_event, void *stop_event);
 
 /*
  * A step workspace that was zeroed and registered with glb_workspace_init is served in ONE launch: the waves that

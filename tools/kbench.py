@@ -8,6 +8,10 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import genlm_backend_amd  # noqa: E402
+from genlm_backend_amd import _lib  # noqa: E402
+
+if os.environ.get("GLB_DBG_LIB"):  # diagnostic build of the library (make -C genlm-backend_amd/csrc dbg)
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ["GLB_DBG_LIB"])
 from genlm_backend_amd.engine import HipEngine  # noqa: E402
 
 
@@ -58,9 +62,15 @@ if __name__ == "__main__":
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--pforbid", action="store_true", help="sweep the forbidden fraction of the masks")
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--stats", action="store_true", help="statistics only (no draw) on the two headline shapes")
     a = ap.parse_args()
     eng = HipEngine("cuda:0")
     f32, bf16 = torch.float32, torch.bfloat16
+    if a.stats:
+        for _ in range(2):
+            run(eng, 1024, 50257, f32, 3, 0, a.nbuf, a.iters)
+            run(eng, 512, 128256, bf16, 3, 0, a.nbuf, a.iters)
+        sys.exit(0)
     if a.pforbid:
         for pf in (1 / 3, 0.05, 0.0001):
             print("pforbid", pf)
