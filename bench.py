@@ -95,7 +95,7 @@ def cpu_baseline(workload, sample_rows, seed=1234):
         torch.manual_seed(seed)
         model = GPT2LMHeadModel(GPT2Config()).eval()
         ids = torch.randint(0, V_GPT2, (rows, 13))  # mid-loop context length: prompt 8 + 5 generated
-        k_all = torch.get_num_threads()
+        k_all = ncpu or torch.get_num_threads()  # all cores of the host, and one
         fwd = {}
         for k, nrow in ((k_all, rows), (1, 8)):
             torch.set_num_threads(k)
@@ -127,7 +127,8 @@ def cpu_baseline(workload, sample_rows, seed=1234):
         torch.manual_seed(seed)
         model = LlamaForCausalLM(llama_1b_config()).to(torch.bfloat16).eval()
         ids = torch.randint(0, V_LLAMA, (rows, 13))
-        k_all = torch.get_num_threads()
+        k_all = ncpu or torch.get_num_threads()
+        torch.set_num_threads(k_all)
         t0 = time.perf_counter()
         with torch.no_grad():
             logits = model(ids).logits
@@ -206,6 +207,8 @@ def main():
                     help="sis workloads with the prompt's KV cached (hf.py:155-164 cache_kv; BASELINE config 3)")
     ap.add_argument("--prompts", type=int, default=1, help="distinct shared prompts over the population (config 3: 1 / 8 / 64)")
     ap.add_argument("--resample", action="store_true", help="systematic resampling after every step (replicated, deterministic)")
+    ap.add_argument("--no-rccl-single", action="store_true",
+                    help="N = 1 sis workloads: do NOT route the per-step exchange through a one-rank RCCL group")
     args = ap.parse_args()
 
     world_env = os.environ.get("WORLD_SIZE")
@@ -238,6 +241,23 @@ def main():
 
     eng = HipEngine(dev)
     workload = args.workload
+    # N = 1: the SIS workloads still run the multi-rank code - a one-rank "nccl" group carries the per-step all-gather
+    # of log-weights (and the resampling exchange) through RCCL, exactly the calls an 8-GPU run makes
+    force_coll, rccl_note = False, None
+    if world == 1 and workload.startswith("sis") and not args.no_rccl_single:
+        try:
+            import socket
+
+            import torch.distributed as dist1
+
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+            sk.close()
+            dist1.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+            dist, force_coll = dist1, True
+        except Exception as e:  # no RCCL for a single rank on this box: run without, and say so
+            dist, rccl_note = None, f"one-rank nccl group unavailable: {type(e).__name__}: {e}"[:200]
     if workload in ("kernel", "kernel-llama"):
         runner = KernelWorkload(eng, dev, rank, world, dist, llama=workload == "kernel-llama")
     elif workload in ("api", "api-coro", "api-logprobs"):
@@ -248,7 +268,7 @@ def main():
         runner = SisBenchWorkload(eng, dev, rank, world, dist, prefix_kv=args.prefix_kv, particle_kv=args.particle_kv,
                                   model="llama-3.2-1b" if workload == "sis-llama" else "gpt2",
                                   n_particles=512 if workload == "sis-llama" else 1024, n_prompts=args.prompts,
-                                  resample=args.resample)
+                                  resample=args.resample, force_collectives=force_coll)
 
     rccl_ranks = None
     if dist is not None:  # one collective before the clock starts: proves every rank is on the RCCL communicator
@@ -297,6 +317,8 @@ def main():
         }
         if rccl_ranks is not None:
             out["rccl_ranks"] = rccl_ranks
+        if rccl_note is not None:
+            out["rccl_note"] = rccl_note
         if kern_us is not None and len(kern_us):
             ach = runner.kernel_bytes / (np.mean(kern_us) * 1e-6) / 1e9
             outer = runner.outer_times_us()

@@ -348,7 +348,26 @@ __global__ __launch_bounds__(1024) void group_contexts_lds_kernel(const int32_t 
   for (int k = 0; k < PER; ++k) {
     const int i = tid * PER + k;
     slot[k] = 0;
-    if (i < n) {
+    // A wave whose contexts are all the same one (SIS step 0, a freshly resampled population) sends its first lane
+    // alone: 64 CAS + atomicMin on ONE LDS word are otherwise 64 serialised turns per wave.
+    bool all_same = false;
+    int leader = 0;
+    if constexpr (HASHED) {
+      const uint64_t act = __ballot(i < n);
+      if (act != 0ull) {
+        leader = __ffsll((long long)act) - 1;
+        const uint32_t h0l = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)h[k], leader);
+        const uint32_t h0h = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(h[k] >> 32), leader);
+        const int32_t l0 = __builtin_amdgcn_readlane(li[k], leader);
+        const uint32_t s0l = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)si[k], leader);
+        const uint32_t s0h = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)si[k] >> 32), leader);
+        const int64_t si0 = (int64_t)(((uint64_t)s0h << 32) | s0l);
+        const bool like = i < n && h[k] == (((uint64_t)h0h << 32) | h0l) && li[k] == l0 &&
+                          (si[k] == si0 || same_tokens(tok + si[k], tok + si0, li[k]));
+        all_same = __ballot(like) == act;
+      }
+    }
+    if (i < n && (!all_same || lane == leader)) {
       int32_t s = (int32_t)(h[k] & (uint64_t)(cap - 1));
       for (;;) {
         const int32_t owner = atomicCAS(&s_table[s], -1, i);
@@ -361,8 +380,9 @@ __global__ __launch_bounds__(1024) void group_contexts_lds_kernel(const int32_t 
         s = (s + 1) & (cap - 1);
       }
       slot[k] = s;
-      atomicMin(&s_min[s], i);
+      atomicMin(&s_min[s], i);  // (the leader has the wave's smallest index of this k)
     }
+    if (all_same) slot[k] = __builtin_amdgcn_readlane(slot[k], leader);
   }
   __syncthreads();
   // group ids in first-appearance order: exclusive scan of the representative flags in index order
@@ -1099,21 +1119,24 @@ int glb_group_contexts(const int32_t *tokens, const int64_t *starts, const int32
   if (n <= 8192) {  // table in LDS (2 * cap ints <= 128 KiB), slots in registers
     const size_t lds = (size_t)cap * 2 * sizeof(int32_t);
     hipStream_t s = (hipStream_t)stream;
-    if (n <= 1024) {  // one launch, the workgroup hashes its own contexts
+    if (n < 256) {  // one launch, the workgroup hashes its own contexts
       hipLaunchKernelGGL((group_contexts_lds_kernel<1, false>), dim3(1), dim3(1024), lds, s, tokens, starts, lengths,
                          (int32_t)n, (int32_t)cap, out_group_of, out_rep, out_n_groups, (const uint64_t *)nullptr);
-    } else {  // hashes by as many workgroups as it takes (many L1s), then the table
+    } else {  // hashes by many small workgroups (one wave each: as many L1s as there are waves), then the table
       uint64_t *hashes = (uint64_t *)((char *)workspace + (size_t)(2 * cap + 2 * n) * sizeof(int32_t));
-      hipLaunchKernelGGL(hash_contexts_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, tokens, starts, lengths,
+      hipLaunchKernelGGL(hash_contexts_kernel, dim3(blocks_for(n, 64)), dim3(64), 0, s, tokens, starts, lengths,
                          (int32_t)n, hashes);
-      if (n > 4096) {
-        static bool big_lds = false;  // more than 64 KiB of dynamic LDS has to be allowed once per process
-        if (!big_lds) {
-          if (hipFuncSetAttribute((const void *)group_contexts_lds_kernel<8, true>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
-            return hip_fail(hipGetLastError(), "hipFuncSetAttribute(group_contexts)");
-          big_lds = true;
-        }
+      if (n <= 1024) {
+        hipLaunchKernelGGL((group_contexts_lds_kernel<1, true>), dim3(1), dim3(1024), lds, s, tokens, starts, lengths,
+                           (int32_t)n, (int32_t)cap, out_group_of, out_rep, out_n_groups, hashes);
+      } else if (n > 4096) {
+        static std::once_flag big_lds;  // more than 64 KiB of dynamic LDS has to be allowed once per process
+        static hipError_t big_lds_rc = hipSuccess;
+        std::call_once(big_lds, [] {
+          big_lds_rc = hipFuncSetAttribute((const void *)group_contexts_lds_kernel<8, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        });
+        if (big_lds_rc != hipSuccess) return hip_fail(big_lds_rc, "hipFuncSetAttribute(group_contexts)");
         hipLaunchKernelGGL((group_contexts_lds_kernel<8, true>), dim3(1), dim3(1024), lds, s, tokens, starts, lengths,
                            (int32_t)n, (int32_t)cap, out_group_of, out_rep, out_n_groups, hashes);
       } else if (n <= 2048) {

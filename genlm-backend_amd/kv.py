@@ -103,11 +103,12 @@ class PrefixLRU:
     """Least-recently-used store of cached prompt prefixes under a byte budget.  Keys are trie nodes; evicting an entry
     drops the node's `past_key_values` (the log-prob rows stay), so later queries fall back to re-encoding."""
 
-    def __init__(self, budget_bytes):
+    def __init__(self, budget_bytes, on_remove=None):
         self.budget = int(budget_bytes)
         self.used = 0
         self._od = OrderedDict()
         self.evictions = 0
+        self.on_remove = on_remove  # called with the node whenever an entry leaves the store (evicted or dropped)
 
     def put(self, node, kv):
         self.drop(node)
@@ -120,6 +121,8 @@ class PrefixLRU:
             old.past_key_values = None
             self.used -= sz
             self.evictions += 1
+            if self.on_remove is not None:
+                self.on_remove(old)
 
     def touch(self, node):
         key = id(node)
@@ -131,12 +134,21 @@ class PrefixLRU:
         if ent is not None:
             self.used -= ent[1]
             ent[0].past_key_values = None
+            if self.on_remove is not None:
+                self.on_remove(ent[0])
 
     def clear(self):
-        for node, _ in self._od.values():
+        nodes = [node for node, _ in self._od.values()]
+        for node in nodes:
             node.past_key_values = None
         self._od.clear()
         self.used = 0
+        if self.on_remove is not None:
+            for node in nodes:
+                self.on_remove(node)
+
+    def nodes(self):
+        return [node for node, _ in self._od.values()]
 
     def __len__(self):
         return len(self._od)

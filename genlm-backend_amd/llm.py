@@ -213,9 +213,11 @@ class AsyncAmdLM(AsyncLM):
         self._body = self.model.base_model
         from .kv import PrefixLRU
 
-        self._kv_lru = PrefixLRU(kv_budget_bytes)  # prompt prefixes pinned by cache_kv, least recently used out first
         self._kv_tokens = {}  # id(trie node) -> the prefix's token ids (for the device prefix table)
         self._ptab = None
+        # prompt prefixes pinned by cache_kv, least recently used out first; an entry that leaves the store takes its
+        # token tuple and the device prefix table (which holds pointers into its slabs) with it
+        self._kv_lru = PrefixLRU(kv_budget_bytes, on_remove=self._forget_prefix)
         # fused-step state
         self._mask_kind = MASK_NONE
         self._masks = None
@@ -229,6 +231,10 @@ class AsyncAmdLM(AsyncLM):
             super().__init__(tokenizer=self.tokenizer)
         else:  # model-only use (synthetic benchmarks): no vocabulary to decode
             self.byte_vocab, self.str_vocab = None, None
+
+    def _forget_prefix(self, node):
+        self._kv_tokens.pop(id(node), None)
+        self._ptab = None
 
     # ---- cache management (hf.py:142-164) ---------------------------------------------------------
     def clear_cache(self):
@@ -247,14 +253,33 @@ class AsyncAmdLM(AsyncLM):
     def cache_kv(self, prompt_tokens):
         """hf.py:155-164: run the prompt once, cache every position's log-probs and keep the KV states
         on the prompt's last node so later queries only feed their new tokens."""
+        key = tuple(int(t) for t in prompt_tokens)
+        # extend_cache makes fresh nodes, so caching the same prompt again (or one that shares leading tokens) orphans
+        # the node that held the KV so far: its entry leaves the store instead of lingering under the budget
+        for old in [n for n in self._kv_lru.nodes() if self._kv_tokens.get(id(n)) == key]:
+            self._kv_lru.drop(old)
         ids = torch.tensor([prompt_tokens], device=self.device)
         out = self._body(input_ids=ids, use_cache=True)
         logits = self._lm_head(out.last_hidden_state[0])
         node = self.cache.extend_cache(0, prompt_tokens, logits, 0, engine=self.engine)
+        # (re-created ancestors: an older, shorter prefix whose node was replaced on the way is unreachable from the
+        # trie now and would only hold memory)
+        reach = set()
+        walk = self.cache
+        for t in prompt_tokens:
+            if not walk.has_token(t):
+                break
+            walk = walk.get_token(t)
+            reach.add(id(walk))
+        for old in self._kv_lru.nodes():
+            toks = self._kv_tokens.get(id(old))
+            if toks is not None and len(toks) <= len(key) and key[:len(toks)] == toks and id(old) not in reach:
+                self._kv_lru.drop(old)
         # pinned under a byte budget: the least recently used prefix loses its KV (its log-prob rows stay), the policy
         # of cache.py:103-191 applied to whole prefix slabs
         self._kv_lru.put(node, KVPrefix.from_hf_cache(out.past_key_values))
-        self._kv_tokens[id(node)] = tuple(int(t) for t in prompt_tokens)
+        self._kv_tokens[id(node)] = key
+        self._ptab = None
 
     # ---- LoRA hooks (hf.py:166-200): weight management is outside the hot path ---------------------
     def add_new_lora(self, lora_path, lora_name="lora_1"):
@@ -608,7 +633,7 @@ class AsyncAmdLM(AsyncLM):
         flat = np.concatenate([np.asarray(t, np.int32) for _, t in entries])
         ptrs = [[torch.tensor([kv.layers[l][j].data_ptr() for kv in kvs], dtype=torch.int64, device=dev)
                  for j in range(2)] for l in range(len(kvs[0].layers))]
-        self._ptab = dict(key=key, n=len(entries), kvs=kvs, tokens=torch.from_numpy(flat).to(dev),
+        self._ptab = dict(key=key, n=len(entries), kvs=kvs, nodes=[n for n, _ in entries], tokens=torch.from_numpy(flat).to(dev),
                           starts=torch.from_numpy(starts).to(dev), lengths=torch.from_numpy(lens).to(dev), ptrs=ptrs,
                           p_max=int(lens.max()))
         return self._ptab
@@ -645,13 +670,23 @@ class AsyncAmdLM(AsyncLM):
             mid = np.zeros(n, np.int32) if mask_ids is None else np.ascontiguousarray(mask_ids, dtype=np.int32)
             mid_d = torch.from_numpy(mid).to(dev)
         head = [ng[0]]
+        used_d = None
         if P["n"]:
             pref, base = eng.match_prefixes(tok_d, st_d, ln_d, P["tokens"], P["starts"], P["lengths"])
             head.append((ln_d - base).max().to(torch.int32))
+            # which cached prefixes this call uses (they count as recently used, like walk_cache's touch)
+            used_d = torch.zeros(P["n"] + 1, dtype=torch.int32, device=dev).index_fill_(0, (pref + 1).long(), 1)[1:]
         if mid_d is not None:  # may the mask ids go per logits row? (they do when the mask is a function of the context)
             row_mid = mid_d[rep.long().clamp(0, n - 1)]  # entries of `rep` past the group count are unspecified
             head.append((row_mid[group_of.long()] == mid_d).all().to(torch.int32))
-        head = torch.stack(head).cpu().tolist()  # the call's one D2H copy before the forward
+        n_head = len(head)
+        head = torch.stack(head) if used_d is None else torch.cat([torch.stack(head), used_d])
+        head = head.cpu().tolist()  # the call's one D2H copy before the forward
+        if used_d is not None:
+            for node, u in zip(P["nodes"], head[n_head:]):
+                if u:
+                    self._kv_lru.touch(node)
+            head = head[:n_head]
         U = head[0]
         l_max = head[1] if P["n"] else int(lens.max())
         by_row = bool(head[-1]) if mid_d is not None else False
@@ -744,11 +779,13 @@ class AsyncAmdLM(AsyncLM):
 
     # ---- sampling (base.py:110-179): a device-resident multi-token loop -----------------------------------------------
     @torch.no_grad()
-    def batch_sample_sync(self, prompt_token_ids_list, max_tokens, eos_token_ids, temperature=1.0, seed=None):
+    def batch_sample_sync(self, prompt_token_ids_list, max_tokens, eos_token_ids, temperature=1.0, seed=None,
+                          sync_every=4):
         """base.py:148-179.  All sequences advance together on the device (sis.DeviceSampler): per-sequence KV slabs,
         softmax(logits / temperature) -> one draw per sequence per forward by the fused step, stop on `eos_token_ids`.
         With a seed every sequence reproduces torch.multinomial under its own torch.Generator().manual_seed(seed)
-        (base.py:125-141); without one the draws come from the in-kernel Philox stream."""
+        (base.py:125-141); without one the draws come from the in-kernel Philox stream.  `sync_every`: how often the
+        loop reads the number of unfinished sequences back (the reference reads every token of every sequence)."""
         from .sis import DeviceSampler
 
         if not prompt_token_ids_list:
@@ -757,7 +794,7 @@ class AsyncAmdLM(AsyncLM):
             raise ValueError("Token ids must not be empty")
         if max_tokens <= 0:
             return [[] for _ in prompt_token_ids_list]
-        smp = DeviceSampler(self, prompt_token_ids_list, max_tokens, eos_token_ids, temperature, seed)
+        smp = DeviceSampler(self, prompt_token_ids_list, max_tokens, eos_token_ids, temperature, seed, sync_every=sync_every)
         return [[int(t) for t in row] for row in smp.generate()]
 
     async def batch_sample(self, prompt_token_ids_list, max_tokens, eos_token_ids, temperature=1.0, seed=None):

@@ -94,13 +94,17 @@ class DeviceSIS:
                      sample size is below `resample_ess * N_total`, the population is resampled systematically from
                      the all-gathered log-weights; every rank computes the same ancestors (glb_resample_systematic),
                      contexts and KV rows follow their ancestors, weights are reset to the population mean.
+    force_collectives  run the collectives of the multi-rank path (all-gather of log-weights / token matrices, the
+                     set-up reductions) through `dist` even when world == 1: a one-rank "nccl" group exercises the RCCL
+                     code of an 8-GPU run on a single GPU.
     """
 
     def __init__(self, llm, n_particles, prompt_ids, max_tokens, eos_id, seed=0, rng="philox", rank=0, world=1,
-                 dist=None, use_prefix_kv=False, use_particle_kv=False, resample_ess=None):
+                 dist=None, use_prefix_kv=False, use_particle_kv=False, resample_ess=None, force_collectives=False):
         self.llm, self.eng, self.dev = llm, llm.engine, llm.device
         self.N, self.max_tokens, self.eos_id = n_particles, max_tokens, eos_id
         self.rank, self.world, self.dist = rank, world, dist
+        self.collective = world > 1 or (bool(force_collectives) and dist is not None)
         self.seed = seed
         self.rng_mode = RNG_PHILOX if rng == "philox" else RNG_NOISE
         self.host_rng = None
@@ -112,14 +116,14 @@ class DeviceSIS:
         assert len(prompts) == n_particles
         self._prompt_len0 = torch.tensor([len(p) for p in prompts], dtype=torch.int32, device=self.dev)
         self.max_prompt = max(len(p) for p in prompts)
-        if world > 1:  # one token-matrix width over all ranks: rows travel between ranks when resampling
+        if self.collective:  # one token-matrix width over all ranks: rows travel between ranks when resampling
             mp_ = torch.tensor([self.max_prompt], dtype=torch.int64, device=self.dev)
             dist.all_reduce(mp_, op=dist.ReduceOp.MAX)
             self.max_prompt = int(mp_.item())
         # the README mask is a function of the number of generated tokens; with prompts of ONE length (over all
         # ranks, if particles can migrate) that makes it a function of the context, i.e. of the logits row
         lens = {len(p) for p in prompts}
-        if world > 1 and resample_ess is not None:
+        if self.collective and resample_ess is not None:
             mm = torch.tensor([min(lens), -max(lens)], dtype=torch.int64, device=self.dev)
             dist.all_reduce(mm, op=dist.ReduceOp.MIN)
             lens = {int(mm[0]), int(-mm[1])}
@@ -134,8 +138,18 @@ class DeviceSIS:
         # cached prompt prefixes (hf.py:155-164): one KV slab set per distinct prompt
         self.prefixes = None
         if use_prefix_kv:
-            distinct = sorted({tuple(p) for p in prompts})
-            self._build_prefixes(distinct)
+            distinct = {tuple(p) for p in prompts}
+            if self.collective and resample_ess is not None:
+                # particles migrate between ranks when the population is resampled, and every context must find its
+                # prompt in the local table (the forward is fed the generated tokens only): cache the prompts of ALL ranks
+                width = self.max_prompt
+                all_p = torch.empty((world * n_particles, width), dtype=torch.int32, device=self.dev)
+                all_l = torch.empty(world * n_particles, dtype=torch.int32, device=self.dev)
+                dist.all_gather_into_tensor(all_p.view(-1), self._ctx0[:, :width].contiguous().view(-1))
+                dist.all_gather_into_tensor(all_l, self._prompt_len0)
+                all_p, all_l = all_p.cpu().numpy(), all_l.cpu().numpy()
+                distinct = {tuple(int(t) for t in all_p[i, :all_l[i]]) for i in range(len(all_l))}
+            self._build_prefixes(sorted(distinct))
         self.particle_kv = bool(use_particle_kv)
         if self.particle_kv:
             assert not use_prefix_kv
@@ -280,7 +294,7 @@ class DeviceSIS:
         rank then holds the population's weights (README.md:108-110 needs all of them) and knows whether anybody,
         anywhere, is still generating - the loop's termination test is collective."""
         count = self.active.sum().to(torch.float32).view(1)
-        if self.world > 1:
+        if self.collective:
             mine = torch.cat([self.log_weights, count])
             out = torch.empty((self.world, self.N + 1), dtype=torch.float32, device=self.dev)
             self.dist.all_gather_into_tensor(out.view(-1), mine)
@@ -379,7 +393,7 @@ class DeviceSIS:
         anc, lse = eng.resample_systematic(self.all_weights, self.seed ^ 0x5eed5a11, self.t)
         mine = anc[self.rank * N:(self.rank + 1) * N].contiguous()
         meta = torch.stack([self.lengths, self.prompt_len, self.active], dim=1).contiguous()  # [N, 3] int32
-        if self.world > 1:
+        if self.collective:
             all_ctx = torch.empty((n_total, self.cap), dtype=torch.int32, device=dev)
             all_meta = torch.empty((n_total, 3), dtype=torch.int32, device=dev)
             self.dist.all_gather_into_tensor(all_ctx.view(-1), self.contexts.view(-1))
@@ -489,7 +503,7 @@ class SisBenchWorkload:
     V = 128256, 512 particles (config 4: 4096 over 8 GPUs)."""
 
     def __init__(self, eng, dev, rank, world, dist, n_particles=1024, max_tokens=10, prefix_kv=False, particle_kv=False,
-                 model="gpt2", n_prompts=1, resample=False):
+                 model="gpt2", n_prompts=1, resample=False, force_collectives=False):
         from .llm import AsyncAmdLM
 
         if model == "gpt2":
@@ -526,7 +540,8 @@ class SisBenchWorkload:
         self.n_prompts = n_prompts
         self.sis = DeviceSIS(self.llm, n_particles, prompts, max_tokens, cfg.eos_token_id,
                              seed=1234, rank=rank, world=world, dist=dist, use_prefix_kv=prefix_kv,
-                             use_particle_kv=particle_kv, resample_ess=1.0 if resample else None)
+                             use_particle_kv=particle_kv, resample_ess=1.0 if resample else None,
+                             force_collectives=force_collectives)
         self.prefix_kv = prefix_kv
         self.particle_kv = particle_kv
         self.resample = resample

@@ -154,6 +154,22 @@ def test_seeded_sample_matches_reference_ids(llm, gold):
     assert np.array_equal(np.array(ids2), gold["batch_sample_ids"])
 
 
+G3 = os.path.join(os.path.dirname(__file__), "golden", "ref_round3.npz")
+
+
+@pytest.mark.parametrize("sync_every", [1, 4])
+def test_batch_sample_ragged_prompts_two_stop_tokens(llm, sync_every):
+    """base.py:148-179 on ten ragged prompts, temperature 0.2, two stopping tokens, sequences ending after 4, 7 and 10
+    tokens (oracle/make_goldens_r3.py ran the reference): every sequence races against the same Exp(1) row per step."""
+    g3 = np.load(G3)
+    prompts = [_strip(r) for r in g3["bs_prompts"]]
+    ids = llm.batch_sample_sync(prompts, max_tokens=int(g3["bs_params"][0]), eos_token_ids=[int(t) for t in g3["bs_eos"]],
+                                temperature=float(g3["bs_temperature"][0]), seed=int(g3["bs_params"][1]),
+                                sync_every=sync_every)
+    assert ids == [_strip(r) for r in g3["bs_ids"]]
+    assert len({len(r) for r in ids}) >= 3
+
+
 def _check_sis(contexts, log_weights, gold):
     want_ctx = [_strip(r) for r in gold["sis_contexts"]]
     assert [list(map(int, c)) for c in contexts] == want_ctx  # sampled ids bit-exact under the fixed seed
@@ -233,6 +249,29 @@ def test_prefix_kv_is_evicted_least_recently_used_first(llm):
     got = asyncio.run(llm.batch_next_token_logprobs([pres[1] + [3], pres[0] + [3]]))
     for p, row in zip((pres[1] + [3], pres[0] + [3]), got):
         assert np.abs(row.numpy() - llm.next_token_logprobs_uncached(p).numpy()).max() < TOL
+
+
+def test_prefix_store_bookkeeping(llm):
+    """Caching a prompt again, or one that re-creates its leading nodes, must not leave orphaned entries under the
+    budget; evicted entries take their token tuple and the device prefix table with them; the batched path counts
+    the prefixes it uses as recently used."""
+    llm.cache_kv([5, 6, 7])
+    one = llm._kv_lru.used
+    llm.cache_kv([5, 6, 7])
+    assert len(llm._kv_lru) == 1 and llm._kv_lru.used == one and len(llm._kv_tokens) == 1
+    llm.cache_kv([5, 6, 7, 8])  # re-creates the nodes of [5, 6, 7]: the shorter prefix's node is unreachable now
+    assert len(llm._kv_lru) == 1 and len(llm._kv_tokens) == 1
+    assert llm.walk_cache([5, 6, 7, 8, 9])[3] == 4
+    llm.clear_cache()
+    pres = [[5, 6, 7], [8, 9, 10], [12, 13, 14]]
+    llm.cache_kv(pres[0])
+    llm._kv_lru.budget = int(llm._kv_lru.used * 2.5)
+    llm.cache_kv(pres[1])
+    logZ, tok = llm.batch_next_token_step_sync([pres[0] + [1], pres[0] + [2]])  # uses prefix 0 only
+    assert llm._ptab is not None and llm._ptab["n"] == 2
+    llm.cache_kv(pres[2])  # evicts the least recently used: prefix 1
+    assert llm._kv_lru.evictions == 1 and len(llm._kv_tokens) == 2 and llm._ptab is None
+    assert llm.walk_cache(pres[1] + [1])[2] is None and llm.walk_cache(pres[0] + [1])[2] is not None
 
 
 @pytest.mark.parametrize("family", ["gemma2", "cohere", "granite"])

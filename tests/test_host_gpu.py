@@ -386,3 +386,126 @@ def test_batched_submit_on_gpu_matches_reference(llm):
                 ctxs[i].append(int(t))
     assert ctxs == [_strip(r) for r in gold["sis_contexts"]]
     assert np.abs(lw - gold["sis_log_weights"]).max() < TOL
+
+
+# ---- the RCCL path on one GPU; the device guard ---------------------------------------------------------------
+@pytest.fixture()
+def nccl_single():
+    """A one-rank "nccl" (= RCCL) process group on this GPU: the collectives of an 8-GPU run, executed."""
+    import socket
+
+    import torch.distributed as dist
+
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    yield dist
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["plain", "pkv", "prefix"])
+def test_rccl_collectives_on_one_rank_change_nothing(llm, nccl_single, mode):
+    """DeviceSIS with the multi-rank branch forced on (all-gather of log-weights + active counts every step, of the
+    token matrices and meta rows at every resampling step, the set-up reductions - all through RCCL) gives the tokens
+    and weights of the run without collectives, through several resampling steps."""
+    from genlm_backend_amd.sis import DeviceSIS
+
+    dist = nccl_single
+    assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+    m, gold = llm
+    m.register_masks(torch.from_numpy(gold["sis_masks"]))
+    p = [int(t) for t in gold["sis_prompt"]]
+    prompts = [p, p[:5], p[2:], p] * 8
+    kw = dict(use_particle_kv=mode == "pkv", use_prefix_kv=mode == "prefix")
+    runs = []
+    for force in (True, False):
+        s = DeviceSIS(m, 32, prompts, max_tokens=6, eos_id=0, seed=5, resample_ess=1.0, dist=dist if force else None,
+                      force_collectives=force, **kw)
+        assert s.collective == force
+        s.run()
+        assert s.n_resamples >= 2
+        probs, stats = s.normalized_weights()
+        runs.append((s.results(), probs.cpu().numpy(), stats.cpu().numpy()))
+    assert runs[0][0][0] == runs[1][0][0]
+    assert np.array_equal(runs[0][0][1].view(np.uint32), runs[1][0][1].view(np.uint32))
+    assert np.array_equal(runs[0][1].view(np.uint32), runs[1][1].view(np.uint32))
+    # the gathered vector really went through the collective
+    probe = torch.arange(4, dtype=torch.float32, device=m.device)
+    got = torch.empty(4, device=m.device)
+    dist.all_gather_into_tensor(got, probe)
+    assert got.cpu().tolist() == [0.0, 1.0, 2.0, 3.0]
+
+
+def test_engine_launches_on_its_own_device(engine, oracle):
+    """HipEngine runs every entry point with ITS device current, whatever the calling thread has set (one process
+    driving several GPUs).  With one visible GPU the guard is exercised through its bookkeeping: the proxy resolves and
+    the call lands on cuda:0; with two, a second engine on cuda:1 is driven while cuda:0 is current and vice versa."""
+    from genlm_backend_amd.engine import HipEngine
+
+    x = synth.logits(11, 3, 1000)
+    want = oracle.step(x, rng_mode=oracle.RNG_PHILOX, seed=3, offset=1)
+    n_dev = torch.cuda.device_count()
+    engines = [engine] + ([HipEngine("cuda:1")] if n_dev > 1 else [])
+    for cur in range(min(n_dev, 2)):
+        torch.cuda.set_device(cur)
+        for eng in engines:
+            got = eng.step(torch.from_numpy(x).to(eng.device), rng_mode=1, seed=3, offset=1)
+            torch.cuda.synchronize(eng.device)
+            for w, g in zip(want, got):
+                assert g.device == eng.device
+                assert np.array_equal(g.cpu().numpy().view(np.uint32), w.view(np.uint32))
+    torch.cuda.set_device(0)
+
+
+# ---- batch_sample on the HIP path (base.py:148-179) ---------------------------------------------------------------
+G3 = os.path.join(os.path.dirname(__file__), "golden", "ref_round3.npz")
+
+
+@pytest.mark.parametrize("sync_every", [1, 4])
+def test_batch_sample_on_gpu_matches_reference(llm, sync_every):
+    """Ten ragged prompts, temperature 0.2, two stopping tokens, sequences ending at different steps: the device loop
+    (per-sequence KV slabs, the fused step with logit_scale = 1/T and ONE Exp(1) row shared by every sequence - noise
+    pitch 0 -, active count read back every `sync_every` steps) returns the reference's ids."""
+    m, _ = llm
+    g3 = np.load(G3)
+    prompts = [_strip(r) for r in g3["bs_prompts"]]
+    ids = m.batch_sample_sync(prompts, max_tokens=int(g3["bs_params"][0]), eos_token_ids=[int(t) for t in g3["bs_eos"]],
+                              temperature=float(g3["bs_temperature"][0]), seed=int(g3["bs_params"][1]),
+                              sync_every=sync_every)
+    assert ids == [_strip(r) for r in g3["bs_ids"]]
+    assert len({len(r) for r in ids}) >= 3
+    free = m.batch_sample_sync(prompts, max_tokens=10, eos_token_ids=[], temperature=float(g3["bs_temperature"][0]),
+                               seed=int(g3["bs_params"][1]), sync_every=sync_every)
+    assert np.array_equal(np.array(free), g3["bs_ids_free"])
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_shared_noise_row_step(engine, oracle, dtype):
+    """engine.step with noise [1, V] and n > 1 particles (pitch 0: one row for everybody) == the oracle with the row
+    repeated; with and without a temperature, over deduplicated rows."""
+    n, U, V = 37, 9, 5003
+    x = synth.logits(21, U, V)
+    row_of = (np.arange(n) * 7 % U).astype(np.int32)
+    E = oracle.mt_exponential(77, V)[0]
+    if dtype == "bf16":
+        xb = oracle.f32_to_bf16_bits(x)
+        xin, xt = xb, torch.from_numpy(xb.view(np.int16)).view(torch.bfloat16)
+    else:
+        xin, xt = x, torch.from_numpy(x)
+    dev = engine.device
+    for scale in (1.0, 1.0 / 0.7):
+        want = oracle.step(xin, row_of=row_of, rng_mode=oracle.RNG_NOISE, noise=np.tile(E, (n, 1)), logit_scale=scale,
+                           want_margin=True)
+        margin = torch.empty(n, device=dev)
+        got = engine.step(xt.to(dev), row_of=torch.from_numpy(row_of).to(dev), rng_mode=2,
+                          noise=torch.from_numpy(E).view(1, V).to(dev), logit_scale=scale, out_margin=margin)
+        torch.cuda.synchronize()
+        for w, g in zip(want[:3], got):
+            assert np.array_equal(g.cpu().numpy().view(np.uint32), w.view(np.uint32))
+        assert np.array_equal(margin.cpu().numpy().view(np.uint32), want[3].view(np.uint32))

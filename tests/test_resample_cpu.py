@@ -92,7 +92,7 @@ def test_slab_kv_equals_reencode_and_prefix_kv(kind):
     assert np.abs(a.results()[1] - b.results()[1]).max() < 1e-4
 
 
-def _worker(rank, world, port, out_dir, kind, pkv):
+def _worker(rank, world, port, out_dir, kind, pkv, prefix=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(2)
@@ -103,7 +103,7 @@ def _worker(rank, world, port, out_dir, kind, pkv):
     n = len(PROMPTS) // world
     mine = PROMPTS[rank * n:(rank + 1) * n]
     sis = DeviceSIS(llm, n, mine, max_tokens=6, eos_id=0, seed=3, rank=rank, world=world, dist=dist,
-                    use_particle_kv=pkv, resample_ess=1.0)
+                    use_particle_kv=pkv, use_prefix_kv=prefix, resample_ess=1.0)
     steps = sis.run()
     ctx, lw = sis.results()
     width = 8
@@ -114,12 +114,14 @@ def _worker(rank, world, port, out_dir, kind, pkv):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("kind,pkv", [("gpt2", True), ("llama", False)])
-def test_two_ranks_equal_one_through_resampling(tmp_path, kind, pkv):
+@pytest.mark.parametrize("kind,pkv,prefix", [("gpt2", True, False), ("llama", False, False), ("gpt2", False, True)])
+def test_two_ranks_equal_one_through_resampling(tmp_path, kind, pkv, prefix):
     """Replicated deterministic resampling: two gloo ranks (4 particles each; ancestors cross the shard boundary, so
-    contexts travel and KV rows are rebuilt) end with the same tokens and weights as one process with all 8."""
+    contexts travel and KV rows are rebuilt) end with the same tokens and weights as one process with all 8.  With
+    cached prompt prefixes the two ranks hold DIFFERENT prompts (PROMPTS[4:] shares only one with PROMPTS[:4]): a
+    migrated particle must still find its prompt's KV, so every rank caches the prompts of all ranks."""
     world, port = 2, 29741 + os.getpid() % 200
-    mp.start_processes(_worker, args=(world, port, str(tmp_path), kind, pkv), nprocs=world, join=True,
+    mp.start_processes(_worker, args=(world, port, str(tmp_path), kind, pkv, prefix), nprocs=world, join=True,
                        start_method="spawn")
     r = [np.load(tmp_path / f"rank{i}.npz") for i in range(world)]
     assert int(r[0]["steps"]) == int(r[1]["steps"]) and int(r[0]["n_res"]) >= 2
@@ -127,7 +129,7 @@ def test_two_ranks_equal_one_through_resampling(tmp_path, kind, pkv):
     from genlm_backend_amd.sis import DeviceSIS
 
     one = DeviceSIS(_tiny(kind), len(PROMPTS), PROMPTS, max_tokens=6, eos_id=0, seed=3, use_particle_kv=pkv,
-                    resample_ess=1.0)
+                    use_prefix_kv=prefix, resample_ess=1.0)
     one.run()
     ctx, lw = one.results()
     got = [[int(t) for t in row if t >= 0] for row in np.concatenate([r[0]["ctx"], r[1]["ctx"]])]
