@@ -77,11 +77,12 @@ SYMBOLS = {
     "glb_log_softmax_rows": (C.c_int, [_vp, _i32, _i64, _i64, _i64, _f32, _vp, _i64, _vp, _vp, _sz, _vp]),
     "glb_mask_f32_to_bits": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp]),
     "glb_group_contexts_workspace": (_sz, [_i64]),
-    "glb_group_contexts": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "glb_group_contexts": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "glb_hash_contexts": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "glb_match_prefixes": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "glb_gather_padded": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "glb_gather_kv_padded": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp]),
-    "glb_particles_advance": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "glb_particles_advance": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "glb_normalize_weights": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
     "glb_kv_append": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
     "glb_kv_gather_rows": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _i32, _vp]),

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void hash_contexts_kernel(const int32_t *tok, 
   if (i >= n) return;
   const int32_t li = len[i];
   const int32_t *t = tok + st[i];
-  uint64_t h = 0xcbf29ce484222325ull ^ (uint64_t)li;
+  uint64_t h = 0xcbf29ce484222325ull;  // (the length is compared on its own: a context's hash extends token by token)
   int j = 0;
   for (; j + 4 <= li; j += 4) {
     const glb::u32x4_t w = *reinterpret_cast<const glb::u32x4_t *>(t + j);
@@ -302,8 +302,13 @@ __global__ __launch_bounds__(1024) void group_contexts_lds_kernel(const int32_t 
                                                                    const int32_t *len, int32_t n, int32_t cap,
                                                                    int32_t *out_group_of, int32_t *out_rep,
                                                                    int32_t *out_n_groups, const uint64_t *hash_in) {
-  extern __shared__ int32_t s_dyn[];
+  extern __shared__ __attribute__((aligned(16))) int32_t s_dyn[];
   int32_t *s_table = s_dyn, *s_min = s_dyn + cap;
+  // !HASHED (up to 2048 contexts, one launch): every context's hash, start and length also sit in LDS, so that a
+  // collision or a duplicate is recognised without going back to global memory for anything but the tokens
+  uint64_t *s_hash = reinterpret_cast<uint64_t *>(s_dyn + 2 * cap);
+  int64_t *s_st = reinterpret_cast<int64_t *>(s_hash + 1024 * PER);
+  int32_t *s_len = reinterpret_cast<int32_t *>(s_st + 1024 * PER);
   __shared__ int32_t s_wave[16];
   const int T = 1024, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < cap; i += T) {
@@ -319,7 +324,7 @@ __global__ __launch_bounds__(1024) void group_contexts_lds_kernel(const int32_t 
     const int i = tid * PER + k;
     li[k] = i < n ? len[i] : 0;
     si[k] = i < n ? st[i] : 0;
-    h[k] = 0xcbf29ce484222325ull ^ (uint64_t)li[k];
+    h[k] = 0xcbf29ce484222325ull;
   }
   if constexpr (HASHED) {
 #pragma unroll
@@ -327,20 +332,23 @@ __global__ __launch_bounds__(1024) void group_contexts_lds_kernel(const int32_t 
       const int i = tid * PER + k;
       if (i < n) h[k] = hash_in[i];
     }
-  }
+  } else {
+    // four tokens per 16-byte load (element-aligned only, like the logits rows): what bounds this phase is cache lines
+    // touched per load instruction on this one CU's L1 - every lane reads another context - and a 16-byte load touches
+    // no more lines than a 4-byte one
 #pragma unroll
-  for (int k = 0; k < (HASHED ? 0 : PER); ++k) {
-    const int32_t *t = tok + si[k];
-    int j = 0;
-    for (; j + 4 <= li[k]; j += 4) {  // four independent loads per trip
-      const uint32_t a = (uint32_t)t[j], b = (uint32_t)t[j + 1], c = (uint32_t)t[j + 2], d = (uint32_t)t[j + 3];
-      h[k] ^= a; h[k] *= 0x100000001b3ull; h[k] ^= h[k] >> 29;
-      h[k] ^= b; h[k] *= 0x100000001b3ull; h[k] ^= h[k] >> 29;
-      h[k] ^= c; h[k] *= 0x100000001b3ull; h[k] ^= h[k] >> 29;
-      h[k] ^= d; h[k] *= 0x100000001b3ull; h[k] ^= h[k] >> 29;
-    }
-    for (; j < li[k]; ++j) {
-      h[k] ^= (uint32_t)t[j]; h[k] *= 0x100000001b3ull; h[k] ^= h[k] >> 29;
+    for (int k = 0; k < PER; ++k) {
+      const int32_t *t = tok + si[k];
+      int j = 0;
+      for (; j + 4 <= li[k]; j += 4) {
+        const glb::u32x4_t w = *reinterpret_cast<const glb::u32x4_t *>(t + j);
+        h[k] = ctx_hash_step(ctx_hash_step(ctx_hash_step(ctx_hash_step(h[k], w.x), w.y), w.z), w.w);
+      }
+      for (; j < li[k]; ++j) h[k] = ctx_hash_step(h[k], (uint32_t)t[j]);
+      const int i = tid * PER + k;
+      s_hash[i] = h[k];
+      s_st[i] = si[k];
+      s_len[i] = li[k];
     }
   }
   __syncthreads();
@@ -352,7 +360,7 @@ __global__ __launch_bounds__(1024) void group_contexts_lds_kernel(const int32_t 
     // alone: 64 CAS + atomicMin on ONE LDS word are otherwise 64 serialised turns per wave.
     bool all_same = false;
     int leader = 0;
-    if constexpr (HASHED) {
+    {
       const uint64_t act = __ballot(i < n);
       if (act != 0ull) {
         leader = __ffsll((long long)act) - 1;
@@ -375,7 +383,7 @@ __global__ __launch_bounds__(1024) void group_contexts_lds_kernel(const int32_t 
         if constexpr (HASHED) {
           if (hash_in[owner] == h[k] && len[owner] == li[k] && same_tokens(tok + si[k], tok + st[owner], li[k])) break;
         } else {
-          if (same_ctx(tok, st, len, owner, i)) break;
+          if (s_hash[owner] == h[k] && s_len[owner] == li[k] && same_tokens(tok + si[k], tok + s_st[owner], li[k])) break;
         }
         s = (s + 1) & (cap - 1);
       }
@@ -503,7 +511,7 @@ __global__ void gather_kv_kernel(const void *const *slabs, const int32_t *slab_l
 __global__ void particles_advance_kernel(int32_t *ctx, int64_t ctx_ld, int32_t *len,
                                          int32_t *active, float *lw, const float *logZ,
                                          const int32_t *tok, int64_t n, int32_t eos,
-                                         int32_t max_len) {
+                                         int32_t max_len, uint64_t *hashes) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || !active[i]) return;
   lw[i] += logZ[i];
@@ -514,6 +522,7 @@ __global__ void particles_advance_kernel(int32_t *ctx, int64_t ctx_ld, int32_t *
     const int32_t l = len[i];
     ctx[i * ctx_ld + l] = t;
     len[i] = l + 1;
+    if (hashes) hashes[i] = ctx_hash_step(hashes[i], (uint32_t)t);  // the context's hash grows with it
     if (l + 1 >= max_len) active[i] = 0;
   }
 }
@@ -1107,9 +1116,20 @@ size_t glb_group_contexts_workspace(int64_t n) {
   return (size_t)(2 * group_cap(n) + 2 * n) * sizeof(int32_t) + (size_t)n * sizeof(uint64_t) + 8;
 }
 
+int glb_hash_contexts(const int32_t *tokens, const int64_t *starts, const int32_t *lengths, int64_t n,
+                      uint64_t *out_hashes, void *stream) {
+  if (!tokens || !starts || !lengths || !out_hashes) return fail(GLB_EINVAL, "null pointer");
+  if (n <= 0 || n > (1 << 28)) return fail(GLB_EINVAL, "n out of range");
+  hipLaunchKernelGGL(hash_contexts_kernel, dim3(blocks_for(n, 64)), dim3(64), 0, (hipStream_t)stream, tokens, starts,
+                     lengths, (int32_t)n, out_hashes);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "hash_contexts launch");
+  return GLB_OK;
+}
+
 int glb_group_contexts(const int32_t *tokens, const int64_t *starts, const int32_t *lengths,
-                       int64_t n, int32_t *out_group_of, int32_t *out_rep, int32_t *out_n_groups,
-                       void *workspace, size_t workspace_bytes, void *stream) {
+                       int64_t n, const uint64_t *ctx_hashes, int32_t *out_group_of, int32_t *out_rep,
+                       int32_t *out_n_groups, void *workspace, size_t workspace_bytes, void *stream) {
   if (!tokens || !starts || !lengths || !out_group_of || !out_rep || !out_n_groups || !workspace)
     return fail(GLB_EINVAL, "null pointer");
   if (n <= 0 || n > (1 << 28)) return fail(GLB_EINVAL, "n out of range");
@@ -1119,13 +1139,19 @@ int glb_group_contexts(const int32_t *tokens, const int64_t *starts, const int32
   if (n <= 8192) {  // table in LDS (2 * cap ints <= 128 KiB), slots in registers
     const size_t lds = (size_t)cap * 2 * sizeof(int32_t);
     hipStream_t s = (hipStream_t)stream;
-    if (n < 256) {  // one launch, the workgroup hashes its own contexts
-      hipLaunchKernelGGL((group_contexts_lds_kernel<1, false>), dim3(1), dim3(1024), lds, s, tokens, starts, lengths,
+    if (n < 256 && !ctx_hashes) {  // one launch: the workgroup hashes its own contexts (16-byte loads), meta data in LDS (36 KiB)
+      const size_t lds1 = lds + 1024 * (sizeof(uint64_t) + sizeof(int64_t) + sizeof(int32_t));
+      hipLaunchKernelGGL((group_contexts_lds_kernel<1, false>), dim3(1), dim3(1024), lds1, s, tokens, starts, lengths,
                          (int32_t)n, (int32_t)cap, out_group_of, out_rep, out_n_groups, (const uint64_t *)nullptr);
-    } else {  // hashes by many small workgroups (one wave each: as many L1s as there are waves), then the table
-      uint64_t *hashes = (uint64_t *)((char *)workspace + (size_t)(2 * cap + 2 * n) * sizeof(int32_t));
-      hipLaunchKernelGGL(hash_contexts_kernel, dim3(blocks_for(n, 64)), dim3(64), 0, s, tokens, starts, lengths,
-                         (int32_t)n, hashes);
+    } else {  // hashes - the caller's (kept up to date token by token: glb_particles_advance), or made here by many small
+              // workgroups (one wave each: as many L1s as there are waves) - then the table
+      const uint64_t *hashes = ctx_hashes;
+      if (!hashes) {
+        uint64_t *hw = (uint64_t *)((char *)workspace + (size_t)(2 * cap + 2 * n) * sizeof(int32_t));
+        hipLaunchKernelGGL(hash_contexts_kernel, dim3(blocks_for(n, 64)), dim3(64), 0, s, tokens, starts, lengths,
+                           (int32_t)n, hw);
+        hashes = hw;
+      }
       if (n <= 1024) {
         hipLaunchKernelGGL((group_contexts_lds_kernel<1, true>), dim3(1), dim3(1024), lds, s, tokens, starts, lengths,
                            (int32_t)n, (int32_t)cap, out_group_of, out_rep, out_n_groups, hashes);
@@ -1152,11 +1178,15 @@ int glb_group_contexts(const int32_t *tokens, const int64_t *starts, const int32
     return GLB_OK;
   }
   int32_t *table = (int32_t *)workspace, *minidx = table + cap, *slot_of = minidx + cap, *gid_of = slot_of + n;
-  uint64_t *hashes = (uint64_t *)(gid_of + n);
+  const uint64_t *hashes = ctx_hashes;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(group_init_kernel, dim3(blocks_for(cap, 256)), dim3(256), 0, s, (int32_t)cap, table, minidx);
-  hipLaunchKernelGGL(hash_contexts_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, tokens, starts, lengths, (int32_t)n,
-                     hashes);
+  if (!hashes) {
+    uint64_t *hw = (uint64_t *)(gid_of + n);
+    hipLaunchKernelGGL(hash_contexts_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, tokens, starts, lengths, (int32_t)n,
+                       hw);
+    hashes = hw;
+  }
   hipLaunchKernelGGL(group_insert_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, tokens, starts, lengths, (int32_t)n,
                      (int32_t)cap, hashes, table, minidx, slot_of);
   hipLaunchKernelGGL(group_number_kernel, dim3(1), dim3(1024), 0, s, (int32_t)n, minidx, slot_of, gid_of, out_group_of,
@@ -1227,13 +1257,13 @@ int glb_gather_kv_padded(const void *const *slabs, const int32_t *slab_len, int6
 
 int glb_particles_advance(int32_t *contexts, int64_t ctx_ld, int32_t *lengths, int32_t *active,
                           float *log_weights, const float *logZ, const int32_t *token, int64_t n,
-                          int32_t eos_id, int32_t max_len, void *stream) {
+                          int32_t eos_id, int32_t max_len, uint64_t *hashes, void *stream) {
   if (!contexts || !lengths || !active || !log_weights || !logZ || !token)
     return fail(GLB_EINVAL, "null pointer");
   if (n <= 0 || ctx_ld <= 0 || max_len > ctx_ld) return fail(GLB_EINVAL, "bad sizes");
   hipLaunchKernelGGL(particles_advance_kernel, dim3(blocks_for(n, 256)), dim3(256), 0,
                      (hipStream_t)stream, contexts, ctx_ld, lengths, active, log_weights, logZ,
-                     token, n, eos_id, max_len);
+                     token, n, eos_id, max_len, hashes);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "particles_advance launch");
   return GLB_OK;

@@ -1182,17 +1182,19 @@ __global__ __launch_bounds__(256) void logprob_rows_kernel(const void *logits, i
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// log-probability rows in one launch: one 1024-thread workgroup per row.  Wave w reduces chunks w, w+16, ... of the
-// row (same per-chunk arithmetic as chunk_stats_kernel, records kept in LDS), one wave folds them into lse, then every
-// wave writes x - lse for its chunks: straight from its registers when the row has at most 16 chunks (ONE: a wave
-// owns one chunk - gpt2-sized rows), else after streaming them again (read microseconds ago: L2 / Infinity Cache serve
-// most of it).  HBM traffic ~ V*s + 4V per row instead of 2*V*s + 4V of the three-launch path; used when there are
-// enough rows to fill the chip (the three-launch path spreads a few rows over the chip chunk by chunk).
+// log-probability rows in one launch: one workgroup of WAVES waves per row.  Wave w reduces chunks w, w + WAVES, ... of
+// the row (the stats role's per-chunk arithmetic, records kept in LDS), one wave folds them into lse, then every wave
+// streams its chunks again - read microseconds ago: L2 / Infinity Cache serve them - and writes x - lse with
+// non-temporal stores (206 MB of output that nobody reads soon must not push the rows out of the caches before their
+// second reading).  HBM traffic ~ V*s + 4V per row.  Four waves per workgroup: four workgroups share a CU, so one row's
+// barrier / fold / store phases overlap the others' loads; round 2's sixteen-wave workgroup had the CU to itself and
+// idled it through every barrier (111 us at 1024 x 50257 fp32).  Used when there are enough rows to fill the chip (the
+// three-launch path spreads a few rows over the chip chunk by chunk).
 // ---------------------------------------------------------------------------------------------------------
-template <int DT, bool SCALED, bool ONE>
-__global__ __launch_bounds__(1024) void logprob_rows_fused_kernel(const void *logits, int64_t ld, int V, int nch,
-                                                                 float scale, float *out, int64_t out_ld,
-                                                                 float *out_lse) {
+template <int DT, bool SCALED, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void logprob_rows_fused_kernel(const void *logits, int64_t ld, int V, int nch,
+                                                                       float scale, float *out, int64_t out_ld,
+                                                                       float *out_lse) {
   constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC;
   extern __shared__ uint64_t s_rec[];  // [nch] chunk sums, then [nch] floats of chunk scales
   float *s_N = reinterpret_cast<float *>(s_rec + nch);
@@ -1201,7 +1203,7 @@ __global__ __launch_bounds__(1024) void logprob_rows_fused_kernel(const void *lo
   const int r = blockIdx.x;
   const char *rowp = (const char *)logits + (int64_t)r * ld * ES;
   float x[64];
-  for (int c = wave; c < nch; c += 16) {
+  for (int c = wave; c < nch; c += WAVES) {
     const int e_base = c * kChunk;
     int nv_valid = (V - e_base + 64 * EPV - 1) / (64 * EPV);
     nv_valid = nv_valid < NVC ? nv_valid : NVC;
@@ -1243,35 +1245,23 @@ __global__ __launch_bounds__(1024) void logprob_rows_fused_kernel(const void *lo
   if (!out) return;
   const float l = s_lse;
   float *orow = out + (int64_t)r * out_ld;
-  for (int c = wave; c < nch; c += 16) {
+  for (int c = wave; c < nch; c += WAVES) {
     const int e_base = c * kChunk;
+    load_chunk<DT, SCALED>(rowp, e_base, V, lane, scale, x);  // all the chunk's loads in flight, then all its stores
 #pragma unroll
     for (int i = 0; i < NVC; ++i) {
       const int e0 = e_base + (i * 64 + lane) * EPV;
       if (e0 >= V) continue;
-      float y[EPV];
-      if constexpr (ONE) {  // the wave's only chunk is still in its registers (already scaled)
-#pragma unroll
-        for (int k = 0; k < EPV; ++k) y[k] = x[i * EPV + k];
-      } else {
-        unpack_vec<DT>(load_vec_guarded<DT>(rowp, e0, V), y);
-        if constexpr (SCALED) {
-#pragma unroll
-          for (int k = 0; k < EPV; ++k) y[k] *= scale;
-        }
-      }
       if (e0 + EPV <= V) {
 #pragma unroll
         for (int h = 0; h < EPV / 4; ++h) {
-          float4 v;
-          v.x = y[4 * h] - l;
-          v.y = y[4 * h + 1] - l;
-          v.z = y[4 * h + 2] - l;
-          v.w = y[4 * h + 3] - l;
-          *reinterpret_cast<float4 *>(orow + e0 + 4 * h) = v;
+          typedef float f32x4_t __attribute__((ext_vector_type(4)));
+          const f32x4_t v{x[i * EPV + 4 * h] - l, x[i * EPV + 4 * h + 1] - l, x[i * EPV + 4 * h + 2] - l,
+                          x[i * EPV + 4 * h + 3] - l};
+          __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t *>(orow + e0 + 4 * h));
         }
       } else {
-        for (int k = 0; k < V - e0; ++k) orow[e0 + k] = y[k] - l;
+        for (int k = 0; k < V - e0; ++k) orow[e0 + k] = x[i * EPV + k] - l;
       }
     }
   }

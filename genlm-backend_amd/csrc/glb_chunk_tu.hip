@@ -115,7 +115,7 @@ template <bool SCALED>
 static void lsm_fused1(const void *logits, int64_t ld, int V, int nch, float scale, float *out, int64_t out_ld, float *out_lse,
                    int n_rows, hipStream_t s) {
   const size_t lds = (size_t)nch * (sizeof(uint64_t) + sizeof(float));
-  hipLaunchKernelGGL((logprob_rows_fused_kernel<GLB_DT, SCALED, false>), dim3((unsigned)n_rows), dim3(1024), lds, s, logits,
+  hipLaunchKernelGGL((logprob_rows_fused_kernel<GLB_DT, SCALED, 16>), dim3((unsigned)n_rows), dim3(1024), lds, s, logits,
                      ld, V, nch, scale, out, out_ld, out_lse);
 }
 

@@ -302,16 +302,26 @@ class HipEngine:
         return bits, flag
 
     # ------------------------------------------------------------------------------------------
-    def group_contexts(self, tokens, starts, lengths):
-        """Exact dedup, first-appearance order.  Returns (group_of[n], rep[n], n_groups[1]) on device."""
+    def hash_contexts(self, tokens, starts, lengths):
+        """The contexts' hashes (int64 tensor holding the 64-bit values) for `group_contexts(hashes=...)`; a context's
+        hash extends token by token (`particles_advance(hashes=...)` keeps it up to date)."""
         n = lengths.numel()
         self._check_dev(tokens, starts, lengths)
+        out = torch.empty(n, dtype=torch.int64, device=self.device)
+        check(self.lib.glb_hash_contexts(_ptr(tokens), _ptr(starts), _ptr(lengths), n, _ptr(out), self._stream()))
+        return out
+
+    def group_contexts(self, tokens, starts, lengths, hashes=None):
+        """Exact dedup, first-appearance order.  Returns (group_of[n], rep[n], n_groups[1]) on device.  `hashes`: the
+        contexts' hashes if the caller keeps them (hash_contexts); the tokens are then read only to confirm duplicates."""
+        n = lengths.numel()
+        self._check_dev(tokens, starts, lengths, hashes)
         need = self.lib.glb_group_contexts_workspace(n)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(max(need, 1 << 16), dtype=torch.uint8, device=self.device)
         group_of, rep, ng = self._i32(n), self._i32(n), self._i32(1)
-        check(self.lib.glb_group_contexts(_ptr(tokens), _ptr(starts), _ptr(lengths), n, _ptr(group_of), _ptr(rep),
-                                          _ptr(ng), _ptr(self._ws), self._ws.numel(), self._stream()))
+        check(self.lib.glb_group_contexts(_ptr(tokens), _ptr(starts), _ptr(lengths), n, _ptr(hashes), _ptr(group_of),
+                                          _ptr(rep), _ptr(ng), _ptr(self._ws), self._ws.numel(), self._stream()))
         return group_of, rep, ng
 
     def match_prefixes(self, tokens, starts, lengths, prefix_tokens, prefix_starts, prefix_lengths):
@@ -343,10 +353,10 @@ class HipEngine:
                                             self._stream()))
         return out
 
-    def particles_advance(self, contexts, lengths, active, log_weights, logZ, token, eos_id, max_len):
+    def particles_advance(self, contexts, lengths, active, log_weights, logZ, token, eos_id, max_len, hashes=None):
         n, ld = contexts.shape
         check(self.lib.glb_particles_advance(_ptr(contexts), ld, _ptr(lengths), _ptr(active), _ptr(log_weights),
-                                             _ptr(logZ), _ptr(token), n, eos_id, max_len, self._stream()))
+                                             _ptr(logZ), _ptr(token), n, eos_id, max_len, _ptr(hashes), self._stream()))
 
     def normalize_weights(self, log_weights):
         n = log_weights.numel()

@@ -194,6 +194,15 @@ class DeviceSIS:
         # active particles over all ranks as of the last exchange (device scalar; read with the step's one D2H copy)
         self._global_active = torch.tensor(self.N * self.world, dtype=torch.int32, device=self.dev)
         self.all_weights = None
+        self._rehash()
+
+    def _rehash(self):
+        """Context hashes for the per-step dedup: a context's hash extends token by token (glb_particles_advance keeps
+        it up to date), so the grouping never reads the contexts again except to confirm duplicates.  A finished
+        particle dedups as its 1-token stub: that hash is kept beside it."""
+        ctx_flat = self.contexts.view(-1)
+        self.hashes = self.eng.hash_contexts(ctx_flat, self.starts, self.lengths)
+        self._hash_stub = self.eng.hash_contexts(ctx_flat, self.starts, torch.ones_like(self.lengths))
 
     # -------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -280,7 +289,7 @@ class DeviceSIS:
             self.kernel_events.append(inner)
             self.outer_events.append((e0, e1))
         eng.particles_advance(self.contexts, self.lengths, self.active, self.log_weights, logZ, tok, self.eos_id,
-                              self.cap)
+                              self.cap, hashes=self.hashes)
         self.t += 1
         self.max_len_now = min(self.max_len_now + 1, self.cap)
         self.last_stats = dict(n_unique=U, n_active=n_active, l_max=l_max, n_rows=U)
@@ -321,7 +330,8 @@ class DeviceSIS:
             last = (self.lengths[rep[:U].long()] - 1).long()
             h_last = out.last_hidden_state[torch.arange(U, device=dev), last]
             return self._finish_step(llm._lm_head(h_last), group_of, U, n_active, n_global, time_kernel, self.max_len_now)
-        group_of, rep, ng = eng.group_contexts(ctx_flat, self.starts, lengths_eff)
+        hashes_eff = torch.where(self.active > 0, self.hashes, self._hash_stub)
+        group_of, rep, ng = eng.group_contexts(ctx_flat, self.starts, lengths_eff, hashes=hashes_eff)
         self._rep = rep
         head = torch.stack([ng[0], self.active.sum().to(torch.int32), self._global_active]).cpu()  # the step's one D2H copy
         U, n_active, n_global = int(head[0]), int(head[1]), int(head[2])
@@ -413,6 +423,7 @@ class DeviceSIS:
             self.pkv.gather(src, kv_len)
             stale = ~is_local
             self._kv_stale = stale if bool(stale.any().item()) else None
+        self._rehash()  # contexts moved between slots (and ranks): one launch, once per resampling step
         self.n_resamples += 1
         self._exchange()
 

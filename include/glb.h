@@ -191,11 +191,16 @@ int glb_mask_f32_to_bits(const float *mask, int64_t n_masks, int64_t vocab, int6
  *   out_rep      [n]   out_rep[g] = smallest context index in group g (only [0, n_groups) valid)
  *   out_n_groups [1]   device int32
  * workspace: device scratch of at least glb_group_contexts_workspace(n) bytes.
+ * ctx_hashes (nullable, [n] device): the contexts' hashes as glb_hash_contexts makes them and glb_particles_advance
+ * keeps them up to date - a context's hash extends token by token, so a loop that only appends never reads its
+ * contexts again to group them (the grouping itself is by exact comparison: hashes only place the slots).
  */
 size_t glb_group_contexts_workspace(int64_t n);
 int glb_group_contexts(const int32_t *tokens, const int64_t *starts, const int32_t *lengths,
-                       int64_t n, int32_t *out_group_of, int32_t *out_rep, int32_t *out_n_groups,
-                       void *workspace, size_t workspace_bytes, void *hip_stream);
+                       int64_t n, const uint64_t *ctx_hashes, int32_t *out_group_of, int32_t *out_rep,
+                       int32_t *out_n_groups, void *workspace, size_t workspace_bytes, void *hip_stream);
+int glb_hash_contexts(const int32_t *tokens, const int64_t *starts, const int32_t *lengths, int64_t n,
+                      uint64_t *out_hashes, void *hip_stream);
 
 /*
  * Cached-prefix match ("trie grouping"): for every context pick the longest cached prefix that
@@ -242,11 +247,12 @@ int glb_gather_kv_padded(const void *const *slabs, const int32_t *slab_len, int6
  * Particle bookkeeping of the SIS loop (README.md:82-91): for every particle that is active,
  *   log_weight += logZ; if token == eos_id (or token < 0) active = 0
  *   else tokens[i, length[i]++] = token; and a context that reaches max_len is deactivated.
- * `contexts` is the padded [n, ctx_ld] int32 matrix the ragged views are cut from.
+ * `contexts` is the padded [n, ctx_ld] int32 matrix the ragged views are cut from.  ctx_hashes (nullable, [n]): the
+ * contexts' hashes (glb_hash_contexts), extended by the appended token.
  */
 int glb_particles_advance(int32_t *contexts, int64_t ctx_ld, int32_t *lengths, int32_t *active,
                           float *log_weights, const float *logZ, const int32_t *token, int64_t n,
-                          int32_t eos_id, int32_t max_len, void *hip_stream);
+                          int32_t eos_id, int32_t max_len, uint64_t *ctx_hashes, void *hip_stream);
 
 /*
  * Weight normalisation over the full particle population (README.md:108-110) on the all-gathered

@@ -78,7 +78,25 @@ class CpuOracleEngine:
         t, s, l = _np(tokens), _np(starts), _np(lengths)
         return [list(t[s[i]:s[i] + l[i]]) for i in range(len(l))]
 
-    def group_contexts(self, tokens, starts, lengths):
+    @staticmethod
+    def _hash(ctx):
+        """The library's context hash (glb_api.hip ctx_hash_step): an FNV-style fold, one token at a time."""
+        M = (1 << 64) - 1
+        h = 0xcbf29ce484222325
+        for t in ctx:
+            h ^= int(t) & 0xffffffff
+            h = (h * 0x100000001b3) & M
+            h ^= h >> 29
+        return h
+
+    def hash_contexts(self, tokens, starts, lengths):
+        hs = [self._hash(c) for c in self._ctxs(tokens, starts, lengths)]
+        return torch.from_numpy(np.array(hs, np.uint64).view(np.int64).copy())
+
+    def group_contexts(self, tokens, starts, lengths, hashes=None):
+        if hashes is not None:  # hashes kept by the caller must be the hashes of the contexts it passes
+            want = self.hash_contexts(tokens, starts, lengths)
+            assert torch.equal(hashes.cpu(), want), "stale context hashes"
         g, rep, ng = O.group_contexts(self._ctxs(tokens, starts, lengths))
         rep_full = np.zeros(len(g), np.int32)
         rep_full[:ng] = rep
@@ -121,9 +139,17 @@ class CpuOracleEngine:
                                      C.c_void_p(out.data_ptr()))
         return out
 
-    def particles_advance(self, contexts, lengths, active, log_weights, logZ, token, eos_id, max_len):
+    def particles_advance(self, contexts, lengths, active, log_weights, logZ, token, eos_id, max_len, hashes=None):
         c, l, a, w = _np(contexts), _np(lengths), _np(active), _np(log_weights)
+        l_before = l.copy()
         O.particles_advance(c, l, a, w, _np(logZ), _np(token), eos_id, max_len)
+        if hashes is not None:
+            M = (1 << 64) - 1
+            hv = hashes.numpy().view(np.uint64)
+            for i in np.nonzero(l != l_before)[0]:
+                h = int(hv[i]) ^ (int(c[i, l_before[i]]) & 0xffffffff)
+                h = (h * 0x100000001b3) & M
+                hv[i] = h ^ (h >> 29)
         contexts.copy_(torch.from_numpy(c))
         lengths.copy_(torch.from_numpy(l))
         active.copy_(torch.from_numpy(a))

@@ -42,7 +42,7 @@ def test_argument_errors_do_not_touch_the_gpu():
     assert lib.glb_step_workspace_bytes(1024, 1024, 50257, 2) >= 1024 * 13 * 32
     assert lib.glb_mask_prepared_bytes(2, 50257) >= 2 * 13 * 512
     assert lib.glb_log_softmax_workspace_bytes(8, 50257) >= 8 * 13 * 32
-    assert lib.glb_group_contexts(None, None, None, 4, None, None, None, None, 0, None) == _lib.GLB_EINVAL
+    assert lib.glb_group_contexts(None, None, None, 4, None, None, None, None, None, 0, None) == _lib.GLB_EINVAL
     assert lib.glb_group_contexts_workspace(1024) >= 1024 * 4 * 4
 
 

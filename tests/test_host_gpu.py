@@ -509,3 +509,36 @@ def test_shared_noise_row_step(engine, oracle, dtype):
         for w, g in zip(want[:3], got):
             assert np.array_equal(g.cpu().numpy().view(np.uint32), w.view(np.uint32))
         assert np.array_equal(margin.cpu().numpy().view(np.uint32), want[3].view(np.uint32))
+
+
+def test_context_hashes_extend_token_by_token(engine, oracle):
+    """glb_hash_contexts == the fold the CPU double states; glb_particles_advance extends a context's hash by the
+    appended token; glb_group_contexts with the caller's hashes groups exactly like the oracle (and like itself
+    without them)."""
+    from tests.cpu_engine import CpuOracleEngine
+
+    rng = np.random.default_rng(4)
+    n, cap = 1024, 24
+    mat = rng.integers(0, 7, size=(n, cap)).astype(np.int32)
+    ln = rng.integers(1, 6, size=n).astype(np.int32)
+    dev = engine.device
+    ctx = _dev(mat, dev)
+    st = _dev(np.arange(n, dtype=np.int64) * cap, dev)
+    ln_d = _dev(ln, dev)
+    h = engine.hash_contexts(ctx.view(-1), st, ln_d)
+    want = np.array([CpuOracleEngine._hash(mat[i, :ln[i]]) for i in range(n)], np.uint64)
+    assert np.array_equal(h.cpu().numpy().view(np.uint64), want)
+    # three appended tokens (some particles stop on the way)
+    active = torch.ones(n, dtype=torch.int32, device=dev)
+    lw = torch.zeros(n, device=dev)
+    for step in range(3):
+        tok = _dev(rng.integers(0, 7, size=n).astype(np.int32), dev)
+        engine.particles_advance(ctx, ln_d, active, lw, torch.zeros(n, device=dev), tok, 0, cap, hashes=h)
+        mat2, ln2 = ctx.cpu().numpy(), ln_d.cpu().numpy()
+        want = np.array([CpuOracleEngine._hash(mat2[i, :ln2[i]]) for i in range(n)], np.uint64)
+        assert np.array_equal(h.cpu().numpy().view(np.uint64), want)
+        g_o, rep_o, ng_o = oracle.group_contexts([list(mat2[i, :ln2[i]]) for i in range(n)])
+        for hashes in (h, None):
+            g, rep, ng = engine.group_contexts(ctx.view(-1), st, ln_d, hashes=hashes)
+            assert int(ng.item()) == ng_o and np.array_equal(g.cpu().numpy(), g_o)
+            assert np.array_equal(rep.cpu().numpy()[:ng_o], rep_o)
