@@ -195,12 +195,17 @@ __device__ __forceinline__ void store_rec(uint64_t *dst, uint32_t epoch, int lan
     __hip_atomic_store(dst + lane, ((uint64_t)epoch << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// one record in; true when every granule carries `epoch`
+// one record in; true when every granule carries `epoch`.  COHERENT: agent-scope loads (past the L1: the stats waves of
+// this very launch may still be writing); otherwise plain loads - records of an earlier launch, and when a thousand
+// particles share one row (SIS step 0) the CU's L1 serves all but the first sweep.
+template <bool COHERENT>
 __device__ __forceinline__ bool load_rec(const uint64_t *src, uint32_t epoch, ChunkRec &r) {
   uint64_t g[12];
 #pragma unroll
-  for (int k = 0; k < 12; ++k)
-    g[k] = __hip_atomic_load(const_cast<uint64_t *>(src) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int k = 0; k < 12; ++k) {
+    if constexpr (COHERENT) g[k] = __hip_atomic_load(const_cast<uint64_t *>(src) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else g[k] = src[k];
+  }
   bool ok = true;
 #pragma unroll
   for (int k = 0; k < 12; ++k) ok = ok && (uint32_t)(g[k] >> 32) == epoch;
@@ -687,7 +692,7 @@ struct Recs {
   __device__ __forceinline__ ChunkRec get(int c) const {  // always called with c = c0 + lane
     if (cached) return mine;
     ChunkRec r;
-    load_rec(base + (int64_t)c * kRecWords, epoch, r);
+    load_rec<true>(base + (int64_t)c * kRecWords, epoch, r);
     return r;
   }
 };
@@ -706,7 +711,7 @@ __device__ __forceinline__ bool recs_acquire(Recs &R, int nch, int lane) {
     for (;;) {
       bool ok = true;
       ChunkRec r = ChunkRec{kNegInf, kNegInf, 0u, 0u, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, 0u, 0u};
-      if (c < nch) ok = load_rec(R.base + (int64_t)c * kRecWords, R.epoch, r);
+      if (c < nch) ok = load_rec<POLL>(R.base + (int64_t)c * kRecWords, R.epoch, r);
       if (c0 == 0) R.mine = r;
       if constexpr (!POLL) break;
       if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
