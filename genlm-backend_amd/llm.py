@@ -21,7 +21,7 @@ from abc import ABC, abstractmethod
 import numpy as np
 import torch
 
-from .cache import KVPrefix, TokenTrie
+from .cache import KVPrefix, RowLRU, TokenTrie
 from .tokenization import decode_vocab
 
 MASK_NONE, MASK_BITS, MASK_F32 = 0, 1, 2
@@ -188,7 +188,7 @@ class AsyncAmdLM(AsyncLM):
 
     @torch.no_grad()
     def __init__(self, hf_model, hf_tokenizer, batch_size=20, timeout=0.02, engine=None, fuse_activations=True,
-                 kv_budget_bytes=8 << 30):
+                 kv_budget_bytes=8 << 30, logprob_budget_bytes=16 << 30):
         self.model = hf_model
         self.tokenizer = hf_tokenizer
         self.device = hf_model.device
@@ -218,6 +218,8 @@ class AsyncAmdLM(AsyncLM):
         # prompt prefixes pinned by cache_kv, least recently used out first; an entry that leaves the store takes its
         # token tuple and the device prefix table (which holds pointers into its slabs) with it
         self._kv_lru = PrefixLRU(kv_budget_bytes, on_remove=self._forget_prefix)
+        # log-prob rows on trie nodes: views into their batch's [R, V] slab, least recently used slab out first
+        self._rows = RowLRU(logprob_budget_bytes)
         # fused-step state
         self._mask_kind = MASK_NONE
         self._masks = None
@@ -240,6 +242,7 @@ class AsyncAmdLM(AsyncLM):
     def clear_cache(self):
         self._kv_lru.clear()
         self._kv_tokens.clear()
+        self._rows.clear()
         self.cache = TokenTrie()
 
     def clear_kv_cache(self):
@@ -261,7 +264,7 @@ class AsyncAmdLM(AsyncLM):
         ids = torch.tensor([prompt_tokens], device=self.device)
         out = self._body(input_ids=ids, use_cache=True)
         logits = self._lm_head(out.last_hidden_state[0])
-        node = self.cache.extend_cache(0, prompt_tokens, logits, 0, engine=self.engine)
+        node = self.cache.extend_cache(0, prompt_tokens, logits, 0, engine=self.engine, store=self._rows)
         # (re-created ancestors: an older, shorter prefix whose node was replaced on the way is unreachable from the
         # trie now and would only hold memory)
         reach = set()
@@ -531,6 +534,7 @@ class AsyncAmdLM(AsyncLM):
     def walk_cache(self, token_ids):
         """hf.py:314-344: deepest matching node, tokens matched, deepest KV on the way and its depth."""
         node = self.cache
+        prev = None
         next_token_index = 0
         past = None
         base = 0
@@ -540,10 +544,15 @@ class AsyncAmdLM(AsyncLM):
                 base = next_token_index
                 self._kv_lru.touch(node)
             if node.has_token(token_ids[next_token_index]):
-                node = node.get_token(token_ids[next_token_index])
+                prev, node = node, node.get_token(token_ids[next_token_index])
                 next_token_index += 1
             else:
                 break
+        if next_token_index == len(token_ids) and prev is not None:
+            if node.logprobs is None:  # the row was evicted under the byte budget (RowLRU): a miss on the last position
+                node, next_token_index = prev, next_token_index - 1
+            else:
+                self._rows.touch(node)
         return node, next_token_index, past, base
 
     async def next_token_logprobs(self, token_ids):
@@ -557,7 +566,7 @@ class AsyncAmdLM(AsyncLM):
         self.add_query(token_ids[base:], future, past, first_new=next_token_index - base)
         rows, first = await future
         node = node.extend_cache_rows(next_token_index, token_ids, rows[next_token_index - base - first:],
-                                      next_token_index)
+                                      next_token_index, store=self._rows)
         return node.logprobs
 
     def _evaluate_one(self, prompt, past, first_new):
@@ -590,7 +599,7 @@ class AsyncAmdLM(AsyncLM):
         if next_token_index == len(token_ids):
             return node.logprobs
         rows, first = self._evaluate_one(token_ids[base:], past, next_token_index - base)
-        node = node.extend_cache_rows(next_token_index, token_ids, rows, next_token_index)
+        node = node.extend_cache_rows(next_token_index, token_ids, rows, next_token_index, store=self._rows)
         return node.logprobs
 
     @torch.no_grad()
@@ -753,21 +762,22 @@ class AsyncAmdLM(AsyncLM):
             def set_exception(self, e):
                 raise e
 
-        pending, nodes = [], [None] * len(token_ids_list)
+        pending, nodes = [], [None] * len(token_ids_list)  # nodes[i]: the ROW of context i (held: the budget may evict)
         for i, token_ids in enumerate(token_ids_list):
             if not token_ids:
                 raise ValueError("Token ids must not be empty")
             node, nti, past, base = self.walk_cache(token_ids)
             if nti == len(token_ids):
-                nodes[i] = node
+                nodes[i] = node.logprobs
             else:
                 pending.append((i, node, nti, base, Query(token_ids[base:], _Slot(), past, first_new=nti - base)))
         if pending:
             self._evaluate([q for *_, q in pending])
             for i, node, nti, base, q in pending:
                 rows, first = q.future.value
-                nodes[i] = node.extend_cache_rows(nti, token_ids_list[i], rows[nti - base - first:], nti)
-        return torch.stack([nd.logprobs for nd in nodes])
+                nodes[i] = node.extend_cache_rows(nti, token_ids_list[i], rows[nti - base - first:], nti,
+                                                  store=self._rows).logprobs
+        return torch.stack(nodes)
 
     async def batch_next_token_logprobs(self, token_ids_list):
         """base.py:47-60 (one batched evaluation instead of a gather over per-context coroutines)"""

@@ -251,6 +251,28 @@ def test_prefix_kv_is_evicted_least_recently_used_first(llm):
         assert np.abs(row.numpy() - llm.next_token_logprobs_uncached(p).numpy()).max() < TOL
 
 
+def test_logprob_rows_stay_under_the_byte_budget(llm):
+    """50 steps of a growing population of contexts: the trie's log-prob rows never exceed the budget by more than the
+    newest slab, evicted rows are recomputed on demand and equal the first computation."""
+    V = llm.model.config.vocab_size
+    rng = np.random.default_rng(0)
+    ctxs = [[int(t) for t in rng.integers(1, V, 3)] for _ in range(48)]
+    first = asyncio.run(llm.batch_next_token_logprobs(ctxs)).clone()
+    slab = llm._rows.used
+    llm._rows.budget = int(slab * 2.5)
+    peak = 0
+    for step in range(50):
+        ctxs2 = [c + [int(rng.integers(1, V))] * (1 + step % 3) for c in ctxs]
+        asyncio.run(llm.batch_next_token_logprobs(ctxs2))
+        peak = max(peak, llm._rows.used)
+    assert llm._rows.evictions > 10
+    assert peak <= llm._rows.budget + 4 * slab  # (one batch's slab holds every new position: up to 3 per context)
+    again = asyncio.run(llm.batch_next_token_logprobs(ctxs))  # rows of step 0 were evicted long ago: recomputed
+    assert np.abs(again.numpy() - first.numpy()).max() < 1e-5
+    one = asyncio.run(llm.next_token_logprobs(ctxs[0]))
+    assert np.abs(one.numpy() - first[0].numpy()).max() < 1e-5
+
+
 def test_prefix_store_bookkeeping(llm):
     """Caching a prompt again, or one that re-creates its leading nodes, must not leave orphaned entries under the
     budget; evicted entries take their token tuple and the device prefix table with them; the batched path counts

@@ -542,3 +542,32 @@ def test_context_hashes_extend_token_by_token(engine, oracle):
             g, rep, ng = engine.group_contexts(ctx.view(-1), st, ln_d, hashes=hashes)
             assert int(ng.item()) == ng_o and np.array_equal(g.cpu().numpy(), g_o)
             assert np.array_equal(rep.cpu().numpy()[:ng_o], rep_o)
+
+
+def test_logprob_rows_stay_under_the_byte_budget_on_gpu(llm):
+    """50 steps of 1024 contexts through batch_next_token_logprobs with a 24 MB budget for the trie's log-prob rows:
+    the store never holds more than the budget plus the newest slab, device memory does not grow with the steps, and
+    an evicted row is recomputed on demand."""
+    m, _ = llm
+    V = m.model.config.vocab_size
+    rng = np.random.default_rng(1)
+    ctxs = [[int(t) for t in rng.integers(1, V, 4)] for _ in range(1024)]
+    first = asyncio.run(m.batch_next_token_logprobs(ctxs)).clone()
+    slab = m._rows.used
+    assert slab >= 1024 * V * 4
+    m._rows.budget = 24 << 20
+    torch.cuda.synchronize()
+    base_mem, peak_store, mems = torch.cuda.memory_allocated(), 0, []
+    for step in range(50):
+        ctxs2 = [c + [int(t)] for c, t in zip(ctxs, rng.integers(1, V, len(ctxs)))]
+        rows = asyncio.run(m.batch_next_token_logprobs(ctxs2))
+        assert rows.shape == (1024, V)
+        del rows
+        peak_store = max(peak_store, m._rows.used)
+        torch.cuda.synchronize()
+        mems.append(torch.cuda.memory_allocated())
+    assert m._rows.evictions >= 40
+    assert peak_store <= m._rows.budget + 3 * slab
+    assert max(mems[10:]) - min(mems[10:]) < 8 * slab and max(mems) - base_mem < m._rows.budget + 12 * slab
+    again = asyncio.run(m.batch_next_token_logprobs(ctxs[:64]))
+    assert np.abs(again.cpu().numpy() - first[:64].cpu().numpy()).max() < 1e-5
