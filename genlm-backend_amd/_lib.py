@@ -84,7 +84,7 @@ SYMBOLS = {
     "glb_gather_kv_padded": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp]),
     "glb_particles_advance": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "glb_normalize_weights": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
-    "glb_kv_append": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
+    "glb_kv_append": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
     "glb_kv_gather_rows": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _i32, _vp]),
     "glb_gather_rows_i32": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),
     "glb_trie_workspace": (_sz, [_i64, _i64]),

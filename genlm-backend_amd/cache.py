@@ -45,7 +45,7 @@ class RowLRU:
             _, (nb, old) = self._od.popitem(last=False)
             for nd in old:
                 if nd.slab is not None:
-                    nd.logprobs = None
+                    nd._rows = None
                     nd.slab = None
             self.used -= nb
             self.evictions += 1
@@ -86,13 +86,28 @@ class KVPrefix:
 class TokenTrie:
     """cache.py:47-100.  `logprobs` is the next-token log-probability row after the path to this node."""
 
-    __slots__ = ("children", "logprobs", "past_key_values", "slab")
+    __slots__ = ("children", "_rows", "_idx", "past_key_values", "slab")
 
-    def __init__(self, parent=None, logprobs=None):
+    def __init__(self, parent=None, logprobs=None, idx=-1):
         self.children = {}
-        self.logprobs = logprobs
+        # the row is kept as (tensor, index) and cut out on access: a batch hands over thousands of rows of one slab,
+        # and a torch view per row costs more than the node itself
+        self._rows = logprobs
+        self._idx = idx
         self.past_key_values = None
         self.slab = None  # RowLRU key of the slab `logprobs` points into
+
+    @property
+    def logprobs(self):
+        r = self._rows
+        if r is None or self._idx < 0:
+            return r
+        return r[self._idx]
+
+    @logprobs.setter
+    def logprobs(self, value):
+        self._rows = value
+        self._idx = -1
 
     def __repr__(self):
         inner = ", ".join(f"{t}: {n!r}" for t, n in self.children.items())
@@ -109,14 +124,14 @@ class TokenTrie:
     def get_token(self, token_id):
         return self.children[token_id]
 
-    def add_token(self, token_id, logprobs=None):
+    def add_token(self, token_id, logprobs=None, idx=-1):
         # like the reference (cache.py:86-88) an existing child is replaced - unless it only lost its row to the byte
-        # budget (RowLRU): then it gets the row back and keeps what hangs below it
+        # budget (RowLRU): then it gets the row back and keeps what hangs below it.  idx >= 0: the row is logprobs[idx].
         old = self.children.get(token_id)
-        if old is not None and old.logprobs is None:
-            old.logprobs = logprobs
+        if old is not None and old._rows is None:
+            old._rows, old._idx = logprobs, idx
             return old
-        node = TokenTrie(self, logprobs)
+        node = TokenTrie(self, logprobs, idx)
         self.children[token_id] = node
         return node
 
@@ -126,7 +141,7 @@ class TokenTrie:
         node = self
         made = []
         for j in range(next_token_index, len(token_ids)):
-            node = node.add_token(token_ids[j], logprob_rows[j - first_row_index])
+            node = node.add_token(token_ids[j], logprob_rows, j - first_row_index)
             made.append(node)
         if store is not None and made:
             store.add(logprob_rows, made)

@@ -598,16 +598,17 @@ __global__ __launch_bounds__(1024) void normalize_weights_kernel(const float *lw
 
 // ---- device-resident particle state: KV slabs, resampling ---------------------------------------------------
 
-// slab[i, h, pos[i], :] = rows[i, h, :]  (one new token per particle; rows may be a strided view)
+// slab[row_of[i] (or i), h, pos[i], :] = rows[i, h, :]  (one new token per forward row; rows may be a strided view)
 template <typename VT>
-__global__ void kv_append_kernel(VT *slab, const VT *rows, const int32_t *pos, int64_t n_rows, int64_t heads,
-                                 int64_t cap, int64_t row_vecs, int64_t rows_stride_row, int64_t rows_stride_head) {
+__global__ void kv_append_kernel(VT *slab, const VT *rows, const int32_t *pos, const int32_t *row_of, int64_t n_rows,
+                                 int64_t heads, int64_t cap, int64_t row_vecs, int64_t rows_stride_row,
+                                 int64_t rows_stride_head) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= n_rows * heads * row_vecs) return;
   const int64_t x = gid % row_vecs, h = (gid / row_vecs) % heads, i = gid / (row_vecs * heads);
-  const int64_t p = pos[i];
-  if (p < 0 || p >= cap) return;
-  slab[((i * heads + h) * cap + p) * row_vecs + x] = rows[i * rows_stride_row + h * rows_stride_head + x];
+  const int64_t p = pos[i], r = row_of ? (int64_t)row_of[i] : i;
+  if (p < 0 || p >= cap || r < 0) return;
+  slab[((r * heads + h) * cap + p) * row_vecs + x] = rows[i * rows_stride_row + h * rows_stride_head + x];
 }
 
 // dst[t][i, h, p, :] = src[t][src_row_of[i], h, p, :] for p < len_of[i]; src_row_of[i] < 0 leaves row i alone.
@@ -1280,9 +1281,9 @@ int glb_normalize_weights(const float *log_weights, int64_t n, float *out_probs,
   return GLB_OK;
 }
 
-int glb_kv_append(void *slab, const void *new_rows, const int32_t *pos, int64_t n_rows, int64_t heads, int64_t cap,
-                  int64_t head_dim, int64_t new_stride_row, int64_t new_stride_head, int32_t elem_bytes,
-                  void *stream) {
+int glb_kv_append(void *slab, const void *new_rows, const int32_t *pos, const int32_t *row_of, int64_t n_rows,
+                  int64_t heads, int64_t cap, int64_t head_dim, int64_t new_stride_row, int64_t new_stride_head,
+                  int32_t elem_bytes, void *stream) {
   if (!slab || !new_rows || !pos) return fail(GLB_EINVAL, "null pointer");
   if (n_rows <= 0 || heads <= 0 || cap <= 0 || head_dim <= 0) return fail(GLB_EINVAL, "bad sizes");
   if (elem_bytes != 2 && elem_bytes != 4) return fail(GLB_EINVAL, "elem_bytes must be 2 or 4");
@@ -1293,16 +1294,16 @@ int glb_kv_append(void *slab, const void *new_rows, const int32_t *pos, int64_t 
   if (wide) {
     const int64_t rv = rowb / 16, total = n_rows * heads * rv;
     hipLaunchKernelGGL(kv_append_kernel<uint4>, dim3(blocks_for(total, 256)), dim3(256), 0, s, (uint4 *)slab,
-                       (const uint4 *)new_rows, pos, n_rows, heads, cap, rv, new_stride_row * elem_bytes / 16,
+                       (const uint4 *)new_rows, pos, row_of, n_rows, heads, cap, rv, new_stride_row * elem_bytes / 16,
                        new_stride_head * elem_bytes / 16);
   } else if (elem_bytes == 4) {
     const int64_t total = n_rows * heads * head_dim;
     hipLaunchKernelGGL(kv_append_kernel<uint32_t>, dim3(blocks_for(total, 256)), dim3(256), 0, s, (uint32_t *)slab,
-                       (const uint32_t *)new_rows, pos, n_rows, heads, cap, head_dim, new_stride_row, new_stride_head);
+                       (const uint32_t *)new_rows, pos, row_of, n_rows, heads, cap, head_dim, new_stride_row, new_stride_head);
   } else {
     const int64_t total = n_rows * heads * head_dim;
     hipLaunchKernelGGL(kv_append_kernel<uint16_t>, dim3(blocks_for(total, 256)), dim3(256), 0, s, (uint16_t *)slab,
-                       (const uint16_t *)new_rows, pos, n_rows, heads, cap, head_dim, new_stride_row, new_stride_head);
+                       (const uint16_t *)new_rows, pos, row_of, n_rows, heads, cap, head_dim, new_stride_row, new_stride_head);
   }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "kv_append launch");

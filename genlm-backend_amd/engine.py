@@ -365,12 +365,15 @@ class HipEngine:
         return probs, stats
 
     # ---- device-resident particle state ------------------------------------------------------------------
-    def kv_append(self, slab, new_rows, pos):
-        """slab[i, h, pos[i], :] = new_rows[i, h, 0, :] (glb_kv_append).  slab [n, H, cap, Dh] contiguous; new_rows
-        [n, H, 1, Dh] with unit inner stride (usually a transposed view of the projection output)."""
-        n, H, cap, Dh = slab.shape
+    def kv_append(self, slab, new_rows, pos, rows=None):
+        """slab[rows[i] (or i), h, pos[i], :] = new_rows[i, h, 0, :] (glb_kv_append).  slab [R, H, cap, Dh] contiguous;
+        new_rows [n, H, 1, Dh] with unit inner stride (usually a transposed view of the projection output); rows: int32
+        [n] slab row of every forward row (shared KV rows), None: row i."""
+        R, H, cap, Dh = slab.shape
+        n = new_rows.shape[0]
         assert new_rows.shape == (n, H, 1, Dh) and new_rows.stride(3) == 1 and slab.is_contiguous()
-        check(self.lib.glb_kv_append(_ptr(slab), _ptr(new_rows), _ptr(pos), n, H, cap, Dh, new_rows.stride(0),
+        assert rows is not None or n == R
+        check(self.lib.glb_kv_append(_ptr(slab), _ptr(new_rows), _ptr(pos), _ptr(rows), n, H, cap, Dh, new_rows.stride(0),
                                      new_rows.stride(1), slab.element_size(), self._stream()))
 
     def kv_gather_rows(self, srcs, dsts, src_row_of, len_of):

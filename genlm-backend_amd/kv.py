@@ -99,6 +99,75 @@ class SlabKV(Cache):
         return sum(t.numel() * t.element_size() for t in self._tensors(self.layers) if t is not None) * (2 if self._alt else 1)
 
 
+class _SharedLayer(_SlabLayer):
+    """One layer of `SharedSlabKV`: the forward's batch row u lives in slab row `owner.rows[u]`; attention reads the
+    forward's rows from the staging slabs `owner.stage()` filled them into."""
+
+    def lazy_initialization(self, key_states, value_states):
+        o = self.owner
+        for name, st in (("keys", key_states), ("values", value_states)):
+            shape = (o.n, st.shape[1], o.cap, st.shape[-1])
+            setattr(self, name, torch.zeros(shape, dtype=st.dtype, device=st.device))
+            setattr(self, "stage_" + name, torch.zeros(shape, dtype=st.dtype, device=st.device))
+        self.is_initialized = True
+
+    def update(self, key_states, value_states, *args, **kwargs):
+        o = self.owner
+        U = o.rows.numel()
+        if key_states.shape[0] != U or key_states.shape[-2] != 1:
+            raise ValueError("SharedSlabKV takes one new token for every row of the forward")
+        eng = o.engine
+        # the new token's K / V: into the row that keeps it, and beside the gathered prefix the attention reads
+        eng.kv_append(self.keys, key_states, o.pos, rows=o.rows)
+        eng.kv_append(self.values, value_states, o.pos, rows=o.rows)
+        eng.kv_append(self.stage_keys, key_states, o.pos, rows=o.ident[:U])
+        eng.kv_append(self.stage_values, value_states, o.pos, rows=o.ident[:U])
+        return self.stage_keys[:U], self.stage_values[:U]
+
+
+class SharedSlabKV(SlabKV):
+    """KV rows SHARED between particles (the reference's per-token KV on trie nodes, cache.py:103-191,
+    restated for a population): `n` slab rows of `cap` positions, a block table outside (DeviceSIS.row_of) that maps
+    particles to rows.  Particles with the same context point to ONE row and one forward row serves them all; when a
+    shared row's particles draw different tokens, one keeps the row and the others get a copy of the prefix into free
+    rows (copy-on-append, one gather launch over all layers); resampling re-points particles to their ancestors' rows
+    and copies nothing.  A forward names its batch's rows (`set_forward`): one gather launch brings their prefixes - all
+    layers, K and V - into staging slabs in batch order (the PyTorch attention wants a dense [U, H, cap, Dh]), the new
+    token's K / V go into the row that keeps them and beside the gathered prefix."""
+
+    def __init__(self, engine, n_rows, cap, n_layers):
+        Cache.__init__(self, layers=[_SharedLayer(self, i) for i in range(n_layers)])
+        self.engine, self.n, self.cap = engine, n_rows, cap
+        self.pos = None
+        self.rows = None   # int32 [U]: slab row of every forward row
+        self.ident = None  # int32 arange(n)
+        self._alt = None
+        self._ptrs = None
+
+    def set_forward(self, rows, pos):
+        """rows, pos: int32 [U] device.  Gathers the U prefixes (pos[u] positions of row rows[u]) into the staging slabs."""
+        self.rows, self.pos = rows, pos
+        U = rows.numel()
+        if self.ident is None:
+            self.ident = torch.arange(self.n, dtype=torch.int32, device=rows.device)
+        src_row_of = torch.full((self.n,), -1, dtype=torch.int32, device=rows.device)
+        src_row_of[:U] = rows
+        len_of = torch.zeros(self.n, dtype=torch.int32, device=rows.device)
+        len_of[:U] = pos
+        slabs = self._tensors(self.layers)
+        stage = [t for layer in self.layers for t in (layer.stage_keys, layer.stage_values)]
+        self.engine.kv_gather_rows(slabs, stage, src_row_of, len_of)
+
+    def copy_rows(self, src_row_of, len_of):
+        """Row r with src_row_of[r] >= 0 takes the first len_of[r] positions of row src_row_of[r] (in place: sources
+        are live rows, destinations free ones)."""
+        cur = self._tensors(self.layers)
+        self.engine.kv_gather_rows(cur, cur, src_row_of, len_of)
+
+    def nbytes(self):
+        return 2 * sum(t.numel() * t.element_size() for t in self._tensors(self.layers) if t is not None)
+
+
 class PrefixLRU:
     """Least-recently-used store of cached prompt prefixes under a byte budget.  Keys are trie nodes; evicting an entry
     drops the node's `past_key_values` (the log-prob rows stay), so later queries fall back to re-encoding."""

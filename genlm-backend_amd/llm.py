@@ -354,6 +354,14 @@ class AsyncAmdLM(AsyncLM):
     def _evaluate(self, queries):
         eng, dev = self.engine, self.device
         n = len(queries)
+        if all(q.kind == "step" and q.past is None for q in queries):
+            # a population of README particles (README.md:82-91) and no cached prefix: the whole batch goes through the
+            # vectorised pipeline of batch_next_token_step_sync - three host arrays in, two out, one loop to resolve
+            logZ, tok = self.batch_next_token_step_sync([q.prompt for q in queries], [q.mask_id for q in queries])
+            for q, z, t in zip(queries, logZ.tolist(), tok.tolist()):
+                if q.future is not None and not q.future.done():
+                    q.future.set_result((z, t))
+            return
         # -- flatten: context i = [prefix slot, past_len, prompt...]; two header words make the dedup key
         #    (hf.py:216 keys on the prompt only; adding the prefix identity cannot merge unequal requests)
         prefixes, prefix_slot = [], {}
@@ -549,7 +557,7 @@ class AsyncAmdLM(AsyncLM):
             else:
                 break
         if next_token_index == len(token_ids) and prev is not None:
-            if node.logprobs is None:  # the row was evicted under the byte budget (RowLRU): a miss on the last position
+            if node._rows is None:  # the row was evicted under the byte budget (RowLRU): a miss on the last position
                 node, next_token_index = prev, next_token_index - 1
             else:
                 self._rows.touch(node)
@@ -617,9 +625,11 @@ class AsyncAmdLM(AsyncLM):
         draw from the masked, renormalised distribution; token is -1 if the mask forbids everything."""
         if not token_ids:
             raise ValueError("Token ids must not be empty")
-        _node, _n, past, base = self.walk_cache(token_ids)
+        past, base = None, 0
+        if len(self._kv_lru):  # the trie walk only serves to find a cached KV prefix: none cached, nothing to find
+            _node, _n, past, base = self.walk_cache(token_ids)
         future = asyncio.get_running_loop().create_future()
-        self.add_query(token_ids[base:], future, past, kind="step", mask_id=mask_id)
+        self.add_query(token_ids[base:] if base else token_ids, future, past, kind="step", mask_id=mask_id)
         return await future
 
     # ---- batched submit: a whole population per call (no per-query futures, no per-query Python) ----------------------

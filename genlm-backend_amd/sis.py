@@ -94,13 +94,22 @@ class DeviceSIS:
                      sample size is below `resample_ess * N_total`, the population is resampled systematically from
                      the all-gathered log-weights; every rank computes the same ancestors (glb_resample_systematic),
                      contexts and KV rows follow their ancestors, weights are reset to the population mean.
+    share_kv         (with use_particle_kv) particles with the same context share ONE KV row and one forward row: a block
+                     table `row_of`, copy-on-append when a shared row's particles draw different tokens, resampling
+                     re-points rows instead of copying them, contexts without a row (step 0, ancestors from another
+                     rank, a row budget that is spent) are encoded from their tokens (kv.SharedSlabKV).  False: every
+                     particle owns row i (kv.SlabKV), no dedup - the decode loop of DeviceSampler, whose sequences
+                     never coincide.
+    kv_rows          row budget of the shared store (default: one per particle, which always suffices); contexts that
+                     find no free row are served without their KV being kept.
     force_collectives  run the collectives of the multi-rank path (all-gather of log-weights / token matrices, the
                      set-up reductions) through `dist` even when world == 1: a one-rank "nccl" group exercises the RCCL
                      code of an 8-GPU run on a single GPU.
     """
 
     def __init__(self, llm, n_particles, prompt_ids, max_tokens, eos_id, seed=0, rng="philox", rank=0, world=1,
-                 dist=None, use_prefix_kv=False, use_particle_kv=False, resample_ess=None, force_collectives=False):
+                 dist=None, use_prefix_kv=False, use_particle_kv=False, resample_ess=None, force_collectives=False,
+                 share_kv=True, kv_rows=None):
         self.llm, self.eng, self.dev = llm, llm.engine, llm.device
         self.N, self.max_tokens, self.eos_id = n_particles, max_tokens, eos_id
         self.rank, self.world, self.dist = rank, world, dist
@@ -151,6 +160,9 @@ class DeviceSIS:
                 distinct = {tuple(int(t) for t in all_p[i, :all_l[i]]) for i in range(len(all_l))}
             self._build_prefixes(sorted(distinct))
         self.particle_kv = bool(use_particle_kv)
+        self.share_kv = bool(share_kv) and self.particle_kv
+        self.kv_rows = int(kv_rows) if kv_rows is not None else n_particles
+        self.kv_stats = dict(forward_rows=0, encoded_rows=0, copied_rows=0, unkept_rows=0, steps=0)
         if self.particle_kv:
             assert not use_prefix_kv
         self.resample_ess = resample_ess
@@ -191,6 +203,7 @@ class DeviceSIS:
         self.pkv = None
         self._head_cache = None
         self._kv_stale = None  # bool [N]: rows whose KV has to be rebuilt from the context (ancestor on another rank)
+        self._row_of_h = np.full(self.N, -1, np.int32)  # shared KV: particle -> slab row (-1: none), host mirror
         # active particles over all ranks as of the last exchange (device scalar; read with the step's one D2H copy)
         self._global_active = torch.tensor(self.N * self.world, dtype=torch.int32, device=self.dev)
         self.all_weights = None
@@ -256,6 +269,95 @@ class DeviceSIS:
             self._noise_groups, _, _ = eng.group_contexts(self.contexts.view(-1), self.starts, lengths_eff)
         return self._finish_step(logits, None, N, n_active, n_global, time_kernel, l_max=1)
 
+    @torch.no_grad()
+    def _step_shared_kv(self, time_kernel):
+        """One step with shared KV rows.  The distinct contexts (hf.py:214-220 dedup) are the forward's rows; each is
+        (A) a context whose prefix sits in a slab row - one new token is fed, its K / V appended in place; when several
+        new contexts grew out of one row, the first keeps it and the others get a copy of the prefix in a free row; or
+        (B) a context without a row (step 0, an ancestor from another rank, a spent row budget) - encoded from its tokens
+        like the reference does every step, its KV kept if a row is free.  The block table lives on the host (a few KB
+        per step ride on the step's one D2H copy); the rows move on the device."""
+        eng, llm, dev, N, R = self.eng, self.llm, self.dev, self.N, self.kv_rows
+        ctx_flat = self.contexts.view(-1)
+        lengths_eff = torch.where(self.active > 0, self.lengths, torch.ones_like(self.lengths))
+        hashes_eff = torch.where(self.active > 0, self.hashes, self._hash_stub)
+        group_of, rep, ng = eng.group_contexts(ctx_flat, self.starts, lengths_eff, hashes=hashes_eff)
+        len_rep = lengths_eff[rep.long().clamp(0, N - 1)]  # (entries of `rep` past the group count are unspecified)
+        head = torch.cat([torch.stack([ng[0], self.active.sum().to(torch.int32), self._global_active]), group_of, rep,
+                          len_rep]).cpu().numpy()  # the step's one D2H copy
+        U, n_active, n_global = int(head[0]), int(head[1]), int(head[2])
+        g_h, rep_h, L = head[3:3 + N], head[3 + N:3 + N + U], head[3 + 2 * N:3 + 2 * N + U]
+        # ---- block table (host): who keeps its row, who gets a copy, who is encoded
+        old = self._row_of_h[rep_h]
+        has = old >= 0
+        idx_has = np.nonzero(has)[0]
+        _, first = np.unique(old[idx_has], return_index=True)
+        keep = idx_has[np.sort(first)]                      # first group (by id) of every live row keeps it
+        copies = np.setdiff1d(idx_has, keep)                # the others grew out of a row somebody else keeps
+        fresh = np.nonzero(~has)[0]
+        grp_row = np.full(U, -1, np.int32)
+        grp_row[keep] = old[keep]
+        live = np.zeros(R, bool)
+        live[grp_row[keep]] = True
+        free = np.nonzero(~live)[0]
+        need = np.concatenate([copies, fresh])              # copies first: a copy is cheaper than an encoding
+        k = min(len(need), len(free))
+        grp_row[need[:k]] = free[:k]
+        copied = copies[grp_row[copies] >= 0]
+        in_a = np.zeros(U, bool)
+        in_a[keep] = True
+        in_a[copied] = True
+        A, B = np.nonzero(in_a)[0], np.nonzero(~in_a)[0]
+        order = np.concatenate([A, B])                      # logits row r belongs to group order[r]
+        inv = np.empty(U, np.int32)
+        inv[order] = np.arange(U, dtype=np.int32)
+        self._row_of_h = grp_row[g_h]
+        st = self.kv_stats
+        st["forward_rows"] += U
+        st["encoded_rows"] += len(B)
+        st["copied_rows"] += len(copied)
+        st["unkept_rows"] += int((grp_row[B] < 0).sum())
+        st["steps"] += 1
+        to_dev = lambda a, dt=torch.int32: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dt, non_blocking=True)
+        logits_parts = []
+        if len(A):
+            if len(copied):
+                src_full, len_full = np.full(R, -1, np.int32), np.zeros(R, np.int32)
+                src_full[grp_row[copied]] = old[copied]
+                len_full[grp_row[copied]] = L[copied] - 1
+                self.pkv.copy_rows(to_dev(src_full), to_dev(len_full))
+            pos_a = to_dev(L[A] - 1)
+            reps_a = to_dev(rep_h[A], torch.int64)
+            ids = self.contexts[reps_a, pos_a.long()].view(-1, 1).long()
+            self.pkv.set_forward(to_dev(grp_row[A]), pos_a)
+            out = llm._body(input_ids=ids, position_ids=pos_a.view(-1, 1).long(),
+                            attention_mask=self.pkv.attention_mask(pos_a), past_key_values=self.pkv, use_cache=True)
+            logits_parts.append(llm._lm_head(out.last_hidden_state[:, 0]))
+        if len(B):
+            sel = to_dev(rep_h[B])
+            l_max = int(L[B].max())
+            ids, am, pos, last = eng.gather_padded(ctx_flat, self.starts, lengths_eff, sel, len(B), None, 0, 0, l_max)
+            out = llm._body(input_ids=ids, attention_mask=am, position_ids=pos, use_cache=True)
+            h_last = out.last_hidden_state[torch.arange(len(B), device=dev), last.long()]
+            logits_parts.append(llm._lm_head(h_last))
+            stored = B[grp_row[B] >= 0]
+            if len(stored):
+                src = [(ly.keys.contiguous(), ly.values.contiguous()) for ly in out.past_key_values.layers]
+                if self.pkv is None:
+                    from .kv import SharedSlabKV
+
+                    self.pkv = SharedSlabKV(eng, R, self.cap, len(src))
+                src_full, len_full = np.full(R, -1, np.int32), np.zeros(R, np.int32)
+                where_b = np.full(U, -1, np.int32)
+                where_b[B] = np.arange(len(B), dtype=np.int32)
+                src_full[grp_row[stored]] = where_b[stored]
+                len_full[grp_row[stored]] = L[stored]
+                self.pkv.fill_rows(src, to_dev(src_full), to_dev(len_full))
+        logits = logits_parts[0] if len(logits_parts) == 1 else torch.cat(logits_parts)
+        self._rep = to_dev(rep_h[order])
+        self._noise_groups = group_of  # parity draws follow the reference's resolution order: by dedup group
+        return self._finish_step(logits, to_dev(inv[g_h]), U, n_active, n_global, time_kernel, l_max=1)
+
     def _finish_step(self, logits, group_of, U, n_active, n_global, time_kernel, l_max):
         eng, llm, N = self.eng, self.llm, self.N
         V = logits.shape[-1]
@@ -272,7 +374,7 @@ class DeviceSIS:
             else:
                 kw["mask_id"] = mask_id
         if self.rng_mode == RNG_NOISE:
-            kw["noise"] = self._parity_noise(group_of if group_of is not None else self._noise_groups, V)
+            kw["noise"] = self._parity_noise(self._noise_groups if self._noise_groups is not None else group_of, V)
         if time_kernel:
             # two clocks on the fused call: HIP events the launch itself carries as its start / stop stamps (the launch
             # duration, as rocprofv3 reports it), and a pair recorded around the call on the stream (adds the two marker
@@ -317,6 +419,8 @@ class DeviceSIS:
     def step(self, time_kernel=False):
         """One SIS step for every active particle.  Returns (n_unique, particles active over ALL ranks before it)."""
         eng, llm, dev, N = self.eng, self.llm, self.dev, self.N
+        if self.share_kv:
+            return self._step_shared_kv(time_kernel)
         if self.particle_kv and self.t > 0:
             return self._step_particle_kv(time_kernel)
         ctx_flat = self.contexts.view(-1)
@@ -358,6 +462,7 @@ class DeviceSIS:
                         use_cache=cache is not None)
         h_last = out.last_hidden_state[torch.arange(U, device=dev), last.long()]
         logits = llm._lm_head(h_last)  # [U, V]
+        self._noise_groups = None
         return self._finish_step(logits, group_of, U, n_active, n_global, time_kernel, l_max)
 
     def _parity_noise(self, group_of, V):
@@ -415,7 +520,11 @@ class DeviceSIS:
         self.lengths, self.prompt_len, self.active = m[:, 0].contiguous(), m[:, 1].contiguous(), m[:, 2].contiguous()
         # equal weights: log of the population's mean weight
         self.log_weights = (lse - float(np.log(n_total))).expand(N).contiguous()
-        if self.particle_kv and self.pkv is not None:
+        if self.share_kv:  # re-point: a particle takes its ancestor's row; ancestors of another rank leave it without one
+            local = (mine - self.rank * N).cpu().numpy()
+            ok = (local >= 0) & (local < N)
+            self._row_of_h = np.where(ok, self._row_of_h[np.clip(local, 0, N - 1)], -1).astype(np.int32)
+        elif self.particle_kv and self.pkv is not None:
             local = mine - self.rank * N
             is_local = (local >= 0) & (local < N)
             src = torch.where(is_local, local, torch.full_like(local, -1))
@@ -459,7 +568,7 @@ class DeviceSampler(DeviceSIS):
 
     def __init__(self, llm, prompts, max_tokens, eos_token_ids, temperature=1.0, seed=None, sync_every=4):
         super().__init__(llm, len(prompts), [list(p) for p in prompts], max_tokens, eos_id=-1,
-                         seed=0 if seed is None else int(seed), rng="philox", use_particle_kv=True)
+                         seed=0 if seed is None else int(seed), rng="philox", use_particle_kv=True, share_kv=False)
         self.sync_every = max(1, int(sync_every))
         self.temperature = float(temperature)
         self.eos = torch.tensor(sorted(set(int(t) for t in eos_token_ids)), dtype=torch.int32, device=self.dev)
@@ -470,6 +579,95 @@ class DeviceSampler(DeviceSIS):
             self.noise_rng = HostRng(int(seed))
         else:  # unseeded: in-kernel Philox keyed from torch's global generator
             self.seed = int(torch.randint(0, 2**62, (1,)).item())
+
+    @torch.no_grad()
+    def _step_shared_kv(self, time_kernel):
+        """One step with shared KV rows.  The distinct contexts (hf.py:214-220 dedup) are the forward's rows; each is
+        (A) a context whose prefix sits in a slab row - one new token is fed, its K / V appended in place; when several
+        new contexts grew out of one row, the first keeps it and the others get a copy of the prefix in a free row; or
+        (B) a context without a row (step 0, an ancestor from another rank, a spent row budget) - encoded from its tokens
+        like the reference does every step, its KV kept if a row is free.  The block table lives on the host (a few KB
+        per step ride on the step's one D2H copy); the rows move on the device."""
+        eng, llm, dev, N, R = self.eng, self.llm, self.dev, self.N, self.kv_rows
+        ctx_flat = self.contexts.view(-1)
+        lengths_eff = torch.where(self.active > 0, self.lengths, torch.ones_like(self.lengths))
+        hashes_eff = torch.where(self.active > 0, self.hashes, self._hash_stub)
+        group_of, rep, ng = eng.group_contexts(ctx_flat, self.starts, lengths_eff, hashes=hashes_eff)
+        len_rep = lengths_eff[rep.long().clamp(0, N - 1)]  # (entries of `rep` past the group count are unspecified)
+        head = torch.cat([torch.stack([ng[0], self.active.sum().to(torch.int32), self._global_active]), group_of, rep,
+                          len_rep]).cpu().numpy()  # the step's one D2H copy
+        U, n_active, n_global = int(head[0]), int(head[1]), int(head[2])
+        g_h, rep_h, L = head[3:3 + N], head[3 + N:3 + N + U], head[3 + 2 * N:3 + 2 * N + U]
+        # ---- block table (host): who keeps its row, who gets a copy, who is encoded
+        old = self._row_of_h[rep_h]
+        has = old >= 0
+        idx_has = np.nonzero(has)[0]
+        _, first = np.unique(old[idx_has], return_index=True)
+        keep = idx_has[np.sort(first)]                      # first group (by id) of every live row keeps it
+        copies = np.setdiff1d(idx_has, keep)                # the others grew out of a row somebody else keeps
+        fresh = np.nonzero(~has)[0]
+        grp_row = np.full(U, -1, np.int32)
+        grp_row[keep] = old[keep]
+        live = np.zeros(R, bool)
+        live[grp_row[keep]] = True
+        free = np.nonzero(~live)[0]
+        need = np.concatenate([copies, fresh])              # copies first: a copy is cheaper than an encoding
+        k = min(len(need), len(free))
+        grp_row[need[:k]] = free[:k]
+        copied = copies[grp_row[copies] >= 0]
+        in_a = np.zeros(U, bool)
+        in_a[keep] = True
+        in_a[copied] = True
+        A, B = np.nonzero(in_a)[0], np.nonzero(~in_a)[0]
+        order = np.concatenate([A, B])                      # logits row r belongs to group order[r]
+        inv = np.empty(U, np.int32)
+        inv[order] = np.arange(U, dtype=np.int32)
+        self._row_of_h = grp_row[g_h]
+        st = self.kv_stats
+        st["forward_rows"] += U
+        st["encoded_rows"] += len(B)
+        st["copied_rows"] += len(copied)
+        st["unkept_rows"] += int((grp_row[B] < 0).sum())
+        st["steps"] += 1
+        to_dev = lambda a, dt=torch.int32: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dt, non_blocking=True)
+        logits_parts = []
+        if len(A):
+            if len(copied):
+                src_full, len_full = np.full(R, -1, np.int32), np.zeros(R, np.int32)
+                src_full[grp_row[copied]] = old[copied]
+                len_full[grp_row[copied]] = L[copied] - 1
+                self.pkv.copy_rows(to_dev(src_full), to_dev(len_full))
+            pos_a = to_dev(L[A] - 1)
+            reps_a = to_dev(rep_h[A], torch.int64)
+            ids = self.contexts[reps_a, pos_a.long()].view(-1, 1).long()
+            self.pkv.set_forward(to_dev(grp_row[A]), pos_a)
+            out = llm._body(input_ids=ids, position_ids=pos_a.view(-1, 1).long(),
+                            attention_mask=self.pkv.attention_mask(pos_a), past_key_values=self.pkv, use_cache=True)
+            logits_parts.append(llm._lm_head(out.last_hidden_state[:, 0]))
+        if len(B):
+            sel = to_dev(rep_h[B])
+            l_max = int(L[B].max())
+            ids, am, pos, last = eng.gather_padded(ctx_flat, self.starts, lengths_eff, sel, len(B), None, 0, 0, l_max)
+            out = llm._body(input_ids=ids, attention_mask=am, position_ids=pos, use_cache=True)
+            h_last = out.last_hidden_state[torch.arange(len(B), device=dev), last.long()]
+            logits_parts.append(llm._lm_head(h_last))
+            stored = B[grp_row[B] >= 0]
+            if len(stored):
+                src = [(ly.keys.contiguous(), ly.values.contiguous()) for ly in out.past_key_values.layers]
+                if self.pkv is None:
+                    from .kv import SharedSlabKV
+
+                    self.pkv = SharedSlabKV(eng, R, self.cap, len(src))
+                src_full, len_full = np.full(R, -1, np.int32), np.zeros(R, np.int32)
+                where_b = np.full(U, -1, np.int32)
+                where_b[B] = np.arange(len(B), dtype=np.int32)
+                src_full[grp_row[stored]] = where_b[stored]
+                len_full[grp_row[stored]] = L[stored]
+                self.pkv.fill_rows(src, to_dev(src_full), to_dev(len_full))
+        logits = logits_parts[0] if len(logits_parts) == 1 else torch.cat(logits_parts)
+        self._rep = to_dev(rep_h[order])
+        self._noise_groups = group_of  # parity draws follow the reference's resolution order: by dedup group
+        return self._finish_step(logits, to_dev(inv[g_h]), U, n_active, n_global, time_kernel, l_max=1)
 
     def _finish_step(self, logits, group_of, U, n_active, n_global, time_kernel, l_max):
         eng, N, dev = self.eng, self.N, self.dev
@@ -597,8 +795,9 @@ class SisBenchWorkload:
                             "tokens, 2 shared bit masks, device-resident population, Philox draws"
                             + (f", {self.n_prompts} distinct shared prompts" if self.n_prompts > 1 else "")
                             + (", prompt KV cached (cache_kv semantics, BASELINE config 3)" if self.prefix_kv else "")
-                            + (", device-resident per-particle KV slabs (one new token per particle per step; NOT the "
-                               "reference's re-encode-every-step algorithm)" if self.particle_kv else "")
+                            + (", device-resident KV rows shared by particles with equal contexts (one new token per distinct "
+                               "context per step; NOT the reference's re-encode-every-step algorithm)" if self.particle_kv else "")
                             + (", systematic resampling after every step" if self.resample else ""),
                 "particles_per_gpu": self.N, "vocab": self.V, "rng": "philox",
-                "mean_unique_contexts_per_step": float(np.mean(self.unique_hist)) if self.unique_hist else None}
+                "mean_unique_contexts_per_step": float(np.mean(self.unique_hist)) if self.unique_hist else None,
+                **({"kv_rows": {k: v for k, v in self.sis.kv_stats.items()}} if self.particle_kv else {})}

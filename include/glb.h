@@ -267,17 +267,18 @@ int glb_normalize_weights(const float *log_weights, int64_t n, float *out_probs,
  * [n_rows, heads, cap, head_dim] (one per layer and K/V) instead of the reference's per-query tuples that are
  * zero-padded and concatenated every batch (hf.py:33-53,247-271) or per-token trie slices (cache.py:103-191).
  *
- * glb_kv_append:      slab[i, h, pos[i], :] = new_rows[i, h, :]   - the new token's K or V of every particle;
- *                     new_rows is addressed by element strides (it is usually a transposed view).
+ * glb_kv_append:      slab[row_of[i], h, pos[i], :] = new_rows[i, h, :]   - the new token's K or V of every forward
+ *                     row (row_of nullable: row i; with rows SHARED by particles of equal contexts it is the block
+ *                     table's row of forward row i); new_rows is addressed by element strides (usually a transposed view).
  * glb_kv_gather_rows: dst[t][i, h, p, :] = src[t][src_row_of[i], h, p, :] for p < len_of[i], all n_tensors
  *                     (layer, K|V) slabs in one launch through device arrays of device pointers.  Fans the KV of
  *                     the distinct prompts out to the particles and gathers ancestors' KV after a resampling
  *                     step; src_row_of[i] < 0 leaves row i untouched.  src and dst must not alias.
  * glb_gather_rows_i32: dst[i, :width] = src[row_of[i], :width]   - the particles' token matrices.
  */
-int glb_kv_append(void *slab, const void *new_rows, const int32_t *pos, int64_t n_rows, int64_t heads, int64_t cap,
-                  int64_t head_dim, int64_t new_stride_row, int64_t new_stride_head, int32_t elem_bytes,
-                  void *hip_stream);
+int glb_kv_append(void *slab, const void *new_rows, const int32_t *pos, const int32_t *row_of, int64_t n_rows,
+                  int64_t heads, int64_t cap, int64_t head_dim, int64_t new_stride_row, int64_t new_stride_head,
+                  int32_t elem_bytes, void *hip_stream);
 int glb_kv_gather_rows(const void *const *src, void *const *dst, int64_t n_tensors, int64_t n_rows, int64_t heads,
                        int64_t head_dim, int64_t src_cap, int64_t dst_cap, const int32_t *src_row_of,
                        const int32_t *len_of, int32_t elem_bytes, void *hip_stream);

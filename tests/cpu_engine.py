@@ -160,9 +160,10 @@ class CpuOracleEngine:
         return torch.from_numpy(p), torch.from_numpy(s)
 
     # ---- device-resident particle state (torch / oracle stand-ins) ---------------------------------------------
-    def kv_append(self, slab, new_rows, pos):
-        n = slab.shape[0]
-        slab[torch.arange(n), :, pos.long()] = new_rows[:, :, 0]
+    def kv_append(self, slab, new_rows, pos, rows=None):
+        n = new_rows.shape[0]
+        r = torch.arange(n) if rows is None else rows.long()
+        slab[r, :, pos.long()] = new_rows[:, :, 0]
 
     def kv_gather_rows(self, srcs, dsts, src_row_of, len_of):
         sr, ln = _np(src_row_of), _np(len_of)

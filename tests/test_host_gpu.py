@@ -571,3 +571,28 @@ def test_logprob_rows_stay_under_the_byte_budget_on_gpu(llm):
     assert max(mems[10:]) - min(mems[10:]) < 8 * slab and max(mems) - base_mem < m._rows.budget + 12 * slab
     again = asyncio.run(m.batch_next_token_logprobs(ctxs[:64]))
     assert np.abs(again.cpu().numpy() - first[:64].cpu().numpy()).max() < 1e-5
+
+
+def test_shared_kv_rows_on_gpu(llm):
+    """Shared KV rows on the device: duplicates of an ancestor are forwarded once (forward rows < particles x steps),
+    diverging particles get copies of the shared prefix, and a row budget that is spent (8 rows for 32 particles)
+    gives the same tokens - the contexts that find no row are encoded from their tokens."""
+    from genlm_backend_amd.sis import DeviceSIS
+
+    m, gold = llm
+    m.register_masks(torch.from_numpy(gold["sis_masks"]))
+    p = [int(t) for t in gold["sis_prompt"]]
+    prompts = [p, p[:5], p[2:], p] * 8
+    ref = DeviceSIS(m, 32, prompts, max_tokens=6, eos_id=0, seed=5, resample_ess=1.0)
+    ref.run()
+    for rows in (None, 8):
+        s = DeviceSIS(m, 32, prompts, max_tokens=6, eos_id=0, seed=5, resample_ess=1.0, use_particle_kv=True, kv_rows=rows)
+        s.run()
+        assert s.results()[0] == ref.results()[0]
+        assert np.abs(s.results()[1] - ref.results()[1]).max() < 1e-4
+        st = s.kv_stats
+        assert st["forward_rows"] < 32 * st["steps"]
+        if rows is None:
+            assert st["encoded_rows"] == 3 and st["unkept_rows"] == 0 and st["copied_rows"] > 0
+        else:
+            assert st["unkept_rows"] > 0 and s.pkv.n == 8

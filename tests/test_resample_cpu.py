@@ -92,6 +92,35 @@ def test_slab_kv_equals_reencode_and_prefix_kv(kind):
     assert np.abs(a.results()[1] - b.results()[1]).max() < 1e-4
 
 
+@pytest.mark.parametrize("kind", ["gpt2", "llama"])
+def test_shared_kv_rows(kind):
+    """Particles with equal contexts share one KV row and one forward row: with resampling after every step the
+    forward runs on the distinct contexts only (fewer rows than particles), rows are copied only when a shared row's
+    particles diverge, and a row budget that is spent (kv_rows = 3 for 16 particles) changes nothing but the number of
+    contexts encoded from their tokens."""
+    from genlm_backend_amd.sis import DeviceSIS
+
+    llm = _tiny(kind)
+    prompts = PROMPTS * 2
+    ref = DeviceSIS(llm, len(prompts), prompts, max_tokens=6, eos_id=0, seed=3, resample_ess=1.0)
+    ref.run()
+    runs = {}
+    for rows in (None, 3):
+        s = DeviceSIS(llm, len(prompts), prompts, max_tokens=6, eos_id=0, seed=3, use_particle_kv=True, resample_ess=1.0,
+                      kv_rows=rows)
+        s.run()
+        runs[rows] = s
+        assert s.results()[0] == ref.results()[0]
+        assert np.abs(s.results()[1] - ref.results()[1]).max() < 1e-4
+    full, tight = runs[None].kv_stats, runs[3].kv_stats
+    n = len(prompts)
+    assert full["forward_rows"] < n * full["steps"]          # dedup: duplicates of an ancestor are forwarded once
+    assert full["encoded_rows"] == len({tuple(p) for p in prompts})   # only step 0 encodes (the distinct prompts)
+    assert full["copied_rows"] > 0 and full["unkept_rows"] == 0
+    assert tight["unkept_rows"] > 0 and tight["encoded_rows"] > full["encoded_rows"]
+    assert runs[3].pkv.n == 3
+
+
 def _worker(rank, world, port, out_dir, kind, pkv, prefix=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
