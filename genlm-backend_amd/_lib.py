@@ -55,6 +55,37 @@ class StepArgs(C.Structure):
     ]
 
 
+class TrieArgs(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("weights", C.c_void_p),
+        ("dtype", C.c_int32),
+        ("ld", C.c_int64),
+        ("n_rows", C.c_int64),
+        ("vocab", C.c_int64),
+        ("lse", C.c_void_p),
+        ("logit_scale", C.c_float),
+        ("from_logprobs", C.c_int32),
+        ("op", C.c_int32),
+        ("n_nodes", C.c_int64),
+        ("n_levels", C.c_int64),
+        ("leaf_node", C.c_void_p),
+        ("level_start_host", C.c_void_p),
+        ("level_nodes", C.c_void_p),
+        ("child_ptr", C.c_void_p),
+        ("child_idx", C.c_void_p),
+        ("out", C.c_void_p),
+        ("out_ld", C.c_int64),
+        ("sel_nodes", C.c_void_p),
+        ("n_sel", C.c_int64),
+        ("out_sel", C.c_void_p),
+        ("out_sel_ld", C.c_int64),
+        ("keep_node_major", C.c_int32),
+        ("workspace", C.c_void_p),
+        ("workspace_bytes", C.c_size_t),
+    ]
+
+
 class MT19937(C.Structure):
     _fields_ = [("mt", C.c_uint32 * 624), ("idx", C.c_int32)]
 
@@ -90,6 +121,8 @@ SYMBOLS = {
     "glb_trie_workspace": (_sz, [_i64, _i64]),
     "glb_trie_reduce": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _sz,
                                   _vp]),
+    "glb_trie_workspace_ex": (_sz, [_i64, _i64]),
+    "glb_trie_masses": (C.c_int, [C.POINTER(TrieArgs), _vp]),
     "glb_resample_workspace": (_sz, [_i64]),
     "glb_resample_systematic": (C.c_int, [_vp, _i64, C.c_uint64, C.c_uint64, _vp, _vp, _vp, _sz, _vp]),
     "glb_mt19937_seed": (None, [C.POINTER(MT19937), C.c_uint64]),

@@ -711,13 +711,28 @@ __global__ __launch_bounds__(1024) void resample_systematic_kernel(const float *
 // in double, the reference's sequential order - and stores it as float32.  A thread is one (row, node); node ids are
 // post-order, so the children of neighbouring nodes are neighbours in memory.  Values live in the output itself: no
 // scratch, every output float written once and read once.
-__global__ void trie_leaves_kernel(const float *ws, int64_t ld, int64_t n_rows, int32_t V, const int32_t *leaf_node,
-                                   int from_logprobs, float *out, int64_t out_ld) {
+// one weight: element k of a row of any element type; from_logprobs: exp(x * scale - lse) - with the row's lse from the
+// fused step this turns LOGITS into probabilities on the way in (no [B, V] log-prob matrix is ever written)
+template <int DT>
+__device__ __forceinline__ float trie_weight(const void *ws, int64_t idx, int from_logprobs, float scale, float lse) {
+  float v;
+  if constexpr (DT == glb::kDtF32) {
+    v = reinterpret_cast<const float *>(ws)[idx];
+  } else {
+    const uint32_t h = reinterpret_cast<const uint16_t *>(ws)[idx];
+    if constexpr (DT == glb::kDtBf16) v = __uint_as_float(h << 16);
+    else v = (float)__builtin_bit_cast(_Float16, (uint16_t)h);
+  }
+  return from_logprobs ? expf(v * scale - lse) : v;
+}
+
+template <int DT>
+__global__ void trie_leaves_kernel(const void *ws, int64_t ld, int64_t n_rows, int32_t V, const int32_t *leaf_node,
+                                   int from_logprobs, const float *lse, float scale, float *out, int64_t out_ld) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= n_rows * V) return;
   const int64_t r = gid / V, k = gid % V;
-  const float v = ws[r * ld + k];
-  out[r * out_ld + leaf_node[k]] = from_logprobs ? expf(v) : v;
+  out[r * out_ld + leaf_node[k]] = trie_weight<DT>(ws, r * ld + k, from_logprobs, scale, lse ? lse[r] : 0.0f);
 }
 
 __global__ void trie_level_kernel(int64_t n_rows, int32_t lo, int32_t hi, const int32_t *level_nodes,
@@ -749,19 +764,17 @@ inline unsigned blocks_for(int64_t n, int t) { return (unsigned)((n + t - 1) / t
 constexpr int kTrieTile = 64;
 constexpr int64_t kTrieNodeMajorRows = 32;  // below this the rows are too short a run to coalesce: row-major kernels
 
-__global__ __launch_bounds__(256) void trie_leaves_t_kernel(const float *ws, int64_t ld, int32_t n_rows, int32_t V,
-                                                             const int32_t *leaf_node, int from_logprobs, float *scr,
-                                                             int64_t pitch) {
+template <int DT>
+__global__ __launch_bounds__(256) void trie_leaves_t_kernel(const void *ws, int64_t ld, int32_t n_rows, int32_t V,
+                                                             const int32_t *leaf_node, int from_logprobs, const float *lse,
+                                                             float scale, float *scr, int64_t pitch) {
   __shared__ float tile[kTrieTile][kTrieTile + 1];
   const int k0 = blockIdx.x * kTrieTile, r0 = blockIdx.y * kTrieTile;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
   for (int j = ty; j < kTrieTile; j += 4) {  // row r0 + j, token k0 + tx: coalesced over tokens
     const int r = r0 + j, k = k0 + tx;
     float v = 0.f;
-    if (r < n_rows && k < V) {
-      v = ws[(int64_t)r * ld + k];
-      if (from_logprobs) v = expf(v);
-    }
+    if (r < n_rows && k < V) v = trie_weight<DT>(ws, (int64_t)r * ld + k, from_logprobs, scale, lse ? lse[r] : 0.0f);
     tile[j][tx] = v;
   }
   __syncthreads();
@@ -771,42 +784,53 @@ __global__ __launch_bounds__(256) void trie_leaves_t_kernel(const float *ws, int
   }
 }
 
-// one workgroup per (node of the level, block of rows); a thread owns four consecutive rows (one 16-byte load per child)
-__global__ __launch_bounds__(256) void trie_level_t_kernel(int32_t rows4, int32_t lo, const int32_t *level_nodes,
+// one workgroup per (node of the level, block of rows); a thread owns four consecutive rows (one 16-byte load per child).
+// (Several nodes per workgroup, taken one after the other, were measured: 8 per workgroup make a 1024-row batch 0.3 ms
+// SLOWER - a node is one short chain of dependent loads, and what hides it is other workgroups, not fewer of them.)
+constexpr int kTrieNodesPerGroup = 1;
+__global__ __launch_bounds__(256) void trie_level_t_kernel(int32_t rows4, int32_t lo, int32_t hi, const int32_t *level_nodes,
                                                             const int32_t *child_ptr, const int32_t *child_idx, int op,
                                                             float4 *scr4) {
-  const int32_t node = level_nodes[lo + blockIdx.x];  // workgroup-uniform: scalar loads
   const int32_t t = blockIdx.y * blockDim.x + threadIdx.x;
   if (t >= rows4) return;
-  const int c0 = child_ptr[node], c1 = child_ptr[node + 1];
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  if (op == 0) {
-    for (int c = c0; c < c1; ++c) {
-      const float4 v = scr4[(int64_t)child_idx[c] * rows4 + t];
-      a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+  const int32_t first = lo + blockIdx.x * kTrieNodesPerGroup;
+  const int32_t last = first + kTrieNodesPerGroup < hi ? first + kTrieNodesPerGroup : hi;
+  for (int32_t j = first; j < last; ++j) {
+    const int32_t node = level_nodes[j];  // workgroup-uniform: scalar loads
+    const int c0 = child_ptr[node], c1 = child_ptr[node + 1];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (op == 0) {
+      for (int c = c0; c < c1; ++c) {
+        const float4 v = scr4[(int64_t)child_idx[c] * rows4 + t];
+        a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+      }
+    } else {
+      for (int c = c0; c < c1; ++c) {
+        const float4 v = scr4[(int64_t)child_idx[c] * rows4 + t];
+        a0 = fmax(a0, (double)v.x); a1 = fmax(a1, (double)v.y); a2 = fmax(a2, (double)v.z); a3 = fmax(a3, (double)v.w);
+      }
     }
-  } else {
-    for (int c = c0; c < c1; ++c) {
-      const float4 v = scr4[(int64_t)child_idx[c] * rows4 + t];
-      a0 = fmax(a0, (double)v.x); a1 = fmax(a1, (double)v.y); a2 = fmax(a2, (double)v.z); a3 = fmax(a3, (double)v.w);
-    }
+    scr4[(int64_t)node * rows4 + t] = make_float4((float)a0, (float)a1, (float)a2, (float)a3);
   }
-  scr4[(int64_t)node * rows4 + t] = make_float4((float)a0, (float)a1, (float)a2, (float)a3);
 }
 
+// node-major values -> row-major output; with sel: only the nodes sel[0 .. n_out) (out[r, j] = value of node sel[j])
 __global__ __launch_bounds__(256) void trie_untranspose_kernel(const float *scr, int64_t pitch, int32_t n_rows,
-                                                                int32_t n_nodes, float *out, int64_t out_ld) {
+                                                                int32_t n_out, const int32_t *sel, float *out,
+                                                                int64_t out_ld) {
   __shared__ float tile[kTrieTile][kTrieTile + 1];
   const int n0 = blockIdx.x * kTrieTile, r0 = blockIdx.y * kTrieTile;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int j = ty; j < kTrieTile; j += 4) {  // node n0 + j, row r0 + tx
     const int nd = n0 + j, r = r0 + tx;
-    tile[j][tx] = (nd < n_nodes && r < n_rows) ? scr[(int64_t)nd * pitch + r] : 0.f;
+    float v = 0.f;
+    if (nd < n_out && r < n_rows) v = scr[(int64_t)(sel ? sel[nd] : nd) * pitch + r];
+    tile[j][tx] = v;
   }
   __syncthreads();
   for (int j = ty; j < kTrieTile; j += 4) {  // row r0 + j, node n0 + tx
     const int r = r0 + j, nd = n0 + tx;
-    if (r < n_rows && nd < n_nodes) out[(int64_t)r * out_ld + nd] = tile[tx][j];
+    if (r < n_rows && nd < n_out) out[(int64_t)r * out_ld + nd] = tile[tx][j];
   }
 }
 
@@ -1372,53 +1396,112 @@ size_t glb_trie_workspace(int64_t n_rows, int64_t n_nodes) {
   return align256((size_t)n_nodes * (size_t)((n_rows + 63) & ~(int64_t)63) * sizeof(float));
 }
 
+int glb_trie_masses(const glb_trie_args *a, void *stream) {
+  if (!a) return fail(GLB_EINVAL, "glb_trie_masses: null args");
+  if (a->struct_size != sizeof(glb_trie_args))
+    return fail(GLB_EINVAL, "glb_trie_args.struct_size %u != %zu (ABI mismatch)", a->struct_size, sizeof(glb_trie_args));
+  if (!a->weights || !a->leaf_node || !a->level_start_host || !a->level_nodes || !a->child_ptr || !a->child_idx)
+    return fail(GLB_EINVAL, "null pointer");
+  const int64_t n_rows = a->n_rows, vocab = a->vocab, n_nodes = a->n_nodes, n_levels = a->n_levels;
+  if (n_rows <= 0 || vocab <= 0 || n_nodes <= vocab || n_levels <= 0 || a->ld < vocab) return fail(GLB_EINVAL, "bad sizes");
+  if (vocab > 0x7fffff00ll || n_nodes > 0x7fffff00ll || n_rows > 0x7fffff00ll) return fail(GLB_EINVAL, "size exceeds 31 bits");
+  if (a->dtype < GLB_F32 || a->dtype > GLB_F16) return fail(GLB_EINVAL, "bad dtype %d", a->dtype);
+  if (a->op != GLB_TRIE_SUM && a->op != GLB_TRIE_MAX) return fail(GLB_EINVAL, "bad op %d", a->op);
+  if (!a->out && !a->out_sel && !a->keep_node_major) return fail(GLB_EINVAL, "no output requested");
+  if (a->out && a->out_ld < n_nodes) return fail(GLB_EINVAL, "out_ld < n_nodes");
+  if (a->out_sel && (!a->sel_nodes || a->n_sel <= 0 || a->out_sel_ld < a->n_sel)) return fail(GLB_EINVAL, "bad node selection");
+  if (!(a->logit_scale == a->logit_scale)) return fail(GLB_EINVAL, "logit_scale is NaN");
+  for (int64_t d = 0; d < n_levels; ++d)
+    if (a->level_start_host[d + 1] < a->level_start_host[d] || a->level_start_host[d + 1] > n_nodes)
+      return fail(GLB_EINVAL, "level_start is not a monotone partition");
+  hipStream_t s = (hipStream_t)stream;
+  const int flp = a->from_logprobs ? 1 : 0;
+  const bool node_major = (n_rows >= kTrieNodeMajorRows || a->out_sel || a->keep_node_major) && a->workspace &&
+                          a->workspace_bytes >= glb_trie_workspace_ex(n_rows, n_nodes) && ((uintptr_t)a->workspace) % 16 == 0;
+  if (node_major) {  // node-major values: every level is a coalesced sweep
+    float *scr = (float *)a->workspace;
+    const int64_t pitch = (n_rows + 63) & ~(int64_t)63;
+    const dim3 tg(blocks_for(vocab, kTrieTile), blocks_for(n_rows, kTrieTile));
+    switch (a->dtype) {
+      case GLB_F32: hipLaunchKernelGGL(trie_leaves_t_kernel<glb::kDtF32>, tg, dim3(256), 0, s, a->weights, a->ld, (int32_t)n_rows, (int32_t)vocab, a->leaf_node, flp, a->lse, a->logit_scale, scr, pitch); break;
+      case GLB_BF16: hipLaunchKernelGGL(trie_leaves_t_kernel<glb::kDtBf16>, tg, dim3(256), 0, s, a->weights, a->ld, (int32_t)n_rows, (int32_t)vocab, a->leaf_node, flp, a->lse, a->logit_scale, scr, pitch); break;
+      default: hipLaunchKernelGGL(trie_leaves_t_kernel<glb::kDtF16>, tg, dim3(256), 0, s, a->weights, a->ld, (int32_t)n_rows, (int32_t)vocab, a->leaf_node, flp, a->lse, a->logit_scale, scr, pitch); break;
+    }
+    for (int64_t d = 0; d < n_levels; ++d) {
+      const int32_t lo = a->level_start_host[d], hi = a->level_start_host[d + 1];
+      if (hi == lo) continue;
+      const int32_t rows4 = (int32_t)(pitch / 4);  // the padding rows of scr are computed too (never read back)
+      const int bt = rows4 < 256 ? (rows4 + 63) & ~63 : 256;
+      hipLaunchKernelGGL(trie_level_t_kernel, dim3(blocks_for(hi - lo, kTrieNodesPerGroup), blocks_for(rows4, bt)), dim3(bt), 0,
+                         s, rows4, lo, hi, a->level_nodes, a->child_ptr, a->child_idx, (int)a->op, (float4 *)scr);
+    }
+    if (a->out) {
+      const dim3 ug(blocks_for(n_nodes, kTrieTile), blocks_for(n_rows, kTrieTile));
+      hipLaunchKernelGGL(trie_untranspose_kernel, ug, dim3(256), 0, s, scr, pitch, (int32_t)n_rows, (int32_t)n_nodes,
+                         (const int32_t *)nullptr, a->out, a->out_ld);
+    }
+    if (a->out_sel) {
+      const dim3 ug(blocks_for(a->n_sel, kTrieTile), blocks_for(n_rows, kTrieTile));
+      hipLaunchKernelGGL(trie_untranspose_kernel, ug, dim3(256), 0, s, scr, pitch, (int32_t)n_rows, (int32_t)a->n_sel,
+                         a->sel_nodes, a->out_sel, a->out_sel_ld);
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "trie_masses launch");
+    return GLB_OK;
+  }
+  if (!a->out) return fail(GLB_ENOSPC, "node-major / selected output needs glb_trie_workspace_ex(n_rows, n_nodes) bytes of workspace");
+  const unsigned lb = blocks_for(n_rows * vocab, 256);
+  switch (a->dtype) {
+    case GLB_F32: hipLaunchKernelGGL(trie_leaves_kernel<glb::kDtF32>, dim3(lb), dim3(256), 0, s, a->weights, a->ld, n_rows, (int32_t)vocab, a->leaf_node, flp, a->lse, a->logit_scale, a->out, a->out_ld); break;
+    case GLB_BF16: hipLaunchKernelGGL(trie_leaves_kernel<glb::kDtBf16>, dim3(lb), dim3(256), 0, s, a->weights, a->ld, n_rows, (int32_t)vocab, a->leaf_node, flp, a->lse, a->logit_scale, a->out, a->out_ld); break;
+    default: hipLaunchKernelGGL(trie_leaves_kernel<glb::kDtF16>, dim3(lb), dim3(256), 0, s, a->weights, a->ld, n_rows, (int32_t)vocab, a->leaf_node, flp, a->lse, a->logit_scale, a->out, a->out_ld); break;
+  }
+  for (int64_t d = 0; d < n_levels; ++d) {  // one launch per tree level, all rows
+    const int32_t lo = a->level_start_host[d], hi = a->level_start_host[d + 1];
+    if (hi == lo) continue;
+    hipLaunchKernelGGL(trie_level_kernel, dim3(blocks_for(n_rows * (hi - lo), 256)), dim3(256), 0, s, n_rows, lo, hi,
+                       a->level_nodes, a->child_ptr, a->child_idx, (int)a->op, a->out, a->out_ld);
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "trie_masses launch");
+  return GLB_OK;
+}
+
+size_t glb_trie_workspace_ex(int64_t n_rows, int64_t n_nodes) {
+  if (n_rows <= 0 || n_nodes <= 0) return 0;
+  return align256((size_t)n_nodes * (size_t)((n_rows + 63) & ~(int64_t)63) * sizeof(float));
+}
+
 int glb_trie_reduce(const float *weights, int64_t ld, int64_t n_rows, int64_t vocab, int64_t n_nodes, int64_t n_levels,
                     const int32_t *leaf_node, const int32_t *level_start_host, const int32_t *level_nodes,
                     const int32_t *child_ptr, const int32_t *child_idx, int32_t op, int32_t from_logprobs, float *out,
                     int64_t out_ld, void *workspace, size_t workspace_bytes, void *stream) {
-  if (!weights || !leaf_node || !level_start_host || !level_nodes || !child_ptr || !child_idx || !out)
-    return fail(GLB_EINVAL, "null pointer");
-  if (n_rows <= 0 || vocab <= 0 || n_nodes <= vocab || n_levels <= 0 || ld < vocab || out_ld < n_nodes)
-    return fail(GLB_EINVAL, "bad sizes");
-  if (vocab > 0x7fffff00ll || n_nodes > 0x7fffff00ll || n_rows > 0x7fffff00ll) return fail(GLB_EINVAL, "size exceeds 31 bits");
-  if (op != GLB_TRIE_SUM && op != GLB_TRIE_MAX) return fail(GLB_EINVAL, "bad op %d", op);
-  for (int64_t d = 0; d < n_levels; ++d)
-    if (level_start_host[d + 1] < level_start_host[d] || level_start_host[d + 1] > n_nodes)
-      return fail(GLB_EINVAL, "level_start is not a monotone partition");
-  hipStream_t s = (hipStream_t)stream;
-  if (n_rows >= kTrieNodeMajorRows && workspace && workspace_bytes >= glb_trie_workspace(n_rows, n_nodes) &&
-      ((uintptr_t)workspace) % 16 == 0) {  // node-major values: every level is a coalesced sweep
-    float *scr = (float *)workspace;
-    const int64_t pitch = (n_rows + 63) & ~(int64_t)63;
-    const dim3 tg(blocks_for(vocab, kTrieTile), blocks_for(n_rows, kTrieTile));
-    hipLaunchKernelGGL(trie_leaves_t_kernel, tg, dim3(256), 0, s, weights, ld, (int32_t)n_rows, (int32_t)vocab, leaf_node,
-                       (int)from_logprobs, scr, pitch);
-    for (int64_t d = 0; d < n_levels; ++d) {
-      const int32_t lo = level_start_host[d], hi = level_start_host[d + 1];
-      if (hi == lo) continue;
-      const int32_t rows4 = (int32_t)(pitch / 4);  // the padding rows of scr are computed too (never read back)
-      const int bt = rows4 < 256 ? (rows4 + 63) & ~63 : 256;
-      hipLaunchKernelGGL(trie_level_t_kernel, dim3((unsigned)(hi - lo), blocks_for(rows4, bt)), dim3(bt), 0, s, rows4, lo,
-                         level_nodes, child_ptr, child_idx, (int)op, (float4 *)scr);
-    }
-    const dim3 ug(blocks_for(n_nodes, kTrieTile), blocks_for(n_rows, kTrieTile));
-    hipLaunchKernelGGL(trie_untranspose_kernel, ug, dim3(256), 0, s, scr, pitch, (int32_t)n_rows, (int32_t)n_nodes, out,
-                       out_ld);
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "trie_reduce launch");
-    return GLB_OK;
+  if (!out) return fail(GLB_EINVAL, "null pointer");
+  glb_trie_args a{};
+  a.struct_size = sizeof(glb_trie_args);
+  a.weights = weights;
+  a.dtype = GLB_F32;
+  a.ld = ld;
+  a.n_rows = n_rows;
+  a.vocab = vocab;
+  a.logit_scale = 1.0f;
+  a.from_logprobs = from_logprobs;
+  a.op = op;
+  a.n_nodes = n_nodes;
+  a.n_levels = n_levels;
+  a.leaf_node = leaf_node;
+  a.level_start_host = level_start_host;
+  a.level_nodes = level_nodes;
+  a.child_ptr = child_ptr;
+  a.child_idx = child_idx;
+  a.out = out;
+  a.out_ld = out_ld;
+  // (batches below 32 rows keep the row-major kernels: the rows are too short a run to coalesce node-major)
+  if (n_rows >= kTrieNodeMajorRows) {
+    a.workspace = workspace;
+    a.workspace_bytes = workspace_bytes;
   }
-  hipLaunchKernelGGL(trie_leaves_kernel, dim3(blocks_for(n_rows * vocab, 256)), dim3(256), 0, s, weights, ld, n_rows,
-                     (int32_t)vocab, leaf_node, (int)from_logprobs, out, out_ld);
-  for (int64_t d = 0; d < n_levels; ++d) {  // one launch per tree level, all rows
-    const int32_t lo = level_start_host[d], hi = level_start_host[d + 1];
-    if (hi == lo) continue;
-    hipLaunchKernelGGL(trie_level_kernel, dim3(blocks_for(n_rows * (hi - lo), 256)), dim3(256), 0, s, n_rows, lo, hi,
-                       level_nodes, child_ptr, child_idx, (int)op, out, out_ld);
-  }
-  const hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return hip_fail(e, "trie_reduce launch");
-  return GLB_OK;
+  return glb_trie_masses(&a, stream);
 }
 
 // ---- host RNG helpers --------------------------------------------------------------------------

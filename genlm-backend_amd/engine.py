@@ -9,7 +9,7 @@ import torch
 
 from . import _lib
 from ._lib import (F32, BF16, F16, MASK_NONE, MASK_BITS, MASK_F32, MASK_PREPARED, RNG_NONE, RNG_PHILOX, RNG_NOISE,
-                   StepArgs, MT19937, check)
+                   StepArgs, TrieArgs, MT19937, check)
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 
@@ -410,6 +410,53 @@ class HipEngine:
         return anc, stats
 
     # ---- token -> byte trie masses ---------------------------------------------------------------------------
+    def trie_masses(self, ws, flat, op=0, from_logprobs=False, lse=None, logit_scale=1.0, nodes=None, layout="rows"):
+        """Token -> byte trie masses (glb_trie_masses).  ws: [B, >=V] rows of any supported element type - weights, or
+        with from_logprobs log-probabilities, or with from_logprobs AND lse (float32 [B], the fused step's out_lse) raw
+        LOGITS: the leaf weight is exp(x * logit_scale - lse[r]), no log-prob matrix in between.  Result:
+          layout "rows"   float32 [B, n_nodes]                       (every node, row-major)
+          nodes given     float32 [B, len(nodes)]                    (only the nodes asked for: int32 device tensor)
+          layout "nodes"  float32 [n_nodes, pitch] view of the engine's scratch, pitch = B rounded up to 64: value of
+                          node n for row r at [n, r]; valid until the next trie call (nothing is transposed back)."""
+        if ws.dim() != 2 or ws.stride(1) != 1 or ws.dtype not in _DT:
+            raise ValueError("weights must be [B, V] float32 / bfloat16 / float16 with unit inner stride")
+        B = ws.shape[0]
+        V, n_nodes = flat["vocab"], flat["n_nodes"]
+        self._check_dev(lse, nodes)
+        a = TrieArgs()
+        a.struct_size = C.sizeof(TrieArgs)
+        a.weights, a.dtype = ws.data_ptr(), _DT[ws.dtype]
+        a.ld = ws.stride(0) if B > 1 else max(V, ws.stride(0))
+        a.n_rows, a.vocab = B, V
+        a.lse = None if lse is None else lse.data_ptr()
+        a.logit_scale, a.from_logprobs, a.op = logit_scale, 1 if from_logprobs else 0, op
+        a.n_nodes, a.n_levels = n_nodes, flat["n_levels"]
+        ls = flat["level_start_host"]  # contiguous int32 NumPy array: it sizes the per-level launches
+        a.leaf_node, a.level_start_host = flat["leaf_node"].data_ptr(), ls.ctypes.data
+        a.level_nodes, a.child_ptr, a.child_idx = (flat[k].data_ptr() for k in ("level_nodes", "child_ptr", "child_idx"))
+        need = self.lib.glb_trie_workspace_ex(B, n_nodes)
+        if self._trie_ws is None or self._trie_ws.numel() < need:
+            self._trie_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        a.workspace, a.workspace_bytes = self._trie_ws.data_ptr(), self._trie_ws.numel()
+        out = None
+        if nodes is not None:
+            if nodes.dtype != torch.int32:
+                raise TypeError("nodes must be int32")
+            out = torch.empty((B, nodes.numel()), dtype=torch.float32, device=self.device)
+            a.sel_nodes, a.n_sel, a.out_sel, a.out_sel_ld = nodes.data_ptr(), nodes.numel(), out.data_ptr(), out.stride(0)
+        elif layout == "nodes":
+            a.keep_node_major = 1
+        elif layout == "rows":
+            out = torch.empty((B, n_nodes), dtype=torch.float32, device=self.device)
+            a.out, a.out_ld = out.data_ptr(), out.stride(0)
+        else:
+            raise ValueError(f"unknown layout {layout!r}")
+        check(self.lib.glb_trie_masses(C.byref(a), self._stream()))
+        if out is not None:
+            return out
+        pitch = (B + 63) // 64 * 64
+        return self._trie_ws[: n_nodes * pitch * 4].view(torch.float32).view(n_nodes, pitch)
+
     def trie_reduce(self, ws, flat, op=0, from_logprobs=False, out=None):
         """out[r, node] = sum / max of the weights of the tokens below `node` (glb_trie_reduce).  ws: float32 [B, >=V]
         device rows; flat: the trie's arrays (trie.TokenByteTrie.device_arrays: device tensors + the host level table)."""

@@ -135,6 +135,17 @@ class TokenByteTrie:
     def batch_weight_max_device(self, ws, from_logprobs=False):
         return self.engine.trie_reduce(self._rows(ws), self.device_arrays(), 1, from_logprobs)
 
+    def masses_from_logits(self, logits, lse, nodes=None, layout="rows", op=0, logit_scale=1.0):
+        """Masses of softmax(logits * logit_scale) straight from the logits rows ([B, V] float32 / bfloat16 / float16 on
+        the device) and the rows' lse (float32 [B]: the fused step's `lse` output, or `log_softmax_rows(want_lse=True)`):
+        what the reference gets from `batch_weight_sum(logprobs.exp())` (trie/parallel.py:92-103) without the [B, V]
+        matrix of log-probabilities ever being written.  nodes: int32 device tensor - only these nodes' masses,
+        [B, len(nodes)]; layout "nodes": every node, node-major [n_nodes, pitch] (see HipEngine.trie_masses)."""
+        if logits.shape[1] < len(self.decode):
+            raise ValueError(f"logits rows have {logits.shape[1]} columns, vocabulary has {len(self.decode)}")
+        return self.engine.trie_masses(logits, self.device_arrays(), op, True, lse=lse, logit_scale=logit_scale,
+                                       nodes=nodes, layout=layout)
+
     def batch_weight_sum(self, ws):
         """base.py:196-205 / parallel.py:92-103: summed weights of every node for a batch of weight rows."""
         return self.batch_weight_sum_device(ws).cpu().numpy()

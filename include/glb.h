@@ -323,6 +323,42 @@ int glb_trie_reduce(const float *weights, int64_t ld, int64_t n_rows, int64_t vo
                     int64_t out_ld, void *workspace, size_t workspace_bytes, void *hip_stream);
 
 /*
+ * The same propagation with everything the pipeline around it wants (SURVEY.md §8 f2 "fuses with the logprob kernel"):
+ *   - weights of any element type; with from_logprobs the leaf weight is exp(x * logit_scale - lse[r]): handing over the
+ *     LOGITS and the lse the fused step returned (out_lse) gives the masses of softmax(logits) without a [B, V]
+ *     log-probability matrix ever being written or read (lse nullable: then x are log-probabilities / weights);
+ *   - three outputs, any subset: `out` row-major [n_rows, n_nodes]; `out_sel` [n_rows, n_sel], only the nodes a caller
+ *     asks for (the children of the nodes its particles stand on); keep_node_major: nothing is transposed back, the
+ *     values stay in `workspace` as float32 [n_nodes, pitch], pitch = n_rows rounded up to 64 (the 795 MB transposed
+ *     copy of a 1024 x 194k-node batch is more than the propagation itself).
+ * workspace: glb_trie_workspace_ex(n_rows, n_nodes) bytes, 16-byte aligned; without it only `out` is served (row-major
+ * kernels).
+ */
+typedef struct glb_trie_args {
+  uint32_t struct_size;  /* sizeof(glb_trie_args) - ABI guard */
+  const void *weights;   /* [n_rows, ld] device */
+  int32_t dtype;         /* GLB_F32 / GLB_BF16 / GLB_F16 */
+  int64_t ld, n_rows, vocab;
+  const float *lse;      /* [n_rows] device, nullable */
+  float logit_scale;     /* from_logprobs: x * logit_scale (1/temperature) */
+  int32_t from_logprobs;
+  int32_t op;            /* GLB_TRIE_SUM / GLB_TRIE_MAX */
+  int64_t n_nodes, n_levels;
+  const int32_t *leaf_node, *level_start_host, *level_nodes, *child_ptr, *child_idx; /* as glb_trie_reduce */
+  float *out;            /* nullable */
+  int64_t out_ld;
+  const int32_t *sel_nodes; /* [n_sel] device */
+  int64_t n_sel;
+  float *out_sel;        /* nullable */
+  int64_t out_sel_ld;
+  int32_t keep_node_major;
+  void *workspace;
+  size_t workspace_bytes;
+} glb_trie_args;
+size_t glb_trie_workspace_ex(int64_t n_rows, int64_t n_nodes);
+int glb_trie_masses(const glb_trie_args *args, void *hip_stream);
+
+/*
  * Host helper for GLB_RNG_NOISE: fills out[0..n) with the float32 Exp(1) variates
  * torch.empty(n).exponential_(1, generator) produces on CPU for a generator whose MT19937 state is
  * `state` (seeded with glb_mt19937_seed).  Serial by construction (one 64-bit draw = two MT words per

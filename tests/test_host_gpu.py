@@ -596,3 +596,43 @@ def test_shared_kv_rows_on_gpu(llm):
             assert st["encoded_rows"] == 3 and st["unkept_rows"] == 0 and st["copied_rows"] > 0
         else:
             assert st["unkept_rows"] > 0 and s.pkv.n == 8
+
+
+def test_trie_masses_from_logits(engine, oracle):
+    """glb_trie_masses: masses of softmax(logits) straight from the logits rows + the fused step's lse (no log-prob
+    matrix), for fp32 and bf16 logits; the three output forms (row-major, node-major, selected nodes) hold the same
+    bits; weights of a 16-bit type == the oracle on the upcast values."""
+    from genlm_backend_amd.tokenization import Token
+    from genlm_backend_amd.trie import TokenByteTrie
+
+    rs = np.random.default_rng(3)
+    words, seen = [], set()
+    while len(words) < 3000:
+        w = bytes(rs.integers(97, 101, int(rs.integers(1, 7))).astype(np.uint8))
+        if w not in seen:
+            seen.add(w)
+            words.append(w)
+    trie = TokenByteTrie([Token(i, w) for i, w in enumerate(words)], engine=engine)
+    dev = engine.device
+    V, nn = len(words), len(trie)
+    for B in (70, 5):
+        x = (rs.standard_normal((B, V)) * 3).astype(np.float32)
+        for dt in (torch.float32, torch.bfloat16):
+            xd = torch.from_numpy(x).to(dev).to(dt)
+            _, lse, _ = engine.step(xd, rng_mode=0)
+            rows = trie.masses_from_logits(xd, lse)
+            p = torch.softmax(xd.float().double(), -1).cpu().numpy()
+            want = oracle.trie_reduce(p.astype(np.float32), trie.flat(), 0)
+            assert np.abs(rows.cpu().numpy() - want).max() < 2e-5
+            assert np.abs(rows[:, trie.root].cpu().numpy() - 1.0).max() < 2e-5
+            sel = torch.from_numpy(rs.choice(nn, 257, replace=False).astype(np.int32)).to(dev)
+            got_sel = trie.masses_from_logits(xd, lse, nodes=sel)
+            assert torch.equal(got_sel, rows[:, sel.long()])
+            nm = trie.masses_from_logits(xd, lse, layout="nodes")
+            assert torch.equal(nm[:, :B].t().contiguous(), rows)
+    # weights (no exp) of a 16-bit type: exact against the oracle on the upcast values
+    w = rs.random((40, V)).astype(np.float32)
+    wb = torch.from_numpy(w).to(torch.bfloat16)
+    got = engine.trie_masses(wb.to(dev), trie.device_arrays(), 0, False)
+    want = oracle.trie_reduce(wb.float().numpy(), trie.flat(), 0)
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))

@@ -26,3 +26,19 @@ for B in (1, 64, 1024):
         torch.cuda.synchronize()
         t = float(np.median([a.elapsed_time(b) * 1e3 for a, b in ev]))
         print(f"trie_reduce op={op} B={B}: {t:9.1f} us  ({t / B:7.2f} us per row)", flush=True)
+# the round-3 entry point: masses straight from logits + lse, selected / node-major output
+B = 1024
+x = torch.randn((B, len(words)), device=dev) * 3
+_, lse, _ = eng.step(x, rng_mode=0)
+sel = torch.from_numpy(rs.choice(len(trie), 4096, replace=False).astype(np.int32)).to(dev)
+for name, kw in (("rows", dict(layout="rows")), ("nodes (node-major, nothing transposed back)", dict(layout="nodes")),
+                 ("4096 selected nodes", dict(nodes=sel))):
+    for xx, tag in ((x, "f32"), (x.to(torch.bfloat16), "bf16")):
+        for _ in range(3): trie.masses_from_logits(xx, lse, **kw)
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+        for a, b in ev:
+            a.record(); trie.masses_from_logits(xx, lse, **kw); b.record()
+        torch.cuda.synchronize()
+        t = float(np.median([a.elapsed_time(b) * 1e3 for a, b in ev]))
+        print(f"masses_from_logits {tag} B={B} -> {name}: {t:9.1f} us", flush=True)
