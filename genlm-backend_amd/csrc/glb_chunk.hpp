@@ -164,7 +164,12 @@ __device__ __forceinline__ void load_chunk(const char *rowp, int e_base, int V, 
   if (e_base + kChunk <= V) {  // wave-uniform: a full chunk, every load in range
     const char *q = rowp + ((int64_t)e_base + lane * EPV) * ES;
 #pragma unroll
-    for (int i = 0; i < NVC; ++i) raw[i] = *reinterpret_cast<const u32x4_t *>(q + (int64_t)i * 64 * 16);
+    // non-temporal: the row is read once (the draw's re-reading of one quarter chunk per particle aside) and must not
+    // push what the launch before it left in L2 / Infinity Cache through the memory system ahead of the stream.  Same-box
+    // A/B (tools/ab.sh, tools/ab_sis.sh): fp32 step 45.4 -> 42.7 us on rotating buffers and 44.5 -> 36.8 us inside the
+    // SIS loop, right behind the lm_head GEMM that wrote the logits; 16-bit rows (bound by VALU issue) unchanged.
+    for (int i = 0; i < NVC; ++i)
+      raw[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(q + (int64_t)i * 64 * 16));
   } else {
 #pragma unroll
     for (int i = 0; i < NVC; ++i) raw[i] = load_vec_guarded<DT>(rowp, e_base + (i * 64 + lane) * EPV, V);
@@ -451,6 +456,10 @@ __device__ __forceinline__ void stats_item(const StepParams &p, int item, int la
   int nv_valid = (V - e_base + 64 * EPV - 1) / (64 * EPV);
   nv_valid = nv_valid < NVC ? nv_valid : NVC;
 
+  // the chunk's loads go out first: everything below that has to wait for a scalar load (the mask id of the unit, then
+  // the mask words) waits while they are in flight, not in front of them
+  float x[64];
+  load_chunk<DT, SCALED>(rowp, e_base, V, lane, p.scale, x);
   MaskAhead ma{};
   cu64_t mt = nullptr;
   uint64_t allows_any = 0;
@@ -461,8 +470,6 @@ __device__ __forceinline__ void stats_item(const StepParams &p, int item, int la
     mask_ahead<DT>(mt, ma);
     allows_any = as_const(p.mask_any)[(int64_t)mi * nch + c];
   }
-  float x[64];
-  load_chunk<DT, SCALED>(rowp, e_base, V, lane, p.scale, x);
   const float Nc = exp_n(chunk_max(x));
   uint32_t pA, pB, rA[4], rB[4];
   float Nm = Nc;
@@ -709,13 +716,30 @@ __device__ __forceinline__ bool recs_acquire(Recs &R, int nch, int lane) {
   for (int c0 = 0; c0 < nch; c0 += 64) {
     const int c = c0 + lane;
     for (;;) {
+      if constexpr (POLL) {
+        // waiting costs one 8-byte load per record and sweep (the last granule of the record's one store instruction);
+        // the full, validated read comes when every record shows it - a row's finishing wave may sweep for
+        // microseconds, and twelve loads per record from a thousand waiting waves are L2 requests the streaming
+        // reads of the still running stats waves queue behind
+        bool seen = true;
+        if (c < nch) {
+          const uint64_t g = __hip_atomic_load(const_cast<uint64_t *>(R.base) + (int64_t)c * kRecWords + 11, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+          seen = (uint32_t)(g >> 32) == R.epoch;
+        }
+        if (__builtin_amdgcn_ballot_w64(!seen) != 0ull) {
+          __builtin_amdgcn_s_sleep(8);
+          if (__builtin_amdgcn_s_memrealtime() - t0 > kSpinTicks) return false;
+          continue;
+        }
+      }
       bool ok = true;
       ChunkRec r = ChunkRec{kNegInf, kNegInf, 0u, 0u, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, 0u, 0u};
       if (c < nch) ok = load_rec<POLL>(R.base + (int64_t)c * kRecWords, R.epoch, r);
       if (c0 == 0) R.mine = r;
       if constexpr (!POLL) break;
       if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
-      __builtin_amdgcn_s_sleep(8);
+      __builtin_amdgcn_s_sleep(2);
       if (__builtin_amdgcn_s_memrealtime() - t0 > kSpinTicks) return false;
     }
   }

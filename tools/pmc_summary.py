@@ -1,6 +1,7 @@
 """Condense the rocprofv3 outputs of tools/profile_round.sh under <dir> into the files committed under profiles/:
-per-kernel stats CSVs (first lines) and, per workload, the HBM traffic of one fused call = chunk_stats_kernel +
-finish_kernel (FETCH_SIZE x2 on gfx950 as MI355X_MICROARCH.md prescribes; WRITE_SIZE as read; counters are in KB)."""
+per-kernel stats CSVs (first lines) and, per workload, the HBM traffic of one fused call = fused_step_kernel (the few
+calls too small for it: chunk_stats_small_kernel + finish_kernel) (FETCH_SIZE x2 on gfx950 as MI355X_MICROARCH.md
+prescribes; WRITE_SIZE as read; counters are in KB)."""
 import csv
 import glob
 import json
@@ -10,7 +11,8 @@ import sys
 root = sys.argv[1]
 ALGO = {"kernel": 1024 * 50257 * 4 + 2 * 1571 * 4 + 1024 * 8, "kernel-llama": 512 * 128256 * 2 + 2 * 4008 * 4 + 512 * 8,
         "sis": None}  # sis: 1 launch in 10 has one unique row; mean algorithmic bytes are in the bench line (about 184.8 MB)
-KERNELS = ("glb::chunk_stats_kernel", "glb::finish_kernel")
+KERNELS = ("glb::fused_step_kernel", "glb::chunk_stats_small_kernel", "glb::chunk_stats_kernel", "glb::finish_kernel")
+CALL_HEADS = ("glb::fused_step_kernel", "glb::chunk_stats_small_kernel", "glb::chunk_stats_kernel")  # one per fused call
 
 
 def first(pattern):
@@ -30,9 +32,9 @@ for wl in ("kernel", "kernel-llama", "sis"):
                 if row.get("Counter_Name") != tag:
                     continue
                 name = row["Kernel_Name"].split("<")[0].replace("void ", "")
-                if name in KERNELS or name.replace("_small", "") in KERNELS:
-                    per.setdefault(name.replace("_small", ""), []).append(float(row["Counter_Value"]))
-        n_calls = max(len(v) for v in per.values()) if per else 0
+                if name in KERNELS:
+                    per.setdefault(name, []).append(float(row["Counter_Value"]))
+        n_calls = sum(len(v) for k, v in per.items() if k in CALL_HEADS)
         for k, v in per.items():  # mean per FUSED CALL (the sis workload's set-up pass of 10 steps is included: same mix)
             out[f"{k}:{tag}"] = {"launches": len(v), "mean_raw_KB": sum(v) / max(n_calls, 1)}
     if not out:
@@ -43,11 +45,11 @@ for wl in ("kernel", "kernel-llama", "sis"):
     out["hbm_write_bytes_per_launch"] = write * 1024
     out["algorithmic_bytes_per_launch"] = ALGO[wl]
     out["note"] = (f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python3 bench.py --workload {wl} "
-                   f"--steps 20 --warmup {0 if wl == 'sis' else 2} --no-cpu`; one fused call = chunk_stats_kernel + finish_kernel; FETCH_SIZE doubled "
+                   f"--steps 20 --warmup {0 if wl == 'sis' else 2} --no-cpu`; one fused call = fused_step_kernel (small calls: chunk_stats_small_kernel + finish_kernel); FETCH_SIZE doubled "
                    "per MI355X_MICROARCH.md (gfx950 tallies 128-B read requests at 64 B)")
     json.dump(out, open(os.path.join(root, f"{wl}_pmc_traffic.json"), "w"), indent=1)
     print(wl, json.dumps(out, indent=1))
-for tag in ("kernel", "kernel-llama", "sis", "sis-llama"):
+for tag in ("kernel", "kernel-llama", "sis", "sis-llama", "lsm", "trie"):
     f = first(f"kstats_{tag}/**/*kernel_stats.csv")
     if f:
         lines = open(f).read().splitlines()

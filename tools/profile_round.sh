@@ -29,6 +29,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_sis -o s -- py
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_sis -o f -- python3 $R/bench.py --workload sis --steps 20 --warmup 0 --no-cpu > $O/pmc_f_sis.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_sis -o w -- python3 $R/bench.py --workload sis --steps 20 --warmup 0 --no-cpu > $O/pmc_w_sis.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_sis-llama -o s -- python3 $R/bench.py --workload sis-llama --steps 20 --warmup 3 --no-cpu > $O/kstats_sis-llama.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_lsm -o l -- python3 $R/tools/kbench_lsm.py > $O/kstats_lsm.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_trie -o t -- python3 $R/tools/tbench.py > $O/kstats_trie.log 2>&1
+python3 $R/tools/gbench.py > $O/gbench.log 2>&1
 python3 $R/tools/pmc_summary.py $O > $O/pmc_summary.log
 find $O -name "*.db" -delete 2>/dev/null || true
 find $O -name "*kernel_trace.csv" -delete 2>/dev/null || true
