@@ -53,5 +53,6 @@ for tag in ("kernel", "kernel-llama", "sis", "sis-llama", "lsm", "trie"):
     f = first(f"kstats_{tag}/**/*kernel_stats.csv")
     if f:
         lines = open(f).read().splitlines()
-        keep = [lines[0]] + [ln for ln in lines[1:] if len(ln) < 700][:25]
+        ours = [ln for ln in lines[1:] if "glb::" in ln or "anonymous namespace" in ln]  # this library's kernels: all
+        keep = [lines[0]] + ours + [ln[:300] for ln in lines[1:] if ln not in ours][:20]
         open(os.path.join(root, f"{tag}_kernel_stats.csv"), "w").write("\n".join(keep) + "\n")
