@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 kernel durations of the fused step on the two headline shapes, once per line of stdin "NAME ENV=VAL ..."
-# (tuning knobs: GLB_K1_LDS, MASK, RNG).  Run on the GPU box through gpurun; output gpurun_out/pp/.
+# (tuning knobs: MASK, RNG).  Run on the GPU box through gpurun; output gpurun_out/pp/.
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 O=$R/gpurun_out/pp
 mkdir -p $O
