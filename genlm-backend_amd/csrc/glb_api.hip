@@ -24,7 +24,10 @@ namespace glb {
   hipError_t launch_logprob_rows_##dt(const void *logits, int64_t ld, int V, float scale, const float *lse,       \
                                       float *out, int64_t out_ld, int n_rows, hipStream_t s);                      \
   hipError_t launch_logprob_fused_##dt(const void *logits, int64_t ld, int V, int nch, float scale, float *out,   \
-                                       int64_t out_ld, float *out_lse, int n_rows, hipStream_t s);
+                                       int64_t out_ld, float *out_lse, int n_rows, hipStream_t s);               \
+  hipError_t launch_logprob_waves_##dt(const void *logits, int64_t ld, int V, int nch, float scale, float *out,   \
+                                       int64_t out_ld, float *out_lse, int n_rows, uint64_t *recs, uint32_t epoch,  \
+                                       int variant, hipStream_t s);
 GLB_DECL(0) GLB_DECL(1) GLB_DECL(2)
 #undef GLB_DECL
 thread_local hipEvent_t g_step_ev_start = nullptr, g_step_ev_stop = nullptr;  // glb_logprob_mask_sample_timed
@@ -89,6 +92,44 @@ int device_cus() {
 
 // finishing waves a one-launch step may have: half of the wave slots the device holds at the kernels' occupancy (4
 // waves per SIMD; 3 with float masks), so that they can never keep the stats waves they wait for from a slot
+// The next epoch of a registered workspace for a launch that tags its records: 1 and *epoch set when `workspace` was
+// initialised with at least `bytes` and `s` is not being captured (the epoch is a launch argument: a replayed graph would
+// reuse it); 0 when the caller has to take its untagged form; -1 on a HIP error.
+int ws_next_epoch(void *workspace, size_t bytes, hipStream_t s, uint32_t *epoch) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cs) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  if (cs != hipStreamCaptureStatusNone) return 0;
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  auto it = g_ws.find(workspace);
+  if (it == g_ws.end() || it->second.bytes < bytes) return 0;
+  if (++it->second.epoch == 0u) {  // 2^32 calls on this workspace: start the tags over
+    if (hipMemsetAsync(workspace, 0, bytes, s) != hipSuccess) return -1;
+    it->second.epoch = 1u;
+  }
+  *epoch = it->second.epoch;
+  return 1;
+}
+
+// which log-softmax kernel: -1 = the best the call allows (independent waves when the workspace carries tags, else a
+// workgroup per row or three launches).  The diagnostic build takes it from the environment for same-box comparisons:
+// 0 = never the independent waves.
+int lsm_mode() {
+#ifdef GLB_STAMPS
+  if (const char *e = getenv("GLB_LSM_GRID")) return atoi(e);
+#endif
+  return -1;
+}
+
+int lsm_variant() {
+#ifdef GLB_STAMPS
+  if (const char *e = getenv("GLB_LSM_VARIANT")) return atoi(e);
+#endif
+  return 0;
+}
+
 int fin_wave_cap(bool float_mask) { return device_cus() * (float_mask ? 6 : 8); }
 
 
@@ -993,27 +1034,9 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
   const bool fmask = kmask == glb::kMaskF32;
   bool fused = a->rng_mode != GLB_RNG_NOISE && items > 512 && a->n_particles <= 16 * (int64_t)fin_wave_cap(fmask);
   if (fused) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cs) != hipSuccess) {
-      (void)hipGetLastError();
-      fused = false;
-    } else if (cs != hipStreamCaptureStatusNone) {
-      fused = false;
-    }
-  }
-  if (fused) {
-    std::lock_guard<std::mutex> lk(g_ws_mu);
-    auto it = g_ws.find(a->workspace);
-    if (it == g_ws.end() || it->second.bytes < fixed_bytes) {
-      fused = false;
-    } else {
-      if (++it->second.epoch == 0u) {  // 2^32 calls on this workspace: start the tags over
-        const hipError_t e = hipMemsetAsync(a->workspace, 0, fixed_bytes, s);
-        if (e != hipSuccess) return hip_fail(e, "workspace re-zero");
-        it->second.epoch = 1u;
-      }
-      p.epoch = it->second.epoch;
-    }
+    const int rc = ws_next_epoch(a->workspace, fixed_bytes, s, &p.epoch);
+    if (rc < 0) return hip_fail(hipGetLastError(), "workspace re-zero");
+    fused = rc > 0;
   }
   if (fused) {
     p.stats_blocks = (int32_t)items;
@@ -1075,12 +1098,31 @@ int glb_log_softmax_rows(const void *logits, int32_t dtype, int64_t n_rows, int6
   if (workspace_bytes < glb_log_softmax_workspace_bytes(n_rows, vocab))
     return fail(GLB_ENOSPC, "workspace %zu < %zu bytes", workspace_bytes, glb_log_softmax_workspace_bytes(n_rows, vocab));
   hipStream_t s = (hipStream_t)stream;
-  if (n_rows >= 128 && n_chunks(vocab) <= 4096) {  // enough rows for one workgroup each: single launch, one HBM read
+  const int nch = (int)n_chunks(vocab);
+  const int mode = lsm_mode();
+  // one launch of independent waves that keep their chunks in registers and meet through tagged records: needs a
+  // workspace glb_workspace_init has seen (the tags) and a row of at most 64 chunks (one lane per record)
+  if (mode < 0 && out && nch <= 64 && n_rows * (int64_t)nch <= 0x7fffffffll) {
+    uint32_t epoch = 0;
+    const int rc = ws_next_epoch(workspace, step_recs_bytes(n_rows, vocab), s, &epoch);
+    if (rc < 0) return hip_fail(hipGetLastError(), "workspace re-zero");
+    if (rc > 0) {
+      hipError_t e;
+      switch (dtype) {
+        case 0: e = glb::launch_logprob_waves_0(logits, ld, (int)vocab, nch, logit_scale, out, out_ld, out_lse, (int)n_rows, (uint64_t *)workspace, epoch, lsm_variant(), s); break;
+        case 1: e = glb::launch_logprob_waves_1(logits, ld, (int)vocab, nch, logit_scale, out, out_ld, out_lse, (int)n_rows, (uint64_t *)workspace, epoch, lsm_variant(), s); break;
+        default: e = glb::launch_logprob_waves_2(logits, ld, (int)vocab, nch, logit_scale, out, out_ld, out_lse, (int)n_rows, (uint64_t *)workspace, epoch, lsm_variant(), s); break;
+      }
+      if (e != hipSuccess) return hip_fail(e, "logprob_rows_waves launch");
+      return GLB_OK;
+    }
+  }
+  if (n_rows >= 128 && nch <= 4096) {  // enough rows for one workgroup each: single launch
     hipError_t e;
     switch (dtype) {
-      case 0: e = glb::launch_logprob_fused_0(logits, ld, (int)vocab, (int)n_chunks(vocab), logit_scale, out, out_ld, out_lse, (int)n_rows, s); break;
-      case 1: e = glb::launch_logprob_fused_1(logits, ld, (int)vocab, (int)n_chunks(vocab), logit_scale, out, out_ld, out_lse, (int)n_rows, s); break;
-      default: e = glb::launch_logprob_fused_2(logits, ld, (int)vocab, (int)n_chunks(vocab), logit_scale, out, out_ld, out_lse, (int)n_rows, s); break;
+      case 0: e = glb::launch_logprob_fused_0(logits, ld, (int)vocab, nch, logit_scale, out, out_ld, out_lse, (int)n_rows, s); break;
+      case 1: e = glb::launch_logprob_fused_1(logits, ld, (int)vocab, nch, logit_scale, out, out_ld, out_lse, (int)n_rows, s); break;
+      default: e = glb::launch_logprob_fused_2(logits, ld, (int)vocab, nch, logit_scale, out, out_ld, out_lse, (int)n_rows, s); break;
     }
     if (e != hipSuccess) return hip_fail(e, "logprob_rows_fused launch");
     return GLB_OK;

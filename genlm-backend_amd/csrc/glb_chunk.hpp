@@ -155,12 +155,11 @@ __device__ __forceinline__ u32x4_t load_vec_guarded(const char *rowp, int e0, in
   return u32x4_t{w[0], w[1], w[2], w[3]};
 }
 
-// the wave's 64 elements per lane of chunk c: vector i covers elements c*4096 + (i*64 + lane)*EPV ...
-template <int DT, bool SCALED>
-__device__ __forceinline__ void load_chunk(const char *rowp, int e_base, int V, int lane, float scale,
-                                           float (&x)[64]) {
+// the wave's vectors of chunk c as loaded: vector i covers elements c*4096 + (i*64 + lane)*EPV ...
+template <int DT>
+__device__ __forceinline__ void load_chunk_raw(const char *rowp, int e_base, int V, int lane,
+                                               u32x4_t (&raw)[ElemTraits<DT>::NVC]) {
   constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC;
-  u32x4_t raw[NVC];
   if (e_base + kChunk <= V) {  // wave-uniform: a full chunk, every load in range
     const char *q = rowp + ((int64_t)e_base + lane * EPV) * ES;
 #pragma unroll
@@ -174,14 +173,27 @@ __device__ __forceinline__ void load_chunk(const char *rowp, int e_base, int V, 
 #pragma unroll
     for (int i = 0; i < NVC; ++i) raw[i] = load_vec_guarded<DT>(rowp, e_base + (i * 64 + lane) * EPV, V);
   }
+}
+
+// one loaded vector as floats, times the caller's scale
+template <int DT, bool SCALED>
+__device__ __forceinline__ void unpack_scaled(const u32x4_t &r, float scale, float *x) {
+  unpack_vec<DT>(r, x);
+  if constexpr (SCALED) {
 #pragma unroll
-  for (int i = 0; i < NVC; ++i) {
-    unpack_vec<DT>(raw[i], &x[i * EPV]);
-    if constexpr (SCALED) {
-#pragma unroll
-      for (int k = 0; k < EPV; ++k) x[i * EPV + k] *= scale;
-    }
+    for (int k = 0; k < ElemTraits<DT>::EPV; ++k) x[k] *= scale;
   }
+}
+
+// the wave's 64 elements per lane of chunk c
+template <int DT, bool SCALED>
+__device__ __forceinline__ void load_chunk(const char *rowp, int e_base, int V, int lane, float scale,
+                                           float (&x)[64]) {
+  constexpr int EPV = ElemTraits<DT>::EPV, NVC = ElemTraits<DT>::NVC;
+  u32x4_t raw[NVC];
+  load_chunk_raw<DT>(rowp, e_base, V, lane, raw);
+#pragma unroll
+  for (int i = 0; i < NVC; ++i) unpack_scaled<DT, SCALED>(raw[i], scale, &x[i * EPV]);
 }
 
 // one record out: lanes 0..11 store one granule each (the values are wave-uniform)
@@ -1215,10 +1227,10 @@ __global__ __launch_bounds__(256) void logprob_rows_kernel(const void *logits, i
 // the row (the stats role's per-chunk arithmetic, records kept in LDS), one wave folds them into lse, then every wave
 // streams its chunks again - read microseconds ago: L2 / Infinity Cache serve them - and writes x - lse with
 // non-temporal stores (206 MB of output that nobody reads soon must not push the rows out of the caches before their
-// second reading).  HBM traffic ~ V*s + 4V per row.  Four waves per workgroup: four workgroups share a CU, so one row's
-// barrier / fold / store phases overlap the others' loads; round 2's sixteen-wave workgroup had the CU to itself and
-// idled it through every barrier (111 us at 1024 x 50257 fp32).  Used when there are enough rows to fill the chip (the
-// three-launch path spreads a few rows over the chip chunk by chunk).
+// second reading).  Any row length; the second reading is served on the die but crosses the XCD <-> memory fabric like
+// the first (111 us at 1024 x 50257 fp32; four-wave workgroups, four to a CU: 146 us).  Used for rows too long for the
+// kernel of independent waves below (more than 64 chunks, or a workspace without tags) when there are enough rows to
+// fill the chip (the three-launch path spreads a few rows over the chip chunk by chunk).
 // ---------------------------------------------------------------------------------------------------------
 template <int DT, bool SCALED, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void logprob_rows_fused_kernel(const void *logits, int64_t ld, int V, int nch,
@@ -1292,6 +1304,161 @@ __global__ __launch_bounds__(64 * WAVES) void logprob_rows_fused_kernel(const vo
       } else {
         for (int k = 0; k < V - e0; ++k) orow[e0 + k] = x[i * EPV + k] - l;
       }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// log-probability rows, one HBM reading, no workgroup structure: one-wave workgroups, block b = (row b / nch, chunk
+// b % nch).  A wave loads its chunk and keeps it in registers as loaded, reduces it, publishes (scale, sum) as three
+// tagged granules of the chunk's record (words 0, 2, 3 - the step kernels' layout), sweeps the records of its row until
+// every tag is this call's epoch (its row-mates are its neighbours in the grid: they were placed within a microsecond
+// of it), folds lse - every wave of the row the same integers, the same result - and writes x - lse from its registers.
+// Waves of different rows are at different points of this at any moment, so reading, arithmetic and writing overlap
+// across the chip by themselves; a workgroup per row with the row in its registers (tried: one 1024-thread workgroup
+// per CU walking its share of the rows) marches in step with all the others - every CU reads, then every CU computes,
+// then every CU writes: 104 us at 1024 x 50257 fp32 where the bytes alone take 70; this kernel: 78 us.  A wave waits only for
+// waves placed before or right behind it, the wait is bounded (NaN out after kSpinTicks), rows of up to 64 chunks.
+// ---------------------------------------------------------------------------------------------------------
+// STORE (16-bit rows; a lane's eight elements of a vector are 32 bytes of output): 0 = two 16-byte stores per lane, each
+// instruction covering every other 16 bytes of a 2 KB span; 2 = through 2 KB of LDS so that each store instruction
+// writes 1 KB of consecutive addresses.
+template <int DT, bool SCALED, int WPS, int STORE>
+__global__ __launch_bounds__(64, WPS) void logprob_rows_waves_kernel(
+    const void *logits, int64_t ld, int V, int nch, float scale, float *out, int64_t out_ld, float *out_lse,
+    uint64_t *recs, uint32_t epoch) {
+  constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC;
+  const int lane = threadIdx.x;
+  const int r = (int)(blockIdx.x / (unsigned)nch), c = (int)(blockIdx.x - (unsigned)r * (unsigned)nch);
+  const char *rowp = (const char *)logits + (int64_t)r * ld * ES;
+  const int e_base = c * kChunk;
+  u32x4_t raw[NVC];
+  load_chunk_raw<DT>(rowp, e_base, V, lane, raw);
+  int nv_valid = (V - e_base + 64 * EPV - 1) / (64 * EPV);
+  nv_valid = nv_valid < NVC ? nv_valid : NVC;
+  float m = kNegInf;
+#pragma unroll
+  for (int i = 0; i < NVC; ++i) {
+    float t[EPV];
+    unpack_scaled<DT, SCALED>(raw[i], scale, t);
+#pragma unroll
+    for (int k = 0; k < EPV; k += 2) m = max3(m, t[k], t[k + 1]);
+  }
+  const float Nc = exp_n(wave_max(m)), magicN = kMagic - Nc;
+  float P[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int i = 0; i < NVC; ++i) {
+    if (i < nv_valid) {  // wave-uniform; vectors wholly past the row end would add +0
+      float t[EPV];
+      unpack_scaled<DT, SCALED>(raw[i], scale, t);
+#pragma unroll
+      for (int k = 0; k < EPV; ++k) t[k] = chunk_term(t[k], magicN);
+#pragma unroll
+      for (int k = 0; k < EPV; ++k) P[i & 3] = P[i & 3] + t[k];
+    }
+    __builtin_amdgcn_sched_barrier(0);  // vector by vector: only the packed form stays live
+  }
+  uint32_t h, l;
+  lane_payload<4>(P, h, l);
+  const uint32_t pA = last_lane(wave_sum_u32_l63(h)), pB = last_lane(wave_sum_u32_l63(l));
+  uint64_t *row_recs = recs + (int64_t)r * nch * kRecWords;
+  {
+    uint32_t v = __float_as_uint(Nc);
+    v = lane == 2 ? pA : v;
+    v = lane == 3 ? pB : v;
+    if (lane == 0 || lane == 2 || lane == 3)
+      __hip_atomic_store(row_recs + (int64_t)c * kRecWords + lane, ((uint64_t)epoch << 32) | v, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // lane j takes record j of the row
+  float Nj = kNegInf;
+  uint64_t Sj = 0;
+  bool have = true;
+  {
+    const uint64_t *q = row_recs + (int64_t)(lane < nch ? lane : 0) * kRecWords;
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+      bool ok = true;
+      if (lane < nch) {
+        const uint64_t g3 = __hip_atomic_load(const_cast<uint64_t *>(q) + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = (uint32_t)(g3 >> 32) == epoch;
+      }
+      if (__builtin_amdgcn_ballot_w64(!ok) != 0ull) {  // one 8-byte load per record and sweep while waiting
+        __builtin_amdgcn_s_sleep(8);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > kSpinTicks) {
+          have = false;
+          break;
+        }
+        continue;
+      }
+      if (lane < nch) {
+        const uint64_t g0 = __hip_atomic_load(const_cast<uint64_t *>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t g2 = __hip_atomic_load(const_cast<uint64_t *>(q) + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t g3 = __hip_atomic_load(const_cast<uint64_t *>(q) + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = (uint32_t)(g0 >> 32) == epoch && (uint32_t)(g2 >> 32) == epoch && (uint32_t)(g3 >> 32) == epoch;
+        Nj = __uint_as_float((uint32_t)g0);
+        Sj = ((uint64_t)(uint32_t)g2 << kGridHi) + (uint32_t)g3;
+      }
+      if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+      __builtin_amdgcn_s_sleep(2);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > kSpinTicks) {
+        have = false;
+        break;
+      }
+    }
+  }
+  float lse = __builtin_nanf("");
+  if (have) {
+    const bool on = lane < nch && Sj != 0;
+    const float N = wave_max(on ? Nj : kNegInf);
+    uint64_t sa = 0;
+    if (on) {
+      const float d = N - Nj;
+      sa = d < 64.0f ? Sj >> (uint32_t)d : 0ull;
+    }
+    const uint64_t S = wave_sum_u64(sa);
+    lse = S ? (float)log_fix(S, (int32_t)N + 1 - kFrac) : kNegInf;
+  }
+  if (c == 0 && lane == 0 && out_lse) out_lse[r] = lse;
+  if (!out) return;
+  float *o = out + (int64_t)r * out_ld + e_base + lane * EPV;
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  if (e_base + kChunk <= V) {  // wave-uniform: a full chunk, straight stores
+    if constexpr (EPV == 8 && STORE == 2) {
+      __shared__ f32x4_t s_t[2][128];  // two vectors' worth: the next one is written while the last one's reads land
+      float *ot = out + (int64_t)r * out_ld + e_base + lane * 4;
+#pragma unroll
+      for (int i = 0; i < NVC; ++i) {
+        float t[EPV];
+        unpack_scaled<DT, SCALED>(raw[i], scale, t);
+        f32x4_t *buf = s_t[i & 1];
+        buf[2 * lane] = f32x4_t{t[0] - lse, t[1] - lse, t[2] - lse, t[3] - lse};
+        buf[2 * lane + 1] = f32x4_t{t[4] - lse, t[5] - lse, t[6] - lse, t[7] - lse};
+        const f32x4_t a = buf[lane], b = buf[64 + lane];  // same wave: program order holds within LDS
+        __builtin_nontemporal_store(a, reinterpret_cast<f32x4_t *>(ot + i * 512));
+        __builtin_nontemporal_store(b, reinterpret_cast<f32x4_t *>(ot + i * 512 + 256));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NVC; ++i) {
+        float t[EPV];
+        unpack_scaled<DT, SCALED>(raw[i], scale, t);
+#pragma unroll
+        for (int hh = 0; hh < EPV / 4; ++hh) {
+          const f32x4_t v{t[4 * hh] - lse, t[4 * hh + 1] - lse, t[4 * hh + 2] - lse, t[4 * hh + 3] - lse};
+          if constexpr (STORE == 1) *reinterpret_cast<f32x4_t *>(o + i * 64 * EPV + 4 * hh) = v;
+          else __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t *>(o + i * 64 * EPV + 4 * hh));
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NVC; ++i) {
+      const int e0 = e_base + (i * 64 + lane) * EPV;
+      float t[EPV];
+      unpack_scaled<DT, SCALED>(raw[i], scale, t);
+      for (int k = 0; k < EPV; ++k)
+        if (e0 + k < V) o[i * 64 * EPV + k] = t[k] - lse;
     }
   }
 }

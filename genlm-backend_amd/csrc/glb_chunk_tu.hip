@@ -126,4 +126,41 @@ hipError_t GLB_CAT(launch_logprob_fused_, GLB_DT)(const void *logits, int64_t ld
   return hipGetLastError();
 }
 
+template <int WPS, int STORE>
+static void lsm_waves1(const void *logits, int64_t ld, int V, int nch, float scale, float *out, int64_t out_ld,
+                       float *out_lse, int n_rows, uint64_t *recs, uint32_t epoch, hipStream_t s) {
+  const dim3 grid((unsigned)((int64_t)n_rows * nch)), block(64);
+  if (scale != 1.0f)
+    hipLaunchKernelGGL((logprob_rows_waves_kernel<GLB_DT, true, WPS, STORE>), grid, block, 0, s, logits, ld, V, nch, scale,
+                       out, out_ld, out_lse, recs, epoch);
+  else
+    hipLaunchKernelGGL((logprob_rows_waves_kernel<GLB_DT, false, WPS, STORE>), grid, block, 0, s, logits, ld, V, nch, scale,
+                       out, out_ld, out_lse, recs, epoch);
+}
+
+// variant: 0 = the product's choice; the diagnostic build passes others (waves per SIMD * 10 + store form)
+hipError_t GLB_CAT(launch_logprob_waves_, GLB_DT)(const void *logits, int64_t ld, int V, int nch, float scale, float *out,
+                                                   int64_t out_ld, float *out_lse, int n_rows, uint64_t *recs,
+                                                   uint32_t epoch, int variant, hipStream_t s) {
+#define GLB_LSM_ARGS logits, ld, V, nch, scale, out, out_ld, out_lse, n_rows, recs, epoch, s
+  if constexpr (GLB_DT == kDtF32) {
+#ifdef GLB_STAMPS
+    if (variant == 50) lsm_waves1<5, 0>(GLB_LSM_ARGS);
+    else if (variant == 30) lsm_waves1<3, 0>(GLB_LSM_ARGS);
+    else
+#endif
+    lsm_waves1<4, 0>(GLB_LSM_ARGS);
+  } else {
+#ifdef GLB_STAMPS
+    if (variant == 50) lsm_waves1<5, 0>(GLB_LSM_ARGS);       // 107 / 141 us at 1024 x 50257 / 512 x 128256 bf16
+    else if (variant == 51) lsm_waves1<5, 1>(GLB_LSM_ARGS);  //  75 / 102 (plain stores: L2 merges the halves)
+    else if (variant == 42) lsm_waves1<4, 2>(GLB_LSM_ARGS);
+    else
+#endif
+    lsm_waves1<5, 2>(GLB_LSM_ARGS);                          //  65 /  94
+  }
+#undef GLB_LSM_ARGS
+  return hipGetLastError();
+}
+
 }  // namespace glb

@@ -273,8 +273,10 @@ class HipEngine:
                                         _ptr(blob), need, self._stream()))
         return PreparedMasks(blob, K, vocab, dt)
 
-    def log_softmax_rows(self, logits, vocab=None, logit_scale=1.0, out=None, want_lse=False):
-        """out[r] = logits[r] - logsumexp(logits[r]) (glb_log_softmax_rows); float32 result."""
+    def log_softmax_rows(self, logits, vocab=None, logit_scale=1.0, out=None, want_lse=False, workspace=None):
+        """out[r] = logits[r] - logsumexp(logits[r]) (glb_log_softmax_rows); float32 result.  `workspace`: a uint8 device
+        tensor to lend instead of the engine's own scratch (one the library has not initialised takes the forms that
+        do not tag their records)."""
         if logits.dim() != 2 or logits.stride(1) != 1:
             raise ValueError("logits must be 2-D with unit inner stride")
         n_rows, width = logits.shape
@@ -284,7 +286,10 @@ class HipEngine:
             out = torch.empty((n_rows, V), dtype=torch.float32, device=self.device)
         lse = self._f32(n_rows) if want_lse else None
         out_ld = out.stride(0) if n_rows > 1 else max(V, out.stride(0))
-        ws = self._scratch(self.lib.glb_log_softmax_workspace_bytes(n_rows, V))
+        need = self.lib.glb_log_softmax_workspace_bytes(n_rows, V)
+        ws = self._scratch(need) if workspace is None else workspace
+        if ws.numel() < need:
+            raise ValueError(f"workspace of {ws.numel()} bytes, {need} needed")
         check(self.lib.glb_log_softmax_rows(_ptr(logits), _DT[logits.dtype], n_rows, V, ld, logit_scale, _ptr(out),
                                             out_ld, _ptr(lse), _ptr(ws), ws.numel(), self._stream()))
         return (out, lse) if want_lse else out

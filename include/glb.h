@@ -164,7 +164,10 @@ int glb_mask_prepare(const uint32_t *mask_bits, int64_t n_masks, int64_t vocab, 
  * Materialise log-probabilities: out[r, j] = x[r, j] - logsumexp(x[r, :]).  Replaces the
  * per-position torch.log_softmax of TokenTrie.extend_cache (cache.py:93-98) and
  * next_token_logprobs_uncached (hf.py:422).  out_lse is optional.  workspace: device scratch of at least
- * glb_log_softmax_workspace_bytes(n_rows, vocab) bytes, 32-byte aligned.
+ * glb_log_softmax_workspace_bytes(n_rows, vocab) bytes, 32-byte aligned.  On a workspace glb_workspace_init has seen
+ * (and outside stream capture, rows of at most 262144 elements) the call is one launch that reads every logit once
+ * and keeps it on the chip until its log-probability is written; otherwise a workgroup per row that reads its row twice
+ * (128 rows and more) or three launches.  Same bits either way.
  */
 size_t glb_log_softmax_workspace_bytes(int64_t n_rows, int64_t vocab);
 int glb_log_softmax_rows(const void *logits, int32_t dtype, int64_t n_rows, int64_t vocab,

@@ -305,10 +305,11 @@ def test_parity_and_float_masks_at_llama_width_fp32(engine, oracle):
 
 
 @pytest.mark.parametrize("B,V,dtype,scale", [(160, 50257, "f32", 1.0), (130, 128256, "bf16", 0.7), (128, 4099, "f16", 1.0),
-                                             (200, 70001, "f32", 1.3)])
+                                             (200, 70001, "f32", 1.3), (130, 270001, "bf16", 1.0)])
 def test_log_softmax_rows_single_launch_path(engine, oracle, B, V, dtype, scale):
-    """128 rows and more take the one-workgroup-per-row kernel (one HBM read of the logits): same bits as the oracle
-    (and as the three-launch path, which smaller batches take)."""
+    """Rows of up to 64 chunks on the engine's workspace take the one-launch kernel of independent waves (each logit
+    read once and kept in registers until its log-probability is written); longer rows and workspaces without tags the
+    workgroup-per-row kernel (128 rows and more) or three launches: same bits as the oracle, all of them."""
     O = oracle
     x_np, x_t = _mk(O, B, V, dtype, seed=V + B)
     dev = engine.device
@@ -322,6 +323,13 @@ def test_log_softmax_rows_single_launch_path(engine, oracle, B, V, dtype, scale)
     assert np.array_equal(_np(got).view(np.uint32), want.view(np.uint32))
     few, lse_few = engine.log_softmax_rows(buf.to(dev)[:5, :V], vocab=V, logit_scale=scale, want_lse=True)
     assert torch.equal(few, got[:5]) and torch.equal(lse_few, lse[:5])
+    # a workspace the library has not initialised: the workgroup-per-row kernel / the three launches, same bits
+    ws = torch.empty(engine.lib.glb_log_softmax_workspace_bytes(B, V) + 64, dtype=torch.uint8, device=dev)
+    ws = ws[(-ws.data_ptr()) % 32:]
+    got2, lse2 = engine.log_softmax_rows(buf.to(dev)[:, :V], vocab=V, logit_scale=scale, want_lse=True, workspace=ws)
+    few2, lse_few2 = engine.log_softmax_rows(buf.to(dev)[:5, :V], vocab=V, logit_scale=scale, want_lse=True, workspace=ws)
+    torch.cuda.synchronize()
+    assert torch.equal(got2, got) and torch.equal(lse2, lse) and torch.equal(few2, few) and torch.equal(lse_few2, lse_few)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])

@@ -3,6 +3,9 @@ import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import genlm_backend_amd
+from genlm_backend_amd import _lib
+if os.environ.get("GLB_DBG_LIB"):  # diagnostic build of the library (make -C genlm-backend_amd/csrc dbg)
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ["GLB_DBG_LIB"])
 from genlm_backend_amd.engine import HipEngine
 eng = HipEngine("cuda:0"); dev = eng.device
 for B, V, dt in [(1024, 50257, torch.float32), (256, 50257, torch.float32), (1024, 50257, torch.bfloat16), (512, 128256, torch.bfloat16), (64, 50257, torch.float32)]:
