@@ -754,6 +754,10 @@ __global__ __launch_bounds__(1024) void resample_systematic_kernel(const float *
 // scratch, every output float written once and read once.
 // one weight: element k of a row of any element type; from_logprobs: exp(x * scale - lse) - with the row's lse from the
 // fused step this turns LOGITS into probabilities on the way in (no [B, V] log-prob matrix is ever written)
+// e^x by the hardware's 2^x (v_exp_f32, 1 ulp) on x * log2(e): relative error about |x| * 1e-7 - the input, a logit minus
+// a float32 lse, is no better known - for 3 instructions instead of expf's 25 (a third of the leaves kernel's time).
+__device__ __forceinline__ float trie_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+
 template <int DT>
 __device__ __forceinline__ float trie_weight(const void *ws, int64_t idx, int from_logprobs, float scale, float lse) {
   float v;
@@ -764,7 +768,7 @@ __device__ __forceinline__ float trie_weight(const void *ws, int64_t idx, int fr
     if constexpr (DT == glb::kDtBf16) v = __uint_as_float(h << 16);
     else v = (float)__builtin_bit_cast(_Float16, (uint16_t)h);
   }
-  return from_logprobs ? expf(v * scale - lse) : v;
+  return from_logprobs ? trie_exp(v * scale - lse) : v;
 }
 
 template <int DT>
@@ -840,18 +844,72 @@ __global__ __launch_bounds__(256) void trie_level_t_kernel(int32_t rows4, int32_
     const int32_t node = level_nodes[j];  // workgroup-uniform: scalar loads
     const int c0 = child_ptr[node], c1 = child_ptr[node + 1];
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    if (op == 0) {
-      for (int c = c0; c < c1; ++c) {
-        const float4 v = scr4[(int64_t)child_idx[c] * rows4 + t];
-        a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
-      }
-    } else {
-      for (int c = c0; c < c1; ++c) {
-        const float4 v = scr4[(int64_t)child_idx[c] * rows4 + t];
-        a0 = fmax(a0, (double)v.x); a1 = fmax(a1, (double)v.y); a2 = fmax(a2, (double)v.z); a3 = fmax(a3, (double)v.w);
+    // children in batches of eight loads in flight (a node near the root has dozens: one load per trip made the top
+    // levels of a 1024-row batch 13-18 us each, all of it latency); added in ascending order all the same
+    for (int c = c0; c < c1; c += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (c + j < c1) v[j] = scr4[(int64_t)child_idx[c + j] * rows4 + t];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (c + j < c1) {
+          if (op == 0) {
+            a0 += (double)v[j].x; a1 += (double)v[j].y; a2 += (double)v[j].z; a3 += (double)v[j].w;
+          } else {
+            a0 = fmax(a0, (double)v[j].x); a1 = fmax(a1, (double)v[j].y); a2 = fmax(a2, (double)v[j].z); a3 = fmax(a3, (double)v[j].w);
+          }
+        }
       }
     }
     scr4[(int64_t)node * rows4 + t] = make_float4((float)a0, (float)a1, (float)a2, (float)a3);
+  }
+}
+
+constexpr int kTrieWide = 256, kTrieWideLd = kTrieWide + 4;
+// (A 64-token x 256-row tile for the leaves, 16 bytes per lane on both sides and 1 KB runs of a node's rows out, was
+// measured at 1024 rows: 140-157 us against the 64 x 64 tile's 128-142 - the scattered node rows, not the run length
+// inside them, are what the memory system sees.  Dropped.)
+
+// node-major values -> row-major output for 256 nodes and more: a 256-node x 64-row tile, four rows of a node in, four
+// nodes of a row out (1 KB runs of the output row instead of 256 bytes)
+__global__ __launch_bounds__(256) void trie_untranspose_wide_kernel(const float *scr, int64_t pitch, int32_t n_rows,
+                                                                     int32_t n_out, const int32_t *sel, float *out,
+                                                                     int64_t out_ld) {
+  __shared__ __attribute__((aligned(16))) float tile[kTrieTile][kTrieWideLd];
+  // row blocks fastest: the workgroups that run together read the pieces of the same nodes' rows
+  const int n0 = blockIdx.y * kTrieWide, r0 = blockIdx.x * kTrieTile;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // 16 row quads x 16 nodes
+  float4 v[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int nd = n0 + ty + 16 * j;
+    v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (nd < n_out) v[j] = *reinterpret_cast<const float4 *>(scr + (int64_t)(sel ? sel[nd] : nd) * pitch + r0 + 4 * tx);
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    tile[4 * tx][ty + 16 * j] = v[j].x;
+    tile[4 * tx + 1][ty + 16 * j] = v[j].y;
+    tile[4 * tx + 2][ty + 16 * j] = v[j].z;
+    tile[4 * tx + 3][ty + 16 * j] = v[j].w;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nd = n0 + 4 * lane;
+#pragma unroll 4
+  for (int j = 0; j < 16; ++j) {
+    const int rr = 4 * j + w, r = r0 + rr;
+    if (r >= n_rows || nd >= n_out) continue;
+    const float4 t = *reinterpret_cast<const float4 *>(&tile[rr][4 * lane]);
+    float *o = out + (int64_t)r * out_ld + nd;
+    if (nd + 4 <= n_out) {
+      typedef float f32x4_t __attribute__((ext_vector_type(4)));
+      *reinterpret_cast<f32x4_t __attribute__((aligned(4))) *>(o) = f32x4_t{t.x, t.y, t.z, t.w};
+    } else {
+      const float e[4] = {t.x, t.y, t.z, t.w};
+      for (int q = 0; q < n_out - nd; ++q) o[q] = e[q];
+    }
   }
 }
 
@@ -1477,16 +1535,16 @@ int glb_trie_masses(const glb_trie_args *a, void *stream) {
       hipLaunchKernelGGL(trie_level_t_kernel, dim3(blocks_for(hi - lo, kTrieNodesPerGroup), blocks_for(rows4, bt)), dim3(bt), 0,
                          s, rows4, lo, hi, a->level_nodes, a->child_ptr, a->child_idx, (int)a->op, (float4 *)scr);
     }
-    if (a->out) {
-      const dim3 ug(blocks_for(n_nodes, kTrieTile), blocks_for(n_rows, kTrieTile));
-      hipLaunchKernelGGL(trie_untranspose_kernel, ug, dim3(256), 0, s, scr, pitch, (int32_t)n_rows, (int32_t)n_nodes,
-                         (const int32_t *)nullptr, a->out, a->out_ld);
-    }
-    if (a->out_sel) {
-      const dim3 ug(blocks_for(a->n_sel, kTrieTile), blocks_for(n_rows, kTrieTile));
-      hipLaunchKernelGGL(trie_untranspose_kernel, ug, dim3(256), 0, s, scr, pitch, (int32_t)n_rows, (int32_t)a->n_sel,
-                         a->sel_nodes, a->out_sel, a->out_sel_ld);
-    }
+    auto untranspose = [&](int64_t n_out, const int32_t *sel, float *out, int64_t out_ld) {
+      if (n_out >= kTrieWide)
+        hipLaunchKernelGGL(trie_untranspose_wide_kernel, dim3(blocks_for(n_rows, kTrieTile), blocks_for(n_out, kTrieWide)),
+                           dim3(256), 0, s, scr, pitch, (int32_t)n_rows, (int32_t)n_out, sel, out, out_ld);
+      else
+        hipLaunchKernelGGL(trie_untranspose_kernel, dim3(blocks_for(n_out, kTrieTile), blocks_for(n_rows, kTrieTile)),
+                           dim3(256), 0, s, scr, pitch, (int32_t)n_rows, (int32_t)n_out, sel, out, out_ld);
+    };
+    if (a->out) untranspose(n_nodes, nullptr, a->out, a->out_ld);
+    if (a->out_sel) untranspose(a->n_sel, a->sel_nodes, a->out_sel, a->out_sel_ld);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "trie_masses launch");
     return GLB_OK;

@@ -79,6 +79,8 @@ class TokenByteTrie:
                 self.node2prefix[y] = self.node2prefix[x] if is_leaf_edge else self.node2prefix[x] + [sym]
         self._flat = None
         self._dev = None
+        self._compact = None
+        self._cdev = None
 
     def __len__(self):
         return len(self.children)
@@ -107,15 +109,63 @@ class TokenByteTrie:
                               child_idx=child_idx.astype(np.int32))
         return self._flat
 
+    def compact(self):
+        """The same trie with its one-child nodes folded away, for the kernel.  A node with exactly one child has that
+        child's value - the sum or the maximum of one term, bit for bit - so it needs neither storage nor a pass of its
+        own: `slot_of[node]` names the slot (a leaf or a node with two children and more, numbered in ascending node
+        order) whose value it shares, and the arrays describe the tree over the slots (children in the original
+        ascending order, so every sum adds the same numbers in the same order).  A byte trie of a BPE vocabulary is
+        mostly such chains - 194 k nodes, 68 k slots for the 50 257 synthetic tokens of tools/tbench.py - and the
+        propagation moves a third of the bytes."""
+        if self._compact is None:
+            n = len(self.children)
+            counts = np.fromiter((len(j) for j in self.jump), np.int64, n)
+            own = counts != 1
+            slot_of = np.full(n, -1, np.int64)
+            slot_of[own] = np.arange(int(own.sum()))
+            first = np.fromiter((j[0] if len(j) else -1 for j in self.jump), np.int64, n)
+            for x in np.nonzero(~own)[0]:  # ascending ids = children first
+                slot_of[x] = slot_of[first[x]]
+            owners = np.nonzero(own)[0]
+            n_slots = len(owners)
+            ccount = np.where(counts[owners] >= 2, counts[owners], 0)
+            child_ptr = np.zeros(n_slots + 1, np.int64)
+            np.cumsum(ccount, out=child_ptr[1:])
+            kids = [slot_of[self.jump[x]] for x in owners if counts[x] >= 2]
+            child_idx = np.concatenate(kids) if kids else np.zeros(0, np.int64)
+            level = np.full(n_slots, -1, np.int64)
+            for s_, x in enumerate(owners):  # ascending
+                if counts[x] >= 2:
+                    level[s_] = 1 + max(-1, int(level[slot_of[self.jump[x]]].max()))
+            internal = np.nonzero(level >= 0)[0]
+            order = internal[np.argsort(level[internal], kind="stable")]
+            n_levels = int(level.max()) + 1 if len(internal) else 0
+            level_start = np.searchsorted(level[order], np.arange(n_levels + 1))
+            self._compact = dict(vocab=len(self.decode), n_nodes=n_slots, n_levels=n_levels,
+                                 leaf_node=slot_of[self.idx_to_leaf[:, 1]].astype(np.int32),
+                                 level_start=level_start.astype(np.int32), level_nodes=order.astype(np.int32),
+                                 child_ptr=child_ptr.astype(np.int32), child_idx=child_idx.astype(np.int32),
+                                 slot_of=slot_of.astype(np.int32))
+        return self._compact
+
+    def _to_device(self, f):
+        if self.engine is None:
+            raise RuntimeError("TokenByteTrie needs a HipEngine to compute masses (there is no CPU path)")
+        dev = self.engine.device
+        d = {k: (torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) else v) for k, v in f.items()}
+        d["level_start_host"] = np.ascontiguousarray(f["level_start"], dtype=np.int32)
+        return d
+
     def device_arrays(self):
         if self._dev is None:
-            if self.engine is None:
-                raise RuntimeError("TokenByteTrie needs a HipEngine to compute masses (there is no CPU path)")
-            f = self.flat()
-            dev = self.engine.device
-            self._dev = {k: (torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) else v) for k, v in f.items()}
-            self._dev["level_start_host"] = np.ascontiguousarray(f["level_start"], dtype=np.int32)
+            self._dev = self._to_device(self.flat())
         return self._dev
+
+    def compact_device_arrays(self):
+        """`compact()` on the device; ["slot_of"]: int32 [n_nodes], the slot that holds a node's value."""
+        if self._cdev is None:
+            self._cdev = self._to_device(self.compact())
+        return self._cdev
 
     # ---- masses -----------------------------------------------------------------------------------------------------
     def _rows(self, ws):
@@ -128,23 +178,47 @@ class TokenByteTrie:
             raise ValueError(f"weight rows have {ws.shape[1]} columns, vocabulary has {len(self.decode)}")
         return ws.to(self.engine.device, torch.float32).contiguous()
 
+    _COMPACT_ROWS = 32  # from here on the kernels keep the values node-major: the folded trie pays
+
+    def _batch(self, ws, op, from_logprobs):
+        ws = self._rows(ws)
+        if ws.shape[0] < self._COMPACT_ROWS or self.compact()["n_levels"] == 0:
+            return self.engine.trie_reduce(ws, self.device_arrays(), op, from_logprobs)
+        c = self.compact_device_arrays()
+        return self.engine.trie_masses(ws, c, op, from_logprobs, nodes=c["slot_of"])
+
     def batch_weight_sum_device(self, ws, from_logprobs=False):
         """[B, V] weights (or log-probabilities) -> float32 [B, n_nodes] on the device."""
-        return self.engine.trie_reduce(self._rows(ws), self.device_arrays(), 0, from_logprobs)
+        return self._batch(ws, 0, from_logprobs)
 
     def batch_weight_max_device(self, ws, from_logprobs=False):
-        return self.engine.trie_reduce(self._rows(ws), self.device_arrays(), 1, from_logprobs)
+        return self._batch(ws, 1, from_logprobs)
 
     def masses_from_logits(self, logits, lse, nodes=None, layout="rows", op=0, logit_scale=1.0):
         """Masses of softmax(logits * logit_scale) straight from the logits rows ([B, V] float32 / bfloat16 / float16 on
         the device) and the rows' lse (float32 [B]: the fused step's `lse` output, or `log_softmax_rows(want_lse=True)`):
         what the reference gets from `batch_weight_sum(logprobs.exp())` (trie/parallel.py:92-103) without the [B, V]
         matrix of log-probabilities ever being written.  nodes: int32 device tensor - only these nodes' masses,
-        [B, len(nodes)]; layout "nodes": every node, node-major [n_nodes, pitch] (see HipEngine.trie_masses)."""
+        [B, len(nodes)]; layout "slots": node-major [n_slots, pitch] over the folded trie (`compact()`: the value of node
+        n for row r is at [slot_of[n], r] - nothing is transposed back, the cheapest form); layout "nodes": the same over
+        all nodes, [n_nodes, pitch] (see HipEngine.trie_masses)."""
         if logits.shape[1] < len(self.decode):
             raise ValueError(f"logits rows have {logits.shape[1]} columns, vocabulary has {len(self.decode)}")
-        return self.engine.trie_masses(logits, self.device_arrays(), op, True, lse=lse, logit_scale=logit_scale,
-                                       nodes=nodes, layout=layout)
+        if layout == "nodes" or self.compact()["n_levels"] == 0:
+            return self.engine.trie_masses(logits, self.device_arrays(), op, True, lse=lse, logit_scale=logit_scale,
+                                           nodes=nodes, layout=layout)
+        c = self.compact_device_arrays()
+        if layout == "slots" and nodes is None:
+            return self.engine.trie_masses(logits, c, op, True, lse=lse, logit_scale=logit_scale, layout="nodes")
+        if layout != "rows":
+            raise ValueError(f"unknown layout {layout!r}")
+        if nodes is None:
+            sel = c["slot_of"]
+        else:
+            if nodes.dtype != torch.int32:
+                raise TypeError("nodes must be int32")
+            sel = c["slot_of"][nodes.long()]
+        return self.engine.trie_masses(logits, c, op, True, lse=lse, logit_scale=logit_scale, nodes=sel)
 
     def batch_weight_sum(self, ws):
         """base.py:196-205 / parallel.py:92-103: summed weights of every node for a batch of weight rows."""

@@ -336,6 +336,11 @@ int glb_trie_reduce(const float *weights, int64_t ld, int64_t n_rows, int64_t vo
  *     copy of a 1024 x 194k-node batch is more than the propagation itself).
  * workspace: glb_trie_workspace_ex(n_rows, n_nodes) bytes, 16-byte aligned; without it only `out` is served (row-major
  * kernels).
+ * The tree is whatever the arrays say: a caller may hand over its trie with the one-child nodes folded away (such a node
+ * has its child's value, bit for bit; a byte trie of a BPE vocabulary is mostly such chains: 194 k nodes, 66 k of them
+ * leaves or branching) - n_nodes then counts the remaining "slots", leaf_node / level_nodes / child_idx name slots, and
+ * sel_nodes maps the nodes the caller wants (all of them, for the reference's [n_rows, n_nodes] result) to their slots.
+ * The propagation then moves a third of the bytes (genlm_backend_amd.trie.TokenByteTrie.compact does this).
  */
 typedef struct glb_trie_args {
   uint32_t struct_size;  /* sizeof(glb_trie_args) - ABI guard */

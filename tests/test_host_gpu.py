@@ -630,6 +630,10 @@ def test_trie_masses_from_logits(engine, oracle):
             assert torch.equal(got_sel, rows[:, sel.long()])
             nm = trie.masses_from_logits(xd, lse, layout="nodes")
             assert torch.equal(nm[:, :B].t().contiguous(), rows)
+            sl = trie.masses_from_logits(xd, lse, layout="slots")   # the folded trie: a node's value sits in its slot
+            slot_of = trie.compact_device_arrays()["slot_of"].long()
+            assert sl.shape[0] == trie.compact()["n_nodes"] < nn
+            assert torch.equal(sl[slot_of][:, :B].t().contiguous(), rows)
     # weights (no exp) of a 16-bit type: exact against the oracle on the upcast values
     w = rs.random((40, V)).astype(np.float32)
     wb = torch.from_numpy(w).to(torch.bfloat16)

@@ -31,7 +31,20 @@ B = 1024
 x = torch.randn((B, len(words)), device=dev) * 3
 _, lse, _ = eng.step(x, rng_mode=0)
 sel = torch.from_numpy(rs.choice(len(trie), 4096, replace=False).astype(np.int32)).to(dev)
+print(f"folded trie: {trie.compact()['n_nodes']} slots, {trie.compact()['n_levels']} levels")
+for B in (64, 1024):
+    ws = torch.rand((B, len(words)), device=dev); ws /= ws.sum(-1, keepdim=True)
+    for _ in range(3): trie.batch_weight_sum_device(ws)
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+    for a, b in ev:
+        a.record(); trie.batch_weight_sum_device(ws); b.record()
+    torch.cuda.synchronize()
+    t = float(np.median([a.elapsed_time(b) * 1e3 for a, b in ev]))
+    print(f"batch_weight_sum_device (folded trie) B={B}: {t:9.1f} us", flush=True)
+B = 1024
 for name, kw in (("rows", dict(layout="rows")), ("nodes (node-major, nothing transposed back)", dict(layout="nodes")),
+                 ("slots (node-major over the folded trie)", dict(layout="slots")),
                  ("4096 selected nodes", dict(nodes=sel))):
     for xx, tag in ((x, "f32"), (x.to(torch.bfloat16), "bf16")):
         for _ in range(3): trie.masses_from_logits(xx, lse, **kw)
