@@ -497,11 +497,8 @@ class AsyncAmdLM(AsyncLM):
             if u in lp_rows:
                 r0, first = lp_rows[u]
                 cnt = len(uniq[u].prompt) - first
-                if slab_row is None:
-                    rows = (lp_slab[r0:r0 + cnt], first)
-                else:
-                    s0 = slab_row[r0]
-                    rows = (lp_slab[s0:s0 + cnt], first)
+                # (slab, index of the row of position `first`, first): no view per query
+                rows = (lp_slab, r0 if slab_row is None else slab_row[r0], first)
             for m in members[u]:
                 if m.kind == "step":
                     res = (step_out[0][si], step_out[1][si])
@@ -557,7 +554,7 @@ class AsyncAmdLM(AsyncLM):
             else:
                 break
         if next_token_index == len(token_ids) and prev is not None:
-            if node._rows is None:  # the row was evicted under the byte budget (RowLRU): a miss on the last position
+            if not node.has_row():  # the row was evicted under the byte budget (RowLRU): a miss on the last position
                 node, next_token_index = prev, next_token_index - 1
             else:
                 self._rows.touch(node)
@@ -572,10 +569,9 @@ class AsyncAmdLM(AsyncLM):
             return node.logprobs
         future = asyncio.get_running_loop().create_future()
         self.add_query(token_ids[base:], future, past, first_new=next_token_index - base)
-        rows, first = await future
-        node = node.extend_cache_rows(next_token_index, token_ids, rows[next_token_index - base - first:],
-                                      next_token_index, store=self._rows)
-        return node.logprobs
+        slab, row0, first = await future  # slab[row0 + t - first]: the row after prompt position t (= context position base + t)
+        t, i = node.extend_cache_lazy(next_token_index, token_ids, slab, base + first - row0, store=self._rows)
+        return t[i]
 
     def _evaluate_one(self, prompt, past, first_new):
         """Synchronous single-query evaluation through the same batched machinery."""
@@ -606,9 +602,9 @@ class AsyncAmdLM(AsyncLM):
         node, next_token_index, past, base = self.walk_cache(token_ids)
         if next_token_index == len(token_ids):
             return node.logprobs
-        rows, first = self._evaluate_one(token_ids[base:], past, next_token_index - base)
-        node = node.extend_cache_rows(next_token_index, token_ids, rows, next_token_index, store=self._rows)
-        return node.logprobs
+        slab, row0, first = self._evaluate_one(token_ids[base:], past, next_token_index - base)
+        t, i = node.extend_cache_lazy(next_token_index, token_ids, slab, base + first - row0, store=self._rows)
+        return t[i]
 
     @torch.no_grad()
     def next_token_logprobs_uncached(self, token_ids):
@@ -772,22 +768,41 @@ class AsyncAmdLM(AsyncLM):
             def set_exception(self, e):
                 raise e
 
-        pending, nodes = [], [None] * len(token_ids_list)  # nodes[i]: the ROW of context i (held: the budget may evict)
+        pending, refs = [], [None] * len(token_ids_list)  # refs[i]: (tensor, index) of context i's row (held: the budget may evict)
         for i, token_ids in enumerate(token_ids_list):
             if not token_ids:
                 raise ValueError("Token ids must not be empty")
             node, nti, past, base = self.walk_cache(token_ids)
             if nti == len(token_ids):
-                nodes[i] = node.logprobs
+                refs[i] = node.row_ref()
             else:
                 pending.append((i, node, nti, base, Query(token_ids[base:], _Slot(), past, first_new=nti - base)))
         if pending:
             self._evaluate([q for *_, q in pending])
             for i, node, nti, base, q in pending:
-                rows, first = q.future.value
-                nodes[i] = node.extend_cache_rows(nti, token_ids_list[i], rows[nti - base - first:], nti,
-                                                  store=self._rows).logprobs
-        return torch.stack(nodes)
+                slab, row0, first = q.future.value
+                refs[i] = node.extend_cache_lazy(nti, token_ids_list[i], slab, base + first - row0, store=self._rows)
+        # rows of one slab leave in one gather
+        by_slab = {}
+        for i, (t, idx) in enumerate(refs):
+            ent = by_slab.get(id(t))
+            if ent is None:
+                ent = by_slab[id(t)] = (t, [], [])
+            ent[1].append(i)
+            ent[2].append(idx)
+        dev = self.device
+        out = None
+        for t, pos, idx in by_slab.values():
+            if idx[0] < 0:  # a row of its own
+                got = t[None].expand(len(pos), -1)
+            else:
+                got = t.index_select(0, torch.from_numpy(np.asarray(idx, np.int64)).to(dev))
+            if len(by_slab) == 1:
+                return got  # positions 0 .. n-1 in order
+            if out is None:
+                out = torch.empty((len(refs), got.shape[-1]), dtype=got.dtype, device=dev)
+            out[torch.from_numpy(np.asarray(pos, np.int64)).to(dev)] = got
+        return out
 
     async def batch_next_token_logprobs(self, token_ids_list):
         """base.py:47-60 (one batched evaluation instead of a gather over per-context coroutines)"""

@@ -350,3 +350,66 @@ def test_activation_fusion_is_optional_and_reversible(gold):
         assert kinds() == before
         with torch.no_grad():
             assert (model(ids).logits - fused).abs().max() < 1e-4  # same function, different rounding
+
+
+def test_lazy_trie_paths_match_eager_ones():
+    """TokenTrie.extend_cache_lazy makes one node and leaves the rest of the path as a tail that grows when a walk gets
+    there: every prefix must then find the same row an eagerly built trie holds, whatever the order of extensions and
+    walks, and rows a budget took away are gone in both."""
+    import random
+
+    from genlm_backend_amd.cache import RowLRU, TokenTrie
+
+    rnd = random.Random(7)
+    V = 8
+    eager, lazy = TokenTrie(), TokenTrie()
+    st_e, st_l = RowLRU(1 << 40), RowLRU(1 << 40)
+
+    def walk(root, toks):
+        node, k = root, 0
+        while k < len(toks) and node.has_token(toks[k]):
+            node, k = node.get_token(toks[k]), k + 1
+        return node, k
+
+    seqs = []
+    for step in range(300):
+        if seqs and rnd.random() < 0.5:  # extend an earlier context or branch off inside it
+            base = list(rnd.choice(seqs))
+            cut = rnd.randint(0, len(base))
+            toks = base[:cut] + [rnd.randrange(5) for _ in range(rnd.randint(1, 6))]
+        else:
+            toks = [rnd.randrange(5) for _ in range(rnd.randint(1, 9))]
+        seqs.append(toks)
+        ne, ke = walk(eager, toks)
+        nl, kl = walk(lazy, toks)
+        assert ke == kl
+        if ke == len(toks):
+            continue
+        rows = torch.full((len(toks) - ke, V), float(step))  # row of position j: rows[j - ke]
+        last = ne.extend_cache_rows(ke, toks, rows, ke, store=st_e)
+        t, i = nl.extend_cache_lazy(kl, list(toks), rows, kl, store=st_l)
+        assert torch.equal(last.logprobs, t[i])
+        if rnd.random() < 0.3:  # look at every prefix of a random earlier context
+            probe = rnd.choice(seqs)
+            for k in range(1, len(probe) + 1):
+                a, ka = walk(eager, probe[:k])
+                b, kb = walk(lazy, probe[:k])
+                assert ka == kb == k and torch.equal(a.logprobs, b.logprobs)
+    for toks in seqs:
+        for k in range(1, len(toks) + 1):
+            a, _ = walk(eager, toks[:k])
+            b, _ = walk(lazy, toks[:k])
+            assert torch.equal(a.logprobs, b.logprobs)
+    # a budget of one slab: older rows are gone from both, the newest stay
+    small_e, small_l = RowLRU(1), RowLRU(1)
+    e2, l2 = TokenTrie(), TokenTrie()
+    for step, toks in enumerate(([1, 2, 3], [1, 2, 4, 4], [3, 3])):
+        rows = torch.full((len(toks), V), float(step))
+        ne, ke = walk(e2, toks)
+        nl, kl = walk(l2, toks)
+        ne.extend_cache_rows(ke, toks, rows[ke:], ke, store=small_e)
+        nl.extend_cache_lazy(kl, toks, rows, 0, store=small_l)
+    for toks, alive in (([1, 2, 3], False), ([1, 2, 4, 4], False), ([3, 3], True), ([3], True)):
+        a, ka = walk(e2, toks)
+        b, kb = walk(l2, toks)
+        assert ka == kb == len(toks) and a.has_row() == b.has_row() == alive
