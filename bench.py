@@ -211,6 +211,8 @@ def main():
                     help="sis workloads with the prompt's KV cached (hf.py:155-164 cache_kv; BASELINE config 3)")
     ap.add_argument("--prompts", type=int, default=1, help="distinct shared prompts over the population (config 3: 1 / 8 / 64)")
     ap.add_argument("--resample", action="store_true", help="systematic resampling after every step (replicated, deterministic)")
+    ap.add_argument("--kv-gather", action="store_true",
+                    help="--particle-kv: always gather the live KV rows into batch order (never run the forward on the slab in place)")
     ap.add_argument("--no-rccl-single", action="store_true",
                     help="N = 1 sis workloads: do NOT route the per-step exchange through a one-rank RCCL group")
     args = ap.parse_args()
@@ -272,7 +274,8 @@ def main():
         runner = SisBenchWorkload(eng, dev, rank, world, dist, prefix_kv=args.prefix_kv, particle_kv=args.particle_kv,
                                   model="llama-3.2-1b" if workload == "sis-llama" else "gpt2",
                                   n_particles=512 if workload == "sis-llama" else 1024, n_prompts=args.prompts,
-                                  resample=args.resample, force_collectives=force_coll)
+                                  resample=args.resample, force_collectives=force_coll,
+                                  kv_in_place=None if args.kv_gather else 0.75)
 
     rccl_ranks = None
     if dist is not None:  # one collective before the clock starts: proves every rank is on the RCCL communicator

@@ -113,10 +113,16 @@ class _SharedLayer(_SlabLayer):
 
     def update(self, key_states, value_states, *args, **kwargs):
         o = self.owner
+        eng = o.engine
+        if o.in_place:  # the forward's batch IS the slab: row b's token goes to row b, attention reads the slabs
+            if key_states.shape[0] != o.n or key_states.shape[-2] != 1:
+                raise ValueError("an in-place forward takes one token for every slab row")
+            eng.kv_append(self.keys, key_states, o.pos)
+            eng.kv_append(self.values, value_states, o.pos)
+            return self.keys, self.values
         U = o.rows.numel()
         if key_states.shape[0] != U or key_states.shape[-2] != 1:
             raise ValueError("SharedSlabKV takes one new token for every row of the forward")
-        eng = o.engine
         # the new token's K / V: into the row that keeps it, and beside the gathered prefix the attention reads
         eng.kv_append(self.keys, key_states, o.pos, rows=o.rows)
         eng.kv_append(self.values, value_states, o.pos, rows=o.rows)
@@ -141,12 +147,13 @@ class SharedSlabKV(SlabKV):
         self.pos = None
         self.rows = None   # int32 [U]: slab row of every forward row
         self.ident = None  # int32 arange(n)
+        self.in_place = False
         self._alt = None
         self._ptrs = None
 
     def set_forward(self, rows, pos):
         """rows, pos: int32 [U] device.  Gathers the U prefixes (pos[u] positions of row rows[u]) into the staging slabs."""
-        self.rows, self.pos = rows, pos
+        self.rows, self.pos, self.in_place = rows, pos, False
         U = rows.numel()
         if self.ident is None:
             self.ident = torch.arange(self.n, dtype=torch.int32, device=rows.device)
@@ -157,6 +164,12 @@ class SharedSlabKV(SlabKV):
         slabs = self._tensors(self.layers)
         stage = [t for layer in self.layers for t in (layer.stage_keys, layer.stage_values)]
         self.engine.kv_gather_rows(slabs, stage, src_row_of, len_of)
+
+    def set_forward_in_place(self, pos):
+        """The next forward runs on ALL slab rows where they lie (batch row b = slab row b, pos: int32 [n] device, the
+        position row b's token is appended at): no gather.  Worth it when most rows are live - a free row costs a
+        forward row whose result nobody reads, the gather costs every live row's whole prefix, read and written."""
+        self.rows, self.pos, self.in_place = None, pos, True
 
     def copy_rows(self, src_row_of, len_of):
         """Row r with src_row_of[r] >= 0 takes the first len_of[r] positions of row src_row_of[r] (in place: sources

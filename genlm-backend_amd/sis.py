@@ -102,6 +102,8 @@ class DeviceSIS:
                      never coincide.
     kv_rows          row budget of the shared store (default: one per particle, which always suffices); contexts that
                      find no free row are served without their KV being kept.
+    kv_in_place      with shared KV rows: the fraction of live slab rows from which a forward runs on the slab in place
+                     (free rows ride along) instead of gathering the live rows' prefixes into batch order
     force_collectives  run the collectives of the multi-rank path (all-gather of log-weights / token matrices, the
                      set-up reductions) through `dist` even when world == 1: a one-rank "nccl" group exercises the RCCL
                      code of an 8-GPU run on a single GPU.
@@ -109,7 +111,7 @@ class DeviceSIS:
 
     def __init__(self, llm, n_particles, prompt_ids, max_tokens, eos_id, seed=0, rng="philox", rank=0, world=1,
                  dist=None, use_prefix_kv=False, use_particle_kv=False, resample_ess=None, force_collectives=False,
-                 share_kv=True, kv_rows=None):
+                 share_kv=True, kv_rows=None, kv_in_place=0.75):
         self.llm, self.eng, self.dev = llm, llm.engine, llm.device
         self.N, self.max_tokens, self.eos_id = n_particles, max_tokens, eos_id
         self.rank, self.world, self.dist = rank, world, dist
@@ -162,7 +164,10 @@ class DeviceSIS:
         self.particle_kv = bool(use_particle_kv)
         self.share_kv = bool(share_kv) and self.particle_kv
         self.kv_rows = int(kv_rows) if kv_rows is not None else n_particles
-        self.kv_stats = dict(forward_rows=0, encoded_rows=0, copied_rows=0, unkept_rows=0, steps=0)
+        self.kv_stats = dict(forward_rows=0, encoded_rows=0, copied_rows=0, unkept_rows=0, steps=0, in_place_steps=0)
+        # a forward runs on the KV slab rows where they lie when at least this fraction of them is live (None: always
+        # gather the live rows into batch order)
+        self.kv_in_place = kv_in_place
         if self.particle_kv:
             assert not use_prefix_kv
         self.resample_ess = resample_ess
@@ -326,13 +331,28 @@ class DeviceSIS:
                 src_full[grp_row[copied]] = old[copied]
                 len_full[grp_row[copied]] = L[copied] - 1
                 self.pkv.copy_rows(to_dev(src_full), to_dev(len_full))
-            pos_a = to_dev(L[A] - 1)
-            reps_a = to_dev(rep_h[A], torch.int64)
-            ids = self.contexts[reps_a, pos_a.long()].view(-1, 1).long()
-            self.pkv.set_forward(to_dev(grp_row[A]), pos_a)
-            out = llm._body(input_ids=ids, position_ids=pos_a.view(-1, 1).long(),
-                            attention_mask=self.pkv.attention_mask(pos_a), past_key_values=self.pkv, use_cache=True)
-            logits_parts.append(llm._lm_head(out.last_hidden_state[:, 0]))
+            if self.kv_in_place is not None and len(A) >= self.kv_in_place * R:
+                # most rows are live: the forward runs on the slab rows where they lie (free rows ride along with a
+                # dummy token) instead of gathering the live rows' prefixes into batch order
+                rows_a = grp_row[A]
+                pos_full, rep_full = np.zeros(R, np.int32), np.zeros(R, np.int64)
+                pos_full[rows_a] = L[A] - 1
+                rep_full[rows_a] = rep_h[A]
+                pos_d = to_dev(pos_full)
+                ids = self.contexts[to_dev(rep_full, torch.int64), pos_d.long()].view(-1, 1).long()
+                self.pkv.set_forward_in_place(pos_d)
+                out = llm._body(input_ids=ids, position_ids=pos_d.view(-1, 1).long(),
+                                attention_mask=self.pkv.attention_mask(pos_d), past_key_values=self.pkv, use_cache=True)
+                logits_parts.append(llm._lm_head(out.last_hidden_state[to_dev(rows_a, torch.int64), 0]))
+                st["in_place_steps"] += 1
+            else:
+                pos_a = to_dev(L[A] - 1)
+                reps_a = to_dev(rep_h[A], torch.int64)
+                ids = self.contexts[reps_a, pos_a.long()].view(-1, 1).long()
+                self.pkv.set_forward(to_dev(grp_row[A]), pos_a)
+                out = llm._body(input_ids=ids, position_ids=pos_a.view(-1, 1).long(),
+                                attention_mask=self.pkv.attention_mask(pos_a), past_key_values=self.pkv, use_cache=True)
+                logits_parts.append(llm._lm_head(out.last_hidden_state[:, 0]))
         if len(B):
             sel = to_dev(rep_h[B])
             l_max = int(L[B].max())
@@ -580,95 +600,6 @@ class DeviceSampler(DeviceSIS):
         else:  # unseeded: in-kernel Philox keyed from torch's global generator
             self.seed = int(torch.randint(0, 2**62, (1,)).item())
 
-    @torch.no_grad()
-    def _step_shared_kv(self, time_kernel):
-        """One step with shared KV rows.  The distinct contexts (hf.py:214-220 dedup) are the forward's rows; each is
-        (A) a context whose prefix sits in a slab row - one new token is fed, its K / V appended in place; when several
-        new contexts grew out of one row, the first keeps it and the others get a copy of the prefix in a free row; or
-        (B) a context without a row (step 0, an ancestor from another rank, a spent row budget) - encoded from its tokens
-        like the reference does every step, its KV kept if a row is free.  The block table lives on the host (a few KB
-        per step ride on the step's one D2H copy); the rows move on the device."""
-        eng, llm, dev, N, R = self.eng, self.llm, self.dev, self.N, self.kv_rows
-        ctx_flat = self.contexts.view(-1)
-        lengths_eff = torch.where(self.active > 0, self.lengths, torch.ones_like(self.lengths))
-        hashes_eff = torch.where(self.active > 0, self.hashes, self._hash_stub)
-        group_of, rep, ng = eng.group_contexts(ctx_flat, self.starts, lengths_eff, hashes=hashes_eff)
-        len_rep = lengths_eff[rep.long().clamp(0, N - 1)]  # (entries of `rep` past the group count are unspecified)
-        head = torch.cat([torch.stack([ng[0], self.active.sum().to(torch.int32), self._global_active]), group_of, rep,
-                          len_rep]).cpu().numpy()  # the step's one D2H copy
-        U, n_active, n_global = int(head[0]), int(head[1]), int(head[2])
-        g_h, rep_h, L = head[3:3 + N], head[3 + N:3 + N + U], head[3 + 2 * N:3 + 2 * N + U]
-        # ---- block table (host): who keeps its row, who gets a copy, who is encoded
-        old = self._row_of_h[rep_h]
-        has = old >= 0
-        idx_has = np.nonzero(has)[0]
-        _, first = np.unique(old[idx_has], return_index=True)
-        keep = idx_has[np.sort(first)]                      # first group (by id) of every live row keeps it
-        copies = np.setdiff1d(idx_has, keep)                # the others grew out of a row somebody else keeps
-        fresh = np.nonzero(~has)[0]
-        grp_row = np.full(U, -1, np.int32)
-        grp_row[keep] = old[keep]
-        live = np.zeros(R, bool)
-        live[grp_row[keep]] = True
-        free = np.nonzero(~live)[0]
-        need = np.concatenate([copies, fresh])              # copies first: a copy is cheaper than an encoding
-        k = min(len(need), len(free))
-        grp_row[need[:k]] = free[:k]
-        copied = copies[grp_row[copies] >= 0]
-        in_a = np.zeros(U, bool)
-        in_a[keep] = True
-        in_a[copied] = True
-        A, B = np.nonzero(in_a)[0], np.nonzero(~in_a)[0]
-        order = np.concatenate([A, B])                      # logits row r belongs to group order[r]
-        inv = np.empty(U, np.int32)
-        inv[order] = np.arange(U, dtype=np.int32)
-        self._row_of_h = grp_row[g_h]
-        st = self.kv_stats
-        st["forward_rows"] += U
-        st["encoded_rows"] += len(B)
-        st["copied_rows"] += len(copied)
-        st["unkept_rows"] += int((grp_row[B] < 0).sum())
-        st["steps"] += 1
-        to_dev = lambda a, dt=torch.int32: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dt, non_blocking=True)
-        logits_parts = []
-        if len(A):
-            if len(copied):
-                src_full, len_full = np.full(R, -1, np.int32), np.zeros(R, np.int32)
-                src_full[grp_row[copied]] = old[copied]
-                len_full[grp_row[copied]] = L[copied] - 1
-                self.pkv.copy_rows(to_dev(src_full), to_dev(len_full))
-            pos_a = to_dev(L[A] - 1)
-            reps_a = to_dev(rep_h[A], torch.int64)
-            ids = self.contexts[reps_a, pos_a.long()].view(-1, 1).long()
-            self.pkv.set_forward(to_dev(grp_row[A]), pos_a)
-            out = llm._body(input_ids=ids, position_ids=pos_a.view(-1, 1).long(),
-                            attention_mask=self.pkv.attention_mask(pos_a), past_key_values=self.pkv, use_cache=True)
-            logits_parts.append(llm._lm_head(out.last_hidden_state[:, 0]))
-        if len(B):
-            sel = to_dev(rep_h[B])
-            l_max = int(L[B].max())
-            ids, am, pos, last = eng.gather_padded(ctx_flat, self.starts, lengths_eff, sel, len(B), None, 0, 0, l_max)
-            out = llm._body(input_ids=ids, attention_mask=am, position_ids=pos, use_cache=True)
-            h_last = out.last_hidden_state[torch.arange(len(B), device=dev), last.long()]
-            logits_parts.append(llm._lm_head(h_last))
-            stored = B[grp_row[B] >= 0]
-            if len(stored):
-                src = [(ly.keys.contiguous(), ly.values.contiguous()) for ly in out.past_key_values.layers]
-                if self.pkv is None:
-                    from .kv import SharedSlabKV
-
-                    self.pkv = SharedSlabKV(eng, R, self.cap, len(src))
-                src_full, len_full = np.full(R, -1, np.int32), np.zeros(R, np.int32)
-                where_b = np.full(U, -1, np.int32)
-                where_b[B] = np.arange(len(B), dtype=np.int32)
-                src_full[grp_row[stored]] = where_b[stored]
-                len_full[grp_row[stored]] = L[stored]
-                self.pkv.fill_rows(src, to_dev(src_full), to_dev(len_full))
-        logits = logits_parts[0] if len(logits_parts) == 1 else torch.cat(logits_parts)
-        self._rep = to_dev(rep_h[order])
-        self._noise_groups = group_of  # parity draws follow the reference's resolution order: by dedup group
-        return self._finish_step(logits, to_dev(inv[g_h]), U, n_active, n_global, time_kernel, l_max=1)
-
     def _finish_step(self, logits, group_of, U, n_active, n_global, time_kernel, l_max):
         eng, N, dev = self.eng, self.N, self.dev
         V = logits.shape[-1]
@@ -712,7 +643,7 @@ class SisBenchWorkload:
     V = 128256, 512 particles (config 4: 4096 over 8 GPUs)."""
 
     def __init__(self, eng, dev, rank, world, dist, n_particles=1024, max_tokens=10, prefix_kv=False, particle_kv=False,
-                 model="gpt2", n_prompts=1, resample=False, force_collectives=False):
+                 model="gpt2", n_prompts=1, resample=False, force_collectives=False, kv_in_place=0.75):
         from .llm import AsyncAmdLM
 
         if model == "gpt2":
@@ -750,7 +681,7 @@ class SisBenchWorkload:
         self.sis = DeviceSIS(self.llm, n_particles, prompts, max_tokens, cfg.eos_token_id,
                              seed=1234, rank=rank, world=world, dist=dist, use_prefix_kv=prefix_kv,
                              use_particle_kv=particle_kv, resample_ess=1.0 if resample else None,
-                             force_collectives=force_collectives)
+                             force_collectives=force_collectives, kv_in_place=kv_in_place)
         self.prefix_kv = prefix_kv
         self.particle_kv = particle_kv
         self.resample = resample
