@@ -30,6 +30,8 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_sis -o f -- pytho
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_sis -o w -- python3 $R/bench.py --workload sis --steps 20 --warmup 0 --no-cpu > $O/pmc_w_sis.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_sis-llama -o s -- python3 $R/bench.py --workload sis-llama --steps 20 --warmup 3 --no-cpu > $O/kstats_sis-llama.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_lsm -o l -- python3 $R/tools/kbench_lsm.py > $O/kstats_lsm.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_lsm -o f -- python3 $R/tools/kbench_lsm.py > $O/pmc_f_lsm.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_lsm -o w -- python3 $R/tools/kbench_lsm.py > $O/pmc_w_lsm.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_trie -o t -- python3 $R/tools/tbench.py > $O/kstats_trie.log 2>&1
 python3 $R/tools/trace_by_grid.py $(find $O/kstats_lsm -name "*kernel_trace.csv" | head -1) > $O/lsm_by_shape.txt 2>&1
 python3 $R/tools/trace_by_grid.py $(find $O/kstats_trie -name "*kernel_trace.csv" | head -1) > $O/trie_by_shape.txt 2>&1
