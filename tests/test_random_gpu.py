@@ -112,3 +112,13 @@ def test_random_case(engine, oracle, c):
             assert np.array_equal(tok.cpu().numpy(), tok_o), f"token ({what})"
 
     check(call(), "auto")
+    # the same rows through glb_log_softmax_rows (the one-launch kernel of independent waves; -inf and NaN logits, odd
+    # sizes, misaligned and padded rows): lse and every finite log-probability bit for bit, NaN where the logit is NaN
+    want, lse_w = O.log_softmax_rows(x_np, c["scale"])
+    got, lse_g = engine.log_softmax_rows(x_d, vocab=V, logit_scale=c["scale"], want_lse=True)
+    torch.cuda.synchronize()
+    got, lse_g = got.cpu().numpy(), lse_g.cpu().numpy()
+    assert np.array_equal(lse_g.view(np.uint32), lse_w.view(np.uint32)), "log_softmax lse"
+    nan = np.isnan(want)
+    assert np.array_equal(np.isnan(got), nan), "log_softmax NaN pattern"
+    assert np.array_equal(got.view(np.uint32)[~nan], want.view(np.uint32)[~nan]), "log_softmax rows"
