@@ -235,3 +235,92 @@ class TokenByteTrie:
     def weight_max(self, ws):
         """base.py:171-193"""
         return self.batch_weight_max(self._rows(ws))[0]
+
+
+class AsyncTokenByteTrie:
+    """Awaitable `weight_sum` / `weight_max` with automatic batching: the counterpart of the reference's
+    `AsyncTokenCharacterTrie` (trie/async_impl.py:10-160).  Coroutines hand over one weight row each; whatever has been
+    handed over by the time the event loop gets back to the drain task goes to the device as ONE batch per operation
+    (glb_trie_masses on the folded trie), and every caller gets its row of the result - a float32 device tensor
+    [n_nodes] (the reference returns NumPy rows; `.cpu().numpy()` gives those).  A failing batch fails every request
+    in it (async_impl.py:129-134)."""
+
+    def __init__(self, trie):
+        self.trie = trie
+        self._pending = []   # (weights row, future, op)
+        self._task = None
+        self._wake = None
+
+    @classmethod
+    def from_vocab(cls, vocab, engine=None, **kwargs):
+        """async_impl.py:23-45 (one implementation here: the device one)."""
+        return cls(TokenByteTrie(vocab, engine=engine, **kwargs))
+
+    def start(self):
+        """Start the drain task on the running loop (done by the first request)."""
+        import asyncio
+
+        if self._task is None or self._task.done():
+            self._wake = asyncio.Event()
+            self._task = asyncio.get_running_loop().create_task(self._drain())
+
+    async def _request(self, ws, op):
+        import asyncio
+
+        self.start()
+        fut = asyncio.get_running_loop().create_future()
+        self._pending.append((ws, fut, op))
+        self._wake.set()
+        return await fut
+
+    async def weight_sum(self, ws):
+        """async_impl.py:55-67"""
+        return await self._request(ws, 0)
+
+    async def weight_max(self, ws):
+        """async_impl.py:69-81"""
+        return await self._request(ws, 1)
+
+    async def _drain(self):
+        while True:
+            await self._wake.wait()
+            self._wake.clear()
+            batch, self._pending = self._pending, []
+            try:
+                for op in (0, 1):
+                    group = [(w, f) for w, f, o in batch if o == op]
+                    if not group:
+                        continue
+                    rows = torch.stack([torch.as_tensor(w, dtype=torch.float32).to(self.trie.engine.device) for w, _ in group])
+                    out = self.trie._batch(rows, op, False)
+                    for (_, f), r in zip(group, out):
+                        if not f.done():
+                            f.set_result(r)
+            except Exception as e:  # noqa: BLE001 - whatever went wrong, nobody may be left waiting
+                for _, f, _ in batch:
+                    if not f.done():
+                        f.set_exception(e)
+
+    async def cleanup(self):
+        """async_impl.py:136-145"""
+        import asyncio
+
+        if self._task is not None and not self._task.done():
+            self._task.cancel()
+            try:
+                await self._task
+            except asyncio.CancelledError:
+                pass
+        self._task = None
+
+    def shutdown(self):
+        """async_impl.py:147-156"""
+        if self._task is not None:
+            try:
+                self._task.cancel()
+            except RuntimeError:  # the loop is gone
+                pass
+            self._task = None
+
+    def __del__(self):
+        self.shutdown()

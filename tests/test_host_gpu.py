@@ -640,3 +640,74 @@ def test_trie_masses_from_logits(engine, oracle):
     got = engine.trie_masses(wb.to(dev), trie.device_arrays(), 0, False)
     want = oracle.trie_reduce(wb.float().numpy(), trie.flat(), 0)
     assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
+
+
+def test_async_trie_batches_concurrent_requests(engine, oracle):
+    """AsyncTokenByteTrie (trie/async_impl.py counterpart): 40 coroutines asking for sums and 9 for maxima are served by
+    one device batch each, every caller gets its own row, bit for bit what the batched call gives; a bad request fails
+    its batch's callers and the trie keeps serving."""
+    import asyncio
+
+    from genlm_backend_amd.tokenization import Token
+    from genlm_backend_amd.trie import AsyncTokenByteTrie
+
+    rs = np.random.default_rng(11)
+    words, seen = [], set()
+    while len(words) < 500:
+        w = bytes(rs.integers(97, 101, int(rs.integers(1, 6))).astype(np.uint8))
+        if w not in seen:
+            seen.add(w)
+            words.append(w)
+    at = AsyncTokenByteTrie.from_vocab([Token(i, w) for i, w in enumerate(words)], engine=engine)
+    ws = rs.random((49, len(words))).astype(np.float32)
+    calls = []
+    orig = at.trie._batch
+    at.trie._batch = lambda rows, op, flp: (calls.append((rows.shape[0], op)), orig(rows, op, flp))[1]
+
+    async def main():
+        res = await asyncio.gather(*[at.weight_sum(torch.from_numpy(ws[i])) for i in range(40)],
+                                   *[at.weight_max(ws[i]) for i in range(40, 49)])
+        with pytest.raises(Exception):
+            await at.weight_sum(torch.zeros(3))          # wrong length: the batch fails, the caller hears of it
+        again = await at.weight_sum(ws[0])
+        await at.cleanup()
+        return res, again
+
+    res, again = asyncio.run(main())
+    assert sorted(calls[:2]) == [(9, 1), (40, 0)]
+    want_s = oracle.trie_reduce(ws[:40], at.trie.flat(), 0)
+    want_m = oracle.trie_reduce(ws[40:], at.trie.flat(), 1)
+    got_s = torch.stack(res[:40]).cpu().numpy()
+    got_m = torch.stack(res[40:]).cpu().numpy()
+    assert np.array_equal(got_s.view(np.uint32), want_s.view(np.uint32))
+    assert np.array_equal(got_m.view(np.uint32), want_m.view(np.uint32))
+    assert torch.equal(again, res[0])
+
+
+def test_prefix_kv_is_evicted_least_recently_used_first_on_gpu(llm):
+    """`cache_kv` prefixes under a byte budget on the device (kv.PrefixLRU): the least recently used prefix leaves,
+    queries below it fall back to re-encoding and still match the uncached evaluation; the ones in use stay and keep
+    serving the batched kernels (glb_match_prefixes / glb_gather_kv_padded read the slabs by pointer)."""
+    m, _ = llm
+    m.clear_cache()
+    pres = [[5, 6, 7], [8, 9, 10, 11], [12, 13]]
+    m.cache_kv(pres[0])
+    one = m._kv_lru.used
+    old_budget = m._kv_lru.budget
+    try:
+        m._kv_lru.budget = int(one * 2.5)  # room for two three-token prefixes
+        m.cache_kv(pres[1])
+        m.walk_cache(pres[0] + [1])        # touch prefix 0: prefix 1 is now the least recently used
+        m.cache_kv(pres[2])
+        assert m._kv_lru.evictions >= 1 and m._kv_lru.used <= m._kv_lru.budget
+        assert m.walk_cache(pres[1] + [1])[2] is None
+        assert m.walk_cache(pres[0] + [1])[2] is not None and m.walk_cache(pres[2] + [1])[2] is not None
+        qs = [pres[1] + [3], pres[0] + [3], pres[2] + [4, 5]]
+        got = asyncio.run(m.batch_next_token_logprobs(qs))
+        for p, row in zip(qs, got):
+            assert np.abs(row.cpu().numpy() - m.next_token_logprobs_uncached(p).cpu().numpy()).max() < TOL
+        logZ, tok = m.batch_next_token_step_sync([pres[0] + [1], pres[1] + [2], pres[2] + [9]])  # device prefix table
+        assert len(tok) == 3 and np.isfinite(np.asarray(logZ)).all()
+    finally:
+        m._kv_lru.budget = old_budget
+        m.clear_cache()
