@@ -211,6 +211,9 @@ def main():
                     help="sis workloads with the prompt's KV cached (hf.py:155-164 cache_kv; BASELINE config 3)")
     ap.add_argument("--prompts", type=int, default=1, help="distinct shared prompts over the population (config 3: 1 / 8 / 64)")
     ap.add_argument("--resample", action="store_true", help="systematic resampling after every step (replicated, deterministic)")
+    ap.add_argument("--auto-kv", action="store_true",
+                    help="api workload: KV rows that follow the contexts handed to batch_next_token_step (beyond the reference: "
+                         "one token per context per step instead of a re-encoding)")
     ap.add_argument("--kv-gather", action="store_true",
                     help="--particle-kv: always gather the live KV rows into batch order (never run the forward on the slab in place)")
     ap.add_argument("--no-rccl-single", action="store_true",
@@ -267,7 +270,8 @@ def main():
     if workload in ("kernel", "kernel-llama"):
         runner = KernelWorkload(eng, dev, rank, world, dist, llama=workload == "kernel-llama")
     elif workload in ("api", "api-coro", "api-logprobs"):
-        runner = ApiWorkload(eng, dev, rank, world, dist, logprobs=workload == "api-logprobs", coro=workload == "api-coro")
+        runner = ApiWorkload(eng, dev, rank, world, dist, logprobs=workload == "api-logprobs", coro=workload == "api-coro",
+                             auto_kv=args.auto_kv)
     else:
         from genlm_backend_amd.sis import SisBenchWorkload
 
@@ -492,7 +496,8 @@ class ApiWorkload:
 
     dtype_name = "f32"
 
-    def __init__(self, eng, dev, rank, world, dist, logprobs=False, coro=False, n_particles=1024, max_tokens=10):
+    def __init__(self, eng, dev, rank, world, dist, logprobs=False, coro=False, n_particles=1024, max_tokens=10,
+                 auto_kv=False):
         import asyncio
 
         from transformers import GPT2Config
@@ -502,7 +507,9 @@ class ApiWorkload:
         self.asyncio = asyncio
         cfg = GPT2Config()
         self.llm = AsyncAmdLM.from_config(cfg, None, device=dev, dtype=torch.float32, seed=1234, engine=eng,
-                                          batch_size=n_particles, timeout=0.02)
+                                          batch_size=n_particles, timeout=0.02,
+                                          auto_kv_rows=n_particles + n_particles // 4 if auto_kv else 0, auto_kv_cap=24)
+        self.auto_kv = auto_kv
         V = cfg.vocab_size
         g = torch.Generator(device=dev)
         g.manual_seed(4321)
@@ -574,7 +581,11 @@ class ApiWorkload:
               "README loop over 1024 Python-side particles, each step's requests submitted as one "
               "AsyncAmdLM.batch_next_token_step call") + ", prompt len 8, <=10 new tokens, 2 shared bit masks, Philox draws "
              "(README.md:72-98)")
-        return {"workload": what + "; gpt2-small shape (random init, fp32)", "particles_per_gpu": self.N, "vocab": self.V}
+        extra = {}
+        if self.auto_kv:
+            what += "; KV rows follow the contexts (AsyncAmdLM(auto_kv_rows=...): beyond the reference)"
+            extra["auto_kv"] = dict(self.llm._auto_kv.stats)
+        return {"workload": what + "; gpt2-small shape (random init, fp32)", "particles_per_gpu": self.N, "vocab": self.V, **extra}
 
 
 if __name__ == "__main__":

@@ -188,7 +188,10 @@ class AsyncAmdLM(AsyncLM):
 
     @torch.no_grad()
     def __init__(self, hf_model, hf_tokenizer, batch_size=20, timeout=0.02, engine=None, fuse_activations=True,
-                 kv_budget_bytes=8 << 30, logprob_budget_bytes=16 << 30):
+                 kv_budget_bytes=8 << 30, logprob_budget_bytes=16 << 30, auto_kv_rows=0, auto_kv_cap=64):
+        """auto_kv_rows > 0: `batch_next_token_step` keeps the KV of the contexts it evaluates in that many slab rows of
+        `auto_kv_cap` positions and feeds one token to every context whose first L - 1 tokens it finds there
+        (autokv.AutoKV; off by default: the reference re-encodes, hf.py:202-288)."""
         self.model = hf_model
         self.tokenizer = hf_tokenizer
         self.device = hf_model.device
@@ -220,6 +223,12 @@ class AsyncAmdLM(AsyncLM):
         self._kv_lru = PrefixLRU(kv_budget_bytes, on_remove=self._forget_prefix)
         # log-prob rows on trie nodes: views into their batch's [R, V] slab, least recently used slab out first
         self._rows = RowLRU(logprob_budget_bytes)
+        # KV rows that follow the contexts handed to batch_next_token_step (off unless auto_kv_rows > 0)
+        self._auto_kv = None
+        if auto_kv_rows:
+            from .autokv import AutoKV
+
+            self._auto_kv = AutoKV(self, auto_kv_rows, auto_kv_cap)
         # fused-step state
         self._mask_kind = MASK_NONE
         self._masks = None
@@ -244,10 +253,14 @@ class AsyncAmdLM(AsyncLM):
         self._kv_tokens.clear()
         self._rows.clear()
         self.cache = TokenTrie()
+        if self._auto_kv is not None:
+            self._auto_kv.reset()
 
     def clear_kv_cache(self):
         self._kv_lru.clear()
         self.cache.clear_kv_cache()
+        if self._auto_kv is not None:
+            self._auto_kv.reset()
 
     def reset_async_queries(self):
         self.queries = []
@@ -686,6 +699,7 @@ class AsyncAmdLM(AsyncLM):
             mid_d = torch.from_numpy(mid).to(dev)
         head = [ng[0]]
         used_d = None
+        auto = self._auto_kv if (self._auto_kv is not None and not P["n"]) else None
         if P["n"]:
             pref, base = eng.match_prefixes(tok_d, st_d, ln_d, P["tokens"], P["starts"], P["lengths"])
             head.append((ln_d - base).max().to(torch.int32))
@@ -694,6 +708,14 @@ class AsyncAmdLM(AsyncLM):
         if mid_d is not None:  # may the mask ids go per logits row? (they do when the mask is a function of the context)
             row_mid = mid_d[rep.long().clamp(0, n - 1)]  # entries of `rep` past the group count are unspecified
             head.append((row_mid[group_of.long()] == mid_d).all().to(torch.int32))
+        if auto is not None:
+            # contexts find the KV rows of their first L - 1 tokens (autokv.AutoKV): one token per context is fed
+            logits, row_of_group, group_of_row, U, extra = auto.logits(tok_d, st_d, ln_d, group_of, rep, ng, head[1:])
+            by_row = bool(extra[-1]) if mid_d is not None else False
+            if mid_d is not None:
+                row_mid = row_mid[group_of_row]
+            return self._finish_batch_step(logits, row_of_group[group_of.long()], group_of, U, n, mid_d,
+                                           row_mid if mid_d is not None else None, by_row)
         n_head = len(head)
         head = torch.stack(head) if used_d is None else torch.cat([torch.stack(head), used_d])
         head = head.cpu().tolist()  # the call's one D2H copy before the forward
@@ -720,6 +742,12 @@ class AsyncAmdLM(AsyncLM):
         hidden = self._body(input_ids=ids, attention_mask=am, position_ids=pos, past_key_values=cache,
                             use_cache=cache is not None).last_hidden_state
         logits = self._lm_head(hidden[torch.arange(U, device=dev), last.long()])  # [U, V]
+        return self._finish_batch_step(logits, group_of, group_of, U, n, mid_d, row_mid if mid_d is not None else None, by_row)
+
+    def _finish_batch_step(self, logits, row_of, group_of, U, n, mid_d, row_mid, by_row):
+        """The fused step over a batch's logits rows (row_of: logits row of every context; group_of: its dedup group -
+        the order parity-mode noise is dealt in) and the call's one D2H copy of the results."""
+        eng, dev = self.engine, self.device
         V = logits.shape[-1]
         kw = self.step_masks(logits.dtype)
         if kw:
@@ -733,7 +761,7 @@ class AsyncAmdLM(AsyncLM):
             noise = torch.empty((n, V), dtype=torch.float32)
             noise[torch.from_numpy(order)] = self._host_rng.exponential(n * V).view(n, V)
             kw["noise"] = noise.to(dev, non_blocking=True)
-        logZ, _, tok = eng.step(logits, vocab=V, row_of=group_of, rng_mode=self._rng_mode, seed=self._rng_seed,
+        logZ, _, tok = eng.step(logits, vocab=V, row_of=row_of, rng_mode=self._rng_mode, seed=self._rng_seed,
                                 offset=self._batch_counter, want_lse=False, **kw)
         self._batch_counter += 1
         self.stats["batches"] += 1

@@ -413,3 +413,58 @@ def test_lazy_trie_paths_match_eager_ones():
         a, ka = walk(e2, toks)
         b, kb = walk(l2, toks)
         assert ka == kb == len(toks) and a.has_row() == b.has_row() == alive
+
+
+@pytest.mark.parametrize("rows,cap", [(64, 32), (6, 32), (64, 12)])
+def test_readme_sis_with_auto_kv_matches_reference(gold, rows, cap):
+    """`batch_next_token_step` with KV rows that follow the contexts (autokv.AutoKV): after the first call every context
+    finds the row of its first L - 1 tokens and feeds one token; tokens and weights of the README loop stay the
+    reference's - with rows to spare, with six rows for sixteen particles (contexts without a row are encoded) and
+    with rows too short for the later contexts (those are encoded and not kept)."""
+    from transformers import GPT2Config, GPT2LMHeadModel
+
+    from genlm_backend_amd.llm import AsyncAmdLM
+
+    cfg = ast.literal_eval(bytes(gold["config_json"]).decode())
+    model = GPT2LMHeadModel(GPT2Config(**cfg)).eval()
+    model.load_state_dict({k[3:]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("w::")})
+    llm = AsyncAmdLM(model, None, batch_size=64, timeout=0.02, engine=CpuOracleEngine(), auto_kv_rows=rows, auto_kv_cap=cap)
+    llm.tokenizer = Tok()
+    llm.register_masks(torch.from_numpy(gold["sis_masks"]))
+    prompt = [int(t) for t in gold["sis_prompt"]]
+    for rep in range(2):  # the second run starts from a cleared cache: same results
+        llm.clear_cache()
+        llm.set_rng("torch", 1234)
+        ctxs, lw, active = [[] for _ in range(16)], np.zeros(16, np.float64), [True] * 16
+        steps = 0
+        while any(active):
+            idx = [i for i in range(16) if active[i]]
+            logZ, tok = llm.batch_next_token_step_sync([prompt + ctxs[i] for i in idx],
+                                                       [1 if len(ctxs[i]) >= 10 else 0 for i in idx])
+            for i, z, t in zip(idx, logZ, tok):
+                lw[i] += z
+                if t == 0 or t < 0:
+                    active[i] = False
+                else:
+                    ctxs[i].append(int(t))
+            steps += 1
+        _check_sis(ctxs, lw, gold)
+        assert steps == int(gold["sis_steps"][0])
+        st = llm._auto_kv.stats
+        assert st["calls"] == steps and st["one_token_rows"] > 0
+        if rows == 64 and cap == 32:
+            assert st["encoded_rows"] == 1 and st["unkept_rows"] == 0 and st["copied_rows"] > 0  # only the prompt is encoded
+        if rows == 6:
+            assert st["unkept_rows"] > 0
+        if cap == 12:
+            assert st["unkept_rows"] > 0  # contexts of 13 tokens and more do not fit a row
+    # the same contexts again: every one finds the row that holds exactly it
+    llm.set_rng("torch", 99)
+    qs = [prompt + c[:3] for c in ctxs[:5]]
+    a = llm.batch_next_token_step_sync(qs, [0] * 5)
+    before = dict(llm._auto_kv.stats)
+    llm.set_rng("torch", 99)
+    b = llm.batch_next_token_step_sync(qs, [0] * 5)
+    assert np.array_equal(a[1], b[1]) and np.abs(a[0] - b[0]).max() < 1e-5
+    if rows == 64 and cap == 32:
+        assert llm._auto_kv.stats["encoded_rows"] == before["encoded_rows"]

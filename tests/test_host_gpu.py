@@ -711,3 +711,45 @@ def test_prefix_kv_is_evicted_least_recently_used_first_on_gpu(llm):
     finally:
         m._kv_lru.budget = old_budget
         m.clear_cache()
+
+
+def test_readme_sis_with_auto_kv_on_gpu(engine, llm):
+    """`batch_next_token_step` with KV rows that follow the contexts (autokv.AutoKV) on the device: the README loop's
+    tokens and weights are the reference's; after the first call every context is fed one token; gathering the rows and
+    running on the slab in place give the same run."""
+    from transformers import GPT2Config, GPT2LMHeadModel
+
+    from genlm_backend_amd.llm import AsyncAmdLM
+
+    _, gold = llm
+    cfg = ast.literal_eval(bytes(gold["config_json"]).decode())
+    runs = []
+    for in_place in (0.75, None):
+        model = GPT2LMHeadModel(GPT2Config(**cfg)).eval()
+        model.load_state_dict({k[3:]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("w::")})
+        m = AsyncAmdLM(model.to(engine.device), None, batch_size=64, timeout=0.02, engine=engine, auto_kv_rows=20, auto_kv_cap=32)
+        m._auto_kv.in_place = in_place
+        m.tokenizer = Tok()
+        m.register_masks(torch.from_numpy(gold["sis_masks"]))
+        m.set_rng("torch", 1234)
+        prompt = [int(t) for t in gold["sis_prompt"]]
+        ctxs, lw, active = [[] for _ in range(16)], np.zeros(16, np.float64), [True] * 16
+        steps = 0
+        while any(active):
+            idx = [i for i in range(16) if active[i]]
+            logZ, tok = m.batch_next_token_step_sync([prompt + ctxs[i] for i in idx],
+                                                     [1 if len(ctxs[i]) >= 10 else 0 for i in idx])
+            for i, z, t in zip(idx, logZ, tok):
+                lw[i] += z
+                if t == 0 or t < 0:
+                    active[i] = False
+                else:
+                    ctxs[i].append(int(t))
+            steps += 1
+        assert ctxs == [_strip(r) for r in gold["sis_contexts"]]
+        assert np.abs(np.asarray(lw, np.float32) - gold["sis_log_weights"]).max() < TOL
+        st = m._auto_kv.stats
+        assert steps == int(gold["sis_steps"][0]) and st["encoded_rows"] == 1 and st["unkept_rows"] == 0
+        assert (st["in_place_calls"] > 0) == (in_place is not None)
+        runs.append((ctxs, lw))
+    assert runs[0][0] == runs[1][0] and np.abs(runs[0][1] - runs[1][1]).max() < 1e-4
