@@ -16,6 +16,8 @@ python3 $R/bench.py --workload sis-llama --steps 30 --warmup 5 > $O/bench_sis-ll
 for w in "api" "api-coro" "api-logprobs"; do
   python3 $R/bench.py --workload $w --steps 20 --warmup 3 --no-cpu > $O/bench_$w.json 2> $O/bench_$w.err
 done
+python3 $R/bench.py --workload api --auto-kv --steps 20 --warmup 3 --no-cpu > $O/bench_api_autokv.json 2>> $O/bench_api.err
+python3 $R/bench.py --workload api-coro --auto-kv --steps 20 --warmup 3 --no-cpu > $O/bench_api-coro_autokv.json 2>> $O/bench_api.err
 python3 $R/bench.py --workload sis --prefix-kv --prompts 8 --steps 30 --warmup 5 --no-cpu > $O/bench_sis_prefixkv_k8.json 2>> $O/bench_sis.err
 python3 $R/bench.py --workload sis --prefix-kv --prompts 64 --steps 30 --warmup 5 --no-cpu > $O/bench_sis_prefixkv_k64.json 2>> $O/bench_sis.err
 python3 $R/bench.py --workload sis --particle-kv --steps 30 --warmup 5 --no-cpu > $O/bench_sis_particlekv.json 2>> $O/bench_sis.err
