@@ -468,3 +468,64 @@ def test_readme_sis_with_auto_kv_matches_reference(gold, rows, cap):
     assert np.array_equal(a[1], b[1]) and np.abs(a[0] - b[0]).max() < 1e-5
     if rows == 64 and cap == 32:
         assert llm._auto_kv.stats["encoded_rows"] == before["encoded_rows"]
+
+
+@pytest.mark.parametrize("collide", [False, True])
+def test_auto_kv_on_a_changing_set_of_contexts(gold, collide):
+    """Contexts that grow, shrink, repeat, fork and appear from nowhere between calls, eight KV rows for up to twelve
+    of them: every call's logZ and tokens equal those of a model without the rows.  `collide`: every context hashes to
+    the same value - the lookup then finds the wrong candidate most of the time, the token comparison rejects it, and
+    the results still hold (a hash never decides alone)."""
+    from transformers import GPT2Config, GPT2LMHeadModel
+
+    from genlm_backend_amd.llm import AsyncAmdLM
+
+    cfg = ast.literal_eval(bytes(gold["config_json"]).decode())
+    V = cfg["vocab_size"]
+
+    def make(**kw):
+        model = GPT2LMHeadModel(GPT2Config(**cfg)).eval()
+        model.load_state_dict({k[3:]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("w::")})
+        m = AsyncAmdLM(model, None, batch_size=64, timeout=0.02, engine=CpuOracleEngine(), **kw)
+        m.tokenizer = Tok()
+        m.register_masks(torch.from_numpy(gold["sis_masks"]))
+        return m
+
+    plain, auto = make(), make(auto_kv_rows=8, auto_kv_cap=10)
+    if collide:
+        eng = auto.engine
+        real = eng.hash_contexts
+        eng.hash_contexts = lambda tok, st, ln: torch.full_like(real(tok, st, ln), 12345)
+    rnd = np.random.default_rng(5)
+    ctxs = [[int(t) for t in rnd.integers(1, V, int(rnd.integers(1, 5)))] for _ in range(6)]
+    for call in range(14):
+        nxt = []
+        for c in ctxs:
+            r = rnd.random()
+            if r < 0.55:
+                nxt.append(c + [int(rnd.integers(1, V))])             # grows by one token
+            elif r < 0.65:
+                nxt.append(list(c))                                    # asked again as it is
+            elif r < 0.75 and len(c) > 1:
+                nxt.append(c[:-1])                                     # shrinks
+            elif r < 0.85:
+                nxt.append(c + [int(t) for t in rnd.integers(1, V, 3)])  # jumps ahead: no row holds its first L - 1 tokens
+            else:
+                nxt.append([int(t) for t in rnd.integers(1, V, int(rnd.integers(1, 12)))])  # from nowhere (some too long for a row)
+        if rnd.random() < 0.7:
+            nxt.append(list(ctxs[int(rnd.integers(0, len(ctxs)))]) + [int(rnd.integers(1, V))])  # a fork: a second child of a row
+        if len(nxt) > 12:
+            nxt = nxt[:12]
+        ctxs = nxt
+        mids = [int(rnd.integers(0, 2)) for _ in ctxs]
+        for m in (plain, auto):
+            m.set_rng("philox", 77 + call)
+        z0, t0 = plain.batch_next_token_step_sync(ctxs, mids)
+        z1, t1 = auto.batch_next_token_step_sync(ctxs, mids)
+        fin = np.isfinite(z0)
+        assert np.array_equal(fin, np.isfinite(z1)) and np.abs(z0[fin] - z1[fin]).max() < 1e-4, call
+        assert np.array_equal(t0, t1), call
+    st = auto._auto_kv.stats
+    assert st["encoded_rows"] > 0 and st["unkept_rows"] > 0
+    if not collide:
+        assert st["one_token_rows"] > 20 and st["copied_rows"] > 0
