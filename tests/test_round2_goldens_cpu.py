@@ -180,7 +180,7 @@ def test_config3_shared_ragged_prompts(gold, K, mode):
     assert sis.last_stats["n_unique"] <= 64
 
 
-def _llama_tiny(gold, engine=None, device="cpu"):
+def _llama_tiny(gold, engine=None, device="cpu", **kw):
     from transformers import LlamaConfig, LlamaForCausalLM
 
     import genlm_backend_amd  # noqa: F401
@@ -189,7 +189,7 @@ def _llama_tiny(gold, engine=None, device="cpu"):
     cfg = ast.literal_eval(bytes(gold["llama::config_json"]).decode())
     model = LlamaForCausalLM(LlamaConfig(**cfg)).eval()
     model.load_state_dict({k[len("llama::w::"):]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("llama::w::")})
-    m = AsyncAmdLM(model.to(device), None, batch_size=64, engine=engine or CpuOracleEngine())
+    m = AsyncAmdLM(model.to(device), None, batch_size=64, engine=engine or CpuOracleEngine(), **kw)
     m.tokenizer = Tok()
     return m
 
@@ -215,3 +215,22 @@ def test_llama_shaped_model_matches_reference(gold):
         ctx, lw = sis.results()
         assert [list(map(int, c)) for c in ctx] == [_strip(r) for r in gold["llama::sis_contexts"]]
         assert np.abs(lw - gold["llama::sis_log_weights"]).max() < TOL
+    # the same loop through the stateless API, with and without KV rows that follow the contexts (autokv.AutoKV)
+    for kw in (dict(), dict(auto_kv_rows=40, auto_kv_cap=24)):
+        a = _llama_tiny(gold, **kw)
+        a.register_masks(torch.from_numpy(gold["llama::sis_masks"]))
+        a.set_rng("torch", 999)
+        gen, lw, active = [[] for _ in range(24)], np.zeros(24, np.float64), [True] * 24
+        while any(active):
+            idx = [i for i in range(24) if active[i]]
+            logZ, tok = a.batch_next_token_step_sync([per[i] + gen[i] for i in idx], [1 if len(gen[i]) >= 6 else 0 for i in idx])
+            for i, z, t in zip(idx, logZ, tok):
+                lw[i] += z
+                if t == 0 or t < 0:
+                    active[i] = False
+                else:
+                    gen[i].append(int(t))
+        assert gen == [_strip(r) for r in gold["llama::sis_contexts"]]
+        assert np.abs(lw.astype(np.float32) - gold["llama::sis_log_weights"]).max() < TOL
+        if kw:
+            assert a._auto_kv.stats["encoded_rows"] == 3 and a._auto_kv.stats["one_token_rows"] > 24
