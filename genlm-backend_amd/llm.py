@@ -375,6 +375,30 @@ class AsyncAmdLM(AsyncLM):
                 if q.future is not None and not q.future.done():
                     q.future.set_result((z, t))
             return
+        if (self._auto_kv is not None and not self._kv_tokens
+                and all(q.kind == "logprobs" and q.past is None and q.first_new == len(q.prompt) - 1 for q in queries)):
+            # every request wants the row after its LAST token only (its shorter prefixes are in the trie - a population
+            # that grew by one token): the contexts find their KV rows (autokv.AutoKV) and one token each is fed
+            import itertools
+
+            lens = np.fromiter((len(q.prompt) for q in queries), np.int32, n)
+            flat = np.fromiter(itertools.chain.from_iterable(q.prompt for q in queries), np.int32, int(lens.sum()))
+            starts = np.zeros(n, np.int64)
+            starts[1:] = np.cumsum(lens[:-1])
+            tok_d, st_d, ln_d = (torch.from_numpy(a).to(dev) for a in (flat, starts, lens))
+            group_of, rep, ng = eng.group_contexts(tok_d, st_d, ln_d)
+            logits, row_of_group, _, U, _ = self._auto_kv.logits(tok_d, st_d, ln_d, group_of, rep, ng)
+            lp = eng.log_softmax_rows(logits)
+            rows = row_of_group[group_of.long()].cpu().tolist()
+            self._batch_counter += 1
+            self.stats["batches"] += 1
+            self.stats["queries"] += n
+            self.stats["unique"] += U
+            self.stats["rows"] += U
+            for q, r in zip(queries, rows):
+                if q.future is not None and not q.future.done():
+                    q.future.set_result((lp, r, q.first_new))
+            return
         # -- flatten: context i = [prefix slot, past_len, prompt...]; two header words make the dedup key
         #    (hf.py:216 keys on the prompt only; adding the prefix identity cannot merge unequal requests)
         prefixes, prefix_slot = [], {}

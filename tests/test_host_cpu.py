@@ -529,3 +529,33 @@ def test_auto_kv_on_a_changing_set_of_contexts(gold, collide):
     assert st["encoded_rows"] > 0 and st["unkept_rows"] > 0
     if not collide:
         assert st["one_token_rows"] > 20 and st["copied_rows"] > 0
+
+
+def test_logprob_requests_for_the_last_position_use_auto_kv(gold):
+    """`next_token_logprobs` / `batch_next_token_logprobs` of contexts whose shorter prefixes are in the trie (a
+    population that grew by one token) go through the KV rows too: one token per context is fed, the rows equal the
+    uncached evaluation."""
+    from transformers import GPT2Config, GPT2LMHeadModel
+
+    from genlm_backend_amd.llm import AsyncAmdLM
+
+    cfg = ast.literal_eval(bytes(gold["config_json"]).decode())
+    model = GPT2LMHeadModel(GPT2Config(**cfg)).eval()
+    model.load_state_dict({k[3:]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("w::")})
+    llm = AsyncAmdLM(model, None, batch_size=64, timeout=0.02, engine=CpuOracleEngine(), auto_kv_rows=24, auto_kv_cap=16)
+    llm.tokenizer = Tok()
+    V = cfg["vocab_size"]
+    rnd = np.random.default_rng(3)
+    ctxs = [[int(t) for t in rnd.integers(1, V, 4)] for _ in range(10)]
+    ctxs[7] = list(ctxs[2])  # duplicates share a row
+    for step in range(6):
+        got = asyncio.run(llm.batch_next_token_logprobs(ctxs))
+        for c, row in zip(ctxs, got):
+            assert np.abs(row.numpy() - llm.next_token_logprobs_uncached(c).numpy()).max() < TOL
+        one = asyncio.run(llm.next_token_logprobs(ctxs[0]))  # served from the trie
+        assert torch.equal(one, got[0])
+        ctxs = [c + [int(rnd.integers(1, V))] for c in ctxs]
+    st = llm._auto_kv.stats
+    # step 0 is a full evaluation (every position's row is wanted); step 1 finds no rows yet and encodes its ten
+    # contexts; steps 2.. feed one token each
+    assert st["calls"] == 5 and st["encoded_rows"] == 10 and st["one_token_rows"] == 40 and st["unkept_rows"] == 0
