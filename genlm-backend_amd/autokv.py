@@ -21,10 +21,11 @@ import torch
 
 
 class AutoKV:
-    def __init__(self, llm, rows, cap=64, in_place=0.75):
+    def __init__(self, llm, rows, cap=64, in_place=0.75, graph=True):
         self.llm, self.eng, self.dev = llm, llm.engine, llm.device
-        self.R, self.cap, self.in_place = int(rows), int(cap), in_place
+        self.R, self.cap, self.in_place, self.graph = int(rows), int(cap), in_place, graph
         self.pkv = None
+        self._slab_fwd = None
         self.reset()
 
     def reset(self):
@@ -129,10 +130,12 @@ class AutoKV:
                 self.row_len[(~is_a_d) & (self.row_len >= cap)] = 0
                 pos_d = torch.where(is_a_d, to_dev(pos_full), self.row_len.clamp(max=cap - 1))
                 ids = ctx_pad[to_dev(grp_full, torch.int64), pos_d.long().clamp(max=cap - 1)].view(-1, 1).long()
-                self.pkv.set_forward_in_place(pos_d)
-                out = llm._body(input_ids=ids, position_ids=pos_d.view(-1, 1).long(),
-                                attention_mask=self.pkv.attention_mask(pos_d), past_key_values=self.pkv, use_cache=True)
-                parts.append(llm._lm_head(out.last_hidden_state[to_dev(rows_a, torch.int64), 0]))
+                if self._slab_fwd is None or self._slab_fwd.pkv is not self.pkv:
+                    from .kv import SlabForward
+
+                    self._slab_fwd = SlabForward(self.pkv, llm._body, graph=self.graph)
+                hidden = self._slab_fwd(ids, pos_d)
+                parts.append(llm._lm_head(hidden[to_dev(rows_a, torch.int64)]))
                 st["in_place_calls"] += 1
             else:
                 pos_a = to_dev(L[A] - 1)

@@ -104,6 +104,7 @@ class DeviceSIS:
                      find no free row are served without their KV being kept.
     kv_in_place      with shared KV rows: the fraction of live slab rows from which a forward runs on the slab in place
                      (free rows ride along) instead of gathering the live rows' prefixes into batch order
+    kv_graph         the in-place forward is replayed from a hipGraph after its second call (kv.SlabForward)
     force_collectives  run the collectives of the multi-rank path (all-gather of log-weights / token matrices, the
                      set-up reductions) through `dist` even when world == 1: a one-rank "nccl" group exercises the RCCL
                      code of an 8-GPU run on a single GPU.
@@ -111,7 +112,7 @@ class DeviceSIS:
 
     def __init__(self, llm, n_particles, prompt_ids, max_tokens, eos_id, seed=0, rng="philox", rank=0, world=1,
                  dist=None, use_prefix_kv=False, use_particle_kv=False, resample_ess=None, force_collectives=False,
-                 share_kv=True, kv_rows=None, kv_in_place=0.75):
+                 share_kv=True, kv_rows=None, kv_in_place=0.75, kv_graph=True):
         self.llm, self.eng, self.dev = llm, llm.engine, llm.device
         self.N, self.max_tokens, self.eos_id = n_particles, max_tokens, eos_id
         self.rank, self.world, self.dist = rank, world, dist
@@ -168,6 +169,8 @@ class DeviceSIS:
         # a forward runs on the KV slab rows where they lie when at least this fraction of them is live (None: always
         # gather the live rows into batch order)
         self.kv_in_place = kv_in_place
+        self.kv_graph = kv_graph
+        self._slab_fwd = None
         if self.particle_kv:
             assert not use_prefix_kv
         self.resample_ess = resample_ess
@@ -205,7 +208,8 @@ class DeviceSIS:
         self.kernel_events = []
         self.outer_events = []
         self._event_pool = []
-        self.pkv = None
+        if not (self.share_kv and self.pkv is not None):
+            self.pkv = None  # (shared rows: the slabs stay - and the hipGraph captured over them -, the block table starts empty)
         self._head_cache = None
         self._kv_stale = None  # bool [N]: rows whose KV has to be rebuilt from the context (ancestor on another rank)
         self._row_of_h = np.full(self.N, -1, np.int32)  # shared KV: particle -> slab row (-1: none), host mirror
@@ -340,10 +344,12 @@ class DeviceSIS:
                 rep_full[rows_a] = rep_h[A]
                 pos_d = to_dev(pos_full)
                 ids = self.contexts[to_dev(rep_full, torch.int64), pos_d.long()].view(-1, 1).long()
-                self.pkv.set_forward_in_place(pos_d)
-                out = llm._body(input_ids=ids, position_ids=pos_d.view(-1, 1).long(),
-                                attention_mask=self.pkv.attention_mask(pos_d), past_key_values=self.pkv, use_cache=True)
-                logits_parts.append(llm._lm_head(out.last_hidden_state[to_dev(rows_a, torch.int64), 0]))
+                if self._slab_fwd is None or self._slab_fwd.pkv is not self.pkv:
+                    from .kv import SlabForward
+
+                    self._slab_fwd = SlabForward(self.pkv, llm._body, graph=self.kv_graph)
+                hidden = self._slab_fwd(ids, pos_d)
+                logits_parts.append(llm._lm_head(hidden[to_dev(rows_a, torch.int64)]))
                 st["in_place_steps"] += 1
             else:
                 pos_a = to_dev(L[A] - 1)
