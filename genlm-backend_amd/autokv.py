@@ -39,9 +39,9 @@ class AutoKV:
                           in_place_calls=0)
 
     # ------------------------------------------------------------------------------------------------------------
-    def _lookup(self, q_hash, q_len, ctx_pad):
-        """Row holding a context of hash q_hash / length q_len whose tokens equal ctx_pad[:, :q_len]; -1 if none."""
-        sorted_h, order = torch.sort(self.row_hash)
+    def _lookup(self, sorted_h, order, q_hash, q_len, ctx_pad):
+        """Row holding a context of hash q_hash / length q_len whose tokens equal ctx_pad[:, :q_len]; -1 if none.
+        (sorted_h, order) = torch.sort(self.row_hash)."""
         idx = torch.searchsorted(sorted_h, q_hash).clamp_(max=self.R - 1)
         cand = order[idx]
         ar = torch.arange(self.cap, device=self.dev, dtype=torch.int32)
@@ -66,8 +66,9 @@ class AutoKV:
         h_full = eng.hash_contexts(tok_d, st_d, ln_d)[rep_l]
         h_par = eng.hash_contexts(tok_d, st_d, (ln_d - 1).clamp_(min=0))[rep_l]
         fits = L_d <= cap
-        exact = self._lookup(h_full, torch.where(fits, L_d, torch.zeros_like(L_d)), ctx_pad)
-        parent = self._lookup(h_par, torch.where(fits, L_d - 1, torch.zeros_like(L_d)), ctx_pad)
+        sorted_h, by_hash = torch.sort(self.row_hash)
+        exact = self._lookup(sorted_h, by_hash, h_full, torch.where(fits, L_d, torch.zeros_like(L_d)), ctx_pad)
+        parent = self._lookup(sorted_h, by_hash, h_par, torch.where(fits, L_d - 1, torch.zeros_like(L_d)), ctx_pad)
         old_d = torch.where(exact >= 0, exact, parent).to(torch.int32)
         head = torch.cat([torch.stack([ng[0].to(torch.int32), *[e.to(torch.int32) for e in extra_head]]), rep.to(torch.int32),
                           L_d.to(torch.int32), old_d]).cpu().numpy()  # the call's one D2H copy before the forward
