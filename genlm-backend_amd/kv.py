@@ -63,6 +63,10 @@ class SlabKV(Cache):
         self._ptrs = None
 
     # ---- forward-side helpers ----------------------------------------------------------------------------------
+    def set_forward_in_place(self, pos):
+        """pos: int32 [n] device - where every row's token of the next forward goes."""
+        self.pos = pos
+
     def attention_mask(self, pos):
         """[n, cap] 0/1: row i sees its `pos[i]` cached tokens and the one being appended at `pos[i]`."""
         ar = torch.arange(self.cap, device=pos.device, dtype=pos.dtype)
@@ -182,19 +186,19 @@ class SharedSlabKV(SlabKV):
 
 
 class SlabForward:
-    """The one-token forward over ALL rows of a `SharedSlabKV` where they lie (`set_forward_in_place`).  Its shapes never
-    change - batch = the slab's rows, one token each, the mask a function of the positions - so after two eager calls
-    the launch sequence (the transformer body's kernels and this library's glb_kv_append launches between them) is
-    captured into a hipGraph once and replayed from static input buffers: same kernels, same bits, without the host
-    walking the model's Python for every step (GPT-2-small, 1024 rows: 4.1 -> 3.4 ms; Llama-3.2-1B shape, 512 rows:
-    10.4 -> 7.2 ms).  `graph=False` (or a CPU device) keeps every call eager."""
+    """The one-token forward over ALL rows of a `SlabKV` / `SharedSlabKV` where they lie (`set_forward_in_place`).  Its
+    shapes never change - batch = the slab's rows, one token each, the mask a function of the positions - so after two
+    eager calls the launch sequence (the transformer body's kernels and this library's glb_kv_append launches between
+    them) is captured into a hipGraph once and replayed from static input buffers: same kernels, same bits, without
+    the host walking the model's Python for every step (GPT-2-small, 1024 rows: 4.1 -> 3.4 ms; Llama-3.2-1B shape, 512
+    rows: 10.4 -> 7.2 ms).  A graph belongs to the slab tensors it was captured over (a resampling `gather` swaps slab
+    sets: one graph each).  `graph=False` (or a CPU device) keeps every call eager."""
 
     def __init__(self, pkv, body, graph=True):
         self.pkv, self.body = pkv, body
         self.graph_ok = bool(graph) and torch.cuda.is_available()
         self.calls = 0
-        self.g = None
-        self.ids = self.pos = self.hidden = None
+        self.graphs = {}  # address of layer 0's key slab -> (graph, ids, pos, hidden)
 
     def _run(self, ids, pos):
         pkv = self.pkv
@@ -207,26 +211,29 @@ class SlabForward:
     def __call__(self, ids, pos):
         """ids: int64 [R, 1], pos: int32 [R] (device).  Returns the last hidden states [R, d] (valid until the next call)."""
         self.calls += 1
-        if not self.graph_ok or not ids.is_cuda:
+        if not self.graph_ok or not ids.is_cuda or self.calls <= 2:  # (allocator growth, library set-up: outside a capture)
             return self._run(ids, pos)
-        if self.g is None:
-            if self.calls <= 2:  # allocator growth and library set-up happen outside the capture
+        key = self.pkv.layers[0].keys.data_ptr()
+        ent = self.graphs.get(key)
+        if ent is None:
+            if len(self.graphs) >= 2:  # slab sets keep changing under this forward: not worth capturing
                 return self._run(ids, pos)
-            self.ids, self.pos = ids.clone(), pos.clone()
+            s_ids, s_pos = ids.clone(), pos.clone()
             g = torch.cuda.CUDAGraph()
             try:
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):  # (a collective's watchdog thread may be about)
-                    self.hidden = self._run(self.ids, self.pos)
+                    hidden = self._run(s_ids, s_pos)
             except Exception:  # a model whose forward cannot be captured (host-side decisions on device data): eager
                 self.graph_ok = False
                 torch.cuda.synchronize()
                 return self._run(ids, pos)
-            self.g = g
-        self.ids.copy_(ids)
-        self.pos.copy_(pos)
-        self.pkv.set_forward_in_place(self.pos)  # (the captured launches read the static buffers)
-        self.g.replay()
-        return self.hidden
+            ent = self.graphs[key] = (g, s_ids, s_pos, hidden)
+        g, s_ids, s_pos, hidden = ent
+        s_ids.copy_(ids)
+        s_pos.copy_(pos)
+        self.pkv.set_forward_in_place(s_pos)  # (the captured launches read the static buffers)
+        g.replay()
+        return hidden
 
 
 class PrefixLRU:

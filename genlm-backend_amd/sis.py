@@ -208,8 +208,8 @@ class DeviceSIS:
         self.kernel_events = []
         self.outer_events = []
         self._event_pool = []
-        if not (self.share_kv and self.pkv is not None):
-            self.pkv = None  # (shared rows: the slabs stay - and the hipGraph captured over them -, the block table starts empty)
+        # (the slabs stay - and the hipGraphs captured over them; shared rows start from an empty block table, private rows
+        # are refilled by step 0's encoding)
         self._head_cache = None
         self._kv_stale = None  # bool [N]: rows whose KV has to be rebuilt from the context (ancestor on another rank)
         self._row_of_h = np.full(self.N, -1, np.int32)  # shared KV: particle -> slab row (-1: none), host mirror
@@ -268,10 +268,11 @@ class DeviceSIS:
         pos = (self.lengths - 1).clamp_min(0)  # tokens already in the row's KV = index of the newest token
         newest = self.contexts[rows, pos.long()]
         ids = torch.where(self.active > 0, newest, torch.zeros_like(newest)).view(N, 1).long()
-        self.pkv.pos = pos
-        out = llm._body(input_ids=ids, position_ids=pos.view(N, 1).long(), attention_mask=self.pkv.attention_mask(pos),
-                        past_key_values=self.pkv, use_cache=True)
-        logits = llm._lm_head(out.last_hidden_state[:, 0])  # [N, V]
+        if self._slab_fwd is None or self._slab_fwd.pkv is not self.pkv:
+            from .kv import SlabForward
+
+            self._slab_fwd = SlabForward(self.pkv, llm._body, graph=self.kv_graph)
+        logits = llm._lm_head(self._slab_fwd(ids, pos))  # [N, V]
         self._noise_groups = None
         if self.rng_mode == RNG_NOISE:  # parity draws follow the reference's resolution order: by dedup group
             lengths_eff = torch.where(self.active > 0, self.lengths, torch.ones_like(self.lengths))
@@ -594,7 +595,8 @@ class DeviceSampler(DeviceSIS):
 
     def __init__(self, llm, prompts, max_tokens, eos_token_ids, temperature=1.0, seed=None, sync_every=4):
         super().__init__(llm, len(prompts), [list(p) for p in prompts], max_tokens, eos_id=-1,
-                         seed=0 if seed is None else int(seed), rng="philox", use_particle_kv=True, share_kv=False)
+                         seed=0 if seed is None else int(seed), rng="philox", use_particle_kv=True, share_kv=False,
+                         kv_graph=max_tokens >= 64)  # (a capture costs a few dozen eager steps: long generations only)
         self.sync_every = max(1, int(sync_every))
         self.temperature = float(temperature)
         self.eos = torch.tensor(sorted(set(int(t) for t in eos_token_ids)), dtype=torch.int32, device=self.dev)

@@ -753,3 +753,34 @@ def test_readme_sis_with_auto_kv_on_gpu(engine, llm):
         assert (st["in_place_calls"] > 0) == (in_place is not None)
         runs.append((ctxs, lw))
     assert runs[0][0] == runs[1][0] and np.abs(runs[0][1] - runs[1][1]).max() < 1e-4
+
+
+@pytest.mark.parametrize("share", [True, False])
+def test_in_place_forward_replayed_from_a_hip_graph(llm, share):
+    """kv.SlabForward: after two eager calls the one-token forward over the KV slab is captured into a hipGraph and
+    replayed - two populations run one after the other on the same slabs (the second starts on the captured graph), with
+    and without resampling (a private-row resampling swaps slab sets: one graph each): tokens and weights equal the
+    eager run's."""
+    from genlm_backend_amd.sis import DeviceSIS
+
+    m, gold = llm
+    m.register_masks(torch.from_numpy(gold["sis_masks"]))
+    p = [int(t) for t in gold["sis_prompt"]]
+    prompts = [p, p[:5], p[2:], p[1:]] * 6
+    for ess in (None, 1.0):
+        runs = []
+        for graph in (False, True):
+            s = DeviceSIS(m, 24, prompts, max_tokens=9, eos_id=-1, seed=11, resample_ess=ess, use_particle_kv=True,
+                          share_kv=share, kv_graph=graph, kv_in_place=0.0)
+            out = []
+            for _ in range(2):
+                s.run()
+                out.append((s.results()[0], s.results()[1].copy()))
+                s.reset()
+            assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
+            n_graphs = len(s._slab_fwd.graphs)
+            assert (n_graphs >= 1) == graph and s._slab_fwd.calls >= 14
+            if graph and not share and ess is not None:
+                assert n_graphs == 2
+            runs.append(out[0])
+        assert runs[0][0] == runs[1][0] and np.array_equal(runs[0][1], runs[1][1])
