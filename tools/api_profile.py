@@ -7,7 +7,7 @@ from genlm_backend_amd.engine import HipEngine
 import bench
 eng = HipEngine("cuda:0")
 w = bench.ApiWorkload(eng, torch.device("cuda:0"), 0, 1, None, logprobs=len(sys.argv) > 1 and sys.argv[1] == "logprobs",
-                      coro=len(sys.argv) > 1 and sys.argv[1] == "coro")
+                      coro=len(sys.argv) > 1 and sys.argv[1] == "coro", auto_kv="autokv" in sys.argv[1:])
 for i in range(4):
     w.step(i, False)
 torch.cuda.synchronize()
