@@ -9,21 +9,25 @@
 // sequence of 4096-element chunks, each with its own binary scale, summed per (lane, class) in float32 in a fixed
 // order and as integers above that.  Two ROLES, normally waves of ONE launch (fused_step_kernel):
 //   stats role    one WAVE per (row|particle, chunk): 16 KiB (fp32) / 8 KiB (16-bit) of the row in one burst of
-//                 global_load_dwordx4, chunk maximum by DPP, one polynomial exp per element, both sums (all / allowed)
-//                 by plain float32 adds, allowed lanes selected by EXEC from a pre-transposed bit mask read through the
-//                 scalar cache.  Out: one 64-byte record of six tagged 8-byte granules {value, epoch} written through
-//                 to memory - fire and forget: no barrier, no fence, no wait, no cross-wave dependency.  Rows shared
-//                 by several particles (dedup fan-out of hf.py:214-220,285-288) are reduced once.
-//   finish role   one wave per PARTICLE, dealt at the END of the grid: sweeps the granules of its row's records until
-//                 every tag carries this call's epoch (the data is the flag: MI355X guide, Guideline 16 form R2; bounded
-//                 spin), folds them into (N, S_all, S_mask), lse / logZ by a double-precision log, picks the chunk with
-//                 the first Philox word, reloads that one chunk (L2 / Infinity Cache: it was streamed microseconds ago),
-//                 sums it again exactly as the stats wave did and walks down the summation tree with the second word:
-//                 lane, class, element.
-// The same roles also exist as two plain launches (chunk_stats_kernel, finish_kernel): under stream capture (the
-// epoch is a launch argument), for populations beyond what the tail of one grid should hold, for workspaces nobody
-// initialised, and for the parity-mode exponential race (four waves per particle over the whole row).
-//   logprob_rows_kernel  x - lse for the API path that materialises log-probabilities (cache.py:93-98).
+//                 non-temporal global_load_dwordx4, chunk maximum by DPP, one polynomial exp per element, both sums (all /
+//                 allowed) by plain float32 adds, allowed lanes selected by EXEC from a pre-transposed bit mask read
+//                 through the scalar cache.  Out: one 128-byte record of twelve tagged 8-byte granules {value, epoch} -
+//                 scales, the sum of all elements, the allowed sums by 16-lane row of the wave - written through to
+//                 memory, fire and forget: no barrier, no fence, no wait, no cross-wave dependency.  Rows shared by
+//                 several particles (dedup fan-out of hf.py:214-220,285-288) are reduced once.
+//   finish role   one wave per PARTICLE, dealt at the END of the grid: sweeps its row's records until every tag carries
+//                 this call's epoch (the data is the flag: MI355X guide, Guideline 16 form R2; bounded spin), folds them
+//                 into (N, S_all, S_mask), lse / logZ by a double-precision log, picks the chunk with the first Philox
+//                 word and the 16-lane row inside it (from the record) with the second, reloads that QUARTER chunk,
+//                 rebuilds its (lane, class) partials bit for bit - finishing lane 16 w + l = class w of row lane l -
+//                 and walks down the summation tree: lane, class, element.
+// The same roles also exist as two plain launches (chunk_stats_kernel / chunk_stats_small_kernel, finish_kernel): under
+// stream capture (the epoch is a launch argument), for workspaces nobody initialised, for launches of at most 512
+// chunks (four waves per chunk), and for the parity-mode exponential race (four waves per particle over the whole row).
+//   logprob_rows_waves_kernel   glb_log_softmax_rows (cache.py:93-98) in one launch: a wave keeps its chunk in registers,
+//                               meets its row-mates through the same tagged records and writes x - lse; the
+//                               workgroup-per-row / three-launch forms serve rows of more than 64 chunks and workspaces
+//                               without tags.
 // mask_prepare_kernel builds the transposed masks ([mask][chunk][vector][component] 64-bit lane words).
 #pragma once
 #include <type_traits>
