@@ -128,7 +128,7 @@ class AutoKV:
                 pos_full[rows_a] = L[A] - 1
                 grp_full[rows_a] = A
                 is_a_d = to_dev(is_a, torch.bool)
-                self.row_len[(~is_a_d) & (self.row_len >= cap)] = 0
+                self.row_len = torch.where((~is_a_d) & (self.row_len >= cap), torch.zeros_like(self.row_len), self.row_len)
                 pos_d = torch.where(is_a_d, to_dev(pos_full), self.row_len.clamp(max=cap - 1))
                 ids = ctx_pad[to_dev(grp_full, torch.int64), pos_d.long().clamp(max=cap - 1)].view(-1, 1).long()
                 if self._slab_fwd is None or self._slab_fwd.pkv is not self.pkv:
