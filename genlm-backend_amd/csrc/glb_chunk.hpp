@@ -969,6 +969,10 @@ __device__ __forceinline__ void finish_draw(const StepParams &p, int pidx, int l
       if (p.out_lse) p.out_lse[pidx] = lse;
       if (p.out_logZ) p.out_logZ[pidx] = logZ;
     }
+#ifdef GLB_STAMPS  // [3]: the quarter chunk has arrived (the wave waits for its last vector here)
+    asm volatile("" ::"v"(y[15]));
+    if (stamps && lane == 0) stamps[3] = __builtin_amdgcn_s_memrealtime();
+#endif
     float t[16], P = 0.0f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {

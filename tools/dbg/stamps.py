@@ -43,7 +43,8 @@ for i in range(iters):
     f = (st[:, :3] - t0) / 100.0
     rows.append((s_start.max(), s_end.max(), np.percentile(s_end, 50), np.percentile(s_end, 90), f[:, 0].min(), f[:, 0].max(),
                  f[:, 2].max(), (f[:, 2] - f[:, 1]).mean(), (f[:, 2] - f[:, 1]).max(), (f[:, 2] - f[:, 1]).min(),
-                 (f[:, 1] - f[:, 0]).mean(), (s_end - s_start).mean(), np.percentile(f[:, 2], 50)))
+                 (f[:, 1] - f[:, 0]).mean(), (s_end - s_start).mean(), np.percentile(f[:, 2], 50),
+                 ((st[:, 3] - st[:, 1]) / 100.0)[st[:, 3] > 0].mean(), ((st[:, 2] - st[:, 3]) / 100.0)[st[:, 3] > 0].mean()))
     if i == iters - 1:
         last = s_end.max(axis=1)  # row completion
         lag = f[:, 2] - last      # finisher end after its row's records
@@ -62,7 +63,8 @@ for i in range(iters):
             print("  %4d  %.2f  %.2f  %.2f  %.2f" % (r, last[r], f[r, 0], f[r, 1], f[r, 2]))
 names = ["last stats wave start", "last stats wave end", "stats end p50", "stats end p90", "first finisher start", "last finisher start",
          "last token written", "finish work mean (records seen -> token)", "finish work max", "finish work min", "wait for records mean",
-         "stats wave lifetime mean", "token written p50"]
+         "stats wave lifetime mean", "token written p50", "records seen -> quarter chunk arrived (fold, picks, reload)",
+         "quarter chunk arrived -> token (partials, picks)"]
 a = np.array(rows)
 for n, col in zip(names, a.T):
     print("%-46s mean %7.2f  min %7.2f  max %7.2f us" % (n, col.mean(), col.min(), col.max()))
