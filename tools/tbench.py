@@ -32,7 +32,7 @@ x = torch.randn((B, len(words)), device=dev) * 3
 _, lse, _ = eng.step(x, rng_mode=0)
 sel = torch.from_numpy(rs.choice(len(trie), 4096, replace=False).astype(np.int32)).to(dev)
 print(f"folded trie: {trie.compact()['n_nodes']} slots, {trie.compact()['n_levels']} levels")
-for B in (64, 1024):
+for B in (1, 8, 64, 1024):
     ws = torch.rand((B, len(words)), device=dev); ws /= ws.sum(-1, keepdim=True)
     for _ in range(3): trie.batch_weight_sum_device(ws)
     torch.cuda.synchronize()
