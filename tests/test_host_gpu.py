@@ -366,6 +366,26 @@ def test_llama_shaped_model_on_gpu_matches_reference(engine):
         ctx, lw = sis.results()
         assert [list(map(int, c)) for c in ctx] == [_strip(r) for r in gold["llama::sis_contexts"]]
         assert np.abs(lw - gold["llama::sis_log_weights"]).max() < TOL
+    # the same loop through the stateless API with KV rows that follow the contexts (RoPE, grouped-query KV slabs)
+    model2 = LlamaForCausalLM(LlamaConfig(**cfg)).eval()
+    model2.load_state_dict(model.state_dict())
+    a = AsyncAmdLM(model2.to(engine.device), None, batch_size=64, engine=engine, auto_kv_rows=30, auto_kv_cap=24)
+    a.tokenizer = Tok()
+    a.register_masks(torch.from_numpy(gold["llama::sis_masks"]))
+    a.set_rng("torch", 999)
+    gen, lw, active = [[] for _ in range(24)], np.zeros(24, np.float64), [True] * 24
+    while any(active):
+        idx = [i for i in range(24) if active[i]]
+        logZ, tok = a.batch_next_token_step_sync([per[i] + gen[i] for i in idx], [1 if len(gen[i]) >= 6 else 0 for i in idx])
+        for i, z, t in zip(idx, logZ, tok):
+            lw[i] += z
+            if t == 0 or t < 0:
+                active[i] = False
+            else:
+                gen[i].append(int(t))
+    assert gen == [_strip(r) for r in gold["llama::sis_contexts"]]
+    assert np.abs(lw.astype(np.float32) - gold["llama::sis_log_weights"]).max() < TOL
+    assert a._auto_kv.stats["encoded_rows"] == 3 and a._auto_kv.stats["in_place_calls"] >= 1
 
 
 def test_batched_submit_on_gpu_matches_reference(llm):
