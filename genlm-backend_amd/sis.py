@@ -698,6 +698,7 @@ class SisBenchWorkload:
         self._outer = []
         self._bytes = []
         self.unique_hist = []
+        self.fed_hist = []
         # set-up, not measurement: one untimed pass over the loop's ten batch shapes (context lengths 8..17) so that
         # GEMM algorithm selection and allocator growth happen before bench.py's own warm-up / timed steps
         for _ in range(max_tokens):
@@ -714,6 +715,7 @@ class SisBenchWorkload:
             # algorithmic bytes of this call: the unique logits rows once + mask bit rows + outputs
             self._bytes.append(U * self.V * self.elem + 2 * ((self.V + 31) // 32) * 4 + self.N * 8)
             self.unique_hist.append(U)
+            self.fed_hist.append(int(self.sis.last_stats["l_max"]))  # tokens per forward row of this step
 
     def _collect(self):
         self._events.extend(self.sis.kernel_events)
@@ -739,4 +741,7 @@ class SisBenchWorkload:
                             + (", systematic resampling after every step" if self.resample else ""),
                 "particles_per_gpu": self.N, "vocab": self.V, "rng": "philox",
                 "mean_unique_contexts_per_step": float(np.mean(self.unique_hist)) if self.unique_hist else None,
+                # what the forward is fed per distinct context, and what the cached prompt KV saves
+                "mean_tokens_fed_per_context": float(np.mean(self.fed_hist)) if self.fed_hist else None,
+                **({"prefixed_tokens_per_context": 8} if self.prefix_kv else {}),
                 **({"kv_rows": {k: v for k, v in self.sis.kv_stats.items()}} if self.particle_kv else {})}
