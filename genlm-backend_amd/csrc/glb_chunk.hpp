@@ -32,6 +32,10 @@
 #pragma once
 #include <type_traits>
 
+#ifndef GLB_STATS_WAVES_16
+#define GLB_STATS_WAVES_16 5  // stats waves per SIMD for 2-byte elements (6: 80 registers, 42 spilled: 43 us against 34)
+#endif
+
 #include "glb_math.hpp"
 
 namespace glb {
@@ -1046,7 +1050,7 @@ __device__ __forceinline__ void finish_draw(const StepParams &p, int pidx, int l
 // fp32 rows spill at five and stream as fast with four.
 template <int DT, int MASK>
 struct StatsWaves {
-  static constexpr int value = MASK == kMaskF32 ? 3 : (DT == kDtF32 ? 4 : 5);
+  static constexpr int value = MASK == kMaskF32 ? 3 : (DT == kDtF32 ? 4 : GLB_STATS_WAVES_16);
 };
 
 template <int DT, int MASK, bool SCALED, int MODE>
