@@ -559,3 +559,44 @@ def test_logprob_requests_for_the_last_position_use_auto_kv(gold):
     # step 0 is a full evaluation (every position's row is wanted); step 1 finds no rows yet and encodes its ten
     # contexts; steps 2.. feed one token each
     assert st["calls"] == 5 and st["encoded_rows"] == 10 and st["one_token_rows"] == 40 and st["unkept_rows"] == 0
+
+
+@pytest.mark.parametrize("auto_kv", [False, True])
+def test_user_side_particle_math_on_the_returned_rows_is_a_drop_in(llm, gold, auto_kv):
+    """The reference's own usage pattern with nothing but `llm` swapped: every particle awaits `next_token_logprobs`,
+    adds its mask, takes logsumexp and draws with torch.multinomial from torch's global generator (the README's
+    Particle.extend, README.md:82-91, written out here as user code).  Rows within 1e-4 and the reference's resolution
+    order of the futures (hf.py:285-288) make the tokens and weights of the golden run come out."""
+    masks = torch.from_numpy(gold["sis_masks"])
+    prompt = [int(t) for t in gold["sis_prompt"]]
+    if auto_kv:  # the same user code on a backend whose requests find their KV rows (one token per context is fed)
+        from genlm_backend_amd.autokv import AutoKV
+
+        llm._auto_kv = AutoKV(llm, 24, 24)
+
+    class UserParticle:
+        def __init__(self):
+            self.context, self.log_weight, self.active = [], 0.0, True
+
+        async def extend(self):
+            logps = await llm.next_token_logprobs(prompt + self.context)
+            masked = logps + masks[1 if len(self.context) >= 10 else 0].to(logps.device)
+            logZ = masked.logsumexp(dim=-1)
+            self.log_weight += logZ
+            tok = torch.multinomial((masked - logZ).exp(), 1).item()
+            if tok == 0:
+                self.active = False
+            else:
+                self.context.append(tok)
+
+    async def run():
+        ps = [UserParticle() for _ in range(16)]
+        while any(p.active for p in ps):
+            await asyncio.gather(*[p.extend() for p in ps if p.active])
+        return ps
+
+    torch.manual_seed(1234)
+    ps = asyncio.run(run())
+    _check_sis([p.context for p in ps], [float(p.log_weight) for p in ps], gold)
+    if auto_kv:
+        assert llm._auto_kv.stats["one_token_rows"] > 50
