@@ -600,3 +600,39 @@ def test_user_side_particle_math_on_the_returned_rows_is_a_drop_in(llm, gold, au
     _check_sis([p.context for p in ps], [float(p.log_weight) for p in ps], gold)
     if auto_kv:
         assert llm._auto_kv.stats["one_token_rows"] > 50
+
+
+def test_load_model_by_name_end_to_end_offline(tmp_path):
+    """`load_model_by_name` (llm/__init__.py:10-43) from a local checkpoint directory - a tiny GPT-2 saved with the
+    byte-level BPE tokenizer of tests/golden -: tokenizer, byte_vocab / str_vocab, the README's mask builder and a
+    short autobatched SIS run through the returned object; the reference's other engines and unknown names are refused."""
+    from tokenizers import Tokenizer
+    from transformers import GPT2Config, GPT2LMHeadModel, PreTrainedTokenizerFast
+
+    from genlm_backend_amd.llm import AsyncAmdLM, load_model_by_name
+    from genlm_backend_amd.sis import autobatched_sis, make_masking_function
+
+    gd = os.path.join(os.path.dirname(__file__), "golden")
+    tok = PreTrainedTokenizerFast(tokenizer_object=Tokenizer.from_file(os.path.join(gd, "bpe_tokenizer.json")),
+                                  eos_token="<|endoftext|>")
+    torch.manual_seed(3)
+    GPT2LMHeadModel(GPT2Config(vocab_size=len(tok), n_positions=64, n_embd=32, n_layer=2, n_head=2, bos_token_id=0,
+                               eos_token_id=0)).save_pretrained(tmp_path)
+    tok.save_pretrained(tmp_path)
+    llm = load_model_by_name(str(tmp_path), backend="amd",
+                             llm_opts={"hf_opts": {"device": "cpu"}, "engine": CpuOracleEngine(), "batch_size": 8})
+    assert isinstance(llm, AsyncAmdLM) and llm.tokenizer.eos_token_id == 0
+    assert len(llm.byte_vocab) == len(llm.str_vocab) == len(tok)
+    assert llm.byte_vocab[llm.tokenizer.encode("ab")[0]] in (b"ab", b"a")
+    sel = make_masking_function(llm, max_token_length=3, max_tokens=4)
+    llm.set_rng("philox", 5)
+    prompt = llm.tokenizer.encode("the cat")
+    parts = asyncio.run(autobatched_sis(8, llm, sel, prompt, eos_id=0))
+    assert all(not p.active and 1 <= len(p.context) + 1 <= 6 and np.isfinite(p.log_weight) for p in parts)
+    for p in parts:  # the README mask: no generated token longer than three bytes
+        assert all(len(llm.byte_vocab[t]) <= 3 for t in p.context)
+    row = asyncio.run(llm.next_token_logprobs(prompt))
+    assert abs(float(row.exp().sum()) - 1.0) < 1e-4
+    for bad in ("vllm", "mlx", "nonsense"):
+        with pytest.raises(ValueError):
+            load_model_by_name(str(tmp_path), backend=bad)
