@@ -24,10 +24,17 @@ class TokenByteTrie:
         edges = [[]]          # per node: [(symbol, child)]
         index = [{}]          # per node: symbol -> child
         leaf_of, keys = [], []
+        warned = False
         for k, item in enumerate(decode):
             if isinstance(item, Token):
                 word, key = item.byte_string, (item.byte_string, item.token_id)
             else:
+                if isinstance(item, (bytes, bytearray)) and not warned:  # (base.py:34-42: once per trie)
+                    import warnings
+
+                    warnings.warn("Passing plain bytes to TokenByteTrie is deprecated. Use Token objects from "
+                                  "decode_vocab() instead.", DeprecationWarning, stacklevel=2)
+                    warned = True
                 word, key = item, item
             at = 0
             for sym in word:

@@ -234,3 +234,30 @@ def test_llama_shaped_model_matches_reference(gold):
         assert np.abs(lw.astype(np.float32) - gold["llama::sis_log_weights"]).max() < TOL
         if kw:
             assert a._auto_kv.stats["encoded_rows"] == 3 and a._auto_kv.stats["one_token_rows"] > 24
+
+
+def test_trie_accepts_plain_iterables_and_refuses_duplicates():
+    """tests/test_trie.py:288-325 of the reference: plain bytes (with a deprecation warning) and other iterables of
+    symbols beside `Token`s; tokens with the same bytes but different ids get leaves of their own (test_duplicates.py);
+    a word that occurs twice is an error."""
+    import warnings
+
+    import genlm_backend_amd  # noqa: F401
+    from genlm_backend_amd.tokenization import Token
+    from genlm_backend_amd.trie import TokenByteTrie
+
+    with pytest.warns(DeprecationWarning, match="plain bytes"):
+        trie = TokenByteTrie([Token(0, b"hello"), b"world", Token(2, b"test"), b"data", ("e", "o", "s")])
+    assert (b"hello", 0) in trie.word2leaf and b"world" in trie.word2leaf and (b"test", 2) in trie.word2leaf
+    assert b"data" in trie.word2leaf and ("e", "o", "s") in trie.word2leaf
+    assert len(trie.idx_to_leaf) == 5 and len(set(trie.idx_to_leaf[:, 1])) == 5
+    dup = TokenByteTrie([Token(0, b"ab"), Token(1, b"ab"), Token(2, b"a")])  # one byte string, two token ids
+    assert dup.word2leaf[(b"ab", 0)] != dup.word2leaf[(b"ab", 1)]
+    c = dup.compact()
+    assert c["n_nodes"] < len(dup) and len(set(c["leaf_node"])) == 3
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", DeprecationWarning)
+        with pytest.raises(ValueError, match="Duplicate word in vocabulary"):
+            TokenByteTrie([b"hello", b"world", b"hello"])
+    with pytest.raises(ValueError, match="Duplicate word in vocabulary"):
+        TokenByteTrie([Token(0, b"test"), Token(1, b"other"), Token(0, b"test")])
