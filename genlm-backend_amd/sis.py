@@ -82,6 +82,26 @@ async def autobatched_sis(n_particles, llm, mask_selector, prompt_ids, eos_id):
 # ------------------------------------------------------------------------------------------------
 # device-resident driver
 # ------------------------------------------------------------------------------------------------
+def _gather_all(dist, out, inp):
+    """all_gather_into_tensor - through host memory when the group's backend cannot take device tensors (a gloo group
+    whose ranks compute on a GPU: the one-GPU rehearsal of the multi-rank path; RCCL groups take the tensors as they are)."""
+    if inp.is_cuda and dist.get_backend() == "gloo":
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, inp.cpu())
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, inp)
+
+
+def _reduce_all(dist, t, op):
+    if t.is_cuda and dist.get_backend() == "gloo":
+        host = t.cpu()
+        dist.all_reduce(host, op=op)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, op=op)
+
+
 class DeviceSIS:
     """N particles over one prompt (or one prompt per particle, any lengths), masks[0] while fewer than `max_tokens`
     tokens were generated and masks[1] afterwards (README.md:57-70's masking function).
@@ -130,14 +150,14 @@ class DeviceSIS:
         self.max_prompt = max(len(p) for p in prompts)
         if self.collective:  # one token-matrix width over all ranks: rows travel between ranks when resampling
             mp_ = torch.tensor([self.max_prompt], dtype=torch.int64, device=self.dev)
-            dist.all_reduce(mp_, op=dist.ReduceOp.MAX)
+            _reduce_all(dist, mp_, dist.ReduceOp.MAX)
             self.max_prompt = int(mp_.item())
         # the README mask is a function of the number of generated tokens; with prompts of ONE length (over all
         # ranks, if particles can migrate) that makes it a function of the context, i.e. of the logits row
         lens = {len(p) for p in prompts}
         if self.collective and resample_ess is not None:
             mm = torch.tensor([min(lens), -max(lens)], dtype=torch.int64, device=self.dev)
-            dist.all_reduce(mm, op=dist.ReduceOp.MIN)
+            _reduce_all(dist, mm, dist.ReduceOp.MIN)
             lens = {int(mm[0]), int(-mm[1])}
         self._mask_by_row = len(lens) == 1
         self._rep = None
@@ -157,8 +177,8 @@ class DeviceSIS:
                 width = self.max_prompt
                 all_p = torch.empty((world * n_particles, width), dtype=torch.int32, device=self.dev)
                 all_l = torch.empty(world * n_particles, dtype=torch.int32, device=self.dev)
-                dist.all_gather_into_tensor(all_p.view(-1), self._ctx0[:, :width].contiguous().view(-1))
-                dist.all_gather_into_tensor(all_l, self._prompt_len0)
+                _gather_all(dist, all_p.view(-1), self._ctx0[:, :width].contiguous().view(-1))
+                _gather_all(dist, all_l, self._prompt_len0)
                 all_p, all_l = all_p.cpu().numpy(), all_l.cpu().numpy()
                 distinct = {tuple(int(t) for t in all_p[i, :all_l[i]]) for i in range(len(all_l))}
             self._build_prefixes(sorted(distinct))
@@ -435,7 +455,7 @@ class DeviceSIS:
         if self.collective:
             mine = torch.cat([self.log_weights, count])
             out = torch.empty((self.world, self.N + 1), dtype=torch.float32, device=self.dev)
-            self.dist.all_gather_into_tensor(out.view(-1), mine)
+            _gather_all(self.dist, out.view(-1), mine)
             self.all_weights = out[:, :self.N].reshape(-1)
             self._global_active = out[:, self.N].sum().to(torch.int32)
         else:
@@ -538,8 +558,8 @@ class DeviceSIS:
         if self.collective:
             all_ctx = torch.empty((n_total, self.cap), dtype=torch.int32, device=dev)
             all_meta = torch.empty((n_total, 3), dtype=torch.int32, device=dev)
-            self.dist.all_gather_into_tensor(all_ctx.view(-1), self.contexts.view(-1))
-            self.dist.all_gather_into_tensor(all_meta.view(-1), meta.view(-1))
+            _gather_all(self.dist, all_ctx.view(-1), self.contexts.view(-1))
+            _gather_all(self.dist, all_meta.view(-1), meta.view(-1))
         else:
             all_ctx, all_meta = self.contexts, meta
         self.contexts = eng.gather_rows_i32(all_ctx, mine)

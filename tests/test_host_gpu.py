@@ -3,6 +3,7 @@ backend against the reference's goldens with the model on the MI355X."""
 import ast
 import asyncio
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -804,3 +805,65 @@ def test_in_place_forward_replayed_from_a_hip_graph(llm, share):
                 assert n_graphs == 2
             runs.append(out[0])
         assert runs[0][0] == runs[1][0] and np.array_equal(runs[0][1], runs[1][1])
+
+
+# ---- two ranks on ONE GPU: the multi-rank code through the HIP kernels (the exchange itself over gloo) ---------------
+def _two_rank_worker(rank, world, port, out_dir, mode):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import genlm_backend_amd  # noqa: F401
+    from transformers import GPT2Config, GPT2LMHeadModel
+
+    from genlm_backend_amd.engine import HipEngine
+    from genlm_backend_amd.llm import AsyncAmdLM
+    from genlm_backend_amd.sis import DeviceSIS
+
+    gold = np.load(G)
+    cfg = ast.literal_eval(bytes(gold["config_json"]).decode())
+    model = GPT2LMHeadModel(GPT2Config(**cfg)).eval()
+    model.load_state_dict({k[3:]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("w::")})
+    eng = HipEngine("cuda:0")
+    m = AsyncAmdLM(model.to(eng.device), None, batch_size=64, engine=eng)
+    m.tokenizer = Tok()
+    m.register_masks(torch.from_numpy(gold["sis_masks"]))
+    p = [int(t) for t in gold["sis_prompt"]]
+    prompts = ([p, p[:5], p[2:], p[1:]] * 4)[rank * 8:(rank + 1) * 8]  # rank-specific prompts
+    kw = dict(use_particle_kv=True) if mode == "pkv" else (dict(use_prefix_kv=True) if mode == "prefix" else {})
+    sis = DeviceSIS(m, 8, prompts, max_tokens=6, eos_id=-1, seed=21, rank=rank, world=world, dist=dist, resample_ess=1.0, **kw)
+    sis.run()
+    ctx, lw = sis.results()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), ctx=np.array([list(c) + [-1] * (20 - len(c)) for c in ctx]), lw=lw,
+             all_lw=sis.all_weights.cpu().numpy(), n_resamples=sis.n_resamples)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["plain", "pkv", "prefix"])
+def test_two_ranks_on_one_gpu_equal_one_rank(llm, tmp_path, mode):
+    """The multi-rank path through the HIP kernels: two processes share this GPU, each holds half of the population
+    (rank-specific ragged prompts), draws by the global particle index, gathers the weights every step (over gloo here
+    - RCCL needs a GPU per rank; `test_rccl_collectives_on_one_rank_change_nothing` covers the RCCL calls) and resamples
+    across the ranks after every step: the union equals one process with the whole population - plain, with shared KV
+    rows (contexts that migrate are encoded on their new rank) and with cached prompt prefixes of all ranks."""
+    import torch.multiprocessing as mp
+
+    from genlm_backend_amd.sis import DeviceSIS
+
+    world, port = 2, 29741 + os.getpid() % 200
+    mp.start_processes(_two_rank_worker, args=(world, port, str(tmp_path), mode), nprocs=world, join=True, start_method="spawn")
+    r = [np.load(tmp_path / f"rank{i}.npz") for i in range(world)]
+    assert np.array_equal(r[0]["all_lw"], r[1]["all_lw"]) and int(r[0]["n_resamples"]) >= 2
+    m, gold = llm
+    m.register_masks(torch.from_numpy(gold["sis_masks"]))
+    p = [int(t) for t in gold["sis_prompt"]]
+    kw = dict(use_particle_kv=True) if mode == "pkv" else (dict(use_prefix_kv=True) if mode == "prefix" else {})
+    one = DeviceSIS(m, 16, [p, p[:5], p[2:], p[1:]] * 4, max_tokens=6, eos_id=-1, seed=21, resample_ess=1.0, **kw)
+    one.run()
+    ctx, lw = one.results()
+    got = [[int(t) for t in row if t >= 0] for row in np.concatenate([r[0]["ctx"], r[1]["ctx"]])]
+    assert got == [list(map(int, c)) for c in ctx]
+    assert np.abs(lw - np.concatenate([r[0]["lw"], r[1]["lw"]])).max() < 1e-4
