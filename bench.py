@@ -218,6 +218,9 @@ def main():
                          "one token per context per step instead of a re-encoding)")
     ap.add_argument("--kv-gather", action="store_true",
                     help="--particle-kv: always gather the live KV rows into batch order (never run the forward on the slab in place)")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="--gpus N on a box with ONE GPU: every rank computes on cuda:0 and the exchange goes over gloo through "
+                         "host memory (RCCL wants a GPU per rank) - a rehearsal of the multi-rank code, not a measurement")
     ap.add_argument("--no-rccl-single", action="store_true",
                     help="N = 1 sis workloads: do NOT route the per-step exchange through a one-rank RCCL group")
     args = ap.parse_args()
@@ -238,6 +241,9 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if cpu_only:
+            dist.init_process_group("gloo")
+        elif args.rehearse_one_gpu:
+            local_rank = 0
             dist.init_process_group("gloo")
         else:
             torch.cuda.set_device(local_rank)
@@ -285,9 +291,11 @@ def main():
 
     rccl_ranks = None
     if dist is not None:  # one collective before the clock starts: proves every rank is on the RCCL communicator
+        from genlm_backend_amd.sis import _gather_all, _reduce_all
+
         probe = torch.full((1,), float(rank), device=dev)
         got = torch.empty(world, device=dev)
-        dist.all_gather_into_tensor(got, probe)
+        _gather_all(dist, got, probe)
         assert got.cpu().tolist() == [float(r) for r in range(world)]
         rccl_ranks = dist.get_world_size()
 
@@ -307,7 +315,7 @@ def main():
     dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        _reduce_all(dist, t, dist.ReduceOp.MAX)
         dt = float(t.item())
 
     kern_us = runner.kernel_times_us()
@@ -329,7 +337,11 @@ def main():
             "config": runner.config(),
         }
         if rccl_ranks is not None:
-            out["rccl_ranks"] = rccl_ranks
+            if args.rehearse_one_gpu and world > 1:  # every rank on cuda:0, exchange over gloo: NOT a measurement
+                out["rehearsal_one_gpu"] = True
+                out["gloo_ranks"] = rccl_ranks
+            else:
+                out["rccl_ranks"] = rccl_ranks
         if rccl_note is not None:
             out["rccl_note"] = rccl_note
         if kern_us is not None and len(kern_us):
@@ -471,7 +483,9 @@ class KernelWorkload:
             plan.run(offset=i)
         self.lw += self.out[0]
         if self.world > 1:
-            self.dist.all_gather_into_tensor(self.gathered, self.lw)
+            from genlm_backend_amd.sis import _gather_all
+
+            _gather_all(self.dist, self.gathered, self.lw)
             self.eng.normalize_weights(self.gathered)
 
     def kernel_times_us(self):
@@ -570,8 +584,10 @@ class ApiWorkload:
                     p.context.append(t)
         self.t += 1
         if self.world > 1:
+            from genlm_backend_amd.sis import _gather_all
+
             lw = torch.tensor([p.log_weight for p in self.particles], dtype=torch.float32, device=self.dev)
-            self.dist.all_gather_into_tensor(self.gathered, lw)
+            _gather_all(self.dist, self.gathered, lw)
 
     def kernel_times_us(self):
         return None

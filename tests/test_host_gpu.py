@@ -867,3 +867,24 @@ def test_two_ranks_on_one_gpu_equal_one_rank(llm, tmp_path, mode):
     got = [[int(t) for t in row if t >= 0] for row in np.concatenate([r[0]["ctx"], r[1]["ctx"]])]
     assert got == [list(map(int, c)) for c in ctx]
     assert np.abs(lw - np.concatenate([r[0]["lw"], r[1]["lw"]])).max() < 1e-4
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """`bench.py --gpus 2 --rehearse-one-gpu`: the driver's multi-rank flow (own ranks through torch.distributed.run,
+    probe collective, barriers around the timed region, max over ranks, rank 0's one JSON line) with both ranks computing
+    on this GPU and the exchange over gloo - the line says it is a rehearsal, and the sharded SIS loop with resampling
+    runs through it."""
+    import json
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-one-gpu", "--workload", "sis",
+                        "--particle-kv", "--resample", "--steps", "12", "--warmup", "2", "--no-cpu"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["gloo_ranks"] == 2 and out["rehearsal_one_gpu"] is True and "rccl_ranks" not in out
+    assert out["steps"] == 12 and out["value"] > 0 and out["roofline"]["launches_timed"] == 12
