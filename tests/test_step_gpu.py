@@ -129,6 +129,7 @@ V2_CASES = [
     (260, 260, 65001, "f16", 22),
     (9, 9, 1000, "f32", 22),
     (1024, 1024, 50257, "f32", 21),
+    (512, 512, 128256, "bf16", 21),  # BASELINE config 5 at its full size, bit for bit
     (2300, 500, 50257, "f32", 21),   # 9 rows per workgroup: one wave per row in the tail
     (700, 300, 16001, "f32", 24),
     (700, 300, 32000, "bf16", 24),
