@@ -306,7 +306,8 @@ def test_parity_and_float_masks_at_llama_width_fp32(engine, oracle):
 
 
 @pytest.mark.parametrize("B,V,dtype,scale", [(160, 50257, "f32", 1.0), (130, 128256, "bf16", 0.7), (128, 4099, "f16", 1.0),
-                                             (200, 70001, "f32", 1.3), (130, 270001, "bf16", 1.0)])
+                                             (200, 70001, "f32", 1.3), (130, 270001, "bf16", 1.0),
+                                             (1024, 50257, "f32", 1.0), (512, 128256, "bf16", 1.0)])  # the headline sizes
 def test_log_softmax_rows_single_launch_path(engine, oracle, B, V, dtype, scale):
     """Rows of up to 64 chunks on the engine's workspace take the one-launch kernel of independent waves (each logit
     read once and kept in registers until its log-probability is written); longer rows and workspaces without tags the
