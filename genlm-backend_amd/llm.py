@@ -793,7 +793,10 @@ class AsyncAmdLM(AsyncLM):
         self.stats["unique"] += U
         self.stats["rows"] += U
         out = torch.stack([logZ, tok.to(torch.float32)]).cpu().numpy()  # token ids < 2^24: exact in float32
-        return out[0], out[1].astype(np.int32)
+        toks = out[1].astype(np.int32)
+        if (toks == -2).any():  # a finishing wave of the one-launch step gave up waiting for its records (include/glb.h)
+            raise RuntimeError("glb_logprob_mask_sample: records of the fused launch did not complete (token -2)")
+        return out[0], toks
 
     async def batch_next_token_step(self, contexts, mask_ids=None):
         """Awaitable form of `batch_next_token_step_sync` (the evaluation itself blocks the loop, like
