@@ -8,8 +8,6 @@ address by pointer) rather than a transformers cache object.
 """
 from collections import OrderedDict
 
-import torch
-
 
 class _Slab:
     """Handle of one [R, V] slab of log-probability rows: the trie's nodes point at the handle, the budget empties it."""
