@@ -9,10 +9,11 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libglb_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 GLB_OK, GLB_EINVAL, GLB_EUNSUPPORTED, GLB_EHIP, GLB_ENOSPC = 0, 1, 2, 3, 4
 F32, BF16, F16 = 0, 1, 2
 MASK_NONE, MASK_BITS, MASK_F32, MASK_PREPARED = 0, 1, 2, 3
+STEP_ROWS_BY_FIRST_USE = 1
 RNG_NONE, RNG_PHILOX, RNG_NOISE = 0, 1, 2
 
 
@@ -49,7 +50,7 @@ class StepArgs(C.Structure):
         ("out_lse", C.c_void_p),
         ("out_token", C.c_void_p),
         ("out_margin", C.c_void_p),
-        ("reserved", C.c_int32),
+        ("flags", C.c_int32),
         ("workspace", C.c_void_p),
         ("workspace_bytes", C.c_size_t),
     ]
@@ -102,10 +103,13 @@ SYMBOLS = {
     "glb_logprob_mask_sample_timed": (C.c_int, [C.POINTER(StepArgs), _vp, _vp, _vp]),
     "glb_workspace_init": (C.c_int, [_vp, _sz, _vp]),
     "glb_workspace_release": (C.c_int, [_vp]),
+    "glb_workspace_check": (C.c_int, [_vp, _vp]),
+    "glb_workspace_error_word": (_vp, [_vp]),
+    "glb_set_spin_limit": (C.c_int, [C.c_uint64]),
     "glb_mask_prepared_bytes": (_sz, [_i64, _i64]),
     "glb_mask_prepare": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _vp, _sz, _vp]),
     "glb_log_softmax_workspace_bytes": (_sz, [_i64, _i64]),
-    "glb_log_softmax_rows": (C.c_int, [_vp, _i32, _i64, _i64, _i64, _f32, _vp, _i64, _vp, _vp, _sz, _vp]),
+    "glb_log_softmax_rows": (C.c_int, [_vp, _i32, _i64, _i64, _i64, _f32, _vp, _i32, _i64, _vp, _vp, _sz, _vp]),
     "glb_mask_f32_to_bits": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp]),
     "glb_group_contexts_workspace": (_sz, [_i64]),
     "glb_group_contexts": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

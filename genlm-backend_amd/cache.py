@@ -210,4 +210,5 @@ class TokenTrie:
             raise RuntimeError("TokenTrie.extend_cache needs the HIP engine that normalises the rows")
         lo = next_token_index - base
         rows = engine.log_softmax_rows(logits[lo:len(token_ids) - base])
+        engine.check()  # (cache_kv is a set-up call: one synchronising look at the error word; no NaN row reaches the trie)
         return self.extend_cache_rows(next_token_index, token_ids, rows, next_token_index, store=store)

@@ -3,6 +3,7 @@
 // gfx950 only.  No entry point allocates, frees or synchronises.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -15,6 +16,18 @@
 #include "../../include/glb.h"
 #include "glb_chunk.hpp"
 
+#ifndef GLB_FIN_LAG_PCT
+// Finishing blocks inside the grid, this many percent of the chip's wave slots behind their rows' stats blocks; -1: at
+// the end of the grid.  Measured (same box, tools/r4_kernel_ab.sh, profiles/r04/ab_lag.log): 1024 x 50257 fp32 42.7 us at
+// the end, 46.3 / 45.9 / 44.7 / 43.2 us at 25 / 50 / 100 / 200 percent; 512 x 128256 bf16 34.0 against 35.9 / 35.6 / 35.3 /
+// 34.7 - a finishing wave that runs beside the stream takes a slot and L2 requests from it and gives nothing back (its
+// work is latency, not throughput), and the last rows' finishing waves end when they did anyway.  Hence -1.
+#define GLB_FIN_LAG_PCT -1
+#endif
+#ifndef GLB_SHORT_LAST
+#define GLB_SHORT_LAST 1
+#endif
+
 namespace glb {
 // launchers exported by the three glb_chunk_tu.hip translation units (one per element type)
 #define GLB_DECL(dt)                                                                                              \
@@ -22,15 +35,14 @@ namespace glb {
   hipError_t launch_fused_step_##dt(const StepParams &p, int mask_kind, int mode, bool scaled, hipStream_t s);     \
   hipError_t launch_finish_##dt(const StepParams &p, int mask_kind, int mode, hipStream_t s);                     \
   hipError_t launch_logprob_rows_##dt(const void *logits, int64_t ld, int V, float scale, const float *lse,       \
-                                      float *out, int64_t out_ld, int n_rows, hipStream_t s);                      \
-  hipError_t launch_logprob_fused_##dt(const void *logits, int64_t ld, int V, int nch, float scale, float *out,   \
-                                       int64_t out_ld, float *out_lse, int n_rows, hipStream_t s);               \
-  hipError_t launch_logprob_waves_##dt(const void *logits, int64_t ld, int V, int nch, float scale, float *out,   \
+                                      void *out, bool out16, int64_t out_ld, int n_rows, hipStream_t s);           \
+  hipError_t launch_logprob_waves_##dt(const void *logits, int64_t ld, int V, int nch, float scale, void *out,    \
                                        int64_t out_ld, float *out_lse, int n_rows, uint64_t *recs, uint32_t epoch,  \
-                                       int variant, hipStream_t s);
+                                       uint32_t *err, uint64_t spin_ticks, bool out16, int variant, hipStream_t s);
 GLB_DECL(0) GLB_DECL(1) GLB_DECL(2)
 #undef GLB_DECL
 thread_local hipEvent_t g_step_ev_start = nullptr, g_step_ev_stop = nullptr;  // glb_logprob_mask_sample_timed
+int g_lds_pad[3] = {0, 0, 0};  // dynamic LDS bytes per one-wave workgroup of the fused step, by element type (occupancy cap)
 }  // namespace glb
 
 namespace {
@@ -75,6 +87,11 @@ struct WsEntry {
   uint32_t epoch;
   size_t bytes;
 };
+// the last 64 bytes of a registered workspace hold its error word: waves of a one-launch call that gave up waiting for
+// their records add 1 to it (glb_workspace_check reads and clears it).  Callers size workspaces with the *_bytes
+// functions, which leave 256 bytes beyond what the calls use.
+constexpr size_t kWsErrTail = 64;
+std::atomic<uint64_t> g_spin_ticks{glb::kSpinTicks};
 std::mutex g_ws_mu;
 std::unordered_map<const void *, WsEntry> g_ws;
 
@@ -95,7 +112,8 @@ int device_cus() {
 // The next epoch of a registered workspace for a launch that tags its records: 1 and *epoch set when `workspace` was
 // initialised with at least `bytes` and `s` is not being captured (the epoch is a launch argument: a replayed graph would
 // reuse it); 0 when the caller has to take its untagged form; -1 on a HIP error.
-int ws_next_epoch(void *workspace, size_t bytes, hipStream_t s, uint32_t *epoch) {
+int ws_next_epoch(void *workspace, size_t bytes, size_t used, hipStream_t s, uint32_t *epoch, uint32_t **err) {
+  *err = nullptr;  // bytes: the tagged records at the workspace's start; used: everything the call touches
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(s, &cs) != hipSuccess) {
     (void)hipGetLastError();
@@ -110,8 +128,12 @@ int ws_next_epoch(void *workspace, size_t bytes, hipStream_t s, uint32_t *epoch)
     it->second.epoch = 1u;
   }
   *epoch = it->second.epoch;
+  if (it->second.bytes >= used + kWsErrTail) *err = (uint32_t *)((char *)workspace + it->second.bytes - kWsErrTail);
   return 1;
 }
+
+// wave slots of the device at `waves_per_simd` (one-wave workgroups)
+int wave_slots(int waves_per_simd) { return device_cus() * 4 * waves_per_simd; }
 
 // which log-softmax kernel: -1 = the best the call allows (independent waves when the workspace carries tags, else a
 // workgroup per row or three launches).  The diagnostic build takes it from the environment for same-box comparisons:
@@ -131,6 +153,15 @@ int lsm_variant() {
 }
 
 int fin_wave_cap(bool float_mask) { return device_cus() * (float_mask ? 6 : 8); }
+
+// how far behind its row's stats blocks a finishing block is dealt, in percent of the chip's wave slots (-1: at the end
+// of the grid).  The diagnostic build reads it from the environment for same-box comparisons.
+int interleave_lag_slots() {
+#ifdef GLB_STAMPS
+  if (const char *e = getenv("GLB_FIN_LAG")) return atoi(e);
+#endif
+  return GLB_FIN_LAG_PCT;
+}
 
 
 hipError_t launch_finish(int dtype, const glb::StepParams &p, int mask_kind, int mode, hipStream_t s) {
@@ -555,8 +586,9 @@ __global__ void particles_advance_kernel(int32_t *ctx, int64_t ctx_ld, int32_t *
                                          int32_t max_len, uint64_t *hashes) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || !active[i]) return;
-  lw[i] += logZ[i];
   const int32_t t = tok[i];
+  if (t == -2) return;  // a failed launch (include/glb.h: out_token), never a result: the particle stays as it was
+  lw[i] += logZ[i];
   if (t == eos || t < 0) {
     active[i] = 0;
   } else {
@@ -1019,7 +1051,7 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
   }
   if (a->rng_mode < GLB_RNG_NONE || a->rng_mode > GLB_RNG_NOISE)
     return fail(GLB_EINVAL, "bad rng_mode %d", a->rng_mode);
-  if (a->reserved != 0) return fail(GLB_EINVAL, "reserved must be 0");
+  if (a->flags & ~(int32_t)GLB_STEP_ROWS_BY_FIRST_USE) return fail(GLB_EINVAL, "unknown bits in flags");
   if (a->rng_mode == GLB_RNG_NOISE && (!a->noise || (a->noise_ld < a->vocab && a->noise_ld != 0)))
     return fail(GLB_EINVAL, "noise tensor missing or noise_ld < vocab (0 = one row shared by every particle)");
   if (a->rng_mode != GLB_RNG_NONE && !a->out_token)
@@ -1091,8 +1123,17 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
   const int64_t items = n_units * (int64_t)p.nch;
   const bool fmask = kmask == glb::kMaskF32;
   bool fused = a->rng_mode != GLB_RNG_NOISE && items > 512 && a->n_particles <= 16 * (int64_t)fin_wave_cap(fmask);
+  p.il_lag = -1;
+  p.spin_ticks = g_spin_ticks.load(std::memory_order_relaxed);
+  // rows that end in at most half a chunk: those light items are dealt last (glb_chunk.hpp: short_last)
+  p.short_last = (p.nch >= 2 && a->vocab - (int64_t)(p.nch - 1) * glb::kChunk <= glb::kChunk / 2) ? GLB_SHORT_LAST : 0;
+#ifdef GLB_STAMPS  // diagnostic build: occupancy cap of the one-launch step from the environment (bytes of unused LDS)
+  if (const char *e = getenv("GLB_LDS_PAD")) glb::g_lds_pad[a->dtype] = atoi(e);
+  if (const char *e = getenv("GLB_SHORT_LAST")) p.short_last = p.short_last ? atoi(e) : 0;
+  if (const char *e = getenv("GLB_DBG_MODE")) p.dbg_mode = atoi(e);
+#endif
   if (fused) {
-    const int rc = ws_next_epoch(a->workspace, fixed_bytes, s, &p.epoch);
+    const int rc = ws_next_epoch(a->workspace, fixed_bytes, need_ws, s, &p.epoch, &p.err);
     if (rc < 0) return hip_fail(hipGetLastError(), "workspace re-zero");
     fused = rc > 0;
   }
@@ -1100,6 +1141,16 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
     p.stats_blocks = (int32_t)items;
     const int64_t cap = fin_wave_cap(fmask);
     p.fin_blocks = (int32_t)(a->n_particles < cap ? a->n_particles : cap);
+    // one finishing wave per particle and no unit numbered above its particles (identity, or the caller says its row
+    // ids are numbered by first use): the finishing blocks go inside the grid, about one chip's worth of wave slots
+    // behind their rows' stats blocks (glb_chunk.hpp: il_lag)
+    const bool ordered = p.pair_of == nullptr || (by_row && (a->flags & GLB_STEP_ROWS_BY_FIRST_USE));
+    if (ordered && a->n_particles <= cap && n_units <= a->n_particles && interleave_lag_slots() >= 0) {
+      const int wps = fmask ? 3 : (a->dtype == GLB_F32 ? 4 : GLB_STATS_WAVES_16);
+      int64_t lag = ((int64_t)interleave_lag_slots() * wave_slots(wps) / 100 + p.nch - 1) / p.nch;
+      p.il_lag = (int32_t)(lag < n_units ? lag : n_units);
+      p.short_last = 0;  // (the interleaved grid deals a unit's items as one run)
+    }
     const hipError_t e = launch_fused_step(a->dtype, p, kmask, a->rng_mode, scaled, s);
     if (e != hipSuccess) return hip_fail(e, "fused_step launch");
     return GLB_OK;
@@ -1130,6 +1181,40 @@ int glb_workspace_init(void *workspace, size_t workspace_bytes, void *stream) {
   return GLB_OK;
 }
 
+int glb_workspace_check(void *workspace, void *stream) {
+  if (!workspace) return fail(GLB_EINVAL, "workspace is null");
+  uint32_t *err = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    auto it = g_ws.find(workspace);
+    if (it == g_ws.end() || it->second.bytes < kWsErrTail) return fail(GLB_EINVAL, "workspace was not registered (glb_workspace_init)");
+    err = (uint32_t *)((char *)workspace + it->second.bytes - kWsErrTail);
+  }
+  uint32_t n = 0;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemcpyAsync(&n, err, sizeof n, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) return hip_fail(e, "workspace check");
+  if (n == 0) return GLB_OK;
+  e = hipMemsetAsync(err, 0, sizeof n, s);
+  if (e != hipSuccess) return hip_fail(e, "workspace check reset");
+  return fail(GLB_EHIP, "%u wave(s) of a one-launch call on this workspace gave up waiting for their row's records "
+              "(token -2 / NaN outputs): the launch did not complete, its results must not be used", n);
+}
+
+const uint32_t *glb_workspace_error_word(void *workspace) {
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  auto it = g_ws.find(workspace);
+  if (it == g_ws.end() || it->second.bytes < kWsErrTail) return nullptr;
+  return (const uint32_t *)((char *)workspace + it->second.bytes - kWsErrTail);
+}
+
+int glb_set_spin_limit(uint64_t microseconds) {
+  const uint64_t ticks = microseconds == GLB_SPIN_NONE ? 0ull : (microseconds > (1ull << 40) ? (1ull << 47) : microseconds * 100ull);
+  g_spin_ticks.store(microseconds ? ticks : glb::kSpinTicks, std::memory_order_relaxed);
+  return GLB_OK;
+}
+
 int glb_workspace_release(void *workspace) {
   std::lock_guard<std::mutex> lk(g_ws_mu);
   g_ws.erase(workspace);
@@ -1142,15 +1227,18 @@ size_t glb_log_softmax_workspace_bytes(int64_t n_rows, int64_t vocab) {
 }
 
 int glb_log_softmax_rows(const void *logits, int32_t dtype, int64_t n_rows, int64_t vocab,
-                         int64_t ld, float logit_scale, float *out, int64_t out_ld, float *out_lse,
+                         int64_t ld, float logit_scale, void *out, int32_t out_dtype, int64_t out_ld, float *out_lse,
                          void *workspace, size_t workspace_bytes, void *stream) {
   if (!logits) return fail(GLB_EINVAL, "logits is null");
   if (dtype < GLB_F32 || dtype > GLB_F16) return fail(GLB_EINVAL, "bad dtype %d", dtype);
+  if (out_dtype != GLB_F32 && out_dtype != dtype)
+    return fail(GLB_EINVAL, "out_dtype %d: log-probabilities leave as float32 or in the logits' own type (%d)", out_dtype, dtype);
   if (n_rows <= 0 || vocab <= 0) return fail(GLB_EINVAL, "n_rows / vocab must be positive");
   if (ld < vocab || (out && out_ld < vocab)) return fail(GLB_EINVAL, "ld / out_ld smaller than vocab");
   if (!out && !out_lse) return fail(GLB_EINVAL, "no output requested");
   if (vocab > 0x7fffff00ll || n_rows > 0x7fffffffll) return fail(GLB_EINVAL, "size exceeds 31 bits");
-  if (out && ((uintptr_t)out) % 4) return fail(GLB_EINVAL, "out pointer not 4-byte aligned");
+  const bool out16 = out_dtype != GLB_F32;
+  if (out && ((uintptr_t)out) % (out16 ? 2 : 4)) return fail(GLB_EINVAL, "out pointer not element aligned");
   if (!(logit_scale == logit_scale)) return fail(GLB_EINVAL, "logit_scale is NaN");
   if (!workspace || ((uintptr_t)workspace) % 32) return fail(GLB_EINVAL, "workspace null or not 32-byte aligned");
   if (workspace_bytes < glb_log_softmax_workspace_bytes(n_rows, vocab))
@@ -1158,34 +1246,26 @@ int glb_log_softmax_rows(const void *logits, int32_t dtype, int64_t n_rows, int6
   hipStream_t s = (hipStream_t)stream;
   const int nch = (int)n_chunks(vocab);
   const int mode = lsm_mode();
+  const size_t recs_bytes = step_recs_bytes(n_rows, vocab);
   // one launch of independent waves that keep their chunks in registers and meet through tagged records: needs a
   // workspace glb_workspace_init has seen (the tags) and a row of at most 64 chunks (one lane per record)
   if (mode < 0 && out && nch <= 64 && n_rows * (int64_t)nch <= 0x7fffffffll) {
-    uint32_t epoch = 0;
-    const int rc = ws_next_epoch(workspace, step_recs_bytes(n_rows, vocab), s, &epoch);
+    uint32_t epoch = 0, *err = nullptr;
+    const int rc = ws_next_epoch(workspace, recs_bytes, recs_bytes + align256((size_t)n_rows * 4), s, &epoch, &err);
     if (rc < 0) return hip_fail(hipGetLastError(), "workspace re-zero");
     if (rc > 0) {
+      const uint64_t spin = g_spin_ticks.load(std::memory_order_relaxed);
       hipError_t e;
       switch (dtype) {
-        case 0: e = glb::launch_logprob_waves_0(logits, ld, (int)vocab, nch, logit_scale, out, out_ld, out_lse, (int)n_rows, (uint64_t *)workspace, epoch, lsm_variant(), s); break;
-        case 1: e = glb::launch_logprob_waves_1(logits, ld, (int)vocab, nch, logit_scale, out, out_ld, out_lse, (int)n_rows, (uint64_t *)workspace, epoch, lsm_variant(), s); break;
-        default: e = glb::launch_logprob_waves_2(logits, ld, (int)vocab, nch, logit_scale, out, out_ld, out_lse, (int)n_rows, (uint64_t *)workspace, epoch, lsm_variant(), s); break;
+        case 0: e = glb::launch_logprob_waves_0(logits, ld, (int)vocab, nch, logit_scale, out, out_ld, out_lse, (int)n_rows, (uint64_t *)workspace, epoch, err, spin, out16, lsm_variant(), s); break;
+        case 1: e = glb::launch_logprob_waves_1(logits, ld, (int)vocab, nch, logit_scale, out, out_ld, out_lse, (int)n_rows, (uint64_t *)workspace, epoch, err, spin, out16, lsm_variant(), s); break;
+        default: e = glb::launch_logprob_waves_2(logits, ld, (int)vocab, nch, logit_scale, out, out_ld, out_lse, (int)n_rows, (uint64_t *)workspace, epoch, err, spin, out16, lsm_variant(), s); break;
       }
       if (e != hipSuccess) return hip_fail(e, "logprob_rows_waves launch");
       return GLB_OK;
     }
   }
-  if (n_rows >= 128 && nch <= 4096) {  // enough rows for one workgroup each: single launch
-    hipError_t e;
-    switch (dtype) {
-      case 0: e = glb::launch_logprob_fused_0(logits, ld, (int)vocab, nch, logit_scale, out, out_ld, out_lse, (int)n_rows, s); break;
-      case 1: e = glb::launch_logprob_fused_1(logits, ld, (int)vocab, nch, logit_scale, out, out_ld, out_lse, (int)n_rows, s); break;
-      default: e = glb::launch_logprob_fused_2(logits, ld, (int)vocab, nch, logit_scale, out, out_ld, out_lse, (int)n_rows, s); break;
-    }
-    if (e != hipSuccess) return hip_fail(e, "logprob_rows_fused launch");
-    return GLB_OK;
-  }
-  const size_t recs_bytes = step_recs_bytes(n_rows, vocab);
+  // any row length, any workspace, stream capture: chunk statistics, one wave per row for lse, one elementwise launch
   float *lse = out_lse ? out_lse : (float *)((char *)workspace + recs_bytes);
   glb::StepParams p{};
   p.logits = logits;
@@ -1197,15 +1277,16 @@ int glb_log_softmax_rows(const void *logits, int32_t dtype, int64_t n_rows, int6
   p.n_pairs = (int32_t)n_rows;
   p.recs = (uint64_t *)workspace;
   p.out_lse = lse;
+  p.il_lag = -1;
   hipError_t e = launch_stats(dtype, p, glb::kMaskNone, logit_scale != 1.0f, s);
   if (e != hipSuccess) return hip_fail(e, "chunk_stats launch");
   e = launch_finish(dtype, p, glb::kMaskNone, glb::kModeStats, s);
   if (e != hipSuccess) return hip_fail(e, "finish launch");
   if (out) {
     switch (dtype) {
-      case 0: e = glb::launch_logprob_rows_0(logits, ld, (int)vocab, logit_scale, lse, out, out_ld, (int)n_rows, s); break;
-      case 1: e = glb::launch_logprob_rows_1(logits, ld, (int)vocab, logit_scale, lse, out, out_ld, (int)n_rows, s); break;
-      default: e = glb::launch_logprob_rows_2(logits, ld, (int)vocab, logit_scale, lse, out, out_ld, (int)n_rows, s); break;
+      case 0: e = glb::launch_logprob_rows_0(logits, ld, (int)vocab, logit_scale, lse, out, out16, out_ld, (int)n_rows, s); break;
+      case 1: e = glb::launch_logprob_rows_1(logits, ld, (int)vocab, logit_scale, lse, out, out16, out_ld, (int)n_rows, s); break;
+      default: e = glb::launch_logprob_rows_2(logits, ld, (int)vocab, logit_scale, lse, out, out16, out_ld, (int)n_rows, s); break;
     }
     if (e != hipSuccess) return hip_fail(e, "logprob_rows launch");
   }

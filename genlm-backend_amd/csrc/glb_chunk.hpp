@@ -59,7 +59,8 @@ struct ChunkRec {  // one (row|particle, chunk) as the finish role holds it
 // granules.  The row sums cost the reducing wave nothing (its DPP sums pass through them) and let a draw re-reduce a
 // quarter of a chunk instead of all of it.
 constexpr int kRecWords = 16;
-constexpr uint64_t kSpinTicks = 200000000ull;  // finish role gives up after 2 s of s_memrealtime (100 MHz): token -2
+constexpr uint64_t kSpinTicks = 200000000ull;  // default watchdog: a waiting wave gives up after 2 s of s_memrealtime
+                                               // (100 MHz): token -2 / NaN, the workspace's error word (glb_set_spin_limit)
 
 struct StepParams {
   const void *logits;
@@ -86,6 +87,20 @@ struct StepParams {
   // fused launch (one-wave workgroups): blocks [0, stats_blocks) reduce one (unit, chunk) each, then fin_blocks
   // finishing waves (wave f takes particles f, f + fin_blocks, ...)
   int32_t stats_blocks, fin_blocks;
+  // il_lag >= 0 (needs fin_blocks == n_particles >= n_pairs): the finishing blocks are dealt INSIDE the grid - units
+  // [0, il_lag) are stats blocks only, the nch stats blocks of every later unit u are followed by the finishing block
+  // of particle u - il_lag, and the finishing blocks of the last particles close the grid.  A particle's unit is never
+  // numbered above the particle (identity, or ids by first appearance), so under in-order dispatch its finishing wave
+  // is placed il_lag units behind its row's stats waves: most of them find their records complete and do their work
+  // while the stream is still running, instead of all of them after it.  il_lag < 0: every finishing block at the end.
+  int32_t il_lag;
+  uint32_t *err;      // nullable: word a wave that gave up waiting adds 1 to (glb_workspace_check)
+  uint64_t spin_ticks;  // the watchdog of the waits inside the launch, in s_memrealtime ticks
+  // short_last != 0 (rows whose last chunk holds at most half a chunk): the stats items are dealt full chunks first, row by
+  // row, and every row's short chunk after all of them - the blocks placed last are the lightest ones (longest processing
+  // time first), so the launch's last stats waves are done in a fraction of a full wave's lifetime
+  int32_t short_last;
+  int32_t dbg_mode;     // diagnostic build only (tools/r4_kernel_ab.sh): 1 = no exponentials, 2 = every row is row 0..7
 };
 
 template <int DT>
@@ -131,6 +146,19 @@ __device__ __forceinline__ void unpack_vec(const u32x4_t &r, float *x) {
       x[2 * i] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[i] & 0xffffu));
       x[2 * i + 1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[i] >> 16));
     }
+  }
+}
+
+// two float32 values as one word of 16-bit elements (round to nearest even; a NaN stays a NaN: plain casts, which
+// hipcc lowers to v_cvt_pk_bf16_f32 / v_cvt_f16_f32 on gfx950)
+template <int DT>
+__device__ __forceinline__ uint32_t pack16(float lo, float hi) {
+  if constexpr (DT == kDtBf16) {
+    const __bf16 a = (__bf16)lo, b = (__bf16)hi;
+    return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+  } else {
+    const _Float16 a = (_Float16)lo, b = (_Float16)hi;
+    return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
   }
 }
 
@@ -469,12 +497,31 @@ __device__ __forceinline__ void stats_item(const StepParams &p, int item, int la
 #ifdef GLB_STAMPS  // diagnostic build (tools/dbg/stamps.py): wave start / end times in the record's padding
   const uint64_t stamp0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  const int pr = item / nch, c = item - pr * nch;  // (dealt row-interleaved instead, the launch is 2.5 us slower)
-  const int row = p.pair_row ? as_const(p.pair_row)[pr] : pr;
+  int pr, c;  // (dealt chunk-major instead - every row's chunk 0, then every row's chunk 1, ... - the launch is 2.5 us slower)
+  if (p.short_last) {
+    const int nfull = nch - 1, split = p.n_pairs * nfull;
+    if (item < split) {
+      pr = item / nfull;
+      c = item - pr * nfull;
+    } else {
+      pr = item - split;
+      c = nfull;
+    }
+  } else {
+    pr = item / nch;
+    c = item - pr * nch;
+  }
+  int row = p.pair_row ? as_const(p.pair_row)[pr] : pr;
+#ifdef GLB_STAMPS
+  if (p.dbg_mode == 2) row &= 7;  // (timing experiment: the rows come out of the caches)
+#endif
   const char *rowp = (const char *)p.logits + (int64_t)row * p.ld * ES;
   const int V = p.V, e_base = c * kChunk;
   int nv_valid = (V - e_base + 64 * EPV - 1) / (64 * EPV);
   nv_valid = nv_valid < NVC ? nv_valid : NVC;
+#ifdef GLB_STAMPS
+  if (p.dbg_mode == 1) nv_valid = 1;  // (timing experiment: one vector's worth of exponentials instead of sixteen / eight)
+#endif
 
   // the chunk's loads go out first: everything below that has to wait for a scalar load (the mask id of the unit, then
   // the mask words) waits while they are in flight, not in front of them
@@ -728,7 +775,7 @@ struct Recs {
 // writing them; relaxed agent-scope loads, a short sleep between sweeps, a bounded wait).  Without POLL the records
 // come from an earlier launch on the stream and the tags are not looked at.
 template <bool POLL>
-__device__ __forceinline__ bool recs_acquire(Recs &R, int nch, int lane) {
+__device__ __forceinline__ bool recs_acquire(Recs &R, int nch, int lane, uint64_t spin_ticks) {
   R.cached = nch <= 64;
   R.mine = ChunkRec{kNegInf, kNegInf, 0u, 0u, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, 0u, 0u};
   uint64_t t0 = 0;
@@ -749,7 +796,7 @@ __device__ __forceinline__ bool recs_acquire(Recs &R, int nch, int lane) {
         }
         if (__builtin_amdgcn_ballot_w64(!seen) != 0ull) {
           __builtin_amdgcn_s_sleep(8);
-          if (__builtin_amdgcn_s_memrealtime() - t0 > kSpinTicks) return false;
+          if (__builtin_amdgcn_s_memrealtime() - t0 > spin_ticks) return false;
           continue;
         }
       }
@@ -760,7 +807,7 @@ __device__ __forceinline__ bool recs_acquire(Recs &R, int nch, int lane) {
       if constexpr (!POLL) break;
       if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
       __builtin_amdgcn_s_sleep(2);
-      if (__builtin_amdgcn_s_memrealtime() - t0 > kSpinTicks) return false;
+      if (__builtin_amdgcn_s_memrealtime() - t0 > spin_ticks) return false;
     }
   }
   return true;
@@ -873,10 +920,12 @@ __device__ __forceinline__ void finish_stats(const StepParams &p, int pidx, int 
   recs.base = p.recs + (int64_t)pr * nch * kRecWords;
   recs.epoch = p.epoch;
   float lse = __uint_as_float(0x7fc00000u), logZ = lse;  // (a wave that gave up waiting: NaN, never in a healthy launch)
-  if (recs_acquire<POLL>(recs, nch, lane)) {
+  if (recs_acquire<POLL>(recs, nch, lane, p.spin_ticks)) {
     PairState st;
     pair_fold<MASK>(recs, nch, lane, st);
     if (lane == 0) pair_logs(st, lse, logZ);
+  } else if (lane == 0 && p.err) {
+    atomicAdd(p.err, 1u);
   }
   if (lane == 0) {
     if (p.out_lse) p.out_lse[pidx] = lse;
@@ -911,8 +960,9 @@ __device__ __forceinline__ void finish_draw(const StepParams &p, int pidx, int l
   Recs recs;
   recs.base = p.recs + (int64_t)pr * nch * kRecWords;
   recs.epoch = p.epoch;
-  if (!recs_acquire<POLL>(recs, nch, lane)) {  // never in a healthy launch: say so in the outputs and leave
+  if (!recs_acquire<POLL>(recs, nch, lane, p.spin_ticks)) {  // never in a healthy launch: say so in the outputs and leave
     if (lane == 0) {
+      if (p.err) atomicAdd(p.err, 1u);
       const float nan = __uint_as_float(0x7fc00000u);
       if (p.out_lse) p.out_lse[pidx] = nan;
       if (p.out_logZ) p.out_logZ[pidx] = nan;
@@ -1057,11 +1107,30 @@ template <int DT, int MASK, bool SCALED, int MODE>
 __global__ __launch_bounds__(64, (StatsWaves<DT, MASK>::value)) void fused_step_kernel(const StepParams p) {
   const int lane = threadIdx.x;
   const int blk = blockIdx.x;
-  if (blk < p.stats_blocks) {
-    stats_item<DT, MASK, SCALED>(p, blk, lane);
+  int item = -1, pfirst = -1;  // (wave-uniform: scalar arithmetic)
+  if (p.il_lag < 0) {
+    if (blk < p.stats_blocks) item = blk;
+    else pfirst = blk - p.stats_blocks;
+  } else {
+    const int head = p.il_lag * p.nch, b = blk - head;
+    if (b < 0) {
+      item = blk;
+    } else {
+      const int per = p.nch + 1, n_mid = p.n_pairs - p.il_lag;
+      const int q = (int)((unsigned)b / (unsigned)per), r = b - q * per;
+      if (q < n_mid) {
+        if (r < p.nch) item = (p.il_lag + q) * p.nch + r;
+        else pfirst = q;
+      } else {
+        pfirst = n_mid + (b - n_mid * per);
+      }
+    }
+  }
+  if (item >= 0) {
+    stats_item<DT, MASK, SCALED>(p, item, lane);
     return;
   }
-  for (int pidx = blk - p.stats_blocks; pidx < p.n_particles; pidx += p.fin_blocks) {
+  for (int pidx = pfirst; pidx < p.n_particles; pidx += p.fin_blocks) {
     if constexpr (MODE == kModePhilox) finish_draw<DT, MASK, true>(p, pidx, lane);
     else finish_stats<MASK, true>(p, pidx, lane);
   }
@@ -1102,7 +1171,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
   Recs recs;
   recs.base = p.recs + (int64_t)pr * nch * kRecWords;
   recs.epoch = p.epoch;
-  recs_acquire<false>(recs, nch, lane);
+  recs_acquire<false>(recs, nch, lane, 0);
 
   RowView<DT, MASK> rv;
   rv.rowp = (const char *)p.logits + (int64_t)row * p.ld * ES;
@@ -1203,11 +1272,13 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// log-probability rows: out[r, j] = x'[r, j] - lse[r]  (one thread per 16-byte input vector)
+// log-probability rows: out[r, j] = x'[r, j] - lse[r]  (one thread per 16-byte input vector).  The last of three
+// launches (chunk statistics, one wave per row for lse, this) that serve what the kernel of independent waves below
+// does not: rows of more than 64 chunks, workspaces without tags, stream capture.
 // ---------------------------------------------------------------------------------------------------------
-template <int DT>
+template <int DT, bool OUT16>
 __global__ __launch_bounds__(256) void logprob_rows_kernel(const void *logits, int64_t ld, int V, float scale,
-                                                          const float *lse, float *out, int64_t out_ld,
+                                                          const float *lse, void *out_v, int64_t out_ld,
                                                           int n_rows) {
   constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES;
   const int nv = (V + EPV - 1) / EPV;
@@ -1218,104 +1289,30 @@ __global__ __launch_bounds__(256) void logprob_rows_kernel(const void *logits, i
   float x[EPV];
   unpack_vec<DT>(load_vec_guarded<DT>(rowp, e0, V), x);
   const float l = lse[r];
-  float *o = out + (int64_t)r * out_ld + e0;
-  if (e0 + EPV <= V) {
 #pragma unroll
-    for (int h = 0; h < EPV / 4; ++h) {
-      float4 v;
-      v.x = x[4 * h] * scale - l;
-      v.y = x[4 * h + 1] * scale - l;
-      v.z = x[4 * h + 2] * scale - l;
-      v.w = x[4 * h + 3] * scale - l;
-      *reinterpret_cast<float4 *>(o + 4 * h) = v;
-    }
+  for (int k = 0; k < EPV; ++k) x[k] = x[k] * scale - l;  // (x * 1.0f == x: the scaled form serves every call)
+  if constexpr (OUT16) {
+    uint16_t *o = reinterpret_cast<uint16_t *>(out_v) + (int64_t)r * out_ld + e0;
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w[k] = pack16<DT>(x[2 * k], x[2 * k + 1]);
+    if (e0 + EPV <= V) *reinterpret_cast<u32x4_t *>(o) = u32x4_t{w[0], w[1], w[2], w[3]};
+    else
+      for (int k = 0; k < V - e0; ++k) o[k] = (uint16_t)(w[k >> 1] >> ((k & 1) * 16));
   } else {
-    for (int k = 0; k < V - e0; ++k) o[k] = x[k] * scale - l;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// log-probability rows in one launch: one workgroup of WAVES waves per row.  Wave w reduces chunks w, w + WAVES, ... of
-// the row (the stats role's per-chunk arithmetic, records kept in LDS), one wave folds them into lse, then every wave
-// streams its chunks again - read microseconds ago: L2 / Infinity Cache serve them - and writes x - lse with
-// non-temporal stores (206 MB of output that nobody reads soon must not push the rows out of the caches before their
-// second reading).  Any row length; the second reading is served on the die but crosses the XCD <-> memory fabric like
-// the first (111 us at 1024 x 50257 fp32; four-wave workgroups, four to a CU: 146 us).  Used for rows too long for the
-// kernel of independent waves below (more than 64 chunks, or a workspace without tags) when there are enough rows to
-// fill the chip (the three-launch path spreads a few rows over the chip chunk by chunk).
-// ---------------------------------------------------------------------------------------------------------
-template <int DT, bool SCALED, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void logprob_rows_fused_kernel(const void *logits, int64_t ld, int V, int nch,
-                                                                       float scale, float *out, int64_t out_ld,
-                                                                       float *out_lse) {
-  constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC;
-  extern __shared__ uint64_t s_rec[];  // [nch] chunk sums, then [nch] floats of chunk scales
-  float *s_N = reinterpret_cast<float *>(s_rec + nch);
-  __shared__ float s_lse;
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int r = blockIdx.x;
-  const char *rowp = (const char *)logits + (int64_t)r * ld * ES;
-  float x[64];
-  for (int c = wave; c < nch; c += WAVES) {
-    const int e_base = c * kChunk;
-    int nv_valid = (V - e_base + 64 * EPV - 1) / (64 * EPV);
-    nv_valid = nv_valid < NVC ? nv_valid : NVC;
-    load_chunk<DT, SCALED>(rowp, e_base, V, lane, scale, x);
-    const float Nc = exp_n(chunk_max(x));
-    float P[4], Pm[4];
-    uint32_t h, l;
-    class_partials<DT, false>(x, kMagic - Nc, nv_valid, nullptr, MaskAhead{}, P, Pm);
-    lane_payload<4>(P, h, l);
-    const uint32_t pA = wave_sum_u32_l63(h), pB = wave_sum_u32_l63(l);
-    if (lane == 63) {
-      s_rec[c] = ((uint64_t)pA << kGridHi) + pB;
-      s_N[c] = Nc;
-    }
-  }
-  __syncthreads();
-  if (wave == 0) {
-    float N = kNegInf;
-    for (int c = lane; c < nch; c += 64)
-      if (s_rec[c]) N = fmaxf(N, s_N[c]);
-    N = wave_max(N);
-    uint64_t S = 0;
-    for (int c0 = 0; c0 < nch; c0 += 64) {
-      const int c = c0 + lane;
-      uint64_t sa = 0;
-      if (c < nch && s_rec[c]) {
-        const float d = N - s_N[c];
-        sa = d < 64.0f ? s_rec[c] >> (uint32_t)d : 0ull;
-      }
-      S += wave_sum_u64(sa);
-    }
-    if (lane == 0) {
-      const float lse = S ? (float)log_fix(S, (int32_t)N + 1 - kFrac) : kNegInf;
-      s_lse = lse;
-      if (out_lse) out_lse[r] = lse;
-    }
-  }
-  __syncthreads();
-  if (!out) return;
-  const float l = s_lse;
-  float *orow = out + (int64_t)r * out_ld;
-  for (int c = wave; c < nch; c += WAVES) {
-    const int e_base = c * kChunk;
-    load_chunk<DT, SCALED>(rowp, e_base, V, lane, scale, x);  // all the chunk's loads in flight, then all its stores
+    float *o = reinterpret_cast<float *>(out_v) + (int64_t)r * out_ld + e0;
+    if (e0 + EPV <= V) {
 #pragma unroll
-    for (int i = 0; i < NVC; ++i) {
-      const int e0 = e_base + (i * 64 + lane) * EPV;
-      if (e0 >= V) continue;
-      if (e0 + EPV <= V) {
-#pragma unroll
-        for (int h = 0; h < EPV / 4; ++h) {
-          typedef float f32x4_t __attribute__((ext_vector_type(4)));
-          const f32x4_t v{x[i * EPV + 4 * h] - l, x[i * EPV + 4 * h + 1] - l, x[i * EPV + 4 * h + 2] - l,
-                          x[i * EPV + 4 * h + 3] - l};
-          __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t *>(orow + e0 + 4 * h));
-        }
-      } else {
-        for (int k = 0; k < V - e0; ++k) orow[e0 + k] = x[i * EPV + k] - l;
+      for (int h = 0; h < EPV / 4; ++h) {
+        float4 v;
+        v.x = x[4 * h];
+        v.y = x[4 * h + 1];
+        v.z = x[4 * h + 2];
+        v.w = x[4 * h + 3];
+        *reinterpret_cast<float4 *>(o + 4 * h) = v;
       }
+    } else {
+      for (int k = 0; k < V - e0; ++k) o[k] = x[k];
     }
   }
 }
@@ -1335,10 +1332,14 @@ __global__ __launch_bounds__(64 * WAVES) void logprob_rows_fused_kernel(const vo
 // STORE (16-bit rows; a lane's eight elements of a vector are 32 bytes of output): 0 = two 16-byte stores per lane, each
 // instruction covering every other 16 bytes of a 2 KB span; 2 = through 2 KB of LDS so that each store instruction
 // writes 1 KB of consecutive addresses.
-template <int DT, bool SCALED, int WPS, int STORE>
+// OUT16 (16-bit rows only): the log-probabilities leave in the logits' own element type, as the reference returns them
+// (cache.py:96 keeps the dtype) - the float32 result rounded to nearest even; a lane's eight outputs of a vector are one
+// 16-byte store and every store instruction writes 1 KB of consecutive addresses, so nothing passes through LDS.
+template <int DT, bool SCALED, int WPS, int STORE, bool OUT16 = false>
 __global__ __launch_bounds__(64, WPS) void logprob_rows_waves_kernel(
-    const void *logits, int64_t ld, int V, int nch, float scale, float *out, int64_t out_ld, float *out_lse,
-    uint64_t *recs, uint32_t epoch) {
+    const void *logits, int64_t ld, int V, int nch, float scale, void *out_v, int64_t out_ld, float *out_lse,
+    uint64_t *recs, uint32_t epoch, uint32_t *err, uint64_t spin_ticks) {
+  static_assert(!OUT16 || DT != kDtF32, "16-bit output goes with 16-bit logits");
   constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC;
   const int lane = threadIdx.x;
   const int r = (int)(blockIdx.x / (unsigned)nch), c = (int)(blockIdx.x - (unsigned)r * (unsigned)nch);
@@ -1397,7 +1398,7 @@ __global__ __launch_bounds__(64, WPS) void logprob_rows_waves_kernel(
       }
       if (__builtin_amdgcn_ballot_w64(!ok) != 0ull) {  // one 8-byte load per record and sweep while waiting
         __builtin_amdgcn_s_sleep(8);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > kSpinTicks) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > spin_ticks) {
           have = false;
           break;
         }
@@ -1413,13 +1414,14 @@ __global__ __launch_bounds__(64, WPS) void logprob_rows_waves_kernel(
       }
       if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
       __builtin_amdgcn_s_sleep(2);
-      if (__builtin_amdgcn_s_memrealtime() - t0 > kSpinTicks) {
+      if (__builtin_amdgcn_s_memrealtime() - t0 > spin_ticks) {
         have = false;
         break;
       }
     }
   }
   float lse = __builtin_nanf("");
+  if (!have && lane == 0 && err) atomicAdd(err, 1u);  // (the row comes out as NaN: a failed launch, never a result)
   if (have) {
     const bool on = lane < nch && Sj != 0;
     const float N = wave_max(on ? Nj : kNegInf);
@@ -1432,7 +1434,29 @@ __global__ __launch_bounds__(64, WPS) void logprob_rows_waves_kernel(
     lse = S ? (float)log_fix(S, (int32_t)N + 1 - kFrac) : kNegInf;
   }
   if (c == 0 && lane == 0 && out_lse) out_lse[r] = lse;
-  if (!out) return;
+  if (!out_v) return;
+  if constexpr (OUT16) {
+    uint16_t *o16 = reinterpret_cast<uint16_t *>(out_v) + (int64_t)r * out_ld + e_base + lane * 8;
+    const bool full = e_base + kChunk <= V;  // wave-uniform
+#pragma unroll
+    for (int i = 0; i < NVC; ++i) {
+      float t[8];
+      unpack_scaled<DT, SCALED>(raw[i], scale, t);
+      uint32_t w[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) w[k] = pack16<DT>(t[2 * k] - lse, t[2 * k + 1] - lse);
+      const int e0 = e_base + (i * 64 + lane) * 8;
+      if (full || e0 + 8 <= V) {
+        // (rows are element aligned only: a 16-byte store to an address that is not 16-byte aligned is legal on gfx950 and
+        // what the unaligned loads of the same rows already do)
+        __builtin_nontemporal_store(u32x4_t{w[0], w[1], w[2], w[3]}, reinterpret_cast<u32x4_t *>(o16 + i * 512));
+      } else {
+        for (int k = 0; k < V - e0; ++k) o16[i * 512 + k] = (uint16_t)(w[k >> 1] >> ((k & 1) * 16));
+      }
+    }
+    return;
+  }
+  float *out = reinterpret_cast<float *>(out_v);
   float *o = out + (int64_t)r * out_ld + e_base + lane * EPV;
   typedef float f32x4_t __attribute__((ext_vector_type(4)));
   if (e_base + kChunk <= V) {  // wave-uniform: a full chunk, straight stores

@@ -16,12 +16,14 @@ namespace glb {
 // glb_logprob_mask_sample_timed (glb_api.hip): HIP events that the step's first / last launch carries as its own start /
 // stop time stamps (hipExtLaunchKernel) - the launch duration as the profiler sees it, without marker packets
 extern thread_local hipEvent_t g_step_ev_start, g_step_ev_stop;
+extern int g_lds_pad[3];
 
 template <class K>
-static void launch_k(K kernel, dim3 grid, dim3 block, hipStream_t s, const StepParams &p, bool first, bool last) {
+static void launch_k(K kernel, dim3 grid, dim3 block, hipStream_t s, const StepParams &p, bool first, bool last,
+                     unsigned lds = 0) {
   hipEvent_t e0 = first ? g_step_ev_start : nullptr, e1 = last ? g_step_ev_stop : nullptr;
-  if (e0 || e1) hipExtLaunchKernelGGL(kernel, grid, block, 0, s, e0, e1, 0, p);
-  else hipLaunchKernelGGL(kernel, grid, block, 0, s, p);
+  if (e0 || e1) hipExtLaunchKernelGGL(kernel, grid, block, lds, s, e0, e1, 0, p);
+  else hipLaunchKernelGGL(kernel, grid, block, lds, s, p);
 }
 
 // launches with fewer items than this use four waves per chunk (the chip has 1024 SIMDs; below about one wave per
@@ -58,8 +60,10 @@ hipError_t GLB_CAT(launch_stats_, GLB_DT)(const StepParams &p, int mask_kind, bo
 template <int MASK, int MODE>
 static hipError_t fused2(const StepParams &p, bool scaled, hipStream_t s) {
   const dim3 grid((unsigned)(p.stats_blocks + p.fin_blocks)), block(64);
-  if (scaled) launch_k(fused_step_kernel<GLB_DT, MASK, true, MODE>, grid, block, s, p, true, true);
-  else launch_k(fused_step_kernel<GLB_DT, MASK, false, MODE>, grid, block, s, p, true, true);
+  // (dynamic LDS nobody touches: a cap on the workgroups a CU holds, for occupancy experiments; 0 in the product)
+  const unsigned lds = (unsigned)g_lds_pad[GLB_DT];
+  if (scaled) launch_k(fused_step_kernel<GLB_DT, MASK, true, MODE>, grid, block, s, p, true, true, lds);
+  else launch_k(fused_step_kernel<GLB_DT, MASK, false, MODE>, grid, block, s, p, true, true, lds);
   return hipGetLastError();
 }
 
@@ -102,47 +106,40 @@ hipError_t GLB_CAT(launch_finish_, GLB_DT)(const StepParams &p, int mask_kind, i
 }
 
 hipError_t GLB_CAT(launch_logprob_rows_, GLB_DT)(const void *logits, int64_t ld, int V, float scale,
-                                                  const float *lse, float *out, int64_t out_ld, int n_rows,
+                                                  const float *lse, void *out, bool out16, int64_t out_ld, int n_rows,
                                                   hipStream_t s) {
   constexpr int EPV = ElemTraits<GLB_DT>::EPV;
   const int64_t total = (int64_t)n_rows * ((V + EPV - 1) / EPV);
-  hipLaunchKernelGGL((logprob_rows_kernel<GLB_DT>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, logits,
-                     ld, V, scale, lse, out, out_ld, n_rows);
+  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if constexpr (GLB_DT != kDtF32) {
+    if (out16) {
+      hipLaunchKernelGGL((logprob_rows_kernel<GLB_DT, true>), grid, block, 0, s, logits, ld, V, scale, lse, out, out_ld, n_rows);
+      return hipGetLastError();
+    }
+  }
+  hipLaunchKernelGGL((logprob_rows_kernel<GLB_DT, false>), grid, block, 0, s, logits, ld, V, scale, lse, out, out_ld, n_rows);
   return hipGetLastError();
 }
 
-template <bool SCALED>
-static void lsm_fused1(const void *logits, int64_t ld, int V, int nch, float scale, float *out, int64_t out_ld, float *out_lse,
-                   int n_rows, hipStream_t s) {
-  const size_t lds = (size_t)nch * (sizeof(uint64_t) + sizeof(float));
-  hipLaunchKernelGGL((logprob_rows_fused_kernel<GLB_DT, SCALED, 16>), dim3((unsigned)n_rows), dim3(1024), lds, s, logits,
-                     ld, V, nch, scale, out, out_ld, out_lse);
-}
-
-hipError_t GLB_CAT(launch_logprob_fused_, GLB_DT)(const void *logits, int64_t ld, int V, int nch, float scale, float *out,
-                                                   int64_t out_ld, float *out_lse, int n_rows, hipStream_t s) {
-  if (scale != 1.0f) lsm_fused1<true>(logits, ld, V, nch, scale, out, out_ld, out_lse, n_rows, s);
-  else lsm_fused1<false>(logits, ld, V, nch, scale, out, out_ld, out_lse, n_rows, s);
-  return hipGetLastError();
-}
-
-template <int WPS, int STORE>
-static void lsm_waves1(const void *logits, int64_t ld, int V, int nch, float scale, float *out, int64_t out_ld,
-                       float *out_lse, int n_rows, uint64_t *recs, uint32_t epoch, hipStream_t s) {
+template <int WPS, int STORE, bool OUT16 = false>
+static void lsm_waves1(const void *logits, int64_t ld, int V, int nch, float scale, void *out, int64_t out_ld,
+                       float *out_lse, int n_rows, uint64_t *recs, uint32_t epoch, uint32_t *err, uint64_t spin,
+                       hipStream_t s) {
   const dim3 grid((unsigned)((int64_t)n_rows * nch)), block(64);
   if (scale != 1.0f)
-    hipLaunchKernelGGL((logprob_rows_waves_kernel<GLB_DT, true, WPS, STORE>), grid, block, 0, s, logits, ld, V, nch, scale,
-                       out, out_ld, out_lse, recs, epoch);
+    hipLaunchKernelGGL((logprob_rows_waves_kernel<GLB_DT, true, WPS, STORE, OUT16>), grid, block, 0, s, logits, ld, V, nch,
+                       scale, out, out_ld, out_lse, recs, epoch, err, spin);
   else
-    hipLaunchKernelGGL((logprob_rows_waves_kernel<GLB_DT, false, WPS, STORE>), grid, block, 0, s, logits, ld, V, nch, scale,
-                       out, out_ld, out_lse, recs, epoch);
+    hipLaunchKernelGGL((logprob_rows_waves_kernel<GLB_DT, false, WPS, STORE, OUT16>), grid, block, 0, s, logits, ld, V, nch,
+                       scale, out, out_ld, out_lse, recs, epoch, err, spin);
 }
 
 // variant: 0 = the product's choice; the diagnostic build passes others (waves per SIMD * 10 + store form)
-hipError_t GLB_CAT(launch_logprob_waves_, GLB_DT)(const void *logits, int64_t ld, int V, int nch, float scale, float *out,
+hipError_t GLB_CAT(launch_logprob_waves_, GLB_DT)(const void *logits, int64_t ld, int V, int nch, float scale, void *out,
                                                    int64_t out_ld, float *out_lse, int n_rows, uint64_t *recs,
-                                                   uint32_t epoch, int variant, hipStream_t s) {
-#define GLB_LSM_ARGS logits, ld, V, nch, scale, out, out_ld, out_lse, n_rows, recs, epoch, s
+                                                   uint32_t epoch, uint32_t *err, uint64_t spin, bool out16, int variant,
+                                                   hipStream_t s) {
+#define GLB_LSM_ARGS logits, ld, V, nch, scale, out, out_ld, out_lse, n_rows, recs, epoch, err, spin, s
   if constexpr (GLB_DT == kDtF32) {
 #ifdef GLB_STAMPS
     if (variant == 50) lsm_waves1<5, 0>(GLB_LSM_ARGS);
@@ -150,6 +147,13 @@ hipError_t GLB_CAT(launch_logprob_waves_, GLB_DT)(const void *logits, int64_t ld
     else
 #endif
     lsm_waves1<4, 0>(GLB_LSM_ARGS);
+  } else if (out16) {
+#ifdef GLB_STAMPS
+    if (variant == 60) lsm_waves1<6, 0, true>(GLB_LSM_ARGS);
+    else if (variant == 40) lsm_waves1<4, 0, true>(GLB_LSM_ARGS);
+    else
+#endif
+    lsm_waves1<5, 0, true>(GLB_LSM_ARGS);
   } else {
 #ifdef GLB_STAMPS
     if (variant == 50) lsm_waves1<5, 0>(GLB_LSM_ARGS);       // 107 / 141 us at 1024 x 50257 / 512 x 128256 bf16

@@ -5,11 +5,13 @@ raises.
 """
 import ctypes as C
 
+import numpy as np
 import torch
 
 from . import _lib
+from ._lib import GLB_EHIP, GlbError
 from ._lib import (F32, BF16, F16, MASK_NONE, MASK_BITS, MASK_F32, MASK_PREPARED, RNG_NONE, RNG_PHILOX, RNG_NOISE,
-                   StepArgs, TrieArgs, MT19937, check)
+                   STEP_ROWS_BY_FIRST_USE, StepArgs, TrieArgs, MT19937, check)
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 
@@ -158,13 +160,16 @@ class HipEngine:
 
     def step(self, logits, vocab=None, row_of=None, mask_kind=MASK_NONE, mask=None, mask_id=None,
              rng_mode=RNG_NONE, noise=None, seed=0, offset=0, particle_base=0, logit_scale=1.0,
-             want_lse=True, variant=0, out=None, row_mask_id=None, out_margin=None, _plan=False, timing_events=None):
+             want_lse=True, out=None, row_mask_id=None, out_margin=None, _plan=False, timing_events=None,
+             rows_by_first_use=False):
         """Fused particle step (glb_logprob_mask_sample).  Returns (logZ, lse, token) device tensors.
 
         logits: [n_rows, ld] (last dim contiguous; rows may be strided), vocab <= ld.
         mask: int32 bit rows / float rows, or a `PreparedMasks` (prepare_masks).  `row_mask_id` gives the mask per
         logits row (the mask is a function of the context): shared rows are then reduced once.
-        `variant` is accepted for source compatibility and ignored (one kernel family serves every shape).
+        rows_by_first_use: `row_of` numbers the rows by first use (row_of[p] <= p: what `group_contexts` returns) -
+        GLB_STEP_ROWS_BY_FIRST_USE, a speed hint.
+        A launch whose waves gave up waiting shows as token -2 / NaN and in `error_word()`: `raise_if_failed`.
         """
         if logits.dim() != 2 or logits.stride(1) != 1:
             raise ValueError("logits must be 2-D with unit inner stride")
@@ -221,6 +226,7 @@ class HipEngine:
             # one row for everybody (batch_sample seeds every sequence alike): pitch 0
             a.noise_ld = noise.stride(0) if noise.shape[0] > 1 else (0 if n > 1 else noise.shape[1])
         a.seed, a.offset, a.particle_base = seed, offset, particle_base
+        a.flags = STEP_ROWS_BY_FIRST_USE if (rows_by_first_use and row_of is not None) else 0
         a.out_logZ = None if logZ is None else logZ.data_ptr()
         a.out_lse = None if lse is None else lse.data_ptr()
         a.out_token = None if tok is None else tok.data_ptr()
@@ -237,6 +243,40 @@ class HipEngine:
         else:
             check(self.lib.glb_logprob_mask_sample(C.byref(a), self._stream()))
         return logZ, lse, tok
+
+    # ---- failed one-launch calls (include/glb.h: glb_workspace_check) ---------------------------------------------
+    def error_word(self):
+        """int32 [1] device view of the scratch buffer's error word: nonzero after a one-launch call whose waves gave
+        up waiting for their records (token -2 / NaN outputs).  Hosts that copy results back let it ride along and hand
+        the value to `raise_if_failed`."""
+        ws = self._step_ws
+        if ws is None:
+            return torch.zeros(1, dtype=torch.int32, device=self.device)
+        return ws[ws.numel() - 64: ws.numel() - 60].view(torch.int32)
+
+    def raise_if_failed(self, err_count=None, tokens=None, lse=None, what="glb_logprob_mask_sample"):
+        """Raise when a one-launch call did not complete: `err_count` (the error word's value, already on the host),
+        host `tokens` holding -2, or host `lse` / logZ values holding NaN.  Clears the error word."""
+        bad = bool(err_count)
+        if tokens is not None and not bad:
+            bad = bool((np.asarray(tokens) == -2).any())
+        if lse is not None and not bad:
+            bad = bool(np.isnan(np.asarray(lse, dtype=np.float32)).any())
+        if bad:
+            if self._step_ws is not None:
+                self.error_word().zero_()
+            raise GlbError(GLB_EHIP, f"{what}: waves of the launch gave up waiting for their row's records (token -2 / "
+                                     "NaN): the call did not complete and its results must not be used")
+
+    def check(self):
+        """Synchronising check of the scratch buffer's error word (glb_workspace_check): raises after a failed call."""
+        if self._step_ws is not None:
+            check(self.lib.glb_workspace_check(_ptr(self._step_ws), self._stream()))
+
+    def set_spin_limit(self, microseconds):
+        """Watchdog of the waits inside the one-launch calls (0: the default, 2 s; None: GLB_SPIN_NONE - a wave gives up
+        at the first poll that finds a record missing, which forces the failure path)."""
+        check(self.lib.glb_set_spin_limit(0xFFFFFFFFFFFFFFFF if microseconds is None else int(microseconds)))
 
     def timing_events(self, n):
         """n (start, stop) pairs of HIP events for `step(timing_events=...)` / `StepPlan.run_timed`: created and
@@ -273,17 +313,21 @@ class HipEngine:
                                         _ptr(blob), need, self._stream()))
         return PreparedMasks(blob, K, vocab, dt)
 
-    def log_softmax_rows(self, logits, vocab=None, logit_scale=1.0, out=None, want_lse=False, workspace=None):
-        """out[r] = logits[r] - logsumexp(logits[r]) (glb_log_softmax_rows); float32 result.  `workspace`: a uint8 device
-        tensor to lend instead of the engine's own scratch (one the library has not initialised takes the forms that
-        do not tag their records)."""
+    def log_softmax_rows(self, logits, vocab=None, logit_scale=1.0, out=None, want_lse=False, workspace=None,
+                         out_dtype=torch.float32):
+        """out[r] = logits[r] - logsumexp(logits[r]) (glb_log_softmax_rows).  `out_dtype`: float32 (default) or the
+        logits' own dtype - what the reference returns (cache.py:96 keeps the model's dtype): the float32 result rounded
+        to nearest even.  `workspace`: a uint8 device tensor to lend instead of the engine's own scratch (one the
+        library has not initialised takes the form that does not tag its records)."""
         if logits.dim() != 2 or logits.stride(1) != 1:
             raise ValueError("logits must be 2-D with unit inner stride")
         n_rows, width = logits.shape
         V = width if vocab is None else vocab
         ld = logits.stride(0) if n_rows > 1 else max(width, logits.stride(0))
         if out is None:
-            out = torch.empty((n_rows, V), dtype=torch.float32, device=self.device)
+            out = torch.empty((n_rows, V), dtype=out_dtype, device=self.device)
+        if out.dtype not in (torch.float32, logits.dtype):
+            raise TypeError(f"log-probabilities leave as float32 or as {logits.dtype}, not {out.dtype}")
         lse = self._f32(n_rows) if want_lse else None
         out_ld = out.stride(0) if n_rows > 1 else max(V, out.stride(0))
         need = self.lib.glb_log_softmax_workspace_bytes(n_rows, V)
@@ -291,7 +335,7 @@ class HipEngine:
         if ws.numel() < need:
             raise ValueError(f"workspace of {ws.numel()} bytes, {need} needed")
         check(self.lib.glb_log_softmax_rows(_ptr(logits), _DT[logits.dtype], n_rows, V, ld, logit_scale, _ptr(out),
-                                            out_ld, _ptr(lse), _ptr(ws), ws.numel(), self._stream()))
+                                            _DT[out.dtype], out_ld, _ptr(lse), _ptr(ws), ws.numel(), self._stream()))
         return (out, lse) if want_lse else out
 
     def mask_to_bits(self, mask):

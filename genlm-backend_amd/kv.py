@@ -198,7 +198,7 @@ class SlabForward:
         self.pkv, self.body = pkv, body
         self.graph_ok = bool(graph) and torch.cuda.is_available()
         self.calls = 0
-        self.graphs = {}  # address of layer 0's key slab -> (graph, ids, pos, hidden)
+        self.graphs = {}  # identity of the slab set -> (graph, ids, pos, hidden, the slab tensors themselves)
 
     def _run(self, ids, pos):
         pkv = self.pkv
@@ -213,7 +213,10 @@ class SlabForward:
         self.calls += 1
         if not self.graph_ok or not ids.is_cuda or self.calls <= 2:  # (allocator growth, library set-up: outside a capture)
             return self._run(ids, pos)
-        key = self.pkv.layers[0].keys.data_ptr()
+        # a graph belongs to the slab tensors it was captured over: every layer's addresses, shape and dtype make the key,
+        # and the entry holds the tensors, so the allocator cannot hand their addresses to another slab set meanwhile
+        slabs = self.pkv._tensors(self.pkv.layers)
+        key = tuple((t.data_ptr(), tuple(t.shape), t.dtype) for t in slabs)
         ent = self.graphs.get(key)
         if ent is None:
             if len(self.graphs) >= 2:  # slab sets keep changing under this forward: not worth capturing
@@ -223,12 +226,20 @@ class SlabForward:
             try:
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):  # (a collective's watchdog thread may be about)
                     hidden = self._run(s_ids, s_pos)
-            except Exception:  # a model whose forward cannot be captured (host-side decisions on device data): eager
+            except RuntimeError as e:
+                # a forward that cannot be captured (a host-side decision on device data, a synchronising call): HIP says
+                # so in a RuntimeError that names the capture - eager from now on.  Anything else (shapes, memory, an
+                # assertion in kv_append) is a real error of the forward and is the caller's to see.
+                msg = str(e).lower()
+                if not any(w in msg for w in ("captur", "graph", "hipstreamsynchronize", "cudastreamsynchronize",
+                                              "operation not permitted")):
+                    raise
                 self.graph_ok = False
+                self.capture_error = e
                 torch.cuda.synchronize()
                 return self._run(ids, pos)
-            ent = self.graphs[key] = (g, s_ids, s_pos, hidden)
-        g, s_ids, s_pos, hidden = ent
+            ent = self.graphs[key] = (g, s_ids, s_pos, hidden, slabs)
+        g, s_ids, s_pos, hidden, _held = ent
         s_ids.copy_(ids)
         s_pos.copy_(pos)
         self.pkv.set_forward_in_place(s_pos)  # (the captured launches read the static buffers)

@@ -389,7 +389,8 @@ class AsyncAmdLM(AsyncLM):
             group_of, rep, ng = eng.group_contexts(tok_d, st_d, ln_d)
             logits, row_of_group, _, U, _ = self._auto_kv.logits(tok_d, st_d, ln_d, group_of, rep, ng)
             lp = eng.log_softmax_rows(logits)
-            rows = row_of_group[group_of.long()].cpu().tolist()
+            rows = torch.cat([row_of_group[group_of.long()], eng.error_word()]).cpu().tolist()
+            eng.raise_if_failed(rows.pop(), what="glb_log_softmax_rows")  # no NaN row may reach the trie
             self._batch_counter += 1
             self.stats["batches"] += 1
             self.stats["queries"] += n
@@ -521,6 +522,9 @@ class AsyncAmdLM(AsyncLM):
             logZ, _lse, tok = eng.step(logits, vocab=V, row_of=row_of, rng_mode=self._rng_mode, seed=self._rng_seed,
                                        offset=self._batch_counter, want_lse=False, **kw)
             step_out = (logZ.cpu().tolist(), tok.cpu().tolist())
+            eng.raise_if_failed(tokens=step_out[1])
+        if lp_slab is not None:  # no NaN row may reach the trie: the error word of the log-softmax launch (one small copy)
+            eng.raise_if_failed(int(eng.error_word().item()), what="glb_log_softmax_rows")
         self._batch_counter += 1
         self.stats["batches"] += 1
         self.stats["queries"] += n
@@ -650,7 +654,7 @@ class AsyncAmdLM(AsyncLM):
             raise ValueError("Token ids must not be empty")
         ids = torch.tensor([token_ids], device=self.device)
         h = self._body(input_ids=ids, use_cache=False).last_hidden_state[0, -1:]
-        return self.engine.log_softmax_rows(self._lm_head(h))[0]
+        return self.engine.log_softmax_rows(self._lm_head(h))[0]  # (a single row: the three-launch form, no waits inside)
 
     # ---- fused particle step (README.md:82-91 moved behind the queue) ------------------------------------
     async def next_token_step(self, token_ids, mask_id=0):
@@ -794,8 +798,7 @@ class AsyncAmdLM(AsyncLM):
         self.stats["rows"] += U
         out = torch.stack([logZ, tok.to(torch.float32)]).cpu().numpy()  # token ids < 2^24: exact in float32
         toks = out[1].astype(np.int32)
-        if (toks == -2).any():  # a finishing wave of the one-launch step gave up waiting for its records (include/glb.h)
-            raise RuntimeError("glb_logprob_mask_sample: records of the fused launch did not complete (token -2)")
+        eng.raise_if_failed(tokens=toks)  # a finishing wave of the one-launch step gave up waiting (include/glb.h)
         return out[0], toks
 
     async def batch_next_token_step(self, contexts, mask_ids=None):

@@ -217,6 +217,8 @@ class DeviceSIS:
                              lengths=torch.from_numpy(lens).to(dev), ptrs=ptrs, p_max=int(lens.max()))
 
     def reset(self):
+        if self.host_rng is not None:  # a run starts its seeded noise stream over
+            self.host_rng = type(self.host_rng)(self.seed)
         self.contexts = self._ctx0.clone()
         self.prompt_len = self._prompt_len0.clone()
         self.lengths = self.prompt_len.clone()
@@ -231,6 +233,8 @@ class DeviceSIS:
         # (the slabs stay - and the hipGraphs captured over them; shared rows start from an empty block table, private rows
         # are refilled by step 0's encoding)
         self._head_cache = None
+        self._noise_groups = None  # parity draws: the dedup grouping the noise rows are dealt by (set per step)
+        self._by_first_use = False  # the step's row_of numbers the logits rows by first use (glb_group_contexts' ids)
         self._kv_stale = None  # bool [N]: rows whose KV has to be rebuilt from the context (ancestor on another rank)
         self._row_of_h = np.full(self.N, -1, np.int32)  # shared KV: particle -> slab row (-1: none), host mirror
         # active particles over all ranks as of the last exchange (device scalar; read with the step's one D2H copy)
@@ -278,7 +282,8 @@ class DeviceSIS:
         """Steps t >= 1 with per-particle KV: one new token per particle (logits row i = particle i), ragged lengths."""
         eng, llm, dev, N = self.eng, self.llm, self.dev, self.N
         if self.t % self.sync_every == 0 or self._head_cache is None:
-            head = torch.stack([self.active.sum().to(torch.int32), self._global_active]).cpu()  # the step's one D2H copy
+            head = torch.stack([self.active.sum().to(torch.int32), self._global_active, eng.error_word()[0]]).cpu()  # the step's one D2H copy
+            eng.raise_if_failed(int(head[2]))  # (the word of every call since the last copy rides along)
             self._head_cache = (int(head[0]), int(head[1]))
         n_active, n_global = self._head_cache
         if self._kv_stale is not None:
@@ -293,7 +298,7 @@ class DeviceSIS:
 
             self._slab_fwd = SlabForward(self.pkv, llm._body, graph=self.kv_graph)
         logits = llm._lm_head(self._slab_fwd(ids, pos))  # [N, V]
-        self._noise_groups = None
+        self._noise_groups, self._by_first_use = None, False
         if self.rng_mode == RNG_NOISE:  # parity draws follow the reference's resolution order: by dedup group
             lengths_eff = torch.where(self.active > 0, self.lengths, torch.ones_like(self.lengths))
             self._noise_groups, _, _ = eng.group_contexts(self.contexts.view(-1), self.starts, lengths_eff)
@@ -313,10 +318,11 @@ class DeviceSIS:
         hashes_eff = torch.where(self.active > 0, self.hashes, self._hash_stub)
         group_of, rep, ng = eng.group_contexts(ctx_flat, self.starts, lengths_eff, hashes=hashes_eff)
         len_rep = lengths_eff[rep.long().clamp(0, N - 1)]  # (entries of `rep` past the group count are unspecified)
-        head = torch.cat([torch.stack([ng[0], self.active.sum().to(torch.int32), self._global_active]), group_of, rep,
-                          len_rep]).cpu().numpy()  # the step's one D2H copy
+        head = torch.cat([torch.stack([ng[0], self.active.sum().to(torch.int32), self._global_active, eng.error_word()[0]]),
+                          group_of, rep, len_rep]).cpu().numpy()  # the step's one D2H copy
         U, n_active, n_global = int(head[0]), int(head[1]), int(head[2])
-        g_h, rep_h, L = head[3:3 + N], head[3 + N:3 + N + U], head[3 + 2 * N:3 + 2 * N + U]
+        eng.raise_if_failed(int(head[3]))
+        g_h, rep_h, L = head[4:4 + N], head[4 + N:4 + N + U], head[4 + 2 * N:4 + 2 * N + U]
         # ---- block table (host): who keeps its row, who gets a copy, who is encoded
         old = self._row_of_h[rep_h]
         has = old >= 0
@@ -403,6 +409,7 @@ class DeviceSIS:
         logits = logits_parts[0] if len(logits_parts) == 1 else torch.cat(logits_parts)
         self._rep = to_dev(rep_h[order])
         self._noise_groups = group_of  # parity draws follow the reference's resolution order: by dedup group
+        self._by_first_use = False  # (rows are in block-table order: kept rows first)
         return self._finish_step(logits, to_dev(inv[g_h]), U, n_active, n_global, time_kernel, l_max=1)
 
     def _finish_step(self, logits, group_of, U, n_active, n_global, time_kernel, l_max):
@@ -422,6 +429,8 @@ class DeviceSIS:
                 kw["mask_id"] = mask_id
         if self.rng_mode == RNG_NOISE:
             kw["noise"] = self._parity_noise(self._noise_groups if self._noise_groups is not None else group_of, V)
+        if group_of is not None and self._by_first_use:
+            kw["rows_by_first_use"] = True
         if time_kernel:
             # two clocks on the fused call: HIP events the launch itself carries as its start / stop stamps (the launch
             # duration, as rocprofv3 reports it), and a pair recorded around the call on the stream (adds the two marker
@@ -474,18 +483,21 @@ class DeviceSIS:
         # finished particles still occupy a row: give them their 1-token stub so they dedup to one group
         lengths_eff = torch.where(self.active > 0, self.lengths, torch.ones_like(self.lengths))
         if self.particle_kv:  # step 0: encode the distinct prompts, keep their KV, fan it out to the particles
-            head = torch.stack([self.active.sum().to(torch.int32), self._global_active]).cpu()
+            head = torch.stack([self.active.sum().to(torch.int32), self._global_active, eng.error_word()[0]]).cpu()
             n_active, n_global = int(head[0]), int(head[1])
+            eng.raise_if_failed(int(head[2]))
             out, group_of, rep, U = self._encode_into_slabs(None)
             self._rep = rep
+            self._noise_groups, self._by_first_use = None, True
             last = (self.lengths[rep[:U].long()] - 1).long()
             h_last = out.last_hidden_state[torch.arange(U, device=dev), last]
             return self._finish_step(llm._lm_head(h_last), group_of, U, n_active, n_global, time_kernel, self.max_len_now)
         hashes_eff = torch.where(self.active > 0, self.hashes, self._hash_stub)
         group_of, rep, ng = eng.group_contexts(ctx_flat, self.starts, lengths_eff, hashes=hashes_eff)
         self._rep = rep
-        head = torch.stack([ng[0], self.active.sum().to(torch.int32), self._global_active]).cpu()  # the step's one D2H copy
+        head = torch.stack([ng[0], self.active.sum().to(torch.int32), self._global_active, eng.error_word()[0]]).cpu()  # the step's one D2H copy
         U, n_active, n_global = int(head[0]), int(head[1]), int(head[2])
+        eng.raise_if_failed(int(head[3]))  # a fused call of an earlier step that did not complete
         base, p_max, cache = None, 0, None
         # at t == 0 every context *is* its prompt, so no cached prefix is a proper prefix yet (hf.py:334-342)
         use_kv = self.prefixes is not None and self.t > 0
@@ -509,7 +521,7 @@ class DeviceSIS:
                         use_cache=cache is not None)
         h_last = out.last_hidden_state[torch.arange(U, device=dev), last.long()]
         logits = llm._lm_head(h_last)  # [U, V]
-        self._noise_groups = None
+        self._noise_groups, self._by_first_use = None, True
         return self._finish_step(logits, group_of, U, n_active, n_global, time_kernel, l_max)
 
     def _parity_noise(self, group_of, V):
@@ -597,6 +609,7 @@ class DeviceSIS:
         return steps
 
     def results(self):
+        self.eng.check()  # the last steps' fused calls completed (glb_workspace_check; synchronises like the copies below)
         ctx = self.contexts.cpu().numpy()
         ln = self.lengths.cpu().numpy()
         pl = self.prompt_len.cpu().numpy()
@@ -638,14 +651,14 @@ class DeviceSampler(DeviceSIS):
             kw["noise"] = self.noise_rng.exponential(V).view(1, V).to(dev, non_blocking=True)
         _, _, tok = eng.step(logits, vocab=V, row_of=group_of, rng_mode=mode, seed=self.seed, offset=self.t,
                              logit_scale=1.0 / self.temperature, want_lse=False, **kw)
-        act = self.active > 0
+        act = (self.active > 0) & (tok != -2)  # token -2: a failed launch, never a result (raised at the next copy / results())
         stop = act & (torch.isin(tok, self.eos) | (tok < 0) | (self.lengths - self.prompt_len >= self.max_tokens))
         keep = act & ~stop
         rows = torch.arange(N, device=dev)
         at = self.lengths.long().clamp_max(self.cap - 1)
         self.contexts[rows, at] = torch.where(keep, tok, self.contexts[rows, at])
         self.lengths = self.lengths + keep.to(torch.int32)
-        self.active = (keep & (self.lengths - self.prompt_len < self.max_tokens)).to(torch.int32)
+        self.active = torch.where(tok == -2, self.active, (keep & (self.lengths - self.prompt_len < self.max_tokens)).to(torch.int32))
         self.t += 1
         self.max_len_now = min(self.max_len_now + 1, self.cap)
         self._exchange()

@@ -288,11 +288,28 @@ class AsyncTokenByteTrie:
         """async_impl.py:69-81"""
         return await self._request(ws, 1)
 
+    def _fail_waiters(self, batch, exc):
+        """nobody may be left waiting: the requests of `batch` and everything still queued get `exc`"""
+        stranded, self._pending = list(batch) + self._pending, []
+        for _, f, _ in stranded:
+            if not f.done():
+                f.set_exception(exc)
+
     async def _drain(self):
+        import asyncio
+
+        batch = []
+        try:
+            await self._drain_loop(batch)
+        except asyncio.CancelledError:  # cleanup() / shutdown(): the requests in flight and in the queue end with it
+            self._fail_waiters(batch, asyncio.CancelledError("AsyncTokenByteTrie was shut down"))
+            raise
+
+    async def _drain_loop(self, batch):
         while True:
             await self._wake.wait()
             self._wake.clear()
-            batch, self._pending = self._pending, []
+            batch[:], self._pending = self._pending, []
             try:
                 for op in (0, 1):
                     group = [(w, f) for w, f, o in batch if o == op]
@@ -307,6 +324,7 @@ class AsyncTokenByteTrie:
                 for _, f, _ in batch:
                     if not f.done():
                         f.set_exception(e)
+            batch.clear()
 
     async def cleanup(self):
         """async_impl.py:136-145"""
@@ -328,6 +346,12 @@ class AsyncTokenByteTrie:
             except RuntimeError:  # the loop is gone
                 pass
             self._task = None
+        import asyncio
+
+        try:  # (a cancelled task that never runs again cannot tell its waiters: do it here)
+            self._fail_waiters([], asyncio.CancelledError("AsyncTokenByteTrie was shut down"))
+        except RuntimeError:  # the waiters' loop is gone, and they with it
+            self._pending = []
 
     def __del__(self):
         self.shutdown()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GLB_ABI_VERSION 4
+#define GLB_ABI_VERSION 5
 
 /* status codes */
 enum {
@@ -84,6 +84,16 @@ int glb_device_count(void);
  * a row shared by several particles is then reduced once and only the draw is done per particle (any number of
  * particles per row: the reduction leaves what every draw needs, whoever makes it).
  */
+/* glb_step_args.flags */
+enum {
+  /* row_of numbers the logits rows by first use: row_of[p] <= p for every particle p (what glb_group_contexts'
+     out_group_of is).  With row_mask_id / no mask - rows reduced once - the one-launch step then deals every particle's
+     finishing wave a fixed distance behind its row's reducing waves inside the grid instead of at its end, so most
+     draws are made while the rows are still streaming.  A speed hint: results do not depend on it, and a row_of that
+     breaks the promise only makes finishing waves wait longer (bounded as ever). */
+  GLB_STEP_ROWS_BY_FIRST_USE = 1
+};
+
 typedef struct glb_step_args {
   uint32_t struct_size; /* sizeof(glb_step_args) — ABI guard */
   /* logits of the unique contexts */
@@ -120,7 +130,7 @@ typedef struct glb_step_args {
                         finishing wave gave up waiting for its row's records - a failed launch, never a result) */
   float *out_margin; /* [n_particles] GLB_RNG_NOISE only: (winner - runner-up) / winner of the race e_j / E_j, i.e. how
                         far the draw is from a tie that float rounding could flip (1 if there is no runner-up) */
-  int32_t reserved;  /* must be 0 */
+  int32_t flags;     /* GLB_STEP_* bits, 0 by default (unknown bits: GLB_EINVAL) */
   /* device scratch of >= glb_step_workspace_bytes(...) bytes, 32-byte aligned: the per-chunk records (64 bytes per
      row and 4096-token chunk) the reducing waves hand to the per-particle waves (and, for GLB_MASK_BITS, the prepared
      masks).  See glb_workspace_init. */
@@ -149,6 +159,23 @@ int glb_logprob_mask_sample_timed(const glb_step_args *args, void *hip_stream, v
  */
 int glb_workspace_init(void *workspace, size_t workspace_bytes, void *hip_stream);
 int glb_workspace_release(void *workspace);
+/*
+ * The one-launch forms (fused step, log-softmax rows) have waves that wait, inside the launch, for records other waves
+ * of the same launch write.  HIP promises no dispatch order, so every such wait is bounded by a watchdog (2 s by
+ * default; glb_set_spin_limit, 0 = default): a wave that gives up writes token -2 and NaN logZ / lse (NaN rows for
+ * glb_log_softmax_rows) and adds 1 to the error word in the last 64 bytes of the registered workspace - which is why a
+ * registered workspace serves the calls of ONE stream at a time, and why its size should come from the *_workspace_bytes
+ * functions (they leave that room).  The calls themselves return GLB_OK: they do not synchronise.
+ *   glb_workspace_check       synchronises `hip_stream`, returns GLB_EHIP (and clears the word) if any wave gave up since
+ *                             the last check - the results of those calls must not be used -, GLB_OK otherwise
+ *   glb_workspace_error_word  the word's device address, for hosts that already copy results back and want it to ride
+ *                             along (null for a workspace that is not registered); nonzero = failed, as above
+ * The reference's counterpart of "nobody is left with a silent wrong answer" is vllm.py:396-400.
+ */
+int glb_workspace_check(void *workspace, void *hip_stream);
+const uint32_t *glb_workspace_error_word(void *workspace);
+#define GLB_SPIN_NONE UINT64_MAX /* give up at the first poll that finds a record missing: forces the failure path (tests) */
+int glb_set_spin_limit(uint64_t microseconds);
 
 /*
  * Bring GLB_MASK_BITS rows into the layout the kernels read ([mask][chunk][vector][component] 64-bit lane
@@ -166,12 +193,14 @@ int glb_mask_prepare(const uint32_t *mask_bits, int64_t n_masks, int64_t vocab, 
  * next_token_logprobs_uncached (hf.py:422).  out_lse is optional.  workspace: device scratch of at least
  * glb_log_softmax_workspace_bytes(n_rows, vocab) bytes, 32-byte aligned.  On a workspace glb_workspace_init has seen
  * (and outside stream capture, rows of at most 262144 elements) the call is one launch that reads every logit once
- * and keeps it on the chip until its log-probability is written; otherwise a workgroup per row that reads its row twice
- * (128 rows and more) or three launches.  Same bits either way.
+ * and keeps it on the chip until its log-probability is written; otherwise three launches.  Same bits either way.
+ * out_dtype: GLB_F32, or the logits' own dtype - the reference returns log-probabilities in the model's dtype
+ * (cache.py:96 keeps it): the float32 result rounded to nearest even, out_ld in elements of that type; for 16-bit
+ * models that is a third fewer bytes per call (512 x 128256 bf16: 263 MB instead of 394 MB).
  */
 size_t glb_log_softmax_workspace_bytes(int64_t n_rows, int64_t vocab);
 int glb_log_softmax_rows(const void *logits, int32_t dtype, int64_t n_rows, int64_t vocab,
-                         int64_t ld, float logit_scale, float *out_logprobs, int64_t out_ld,
+                         int64_t ld, float logit_scale, void *out_logprobs, int32_t out_dtype, int64_t out_ld,
                          float *out_lse, void *workspace, size_t workspace_bytes, void *hip_stream);
 
 /*

@@ -772,6 +772,7 @@ int orc_particles_advance(int32_t *ctx, int64_t ctx_ld, int32_t *len, int32_t *a
                           int32_t eos, int32_t max_len) {
   for (int64_t i = 0; i < n; ++i) {
     if (!active[i]) continue;
+    if (tok[i] == -2) continue; /* a failed launch (include/glb.h: out_token), never a result: left as it was */
     lw[i] += logZ[i];
     if (tok[i] == eos || tok[i] < 0) {
       active[i] = 0;

@@ -107,6 +107,21 @@ def log_softmax_rows(logits, logit_scale=1.0):
     return out, lse
 
 
+def round_rows_16(rows32, dtype):
+    """Layer B of glb_log_softmax_rows' out_dtype: the float32 log-probabilities rounded to nearest even into the
+    logits' own 16-bit type - what the reference's `torch.log_softmax` on a 16-bit tensor returns up to the last bit
+    of its own float32 intermediate (cache.py:96 keeps the dtype).  dtype "bf16" -> uint16 words, "f16" -> float16."""
+    rows32 = np.ascontiguousarray(rows32, dtype=np.float32)
+    if dtype == "f16":
+        return rows32.astype(np.float16)  # IEEE round to nearest even
+    u = rows32.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+    nan = np.isnan(rows32)
+    if nan.any():  # (the integer recipe can turn a NaN into an infinity: keep it a NaN, as the hardware conversion does)
+        r[nan] = ((u[nan] >> 16) | 0x0040).astype(np.uint16)
+    return r
+
+
 def mask_f32_to_bits(mask):
     mask = np.ascontiguousarray(mask, dtype=np.float32)
     k, V = mask.shape

@@ -31,8 +31,10 @@ class CpuOracleEngine:
         return _Prepared(bits)
 
     def step(self, logits, vocab=None, row_of=None, mask_kind=0, mask=None, mask_id=None, rng_mode=0, noise=None,
-             seed=0, offset=0, particle_base=0, logit_scale=1.0, want_lse=True, variant=0, out=None, row_mask_id=None,
-             out_margin=None):
+             seed=0, offset=0, particle_base=0, logit_scale=1.0, want_lse=True, out=None, row_mask_id=None,
+             out_margin=None, rows_by_first_use=False):
+        if rows_by_first_use and row_of is not None:  # the promise GLB_STEP_ROWS_BY_FIRST_USE makes
+            assert bool((row_of.cpu() <= torch.arange(row_of.numel())).all())
         V = logits.shape[1] if vocab is None else vocab
         x = _logits_np(logits[:, :V])
         if isinstance(mask, _Prepared):
@@ -58,10 +60,19 @@ class CpuOracleEngine:
             return out
         return res
 
-    def log_softmax_rows(self, logits, vocab=None, logit_scale=1.0, out=None, want_lse=False):
+    def error_word(self):
+        return torch.zeros(1, dtype=torch.int32)
+
+    def raise_if_failed(self, err_count=None, tokens=None, lse=None, what=""):
+        assert not err_count and (tokens is None or not (np.asarray(tokens) == -2).any())
+
+    def check(self):
+        pass
+
+    def log_softmax_rows(self, logits, vocab=None, logit_scale=1.0, out=None, want_lse=False, out_dtype=torch.float32):
         V = logits.shape[1] if vocab is None else vocab
         lp, lse = O.log_softmax_rows(_logits_np(logits[:, :V]), logit_scale)
-        lp = torch.from_numpy(lp)
+        lp = torch.from_numpy(lp).to(out_dtype)  # (torch rounds float32 -> bf16 / f16 to nearest even)
         if out is not None:
             out.copy_(lp)
             lp = out

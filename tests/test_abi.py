@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     raw = C.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert lib.glb_abi_version() == 4
+    assert lib.glb_abi_version() == 5
     assert b"gfx950" in lib.glb_version()
     assert C.sizeof(_lib.StepArgs) == 224  # layout guard of glb_step_args
 
@@ -37,7 +37,10 @@ def test_argument_errors_do_not_touch_the_gpu():
     assert "struct_size" in _lib.last_error()
     a.struct_size = C.sizeof(_lib.StepArgs)
     assert lib.glb_logprob_mask_sample(C.byref(a), None) == _lib.GLB_EINVAL
-    assert lib.glb_log_softmax_rows(None, 0, 1, 1, 1, 1.0, None, 0, None, None, 0, None) == _lib.GLB_EINVAL
+    assert lib.glb_log_softmax_rows(None, 0, 1, 1, 1, 1.0, None, 0, 0, None, None, 0, None) == _lib.GLB_EINVAL
+    assert lib.glb_workspace_check(None, None) == _lib.GLB_EINVAL
+    assert lib.glb_workspace_error_word(None) is None  # not registered
+    assert lib.glb_set_spin_limit(0) == _lib.GLB_OK
     assert lib.glb_mask_prepare(None, 1, 64, 2, 0, None, 0, None) == _lib.GLB_EINVAL
     assert lib.glb_step_workspace_bytes(1024, 1024, 50257, 2) >= 1024 * 13 * 32
     assert lib.glb_mask_prepared_bytes(2, 50257) >= 2 * 13 * 512

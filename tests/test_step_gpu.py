@@ -471,3 +471,153 @@ def test_step_plan_equals_step(engine):
         torch.cuda.synchronize()
         for a, b in zip(want, got):
             assert torch.equal(a, b)
+
+
+def _first_use_rows(n, distinct, seed):
+    """row ids numbered by first use (what glb_group_contexts' out_group_of looks like): row_of[p] <= p"""
+    rng = np.random.default_rng(seed)
+    raw = rng.integers(0, distinct, n)
+    seen, out = {}, np.empty(n, np.int32)
+    for i, g in enumerate(raw):
+        out[i] = seen.setdefault(int(g), len(seen))
+    return out, len(seen)
+
+
+@pytest.mark.parametrize("N,distinct,V,dtype", [(1024, 4000, 50257, "f32"), (512, 3000, 128256, "bf16"), (700, 300, 50257, "f32"),
+                                                (300, 64, 4099, "f16")])
+def test_finishing_blocks_inside_the_grid_bit_exact(engine, oracle, N, distinct, V, dtype):
+    """GLB_STEP_ROWS_BY_FIRST_USE (and identity row_of): the one-launch step deals the finishing blocks inside the grid,
+    one chip's worth of wave slots behind their rows.  A speed hint only: same bits as the oracle with and without it,
+    masks handed over per row, shared rows reduced once."""
+    O = oracle
+    row_of, U = _first_use_rows(N, distinct, seed=N + V)
+    assert (row_of <= np.arange(N)).all()
+    x_np, x_t = _mk(O, U, V, dtype, seed=V + U)
+    dev = engine.device
+    masks = synth.binary_masks(V + 2, 2, V)
+    bits, _ = O.mask_f32_to_bits(masks)
+    mid_row = (np.arange(U) % 2).astype(np.int32)
+    want = O.step(x_np, row_of=row_of, mask_kind=O.MASK_BITS, mask=bits, mask_id=mid_row[row_of], rng_mode=O.RNG_PHILOX,
+                  seed=9, offset=4, particle_base=5)
+    tdt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[dtype]
+    prep = engine.prepare_masks(_bits_dev(bits, dev), V, tdt)
+    for flag in (True, False):
+        got = engine.step(x_t.to(dev), row_of=torch.from_numpy(row_of).to(dev), mask=prep,
+                          row_mask_id=torch.from_numpy(mid_row).to(dev), rng_mode=1, seed=9, offset=4, particle_base=5,
+                          rows_by_first_use=flag)
+        torch.cuda.synchronize()
+        for w, g in zip(want, got):
+            assert np.array_equal(_np(g).view(np.uint32), w.view(np.uint32)), flag
+    # a row_of that breaks the promise only waits longer: same bits
+    rev = (U - 1 - row_of).astype(np.int32)
+    want_r = O.step(x_np, row_of=rev, mask_kind=O.MASK_BITS, mask=bits, mask_id=mid_row[rev], rng_mode=O.RNG_PHILOX, seed=9,
+                    offset=4)
+    got_r = engine.step(x_t.to(dev), row_of=torch.from_numpy(rev).to(dev), mask=prep, row_mask_id=torch.from_numpy(mid_row).to(dev),
+                        rng_mode=1, seed=9, offset=4, rows_by_first_use=True)
+    torch.cuda.synchronize()
+    for w, g in zip(want_r, got_r):
+        assert np.array_equal(_np(g).view(np.uint32), w.view(np.uint32))
+    engine.check()
+
+
+@pytest.mark.parametrize("B,V,dtype,scale", [(160, 50257, "bf16", 1.0), (130, 128256, "bf16", 0.7), (128, 4099, "f16", 1.0),
+                                             (9, 270001, "bf16", 1.0), (512, 128256, "bf16", 1.0), (3, 50257, "f16", 1.3)])
+def test_log_softmax_rows_in_the_logits_dtype(engine, oracle, B, V, dtype, scale):
+    """cache.py:96 keeps the model's dtype: `out_dtype` = the logits' type gives the float32 log-probabilities rounded to
+    nearest even (bit for bit the oracle's float32 rows cast by torch), within one 16-bit ulp of torch.log_softmax on the
+    16-bit tensor itself; every form (one launch of independent waves, three launches) the same bits."""
+    O = oracle
+    x_np, x_t = _mk(O, B, V, dtype, seed=V + B)
+    dev = engine.device
+    ld = V + 5
+    buf = torch.zeros((B, ld), dtype=x_t.dtype)
+    buf[:, :V] = x_t
+    want32, lse_o = O.log_softmax_rows(x_np, scale)
+    want = torch.from_numpy(want32).to(x_t.dtype)
+    got, lse = engine.log_softmax_rows(buf.to(dev)[:, :V], vocab=V, logit_scale=scale, want_lse=True, out_dtype=x_t.dtype)
+    torch.cuda.synchronize()
+    assert got.dtype == x_t.dtype
+    assert np.array_equal(_np(lse).view(np.uint32), lse_o.view(np.uint32))
+    assert torch.equal(got.cpu().view(torch.int16), want.view(torch.int16))
+    want_o = O.round_rows_16(want32, dtype)  # the oracle's own statement of the rounding
+    assert np.array_equal(got.cpu().view(torch.int16).numpy().view(np.uint16), want_o.view(np.uint16))
+    out = torch.zeros((B, ld), dtype=x_t.dtype, device=dev)  # a padded output: pitch in elements of the output type
+    engine.log_softmax_rows(buf.to(dev)[:, :V], vocab=V, logit_scale=scale, out=out[:, :V])
+    assert torch.equal(out[:, :V], got) and not bool(out[:, V:].any())
+    ws = torch.empty(engine.lib.glb_log_softmax_workspace_bytes(B, V) + 64, dtype=torch.uint8, device=dev)
+    ws = ws[(-ws.data_ptr()) % 32:]
+    got2 = engine.log_softmax_rows(buf.to(dev)[:, :V], vocab=V, logit_scale=scale, workspace=ws, out_dtype=x_t.dtype)
+    assert torch.equal(got2, got)
+    if scale == 1.0 and B <= 160:
+        ref = torch.log_softmax(x_t[:, :V], -1)  # the reference's op on the 16-bit tensor (CPU)
+        a, b = got.cpu().float(), ref.float()
+        ulp = (2.0 ** -7 if dtype == "bf16" else 2.0 ** -10) * b.abs().clamp_min(1.0) * 2
+        assert bool(((a - b).abs() <= ulp).all())
+    with pytest.raises(TypeError):
+        engine.log_softmax_rows(buf.to(dev)[:, :V], vocab=V, out_dtype=torch.float16 if dtype == "bf16" else torch.bfloat16)
+
+
+def test_failed_one_launch_calls_are_reported(engine, oracle):
+    """A wave that gives up waiting for its row's records (GLB_SPIN_NONE forces it) writes token -2 / NaN and counts in
+    the workspace's error word: glb_workspace_check returns GLB_EHIP, `raise_if_failed` raises, and the next healthy
+    call is bit-exact again."""
+    from genlm_backend_amd._lib import GlbError
+
+    O = oracle
+    B, V = 1024, 50257
+    x_np, x_t = _mk(O, B, V, "f32", seed=5)
+    dev = engine.device
+    x_d = x_t.to(dev)
+    want = O.step(x_np, rng_mode=O.RNG_PHILOX, seed=3, offset=1)
+    engine.check()
+    try:
+        engine.set_spin_limit(None)
+        logZ, lse, tok = engine.step(x_d, rng_mode=1, seed=3, offset=1)
+        t = _np(tok)
+        assert (t == -2).any(), "no finishing wave had to wait: the failure path was not exercised"
+        bad = t == -2
+        assert np.isnan(_np(logZ)[bad]).all() and np.isnan(_np(lse)[bad]).all()
+        # waves that did not have to wait still deliver the oracle's bits
+        assert np.array_equal(t[~bad], want[2][~bad])
+        assert int(engine.error_word().item()) == int(bad.sum())
+        with pytest.raises(GlbError, match="gave up waiting"):
+            engine.check()
+        assert int(engine.error_word().item()) == 0  # cleared by the check
+        engine.step(x_d, rng_mode=1, seed=3, offset=1)
+        with pytest.raises(GlbError):
+            engine.raise_if_failed(int(engine.error_word().item()))
+        with pytest.raises(GlbError):
+            engine.raise_if_failed(tokens=t)
+        # log-softmax rows: NaN rows + the error word
+        lp = engine.log_softmax_rows(x_d)
+        torch.cuda.synchronize()
+        if int(engine.error_word().item()):
+            assert bool(torch.isnan(lp).any())
+            with pytest.raises(GlbError):
+                engine.check()
+    finally:
+        engine.set_spin_limit(0)
+    engine.check()
+    got = engine.step(x_d, rng_mode=1, seed=3, offset=1)
+    torch.cuda.synchronize()
+    for w, g in zip(want, got):
+        assert np.array_equal(_np(g).view(np.uint32), w.view(np.uint32))
+    engine.check()
+
+
+def test_particles_advance_leaves_failed_particles_untouched(engine, oracle):
+    dev = engine.device
+    n, cap = 6, 8
+    ctx = torch.zeros((n, cap), dtype=torch.int32, device=dev)
+    ln = torch.full((n,), 2, dtype=torch.int32, device=dev)
+    act = torch.ones(n, dtype=torch.int32, device=dev)
+    lw = torch.zeros(n, device=dev)
+    logZ = torch.tensor([1.0, float("nan"), 2.0, 3.0, float("nan"), 4.0], device=dev)
+    tok = torch.tensor([5, -2, -1, 7, -2, 9], dtype=torch.int32, device=dev)
+    engine.particles_advance(ctx, ln, act, lw, logZ, tok, 7, cap)
+    torch.cuda.synchronize()
+    assert act.tolist() == [1, 1, 0, 0, 1, 1] and ln.tolist() == [3, 2, 2, 2, 2, 3]
+    assert lw.tolist() == [1.0, 0.0, 2.0, 3.0, 0.0, 4.0]
+    c2, l2, a2, w2 = (np.zeros((n, cap), np.int32), np.full(n, 2, np.int32), np.ones(n, np.int32), np.zeros(n, np.float32))
+    oracle.particles_advance(c2, l2, a2, w2, _np(logZ), _np(tok), 7, cap)
+    assert np.array_equal(c2, _np(ctx)) and np.array_equal(l2, _np(ln)) and np.array_equal(a2, _np(act))
