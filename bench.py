@@ -22,7 +22,10 @@ A step is one pass of the hot path over one batch of synthetic input that is alr
   kernel-llama  (config 5) only the fused step on [512, 128256] bf16 logits, 4 rotating buffers.
   api           the README loop through the backend's API, the population submitted as one batched call per step
                 (`AsyncAmdLM.batch_next_token_step`: contexts as Python lists in, logZ / tokens out).
-  api-coro      the README loop verbatim: 1024 coroutines awaiting `AsyncAmdLM.next_token_step` (autobatched).
+  api-coro      the README loop with lines 82-87 as one fused call: 1024 coroutines awaiting `AsyncAmdLM.next_token_step`.
+  api-readme    the README loop VERBATIM, only `llm` swapped (README.md:72-98): 1024 coroutines await
+                `next_token_logprobs`, then add their mask, take logsumexp and draw with torch.multinomial themselves
+                (user-side torch ops on the returned device rows) - what a user who changes nothing else gets.
   api-logprobs  `batch_next_token_logprobs` of 1024 contexts per step, log-prob rows materialised ([1024, V] fp32).
   plumbing      CPU / gloo self-test of the multi-rank launch, barrier, all-gather and JSON relay (tests only; no
                 kernel is run and the line says so).
@@ -49,7 +52,7 @@ sys.path.insert(0, ROOT)
 V_GPT2, V_LLAMA = 50257, 128256
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 METRIC = "particles/sec + logprob-kernel HBM GB/s (% of 8 TB/s), 1024 particles gpt2"
-WORKLOADS = ["sis", "sis-llama", "kernel", "kernel-llama", "api", "api-coro", "api-logprobs", "plumbing"]
+WORKLOADS = ["sis", "sis-llama", "kernel", "kernel-llama", "api", "api-coro", "api-readme", "api-logprobs", "plumbing"]
 
 
 def algorithmic_bytes(B, V, elem_size, n_masks, mask_words, n_particles=None):
@@ -87,7 +90,7 @@ def cpu_baseline(workload, sample_rows, seed=1234):
 
     O.build()
     ncpu = os.cpu_count()
-    if workload in ("sis", "api", "api-coro", "api-logprobs"):
+    if workload in ("sis", "api", "api-coro", "api-readme", "api-logprobs"):
         from transformers import GPT2Config, GPT2LMHeadModel
 
         masks = synth.binary_masks(seed, 2, V_GPT2)
@@ -218,9 +221,14 @@ def main():
                          "one token per context per step instead of a re-encoding)")
     ap.add_argument("--kv-gather", action="store_true",
                     help="--particle-kv: always gather the live KV rows into batch order (never run the forward on the slab in place)")
+    ap.add_argument("--per-row-masks", action="store_true",
+                    help="kernel workloads: one bit mask PER PARTICLE (GLB_MASK_BITS, n_masks == n_particles: what a grammar gives), "
+                         "handed over raw every call - the call brings them into the kernels' layout itself; sis workloads: "
+                         "one mask per particle, every particle its own reduction unit")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="--gpus N on a box with ONE GPU: every rank computes on cuda:0 and the exchange goes over gloo through "
                          "host memory (RCCL wants a GPU per rank) - a rehearsal of the multi-rank code, not a measurement")
+    ap.add_argument("--no-kv-line", action="store_true", help="default sis workload: do not also time the shared-KV-rows variant (value_kv)")
     ap.add_argument("--no-rccl-single", action="store_true",
                     help="N = 1 sis workloads: do NOT route the per-step exchange through a one-rank RCCL group")
     args = ap.parse_args()
@@ -276,10 +284,10 @@ def main():
         except Exception as e:  # no RCCL for a single rank on this box: run without, and say so
             dist, rccl_note = None, f"one-rank nccl group unavailable: {type(e).__name__}: {e}"[:200]
     if workload in ("kernel", "kernel-llama"):
-        runner = KernelWorkload(eng, dev, rank, world, dist, llama=workload == "kernel-llama")
-    elif workload in ("api", "api-coro", "api-logprobs"):
+        runner = KernelWorkload(eng, dev, rank, world, dist, llama=workload == "kernel-llama", per_row_masks=args.per_row_masks)
+    elif workload in ("api", "api-coro", "api-readme", "api-logprobs"):
         runner = ApiWorkload(eng, dev, rank, world, dist, logprobs=workload == "api-logprobs", coro=workload == "api-coro",
-                             auto_kv=args.auto_kv)
+                             auto_kv=args.auto_kv, readme=workload == "api-readme")
     else:
         from genlm_backend_amd.sis import SisBenchWorkload
 
@@ -287,7 +295,7 @@ def main():
                                   model="llama-3.2-1b" if workload == "sis-llama" else "gpt2",
                                   n_particles=512 if workload == "sis-llama" else 1024, n_prompts=args.prompts,
                                   resample=args.resample, force_collectives=force_coll,
-                                  kv_in_place=None if args.kv_gather else 0.75)
+                                  kv_in_place=None if args.kv_gather else 0.75, per_particle_masks=args.per_row_masks)
 
     rccl_ranks = None
     if dist is not None:  # one collective before the clock starts: proves every rank is on the RCCL communicator
@@ -299,24 +307,47 @@ def main():
         assert got.cpu().tolist() == [float(r) for r in range(world)]
         rccl_ranks = dist.get_world_size()
 
-    for i in range(args.warmup):
-        runner.step(i, timed=False)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        runner.step(args.warmup + i, timed=True)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        _reduce_all(dist, t, dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed_run(r):
+        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; the MAX over ranks."""
+        for i in range(args.warmup):
+            r.step(i, timed=False)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            r.step(args.warmup + i, timed=True)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            _reduce_all(dist, t, dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    dt = timed_run(runner)
+    # The default line also carries the same loop with KV rows shared by equal contexts (`--particle-kv`: one new token
+    # per distinct context per step instead of the reference's re-encoding; tokens proven equal to the reference's by
+    # tests/test_host_gpu.py) as value_kv / ms_per_step_kv.  `value` itself stays BASELINE config 2's algorithm.
+    kv_extra = None
+    if workload == "sis" and not (args.particle_kv or args.prefix_kv or args.per_row_masks or args.resample) and not args.no_kv_line:
+        from genlm_backend_amd.sis import SisBenchWorkload
+
+        runner_kv = SisBenchWorkload(eng, dev, rank, world, dist, particle_kv=True, model="gpt2", n_particles=1024,
+                                     n_prompts=args.prompts, force_collectives=force_coll)
+        dt_kv = timed_run(runner_kv)
+        kv_extra = {"value_kv": runner_kv.particles_per_step * world * args.steps / dt_kv,
+                    "ms_per_step_kv": dt_kv / args.steps * 1e3,
+                    "config_kv": "the same loop with device-resident KV rows shared by particles of equal contexts (block table "
+                                 "decided on the device, one new token per distinct context per step, in-place forward replayed "
+                                 "from a hipGraph with glb_slab_attention): beyond the reference's re-encode-every-step algorithm; "
+                                 "same tokens",
+                    "kv_rows": dict(runner_kv.sis.kv_stats)}
+        del runner_kv
 
     kern_us = runner.kernel_times_us()
     if rank == 0:
@@ -344,6 +375,8 @@ def main():
                 out["rccl_ranks"] = rccl_ranks
         if rccl_note is not None:
             out["rccl_note"] = rccl_note
+        if kv_extra is not None:
+            out.update(kv_extra)
         if kern_us is not None and len(kern_us):
             ach = runner.kernel_bytes / (np.mean(kern_us) * 1e-6) / 1e9
             outer = runner.outer_times_us()
@@ -358,7 +391,9 @@ def main():
                 "kernel": "glb::fused_step_kernel (fused log-softmax + mask + logsumexp + sample in ONE launch: stats waves "
                           "stream the rows chunk by chunk, finishing waves at the end of the grid fold the tagged records "
                           "and draw); the few calls too small for it (one shared row: SIS step 0) run "
-                          "glb::chunk_stats_small_kernel + glb::finish_kernel and are timed first start to last stop",
+                          "glb::chunk_stats_small_kernel + glb::finish_kernel and are timed first start to last stop"
+                          + ("; with one raw bit mask per particle the call's glb::mask_prepare_kernel launch comes first and is "
+                             "inside the span" if args.per_row_masks else ""),
                 "timing": "every fused call of the timed region, none left out: HIP events carried by the launch itself as "
                           "its start / stop stamps (hipExtLaunchKernel through glb_logprob_mask_sample_timed) = the launch "
                           "duration rocprofv3 reports; *_outer_events = the same calls between two hipEventRecord markers "
@@ -439,7 +474,7 @@ class KernelWorkload:
     """Fused step only: [1024, 50257] fp32 (or [512, 128256] bf16) logits, two shared {0,-inf} masks prepared once
     (like the README's two masks), mask ids per row, in-kernel Philox."""
 
-    def __init__(self, eng, dev, rank, world, dist, llama=False, nbuf=4):
+    def __init__(self, eng, dev, rank, world, dist, llama=False, nbuf=4, per_row_masks=False):
         self.eng, self.dev, self.rank, self.world, self.dist = eng, dev, rank, world, dist
         g = torch.Generator(device=dev)
         g.manual_seed(1234 + rank)
@@ -448,23 +483,30 @@ class KernelWorkload:
         self.dtype_name = "bf16" if llama else "f32"
         self.particles_per_step = B
         self.bufs = [(torch.randn((B, V), device=dev, generator=g) * 3.0).to(dt) for _ in range(nbuf)]
-        maskf = torch.where(torch.rand((2, V), device=dev, generator=g) < 1 / 3, float("-inf"), 0.0)
+        self.per_row_masks = per_row_masks
+        n_masks = B if per_row_masks else 2
+        maskf = torch.where(torch.rand((n_masks, V), device=dev, generator=g) < 1 / 3, float("-inf"), 0.0)
         maskf[:, 0] = 0.0
         self.bits, _ = eng.mask_to_bits(maskf)
-        self.masks = eng.prepare_masks(self.bits, V, dt)
+        del maskf
+        self.masks = None if per_row_masks else eng.prepare_masks(self.bits, V, dt)
         self.mask_id = (torch.arange(B, device=dev) % 2).to(torch.int32)
         self.out = (torch.empty(B, device=dev), torch.empty(B, device=dev),
                     torch.empty(B, dtype=torch.int32, device=dev))
         self.lw = torch.zeros(B, device=dev)
         self.gathered = torch.empty(B * world, device=dev) if world > 1 else None
-        self.kernel_bytes = algorithmic_bytes(B, V, 2 if llama else 4, 2, (V + 31) // 32)
+        self.kernel_bytes = algorithmic_bytes(B, V, 2 if llama else 4, n_masks, (V + 31) // 32)
         self.events = []
         self.outer = []
         self._pool = []
         # the argument block of every buffer's call is filled once: a step's host work is then a few microseconds, so
         # the host stays ahead of the GPU and the event interval holds no wait for the next launch packet
-        self.plans = [eng.step_plan(x, mask=self.masks, row_mask_id=self.mask_id, rng_mode=1, seed=1234, offset=0,
-                                    particle_base=rank * B, out=self.out) for x in self.bufs]
+        if per_row_masks:  # raw bit rows, one per particle (mask ids = identity): every call prepares them itself
+            self.plans = [eng.step_plan(x, mask_kind=1, mask=self.bits, rng_mode=1, seed=1234, offset=0,
+                                        particle_base=rank * B, out=self.out) for x in self.bufs]
+        else:
+            self.plans = [eng.step_plan(x, mask=self.masks, row_mask_id=self.mask_id, rng_mode=1, seed=1234, offset=0,
+                                        particle_base=rank * B, out=self.out) for x in self.bufs]
 
     def step(self, i, timed):
         plan = self.plans[i % len(self.plans)]
@@ -497,8 +539,9 @@ class KernelWorkload:
     def config(self):
         shape = "512 particles x Llama vocab 128256, bf16 logits [512,128256]" if self.llama else \
             "1024 particles x gpt2 vocab 50257, fp32 logits [1024,50257]"
-        return {"workload": f"fused step only: {shape} ld=V, 2 shared bit masks (prepared once), Philox draw, "
-                            "4 rotating logits buffers",
+        masks = (f"{self.B} bit masks, one per particle (GLB_MASK_BITS, handed over raw: the call's own mask_prepare launch is "
+                 "inside the timed launch span)") if self.per_row_masks else "2 shared bit masks (prepared once)"
+        return {"workload": f"fused step only: {shape} ld=V, {masks}, Philox draw, 4 rotating logits buffers",
                 "particles_per_gpu": self.B, "vocab": self.V, "rng": "philox"}
 
 
@@ -513,7 +556,7 @@ class ApiWorkload:
     dtype_name = "f32"
 
     def __init__(self, eng, dev, rank, world, dist, logprobs=False, coro=False, n_particles=1024, max_tokens=10,
-                 auto_kv=False):
+                 auto_kv=False, readme=False):
         import asyncio
 
         from transformers import GPT2Config
@@ -534,6 +577,8 @@ class ApiWorkload:
         eos1 = torch.full((V,), float("-inf"), device=dev)
         eos1[cfg.eos_token_id] = 0.0
         self.llm.register_masks(torch.stack([valid, eos1]))
+        self.user_masks = torch.stack([valid, eos1])  # api-readme: the user's own mask tensors (README.md:57-70)
+        self.readme = readme
         self.llm.set_rng("philox", seed=1234 + rank)
         self.N, self.V, self.max_tokens, self.eos = n_particles, V, max_tokens, cfg.eos_token_id
         self.particles_per_step = n_particles
@@ -554,7 +599,29 @@ class ApiWorkload:
         from genlm_backend_amd.sis import Particle
 
         sel = lambda context: 1 if len(context) >= self.max_tokens else 0
-        self.particles = [Particle(self.llm, sel, self.prompt, self.eos) for _ in range(self.N)]
+        if self.readme:
+            self.llm.clear_cache()
+            llm, masks, prompt, eos = self.llm, self.user_masks, self.prompt, self.eos
+
+            class ReadmeParticle:  # README.md:72-91, verbatim user code
+                def __init__(self):
+                    self.context, self.log_weight, self.active = [], 0.0, True
+
+                async def extend(self):
+                    logps = await llm.next_token_logprobs(prompt + self.context)
+                    masked = logps + masks[sel(self.context)].to(logps.device)
+                    logZ = masked.logsumexp(dim=-1)
+                    p = (masked - logZ).exp()
+                    next_token_id = torch.multinomial(p, 1).item()
+                    self.log_weight += logZ
+                    if next_token_id == eos:
+                        self.active = False
+                    else:
+                        self.context.append(next_token_id)
+
+            self.particles = [ReadmeParticle() for _ in range(self.N)]
+        else:
+            self.particles = [Particle(self.llm, sel, self.prompt, self.eos) for _ in range(self.N)]
         self.t = 0
 
     def step(self, i, timed):
@@ -567,7 +634,7 @@ class ApiWorkload:
         if self.t >= self.max_tokens:
             self._reset()
 
-        if self.coro:
+        if self.coro or self.readme:
             async def one_step():
                 await aio.gather(*[p.extend() for p in self.particles if p.active])
 
@@ -595,7 +662,9 @@ class ApiWorkload:
     def config(self):
         what = ("batch_next_token_logprobs of 1024 distinct 13-token contexts, [1024, V] fp32 log-prob rows materialised "
                 "on the device (base.py:47-60)") if self.logprobs else \
-            (("README loop: 1024 coroutines awaiting AsyncAmdLM.next_token_step, autobatched (batch_size 1024)" if self.coro else
+            (("README loop VERBATIM (README.md:72-98, only `llm` swapped): 1024 coroutines await next_token_logprobs, then add "
+              "their mask, take logsumexp and draw with torch.multinomial on the returned device rows themselves" if self.readme else
+              "README loop: 1024 coroutines awaiting AsyncAmdLM.next_token_step, autobatched (batch_size 1024)" if self.coro else
               "README loop over 1024 Python-side particles, each step's requests submitted as one "
               "AsyncAmdLM.batch_next_token_step call") + ", prompt len 8, <=10 new tokens, 2 shared bit masks, Philox draws "
              "(README.md:72-98)")

@@ -13,7 +13,6 @@ ABI_VERSION = 5
 GLB_OK, GLB_EINVAL, GLB_EUNSUPPORTED, GLB_EHIP, GLB_ENOSPC = 0, 1, 2, 3, 4
 F32, BF16, F16 = 0, 1, 2
 MASK_NONE, MASK_BITS, MASK_F32, MASK_PREPARED = 0, 1, 2, 3
-STEP_ROWS_BY_FIRST_USE = 1
 RNG_NONE, RNG_PHILOX, RNG_NOISE = 0, 1, 2
 
 
@@ -87,6 +86,30 @@ class TrieArgs(C.Structure):
     ]
 
 
+class KvPlanArgs(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("n", C.c_int64), ("n_rows", C.c_int64), ("cap", C.c_int64),
+        ("group_of", C.c_void_p), ("rep", C.c_void_p), ("n_groups", C.c_void_p),
+        ("old_row", C.c_void_p),
+        ("old_row_by_context", C.c_int32),
+        ("lengths", C.c_void_p),
+        ("row_stamps", C.c_void_p),
+        ("call_no", C.c_int64),
+        ("row_tok", C.c_void_p), ("row_len", C.c_void_p),
+        ("row_hash", C.c_void_p),
+        ("group_hash", C.c_void_p),
+        ("tokens", C.c_void_p),
+        ("starts", C.c_void_p),
+        ("out_group_row", C.c_void_p), ("out_logits_row", C.c_void_p), ("out_rows_a", C.c_void_p), ("out_ctx_a", C.c_void_p),
+        ("out_pos_a", C.c_void_p), ("out_ctx_b", C.c_void_p), ("out_rows_b", C.c_void_p), ("out_copy_src", C.c_void_p),
+        ("out_copy_len", C.c_void_p), ("out_ctx_of_row", C.c_void_p), ("out_pos_of_row", C.c_void_p),
+        ("out_row_of_context", C.c_void_p), ("out_head", C.c_void_p),
+        ("workspace", C.c_void_p),
+        ("workspace_bytes", C.c_size_t),
+    ]
+
+
 class MT19937(C.Structure):
     _fields_ = [("mt", C.c_uint32 * 624), ("idx", C.c_int32)]
 
@@ -122,6 +145,11 @@ SYMBOLS = {
     "glb_kv_append": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
     "glb_kv_gather_rows": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _i32, _vp]),
     "glb_gather_rows_i32": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),
+    "glb_match_rows": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "glb_slab_attention": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _f32, _i32,
+                                     _vp, _vp]),
+    "glb_kv_plan_workspace": (_sz, [_i64, _i64]),
+    "glb_kv_plan": (C.c_int, [C.POINTER(KvPlanArgs), _vp]),
     "glb_trie_workspace": (_sz, [_i64, _i64]),
     "glb_trie_reduce": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _sz,
                                   _vp]),

@@ -1,6 +1,7 @@
 // glb_api.hip — C ABI of libglb_hip.so (include/glb.h): argument validation, launch-geometry
 // selection, the small bookkeeping kernels of the hot path, and the host-side RNG helpers.
 // gfx950 only.  No entry point allocates, frees or synchronises.
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -15,18 +16,7 @@
 
 #include "../../include/glb.h"
 #include "glb_chunk.hpp"
-
-#ifndef GLB_FIN_LAG_PCT
-// Finishing blocks inside the grid, this many percent of the chip's wave slots behind their rows' stats blocks; -1: at
-// the end of the grid.  Measured (same box, tools/r4_kernel_ab.sh, profiles/r04/ab_lag.log): 1024 x 50257 fp32 42.7 us at
-// the end, 46.3 / 45.9 / 44.7 / 43.2 us at 25 / 50 / 100 / 200 percent; 512 x 128256 bf16 34.0 against 35.9 / 35.6 / 35.3 /
-// 34.7 - a finishing wave that runs beside the stream takes a slot and L2 requests from it and gives nothing back (its
-// work is latency, not throughput), and the last rows' finishing waves end when they did anyway.  Hence -1.
-#define GLB_FIN_LAG_PCT -1
-#endif
-#ifndef GLB_SHORT_LAST
-#define GLB_SHORT_LAST 1
-#endif
+#include "glb_common.hpp"
 
 namespace glb {
 // launchers exported by the three glb_chunk_tu.hip translation units (one per element type)
@@ -62,6 +52,22 @@ int fail(int code, const char *fmt, ...) {
 int hip_fail(hipError_t e, const char *what) {
   return fail(GLB_EHIP, "%s: %s", what, hipGetErrorString(e));
 }
+}  // namespace
+
+namespace glb {  // the error slot for the library's other translation units (glb_common.hpp)
+int api_fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+int api_hip_fail(hipError_t e, const char *what) { return hip_fail(e, what); }
+}  // namespace glb
+
+namespace {
 
 hipError_t launch_stats(int dtype, const glb::StepParams &p, int mask_kind, bool scaled, hipStream_t s) {
   switch (dtype) {
@@ -154,14 +160,6 @@ int lsm_variant() {
 
 int fin_wave_cap(bool float_mask) { return device_cus() * (float_mask ? 6 : 8); }
 
-// how far behind its row's stats blocks a finishing block is dealt, in percent of the chip's wave slots (-1: at the end
-// of the grid).  The diagnostic build reads it from the environment for same-box comparisons.
-int interleave_lag_slots() {
-#ifdef GLB_STAMPS
-  if (const char *e = getenv("GLB_FIN_LAG")) return atoi(e);
-#endif
-  return GLB_FIN_LAG_PCT;
-}
 
 
 hipError_t launch_finish(int dtype, const glb::StepParams &p, int mask_kind, int mode, hipStream_t s) {
@@ -189,16 +187,18 @@ inline size_t step_recs_bytes(int64_t units, int64_t vocab) {
 }
 inline size_t step_fixed_bytes(int64_t units, int64_t vocab) { return step_recs_bytes(units, vocab); }
 
+// start: an event the launch carries as its start stamp (glb_logprob_mask_sample_timed: a call that prepares its own masks
+// is timed from this launch on)
 hipError_t launch_mask_prepare(const uint32_t *bits, int64_t n_masks, int64_t vocab, int64_t mask_ld, int dtype,
-                               void *out, hipStream_t s) {
+                               void *out, hipStream_t s, hipEvent_t start = nullptr) {
   const int nch = (int)n_chunks(vocab);
   uint64_t *mt = (uint64_t *)out;
   uint64_t *many = (uint64_t *)((char *)out + prepared_words_bytes(n_masks, vocab));
   const dim3 grid((unsigned)nch, (unsigned)n_masks), block(256);
   if (dtype == GLB_F32)
-    hipLaunchKernelGGL((glb::mask_prepare_kernel<4>), grid, block, 0, s, bits, mask_ld, (int)vocab, nch, mt, many);
+    hipExtLaunchKernelGGL((glb::mask_prepare_kernel<4>), grid, block, 0, s, start, nullptr, 0, bits, mask_ld, (int)vocab, nch, mt, many);
   else
-    hipLaunchKernelGGL((glb::mask_prepare_kernel<8>), grid, block, 0, s, bits, mask_ld, (int)vocab, nch, mt, many);
+    hipExtLaunchKernelGGL((glb::mask_prepare_kernel<8>), grid, block, 0, s, start, nullptr, 0, bits, mask_ld, (int)vocab, nch, mt, many);
   return hipGetLastError();
 }
 
@@ -1051,7 +1051,7 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
   }
   if (a->rng_mode < GLB_RNG_NONE || a->rng_mode > GLB_RNG_NOISE)
     return fail(GLB_EINVAL, "bad rng_mode %d", a->rng_mode);
-  if (a->flags & ~(int32_t)GLB_STEP_ROWS_BY_FIRST_USE) return fail(GLB_EINVAL, "unknown bits in flags");
+  if (a->flags != 0) return fail(GLB_EINVAL, "flags must be 0 (no bits are defined)");
   if (a->rng_mode == GLB_RNG_NOISE && (!a->noise || (a->noise_ld < a->vocab && a->noise_ld != 0)))
     return fail(GLB_EINVAL, "noise tensor missing or noise_ld < vocab (0 = one row shared by every particle)");
   if (a->rng_mode != GLB_RNG_NONE && !a->out_token)
@@ -1095,7 +1095,9 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
     const char *prep = (const char *)a->mask;
     if (own_prep) {  // transposed form into the workspace, on the same stream
       char *dst = (char *)a->workspace + fixed_bytes;
-      const hipError_t e = launch_mask_prepare((const uint32_t *)a->mask, a->n_masks, a->vocab, a->mask_ld, a->dtype, dst, s);
+      const hipError_t e = launch_mask_prepare((const uint32_t *)a->mask, a->n_masks, a->vocab, a->mask_ld, a->dtype, dst, s,
+                                               glb::g_step_ev_start);
+      glb::g_step_ev_start = nullptr;  // (a timed call starts with this launch)
       if (e != hipSuccess) return hip_fail(e, "mask_prepare launch");
       prep = dst;
     }
@@ -1125,11 +1127,8 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
   bool fused = a->rng_mode != GLB_RNG_NOISE && items > 512 && a->n_particles <= 16 * (int64_t)fin_wave_cap(fmask);
   p.il_lag = -1;
   p.spin_ticks = g_spin_ticks.load(std::memory_order_relaxed);
-  // rows that end in at most half a chunk: those light items are dealt last (glb_chunk.hpp: short_last)
-  p.short_last = (p.nch >= 2 && a->vocab - (int64_t)(p.nch - 1) * glb::kChunk <= glb::kChunk / 2) ? GLB_SHORT_LAST : 0;
 #ifdef GLB_STAMPS  // diagnostic build: occupancy cap of the one-launch step from the environment (bytes of unused LDS)
   if (const char *e = getenv("GLB_LDS_PAD")) glb::g_lds_pad[a->dtype] = atoi(e);
-  if (const char *e = getenv("GLB_SHORT_LAST")) p.short_last = p.short_last ? atoi(e) : 0;
   if (const char *e = getenv("GLB_DBG_MODE")) p.dbg_mode = atoi(e);
 #endif
   if (fused) {
@@ -1141,16 +1140,18 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
     p.stats_blocks = (int32_t)items;
     const int64_t cap = fin_wave_cap(fmask);
     p.fin_blocks = (int32_t)(a->n_particles < cap ? a->n_particles : cap);
-    // one finishing wave per particle and no unit numbered above its particles (identity, or the caller says its row
-    // ids are numbered by first use): the finishing blocks go inside the grid, about one chip's worth of wave slots
-    // behind their rows' stats blocks (glb_chunk.hpp: il_lag)
-    const bool ordered = p.pair_of == nullptr || (by_row && (a->flags & GLB_STEP_ROWS_BY_FIRST_USE));
-    if (ordered && a->n_particles <= cap && n_units <= a->n_particles && interleave_lag_slots() >= 0) {
-      const int wps = fmask ? 3 : (a->dtype == GLB_F32 ? 4 : GLB_STATS_WAVES_16);
-      int64_t lag = ((int64_t)interleave_lag_slots() * wave_slots(wps) / 100 + p.nch - 1) / p.nch;
-      p.il_lag = (int32_t)(lag < n_units ? lag : n_units);
-      p.short_last = 0;  // (the interleaved grid deals a unit's items as one run)
+#ifdef GLB_STAMPS  // diagnostic build: the placements that were measured and not kept (glb_chunk.hpp: il_lag, short_last)
+    if (const char *e = getenv("GLB_FIN_LAG")) {
+      const int pct = atoi(e);
+      if (pct >= 0 && p.pair_of == nullptr && a->n_particles <= cap) {
+        const int wps = fmask ? 3 : (a->dtype == GLB_F32 ? 4 : GLB_STATS_WAVES_16);
+        const int64_t lag = ((int64_t)pct * wave_slots(wps) / 100 + p.nch - 1) / p.nch;
+        p.il_lag = (int32_t)(lag < n_units ? lag : n_units);
+      }
     }
+    if (const char *e = getenv("GLB_SHORT_LAST"))
+      p.short_last = (atoi(e) && p.il_lag < 0 && p.nch >= 2 && a->vocab - (int64_t)(p.nch - 1) * glb::kChunk <= glb::kChunk / 2) ? 1 : 0;
+#endif
     const hipError_t e = launch_fused_step(a->dtype, p, kmask, a->rng_mode, scaled, s);
     if (e != hipSuccess) return hip_fail(e, "fused_step launch");
     return GLB_OK;

@@ -87,20 +87,12 @@ struct StepParams {
   // fused launch (one-wave workgroups): blocks [0, stats_blocks) reduce one (unit, chunk) each, then fin_blocks
   // finishing waves (wave f takes particles f, f + fin_blocks, ...)
   int32_t stats_blocks, fin_blocks;
-  // il_lag >= 0 (needs fin_blocks == n_particles >= n_pairs): the finishing blocks are dealt INSIDE the grid - units
-  // [0, il_lag) are stats blocks only, the nch stats blocks of every later unit u are followed by the finishing block
-  // of particle u - il_lag, and the finishing blocks of the last particles close the grid.  A particle's unit is never
-  // numbered above the particle (identity, or ids by first appearance), so under in-order dispatch its finishing wave
-  // is placed il_lag units behind its row's stats waves: most of them find their records complete and do their work
-  // while the stream is still running, instead of all of them after it.  il_lag < 0: every finishing block at the end.
-  int32_t il_lag;
+  // diagnostic build only (GLB_STAMPS; tools/r4_kernel_ab.sh, DESIGN.md §5 - both placements measured slower and are not
+  // in the product): il_lag >= 0 deals the finishing blocks INSIDE the grid, il_lag units behind their rows' stats
+  // blocks; short_last deals every row's short last chunk after all full chunks
+  int32_t il_lag, short_last, dbg_mode;
   uint32_t *err;      // nullable: word a wave that gave up waiting adds 1 to (glb_workspace_check)
   uint64_t spin_ticks;  // the watchdog of the waits inside the launch, in s_memrealtime ticks
-  // short_last != 0 (rows whose last chunk holds at most half a chunk): the stats items are dealt full chunks first, row by
-  // row, and every row's short chunk after all of them - the blocks placed last are the lightest ones (longest processing
-  // time first), so the launch's last stats waves are done in a fraction of a full wave's lifetime
-  int32_t short_last;
-  int32_t dbg_mode;     // diagnostic build only (tools/r4_kernel_ab.sh): 1 = no exponentials, 2 = every row is row 0..7
 };
 
 template <int DT>
@@ -497,20 +489,14 @@ __device__ __forceinline__ void stats_item(const StepParams &p, int item, int la
 #ifdef GLB_STAMPS  // diagnostic build (tools/dbg/stamps.py): wave start / end times in the record's padding
   const uint64_t stamp0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  int pr, c;  // (dealt chunk-major instead - every row's chunk 0, then every row's chunk 1, ... - the launch is 2.5 us slower)
-  if (p.short_last) {
+  int pr = item / nch, c = item - pr * nch;  // (dealt chunk-major instead - every row's chunk 0, then every row's chunk 1, ... - the launch is 2.5 us slower)
+#ifdef GLB_STAMPS
+  if (p.short_last) {  // every row's short last chunk after all the full ones: 2 us slower (profiles/r04/ab_short_last_v1.log)
     const int nfull = nch - 1, split = p.n_pairs * nfull;
-    if (item < split) {
-      pr = item / nfull;
-      c = item - pr * nfull;
-    } else {
-      pr = item - split;
-      c = nfull;
-    }
-  } else {
-    pr = item / nch;
-    c = item - pr * nch;
+    pr = item < split ? item / nfull : item - split;
+    c = item < split ? item - pr * nfull : nfull;
   }
+#endif
   int row = p.pair_row ? as_const(p.pair_row)[pr] : pr;
 #ifdef GLB_STAMPS
   if (p.dbg_mode == 2) row &= 7;  // (timing experiment: the rows come out of the caches)
@@ -795,7 +781,7 @@ __device__ __forceinline__ bool recs_acquire(Recs &R, int nch, int lane, uint64_
           seen = (uint32_t)(g >> 32) == R.epoch;
         }
         if (__builtin_amdgcn_ballot_w64(!seen) != 0ull) {
-          __builtin_amdgcn_s_sleep(8);
+          __builtin_amdgcn_s_sleep(2);
           if (__builtin_amdgcn_s_memrealtime() - t0 > spin_ticks) return false;
           continue;
         }
@@ -858,10 +844,19 @@ __device__ __forceinline__ void pair_fold(const Recs &recs, int nch, int lane, P
   st.S_msk = S_msk;
 }
 
-// lse / logZ (sum of e^x = 2^(N + 1 - 36) * S) - call from one lane
-__device__ __forceinline__ void pair_logs(const PairState &st, float &lse, float &logZ) {
-  const double lse_all = st.S_all ? log_fix(st.S_all, (int32_t)st.N_all + 1 - kFrac) : (double)kNegInf;
-  const double lse_msk = st.S_msk ? log_fix(st.S_msk, (int32_t)st.N_msk + 1 - kFrac) : (double)kNegInf;
+// lse / logZ (sum of e^x = 2^(N + 1 - 36) * S), called by the whole wave: lane 1 takes the logarithm of the allowed
+// sum while lane 0 takes the one of all elements - one pass through the double-precision instruction stream instead of
+// two (a finishing wave is alone on its SIMD and these ~80 dependent fp64 operations sit on the launch's last
+// microseconds).  Results wave-uniform.
+__device__ __forceinline__ void pair_logs(const PairState &st, int lane, float &lse, float &logZ) {
+  const bool msk = lane == 1;
+  const uint64_t S = msk ? st.S_msk : st.S_all;
+  const float N = msk ? st.N_msk : st.N_all;
+  double l = (double)kNegInf;
+  if (S) l = log_fix(S, (int32_t)N + 1 - kFrac);
+  const uint64_t lb = (uint64_t)__double_as_longlong(l);
+  const double lse_all = __longlong_as_double((long long)readlane_u64(lb, 0));
+  const double lse_msk = __longlong_as_double((long long)readlane_u64(lb, 1));
   lse = (float)lse_all;
   logZ = (float)(lse_msk - lse_all);
 }
@@ -923,7 +918,7 @@ __device__ __forceinline__ void finish_stats(const StepParams &p, int pidx, int 
   if (recs_acquire<POLL>(recs, nch, lane, p.spin_ticks)) {
     PairState st;
     pair_fold<MASK>(recs, nch, lane, st);
-    if (lane == 0) pair_logs(st, lse, logZ);
+    pair_logs(st, lane, lse, logZ);
   } else if (lane == 0 && p.err) {
     atomicAdd(p.err, 1u);
   }
@@ -1017,11 +1012,13 @@ __device__ __forceinline__ void finish_draw(const StepParams &p, int pidx, int l
         }
       }
     }
-    if (lane == 0) {  // the logarithms: one lane's work for the time the loads are in flight
+    {  // the logarithms: two lanes' work for the time the loads are in flight
       float lse, logZ;
-      pair_logs(st, lse, logZ);
-      if (p.out_lse) p.out_lse[pidx] = lse;
-      if (p.out_logZ) p.out_logZ[pidx] = logZ;
+      pair_logs(st, lane, lse, logZ);
+      if (lane == 0) {
+        if (p.out_lse) p.out_lse[pidx] = lse;
+        if (p.out_logZ) p.out_logZ[pidx] = logZ;
+      }
     }
 #ifdef GLB_STAMPS  // [3]: the quarter chunk has arrived (the wave waits for its last vector here)
     asm volatile("" ::"v"(y[15]));
@@ -1074,11 +1071,13 @@ __device__ __forceinline__ void finish_draw(const StepParams &p, int pidx, int l
         if (psel >= 0) tok = e_base + ((wsel + 4 * (psel / EPV)) * 64 + 16 * gsel + lsel) * EPV + (psel % EPV);
       }
     }
-  } else if (lane == 0) {
+  } else {
     float lse, logZ;
-    pair_logs(st, lse, logZ);
-    if (p.out_lse) p.out_lse[pidx] = lse;
-    if (p.out_logZ) p.out_logZ[pidx] = logZ;
+    pair_logs(st, lane, lse, logZ);
+    if (lane == 0) {
+      if (p.out_lse) p.out_lse[pidx] = lse;
+      if (p.out_logZ) p.out_logZ[pidx] = logZ;
+    }
   }
   if (lane == 0) p.out_token[pidx] = tok;
 #ifdef GLB_STAMPS
@@ -1107,25 +1106,19 @@ template <int DT, int MASK, bool SCALED, int MODE>
 __global__ __launch_bounds__(64, (StatsWaves<DT, MASK>::value)) void fused_step_kernel(const StepParams p) {
   const int lane = threadIdx.x;
   const int blk = blockIdx.x;
-  int item = -1, pfirst = -1;  // (wave-uniform: scalar arithmetic)
-  if (p.il_lag < 0) {
-    if (blk < p.stats_blocks) item = blk;
-    else pfirst = blk - p.stats_blocks;
-  } else {
+  int item = blk < p.stats_blocks ? blk : -1, pfirst = blk - p.stats_blocks;
+#ifdef GLB_STAMPS
+  if (p.il_lag >= 0) {  // finishing blocks inside the grid (slower at every lag tried: profiles/r04/ab_fin_lag_v1.log)
     const int head = p.il_lag * p.nch, b = blk - head;
-    if (b < 0) {
-      item = blk;
-    } else {
+    item = blk;
+    if (b >= 0) {
       const int per = p.nch + 1, n_mid = p.n_pairs - p.il_lag;
       const int q = (int)((unsigned)b / (unsigned)per), r = b - q * per;
-      if (q < n_mid) {
-        if (r < p.nch) item = (p.il_lag + q) * p.nch + r;
-        else pfirst = q;
-      } else {
-        pfirst = n_mid + (b - n_mid * per);
-      }
+      item = q < n_mid && r < p.nch ? (p.il_lag + q) * p.nch + r : -1;
+      pfirst = q < n_mid ? q : n_mid + (b - n_mid * per);
     }
   }
+#endif
   if (item >= 0) {
     stats_item<DT, MASK, SCALED>(p, item, lane);
     return;
@@ -1183,11 +1176,13 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
 
   PairState st;
   pair_fold<MASK>(recs, nch, lane, st);
-  if (wave == 0 && lane == 0) {
+  if (wave == 0) {
     float lse, logZ;
-    pair_logs(st, lse, logZ);
-    if (p.out_lse) p.out_lse[pidx] = lse;
-    if (p.out_logZ) p.out_logZ[pidx] = logZ;
+    pair_logs(st, lane, lse, logZ);
+    if (lane == 0) {
+      if (p.out_lse) p.out_lse[pidx] = lse;
+      if (p.out_logZ) p.out_logZ[pidx] = logZ;
+    }
   }
   if (!p.out_token) return;
   {

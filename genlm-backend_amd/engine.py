@@ -11,7 +11,7 @@ import torch
 from . import _lib
 from ._lib import GLB_EHIP, GlbError
 from ._lib import (F32, BF16, F16, MASK_NONE, MASK_BITS, MASK_F32, MASK_PREPARED, RNG_NONE, RNG_PHILOX, RNG_NOISE,
-                   STEP_ROWS_BY_FIRST_USE, StepArgs, TrieArgs, MT19937, check)
+                   KvPlanArgs, StepArgs, TrieArgs, MT19937, check)
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 
@@ -160,15 +160,12 @@ class HipEngine:
 
     def step(self, logits, vocab=None, row_of=None, mask_kind=MASK_NONE, mask=None, mask_id=None,
              rng_mode=RNG_NONE, noise=None, seed=0, offset=0, particle_base=0, logit_scale=1.0,
-             want_lse=True, out=None, row_mask_id=None, out_margin=None, _plan=False, timing_events=None,
-             rows_by_first_use=False):
+             want_lse=True, out=None, row_mask_id=None, out_margin=None, _plan=False, timing_events=None):
         """Fused particle step (glb_logprob_mask_sample).  Returns (logZ, lse, token) device tensors.
 
         logits: [n_rows, ld] (last dim contiguous; rows may be strided), vocab <= ld.
         mask: int32 bit rows / float rows, or a `PreparedMasks` (prepare_masks).  `row_mask_id` gives the mask per
         logits row (the mask is a function of the context): shared rows are then reduced once.
-        rows_by_first_use: `row_of` numbers the rows by first use (row_of[p] <= p: what `group_contexts` returns) -
-        GLB_STEP_ROWS_BY_FIRST_USE, a speed hint.
         A launch whose waves gave up waiting shows as token -2 / NaN and in `error_word()`: `raise_if_failed`.
         """
         if logits.dim() != 2 or logits.stride(1) != 1:
@@ -226,7 +223,6 @@ class HipEngine:
             # one row for everybody (batch_sample seeds every sequence alike): pitch 0
             a.noise_ld = noise.stride(0) if noise.shape[0] > 1 else (0 if n > 1 else noise.shape[1])
         a.seed, a.offset, a.particle_base = seed, offset, particle_base
-        a.flags = STEP_ROWS_BY_FIRST_USE if (rows_by_first_use and row_of is not None) else 0
         a.out_logZ = None if logZ is None else logZ.data_ptr()
         a.out_lse = None if lse is None else lse.data_ptr()
         a.out_token = None if tok is None else tok.data_ptr()
@@ -425,6 +421,24 @@ class HipEngine:
         check(self.lib.glb_kv_append(_ptr(slab), _ptr(new_rows), _ptr(pos), _ptr(rows), n, H, cap, Dh, new_rows.stride(0),
                                      new_rows.stride(1), slab.element_size(), self._stream()))
 
+    def slab_attention(self, query, k_new, v_new, k_slab, v_slab, pos, scale):
+        """Attention of a one-token forward over slab rows where they lie, the new token's K / V appended on the way
+        (glb_slab_attention).  query [R, H, 1, Dh], k_new / v_new [R, H_kv, 1, Dh] (unit inner stride; usually strided
+        views of the projection output), slabs [R, H_kv, cap, Dh] contiguous, pos int32 [R].  Returns [R, 1, H, Dh]."""
+        R, H, _, Dh = query.shape
+        Hkv, cap = k_slab.shape[1], k_slab.shape[2]
+        assert query.stride(3) == 1 and k_new.stride(3) == 1 and v_new.stride(3) == 1 and k_slab.is_contiguous() and v_slab.is_contiguous()
+        assert k_new.stride() == v_new.stride() and k_new.dtype == query.dtype == k_slab.dtype
+        out = torch.empty((R, 1, H, Dh), dtype=query.dtype, device=self.device)
+        check(self.lib.glb_slab_attention(_ptr(query), query.stride(0), query.stride(1), _ptr(k_new), _ptr(v_new),
+                                          k_new.stride(0), k_new.stride(1), _ptr(k_slab), _ptr(v_slab), _ptr(pos), R, H, Hkv,
+                                          cap, Dh, float(scale), _DT[query.dtype], _ptr(out), self._stream()))
+        return out
+
+    @staticmethod
+    def slab_attention_supports(dtype, head_dim):
+        return dtype in _DT and head_dim in (64, 128)
+
     def kv_gather_rows(self, srcs, dsts, src_row_of, len_of):
         """dsts[t][i, h, p] = srcs[t][src_row_of[i], h, p] for p < len_of[i], for every tensor pair of the two lists
         (all [rows, heads, cap, head_dim], contiguous) in ONE launch through device pointer tables
@@ -444,6 +458,63 @@ class HipEngine:
             out = torch.empty((n, width), dtype=torch.int32, device=self.device)
         check(self.lib.glb_gather_rows_i32(_ptr(src), src.stride(0), _ptr(row_of), n, width, _ptr(out), out.stride(0),
                                            self._stream()))
+        return out
+
+    # ---- KV rows shared between contexts: the block table on the device ------------------------------------------
+    def match_rows(self, tokens, starts, lengths, rep, n_groups, row_tok, row_len, row_hash):
+        """For every dedup group the table row that holds exactly its context, else the row that holds its first L - 1
+        tokens, else -1 (glb_match_rows).  Returns (old_row int32 [n], group_hash int64 [n]); entries past the group
+        count are unspecified."""
+        n = lengths.numel()
+        R, cap = row_tok.shape
+        self._check_dev(tokens, starts, lengths, rep, n_groups, row_tok, row_len, row_hash)
+        old = self._i32(n)
+        gh = torch.empty(n, dtype=torch.int64, device=self.device)
+        check(self.lib.glb_match_rows(_ptr(tokens), _ptr(starts), _ptr(lengths), _ptr(rep), _ptr(n_groups), n, _ptr(row_tok),
+                                      _ptr(row_len), _ptr(row_hash), R, cap, _ptr(old), _ptr(gh), self._stream()))
+        return old, gh
+
+    def kv_plan(self, group_of, rep, n_groups, old_row, lengths, n_rows, cap, by_context=False, stamps=None, call_no=0,
+                table=None):
+        """The block table of one step (glb_kv_plan).  `old_row`: the row every group's prefix sits in (match_rows'
+        output), or with `by_context` every CONTEXT's row (the previous plan's `row_of_context`).  `stamps`: int64
+        [n_rows], free rows are handed out longest unused first (and stamped `call_no`).  `table`: (row_tok, row_len,
+        row_hash, group_hash, tokens, starts) - the rows' contents, rewritten for every group that holds a row.
+        Returns a dict of int32 device tensors (include/glb.h names without the out_ prefix); `head` (8 words) is all
+        the host has to read."""
+        n = group_of.numel()
+        self._check_dev(group_of, rep, n_groups, old_row, lengths, stamps)
+        buf = torch.empty(8 * n + 4 * n_rows + 8, dtype=torch.int32, device=self.device)
+        names_n = ("group_row", "logits_row", "rows_a", "ctx_a", "pos_a", "ctx_b", "rows_b", "row_of_context")
+        names_r = ("copy_src", "copy_len", "ctx_of_row", "pos_of_row")
+        out, o = {}, 0
+        for k in names_n:
+            out[k] = buf[o:o + n]
+            o += n
+        for k in names_r:
+            out[k] = buf[o:o + n_rows]
+            o += n_rows
+        out["head"] = buf[o:o + 8]
+        need = self.lib.glb_kv_plan_workspace(n, n_rows)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(max(need, 1 << 16), dtype=torch.uint8, device=self.device)
+        a = KvPlanArgs()
+        a.struct_size = C.sizeof(KvPlanArgs)
+        a.n, a.n_rows, a.cap = n, n_rows, cap
+        a.group_of, a.rep, a.n_groups = group_of.data_ptr(), rep.data_ptr(), n_groups.data_ptr()
+        a.old_row, a.old_row_by_context = old_row.data_ptr(), 1 if by_context else 0
+        a.lengths = lengths.data_ptr()
+        a.row_stamps = None if stamps is None else stamps.data_ptr()
+        a.call_no = int(call_no)
+        if table is not None:
+            row_tok, row_len, row_hash, group_hash, tokens, starts = table
+            self._check_dev(row_tok, row_len, row_hash, group_hash, tokens, starts)
+            a.row_tok, a.row_len, a.row_hash = row_tok.data_ptr(), row_len.data_ptr(), row_hash.data_ptr()
+            a.group_hash, a.tokens, a.starts = group_hash.data_ptr(), tokens.data_ptr(), starts.data_ptr()
+        for k in names_n + names_r + ("head",):
+            setattr(a, "out_" + k, out[k].data_ptr())
+        a.workspace, a.workspace_bytes = self._ws.data_ptr(), self._ws.numel()
+        check(self.lib.glb_kv_plan(C.byref(a), self._stream()))
         return out
 
     def resample_systematic(self, log_weights, seed, offset):

@@ -15,6 +15,35 @@ import torch
 from transformers.cache_utils import Cache, CacheLayerMixin
 
 
+# ---- the attention of the in-place one-token forward (glb_slab_attention) -------------------------------------------------
+# Registered with transformers' attention interface under its own name; SlabForward points the model's configuration at
+# it.  Whatever is not the in-place forward of the slab set that is current (encodings of whole contexts, gathered
+# batches, CPU runs) goes to the library's own SDPA path, exactly as before.
+_ACTIVE = None  # the SlabKV whose in-place forward is running (set by SlabForward._run)
+_ATTN_NAME = "glb_slab"
+
+
+def _slab_attention_forward(module, query, key, value, attention_mask, dropout=0.0, scaling=None, **kwargs):
+    from transformers.integrations.sdpa_attention import sdpa_attention_forward
+
+    pkv = _ACTIVE
+    layer = None if pkv is None else pkv.layers[module.layer_idx]
+    if layer is None or layer._new_k is None or key is not layer.keys or query.shape[2] != 1:
+        return sdpa_attention_forward(module, query, key, value, attention_mask, dropout=dropout, scaling=scaling, **kwargs)
+    k_new, v_new, layer._new_k, layer._new_v = layer._new_k, layer._new_v, None, None
+    scale = scaling if scaling is not None else query.shape[-1] ** -0.5
+    return pkv.engine.slab_attention(query, k_new, v_new, layer.keys, layer.values, pkv.pos, scale), None
+
+
+def _register_attention():
+    from transformers.masking_utils import ALL_MASK_ATTENTION_FUNCTIONS
+    from transformers.modeling_utils import ALL_ATTENTION_FUNCTIONS
+
+    if _ATTN_NAME not in ALL_ATTENTION_FUNCTIONS:
+        ALL_ATTENTION_FUNCTIONS.register(_ATTN_NAME, _slab_attention_forward)
+        ALL_MASK_ATTENTION_FUNCTIONS.register(_ATTN_NAME, ALL_MASK_ATTENTION_FUNCTIONS["sdpa"])
+
+
 class _SlabLayer(CacheLayerMixin):
     """One layer's K / V slabs.  `update` appends one token per row at `owner.pos` and returns the whole slabs; which
     positions a row may attend to is the 2-D attention mask's business (`SlabKV.attention_mask`)."""
@@ -25,6 +54,7 @@ class _SlabLayer(CacheLayerMixin):
     def __init__(self, owner, idx):
         super().__init__()
         self.owner, self.idx = owner, idx
+        self._new_k = self._new_v = None
 
     def lazy_initialization(self, key_states, value_states):
         o = self.owner
@@ -40,6 +70,9 @@ class _SlabLayer(CacheLayerMixin):
         o = self.owner
         if key_states.shape[0] != o.n or key_states.shape[-2] != 1:
             raise ValueError("SlabKV takes one new token for every particle per forward")
+        if o.fused_attention:  # glb_slab_attention appends: it gets the new K / V where the projection left them
+            self._new_k, self._new_v = key_states, value_states
+            return self.keys, self.values
         o.engine.kv_append(self.keys, key_states, o.pos)
         o.engine.kv_append(self.values, value_states, o.pos)
         return self.keys, self.values
@@ -58,6 +91,7 @@ class SlabKV(Cache):
     def __init__(self, engine, n, cap, n_layers):
         self.engine, self.n, self.cap = engine, n, cap
         self.pos = None  # int32 [n] device: where this forward's token goes (= tokens already held by the row)
+        self.fused_attention = False  # the running forward's attention appends (SlabForward sets it per call)
         super().__init__(layers=[_SlabLayer(self, i) for i in range(n_layers)])
         self._alt = None
         self._ptrs = None
@@ -121,6 +155,9 @@ class _SharedLayer(_SlabLayer):
         if o.in_place:  # the forward's batch IS the slab: row b's token goes to row b, attention reads the slabs
             if key_states.shape[0] != o.n or key_states.shape[-2] != 1:
                 raise ValueError("an in-place forward takes one token for every slab row")
+            if o.fused_attention:
+                self._new_k, self._new_v = key_states, value_states
+                return self.keys, self.values
             eng.kv_append(self.keys, key_states, o.pos)
             eng.kv_append(self.values, value_states, o.pos)
             return self.keys, self.values
@@ -149,6 +186,7 @@ class SharedSlabKV(SlabKV):
         Cache.__init__(self, layers=[_SharedLayer(self, i) for i in range(n_layers)])
         self.engine, self.n, self.cap = engine, n_rows, cap
         self.pos = None
+        self.fused_attention = False
         self.rows = None   # int32 [U]: slab row of every forward row
         self.ident = None  # int32 arange(n)
         self.in_place = False
@@ -194,15 +232,37 @@ class SlabForward:
     rows: 10.4 -> 7.2 ms).  A graph belongs to the slab tensors it was captured over (a resampling `gather` swaps slab
     sets: one graph each).  `graph=False` (or a CPU device) keeps every call eager."""
 
-    def __init__(self, pkv, body, graph=True):
+    def __init__(self, pkv, body, graph=True, fused_attention=True):
         self.pkv, self.body = pkv, body
         self.graph_ok = bool(graph) and torch.cuda.is_available()
         self.calls = 0
         self.graphs = {}  # identity of the slab set -> (graph, ids, pos, hidden, the slab tensors themselves)
+        # glb_slab_attention instead of two appends + a mask + a dense SDPA call per layer: for models whose attention
+        # goes through transformers' attention interface with plain softmax(q k^T * scale) v semantics on a HIP device
+        cfg = getattr(body, "config", None)
+        k0 = pkv.layers[0].keys if pkv.layers and getattr(pkv.layers[0], "is_initialized", False) else None
+        self.fused = bool(fused_attention and cfg is not None and k0 is not None and k0.is_cuda
+                          and hasattr(pkv.engine, "slab_attention")
+                          and pkv.engine.slab_attention_supports(k0.dtype, k0.shape[-1])
+                          and getattr(cfg, "_attn_implementation", None) in ("sdpa", _ATTN_NAME)
+                          and not getattr(cfg, "attn_logit_softcapping", None) and not getattr(cfg, "sliding_window", None)
+                          and not getattr(cfg, "scale_attn_by_inverse_layer_idx", False))
+        if self.fused:
+            _register_attention()
+            cfg._attn_implementation = _ATTN_NAME  # (every other forward of the model falls through to SDPA)
 
     def _run(self, ids, pos):
+        global _ACTIVE
         pkv = self.pkv
         pkv.set_forward_in_place(pos)
+        if self.fused:
+            pkv.fused_attention, _ACTIVE = True, pkv
+            try:  # (no mask: the kernel attends to positions 0 .. pos[r] and nothing else)
+                out = self.body(input_ids=ids, position_ids=pos.view(-1, 1).long(), attention_mask=None,
+                                past_key_values=pkv, use_cache=True)
+            finally:
+                pkv.fused_attention, _ACTIVE = False, None
+            return out.last_hidden_state[:, 0]
         out = self.body(input_ids=ids, position_ids=pos.view(-1, 1).long(), attention_mask=pkv.attention_mask(pos),
                         past_key_values=pkv, use_cache=True)
         return out.last_hidden_state[:, 0]

@@ -125,6 +125,10 @@ class DeviceSIS:
     kv_in_place      with shared KV rows: the fraction of live slab rows from which a forward runs on the slab in place
                      (free rows ride along) instead of gathering the live rows' prefixes into batch order
     kv_graph         the in-place forward is replayed from a hipGraph after its second call (kv.SlabForward)
+    particle_masks   int32 bit rows [n_particles + 1, ceil(V / 32)] on the device: particle i's OWN mask (row i; what a
+                     grammar gives: README.md:57-70 generalised) while it generates, row n_particles once
+                     `max_tokens` are out.  Handed to the fused step raw on every call (GLB_MASK_BITS: masks that change
+                     every step cannot be prepared ahead); every particle is its own reduction unit.
     force_collectives  run the collectives of the multi-rank path (all-gather of log-weights / token matrices, the
                      set-up reductions) through `dist` even when world == 1: a one-rank "nccl" group exercises the RCCL
                      code of an 8-GPU run on a single GPU.
@@ -132,7 +136,7 @@ class DeviceSIS:
 
     def __init__(self, llm, n_particles, prompt_ids, max_tokens, eos_id, seed=0, rng="philox", rank=0, world=1,
                  dist=None, use_prefix_kv=False, use_particle_kv=False, resample_ess=None, force_collectives=False,
-                 share_kv=True, kv_rows=None, kv_in_place=0.75, kv_graph=True):
+                 share_kv=True, kv_rows=None, kv_in_place=0.75, kv_graph=True, particle_masks=None):
         self.llm, self.eng, self.dev = llm, llm.engine, llm.device
         self.N, self.max_tokens, self.eos_id = n_particles, max_tokens, eos_id
         self.rank, self.world, self.dist = rank, world, dist
@@ -193,6 +197,7 @@ class DeviceSIS:
         self._slab_fwd = None
         if self.particle_kv:
             assert not use_prefix_kv
+        self.particle_masks = particle_masks
         self.resample_ess = resample_ess
         self.n_resamples = 0
         self.sync_every = 1  # per-particle-KV steps: how often the active counts are read back (one small D2H copy)
@@ -234,9 +239,8 @@ class DeviceSIS:
         # are refilled by step 0's encoding)
         self._head_cache = None
         self._noise_groups = None  # parity draws: the dedup grouping the noise rows are dealt by (set per step)
-        self._by_first_use = False  # the step's row_of numbers the logits rows by first use (glb_group_contexts' ids)
         self._kv_stale = None  # bool [N]: rows whose KV has to be rebuilt from the context (ancestor on another rank)
-        self._row_of_h = np.full(self.N, -1, np.int32)  # shared KV: particle -> slab row (-1: none), host mirror
+        self._row_of_d = torch.full((self.N,), -1, dtype=torch.int32, device=self.dev)  # shared KV: particle -> slab row (-1: none)
         # active particles over all ranks as of the last exchange (device scalar; read with the step's one D2H copy)
         self._global_active = torch.tensor(self.N * self.world, dtype=torch.int32, device=self.dev)
         self.all_weights = None
@@ -298,7 +302,7 @@ class DeviceSIS:
 
             self._slab_fwd = SlabForward(self.pkv, llm._body, graph=self.kv_graph)
         logits = llm._lm_head(self._slab_fwd(ids, pos))  # [N, V]
-        self._noise_groups, self._by_first_use = None, False
+        self._noise_groups = None
         if self.rng_mode == RNG_NOISE:  # parity draws follow the reference's resolution order: by dedup group
             lengths_eff = torch.where(self.active > 0, self.lengths, torch.ones_like(self.lengths))
             self._noise_groups, _, _ = eng.group_contexts(self.contexts.view(-1), self.starts, lengths_eff)
@@ -310,114 +314,83 @@ class DeviceSIS:
         (A) a context whose prefix sits in a slab row - one new token is fed, its K / V appended in place; when several
         new contexts grew out of one row, the first keeps it and the others get a copy of the prefix in a free row; or
         (B) a context without a row (step 0, an ancestor from another rank, a spent row budget) - encoded from its tokens
-        like the reference does every step, its KV kept if a row is free.  The block table lives on the host (a few KB
-        per step ride on the step's one D2H copy); the rows move on the device."""
+        like the reference does every step, its KV kept if a row is free.  The block table is decided on the device
+        (glb_kv_plan, one launch); the host reads nine words - how many rows of which kind - and launches the forwards."""
         eng, llm, dev, N, R = self.eng, self.llm, self.dev, self.N, self.kv_rows
         ctx_flat = self.contexts.view(-1)
         lengths_eff = torch.where(self.active > 0, self.lengths, torch.ones_like(self.lengths))
         hashes_eff = torch.where(self.active > 0, self.hashes, self._hash_stub)
         group_of, rep, ng = eng.group_contexts(ctx_flat, self.starts, lengths_eff, hashes=hashes_eff)
-        len_rep = lengths_eff[rep.long().clamp(0, N - 1)]  # (entries of `rep` past the group count are unspecified)
-        head = torch.cat([torch.stack([ng[0], self.active.sum().to(torch.int32), self._global_active, eng.error_word()[0]]),
-                          group_of, rep, len_rep]).cpu().numpy()  # the step's one D2H copy
-        U, n_active, n_global = int(head[0]), int(head[1]), int(head[2])
-        eng.raise_if_failed(int(head[3]))
-        g_h, rep_h, L = head[4:4 + N], head[4 + N:4 + N + U], head[4 + 2 * N:4 + 2 * N + U]
-        # ---- block table (host): who keeps its row, who gets a copy, who is encoded
-        old = self._row_of_h[rep_h]
-        has = old >= 0
-        idx_has = np.nonzero(has)[0]
-        _, first = np.unique(old[idx_has], return_index=True)
-        keep = idx_has[np.sort(first)]                      # first group (by id) of every live row keeps it
-        copies = np.setdiff1d(idx_has, keep)                # the others grew out of a row somebody else keeps
-        fresh = np.nonzero(~has)[0]
-        grp_row = np.full(U, -1, np.int32)
-        grp_row[keep] = old[keep]
-        live = np.zeros(R, bool)
-        live[grp_row[keep]] = True
-        free = np.nonzero(~live)[0]
-        need = np.concatenate([copies, fresh])              # copies first: a copy is cheaper than an encoding
-        k = min(len(need), len(free))
-        grp_row[need[:k]] = free[:k]
-        copied = copies[grp_row[copies] >= 0]
-        in_a = np.zeros(U, bool)
-        in_a[keep] = True
-        in_a[copied] = True
-        A, B = np.nonzero(in_a)[0], np.nonzero(~in_a)[0]
-        order = np.concatenate([A, B])                      # logits row r belongs to group order[r]
-        inv = np.empty(U, np.int32)
-        inv[order] = np.arange(U, dtype=np.int32)
-        self._row_of_h = grp_row[g_h]
+        plan = eng.kv_plan(group_of, rep, ng, self._row_of_d, lengths_eff, R, self.cap, by_context=True)
+        head = torch.cat([plan["head"][:6], torch.stack([self.active.sum().to(torch.int32), self._global_active,
+                                                          eng.error_word()[0]])]).cpu().tolist()  # the step's one D2H copy
+        U, nA, nB, n_copied, n_unkept, l_max_b, n_active, n_global = head[:8]
+        eng.raise_if_failed(head[8])
+        self._row_of_d = plan["row_of_context"]
         st = self.kv_stats
         st["forward_rows"] += U
-        st["encoded_rows"] += len(B)
-        st["copied_rows"] += len(copied)
-        st["unkept_rows"] += int((grp_row[B] < 0).sum())
+        st["encoded_rows"] += nB
+        st["copied_rows"] += n_copied
+        st["unkept_rows"] += n_unkept
         st["steps"] += 1
-        to_dev = lambda a, dt=torch.int32: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dt, non_blocking=True)
         logits_parts = []
-        if len(A):
-            if len(copied):
-                src_full, len_full = np.full(R, -1, np.int32), np.zeros(R, np.int32)
-                src_full[grp_row[copied]] = old[copied]
-                len_full[grp_row[copied]] = L[copied] - 1
-                self.pkv.copy_rows(to_dev(src_full), to_dev(len_full))
-            if self.kv_in_place is not None and len(A) >= self.kv_in_place * R:
-                # most rows are live: the forward runs on the slab rows where they lie (free rows ride along with a
-                # dummy token) instead of gathering the live rows' prefixes into batch order
-                rows_a = grp_row[A]
-                pos_full, rep_full = np.zeros(R, np.int32), np.zeros(R, np.int64)
-                pos_full[rows_a] = L[A] - 1
-                rep_full[rows_a] = rep_h[A]
-                pos_d = to_dev(pos_full)
-                ids = self.contexts[to_dev(rep_full, torch.int64), pos_d.long()].view(-1, 1).long()
+        if nA:
+            if n_copied:
+                self.pkv.copy_rows(plan["copy_src"], plan["copy_len"])
+            if self.kv_in_place is not None and nA >= self.kv_in_place * R:
+                # most rows are live: the forward runs on the slab rows where they lie (rows outside it ride along with a
+                # dummy token at position 0) instead of gathering the live rows' prefixes into batch order
+                pos_d = plan["pos_of_row"]
+                ids = self.contexts[plan["ctx_of_row"].clamp_min(0).long(), pos_d.long()].view(-1, 1).long()
                 if self._slab_fwd is None or self._slab_fwd.pkv is not self.pkv:
                     from .kv import SlabForward
 
                     self._slab_fwd = SlabForward(self.pkv, llm._body, graph=self.kv_graph)
                 hidden = self._slab_fwd(ids, pos_d)
-                logits_parts.append(llm._lm_head(hidden[to_dev(rows_a, torch.int64)]))
+                logits_parts.append(llm._lm_head(hidden.index_select(0, plan["rows_a"][:nA].long())))
                 st["in_place_steps"] += 1
             else:
-                pos_a = to_dev(L[A] - 1)
-                reps_a = to_dev(rep_h[A], torch.int64)
-                ids = self.contexts[reps_a, pos_a.long()].view(-1, 1).long()
-                self.pkv.set_forward(to_dev(grp_row[A]), pos_a)
+                pos_a = plan["pos_a"][:nA].contiguous()
+                ids = self.contexts[plan["ctx_a"][:nA].long(), pos_a.long()].view(-1, 1).long()
+                self.pkv.set_forward(plan["rows_a"][:nA].contiguous(), pos_a)
                 out = llm._body(input_ids=ids, position_ids=pos_a.view(-1, 1).long(),
                                 attention_mask=self.pkv.attention_mask(pos_a), past_key_values=self.pkv, use_cache=True)
                 logits_parts.append(llm._lm_head(out.last_hidden_state[:, 0]))
-        if len(B):
-            sel = to_dev(rep_h[B])
-            l_max = int(L[B].max())
-            ids, am, pos, last = eng.gather_padded(ctx_flat, self.starts, lengths_eff, sel, len(B), None, 0, 0, l_max)
+        if nB:
+            sel = plan["ctx_b"][:nB].contiguous()
+            ids, am, pos, last = eng.gather_padded(ctx_flat, self.starts, lengths_eff, sel, nB, None, 0, 0, l_max_b)
             out = llm._body(input_ids=ids, attention_mask=am, position_ids=pos, use_cache=True)
-            h_last = out.last_hidden_state[torch.arange(len(B), device=dev), last.long()]
+            h_last = out.last_hidden_state[torch.arange(nB, device=dev), last.long()]
             logits_parts.append(llm._lm_head(h_last))
-            stored = B[grp_row[B] >= 0]
-            if len(stored):
+            if nB > n_unkept:  # rows that keep the KV of what was just encoded
                 src = [(ly.keys.contiguous(), ly.values.contiguous()) for ly in out.past_key_values.layers]
                 if self.pkv is None:
                     from .kv import SharedSlabKV
 
                     self.pkv = SharedSlabKV(eng, R, self.cap, len(src))
-                src_full, len_full = np.full(R, -1, np.int32), np.zeros(R, np.int32)
-                where_b = np.full(U, -1, np.int32)
-                where_b[B] = np.arange(len(B), dtype=np.int32)
-                src_full[grp_row[stored]] = where_b[stored]
-                len_full[grp_row[stored]] = L[stored]
-                self.pkv.fill_rows(src, to_dev(src_full), to_dev(len_full))
+                rows_b = plan["rows_b"][:nB].long()
+                slot = torch.where(rows_b >= 0, rows_b, torch.full_like(rows_b, R))  # (rows nobody keeps: a slot past the end)
+                src_full = torch.full((R + 1,), -1, dtype=torch.int32, device=dev)
+                len_full = torch.zeros(R + 1, dtype=torch.int32, device=dev)
+                src_full[slot] = torch.arange(nB, dtype=torch.int32, device=dev)
+                len_full[slot] = lengths_eff[sel.long()]
+                src_full[R] = -1
+                self.pkv.fill_rows(src, src_full[:R].contiguous(), len_full[:R].contiguous())
         logits = logits_parts[0] if len(logits_parts) == 1 else torch.cat(logits_parts)
-        self._rep = to_dev(rep_h[order])
+        self._rep = torch.cat([plan["ctx_a"][:nA], plan["ctx_b"][:nB]])  # the context behind every logits row
         self._noise_groups = group_of  # parity draws follow the reference's resolution order: by dedup group
-        self._by_first_use = False  # (rows are in block-table order: kept rows first)
-        return self._finish_step(logits, to_dev(inv[g_h]), U, n_active, n_global, time_kernel, l_max=1)
+        row_of = plan["logits_row"][group_of.long()]
+        return self._finish_step(logits, row_of, U, n_active, n_global, time_kernel, l_max=1)
 
     def _finish_step(self, logits, group_of, U, n_active, n_global, time_kernel, l_max):
         eng, llm, N = self.eng, self.llm, self.N
         V = logits.shape[-1]
         mask_id = ((self.lengths - self.prompt_len) >= self.max_tokens).to(torch.int32)
-        kw = llm.step_masks(logits.dtype)
-        if kw:
+        kw = llm.step_masks(logits.dtype) if self.particle_masks is None else {}
+        if self.particle_masks is not None:  # one mask per particle, raw bit rows: per-particle ids, no dedup of the math
+            own = torch.arange(N, dtype=torch.int32, device=self.dev)
+            kw = dict(mask_kind=1, mask=self.particle_masks, mask_id=torch.where(mask_id > 0, torch.full_like(own, N), own))
+        elif kw:
             # The mask depends on the number of generated tokens only; with prompts of one length that makes it a
             # function of the context, so identical contexts (one logits row) share it: ids go per ROW and a shared
             # row is reduced once (hf.py:214-220 dedup carried through the particle math).
@@ -429,8 +402,6 @@ class DeviceSIS:
                 kw["mask_id"] = mask_id
         if self.rng_mode == RNG_NOISE:
             kw["noise"] = self._parity_noise(self._noise_groups if self._noise_groups is not None else group_of, V)
-        if group_of is not None and self._by_first_use:
-            kw["rows_by_first_use"] = True
         if time_kernel:
             # two clocks on the fused call: HIP events the launch itself carries as its start / stop stamps (the launch
             # duration, as rocprofv3 reports it), and a pair recorded around the call on the stream (adds the two marker
@@ -488,7 +459,7 @@ class DeviceSIS:
             eng.raise_if_failed(int(head[2]))
             out, group_of, rep, U = self._encode_into_slabs(None)
             self._rep = rep
-            self._noise_groups, self._by_first_use = None, True
+            self._noise_groups = None
             last = (self.lengths[rep[:U].long()] - 1).long()
             h_last = out.last_hidden_state[torch.arange(U, device=dev), last]
             return self._finish_step(llm._lm_head(h_last), group_of, U, n_active, n_global, time_kernel, self.max_len_now)
@@ -521,7 +492,7 @@ class DeviceSIS:
                         use_cache=cache is not None)
         h_last = out.last_hidden_state[torch.arange(U, device=dev), last.long()]
         logits = llm._lm_head(h_last)  # [U, V]
-        self._noise_groups, self._by_first_use = None, True
+        self._noise_groups = None
         return self._finish_step(logits, group_of, U, n_active, n_global, time_kernel, l_max)
 
     def _parity_noise(self, group_of, V):
@@ -580,9 +551,9 @@ class DeviceSIS:
         # equal weights: log of the population's mean weight
         self.log_weights = (lse - float(np.log(n_total))).expand(N).contiguous()
         if self.share_kv:  # re-point: a particle takes its ancestor's row; ancestors of another rank leave it without one
-            local = (mine - self.rank * N).cpu().numpy()
+            local = mine - self.rank * N
             ok = (local >= 0) & (local < N)
-            self._row_of_h = np.where(ok, self._row_of_h[np.clip(local, 0, N - 1)], -1).astype(np.int32)
+            self._row_of_d = torch.where(ok, self._row_of_d[local.clamp(0, N - 1).long()], torch.full_like(local, -1))
         elif self.particle_kv and self.pkv is not None:
             local = mine - self.rank * N
             is_local = (local >= 0) & (local < N)
@@ -684,7 +655,8 @@ class SisBenchWorkload:
     V = 128256, 512 particles (config 4: 4096 over 8 GPUs)."""
 
     def __init__(self, eng, dev, rank, world, dist, n_particles=1024, max_tokens=10, prefix_kv=False, particle_kv=False,
-                 model="gpt2", n_prompts=1, resample=False, force_collectives=False, kv_in_place=0.75):
+                 model="gpt2", n_prompts=1, resample=False, force_collectives=False, kv_in_place=0.75,
+                 per_particle_masks=False):
         from .llm import AsyncAmdLM
 
         if model == "gpt2":
@@ -713,6 +685,13 @@ class SisBenchWorkload:
         eos1 = torch.full((V,), float("-inf"), device=dev)
         eos1[cfg.eos_token_id] = 0.0
         self.llm.register_masks(torch.stack([valid, eos1]))
+        pm = None
+        if per_particle_masks:  # every particle its own random third forbidden (+ the EOS-only row behind them)
+            own = torch.where(torch.rand((n_particles, V), device=dev, generator=g) < 1 / 3, float("-inf"), 0.0)
+            own[:, cfg.eos_token_id] = 0.0
+            pm, _ = eng.mask_to_bits(torch.cat([own, eos1[None]]))
+            del own
+        self.per_particle_masks = per_particle_masks
         self.V, self.N, self.max_tokens = V, n_particles, max_tokens
         self.particles_per_step = n_particles
         rs = np.random.default_rng(99)
@@ -722,7 +701,7 @@ class SisBenchWorkload:
         self.sis = DeviceSIS(self.llm, n_particles, prompts, max_tokens, cfg.eos_token_id,
                              seed=1234, rank=rank, world=world, dist=dist, use_prefix_kv=prefix_kv,
                              use_particle_kv=particle_kv, resample_ess=1.0 if resample else None,
-                             force_collectives=force_collectives, kv_in_place=kv_in_place)
+                             force_collectives=force_collectives, kv_in_place=kv_in_place, particle_masks=pm)
         self.prefix_kv = prefix_kv
         self.particle_kv = particle_kv
         self.resample = resample
@@ -746,7 +725,8 @@ class SisBenchWorkload:
         U, _ = self.sis.step(time_kernel=timed)
         if timed:
             # algorithmic bytes of this call: the unique logits rows once + mask bit rows + outputs
-            self._bytes.append(U * self.V * self.elem + 2 * ((self.V + 31) // 32) * 4 + self.N * 8)
+            n_masks = self.N + 1 if self.per_particle_masks else 2
+            self._bytes.append(U * self.V * self.elem + n_masks * ((self.V + 31) // 32) * 4 + self.N * 8)
             self.unique_hist.append(U)
             self.fed_hist.append(int(self.sis.last_stats["l_max"]))  # tokens per forward row of this step
 
@@ -766,7 +746,8 @@ class SisBenchWorkload:
 
     def config(self):
         return {"workload": f"SIS step: {self.N} particles/GPU, {self.model_name}, prompt len 8, <=10 new "
-                            "tokens, 2 shared bit masks, device-resident population, Philox draws"
+                            "tokens, " + (f"{self.N} per-particle bit masks handed over raw every step" if self.per_particle_masks
+                                          else "2 shared bit masks") + ", device-resident population, Philox draws"
                             + (f", {self.n_prompts} distinct shared prompts" if self.n_prompts > 1 else "")
                             + (", prompt KV cached (cache_kv semantics, BASELINE config 3)" if self.prefix_kv else "")
                             + (", device-resident KV rows shared by particles with equal contexts (one new token per distinct "

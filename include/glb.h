@@ -84,16 +84,6 @@ int glb_device_count(void);
  * a row shared by several particles is then reduced once and only the draw is done per particle (any number of
  * particles per row: the reduction leaves what every draw needs, whoever makes it).
  */
-/* glb_step_args.flags */
-enum {
-  /* row_of numbers the logits rows by first use: row_of[p] <= p for every particle p (what glb_group_contexts'
-     out_group_of is).  With row_mask_id / no mask - rows reduced once - the one-launch step then deals every particle's
-     finishing wave a fixed distance behind its row's reducing waves inside the grid instead of at its end, so most
-     draws are made while the rows are still streaming.  A speed hint: results do not depend on it, and a row_of that
-     breaks the promise only makes finishing waves wait longer (bounded as ever). */
-  GLB_STEP_ROWS_BY_FIRST_USE = 1
-};
-
 typedef struct glb_step_args {
   uint32_t struct_size; /* sizeof(glb_step_args) — ABI guard */
   /* logits of the unique contexts */
@@ -130,7 +120,7 @@ typedef struct glb_step_args {
                         finishing wave gave up waiting for its row's records - a failed launch, never a result) */
   float *out_margin; /* [n_particles] GLB_RNG_NOISE only: (winner - runner-up) / winner of the race e_j / E_j, i.e. how
                         far the draw is from a tie that float rounding could flip (1 if there is no runner-up) */
-  int32_t flags;     /* GLB_STEP_* bits, 0 by default (unknown bits: GLB_EINVAL) */
+  int32_t flags;     /* must be 0 (no bits are defined) */
   /* device scratch of >= glb_step_workspace_bytes(...) bytes, 32-byte aligned: the per-chunk records (64 bytes per
      row and 4096-token chunk) the reducing waves hand to the per-particle waves (and, for GLB_MASK_BITS, the prepared
      masks).  See glb_workspace_init. */
@@ -316,6 +306,81 @@ int glb_kv_gather_rows(const void *const *src, void *const *dst, int64_t n_tenso
                        const int32_t *len_of, int32_t elem_bytes, void *hip_stream);
 int glb_gather_rows_i32(const int32_t *src, int64_t src_ld, const int32_t *row_of, int64_t n, int64_t width,
                         int32_t *dst, int64_t dst_ld, void *hip_stream);
+
+/*
+ * KV rows shared between contexts, decided on the device.  The reference keeps per-token KV on trie
+ * nodes (cache.py:103-191, mlx.py:177-318); here the prefixes sit in slab rows and a block table says which.
+ *
+ * glb_match_rows: for every dedup group g < *n_groups (its context = rep[g]), the table row that holds exactly the
+ *   context, else the row that holds its first L - 1 tokens, else -1 (the smallest row index wins among equals).  The
+ *   table is (row_tok [n_rows, cap] int32, row_len [n_rows] - 0: the row holds nothing -, row_hash [n_rows]: the hash of
+ *   glb_hash_contexts); hashes only select candidates, every candidate's tokens are compared.  out_hash [n] (nullable): the
+ *   groups' own hashes, for the table update of glb_kv_plan.  Contexts longer than cap match nothing.
+ *
+ * glb_kv_plan: the block table of one step, one small launch.  In: the dedup of the step's contexts (group_of [n], rep,
+ *   n_groups: glb_group_contexts' outputs), the contexts' lengths, and where every group's prefix sits now - old_row[g]
+ *   (old_row_by_context == 0: glb_match_rows' output) or old_row[rep[g]] (old_row_by_context != 0: the previous step's
+ *   out_row_of_context: a population that only appends).  Decides: the first group (by id) of every live row KEEPS it and
+ *   appends in place; the other groups that grew out of that row get a COPY of the prefix in a free row (copy-on-append),
+ *   groups without a row whose context fits one get a free row to be filled from an ENCODING, in that order, for as long as
+ *   free rows last - handed out by ascending row index, or longest unused first when row_stamps [n_rows] (int64, the call
+ *   that used the row last; updated to call_no for every row in use) is given.  Out (int32, device):
+ *     out_group_row [n]       the group's row from now on (-1: none)
+ *     out_logits_row [n]      the forward row of the group: groups with a prefix in a row first, the ones to encode behind
+ *     out_rows_a / out_ctx_a / out_pos_a [n]   per forward row k < head[1]: slab row, context index, position of the token fed
+ *     out_ctx_b / out_rows_b [n]               per encoded row k < head[2]: context index, the row that keeps its KV (-1: none)
+ *     out_copy_src / out_copy_len [n_rows]     row r takes out_copy_len[r] positions of row out_copy_src[r] (-1: nothing)
+ *     out_ctx_of_row / out_pos_of_row [n_rows] for a forward that runs on ALL rows where they lie: the context that feeds
+ *                                              row r and the position its token goes to (-1: the row is not in this
+ *                                              forward; -2: it is being filled from an encoding)
+ *     out_row_of_context [n]  (nullable) out_group_row[group_of[i]]: next step's old_row
+ *     out_head [8]            n_groups, rows with a prefix, rows to encode, copies, encoded rows nobody keeps, the longest
+ *                             context to encode, free rows before the call, 0 - all the host has to read
+ *   With row_tok != null the table rows of every group that holds a row now are rewritten (tokens zero-padded to cap,
+ *   length, group_hash[g]).  workspace: glb_kv_plan_workspace(n, n_rows) bytes, 4-byte aligned.
+ */
+int glb_match_rows(const int32_t *tokens, const int64_t *starts, const int32_t *lengths, const int32_t *rep,
+                   const int32_t *n_groups, int64_t n, const int32_t *row_tok, const int32_t *row_len,
+                   const uint64_t *row_hash, int64_t n_rows, int64_t cap, int32_t *out_old_row, uint64_t *out_hash,
+                   void *hip_stream);
+typedef struct glb_kv_plan_args {
+  uint32_t struct_size; /* sizeof(glb_kv_plan_args) - ABI guard */
+  int64_t n, n_rows, cap;
+  const int32_t *group_of, *rep, *n_groups;
+  const int32_t *old_row;
+  int32_t old_row_by_context;
+  const int32_t *lengths;
+  int64_t *row_stamps; /* nullable */
+  int64_t call_no;
+  /* the table of what the rows hold (all nullable together) */
+  int32_t *row_tok, *row_len;
+  uint64_t *row_hash;
+  const uint64_t *group_hash;
+  const int32_t *tokens;
+  const int64_t *starts;
+  /* outputs */
+  int32_t *out_group_row, *out_logits_row, *out_rows_a, *out_ctx_a, *out_pos_a, *out_ctx_b, *out_rows_b, *out_copy_src,
+      *out_copy_len, *out_ctx_of_row, *out_pos_of_row, *out_row_of_context, *out_head;
+  void *workspace;
+  size_t workspace_bytes;
+} glb_kv_plan_args;
+size_t glb_kv_plan_workspace(int64_t n, int64_t n_rows);
+int glb_kv_plan(const glb_kv_plan_args *args, void *hip_stream);
+
+/*
+ * Attention of a one-token forward over KV slab rows where they lie (the read side of the device-resident KV, SURVEY.md
+ * §8 f1; the reference hands zero-padded per-query KV to the model's own attention, hf.py:247-281): for every row r and
+ * query head h, softmax(q . K[r, h / G, 0 .. pos[r]] * scale) . V[r, h / G, 0 .. pos[r]], where position pos[r] is the token
+ * of this forward - its K / V (k_new, v_new: [n_rows, kv_heads, head_dim] by element strides, the projection's output)
+ * are used from where they are AND written to slab position pos[r] (glb_kv_append, fused).  q by element strides
+ * (row, head), unit inner stride; slabs [n_rows, kv_heads, cap, head_dim] contiguous; out [n_rows, heads, head_dim]
+ * contiguous; all of one dtype, float32 accumulation; head_dim 64 or 128 (GLB_EUNSUPPORTED otherwise); every pointer and
+ * stride a multiple of 16 bytes.  One launch per layer instead of two appends, a mask and a dense SDPA call.
+ */
+int glb_slab_attention(const void *q, int64_t q_stride_row, int64_t q_stride_head, const void *k_new, const void *v_new,
+                       int64_t kv_stride_row, int64_t kv_stride_head, void *k_slab, void *v_slab, const int32_t *pos,
+                       int64_t n_rows, int64_t heads, int64_t kv_heads, int64_t cap, int64_t head_dim, float scale,
+                       int32_t dtype, void *out, void *hip_stream);
 
 /*
  * Systematic resampling of the whole population from the all-gathered log-weights (the step the all-gather of

@@ -280,3 +280,94 @@ def trie_reduce(ws, flat, op=0, from_logprobs=False):
     if rc:
         raise RuntimeError(f"orc_trie_reduce rc={rc}")
     return out
+
+
+# ---- KV rows shared between contexts: the block table (layer B of glb_match_rows / glb_kv_plan; integer work) -------
+def ctx_hash(ctx):
+    """The library's context hash (glb_hash_contexts): an FNV-style fold, one token at a time."""
+    M = (1 << 64) - 1
+    h = 0xcbf29ce484222325
+    for t in ctx:
+        h ^= int(t) & 0xffffffff
+        h = (h * 0x100000001b3) & M
+        h ^= h >> 29
+    return h
+
+
+def match_rows(contexts, rep, n_groups, row_tok, row_len, row_hash):
+    """For every dedup group the smallest table row that holds exactly its context, else the smallest row that holds
+    its first L - 1 tokens, else -1; plus the groups' hashes.  (The reference's counterpart is the trie walk that finds
+    the deepest node with KV, hf.py:314-344 / cache.py:103-191.)"""
+    R, cap = row_tok.shape
+    old = np.full(n_groups, -1, np.int32)
+    gh = np.zeros(n_groups, np.uint64)
+    for u in range(n_groups):
+        c = [int(t) for t in contexts[rep[u]]]
+        L = len(c)
+        gh[u] = ctx_hash(c)
+        if L == 0 or L > cap:
+            continue
+        exact = par = -1
+        for r in range(R):
+            rl = int(row_len[r])
+            if rl <= 0:
+                continue
+            if rl == L and int(row_hash[r]) == int(gh[u]) and list(row_tok[r, :rl]) == c:
+                exact = r if exact < 0 else exact
+            elif rl == L - 1 and int(row_hash[r]) == ctx_hash(c[:-1]) and list(row_tok[r, :rl]) == c[:-1]:
+                par = r if par < 0 else par
+        old[u] = exact if exact >= 0 else par
+    return old, gh
+
+
+def kv_plan(group_of, rep, n_groups, old, lengths, n_rows, cap, stamps=None, call_no=0):
+    """The block table of one step, as include/glb.h states it for glb_kv_plan (`old`: per GROUP).  Returns a dict of
+    int32 arrays with the library's output names; `stamps` (int64, optional) is updated in place."""
+    n, U, R = len(group_of), int(n_groups), int(n_rows)
+    L = np.array([int(lengths[rep[u]]) for u in range(U)], np.int64)
+    keeper = {}
+    for u in range(U):
+        if old[u] >= 0:
+            keeper.setdefault(int(old[u]), u)
+    keep = [u for u in range(U) if old[u] >= 0 and keeper[int(old[u])] == u]
+    cand = [u for u in range(U) if old[u] >= 0 and keeper[int(old[u])] != u]
+    fresh = [u for u in range(U) if old[u] < 0 and L[u] <= cap]
+    live = {int(old[u]) for u in keep}
+    free = [r for r in range(R) if r not in live]
+    if stamps is not None:
+        free.sort(key=lambda r: (int(stamps[r]), r))
+    grp_row = np.full(n, -1, np.int32)
+    for u in keep:
+        grp_row[u] = old[u]
+    for u, r in zip(cand + fresh, free):
+        grp_row[u] = r
+    in_a = [u for u in range(U) if old[u] >= 0 and grp_row[u] >= 0]
+    in_b = [u for u in range(U) if not (old[u] >= 0 and grp_row[u] >= 0)]
+    out = {k: np.zeros(n, np.int32) for k in ("logits_row", "rows_a", "ctx_a", "pos_a", "ctx_b", "rows_b", "row_of_context")}
+    out["group_row"] = grp_row
+    out["copy_src"], out["copy_len"] = np.full(R, -1, np.int32), np.zeros(R, np.int32)
+    out["ctx_of_row"], out["pos_of_row"] = np.full(R, -1, np.int32), np.zeros(R, np.int32)
+    copied = 0
+    for k, u in enumerate(in_a):
+        r = int(grp_row[u])
+        out["logits_row"][u] = k
+        out["rows_a"][k], out["ctx_a"][k], out["pos_a"][k] = r, rep[u], L[u] - 1
+        out["ctx_of_row"][r], out["pos_of_row"][r] = rep[u], L[u] - 1
+        if r != old[u]:
+            out["copy_src"][r], out["copy_len"][r] = old[u], L[u] - 1
+            copied += 1
+    for k, u in enumerate(in_b):
+        out["logits_row"][u] = len(in_a) + k
+        out["ctx_b"][k], out["rows_b"][k] = rep[u], grp_row[u]
+        if grp_row[u] >= 0:
+            out["ctx_of_row"][grp_row[u]] = -2
+    if stamps is not None:
+        for u in range(U):
+            if grp_row[u] >= 0:
+                stamps[grp_row[u]] = call_no
+    out["row_of_context"] = grp_row[np.asarray(group_of, np.int64)].astype(np.int32)
+    out["head"] = np.array([U, len(in_a), len(in_b), copied, sum(1 for u in in_b if grp_row[u] < 0),
+                            max([int(L[u]) for u in in_b], default=0), len(free), 0], np.int32)
+    out["n_valid"] = dict(group_row=U, logits_row=U, rows_a=len(in_a), ctx_a=len(in_a), pos_a=len(in_a), ctx_b=len(in_b),
+                          rows_b=len(in_b), row_of_context=n)
+    return out

@@ -32,9 +32,7 @@ class CpuOracleEngine:
 
     def step(self, logits, vocab=None, row_of=None, mask_kind=0, mask=None, mask_id=None, rng_mode=0, noise=None,
              seed=0, offset=0, particle_base=0, logit_scale=1.0, want_lse=True, out=None, row_mask_id=None,
-             out_margin=None, rows_by_first_use=False):
-        if rows_by_first_use and row_of is not None:  # the promise GLB_STEP_ROWS_BY_FIRST_USE makes
-            assert bool((row_of.cpu() <= torch.arange(row_of.numel())).all())
+             out_margin=None):
         V = logits.shape[1] if vocab is None else vocab
         x = _logits_np(logits[:, :V])
         if isinstance(mask, _Prepared):
@@ -190,6 +188,36 @@ class CpuOracleEngine:
             out.copy_(res)
             return out
         return res
+
+    def match_rows(self, tokens, starts, lengths, rep, n_groups, row_tok, row_len, row_hash):
+        ctxs = self._ctxs(tokens, starts, lengths)
+        U = int(n_groups.item())
+        old, gh = O.match_rows(ctxs, _np(rep), U, _np(row_tok), _np(row_len), _np(row_hash).view(np.uint64))
+        n = len(ctxs)
+        old_f, gh_f = np.full(n, -1, np.int32), np.zeros(n, np.uint64)
+        old_f[:U], gh_f[:U] = old, gh
+        return torch.from_numpy(old_f), torch.from_numpy(gh_f.view(np.int64).copy())
+
+    def kv_plan(self, group_of, rep, n_groups, old_row, lengths, n_rows, cap, by_context=False, stamps=None, call_no=0,
+                table=None):
+        U = int(n_groups.item())
+        rep_h, old_h = _np(rep), _np(old_row)
+        old_g = old_h[rep_h[:U]] if by_context else old_h[:U]
+        st = None if stamps is None else stamps.numpy()  # (updated in place)
+        out = O.kv_plan(_np(group_of), rep_h, U, old_g, _np(lengths), n_rows, cap, stamps=st, call_no=call_no)
+        out.pop("n_valid")
+        if table is not None:
+            row_tok, row_len, row_hash, group_hash, tokens, starts = table
+            t, s, gh = _np(tokens), _np(starts), _np(group_hash)
+            for u in range(U):
+                r = int(out["group_row"][u])
+                if r >= 0:
+                    L = int(_np(lengths)[rep_h[u]])
+                    row_tok[r] = 0
+                    row_tok[r, :L] = torch.from_numpy(t[s[rep_h[u]]:s[rep_h[u]] + L].copy())
+                    row_len[r] = L
+                    row_hash[r] = int(gh[u])
+        return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in out.items()}
 
     def resample_systematic(self, log_weights, seed, offset):
         anc, lse = O.resample_systematic(_np(log_weights), seed, offset)

@@ -206,6 +206,32 @@ def test_device_sis_parity_draws_with_kv_rows_run_reset_run(llm, gold, share):
         sis.reset()  # (starts the seeded noise stream over as well)
 
 
+def test_device_sis_with_one_mask_per_particle(llm, gold):
+    """`particle_masks`: every particle brings its own bit mask (what a grammar gives), handed to the fused
+    step raw on every call.  With every particle's mask equal to the README's `valid` mask the run IS the reference's
+    golden run; with particles that may only emit one token each, that is what they emit."""
+    from genlm_backend_amd.sis import DeviceSIS
+
+    masks = torch.from_numpy(gold["sis_masks"])
+    llm.register_masks(masks)
+    prompt = [int(t) for t in gold["sis_prompt"]]
+    bits, _ = llm.engine.mask_to_bits(masks)
+    pm = torch.cat([bits[:1].expand(16, -1), bits[1:2]]).contiguous()
+    sis = DeviceSIS(llm, 16, prompt, max_tokens=10, eos_id=0, seed=1234, rng="torch", particle_masks=pm)
+    assert sis.run() == int(gold["sis_steps"][0])
+    _check_sis(*sis.results(), gold)
+    V = masks.shape[1]
+    only = torch.full((17, V), float("-inf"))
+    for i in range(16):
+        only[i, 3 + i] = 0.0
+    only[16, 0] = 0.0
+    pm2, _ = llm.engine.mask_to_bits(only)
+    sis = DeviceSIS(llm, 16, prompt, max_tokens=3, eos_id=0, seed=1, particle_masks=pm2)
+    sis.run()
+    ctx, _ = sis.results()
+    assert [list(map(int, c)) for c in ctx] == [[3 + i] * 3 for i in range(16)]
+
+
 @pytest.mark.parametrize("use_kv", [False, True])
 def test_device_sis_matches_reference(llm, gold, use_kv):
     from genlm_backend_amd.sis import DeviceSIS

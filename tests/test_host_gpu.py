@@ -966,3 +966,166 @@ def test_failed_launch_raises_on_every_host_path(engine, wide_llm):
     lp = llm.batch_next_token_logprobs_sync(ctxs)
     assert not bool(torch.isnan(lp).any())
     engine.check()
+
+
+# ---- the block table of the shared KV rows, decided on the device (glb_match_rows / glb_kv_plan) ---------------------------
+@pytest.mark.parametrize("n,distinct,R,cap,lru", [(64, 20, 40, 12, False), (1024, 900, 1024, 19, False), (1024, 700, 512, 19, True),
+                                                  (3000, 2500, 3500, 16, True), (5, 5, 3, 8, False), (2500, 40, 64, 10, True)])
+def test_kv_plan_matches_oracle(engine, oracle, n, distinct, R, cap, lru):
+    rng = np.random.default_rng(n + R)
+    ctxs = synth.contexts(n + distinct, n, distinct, lo=1, hi=cap + 3)  # some contexts longer than a row
+    tok, st, ln = oracle.ragged(ctxs)
+    g_o, rep_o, ng_o = oracle.group_contexts(ctxs)
+    dev = engine.device
+    tok_d, st_d, ln_d = _dev(tok, dev), _dev(st, dev), _dev(ln, dev)
+    g, rep, ng = engine.group_contexts(tok_d, st_d, ln_d)
+    # where the groups' prefixes sit: some in rows of their own, some sharing a row (copy-on-append), some nowhere
+    old = rng.integers(-1, R, size=n).astype(np.int32)
+    old[rng.random(n) < 0.3] = -1
+    share = rng.random(n) < 0.3
+    old[share] = old[rng.integers(0, n, size=int(share.sum()))]
+    stamps = rng.integers(0, 5, size=R).astype(np.int64) if lru else None
+    want = oracle.kv_plan(g_o, np.concatenate([rep_o, np.zeros(n - ng_o, np.int32)]), ng_o, old[:ng_o], ln, R, cap,
+                          stamps=None if stamps is None else stamps.copy(), call_no=7)
+    st_dv = None if stamps is None else _dev(stamps, dev)
+    got = engine.kv_plan(g, rep, ng, _dev(old, dev), ln_d, R, cap, stamps=st_dv, call_no=7)
+    torch.cuda.synchronize()
+    assert got["head"].cpu().tolist() == want["head"].tolist()
+    for k, cnt in want["n_valid"].items():
+        assert np.array_equal(got[k].cpu().numpy()[:cnt], want[k][:cnt]), k
+    for k in ("copy_src", "copy_len", "ctx_of_row", "pos_of_row"):
+        assert np.array_equal(got[k].cpu().numpy(), want[k]), k
+    if lru:
+        st_w = stamps.copy()
+        oracle.kv_plan(g_o, np.concatenate([rep_o, np.zeros(n - ng_o, np.int32)]), ng_o, old[:ng_o], ln, R, cap, stamps=st_w, call_no=7)
+        assert np.array_equal(st_dv.cpu().numpy(), st_w)
+    # the same table handed over per CONTEXT (a population that only appends: the previous plan's row_of_context)
+    old_ctx = np.full(n, -1, np.int32)
+    old_ctx[rep_o] = old[:ng_o]
+    got2 = engine.kv_plan(g, rep, ng, _dev(old_ctx, dev), ln_d, R, cap, by_context=True,
+                          stamps=None if stamps is None else _dev(stamps, dev), call_no=7)
+    assert got2["head"].cpu().tolist() == want["head"].tolist()
+    assert np.array_equal(got2["row_of_context"].cpu().numpy(), want["row_of_context"])
+
+
+@pytest.mark.parametrize("n,distinct,R,cap", [(50, 30, 64, 12), (1024, 1000, 1280, 24), (300, 10, 16, 6)])
+def test_match_rows_and_table_update(engine, oracle, n, distinct, R, cap):
+    """glb_match_rows finds the row that holds a context or its first L - 1 tokens - every candidate's tokens are compared,
+    also behind EQUAL hashes of unequal contexts - and glb_kv_plan rewrites the table rows of whoever holds a row."""
+    rng = np.random.default_rng(n)
+    ctxs = synth.contexts(n + 1, n, distinct, lo=1, hi=cap + 2)
+    tok, st, ln = oracle.ragged(ctxs)
+    g_o, rep_o, ng_o = oracle.group_contexts(ctxs)
+    row_tok = np.zeros((R, cap), np.int32)
+    row_len = np.zeros(R, np.int32)
+    row_hash = np.zeros(R, np.uint64)
+    rows = rng.permutation(R)
+    k = 0
+    for u in range(0, ng_o, 2):  # every other group has its parent in a row, some their whole context, some an impostor
+        c = list(ctxs[rep_o[u]])
+        if len(c) > cap or k + 2 >= R:
+            continue
+        held = c if u % 4 == 0 else c[:-1]
+        if held:
+            r = rows[k]; k += 1
+            row_tok[r, :len(held)] = held; row_len[r] = len(held); row_hash[r] = oracle.ctx_hash(held)
+            imp = rows[k]; k += 1  # same hash and length, other tokens: must not match
+            fake = [t + 1 for t in held]
+            row_tok[imp, :len(held)] = fake; row_len[imp] = len(held); row_hash[imp] = oracle.ctx_hash(held)
+    dev = engine.device
+    tok_d, st_d, ln_d = _dev(tok, dev), _dev(st, dev), _dev(ln, dev)
+    g, rep, ng = engine.group_contexts(tok_d, st_d, ln_d)
+    rt, rl, rh = _dev(row_tok, dev), _dev(row_len, dev), _dev(row_hash.view(np.int64), dev)
+    old, gh = engine.match_rows(tok_d, st_d, ln_d, rep, ng, rt, rl, rh)
+    old_o, gh_o = oracle.match_rows(ctxs, rep_o, ng_o, row_tok, row_len, row_hash)
+    assert np.array_equal(old.cpu().numpy()[:ng_o], old_o)
+    assert np.array_equal(gh.cpu().numpy()[:ng_o].view(np.uint64), gh_o)
+    assert (old_o >= 0).sum() > 0
+    plan = engine.kv_plan(g, rep, ng, old, ln_d, R, cap, table=(rt, rl, rh, gh, tok_d, st_d))
+    torch.cuda.synchronize()
+    grp_row = plan["group_row"].cpu().numpy()[:ng_o]
+    rt_h, rl_h, rh_h = rt.cpu().numpy(), rl.cpu().numpy(), rh.cpu().numpy().view(np.uint64)
+    for u in range(ng_o):
+        r = grp_row[u]
+        if r >= 0:
+            c = list(ctxs[rep_o[u]])
+            assert rl_h[r] == len(c) and list(rt_h[r, :len(c)]) == c and not rt_h[r, len(c):].any() and rh_h[r] == gh_o[u]
+
+
+@pytest.mark.parametrize("dtype,R,H,Hkv,cap,Dh", [(torch.float32, 37, 12, 12, 19, 64), (torch.bfloat16, 20, 32, 8, 24, 64),
+                                                  (torch.float16, 9, 8, 2, 70, 128), (torch.float32, 5, 4, 4, 130, 128),
+                                                  (torch.bfloat16, 1024, 12, 12, 19, 64)])
+def test_slab_attention_matches_torch(engine, dtype, R, H, Hkv, cap, Dh):
+    """glb_slab_attention (one-token attention over KV slab rows where they lie, the new token's K / V appended on the
+    way) against softmax(q k^T * scale) v computed by torch in float32 on the same values: ragged positions incl. 0 and
+    cap - 1, grouped query heads, strided projection outputs."""
+    dev = engine.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(R + cap)
+    ks = torch.randn((R, Hkv, cap, Dh), device=dev, generator=g).to(dtype)
+    vs = torch.randn((R, Hkv, cap, Dh), device=dev, generator=g).to(dtype)
+    pos = torch.randint(0, cap, (R,), device=dev, generator=g, dtype=torch.int32)
+    pos[0], pos[-1] = 0, cap - 1
+    proj = torch.randn((R, 1, (H + 2 * Hkv) * Dh), device=dev, generator=g).to(dtype)  # q | k | v of one projection
+    q = proj[..., :H * Dh].view(R, 1, H, Dh).transpose(1, 2)
+    kn = proj[..., H * Dh:(H + Hkv) * Dh].view(R, 1, Hkv, Dh).transpose(1, 2)
+    vn = proj[..., (H + Hkv) * Dh:].view(R, 1, Hkv, Dh).transpose(1, 2)
+    scale = Dh ** -0.5
+    k_ref, v_ref = ks.clone(), vs.clone()
+    rows = torch.arange(R, device=dev)
+    k_ref[rows, :, pos.long()] = kn[:, :, 0]
+    v_ref[rows, :, pos.long()] = vn[:, :, 0]
+    G = H // Hkv
+    kf = k_ref.float().repeat_interleave(G, dim=1)
+    vf = v_ref.float().repeat_interleave(G, dim=1)
+    sc = torch.einsum("rhd,rhpd->rhp", q[:, :, 0].float(), kf) * scale
+    sc = sc.masked_fill(torch.arange(cap, device=dev)[None, None, :] > pos[:, None, None], float("-inf"))
+    want = torch.einsum("rhp,rhpd->rhd", torch.softmax(sc, -1), vf)
+    out = engine.slab_attention(q, kn, vn, ks, vs, pos, scale)
+    torch.cuda.synchronize()
+    assert out.shape == (R, 1, H, Dh) and out.dtype == dtype
+    tol = 2e-5 if dtype == torch.float32 else (2e-2 if dtype == torch.bfloat16 else 3e-3)
+    assert (out[:, 0].float() - want).abs().max().item() < tol
+    assert torch.equal(ks, k_ref) and torch.equal(vs, v_ref)  # the append, and nothing else, happened to the slabs
+
+
+@pytest.mark.parametrize("auto_kv", [False, True])
+def test_user_side_particle_math_on_gpu_rows_is_a_drop_in(llm, auto_kv):
+    """GPU twin of test_host_cpu's drop-in test: the README's Particle.extend (README.md:82-91) as user code on the rows
+    `next_token_logprobs` returns from the MI355X.  The rows live on the device (vllm-style); the golden
+    run drew with torch's CPU generator, so the user's draw takes the probabilities to the host like the reference's
+    CPU rows would be - everything else is device math.  Tokens and weights of the reference's golden run come out."""
+    m, gold = llm
+    masks = torch.from_numpy(gold["sis_masks"]).to(m.device)
+    prompt = [int(t) for t in gold["sis_prompt"]]
+    if auto_kv:
+        from genlm_backend_amd.autokv import AutoKV
+
+        m._auto_kv = AutoKV(m, 24, 24)
+
+    class UserParticle:
+        def __init__(self):
+            self.context, self.log_weight, self.active = [], 0.0, True
+
+        async def extend(self):
+            logps = await m.next_token_logprobs(prompt + self.context)
+            assert logps.is_cuda
+            masked = logps + masks[1 if len(self.context) >= 10 else 0].to(logps.device)
+            logZ = masked.logsumexp(dim=-1)
+            self.log_weight += logZ
+            tok = torch.multinomial((masked - logZ).exp().cpu(), 1).item()
+            if tok == 0:
+                self.active = False
+            else:
+                self.context.append(tok)
+
+    async def run():
+        ps = [UserParticle() for _ in range(16)]
+        while any(p.active for p in ps):
+            await asyncio.gather(*[p.extend() for p in ps if p.active])
+        return ps
+
+    torch.manual_seed(1234)
+    ps = asyncio.run(run())
+    assert [[int(t) for t in p.context] for p in ps] == [_strip(r) for r in gold["sis_contexts"]]
+    assert np.abs(np.array([float(p.log_weight) for p in ps], np.float32) - gold["sis_log_weights"]).max() < TOL

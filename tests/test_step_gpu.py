@@ -485,10 +485,9 @@ def _first_use_rows(n, distinct, seed):
 
 @pytest.mark.parametrize("N,distinct,V,dtype", [(1024, 4000, 50257, "f32"), (512, 3000, 128256, "bf16"), (700, 300, 50257, "f32"),
                                                 (300, 64, 4099, "f16")])
-def test_finishing_blocks_inside_the_grid_bit_exact(engine, oracle, N, distinct, V, dtype):
-    """GLB_STEP_ROWS_BY_FIRST_USE (and identity row_of): the one-launch step deals the finishing blocks inside the grid,
-    one chip's worth of wave slots behind their rows.  A speed hint only: same bits as the oracle with and without it,
-    masks handed over per row, shared rows reduced once."""
+def test_deduplicated_rows_at_headline_sizes_bit_exact(engine, oracle, N, distinct, V, dtype):
+    """The SIS loop's hand-over at its real sizes: row ids numbered by first use (glb_group_contexts' out_group_of), masks
+    per logits row, shared rows reduced once - and the same rows in reverse numbering: same bits as the oracle."""
     O = oracle
     row_of, U = _first_use_rows(N, distinct, seed=N + V)
     assert (row_of <= np.arange(N)).all()
@@ -497,26 +496,16 @@ def test_finishing_blocks_inside_the_grid_bit_exact(engine, oracle, N, distinct,
     masks = synth.binary_masks(V + 2, 2, V)
     bits, _ = O.mask_f32_to_bits(masks)
     mid_row = (np.arange(U) % 2).astype(np.int32)
-    want = O.step(x_np, row_of=row_of, mask_kind=O.MASK_BITS, mask=bits, mask_id=mid_row[row_of], rng_mode=O.RNG_PHILOX,
-                  seed=9, offset=4, particle_base=5)
     tdt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[dtype]
     prep = engine.prepare_masks(_bits_dev(bits, dev), V, tdt)
-    for flag in (True, False):
-        got = engine.step(x_t.to(dev), row_of=torch.from_numpy(row_of).to(dev), mask=prep,
-                          row_mask_id=torch.from_numpy(mid_row).to(dev), rng_mode=1, seed=9, offset=4, particle_base=5,
-                          rows_by_first_use=flag)
+    for ro in (row_of, (U - 1 - row_of).astype(np.int32)):
+        want = O.step(x_np, row_of=ro, mask_kind=O.MASK_BITS, mask=bits, mask_id=mid_row[ro], rng_mode=O.RNG_PHILOX,
+                      seed=9, offset=4, particle_base=5)
+        got = engine.step(x_t.to(dev), row_of=torch.from_numpy(ro).to(dev), mask=prep,
+                          row_mask_id=torch.from_numpy(mid_row).to(dev), rng_mode=1, seed=9, offset=4, particle_base=5)
         torch.cuda.synchronize()
         for w, g in zip(want, got):
-            assert np.array_equal(_np(g).view(np.uint32), w.view(np.uint32)), flag
-    # a row_of that breaks the promise only waits longer: same bits
-    rev = (U - 1 - row_of).astype(np.int32)
-    want_r = O.step(x_np, row_of=rev, mask_kind=O.MASK_BITS, mask=bits, mask_id=mid_row[rev], rng_mode=O.RNG_PHILOX, seed=9,
-                    offset=4)
-    got_r = engine.step(x_t.to(dev), row_of=torch.from_numpy(rev).to(dev), mask=prep, row_mask_id=torch.from_numpy(mid_row).to(dev),
-                        rng_mode=1, seed=9, offset=4, rows_by_first_use=True)
-    torch.cuda.synchronize()
-    for w, g in zip(want_r, got_r):
-        assert np.array_equal(_np(g).view(np.uint32), w.view(np.uint32))
+            assert np.array_equal(_np(g).view(np.uint32), w.view(np.uint32))
     engine.check()
 
 
