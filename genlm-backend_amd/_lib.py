@@ -146,8 +146,8 @@ SYMBOLS = {
     "glb_kv_gather_rows": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _i32, _vp]),
     "glb_gather_rows_i32": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),
     "glb_match_rows": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
-    "glb_slab_attention": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _f32, _i32,
-                                     _vp, _vp]),
+    "glb_slab_attention": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
+                                     _f32, _i32, _vp, _vp]),
     "glb_kv_plan_workspace": (_sz, [_i64, _i64]),
     "glb_kv_plan": (C.c_int, [C.POINTER(KvPlanArgs), _vp]),
     "glb_trie_workspace": (_sz, [_i64, _i64]),

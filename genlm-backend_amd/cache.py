@@ -203,12 +203,13 @@ class TokenTrie:
                 break
         return logprob_rows, n - 1 - first_row_index
 
-    def extend_cache(self, next_token_index, token_ids, logits, base, engine=None, store=None):
+    def extend_cache(self, next_token_index, token_ids, logits, base, engine=None, store=None, out_dtype=None):
         """cache.py:90-100 signature: `logits[j - base]` are raw logits of position j; they are
-        normalised by the HIP log-softmax kernel in one launch."""
+        normalised by the HIP log-softmax kernel in one launch (`out_dtype`: float32 by default, or the logits' own)."""
         if engine is None:
             raise RuntimeError("TokenTrie.extend_cache needs the HIP engine that normalises the rows")
         lo = next_token_index - base
-        rows = engine.log_softmax_rows(logits[lo:len(token_ids) - base])
+        kw = {} if out_dtype is None else {"out_dtype": out_dtype}
+        rows = engine.log_softmax_rows(logits[lo:len(token_ids) - base], **kw)
         engine.check()  # (cache_kv is a set-up call: one synchronising look at the error word; no NaN row reaches the trie)
         return self.extend_cache_rows(next_token_index, token_ids, rows, next_token_index, store=store)

@@ -194,7 +194,7 @@ hipError_t launch_mask_prepare(const uint32_t *bits, int64_t n_masks, int64_t vo
   const int nch = (int)n_chunks(vocab);
   uint64_t *mt = (uint64_t *)out;
   uint64_t *many = (uint64_t *)((char *)out + prepared_words_bytes(n_masks, vocab));
-  const dim3 grid((unsigned)nch, (unsigned)n_masks), block(256);
+  const dim3 grid((unsigned)nch, (unsigned)n_masks), block(64);
   if (dtype == GLB_F32)
     hipExtLaunchKernelGGL((glb::mask_prepare_kernel<4>), grid, block, 0, s, start, nullptr, 0, bits, mask_ld, (int)vocab, nch, mt, many);
   else

@@ -1495,32 +1495,57 @@ __global__ __launch_bounds__(64, WPS) void logprob_rows_waves_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// mask preparation: bit rows [n_masks, mask_ld] -> transposed lane words.  Block (c, k) transposes chunk c of mask k.
+// mask preparation: bit rows [n_masks, mask_ld] -> transposed lane words.  One WAVE per (chunk c, mask k).  Lane l
+// gathers the 64 bits of ITS elements of the chunk - bit j = i * EPV + kk of X[l] is element (i * 64 + l) * EPV + kk; the
+// EPV bits of a vector sit in one word of the row (fp32: bits 4 (i*64 + l) .. +3 of the chunk; 16-bit: one byte), so that
+// is NVC loads served by the L1 - and the wave transposes the 64 x 64 bit matrix in six butterfly exchanges: lane word
+// j (bit l = lane l's element j allowed) ends up in lane j, and the wave leaves with ONE coalesced 512-byte store.
+// (Round 3's form - 256-thread workgroups, a ballot per (vector, component), lane 0 of every wave storing its words one
+// by one - took 40 us for 1024 masks of 50257 tokens, as long as the step that reads them; one-wave workgroups with a
+// ballot per word 18 us; the butterfly does 64 words' worth of ballots in 6 x ~14 instructions.)
 // ---------------------------------------------------------------------------------------------------------
+template <int S>
+__device__ __forceinline__ uint64_t bit_transpose_step(uint64_t x, int lane) {
+  constexpr uint64_t low = S == 32 ? 0x00000000ffffffffull : S == 16 ? 0x0000ffff0000ffffull : S == 8 ? 0x00ff00ff00ff00ffull
+                         : S == 4 ? 0x0f0f0f0f0f0f0f0full : S == 2 ? 0x3333333333333333ull : 0x5555555555555555ull;
+  const uint32_t tl = (uint32_t)__shfl_xor((int)(uint32_t)x, S, 64), th = (uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), S, 64);
+  const uint64_t t = ((uint64_t)th << 32) | tl;
+  return (lane & S) ? ((x & ~low) | ((t & ~low) >> S)) : ((x & low) | ((t & low) << S));
+}
+
 template <int EPV>
-__global__ __launch_bounds__(256) void mask_prepare_kernel(const uint32_t *bits, int64_t mask_ld, int V, int nch,
-                                                          uint64_t *mask_t, uint64_t *mask_any) {
-  __shared__ uint64_t s_any[4];
-  const int k = blockIdx.y, c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__global__ __launch_bounds__(64) void mask_prepare_kernel(const uint32_t *bits, int64_t mask_ld, int V, int nch,
+                                                         uint64_t *mask_t, uint64_t *mask_any) {
+  constexpr int NVC = 64 / EPV;
+  const int k = blockIdx.y, c = blockIdx.x, lane = threadIdx.x;
   const uint32_t *row = bits + (int64_t)k * mask_ld;
   uint64_t *dst = mask_t + ((int64_t)k * nch + c) * 64;
-  bool on[16];
+  const int n_words = (V + 31) >> 5;
+  uint32_t w[NVC];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {  // word w = wave + 4j = vector (w / EPV), component (w % EPV); loads first
-    const int w = wave + 4 * j, i = w / EPV, kk = w % EPV;
-    const int e = c * kChunk + (i * 64 + lane) * EPV + kk;
-    on[j] = e < V && ((row[e < V ? e >> 5 : 0] >> (e & 31)) & 1u);
+  for (int i = 0; i < NVC; ++i) {  // the word that holds this lane's EPV bits of vector i (loads first)
+    const int wi = (c * kChunk + (i * 64 + lane) * EPV) >> 5;
+    w[i] = wi < n_words ? row[wi] : 0u;
   }
-  uint64_t any = 0;
+  uint64_t x = 0;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const uint64_t m = __ballot(on[j]);
-    any |= m;
-    if (lane == 0) dst[wave + 4 * j] = m;
+  for (int i = 0; i < NVC; ++i) {
+    const int e0 = c * kChunk + (i * 64 + lane) * EPV;
+    const int valid = V - e0;  // elements of this vector that exist: the rest read as forbidden
+    uint32_t v = (w[i] >> (e0 & 31)) & ((1u << EPV) - 1u);
+    if (valid < EPV) v &= valid > 0 ? ((1u << valid) - 1u) : 0u;
+    x |= (uint64_t)v << (i * EPV);
   }
-  if (lane == 0) s_any[wave] = any;
-  __syncthreads();
-  if (tid == 0) mask_any[(int64_t)k * nch + c] = (s_any[0] | s_any[1] | s_any[2] | s_any[3]) ? 1ull : 0ull;
+  // 64 x 64 bit-matrix transpose across the wave: exchange the off-diagonal s x s blocks, s = 32 .. 1
+  x = bit_transpose_step<32>(x, lane);
+  x = bit_transpose_step<16>(x, lane);
+  x = bit_transpose_step<8>(x, lane);
+  x = bit_transpose_step<4>(x, lane);
+  x = bit_transpose_step<2>(x, lane);
+  x = bit_transpose_step<1>(x, lane);
+  dst[lane] = x;  // lane j holds lane word j = (vector j / EPV, component j % EPV)
+  const uint64_t any = __ballot(x != 0ull);
+  if (lane == 0) mask_any[(int64_t)k * nch + c] = any ? 1ull : 0ull;
 }
 
 }  // namespace glb

@@ -382,7 +382,7 @@ struct AttnArgs {
   const char *q, *k_new, *v_new;
   char *k_slab, *v_slab, *out;
   const int32_t *pos;
-  int64_t q_sr, q_sh, kv_sr, kv_sh;  // element strides (row, head) of the query / the new K and V
+  int64_t q_sr, q_sh, k_sr, k_sh, v_sr, v_sh;  // element strides (row, head) of the query, the new K, the new V
   int32_t R, H, Hkv, cap;
   float scale;
 };
@@ -397,8 +397,8 @@ __global__ __launch_bounds__(64) void slab_attention_kernel(const AttnArgs a) {
   const int p_new = a.pos[r];  // the token being appended sits at p_new; positions 0 .. p_new are attended to
   float qf[EPV], kn[EPV], vn[EPV];
   unpack16<DT>(*reinterpret_cast<const u32x4 *>(a.q + ((int64_t)r * a.q_sr + (int64_t)h * a.q_sh + i * EPV) * ES), qf);
-  const u32x4 kn_raw = *reinterpret_cast<const u32x4 *>(a.k_new + ((int64_t)r * a.kv_sr + (int64_t)hk * a.kv_sh + i * EPV) * ES);
-  const u32x4 vn_raw = *reinterpret_cast<const u32x4 *>(a.v_new + ((int64_t)r * a.kv_sr + (int64_t)hk * a.kv_sh + i * EPV) * ES);
+  const u32x4 kn_raw = *reinterpret_cast<const u32x4 *>(a.k_new + ((int64_t)r * a.k_sr + (int64_t)hk * a.k_sh + i * EPV) * ES);
+  const u32x4 vn_raw = *reinterpret_cast<const u32x4 *>(a.v_new + ((int64_t)r * a.v_sr + (int64_t)hk * a.v_sh + i * EPV) * ES);
   unpack16<DT>(kn_raw, kn);
   unpack16<DT>(vn_raw, vn);
   const int64_t slab_row = ((int64_t)r * a.Hkv + hk) * a.cap;
@@ -465,8 +465,9 @@ hipError_t launch_attention(const AttnArgs &a, int head_dim, hipStream_t s) {
 
 extern "C" {
 
-int glb_slab_attention(const void *q, int64_t q_stride_row, int64_t q_stride_head, const void *k_new, const void *v_new,
-                       int64_t kv_stride_row, int64_t kv_stride_head, void *k_slab, void *v_slab, const int32_t *pos,
+int glb_slab_attention(const void *q, int64_t q_stride_row, int64_t q_stride_head, const void *k_new, int64_t k_stride_row,
+                       int64_t k_stride_head, const void *v_new, int64_t v_stride_row, int64_t v_stride_head, void *k_slab,
+                       void *v_slab, const int32_t *pos,
                        int64_t n_rows, int64_t heads, int64_t kv_heads, int64_t cap, int64_t head_dim, float scale,
                        int32_t dtype, void *out, void *stream) {
   if (!q || !k_new || !v_new || !k_slab || !v_slab || !pos || !out) return glb::api_fail(GLB_EINVAL, "glb_slab_attention: null pointer");
@@ -476,7 +477,8 @@ int glb_slab_attention(const void *q, int64_t q_stride_row, int64_t q_stride_hea
   if (head_dim != 64 && head_dim != 128) return glb::api_fail(GLB_EUNSUPPORTED, "glb_slab_attention: head_dim %lld (64 and 128 are built)", (long long)head_dim);
   const int es = dtype == GLB_F32 ? 4 : 2;
   if (((uintptr_t)q | (uintptr_t)k_new | (uintptr_t)v_new | (uintptr_t)k_slab | (uintptr_t)v_slab | (uintptr_t)out) % 16 ||
-      (q_stride_row * es) % 16 || (q_stride_head * es) % 16 || (kv_stride_row * es) % 16 || (kv_stride_head * es) % 16)
+      (q_stride_row * es) % 16 || (q_stride_head * es) % 16 || (k_stride_row * es) % 16 || (k_stride_head * es) % 16 ||
+      (v_stride_row * es) % 16 || (v_stride_head * es) % 16)
     return glb::api_fail(GLB_EINVAL, "glb_slab_attention: pointers and strides must be 16-byte aligned");
   AttnArgs a{};
   a.q = (const char *)q;
@@ -488,8 +490,10 @@ int glb_slab_attention(const void *q, int64_t q_stride_row, int64_t q_stride_hea
   a.pos = pos;
   a.q_sr = q_stride_row;
   a.q_sh = q_stride_head;
-  a.kv_sr = kv_stride_row;
-  a.kv_sh = kv_stride_head;
+  a.k_sr = k_stride_row;
+  a.k_sh = k_stride_head;
+  a.v_sr = v_stride_row;
+  a.v_sh = v_stride_head;
   a.R = (int32_t)n_rows;
   a.H = (int32_t)heads;
   a.Hkv = (int32_t)kv_heads;

@@ -428,10 +428,11 @@ class HipEngine:
         R, H, _, Dh = query.shape
         Hkv, cap = k_slab.shape[1], k_slab.shape[2]
         assert query.stride(3) == 1 and k_new.stride(3) == 1 and v_new.stride(3) == 1 and k_slab.is_contiguous() and v_slab.is_contiguous()
-        assert k_new.stride() == v_new.stride() and k_new.dtype == query.dtype == k_slab.dtype
+        assert k_new.dtype == v_new.dtype == query.dtype == k_slab.dtype
         out = torch.empty((R, 1, H, Dh), dtype=query.dtype, device=self.device)
-        check(self.lib.glb_slab_attention(_ptr(query), query.stride(0), query.stride(1), _ptr(k_new), _ptr(v_new),
-                                          k_new.stride(0), k_new.stride(1), _ptr(k_slab), _ptr(v_slab), _ptr(pos), R, H, Hkv,
+        check(self.lib.glb_slab_attention(_ptr(query), query.stride(0), query.stride(1), _ptr(k_new), k_new.stride(0),
+                                          k_new.stride(1), _ptr(v_new), v_new.stride(0), v_new.stride(1), _ptr(k_slab),
+                                          _ptr(v_slab), _ptr(pos), R, H, Hkv,
                                           cap, Dh, float(scale), _DT[query.dtype], _ptr(out), self._stream()))
         return out
 

@@ -176,6 +176,10 @@ class AsyncAmdLM(AsyncLM):
             cap = float(config.final_logit_softcapping)
         return mult, cap
 
+    def _log_softmax(self, logits):
+        """log-prob rows of `logits` in the dtype this backend returns (glb_log_softmax_rows)"""
+        return self.engine.log_softmax_rows(logits, out_dtype=logits.dtype if self._lp_model_dtype else torch.float32)
+
     def _lm_head(self, hidden):
         """Logits of the given hidden rows exactly as `model(...).logits` has them: output embedding, then the
         family's post-head scaling / soft-capping."""
@@ -188,8 +192,12 @@ class AsyncAmdLM(AsyncLM):
 
     @torch.no_grad()
     def __init__(self, hf_model, hf_tokenizer, batch_size=20, timeout=0.02, engine=None, fuse_activations=True,
-                 kv_budget_bytes=8 << 30, logprob_budget_bytes=16 << 30, auto_kv_rows=0, auto_kv_cap=64):
-        """auto_kv_rows > 0: `batch_next_token_step` keeps the KV of the contexts it evaluates in that many slab rows of
+                 kv_budget_bytes=8 << 30, logprob_budget_bytes=16 << 30, auto_kv_rows=0, auto_kv_cap=64,
+                 logprob_dtype="float32"):
+        """logprob_dtype: "float32" (default: every row `next_token_logprobs` returns is float32, whatever the checkpoint's
+        dtype) or "model" - rows in the model's own dtype, what the reference returns (cache.py:96 keeps the dtype; for a
+        bfloat16 checkpoint a third fewer bytes per materialised row: glb_log_softmax_rows' out_dtype).
+        auto_kv_rows > 0: `batch_next_token_step` keeps the KV of the contexts it evaluates in that many slab rows of
         `auto_kv_cap` positions and feeds one token to every context whose first L - 1 tokens it finds there
         (autokv.AutoKV; off by default: the reference re-encodes, hf.py:202-288)."""
         self.model = hf_model
@@ -200,8 +208,12 @@ class AsyncAmdLM(AsyncLM):
 
             engine = HipEngine(self.device)
         self.engine = engine
+        if logprob_dtype not in ("float32", "model"):
+            raise ValueError(f"logprob_dtype must be 'float32' or 'model', got {logprob_dtype!r}")
+        self._lp_model_dtype = logprob_dtype == "model"
         self.cache = TokenTrie()
         self.queries = []
+        self._sq = None  # pending `next_token_step` requests without a cached prefix: [contexts, mask ids, ONE future]
         self.batch_size = batch_size
         self.timeout = timeout
         self.timer = None
@@ -264,6 +276,7 @@ class AsyncAmdLM(AsyncLM):
 
     def reset_async_queries(self):
         self.queries = []
+        self._sq = None
 
     @torch.no_grad()
     def cache_kv(self, prompt_tokens):
@@ -277,7 +290,8 @@ class AsyncAmdLM(AsyncLM):
         ids = torch.tensor([prompt_tokens], device=self.device)
         out = self._body(input_ids=ids, use_cache=True)
         logits = self._lm_head(out.last_hidden_state[0])
-        node = self.cache.extend_cache(0, prompt_tokens, logits, 0, engine=self.engine, store=self._rows)
+        node = self.cache.extend_cache(0, prompt_tokens, logits, 0, engine=self.engine, store=self._rows,
+                                       out_dtype=logits.dtype if self._lp_model_dtype else None)
         # (re-created ancestors: an older, shorter prefix whose node was replaced on the way is unreachable from the
         # trie now and would only hold memory)
         reach = set()
@@ -352,6 +366,7 @@ class AsyncAmdLM(AsyncLM):
     # ---- the batched evaluation (hf.py:202-288) -------------------------------------------------------
     @torch.no_grad()
     def batch_evaluate_queries(self):
+        self._fire_step_batch()
         queries, self.queries = self.queries, []
         if len(queries) == 0:
             return
@@ -388,7 +403,7 @@ class AsyncAmdLM(AsyncLM):
             tok_d, st_d, ln_d = (torch.from_numpy(a).to(dev) for a in (flat, starts, lens))
             group_of, rep, ng = eng.group_contexts(tok_d, st_d, ln_d)
             logits, row_of_group, _, U, _ = self._auto_kv.logits(tok_d, st_d, ln_d, group_of, rep, ng)
-            lp = eng.log_softmax_rows(logits)
+            lp = self._log_softmax(logits)
             rows = torch.cat([row_of_group[group_of.long()], eng.error_word()]).cpu().tolist()
             eng.raise_if_failed(rows.pop(), what="glb_log_softmax_rows")  # no NaN row may reach the trie
             self._batch_counter += 1
@@ -501,10 +516,10 @@ class AsyncAmdLM(AsyncLM):
         if lp_rows:
             need = sorted(r for u, (r0, f) in lp_rows.items() for r in range(r0, r0 + len(uniq[u].prompt) - f))
             if len(need) == R:
-                lp_slab = eng.log_softmax_rows(logits)
+                lp_slab = self._log_softmax(logits)
             else:
                 idx = torch.from_numpy(np.asarray(need, np.int64)).to(dev)
-                lp_slab = eng.log_softmax_rows(logits[idx].contiguous())
+                lp_slab = self._log_softmax(logits[idx].contiguous())
                 slab_row = {r: i for i, r in enumerate(need)}
 
         # -- fused step for every step query, in resolution order (group order, duplicates contiguous)
@@ -568,7 +583,7 @@ class AsyncAmdLM(AsyncLM):
 
     def _on_timer(self):
         self.timer = None
-        if not self.queries:
+        if not self.queries and self._sq is None:
             return
         loop = asyncio.get_running_loop()
         remaining = self._deadline - loop.time()
@@ -654,7 +669,7 @@ class AsyncAmdLM(AsyncLM):
             raise ValueError("Token ids must not be empty")
         ids = torch.tensor([token_ids], device=self.device)
         h = self._body(input_ids=ids, use_cache=False).last_hidden_state[0, -1:]
-        return self.engine.log_softmax_rows(self._lm_head(h))[0]  # (a single row: the three-launch form, no waits inside)
+        return self._log_softmax(self._lm_head(h))[0]  # (a single row: the three-launch form, no waits inside)
 
     # ---- fused particle step (README.md:82-91 moved behind the queue) ------------------------------------
     async def next_token_step(self, token_ids, mask_id=0):
@@ -662,12 +677,47 @@ class AsyncAmdLM(AsyncLM):
         draw from the masked, renormalised distribution; token is -1 if the mask forbids everything."""
         if not token_ids:
             raise ValueError("Token ids must not be empty")
-        past, base = None, 0
-        if len(self._kv_lru):  # the trie walk only serves to find a cached KV prefix: none cached, nothing to find
+        if len(self._kv_lru):  # a cached KV prefix may serve this request: the trie walk finds it, the request is queued on its own
             _node, _n, past, base = self.walk_cache(token_ids)
-        future = asyncio.get_running_loop().create_future()
-        self.add_query(token_ids[base:] if base else token_ids, future, past, kind="step", mask_id=mask_id)
-        return await future
+            future = asyncio.get_running_loop().create_future()
+            self.add_query(token_ids[base:] if base else token_ids, future, past, kind="step", mask_id=mask_id)
+            return await future
+        # No prefix is cached, so there is nothing to walk and nothing per-request to keep: the requests of a batch share
+        # ONE future (a population of README particles awaits the same evaluation, hf.py:290-312's queue without a future,
+        # a Query object and a timer operation per particle) and pick their slot out of its result.
+        sq = self._sq
+        if sq is None:
+            sq = self._sq = ([], [], asyncio.get_running_loop().create_future())
+        slot = len(sq[0])
+        sq[0].append(token_ids)
+        sq[1].append(mask_id)
+        if slot + 1 + len(self.queries) >= self.batch_size:
+            if self.timer:
+                self.timer.cancel()
+                self.timer = None
+            self.batch_evaluate_queries()
+        else:
+            loop = asyncio.get_running_loop()
+            self._deadline = loop.time() + self.timeout
+            if self.timer is None:
+                self.timer = loop.call_later(self.timeout, self._on_timer)
+        logZ, tok = await sq[2]
+        return logZ[slot], tok[slot]
+
+    def _fire_step_batch(self):
+        """Evaluate the pending `next_token_step` requests (one vectorised call) and resolve their shared future."""
+        sq, self._sq = self._sq, None
+        if sq is None:
+            return
+        contexts, mask_ids, future = sq
+        try:
+            logZ, tok = self.batch_next_token_step_sync(contexts, mask_ids)
+        except Exception as e:  # vllm.py:396-400 behaviour: nobody is left waiting
+            if not future.done():
+                future.set_exception(e)
+            return
+        if not future.done():
+            future.set_result((logZ.tolist(), tok.tolist()))
 
     # ---- batched submit: a whole population per call (no per-query futures, no per-query Python) ----------------------
     def _prefix_table(self):

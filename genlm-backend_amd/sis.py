@@ -93,6 +93,17 @@ def _gather_all(dist, out, inp):
         dist.all_gather_into_tensor(out, inp)
 
 
+def _all_to_all(dist, out, inp, out_splits, in_splits):
+    """all_to_all_single with uneven splits (rows of an int32 matrix) - through host memory for a gloo group whose ranks
+    compute on a GPU, like _gather_all."""
+    if inp.is_cuda and dist.get_backend() == "gloo":
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(host, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits)
+        out.copy_(host)
+    else:
+        dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits)
+
+
 def _reduce_all(dist, t, op):
     if t.is_cuda and dist.get_backend() == "gloo":
         host = t.cpu()
@@ -198,6 +209,7 @@ class DeviceSIS:
         if self.particle_kv:
             assert not use_prefix_kv
         self.particle_masks = particle_masks
+        self.rows_moved = 0  # particles that changed ranks in the last resampling step (over all ranks)
         self.resample_ess = resample_ess
         self.n_resamples = 0
         self.sync_every = 1  # per-particle-KV steps: how often the active counts are read back (one small D2H copy)
@@ -531,23 +543,40 @@ class DeviceSIS:
     def resample(self):
         """Systematic resampling of the whole population, replicated on every rank: identical gathered weights give
         identical ancestors (integer comb, one Philox draw keyed by (seed, step)); slot i of rank r takes ancestor
-        anc[r*N + i].  Token matrices are all-gathered (N_total x cap int32) and gathered by ancestor; KV rows follow
-        a local ancestor with one gather launch and are rebuilt from the context when the ancestor lived elsewhere."""
+        anc[r*N + i].  A particle whose ancestor lives on this rank is one row gather; the rows that change ranks - and only
+        those - travel in one all-to-all (every rank derives who sends what to whom from the replicated ancestors); KV rows
+        follow a local ancestor and are rebuilt from the context when the ancestor lived elsewhere."""
         eng, N, dev = self.eng, self.N, self.dev
         n_total = N * self.world
         anc, lse = eng.resample_systematic(self.all_weights, self.seed ^ 0x5eed5a11, self.t)
         mine = anc[self.rank * N:(self.rank + 1) * N].contiguous()
-        meta = torch.stack([self.lengths, self.prompt_len, self.active], dim=1).contiguous()  # [N, 3] int32
-        if self.collective:
-            all_ctx = torch.empty((n_total, self.cap), dtype=torch.int32, device=dev)
-            all_meta = torch.empty((n_total, 3), dtype=torch.int32, device=dev)
-            _gather_all(self.dist, all_ctx.view(-1), self.contexts.view(-1))
-            _gather_all(self.dist, all_meta.view(-1), meta.view(-1))
-        else:
-            all_ctx, all_meta = self.contexts, meta
-        self.contexts = eng.gather_rows_i32(all_ctx, mine)
-        m = eng.gather_rows_i32(all_meta, mine)
-        self.lengths, self.prompt_len, self.active = m[:, 0].contiguous(), m[:, 1].contiguous(), m[:, 2].contiguous()
+        # a particle's state as one int32 row: its tokens, then (length, prompt length, active)
+        state = torch.cat([self.contexts, torch.stack([self.lengths, self.prompt_len, self.active], dim=1)], dim=1).contiguous()
+        local = mine - self.rank * N
+        new_state = eng.gather_rows_i32(state, local.clamp(0, N - 1))  # (slots whose ancestor lives elsewhere: overwritten below)
+        if self.collective and self.world > 1:
+            # Only what moves travels: the ancestors are replicated, so every rank knows which of its rows the others take
+            # and which rows it is sent - no request round, one all-to-all of exactly those rows (round 3 all-gathered the
+            # whole N_total x cap token matrix on every resampling step).
+            anc_h = anc.cpu().numpy()  # the resampling step's one D2H copy
+            owner = anc_h // N
+            r = self.rank
+            send_idx = [anc_h[d * N:(d + 1) * N][owner[d * N:(d + 1) * N] == r] - r * N if d != r else anc_h[:0]
+                        for d in range(self.world)]
+            mine_owner = owner[r * N:(r + 1) * N]
+            recv_cnt = [int((mine_owner == src).sum()) if src != r else 0 for src in range(self.world)]
+            self.rows_moved = int((owner != np.repeat(np.arange(self.world), N)).sum())  # over all ranks (replicated value)
+            if self.rows_moved:
+                take = np.concatenate(send_idx).astype(np.int64)
+                send = state[torch.from_numpy(take).to(dev)] if len(take) else state[:0]
+                recv = torch.empty((sum(recv_cnt), state.shape[1]), dtype=torch.int32, device=dev)
+                _all_to_all(self.dist, recv, send.contiguous(), recv_cnt, [len(x) for x in send_idx])
+                if sum(recv_cnt):
+                    # rows arrive ordered by source rank, then by this rank's slot order - the order the senders used
+                    slots = np.concatenate([np.nonzero(mine_owner == src)[0] for src in range(self.world) if src != r])
+                    new_state[torch.from_numpy(slots.astype(np.int64)).to(dev)] = recv
+        self.contexts = new_state[:, :self.cap].contiguous()
+        self.lengths, self.prompt_len, self.active = (new_state[:, self.cap + k].contiguous() for k in range(3))
         # equal weights: log of the population's mean weight
         self.log_weights = (lse - float(np.log(n_total))).expand(N).contiguous()
         if self.share_kv:  # re-point: a particle takes its ancestor's row; ancestors of another rank leave it without one

@@ -371,14 +371,15 @@ int glb_kv_plan(const glb_kv_plan_args *args, void *hip_stream);
  * Attention of a one-token forward over KV slab rows where they lie (the read side of the device-resident KV, SURVEY.md
  * §8 f1; the reference hands zero-padded per-query KV to the model's own attention, hf.py:247-281): for every row r and
  * query head h, softmax(q . K[r, h / G, 0 .. pos[r]] * scale) . V[r, h / G, 0 .. pos[r]], where position pos[r] is the token
- * of this forward - its K / V (k_new, v_new: [n_rows, kv_heads, head_dim] by element strides, the projection's output)
+ * of this forward - its K / V (k_new, v_new: [n_rows, kv_heads, head_dim], each by its own element strides: the projections' outputs)
  * are used from where they are AND written to slab position pos[r] (glb_kv_append, fused).  q by element strides
  * (row, head), unit inner stride; slabs [n_rows, kv_heads, cap, head_dim] contiguous; out [n_rows, heads, head_dim]
  * contiguous; all of one dtype, float32 accumulation; head_dim 64 or 128 (GLB_EUNSUPPORTED otherwise); every pointer and
  * stride a multiple of 16 bytes.  One launch per layer instead of two appends, a mask and a dense SDPA call.
  */
-int glb_slab_attention(const void *q, int64_t q_stride_row, int64_t q_stride_head, const void *k_new, const void *v_new,
-                       int64_t kv_stride_row, int64_t kv_stride_head, void *k_slab, void *v_slab, const int32_t *pos,
+int glb_slab_attention(const void *q, int64_t q_stride_row, int64_t q_stride_head, const void *k_new, int64_t k_stride_row,
+                       int64_t k_stride_head, const void *v_new, int64_t v_stride_row, int64_t v_stride_head, void *k_slab,
+                       void *v_slab, const int32_t *pos,
                        int64_t n_rows, int64_t heads, int64_t kv_heads, int64_t cap, int64_t head_dim, float scale,
                        int32_t dtype, void *out, void *hip_stream);
 

@@ -1129,3 +1129,206 @@ def test_user_side_particle_math_on_gpu_rows_is_a_drop_in(llm, auto_kv):
     ps = asyncio.run(run())
     assert [[int(t) for t in p.context] for p in ps] == [_strip(r) for r in gold["sis_contexts"]]
     assert np.abs(np.array([float(p.log_weight) for p in ps], np.float32) - gold["sis_log_weights"]).max() < TOL
+
+
+# ---- BASELINE config 4's per-rank size on the HIP path: 512 particles per rank, more than two ranks ----------------------
+# (a GPU box admits at most 6 processes on its card: 4 ranks + this process; tests/test_resample_cpu.py runs the full
+#  8 x 512 population over gloo on the CPU engine double)
+def _many_rank_prompts(n_total, vocab):
+    rs = np.random.default_rng(45)
+    pool = [[int(t) for t in rs.integers(1, vocab, size=rs.integers(2, 7))] for _ in range(40)]
+    return [pool[i] for i in rs.integers(0, len(pool), size=n_total)]
+
+
+def _many_rank_worker(rank, world, port, out_dir, per_rank):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import genlm_backend_amd  # noqa: F401
+    from transformers import GPT2Config, GPT2LMHeadModel
+
+    from genlm_backend_amd.engine import HipEngine
+    from genlm_backend_amd.llm import AsyncAmdLM
+    from genlm_backend_amd.sis import DeviceSIS
+
+    gold = np.load(G)
+    cfg = ast.literal_eval(bytes(gold["config_json"]).decode())
+    model = GPT2LMHeadModel(GPT2Config(**cfg)).eval()
+    model.load_state_dict({k[3:]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("w::")})
+    eng = HipEngine("cuda:0")
+    m = AsyncAmdLM(model.to(eng.device), None, batch_size=64, engine=eng)
+    m.tokenizer = Tok()
+    m.register_masks(torch.from_numpy(gold["sis_masks"]))
+    prompts = _many_rank_prompts(world * per_rank, cfg["vocab_size"])[rank * per_rank:(rank + 1) * per_rank]
+    sis = DeviceSIS(m, per_rank, prompts, max_tokens=4, eos_id=-1, seed=23, rank=rank, world=world, dist=dist, resample_ess=1.0,
+                    use_particle_kv=True)
+    moved = []
+    for _ in range(5):
+        sis.step()
+        moved.append(sis.rows_moved)
+    ctx, lw = sis.results()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), ctx=np.array([list(c) + [-1] * (8 - len(c)) for c in ctx]), lw=lw,
+             all_lw=sis.all_weights.cpu().numpy(), moved=np.array(moved))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_four_ranks_of_512_on_one_gpu_equal_one_rank(llm, tmp_path):
+    """Config 4's per-rank population (512 particles) on four ranks sharing this GPU - HIP kernels, shared KV rows with the
+    block table on the device, systematic resampling after every step, the rows that change ranks travelling in one
+    all-to-all (over gloo: RCCL wants a GPU per rank) - equals one process with all 2048 particles."""
+    import torch.multiprocessing as mp
+
+    from genlm_backend_amd.sis import DeviceSIS
+
+    world, per_rank, port = 4, 512, 30341 + os.getpid() % 200
+    mp.start_processes(_many_rank_worker, args=(world, port, str(tmp_path), per_rank), nprocs=world, join=True, start_method="spawn")
+    r = [np.load(tmp_path / f"rank{i}.npz") for i in range(world)]
+    for x in r[1:]:
+        assert np.array_equal(x["all_lw"], r[0]["all_lw"]) and np.array_equal(x["moved"], r[0]["moved"])
+    assert 0 < r[0]["moved"].max() < world * per_rank // 2
+    m, gold = llm
+    m.register_masks(torch.from_numpy(gold["sis_masks"]))
+    cfg = ast.literal_eval(bytes(gold["config_json"]).decode())
+    one = DeviceSIS(m, world * per_rank, _many_rank_prompts(world * per_rank, cfg["vocab_size"]), max_tokens=4, eos_id=-1, seed=23,
+                    resample_ess=1.0, use_particle_kv=True)
+    for _ in range(5):
+        one.step()
+    ctx, lw = one.results()
+    got = [[int(t) for t in row if t >= 0] for row in np.concatenate([x["ctx"] for x in r])]
+    assert got == [list(map(int, c)) for c in ctx]
+    assert np.abs(lw - np.concatenate([x["lw"] for x in r])).max() < 1e-4
+
+
+def test_bench_four_ranks_rehearsal_of_config4_on_one_gpu():
+    """`bench.py --gpus 4 --rehearse-one-gpu --workload sis-llama`: config 4's per-GPU work (Llama-3.2-1B shape, bf16, V =
+    128256, 512 particles per rank) on four ranks of the driver's multi-rank flow, all computing on this GPU (the box
+    admits six processes on its card, so eight ranks cannot be rehearsed here; an 8-GPU run needs no other code)."""
+    import json
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--rehearse-one-gpu", "--workload", "sis-llama",
+                        "--particle-kv", "--resample", "--steps", "3", "--warmup", "1", "--no-cpu"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["gloo_ranks"] == 4 and out["rehearsal_one_gpu"] is True
+    assert out["config"]["particles_per_gpu"] == 512 and out["config"]["vocab"] == 128256 and out["value"] > 0
+
+
+@pytest.mark.parametrize("family", ["gpt2", "llama"])
+def test_in_place_forward_with_fused_slab_attention_equals_sdpa(engine, family):
+    """The in-place one-token forward with glb_slab_attention (registered with transformers' attention interface, append
+    fused, no mask tensor) against the same forward through PyTorch's SDPA with glb_kv_append and the explicit mask: same
+    hidden states within float32 rounding, same slabs - for a GPT-2 and a grouped-query RoPE model with 64-wide heads,
+    eager and replayed from a hipGraph."""
+    from transformers import GPT2Config, GPT2LMHeadModel, LlamaConfig, LlamaForCausalLM
+
+    from genlm_backend_amd.kv import SlabForward, SlabKV
+
+    torch.manual_seed(5)
+    dev = engine.device
+    if family == "gpt2":
+        model = GPT2LMHeadModel(GPT2Config(vocab_size=500, n_positions=32, n_embd=128, n_layer=2, n_head=2)).eval().to(dev)
+        H_kv = 2
+    else:
+        model = LlamaForCausalLM(LlamaConfig(vocab_size=500, hidden_size=256, intermediate_size=256, num_hidden_layers=2,
+                                             num_attention_heads=4, num_key_value_heads=2, head_dim=64,
+                                             max_position_embeddings=32)).eval().to(dev)
+        H_kv = 2
+    body = model.base_model
+    R, cap, L = 24, 14, 2
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+
+    def make():
+        pkv = SlabKV(engine, R, cap, L)
+        for layer in pkv.layers:
+            layer.lazy_initialization(torch.zeros((1, H_kv, 1, 64), device=dev), torch.zeros((1, H_kv, 1, 64), device=dev))
+        return pkv
+
+    a, b = make(), make()
+    gg = torch.Generator(device=dev)
+    gg.manual_seed(2)
+    for la, lb in zip(a.layers, b.layers):
+        la.keys.copy_(torch.randn(la.keys.shape, device=dev, generator=gg))
+        la.values.copy_(torch.randn(la.values.shape, device=dev, generator=gg))
+        lb.keys.copy_(la.keys)
+        lb.values.copy_(la.values)
+    fa = SlabForward(a, body, graph=True, fused_attention=True)
+    fb = SlabForward(b, body, graph=False, fused_attention=False)
+    assert fa.fused and not fb.fused
+    with torch.no_grad():
+        for step in range(5):  # (the third call captures the hipGraph, later ones replay it)
+            ids = torch.randint(0, 500, (R, 1), device=dev, generator=g)
+            pos = torch.randint(0, cap, (R,), device=dev, generator=g, dtype=torch.int32)
+            pos[0], pos[1] = 0, cap - 1
+            ha, hb = fa(ids, pos).clone(), fb(ids, pos).clone()
+            torch.cuda.synchronize()
+            assert (ha - hb).abs().max().item() < 2e-4, step
+            for la, lb in zip(a.layers, b.layers):
+                assert (la.keys - lb.keys).abs().max().item() < 1e-4 and (la.values - lb.values).abs().max().item() < 1e-4
+    assert len(fa.graphs) == 1
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_load_model_by_name_end_to_end_on_gpu(tmp_path, dtype):
+    """The public entry point (llm/__init__.py:10-43) on the hardware: `load_model_by_name` of a local checkpoint directory
+    (a small GPT-2 with 64-wide heads saved with the byte-level BPE tokenizer of tests/golden, float32 and bfloat16) builds
+    its own HipEngine; tokenizer -> byte_vocab -> the README's mask builder -> autobatched SIS (the coroutine API), the
+    device-resident loop with shared KV rows, and a log-prob row that sums to one - in the checkpoint's dtype path."""
+    from tokenizers import Tokenizer
+    from transformers import GPT2Config, GPT2LMHeadModel, PreTrainedTokenizerFast
+
+    from genlm_backend_amd.engine import HipEngine
+    from genlm_backend_amd.llm import AsyncAmdLM, load_model_by_name
+    from genlm_backend_amd.sis import DeviceSIS, autobatched_sis, make_masking_function
+
+    gd = os.path.join(os.path.dirname(__file__), "golden")
+    tok = PreTrainedTokenizerFast(tokenizer_object=Tokenizer.from_file(os.path.join(gd, "bpe_tokenizer.json")),
+                                  eos_token="<|endoftext|>")
+    torch.manual_seed(3)
+    GPT2LMHeadModel(GPT2Config(vocab_size=len(tok), n_positions=64, n_embd=128, n_layer=2, n_head=2, bos_token_id=0,
+                               eos_token_id=0)).to(dtype).save_pretrained(tmp_path)
+    tok.save_pretrained(tmp_path)
+    llm = load_model_by_name(str(tmp_path), backend="amd", llm_opts={"hf_opts": {"device": "cuda:0"}, "batch_size": 8})
+    assert isinstance(llm, AsyncAmdLM) and isinstance(llm.engine, HipEngine) and llm.tokenizer.eos_token_id == 0
+    assert next(llm.model.parameters()).dtype == dtype and llm.device.type == "cuda"
+    assert len(llm.byte_vocab) == len(llm.str_vocab) == len(tok)
+    sel = make_masking_function(llm, max_token_length=3, max_tokens=4)
+    llm.set_rng("philox", 5)
+    prompt = llm.tokenizer.encode("the cat")
+    parts = asyncio.run(autobatched_sis(8, llm, sel, prompt, eos_id=0))
+    assert all(not p.active and 1 <= len(p.context) + 1 <= 6 and np.isfinite(p.log_weight) for p in parts)
+    for p in parts:  # the README mask: no generated token longer than three bytes
+        assert all(len(llm.byte_vocab[t]) <= 3 for t in p.context)
+    row = asyncio.run(llm.next_token_logprobs(prompt))
+    assert row.is_cuda and row.dtype == torch.float32 and abs(float(row.exp().sum()) - 1.0) < 1e-4
+    # rows in the model's own dtype, as the reference returns them (cache.py:96): within one 16-bit ulp of the float32 rows
+    llm_m = load_model_by_name(str(tmp_path), backend="amd", llm_opts={"hf_opts": {"device": "cuda:0"}, "batch_size": 8,
+                                                                      "engine": llm.engine, "logprob_dtype": "model"})
+    row_m = llm_m.next_token_logprobs_sync(prompt)
+    assert row_m.dtype == dtype
+    assert bool(((row_m.float() - row).abs() <= (2.0 ** -7 if dtype == torch.bfloat16 else 1e-6) * row.abs().clamp_min(1.0)).all())
+    # the device-resident loop on the same object: shared KV rows, the in-place forward with glb_slab_attention
+    sis = DeviceSIS(llm, 32, prompt, max_tokens=4, eos_id=0, seed=5, use_particle_kv=True, kv_graph=False)
+    sis.run()
+    ctx, lw = sis.results()
+    assert sis._slab_fwd is None or sis._slab_fwd.fused
+    assert all(len(llm.byte_vocab[t]) <= 3 for c in ctx for t in c) and np.isfinite(lw).all()
+    # the same population without KV rows: the reference's re-encoding algorithm gives the same tokens
+    ref = DeviceSIS(llm, 32, prompt, max_tokens=4, eos_id=0, seed=5)
+    ref.run()
+    ctx_r, lw_r = ref.results()
+    if dtype == torch.float32:
+        assert [list(map(int, c)) for c in ctx] == [list(map(int, c)) for c in ctx_r]
+        assert np.abs(lw - lw_r).max() < 1e-3
+    for bad in ("vllm", "mlx", "nonsense"):
+        with pytest.raises(ValueError):
+            load_model_by_name(str(tmp_path), backend=bad)

@@ -195,3 +195,62 @@ def test_shard_that_finishes_early_keeps_the_collectives_matched(tmp_path):
     assert int(r[0]["steps"]) == int(r[1]["steps"]) > 2
     assert int(r[0]["active"]) == 0
     assert np.array_equal(r[0]["all_lw"], r[1]["all_lw"])
+
+
+# ---- BASELINE config 4's real sizes: 4096 particles over 8 ranks (512 each), resampling after every step --------------
+def _config4_prompts(n_total):
+    rs = np.random.default_rng(44)
+    pool = [[int(t) for t in rs.integers(1, 290, size=rs.integers(2, 7))] for _ in range(48)]
+    return [pool[i] for i in rs.integers(0, len(pool), size=n_total)]
+
+
+def _config4_worker(rank, world, port, out_dir, per_rank):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from genlm_backend_amd.sis import DeviceSIS
+
+    prompts = _config4_prompts(world * per_rank)[rank * per_rank:(rank + 1) * per_rank]
+    sis = DeviceSIS(_tiny("llama"), per_rank, prompts, max_tokens=4, eos_id=0, seed=9, rank=rank, world=world, dist=dist,
+                    use_particle_kv=True, resample_ess=1.0)
+    moved = []
+    steps = 0
+    while steps < 5:
+        _, n_global = sis.step()
+        steps += 1
+        moved.append(sis.rows_moved)
+        if n_global == 0:
+            break
+    ctx, lw = sis.results()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), ctx=np.array([list(c) + [-1] * (6 - len(c)) for c in ctx]), lw=lw,
+             all_lw=sis.all_weights.numpy(), steps=steps, n_res=sis.n_resamples, moved=np.array(moved))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(1500)
+def test_eight_ranks_of_512_equal_one_process(tmp_path):
+    """Config 4's shape of the population (4096 particles, 512 per rank, 8 ranks; gloo on the CPU engine double, a tiny
+    Llama-shaped model): rank-specific ragged prompts, shared KV rows, systematic resampling after every step.  The
+    union equals one process with all 4096; and a resampling step moves only the particles whose ancestor lives on another
+    rank (one all-to-all), not the population."""
+    world, per_rank, port = 8, 512, 30141 + os.getpid() % 200
+    mp.start_processes(_config4_worker, args=(world, port, str(tmp_path), per_rank), nprocs=world, join=True,
+                       start_method="spawn")
+    r = [np.load(tmp_path / f"rank{i}.npz") for i in range(world)]
+    assert len({int(x["steps"]) for x in r}) == 1 and int(r[0]["n_res"]) >= 3
+    for x in r[1:]:
+        assert np.array_equal(x["all_lw"], r[0]["all_lw"]) and np.array_equal(x["moved"], r[0]["moved"])
+    moved = r[0]["moved"]
+    assert 0 < moved.max() < world * per_rank // 2  # something crossed ranks, and far from everything
+    from genlm_backend_amd.sis import DeviceSIS
+
+    one = DeviceSIS(_tiny("llama"), world * per_rank, _config4_prompts(world * per_rank), max_tokens=4, eos_id=0, seed=9,
+                    use_particle_kv=True, resample_ess=1.0)
+    for _ in range(int(r[0]["steps"])):
+        one.step()
+    ctx, lw = one.results()
+    got = [[int(t) for t in row if t >= 0] for row in np.concatenate([x["ctx"] for x in r])]
+    assert got == [list(map(int, c)) for c in ctx]
+    assert np.abs(lw - r[0]["all_lw"]).max() < 1e-4

@@ -610,3 +610,34 @@ def test_particles_advance_leaves_failed_particles_untouched(engine, oracle):
     c2, l2, a2, w2 = (np.zeros((n, cap), np.int32), np.full(n, 2, np.int32), np.ones(n, np.int32), np.zeros(n, np.float32))
     oracle.particles_advance(c2, l2, a2, w2, _np(logZ), _np(tok), 7, cap)
     assert np.array_equal(c2, _np(ctx)) and np.array_equal(l2, _np(ln)) and np.array_equal(a2, _np(act))
+
+
+@pytest.mark.parametrize("B,V,dtype", [(1024, 50257, "f32"), (512, 128256, "bf16"), (70, 4099, "f16")])
+def test_one_bit_mask_per_particle_bit_exact(engine, oracle, B, V, dtype):
+    """What a grammar gives (README.md:57-70 generalised): one bit mask PER PARTICLE, handed over raw
+    (GLB_MASK_BITS, n_masks == n_particles, no ids) so the call transposes them itself (mask_prepare_kernel: a 64 x 64
+    bit-matrix transpose per chunk) - at the headline sizes, same bits as the oracle; and the same masks prepared ahead."""
+    O = oracle
+    x_np, x_t = _mk(O, B, V, dtype, seed=V + B + 1)
+    dev = engine.device
+    rng = np.random.default_rng(B)
+    masks = np.where(rng.random((B, V)) < 1 / 3, -np.inf, 0.0).astype(np.float32)
+    masks[1, :] = -np.inf          # nothing allowed
+    masks[2, :] = -np.inf
+    masks[2, V - 1] = 0.0          # only the row's last token
+    masks[3, :] = 0.0              # everything allowed
+    bits, _ = O.mask_f32_to_bits(masks)
+    want = O.step(x_np, mask_kind=O.MASK_BITS, mask=bits, mask_id=np.arange(B, dtype=np.int32), rng_mode=O.RNG_PHILOX, seed=31,
+                  offset=2, particle_base=7)
+    bits_d = _bits_dev(bits, dev)
+    got = engine.step(x_t.to(dev), mask_kind=1, mask=bits_d, rng_mode=1, seed=31, offset=2, particle_base=7)
+    torch.cuda.synchronize()
+    for w, g in zip(want, got):
+        assert np.array_equal(_np(g).view(np.uint32), w.view(np.uint32))
+    assert _np(got[2])[1] == -1 and _np(got[2])[2] == V - 1
+    tdt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[dtype]
+    got_p = engine.step(x_t.to(dev), mask=engine.prepare_masks(bits_d, V, tdt), rng_mode=1, seed=31, offset=2, particle_base=7)
+    torch.cuda.synchronize()
+    for a, b in zip(got, got_p):
+        assert torch.equal(a, b)
+    engine.check()

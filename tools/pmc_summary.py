@@ -10,8 +10,9 @@ import sys
 
 root = sys.argv[1]
 ALGO = {"kernel": 1024 * 50257 * 4 + 2 * 1571 * 4 + 1024 * 8, "kernel-llama": 512 * 128256 * 2 + 2 * 4008 * 4 + 512 * 8,
-        "sis": None}  # sis: 1 launch in 10 has one unique row; mean algorithmic bytes are in the bench line (about 184.8 MB)
-KERNELS = ("glb::fused_step_kernel", "glb::chunk_stats_small_kernel", "glb::chunk_stats_kernel", "glb::finish_kernel")
+        "kernel-rowmasks": 1024 * 50257 * 4 + 1024 * 1571 * 4 + 1024 * 8, "sis": None}  # sis: 1 launch in 10 has one unique row; mean algorithmic bytes are in the bench line (about 184.8 MB)
+KERNELS = ("glb::fused_step_kernel", "glb::chunk_stats_small_kernel", "glb::chunk_stats_kernel", "glb::finish_kernel",
+           "glb::mask_prepare_kernel")
 CALL_HEADS = ("glb::fused_step_kernel", "glb::chunk_stats_small_kernel", "glb::chunk_stats_kernel")  # one per fused call
 
 
@@ -20,7 +21,7 @@ def first(pattern):
     return g[0] if g else None
 
 
-for wl in ("kernel", "kernel-llama", "sis"):
+for wl in ("kernel", "kernel-llama", "kernel-rowmasks", "sis"):
     out = {}
     for tag, sub in (("FETCH_SIZE", f"pmc_fetch_{wl}"), ("WRITE_SIZE", f"pmc_write_{wl}")):
         f = first(f"{sub}/**/*counter_collection.csv")
@@ -44,7 +45,7 @@ for wl in ("kernel", "kernel-llama", "sis"):
     out["hbm_read_bytes_per_launch_corrected"] = fetch * 1024 * 2
     out["hbm_write_bytes_per_launch"] = write * 1024
     out["algorithmic_bytes_per_launch"] = ALGO[wl]
-    out["note"] = (f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python3 bench.py --workload {wl} "
+    out["note"] = (f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python3 bench.py --workload {wl.replace('-rowmasks', ' --per-row-masks')} "
                    f"--steps 20 --warmup {0 if wl == 'sis' else 2} --no-cpu`; one fused call = fused_step_kernel (small calls: chunk_stats_small_kernel + finish_kernel); FETCH_SIZE doubled "
                    "per MI355X_MICROARCH.md (gfx950 tallies 128-B read requests at 64 B)")
     json.dump(out, open(os.path.join(root, f"{wl}_pmc_traffic.json"), "w"), indent=1)
@@ -71,7 +72,28 @@ if lsm:
                    "128256 bf16 (131.3 MB in, 262.7 MB out); FETCH_SIZE doubled per MI355X_MICROARCH.md")
     json.dump(out, open(os.path.join(root, "lsm_pmc_traffic.json"), "w"), indent=1)
     print("lsm", json.dumps(out, indent=1))
-for tag in ("kernel", "kernel-llama", "sis", "sis-llama", "lsm", "trie"):
+# trie masses: traffic per launch of every trie kernel (tools/tbench.py)
+trie = {}
+for tag, sub in (("FETCH_SIZE", "pmc_fetch_trie"), ("WRITE_SIZE", "pmc_write_trie")):
+    f = first(f"{sub}/**/*counter_collection.csv")
+    if not f:
+        continue
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            if row.get("Counter_Name") == tag and "trie_" in row["Kernel_Name"]:
+                key = f"{row['Kernel_Name'].split('(')[0].replace('void ', '')} grid {row.get('Grid_Size') or row.get('Grid_Size_X')}"
+                trie.setdefault(key, {}).setdefault(tag, []).append(float(row["Counter_Value"]))
+if trie:
+    out = {}
+    for key, d in sorted(trie.items()):
+        rd = sum(d.get("FETCH_SIZE", [0])) / max(len(d.get("FETCH_SIZE", [0])), 1) * 1024 * 2
+        wr = sum(d.get("WRITE_SIZE", [0])) / max(len(d.get("WRITE_SIZE", [0])), 1) * 1024
+        out[key] = {"launches": len(d.get("FETCH_SIZE", [])), "hbm_read_bytes_per_launch_corrected": rd, "hbm_write_bytes_per_launch": wr}
+    out["note"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python3 tools/tbench.py`; FETCH_SIZE doubled per "
+                   "MI355X_MICROARCH.md (calibrated there for 16-byte-per-lane streaming reads; the level kernels read 16 bytes per lane)")
+    json.dump(out, open(os.path.join(root, "trie_pmc_traffic.json"), "w"), indent=1)
+    print("trie", json.dumps(out, indent=1))
+for tag in ("kernel", "kernel-llama", "kernel-rowmasks", "sis", "sis-llama", "sisparticlekv", "apiautokv", "lsm", "trie"):
     f = first(f"kstats_{tag}/**/*kernel_stats.csv")
     if f:
         lines = open(f).read().splitlines()

@@ -37,6 +37,22 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_lsm -o w -- pytho
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_trie -o t -- python3 $R/tools/tbench.py > $O/kstats_trie.log 2>&1
 python3 $R/tools/trace_by_grid.py $(find $O/kstats_lsm -name "*kernel_trace.csv" | head -1) > $O/lsm_by_shape.txt 2>&1
 python3 $R/tools/trace_by_grid.py $(find $O/kstats_trie -name "*kernel_trace.csv" | head -1) > $O/trie_by_shape.txt 2>&1
+# ---- round 4: per-particle masks, the verbatim README loop, the KV step, SQ counters, trie traffic -------------------------
+python3 $R/bench.py --workload kernel --per-row-masks --steps 200 --warmup 10 --no-cpu > $O/bench_kernel_rowmasks.json 2>> $O/bench_kernel.err
+python3 $R/bench.py --workload kernel-llama --per-row-masks --steps 200 --warmup 10 --no-cpu > $O/bench_kernel-llama_rowmasks.json 2>> $O/bench_kernel.err
+python3 $R/bench.py --workload sis --per-row-masks --steps 30 --warmup 5 --no-cpu > $O/bench_sis_rowmasks.json 2>> $O/bench_sis.err
+python3 $R/bench.py --workload api-readme --steps 10 --warmup 2 --no-cpu > $O/bench_api-readme.json 2>> $O/bench_api.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_kernel-rowmasks -o k -- python3 $R/bench.py --workload kernel --per-row-masks --steps 100 --warmup 5 --no-cpu > $O/kstats_kernel-rowmasks.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_kernel-rowmasks -o f -- python3 $R/bench.py --workload kernel --per-row-masks --steps 20 --warmup 2 --no-cpu > $O/pmc_f_kernel-rowmasks.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_kernel-rowmasks -o w -- python3 $R/bench.py --workload kernel --per-row-masks --steps 20 --warmup 2 --no-cpu > $O/pmc_w_kernel-rowmasks.log 2>&1
+for t in "sis --particle-kv" "api --auto-kv"; do
+  n=$(echo $t | tr -d ' -')
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_$n -o s -- python3 $R/bench.py --workload $t --steps 50 --warmup 10 --no-cpu > $O/kstats_$n.log 2>&1
+  tr=$(find $O/kstats_$n -name "*kernel_trace.csv" | head -1)
+  [ -n "$tr" ] && python3 $R/tools/gpu_busy.py $tr > $O/${n}_gpu_busy.txt 2>&1
+done
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_trie -o f -- python3 $R/tools/tbench.py > $O/pmc_f_trie.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_trie -o w -- python3 $R/tools/tbench.py > $O/pmc_w_trie.log 2>&1
 python3 $R/tools/gbench.py > $O/gbench.log 2>&1
 python3 $R/tools/pmc_summary.py $O > $O/pmc_summary.log
 find $O -name "*.db" -delete 2>/dev/null || true
