@@ -380,6 +380,7 @@ def main():
         if kern_us is not None and len(kern_us):
             ach = runner.kernel_bytes / (np.mean(kern_us) * 1e-6) / 1e9
             outer = runner.outer_times_us()
+            traffic, traffic_src = pmc_traffic(workload + ("-rowmasks" if args.per_row_masks and workload.startswith("kernel") else ""))
             out["roofline"] = {
                 "bound": "hbm",
                 "achieved": ach,
@@ -387,7 +388,11 @@ def main():
                 "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS,
                 "frac_median": runner.kernel_bytes / (np.median(kern_us) * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(workload),
+                "traffic": traffic,
+                # (counters cannot be read from inside the process: NOT measured in this run, but by an earlier rocprofv3
+                # --pmc pass of this same command whose summary is committed under profiles/)
+                "traffic_source": (f"{traffic_src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this "
+                                   "command, not this run") if traffic_src else None,
                 "kernel": "glb::fused_step_kernel (fused log-softmax + mask + logsumexp + sample in ONE launch: stats waves "
                           "stream the rows chunk by chunk, finishing waves at the end of the grid fold the tagged records "
                           "and draw); the few calls too small for it (one shared row: SIS step 0) run "
@@ -428,10 +433,10 @@ def pmc_traffic(workload):
         prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"{workload}_pmc_traffic*.json")), key=order)
         if prof:
             t = json.load(open(prof[-1]))
-            return t["hbm_read_bytes_per_launch_corrected"] + t["hbm_write_bytes_per_launch"]
+            return t["hbm_read_bytes_per_launch_corrected"] + t["hbm_write_bytes_per_launch"], os.path.relpath(prof[-1], ROOT)
     except (OSError, ValueError, KeyError):
         pass
-    return None
+    return None, None
 
 
 def plumbing(args, rank, world, dist):

@@ -148,6 +148,8 @@ SYMBOLS = {
     "glb_match_rows": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "glb_slab_attention": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
                                      _f32, _i32, _vp, _vp]),
+    "glb_short_attention": (C.c_int, [_vp, C.POINTER(C.c_int64), _vp, C.POINTER(C.c_int64), _vp, C.POINTER(C.c_int64), _vp, _i64, _i64,
+                                      _i64, _i64, _i64, _i64, _i64, _i64, _f32, _i32, _vp, _vp]),
     "glb_kv_plan_workspace": (_sz, [_i64, _i64]),
     "glb_kv_plan": (C.c_int, [C.POINTER(KvPlanArgs), _vp]),
     "glb_trie_workspace": (_sz, [_i64, _i64]),

@@ -15,7 +15,7 @@
 //                 scales, the sum of all elements, the allowed sums by 16-lane row of the wave - written through to
 //                 memory, fire and forget: no barrier, no fence, no wait, no cross-wave dependency.  Rows shared by
 //                 several particles (dedup fan-out of hf.py:214-220,285-288) are reduced once.
-//   finish role   one wave per PARTICLE, dealt at the END of the grid: sweeps its row's records until every tag carries
+//   finish role   one wave per PARTICLE, dealt at the END of the grid (inside it was measured: slower): sweeps its row's records until every tag carries
 //                 this call's epoch (the data is the flag: MI355X guide, Guideline 16 form R2; bounded spin), folds them
 //                 into (N, S_all, S_mask), lse / logZ by a double-precision log, picks the chunk with the first Philox
 //                 word and the 16-lane row inside it (from the record) with the second, reloads that QUARTER chunk,
@@ -25,9 +25,12 @@
 // stream capture (the epoch is a launch argument), for workspaces nobody initialised, for launches of at most 512
 // chunks (four waves per chunk), and for the parity-mode exponential race (four waves per particle over the whole row).
 //   logprob_rows_waves_kernel   glb_log_softmax_rows (cache.py:93-98) in one launch: a wave keeps its chunk in registers,
-//                               meets its row-mates through the same tagged records and writes x - lse; the
-//                               workgroup-per-row / three-launch forms serve rows of more than 64 chunks and workspaces
-//                               without tags.
+//                               meets its row-mates through the same tagged records and writes x - lse (float32, or
+//                               rounded into the logits' own 16-bit type: cache.py:96 keeps the dtype); three launches
+//                               (statistics, one wave per row, logprob_rows_kernel) serve rows of more than 64 chunks and
+//                               workspaces without tags.
+// A wave that gives up a wait inside a launch (kSpinTicks / glb_set_spin_limit) writes token -2 / NaN and counts in the
+// workspace's error word (StepParams::err): include/glb.h, glb_workspace_check.
 // mask_prepare_kernel builds the transposed masks ([mask][chunk][vector][component] 64-bit lane words).
 #pragma once
 #include <type_traits>

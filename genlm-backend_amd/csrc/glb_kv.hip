@@ -457,6 +457,94 @@ hipError_t launch_attention(const AttnArgs &a, int head_dim, hipStream_t s) {
   const dim3 grid((unsigned)((int64_t)a.R * a.H)), block(64);
   if (head_dim == 64) hipLaunchKernelGGL((slab_attention_kernel<DT, 64>), grid, block, 0, s, a);
   else if (head_dim == 128) hipLaunchKernelGGL((slab_attention_kernel<DT, 128>), grid, block, 0, s, a);
+  else if (head_dim == 32) hipLaunchKernelGGL((slab_attention_kernel<DT, 32>), grid, block, 0, s, a);
+  else if (head_dim == 16) hipLaunchKernelGGL((slab_attention_kernel<DT, 16>), grid, block, 0, s, a);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// glb_short_attention: masked attention of the padded batches of short contexts the hot path feeds the transformer
+// (hf.py:232-281: ragged contexts right-padded to the batch's longest, optionally behind zero-padded cached prefixes) -
+// a dozen query positions against a dozen or two keys per (row, head).  PyTorch's SDPA spends 410 us per GPT-2-small layer
+// on 919 rows x 12 heads x 13 tokens with the padding mask (a fifth of the 24 ms step); the arithmetic is 5 k MACs per
+// (row, head).  One wave per (row, head, query position), the slab kernel's scheme: LP lanes per key, PP keys per pass,
+// an online softmax per key slot, slots merged at the end; the (row, head)'s K / V are read by its Lq waves out of the
+// L1 / L2.  Which keys a query may see comes from the boolean mask transformers built ([U, 1, Lq, Lk], true = attend),
+// or without one from causality (key s <= query t + Lk - Lq).  A query that may see nothing gets zeros.
+// ---------------------------------------------------------------------------------------------------------------------
+struct ShortArgs {
+  const char *q, *k, *v;
+  const uint8_t *mask;  // nullable
+  char *out;
+  int64_t q_sr, q_sh, q_sp, k_sr, k_sh, k_sp, v_sr, v_sh, v_sp, m_sr, m_sq;  // element strides: row, head, position
+  int32_t U, H, Hkv, Lq, Lk;
+  float scale;
+};
+
+template <int DT, int DH>
+__global__ __launch_bounds__(64) void short_attention_kernel(const ShortArgs a) {
+  constexpr int ES = DT == GLB_F32 ? 4 : 2, EPV = 16 / ES, LP = DH / EPV, PP = 64 / LP;
+  static_assert(LP >= 1 && LP <= 64 && PP * LP == 64, "head_dim / vector width must divide the wave");
+  const int lane = threadIdx.x, j = lane / LP, i = lane - j * LP;
+  const int t = blockIdx.x % a.Lq, uh = blockIdx.x / a.Lq, h = uh % a.H, u = uh / a.H;
+  const int hk = h / (a.H / a.Hkv);
+  float qf[EPV];
+  unpack16<DT>(*reinterpret_cast<const u32x4 *>(a.q + ((int64_t)u * a.q_sr + (int64_t)h * a.q_sh + (int64_t)t * a.q_sp + i * EPV) * ES), qf);
+  const uint8_t *mrow = a.mask ? a.mask + (int64_t)u * a.m_sr + (int64_t)t * a.m_sq : nullptr;
+  const int last = mrow ? a.Lk - 1 : (t + a.Lk - a.Lq < a.Lk - 1 ? t + a.Lk - a.Lq : a.Lk - 1);  // causal: keys beyond it are never seen
+  const char *kb = a.k + ((int64_t)u * a.k_sr + (int64_t)hk * a.k_sh + i * EPV) * ES;
+  const char *vb = a.v + ((int64_t)u * a.v_sr + (int64_t)hk * a.v_sh + i * EPV) * ES;
+  float m = -__builtin_huge_valf(), l = 0.0f, acc[EPV];
+#pragma unroll
+  for (int k = 0; k < EPV; ++k) acc[k] = 0.0f;
+  for (int p0 = 0; p0 <= last; p0 += PP) {
+    const int p = p0 + j;
+    const bool in = p <= last;
+    const bool see = in && (mrow ? mrow[p] != 0 : true);
+    float kf[EPV], vf[EPV];
+    const int pc = in ? p : last;  // (lanes past the end read the last key and ignore it)
+    unpack16<DT>(*reinterpret_cast<const u32x4 *>(kb + (int64_t)pc * a.k_sp * ES), kf);
+    unpack16<DT>(*reinterpret_cast<const u32x4 *>(vb + (int64_t)pc * a.v_sp * ES), vf);
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < EPV; ++k) s = __builtin_fmaf(qf[k], kf[k], s);
+#pragma unroll
+    for (int o = 1; o < LP; o <<= 1) s += __shfl_xor(s, o, 64);
+    if (see) {
+      s *= a.scale;
+      const float m2 = fmaxf(m, s), c = __expf(m - m2), w = __expf(s - m2);
+      l = l * c + w;
+#pragma unroll
+      for (int k = 0; k < EPV; ++k) acc[k] = __builtin_fmaf(acc[k], c, w * vf[k]);
+      m = m2;
+    }
+  }
+#pragma unroll
+  for (int o = LP; o < 64; o <<= 1) {
+    const float mo = __shfl_xor(m, o, 64), lo = __shfl_xor(l, o, 64);
+    const float m2 = fmaxf(m, mo);
+    const float c = m == m2 ? 1.0f : __expf(m - m2), co = mo == m2 ? 1.0f : __expf(mo - m2);
+    l = l * c + lo * co;
+#pragma unroll
+    for (int k = 0; k < EPV; ++k) acc[k] = acc[k] * c + __shfl_xor(acc[k], o, 64) * co;
+    m = m2;
+  }
+  if (j == 0) {
+    const float inv = l > 0.0f ? 1.0f / l : 0.0f;
+#pragma unroll
+    for (int k = 0; k < EPV; ++k) acc[k] *= inv;
+    *reinterpret_cast<u32x4 *>(a.out + ((((int64_t)u * a.Lq + t) * a.H + h) * DH + i * EPV) * ES) = pack16v<DT>(acc);
+  }
+}
+
+template <int DT>
+hipError_t launch_short_attention(const ShortArgs &a, int head_dim, hipStream_t s) {
+  const dim3 grid((unsigned)((int64_t)a.U * a.H * a.Lq)), block(64);
+  if (head_dim == 64) hipLaunchKernelGGL((short_attention_kernel<DT, 64>), grid, block, 0, s, a);
+  else if (head_dim == 128) hipLaunchKernelGGL((short_attention_kernel<DT, 128>), grid, block, 0, s, a);
+  else if (head_dim == 32) hipLaunchKernelGGL((short_attention_kernel<DT, 32>), grid, block, 0, s, a);
+  else if (head_dim == 16) hipLaunchKernelGGL((short_attention_kernel<DT, 16>), grid, block, 0, s, a);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
@@ -474,7 +562,8 @@ int glb_slab_attention(const void *q, int64_t q_stride_row, int64_t q_stride_hea
   if (dtype < GLB_F32 || dtype > GLB_F16) return glb::api_fail(GLB_EINVAL, "bad dtype %d", dtype);
   if (n_rows <= 0 || heads <= 0 || kv_heads <= 0 || cap <= 0 || heads % kv_heads || n_rows * heads > 0x7fffffffll)
     return glb::api_fail(GLB_EINVAL, "glb_slab_attention: bad sizes");
-  if (head_dim != 64 && head_dim != 128) return glb::api_fail(GLB_EUNSUPPORTED, "glb_slab_attention: head_dim %lld (64 and 128 are built)", (long long)head_dim);
+  if (head_dim != 16 && head_dim != 32 && head_dim != 64 && head_dim != 128)
+    return glb::api_fail(GLB_EUNSUPPORTED, "glb_slab_attention: head_dim %lld (16, 32, 64 and 128 are built)", (long long)head_dim);
   const int es = dtype == GLB_F32 ? 4 : 2;
   if (((uintptr_t)q | (uintptr_t)k_new | (uintptr_t)v_new | (uintptr_t)k_slab | (uintptr_t)v_slab | (uintptr_t)out) % 16 ||
       (q_stride_row * es) % 16 || (q_stride_head * es) % 16 || (k_stride_row * es) % 16 || (k_stride_head * es) % 16 ||
@@ -585,6 +674,48 @@ int glb_kv_plan(const glb_kv_plan_args *a, void *stream) {
   hipLaunchKernelGGL(kv_plan_kernel, dim3(1), dim3(kT), (size_t)p.lds_rows * sizeof(int), (hipStream_t)stream, p);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return glb::api_hip_fail(e, "kv_plan launch");
+  return GLB_OK;
+}
+
+int glb_short_attention(const void *q, const int64_t q_strides[3], const void *k, const int64_t k_strides[3], const void *v,
+                        const int64_t v_strides[3], const uint8_t *mask, int64_t mask_stride_row, int64_t mask_stride_query,
+                        int64_t n_rows, int64_t heads, int64_t kv_heads, int64_t q_len, int64_t k_len, int64_t head_dim,
+                        float scale, int32_t dtype, void *out, void *stream) {
+  if (!q || !k || !v || !out || !q_strides || !k_strides || !v_strides) return glb::api_fail(GLB_EINVAL, "glb_short_attention: null pointer");
+  if (dtype < GLB_F32 || dtype > GLB_F16) return glb::api_fail(GLB_EINVAL, "bad dtype %d", dtype);
+  if (n_rows <= 0 || heads <= 0 || kv_heads <= 0 || q_len <= 0 || k_len <= 0 || heads % kv_heads || k_len < q_len ||
+      n_rows * heads * q_len > 0x7fffffffll || k_len > 0x7fffffffll)
+    return glb::api_fail(GLB_EINVAL, "glb_short_attention: bad sizes");
+  if (head_dim != 16 && head_dim != 32 && head_dim != 64 && head_dim != 128)
+    return glb::api_fail(GLB_EUNSUPPORTED, "glb_short_attention: head_dim %lld (16, 32, 64 and 128 are built)", (long long)head_dim);
+  const int es = dtype == GLB_F32 ? 4 : 2;
+  bool aligned = (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) % 16) == 0;
+  for (int d = 0; d < 3; ++d) aligned = aligned && (q_strides[d] * es) % 16 == 0 && (k_strides[d] * es) % 16 == 0 && (v_strides[d] * es) % 16 == 0;
+  if (!aligned) return glb::api_fail(GLB_EINVAL, "glb_short_attention: pointers and strides must be 16-byte aligned");
+  ShortArgs a{};
+  a.q = (const char *)q;
+  a.k = (const char *)k;
+  a.v = (const char *)v;
+  a.mask = mask;
+  a.out = (char *)out;
+  a.q_sr = q_strides[0], a.q_sh = q_strides[1], a.q_sp = q_strides[2];
+  a.k_sr = k_strides[0], a.k_sh = k_strides[1], a.k_sp = k_strides[2];
+  a.v_sr = v_strides[0], a.v_sh = v_strides[1], a.v_sp = v_strides[2];
+  a.m_sr = mask_stride_row;
+  a.m_sq = mask_stride_query;
+  a.U = (int32_t)n_rows;
+  a.H = (int32_t)heads;
+  a.Hkv = (int32_t)kv_heads;
+  a.Lq = (int32_t)q_len;
+  a.Lk = (int32_t)k_len;
+  a.scale = scale;
+  hipError_t e;
+  switch (dtype) {
+    case GLB_F32: e = launch_short_attention<GLB_F32>(a, (int)head_dim, (hipStream_t)stream); break;
+    case GLB_BF16: e = launch_short_attention<GLB_BF16>(a, (int)head_dim, (hipStream_t)stream); break;
+    default: e = launch_short_attention<GLB_F16>(a, (int)head_dim, (hipStream_t)stream); break;
+  }
+  if (e != hipSuccess) return glb::api_hip_fail(e, "short_attention launch");
   return GLB_OK;
 }
 

@@ -438,7 +438,25 @@ class HipEngine:
 
     @staticmethod
     def slab_attention_supports(dtype, head_dim):
-        return dtype in _DT and head_dim in (64, 128)
+        return dtype in _DT and head_dim in (16, 32, 64, 128)
+
+    def short_attention(self, query, key, value, mask, scale):
+        """Masked attention of a padded batch of short contexts (glb_short_attention).  query [U, H, Lq, Dh], key / value
+        [U, H_kv, Lk, Dh] (unit inner stride), mask: bool [U, 1, Lq, Lk] (true = attend) or None (causal).  Returns
+        [U, Lq, H, Dh]."""
+        U, H, Lq, Dh = query.shape
+        Hkv, Lk = key.shape[1], key.shape[2]
+        assert query.stride(3) == 1 and key.stride(3) == 1 and value.stride(3) == 1 and key.dtype == value.dtype == query.dtype
+        out = torch.empty((U, Lq, H, Dh), dtype=query.dtype, device=self.device)
+        i64x3 = C.c_int64 * 3
+        m_ptr, m_sr, m_sq = None, 0, 0
+        if mask is not None:
+            assert mask.dtype == torch.bool and mask.dim() == 4 and mask.shape[-1] == Lk and mask.stride(3) == 1 and mask.shape[1] == 1
+            m_ptr, m_sr, m_sq = _ptr(mask), (mask.stride(0) if mask.shape[0] > 1 else 0), (mask.stride(2) if mask.shape[2] > 1 else 0)
+        check(self.lib.glb_short_attention(_ptr(query), i64x3(*query.stride()[:3]), _ptr(key), i64x3(*key.stride()[:3]), _ptr(value),
+                                           i64x3(*value.stride()[:3]), m_ptr, m_sr, m_sq, U, H, Hkv, Lq, Lk, Dh, float(scale),
+                                           _DT[query.dtype], _ptr(out), self._stream()))
+        return out
 
     def kv_gather_rows(self, srcs, dsts, src_row_of, len_of):
         """dsts[t][i, h, p] = srcs[t][src_row_of[i], h, p] for p < len_of[i], for every tensor pair of the two lists

@@ -15,24 +15,42 @@ import torch
 from transformers.cache_utils import Cache, CacheLayerMixin
 
 
-# ---- the attention of the in-place one-token forward (glb_slab_attention) -------------------------------------------------
-# Registered with transformers' attention interface under its own name; SlabForward points the model's configuration at
-# it.  Whatever is not the in-place forward of the slab set that is current (encodings of whole contexts, gathered
-# batches, CPU runs) goes to the library's own SDPA path, exactly as before.
-_ACTIVE = None  # the SlabKV whose in-place forward is running (set by SlabForward._run)
-_ATTN_NAME = "glb_slab"
+# ---- the attention kernels of the path behind transformers' attention interface -----------------------------------------
+# Registered under one name; AsyncAmdLM points its model's configuration at it.  Two forwards of the hot path are served
+# by this library's kernels - the in-place one-token forward over KV slab rows (glb_slab_attention: append fused, no mask
+# tensor) and the padded batches of short contexts (glb_short_attention: a dozen tokens per row, where the library SDPA
+# kernels spend a fifth of the step) - and everything else (long sequences, dropout, exotic masks, CPU runs) goes to
+# transformers' own SDPA path exactly as before.
+_ACTIVE = None     # the SlabKV whose in-place forward is running (set by SlabForward._run)
+_ENGINES = {}      # id(model config) -> HipEngine (set by use_glb_attention)
+_ATTN_NAME = "glb"
+SHORT_ATTENTION_MAX = 4096  # q_len * k_len up to which glb_short_attention is used
 
 
-def _slab_attention_forward(module, query, key, value, attention_mask, dropout=0.0, scaling=None, **kwargs):
+def _glb_attention_forward(module, query, key, value, attention_mask, dropout=0.0, scaling=None, **kwargs):
     from transformers.integrations.sdpa_attention import sdpa_attention_forward
 
     pkv = _ACTIVE
     layer = None if pkv is None else pkv.layers[module.layer_idx]
-    if layer is None or layer._new_k is None or key is not layer.keys or query.shape[2] != 1:
-        return sdpa_attention_forward(module, query, key, value, attention_mask, dropout=dropout, scaling=scaling, **kwargs)
-    k_new, v_new, layer._new_k, layer._new_v = layer._new_k, layer._new_v, None, None
-    scale = scaling if scaling is not None else query.shape[-1] ** -0.5
-    return pkv.engine.slab_attention(query, k_new, v_new, layer.keys, layer.values, pkv.pos, scale), None
+    if layer is not None and layer._new_k is not None and key is layer.keys and query.shape[2] == 1:
+        k_new, v_new, layer._new_k, layer._new_v = layer._new_k, layer._new_v, None, None
+        scale = scaling if scaling is not None else query.shape[-1] ** -0.5
+        return pkv.engine.slab_attention(query, k_new, v_new, layer.keys, layer.values, pkv.pos, scale), None
+    eng = _ENGINES.get(id(getattr(module, "config", None)))
+    Lq, Lk = query.shape[2], key.shape[2]
+    if (eng is not None and query.is_cuda and not dropout and Lq * Lk <= SHORT_ATTENTION_MAX and Lk >= Lq
+            and eng.slab_attention_supports(query.dtype, query.shape[-1]) and key.dtype == query.dtype == value.dtype
+            and query.stride(3) == 1 and key.stride(3) == 1 and value.stride(3) == 1
+            and kwargs.get("is_causal", True) is not False and not kwargs.get("softcap") and not kwargs.get("sliding_window")
+            and getattr(module, "is_causal", True)
+            and (attention_mask is None or (attention_mask.dtype == torch.bool and attention_mask.dim() == 4
+                                            and attention_mask.shape[1] == 1 and attention_mask.shape[-1] == Lk
+                                            and attention_mask.stride(3) == 1))
+            and all((st * query.element_size()) % 16 == 0 for t in (query, key, value) for st in t.stride()[:3])
+            and all(t.data_ptr() % 16 == 0 for t in (query, key, value))):
+        scale = scaling if scaling is not None else query.shape[-1] ** -0.5
+        return eng.short_attention(query, key, value, attention_mask, scale), None
+    return sdpa_attention_forward(module, query, key, value, attention_mask, dropout=dropout, scaling=scaling, **kwargs)
 
 
 def _register_attention():
@@ -40,8 +58,29 @@ def _register_attention():
     from transformers.modeling_utils import ALL_ATTENTION_FUNCTIONS
 
     if _ATTN_NAME not in ALL_ATTENTION_FUNCTIONS:
-        ALL_ATTENTION_FUNCTIONS.register(_ATTN_NAME, _slab_attention_forward)
+        ALL_ATTENTION_FUNCTIONS.register(_ATTN_NAME, _glb_attention_forward)
         ALL_MASK_ATTENTION_FUNCTIONS.register(_ATTN_NAME, ALL_MASK_ATTENTION_FUNCTIONS["sdpa"])
+
+
+def use_glb_attention(model, engine):
+    """Point `model` (a transformers model whose attention goes through the attention interface as "sdpa") at this
+    library's attention kernels; returns whether it was done.  Undo with `restore_attention(model)`."""
+    cfg = getattr(model, "config", None)
+    if (cfg is None or not hasattr(engine, "short_attention") or getattr(cfg, "_attn_implementation", None) != "sdpa"
+            or getattr(cfg, "attn_logit_softcapping", None) or getattr(cfg, "sliding_window", None)
+            or getattr(cfg, "scale_attn_by_inverse_layer_idx", False)):
+        return False
+    _register_attention()
+    cfg._attn_implementation = _ATTN_NAME
+    _ENGINES[id(cfg)] = engine
+    return True
+
+
+def restore_attention(model):
+    cfg = getattr(model, "config", None)
+    if cfg is not None and getattr(cfg, "_attn_implementation", None) == _ATTN_NAME:
+        cfg._attn_implementation = "sdpa"
+        _ENGINES.pop(id(cfg), None)
 
 
 class _SlabLayer(CacheLayerMixin):
@@ -244,12 +283,7 @@ class SlabForward:
         self.fused = bool(fused_attention and cfg is not None and k0 is not None and k0.is_cuda
                           and hasattr(pkv.engine, "slab_attention")
                           and pkv.engine.slab_attention_supports(k0.dtype, k0.shape[-1])
-                          and getattr(cfg, "_attn_implementation", None) in ("sdpa", _ATTN_NAME)
-                          and not getattr(cfg, "attn_logit_softcapping", None) and not getattr(cfg, "sliding_window", None)
-                          and not getattr(cfg, "scale_attn_by_inverse_layer_idx", False))
-        if self.fused:
-            _register_attention()
-            cfg._attn_implementation = _ATTN_NAME  # (every other forward of the model falls through to SDPA)
+                          and (getattr(cfg, "_attn_implementation", None) == _ATTN_NAME or use_glb_attention(body, pkv.engine)))
 
     def _run(self, ids, pos):
         global _ACTIVE

@@ -155,6 +155,13 @@ class AsyncAmdLM(AsyncLM):
                     replaced.append((mod, name, child))
         return replaced
 
+    def restore_attention(self):
+        """Undo `glb_attention` on the wrapped HuggingFace model (its configuration is patched in place)."""
+        from .kv import restore_attention
+
+        restore_attention(self.model)
+        self.glb_attention = False
+
     def restore_activations(self):
         """Undo `fuse_activations` on the wrapped HuggingFace model (it is patched in place)."""
         for mod, name, child in self._replaced_activations:
@@ -193,8 +200,13 @@ class AsyncAmdLM(AsyncLM):
     @torch.no_grad()
     def __init__(self, hf_model, hf_tokenizer, batch_size=20, timeout=0.02, engine=None, fuse_activations=True,
                  kv_budget_bytes=8 << 30, logprob_budget_bytes=16 << 30, auto_kv_rows=0, auto_kv_cap=64,
-                 logprob_dtype="float32"):
-        """logprob_dtype: "float32" (default: every row `next_token_logprobs` returns is float32, whatever the checkpoint's
+                 logprob_dtype="float32", glb_attention=True):
+        """glb_attention: route the model's attention through this library's kernels where they apply (padded batches of
+        short contexts: glb_short_attention; the in-place one-token forward over KV rows: glb_slab_attention) by
+        registering them with transformers' attention interface - `hf_model.config` is pointed at them IN PLACE
+        (`restore_attention()` undoes it); everything else still runs the model's SDPA path.  False: the model is left
+        as it is.
+        logprob_dtype: "float32" (default: every row `next_token_logprobs` returns is float32, whatever the checkpoint's
         dtype) or "model" - rows in the model's own dtype, what the reference returns (cache.py:96 keeps the dtype; for a
         bfloat16 checkpoint a third fewer bytes per materialised row: glb_log_softmax_rows' out_dtype).
         auto_kv_rows > 0: `batch_next_token_step` keeps the KV of the contexts it evaluates in that many slab rows of
@@ -221,6 +233,11 @@ class AsyncAmdLM(AsyncLM):
         # fuse_activations=True rewrites GPT-2's activation modules of `hf_model` IN PLACE (numerics: same formula,
         # different rounding; `restore_activations()` undoes it); pass False to leave the model untouched
         self._replaced_activations = self._fuse_activations(self.model) if fuse_activations else []
+        self.glb_attention = False
+        if glb_attention and self.device.type == "cuda":
+            from .kv import use_glb_attention
+
+            self.glb_attention = use_glb_attention(self.model, self.engine)
         self._head = self.model.get_output_embeddings()
         if self._head is None:
             raise NotImplementedError(f"{type(hf_model).__name__} has no output embedding (get_output_embeddings() is None)")

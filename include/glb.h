@@ -374,7 +374,7 @@ int glb_kv_plan(const glb_kv_plan_args *args, void *hip_stream);
  * of this forward - its K / V (k_new, v_new: [n_rows, kv_heads, head_dim], each by its own element strides: the projections' outputs)
  * are used from where they are AND written to slab position pos[r] (glb_kv_append, fused).  q by element strides
  * (row, head), unit inner stride; slabs [n_rows, kv_heads, cap, head_dim] contiguous; out [n_rows, heads, head_dim]
- * contiguous; all of one dtype, float32 accumulation; head_dim 64 or 128 (GLB_EUNSUPPORTED otherwise); every pointer and
+ * contiguous; all of one dtype, float32 accumulation; head_dim 16 / 32 / 64 / 128 (GLB_EUNSUPPORTED otherwise); every pointer and
  * stride a multiple of 16 bytes.  One launch per layer instead of two appends, a mask and a dense SDPA call.
  */
 int glb_slab_attention(const void *q, int64_t q_stride_row, int64_t q_stride_head, const void *k_new, int64_t k_stride_row,
@@ -382,6 +382,21 @@ int glb_slab_attention(const void *q, int64_t q_stride_row, int64_t q_stride_hea
                        void *v_slab, const int32_t *pos,
                        int64_t n_rows, int64_t heads, int64_t kv_heads, int64_t cap, int64_t head_dim, float scale,
                        int32_t dtype, void *out, void *hip_stream);
+
+/*
+ * Masked attention of the padded batches of short contexts the path feeds the transformer (hf.py:232-281): for every row u,
+ * query head h and query position t, softmax over the keys s it may see of q[u,h,t] . k[u,h/G,s] * scale, times v.  q / k / v
+ * by element strides {row, head, position} with unit inner stride (the projections' outputs, cached prefixes in front of
+ * the keys); mask: bool / uint8 [n_rows, q_len, k_len] by strides (row, query), nonzero = attend - the 4-D mask
+ * transformers builds from the padding mask - or null: causal, key s <= t + k_len - q_len.  out [n_rows, q_len, heads,
+ * head_dim] contiguous.  float32 accumulation; head_dim 16 / 32 / 64 / 128; pointers and strides multiples of 16 bytes.
+ * One wave per (row, head, query): meant for q_len * k_len of a few hundred (a dozen tokens per context), where the
+ * library SDPA kernels spend a fifth of a 24 ms step; long sequences stay with them.
+ */
+int glb_short_attention(const void *q, const int64_t q_strides[3], const void *k, const int64_t k_strides[3], const void *v,
+                        const int64_t v_strides[3], const uint8_t *mask, int64_t mask_stride_row, int64_t mask_stride_query,
+                        int64_t n_rows, int64_t heads, int64_t kv_heads, int64_t q_len, int64_t k_len, int64_t head_dim,
+                        float scale, int32_t dtype, void *out, void *hip_stream);
 
 /*
  * Systematic resampling of the whole population from the all-gathered log-weights (the step the all-gather of

@@ -1261,19 +1261,31 @@ def test_in_place_forward_with_fused_slab_attention_equals_sdpa(engine, family):
         la.values.copy_(torch.randn(la.values.shape, device=dev, generator=gg))
         lb.keys.copy_(la.keys)
         lb.values.copy_(la.values)
-    fa = SlabForward(a, body, graph=True, fused_attention=True)
-    fb = SlabForward(b, body, graph=False, fused_attention=False)
-    assert fa.fused and not fb.fused
+    steps = []
+    for _ in range(5):
+        ids = torch.randint(0, 500, (R, 1), device=dev, generator=g)
+        pos = torch.randint(0, cap, (R,), device=dev, generator=g, dtype=torch.int32)
+        pos[0], pos[1] = 0, cap - 1
+        steps.append((ids, pos))
     with torch.no_grad():
-        for step in range(5):  # (the third call captures the hipGraph, later ones replay it)
-            ids = torch.randint(0, 500, (R, 1), device=dev, generator=g)
-            pos = torch.randint(0, cap, (R,), device=dev, generator=g, dtype=torch.int32)
-            pos[0], pos[1] = 0, cap - 1
-            ha, hb = fa(ids, pos).clone(), fb(ids, pos).clone()
+        # the reference arm first, while the model's configuration still says "sdpa"
+        assert model.config._attn_implementation == "sdpa"
+        fb = SlabForward(b, body, graph=False, fused_attention=False)
+        assert not fb.fused
+        want = []
+        for ids, pos in steps:
+            h = fb(ids, pos).clone()
+            want.append((h, [(lb.keys.clone(), lb.values.clone()) for lb in b.layers]))
+        assert model.config._attn_implementation == "sdpa"
+        fa = SlabForward(a, body, graph=True, fused_attention=True)
+        assert fa.fused and model.config._attn_implementation == "glb"
+        for step, (ids, pos) in enumerate(steps):  # (the third call captures the hipGraph, later ones replay it)
+            ha = fa(ids, pos).clone()
             torch.cuda.synchronize()
+            hb, slabs = want[step]
             assert (ha - hb).abs().max().item() < 2e-4, step
-            for la, lb in zip(a.layers, b.layers):
-                assert (la.keys - lb.keys).abs().max().item() < 1e-4 and (la.values - lb.values).abs().max().item() < 1e-4
+            for la, (kb, vb) in zip(a.layers, slabs):
+                assert (la.keys - kb).abs().max().item() < 1e-4 and (la.values - vb).abs().max().item() < 1e-4
     assert len(fa.graphs) == 1
 
 
@@ -1332,3 +1344,45 @@ def test_load_model_by_name_end_to_end_on_gpu(tmp_path, dtype):
     for bad in ("vllm", "mlx", "nonsense"):
         with pytest.raises(ValueError):
             load_model_by_name(str(tmp_path), backend=bad)
+
+
+@pytest.mark.parametrize("dtype,U,H,Hkv,Lq,Lk,Dh", [(torch.float32, 50, 12, 12, 13, 13, 64), (torch.float32, 33, 4, 4, 10, 18, 16),
+                                                     (torch.bfloat16, 20, 32, 8, 9, 9, 64), (torch.float16, 7, 8, 2, 5, 30, 128),
+                                                     (torch.float32, 919, 12, 12, 13, 13, 64), (torch.bfloat16, 6, 4, 2, 1, 40, 32)])
+def test_short_attention_matches_torch(engine, dtype, U, H, Hkv, Lq, Lk, Dh):
+    """glb_short_attention on the padded batches the path builds (hf.py:232-281: right-padded contexts, optionally behind
+    zero-padded cached prefixes - the 4-D boolean mask transformers makes of them) and without a mask (causal), against
+    torch's scaled_dot_product_attention in float32 on the same values: grouped query heads, strided projection outputs."""
+    dev = engine.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(U + Lk)
+    proj = torch.randn((U, Lq, (H + 2 * Hkv) * Dh), device=dev, generator=g).to(dtype)  # q | k | v of one projection
+    q = proj[..., :H * Dh].view(U, Lq, H, Dh).transpose(1, 2)
+    k_new = proj[..., H * Dh:(H + Hkv) * Dh].view(U, Lq, Hkv, Dh).transpose(1, 2)
+    v_new = proj[..., (H + Hkv) * Dh:].view(U, Lq, Hkv, Dh).transpose(1, 2)
+    P = Lk - Lq  # cached prefix positions in front of the new keys
+    if P:
+        k = torch.cat([torch.randn((U, Hkv, P, Dh), device=dev, generator=g).to(dtype), k_new], dim=2)
+        v = torch.cat([torch.randn((U, Hkv, P, Dh), device=dev, generator=g).to(dtype), v_new], dim=2)
+    else:
+        k, v = k_new, v_new
+    lens = torch.randint(1, Lq + 1, (U,), device=dev, generator=g)
+    base = torch.randint(0, P + 1, (U,), device=dev, generator=g) if P else torch.zeros(U, dtype=torch.long, device=dev)
+    ar = torch.arange(Lk, device=dev)
+    key_ok = (ar[None, :] < base[:, None]) | ((ar[None, :] >= P) & (ar[None, :] < P + lens[:, None]))  # hf.py:58-64
+    causal = ar[None, :] <= (torch.arange(Lq, device=dev)[:, None] + P)
+    mask = (key_ok[:, None, None, :] & causal[None, None, :, :]).contiguous()
+    scale = Dh ** -0.5
+    G = H // Hkv
+    for m in (mask, None):
+        out = engine.short_attention(q, k, v, m, scale)
+        torch.cuda.synchronize()
+        ref_mask = m if m is not None else causal[None, None].expand(U, 1, Lq, Lk)
+        want = torch.nn.functional.scaled_dot_product_attention(q.float(), k.float().repeat_interleave(G, 1),
+                                                                v.float().repeat_interleave(G, 1), attn_mask=ref_mask, scale=scale)
+        want = want.transpose(1, 2)  # [U, Lq, H, Dh]
+        live = ref_mask.any(-1)[:, 0]  # queries that see at least one key (the others are padding: zeros here)
+        tol = 3e-5 if dtype == torch.float32 else (2e-2 if dtype == torch.bfloat16 else 3e-3)
+        assert out.shape == (U, Lq, H, Dh) and out.dtype == dtype
+        assert (out.float() - want)[live].abs().max().item() < tol
+        assert not bool(out[~live].any())

@@ -9,7 +9,7 @@ import genlm_backend_amd  # noqa: E402,F401
 from genlm_backend_amd import _lib  # noqa: E402
 
 if os.environ.get("GLB_DBG_LIB"):
-    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ["GLB_DBG_LIB"])
+    _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dbg", os.environ["GLB_DBG_LIB"])
 import bench  # noqa: E402
 
 bench.main()

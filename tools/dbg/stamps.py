@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 import genlm_backend_amd  # noqa: E402
 from genlm_backend_amd import _lib  # noqa: E402
 
-_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ.get("GLB_DBG_LIB", "libglb_hip_dbg.so"))
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get("GLB_DBG_LIB", "libglb_hip_dbg.so"))
 from genlm_backend_amd.engine import HipEngine  # noqa: E402
 
 shape = sys.argv[1] if len(sys.argv) > 1 else "gpt2"

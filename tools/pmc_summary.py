@@ -81,7 +81,10 @@ for tag, sub in (("FETCH_SIZE", "pmc_fetch_trie"), ("WRITE_SIZE", "pmc_write_tri
     with open(f) as fh:
         for row in csv.DictReader(fh):
             if row.get("Counter_Name") == tag and "trie_" in row["Kernel_Name"]:
-                key = f"{row['Kernel_Name'].split('(')[0].replace('void ', '')} grid {row.get('Grid_Size') or row.get('Grid_Size_X')}"
+                import re
+
+                name = re.search(r"trie_\w+(<[^>]*>)?", row["Kernel_Name"]).group(0)
+                key = f"{name} grid {row.get('Grid_Size') or row.get('Grid_Size_X')}"
                 trie.setdefault(key, {}).setdefault(tag, []).append(float(row["Counter_Value"]))
 if trie:
     out = {}
