@@ -138,9 +138,10 @@ __global__ __launch_bounds__(kT) void kv_plan_kernel(const PlanArgs a) {
   __syncthreads();
   // ---- the row a group's prefix sits in; the first group (by id) of every live row keeps it
   for (int u = tid; u < U; u += kT) {
-    const int o = a.old_src[a.old_sel ? a.old_sel[u] : u];
+    int o = a.old_src[a.old_sel ? a.old_sel[u] : u];
+    o = o >= 0 && o < R ? o : -1;  // (a row index outside the table reads as "no row")
     a.flags[u] = o;
-    if (o >= 0 && o < R) atomicMin(&a.keeper[o], u);
+    if (o >= 0) atomicMin(&a.keeper[o], u);
   }
   __syncthreads();
   // ---- free rows in the order they are handed out: by (stamp, row) - longest unused first - or by row
@@ -394,7 +395,8 @@ __global__ __launch_bounds__(64) void slab_attention_kernel(const AttnArgs a) {
   const int lane = threadIdx.x, j = lane / LP, i = lane - j * LP;
   const int r = blockIdx.x / a.H, h = blockIdx.x - r * a.H;
   const int G = a.H / a.Hkv, hk = h / G;
-  const int p_new = a.pos[r];  // the token being appended sits at p_new; positions 0 .. p_new are attended to
+  int p_new = a.pos[r];  // the token being appended sits at p_new; positions 0 .. p_new are attended to
+  p_new = p_new < 0 ? 0 : (p_new < a.cap ? p_new : a.cap - 1);  // (a position outside the row is the caller's bug, not a fault)
   float qf[EPV], kn[EPV], vn[EPV];
   unpack16<DT>(*reinterpret_cast<const u32x4 *>(a.q + ((int64_t)r * a.q_sr + (int64_t)h * a.q_sh + i * EPV) * ES), qf);
   const u32x4 kn_raw = *reinterpret_cast<const u32x4 *>(a.k_new + ((int64_t)r * a.k_sr + (int64_t)hk * a.k_sh + i * EPV) * ES);
