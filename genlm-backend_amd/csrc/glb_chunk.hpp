@@ -935,13 +935,32 @@ __device__ __forceinline__ void finish_stats(const StepParams &p, int pidx, int 
 // finish role with a Philox draw: one wave per particle.  Sweeps the records of the particle's row until they are
 // complete (POLL), folds them, draws the chunk with the first Philox word and, with the second, walks down the chunk's
 // summation tree: 16-lane row (the record carries the four row sums), lane, class, element.  Only the chosen ROW is
-// reduced again - a quarter of the chunk, 4 KiB that L2 / Infinity Cache still hold: finishing lane L = 16 w + l takes
-// class w of the row's lane l (its 16 elements, in the order the stats wave added them), so every (lane, class) partial
-// is rebuilt bit for bit by one lane, the four classes of a lane are added with two lane exchanges, and the chosen
-// (lane, class)'s running sum is rebuilt in order by 15 dependent DPP adds.
+// reduced again - a quarter of the chunk, 4 KiB: finishing lane L = 4 l + w takes class w of the row's lane l (its 16
+// elements, in the order the stats wave added them), so every (lane, class) partial is rebuilt bit for bit by one lane and
+// the finishing lanes stand in the order of the summation tree - lane by lane, class by class inside a lane - : ONE
+// inclusive scan of their payloads picks lane and class together (the first prefix above the target, exactly what picking
+// the lane by its four-class total and then the class inside it gives: every sum is an integer sum).  The chosen (lane,
+// class)'s running sum is rebuilt in order by 15 dependent DPP adds.
+// The wave's serial chain is what the launch's last microseconds are made of (in-kernel stamps, DESIGN.md §5: fold 0.8 us,
+// chunk pick 0.5, row pick + addresses 0.6, partials and picks 1.1 of 3.6 us from "records complete" to "token"), so
+// only what the DRAW needs sits on it: the scale and the inclusive scan of the allowed sums (the scan's last lane is their
+// total), the row pick in scalar registers; the sums of ALL elements and both logarithms - outputs, not inputs of the
+// draw - are taken while the quarter chunk is on its way.
 // Nothing per particle is ever written by the stats role: round 2 left 512 bytes of lane scans per chunk for this
 // step - 2 us of a read-bound launch.
 // ---------------------------------------------------------------------------------------------------------
+// the row scale and the sum on it of ALL elements (off the draw's critical path); rows of up to 64 chunks: lane c = record c
+__device__ __forceinline__ void fold_all_fast(const ChunkRec &r, bool have, float &N_all, uint64_t &S_all) {
+  const uint64_t a = have ? ((uint64_t)r.pA << kGridHi) + r.pB : 0ull;
+  N_all = wave_max(a ? r.Nc : kNegInf);
+  uint64_t sa = 0;
+  if (a) {
+    const float d = N_all - r.Nc;  // >= 0, integer valued
+    sa = d < 64.0f ? a >> (uint32_t)d : 0ull;
+  }
+  S_all = wave_sum_u64(sa);
+}
+
 template <int DT, int MASK, bool POLL>
 __device__ __forceinline__ void finish_draw(const StepParams &p, int pidx, int lane) {
   constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC, NVW = NVC / 4;
@@ -949,8 +968,8 @@ __device__ __forceinline__ void finish_draw(const StepParams &p, int pidx, int l
   const int pr = p.pair_of ? as_const(p.pair_of)[pidx] : pidx;
   const int row = p.pair_row ? as_const(p.pair_row)[pr] : pr;
   const int mi = MASK == kMaskNone ? 0 : (p.pair_mask ? as_const(p.pair_mask)[pr] : (p.n_masks == 1 ? 0 : pr));
-#ifdef GLB_STAMPS  // diagnostic build: [start, records complete, token written] of every particle through out_margin
-  uint64_t *stamps = p.out_margin ? reinterpret_cast<uint64_t *>(p.out_margin) + (int64_t)pidx * 4 : nullptr;
+#ifdef GLB_STAMPS  // diagnostic build: time stamps of every particle's finishing wave through out_margin (tools/dbg/stamps.py)
+  uint64_t *stamps = p.out_margin ? reinterpret_cast<uint64_t *>(p.out_margin) + (int64_t)pidx * 8 : nullptr;
   if (stamps && lane == 0) stamps[0] = __builtin_amdgcn_s_memrealtime();
 #endif
   uint64_t R1, R2;
@@ -972,36 +991,75 @@ __device__ __forceinline__ void finish_draw(const StepParams &p, int pidx, int l
   if (stamps && lane == 0) stamps[1] = __builtin_amdgcn_s_memrealtime();
 #endif
   PairState st;
-  pair_fold<MASK>(recs, nch, lane, st);
-  const ChunkPick pick = pair_pick_chunk(recs, st, R1, R2, nch, lane);
+  ChunkPick pick{-1, 0.f, R2, {0ull, 0ull, 0ull, 0ull}};
+  const bool fast = recs.cached;  // rows of up to 64 chunks: lane c holds record c
+  if (fast) {
+    // ---- the draw's side of the fold: scale and inclusive scan of the allowed sums; the scan's last lane is their total
+    const ChunkRec &r = recs.mine;
+    const bool have = lane < nch;
+    const uint64_t mm = have ? ((uint64_t)r.pAm << kGridHi) + r.pBm : 0ull;
+    st.N_msk = wave_max(mm ? r.Nm : kNegInf);
+    uint64_t sm = 0;
+    if (mm) {
+      const float d = st.N_msk - r.Nm;
+      sm = d < 64.0f ? mm >> (uint32_t)d : 0ull;
+    }
+    const uint64_t incl = wave_scan_u64(sm);
+    st.S_msk = readlane_u64(incl, 63);
+#ifdef GLB_STAMPS
+    if (stamps && lane == 0) stamps[4] = __builtin_amdgcn_s_memrealtime();
+#endif
+    uint32_t nz = (uint32_t)st.S_msk | (uint32_t)(st.S_msk >> 32);
+    opaque_u32(nz);
+    if (nz != 0u) {
+      const uint64_t T = __umul64hi(R1, st.S_msk);  // uniform integer in [0, S_msk)
+      const int lsel = first_lane_above(incl, T);
+      pick.csel = lsel;
+      pick.Nms = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(r.Nm), lsel));
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        pick.qg[g] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)r.rA[g], lsel) << kGridHi) +
+                     (uint32_t)__builtin_amdgcn_readlane((int)r.rB[g], lsel);
+    }
+  } else {
+    pair_fold<MASK>(recs, nch, lane, st);
+#ifdef GLB_STAMPS
+    if (stamps && lane == 0) stamps[4] = __builtin_amdgcn_s_memrealtime();
+#endif
+    pick = pair_pick_chunk(recs, st, R1, R2, nch, lane);
+  }
+#ifdef GLB_STAMPS
+  if (stamps && lane == 0) stamps[5] = __builtin_amdgcn_s_memrealtime();
+#endif
   int32_t tok = -1;
   if (pick.csel >= 0) {
-    // ---- the row: lanes 0..3 hold the four row sums
-    const uint64_t qg = lane == 0 ? pick.qg[0] : lane == 1 ? pick.qg[1] : lane == 2 ? pick.qg[2] : lane == 3 ? pick.qg[3] : 0ull;
-    const uint64_t inclg = wave_scan_u64(qg);
-    const uint64_t Sc = readlane_u64(inclg, 63);
+    // ---- the 16-lane row: four wave-uniform sums, picked in scalar registers
+    const uint64_t i0 = pick.qg[0], i1 = i0 + pick.qg[1], i2 = i1 + pick.qg[2], Sc = i2 + pick.qg[3];
     const uint64_t T2 = __umul64hi(pick.R2, Sc);  // uniform integer in [0, S_c)
-    const int gsel = first_lane_above(inclg, T2);  // 0..3 (S_c > 0: the chunk was drawn)
-    const uint64_t Tg = T2 - (gsel > 0 ? readlane_u64(inclg, gsel > 0 ? gsel - 1 : 0) : 0ull);
-    // ---- this lane's (row lane, class): 16 elements
+    const int gsel = T2 < i0 ? 0 : (T2 < i1 ? 1 : (T2 < i2 ? 2 : 3));  // (S_c > 0: the chunk was drawn)
+    const uint64_t Tg = T2 - (gsel == 0 ? 0ull : (gsel == 1 ? i0 : (gsel == 2 ? i1 : i2)));
+    // ---- this lane's (row lane, class): 16 elements; finishing lane L = 4 l + w
     const int c = pick.csel, e_base = c * kChunk;
-    const int w = lane >> 4, sl = 16 * gsel + (lane & 15);  // class, lane of the stats wave
+    const int w = lane & 3, sl = 16 * gsel + (lane >> 2);  // class, lane of the stats wave
     const char *rowp = (const char *)p.logits + (int64_t)row * p.ld * ES;
     const float magicN = kMagic - pick.Nms;
     float y[16];
+    const bool whole = e_base + kChunk <= V;  // wave-uniform: every chunk of a row but its last - no per-lane guards
 #pragma unroll
     for (int j = 0; j < NVW; ++j) {
       const int iv = w + 4 * j;
       const int e0 = e_base + (iv * 64 + sl) * EPV;
-      const u32x4_t r = load_vec_guarded<DT>(rowp, e0 < V ? e0 : V, V);
+      const u32x4_t r = whole ? *reinterpret_cast<const u32x4_t *>(rowp + (int64_t)e0 * ES)
+                              : load_vec_guarded<DT>(rowp, e0 < V ? e0 : V, V);
       unpack_vec<DT>(r, &y[j * EPV]);
 #pragma unroll
       for (int k = 0; k < EPV; ++k) y[j * EPV + k] *= p.scale;  // (x * 1.0f == x: the scaled form serves every call)
       if constexpr (MASK == kMaskBits) {
-        const uint64_t *mw = p.mask_t + ((int64_t)mi * nch + c) * 64 + iv * EPV;
+        // (the 32-bit half of the lane word that holds this lane's bit: one register per element in flight, not two)
+        const uint32_t *mw = reinterpret_cast<const uint32_t *>(p.mask_t + ((int64_t)mi * nch + c) * 64 + iv * EPV) + (sl >> 5);
 #pragma unroll
         for (int k = 0; k < EPV; ++k)
-          if (!((mw[k] >> sl) & 1ull)) y[j * EPV + k] = kNegInf;
+          if (!((mw[2 * k] >> (sl & 31)) & 1u)) y[j * EPV + k] = kNegInf;
       } else if constexpr (MASK == kMaskF32) {
         const char *mrow = (const char *)(p.mask_f + (int64_t)mi * p.mask_ld);
 #pragma unroll
@@ -1015,7 +1073,14 @@ __device__ __forceinline__ void finish_draw(const StepParams &p, int pidx, int l
         }
       }
     }
-    {  // the logarithms: two lanes' work for the time the loads are in flight
+#ifdef GLB_STAMPS
+    if (stamps && lane == 0) stamps[6] = __builtin_amdgcn_s_memrealtime();
+#endif
+    {  // while the quarter chunk is on its way: the sums of all elements and the two logarithms (outputs, not inputs of the draw)
+      if (fast) {
+        if constexpr (MASK == kMaskNone) st.N_all = st.N_msk, st.S_all = st.S_msk;
+        else fold_all_fast(recs.mine, lane < nch, st.N_all, st.S_all);
+      }
       float lse, logZ;
       pair_logs(st, lane, lse, logZ);
       if (lane == 0) {
@@ -1023,8 +1088,9 @@ __device__ __forceinline__ void finish_draw(const StepParams &p, int pidx, int l
         if (p.out_logZ) p.out_logZ[pidx] = logZ;
       }
     }
-#ifdef GLB_STAMPS  // [3]: the quarter chunk has arrived (the wave waits for its last vector here)
-    asm volatile("" ::"v"(y[15]));
+#ifdef GLB_STAMPS
+    if (stamps && lane == 0) stamps[7] = __builtin_amdgcn_s_memrealtime();
+    asm volatile("" ::"v"(y[15]));  // [3]: the quarter chunk has arrived (the wave waits for its last vector here)
     if (stamps && lane == 0) stamps[3] = __builtin_amdgcn_s_memrealtime();
 #endif
     float t[16], P = 0.0f;
@@ -1035,46 +1101,34 @@ __device__ __forceinline__ void finish_draw(const StepParams &p, int pidx, int l
     }
     uint32_t h, l;
     partial_q(P, h, l);
-    const uint64_t qown = ((uint64_t)h << kGridHi) + l;  // q of (row lane lane & 15, class w)
-    // ---- the lane of the row: lanes 0..15 get the sum over the four classes
-    uint32_t hs = h + (uint32_t)__shfl_xor((int)h, 16, 64), ls = l + (uint32_t)__shfl_xor((int)l, 16, 64);
-    hs += (uint32_t)__shfl_xor((int)hs, 32, 64);
-    ls += (uint32_t)__shfl_xor((int)ls, 32, 64);
-    const uint64_t ql = lane < 16 ? ((uint64_t)hs << kGridHi) + ls : 0ull;
-    const uint64_t incll = wave_scan_u64(ql);
-    const int lsel = first_lane_above(incll, Tg);
-    if (lsel >= 0 && lsel < 16) {
-      const uint64_t Tl = Tg - (lsel > 0 ? readlane_u64(incll, lsel > 0 ? lsel - 1 : 0) : 0ull);
-      // ---- the class: lanes 0..3 get the four class terms of row lane lsel
-      uint64_t qw = 0;
+    // ---- lane and class at once: the finishing lanes stand in summation order, one scan of their payloads
+    const uint64_t qown = ((uint64_t)h << kGridHi) + l;  // q of (row lane lane >> 2, class lane & 3)
+    const uint64_t incl2 = wave_scan_u64(qown);
+    const int Lsel = first_lane_above(incl2, Tg);
+    if (Lsel >= 0) {
+      const uint64_t Tw = Tg - (Lsel > 0 ? readlane_u64(incl2, Lsel > 0 ? Lsel - 1 : 0) : 0ull);
+      const int lsel = Lsel >> 2, wsel = Lsel & 3;
+      // ---- the element: lane pos < 16 gets term pos of finishing lane Lsel, then the running sum in order
+      float tv = 0.0f;
 #pragma unroll
-      for (int ww = 0; ww < 4; ++ww) {
-        const uint64_t q = readlane_u64(qown, lsel + 16 * ww);
-        qw = lane == ww ? q : qw;
+      for (int j = 0; j < 16; ++j) {
+        const float tj = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(t[j]), Lsel));
+        tv = (lane & 15) == j ? tj : tv;
       }
-      const uint64_t inclw = wave_scan_u64(qw);
-      const int wsel = first_lane_above(inclw, Tl);
-      if (wsel >= 0 && wsel < 4) {
-        const uint64_t Tw = Tl - (wsel > 0 ? readlane_u64(inclw, wsel > 0 ? wsel - 1 : 0) : 0ull);
-        // ---- the element: lane pos < 16 gets term pos of finishing lane 16 wsel + lsel, then the running sum in order
-        const int Lsel = 16 * wsel + lsel;
-        float tv = 0.0f;
+      float cs = tv;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const float tj = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(t[j]), Lsel));
-          tv = (lane & 15) == j ? tj : tv;
-        }
-        float cs = tv;
-#pragma unroll
-        for (int s2 = 1; s2 < 16; ++s2) cs = __uint_as_float(dpp_u32<0x111, 0xf>(0u, __float_as_uint(cs))) + tv;
-        uint32_t hc, lc;
-        partial_q(cs, hc, lc);
-        const uint64_t qc = lane < 16 ? ((uint64_t)hc << kGridHi) + lc : 0ull;
-        const int psel = first_lane_above(qc, Tw);
-        if (psel >= 0) tok = e_base + ((wsel + 4 * (psel / EPV)) * 64 + 16 * gsel + lsel) * EPV + (psel % EPV);
-      }
+      for (int s2 = 1; s2 < 16; ++s2) cs = __uint_as_float(dpp_u32<0x111, 0xf>(0u, __float_as_uint(cs))) + tv;
+      uint32_t hc, lc;
+      partial_q(cs, hc, lc);
+      const uint64_t qc = lane < 16 ? ((uint64_t)hc << kGridHi) + lc : 0ull;
+      const int psel = first_lane_above(qc, Tw);
+      if (psel >= 0) tok = e_base + ((wsel + 4 * (psel / EPV)) * 64 + 16 * gsel + lsel) * EPV + (psel % EPV);
     }
   } else {
+    if (fast) {
+      if constexpr (MASK == kMaskNone) st.N_all = st.N_msk, st.S_all = st.S_msk;
+      else fold_all_fast(recs.mine, lane < nch, st.N_all, st.S_all);
+    }
     float lse, logZ;
     pair_logs(st, lane, lse, logZ);
     if (lane == 0) {

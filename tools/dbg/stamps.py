@@ -28,7 +28,7 @@ bits, _ = eng.mask_to_bits(maskf)
 masks = eng.prepare_masks(bits, V, dt)
 mid = (torch.arange(B, device=dev) % 2).to(torch.int32)
 out = (torch.empty(B, device=dev), torch.empty(B, device=dev), torch.empty(B, dtype=torch.int32, device=dev))
-stamps = torch.zeros(B * 8, device=dev)
+stamps = torch.zeros(B * 16, device=dev)
 nch = (V + 4095) // 4096
 rows = []
 for i in range(iters):
@@ -37,7 +37,7 @@ for i in range(iters):
     if i < 4:
         continue
     ws = eng._step_ws[: B * nch * 128].view(torch.int64).view(B, nch, 16).cpu().numpy()
-    st = stamps.view(torch.int64).view(B, 4).cpu().numpy()
+    st = stamps.view(torch.int64).view(B, 8).cpu().numpy()
     t0 = ws[:, :, 12].min()
     s_start, s_end = (ws[:, :, 12] - t0) / 100.0, (ws[:, :, 13] - t0) / 100.0  # microseconds
     f = (st[:, :3] - t0) / 100.0
@@ -61,6 +61,12 @@ for i in range(iters):
         print("last 10 tokens written: particle, records done at, finisher start, records seen, token at")
         for r in order[-10:]:
             print("  %4d  %.2f  %.2f  %.2f  %.2f" % (r, last[r], f[r, 0], f[r, 1], f[r, 2]))
+    if i == iters - 1 and (st[:, 4] > 0).all():
+        seg = lambda a, b: ((st[:, b] - st[:, a]) / 100.0)
+        print("finishing wave, per segment (us; mean / min): records complete -> folded %.2f / %.2f; -> chunk picked %.2f / %.2f; -> "
+              "row picked, loads issued %.2f / %.2f; -> logarithms done %.2f / %.2f; -> quarter chunk arrived %.2f / %.2f; -> token %.2f / %.2f"
+              % (seg(1, 4).mean(), seg(1, 4).min(), seg(4, 5).mean(), seg(4, 5).min(), seg(5, 6).mean(), seg(5, 6).min(),
+                 seg(6, 7).mean(), seg(6, 7).min(), seg(7, 3).mean(), seg(7, 3).min(), seg(3, 2).mean(), seg(3, 2).min()))
 names = ["last stats wave start", "last stats wave end", "stats end p50", "stats end p90", "first finisher start", "last finisher start",
          "last token written", "finish work mean (records seen -> token)", "finish work max", "finish work min", "wait for records mean",
          "stats wave lifetime mean", "token written p50", "records seen -> quarter chunk arrived (fold, picks, reload)",
