@@ -474,6 +474,10 @@ hipError_t launch_attention(const AttnArgs &a, int head_dim, hipStream_t s) {
 // an online softmax per key slot, slots merged at the end; the (row, head)'s K / V are read by its Lq waves out of the
 // L1 / L2.  Which keys a query may see comes from the boolean mask transformers built ([U, 1, Lq, Lk], true = attend),
 // or without one from causality (key s <= query t + Lk - Lq).  A query that may see nothing gets zeros.
+// (Measured and not kept: a tile of 256 / head_dim queries per wave with the whole dot product inside a lane - v_dot2_f32_bf16
+// on the packed pairs for 16-bit types - scores through LDS and a second phase of four output dimensions per lane: a third
+// of the instructions per query, but every lane then reads whole K / q rows 256 bytes apart, sixteen cache lines per load
+// instruction: 105.6 us against 72.8 for fp32 GPT-2-small rows, 84.0 against 92.8 for bf16 Llama rows.)
 // ---------------------------------------------------------------------------------------------------------------------
 struct ShortArgs {
   const char *q, *k, *v;

@@ -1348,11 +1348,14 @@ def test_load_model_by_name_end_to_end_on_gpu(tmp_path, dtype):
 
 @pytest.mark.parametrize("dtype,U,H,Hkv,Lq,Lk,Dh", [(torch.float32, 50, 12, 12, 13, 13, 64), (torch.float32, 33, 4, 4, 10, 18, 16),
                                                      (torch.bfloat16, 20, 32, 8, 9, 9, 64), (torch.float16, 7, 8, 2, 5, 30, 128),
-                                                     (torch.float32, 919, 12, 12, 13, 13, 64), (torch.bfloat16, 6, 4, 2, 1, 40, 32)])
+                                                     (torch.float32, 919, 12, 12, 13, 13, 64), (torch.bfloat16, 6, 4, 2, 1, 40, 32),
+                                                     (torch.float32, 3, 4, 4, 2, 70, 64), (torch.bfloat16, 460, 32, 8, 13, 13, 64),
+                                                     (torch.float16, 5, 2, 1, 17, 64, 16), (torch.float32, 4, 2, 2, 3, 33, 128)])
 def test_short_attention_matches_torch(engine, dtype, U, H, Hkv, Lq, Lk, Dh):
     """glb_short_attention on the padded batches the path builds (hf.py:232-281: right-padded contexts, optionally behind
     zero-padded cached prefixes - the 4-D boolean mask transformers makes of them) and without a mask (causal), against
-    torch's scaled_dot_product_attention in float32 on the same values: grouped query heads, strided projection outputs."""
+    torch's scaled_dot_product_attention in float32 on the same values: grouped query heads, strided projection outputs;
+    short and longer key ranges, every head width the kernels are built for."""
     dev = engine.device
     g = torch.Generator(device=dev)
     g.manual_seed(U + Lk)
