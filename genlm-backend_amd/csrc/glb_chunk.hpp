@@ -24,8 +24,9 @@
 // The same roles also exist as two plain launches (chunk_stats_kernel / chunk_stats_small_kernel, finish_kernel): under
 // stream capture (the epoch is a launch argument), for workspaces nobody initialised, for launches of at most 512
 // chunks (four waves per chunk), and for the parity-mode exponential race (four waves per particle over the whole row).
-//   logprob_rows_waves_kernel   glb_log_softmax_rows (cache.py:93-98) in one launch: a wave keeps its chunk in registers,
-//                               meets its row-mates through the same tagged records and writes x - lse (float32, or
+//   logprob_rows_waves_kernel   glb_log_softmax_rows (cache.py:93-98) in one launch: a wave keeps its one to three chunks
+//                               in registers, meets its row-mates through the same tagged records (the row's first
+//                               wave folds, the others wait for its result) and writes x - lse (float32, or
 //                               rounded into the logits' own 16-bit type: cache.py:96 keeps the dtype); three launches
 //                               (statistics, one wave per row, logprob_rows_kernel) serve rows of more than 64 chunks and
 //                               workspaces without tags.
@@ -154,6 +155,31 @@ __device__ __forceinline__ uint32_t pack16(float lo, float hi) {
   } else {
     const _Float16 a = (_Float16)lo, b = (_Float16)hi;
     return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+  }
+}
+
+// one word of two 16-bit logits -> the word of their two log-probabilities, (x * scale) - lse each, rounded as pack16
+// rounds: the pair stays a pair from the unpack to the packed conversion (two unpack operations, one packed subtraction,
+// one v_cvt_pk per word - left to itself the compiler pairs elements of DIFFERENT words for the packed arithmetic and
+// then spends two more operations per word putting the halves back in order)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+template <int DT, bool SCALED>
+__device__ __forceinline__ uint32_t logprob_word16(uint32_t w, float scale, float lse) {
+  f32x2_t x;
+  if constexpr (DT == kDtBf16) {
+    x = f32x2_t{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+  } else {
+    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+    x = __builtin_convertvector(__builtin_bit_cast(f16x2_t, w), f32x2_t);
+  }
+  if constexpr (SCALED) x = x * scale;
+  x = x - lse;
+  if constexpr (DT == kDtBf16) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2_t));
+  } else {
+    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(x, f16x2_t));
   }
 }
 
@@ -1370,16 +1396,19 @@ __global__ __launch_bounds__(256) void logprob_rows_kernel(const void *logits, i
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// log-probability rows, one HBM reading, no workgroup structure: one-wave workgroups, block b = (row b / nch, chunk
-// b % nch).  A wave loads its chunk and keeps it in registers as loaded, reduces it, publishes (scale, sum) as three
-// tagged granules of the chunk's record (words 0, 2, 3 - the step kernels' layout), sweeps the records of its row until
-// every tag is this call's epoch (its row-mates are its neighbours in the grid: they were placed within a microsecond
-// of it), folds lse - every wave of the row the same integers, the same result - and writes x - lse from its registers.
+// log-probability rows, one HBM reading, no workgroup structure: one-wave workgroups, block b = (row b / wpr, wave
+// b % wpr of the row), a wave owning CPW consecutive chunks.  A wave loads its chunks and keeps them in registers as
+// loaded, reduces each and publishes (scale, sum) as three tagged granules of the chunk's record (words 0, 2, 3 - the
+// step kernels' layout).  The row's first wave then sweeps the row's records until every tag is this call's epoch (its
+// row-mates are its neighbours in the grid: they were placed within microseconds of it), folds lse and publishes it as
+// a fourth tagged granule; the other waves poll that one granule; every wave writes x - lse from its registers.
 // Waves of different rows are at different points of this at any moment, so reading, arithmetic and writing overlap
 // across the chip by themselves; a workgroup per row with the row in its registers (tried: one 1024-thread workgroup
 // per CU walking its share of the rows) marches in step with all the others - every CU reads, then every CU computes,
-// then every CU writes: 104 us at 1024 x 50257 fp32 where the bytes alone take 70; this kernel: 78 us.  A wave waits only for
-// waves placed before or right behind it, the wait is bounded (NaN out after kSpinTicks), rows of up to 64 chunks.
+// then every CU writes: 104 us at 1024 x 50257 fp32 where the bytes alone take 70; this kernel: 74 us.  A wave waits only
+// for waves placed before or right behind it (the oldest unfinished row of the grid has all its waves resident, on
+// whatever XCD they were placed: it completes), the wait is bounded (NaN out after the watchdog's ticks), rows of up to
+// 64 chunks.
 // ---------------------------------------------------------------------------------------------------------
 // STORE (16-bit rows; a lane's eight elements of a vector are 32 bytes of output): 0 = two 16-byte stores per lane, each
 // instruction covering every other 16 bytes of a 2 KB span; 2 = through 2 KB of LDS so that each store instruction
@@ -1387,20 +1416,26 @@ __global__ __launch_bounds__(256) void logprob_rows_kernel(const void *logits, i
 // OUT16 (16-bit rows only): the log-probabilities leave in the logits' own element type, as the reference returns them
 // (cache.py:96 keeps the dtype) - the float32 result rounded to nearest even; a lane's eight outputs of a vector are one
 // 16-byte store and every store instruction writes 1 KB of consecutive addresses, so nothing passes through LDS.
-template <int DT, bool SCALED, int WPS, int STORE, bool OUT16 = false>
-__global__ __launch_bounds__(64, WPS) void logprob_rows_waves_kernel(
-    const void *logits, int64_t ld, int V, int nch, float scale, void *out_v, int64_t out_ld, float *out_lse,
-    uint64_t *recs, uint32_t epoch, uint32_t *err, uint64_t spin_ticks) {
-  static_assert(!OUT16 || DT != kDtF32, "16-bit output goes with 16-bit logits");
-  constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC;
-  const int lane = threadIdx.x;
-  const int r = (int)(blockIdx.x / (unsigned)nch), c = (int)(blockIdx.x - (unsigned)r * (unsigned)nch);
-  const char *rowp = (const char *)logits + (int64_t)r * ld * ES;
-  const int e_base = c * kChunk;
-  u32x4_t raw[NVC];
-  load_chunk_raw<DT>(rowp, e_base, V, lane, raw);
-  int nv_valid = (V - e_base + 64 * EPV - 1) / (64 * EPV);
-  nv_valid = nv_valid < NVC ? nv_valid : NVC;
+// CPW: chunks per wave.  With one chunk per wave, what a wave does for its chunk takes 4 us at 512 x 128256 bf16 and its
+// wait for the row 13 us (tools/dbg/stamps_lsm.py, profiles/r04/stamps_lsm_before_v4.log: the row's last record is out
+// 6 us after the average one, the first wave has folded 5 us later, the row-mates have the result 1.7 us after that):
+// four resident waves in five are waiting and the launch runs at the rate the remaining fifth can load - 67 us where
+// the same kernel without the wait takes 46 (profiles/r04/ab_lsm_nowait_nostore_v4.log).  A 16-bit chunk is 8 KB, half
+// the registers of a float32 chunk: two or three chunks per wave put that many times the bytes behind every wait and
+// divide the waves a row waits for (52 us; the launcher picks CPW by the row's length).
+// a loaded vector as a value the compiler knows nothing about: what it unpacked from the vector before is not carried
+// over (16-bit rows: the unpacked form of a chunk is 64 registers a lane, the loaded form 32 - kept across the passes
+// of a wave it is the difference between five waves a SIMD with spills and without)
+template <int DT>
+__device__ __forceinline__ u32x4_t as_loaded(u32x4_t v) {
+  if constexpr (DT != kDtF32) asm volatile("" : "+v"(v));  // (float32: the loaded form is the unpacked form)
+  return v;
+}
+
+template <int DT, bool SCALED>
+__device__ __forceinline__ void chunk_scale_sum(const u32x4_t (&raw)[ElemTraits<DT>::NVC], int nv_valid, float scale, float &Nc,
+                                                uint32_t &pA, uint32_t &pB) {
+  constexpr int EPV = ElemTraits<DT>::EPV, NVC = ElemTraits<DT>::NVC;
   float m = kNegInf;
 #pragma unroll
   for (int i = 0; i < NVC; ++i) {
@@ -1409,13 +1444,14 @@ __global__ __launch_bounds__(64, WPS) void logprob_rows_waves_kernel(
 #pragma unroll
     for (int k = 0; k < EPV; k += 2) m = max3(m, t[k], t[k + 1]);
   }
-  const float Nc = exp_n(wave_max(m)), magicN = kMagic - Nc;
+  Nc = exp_n(wave_max(m));
+  const float magicN = kMagic - Nc;
   float P[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int i = 0; i < NVC; ++i) {
     if (i < nv_valid) {  // wave-uniform; vectors wholly past the row end would add +0
       float t[EPV];
-      unpack_scaled<DT, SCALED>(raw[i], scale, t);
+      unpack_scaled<DT, SCALED>(as_loaded<DT>(raw[i]), scale, t);
 #pragma unroll
       for (int k = 0; k < EPV; ++k) t[k] = chunk_term(t[k], magicN);
 #pragma unroll
@@ -1425,78 +1461,23 @@ __global__ __launch_bounds__(64, WPS) void logprob_rows_waves_kernel(
   }
   uint32_t h, l;
   lane_payload<4>(P, h, l);
-  const uint32_t pA = last_lane(wave_sum_u32_l63(h)), pB = last_lane(wave_sum_u32_l63(l));
-  uint64_t *row_recs = recs + (int64_t)r * nch * kRecWords;
-  {
-    uint32_t v = __float_as_uint(Nc);
-    v = lane == 2 ? pA : v;
-    v = lane == 3 ? pB : v;
-    if (lane == 0 || lane == 2 || lane == 3)
-      __hip_atomic_store(row_recs + (int64_t)c * kRecWords + lane, ((uint64_t)epoch << 32) | v, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-  }
-  // lane j takes record j of the row
-  float Nj = kNegInf;
-  uint64_t Sj = 0;
-  bool have = true;
-  {
-    const uint64_t *q = row_recs + (int64_t)(lane < nch ? lane : 0) * kRecWords;
-    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-    for (;;) {
-      bool ok = true;
-      if (lane < nch) {
-        const uint64_t g3 = __hip_atomic_load(const_cast<uint64_t *>(q) + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = (uint32_t)(g3 >> 32) == epoch;
-      }
-      if (__builtin_amdgcn_ballot_w64(!ok) != 0ull) {  // one 8-byte load per record and sweep while waiting
-        __builtin_amdgcn_s_sleep(8);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > spin_ticks) {
-          have = false;
-          break;
-        }
-        continue;
-      }
-      if (lane < nch) {
-        const uint64_t g0 = __hip_atomic_load(const_cast<uint64_t *>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint64_t g2 = __hip_atomic_load(const_cast<uint64_t *>(q) + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint64_t g3 = __hip_atomic_load(const_cast<uint64_t *>(q) + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = (uint32_t)(g0 >> 32) == epoch && (uint32_t)(g2 >> 32) == epoch && (uint32_t)(g3 >> 32) == epoch;
-        Nj = __uint_as_float((uint32_t)g0);
-        Sj = ((uint64_t)(uint32_t)g2 << kGridHi) + (uint32_t)g3;
-      }
-      if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
-      __builtin_amdgcn_s_sleep(2);
-      if (__builtin_amdgcn_s_memrealtime() - t0 > spin_ticks) {
-        have = false;
-        break;
-      }
-    }
-  }
-  float lse = __builtin_nanf("");
-  if (!have && lane == 0 && err) atomicAdd(err, 1u);  // (the row comes out as NaN: a failed launch, never a result)
-  if (have) {
-    const bool on = lane < nch && Sj != 0;
-    const float N = wave_max(on ? Nj : kNegInf);
-    uint64_t sa = 0;
-    if (on) {
-      const float d = N - Nj;
-      sa = d < 64.0f ? Sj >> (uint32_t)d : 0ull;
-    }
-    const uint64_t S = wave_sum_u64(sa);
-    lse = S ? (float)log_fix(S, (int32_t)N + 1 - kFrac) : kNegInf;
-  }
-  if (c == 0 && lane == 0 && out_lse) out_lse[r] = lse;
-  if (!out_v) return;
+  pA = last_lane(wave_sum_u32_l63(h));
+  pB = last_lane(wave_sum_u32_l63(l));
+}
+
+// x - lse of one chunk, from the registers it was loaded into
+template <int DT, bool SCALED, int STORE, bool OUT16>
+__device__ __forceinline__ void chunk_store_logprobs(const u32x4_t (&raw)[ElemTraits<DT>::NVC], float scale, float lse, void *out_v,
+                                                     int64_t out_off, int e_base, int V, int lane) {
+  constexpr int EPV = ElemTraits<DT>::EPV, NVC = ElemTraits<DT>::NVC;
   if constexpr (OUT16) {
-    uint16_t *o16 = reinterpret_cast<uint16_t *>(out_v) + (int64_t)r * out_ld + e_base + lane * 8;
+    uint16_t *o16 = reinterpret_cast<uint16_t *>(out_v) + out_off + e_base + lane * 8;
     const bool full = e_base + kChunk <= V;  // wave-uniform
 #pragma unroll
     for (int i = 0; i < NVC; ++i) {
-      float t[8];
-      unpack_scaled<DT, SCALED>(raw[i], scale, t);
-      uint32_t w[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) w[k] = pack16<DT>(t[2 * k] - lse, t[2 * k + 1] - lse);
+      const u32x4_t x = as_loaded<DT>(raw[i]);
+      const uint32_t w[4] = {logprob_word16<DT, SCALED>(x.x, scale, lse), logprob_word16<DT, SCALED>(x.y, scale, lse),
+                             logprob_word16<DT, SCALED>(x.z, scale, lse), logprob_word16<DT, SCALED>(x.w, scale, lse)};
       const int e0 = e_base + (i * 64 + lane) * 8;
       if (full || e0 + 8 <= V) {
         // (rows are element aligned only: a 16-byte store to an address that is not 16-byte aligned is legal on gfx950 and
@@ -1506,49 +1487,168 @@ __global__ __launch_bounds__(64, WPS) void logprob_rows_waves_kernel(
         for (int k = 0; k < V - e0; ++k) o16[i * 512 + k] = (uint16_t)(w[k >> 1] >> ((k & 1) * 16));
       }
     }
-    return;
-  }
-  float *out = reinterpret_cast<float *>(out_v);
-  float *o = out + (int64_t)r * out_ld + e_base + lane * EPV;
-  typedef float f32x4_t __attribute__((ext_vector_type(4)));
-  if (e_base + kChunk <= V) {  // wave-uniform: a full chunk, straight stores
-    if constexpr (EPV == 8 && STORE == 2) {
-      __shared__ f32x4_t s_t[2][128];  // two vectors' worth: the next one is written while the last one's reads land
-      float *ot = out + (int64_t)r * out_ld + e_base + lane * 4;
+  } else {
+    float *out = reinterpret_cast<float *>(out_v) + out_off;
+    float *o = out + e_base + lane * EPV;
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    if (e_base + kChunk <= V) {  // wave-uniform: a full chunk, straight stores
+      if constexpr (EPV == 8 && STORE == 2) {
+        __shared__ f32x4_t s_t[2][128];  // two vectors' worth: the next one is written while the last one's reads land
+        float *ot = out + e_base + lane * 4;
 #pragma unroll
-      for (int i = 0; i < NVC; ++i) {
-        float t[EPV];
-        unpack_scaled<DT, SCALED>(raw[i], scale, t);
-        f32x4_t *buf = s_t[i & 1];
-        buf[2 * lane] = f32x4_t{t[0] - lse, t[1] - lse, t[2] - lse, t[3] - lse};
-        buf[2 * lane + 1] = f32x4_t{t[4] - lse, t[5] - lse, t[6] - lse, t[7] - lse};
-        const f32x4_t a = buf[lane], b = buf[64 + lane];  // same wave: program order holds within LDS
-        __builtin_nontemporal_store(a, reinterpret_cast<f32x4_t *>(ot + i * 512));
-        __builtin_nontemporal_store(b, reinterpret_cast<f32x4_t *>(ot + i * 512 + 256));
+        for (int i = 0; i < NVC; ++i) {
+          float t[EPV];
+          unpack_scaled<DT, SCALED>(as_loaded<DT>(raw[i]), scale, t);
+          f32x4_t *buf = s_t[i & 1];
+          buf[2 * lane] = f32x4_t{t[0] - lse, t[1] - lse, t[2] - lse, t[3] - lse};
+          buf[2 * lane + 1] = f32x4_t{t[4] - lse, t[5] - lse, t[6] - lse, t[7] - lse};
+          const f32x4_t a = buf[lane], b = buf[64 + lane];  // same wave: program order holds within LDS
+          __builtin_nontemporal_store(a, reinterpret_cast<f32x4_t *>(ot + i * 512));
+          __builtin_nontemporal_store(b, reinterpret_cast<f32x4_t *>(ot + i * 512 + 256));
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NVC; ++i) {
+          float t[EPV];
+          unpack_scaled<DT, SCALED>(as_loaded<DT>(raw[i]), scale, t);
+#pragma unroll
+          for (int hh = 0; hh < EPV / 4; ++hh) {
+            const f32x4_t v{t[4 * hh] - lse, t[4 * hh + 1] - lse, t[4 * hh + 2] - lse, t[4 * hh + 3] - lse};
+            if constexpr (STORE == 1) *reinterpret_cast<f32x4_t *>(o + i * 64 * EPV + 4 * hh) = v;
+            else __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t *>(o + i * 64 * EPV + 4 * hh));
+          }
+        }
       }
     } else {
 #pragma unroll
       for (int i = 0; i < NVC; ++i) {
+        const int e0 = e_base + (i * 64 + lane) * EPV;
         float t[EPV];
-        unpack_scaled<DT, SCALED>(raw[i], scale, t);
+        unpack_scaled<DT, SCALED>(as_loaded<DT>(raw[i]), scale, t);
+        for (int k = 0; k < EPV; ++k)
+          if (e0 + k < V) o[i * 64 * EPV + k] = t[k] - lse;
+      }
+    }
+  }
+}
+
+// grid: n_rows * wpr blocks, wpr = ceil(nch / CPW) waves per row
+template <int DT, bool SCALED, int WPS, int STORE, bool OUT16 = false, int CPW = 1>
+__global__ __launch_bounds__(64, WPS) void logprob_rows_waves_kernel(
+    const void *logits, int64_t ld, int V, int nch, int wpr, float scale, void *out_v, int64_t out_ld, float *out_lse,
+    uint64_t *recs, uint32_t epoch, uint32_t *err, uint64_t spin_ticks) {
+  static_assert(!OUT16 || DT != kDtF32, "16-bit output goes with 16-bit logits");
+  static_assert(CPW == 1 || DT != kDtF32, "a float32 chunk fills the registers by itself");
+  constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC;
+  const int lane = threadIdx.x;
+#ifdef GLB_STAMPS  // diagnostic build (tools/dbg/stamps_lsm.py): [start, record out, lse in, stores drained] in the record's padding
+  const uint64_t stamp0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  const int r = (int)(blockIdx.x / (unsigned)wpr), w = (int)(blockIdx.x - (unsigned)r * (unsigned)wpr);
+  const int c0 = w * CPW;
+  const char *rowp = (const char *)logits + (int64_t)r * ld * ES;
+  u32x4_t raw[CPW][NVC];
 #pragma unroll
-        for (int hh = 0; hh < EPV / 4; ++hh) {
-          const f32x4_t v{t[4 * hh] - lse, t[4 * hh + 1] - lse, t[4 * hh + 2] - lse, t[4 * hh + 3] - lse};
-          if constexpr (STORE == 1) *reinterpret_cast<f32x4_t *>(o + i * 64 * EPV + 4 * hh) = v;
-          else __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t *>(o + i * 64 * EPV + 4 * hh));
-        }
+  for (int j = 0; j < CPW; ++j)
+    if (j == 0 || c0 + j < nch) load_chunk_raw<DT>(rowp, (c0 + j) * kChunk, V, lane, raw[j]);  // wave-uniform
+  uint64_t *row_recs = recs + (int64_t)r * nch * kRecWords;
+#pragma unroll
+  for (int j = 0; j < CPW; ++j) {
+    if (j == 0 || c0 + j < nch) {
+      const int e_base = (c0 + j) * kChunk;
+      int nv_valid = (V - e_base + 64 * EPV - 1) / (64 * EPV);
+      nv_valid = nv_valid < NVC ? nv_valid : NVC;
+      float Nc;
+      uint32_t pA, pB;
+      chunk_scale_sum<DT, SCALED>(raw[j], nv_valid, scale, Nc, pA, pB);
+      uint32_t v = __float_as_uint(Nc);
+      v = lane == 2 ? pA : v;
+      v = lane == 3 ? pB : v;
+      if (lane == 0 || lane == 2 || lane == 3)
+        __hip_atomic_store(row_recs + (int64_t)(c0 + j) * kRecWords + lane, ((uint64_t)epoch << 32) | v, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+#ifdef GLB_STAMPS
+  uint64_t *stamps = row_recs + (int64_t)c0 * kRecWords + 12;
+  if (lane == 0) stamps[0] = stamp0, stamps[1] = __builtin_amdgcn_s_memrealtime();
+#endif
+  // The row's FIRST wave (placed before its row-mates) sweeps the records - lane j takes record j: the three granules in
+  // one sweep, so the sweep that finds every tag in place already holds the values -, folds lse and publishes it as one
+  // more tagged granule (word 1 of chunk 0's record); the other waves of the row wait for that one granule: one 8-byte
+  // poll per sweep instead of nch of them, and one pass through the double-precision logarithm per row instead of one per
+  // wave (fp64 instructions issue at a fraction of the fp32 rate).
+  float lse = __builtin_nanf("");
+  const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+  if (w != 0) {
+    for (;;) {
+      const uint64_t g = __hip_atomic_load(row_recs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((uint32_t)(g >> 32) == epoch) {
+        lse = __uint_as_float((uint32_t)g);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > spin_ticks) {
+        if (lane == 0 && err) atomicAdd(err, 1u);  // (the chunks come out as NaN: a failed launch, never a result)
+        break;
       }
     }
   } else {
-#pragma unroll
-    for (int i = 0; i < NVC; ++i) {
-      const int e0 = e_base + (i * 64 + lane) * EPV;
-      float t[EPV];
-      unpack_scaled<DT, SCALED>(raw[i], scale, t);
-      for (int k = 0; k < EPV; ++k)
-        if (e0 + k < V) o[i * 64 * EPV + k] = t[k] - lse;
+    float Nj = kNegInf;
+    uint64_t Sj = 0;
+    bool have = true;
+    const uint64_t *q = row_recs + (int64_t)(lane < nch ? lane : 0) * kRecWords;
+    for (;;) {
+      bool ok = true;
+      if (lane < nch) {
+        const uint64_t g0 = __hip_atomic_load(const_cast<uint64_t *>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t g2 = __hip_atomic_load(const_cast<uint64_t *>(q) + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t g3 = __hip_atomic_load(const_cast<uint64_t *>(q) + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = (uint32_t)(g0 >> 32) == epoch && (uint32_t)(g2 >> 32) == epoch && (uint32_t)(g3 >> 32) == epoch;
+        Nj = __uint_as_float((uint32_t)g0);
+        Sj = ((uint64_t)(uint32_t)g2 << kGridHi) + (uint32_t)g3;
+      }
+      if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+      __builtin_amdgcn_s_sleep(8);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > spin_ticks) {
+        have = false;
+        break;
+      }
+    }
+    if (!have && lane == 0 && err) atomicAdd(err, 1u);  // (the row comes out as NaN: a failed launch, never a result)
+    if (have) {
+      const bool on = lane < nch && Sj != 0;
+      const float N = wave_max(on ? Nj : kNegInf);
+      uint64_t sa = 0;
+      if (on) {
+        const float d = N - Nj;
+        sa = d < 64.0f ? Sj >> (uint32_t)d : 0ull;
+      }
+      const uint64_t S = wave_sum_u64(sa);
+      lse = S ? (float)log_fix(S, (int32_t)N + 1 - kFrac) : kNegInf;
+    }
+    if (lane == 0) {  // (a NaN too: the row-mates then leave with it instead of waiting out their own watchdog)
+      __hip_atomic_store(row_recs + 1, ((uint64_t)epoch << 32) | __float_as_uint(lse), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (out_lse) out_lse[r] = lse;
     }
   }
+#ifdef GLB_STAMPS
+  if (lane == 0) stamps[2] = __builtin_amdgcn_s_memrealtime();
+#endif
+  if (out_v) {
+    // (the lane index as a new value: element indices of the ragged last chunk's stores are otherwise computed next to
+    // those of its loads, ahead of the wait, and spilled across it)
+    int lane_s = lane;
+    asm volatile("" : "+v"(lane_s));
+#pragma unroll
+    for (int j = 0; j < CPW; ++j)
+      if (j == 0 || c0 + j < nch)
+        chunk_store_logprobs<DT, SCALED, STORE, OUT16>(raw[j], scale, lse, out_v, (int64_t)r * out_ld, (c0 + j) * kChunk, V, lane_s);
+  }
+#ifdef GLB_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the stores have left the wave's queue)
+  if (lane == 0) stamps[3] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------

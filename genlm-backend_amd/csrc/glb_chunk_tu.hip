@@ -121,20 +121,22 @@ hipError_t GLB_CAT(launch_logprob_rows_, GLB_DT)(const void *logits, int64_t ld,
   return hipGetLastError();
 }
 
-template <int WPS, int STORE, bool OUT16 = false>
+template <int WPS, int STORE, bool OUT16 = false, int CPW = 1>
 static void lsm_waves1(const void *logits, int64_t ld, int V, int nch, float scale, void *out, int64_t out_ld,
                        float *out_lse, int n_rows, uint64_t *recs, uint32_t epoch, uint32_t *err, uint64_t spin,
                        hipStream_t s) {
-  const dim3 grid((unsigned)((int64_t)n_rows * nch)), block(64);
+  const int wpr = (nch + CPW - 1) / CPW;
+  const dim3 grid((unsigned)((int64_t)n_rows * wpr)), block(64);
   if (scale != 1.0f)
-    hipLaunchKernelGGL((logprob_rows_waves_kernel<GLB_DT, true, WPS, STORE, OUT16>), grid, block, 0, s, logits, ld, V, nch,
-                       scale, out, out_ld, out_lse, recs, epoch, err, spin);
+    hipLaunchKernelGGL((logprob_rows_waves_kernel<GLB_DT, true, WPS, STORE, OUT16, CPW>), grid, block, 0, s, logits, ld, V, nch,
+                       wpr, scale, out, out_ld, out_lse, recs, epoch, err, spin);
   else
-    hipLaunchKernelGGL((logprob_rows_waves_kernel<GLB_DT, false, WPS, STORE, OUT16>), grid, block, 0, s, logits, ld, V, nch,
-                       scale, out, out_ld, out_lse, recs, epoch, err, spin);
+    hipLaunchKernelGGL((logprob_rows_waves_kernel<GLB_DT, false, WPS, STORE, OUT16, CPW>), grid, block, 0, s, logits, ld, V, nch,
+                       wpr, scale, out, out_ld, out_lse, recs, epoch, err, spin);
 }
 
-// variant: 0 = the product's choice; the diagnostic build passes others (waves per SIMD * 10 + store form)
+// variant: 0 = the product's choice; the diagnostic build passes others (waves per SIMD * 10 + store form, + 100 * (chunks
+// per wave - 1))
 hipError_t GLB_CAT(launch_logprob_waves_, GLB_DT)(const void *logits, int64_t ld, int V, int nch, float scale, void *out,
                                                    int64_t out_ld, float *out_lse, int n_rows, uint64_t *recs,
                                                    uint32_t epoch, uint32_t *err, uint64_t spin, bool out16, int variant,
@@ -151,17 +153,33 @@ hipError_t GLB_CAT(launch_logprob_waves_, GLB_DT)(const void *logits, int64_t ld
 #ifdef GLB_STAMPS
     if (variant == 60) lsm_waves1<6, 0, true>(GLB_LSM_ARGS);
     else if (variant == 40) lsm_waves1<4, 0, true>(GLB_LSM_ARGS);
+    else if (variant == 50) lsm_waves1<5, 0, true>(GLB_LSM_ARGS);
+    else if (variant == 80) lsm_waves1<8, 0, true>(GLB_LSM_ARGS);
+    else if (variant == 140) lsm_waves1<4, 0, true, 2>(GLB_LSM_ARGS);
+    else if (variant == 150) lsm_waves1<5, 0, true, 2>(GLB_LSM_ARGS);
+    else if (variant == 240) lsm_waves1<4, 0, true, 3>(GLB_LSM_ARGS);
+    else if (variant == 330) lsm_waves1<3, 0, true, 4>(GLB_LSM_ARGS);
     else
 #endif
-    lsm_waves1<5, 0, true>(GLB_LSM_ARGS);
+    // chunks per wave by the row's length (same-box, bf16 -> bf16, us at 1024 x 50257 / 512 x 128256: one chunk per wave
+    // 43 / 69, two 44 / 55, three 47 / 52, four 63 / 60 - profiles/r04/ab_lsm_cpw_v4.log)
+    if (nch > 16) lsm_waves1<4, 0, true, 3>(GLB_LSM_ARGS);
+    else lsm_waves1<8, 0, true, 1>(GLB_LSM_ARGS);
   } else {
 #ifdef GLB_STAMPS
     if (variant == 50) lsm_waves1<5, 0>(GLB_LSM_ARGS);       // 107 / 141 us at 1024 x 50257 / 512 x 128256 bf16
     else if (variant == 51) lsm_waves1<5, 1>(GLB_LSM_ARGS);  //  75 / 102 (plain stores: L2 merges the halves)
     else if (variant == 42) lsm_waves1<4, 2>(GLB_LSM_ARGS);
+    else if (variant == 52) lsm_waves1<5, 2>(GLB_LSM_ARGS);  //  65 /  94
+    else if (variant == 142) lsm_waves1<4, 2, false, 2>(GLB_LSM_ARGS);
+    else if (variant == 152) lsm_waves1<5, 2, false, 2>(GLB_LSM_ARGS);
+    else if (variant == 242) lsm_waves1<4, 2, false, 3>(GLB_LSM_ARGS);
+    else if (variant == 332) lsm_waves1<3, 2, false, 4>(GLB_LSM_ARGS);
     else
 #endif
-    lsm_waves1<5, 2>(GLB_LSM_ARGS);                          //  65 /  94
+    // (bf16 -> float32: one chunk per wave 61 / 94, two 63 / 76, three 68 / 76, four 77 / 82)
+    if (nch > 16) lsm_waves1<5, 2, false, 2>(GLB_LSM_ARGS);
+    else lsm_waves1<5, 2, false, 1>(GLB_LSM_ARGS);
   }
 #undef GLB_LSM_ARGS
   return hipGetLastError();
