@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libglb_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 GLB_OK, GLB_EINVAL, GLB_EUNSUPPORTED, GLB_EHIP, GLB_ENOSPC = 0, 1, 2, 3, 4
 F32, BF16, F16 = 0, 1, 2
 MASK_NONE, MASK_BITS, MASK_F32, MASK_PREPARED = 0, 1, 2, 3
@@ -50,6 +50,38 @@ class StepArgs(C.Structure):
         ("out_token", C.c_void_p),
         ("out_margin", C.c_void_p),
         ("flags", C.c_int32),
+        ("workspace", C.c_void_p),
+        ("workspace_bytes", C.c_size_t),
+    ]
+
+
+class TriePlan(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32)] + [(k, C.c_int32) for k in ("n_parts", "n_top", "n_cut", "n_slots", "max_local", "top_base",
+                                                                          "lds_bytes")] + [
+        ("n_nodes", C.c_int64)] + [(k, C.c_void_p) for k in ("desc", "idepth", "leaf_src", "leaf_local", "pn_node", "pn_local", "top_local",
+                                                             "slot_of", "cptr16", "inode16")]
+
+
+class TrieRowsArgs(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("weights", C.c_void_p),
+        ("dtype", C.c_int32),
+        ("ld", C.c_int64),
+        ("n_rows", C.c_int64),
+        ("vocab", C.c_int64),
+        ("lse", C.c_void_p),
+        ("logit_scale", C.c_float),
+        ("from_logprobs", C.c_int32),
+        ("op", C.c_int32),
+        ("out_slots", C.c_void_p),
+        ("out_slots_ld", C.c_int64),
+        ("out_nodes", C.c_void_p),
+        ("out_nodes_ld", C.c_int64),
+        ("sel_nodes", C.c_void_p),
+        ("n_sel", C.c_int64),
+        ("out_sel", C.c_void_p),
+        ("out_sel_ld", C.c_int64),
         ("workspace", C.c_void_p),
         ("workspace_bytes", C.c_size_t),
     ]
@@ -157,6 +189,8 @@ SYMBOLS = {
                                   _vp]),
     "glb_trie_workspace_ex": (_sz, [_i64, _i64]),
     "glb_trie_masses": (C.c_int, [C.POINTER(TrieArgs), _vp]),
+    "glb_trie_rows_workspace": (_sz, [_i64, C.POINTER(TriePlan)]),
+    "glb_trie_rows": (C.c_int, [C.POINTER(TrieRowsArgs), C.POINTER(TriePlan), _vp]),
     "glb_resample_workspace": (_sz, [_i64]),
     "glb_resample_systematic": (C.c_int, [_vp, _i64, C.c_uint64, C.c_uint64, _vp, _vp, _vp, _sz, _vp]),
     "glb_mt19937_seed": (None, [C.POINTER(MT19937), C.c_uint64]),

@@ -17,6 +17,7 @@
 #include "../../include/glb.h"
 #include "glb_chunk.hpp"
 #include "glb_common.hpp"
+#include "glb_trie.hpp"
 
 namespace glb {
 // launchers exported by the three glb_chunk_tu.hip translation units (one per element type)
@@ -784,24 +785,8 @@ __global__ __launch_bounds__(1024) void resample_systematic_kernel(const float *
 // in double, the reference's sequential order - and stores it as float32.  A thread is one (row, node); node ids are
 // post-order, so the children of neighbouring nodes are neighbours in memory.  Values live in the output itself: no
 // scratch, every output float written once and read once.
-// one weight: element k of a row of any element type; from_logprobs: exp(x * scale - lse) - with the row's lse from the
-// fused step this turns LOGITS into probabilities on the way in (no [B, V] log-prob matrix is ever written)
-// e^x by the hardware's 2^x (v_exp_f32, 1 ulp) on x * log2(e): relative error about |x| * 1e-7 - the input, a logit minus
-// a float32 lse, is no better known - for 3 instructions instead of expf's 25 (a third of the leaves kernel's time).
-__device__ __forceinline__ float trie_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
-
-template <int DT>
-__device__ __forceinline__ float trie_weight(const void *ws, int64_t idx, int from_logprobs, float scale, float lse) {
-  float v;
-  if constexpr (DT == glb::kDtF32) {
-    v = reinterpret_cast<const float *>(ws)[idx];
-  } else {
-    const uint32_t h = reinterpret_cast<const uint16_t *>(ws)[idx];
-    if constexpr (DT == glb::kDtBf16) v = __uint_as_float(h << 16);
-    else v = (float)__builtin_bit_cast(_Float16, (uint16_t)h);
-  }
-  return from_logprobs ? trie_exp(v * scale - lse) : v;
-}
+// (the leaf weight - trie_weight, trie_exp - lives in glb_trie.hpp: the row-resident kernel of glb_trie.hip shares it)
+using glb::trie_weight;
 
 template <int DT>
 __global__ void trie_leaves_kernel(const void *ws, int64_t ld, int64_t n_rows, int32_t V, const int32_t *leaf_node,

@@ -1,0 +1,356 @@
+// glb_trie.hip — token -> byte trie masses with ONE ROW of a part of the trie resident in LDS (include/glb.h:
+// glb_trie_rows; replaces trie/base.py:346-393's per-row loops and trie/parallel.py:92-145's sparse product for
+// batches).
+//
+// The level-synchronous kernels of glb_api.hip keep the values node-major in HBM (scr[slot][row]): the weights pass
+// through a transpose (206 MB in, 206 MB out in 256-byte runs at 1024 x 50257), every slot is read once more as a child
+// and the result is transposed back for a row-major caller - 750 MB of scattered traffic at ~3 TB/s for 478 MB of
+// algorithmic bytes, seven launches.  Here a workgroup owns (row, part): the host cuts the folded trie into parts of
+// subtrees that fit the LDS (trie.TokenByteTrie.plan), numbered breadth first so that a node's children are
+// consecutive and a depth is a range.  The workgroup gathers its part's token weights from the row (tokens ascending:
+// the row is read line by line; the parts of a row run on the same XCD, so the row comes from HBM once and from that
+// XCD's L2 afterwards), reduces depth by depth in LDS - a thread per node, children added in ascending order in double,
+// the node stored as float32: the arithmetic and the order of the reference's loop - and writes its run of the row of
+// the output.  The few nodes above the parts (the root and what else has more descendants than a part holds) are a
+// last small part whose leaves are the parts' subtree roots, one more launch of the same kernel.
+// Traffic: the weights once, the output once.
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cstdlib>
+
+#include "../../include/glb.h"
+#include "glb_common.hpp"
+#include "glb_trie.hpp"
+
+namespace {
+
+constexpr int kDesc = 16;  // int32 words per part descriptor (trie.py: plan()["desc"])
+enum { D_SLOT_BASE = 0, D_N_LOCAL, D_N_ROOTS, D_N_DEPTHS, D_DEPTH_OFF, D_CPTR_OFF, D_LEAF_OFF, D_N_LEAVES, D_CUT_BASE, D_NODE_OFF, D_N_NODES,
+       D_INODE_OFF, D_N_INODES, D_IDEPTH_OFF };
+constexpr int kMaxThreads = 1024;
+
+struct TrieRowsParams {
+  const void *ws;
+  int64_t ld;
+  int32_t n_rows, n_parts, from_logprobs, op;
+  const float *lse;
+  float scale;
+  const int32_t *desc, *idepth, *leaf_src, *leaf_local, *pn_node, *pn_local, *top_local;
+  const uint16_t *cptr16, *inode16;
+  int32_t top_base, n_cut;
+  float *cut_vals;  // [n_rows][n_cut]: the values of the parts' subtree roots, the leaves of the top
+  float *out_slots;
+  int64_t out_slots_ld;
+  float *out_nodes;
+  int64_t out_nodes_ld;
+  const int32_t *sel_slot;  // [n_sel]: the slots of the selected nodes (workspace)
+  int32_t n_sel;
+  float *out_sel;
+  int64_t out_sel_ld;
+#ifdef GLB_STAMPS  // diagnostic build (tools/dbg/stamps_trie.py): per workgroup [start, leaves in flight, leaves in LDS, reduced, written]
+  uint64_t *stamps;
+#endif
+};
+
+// TOP: the part above the cut (leaves = the cut roots' values of this row); otherwise block b = (row, part) with the
+// parts of a row on consecutive blocks of the SAME XCD (blocks go round the eight XCDs one by one).
+// LDS: val[n_local] float32, then as 16-bit words (a part has fewer than 65536 slots) the part's child pointers and its
+// internal nodes, depth by depth: the reduction touches no global memory, and a thread gets an INTERNAL node (three
+// slots in four are leaves; dealt by slot, every wave would run a node's loop for a handful of busy lanes - 6.6 us of a
+// workgroup's 17; within a depth the host lists the nodes with the most children first, so the lanes of a wave run
+// loops of about the same length).  Everything that reads an index from global memory and then uses it (token ->
+// weight, node -> output position) is unrolled kU deep with the index loads in front: one memory latency per kU
+// elements instead of one or two per element (a thread handles a dozen leaves and some fifty nodes of the row-major
+// output; one by one that was 25 us per (row, part)).
+constexpr int kU = 8;
+
+template <int DT, bool TOP>
+__global__ __launch_bounds__(kMaxThreads) void trie_rows_kernel(TrieRowsParams p) {
+  extern __shared__ float val[];
+  int r, part;
+  if constexpr (TOP) {
+    r = blockIdx.x;
+    part = p.n_parts;
+  } else {
+    const int b = blockIdx.x, xcd = b & 7, q = b >> 3;
+    part = q % p.n_parts;
+    r = (q / p.n_parts) * 8 + xcd;
+    if (r >= p.n_rows) return;
+  }
+  const int32_t *d = p.desc + part * kDesc;  // workgroup-uniform: scalar loads
+  const int n_local = d[D_N_LOCAL], n_depths = d[D_N_DEPTHS], n_leaves = d[D_N_LEAVES], n_inodes = d[D_N_INODES];
+  const int tid = threadIdx.x, nt = blockDim.x;
+#ifdef GLB_STAMPS
+  uint64_t *st = (!TOP && p.stamps && blockIdx.x < 65536u) ? p.stamps + (int64_t)blockIdx.x * 8 : nullptr;
+  if (st && tid == 0) st[0] = __builtin_amdgcn_s_memrealtime();
+#define GLB_TRIE_STAMP(k) if (st && tid == 0) st[k] = __builtin_amdgcn_s_memrealtime();
+#else
+#define GLB_TRIE_STAMP(k)
+#endif
+  const int cp_words = (n_local + 2) >> 1, in_words = (n_inodes + 1) >> 1;  // 32-bit words of the two 16-bit tables
+  uint32_t *tab = reinterpret_cast<uint32_t *>(val + n_local);
+  const uint16_t *cp16 = reinterpret_cast<const uint16_t *>(tab), *in16 = reinterpret_cast<const uint16_t *>(tab + cp_words);
+  // ---- leaves: indices first, then the weights they name, then LDS
+  {
+    const int32_t *src = p.leaf_src + d[D_LEAF_OFF], *loc = p.leaf_local + d[D_LEAF_OFF];
+    const float *cv = TOP ? p.cut_vals + (int64_t)r * p.n_cut : nullptr;
+    const float lse = (!TOP && p.lse) ? p.lse[r] : 0.0f;
+    const int64_t row = (int64_t)r * p.ld;
+    for (int i0 = tid; i0 < n_leaves; i0 += nt * kU) {
+      int sj[kU], lj[kU];
+      float w[kU];
+#pragma unroll
+      for (int j = 0; j < kU; ++j) {
+        const int i = i0 + j * nt;
+        const bool ok = i < n_leaves;
+        sj[j] = ok ? src[i] : -1;
+        lj[j] = ok ? loc[i] : 0;
+      }
+#pragma unroll
+      for (int j = 0; j < kU; ++j) {
+        if (sj[j] >= 0) {
+          if constexpr (TOP) w[j] = cv[sj[j]];
+          else w[j] = glb::trie_weight<DT>(p.ws, row + sj[j], p.from_logprobs, p.scale, lse);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kU; ++j)
+        if (sj[j] >= 0) val[lj[j]] = w[j];
+    }
+  }
+  // ---- the part's tables into LDS (two 16-bit entries a word; both tables start on a word in global memory)
+  {
+    const uint32_t *g = reinterpret_cast<const uint32_t *>(p.cptr16 + d[D_CPTR_OFF]);
+    for (int i0 = tid; i0 < cp_words; i0 += nt * kU) {
+      uint32_t t[kU];
+#pragma unroll
+      for (int j = 0; j < kU; ++j) t[j] = i0 + j * nt < cp_words ? g[i0 + j * nt] : 0u;
+#pragma unroll
+      for (int j = 0; j < kU; ++j)
+        if (i0 + j * nt < cp_words) tab[i0 + j * nt] = t[j];
+    }
+    const uint32_t *gi = reinterpret_cast<const uint32_t *>(p.inode16 + d[D_INODE_OFF]);
+    for (int i0 = tid; i0 < in_words; i0 += nt * 4) {
+      uint32_t t[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t[j] = i0 + j * nt < in_words ? gi[i0 + j * nt] : 0u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (i0 + j * nt < in_words) tab[cp_words + i0 + j * nt] = t[j];
+    }
+  }
+  GLB_TRIE_STAMP(1)
+  __syncthreads();
+  GLB_TRIE_STAMP(2)
+  // ---- depth by depth, deepest first: a thread per internal node, its children consecutive in LDS
+  {
+    const int32_t *idp = p.idepth + d[D_IDEPTH_OFF];
+    for (int k = n_depths - 2; k >= 0; --k) {  // (the deepest depth holds leaves only)
+      const int lo = idp[k], hi = idp[k + 1];
+      for (int i = lo + tid; i < hi; i += nt) {
+        const int s = in16[i], c0 = cp16[s], c1 = cp16[s + 1];
+        double acc = 0.0;
+        if (p.op == GLB_TRIE_SUM) {
+          int c = c0;
+          for (; c + 4 <= c1; c += 4) {  // four loads in flight; added one by one in ascending order all the same
+            const float v0 = val[c], v1 = val[c + 1], v2 = val[c + 2], v3 = val[c + 3];
+            acc += (double)v0;
+            acc += (double)v1;
+            acc += (double)v2;
+            acc += (double)v3;
+          }
+          for (; c < c1; ++c) acc += (double)val[c];
+        } else {
+          for (int c = c0; c < c1; ++c) acc = fmax(acc, (double)val[c]);
+        }
+        val[s] = (float)acc;
+      }
+      __syncthreads();
+    }
+  }
+  GLB_TRIE_STAMP(3)
+  // ---- outputs
+  if (p.out_slots) {
+    float *o = p.out_slots + (int64_t)r * p.out_slots_ld;
+    if constexpr (TOP) {
+      const int n_top = n_local - n_leaves;
+      for (int i = tid; i < n_top; i += nt) o[p.top_base + i] = val[p.top_local[i]];
+    } else {
+      o += d[D_SLOT_BASE];
+      for (int i = tid; i < n_local; i += nt) o[i] = val[i];
+    }
+  }
+  if (p.out_nodes) {
+    float *o = p.out_nodes + (int64_t)r * p.out_nodes_ld;
+    const int32_t *nd = p.pn_node + d[D_NODE_OFF], *nl = p.pn_local + d[D_NODE_OFF];
+    const int n = d[D_N_NODES];
+    for (int i0 = tid; i0 < n; i0 += nt * kU) {
+      int nj[kU], lj[kU];
+#pragma unroll
+      for (int j = 0; j < kU; ++j) {
+        const int i = i0 + j * nt;
+        const bool ok = i < n;
+        nj[j] = ok ? nd[i] : -1;
+        lj[j] = ok ? nl[i] : 0;
+      }
+#pragma unroll
+      for (int j = 0; j < kU; ++j)
+        if (nj[j] >= 0) o[nj[j]] = val[lj[j]];
+    }
+  }
+  if (p.out_sel) {
+    float *o = p.out_sel + (int64_t)r * p.out_sel_ld;
+    const int base = d[D_SLOT_BASE];
+    for (int j0 = tid; j0 < p.n_sel; j0 += nt * 4) {
+      int sl[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int jj = j0 + j * nt;
+        sl[j] = jj < p.n_sel ? p.sel_slot[jj] : -1;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int jj = j0 + j * nt, s = sl[j];
+        if constexpr (TOP) {
+          if (s >= base) o[jj] = val[p.top_local[s - base]];
+        } else {
+          if (s >= base && s < base + n_local) o[jj] = val[s - base];
+        }
+      }
+    }
+  }
+  if constexpr (!TOP) {
+    if (p.cut_vals) {
+      float *cv = p.cut_vals + (int64_t)r * p.n_cut + d[D_CUT_BASE];
+      const int n_roots = d[D_N_ROOTS];
+      for (int i = tid; i < n_roots; i += nt) cv[i] = val[i];
+    }
+  }
+#ifdef GLB_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  GLB_TRIE_STAMP(4)
+  if (st && tid == 0) st[5] = ((uint64_t)part << 32) | (uint32_t)r;
+#endif
+}
+
+// the selected nodes' slots, once per call (the same for every row)
+__global__ void trie_sel_slots_kernel(const int32_t *sel, int32_t n_sel, const int32_t *slot_of, int32_t *sel_slot) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n_sel) sel_slot[j] = slot_of[sel[j]];
+}
+
+template <int DT>
+hipError_t launch_rows(const TrieRowsParams &p, int n_top, size_t lds, int threads, hipStream_t s) {
+  static bool big_lds_set = false;  // (more than 64 KB of dynamic LDS has to be asked for, once per kernel)
+  if (!big_lds_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)trie_rows_kernel<DT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)trie_rows_kernel<DT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    big_lds_set = true;
+  }
+  const unsigned blocks = (unsigned)(((int64_t)p.n_rows + 7) / 8 * 8 * p.n_parts);
+  hipLaunchKernelGGL((trie_rows_kernel<DT, false>), dim3(blocks), dim3(threads), lds, s, p);
+  if (n_top > 0) hipLaunchKernelGGL((trie_rows_kernel<DT, true>), dim3((unsigned)p.n_rows), dim3(256), lds, s, p);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+constexpr int64_t kMaxSel = 1 << 20;  // selected nodes per call (their slots sit behind the cut values in the workspace)
+static size_t cut_bytes(int64_t n_rows, const glb_trie_plan *pl) {
+  return pl->n_top > 0 ? (((size_t)n_rows * (size_t)pl->n_cut * sizeof(float) + 255) & ~(size_t)255) : 0;
+}
+
+extern "C" {
+
+size_t glb_trie_rows_workspace(int64_t n_rows, const glb_trie_plan *plan) {
+  if (!plan || n_rows <= 0) return 0;
+  return cut_bytes(n_rows, plan) + kMaxSel * sizeof(int32_t);
+}
+
+int glb_trie_rows(const glb_trie_rows_args *a, const glb_trie_plan *pl, void *stream) {
+  using glb::api_fail;
+  if (!a || !pl) return api_fail(GLB_EINVAL, "glb_trie_rows: null args");
+  if (a->struct_size != sizeof(glb_trie_rows_args))
+    return api_fail(GLB_EINVAL, "glb_trie_rows_args.struct_size %u != %zu (ABI mismatch)", a->struct_size, sizeof(glb_trie_rows_args));
+  if (pl->struct_size != sizeof(glb_trie_plan))
+    return api_fail(GLB_EINVAL, "glb_trie_plan.struct_size %u != %zu (ABI mismatch)", pl->struct_size, sizeof(glb_trie_plan));
+  if (a->n_rows == 0) return GLB_OK;
+  if (!a->weights || a->n_rows < 0 || a->vocab <= 0 || a->ld < a->vocab)
+    return api_fail(GLB_EINVAL, "glb_trie_rows: bad weights shape");
+  if (a->n_rows > INT32_MAX / 2 || a->ld * a->n_rows <= 0) return api_fail(GLB_EINVAL, "glb_trie_rows: too many rows");
+  if (a->dtype != GLB_F32 && a->dtype != GLB_BF16 && a->dtype != GLB_F16) return api_fail(GLB_EINVAL, "glb_trie_rows: bad dtype");
+  if (a->op != GLB_TRIE_SUM && a->op != GLB_TRIE_MAX) return api_fail(GLB_EINVAL, "glb_trie_rows: bad op");
+  if (!(a->logit_scale == a->logit_scale)) return api_fail(GLB_EINVAL, "glb_trie_rows: logit_scale is NaN");
+  if (!a->out_slots && !a->out_nodes && !(a->out_sel && a->n_sel > 0)) return api_fail(GLB_EINVAL, "glb_trie_rows: no output requested");
+  if (pl->n_parts <= 0 || pl->max_local <= 0 || pl->n_slots <= 0 || pl->n_top < 0 || pl->n_cut < 0 || !pl->desc ||
+      !pl->idepth || !pl->cptr16 || !pl->inode16 || !pl->leaf_src || !pl->leaf_local || !pl->slot_of)
+    return api_fail(GLB_EINVAL, "glb_trie_rows: incomplete plan");
+  const size_t lds = (size_t)pl->lds_bytes;
+  if (pl->lds_bytes < pl->max_local * 6 || lds > 160 * 1024 || pl->max_local >= 65536)
+    return api_fail(GLB_EINVAL, "glb_trie_rows: a part of %d slots does not fit the LDS", pl->max_local);
+  if (a->out_nodes && (!pl->pn_node || !pl->pn_local)) return api_fail(GLB_EINVAL, "glb_trie_rows: plan without node lists");
+  if (pl->n_top > 0 && !pl->top_local) return api_fail(GLB_EINVAL, "glb_trie_rows: plan without top_local");
+  if ((a->out_slots && a->out_slots_ld < pl->n_slots) || (a->out_nodes && a->out_nodes_ld < pl->n_nodes) ||
+      (a->out_sel && a->out_sel_ld < a->n_sel))
+    return api_fail(GLB_EINVAL, "glb_trie_rows: output pitch below its width");
+  if (a->n_sel < 0 || a->n_sel > kMaxSel || (a->out_sel && a->n_sel > 0 && !a->sel_nodes))
+    return api_fail(GLB_EINVAL, "glb_trie_rows: bad selection");
+  const size_t need = glb_trie_rows_workspace(a->n_rows, pl);
+  if (need && (!a->workspace || a->workspace_bytes < need))
+    return api_fail(GLB_ENOSPC, "glb_trie_rows: %zu bytes of workspace needed (glb_trie_rows_workspace)", need);
+  TrieRowsParams p{};
+  p.ws = a->weights;
+  p.ld = a->ld;
+  p.n_rows = (int32_t)a->n_rows;
+  p.n_parts = pl->n_parts;
+  p.from_logprobs = a->from_logprobs;
+  p.op = a->op;
+  p.lse = a->lse;
+  p.scale = a->from_logprobs ? a->logit_scale : 1.0f;
+  p.desc = pl->desc;
+  p.idepth = pl->idepth;
+  p.cptr16 = pl->cptr16;
+  p.inode16 = pl->inode16;
+  p.leaf_src = pl->leaf_src;
+  p.leaf_local = pl->leaf_local;
+  p.pn_node = pl->pn_node;
+  p.pn_local = pl->pn_local;
+  p.top_local = pl->top_local;
+  p.top_base = pl->top_base;
+  p.n_cut = pl->n_cut;
+  p.cut_vals = pl->n_top > 0 ? (float *)a->workspace : nullptr;
+  p.out_slots = a->out_slots;
+  p.out_slots_ld = a->out_slots_ld;
+  p.out_nodes = a->out_nodes;
+  p.out_nodes_ld = a->out_nodes_ld;
+  p.n_sel = a->out_sel ? (int32_t)a->n_sel : 0;
+  p.sel_slot = (const int32_t *)((char *)a->workspace + cut_bytes(a->n_rows, pl));
+#ifdef GLB_STAMPS
+  p.stamps = p.n_sel == 0 ? (uint64_t *)p.sel_slot : nullptr;  // (the selection's area, when there is no selection)
+#endif
+  p.out_sel = a->n_sel > 0 ? a->out_sel : nullptr;
+  p.out_sel_ld = a->out_sel_ld;
+  hipStream_t s = (hipStream_t)stream;
+  if (p.out_sel)
+    hipLaunchKernelGGL(trie_sel_slots_kernel, dim3((unsigned)((p.n_sel + 255) / 256)), dim3(256), 0, s, a->sel_nodes, p.n_sel,
+                       pl->slot_of, (int32_t *)p.sel_slot);
+  // threads per workgroup: as many workgroups as the LDS lets a CU hold (at most 2048 threads a CU)
+  int threads = 1024;
+  if (lds * 4 <= 160 * 1024) threads = 512;
+  if (lds * 8 <= 160 * 1024) threads = 256;
+#ifdef GLB_STAMPS
+  if (const char *e = getenv("GLB_TRIE_THREADS")) threads = atoi(e);
+#endif
+  hipError_t e;
+  switch (a->dtype) {
+    case GLB_F32: e = launch_rows<GLB_F32>(p, pl->n_top, lds, threads, s); break;
+    case GLB_BF16: e = launch_rows<GLB_BF16>(p, pl->n_top, lds, threads, s); break;
+    default: e = launch_rows<GLB_F16>(p, pl->n_top, lds, threads, s); break;
+  }
+  if (e != hipSuccess) return glb::api_hip_fail(e, "glb_trie_rows launch");
+  return GLB_OK;
+}
+
+}  // extern "C"

@@ -11,7 +11,7 @@ import torch
 from . import _lib
 from ._lib import GLB_EHIP, GlbError
 from ._lib import (F32, BF16, F16, MASK_NONE, MASK_BITS, MASK_F32, MASK_PREPARED, RNG_NONE, RNG_PHILOX, RNG_NOISE,
-                   KvPlanArgs, StepArgs, TrieArgs, MT19937, check)
+                   KvPlanArgs, StepArgs, TrieArgs, TriePlan, TrieRowsArgs, MT19937, check)
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 
@@ -595,6 +595,62 @@ class HipEngine:
             return out
         pitch = (B + 63) // 64 * 64
         return self._trie_ws[: n_nodes * pitch * 4].view(torch.float32).view(n_nodes, pitch)
+
+    def trie_rows(self, ws, plan, op=0, from_logprobs=False, lse=None, logit_scale=1.0, nodes=None, layout="rows", out=None):
+        """Token -> byte trie masses with one row of a part of the trie resident in LDS (glb_trie_rows): the weights are
+        read once, the result written once, row-major.  plan: `TokenByteTrie.plan_device_arrays()`.  ws as in
+        `trie_masses`.  Result: layout "rows" float32 [B, n_nodes]; nodes given (int32 device tensor) [B, len(nodes)];
+        layout "slots" [B, n_slots] in the plan's slot numbering (plan["slot_of"]: node -> slot)."""
+        if ws.dim() != 2 or ws.stride(1) != 1 or ws.dtype not in _DT:
+            raise ValueError("weights must be [B, V] float32 / bfloat16 / float16 with unit inner stride")
+        B = ws.shape[0]
+        V = plan["vocab"]
+        self._check_dev(lse, nodes, out)
+        pl = plan.get("_c")
+        if pl is None:
+            pl = TriePlan()
+            pl.struct_size = C.sizeof(TriePlan)
+            for k in ("n_parts", "n_top", "n_cut", "n_slots", "max_local", "top_base", "lds_bytes", "n_nodes"):
+                setattr(pl, k, int(plan[k]))
+            for k in ("desc", "idepth", "leaf_src", "leaf_local", "pn_node", "pn_local", "top_local", "slot_of", "cptr16", "inode16"):
+                setattr(pl, k, plan[k].data_ptr())
+            plan["_c"] = pl
+        a = TrieRowsArgs()
+        a.struct_size = C.sizeof(TrieRowsArgs)
+        a.weights, a.dtype = ws.data_ptr(), _DT[ws.dtype]
+        a.ld = ws.stride(0) if B > 1 else max(V, ws.stride(0))
+        a.n_rows, a.vocab = B, V
+        a.lse = None if lse is None else lse.data_ptr()
+        a.logit_scale, a.from_logprobs, a.op = logit_scale, 1 if from_logprobs else 0, op
+        need = self.lib.glb_trie_rows_workspace(B, C.byref(pl))
+        if need:
+            if self._trie_ws is None or self._trie_ws.numel() < need:
+                self._trie_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            a.workspace, a.workspace_bytes = self._trie_ws.data_ptr(), self._trie_ws.numel()
+        if nodes is not None:
+            if nodes.dtype != torch.int32:
+                raise TypeError("nodes must be int32")
+            width = nodes.numel()
+        elif layout == "rows":
+            width = plan["n_nodes"]
+        elif layout == "slots":
+            width = plan["n_slots"]
+        else:
+            raise ValueError(f"unknown layout {layout!r}")
+        if out is None:
+            out = torch.empty((B, width), dtype=torch.float32, device=self.device)
+        elif out.shape != (B, width) or out.dtype != torch.float32 or out.stride(1) != 1:
+            raise ValueError(f"out must be float32 [{B}, {width}] with unit inner stride")
+        if width == 0 or B == 0:
+            return out
+        if nodes is not None:
+            a.sel_nodes, a.n_sel, a.out_sel, a.out_sel_ld = nodes.data_ptr(), width, out.data_ptr(), out.stride(0)
+        elif layout == "rows":
+            a.out_nodes, a.out_nodes_ld = out.data_ptr(), out.stride(0)
+        else:
+            a.out_slots, a.out_slots_ld = out.data_ptr(), out.stride(0)
+        check(self.lib.glb_trie_rows(C.byref(a), C.byref(pl), self._stream()))
+        return out
 
     def trie_reduce(self, ws, flat, op=0, from_logprobs=False, out=None):
         """out[r, node] = sum / max of the weights of the tokens below `node` (glb_trie_reduce).  ws: float32 [B, >=V]

@@ -88,6 +88,8 @@ class TokenByteTrie:
         self._dev = None
         self._compact = None
         self._cdev = None
+        self._plan = None
+        self._pdev = None
 
     def __len__(self):
         return len(self.children)
@@ -155,6 +157,183 @@ class TokenByteTrie:
                                  slot_of=slot_of.astype(np.int32))
         return self._compact
 
+    PLAN_CAP = 12000  # slots per part: ~6.5 bytes of LDS a slot (value, child pointer, list of internal nodes) = 78 KB, two workgroups a CU
+
+    def plan(self, cap=None):
+        """The folded trie (`compact()`) cut for glb_trie_rows, which keeps ONE ROW's values of a part of the trie in
+        the LDS of a compute unit: subtrees of at most `cap` slots are packed into parts of at most `cap` slots; the few
+        nodes above them (the root and what else is too big - `top`) form one more part whose leaves are the cut
+        subtrees' roots.  Inside a part the slots are numbered breadth first over its subtrees (roots, then their
+        children in the original ascending order, ...), so a node's children are consecutive - `cptr[s] .. cptr[s + 1]` -
+        and a depth is a range `depth_start[d] .. depth_start[d + 1]`; every sum still adds the same numbers in the same
+        order as the reference's loop (base.py:346-393).  Slots are renumbered part by part (`slot_of`: node -> new
+        slot; the top's nodes come last), so a part's values are one run of a row of the slot-major output.
+        Returns None when the top does not fit a part (a trie with a node of more than `cap` children)."""
+        cap = int(cap or self.PLAN_CAP)
+        if self._plan is not None and self._plan[0] == cap:
+            return self._plan[1]
+        c = self.compact()
+        n_slots = int(c["n_nodes"])
+        cp, ci = c["child_ptr"].astype(np.int64), c["child_idx"].astype(np.int64)
+        kids = [ci[cp[s]:cp[s + 1]] for s in range(n_slots)]
+        size = np.ones(n_slots, np.int64)
+        for s in range(n_slots):  # ascending slots = children first
+            if len(kids[s]):
+                size[s] += size[kids[s]].sum()
+        root = int(c["slot_of"][self.root])
+        # -- the cut: descend from the root while a subtree is too big for a part
+        top, cut = [], []
+        stack = [root]
+        while stack:
+            s = stack.pop()
+            if size[s] <= cap:
+                cut.append(s)
+            else:
+                top.append(s)
+                stack.extend(kids[s].tolist())
+        top.sort()
+        cut.sort()
+        if len(top) + len(cut) > cap or cap >= 65536:
+            self._plan = (cap, None)
+            return None
+        # -- parts: first fit, biggest subtrees first
+        bins, room = [], []
+        for s in sorted(cut, key=lambda s: -size[s]):
+            for b in range(len(bins)):
+                if room[b] >= size[s]:
+                    bins[b].append(s)
+                    room[b] -= size[s]
+                    break
+            else:
+                bins.append([s])
+                room.append(cap - size[s])
+        n_parts = len(bins)
+        DESC = 16
+        desc = np.zeros((n_parts + 1, DESC), np.int32)
+        cptr_all, depth_all, leaf_src, leaf_local = [], [], [], []
+        new_slot = np.full(n_slots, -1, np.int64)
+        part_of = np.full(n_slots, -1, np.int64)
+        local_of = np.full(n_slots, -1, np.int64)
+        cut_index = {}
+        slot_base = 0
+        tok_slot = c["leaf_node"].astype(np.int64)  # compact slot of every token's leaf
+
+        def bfs(roots, is_leaf_here):
+            order = list(roots)
+            cptr = []
+            depth_start = [0]
+            lo, nxt = 0, len(order)
+            while lo < len(order):
+                hi = len(order)
+                for i in range(lo, hi):
+                    cptr.append(len(order))
+                    if not is_leaf_here(order[i]):
+                        order.extend(kids[order[i]].tolist())
+                depth_start.append(hi)
+                lo = hi
+            cptr.append(len(order))
+            return order, cptr, depth_start
+
+        for p, roots in enumerate(bins):
+            roots = sorted(roots)
+            order, cptr, depth_start = bfs(roots, lambda s: False)
+            order = np.asarray(order, np.int64)
+            part_of[order] = p
+            local_of[order] = np.arange(len(order))
+            new_slot[order] = slot_base + np.arange(len(order))
+            for i, s in enumerate(roots):
+                cut_index[s] = len(cut_index)
+            desc[p, 0], desc[p, 1], desc[p, 2], desc[p, 3] = slot_base, len(order), len(roots), len(depth_start) - 1
+            desc[p, 4], desc[p, 5] = sum(len(d) for d in depth_all), sum(len(x) for x in cptr_all)
+            desc[p, 8] = cut_index[roots[0]]
+            depth_all.append(depth_start)
+            cptr_all.append(cptr)
+            slot_base += len(order)
+        # leaves of the parts: tokens in ascending order with their local slots
+        tok_part = part_of[tok_slot]
+        for p in range(n_parts):
+            toks = np.nonzero(tok_part == p)[0]
+            desc[p, 6], desc[p, 7] = sum(len(x) for x in leaf_src), len(toks)
+            leaf_src.append(toks)
+            leaf_local.append(local_of[tok_slot[toks]])
+        # -- the top: one more part, its leaves are the cut roots
+        top_set, T = set(top), n_parts
+        n_top = len(top)
+        toplocal = np.zeros(0, np.int64)
+        if n_top:
+            order, cptr, depth_start = bfs([root], lambda s: s not in top_set)
+            order = np.asarray(order, np.int64)
+            is_top = np.fromiter((s in top_set for s in order), bool, len(order))
+            top_order = order[is_top]  # breadth first; new slots of the top follow this order
+            new_slot[top_order] = slot_base + np.arange(n_top)
+            part_of[top_order] = T
+            toplocal = np.nonzero(is_top)[0]
+            local_of[top_order] = toplocal
+            leaves = np.nonzero(~is_top)[0]
+            desc[T, 0], desc[T, 1], desc[T, 2], desc[T, 3] = slot_base, len(order), 1, len(depth_start) - 1
+            desc[T, 4], desc[T, 5] = sum(len(d) for d in depth_all), sum(len(x) for x in cptr_all)
+            desc[T, 6], desc[T, 7] = sum(len(x) for x in leaf_src), len(leaves)
+            depth_all.append(depth_start)
+            cptr_all.append(cptr)
+            leaf_src.append(np.asarray([cut_index[int(s)] for s in order[leaves]], np.int64))
+            leaf_local.append(leaves)
+        # every node's new slot; the nodes of a part in ascending order with their local slots
+        node_slot = c["slot_of"].astype(np.int64)
+        slot_of_new = new_slot[node_slot]
+        node_part = part_of[node_slot]
+        pn_node, pn_local = [], []
+        for p in range(n_parts + 1):
+            nodes = np.nonzero(node_part == p)[0]
+            desc[p, 9], desc[p, 10] = sum(len(x) for x in pn_node), len(nodes)
+            pn_node.append(nodes)
+            pn_local.append(local_of[node_slot[nodes]])
+        cat = lambda xs: (np.concatenate([np.asarray(x, np.int64) for x in xs]) if xs else np.zeros(0, np.int64)).astype(np.int32)
+        # what the kernel keeps in LDS next to the values, as 16-bit words (a part has fewer than 65536 slots): the child
+        # pointers, and the part's internal nodes depth by depth (within a depth the nodes with the most children first:
+        # the lanes of a wave then run loops of about the same length)
+        cptr16, inode16, idepth = [], [], []
+        lds_bytes = 0
+        for p in range(len(cptr_all)):
+            cp = np.asarray(cptr_all[p], np.int64)
+            ds = np.asarray(depth_all[p], np.int64)
+            nch = np.diff(cp)
+            desc[p, 5] = sum(len(x) for x in cptr16)          # (offsets in 16-bit words, even)
+            cptr16.append(np.concatenate([cp, np.zeros(len(cp) & 1, np.int64)]))
+            ins, idp = [], [0]
+            for k in range(len(ds) - 1):
+                sl = np.arange(ds[k], ds[k + 1])
+                sl = sl[nch[sl] > 0]
+                ins.append(sl[np.argsort(-nch[sl], kind="stable")])
+                idp.append(idp[-1] + len(sl))
+            ins = np.concatenate(ins) if ins else np.zeros(0, np.int64)
+            desc[p, 11], desc[p, 12], desc[p, 13] = sum(len(x) for x in inode16), len(ins), sum(len(x) for x in idepth)
+            inode16.append(np.concatenate([ins, np.zeros(len(ins) & 1, np.int64)]))
+            idepth.append(idp)
+            lds_bytes = max(lds_bytes, 4 * int(desc[p, 1]) + 2 * len(cptr16[-1]) + 2 * len(inode16[-1]))
+        cat16 = lambda xs: (np.concatenate(xs) if xs else np.zeros(0, np.int64)).astype(np.uint16)
+        plan = dict(n_parts=n_parts, n_top=n_top, n_slots=n_slots, n_cut=len(cut), cap=cap, vocab=len(self.decode),
+                    n_nodes=len(self.children), max_local=int(desc[:, 1].max()), top_base=slot_base,
+                    lds_bytes=lds_bytes, cptr16=cat16(cptr16), inode16=cat16(inode16), idepth=cat(idepth),
+                    desc=desc, depth_start=cat(depth_all), cptr=cat(cptr_all), leaf_src=cat(leaf_src),
+                    leaf_local=cat(leaf_local), pn_node=cat(pn_node), pn_local=cat(pn_local),
+                    top_local=toplocal.astype(np.int32), slot_of=slot_of_new.astype(np.int32),
+                    slot_compact=np.argsort(new_slot).astype(np.int32))  # new slot -> compact() slot
+        self._plan = (cap, plan)
+        return plan
+
+    def plan_device_arrays(self, cap=None):
+        """`plan()` on the device (None when the trie has no usable plan)."""
+        pl = self.plan(cap)
+        if pl is None:
+            return None
+        if self._pdev is None or self._pdev[0] != pl["cap"]:
+            if self.engine is None:
+                raise RuntimeError("TokenByteTrie needs a HipEngine to compute masses (there is no CPU path)")
+            dev = self.engine.device
+            self._pdev = (pl["cap"], {k: (torch.from_numpy(v.view(np.int16) if v.dtype == np.uint16 else v).to(dev)
+                                          if isinstance(v, np.ndarray) else v) for k, v in pl.items()})
+        return self._pdev[1]
+
     def _to_device(self, f):
         if self.engine is None:
             raise RuntimeError("TokenByteTrie needs a HipEngine to compute masses (there is no CPU path)")
@@ -187,8 +366,13 @@ class TokenByteTrie:
 
     _COMPACT_ROWS = 32  # from here on the kernels keep the values node-major: the folded trie pays
 
+    resident = True  # glb_trie_rows (a row of a part of the trie in LDS) when the trie has a plan; False: the level-synchronous kernels
+
     def _batch(self, ws, op, from_logprobs):
         ws = self._rows(ws)
+        pl = self.plan_device_arrays() if self.resident else None
+        if pl is not None:
+            return self.engine.trie_rows(ws, pl, op, from_logprobs)
         if ws.shape[0] < self._COMPACT_ROWS or self.compact()["n_levels"] == 0:
             return self.engine.trie_reduce(ws, self.device_arrays(), op, from_logprobs)
         c = self.compact_device_arrays()
@@ -207,10 +391,19 @@ class TokenByteTrie:
         what the reference gets from `batch_weight_sum(logprobs.exp())` (trie/parallel.py:92-103) without the [B, V]
         matrix of log-probabilities ever being written.  nodes: int32 device tensor - only these nodes' masses,
         [B, len(nodes)]; layout "slots": node-major [n_slots, pitch] over the folded trie (`compact()`: the value of node
-        n for row r is at [slot_of[n], r] - nothing is transposed back, the cheapest form); layout "nodes": the same over
-        all nodes, [n_nodes, pitch] (see HipEngine.trie_masses)."""
+        n for row r is at [slot_of[n], r] - nothing is transposed back); layout "nodes": the same over all nodes,
+        [n_nodes, pitch] (see HipEngine.trie_masses); layout "slot_rows": row-major [B, n_slots] over the plan's slots
+        (`plan()["slot_of"]`: node -> slot) - the cheapest form: the logits are read once and nothing else is written."""
         if logits.shape[1] < len(self.decode):
             raise ValueError(f"logits rows have {logits.shape[1]} columns, vocabulary has {len(self.decode)}")
+        if nodes is not None and nodes.dtype != torch.int32:
+            raise TypeError("nodes must be int32")
+        pl = self.plan_device_arrays() if self.resident and (layout in ("rows", "slot_rows")) else None
+        if pl is not None:
+            return self.engine.trie_rows(logits, pl, op, True, lse=lse, logit_scale=logit_scale, nodes=nodes,
+                                         layout="slots" if layout == "slot_rows" and nodes is None else "rows")
+        if layout == "slot_rows":
+            raise ValueError("layout 'slot_rows' needs a plan (TokenByteTrie.plan() returned None, or resident is off)")
         if layout == "nodes" or self.compact()["n_levels"] == 0:
             return self.engine.trie_masses(logits, self.device_arrays(), op, True, lse=lse, logit_scale=logit_scale,
                                            nodes=nodes, layout=layout)

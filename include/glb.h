@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GLB_ABI_VERSION 5
+#define GLB_ABI_VERSION 6
 
 /* status codes */
 enum {
@@ -475,6 +475,60 @@ typedef struct glb_trie_args {
 } glb_trie_args;
 size_t glb_trie_workspace_ex(int64_t n_rows, int64_t n_nodes);
 int glb_trie_masses(const glb_trie_args *args, void *hip_stream);
+
+/*
+ * The same masses with ONE ROW's values of a part of the trie resident in LDS (round 4; glb_trie.hip).  Replaces the
+ * batch paths of trie/base.py:196-216 and trie/parallel.py:92-145 for row-major results: the weights are read once
+ * and the output written once - no node-major scratch, no transposes.  `plan` is the folded trie cut into parts of at
+ * most 160 KB / 6 slots (a slot takes a float32 value and a 16-bit child pointer in LDS;
+ * genlm_backend_amd.trie.TokenByteTrie.plan builds it; every array lives on the device):
+ *   desc [n_parts + 1][16] int32, per part: slot_base, n_local, n_roots, n_depths, (unused), cptr_off, leaf_off,
+ *        n_leaves, cut_base, node_off, n_nodes, inode_off, n_inodes, idepth_off (the rest 0); part n_parts is the top
+ *        when n_top > 0
+ *   local slots of a part are numbered breadth first over its subtrees: the children of local slot s are
+ *        cptr16[cptr_off + s] .. cptr16[cptr_off + s + 1] (ascending child order; cptr_off even)
+ *   inode16 [inode_off ..+ n_inodes] (inode_off even): the part's internal local slots depth by depth; depth k is
+ *        idepth[idepth_off + k] .. idepth[idepth_off + k + 1] of them, its children all sit in depth k + 1
+ *   leaf_src / leaf_local [leaf_off ..+ n_leaves]: the part's tokens in ascending order (top: indices of cut roots) and
+ *        the local slots their weights go to
+ *   pn_node / pn_local [node_off ..+ n_nodes]: the trie nodes whose value a local slot of the part holds
+ *   top_local [n_top]: local slot of top slot top_base + i;  slot_of [n_nodes]: node -> slot (parts first, top last)
+ *   lds_bytes: the largest part's 4 n_local + 2 (n_local + 1, rounded up to even) + 2 (n_inodes, rounded up to even)
+ * Same arithmetic per node as glb_trie_reduce (children in ascending order, accumulated in double, stored as float32),
+ * so the results are bit-equal to glb_trie_masses on the same folded trie.
+ * Outputs (any subset): out_slots [n_rows, n_slots] in the plan's slot numbering; out_nodes [n_rows, n_nodes];
+ * out_sel [n_rows, n_sel] = the nodes sel_nodes[0 .. n_sel), n_sel <= 2^20.  workspace: glb_trie_rows_workspace bytes
+ * (the values of the parts' subtree roots, read by the top's launch; the slots of the selected nodes).
+ */
+typedef struct glb_trie_plan {
+  uint32_t struct_size;  /* sizeof(glb_trie_plan) - ABI guard */
+  int32_t n_parts, n_top, n_cut, n_slots, max_local, top_base, lds_bytes;
+  int64_t n_nodes;
+  const int32_t *desc, *idepth, *leaf_src, *leaf_local, *pn_node, *pn_local, *top_local, *slot_of;
+  const uint16_t *cptr16, *inode16;
+} glb_trie_plan;
+typedef struct glb_trie_rows_args {
+  uint32_t struct_size;  /* sizeof(glb_trie_rows_args) - ABI guard */
+  const void *weights;   /* [n_rows, ld] device */
+  int32_t dtype;         /* GLB_F32 / GLB_BF16 / GLB_F16 */
+  int64_t ld, n_rows, vocab;
+  const float *lse;      /* [n_rows] device, nullable (from_logprobs: exp(x * logit_scale - lse[r])) */
+  float logit_scale;
+  int32_t from_logprobs;
+  int32_t op;            /* GLB_TRIE_SUM / GLB_TRIE_MAX */
+  float *out_slots;      /* nullable */
+  int64_t out_slots_ld;
+  float *out_nodes;      /* nullable */
+  int64_t out_nodes_ld;
+  const int32_t *sel_nodes; /* [n_sel] device */
+  int64_t n_sel;
+  float *out_sel;        /* nullable */
+  int64_t out_sel_ld;
+  void *workspace;
+  size_t workspace_bytes;
+} glb_trie_rows_args;
+size_t glb_trie_rows_workspace(int64_t n_rows, const glb_trie_plan *plan);
+int glb_trie_rows(const glb_trie_rows_args *args, const glb_trie_plan *plan, void *hip_stream);
 
 /*
  * Host helper for GLB_RNG_NOISE: fills out[0..n) with the float32 Exp(1) variates

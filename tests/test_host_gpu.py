@@ -663,6 +663,53 @@ def test_trie_masses_from_logits(engine, oracle):
     assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
 
 
+@pytest.mark.parametrize("cap", [250, 700, 20000])
+def test_trie_rows_in_lds_equal_the_level_kernels_and_the_oracle(engine, oracle, cap):
+    """glb_trie_rows (one row of a part of the trie resident in LDS; trie.plan cuts the folded trie into parts of at most
+    `cap` slots - several parts and a top for the small caps, one part for the big one): every node, selected nodes and
+    the slot-major form hold the oracle's bits for weights (sum and max, fp32 and bf16, 1 / 9 / 70 rows) and the
+    level-synchronous kernels' bits for masses straight from logits + lse."""
+    from genlm_backend_amd.tokenization import Token
+    from genlm_backend_amd.trie import TokenByteTrie
+
+    rs = np.random.default_rng(17)
+    words, seen = [], set()
+    while len(words) < 3000:
+        w = bytes(rs.integers(97, 102, int(rs.integers(1, 7))).astype(np.uint8))
+        if w not in seen:
+            seen.add(w)
+            words.append(w)
+    trie = TokenByteTrie([Token(i, w) for i, w in enumerate(words)], engine=engine)
+    trie.PLAN_CAP = cap
+    pl = trie.plan()
+    assert pl is not None and pl["max_local"] <= cap and (pl["n_top"] > 0) == (cap < pl["n_slots"])
+    old = TokenByteTrie([Token(i, w) for i, w in enumerate(words)], engine=engine)
+    old.resident = False
+    dev = engine.device
+    V, nn = len(words), len(trie)
+    for B in (1, 9, 70):
+        w = rs.random((B, V)).astype(np.float32)
+        for op in (0, 1):
+            got = trie._batch(torch.from_numpy(w), op, False).cpu().numpy()
+            assert np.array_equal(got.view(np.uint32), oracle.trie_reduce(w, trie.flat(), op).view(np.uint32))
+        wb = torch.from_numpy(w).to(torch.bfloat16).to(dev)
+        got = engine.trie_rows(wb, trie.plan_device_arrays(), 0, False).cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), oracle.trie_reduce(wb.float().cpu().numpy(), trie.flat(), 0).view(np.uint32))
+        x = (rs.standard_normal((B, V + 5)) * 3).astype(np.float32)  # (a row pitch above the vocabulary)
+        for dt in (torch.float32, torch.bfloat16, torch.float16):
+            xd = torch.from_numpy(x).to(dev).to(dt)
+            _, lse, _ = engine.step(xd, vocab=V, rng_mode=0)
+            rows = trie.masses_from_logits(xd, lse)
+            assert torch.equal(rows, old.masses_from_logits(xd, lse))
+            sel = torch.from_numpy(rs.choice(nn, 300, replace=True).astype(np.int32)).to(dev)
+            assert torch.equal(trie.masses_from_logits(xd, lse, nodes=sel), rows[:, sel.long()])
+            sl = trie.masses_from_logits(xd, lse, layout="slot_rows")
+            assert sl.shape == (B, pl["n_slots"])
+            assert torch.equal(sl[:, trie.plan_device_arrays()["slot_of"].long()], rows)
+            half = trie.masses_from_logits(xd, lse, logit_scale=0.5)
+            assert torch.equal(half, old.masses_from_logits(xd, lse, logit_scale=0.5))
+
+
 def test_async_trie_batches_concurrent_requests(engine, oracle):
     """AsyncTokenByteTrie (trie/async_impl.py counterpart): 40 coroutines asking for sums and 9 for maxima are served by
     one device batch each, every caller gets its own row, bit for bit what the batched call gives; a bad request fails

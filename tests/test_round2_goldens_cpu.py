@@ -261,3 +261,72 @@ def test_trie_accepts_plain_iterables_and_refuses_duplicates():
             TokenByteTrie([b"hello", b"world", b"hello"])
     with pytest.raises(ValueError, match="Duplicate word in vocabulary"):
         TokenByteTrie([Token(0, b"test"), Token(1, b"other"), Token(0, b"test")])
+
+
+def _run_plan(pl, ws, op):
+    """What glb_trie_rows does with a plan (glb_trie.hip), in numpy: per part the leaves, then depth by depth - children
+    consecutive, ascending, in double, stored as float32 -, then the top from the parts' roots.  Returns [B, n_nodes]."""
+    B = ws.shape[0]
+    out = np.full((B, pl["n_nodes"]), np.nan, np.float32)
+    cut = np.full((B, max(pl["n_cut"], 1)), np.nan, np.float32)
+    parts = list(range(pl["n_parts"])) + ([pl["n_parts"]] if pl["n_top"] else [])
+    for p in parts:
+        d = pl["desc"][p]
+        top = p == pl["n_parts"]
+        n_local, n_roots, n_depths = int(d[1]), int(d[2]), int(d[3])
+        ds = pl["depth_start"][d[4]:d[4] + n_depths + 1]
+        assert d[5] % 2 == 0 and d[11] % 2 == 0  # (the kernel copies the 16-bit tables word by word)
+        cp = pl["cptr16"][d[5]:d[5] + n_local + 1].astype(np.int64)
+        ins = pl["inode16"][d[11]:d[11] + d[12]].astype(np.int64)
+        idp = pl["idepth"][d[13]:d[13] + n_depths + 1]
+        src, loc = pl["leaf_src"][d[6]:d[6] + d[7]], pl["leaf_local"][d[6]:d[6] + d[7]]
+        assert ds[0] == 0 and ds[-1] == n_local and cp[-1] == n_local and (np.diff(cp) >= 0).all()
+        assert idp[0] == 0 and idp[-1] == len(ins) == int((np.diff(cp) > 0).sum()) and len(set(ins)) == len(ins)
+        assert pl["lds_bytes"] >= 4 * n_local + 2 * (n_local + 1) + 2 * len(ins)
+        for r in range(B):
+            val = np.full(n_local, np.nan, np.float32)
+            val[loc] = cut[r, src] if top else ws[r, src]
+            for k in range(n_depths - 2, -1, -1):
+                for s in ins[idp[k]:idp[k + 1]]:
+                    assert ds[k] <= s < ds[k + 1] and cp[s] >= ds[k + 1] and cp[s + 1] <= ds[k + 2]  # children sit one depth down
+                    acc = 0.0
+                    for v in val[cp[s]:cp[s + 1]].astype(np.float64):
+                        acc = acc + v if op == 0 else max(acc, v)
+                    val[s] = np.float32(acc)
+            assert not np.isnan(val).any()
+            nd, nl = pl["pn_node"][d[9]:d[9] + d[10]], pl["pn_local"][d[9]:d[9] + d[10]]
+            out[r, nd] = val[nl]
+            if not top:
+                cut[r, d[8]:d[8] + n_roots] = val[:n_roots]
+    return out
+
+
+@pytest.mark.parametrize("cap", [40, 300, 20000])
+def test_trie_plan_gives_the_reference_masses(gold, oracle, cap):
+    """TokenByteTrie.plan (the folded trie cut into LDS-sized parts for glb_trie_rows): every node's value lands in
+    exactly one part, a node's children are consecutive and one depth down, and the planned arithmetic equals the
+    oracle's level-synchronous loop bit for bit - with a cut below the root (small caps) and without one."""
+    from genlm_backend_amd.tokenization import Token
+    from genlm_backend_amd.trie import TokenByteTrie
+
+    rs = np.random.default_rng(5)
+    words, seen = [], set()
+    while len(words) < 1200:
+        w = bytes(rs.integers(97, 103, int(rs.integers(1, 7))).astype(np.uint8))
+        if w not in seen:
+            seen.add(w)
+            words.append(w)
+    for vocab in (words, _words(gold, "kat")):
+        trie = TokenByteTrie([Token(i, w) for i, w in enumerate(vocab)])
+        pl = trie.plan(cap)
+        if pl is None:  # (a node with more children than a part holds: the level-synchronous kernels serve such a trie)
+            assert cap == 40
+            continue
+        assert pl["max_local"] <= cap and pl["n_slots"] == trie.compact()["n_nodes"]
+        assert (pl["n_top"] == 0) == (pl["n_slots"] <= cap)
+        assert sorted(pl["slot_of"][np.unique(pl["slot_of"], return_index=True)[1]]) == list(range(pl["n_slots"]))
+        assert np.array_equal(np.sort(np.concatenate([pl["pn_node"]])), np.arange(len(trie)))
+        ws = rs.random((3, len(vocab))).astype(np.float32)
+        for op in (0, 1):
+            got = _run_plan(pl, ws, op)
+            assert np.array_equal(got.view(np.uint32), oracle.trie_reduce(ws, trie.flat(), op).view(np.uint32))

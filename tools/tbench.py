@@ -32,6 +32,30 @@ x = torch.randn((B, len(words)), device=dev) * 3
 _, lse, _ = eng.step(x, rng_mode=0)
 sel = torch.from_numpy(rs.choice(len(trie), 4096, replace=False).astype(np.int32)).to(dev)
 print(f"folded trie: {trie.compact()['n_nodes']} slots, {trie.compact()['n_levels']} levels")
+pl = trie.plan()
+print(f"plan: {pl['n_parts']} parts of at most {pl['max_local']} slots, top of {pl['n_top']} nodes over {pl['n_cut']} subtrees")
+def timed(fn, n=10):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a, b in ev:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    return float(np.median([a.elapsed_time(b) * 1e3 for a, b in ev]))
+# round 4: a row of a part of the trie resident in LDS (glb_trie_rows) against the level-synchronous kernels
+for B in (1, 8, 64, 1024):
+    xb = x[:B].contiguous(); lb = lse[:B].contiguous()
+    for xx, tag in ((xb, "f32"), (xb.to(torch.bfloat16), "bf16")):
+        for name, kw in (("rows", dict(layout="rows")), ("slot_rows", dict(layout="slot_rows")), ("4096 selected nodes", dict(nodes=sel))):
+            res = []
+            for resident in (True, False):
+                trie.resident = resident
+                if name == "slot_rows" and not resident:
+                    res.append(timed(lambda: trie.masses_from_logits(xx, lb, layout="slots")))  # (node-major: the old path's cheapest form)
+                else:
+                    res.append(timed(lambda: trie.masses_from_logits(xx, lb, **kw)))
+            print(f"masses_from_logits {tag} B={B} -> {name}: in LDS {res[0]:9.1f} us   level kernels {res[1]:9.1f} us", flush=True)
+trie.resident = False
 for B in (1, 8, 64, 1024):
     ws = torch.rand((B, len(words)), device=dev); ws /= ws.sum(-1, keepdim=True)
     for _ in range(3): trie.batch_weight_sum_device(ws)
@@ -43,6 +67,7 @@ for B in (1, 8, 64, 1024):
     t = float(np.median([a.elapsed_time(b) * 1e3 for a, b in ev]))
     print(f"batch_weight_sum_device (folded trie) B={B}: {t:9.1f} us", flush=True)
 B = 1024
+trie.resident = False  # (the level-synchronous kernels, as in rounds 2-3)
 for name, kw in (("rows", dict(layout="rows")), ("nodes (node-major, nothing transposed back)", dict(layout="nodes")),
                  ("slots (node-major over the folded trie)", dict(layout="slots")),
                  ("4096 selected nodes", dict(nodes=sel))):
