@@ -38,6 +38,7 @@ struct TrieRowsParams {
   float scale;
   const int32_t *desc, *idepth, *leaf_src, *leaf_local, *pn_node, *pn_local, *top_local;
   const uint16_t *cptr16, *inode16;
+
   int32_t top_base, n_cut;
   float *cut_vals;  // [n_rows][n_cut]: the values of the parts' subtree roots, the leaves of the top
   float *out_slots;
@@ -53,138 +54,87 @@ struct TrieRowsParams {
 #endif
 };
 
-// TOP: the part above the cut (leaves = the cut roots' values of this row); otherwise block b = (row, part) with the
-// parts of a row on consecutive blocks of the SAME XCD (blocks go round the eight XCDs one by one).
-// LDS: val[n_local] float32, then as 16-bit words (a part has fewer than 65536 slots) the part's child pointers and its
-// internal nodes, depth by depth: the reduction touches no global memory, and a thread gets an INTERNAL node (three
-// slots in four are leaves; dealt by slot, every wave would run a node's loop for a handful of busy lanes - 6.6 us of a
-// workgroup's 17; within a depth the host lists the nodes with the most children first, so the lanes of a wave run
-// loops of about the same length).  Everything that reads an index from global memory and then uses it (token ->
-// weight, node -> output position) is unrolled kU deep with the index loads in front: one memory latency per kU
-// elements instead of one or two per element (a thread handles a dozen leaves and some fifty nodes of the row-major
-// output; one by one that was 25 us per (row, part)).
+// LDS of a part: val[n_local] float32, then as 16-bit words (a part has fewer than 65536 slots) the part's child
+// pointers and its internal nodes, depth by depth: the reduction touches no global memory, and a thread gets an
+// INTERNAL node (three slots in four are leaves; dealt by slot, every wave would run a node's loop for a handful of
+// busy lanes - 6.6 us of a workgroup's 17; within a depth the host lists the nodes with the most children first, so the
+// lanes of a wave run loops of about the same length).  Everything that reads an index from global memory and then uses
+// it (token -> weight, node -> output position) is unrolled kU deep with the index loads in front: one memory latency
+// per kU elements instead of one or two per element.
 constexpr int kU = 8;
 
-template <int DT, bool TOP>
-__global__ __launch_bounds__(kMaxThreads) void trie_rows_kernel(TrieRowsParams p) {
-  extern __shared__ float val[];
-  int r, part;
-  if constexpr (TOP) {
-    r = blockIdx.x;
-    part = p.n_parts;
-  } else {
-    const int b = blockIdx.x, xcd = b & 7, q = b >> 3;
-    part = q % p.n_parts;
-    r = (q / p.n_parts) * 8 + xcd;
-    if (r >= p.n_rows) return;
-  }
-  const int32_t *d = p.desc + part * kDesc;  // workgroup-uniform: scalar loads
-  const int n_local = d[D_N_LOCAL], n_depths = d[D_N_DEPTHS], n_leaves = d[D_N_LEAVES], n_inodes = d[D_N_INODES];
-  const int tid = threadIdx.x, nt = blockDim.x;
-#ifdef GLB_STAMPS
-  uint64_t *st = (!TOP && p.stamps && blockIdx.x < 65536u) ? p.stamps + (int64_t)blockIdx.x * 8 : nullptr;
-  if (st && tid == 0) st[0] = __builtin_amdgcn_s_memrealtime();
-#define GLB_TRIE_STAMP(k) if (st && tid == 0) st[k] = __builtin_amdgcn_s_memrealtime();
-#else
-#define GLB_TRIE_STAMP(k)
-#endif
-  const int cp_words = (n_local + 2) >> 1, in_words = (n_inodes + 1) >> 1;  // 32-bit words of the two 16-bit tables
-  uint32_t *tab = reinterpret_cast<uint32_t *>(val + n_local);
-  const uint16_t *cp16 = reinterpret_cast<const uint16_t *>(tab), *in16 = reinterpret_cast<const uint16_t *>(tab + cp_words);
-  // ---- leaves: indices first, then the weights they name, then LDS
-  {
-    const int32_t *src = p.leaf_src + d[D_LEAF_OFF], *loc = p.leaf_local + d[D_LEAF_OFF];
-    const float *cv = TOP ? p.cut_vals + (int64_t)r * p.n_cut : nullptr;
-    const float lse = (!TOP && p.lse) ? p.lse[r] : 0.0f;
-    const int64_t row = (int64_t)r * p.ld;
-    for (int i0 = tid; i0 < n_leaves; i0 += nt * kU) {
-      int sj[kU], lj[kU];
-      float w[kU];
+struct PartView {  // one part as the workgroup sees it
+  const int32_t *d;  // its descriptor (workgroup-uniform: scalar loads)
+  int n_local, n_depths, n_leaves, n_inodes, cp_words, in_words;
+  __device__ explicit PartView(const int32_t *desc)
+      : d(desc), n_local(desc[D_N_LOCAL]), n_depths(desc[D_N_DEPTHS]), n_leaves(desc[D_N_LEAVES]), n_inodes(desc[D_N_INODES]),
+        cp_words((desc[D_N_LOCAL] + 2) >> 1), in_words((desc[D_N_INODES] + 1) >> 1) {}  // 32-bit words of the two 16-bit tables
+};
+
+// The part's tables: child pointers and internal nodes (two 16-bit entries a word; both start on a word in global
+// memory), then the depth table (n_depths + 1 words; the plan keeps n_depths <= 30 and counts 32 words for it) - one run
+// of words in LDS behind the values.
+__device__ __forceinline__ uint32_t part_table_word(const TrieRowsParams &p, const PartView &v, int i) {
+  const uint32_t *g = reinterpret_cast<const uint32_t *>(p.cptr16 + v.d[D_CPTR_OFF]);
+  const uint32_t *gi = reinterpret_cast<const uint32_t *>(p.inode16 + v.d[D_INODE_OFF]);
+  const uint32_t *gd = reinterpret_cast<const uint32_t *>(p.idepth + v.d[D_IDEPTH_OFF]);
+  const int a = v.cp_words, b = a + v.in_words;
+  const uint32_t *q = i < a ? g + i : (i < b ? gi + (i - a) : gd + (i - b));
+  return *q;
+}
+
+// depth by depth, deepest first: a thread per internal node, its children consecutive in LDS, added in ascending order
+// in double, the node stored as float32.  Ends on a barrier.
+__device__ __forceinline__ void part_reduce(const TrieRowsParams &p, const PartView &v, float *val, const uint32_t *tab, int tid, int nt) {
+  const uint16_t *cp16 = reinterpret_cast<const uint16_t *>(tab), *in16 = reinterpret_cast<const uint16_t *>(tab + v.cp_words);
+  const uint32_t *idp = tab + v.cp_words + v.in_words;  // (in LDS: a scalar load from global memory per depth cost the workgroup a memory latency each)
+  for (int k = v.n_depths - 2; k >= 0; --k) {  // (the deepest depth holds leaves only)
+    const int lo = idp[k], hi = idp[k + 1];
+    for (int i = lo + tid; i < hi; i += nt) {
+      const int s = in16[i], c0 = cp16[s], c1 = cp16[s + 1];
+      double acc = 0.0;
+      if (p.op == GLB_TRIE_SUM) {
+        int c = c0;
+        for (; c + 8 <= c1; c += 8) {  // eight loads in flight; added one by one in ascending order all the same
+          float x[8];
 #pragma unroll
-      for (int j = 0; j < kU; ++j) {
-        const int i = i0 + j * nt;
-        const bool ok = i < n_leaves;
-        sj[j] = ok ? src[i] : -1;
-        lj[j] = ok ? loc[i] : 0;
-      }
+          for (int j = 0; j < 8; ++j) x[j] = val[c + j];
 #pragma unroll
-      for (int j = 0; j < kU; ++j) {
-        if (sj[j] >= 0) {
-          if constexpr (TOP) w[j] = cv[sj[j]];
-          else w[j] = glb::trie_weight<DT>(p.ws, row + sj[j], p.from_logprobs, p.scale, lse);
+          for (int j = 0; j < 8; ++j) acc += (double)x[j];
         }
-      }
+        if (c < c1) {
+          float x[8];
 #pragma unroll
-      for (int j = 0; j < kU; ++j)
-        if (sj[j] >= 0) val[lj[j]] = w[j];
-    }
-  }
-  // ---- the part's tables into LDS (two 16-bit entries a word; both tables start on a word in global memory)
-  {
-    const uint32_t *g = reinterpret_cast<const uint32_t *>(p.cptr16 + d[D_CPTR_OFF]);
-    for (int i0 = tid; i0 < cp_words; i0 += nt * kU) {
-      uint32_t t[kU];
+          for (int j = 0; j < 7; ++j) x[j] = val[c + j < c1 ? c + j : c];
 #pragma unroll
-      for (int j = 0; j < kU; ++j) t[j] = i0 + j * nt < cp_words ? g[i0 + j * nt] : 0u;
-#pragma unroll
-      for (int j = 0; j < kU; ++j)
-        if (i0 + j * nt < cp_words) tab[i0 + j * nt] = t[j];
-    }
-    const uint32_t *gi = reinterpret_cast<const uint32_t *>(p.inode16 + d[D_INODE_OFF]);
-    for (int i0 = tid; i0 < in_words; i0 += nt * 4) {
-      uint32_t t[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) t[j] = i0 + j * nt < in_words ? gi[i0 + j * nt] : 0u;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (i0 + j * nt < in_words) tab[cp_words + i0 + j * nt] = t[j];
-    }
-  }
-  GLB_TRIE_STAMP(1)
-  __syncthreads();
-  GLB_TRIE_STAMP(2)
-  // ---- depth by depth, deepest first: a thread per internal node, its children consecutive in LDS
-  {
-    const int32_t *idp = p.idepth + d[D_IDEPTH_OFF];
-    for (int k = n_depths - 2; k >= 0; --k) {  // (the deepest depth holds leaves only)
-      const int lo = idp[k], hi = idp[k + 1];
-      for (int i = lo + tid; i < hi; i += nt) {
-        const int s = in16[i], c0 = cp16[s], c1 = cp16[s + 1];
-        double acc = 0.0;
-        if (p.op == GLB_TRIE_SUM) {
-          int c = c0;
-          for (; c + 4 <= c1; c += 4) {  // four loads in flight; added one by one in ascending order all the same
-            const float v0 = val[c], v1 = val[c + 1], v2 = val[c + 2], v3 = val[c + 3];
-            acc += (double)v0;
-            acc += (double)v1;
-            acc += (double)v2;
-            acc += (double)v3;
-          }
-          for (; c < c1; ++c) acc += (double)val[c];
-        } else {
-          for (int c = c0; c < c1; ++c) acc = fmax(acc, (double)val[c]);
+          for (int j = 0; j < 7; ++j)
+            if (c + j < c1) acc += (double)x[j];
         }
-        val[s] = (float)acc;
+      } else {
+        for (int c = c0; c < c1; ++c) acc = fmax(acc, (double)val[c]);
       }
-      __syncthreads();
+      val[s] = (float)acc;
     }
+    __syncthreads();
   }
-  GLB_TRIE_STAMP(3)
-  // ---- outputs
+}
+
+// the part's values out: its run of the slot-major row, the trie nodes it holds, the selected nodes that are its own
+__device__ __forceinline__ void part_write(const TrieRowsParams &p, const PartView &v, const float *val, bool top, int r, int tid, int nt) {
   if (p.out_slots) {
     float *o = p.out_slots + (int64_t)r * p.out_slots_ld;
-    if constexpr (TOP) {
-      const int n_top = n_local - n_leaves;
+    if (top) {
+      const int n_top = v.n_local - v.n_leaves;
       for (int i = tid; i < n_top; i += nt) o[p.top_base + i] = val[p.top_local[i]];
     } else {
-      o += d[D_SLOT_BASE];
-      for (int i = tid; i < n_local; i += nt) o[i] = val[i];
+      o += v.d[D_SLOT_BASE];
+      for (int i = tid; i < v.n_local; i += nt) o[i] = val[i];
     }
   }
   if (p.out_nodes) {
     float *o = p.out_nodes + (int64_t)r * p.out_nodes_ld;
-    const int32_t *nd = p.pn_node + d[D_NODE_OFF], *nl = p.pn_local + d[D_NODE_OFF];
-    const int n = d[D_N_NODES];
+    const int32_t *nd = p.pn_node + v.d[D_NODE_OFF], *nl = p.pn_local + v.d[D_NODE_OFF];
+    const int n = v.d[D_N_NODES];
     for (int i0 = tid; i0 < n; i0 += nt * kU) {
       int nj[kU], lj[kU];
 #pragma unroll
@@ -201,7 +151,7 @@ __global__ __launch_bounds__(kMaxThreads) void trie_rows_kernel(TrieRowsParams p
   }
   if (p.out_sel) {
     float *o = p.out_sel + (int64_t)r * p.out_sel_ld;
-    const int base = d[D_SLOT_BASE];
+    const int base = v.d[D_SLOT_BASE];
     for (int j0 = tid; j0 < p.n_sel; j0 += nt * 4) {
       int sl[4];
 #pragma unroll
@@ -212,18 +162,102 @@ __global__ __launch_bounds__(kMaxThreads) void trie_rows_kernel(TrieRowsParams p
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int jj = j0 + j * nt, s = sl[j];
-        if constexpr (TOP) {
+        if (top) {
           if (s >= base) o[jj] = val[p.top_local[s - base]];
         } else {
-          if (s >= base && s < base + n_local) o[jj] = val[s - base];
+          if (s >= base && s < base + v.n_local) o[jj] = val[s - base];
         }
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// (row, part) per workgroup.  TOP: the part above the cut (leaves = the cut roots' values of the row, a second launch);
+// otherwise block b = (row, part) with the parts of a row on consecutive blocks of the SAME XCD (blocks go round the
+// eight XCDs one by one): the row comes from HBM once and from that XCD's L2 for its other parts.
+// Measured and not kept (tools/dbg/stamps_trie.py, 1024 x 50257, profiles/r04/stamps_trie_*): the whole row in a
+// workgroup's registers and the parts through its LDS one after the other (one workgroup a CU, every latency exposed:
+// 79 us a row); a part reading the whole row in one coalesced sweep and picking its tokens by a mask (more trips to
+// memory than the gathers: 14 against 8-10 us); two rows a workgroup sharing tables, indices and the reduction (the
+// values of two rows halve the workgroups a CU holds: 257 against 206 us).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int DT, bool TOP, int kL>  // kL: leaves (and table words) a thread has in flight
+__global__ __launch_bounds__(kMaxThreads) void trie_rows_kernel(TrieRowsParams p) {
+  extern __shared__ float val[];
+  int r, part;
+  if constexpr (TOP) {
+    r = blockIdx.x;
+    part = p.n_parts;
+  } else {
+    const int b = blockIdx.x, xcd = b & 7, q = b >> 3;
+    part = q % p.n_parts;
+    r = (q / p.n_parts) * 8 + xcd;
+    if (r >= p.n_rows) return;
+  }
+  const PartView v(p.desc + part * kDesc);
+  const int tid = threadIdx.x, nt = blockDim.x;
+#ifdef GLB_STAMPS
+  uint64_t *st = (!TOP && p.stamps && blockIdx.x < 65536u) ? p.stamps + (int64_t)blockIdx.x * 8 : nullptr;
+  if (st && tid == 0) st[0] = __builtin_amdgcn_s_memrealtime();
+#define GLB_TRIE_STAMP(k) if (st && tid == 0) st[k] = __builtin_amdgcn_s_memrealtime();
+#else
+#define GLB_TRIE_STAMP(k)
+#endif
+  uint32_t *tab = reinterpret_cast<uint32_t *>(val + v.n_local);
+  // ---- tables and leaves, two memory latencies in all: the table words and the leaves' indices (token, local slot) go
+  // out together; the weights the indices name follow; the table words go to LDS while those are on their way.  (One
+  // leaf at a time and the tables behind them, a workgroup spent 8-10 of its 17 us here: every trip to memory takes
+  // 1.5-2.5 us with the chip full of these workgroups.)
+  {
+    constexpr int kT = kL;
+    const int tot_words = v.cp_words + v.in_words + v.n_depths + 1;
+    uint32_t tw[kT];
+#pragma unroll
+    for (int j = 0; j < kT; ++j) tw[j] = tid + j * nt < tot_words ? part_table_word(p, v, tid + j * nt) : 0u;
+    const int32_t *src = p.leaf_src + v.d[D_LEAF_OFF], *loc = p.leaf_local + v.d[D_LEAF_OFF];
+    const float *cv = TOP ? p.cut_vals + (int64_t)r * p.n_cut : nullptr;
+    const float lse = (!TOP && p.lse) ? p.lse[r] : 0.0f;
+    const int64_t row = (int64_t)r * p.ld;
+    for (int i0 = tid; i0 < v.n_leaves || i0 == tid; i0 += nt * kL) {
+      int sj[kL], lj[kL];
+      float w[kL];
+#pragma unroll
+      for (int j = 0; j < kL; ++j) {
+        const int i = i0 + j * nt;
+        const bool ok = i < v.n_leaves;
+        sj[j] = ok ? src[i] : -1;
+        lj[j] = ok ? loc[i] : 0;
+      }
+#pragma unroll
+      for (int j = 0; j < kL; ++j) {
+        w[j] = 0.0f;
+        if (sj[j] >= 0) {
+          if constexpr (TOP) w[j] = cv[sj[j]];
+          else w[j] = glb::trie_weight_load<DT>(p.ws, row + sj[j]);
+        }
+      }
+      if (i0 == tid) {  // (first trip: the table words have arrived with the indices)
+#pragma unroll
+        for (int j = 0; j < kT; ++j)
+          if (tid + j * nt < tot_words) tab[tid + j * nt] = tw[j];
+        for (int i = tid + kT * nt; i < tot_words; i += nt) tab[i] = part_table_word(p, v, i);  // (a part too big for kT words a thread)
+      }
+#pragma unroll
+      for (int j = 0; j < kL; ++j)
+        if (sj[j] >= 0) val[lj[j]] = TOP ? w[j] : glb::trie_weight_value(w[j], p.from_logprobs, p.scale, lse);
+    }
+  }
+  GLB_TRIE_STAMP(1)
+  __syncthreads();
+  GLB_TRIE_STAMP(2)
+  part_reduce(p, v, val, tab, tid, nt);
+  GLB_TRIE_STAMP(3)
+  part_write(p, v, val, TOP, r, tid, nt);
   if constexpr (!TOP) {
     if (p.cut_vals) {
-      float *cv = p.cut_vals + (int64_t)r * p.n_cut + d[D_CUT_BASE];
-      const int n_roots = d[D_N_ROOTS];
+      float *cv = p.cut_vals + (int64_t)r * p.n_cut + v.d[D_CUT_BASE];
+      const int n_roots = v.d[D_N_ROOTS];
       for (int i = tid; i < n_roots; i += nt) cv[i] = val[i];
     }
   }
@@ -240,19 +274,26 @@ __global__ void trie_sel_slots_kernel(const int32_t *sel, int32_t n_sel, const i
   if (j < n_sel) sel_slot[j] = slot_of[sel[j]];
 }
 
-template <int DT>
-hipError_t launch_rows(const TrieRowsParams &p, int n_top, size_t lds, int threads, hipStream_t s) {
+template <int DT, int kL>
+hipError_t launch_rows1(const TrieRowsParams &p, int n_top, size_t lds, int threads, hipStream_t s) {
   static bool big_lds_set = false;  // (more than 64 KB of dynamic LDS has to be asked for, once per kernel)
   if (!big_lds_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)trie_rows_kernel<DT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)trie_rows_kernel<DT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void *)trie_rows_kernel<DT, false, kL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)trie_rows_kernel<DT, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     big_lds_set = true;
   }
   const unsigned blocks = (unsigned)(((int64_t)p.n_rows + 7) / 8 * 8 * p.n_parts);
-  hipLaunchKernelGGL((trie_rows_kernel<DT, false>), dim3(blocks), dim3(threads), lds, s, p);
-  if (n_top > 0) hipLaunchKernelGGL((trie_rows_kernel<DT, true>), dim3((unsigned)p.n_rows), dim3(256), lds, s, p);
+  hipLaunchKernelGGL((trie_rows_kernel<DT, false, kL>), dim3(blocks), dim3(threads), lds, s, p);
+  if (n_top > 0) hipLaunchKernelGGL((trie_rows_kernel<DT, true, 8>), dim3((unsigned)p.n_rows), dim3(256), lds, s, p);
   return hipGetLastError();
+}
+
+// deep: sixteen leaves a thread in flight (93 registers: two 512-thread workgroups a CU, what parts of 80 KB allow
+// anyway); otherwise eight (53 registers: four)
+template <int DT>
+hipError_t launch_rows(const TrieRowsParams &p, int n_top, size_t lds, int threads, bool deep, hipStream_t s) {
+  return deep ? launch_rows1<DT, 16>(p, n_top, lds, threads, s) : launch_rows1<DT, 8>(p, n_top, lds, threads, s);
 }
 
 }  // namespace
@@ -336,18 +377,20 @@ int glb_trie_rows(const glb_trie_rows_args *a, const glb_trie_plan *pl, void *st
   if (p.out_sel)
     hipLaunchKernelGGL(trie_sel_slots_kernel, dim3((unsigned)((p.n_sel + 255) / 256)), dim3(256), 0, s, a->sel_nodes, p.n_sel,
                        pl->slot_of, (int32_t *)p.sel_slot);
-  // threads per workgroup: as many workgroups as the LDS lets a CU hold (at most 2048 threads a CU)
-  int threads = 1024;
-  if (lds * 4 <= 160 * 1024) threads = 512;
+  // threads per workgroup: as many workgroups as the LDS lets a CU hold.  (1024-thread workgroups were never seen two to
+  // a CU, whatever their LDS - tools/dbg/stamps_trie.py; 512-thread ones are.)
+  int threads = 512;
   if (lds * 8 <= 160 * 1024) threads = 256;
+  bool deep = lds * 3 > 160 * 1024;
 #ifdef GLB_STAMPS
-  if (const char *e = getenv("GLB_TRIE_THREADS")) threads = atoi(e);
+  if (const char *ev = getenv("GLB_TRIE_THREADS")) threads = atoi(ev);
+  if (const char *ev = getenv("GLB_TRIE_DEEP")) deep = atoi(ev) != 0;
 #endif
   hipError_t e;
   switch (a->dtype) {
-    case GLB_F32: e = launch_rows<GLB_F32>(p, pl->n_top, lds, threads, s); break;
-    case GLB_BF16: e = launch_rows<GLB_BF16>(p, pl->n_top, lds, threads, s); break;
-    default: e = launch_rows<GLB_F16>(p, pl->n_top, lds, threads, s); break;
+    case GLB_F32: e = launch_rows<GLB_F32>(p, pl->n_top, lds, threads, deep, s); break;
+    case GLB_BF16: e = launch_rows<GLB_BF16>(p, pl->n_top, lds, threads, deep, s); break;
+    default: e = launch_rows<GLB_F16>(p, pl->n_top, lds, threads, deep, s); break;
   }
   if (e != hipSuccess) return glb::api_hip_fail(e, "glb_trie_rows launch");
   return GLB_OK;

@@ -157,7 +157,8 @@ class TokenByteTrie:
                                  slot_of=slot_of.astype(np.int32))
         return self._compact
 
-    PLAN_CAP = 12000  # slots per part: ~6.5 bytes of LDS a slot (value, child pointer, list of internal nodes) = 78 KB, two workgroups a CU
+    PLAN_CAP = 9500  # slots per part: ~6.5 bytes of LDS a slot (value, child pointer, list of internal nodes); three 512-thread workgroups a CU
+    # (tools/dbg/stamps_trie.py at 1024 x 50257: parts of <= 5267 / 7875 / 10481 / 23440 slots: 232 / 206 / 225 / 225 us)
 
     def plan(self, cap=None):
         """The folded trie (`compact()`) cut for glb_trie_rows, which keeps ONE ROW's values of a part of the trie in
@@ -309,7 +310,10 @@ class TokenByteTrie:
             desc[p, 11], desc[p, 12], desc[p, 13] = sum(len(x) for x in inode16), len(ins), sum(len(x) for x in idepth)
             inode16.append(np.concatenate([ins, np.zeros(len(ins) & 1, np.int64)]))
             idepth.append(idp)
-            lds_bytes = max(lds_bytes, 4 * int(desc[p, 1]) + 2 * len(cptr16[-1]) + 2 * len(inode16[-1]))
+            if len(idp) > 31:  # (the kernel keeps a part's depth table in 32 words of LDS)
+                self._plan = (cap, None)
+                return None
+            lds_bytes = max(lds_bytes, 4 * int(desc[p, 1]) + 2 * len(cptr16[-1]) + 2 * len(inode16[-1]) + 4 * 32)
         cat16 = lambda xs: (np.concatenate(xs) if xs else np.zeros(0, np.int64)).astype(np.uint16)
         plan = dict(n_parts=n_parts, n_top=n_top, n_slots=n_slots, n_cut=len(cut), cap=cap, vocab=len(self.decode),
                     n_nodes=len(self.children), max_local=int(desc[:, 1].max()), top_base=slot_base,
@@ -330,7 +334,8 @@ class TokenByteTrie:
             if self.engine is None:
                 raise RuntimeError("TokenByteTrie needs a HipEngine to compute masses (there is no CPU path)")
             dev = self.engine.device
-            self._pdev = (pl["cap"], {k: (torch.from_numpy(v.view(np.int16) if v.dtype == np.uint16 else v).to(dev)
+            signed = {np.dtype(np.uint16): np.int16, np.dtype(np.uint32): np.int32, np.dtype(np.uint64): np.int64}
+            self._pdev = (pl["cap"], {k: (torch.from_numpy(v.view(signed.get(v.dtype, v.dtype))).to(dev)
                                           if isinstance(v, np.ndarray) else v) for k, v in pl.items()})
         return self._pdev[1]
 

@@ -494,6 +494,7 @@ int glb_trie_masses(const glb_trie_args *args, void *hip_stream);
  *   pn_node / pn_local [node_off ..+ n_nodes]: the trie nodes whose value a local slot of the part holds
  *   top_local [n_top]: local slot of top slot top_base + i;  slot_of [n_nodes]: node -> slot (parts first, top last)
  *   lds_bytes: the largest part's 4 n_local + 2 (n_local + 1, rounded up to even) + 2 (n_inodes, rounded up to even)
+ *        + 128 (its depth table: n_depths <= 30)
  * Same arithmetic per node as glb_trie_reduce (children in ascending order, accumulated in double, stored as float32),
  * so the results are bit-equal to glb_trie_masses on the same folded trie.
  * Outputs (any subset): out_slots [n_rows, n_slots] in the plan's slot numbering; out_nodes [n_rows, n_nodes];

@@ -666,9 +666,9 @@ def test_trie_masses_from_logits(engine, oracle):
 @pytest.mark.parametrize("cap", [250, 700, 20000])
 def test_trie_rows_in_lds_equal_the_level_kernels_and_the_oracle(engine, oracle, cap):
     """glb_trie_rows (one row of a part of the trie resident in LDS; trie.plan cuts the folded trie into parts of at most
-    `cap` slots - several parts and a top for the small caps, one part for the big one): every node, selected nodes and
-    the slot-major form hold the oracle's bits for weights (sum and max, fp32 and bf16, 1 / 9 / 70 rows) and the
-    level-synchronous kernels' bits for masses straight from logits + lse."""
+    `cap` slots - several parts and a top for the small caps, one part for the big one): every node,
+    selected nodes and the slot-major form hold the oracle's bits for weights (sum and max, fp32 and bf16, 1 / 9 / 70 rows)
+    and the level-synchronous kernels' bits for masses straight from logits + lse."""
     from genlm_backend_amd.tokenization import Token
     from genlm_backend_amd.trie import TokenByteTrie
 

@@ -282,7 +282,7 @@ def _run_plan(pl, ws, op):
         src, loc = pl["leaf_src"][d[6]:d[6] + d[7]], pl["leaf_local"][d[6]:d[6] + d[7]]
         assert ds[0] == 0 and ds[-1] == n_local and cp[-1] == n_local and (np.diff(cp) >= 0).all()
         assert idp[0] == 0 and idp[-1] == len(ins) == int((np.diff(cp) > 0).sum()) and len(set(ins)) == len(ins)
-        assert pl["lds_bytes"] >= 4 * n_local + 2 * (n_local + 1) + 2 * len(ins)
+        assert pl["lds_bytes"] >= 4 * n_local + 2 * (n_local + 1) + 2 * len(ins) + 4 * (n_depths + 1) and n_depths <= 30
         for r in range(B):
             val = np.full(n_local, np.nan, np.float32)
             val[loc] = cut[r, src] if top else ws[r, src]
