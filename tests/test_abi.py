@@ -25,6 +25,8 @@ def test_library_exports_every_declared_symbol():
     assert lib.glb_abi_version() == 6
     assert b"gfx950" in lib.glb_version()
     assert C.sizeof(_lib.StepArgs) == 224  # layout guard of glb_step_args
+    # ... and of the other argument blocks (sizeof in C, include/glb.h compiled with gcc: 264 / 200 / 120 / 152)
+    assert (C.sizeof(_lib.KvPlanArgs), C.sizeof(_lib.TrieArgs), C.sizeof(_lib.TriePlan), C.sizeof(_lib.TrieRowsArgs)) == (264, 200, 120, 152)
 
 
 def test_argument_errors_do_not_touch_the_gpu():
@@ -45,6 +47,13 @@ def test_argument_errors_do_not_touch_the_gpu():
     assert lib.glb_step_workspace_bytes(1024, 1024, 50257, 2) >= 1024 * 13 * 32
     assert lib.glb_mask_prepared_bytes(2, 50257) >= 2 * 13 * 512
     assert lib.glb_log_softmax_workspace_bytes(8, 50257) >= 8 * 13 * 32
+    ta, tp = _lib.TrieRowsArgs(), _lib.TriePlan()
+    assert lib.glb_trie_rows(None, None, None) == _lib.GLB_EINVAL
+    assert lib.glb_trie_rows(C.byref(ta), C.byref(tp), None) == _lib.GLB_EINVAL and "struct_size" in _lib.last_error()
+    ta.struct_size, tp.struct_size = C.sizeof(_lib.TrieRowsArgs), C.sizeof(_lib.TriePlan)
+    ta.n_rows = 1
+    assert lib.glb_trie_rows(C.byref(ta), C.byref(tp), None) == _lib.GLB_EINVAL  # no weights
+    assert lib.glb_trie_rows_workspace(0, C.byref(tp)) == 0 and lib.glb_trie_rows_workspace(4, C.byref(tp)) >= 4 << 20
     assert lib.glb_group_contexts(None, None, None, 4, None, None, None, None, None, 0, None) == _lib.GLB_EINVAL
     assert lib.glb_group_contexts_workspace(1024) >= 1024 * 4 * 4
 
