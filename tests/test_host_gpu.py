@@ -710,6 +710,37 @@ def test_trie_rows_in_lds_equal_the_level_kernels_and_the_oracle(engine, oracle,
             assert torch.equal(half, old.masses_from_logits(xd, lse, logit_scale=0.5))
 
 
+def test_trie_rows_at_llama_vocabulary_size(engine, oracle):
+    """128 256 synthetic tokens (config 5's vocabulary size; 159 k slots in 26 parts + the root): weights == the oracle bit
+    for bit, masses from bf16 logits + lse == the level-synchronous kernels' bits, selected nodes == columns of the rows."""
+    from genlm_backend_amd.tokenization import Token
+    from genlm_backend_amd.trie import TokenByteTrie
+
+    rs = np.random.default_rng(1)
+    words, seen = [], set()
+    while len(words) < 128256:
+        w = bytes(rs.integers(97, 123, int(rs.integers(1, 10))).astype(np.uint8))
+        if w not in seen:
+            seen.add(w)
+            words.append(w)
+    trie = TokenByteTrie([Token(i, w) for i, w in enumerate(words)], engine=engine)
+    pl = trie.plan()
+    assert pl is not None and pl["n_parts"] > 8 and pl["n_top"] >= 1
+    dev = engine.device
+    w = rs.random((3, len(words))).astype(np.float32)
+    got = trie.batch_weight_sum(torch.from_numpy(w))
+    assert np.array_equal(got.view(np.uint32), oracle.trie_reduce(w, trie.flat(), 0).view(np.uint32))
+    x = (torch.randn((40, len(words)), device=dev) * 3).to(torch.bfloat16)
+    _, lse, _ = engine.step(x, rng_mode=0)
+    rows = trie.masses_from_logits(x, lse)
+    trie.resident = False
+    assert torch.equal(rows, trie.masses_from_logits(x, lse))
+    trie.resident = True
+    sel = torch.from_numpy(rs.choice(len(trie), 1000, replace=False).astype(np.int32)).to(dev)
+    assert torch.equal(trie.masses_from_logits(x, lse, nodes=sel), rows[:, sel.long()])
+    assert (rows[:, trie.root] - 1.0).abs().max().item() < 1e-3  # (bf16 logits against a float32 lse of the same values)
+
+
 def test_async_trie_batches_concurrent_requests(engine, oracle):
     """AsyncTokenByteTrie (trie/async_impl.py counterpart): 40 coroutines asking for sums and 9 for maxima are served by
     one device batch each, every caller gets its own row, bit for bit what the batched call gives; a bad request fails

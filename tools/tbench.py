@@ -80,3 +80,24 @@ for name, kw in (("rows", dict(layout="rows")), ("nodes (node-major, nothing tra
         torch.cuda.synchronize()
         t = float(np.median([a.elapsed_time(b) * 1e3 for a, b in ev]))
         print(f"masses_from_logits {tag} B={B} -> {name}: {t:9.1f} us", flush=True)
+
+# config 5's vocabulary size: 128 256 synthetic tokens, 512 rows of bf16 logits
+words2, seen2 = [], set()
+while len(words2) < 128256:
+    w = bytes(rs.integers(97, 123, int(rs.integers(1, 10))).astype(np.uint8))
+    if w not in seen2: seen2.add(w); words2.append(w)
+trie2 = TokenByteTrie([Token(i, w) for i, w in enumerate(words2)], engine=eng)
+pl2 = trie2.plan()
+print(f"128256 tokens: {len(trie2)} nodes, {pl2['n_slots']} slots, plan: {pl2['n_parts']} parts of at most {pl2['max_local']} slots, top of {pl2['n_top']}")
+x2 = (torch.randn((512, len(words2)), device=dev) * 3).to(torch.bfloat16)
+_, lse2, _ = eng.step(x2, rng_mode=0)
+sel2 = torch.from_numpy(rs.choice(len(trie2), 4096, replace=False).astype(np.int32)).to(dev)
+for name, kw in (("rows", dict(layout="rows")), ("slot_rows", dict(layout="slot_rows")), ("4096 selected nodes", dict(nodes=sel2))):
+    res = []
+    for resident in (True, False):
+        trie2.resident = resident
+        if name == "slot_rows" and not resident:
+            res.append(timed(lambda: trie2.masses_from_logits(x2, lse2, layout="slots"), 5))
+        else:
+            res.append(timed(lambda: trie2.masses_from_logits(x2, lse2, **kw), 5))
+    print(f"masses_from_logits bf16 B=512 V=128256 -> {name}: in LDS {res[0]:9.1f} us   level kernels {res[1]:9.1f} us", flush=True)
