@@ -58,8 +58,8 @@ class StepArgs(C.Structure):
 class TriePlan(C.Structure):
     _fields_ = [("struct_size", C.c_uint32)] + [(k, C.c_int32) for k in ("n_parts", "n_top", "n_cut", "n_slots", "max_local", "top_base",
                                                                           "lds_bytes")] + [
-        ("n_nodes", C.c_int64)] + [(k, C.c_void_p) for k in ("desc", "idepth", "leaf_src", "leaf_local", "pn_node", "pn_local", "top_local",
-                                                             "slot_of", "cptr16", "inode16")]
+        ("n_nodes", C.c_int64)] + [(k, C.c_void_p) for k in ("desc", "idepth", "leaf_src", "leaf_local", "run_tab", "top_local", "slot_of",
+                                                             "cptr16", "inode16", "pn_local16")]
 
 
 class TrieRowsArgs(C.Structure):

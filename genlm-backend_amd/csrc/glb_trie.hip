@@ -27,7 +27,7 @@ namespace {
 
 constexpr int kDesc = 16;  // int32 words per part descriptor (trie.py: plan()["desc"])
 enum { D_SLOT_BASE = 0, D_N_LOCAL, D_N_ROOTS, D_N_DEPTHS, D_DEPTH_OFF, D_CPTR_OFF, D_LEAF_OFF, D_N_LEAVES, D_CUT_BASE, D_NODE_OFF, D_N_NODES,
-       D_INODE_OFF, D_N_INODES, D_IDEPTH_OFF };
+       D_INODE_OFF, D_N_INODES, D_IDEPTH_OFF, D_RUN_OFF, D_N_RUNS };
 constexpr int kMaxThreads = 1024;
 
 struct TrieRowsParams {
@@ -36,8 +36,8 @@ struct TrieRowsParams {
   int32_t n_rows, n_parts, from_logprobs, op;
   const float *lse;
   float scale;
-  const int32_t *desc, *idepth, *leaf_src, *leaf_local, *pn_node, *pn_local, *top_local;
-  const uint16_t *cptr16, *inode16;
+  const int32_t *desc, *idepth, *leaf_src, *leaf_local, *run_tab, *top_local;
+  const uint16_t *cptr16, *inode16, *pn_local16;
 
   int32_t top_base, n_cut;
   float *cut_vals;  // [n_rows][n_cut]: the values of the parts' subtree roots, the leaves of the top
@@ -59,9 +59,8 @@ struct TrieRowsParams {
 // INTERNAL node (three slots in four are leaves; dealt by slot, every wave would run a node's loop for a handful of
 // busy lanes - 6.6 us of a workgroup's 17; within a depth the host lists the nodes with the most children first, so the
 // lanes of a wave run loops of about the same length).  Everything that reads an index from global memory and then uses
-// it (token -> weight, node -> output position) is unrolled kU deep with the index loads in front: one memory latency
-// per kU elements instead of one or two per element.
-constexpr int kU = 8;
+// it (token -> weight, node -> output position) is unrolled with the index loads in front: one memory latency per 4-16
+// elements instead of one or two per element.
 
 struct PartView {  // one part as the workgroup sees it
   const int32_t *d;  // its descriptor (workgroup-uniform: scalar loads)
@@ -128,25 +127,41 @@ __device__ __forceinline__ void part_write(const TrieRowsParams &p, const PartVi
       for (int i = tid; i < n_top; i += nt) o[p.top_base + i] = val[p.top_local[i]];
     } else {
       o += v.d[D_SLOT_BASE];
-      for (int i = tid; i < v.n_local; i += nt) o[i] = val[i];
+      typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));  // (the run of a row starts on any word)
+      typedef float f32x4_t __attribute__((ext_vector_type(4)));
+      const int n4 = v.n_local & ~3;
+      for (int i = 4 * tid; i < n4; i += 4 * nt) *reinterpret_cast<f32x4_u *>(o + i) = *reinterpret_cast<const f32x4_t *>(val + i);
+      for (int i = n4 + tid; i < v.n_local; i += nt) o[i] = val[i];
     }
   }
   if (p.out_nodes) {
+    // the part's nodes are a few runs of consecutive ids (a subtree is an interval of the post-order numbering, the
+    // one-child nodes folded into its root follow it): consecutive stores, one 16-bit local slot read per node
     float *o = p.out_nodes + (int64_t)r * p.out_nodes_ld;
-    const int32_t *nd = p.pn_node + v.d[D_NODE_OFF], *nl = p.pn_local + v.d[D_NODE_OFF];
-    const int n = v.d[D_N_NODES];
-    for (int i0 = tid; i0 < n; i0 += nt * kU) {
-      int nj[kU], lj[kU];
+    const uint16_t *nl = p.pn_local16 + v.d[D_NODE_OFF];
+    const int32_t *runs = p.run_tab + 2 * v.d[D_RUN_OFF];
+    const int n_runs = v.d[D_N_RUNS];
+    typedef uint64_t u64_u __attribute__((aligned(2)));
+    typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+    int at = 0;
+    for (int k = 0; k < n_runs; ++k) {  // (workgroup-uniform)
+      const int lo = runs[2 * k], cnt = runs[2 * k + 1], cnt4 = cnt & ~3;
+      // four nodes a lane: one 8-byte read of local slots, one 16-byte store (1 KB of consecutive output a wave instruction)
+      for (int i0 = 4 * tid; i0 < cnt4; i0 += 4 * nt * 4) {
+        uint64_t q[4];
 #pragma unroll
-      for (int j = 0; j < kU; ++j) {
-        const int i = i0 + j * nt;
-        const bool ok = i < n;
-        nj[j] = ok ? nd[i] : -1;
-        lj[j] = ok ? nl[i] : 0;
+        for (int j = 0; j < 4; ++j) q[j] = i0 + j * 4 * nt < cnt4 ? *reinterpret_cast<const u64_u *>(nl + at + i0 + j * 4 * nt) : 0ull;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int i = i0 + j * 4 * nt;
+          if (i < cnt4) {
+            const f32x4_u x{val[q[j] & 0xffffu], val[(q[j] >> 16) & 0xffffu], val[(q[j] >> 32) & 0xffffu], val[q[j] >> 48]};
+            *reinterpret_cast<f32x4_u *>(o + lo + i) = x;
+          }
+        }
       }
-#pragma unroll
-      for (int j = 0; j < kU; ++j)
-        if (nj[j] >= 0) o[nj[j]] = val[lj[j]];
+      for (int i = cnt4 + tid; i < cnt; i += nt) o[lo + i] = val[nl[at + i]];
+      at += cnt;
     }
   }
   if (p.out_sel) {
@@ -331,7 +346,7 @@ int glb_trie_rows(const glb_trie_rows_args *a, const glb_trie_plan *pl, void *st
   const size_t lds = (size_t)pl->lds_bytes;
   if (pl->lds_bytes < pl->max_local * 6 || lds > 160 * 1024 || pl->max_local >= 65536)
     return api_fail(GLB_EINVAL, "glb_trie_rows: a part of %d slots does not fit the LDS", pl->max_local);
-  if (a->out_nodes && (!pl->pn_node || !pl->pn_local)) return api_fail(GLB_EINVAL, "glb_trie_rows: plan without node lists");
+  if (a->out_nodes && (!pl->run_tab || !pl->pn_local16)) return api_fail(GLB_EINVAL, "glb_trie_rows: plan without node lists");
   if (pl->n_top > 0 && !pl->top_local) return api_fail(GLB_EINVAL, "glb_trie_rows: plan without top_local");
   if ((a->out_slots && a->out_slots_ld < pl->n_slots) || (a->out_nodes && a->out_nodes_ld < pl->n_nodes) ||
       (a->out_sel && a->out_sel_ld < a->n_sel))
@@ -356,8 +371,8 @@ int glb_trie_rows(const glb_trie_rows_args *a, const glb_trie_plan *pl, void *st
   p.inode16 = pl->inode16;
   p.leaf_src = pl->leaf_src;
   p.leaf_local = pl->leaf_local;
-  p.pn_node = pl->pn_node;
-  p.pn_local = pl->pn_local;
+  p.run_tab = pl->run_tab;
+  p.pn_local16 = pl->pn_local16;
   p.top_local = pl->top_local;
   p.top_base = pl->top_base;
   p.n_cut = pl->n_cut;

@@ -612,7 +612,7 @@ class HipEngine:
             pl.struct_size = C.sizeof(TriePlan)
             for k in ("n_parts", "n_top", "n_cut", "n_slots", "max_local", "top_base", "lds_bytes", "n_nodes"):
                 setattr(pl, k, int(plan[k]))
-            for k in ("desc", "idepth", "leaf_src", "leaf_local", "pn_node", "pn_local", "top_local", "slot_of", "cptr16", "inode16"):
+            for k in ("desc", "idepth", "leaf_src", "leaf_local", "run_tab", "top_local", "slot_of", "cptr16", "inode16", "pn_local16"):
                 setattr(pl, k, plan[k].data_ptr())
             plan["_c"] = pl
         a = TrieRowsArgs()

@@ -289,6 +289,15 @@ class TokenByteTrie:
             pn_node.append(nodes)
             pn_local.append(local_of[node_slot[nodes]])
         cat = lambda xs: (np.concatenate([np.asarray(x, np.int64) for x in xs]) if xs else np.zeros(0, np.int64)).astype(np.int32)
+        # a part's nodes are a few runs of consecutive ids (post-order: a subtree is an interval, and the one-child nodes
+        # folded into its root follow it): (first node, count) per run; the local slots as 16-bit words
+        run_tab = []
+        for p in range(n_parts + 1):
+            nd = np.asarray(pn_node[p], np.int64)
+            cuts = np.nonzero(np.diff(nd) != 1)[0] + 1 if len(nd) else np.zeros(0, np.int64)
+            b = np.concatenate([[0], cuts, [len(nd)]]) if len(nd) else np.zeros(1, np.int64)
+            desc[p, 14], desc[p, 15] = len(run_tab), len(b) - 1
+            run_tab.extend((int(nd[b[k]]), int(b[k + 1] - b[k])) for k in range(len(b) - 1))
         # what the kernel keeps in LDS next to the values, as 16-bit words (a part has fewer than 65536 slots): the child
         # pointers, and the part's internal nodes depth by depth (within a depth the nodes with the most children first:
         # the lanes of a wave then run loops of about the same length)
@@ -320,6 +329,7 @@ class TokenByteTrie:
                     lds_bytes=lds_bytes, cptr16=cat16(cptr16), inode16=cat16(inode16), idepth=cat(idepth),
                     desc=desc, depth_start=cat(depth_all), cptr=cat(cptr_all), leaf_src=cat(leaf_src),
                     leaf_local=cat(leaf_local), pn_node=cat(pn_node), pn_local=cat(pn_local),
+                    run_tab=np.asarray(run_tab, np.int32).reshape(-1, 2), pn_local16=cat(pn_local).astype(np.uint16),
                     top_local=toplocal.astype(np.int32), slot_of=slot_of_new.astype(np.int32),
                     slot_compact=np.argsort(new_slot).astype(np.int32))  # new slot -> compact() slot
         self._plan = (cap, plan)

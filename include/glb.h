@@ -483,15 +483,17 @@ int glb_trie_masses(const glb_trie_args *args, void *hip_stream);
  * most 160 KB / 6 slots (a slot takes a float32 value and a 16-bit child pointer in LDS;
  * genlm_backend_amd.trie.TokenByteTrie.plan builds it; every array lives on the device):
  *   desc [n_parts + 1][16] int32, per part: slot_base, n_local, n_roots, n_depths, (unused), cptr_off, leaf_off,
- *        n_leaves, cut_base, node_off, n_nodes, inode_off, n_inodes, idepth_off (the rest 0); part n_parts is the top
- *        when n_top > 0
+ *        n_leaves, cut_base, node_off, n_nodes, inode_off, n_inodes, idepth_off, run_off, n_runs; part n_parts is the
+ *        top when n_top > 0
  *   local slots of a part are numbered breadth first over its subtrees: the children of local slot s are
  *        cptr16[cptr_off + s] .. cptr16[cptr_off + s + 1] (ascending child order; cptr_off even)
  *   inode16 [inode_off ..+ n_inodes] (inode_off even): the part's internal local slots depth by depth; depth k is
  *        idepth[idepth_off + k] .. idepth[idepth_off + k + 1] of them, its children all sit in depth k + 1
  *   leaf_src / leaf_local [leaf_off ..+ n_leaves]: the part's tokens in ascending order (top: indices of cut roots) and
  *        the local slots their weights go to
- *   pn_node / pn_local [node_off ..+ n_nodes]: the trie nodes whose value a local slot of the part holds
+ *   the trie nodes whose value a local slot of the part holds are n_runs runs of consecutive node ids (a subtree is an
+ *        interval of the post-order numbering): run_tab [run_off ..+ n_runs][2] = (first node, count), and
+ *        pn_local16 [node_off ..+ n_nodes]: the local slots of those nodes, run after run
  *   top_local [n_top]: local slot of top slot top_base + i;  slot_of [n_nodes]: node -> slot (parts first, top last)
  *   lds_bytes: the largest part's 4 n_local + 2 (n_local + 1, rounded up to even) + 2 (n_inodes, rounded up to even)
  *        + 128 (its depth table: n_depths <= 30)
@@ -505,8 +507,8 @@ typedef struct glb_trie_plan {
   uint32_t struct_size;  /* sizeof(glb_trie_plan) - ABI guard */
   int32_t n_parts, n_top, n_cut, n_slots, max_local, top_base, lds_bytes;
   int64_t n_nodes;
-  const int32_t *desc, *idepth, *leaf_src, *leaf_local, *pn_node, *pn_local, *top_local, *slot_of;
-  const uint16_t *cptr16, *inode16;
+  const int32_t *desc, *idepth, *leaf_src, *leaf_local, *run_tab, *top_local, *slot_of;
+  const uint16_t *cptr16, *inode16, *pn_local16;
 } glb_trie_plan;
 typedef struct glb_trie_rows_args {
   uint32_t struct_size;  /* sizeof(glb_trie_rows_args) - ABI guard */

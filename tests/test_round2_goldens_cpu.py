@@ -294,7 +294,10 @@ def _run_plan(pl, ws, op):
                         acc = acc + v if op == 0 else max(acc, v)
                     val[s] = np.float32(acc)
             assert not np.isnan(val).any()
-            nd, nl = pl["pn_node"][d[9]:d[9] + d[10]], pl["pn_local"][d[9]:d[9] + d[10]]
+            nl = pl["pn_local16"][d[9]:d[9] + d[10]].astype(np.int64)
+            runs = pl["run_tab"][d[14]:d[14] + d[15]]
+            nd = np.concatenate([np.arange(lo, lo + cnt) for lo, cnt in runs]) if len(runs) else np.zeros(0, np.int64)
+            assert np.array_equal(nd, pl["pn_node"][d[9]:d[9] + d[10]]) and (top or len(runs) <= int(d[2]))  # (a run per subtree)
             out[r, nd] = val[nl]
             if not top:
                 cut[r, d[8]:d[8] + n_roots] = val[:n_roots]
