@@ -36,7 +36,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_lsm -o f -- pytho
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_lsm -o w -- python3 $R/tools/kbench_lsm.py > $O/pmc_w_lsm.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_trie -o t -- python3 $R/tools/tbench.py > $O/kstats_trie.log 2>&1
 python3 $R/tools/trace_by_grid.py $(find $O/kstats_lsm -name "*kernel_trace.csv" | head -1) > $O/lsm_by_shape.txt 2>&1
-python3 $R/tools/trace_by_grid.py $(find $O/kstats_trie -name "*kernel_trace.csv" | head -1) > $O/trie_by_shape.txt 2>&1
+python3 $R/tools/trace_by_grid.py $(find $O/kstats_trie -name "*kernel_trace.csv" | head -1) trie_ > $O/trie_by_shape.txt 2>&1
 # ---- round 4: per-particle masks, the verbatim README loop, the KV step, SQ counters, trie traffic -------------------------
 python3 $R/bench.py --workload kernel --per-row-masks --steps 200 --warmup 10 --no-cpu > $O/bench_kernel_rowmasks.json 2>> $O/bench_kernel.err
 python3 $R/bench.py --workload kernel-llama --per-row-masks --steps 200 --warmup 10 --no-cpu > $O/bench_kernel-llama_rowmasks.json 2>> $O/bench_kernel.err

@@ -8,7 +8,9 @@ g = collections.defaultdict(list)
 for r in rows:
     n = r["Kernel_Name"]
     if flt in n:
-        g[(n[: n.rfind("(")].replace("void ", "").replace("(anonymous namespace)::", ""), int(r.get("Grid_Size") or r["Grid_Size_X"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        short = n.replace("void ", "").replace("(anonymous namespace)::", "")
+        short = short[: short.find("(")] if "(" in short else short  # (the argument list goes)
+        g[(short, int(r.get("Grid_Size") or r["Grid_Size_X"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 print(f"{'kernel':60s} {'grid (threads)':>14s} {'launches':>8s} {'mean us':>9s} {'median':>9s} {'min':>9s} {'max':>9s}")
 for (n, grid), v in sorted(g.items()):
     print(f"{n:60s} {grid:14d} {len(v):8d} {statistics.mean(v) / 1e3:9.2f} {statistics.median(v) / 1e3:9.2f} {min(v) / 1e3:9.2f} {max(v) / 1e3:9.2f}")
