@@ -323,7 +323,7 @@ class TokenByteTrie:
                 self._plan = (cap, None)
                 return None
             lds_bytes = max(lds_bytes, 4 * int(desc[p, 1]) + 2 * len(cptr16[-1]) + 2 * len(inode16[-1]) + 4 * 32)
-        cat16 = lambda xs: (np.concatenate(xs) if xs else np.zeros(0, np.int64)).astype(np.uint16)
+        cat16 = lambda xs: np.concatenate(list(xs) + [np.zeros(2, np.int64)]).astype(np.uint16)  # (never empty: a device pointer)
         plan = dict(n_parts=n_parts, n_top=n_top, n_slots=n_slots, n_cut=len(cut), cap=cap, vocab=len(self.decode),
                     n_nodes=len(self.children), max_local=int(desc[:, 1].max()), top_base=slot_base,
                     lds_bytes=lds_bytes, cptr16=cat16(cptr16), inode16=cat16(inode16), idepth=cat(idepth),

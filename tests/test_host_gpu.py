@@ -710,6 +710,19 @@ def test_trie_rows_in_lds_equal_the_level_kernels_and_the_oracle(engine, oracle,
             assert torch.equal(half, old.masses_from_logits(xd, lse, logit_scale=0.5))
 
 
+def test_trie_rows_on_degenerate_vocabularies(engine, oracle):
+    """One token, one chain, two leaves under the root: the plan has one part of one to five slots and no top."""
+    from genlm_backend_amd.tokenization import Token
+    from genlm_backend_amd.trie import TokenByteTrie
+
+    for vocab in ([b"a"], [b"abc"], [b"a", b"b"], [b"a", b"ab", b"abc"]):
+        trie = TokenByteTrie([Token(i, w) for i, w in enumerate(vocab)], engine=engine)
+        assert trie.plan()["n_top"] == 0
+        ws = np.random.default_rng(3).random((3, len(vocab))).astype(np.float32)
+        for op, fn in ((0, trie.batch_weight_sum), (1, trie.batch_weight_max)):
+            assert np.array_equal(fn(torch.from_numpy(ws)).view(np.uint32), oracle.trie_reduce(ws, trie.flat(), op).view(np.uint32))
+
+
 def test_trie_rows_at_llama_vocabulary_size(engine, oracle):
     """128 256 synthetic tokens (config 5's vocabulary size; 159 k slots in 26 parts + the root): weights == the oracle bit
     for bit, masses from bf16 logits + lse == the level-synchronous kernels' bits, selected nodes == columns of the rows."""
