@@ -1348,12 +1348,8 @@ int glb_group_contexts(const int32_t *tokens, const int64_t *starts, const int32
         hipLaunchKernelGGL((group_contexts_lds_kernel<1, true>), dim3(1), dim3(1024), lds, s, tokens, starts, lengths,
                            (int32_t)n, (int32_t)cap, out_group_of, out_rep, out_n_groups, hashes);
       } else if (n > 4096) {
-        static std::once_flag big_lds;  // more than 64 KiB of dynamic LDS has to be allowed once per process
-        static hipError_t big_lds_rc = hipSuccess;
-        std::call_once(big_lds, [] {
-          big_lds_rc = hipFuncSetAttribute((const void *)group_contexts_lds_kernel<8, true>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        });
+        static std::atomic<uint64_t> big_lds{0};  // (more than 64 KiB of dynamic LDS: allowed once per device)
+        const hipError_t big_lds_rc = glb::allow_dynamic_lds((const void *)group_contexts_lds_kernel<8, true>, 128 * 1024, big_lds);
         if (big_lds_rc != hipSuccess) return hip_fail(big_lds_rc, "hipFuncSetAttribute(group_contexts)");
         hipLaunchKernelGGL((group_contexts_lds_kernel<8, true>), dim3(1), dim3(1024), lds, s, tokens, starts, lengths,
                            (int32_t)n, (int32_t)cap, out_group_of, out_rep, out_n_groups, hashes);

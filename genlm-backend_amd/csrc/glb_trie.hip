@@ -291,13 +291,10 @@ __global__ void trie_sel_slots_kernel(const int32_t *sel, int32_t n_sel, const i
 
 template <int DT, int kL>
 hipError_t launch_rows1(const TrieRowsParams &p, int n_top, size_t lds, int threads, hipStream_t s) {
-  static bool big_lds_set = false;  // (more than 64 KB of dynamic LDS has to be asked for, once per kernel)
-  if (!big_lds_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)trie_rows_kernel<DT, false, kL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)trie_rows_kernel<DT, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    big_lds_set = true;
-  }
+  static std::atomic<uint64_t> big_lds{0}, big_lds_top{0};  // (more than 64 KB of dynamic LDS: allowed per kernel and device)
+  hipError_t e0 = glb::allow_dynamic_lds((const void *)trie_rows_kernel<DT, false, kL>, 160 * 1024, big_lds);
+  if (e0 == hipSuccess) e0 = glb::allow_dynamic_lds((const void *)trie_rows_kernel<DT, true, 8>, 160 * 1024, big_lds_top);
+  if (e0 != hipSuccess) return e0;
   const unsigned blocks = (unsigned)(((int64_t)p.n_rows + 7) / 8 * 8 * p.n_parts);
   hipLaunchKernelGGL((trie_rows_kernel<DT, false, kL>), dim3(blocks), dim3(threads), lds, s, p);
   if (n_top > 0) hipLaunchKernelGGL((trie_rows_kernel<DT, true, 8>), dim3((unsigned)p.n_rows), dim3(256), lds, s, p);
