@@ -11,7 +11,9 @@ from tests import synth
 
 pytestmark = pytest.mark.gpu
 
-V_POOL = [1, 2, 3, 5, 31, 32, 33, 127, 255, 1000, 4097, 8191, 16380, 16381, 32765, 32769, 50257, 65528, 65529, 70001]
+V_POOL = [1, 2, 3, 5, 31, 32, 33, 127, 255, 1000, 4097, 8191, 16380, 16381, 32765, 32769, 50257, 65528, 65529, 70001,
+          69633, 73729, 131071, 200003, 262144, 262145]  # (17 / 18 / 19 / 32 / 49 / 64 / 65 chunks: waves of the log-softmax kernel
+                                                          # carry one to three chunks; 65 chunks take its three-launch form)
 
 
 def _case(rng):
@@ -122,3 +124,10 @@ def test_random_case(engine, oracle, c):
     nan = np.isnan(want)
     assert np.array_equal(np.isnan(got), nan), "log_softmax NaN pattern"
     assert np.array_equal(got.view(np.uint32)[~nan], want.view(np.uint32)[~nan]), "log_softmax rows"
+    if c["dtype"] != "f32":  # ... and in the logits' own 16-bit type: the float32 result rounded to nearest even
+        got16 = engine.log_softmax_rows(x_d, vocab=V, logit_scale=c["scale"], out_dtype=tdt)
+        torch.cuda.synchronize()
+        want16 = O.round_rows_16(want, c["dtype"])
+        g16 = got16.cpu().view(torch.int16).numpy().view(np.uint16)
+        assert np.array_equal(g16[~nan], want16.view(np.uint16)[~nan]), "log_softmax rows in the logits' dtype"
+        assert np.array_equal(np.isnan(got16.float().cpu().numpy()), nan), "log_softmax NaN pattern (16-bit)"
