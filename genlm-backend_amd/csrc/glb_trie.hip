@@ -28,7 +28,7 @@ namespace {
 constexpr int kDesc = 16;  // int32 words per part descriptor (trie.py: plan()["desc"])
 enum { D_SLOT_BASE = 0, D_N_LOCAL, D_N_ROOTS, D_N_DEPTHS, D_DEPTH_OFF, D_CPTR_OFF, D_LEAF_OFF, D_N_LEAVES, D_CUT_BASE, D_NODE_OFF, D_N_NODES,
        D_INODE_OFF, D_N_INODES, D_IDEPTH_OFF, D_RUN_OFF, D_N_RUNS };
-constexpr int kMaxThreads = 1024;
+constexpr int kMaxThreads = 512;
 
 struct TrieRowsParams {
   const void *ws;
@@ -198,7 +198,7 @@ __device__ __forceinline__ void part_write(const TrieRowsParams &p, const PartVi
 // values of two rows halve the workgroups a CU holds: 257 against 206 us).
 // ---------------------------------------------------------------------------------------------------------------------
 template <int DT, bool TOP, int kL>  // kL: leaves (and table words) a thread has in flight
-__global__ __launch_bounds__(kMaxThreads) void trie_rows_kernel(TrieRowsParams p) {
+__global__ __launch_bounds__(kMaxThreads, 6) void trie_rows_kernel(TrieRowsParams p) {
   extern __shared__ float val[];
   int r, part;
   if constexpr (TOP) {
@@ -301,11 +301,12 @@ hipError_t launch_rows1(const TrieRowsParams &p, int n_top, size_t lds, int thre
   return hipGetLastError();
 }
 
-// deep: sixteen leaves a thread in flight (93 registers: two 512-thread workgroups a CU, what parts of 80 KB allow
-// anyway); otherwise eight (53 registers: four)
+// deep: twelve leaves a thread in flight (73 registers: three 512-thread workgroups a CU, what parts of 9 500 slots allow
+// by their LDS; the leaves of such a part in ONE trip); otherwise eight (53 registers).  Sixteen: 93 registers, two
+// workgroups a CU - 234 against 206 us at 1024 x 50257.
 template <int DT>
 hipError_t launch_rows(const TrieRowsParams &p, int n_top, size_t lds, int threads, bool deep, hipStream_t s) {
-  return deep ? launch_rows1<DT, 16>(p, n_top, lds, threads, s) : launch_rows1<DT, 8>(p, n_top, lds, threads, s);
+  return deep ? launch_rows1<DT, 12>(p, n_top, lds, threads, s) : launch_rows1<DT, 8>(p, n_top, lds, threads, s);
 }
 
 }  // namespace
@@ -393,7 +394,7 @@ int glb_trie_rows(const glb_trie_rows_args *a, const glb_trie_plan *pl, void *st
   // a CU, whatever their LDS - tools/dbg/stamps_trie.py; 512-thread ones are.)
   int threads = 512;
   if (lds * 8 <= 160 * 1024) threads = 256;
-  bool deep = lds * 3 > 160 * 1024;
+  bool deep = pl->max_local > 8 * threads;  // (a part's leaves - three slots in four - in one trip of twelve a thread)
 #ifdef GLB_STAMPS
   if (const char *ev = getenv("GLB_TRIE_THREADS")) threads = atoi(ev);
   if (const char *ev = getenv("GLB_TRIE_DEEP")) deep = atoi(ev) != 0;
