@@ -216,6 +216,9 @@ def main():
                     help="sis workloads with the prompt's KV cached (hf.py:155-164 cache_kv; BASELINE config 3)")
     ap.add_argument("--prompts", type=int, default=1, help="distinct shared prompts over the population (config 3: 1 / 8 / 64)")
     ap.add_argument("--resample", action="store_true", help="systematic resampling after every step (replicated, deterministic)")
+    ap.add_argument("--llm-gather", action="store_true",
+                    help="api-coro / api-readme: run a step's coroutines with AsyncAmdLM.gather (advanced by hand, no asyncio Task per "
+                         "particle) instead of asyncio.gather - the README's user code with ONE name changed")
     ap.add_argument("--auto-kv", action="store_true",
                     help="api workload: KV rows that follow the contexts handed to batch_next_token_step (beyond the reference: "
                          "one token per context per step instead of a re-encoding)")
@@ -287,7 +290,7 @@ def main():
         runner = KernelWorkload(eng, dev, rank, world, dist, llama=workload == "kernel-llama", per_row_masks=args.per_row_masks)
     elif workload in ("api", "api-coro", "api-readme", "api-logprobs"):
         runner = ApiWorkload(eng, dev, rank, world, dist, logprobs=workload == "api-logprobs", coro=workload == "api-coro",
-                             auto_kv=args.auto_kv, readme=workload == "api-readme")
+                             auto_kv=args.auto_kv, readme=workload == "api-readme", llm_gather=args.llm_gather)
     else:
         from genlm_backend_amd.sis import SisBenchWorkload
 
@@ -561,7 +564,7 @@ class ApiWorkload:
     dtype_name = "f32"
 
     def __init__(self, eng, dev, rank, world, dist, logprobs=False, coro=False, n_particles=1024, max_tokens=10,
-                 auto_kv=False, readme=False):
+                 auto_kv=False, readme=False, llm_gather=False):
         import asyncio
 
         from transformers import GPT2Config
@@ -574,6 +577,7 @@ class ApiWorkload:
                                           batch_size=n_particles, timeout=0.02,
                                           auto_kv_rows=n_particles + n_particles // 4 if auto_kv else 0, auto_kv_cap=24)
         self.auto_kv = auto_kv
+        self.llm_gather = llm_gather
         V = cfg.vocab_size
         g = torch.Generator(device=dev)
         g.manual_seed(4321)
@@ -640,8 +644,10 @@ class ApiWorkload:
             self._reset()
 
         if self.coro or self.readme:
+            gather = self.llm.gather if self.llm_gather else aio.gather
+
             async def one_step():
-                await aio.gather(*[p.extend() for p in self.particles if p.active])
+                await gather(*[p.extend() for p in self.particles if p.active])
 
             self.loop.run_until_complete(one_step())
         else:  # README.md:82-91 for every active particle, lines 82-87 as one batched call
@@ -674,6 +680,8 @@ class ApiWorkload:
               "AsyncAmdLM.batch_next_token_step call") + ", prompt len 8, <=10 new tokens, 2 shared bit masks, Philox draws "
              "(README.md:72-98)")
         extra = {}
+        if self.llm_gather and (self.coro or self.readme):
+            what += "; the coroutines of a step run by AsyncAmdLM.gather (no asyncio Task per particle) instead of asyncio.gather"
         if self.auto_kv:
             what += "; KV rows follow the contexts (AsyncAmdLM(auto_kv_rows=...): beyond the reference)"
             extra["auto_kv"] = dict(self.llm._auto_kv.stats)

@@ -721,6 +721,65 @@ class AsyncAmdLM(AsyncLM):
         logZ, tok = await sq[2]
         return logZ[slot], tok[slot]
 
+    async def gather(self, *coros, return_exceptions=False):
+        """`asyncio.gather` for coroutines that spend their time awaiting THIS backend (a population of README particles:
+        `await llm.gather(*[p.extend() for p in particles])`), without a Task per coroutine.  asyncio.gather wraps every
+        coroutine in a Task: creating it, one trip through the event loop to start it, one to wake it when the shared
+        future resolves and one done-callback cost CPython ~15 us per particle and step - at 1024 particles more than
+        the step on the GPU takes.  Here the coroutines are advanced by hand (`send`): each runs to the point where it
+        awaits this backend, the queued requests are evaluated as one batch, each is resumed with the result.  A
+        coroutine that awaits something else (a foreign future, `asyncio.sleep`) is simply awaited from here, so any
+        coroutine works - only slower.  Results in argument order; the first exception closes the other coroutines and
+        propagates (with `return_exceptions` it takes the failed coroutine's place in the results, as in asyncio).
+        No counterpart in the reference (its callers use asyncio.gather, README.md:96)."""
+        n = len(coros)
+        results = [None] * n
+        live = list(range(n))   # coroutines that have not finished
+        blocked = [None] * n    # what coroutine i is waiting for: a future, or None = ready to be resumed
+        try:
+            while live:
+                nxt = []
+                for i in live:
+                    fut = blocked[i]
+                    if fut is not None and not fut.done():
+                        nxt.append(i)
+                        continue
+                    blocked[i] = None
+                    try:
+                        y = coros[i].send(None)
+                    except StopIteration as e:
+                        results[i] = e.value
+                        continue
+                    except Exception as e:
+                        if not return_exceptions:
+                            raise
+                        results[i] = e
+                        continue
+                    if y is not None:  # `await future`: the future itself comes out (asyncio's protocol), flagged as awaited
+                        if getattr(y, "_asyncio_future_blocking", None) is None:
+                            raise RuntimeError(f"coroutine yielded {y!r}: not an asyncio awaitable")
+                        y._asyncio_future_blocking = False
+                        blocked[i] = y
+                    nxt.append(i)
+                live = nxt
+                if not live:
+                    break
+                if self.queries or self._sq is not None:
+                    if self.timer:
+                        self.timer.cancel()
+                        self.timer = None
+                    self.batch_evaluate_queries()  # everything queued so far is one batch: its futures resolve here
+                waiting = [blocked[i] for i in live if blocked[i] is not None and not blocked[i].done()]
+                if waiting and len(waiting) == len(live):
+                    await asyncio.wait(waiting, return_when=asyncio.FIRST_COMPLETED)  # (foreign futures: the event loop's business)
+                elif not waiting and all(blocked[i] is None for i in live):
+                    await asyncio.sleep(0)  # (bare yields, e.g. asyncio.sleep(0): give the loop its turn)
+        except BaseException:
+            for i in live:
+                coros[i].close()
+            raise
+        return results
+
     def _fire_step_batch(self):
         """Evaluate the pending `next_token_step` requests (one vectorised call) and resolve their shared future."""
         sq, self._sq = self._sq, None

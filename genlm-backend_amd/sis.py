@@ -71,11 +71,13 @@ class Particle:
             self.context.append(token)
 
 
-async def autobatched_sis(n_particles, llm, mask_selector, prompt_ids, eos_id):
-    """README.md:94-98"""
+async def autobatched_sis(n_particles, llm, mask_selector, prompt_ids, eos_id, gather=None):
+    """README.md:94-98.  gather: what runs a step's coroutines together - `asyncio.gather` as in the README (default), or
+    `llm.gather` (AsyncAmdLM.gather: the same results without a Task per particle)."""
+    gather = gather or asyncio.gather
     particles = [Particle(llm, mask_selector, prompt_ids, eos_id) for _ in range(n_particles)]
     while any(p.active for p in particles):
-        await asyncio.gather(*[p.extend() for p in particles if p.active])
+        await gather(*[p.extend() for p in particles if p.active])
     return particles
 
 

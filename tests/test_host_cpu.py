@@ -190,6 +190,52 @@ def test_readme_sis_async_matches_reference(llm, gold):
     assert llm.stats["queries"] > llm.stats["unique"]
 
 
+def test_gather_without_tasks_gives_the_same_particles(llm, gold):
+    """AsyncAmdLM.gather (the coroutines of a step advanced by hand instead of one asyncio Task each): the reference's golden
+    tokens and weights, the same number of batches; coroutines that also await other things, return values in order,
+    exceptions with and without return_exceptions."""
+    from genlm_backend_amd.sis import autobatched_sis
+
+    llm.register_masks(torch.from_numpy(gold["sis_masks"]))
+    llm.set_rng("torch", 1234)
+    prompt = [int(t) for t in gold["sis_prompt"]]
+    parts = asyncio.run(autobatched_sis(16, llm, lambda c: 1 if len(c) >= 10 else 0, prompt, eos_id=0, gather=llm.gather))
+    _check_sis([p.context for p in parts], [p.log_weight for p in parts], gold)
+    assert llm.stats["batches"] == int(gold["sis_steps"][0])
+
+    async def mixed():
+        async def plain(i):
+            return i
+
+        async def sleeper(i):
+            await asyncio.sleep(0)
+            await asyncio.sleep(0.002)
+            z, t = await llm.next_token_step(prompt + [i + 1], 0)
+            return i, t
+
+        async def stepper(i):
+            z, t = await llm.next_token_step(prompt + [i + 1], 0)
+            z2, t2 = await llm.next_token_step(prompt + [i + 1, 7], 0)
+            return i, t
+
+        async def failing():
+            await llm.next_token_step(prompt, 0)
+            raise KeyError("boom")
+
+        before = llm.stats["batches"]
+        res = await llm.gather(plain(0), sleeper(1), stepper(2), stepper(3), plain(4))
+        assert res[0] == 0 and res[4] == 4 and [r[0] for r in res[1:4]] == [1, 2, 3]
+        assert llm.stats["batches"] - before <= 6
+        res = await llm.gather(plain(1), failing(), return_exceptions=True)
+        assert res[0] == 1 and isinstance(res[1], KeyError)
+        with pytest.raises(KeyError):
+            await llm.gather(stepper(5), failing())
+        return True
+
+    llm.set_rng("torch", 99)
+    assert asyncio.run(mixed())
+
+
 @pytest.mark.parametrize("share", [False, True])
 def test_device_sis_parity_draws_with_kv_rows_run_reset_run(llm, gold, share):
     """Parity draws (rng="torch") with per-particle KV rows, private and shared: the noise rows are dealt by this step's
