@@ -179,6 +179,10 @@ def test_backend_sis_on_gpu_matches_reference(llm):
     m.set_rng("torch", 1234)
     parts = asyncio.run(autobatched_sis(16, m, lambda c: 1 if len(c) >= 10 else 0, prompt, eos_id=0))
     assert [p.context for p in parts] == want_ctx
+    m.set_rng("torch", 1234)  # the same loop with the step's coroutines run by AsyncAmdLM.gather (no Task per particle)
+    parts = asyncio.run(autobatched_sis(16, m, lambda c: 1 if len(c) >= 10 else 0, prompt, eos_id=0, gather=m.gather))
+    assert [p.context for p in parts] == want_ctx
+    assert np.abs(np.asarray([p.log_weight for p in parts], np.float32) - gold["sis_log_weights"]).max() < TOL
     ids = asyncio.run(m.sample([int(t) for t in gold["sample_prompt"]], max_tokens=12, eos_token_ids=[0],
                                temperature=0.5, seed=80808))
     assert ids == [int(t) for t in gold["sample_ids"]]
