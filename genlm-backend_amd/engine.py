@@ -334,6 +334,20 @@ class HipEngine:
                                             _DT[out.dtype], out_ld, _ptr(lse), _ptr(ws), ws.numel(), self._stream()))
         return (out, lse) if want_lse else out
 
+    def row_lse(self, logits, vocab=None, logit_scale=1.0):
+        """logsumexp(logits[r] * logit_scale) per row, float32 [n_rows] (glb_log_softmax_rows with no rows out: the rows are
+        read once, nothing but n_rows floats is written) - the lse `trie_rows` / `trie_masses` take next to raw logits."""
+        if logits.dim() != 2 or logits.stride(1) != 1:
+            raise ValueError("logits must be 2-D with unit inner stride")
+        n_rows, width = logits.shape
+        V = width if vocab is None else vocab
+        ld = logits.stride(0) if n_rows > 1 else max(width, logits.stride(0))
+        lse = self._f32(n_rows)
+        ws = self._scratch(self.lib.glb_log_softmax_workspace_bytes(n_rows, V))
+        check(self.lib.glb_log_softmax_rows(_ptr(logits), _DT[logits.dtype], n_rows, V, ld, logit_scale, None, F32, 0,
+                                            _ptr(lse), _ptr(ws), ws.numel(), self._stream()))
+        return lse
+
     def mask_to_bits(self, mask):
         """{0,-inf} float log-masks [K, V] -> packed int32 bit rows [K, ceil(V/32)] + non-binary flag."""
         if mask.dim() == 1:

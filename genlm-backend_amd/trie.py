@@ -400,9 +400,9 @@ class TokenByteTrie:
     def batch_weight_max_device(self, ws, from_logprobs=False):
         return self._batch(ws, 1, from_logprobs)
 
-    def masses_from_logits(self, logits, lse, nodes=None, layout="rows", op=0, logit_scale=1.0):
+    def masses_from_logits(self, logits, lse=None, nodes=None, layout="rows", op=0, logit_scale=1.0):
         """Masses of softmax(logits * logit_scale) straight from the logits rows ([B, V] float32 / bfloat16 / float16 on
-        the device) and the rows' lse (float32 [B]: the fused step's `lse` output, or `log_softmax_rows(want_lse=True)`):
+        the device) and the rows' lse (float32 [B]: the fused step's `lse` output; None: computed here, `HipEngine.row_lse`):
         what the reference gets from `batch_weight_sum(logprobs.exp())` (trie/parallel.py:92-103) without the [B, V]
         matrix of log-probabilities ever being written.  nodes: int32 device tensor - only these nodes' masses,
         [B, len(nodes)]; layout "slots": node-major [n_slots, pitch] over the folded trie (`compact()`: the value of node
@@ -411,6 +411,8 @@ class TokenByteTrie:
         (`plan()["slot_of"]`: node -> slot) - the cheapest form: the logits are read once and nothing else is written."""
         if logits.shape[1] < len(self.decode):
             raise ValueError(f"logits rows have {logits.shape[1]} columns, vocabulary has {len(self.decode)}")
+        if lse is None:  # (one more reading of the rows: hand the fused step's lse over when there is one)
+            lse = self.engine.row_lse(logits, vocab=len(self.decode), logit_scale=logit_scale)
         if nodes is not None and nodes.dtype != torch.int32:
             raise TypeError("nodes must be int32")
         pl = self.plan_device_arrays() if self.resident and (layout in ("rows", "slot_rows")) else None

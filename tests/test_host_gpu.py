@@ -712,6 +712,8 @@ def test_trie_rows_in_lds_equal_the_level_kernels_and_the_oracle(engine, oracle,
             assert torch.equal(sl[:, trie.plan_device_arrays()["slot_of"].long()], rows)
             half = trie.masses_from_logits(xd, lse, logit_scale=0.5)
             assert torch.equal(half, old.masses_from_logits(xd, lse, logit_scale=0.5))
+            own = trie.masses_from_logits(xd[:, :V].contiguous(), logit_scale=0.5)  # lse computed by the call itself (row_lse)
+            assert (own[:, trie.root] - 1.0).abs().max().item() < 1e-4
 
 
 def test_trie_rows_on_degenerate_vocabularies(engine, oracle):
