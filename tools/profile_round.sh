@@ -42,6 +42,10 @@ python3 $R/bench.py --workload kernel --per-row-masks --steps 200 --warmup 10 --
 python3 $R/bench.py --workload kernel-llama --per-row-masks --steps 200 --warmup 10 --no-cpu > $O/bench_kernel-llama_rowmasks.json 2>> $O/bench_kernel.err
 python3 $R/bench.py --workload sis --per-row-masks --steps 30 --warmup 5 --no-cpu > $O/bench_sis_rowmasks.json 2>> $O/bench_sis.err
 python3 $R/bench.py --workload api-readme --steps 10 --warmup 2 --no-cpu > $O/bench_api-readme.json 2>> $O/bench_api.err
+# the coroutine workloads with AsyncAmdLM.gather instead of asyncio.gather
+python3 $R/bench.py --workload api-coro --llm-gather --steps 20 --warmup 3 --no-cpu > $O/bench_api-coro_llmgather.json 2>> $O/bench_api.err
+python3 $R/bench.py --workload api-coro --auto-kv --llm-gather --steps 20 --warmup 3 --no-cpu > $O/bench_api-coro_autokv_llmgather.json 2>> $O/bench_api.err
+python3 $R/bench.py --workload api-readme --llm-gather --steps 10 --warmup 2 --no-cpu > $O/bench_api-readme_llmgather.json 2>> $O/bench_api.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_kernel-rowmasks -o k -- python3 $R/bench.py --workload kernel --per-row-masks --steps 100 --warmup 5 --no-cpu > $O/kstats_kernel-rowmasks.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_kernel-rowmasks -o f -- python3 $R/bench.py --workload kernel --per-row-masks --steps 20 --warmup 2 --no-cpu > $O/pmc_f_kernel-rowmasks.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_kernel-rowmasks -o w -- python3 $R/bench.py --workload kernel --per-row-masks --steps 20 --warmup 2 --no-cpu > $O/pmc_w_kernel-rowmasks.log 2>&1
