@@ -106,6 +106,16 @@ def _all_to_all(dist, out, inp, out_splits, in_splits):
         dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits)
 
 
+def _all_to_all_any(dist, out, inp, out_splits, in_splits):
+    """_all_to_all for tensors of any shape and element type (KV rows): split along the first dimension."""
+    if inp.is_cuda and dist.get_backend() == "gloo":
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(host, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits)
+        out.copy_(host)
+    else:
+        dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits)
+
+
 def _reduce_all(dist, t, op):
     if t.is_cuda and dist.get_backend() == "gloo":
         host = t.cpu()
@@ -149,11 +159,13 @@ class DeviceSIS:
 
     def __init__(self, llm, n_particles, prompt_ids, max_tokens, eos_id, seed=0, rng="philox", rank=0, world=1,
                  dist=None, use_prefix_kv=False, use_particle_kv=False, resample_ess=None, force_collectives=False,
-                 share_kv=True, kv_rows=None, kv_in_place=0.75, kv_graph=True, particle_masks=None):
+                 share_kv=True, kv_rows=None, kv_in_place=0.75, kv_graph=True, particle_masks=None, migrate_kv=True):
         self.llm, self.eng, self.dev = llm, llm.engine, llm.device
         self.N, self.max_tokens, self.eos_id = n_particles, max_tokens, eos_id
         self.rank, self.world, self.dist = rank, world, dist
         self.collective = world > 1 or (bool(force_collectives) and dist is not None)
+        self.migrate_kv = bool(migrate_kv)  # private KV slabs: a particle resampled from another rank brings its KV rows along
+        self.kv_rows_moved = 0
         self.seed = seed
         self.rng_mode = RNG_PHILOX if rng == "philox" else RNG_NOISE
         self.host_rng = None
@@ -568,15 +580,21 @@ class DeviceSIS:
             mine_owner = owner[r * N:(r + 1) * N]
             recv_cnt = [int((mine_owner == src).sum()) if src != r else 0 for src in range(self.world)]
             self.rows_moved = int((owner != np.repeat(np.arange(self.world), N)).sum())  # over all ranks (replicated value)
+            moved = None
             if self.rows_moved:
                 take = np.concatenate(send_idx).astype(np.int64)
-                send = state[torch.from_numpy(take).to(dev)] if len(take) else state[:0]
+                take_d = torch.from_numpy(take).to(dev)
+                send = state[take_d] if len(take) else state[:0]
                 recv = torch.empty((sum(recv_cnt), state.shape[1]), dtype=torch.int32, device=dev)
-                _all_to_all(self.dist, recv, send.contiguous(), recv_cnt, [len(x) for x in send_idx])
+                send_cnt = [len(x) for x in send_idx]
+                _all_to_all(self.dist, recv, send.contiguous(), recv_cnt, send_cnt)
+                slots_d = None
                 if sum(recv_cnt):
                     # rows arrive ordered by source rank, then by this rank's slot order - the order the senders used
                     slots = np.concatenate([np.nonzero(mine_owner == src)[0] for src in range(self.world) if src != r])
-                    new_state[torch.from_numpy(slots.astype(np.int64)).to(dev)] = recv
+                    slots_d = torch.from_numpy(slots.astype(np.int64)).to(dev)
+                    new_state[slots_d] = recv
+                moved = (take_d, send_cnt, slots_d, recv_cnt)
         self.contexts = new_state[:, :self.cap].contiguous()
         self.lengths, self.prompt_len, self.active = (new_state[:, self.cap + k].contiguous() for k in range(3))
         # equal weights: log of the population's mean weight
@@ -592,10 +610,37 @@ class DeviceSIS:
             kv_len = (self.lengths - 1).clamp_min(0)
             self.pkv.gather(src, kv_len)
             stale = ~is_local
-            self._kv_stale = stale if bool(stale.any().item()) else None
+            if self.migrate_kv and self.collective and self.world > 1:
+                # the KV rows of the particles that changed ranks travel with them: ONE all-to-all of [rows, layers x {K, V},
+                # heads, cap, head_dim] (the senders' rows as they were before the gather above: the second slab set)
+                if self.rows_moved:
+                    self._migrate_kv(*moved)
+                self._kv_stale = None
+            else:  # rebuilt from the context in the next step
+                self._kv_stale = stale if bool(stale.any().item()) else None
         self._rehash()  # contexts moved between slots (and ranks): one launch, once per resampling step
         self.n_resamples += 1
         self._exchange()
+
+    def _migrate_kv(self, take_d, send_cnt, slots_d, recv_cnt):
+        """Private KV slabs after a resampling step: row take_d[k] of the OLD slabs (SlabKV.gather has just swapped them
+        into its second set) goes to the rank that took it, the rows received land in slots_d of the new slabs.  One
+        collective for all layers: fewer, larger messages are what xGMI's point-to-point links want."""
+        pkv = self.pkv
+        new = pkv._tensors(pkv.layers)
+        old = pkv._alt
+        n_send, n_recv = int(sum(send_cnt)), int(sum(recv_cnt))
+        shape = tuple(new[0].shape[1:])
+        for t in new:
+            if tuple(t.shape[1:]) != shape or t.dtype != new[0].dtype:
+                raise ValueError("KV layers of different shapes: rows cannot travel in one message")
+        send = torch.stack([t[take_d] for t in old], dim=1).contiguous() if n_send else new[0].new_zeros((0, len(new)) + shape)
+        recv = new[0].new_empty((n_recv, len(new)) + shape)
+        _all_to_all_any(self.dist, recv, send, recv_cnt, send_cnt)
+        if n_recv:
+            for j, t in enumerate(new):
+                t[slots_d] = recv[:, j]
+        self.kv_rows_moved += n_recv
 
     @torch.no_grad()
     def run(self, max_steps=None):

@@ -930,22 +930,27 @@ def _two_rank_worker(rank, world, port, out_dir, mode):
     p = [int(t) for t in gold["sis_prompt"]]
     prompts = ([p, p[:5], p[2:], p[1:]] * 4)[rank * 8:(rank + 1) * 8]  # rank-specific prompts
     kw = dict(use_particle_kv=True) if mode == "pkv" else (dict(use_prefix_kv=True) if mode == "prefix" else {})
+    if mode == "private":  # per-particle KV slabs: the rows of a particle that changes ranks travel with it
+        kw = dict(use_particle_kv=True, share_kv=False)
     sis = DeviceSIS(m, 8, prompts, max_tokens=6, eos_id=-1, seed=21, rank=rank, world=world, dist=dist, resample_ess=1.0, **kw)
+    if mode == "private":
+        sis.log_weights = sis.log_weights - 4.0 * rank  # (the first resampling step fills rank 1's slots from rank 0)
     sis.run()
     ctx, lw = sis.results()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), ctx=np.array([list(c) + [-1] * (20 - len(c)) for c in ctx]), lw=lw,
-             all_lw=sis.all_weights.cpu().numpy(), n_resamples=sis.n_resamples)
+             all_lw=sis.all_weights.cpu().numpy(), n_resamples=sis.n_resamples, kv_moved=sis.kv_rows_moved)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["plain", "pkv", "prefix"])
+@pytest.mark.parametrize("mode", ["plain", "pkv", "prefix", "private"])
 def test_two_ranks_on_one_gpu_equal_one_rank(llm, tmp_path, mode):
     """The multi-rank path through the HIP kernels: two processes share this GPU, each holds half of the population
     (rank-specific ragged prompts), draws by the global particle index, gathers the weights every step (over gloo here
     - RCCL needs a GPU per rank; `test_rccl_collectives_on_one_rank_change_nothing` covers the RCCL calls) and resamples
     across the ranks after every step: the union equals one process with the whole population - plain, with shared KV
-    rows (contexts that migrate are encoded on their new rank) and with cached prompt prefixes of all ranks."""
+    rows (contexts that migrate are encoded on their new rank), with cached prompt prefixes of all ranks, and with private
+    KV slabs whose rows travel with the particles that change ranks."""
     import torch.multiprocessing as mp
 
     from genlm_backend_amd.sis import DeviceSIS
@@ -958,7 +963,12 @@ def test_two_ranks_on_one_gpu_equal_one_rank(llm, tmp_path, mode):
     m.register_masks(torch.from_numpy(gold["sis_masks"]))
     p = [int(t) for t in gold["sis_prompt"]]
     kw = dict(use_particle_kv=True) if mode == "pkv" else (dict(use_prefix_kv=True) if mode == "prefix" else {})
+    if mode == "private":
+        kw = dict(use_particle_kv=True, share_kv=False)
     one = DeviceSIS(m, 16, [p, p[:5], p[2:], p[1:]] * 4, max_tokens=6, eos_id=-1, seed=21, resample_ess=1.0, **kw)
+    if mode == "private":
+        one.log_weights[8:] -= 4.0
+        assert int(r[0]["kv_moved"]) + int(r[1]["kv_moved"]) > 0  # KV rows crossed the ranks (one all-to-all per resampling step)
     one.run()
     ctx, lw = one.results()
     got = [[int(t) for t in row if t >= 0] for row in np.concatenate([r[0]["ctx"], r[1]["ctx"]])]

@@ -121,7 +121,7 @@ def test_shared_kv_rows(kind):
     assert runs[3].pkv.n == 3
 
 
-def _worker(rank, world, port, out_dir, kind, pkv, prefix=False):
+def _worker(rank, world, port, out_dir, kind, pkv, prefix=False, share=True, migrate=True):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(2)
@@ -132,12 +132,20 @@ def _worker(rank, world, port, out_dir, kind, pkv, prefix=False):
     n = len(PROMPTS) // world
     mine = PROMPTS[rank * n:(rank + 1) * n]
     sis = DeviceSIS(llm, n, mine, max_tokens=6, eos_id=0, seed=3, rank=rank, world=world, dist=dist,
-                    use_particle_kv=pkv, use_prefix_kv=prefix, resample_ess=1.0)
+                    use_particle_kv=pkv, use_prefix_kv=prefix, resample_ess=1.0, share_kv=share, migrate_kv=migrate)
+    encoded = []
+    if pkv and not share:
+        # (the second rank's particles start 5 nats behind: the first resampling step fills its slots from rank 0)
+        sis.log_weights = sis.log_weights - 5.0 * rank
+        # count the rows whose KV is rebuilt from the context after a resampling step
+        orig = sis._encode_into_slabs
+        sis._encode_into_slabs = lambda idx: (encoded.append(-1 if idx is None else int(idx.numel())), orig(idx))[1]  # (None: step 0, every row)
     steps = sis.run()
     ctx, lw = sis.results()
     width = 8
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), ctx=np.array([list(c) + [-1] * (width - len(c)) for c in ctx]),
-             lw=lw, all_lw=sis.all_weights.numpy(), steps=steps, n_res=sis.n_resamples)
+             lw=lw, all_lw=sis.all_weights.numpy(), steps=steps, n_res=sis.n_resamples, kv_moved=sis.kv_rows_moved,
+             rows_moved=sis.rows_moved, reencoded=sum(e for e in encoded if e > 0))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -164,6 +172,35 @@ def test_two_ranks_equal_one_through_resampling(tmp_path, kind, pkv, prefix):
     got = [[int(t) for t in row if t >= 0] for row in np.concatenate([r[0]["ctx"], r[1]["ctx"]])]
     assert got == [list(map(int, c)) for c in ctx]
     assert np.abs(lw - r[0]["all_lw"]).max() < 1e-4
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("migrate", [True, False])
+def test_private_kv_rows_travel_with_their_particles(tmp_path, migrate):
+    """Per-particle KV slabs (share_kv=False) on two gloo ranks: a particle resampled from the other rank brings its KV rows
+    along in the resampling step's second all-to-all (migrate_kv, the default) instead of having them rebuilt from its
+    context - same tokens and weights as one process either way; with migration nothing is re-encoded after step 0."""
+    world, port = 2, 29941 + os.getpid() % 200
+    mp.start_processes(_worker, args=(world, port, str(tmp_path), "gpt2", True, False, False, migrate), nprocs=world, join=True,
+                       start_method="spawn")
+    r = [np.load(tmp_path / f"rank{i}.npz") for i in range(world)]
+    assert int(r[0]["n_res"]) >= 2 and np.array_equal(r[0]["all_lw"], r[1]["all_lw"])
+    from genlm_backend_amd.sis import DeviceSIS
+
+    one = DeviceSIS(_tiny("gpt2"), len(PROMPTS), PROMPTS, max_tokens=6, eos_id=0, seed=3, use_particle_kv=True,
+                    resample_ess=1.0, share_kv=False)
+    one.log_weights[len(PROMPTS) // 2:] -= 5.0
+    one.run()
+    ctx, lw = one.results()
+    got = [[int(t) for t in row if t >= 0] for row in np.concatenate([r[0]["ctx"], r[1]["ctx"]])]
+    assert got == [list(map(int, c)) for c in ctx]
+    assert np.abs(lw - r[0]["all_lw"]).max() < 1e-4
+    moved = int(r[0]["kv_moved"]) + int(r[1]["kv_moved"])
+    reenc = int(r[0]["reencoded"]) + int(r[1]["reencoded"])
+    if migrate:
+        assert moved > 0 and reenc == 0
+    else:
+        assert moved == 0 and reenc > 0
 
 
 def _early_worker(rank, world, port, out_dir):
