@@ -23,6 +23,8 @@ A step is one pass of the hot path over one batch of synthetic input that is alr
   api           the README loop through the backend's API, the population submitted as one batched call per step
                 (`AsyncAmdLM.batch_next_token_step`: contexts as Python lists in, logZ / tokens out).
   api-coro      the README loop with lines 82-87 as one fused call: 1024 coroutines awaiting `AsyncAmdLM.next_token_step`.
+  trie          token->byte trie masses of 1024 rows of gpt2-sized logits (trie/base.py:147-213,346-393,
+                trie/parallel.py:92-145) through glb_trie_rows: --trie-out rows (all nodes, row-major) | slots | selected.
   api-readme    the README loop VERBATIM, only `llm` swapped (README.md:72-98): 1024 coroutines await
                 `next_token_logprobs`, then add their mask, take logsumexp and draw with torch.multinomial themselves
                 (user-side torch ops on the returned device rows) - what a user who changes nothing else gets.
@@ -52,7 +54,7 @@ sys.path.insert(0, ROOT)
 V_GPT2, V_LLAMA = 50257, 128256
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 METRIC = "particles/sec + logprob-kernel HBM GB/s (% of 8 TB/s), 1024 particles gpt2"
-WORKLOADS = ["sis", "sis-llama", "kernel", "kernel-llama", "api", "api-coro", "api-readme", "api-logprobs", "plumbing"]
+WORKLOADS = ["sis", "sis-llama", "kernel", "kernel-llama", "api", "api-coro", "api-readme", "api-logprobs", "trie", "plumbing"]
 
 
 def algorithmic_bytes(B, V, elem_size, n_masks, mask_words, n_particles=None):
@@ -150,6 +152,29 @@ def cpu_baseline(workload, sample_rows, seed=1234):
                       f"({t_fwd * 1e3:.1f} ms/particle) + per-particle math on fp32-upcast rows (V={V_LLAMA}) "
                       f"{t_part / done * 1e3:.2f} ms/particle single-threaded; host has {ncpu} cores",
         }
+    if workload == "trie":
+        # the reference's per-row loop (trie/base.py:346-393 - numba-compiled there; here the oracle's C restatement of the
+        # same loop, same order of additions) over the unfolded trie, one thread
+        from genlm_backend_amd.tokenization import Token
+        from genlm_backend_amd.trie import TokenByteTrie
+
+        rs = np.random.default_rng(0)
+        words, seen = [], set()
+        while len(words) < V_GPT2:
+            w = bytes(rs.integers(97, 123, int(rs.integers(1, 9))).astype(np.uint8))
+            if w not in seen:
+                seen.add(w)
+                words.append(w)
+        flat = TokenByteTrie([Token(i, w) for i, w in enumerate(words)]).flat()
+        rows = min(sample_rows, 2048)
+        ws = rs.random((rows, V_GPT2)).astype(np.float32)
+        O.trie_reduce(ws[:8], flat, 0)
+        t0 = time.perf_counter()
+        O.trie_reduce(ws, flat, 0)
+        dt = time.perf_counter() - t0
+        return {"value": rows / dt, "unit": "particles/s", "cores": 1, "kind": "port",
+                "sample": f"weight_sum of {rows} weight rows over the {flat['n_nodes']}-node trie of {V_GPT2} tokens (the reference's "
+                          f"per-row loop, trie/base.py:346-393, restated in C) in {dt:.1f} s, single thread; host has {ncpu} cores"}
     # kernel-only analogues: per-particle math on synthetic rows
     V = V_GPT2 if workload == "kernel" else V_LLAMA
     rows = min(sample_rows, 1024 if workload == "kernel" else 256)
@@ -216,6 +241,8 @@ def main():
                     help="sis workloads with the prompt's KV cached (hf.py:155-164 cache_kv; BASELINE config 3)")
     ap.add_argument("--prompts", type=int, default=1, help="distinct shared prompts over the population (config 3: 1 / 8 / 64)")
     ap.add_argument("--resample", action="store_true", help="systematic resampling after every step (replicated, deterministic)")
+    ap.add_argument("--trie-out", choices=["rows", "slots", "selected"], default="rows",
+                    help="trie workload: all nodes row-major / the folded trie's slots row-major / 4096 selected nodes")
     ap.add_argument("--llm-gather", action="store_true",
                     help="api-coro / api-readme: run a step's coroutines with AsyncAmdLM.gather (advanced by hand, no asyncio Task per "
                          "particle) instead of asyncio.gather - the README's user code with ONE name changed")
@@ -286,7 +313,9 @@ def main():
             dist, force_coll = dist1, True
         except Exception as e:  # no RCCL for a single rank on this box: run without, and say so
             dist, rccl_note = None, f"one-rank nccl group unavailable: {type(e).__name__}: {e}"[:200]
-    if workload in ("kernel", "kernel-llama"):
+    if workload == "trie":
+        runner = TrieWorkload(eng, dev, rank, out=args.trie_out)
+    elif workload in ("kernel", "kernel-llama"):
         runner = KernelWorkload(eng, dev, rank, world, dist, llama=workload == "kernel-llama", per_row_masks=args.per_row_masks)
     elif workload in ("api", "api-coro", "api-readme", "api-logprobs"):
         runner = ApiWorkload(eng, dev, rank, world, dist, logprobs=workload == "api-logprobs", coro=workload == "api-coro",
@@ -396,16 +425,18 @@ def main():
                 # --pmc pass of this same command whose summary is committed under profiles/)
                 "traffic_source": (f"{traffic_src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this "
                                    "command, not this run") if traffic_src else None,
-                "kernel": "glb::fused_step_kernel (fused log-softmax + mask + logsumexp + sample in ONE launch: stats waves "
+                "kernel": getattr(runner, "roofline_kernel", None) or (
+                          "glb::fused_step_kernel (fused log-softmax + mask + logsumexp + sample in ONE launch: stats waves "
                           "stream the rows chunk by chunk, finishing waves at the end of the grid fold the tagged records "
                           "and draw); the few calls too small for it (one shared row: SIS step 0) run "
                           "glb::chunk_stats_small_kernel + glb::finish_kernel and are timed first start to last stop"
                           + ("; with one raw bit mask per particle the call's glb::mask_prepare_kernel launch comes first and is "
-                             "inside the span" if args.per_row_masks else ""),
-                "timing": "every fused call of the timed region, none left out: HIP events carried by the launch itself as "
+                             "inside the span" if args.per_row_masks else "")),
+                "timing": getattr(runner, "roofline_timing", None) or (
+                          "every fused call of the timed region, none left out: HIP events carried by the launch itself as "
                           "its start / stop stamps (hipExtLaunchKernel through glb_logprob_mask_sample_timed) = the launch "
                           "duration rocprofv3 reports; *_outer_events = the same calls between two hipEventRecord markers "
-                          "on the stream (adds the marker packets)",
+                          "on the stream (adds the marker packets)"),
                 "bytes_per_launch": runner.kernel_bytes,
                 "us_per_launch_mean": float(np.mean(kern_us)),
                 "us_per_launch_median": float(np.median(kern_us)),
@@ -476,6 +507,70 @@ def plumbing(args, rank, world, dist):
                           "rccl_ranks": world if dist is not None else None}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+class TrieWorkload:
+    """Token -> byte trie masses of 1024 rows of [1024, 50257] fp32 logits + their lse, straight from the
+    logits (no log-prob matrix), on a synthetic gpt2-sized vocabulary of byte strings (tools/tbench.py's): one
+    `TokenByteTrie.masses_from_logits` call per step through glb_trie_rows (a row of a part of the folded trie resident in
+    LDS).  Algorithmic bytes: the logits once + the result once."""
+
+    dtype_name = "f32"
+
+    def __init__(self, eng, dev, rank, out="rows", B=1024, V=V_GPT2, nbuf=3):
+        from genlm_backend_amd.tokenization import Token
+        from genlm_backend_amd.trie import TokenByteTrie
+
+        rs = np.random.default_rng(0)
+        words, seen = [], set()
+        while len(words) < V:
+            w = bytes(rs.integers(97, 123, int(rs.integers(1, 9))).astype(np.uint8))
+            if w not in seen:
+                seen.add(w)
+                words.append(w)
+        self.trie = TokenByteTrie([Token(i, w) for i, w in enumerate(words)], engine=eng)
+        self.plan = self.trie.plan()
+        g = torch.Generator(device=dev)
+        g.manual_seed(77 + rank)
+        self.bufs = [torch.randn((B, V), device=dev, generator=g) * 3.0 for _ in range(nbuf)]
+        self.lse = [eng.row_lse(x) for x in self.bufs]
+        self.out_kind, self.B, self.V, self.eng = out, B, V, eng
+        self.particles_per_step = B
+        self.sel = torch.from_numpy(rs.choice(len(self.trie), 4096, replace=False).astype(np.int32)).to(dev)
+        width = {"rows": len(self.trie), "slots": self.plan["n_slots"], "selected": 4096}[out]
+        self.kernel_bytes = B * V * 4 + B * width * 4 + B * 4
+        self.outer = []
+        self.roofline_kernel = ("(anonymous)::trie_rows_kernel x 2 launches (glb_trie_rows: a workgroup per (row, part) of the "
+                                "folded trie - leaves gathered from the row, reduced depth by depth in LDS in the reference's order, "
+                                "the part's run of the output row written; then the few nodes above the parts)")
+        self.roofline_timing = ("every call of the timed region between two hipEventRecord markers on the stream (both launches "
+                                "and, for selected nodes, the slot look-up launch inside the span)")
+
+    def step(self, i, timed):
+        x, lse = self.bufs[i % len(self.bufs)], self.lse[i % len(self.bufs)]
+        kw = {"rows": dict(layout="rows"), "slots": dict(layout="slot_rows"), "selected": dict(nodes=self.sel)}[self.out_kind]
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.trie.masses_from_logits(x, lse, **kw)
+            e1.record()
+            self.outer.append((e0, e1))
+        else:
+            self.trie.masses_from_logits(x, lse, **kw)
+
+    def kernel_times_us(self):
+        return np.array([a.elapsed_time(b) * 1e3 for a, b in self.outer])
+
+    def outer_times_us(self):
+        return self.kernel_times_us()
+
+    def config(self):
+        pl = self.plan
+        return {"workload": f"token->byte trie masses of {self.B} rows of [{self.B}, {self.V}] fp32 logits + lse -> "
+                            f"{ {'rows': 'all nodes, row-major', 'slots': 'the folded trie slots, row-major', 'selected': '4096 selected nodes'}[self.out_kind] }"
+                            f" (glb_trie_rows; {len(self.trie)} nodes, {pl['n_slots']} slots in {pl['n_parts']} parts of <= {pl['max_local']}; "
+                            "synthetic vocabulary of 1-8 letter byte strings)",
+                "rows_per_gpu": self.B, "vocab": self.V}
 
 
 class KernelWorkload:

@@ -57,6 +57,9 @@ for t in "sis --particle-kv" "api --auto-kv"; do
 done
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_trie -o f -- python3 $R/tools/tbench.py > $O/pmc_f_trie.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_trie -o w -- python3 $R/tools/tbench.py > $O/pmc_w_trie.log 2>&1
+for o in rows slots selected; do
+  python3 $R/bench.py --workload trie --trie-out $o --steps 50 --warmup 5 $([ $o = rows ] || echo --no-cpu) > $O/bench_trie_$o.json 2>> $O/bench_trie.err
+done
 python3 $R/tools/gbench.py > $O/gbench.log 2>&1
 python3 $R/tools/pmc_summary.py $O > $O/pmc_summary.log
 find $O -name "*.db" -delete 2>/dev/null || true
