@@ -54,6 +54,7 @@ sys.path.insert(0, ROOT)
 V_GPT2, V_LLAMA = 50257, 128256
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 METRIC = "particles/sec + logprob-kernel HBM GB/s (% of 8 TB/s), 1024 particles gpt2"
+_LINE_OUT = sys.stdout  # where the ONE JSON line goes (main() keeps the real stdout for it and sends everything else to stderr)
 WORKLOADS = ["sis", "sis-llama", "kernel", "kernel-llama", "api", "api-coro", "api-readme", "api-logprobs", "trie", "plumbing"]
 
 
@@ -266,6 +267,12 @@ def main():
     world_env = os.environ.get("WORLD_SIZE")
     if world_env is None and args.gpus > 1:
         spawn_ranks(args.gpus)  # does not return
+    # stdout carries the ONE JSON line and nothing else: RCCL prints a version banner to file descriptor 1 when its
+    # first communicator is made - everything but the line goes to stderr from here on
+    global _LINE_OUT
+    sys.stdout.flush()
+    _LINE_OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(world_env or "1")
@@ -446,7 +453,7 @@ def main():
             }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(workload, args.cpu_sample)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=_LINE_OUT, flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
@@ -504,7 +511,7 @@ def plumbing(args, rank, world, dist):
                           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "none", "data": "synthetic",
                           "config": {"workload": "plumbing self-test on CPU/gloo"},
-                          "rccl_ranks": world if dist is not None else None}), flush=True)
+                          "rccl_ranks": world if dist is not None else None}), file=_LINE_OUT, flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
