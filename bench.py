@@ -256,6 +256,12 @@ def main():
                     help="kernel workloads: one bit mask PER PARTICLE (GLB_MASK_BITS, n_masks == n_particles: what a grammar gives), "
                          "handed over raw every call - the call brings them into the kernels' layout itself; sis workloads: "
                          "one mask per particle, every particle its own reduction unit")
+    ap.add_argument("--logits", choices=["gaussian", "peaked"], default="gaussian",
+                    help="kernel workloads: N(0, 3^2) rows (default) or real-shaped rows - top-1 probability 0.9 over a Zipf tail, "
+                         "the top token forbidden by the row's mask in a third of the rows (the low-mass re-reduction path)")
+    ap.add_argument("--mask", choices=["random", "eos-only"], default="random",
+                    help="kernel workloads: two shared masks forbidding a random third of the vocabulary (default), or the README's "
+                         "EOS-only mask (README.md:63-66: one allowed token) on every row")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="--gpus N on a box with ONE GPU: every rank computes on cuda:0 and the exchange goes over gloo through "
                          "host memory (RCCL wants a GPU per rank) - a rehearsal of the multi-rank code, not a measurement")
@@ -323,7 +329,8 @@ def main():
     if workload == "trie":
         runner = TrieWorkload(eng, dev, rank, out=args.trie_out)
     elif workload in ("kernel", "kernel-llama"):
-        runner = KernelWorkload(eng, dev, rank, world, dist, llama=workload == "kernel-llama", per_row_masks=args.per_row_masks)
+        runner = KernelWorkload(eng, dev, rank, world, dist, llama=workload == "kernel-llama", per_row_masks=args.per_row_masks,
+                                logits=args.logits, mask_mode=args.mask)
     elif workload in ("api", "api-coro", "api-readme", "api-logprobs"):
         runner = ApiWorkload(eng, dev, rank, world, dist, logprobs=workload == "api-logprobs", coro=workload == "api-coro",
                              auto_kv=args.auto_kv, readme=workload == "api-readme", llm_gather=args.llm_gather)
@@ -584,7 +591,8 @@ class KernelWorkload:
     """Fused step only: [1024, 50257] fp32 (or [512, 128256] bf16) logits, two shared {0,-inf} masks prepared once
     (like the README's two masks), mask ids per row, in-kernel Philox."""
 
-    def __init__(self, eng, dev, rank, world, dist, llama=False, nbuf=4, per_row_masks=False):
+    def __init__(self, eng, dev, rank, world, dist, llama=False, nbuf=4, per_row_masks=False, logits="gaussian",
+                 mask_mode="random"):
         self.eng, self.dev, self.rank, self.world, self.dist = eng, dev, rank, world, dist
         g = torch.Generator(device=dev)
         g.manual_seed(1234 + rank)
@@ -592,11 +600,19 @@ class KernelWorkload:
         self.B, self.V, self.llama = B, V, llama
         self.dtype_name = "bf16" if llama else "f32"
         self.particles_per_step = B
-        self.bufs = [(torch.randn((B, V), device=dev, generator=g) * 3.0).to(dt) for _ in range(nbuf)]
         self.per_row_masks = per_row_masks
+        self.logits_kind, self.mask_mode = logits, mask_mode
         n_masks = B if per_row_masks else 2
-        maskf = torch.where(torch.rand((n_masks, V), device=dev, generator=g) < 1 / 3, float("-inf"), 0.0)
-        maskf[:, 0] = 0.0
+        if mask_mode == "eos-only":  # README.md:63-66 `eos_one_hot.log()`: one allowed token
+            maskf = torch.full((n_masks, V), float("-inf"), device=dev)
+            maskf[:, V - 1] = 0.0
+        else:
+            maskf = torch.where(torch.rand((n_masks, V), device=dev, generator=g) < 1 / 3, float("-inf"), 0.0)
+            maskf[:, 0] = 0.0
+        if logits == "peaked":
+            self.bufs = [self._peaked_rows(B, V, g, maskf).to(dt) for _ in range(nbuf)]
+        else:
+            self.bufs = [(torch.randn((B, V), device=dev, generator=g) * 3.0).to(dt) for _ in range(nbuf)]
         self.bits, _ = eng.mask_to_bits(maskf)
         del maskf
         self.masks = None if per_row_masks else eng.prepare_masks(self.bits, V, dt)
@@ -617,6 +633,26 @@ class KernelWorkload:
         else:
             self.plans = [eng.step_plan(x, mask=self.masks, row_mask_id=self.mask_id, rng_mode=1, seed=1234, offset=0,
                                         particle_base=rank * B, out=self.out) for x in self.bufs]
+
+    def _peaked_rows(self, B, V, g, maskf, p_top=0.9, zipf=1.1):
+        """Real-shaped next-token rows: one token holds `p_top` of the mass, the others fall off as rank^-zipf in a random
+        order; in every third row the top token sits where the row's mask (row % n_masks) forbids it - a model that is
+        sure of a token the constraint rules out, constrained decoding's everyday case -, elsewhere where it is allowed."""
+        dev = self.dev
+        rank = torch.argsort(torch.rand((B, V), device=dev, generator=g), dim=1) + 1  # a permutation of 1..V per row
+        x = -zipf * torch.log(rank.to(torch.float32))
+        tail = float((torch.arange(2, V + 1, dtype=torch.float64) ** -zipf).sum())
+        top_logit = float(np.log(p_top / (1.0 - p_top) * tail))
+        rows = torch.arange(B, device=dev)
+        top = (rank == 1).to(torch.int32).argmax(dim=1)
+        allowed = maskf[rows % maskf.shape[0]] == 0  # [B, V]
+        want_forbidden = (rows % 3 == 0) & (~allowed).any(dim=1)
+        score = torch.rand((B, V), device=dev, generator=g)
+        target = torch.where(want_forbidden[:, None], ~allowed, allowed).to(torch.float32) * (1.0 + score)
+        col = target.argmax(dim=1)  # a random column of the wanted kind
+        x[rows, top] = x[rows, col]
+        x[rows, col] = top_logit
+        return x
 
     def step(self, i, timed):
         plan = self.plans[i % len(self.plans)]
@@ -651,8 +687,13 @@ class KernelWorkload:
             "1024 particles x gpt2 vocab 50257, fp32 logits [1024,50257]"
         masks = (f"{self.B} bit masks, one per particle (GLB_MASK_BITS, handed over raw: the call's own mask_prepare launch is "
                  "inside the timed launch span)") if self.per_row_masks else "2 shared bit masks (prepared once)"
-        return {"workload": f"fused step only: {shape} ld=V, {masks}, Philox draw, 4 rotating logits buffers",
-                "particles_per_gpu": self.B, "vocab": self.V, "rng": "philox"}
+        if self.mask_mode == "eos-only":
+            masks += ", EOS-only (one allowed token, README.md:63-66) on every row"
+        rows = ("N(0, 3^2) logits" if self.logits_kind == "gaussian" else
+                "peaked logits (top-1 p = 0.9 over a Zipf(1.1) tail in random order; the top token forbidden by the row's mask in "
+                "every third row)")
+        return {"workload": f"fused step only: {shape} ld=V, {rows}, {masks}, Philox draw, 4 rotating logits buffers",
+                "particles_per_gpu": self.B, "vocab": self.V, "rng": "philox", "logits": self.logits_kind, "mask": self.mask_mode}
 
 
 class ApiWorkload:

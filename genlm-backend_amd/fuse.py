@@ -1,0 +1,131 @@
+"""A private view of the caller's HuggingFace model for this backend's forwards.
+
+The reference leaves the model it is handed alone (hf.py:114-140).  Earlier rounds rewrote activation modules of
+`hf_model` and re-pointed `hf_model.config._attn_implementation` in place; now `AsyncAmdLM` runs its forwards on a
+**shadow** of the module tree: every module is a shallow copy (`copy.copy`) that SHARES its `_parameters` / `_buffers`
+dictionaries with the original - the same weights, also after the caller replaces them (`model.to(...)`,
+`load_state_dict`) - but has its own `_modules` table and its own copy of the configuration.  Whatever is swapped below
+happens in the shadow only; the caller's model, its configuration and its forward are never touched, so two backends over
+one model, or a foreign thread running `hf_model(...)`, see exactly the model they built.
+
+What the shadow swaps (PyTorch ops only - no kernels of this library inside the transformer body except attention):
+  * GPT-2's `gelu_new` spelled as eight elementwise ops      -> `torch.nn.GELU(approximate="tanh")`     (one kernel)
+  * Llama-family RMSNorm spelled as pow / mean / add / rsqrt / mul / two casts / mul (hf modeling_llama.py:52-67)
+                                                             -> `torch.nn.functional.rms_norm`          (one kernel)
+  * Llama-family rotary embedding spelled as slice / neg / cat / mul / mul / add per tensor (modeling_llama.py:130-160)
+                                                             -> roll + mul + addcmul on the projection's own layout
+  * the attention interface                                  -> kv.py's "glb" entry (glb_short_attention /
+                                                                glb_slab_attention where they apply, SDPA otherwise)
+Same functions, different rounding (float32 inside the fused ops, one rounding at the end): the reference's goldens hold
+within 1e-4 with identical tokens (tests/test_host_cpu.py, tests/test_host_gpu.py).
+"""
+import copy
+import types
+
+import torch
+
+RMSNORM_CLASSES = ("LlamaRMSNorm", "MistralRMSNorm", "Qwen2RMSNorm", "Qwen3RMSNorm")  # x * rsqrt(mean(x^2) + eps) * weight
+ROPE_ATTENTION_CLASSES = ("LlamaAttention",)
+
+
+def shadow_model(model):
+    """Shallow structural copy of a module tree: new module objects and `_modules` tables, shared parameter / buffer
+    tables, one private copy of the configuration (modules that referenced the original configuration reference the copy)."""
+    cfg = getattr(model, "config", None)
+    new_cfg = copy.copy(cfg) if cfg is not None else None
+    memo = {}
+
+    def walk(mod):
+        got = memo.get(id(mod))
+        if got is not None:
+            return got
+        new = copy.copy(mod)
+        memo[id(mod)] = new
+        new._modules = {name: (walk(child) if child is not None else None) for name, child in mod._modules.items()}
+        if cfg is not None and new.__dict__.get("config") is cfg:
+            new.__dict__["config"] = new_cfg
+        return new
+
+    return walk(model)
+
+
+class FusedRMSNorm(torch.nn.Module):
+    """`weight * (x * rsqrt(mean(x^2) + eps))` as one `rms_norm` call; shares the original module's parameter table."""
+
+    def __init__(self, src):
+        super().__init__()
+        self._parameters = src._parameters
+        self.eps = float(src.variance_epsilon)
+
+    def forward(self, hidden_states):
+        return torch.nn.functional.rms_norm(hidden_states, (hidden_states.shape[-1],), self.weight, self.eps)
+
+    def extra_repr(self):
+        return f"{tuple(self.weight.shape)}, eps={self.eps} (fused)"
+
+
+def _rope(x, cos, sin_signed, half):
+    """x [B, T, H, D] (the projection's own layout), cos / sin_signed [B, T, 1, D].  x * cos + rotate_half(x) * sin with
+    rotate_half(x) * sin = roll(x, D/2) * (sin with its first half negated): three kernels instead of six."""
+    return torch.addcmul(x * cos, torch.roll(x, half, -1), sin_signed)
+
+
+def _llama_attention_forward(self, hidden_states, position_embeddings=None, attention_mask=None, past_key_values=None,
+                             **kwargs):
+    """modeling_llama.py:243-281 with the rotary embedding applied before the head transpose (see `_rope`)."""
+    from transformers.modeling_utils import ALL_ATTENTION_FUNCTIONS
+    from transformers.models.llama.modeling_llama import eager_attention_forward
+
+    input_shape = hidden_states.shape[:-1]
+    hidden_shape = (*input_shape, -1, self.head_dim)
+    q = self.q_proj(hidden_states).view(hidden_shape)
+    k = self.k_proj(hidden_states).view(hidden_shape)
+    v = self.v_proj(hidden_states).view(hidden_shape).transpose(1, 2)
+    cos, sin = position_embeddings
+    ss = getattr(sin, "_glb_signed", None)
+    half = cos.shape[-1] // 2
+    if ss is None:
+        ss = torch.cat((-sin[..., :half], sin[..., half:]), dim=-1)
+    cos, ss = cos.unsqueeze(2), ss.unsqueeze(2)
+    q = _rope(q, cos, ss, half).transpose(1, 2)
+    k = _rope(k, cos, ss, half).transpose(1, 2)
+    if past_key_values is not None:
+        k, v = past_key_values.update(k, v, self.layer_idx)
+    attention_interface = ALL_ATTENTION_FUNCTIONS.get_interface(self.config._attn_implementation, eager_attention_forward)
+    attn_output, attn_weights = attention_interface(self, q, k, v, attention_mask,
+                                                    dropout=0.0 if not self.training else self.attention_dropout,
+                                                    scaling=self.scaling, **kwargs)
+    attn_output = attn_output.reshape(*input_shape, -1).contiguous()
+    return self.o_proj(attn_output), attn_weights
+
+
+def _rotary_forward_signed(self, x, position_ids):
+    """The rotary module's own forward, its sine tagged with the half-negated copy `_rope` multiplies the rolled tensor
+    by (made once per forward instead of once per layer)."""
+    cos, sin = type(self).forward(self, x, position_ids)
+    half = sin.shape[-1] // 2
+    sin._glb_signed = torch.cat((-sin[..., :half], sin[..., half:]), dim=-1)
+    return cos, sin
+
+
+def fuse_shadow(shadow, activations=True):
+    """Swap the decomposed activations / norms / rotary embedding of a SHADOW tree (never call this on a caller's model).
+    Returns the names of what was swapped."""
+    done = []
+    if not activations:
+        return done
+    for mod in list(shadow.modules()):
+        for name, child in list(mod._modules.items()):
+            kind = type(child).__name__
+            if kind == "NewGELUActivation":
+                mod._modules[name] = torch.nn.GELU(approximate="tanh")
+                done.append("gelu_new")
+            elif kind in RMSNORM_CLASSES and hasattr(child, "variance_epsilon") and "weight" in child._parameters:
+                mod._modules[name] = FusedRMSNorm(child)
+                done.append("rms_norm")
+            elif kind in ROPE_ATTENTION_CLASSES:
+                child.forward = types.MethodType(_llama_attention_forward, child)
+                done.append("rope")
+            elif kind == "LlamaRotaryEmbedding":
+                child.forward = types.MethodType(_rotary_forward_signed, child)
+    return done

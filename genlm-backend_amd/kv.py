@@ -16,13 +16,13 @@ from transformers.cache_utils import Cache, CacheLayerMixin
 
 
 # ---- the attention kernels of the path behind transformers' attention interface -----------------------------------------
-# Registered under one name; AsyncAmdLM points its model's configuration at it.  Two forwards of the hot path are served
-# by this library's kernels - the in-place one-token forward over KV slab rows (glb_slab_attention: append fused, no mask
-# tensor) and the padded batches of short contexts (glb_short_attention: a dozen tokens per row, where the library SDPA
-# kernels spend a fifth of the step) - and everything else (long sequences, dropout, exotic masks, CPU runs) goes to
-# transformers' own SDPA path exactly as before.
-_ACTIVE = None     # the SlabKV whose in-place forward is running (set by SlabForward._run)
-_ENGINES = {}      # id(model config) -> HipEngine (set by use_glb_attention)
+# Registered under one name; AsyncAmdLM points the configuration of its SHADOW of the model (fuse.shadow_model - never the
+# caller's own configuration) at it.  Two forwards of the hot path are served by this library's kernels - the in-place
+# one-token forward over KV slab rows (glb_slab_attention: append fused, no mask tensor) and the padded batches of short
+# contexts (glb_short_attention: a dozen tokens per row, where the library SDPA kernels spend a fifth of the step) - and
+# everything else (long sequences, dropout, training / autograd, exotic masks, CPU runs) goes to transformers' own SDPA
+# path exactly as before.  No module-level state: the engine rides on the shadow configuration (`_glb_engine`), the slab
+# layer of a running in-place forward on the key tensor `Cache.update` returned (`_glb_layer`).
 _ATTN_NAME = "glb"
 SHORT_ATTENTION_MAX = 4096  # q_len * k_len up to which glb_short_attention is used
 
@@ -30,15 +30,23 @@ SHORT_ATTENTION_MAX = 4096  # q_len * k_len up to which glb_short_attention is u
 def _glb_attention_forward(module, query, key, value, attention_mask, dropout=0.0, scaling=None, **kwargs):
     from transformers.integrations.sdpa_attention import sdpa_attention_forward
 
-    pkv = _ACTIVE
-    layer = None if pkv is None else pkv.layers[module.layer_idx]
-    if layer is not None and layer._new_k is not None and key is layer.keys and query.shape[2] == 1:
+    layer = getattr(key, "_glb_layer", None)
+    if layer is not None and layer._new_k is not None:
+        # an in-place forward whose append is this kernel's job: the new token's K / V are only in the stash
+        if key is not layer.keys or value is not layer.values or query.shape[2] != 1:
+            raise RuntimeError("glb_slab_attention: the attention module changed the key / value tensors the KV slab handed "
+                               "out (or feeds more than one token): the new token was never appended - run this model with "
+                               "SlabForward(fused_attention=False)")
         k_new, v_new, layer._new_k, layer._new_v = layer._new_k, layer._new_v, None, None
+        o = layer.owner
         scale = scaling if scaling is not None else query.shape[-1] ** -0.5
-        return pkv.engine.slab_attention(query, k_new, v_new, layer.keys, layer.values, pkv.pos, scale), None
-    eng = _ENGINES.get(id(getattr(module, "config", None)))
+        return o.engine.slab_attention(query, k_new, v_new, layer.keys, layer.values, o.pos, scale), None
+    eng = getattr(getattr(module, "config", None), "_glb_engine", None)
     Lq, Lk = query.shape[2], key.shape[2]
-    if (eng is not None and query.is_cuda and not dropout and Lq * Lk <= SHORT_ATTENTION_MAX and Lk >= Lq
+    # the kernels write into fresh tensors outside autograd: a forward that may be differentiated keeps the SDPA path
+    wants_grad = torch.is_grad_enabled() and (query.requires_grad or key.requires_grad or value.requires_grad)
+    if (eng is not None and query.is_cuda and not dropout and not wants_grad and not getattr(module, "training", False)
+            and Lq * Lk <= SHORT_ATTENTION_MAX and Lk >= Lq
             and eng.slab_attention_supports(query.dtype, query.shape[-1]) and key.dtype == query.dtype == value.dtype
             and query.stride(3) == 1 and key.stride(3) == 1 and value.stride(3) == 1
             and kwargs.get("is_causal", True) is not False and not kwargs.get("softcap") and not kwargs.get("sliding_window")
@@ -62,25 +70,20 @@ def _register_attention():
         ALL_MASK_ATTENTION_FUNCTIONS.register(_ATTN_NAME, ALL_MASK_ATTENTION_FUNCTIONS["sdpa"])
 
 
-def use_glb_attention(model, engine):
-    """Point `model` (a transformers model whose attention goes through the attention interface as "sdpa") at this
-    library's attention kernels; returns whether it was done.  Undo with `restore_attention(model)`."""
-    cfg = getattr(model, "config", None)
+def use_glb_attention(shadow, engine):
+    """Point a SHADOW of a transformers model (fuse.shadow_model: its configuration is a private copy) whose attention goes
+    through the attention interface as "sdpa" at this library's attention kernels; returns whether it was done."""
+    cfg = getattr(shadow, "config", None)
+    if cfg is not None and getattr(cfg, "_attn_implementation", None) == _ATTN_NAME:
+        return getattr(cfg, "_glb_engine", None) is engine
     if (cfg is None or not hasattr(engine, "short_attention") or getattr(cfg, "_attn_implementation", None) != "sdpa"
             or getattr(cfg, "attn_logit_softcapping", None) or getattr(cfg, "sliding_window", None)
             or getattr(cfg, "scale_attn_by_inverse_layer_idx", False)):
         return False
     _register_attention()
     cfg._attn_implementation = _ATTN_NAME
-    _ENGINES[id(cfg)] = engine
+    cfg._glb_engine = engine
     return True
-
-
-def restore_attention(model):
-    cfg = getattr(model, "config", None)
-    if cfg is not None and getattr(cfg, "_attn_implementation", None) == _ATTN_NAME:
-        cfg._attn_implementation = "sdpa"
-        _ENGINES.pop(id(cfg), None)
 
 
 class _SlabLayer(CacheLayerMixin):
@@ -111,6 +114,7 @@ class _SlabLayer(CacheLayerMixin):
             raise ValueError("SlabKV takes one new token for every particle per forward")
         if o.fused_attention:  # glb_slab_attention appends: it gets the new K / V where the projection left them
             self._new_k, self._new_v = key_states, value_states
+            self.keys._glb_layer = self  # (how the attention entry finds this layer: no module-level state)
             return self.keys, self.values
         o.engine.kv_append(self.keys, key_states, o.pos)
         o.engine.kv_append(self.values, value_states, o.pos)
@@ -196,6 +200,7 @@ class _SharedLayer(_SlabLayer):
                 raise ValueError("an in-place forward takes one token for every slab row")
             if o.fused_attention:
                 self._new_k, self._new_v = key_states, value_states
+                self.keys._glb_layer = self
                 return self.keys, self.values
             eng.kv_append(self.keys, key_states, o.pos)
             eng.kv_append(self.values, value_states, o.pos)
@@ -280,22 +285,30 @@ class SlabForward:
         # goes through transformers' attention interface with plain softmax(q k^T * scale) v semantics on a HIP device
         cfg = getattr(body, "config", None)
         k0 = pkv.layers[0].keys if pkv.layers and getattr(pkv.layers[0], "is_initialized", False) else None
+        # (the body is AsyncAmdLM's shadow of the model, already pointed at the "glb" attention entry when glb_attention is on;
+        # a body that is not - the caller's own model, glb_attention=False - keeps appends + mask + SDPA)
         self.fused = bool(fused_attention and cfg is not None and k0 is not None and k0.is_cuda
                           and hasattr(pkv.engine, "slab_attention")
                           and pkv.engine.slab_attention_supports(k0.dtype, k0.shape[-1])
-                          and (getattr(cfg, "_attn_implementation", None) == _ATTN_NAME or use_glb_attention(body, pkv.engine)))
+                          and getattr(cfg, "_attn_implementation", None) == _ATTN_NAME
+                          and getattr(cfg, "_glb_engine", None) is pkv.engine)
 
     def _run(self, ids, pos):
-        global _ACTIVE
         pkv = self.pkv
         pkv.set_forward_in_place(pos)
         if self.fused:
-            pkv.fused_attention, _ACTIVE = True, pkv
+            pkv.fused_attention = True
             try:  # (no mask: the kernel attends to positions 0 .. pos[r] and nothing else)
                 out = self.body(input_ids=ids, position_ids=pos.view(-1, 1).long(), attention_mask=None,
                                 past_key_values=pkv, use_cache=True)
             finally:
-                pkv.fused_attention, _ACTIVE = False, None
+                pkv.fused_attention = False
+                stale = [i for i, ly in enumerate(pkv.layers) if ly._new_k is not None]
+                for i in stale:
+                    pkv.layers[i]._new_k = pkv.layers[i]._new_v = None
+            if stale:  # an attention module that bypassed the attention interface: its token was never appended
+                raise RuntimeError(f"glb_slab_attention was not reached in layers {stale}: the new token's K / V were not "
+                                   "appended - run this model with SlabForward(fused_attention=False)")
             return out.last_hidden_state[:, 0]
         out = self.body(input_ids=ids, position_ids=pos.view(-1, 1).long(), attention_mask=pkv.attention_mask(pos),
                         past_key_values=pkv, use_cache=True)

@@ -143,32 +143,6 @@ class AsyncAmdLM(AsyncLM):
         return cls(mod, tokenizer, **kwargs)
 
     @staticmethod
-    def _fuse_activations(model):
-        """transformers spells GPT-2's `gelu_new` as eight elementwise torch ops (a fifth of the forward's GPU time at
-        1024 x 13 tokens); `torch.nn.GELU(approximate="tanh")` is the same function in one kernel (same formula,
-        results agree to rounding, not bit for bit).  Returns the replaced modules so the change can be undone."""
-        replaced = []
-        for mod in model.modules():
-            for name, child in list(mod.named_children()):
-                if isinstance(child, torch.nn.Module) and type(child).__name__ == "NewGELUActivation":
-                    setattr(mod, name, torch.nn.GELU(approximate="tanh"))
-                    replaced.append((mod, name, child))
-        return replaced
-
-    def restore_attention(self):
-        """Undo `glb_attention` on the wrapped HuggingFace model (its configuration is patched in place)."""
-        from .kv import restore_attention
-
-        restore_attention(self.model)
-        self.glb_attention = False
-
-    def restore_activations(self):
-        """Undo `fuse_activations` on the wrapped HuggingFace model (it is patched in place)."""
-        for mod, name, child in self._replaced_activations:
-            setattr(mod, name, child)
-        self._replaced_activations = []
-
-    @staticmethod
     def _post_head(config):
         """What the model's own forward applies to `lm_head(hidden)` (the reference reads `model(...).logits`, hf.py:275):
         Cohere `logit_scale`, Granite `logits_scaling`, Gemma-2 `final_logit_softcapping`.  Returned as
@@ -201,11 +175,14 @@ class AsyncAmdLM(AsyncLM):
     def __init__(self, hf_model, hf_tokenizer, batch_size=20, timeout=0.02, engine=None, fuse_activations=True,
                  kv_budget_bytes=8 << 30, logprob_budget_bytes=16 << 30, auto_kv_rows=0, auto_kv_cap=64,
                  logprob_dtype="float32", glb_attention=True):
-        """glb_attention: route the model's attention through this library's kernels where they apply (padded batches of
-        short contexts: glb_short_attention; the in-place one-token forward over KV rows: glb_slab_attention) by
-        registering them with transformers' attention interface - `hf_model.config` is pointed at them IN PLACE
-        (`restore_attention()` undoes it); everything else still runs the model's SDPA path.  False: the model is left
-        as it is.
+        """The caller's `hf_model` is never modified (hf.py:114-140 leaves it alone too): with `fuse_activations` or
+        `glb_attention` the forwards of this backend run on a private SHADOW of its module tree that shares every weight
+        (fuse.shadow_model); `self.model` stays the caller's object.
+        fuse_activations: in the shadow, GPT-2's eight-op `gelu_new` becomes one GELU kernel, Llama-family RMSNorm one
+        `rms_norm` call, the rotary embedding three elementwise ops per tensor instead of six (same functions, different
+        rounding).  glb_attention: the shadow's attention goes through this library's kernels where they apply (padded
+        batches of short contexts: glb_short_attention; the in-place one-token forward over KV rows: glb_slab_attention),
+        everything else still runs the SDPA path.  Both False: the forwards run on `hf_model` itself.
         logprob_dtype: "float32" (default: every row `next_token_logprobs` returns is float32, whatever the checkpoint's
         dtype) or "model" - rows in the model's own dtype, what the reference returns (cache.py:96 keeps the dtype; for a
         bfloat16 checkpoint a third fewer bytes per materialised row: glb_log_softmax_rows' out_dtype).
@@ -230,19 +207,24 @@ class AsyncAmdLM(AsyncLM):
         self.timeout = timeout
         self.timer = None
         self.model.eval()
-        # fuse_activations=True rewrites GPT-2's activation modules of `hf_model` IN PLACE (numerics: same formula,
-        # different rounding; `restore_activations()` undoes it); pass False to leave the model untouched
-        self._replaced_activations = self._fuse_activations(self.model) if fuse_activations else []
         self.glb_attention = False
-        if glb_attention and self.device.type == "cuda":
-            from .kv import use_glb_attention
+        self.fused = []
+        self._net = self.model  # what this backend's forwards run on: the caller's model, or its shadow
+        want_attention = bool(glb_attention) and self.device.type == "cuda"
+        if fuse_activations or want_attention:
+            from .fuse import fuse_shadow, shadow_model
 
-            self.glb_attention = use_glb_attention(self.model, self.engine)
-        self._head = self.model.get_output_embeddings()
+            self._net = shadow_model(self.model)
+            self.fused = fuse_shadow(self._net, activations=bool(fuse_activations))
+            if want_attention:
+                from .kv import use_glb_attention
+
+                self.glb_attention = use_glb_attention(self._net, self.engine)
+        self._head = self._net.get_output_embeddings()
         if self._head is None:
             raise NotImplementedError(f"{type(hf_model).__name__} has no output embedding (get_output_embeddings() is None)")
         self._head_mult, self._head_cap = self._post_head(self.model.config)
-        self._body = self.model.base_model
+        self._body = self._net.base_model
         from .kv import PrefixLRU
 
         self._kv_tokens = {}  # id(trie node) -> the prefix's token ids (for the device prefix table)

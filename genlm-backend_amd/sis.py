@@ -264,6 +264,7 @@ class DeviceSIS:
         # (the slabs stay - and the hipGraphs captured over them; shared rows start from an empty block table, private rows
         # are refilled by step 0's encoding)
         self._head_cache = None
+        self._fwd_tokens = None  # tokens the transformer body was fed in the running step, when that is not n_unique x l_max
         self._noise_groups = None  # parity draws: the dedup grouping the noise rows are dealt by (set per step)
         self._kv_stale = None  # bool [N]: rows whose KV has to be rebuilt from the context (ancestor on another rank)
         self._row_of_d = torch.full((self.N,), -1, dtype=torch.int32, device=self.dev)  # shared KV: particle -> slab row (-1: none)
@@ -360,6 +361,7 @@ class DeviceSIS:
         st["unkept_rows"] += n_unkept
         st["steps"] += 1
         logits_parts = []
+        fed_a = 0  # tokens the one-token forward is fed: its live rows, or every slab row when it runs in place
         if nA:
             if n_copied:
                 self.pkv.copy_rows(plan["copy_src"], plan["copy_len"])
@@ -375,6 +377,7 @@ class DeviceSIS:
                 hidden = self._slab_fwd(ids, pos_d)
                 logits_parts.append(llm._lm_head(hidden.index_select(0, plan["rows_a"][:nA].long())))
                 st["in_place_steps"] += 1
+                fed_a = R
             else:
                 pos_a = plan["pos_a"][:nA].contiguous()
                 ids = self.contexts[plan["ctx_a"][:nA].long(), pos_a.long()].view(-1, 1).long()
@@ -382,6 +385,7 @@ class DeviceSIS:
                 out = llm._body(input_ids=ids, position_ids=pos_a.view(-1, 1).long(),
                                 attention_mask=self.pkv.attention_mask(pos_a), past_key_values=self.pkv, use_cache=True)
                 logits_parts.append(llm._lm_head(out.last_hidden_state[:, 0]))
+                fed_a = nA
         if nB:
             sel = plan["ctx_b"][:nB].contiguous()
             ids, am, pos, last = eng.gather_padded(ctx_flat, self.starts, lengths_eff, sel, nB, None, 0, 0, l_max_b)
@@ -402,6 +406,7 @@ class DeviceSIS:
                 len_full[slot] = lengths_eff[sel.long()]
                 src_full[R] = -1
                 self.pkv.fill_rows(src, src_full[:R].contiguous(), len_full[:R].contiguous())
+        self._fwd_tokens = fed_a + nB * l_max_b
         logits = logits_parts[0] if len(logits_parts) == 1 else torch.cat(logits_parts)
         self._rep = torch.cat([plan["ctx_a"][:nA], plan["ctx_b"][:nB]])  # the context behind every logits row
         self._noise_groups = group_of  # parity draws follow the reference's resolution order: by dedup group
@@ -447,7 +452,9 @@ class DeviceSIS:
                               self.cap, hashes=self.hashes)
         self.t += 1
         self.max_len_now = min(self.max_len_now + 1, self.cap)
-        self.last_stats = dict(n_unique=U, n_active=n_active, l_max=l_max, n_rows=U)
+        ft = self._fwd_tokens if self._fwd_tokens is not None else U * l_max
+        self._fwd_tokens = None
+        self.last_stats = dict(n_unique=U, n_active=n_active, l_max=l_max, n_rows=U, fwd_tokens=ft, head_rows=logits.shape[0])
         self._exchange()
         if self.resample_ess is not None:
             self._maybe_resample()
@@ -787,6 +794,12 @@ class SisBenchWorkload:
         self._bytes = []
         self.unique_hist = []
         self.fed_hist = []
+        self.flops_hist = []
+        # GEMM work of a step, analytically: 2 x (weights of the body's linear layers) per token fed + 2 x d x V per row
+        # through the output embedding (tools/gemm_table.py divides by the Tensile kernels' time in a rocprofv3 trace)
+        body = self.llm._body
+        self._lin_w = sum(m.weight.numel() for m in body.modules() if type(m).__name__ in ("Linear", "Conv1D"))
+        self._head_w = self.llm._head.weight.numel()
         # set-up, not measurement: one untimed pass over the loop's ten batch shapes (context lengths 8..17) so that
         # GEMM algorithm selection and allocator growth happen before bench.py's own warm-up / timed steps
         for _ in range(max_tokens):
@@ -805,6 +818,8 @@ class SisBenchWorkload:
             self._bytes.append(U * self.V * self.elem + n_masks * ((self.V + 31) // 32) * 4 + self.N * 8)
             self.unique_hist.append(U)
             self.fed_hist.append(int(self.sis.last_stats["l_max"]))  # tokens per forward row of this step
+            ls = self.sis.last_stats
+            self.flops_hist.append(2.0 * self._lin_w * ls["fwd_tokens"] + 2.0 * self._head_w * ls["head_rows"])
 
     def _collect(self):
         self._events.extend(self.sis.kernel_events)
@@ -833,5 +848,6 @@ class SisBenchWorkload:
                 "mean_unique_contexts_per_step": float(np.mean(self.unique_hist)) if self.unique_hist else None,
                 # what the forward is fed per distinct context, and what the cached prompt KV saves
                 "mean_tokens_fed_per_context": float(np.mean(self.fed_hist)) if self.fed_hist else None,
+                "gemm_flops_per_step": float(np.mean(self.flops_hist)) if self.flops_hist else None,
                 **({"prefixed_tokens_per_context": 8} if self.prefix_kv else {}),
                 **({"kv_rows": {k: v for k, v in self.sis.kv_stats.items()}} if self.particle_kv else {})}

@@ -416,28 +416,68 @@ def test_logits_include_the_models_post_head_transform(family):
     assert np.abs(asyncio.run(m.next_token_logprobs(ids)).numpy() - want).max() < TOL
 
 
-def test_activation_fusion_is_optional_and_reversible(gold):
-    from transformers import GPT2Config, GPT2LMHeadModel
+def test_the_callers_model_is_never_modified(gold):
+    """hf.py:114-140 leaves the model it is handed alone; so does this backend: fused activations / norms / rotary embedding
+    and the attention entry live in a private shadow of the module tree that shares the weights (fuse.shadow_model).  Two
+    backends over one model, and the model's own forward from a foreign thread while a backend is evaluating, see the model
+    as it was built."""
+    import threading
+
+    from transformers import GPT2Config, GPT2LMHeadModel, LlamaConfig, LlamaForCausalLM
 
     import genlm_backend_amd  # noqa: F401
     from genlm_backend_amd.llm import AsyncAmdLM
 
     cfg = ast.literal_eval(bytes(gold["config_json"]).decode())
-    model = GPT2LMHeadModel(GPT2Config(**cfg)).eval()
-    kinds = lambda: {type(c).__name__ for c in model.modules()}
-    before = kinds()
-    AsyncAmdLM(model, None, engine=CpuOracleEngine(), fuse_activations=False)
-    assert kinds() == before
-    m = AsyncAmdLM(model, None, engine=CpuOracleEngine())
-    if "NewGELUActivation" in before:
-        assert "NewGELUActivation" not in kinds()
-        ids = torch.tensor([[3, 1, 4, 1, 5]])
+    torch.manual_seed(3)
+    llama = LlamaForCausalLM(LlamaConfig(vocab_size=cfg["vocab_size"], hidden_size=32, intermediate_size=64, num_hidden_layers=2,
+                                         num_attention_heads=4, num_key_value_heads=2, head_dim=8, max_position_embeddings=64,
+                                         bos_token_id=1, eos_token_id=2)).eval()
+    for model in (GPT2LMHeadModel(GPT2Config(**cfg)).eval(), llama):
+        kinds = lambda: [type(c).__name__ for c in model.modules()]
+        before, impl = kinds(), model.config._attn_implementation
+        fwd_attrs = [("forward" in c.__dict__) for c in model.modules()]
+        ids = torch.tensor([[3, 1, 4, 1, 5, 9, 2, 6]])
         with torch.no_grad():
-            fused = model(ids).logits
-        m.restore_activations()
-        assert kinds() == before
+            want = model(ids).logits
+        plain = AsyncAmdLM(model, None, engine=CpuOracleEngine(), fuse_activations=False, glb_attention=False)
+        assert plain._net is model and plain.fused == []
+        a = AsyncAmdLM(model, None, engine=CpuOracleEngine())
+        b = AsyncAmdLM(model, None, engine=CpuOracleEngine())
+        assert a._net is not model and a._net is not b._net and a.fused
+        assert kinds() == before and model.config._attn_implementation == impl
+        assert [("forward" in c.__dict__) for c in model.modules()] == fwd_attrs
+        assert a._net.config is not model.config
+        # the shadow shares the weights: same log-probs as the caller's model (different rounding only), from both backends
+        ref = torch.log_softmax(want[0, -1], -1).numpy()
+        for m in (plain, a, b):
+            assert np.abs(m.next_token_logprobs_uncached(ids[0].tolist()).numpy() - ref).max() < TOL
+        # a foreign thread runs the caller's model while the backends evaluate: bit-identical to before
+        got, stop = [], threading.Event()
+
+        def foreign():
+            while not stop.is_set():
+                with torch.no_grad():
+                    got.append(model(ids).logits)
+
+        th = threading.Thread(target=foreign)
+        th.start()
+        try:
+            for _ in range(5):
+                for m in (a, b):
+                    m.clear_cache()
+                    assert np.abs(m.next_token_logprobs_sync(ids[0].tolist()).numpy() - ref).max() < TOL
+        finally:
+            stop.set()
+            th.join()
+        assert got and all(torch.equal(g, want) for g in got)
+        # weights replaced or changed in place by the caller reach the shadow
         with torch.no_grad():
-            assert (model(ids).logits - fused).abs().max() < 1e-4  # same function, different rounding
+            next(model.parameters()).mul_(1.25)
+            want2 = model(ids).logits
+        ref2 = torch.log_softmax(want2[0, -1], -1).numpy()
+        a.clear_cache()
+        assert np.abs(a.next_token_logprobs_sync(ids[0].tolist()).numpy() - ref2).max() < TOL
 
 
 def test_lazy_trie_paths_match_eager_ones():

@@ -467,6 +467,49 @@ def test_rccl_collectives_on_one_rank_change_nothing(llm, nccl_single, mode):
     assert got.cpu().tolist() == [0.0, 1.0, 2.0, 3.0]
 
 
+def test_rccl_self_exchange_of_the_calls_a_multi_gpu_run_makes(nccl_single):
+    """The RCCL calls of the N > 1 path that a one-rank run never reaches by itself (with one rank no particle changes
+    ranks, so `rows_moved == 0`): forced here as self-exchanges on DEVICE tensors through the "nccl" backend -
+    `all_to_all_single` with uneven split lists on int32 particle rows (sis._all_to_all: resample()), on bf16 5-D KV rows
+    (sis._all_to_all_any: _migrate_kv()), an empty exchange, and the float64 all_reduce(MAX) of bench.py's clock."""
+    from genlm_backend_amd.sis import _all_to_all, _all_to_all_any, _gather_all, _reduce_all
+
+    dist = nccl_single
+    assert dist.get_backend() == "nccl"
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    for rows, width in ((37, 22), (1, 3), (512, 19 + 3)):
+        send = torch.randint(-5, 1 << 30, (rows, width), dtype=torch.int32, device=dev, generator=g)
+        recv = torch.full_like(send, -7)
+        _all_to_all(dist, recv, send, [rows], [rows])
+        torch.cuda.synchronize()
+        assert torch.equal(recv, send)
+    # KV rows as _migrate_kv sends them: [rows, layers x {K, V}, heads, cap, head_dim], bf16 and fp32
+    for dt in (torch.bfloat16, torch.float32):
+        send = torch.randn((9, 2 * 3, 4, 14, 16), device=dev, generator=g).to(dt)
+        recv = torch.zeros_like(send)
+        _all_to_all_any(dist, recv, send, [9], [9])
+        torch.cuda.synchronize()
+        assert torch.equal(recv, send)
+    # nothing moves (what every step of a one-rank run would send): legal, a no-op
+    empty_s = torch.empty((0, 22), dtype=torch.int32, device=dev)
+    empty_r = torch.empty((0, 22), dtype=torch.int32, device=dev)
+    _all_to_all(dist, empty_r, empty_s, [0], [0])
+    # bench.py:366-368's max-over-ranks clock and the all-gather of log-weights (4 KiB at 1024 particles)
+    t = torch.tensor([1.2345678901234567], dtype=torch.float64, device=dev)
+    _reduce_all(dist, t, dist.ReduceOp.MAX)
+    assert float(t.item()) == 1.2345678901234567
+    mm = torch.tensor([8, -17], dtype=torch.int64, device=dev)
+    _reduce_all(dist, mm, dist.ReduceOp.MIN)
+    assert mm.cpu().tolist() == [8, -17]
+    lw = torch.randn(1025, device=dev, generator=g)
+    out = torch.empty(1025, device=dev)
+    _gather_all(dist, out, lw)
+    torch.cuda.synchronize()
+    assert torch.equal(out, lw)
+
+
 def test_engine_launches_on_its_own_device(engine, oracle):
     """HipEngine runs every entry point with ITS device current, whatever the calling thread has set (one process
     driving several GPUs).  With one visible GPU the guard is exercised through its bookkeeping: the proxy resolves and
@@ -1384,8 +1427,16 @@ def test_in_place_forward_with_fused_slab_attention_equals_sdpa(engine, family):
             h = fb(ids, pos).clone()
             want.append((h, [(lb.keys.clone(), lb.values.clone()) for lb in b.layers]))
         assert model.config._attn_implementation == "sdpa"
-        fa = SlabForward(a, body, graph=True, fused_attention=True)
-        assert fa.fused and model.config._attn_implementation == "glb"
+        # the fused arm runs on a shadow of the model pointed at the "glb" attention entry (what AsyncAmdLM builds); the
+        # caller's model and its configuration stay as they were
+        from genlm_backend_amd.fuse import shadow_model
+        from genlm_backend_amd.kv import use_glb_attention
+
+        shadow = shadow_model(model)
+        assert use_glb_attention(shadow, engine)
+        assert not SlabForward(a, body, graph=False, fused_attention=True).fused  # (the caller's own body: never fused)
+        fa = SlabForward(a, shadow.base_model, graph=True, fused_attention=True)
+        assert fa.fused and model.config._attn_implementation == "sdpa" and shadow.config._attn_implementation == "glb"
         for step, (ids, pos) in enumerate(steps):  # (the third call captures the hipGraph, later ones replay it)
             ha = fa(ids, pos).clone()
             torch.cuda.synchronize()

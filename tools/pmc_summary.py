@@ -96,10 +96,29 @@ if trie:
                    "MI355X_MICROARCH.md (calibrated there for 16-byte-per-lane streaming reads; the level kernels read 16 bytes per lane)")
     json.dump(out, open(os.path.join(root, "trie_pmc_traffic.json"), "w"), indent=1)
     print("trie", json.dumps(out, indent=1))
-for tag in ("kernel", "kernel-llama", "kernel-rowmasks", "sis", "sis-llama", "sisparticlekv", "apiautokv", "lsm", "trie"):
+def short_name(name, limit=150):
+    """Kernel names of Tensile / ATen run to several hundred characters: keep the head that identifies them (macro-tile for
+    Tensile, functor for ATen) - the NAME is cut, never the row's numbers (round 4 cut the line and lost them)."""
+    return name if len(name) <= limit else name[:limit] + "..."
+
+
+for f in sorted(glob.glob(os.path.join(root, "kstats_*"))):
+    tag = os.path.basename(f)[len("kstats_"):]
     f = first(f"kstats_{tag}/**/*kernel_stats.csv")
-    if f:
-        lines = open(f).read().splitlines()
-        ours = [ln for ln in lines[1:] if "glb::" in ln or "anonymous namespace" in ln]  # this library's kernels: all
-        keep = [lines[0]] + ours + [ln[:300] for ln in lines[1:] if ln not in ours][:20]
-        open(os.path.join(root, f"{tag}_kernel_stats.csv"), "w").write("\n".join(keep) + "\n")
+    if not f or not os.path.isdir(os.path.join(root, f"kstats_{tag}")):
+        continue
+    with open(f, newline="") as fh:
+        rows = list(csv.reader(fh))
+    head, body = rows[0], rows[1:]
+    ours = [r for r in body if "glb::" in r[0] or "anonymous namespace)::" in r[0] and "at::native" not in r[0]]
+    rest = [r for r in body if r not in ours]
+    rest.sort(key=lambda r: -float(r[2]))
+    with open(os.path.join(root, f"{tag}_kernel_stats.csv"), "w", newline="") as fh:
+        w = csv.writer(fh, quoting=csv.QUOTE_NONNUMERIC)
+        w.writerow(head)
+        for r in ours + rest[:40]:  # this library's kernels: all; the others: the 40 with the most time, numbers intact
+            w.writerow([short_name(r[0])] + [float(x) if i != 0 else x for i, x in enumerate(r[1:], 1)])
+        if len(rest) > 40:
+            tail = rest[40:]
+            w.writerow([f"({len(tail)} more kernels)", sum(float(r[1]) for r in tail), sum(float(r[2]) for r in tail), 0.0,
+                        sum(float(r[4]) for r in tail), 0.0, 0.0, 0.0])
