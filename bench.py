@@ -256,6 +256,10 @@ def main():
                     help="kernel workloads: one bit mask PER PARTICLE (GLB_MASK_BITS, n_masks == n_particles: what a grammar gives), "
                          "handed over raw every call - the call brings them into the kernels' layout itself; sis workloads: "
                          "one mask per particle, every particle its own reduction unit")
+    ap.add_argument("--rng", choices=["philox", "parity"], default="philox",
+                    help="kernel / sis workloads: in-kernel Philox draws (default), or the reference's draws - torch.multinomial's CPU "
+                         "MT19937 stream (README.md:87), generated on the device (glb_mt19937_exponential_rows) and raced against "
+                         "(GLB_RNG_NOISE): token ids identical to the reference's under a fixed seed")
     ap.add_argument("--logits", choices=["gaussian", "peaked"], default="gaussian",
                     help="kernel workloads: N(0, 3^2) rows (default) or real-shaped rows - top-1 probability 0.9 over a Zipf tail, "
                          "the top token forbidden by the row's mask in a third of the rows (the low-mass re-reduction path)")
@@ -330,7 +334,7 @@ def main():
         runner = TrieWorkload(eng, dev, rank, out=args.trie_out)
     elif workload in ("kernel", "kernel-llama"):
         runner = KernelWorkload(eng, dev, rank, world, dist, llama=workload == "kernel-llama", per_row_masks=args.per_row_masks,
-                                logits=args.logits, mask_mode=args.mask)
+                                logits=args.logits, mask_mode=args.mask, rng=args.rng)
     elif workload in ("api", "api-coro", "api-readme", "api-logprobs"):
         runner = ApiWorkload(eng, dev, rank, world, dist, logprobs=workload == "api-logprobs", coro=workload == "api-coro",
                              auto_kv=args.auto_kv, readme=workload == "api-readme", llm_gather=args.llm_gather)
@@ -341,7 +345,8 @@ def main():
                                   model="llama-3.2-1b" if workload == "sis-llama" else "gpt2",
                                   n_particles=512 if workload == "sis-llama" else 1024, n_prompts=args.prompts,
                                   resample=args.resample, force_collectives=force_coll,
-                                  kv_in_place=None if args.kv_gather else 0.75, per_particle_masks=args.per_row_masks)
+                                  kv_in_place=None if args.kv_gather else 0.75, per_particle_masks=args.per_row_masks,
+                                  rng="torch" if args.rng == "parity" else "philox")
 
     rccl_ranks = None
     if dist is not None:  # one collective before the clock starts: proves every rank is on the RCCL communicator
@@ -380,7 +385,8 @@ def main():
     # per distinct context per step instead of the reference's re-encoding; tokens proven equal to the reference's by
     # tests/test_host_gpu.py) as value_kv / ms_per_step_kv.  `value` itself stays BASELINE config 2's algorithm.
     kv_extra = None
-    if workload == "sis" and not (args.particle_kv or args.prefix_kv or args.per_row_masks or args.resample) and not args.no_kv_line:
+    if (workload == "sis" and not (args.particle_kv or args.prefix_kv or args.per_row_masks or args.resample or args.rng != "philox")
+            and not args.no_kv_line):
         from genlm_backend_amd.sis import SisBenchWorkload
 
         runner_kv = SisBenchWorkload(eng, dev, rank, world, dist, particle_kv=True, model="gpt2", n_particles=1024,
@@ -592,7 +598,7 @@ class KernelWorkload:
     (like the README's two masks), mask ids per row, in-kernel Philox."""
 
     def __init__(self, eng, dev, rank, world, dist, llama=False, nbuf=4, per_row_masks=False, logits="gaussian",
-                 mask_mode="random"):
+                 mask_mode="random", rng="philox"):
         self.eng, self.dev, self.rank, self.world, self.dist = eng, dev, rank, world, dist
         g = torch.Generator(device=dev)
         g.manual_seed(1234 + rank)
@@ -622,17 +628,31 @@ class KernelWorkload:
         self.lw = torch.zeros(B, device=dev)
         self.gathered = torch.empty(B * world, device=dev) if world > 1 else None
         self.kernel_bytes = algorithmic_bytes(B, V, 2 if llama else 4, n_masks, (V + 31) // 32)
+        self.parity = rng == "parity"
+        self.noise_src = self.noise_buf = None
+        if self.parity:
+            # torch's CPU generator on the device: one Exp(1) row per particle per step (+ B V 4 bytes read)
+            self.noise_src = eng.noise_rng(1234 + rank, V)
+            self.noise_buf = torch.empty((B, V), dtype=torch.float32, device=dev)
+            self.kernel_bytes += B * V * 4
+            self.roofline_kernel = ("(anonymous)::mt_jump_kernel x 2 + mt_rows_kernel (glb_mt19937_exponential_rows: torch's CPU MT19937 "
+                                    "stream entered at every particle's row, [B, V] float32 noise written) + glb::chunk_stats_kernel / "
+                                    "finish_kernel in GLB_RNG_NOISE mode (the race p / E over the masked row)")
+            self.roofline_timing = ("every call of the timed region between two hipEventRecord markers on the stream: noise generation + "
+                                    "the step; bytes = logits + noise read once + masks + outputs (the noise is also WRITTEN once, "
+                                    "which the byte count leaves out)")
         self.events = []
         self.outer = []
         self._pool = []
         # the argument block of every buffer's call is filled once: a step's host work is then a few microseconds, so
         # the host stays ahead of the GPU and the event interval holds no wait for the next launch packet
+        draw = dict(rng_mode=2, noise=self.noise_buf) if self.parity else dict(rng_mode=1, seed=1234, offset=0)
         if per_row_masks:  # raw bit rows, one per particle (mask ids = identity): every call prepares them itself
-            self.plans = [eng.step_plan(x, mask_kind=1, mask=self.bits, rng_mode=1, seed=1234, offset=0,
-                                        particle_base=rank * B, out=self.out) for x in self.bufs]
+            self.plans = [eng.step_plan(x, mask_kind=1, mask=self.bits, particle_base=rank * B, out=self.out, **draw)
+                          for x in self.bufs]
         else:
-            self.plans = [eng.step_plan(x, mask=self.masks, row_mask_id=self.mask_id, rng_mode=1, seed=1234, offset=0,
-                                        particle_base=rank * B, out=self.out) for x in self.bufs]
+            self.plans = [eng.step_plan(x, mask=self.masks, row_mask_id=self.mask_id, particle_base=rank * B, out=self.out, **draw)
+                          for x in self.bufs]
 
     def _peaked_rows(self, B, V, g, maskf, p_top=0.9, zipf=1.1):
         """Real-shaped next-token rows: one token holds `p_top` of the mass, the others fall off as rank^-zipf in a random
@@ -663,11 +683,15 @@ class KernelWorkload:
                 self._pool = self.eng.timing_events(128)
             inner, (e0, e1) = self._pool.pop(), self._pool.pop()
             e0.record()
+            if self.parity:
+                self.noise_src.rows(self.B, out=self.noise_buf)
             plan.run_timed(inner, offset=i)
             e1.record()
             self.events.append(inner)
             self.outer.append((e0, e1))
         else:
+            if self.parity:
+                self.noise_src.rows(self.B, out=self.noise_buf)
             plan.run(offset=i)
         self.lw += self.out[0]
         if self.world > 1:
@@ -677,6 +701,11 @@ class KernelWorkload:
             self.eng.normalize_weights(self.gathered)
 
     def kernel_times_us(self):
+        if self.parity:  # the span that holds the noise generation too
+            return self.outer_times_us()
+        return np.array([a.elapsed_time(b) * 1e3 for a, b in self.events])
+
+    def race_times_us(self):
         return np.array([a.elapsed_time(b) * 1e3 for a, b in self.events])
 
     def outer_times_us(self):
@@ -692,8 +721,12 @@ class KernelWorkload:
         rows = ("N(0, 3^2) logits" if self.logits_kind == "gaussian" else
                 "peaked logits (top-1 p = 0.9 over a Zipf(1.1) tail in random order; the top token forbidden by the row's mask in "
                 "every third row)")
-        return {"workload": f"fused step only: {shape} ld=V, {rows}, {masks}, Philox draw, 4 rotating logits buffers",
-                "particles_per_gpu": self.B, "vocab": self.V, "rng": "philox", "logits": self.logits_kind, "mask": self.mask_mode}
+        draw = ("the reference's draw: torch.multinomial's CPU MT19937 stream generated on the device, first argmax p / E "
+                "(ids identical to torch's)" if self.parity else "Philox draw")
+        extra = {"us_race_only_mean": float(np.mean(self.race_times_us()))} if self.parity and self.events else {}
+        return {"workload": f"fused step only: {shape} ld=V, {rows}, {masks}, {draw}, 4 rotating logits buffers",
+                "particles_per_gpu": self.B, "vocab": self.V, "rng": "parity (torch CPU generator on the device)" if self.parity else "philox",
+                "logits": self.logits_kind, "mask": self.mask_mode, **extra}
 
 
 class ApiWorkload:

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libglb_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 GLB_OK, GLB_EINVAL, GLB_EUNSUPPORTED, GLB_EHIP, GLB_ENOSPC = 0, 1, 2, 3, 4
 F32, BF16, F16 = 0, 1, 2
 MASK_NONE, MASK_BITS, MASK_F32, MASK_PREPARED = 0, 1, 2, 3
@@ -146,6 +146,23 @@ class MT19937(C.Structure):
     _fields_ = [("mt", C.c_uint32 * 624), ("idx", C.c_int32)]
 
 
+MT_POLY_WORDS = 312
+
+
+class MtRowsArgs(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("window", C.c_void_p), ("window_out", C.c_void_p), ("polys", C.c_void_p),
+        ("n_small", C.c_int32), ("n_big", C.c_int32),
+        ("vocab", C.c_int64), ("max_draw_rows", C.c_int64),
+        ("n_draw", C.c_void_p),
+        ("n_out_rows", C.c_int64),
+        ("row_slot", C.c_void_p),
+        ("out", C.c_void_p), ("out_ld", C.c_int64),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
 # every symbol include/glb.h declares: name -> (restype, argtypes)
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 SYMBOLS = {
@@ -195,6 +212,11 @@ SYMBOLS = {
     "glb_resample_systematic": (C.c_int, [_vp, _i64, C.c_uint64, C.c_uint64, _vp, _vp, _vp, _sz, _vp]),
     "glb_mt19937_seed": (None, [C.POINTER(MT19937), C.c_uint64]),
     "glb_mt19937_exponential_f32": (C.c_int, [C.POINTER(MT19937), _vp, _i64]),
+    "glb_mt19937_window": (C.c_int, [C.c_uint64, _vp]),
+    "glb_mt19937_jump_polys": (C.c_int, [_i64, _i32, _i32, _vp]),
+    "glb_mt19937_jump_host": (C.c_int, [_vp, _vp, _vp]),
+    "glb_mt19937_rows_workspace": (_sz, [_i64, _i32]),
+    "glb_mt19937_exponential_rows": (C.c_int, [C.POINTER(MtRowsArgs), _vp]),
     "glb_philox4x32_10": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
 }
 

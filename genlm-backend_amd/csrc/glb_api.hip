@@ -1667,52 +1667,6 @@ int glb_trie_reduce(const float *weights, int64_t ld, int64_t n_rows, int64_t vo
   return glb_trie_masses(&a, stream);
 }
 
-// ---- host RNG helpers --------------------------------------------------------------------------
-
-void glb_mt19937_seed(glb_mt19937 *st, uint64_t seed) {
-  st->mt[0] = (uint32_t)seed;
-  for (int i = 1; i < 624; ++i)
-    st->mt[i] = 1812433253u * (st->mt[i - 1] ^ (st->mt[i - 1] >> 30)) + (uint32_t)i;
-  st->idx = 624;
-}
-
-static inline void mt_refill(glb_mt19937 *st) {
-  uint32_t *mt = st->mt;
-  int i = 0;
-  for (; i < 624 - 397; ++i) {
-    const uint32_t y = (mt[i] & 0x80000000u) | (mt[i + 1] & 0x7fffffffu);
-    mt[i] = mt[i + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-  }
-  for (; i < 623; ++i) {
-    const uint32_t y = (mt[i] & 0x80000000u) | (mt[i + 1] & 0x7fffffffu);
-    mt[i] = mt[i - 227] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-  }
-  const uint32_t y = (mt[623] & 0x80000000u) | (mt[0] & 0x7fffffffu);
-  mt[623] = mt[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-  st->idx = 0;
-}
-
-static inline uint32_t mt_next(glb_mt19937 *st) {
-  if (st->idx >= 624) mt_refill(st);
-  uint32_t y = st->mt[st->idx++];
-  y ^= y >> 11;
-  y ^= (y << 7) & 0x9d2c5680u;
-  y ^= (y << 15) & 0xefc60000u;
-  y ^= y >> 18;
-  return y;
-}
-
-int glb_mt19937_exponential_f32(glb_mt19937 *st, float *out, int64_t n) {
-  if (!st || !out || n < 0) return fail(GLB_EINVAL, "bad arguments");
-  for (int64_t i = 0; i < n; ++i) {
-    const uint64_t hi = mt_next(st), lo = mt_next(st);
-    const uint64_t r = (hi << 32) | lo;
-    const double u = (double)(r & ((1ull << 53) - 1)) * (1.0 / 9007199254740992.0);
-    out[i] = (float)(-log1p(-u));
-  }
-  return GLB_OK;
-}
-
 void glb_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
   glb::philox4x32_10(ctr, key, out);
 }

@@ -11,7 +11,7 @@ import torch
 from . import _lib
 from ._lib import GLB_EHIP, GlbError
 from ._lib import (F32, BF16, F16, MASK_NONE, MASK_BITS, MASK_F32, MASK_PREPARED, RNG_NONE, RNG_PHILOX, RNG_NOISE,
-                   KvPlanArgs, StepArgs, TrieArgs, TriePlan, TrieRowsArgs, MT19937, check)
+                   KvPlanArgs, MtRowsArgs, StepArgs, TrieArgs, TriePlan, TrieRowsArgs, MT19937, MT_POLY_WORDS, check)
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 
@@ -36,6 +36,61 @@ class HostRng:
             out = torch.empty(n, dtype=torch.float32, pin_memory=torch.cuda.is_available())
         assert out.dtype == torch.float32 and out.is_contiguous() and out.device.type == "cpu"
         check(self._lib.glb_mt19937_exponential_f32(C.byref(self.state), _ptr(out), n))
+        return out
+
+
+class DeviceRng:
+    """torch's CPU generator for the parity draw, ON THE DEVICE (glb_mt19937_exponential_rows): the MT19937 stream of
+    `torch.Generator().manual_seed(seed)` entered at every particle's row at once - no serial host loop, no noise tensor
+    over PCIe.  `rows(...)` returns float32 [n_out, V] Exp(1) rows exactly as `torch.empty(V).exponential_(1, generator)`
+    would yield them one after the other, and moves the stream on by the rows consumed.
+
+    The stream's position is a 624-word window on the device; the jump polynomials for stride 2 V are computed on the host
+    once per vocabulary (about 0.1 s) and cached on the engine."""
+
+    SMALL = 32
+
+    def __init__(self, engine, seed, vocab):
+        self.eng, self.seed, self.vocab = engine, int(seed), int(vocab)
+        self.reset()
+
+    def reset(self):
+        w = np.zeros(624, np.uint32)
+        check(self.eng.lib.glb_mt19937_window(C.c_uint64(self.seed & 0xFFFFFFFFFFFFFFFF), C.c_void_p(w.ctypes.data)))
+        self.window = torch.from_numpy(w.view(np.int32)).to(self.eng.device)
+        self.rows_drawn = 0  # host-side tally when the counts are known here (diagnostic)
+
+    def rows(self, n_out, row_slot=None, n_draw=None, max_draw=None, out=None):
+        """n_out rows; row_slot: int32 [n_out] device - the stream row every output row takes (negative: a row of ones),
+        None: identity; n_draw: int32 device scalar tensor - rows the stream moves on by (None: max_draw); max_draw: host
+        upper bound of it (default n_out)."""
+        eng, V = self.eng, self.vocab
+        max_draw = int(n_out if max_draw is None else max_draw)
+        polys, n_big = eng.mt_polys(V, max_draw + 1)
+        if out is None:
+            out = torch.empty((n_out, V), dtype=torch.float32, device=eng.device)
+        eng._check_dev(row_slot, n_draw, out)
+        if row_slot is not None and (row_slot.dtype != torch.int32 or row_slot.numel() != n_out):
+            raise ValueError("row_slot must be int32 [n_out]")
+        if n_draw is not None and n_draw.dtype != torch.int32:
+            raise TypeError("n_draw must be an int32 device scalar")
+        need = eng.lib.glb_mt19937_rows_workspace(max_draw, self.SMALL)
+        if eng._mt_ws is None or eng._mt_ws.numel() < need:
+            eng._mt_ws = torch.empty(need, dtype=torch.uint8, device=eng.device)
+        a = MtRowsArgs()
+        a.struct_size = C.sizeof(MtRowsArgs)
+        a.window = a.window_out = self.window.data_ptr()
+        a.polys = polys.data_ptr()
+        a.n_small, a.n_big = self.SMALL, n_big
+        a.vocab, a.max_draw_rows = V, max_draw
+        a.n_draw = None if n_draw is None else n_draw.data_ptr()
+        a.n_out_rows = n_out
+        a.row_slot = None if row_slot is None else row_slot.data_ptr()
+        a.out, a.out_ld = out.data_ptr(), out.stride(0) if n_out > 1 else max(V, out.stride(0))
+        a.workspace, a.workspace_bytes = eng._mt_ws.data_ptr(), eng._mt_ws.numel()
+        check(eng.lib.glb_mt19937_exponential_rows(C.byref(a), eng._stream()))
+        if n_draw is None:
+            self.rows_drawn += max_draw
         return out
 
 
@@ -122,6 +177,8 @@ class HipEngine:
         self._ws = None
         self._step_ws = None
         self._trie_ws = None
+        self._mt_ws = None
+        self._mt_polys = {}
 
     def __del__(self):
         try:
@@ -293,6 +350,25 @@ class HipEngine:
         their storage; the scratch buffer is the engine's, so a plan is valid until another, larger step reallocates
         it (run() checks)."""
         return self.step(logits, _plan=True, **kw)
+
+    def noise_rng(self, seed, vocab):
+        """The parity draw's noise source: torch's CPU generator seeded with `seed`, rows of `vocab` exponentials, on the
+        device (DeviceRng)."""
+        return DeviceRng(self, seed, vocab)
+
+    def mt_polys(self, vocab, n_windows):
+        """Device table of the MT19937 jump polynomials for rows of `vocab` exponentials (stride 2 * vocab words), enough
+        for `n_windows` row windows per call (glb_mt19937_jump_polys; computed on the host once and cached).  Returns
+        (int64 tensor [(SMALL + n_big), 312], n_big)."""
+        small = DeviceRng.SMALL
+        need_big = max(1, -(-int(n_windows) // small))
+        ent = self._mt_polys.get(vocab)
+        if ent is None or ent[1] < need_big:
+            n_big = max(need_big, 2 * ent[1] if ent else 0)
+            host = np.zeros((small + n_big, MT_POLY_WORDS), np.uint64)
+            check(self.lib.glb_mt19937_jump_polys(2 * int(vocab), small, n_big, C.c_void_p(host.ctypes.data)))
+            ent = self._mt_polys[vocab] = (torch.from_numpy(host.view(np.int64)).to(self.device), n_big)
+        return ent
 
     def prepare_masks(self, bits, vocab, logits_dtype=torch.float32):
         """int32 bit rows [K, >= ceil(V/32)] -> `PreparedMasks` for logits of `logits_dtype` (glb_mask_prepare)."""

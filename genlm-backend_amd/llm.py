@@ -246,7 +246,7 @@ class AsyncAmdLM(AsyncLM):
         self._masks_prepared = {}
         self._rng_mode = RNG_PHILOX
         self._rng_seed = 0
-        self._host_rng = None
+        self._noise_src = None  # "torch" draws: the CPU generator's stream on the device, made at the first evaluation
         self._batch_counter = 0
         self.stats = {"batches": 0, "queries": 0, "unique": 0, "rows": 0}
         if hf_tokenizer is not None:
@@ -350,17 +350,20 @@ class AsyncAmdLM(AsyncLM):
 
     def set_rng(self, mode="philox", seed=0):
         """"philox": in-kernel counter RNG (fast).  "torch": parity with the reference's CPU
-        torch.multinomial under torch.manual_seed(seed) (README.md:87): exponentials are drawn on the
-        host from the same MT19937 stream, in the reference's particle order."""
+        torch.multinomial under torch.manual_seed(seed) (README.md:87): the exponentials come from the same MT19937
+        stream, in the reference's particle order - generated on the device (engine.DeviceRng)."""
         if mode == "philox":
-            self._rng_mode, self._rng_seed, self._host_rng = RNG_PHILOX, int(seed), None
+            self._rng_mode, self._rng_seed, self._noise_src = RNG_PHILOX, int(seed), None
         elif mode == "torch":
-            from .engine import HostRng
-
-            self._rng_mode, self._rng_seed, self._host_rng = RNG_NOISE, int(seed), HostRng(int(seed))
+            self._rng_mode, self._rng_seed, self._noise_src = RNG_NOISE, int(seed), None
         else:
             raise ValueError(f"unknown rng mode {mode!r}")
         self._batch_counter = 0
+
+    def _noise_rows(self, V):
+        if self._noise_src is None:
+            self._noise_src = self.engine.noise_rng(self._rng_seed, V)
+        return self._noise_src
 
     # ---- the batched evaluation (hf.py:202-288) -------------------------------------------------------
     @torch.no_grad()
@@ -530,9 +533,8 @@ class AsyncAmdLM(AsyncLM):
             kw = self.step_masks(logits.dtype)
             if kw:
                 kw["mask_id"] = mask_id
-            if self._rng_mode == RNG_NOISE:
-                noise = self._host_rng.exponential(len(step_q) * V).view(len(step_q), V).to(dev, non_blocking=True)
-                kw["noise"] = noise
+            if self._rng_mode == RNG_NOISE:  # (step_q is in resolution order already: by group, duplicates contiguous)
+                kw["noise"] = self._noise_rows(V).rows(len(step_q))
             logZ, _lse, tok = eng.step(logits, vocab=V, row_of=row_of, rng_mode=self._rng_mode, seed=self._rng_seed,
                                        offset=self._batch_counter, want_lse=False, **kw)
             step_out = (logZ.cpu().tolist(), tok.cpu().tolist())
@@ -893,10 +895,10 @@ class AsyncAmdLM(AsyncLM):
                 kw["mask_id"] = mid_d
         if self._rng_mode == RNG_NOISE:
             # Exp(1) rows in the reference's resolution order: by dedup group, duplicates contiguous (hf.py:285-288)
-            order = np.argsort(group_of.cpu().numpy(), kind="stable")
-            noise = torch.empty((n, V), dtype=torch.float32)
-            noise[torch.from_numpy(order)] = self._host_rng.exponential(n * V).view(n, V)
-            kw["noise"] = noise.to(dev, non_blocking=True)
+            order = torch.argsort(group_of.to(torch.int64), stable=True)
+            slot = torch.empty(n, dtype=torch.int32, device=dev)
+            slot[order] = torch.arange(n, dtype=torch.int32, device=dev)
+            kw["noise"] = self._noise_rows(V).rows(n, row_slot=slot)
         logZ, _, tok = eng.step(logits, vocab=V, row_of=row_of, rng_mode=self._rng_mode, seed=self._rng_seed,
                                 offset=self._batch_counter, want_lse=False, **kw)
         self._batch_counter += 1

@@ -168,11 +168,7 @@ class DeviceSIS:
         self.kv_rows_moved = 0
         self.seed = seed
         self.rng_mode = RNG_PHILOX if rng == "philox" else RNG_NOISE
-        self.host_rng = None
-        if self.rng_mode == RNG_NOISE:
-            from .engine import HostRng
-
-            self.host_rng = HostRng(seed)
+        self.noise_src = None  # parity draws: torch's CPU generator on the device (engine.DeviceRng), made at the first step
         prompts = prompt_ids if isinstance(prompt_ids[0], (list, tuple)) else [prompt_ids] * n_particles
         assert len(prompts) == n_particles
         self._prompt_len0 = torch.tensor([len(p) for p in prompts], dtype=torch.int32, device=self.dev)
@@ -248,8 +244,8 @@ class DeviceSIS:
                              lengths=torch.from_numpy(lens).to(dev), ptrs=ptrs, p_max=int(lens.max()))
 
     def reset(self):
-        if self.host_rng is not None:  # a run starts its seeded noise stream over
-            self.host_rng = type(self.host_rng)(self.seed)
+        if self.noise_src is not None:  # a run starts its seeded noise stream over
+            self.noise_src.reset()
         self.contexts = self._ctx0.clone()
         self.prompt_len = self._prompt_len0.clone()
         self.lengths = self.prompt_len.clone()
@@ -264,6 +260,7 @@ class DeviceSIS:
         # (the slabs stay - and the hipGraphs captured over them; shared rows start from an empty block table, private rows
         # are refilled by step 0's encoding)
         self._head_cache = None
+        self._noise_buf = getattr(self, "_noise_buf", None)
         self._fwd_tokens = None  # tokens the transformer body was fed in the running step, when that is not n_unique x l_max
         self._noise_groups = None  # parity draws: the dedup grouping the noise rows are dealt by (set per step)
         self._kv_stale = None  # bool [N]: rows whose KV has to be rebuilt from the context (ancestor on another rank)
@@ -529,17 +526,22 @@ class DeviceSIS:
         return self._finish_step(logits, group_of, U, n_active, n_global, time_kernel, l_max)
 
     def _parity_noise(self, group_of, V):
-        """Exp(1) rows in the order the reference's particles reach torch.multinomial: by dedup group
-        (first appearance), duplicates contiguous, inactive particles draw nothing (hf.py:285-288,
-        README.md:94-98)."""
-        g = group_of.cpu().numpy()
-        act = self.active.cpu().numpy() > 0
-        idx = np.nonzero(act)[0]
-        order = idx[np.argsort(g[idx], kind="stable")]
-        noise = torch.ones((self.N, V), dtype=torch.float32)
-        block = self.host_rng.exponential(len(order) * V).view(len(order), V)
-        noise[torch.from_numpy(order)] = block
-        return noise.to(self.dev)
+        """Exp(1) rows in the order the reference's particles reach torch.multinomial: by dedup group (first appearance),
+        duplicates contiguous, inactive particles draw nothing (hf.py:285-288, README.md:94-98).  The stream is torch's CPU
+        generator, entered on the device at every particle's row at once (glb_mt19937_exponential_rows): the order is a
+        stable sort of the group ids, the number of rows consumed a device scalar - nothing crosses the host."""
+        N = self.N
+        if self.noise_src is None:
+            self.noise_src = self.eng.noise_rng(self.seed, V)
+        act = self.active > 0
+        key = torch.where(act, group_of.to(torch.int64), torch.full((N,), 1 << 40, dtype=torch.int64, device=self.dev))
+        order = torch.argsort(key, stable=True)
+        rank = torch.empty(N, dtype=torch.int32, device=self.dev)
+        rank[order] = torch.arange(N, dtype=torch.int32, device=self.dev)
+        slot = torch.where(act, rank, torch.full_like(rank, -1))
+        if self._noise_buf is None or self._noise_buf.shape != (N, V):
+            self._noise_buf = torch.empty((N, V), dtype=torch.float32, device=self.dev)
+        return self.noise_src.rows(N, row_slot=slot, n_draw=act.sum().to(torch.int32), max_draw=N, out=self._noise_buf)
 
     # -------------------------------------------------------------------------------------------
     def gather_weights(self):
@@ -687,12 +689,8 @@ class DeviceSampler(DeviceSIS):
         self.sync_every = max(1, int(sync_every))
         self.temperature = float(temperature)
         self.eos = torch.tensor(sorted(set(int(t) for t in eos_token_ids)), dtype=torch.int32, device=self.dev)
-        self.noise_rng = None
-        if seed is not None:
-            from .engine import HostRng
-
-            self.noise_rng = HostRng(int(seed))
-        else:  # unseeded: in-kernel Philox keyed from torch's global generator
+        self.seeded = seed is not None
+        if not self.seeded:  # unseeded: in-kernel Philox keyed from torch's global generator
             self.seed = int(torch.randint(0, 2**62, (1,)).item())
 
     def _finish_step(self, logits, group_of, U, n_active, n_global, time_kernel, l_max):
@@ -700,9 +698,11 @@ class DeviceSampler(DeviceSIS):
         V = logits.shape[-1]
         kw = {}
         mode = RNG_PHILOX
-        if self.noise_rng is not None:
+        if self.seeded:  # step t of every sequence races against the SAME row of torch's CPU stream (made on the device)
             mode = RNG_NOISE
-            kw["noise"] = self.noise_rng.exponential(V).view(1, V).to(dev, non_blocking=True)
+            if self.noise_src is None:
+                self.noise_src = eng.noise_rng(self.seed, V)
+            kw["noise"] = self.noise_src.rows(1)
         _, _, tok = eng.step(logits, vocab=V, row_of=group_of, rng_mode=mode, seed=self.seed, offset=self.t,
                              logit_scale=1.0 / self.temperature, want_lse=False, **kw)
         act = (self.active > 0) & (tok != -2)  # token -2: a failed launch, never a result (raised at the next copy / results())
@@ -739,7 +739,7 @@ class SisBenchWorkload:
 
     def __init__(self, eng, dev, rank, world, dist, n_particles=1024, max_tokens=10, prefix_kv=False, particle_kv=False,
                  model="gpt2", n_prompts=1, resample=False, force_collectives=False, kv_in_place=0.75,
-                 per_particle_masks=False):
+                 per_particle_masks=False, rng="philox"):
         from .llm import AsyncAmdLM
 
         if model == "gpt2":
@@ -781,8 +781,9 @@ class SisBenchWorkload:
         base = [list(range(100, 108))] + [[int(t) for t in rs.integers(1000, 30000, 8)] for _ in range(n_prompts - 1)]
         prompts = [base[i % n_prompts] for i in range(n_particles)] if n_prompts > 1 else base[0]
         self.n_prompts = n_prompts
+        self.rng = rng
         self.sis = DeviceSIS(self.llm, n_particles, prompts, max_tokens, cfg.eos_token_id,
-                             seed=1234, rank=rank, world=world, dist=dist, use_prefix_kv=prefix_kv,
+                             seed=1234, rng=rng, rank=rank, world=world, dist=dist, use_prefix_kv=prefix_kv,
                              use_particle_kv=particle_kv, resample_ess=1.0 if resample else None,
                              force_collectives=force_collectives, kv_in_place=kv_in_place, particle_masks=pm)
         self.prefix_kv = prefix_kv
@@ -815,7 +816,8 @@ class SisBenchWorkload:
         if timed:
             # algorithmic bytes of this call: the unique logits rows once + mask bit rows + outputs
             n_masks = self.N + 1 if self.per_particle_masks else 2
-            self._bytes.append(U * self.V * self.elem + n_masks * ((self.V + 31) // 32) * 4 + self.N * 8)
+            self._bytes.append(U * self.V * self.elem + n_masks * ((self.V + 31) // 32) * 4 + self.N * 8
+                               + (self.N * self.V * 4 if self.rng != "philox" else 0))  # parity draws: + one noise row per particle
             self.unique_hist.append(U)
             self.fed_hist.append(int(self.sis.last_stats["l_max"]))  # tokens per forward row of this step
             ls = self.sis.last_stats
@@ -838,13 +840,16 @@ class SisBenchWorkload:
     def config(self):
         return {"workload": f"SIS step: {self.N} particles/GPU, {self.model_name}, prompt len 8, <=10 new "
                             "tokens, " + (f"{self.N} per-particle bit masks handed over raw every step" if self.per_particle_masks
-                                          else "2 shared bit masks") + ", device-resident population, Philox draws"
+                                          else "2 shared bit masks") + ", device-resident population, "
+                            + ("Philox draws" if self.rng == "philox" else "the reference's draws (torch.multinomial's CPU MT19937 stream, "
+                               "generated on the device: ids identical to torch's under the seed)")
                             + (f", {self.n_prompts} distinct shared prompts" if self.n_prompts > 1 else "")
                             + (", prompt KV cached (cache_kv semantics, BASELINE config 3)" if self.prefix_kv else "")
                             + (", device-resident KV rows shared by particles with equal contexts (one new token per distinct "
                                "context per step; NOT the reference's re-encode-every-step algorithm)" if self.particle_kv else "")
                             + (", systematic resampling after every step" if self.resample else ""),
-                "particles_per_gpu": self.N, "vocab": self.V, "rng": "philox",
+                "particles_per_gpu": self.N, "vocab": self.V,
+                "rng": "philox" if self.rng == "philox" else "parity (torch CPU generator on the device)",
                 "mean_unique_contexts_per_step": float(np.mean(self.unique_hist)) if self.unique_hist else None,
                 # what the forward is fed per distinct context, and what the cached prompt KV saves
                 "mean_tokens_fed_per_context": float(np.mean(self.fed_hist)) if self.fed_hist else None,

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GLB_ABI_VERSION 6
+#define GLB_ABI_VERSION 7
 
 /* status codes */
 enum {
@@ -534,10 +534,13 @@ size_t glb_trie_rows_workspace(int64_t n_rows, const glb_trie_plan *plan);
 int glb_trie_rows(const glb_trie_rows_args *args, const glb_trie_plan *plan, void *hip_stream);
 
 /*
- * Host helper for GLB_RNG_NOISE: fills out[0..n) with the float32 Exp(1) variates
- * torch.empty(n).exponential_(1, generator) produces on CPU for a generator whose MT19937 state is
- * `state` (seeded with glb_mt19937_seed).  Serial by construction (one 64-bit draw = two MT words per
- * variate).  Host pointers only.
+ * torch's CPU generator for GLB_RNG_NOISE (parity mode).  The reference draws every token with torch.multinomial on the
+ * CPU (README.md:87, base.py:136-141): V float32 Exp(1) variates per particle from ONE serial MT19937 stream - each
+ * variate is one random64() = two MT words, u = (r & (2^53 - 1)) 2^-53, E = (float)(-log1p(-u)) - particles in
+ * resolution order (hf.py:285-288).
+ *
+ * Host, serial (validation, small cases): glb_mt19937_seed + glb_mt19937_exponential_f32 fill out[0..n) with what
+ * torch.empty(n).exponential_(1, generator) produces for a generator seeded alike.  Host pointers only.
  */
 typedef struct glb_mt19937 {
   uint32_t mt[624];
@@ -545,6 +548,47 @@ typedef struct glb_mt19937 {
 } glb_mt19937;
 void glb_mt19937_seed(glb_mt19937 *st, uint64_t seed);
 int glb_mt19937_exponential_f32(glb_mt19937 *st, float *out, int64_t n);
+
+/*
+ * The same stream on the DEVICE, entered at every particle's row at once (csrc/glb_mt.hip).  The stream's position is a
+ * WINDOW: the 624 untempered words x[o .. o+623] that precede the next output (after seeding: the seeded array itself,
+ * glb_mt19937_window).  A window `J` words ahead is g_J(T) applied to a window, g_J(t) = t^J mod the generator's minimal
+ * polynomial: glb_mt19937_jump_polys computes, on the host, once per stride (stride_words = 2 V: one particle's row),
+ *     polys[r]           = g_{r * stride}              r = 0 .. n_small - 1
+ *     polys[n_small + m] = g_{m * n_small * stride}    m = 0 .. n_big - 1
+ * (GLB_MT_POLY_WORDS 64-bit words each, coefficient i = bit i % 64 of word i / 64; about 2 ms per polynomial), enough
+ * for n_small * n_big - 1 rows per call.  glb_mt19937_jump_host applies one polynomial to a window on the host (tests).
+ * Only the top bit of a window's word 0 is state; its other 31 bits are unspecified after a jump.
+ */
+#define GLB_MT_POLY_WORDS 312
+int glb_mt19937_window(uint64_t seed, uint32_t *out_window /* [624] host */);
+int glb_mt19937_jump_polys(int64_t stride_words, int32_t n_small, int32_t n_big, uint64_t *out_polys /* host */);
+int glb_mt19937_jump_host(const uint32_t *window_in, const uint64_t *poly, uint32_t *window_out);
+/*
+ * out[i, 0..V) = the V exponentials of stream row row_slot[i] (row k = words [2 V k, 2 V (k + 1)) after the position
+ * `window`); row_slot[i] < 0: a row of ones (a particle that draws nothing this step); row_slot null: identity.  Then
+ * window_out (nullable; may be `window` itself) = the position after *n_draw rows (n_draw: device scalar <= max_draw_rows,
+ * null: max_draw_rows) - the stream moves on by what was consumed, decided on the device.  Three launches, no host
+ * synchronisation.  All pointers device pointers.
+ */
+typedef struct glb_mt_rows_args {
+  uint32_t struct_size;
+  const uint32_t *window;   /* [624] */
+  uint32_t *window_out;     /* [624], nullable */
+  const uint64_t *polys;    /* [(n_small + n_big), GLB_MT_POLY_WORDS] as glb_mt19937_jump_polys made them for stride 2 * vocab */
+  int32_t n_small, n_big;
+  int64_t vocab;            /* V */
+  int64_t max_draw_rows;    /* host: upper bound of the stream rows this call consumes; < n_small * n_big */
+  const int32_t *n_draw;    /* device scalar, nullable */
+  int64_t n_out_rows;
+  const int32_t *row_slot;  /* [n_out_rows], nullable */
+  float *out;               /* [n_out_rows, out_ld] */
+  int64_t out_ld;           /* >= vocab */
+  void *workspace;          /* >= glb_mt19937_rows_workspace(max_draw_rows, n_small) bytes */
+  size_t workspace_bytes;
+} glb_mt_rows_args;
+size_t glb_mt19937_rows_workspace(int64_t max_draw_rows, int32_t n_small);
+int glb_mt19937_exponential_rows(const glb_mt_rows_args *args, void *hip_stream);
 
 /* Philox4x32-10 block function, exposed so hosts can reproduce the device draws. */
 void glb_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

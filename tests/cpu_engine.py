@@ -24,8 +24,33 @@ class _Prepared:
         self.bits = bits
 
 
+class _OracleNoise:
+    """stand-in for engine.DeviceRng: the oracle's serial MT19937 -> exponential_ stream dealt out by row slots"""
+
+    def __init__(self, seed, vocab):
+        self.seed, self.vocab = seed, vocab
+        self.reset()
+
+    def reset(self):
+        self.state = None
+
+    def rows(self, n_out, row_slot=None, n_draw=None, max_draw=None, out=None):
+        V = self.vocab
+        slot = np.arange(n_out) if row_slot is None else row_slot.cpu().numpy()
+        n = int(n_out if max_draw is None else max_draw) if n_draw is None else int(n_draw)
+        assert (slot < n).all()
+        block, self.state = O.mt_exponential(self.seed, n * V, self.state)
+        block = block.reshape(n, V)
+        res = np.ones((n_out, V), np.float32)
+        res[slot >= 0] = block[slot[slot >= 0]]
+        return torch.from_numpy(res)
+
+
 class CpuOracleEngine:
     device = torch.device("cpu")
+
+    def noise_rng(self, seed, vocab):
+        return _OracleNoise(seed, vocab)
 
     def prepare_masks(self, bits, vocab, logits_dtype=torch.float32):
         return _Prepared(bits)

@@ -1,0 +1,94 @@
+"""torch's CPU generator on the device (glb_mt19937_exponential_rows, csrc/glb_mt.hip) against the serial host stream the
+reference runs (glb_mt19937_exponential_f32 == the oracle == torch, tests/test_oracle.py, tests/test_mt_cpu.py): bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import genlm_backend_amd  # noqa: F401
+from genlm_backend_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _host_stream(seed, n):
+    lib = _lib.load()
+    st = _lib.MT19937()
+    lib.glb_mt19937_seed(C.byref(st), seed)
+    out = np.empty(n, np.float32)
+    assert lib.glb_mt19937_exponential_f32(C.byref(st), out.ctypes.data_as(C.c_void_p), n) == 0
+    return out
+
+
+@pytest.mark.parametrize("V,rows", [(50257, 70), (4099, 33), (1, 40), (128256, 9), (311, 1)])
+def test_rows_equal_the_serial_stream(engine, V, rows):
+    """Several calls in a row: the stream moves on by what each call consumed; rows beyond one polynomial level (rows > 32)
+    take both jump launches."""
+    from genlm_backend_amd.engine import DeviceRng
+
+    rng = DeviceRng(engine, 1234, V)
+    want = _host_stream(1234, 3 * rows * V).reshape(3 * rows, V)
+    for call in range(3):
+        got = rng.rows(rows)
+        torch.cuda.synchronize()
+        assert np.array_equal(got.cpu().numpy().view(np.uint32), want[call * rows:(call + 1) * rows].view(np.uint32)), call
+
+
+def test_slots_counts_on_the_device_and_rows_of_ones(engine):
+    """Output rows take stream rows in any order (row_slot), particles that draw nothing get ones, and the stream moves on
+    by a count that lives on the device - the resolution order of hf.py:285-288 with inactive particles skipped."""
+    from genlm_backend_amd.engine import DeviceRng
+
+    V, N = 50257, 48
+    rng = DeviceRng(engine, 7, V)
+    rs = np.random.default_rng(3)
+    want = _host_stream(7, (N + 20) * V).reshape(N + 20, V)
+    used = 0
+    for call in range(3):
+        act = rs.random(N) < 0.7
+        n_act = int(act.sum())
+        perm = rs.permutation(n_act)
+        slot = np.full(N, -1, np.int32)
+        slot[np.nonzero(act)[0]] = perm
+        if call == 2:  # nothing is consumed when nobody draws
+            slot[:] = -1
+            n_act = 0
+        got = rng.rows(N, row_slot=torch.from_numpy(slot).to(engine.device),
+                       n_draw=torch.tensor(n_act, dtype=torch.int32, device=engine.device), max_draw=N)
+        torch.cuda.synchronize()
+        got = got.cpu().numpy()
+        for i in range(N):
+            if slot[i] < 0:
+                assert (got[i] == 1.0).all()
+            else:
+                assert np.array_equal(got[i].view(np.uint32), want[used + slot[i]].view(np.uint32)), (call, i)
+        used += n_act
+    # one shared row per step (base.py:148-179: every sequence of batch_sample is seeded alike): DeviceSampler's use
+    one = rng.rows(1).cpu().numpy()
+    assert np.array_equal(one[0].view(np.uint32), want[used].view(np.uint32))
+
+
+def test_headline_size_and_a_later_position(engine):
+    """1024 particles x 50257 (BASELINE config 2), the second step of a run: 206 MB of noise that used to be 0.8 s of host
+    time + a PCIe copy."""
+    from genlm_backend_amd.engine import DeviceRng
+
+    V, N = 50257, 1024
+    rng = DeviceRng(engine, 1234, V)
+    rng.rows(N)
+    got = rng.rows(N)
+    torch.cuda.synchronize()
+    want = _host_stream(1234, 2 * N * V)[N * V:].reshape(N, V)
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
+
+
+def test_argument_errors(engine):
+    from genlm_backend_amd.engine import DeviceRng
+
+    rng = DeviceRng(engine, 1, 100)
+    with pytest.raises(ValueError):
+        rng.rows(4, row_slot=torch.zeros(3, dtype=torch.int32, device=engine.device))
+    a = _lib.MtRowsArgs()
+    a.struct_size = 4
+    assert engine.lib.glb_mt19937_exponential_rows(C.byref(a), None) == _lib.GLB_EINVAL
