@@ -544,8 +544,122 @@ __global__ __launch_bounds__(64) void short_attention_kernel(const ShortArgs a) 
   }
 }
 
+// Round 5: the same attention with a wave per (row, KV head) instead of per (row, head, query).  The wave above was a
+// query: eight key slots of eight lanes, an online softmax per slot and a merge of the slots through three rounds of
+// nine lane exchanges - ~140 instructions and three memory round trips for 13 keys, 191 000 waves a layer at 460 rows x
+// 32 heads x 13 positions (96 us a layer: a tenth of the Llama-shaped step).  Here the SLOTS ARE QUERIES: the (row, KV
+// head)'s K and V go to LDS once as float32 (13 keys x 64 dims: 6.6 KB), the wave walks the G x Lq queries that share
+// them PP at a time (PP = 64 / LP slots of LP lanes, a lane holds the query's and the output's EPV-element chunk), a
+// key's score is one dot product chunk per lane + log2(LP) DPP adds inside the slot, the scores of a query stay in
+// registers, and nothing is ever merged across slots: ~40 instructions a query.  Keys up to KMAX (16 / 32) per call;
+// longer key ranges keep the kernel above.
+template <int LP>
+__device__ __forceinline__ float slot_sum(float v) {
+  // sum over the LP consecutive lanes of a slot, every lane gets it (DPP: quad_perm xor 1, xor 2, row_half_mirror, row_mirror)
+  if constexpr (LP >= 2) v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0xB1, 0xf, 0xf, false));
+  if constexpr (LP >= 4) v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x4E, 0xf, 0xf, false));
+  if constexpr (LP >= 8) v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x141, 0xf, 0xf, false));
+  if constexpr (LP >= 16) v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x140, 0xf, 0xf, false));
+  if constexpr (LP >= 32) v += __shfl_xor(v, 16, 64);
+  if constexpr (LP >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+template <int DT, int DH, int KMAX>
+__global__ __launch_bounds__(64) void short_attention_rows_kernel(const ShortArgs a) {
+  constexpr int ES = DT == GLB_F32 ? 4 : 2, EPV = 16 / ES, LP = DH / EPV, PP = 64 / LP;
+  static_assert(LP >= 1 && LP <= 64 && PP * LP == 64, "head_dim / vector width must divide the wave");
+  extern __shared__ float kv_lds[];  // K [Lk][DH], then V [Lk][DH], float32
+  const int lane = threadIdx.x, j = lane / LP, i = lane - j * LP;
+  const int G = a.H / a.Hkv;
+  const int hk = blockIdx.x % a.Hkv, u = blockIdx.x / a.Hkv;
+  float *Ks = kv_lds, *Vs = kv_lds + a.Lk * DH;
+  {
+    const char *kb = a.k + ((int64_t)u * a.k_sr + (int64_t)hk * a.k_sh) * ES;
+    const char *vb = a.v + ((int64_t)u * a.v_sr + (int64_t)hk * a.v_sh) * ES;
+    for (int x = lane; x < a.Lk * LP; x += 64) {
+      const int p = x / LP, c = x - p * LP;
+      float kf[EPV], vf[EPV];
+      unpack16<DT>(*reinterpret_cast<const u32x4 *>(kb + ((int64_t)p * a.k_sp + c * EPV) * ES), kf);
+      unpack16<DT>(*reinterpret_cast<const u32x4 *>(vb + ((int64_t)p * a.v_sp + c * EPV) * ES), vf);
+#pragma unroll
+      for (int k = 0; k < EPV; ++k) Ks[p * DH + c * EPV + k] = kf[k], Vs[p * DH + c * EPV + k] = vf[k];
+    }
+  }
+  __syncthreads();
+  const int nq = G * a.Lq;
+  const uint32_t all_keys = a.Lk >= 32 ? 0xffffffffu : ((1u << a.Lk) - 1u);
+  for (int q0 = 0; q0 < nq; q0 += PP) {
+    const int qi = q0 + j;
+    const bool live = qi < nq;
+    const int qc = live ? qi : nq - 1;
+    const int g = qc / a.Lq, t = qc - g * a.Lq, h = hk * G + g;
+    float qf[EPV];
+    unpack16<DT>(*reinterpret_cast<const u32x4 *>(a.q + ((int64_t)u * a.q_sr + (int64_t)h * a.q_sh + (int64_t)t * a.q_sp + i * EPV) * ES), qf);
+    uint32_t vis = 0;  // bit p: query t may see key p
+    if (a.mask) {
+      const uint8_t *mrow = a.mask + (int64_t)u * a.m_sr + (int64_t)t * a.m_sq;
+      for (int p = 0; p < a.Lk; ++p) vis |= (mrow[p] != 0 ? 1u : 0u) << p;
+    } else {
+      const int last = t + a.Lk - a.Lq;  // causal: keys 0 .. last
+      vis = last >= 31 ? 0xffffffffu : ((2u << last) - 1u);
+    }
+    vis &= all_keys;
+    float sc[KMAX];
+    float m = -__builtin_huge_valf();
+#pragma unroll
+    for (int p = 0; p < KMAX; ++p) {
+      sc[p] = -__builtin_huge_valf();
+      if (p < a.Lk) {  // (wave-uniform)
+        const float *kp = Ks + p * DH + i * EPV;
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < EPV; ++k) s = __builtin_fmaf(qf[k], kp[k], s);
+        s = slot_sum<LP>(s) * a.scale;
+        sc[p] = ((vis >> p) & 1u) ? s : -__builtin_huge_valf();
+        m = fmaxf(m, sc[p]);
+      }
+    }
+    float l = 0.0f, acc[EPV];
+#pragma unroll
+    for (int k = 0; k < EPV; ++k) acc[k] = 0.0f;
+#pragma unroll
+    for (int p = 0; p < KMAX; ++p) {
+      if (p < a.Lk) {
+        const float w = ((vis >> p) & 1u) ? __expf(sc[p] - m) : 0.0f;
+        const float *vp = Vs + p * DH + i * EPV;
+        l += w;
+#pragma unroll
+        for (int k = 0; k < EPV; ++k) acc[k] = __builtin_fmaf(w, vp[k], acc[k]);
+      }
+    }
+    if (live) {
+      const float inv = l > 0.0f ? 1.0f / l : 0.0f;  // a query that sees nothing (padding): zeros
+#pragma unroll
+      for (int k = 0; k < EPV; ++k) acc[k] *= inv;
+      *reinterpret_cast<u32x4 *>(a.out + ((((int64_t)u * a.Lq + t) * a.H + h) * DH + i * EPV) * ES) = pack16v<DT>(acc);
+    }
+  }
+}
+
+template <int DT, int DH>
+hipError_t launch_short_rows(const ShortArgs &a, hipStream_t s) {
+  const dim3 grid((unsigned)((int64_t)a.U * a.Hkv)), block(64);
+  const size_t lds = (size_t)2 * a.Lk * DH * sizeof(float);
+  if (a.Lk <= 16) hipLaunchKernelGGL((short_attention_rows_kernel<DT, DH, 16>), grid, block, lds, s, a);
+  else hipLaunchKernelGGL((short_attention_rows_kernel<DT, DH, 32>), grid, block, lds, s, a);
+  return hipGetLastError();
+}
+
 template <int DT>
 hipError_t launch_short_attention(const ShortArgs &a, int head_dim, hipStream_t s) {
+  if (a.Lk <= 32 && (int64_t)a.U * a.Hkv <= 0x7fffffffll) {  // the (row, KV head) form: K / V in LDS once, slots are queries
+    if (head_dim == 64) return launch_short_rows<DT, 64>(a, s);
+    if (head_dim == 128) return launch_short_rows<DT, 128>(a, s);
+    if (head_dim == 32) return launch_short_rows<DT, 32>(a, s);
+    if (head_dim == 16) return launch_short_rows<DT, 16>(a, s);
+    return hipErrorInvalidValue;
+  }
   const dim3 grid((unsigned)((int64_t)a.U * a.H * a.Lq)), block(64);
   if (head_dim == 64) hipLaunchKernelGGL((short_attention_kernel<DT, 64>), grid, block, 0, s, a);
   else if (head_dim == 128) hipLaunchKernelGGL((short_attention_kernel<DT, 128>), grid, block, 0, s, a);

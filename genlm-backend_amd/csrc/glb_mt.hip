@@ -11,10 +11,11 @@
 //     "Efficient jump ahead for F2-linear random number generators", 2008).
 //   * Host, once per vocabulary (glb_mt19937_jump_polys): phi by Berlekamp-Massey, g_{r s} for r < n_small and
 //     g_{m n_small s} for m < n_big, s = 2 V words = one particle's stride.
-//   * mt_jump_kernel: a workgroup extends its source window by 19 976 words in LDS (227 words per step: the recurrence
-//     reaches back 227) and each of its four waves convolves that sequence with one polynomial - lane l keeps 11
-//     consecutive output words, a 42-word sliding window of the sequence serves 32 coefficients.  Two launches: the base
-//     window -> every n_small-th row's window, those -> every row's window.
+//   * mt_jump_kernel: a workgroup runs the recurrence from its source window through a ring in LDS (227 words per step:
+//     the recurrence reaches back 227) up to the quarter of the sequence it convolves, and each of its four waves
+//     convolves that quarter with the matching quarter of one polynomial - lane l keeps 11 consecutive output words, a
+//     42-word sliding window of the sequence serves 32 coefficients; a window is the XOR of its four partial planes.  Two
+//     launches: the base window -> every n_small-th row's window, those -> every row's window.
 //   * mt_rows_kernel: a workgroup per output row runs the recurrence from its window (454 words per round through a
 //     2048-word ring in LDS), tempers, pairs the words as random64() and turns them into E = (float)(-log1p(-u)) with
 //     glibc's log1p restated operation for operation (glb_log1p.hpp); one more block leaves the window after the last
@@ -40,10 +41,11 @@ using glb::api_hip_fail;
 constexpr int kN = 624, kM = 397, kDeg = 19937;
 constexpr int kPW = GLB_MT_POLY_WORDS;  // 312 64-bit words: coefficients 0 .. 19967
 constexpr int kStep = kN - kM;          // 227: how many new words one step of the recurrence can make at once
-constexpr int kExtSteps = 88;
-constexpr int kExt = kExtSteps * kStep;  // 19 976 >= kDeg words beyond the window
-constexpr int kSeq = kN + kExt;          // words of LDS of a jumping workgroup (82 400 B)
 constexpr int kPerLane = 11;             // output words a lane of mt_jump_kernel keeps (57 lanes x 11 >= 624; stride 11: no bank conflicts)
+constexpr int kParts = 4;                // a polynomial's coefficients are applied in four parts by four workgroups
+constexpr int kPartWords = kN / kParts;  // 156 32-bit coefficient words (4992 coefficients) a part
+constexpr int kPartSeq = kPartWords * 32 + 56 * kPerLane + 32 + kPerLane - 1;  // sequence words a part reads: 5650
+constexpr int kJumpRing = 8192;          // words of LDS of a jumping workgroup (32 KB) >= kPartSeq + kN + kStep
 constexpr int kRing = 2048;
 
 __host__ __device__ static inline uint32_t mt_twist(uint32_t a, uint32_t b, uint32_t c) {
@@ -200,20 +202,32 @@ static void jump_host(const uint32_t *win, const uint64_t *poly, uint32_t *out) 
 }
 
 // ---- device ------------------------------------------------------------------------------------------------------------
-// Block (src, quad): waves 0..3 apply polynomials 4 quad + wave to source window src; dst[src * n_poly + p].
-__global__ __launch_bounds__(256) void mt_jump_kernel(const uint32_t *__restrict__ src, const uint64_t *__restrict__ polys, int n_poly,
-                                                      uint32_t *__restrict__ dst, int n_dst) {
-  extern __shared__ uint32_t seq[];
+// Block (src, quad, part): waves 0..3 apply coefficients [part * 4992, (part + 1) * 4992) of polynomials 4 quad + wave to
+// source window src.  A window is kept as kParts PLANES whose XOR it is (dst[part][src * n_poly + p]): the four parts of a
+// polynomial are four workgroups that never meet, each with a quarter of the sequence in LDS (32 KB: five workgroups a CU,
+// so that one wave's LDS waits and taken branches are another's issue slots; the whole sequence in one workgroup - 82 KB,
+// one wave a SIMD - took 577 us a launch, VALU idle two thirds of the time).  The source window is the XOR of its own planes.
+__global__ __launch_bounds__(256) void mt_jump_kernel(const uint32_t *__restrict__ src, int src_planes, int64_t src_plane_stride,
+                                                      const uint64_t *__restrict__ polys, int n_poly, uint32_t *__restrict__ dst,
+                                                      int n_dst, int64_t dst_plane_stride) {
+  __shared__ uint32_t ring[kJumpRing];
   const int quads = (n_poly + 3) >> 2;
-  const int s = (int)blockIdx.x / quads, q = (int)blockIdx.x % quads;
+  const int part = (int)blockIdx.x % kParts, sq = (int)blockIdx.x / kParts;
+  const int s = sq / quads, q = sq % quads;
   const int t = (int)threadIdx.x;
-  const uint32_t *w = src + (size_t)s * kN;
-  for (int i = t; i < kN; i += 256) seq[i] = w[i];
+  // word n of the sequence lives at ring[(n - lo) & (kJumpRing - 1)]: the part's range [lo, lo + kPartSeq) is contiguous
+  const int lo = part * kPartWords * 32;
+  for (int i = t; i < kN; i += 256) {
+    uint32_t v = 0;
+    for (int pl = 0; pl < src_planes; ++pl) v ^= src[(size_t)pl * src_plane_stride + (size_t)s * kN + i];
+    ring[(i - lo) & (kJumpRing - 1)] = v;
+  }
   __syncthreads();
-  for (int base = 0; base < kExt; base += kStep) {
+  const int need = lo + kPartSeq;  // words [0, need) have to exist
+  for (int base = 0; base + kN < need; base += kStep) {
     if (t < kStep) {
-      const int i = base + t;
-      seq[i + kN] = mt_twist(seq[i], seq[i + 1], seq[i + kM]);
+      const int i = base + t - lo;
+      ring[(i + kN) & (kJumpRing - 1)] = mt_twist(ring[i & (kJumpRing - 1)], ring[(i + 1) & (kJumpRing - 1)], ring[(i + kM) & (kJumpRing - 1)]);
     }
     __syncthreads();
   }
@@ -221,17 +235,18 @@ __global__ __launch_bounds__(256) void mt_jump_kernel(const uint32_t *__restrict
   const int p = q * 4 + wave;
   const int d = s * n_poly + p;
   if (p >= n_poly || d >= n_dst) return;  // (no barrier below)
-  const uint32_t *c = reinterpret_cast<const uint32_t *>(polys + (size_t)p * kPW);  // coefficient i: word i / 32, bit i % 32
+  // coefficient i: 32-bit word i / 32, bit i % 32; this part's words
+  const uint32_t *c = reinterpret_cast<const uint32_t *>(polys + (size_t)p * kPW) + part * kPartWords;
   const int j0 = lane * kPerLane;
   if (j0 >= kN) return;
   uint32_t acc[kPerLane];
 #pragma unroll
   for (int k = 0; k < kPerLane; ++k) acc[k] = 0;
-  for (int wi = 0; wi < kN; ++wi) {  // 624 words of 32 coefficients (those from 19937 on are zero)
+  for (int wi = 0; wi < kPartWords; ++wi) {
     const uint32_t cw = __builtin_amdgcn_readfirstlane(c[wi]);
     if (cw == 0) continue;
     uint32_t win[32 + kPerLane - 1];
-    const uint32_t *sp = seq + 32 * wi + j0;
+    const uint32_t *sp = ring + 32 * wi + j0;
 #pragma unroll
     for (int u = 0; u < 32 + kPerLane - 1; ++u) win[u] = sp[u];
 #pragma unroll
@@ -241,7 +256,7 @@ __global__ __launch_bounds__(256) void mt_jump_kernel(const uint32_t *__restrict
         for (int k = 0; k < kPerLane; ++k) acc[k] ^= win[b + k];
       }
   }
-  uint32_t *o = dst + (size_t)d * kN;
+  uint32_t *o = dst + (size_t)part * dst_plane_stride + (size_t)d * kN;
 #pragma unroll
   for (int k = 0; k < kPerLane; ++k)
     if (j0 + k < kN) o[j0 + k] = acc[k];
@@ -249,7 +264,8 @@ __global__ __launch_bounds__(256) void mt_jump_kernel(const uint32_t *__restrict
 
 // Block r < n_out: output row r = the V exponentials of stream row row_slot[r] (window windows[slot]); ones for slot < 0.
 // Block n_out: window_out = windows[n_draw].
-__global__ __launch_bounds__(256) void mt_rows_kernel(const uint32_t *__restrict__ windows, int n_win, const int32_t *__restrict__ row_slot,
+__global__ __launch_bounds__(256) void mt_rows_kernel(const uint32_t *__restrict__ windows, int64_t plane_stride, int n_win,
+                                                      const int32_t *__restrict__ row_slot,
                                                       int n_out, int64_t V, float *__restrict__ out, int64_t ld,
                                                       const int32_t *__restrict__ n_draw_dev, int n_draw_host, uint32_t *window_out) {
   __shared__ uint32_t st[kRing];
@@ -258,9 +274,12 @@ __global__ __launch_bounds__(256) void mt_rows_kernel(const uint32_t *__restrict
     int nd = n_draw_dev ? *n_draw_dev : n_draw_host;
     nd = nd < 0 ? 0 : (nd > n_win - 1 ? n_win - 1 : nd);
     const uint32_t *w = windows + (size_t)nd * kN;
-    for (int i = t; i < kN; i += 256) st[i] = w[i];  // (through LDS: window_out may be the base window itself)
-    __syncthreads();
-    for (int i = t; i < kN; i += 256) window_out[i] = st[i];
+    for (int i = t; i < kN; i += 256) {
+      uint32_t v = 0;
+#pragma unroll
+      for (int pl = 0; pl < kParts; ++pl) v ^= w[(size_t)pl * plane_stride + i];
+      window_out[i] = v;
+    }
     return;
   }
   const int slot = row_slot ? row_slot[r] : r;
@@ -271,7 +290,12 @@ __global__ __launch_bounds__(256) void mt_rows_kernel(const uint32_t *__restrict
     return;
   }
   const uint32_t *w = windows + (size_t)slot * kN;
-  for (int i = t; i < kN; i += 256) st[i] = w[i];
+  for (int i = t; i < kN; i += 256) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int pl = 0; pl < kParts; ++pl) v ^= w[(size_t)pl * plane_stride + i];
+    st[i] = v;
+  }
   __syncthreads();
   int pos = 0;  // st[(pos + i) & (kRing - 1)] = x[row start + consumed + i]
   for (int64_t v0 = 0; v0 < V; v0 += kStep) {
@@ -296,14 +320,12 @@ __global__ __launch_bounds__(256) void mt_rows_kernel(const uint32_t *__restrict
   }
 }
 
-std::atomic<uint64_t> g_jump_lds_done{0};
-
-int launch_jump(const uint32_t *src, int n_src, const uint64_t *polys, int n_poly, uint32_t *dst, int n_dst, hipStream_t st) {
-  hipError_t e = glb::allow_dynamic_lds(reinterpret_cast<const void *>(mt_jump_kernel), kSeq * (int)sizeof(uint32_t), g_jump_lds_done);
-  if (e != hipSuccess) return api_hip_fail(e, "hipFuncSetAttribute(mt_jump_kernel)");
+int launch_jump(const uint32_t *src, int src_planes, int64_t src_plane_stride, int n_src, const uint64_t *polys, int n_poly,
+                uint32_t *dst, int n_dst, int64_t dst_plane_stride, hipStream_t st) {
   const int quads = (n_poly + 3) / 4;
-  hipLaunchKernelGGL(mt_jump_kernel, dim3((unsigned)(n_src * quads)), dim3(256), kSeq * sizeof(uint32_t), st, src, polys, n_poly, dst, n_dst);
-  e = hipGetLastError();
+  hipLaunchKernelGGL(mt_jump_kernel, dim3((unsigned)(n_src * quads * kParts)), dim3(256), 0, st, src, src_planes, src_plane_stride, polys,
+                     n_poly, dst, n_dst, dst_plane_stride);
+  const hipError_t e = hipGetLastError();
   return e == hipSuccess ? GLB_OK : api_hip_fail(e, "mt_jump_kernel");
 }
 
@@ -372,8 +394,8 @@ int glb_mt19937_jump_host(const uint32_t *window_in, const uint64_t *poly, uint3
 
 size_t glb_mt19937_rows_workspace(int64_t max_draw_rows, int32_t n_small) {
   if (max_draw_rows < 0 || n_small < 2) return 0;
-  const int64_t n_big = (max_draw_rows + 1 + n_small - 1) / n_small;
-  return (size_t)(n_big + n_big * n_small) * kN * sizeof(uint32_t);
+  const int64_t n_big = (max_draw_rows + 1 + n_small - 1) / n_small;  // windows are kept as kParts planes (csrc/glb_mt.hip)
+  return (size_t)(n_big + n_big * n_small) * kN * sizeof(uint32_t) * kParts;
 }
 
 int glb_mt19937_exponential_rows(const glb_mt_rows_args *a, void *hip_stream) {
@@ -390,20 +412,27 @@ int glb_mt19937_exponential_rows(const glb_mt_rows_args *a, void *hip_stream) {
   hipStream_t st = (hipStream_t)hip_stream;
   const int n_win = (int)a->max_draw_rows + 1;
   const int m_need = (n_win + a->n_small - 1) / a->n_small;
-  uint32_t *big = (uint32_t *)a->workspace, *all = big + (size_t)m_need * kN;
+  // (window_out may be `window`: the launches below read `window` before the last one writes window_out)
+  const int64_t big_plane = (int64_t)m_need * kN, all_plane = (int64_t)m_need * a->n_small * kN;
+  uint32_t *big = (uint32_t *)a->workspace, *all = big + big_plane * kParts;
   const uint32_t *lvl1 = a->window;
+  int lvl1_planes = 1;
+  int64_t lvl1_stride = 0;
   if (m_need > 1) {  // the base window -> the window of every n_small-th row
-    int rc = launch_jump(a->window, 1, a->polys + (size_t)a->n_small * kPW, m_need, big, m_need, st);
+    int rc = launch_jump(a->window, 1, 0, 1, a->polys + (size_t)a->n_small * kPW, m_need, big, m_need, big_plane, st);
     if (rc) return rc;
     lvl1 = big;
+    lvl1_planes = kParts;
+    lvl1_stride = big_plane;
   }
-  int rc = launch_jump(lvl1, m_need, a->polys, a->n_small, all, n_win, st);  // -> every row's window (and the one after the last)
+  // -> every row's window (and the one after the last)
+  int rc = launch_jump(lvl1, lvl1_planes, lvl1_stride, m_need, a->polys, a->n_small, all, n_win, all_plane, st);
   if (rc) return rc;
   if (a->n_out_rows || a->window_out) {
     uint32_t *wo = a->window_out;
     const int n_blocks = (int)a->n_out_rows + (wo ? 1 : 0);
-    hipLaunchKernelGGL(mt_rows_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, all, n_win, a->row_slot, (int)a->n_out_rows, a->vocab,
-                       a->out, a->out_ld, a->n_draw, (int)a->max_draw_rows, wo);
+    hipLaunchKernelGGL(mt_rows_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, all, all_plane, n_win, a->row_slot, (int)a->n_out_rows,
+                       a->vocab, a->out, a->out_ld, a->n_draw, (int)a->max_draw_rows, wo);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return api_hip_fail(e, "mt_rows_kernel");
   }

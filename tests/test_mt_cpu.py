@@ -77,4 +77,4 @@ def test_polys_of_another_stride_and_argument_errors():
     assert lib.glb_mt19937_jump_polys(0, 2, 1, polys.ctypes.data_as(C.c_void_p)) == _lib.GLB_EINVAL
     assert lib.glb_mt19937_jump_polys(7, 1, 1, polys.ctypes.data_as(C.c_void_p)) == _lib.GLB_EINVAL
     assert lib.glb_mt19937_jump_polys(7, 2, 1, None) == _lib.GLB_EINVAL
-    assert lib.glb_mt19937_rows_workspace(1024, 32) == (33 + 33 * 32) * 624 * 4
+    assert lib.glb_mt19937_rows_workspace(1024, 32) == (33 + 33 * 32) * 624 * 4 * 4  # (windows as four partial planes)

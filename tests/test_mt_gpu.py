@@ -43,7 +43,7 @@ def test_slots_counts_on_the_device_and_rows_of_ones(engine):
     V, N = 50257, 48
     rng = DeviceRng(engine, 7, V)
     rs = np.random.default_rng(3)
-    want = _host_stream(7, (N + 20) * V).reshape(N + 20, V)
+    want = _host_stream(7, (3 * N + 1) * V).reshape(3 * N + 1, V)
     used = 0
     for call in range(3):
         act = rs.random(N) < 0.7
