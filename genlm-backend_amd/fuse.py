@@ -13,7 +13,9 @@ What the shadow swaps (PyTorch ops only - no kernels of this library inside the 
   * Llama-family RMSNorm spelled as pow / mean / add / rsqrt / mul / two casts / mul (hf modeling_llama.py:52-67)
                                                              -> `torch.nn.functional.rms_norm`          (one kernel)
   * Llama-family rotary embedding spelled as slice / neg / cat / mul / mul / add per tensor (modeling_llama.py:130-160)
-                                                             -> roll + mul + addcmul on the projection's own layout
+                                                             -> roll + mul + addcmul, queries and keys in one pass
+  * the q / k / v projections (three GEMMs)                  -> one GEMM on a derived [q; k; v] weight (a copy of those
+                                                                rows, rebuilt when the caller's weights change)
   * the attention interface                                  -> kv.py's "glb" entry (glb_short_attention /
                                                                 glb_slab_attention where they apply, SDPA otherwise)
 Same functions, different rounding (float32 inside the fused ops, one rounding at the end): the reference's goldens hold
@@ -64,31 +66,68 @@ class FusedRMSNorm(torch.nn.Module):
         return f"{tuple(self.weight.shape)}, eps={self.eps} (fused)"
 
 
-def _rope(x, cos, sin_signed, half):
-    """x [B, T, H, D] (the projection's own layout), cos / sin_signed [B, T, 1, D].  x * cos + rotate_half(x) * sin with
-    rotate_half(x) * sin = roll(x, D/2) * (sin with its first half negated): three kernels instead of six."""
-    return torch.addcmul(x * cos, torch.roll(x, half, -1), sin_signed)
+def _rope(x, rolled, cos, sin_signed):
+    """x, rolled [B, T, H, D] (the projection's own layout; rolled = x with the halves of D swapped), cos / sin_signed
+    [B, T, 1, D].  x * cos + rotate_half(x) * sin with rotate_half(x) * sin = roll(x, D/2) * (sin with its first half
+    negated): three kernels (roll, mul, addcmul) instead of six (slice, neg, cat, mul, mul, add)."""
+    return torch.addcmul(x * cos, rolled, sin_signed)
+
+
+def _merged_qkv(attn):
+    """One weight [q; k; v] for the three projections (one GEMM instead of three, two of them a quarter as wide, and the
+    rotary embedding applied to queries and keys in ONE pass over the joint output).  A derived copy of the caller's
+    weights (q + k + v rows: 12.6 MB a layer at Llama-3.2-1B's shape), rebuilt whenever one of them is replaced or changed
+    in place (`Tensor._version`)."""
+    ws = (attn.q_proj.weight, attn.k_proj.weight, attn.v_proj.weight)
+    bs = (attn.q_proj.bias, attn.k_proj.bias, attn.v_proj.bias)
+    key = tuple((id(t), t._version, t.data_ptr()) for t in ws + bs if t is not None)
+    ent = attn.__dict__.get("_glb_qkv")
+    if ent is None or ent[0] != key:
+        with torch.no_grad():
+            w = torch.cat(ws, 0)
+            b = torch.cat(bs, 0) if bs[0] is not None else None
+        ent = attn.__dict__["_glb_qkv"] = (key, w, b)
+    return ent[1], ent[2]
+
+
+def weights_version(net):
+    """A number that changes when a weight the shadow keeps a derived copy of changes (SlabForward drops its hipGraphs then:
+    a captured launch would keep reading the stale copy)."""
+    v = 0
+    for mod in net.modules():
+        ent = mod.__dict__.get("_glb_qkv")
+        if ent is not None:
+            for t in (mod.q_proj.weight, mod.k_proj.weight, mod.v_proj.weight):
+                v += t._version + (id(t) & 0xFFFF)
+    return v
 
 
 def _llama_attention_forward(self, hidden_states, position_embeddings=None, attention_mask=None, past_key_values=None,
                              **kwargs):
-    """modeling_llama.py:243-281 with the rotary embedding applied before the head transpose (see `_rope`)."""
+    """modeling_llama.py:243-281 with q / k / v from one GEMM and the rotary embedding applied to queries and keys together,
+    before the head transpose (see `_rope`).  A forward that may be differentiated runs the module's own code."""
     from transformers.modeling_utils import ALL_ATTENTION_FUNCTIONS
     from transformers.models.llama.modeling_llama import eager_attention_forward
 
+    if torch.is_grad_enabled() and (hidden_states.requires_grad or self.q_proj.weight.requires_grad):
+        return type(self).forward(self, hidden_states, position_embeddings=position_embeddings, attention_mask=attention_mask,
+                                  past_key_values=past_key_values, **kwargs)
     input_shape = hidden_states.shape[:-1]
-    hidden_shape = (*input_shape, -1, self.head_dim)
-    q = self.q_proj(hidden_states).view(hidden_shape)
-    k = self.k_proj(hidden_states).view(hidden_shape)
-    v = self.v_proj(hidden_states).view(hidden_shape).transpose(1, 2)
+    D = self.head_dim
+    w, b = _merged_qkv(self)
+    qkv = torch.nn.functional.linear(hidden_states, w, b).view(*input_shape, -1, D)  # [B, T, Hq + 2 Hkv, D]
+    n_kv = self.k_proj.weight.shape[0] // D
+    n_q = qkv.shape[-2] - 2 * n_kv
     cos, sin = position_embeddings
     ss = getattr(sin, "_glb_signed", None)
-    half = cos.shape[-1] // 2
+    half = D // 2
     if ss is None:
         ss = torch.cat((-sin[..., :half], sin[..., half:]), dim=-1)
-    cos, ss = cos.unsqueeze(2), ss.unsqueeze(2)
-    q = _rope(q, cos, ss, half).transpose(1, 2)
-    k = _rope(k, cos, ss, half).transpose(1, 2)
+    rolled = torch.roll(qkv, half, -1)  # (the whole joint tensor: a roll of a strided slice would copy it first)
+    qk = _rope(qkv[..., :n_q + n_kv, :], rolled[..., :n_q + n_kv, :], cos.unsqueeze(2), ss.unsqueeze(2))
+    q = qk[..., :n_q, :].transpose(1, 2)
+    k = qk[..., n_q:, :].transpose(1, 2)
+    v = qkv[..., n_q + n_kv:, :].transpose(1, 2)
     if past_key_values is not None:
         k, v = past_key_values.update(k, v, self.layer_idx)
     attention_interface = ALL_ATTENTION_FUNCTIONS.get_interface(self.config._attn_implementation, eager_attention_forward)

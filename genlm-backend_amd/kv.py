@@ -281,6 +281,11 @@ class SlabForward:
         self.graph_ok = bool(graph) and torch.cuda.is_available()
         self.calls = 0
         self.graphs = {}  # identity of the slab set -> (graph, ids, pos, hidden, the slab tensors themselves)
+        # weights the shadow keeps derived copies of (fuse._merged_qkv): a captured graph reads the copy it was captured
+        # with, so the graphs are dropped when one of the sources changes
+        self._watched = [t for mod in body.modules() if hasattr(mod, "q_proj") and hasattr(mod, "k_proj") and hasattr(mod, "v_proj")
+                         for t in (mod.q_proj.weight, mod.k_proj.weight, mod.v_proj.weight)]
+        self._watched_version = self._weights_version()
         # glb_slab_attention instead of two appends + a mask + a dense SDPA call per layer: for models whose attention
         # goes through transformers' attention interface with plain softmax(q k^T * scale) v semantics on a HIP device
         cfg = getattr(body, "config", None)
@@ -292,6 +297,9 @@ class SlabForward:
                           and pkv.engine.slab_attention_supports(k0.dtype, k0.shape[-1])
                           and getattr(cfg, "_attn_implementation", None) == _ATTN_NAME
                           and getattr(cfg, "_glb_engine", None) is pkv.engine)
+
+    def _weights_version(self):
+        return sum(t._version for t in self._watched)
 
     def _run(self, ids, pos):
         pkv = self.pkv
@@ -320,6 +328,11 @@ class SlabForward:
         self.calls += 1
         if not self.graph_ok or not ids.is_cuda or self.calls <= 2:  # (allocator growth, library set-up: outside a capture)
             return self._run(ids, pos)
+        if self._watched:
+            ver = self._weights_version()
+            if ver != self._watched_version:  # the caller changed a weight in place: captured launches would read stale copies
+                self.graphs.clear()
+                self._watched_version = ver
         # a graph belongs to the slab tensors it was captured over: every layer's addresses, shape and dtype make the key,
         # and the entry holds the tensors, so the allocator cannot hand their addresses to another slab set meanwhile
         slabs = self.pkv._tensors(self.pkv.layers)
