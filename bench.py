@@ -250,6 +250,10 @@ def main():
     ap.add_argument("--auto-kv", action="store_true",
                     help="api workload: KV rows that follow the contexts handed to batch_next_token_step (beyond the reference: "
                          "one token per context per step instead of a re-encoding)")
+    ap.add_argument("--device-batch", action="store_true",
+                    help="api workload: the population lives on the device and is submitted as a padded [N, cap] int32 matrix + lengths "
+                         "(AsyncAmdLM.batch_next_token_step_device); results stay on the device, the user-side bookkeeping is one "
+                         "glb_particles_advance launch")
     ap.add_argument("--kv-gather", action="store_true",
                     help="--particle-kv: always gather the live KV rows into batch order (never run the forward on the slab in place)")
     ap.add_argument("--per-row-masks", action="store_true",
@@ -337,7 +341,8 @@ def main():
                                 logits=args.logits, mask_mode=args.mask, rng=args.rng)
     elif workload in ("api", "api-coro", "api-readme", "api-logprobs"):
         runner = ApiWorkload(eng, dev, rank, world, dist, logprobs=workload == "api-logprobs", coro=workload == "api-coro",
-                             auto_kv=args.auto_kv, readme=workload == "api-readme", llm_gather=args.llm_gather)
+                             auto_kv=args.auto_kv, readme=workload == "api-readme", llm_gather=args.llm_gather,
+                             device_batch=args.device_batch)
     else:
         from genlm_backend_amd.sis import SisBenchWorkload
 
@@ -740,7 +745,7 @@ class ApiWorkload:
     dtype_name = "f32"
 
     def __init__(self, eng, dev, rank, world, dist, logprobs=False, coro=False, n_particles=1024, max_tokens=10,
-                 auto_kv=False, readme=False, llm_gather=False):
+                 auto_kv=False, readme=False, llm_gather=False, device_batch=False):
         import asyncio
 
         from transformers import GPT2Config
@@ -754,6 +759,8 @@ class ApiWorkload:
                                           auto_kv_rows=n_particles + n_particles // 4 if auto_kv else 0, auto_kv_cap=24)
         self.auto_kv = auto_kv
         self.llm_gather = llm_gather
+        self.device_batch = device_batch and not (logprobs or coro or readme)
+        self.eng = eng
         V = cfg.vocab_size
         g = torch.Generator(device=dev)
         g.manual_seed(4321)
@@ -783,6 +790,18 @@ class ApiWorkload:
     def _reset(self):
         from genlm_backend_amd.sis import Particle
 
+        if self.device_batch:  # the user's population as device tensors: [N, cap] tokens, lengths, active flags, log-weights
+            N, P = self.N, len(self.prompt)
+            self.cap = P + self.max_tokens + 1
+            ctx = np.zeros((N, self.cap), np.int32)
+            ctx[:, :P] = self.prompt
+            self.d_ctx = torch.from_numpy(ctx).to(self.dev)
+            self.d_len = torch.full((N,), P, dtype=torch.int32, device=self.dev)
+            self.d_act = torch.ones(N, dtype=torch.int32, device=self.dev)
+            self.d_lw = torch.zeros(N, dtype=torch.float32, device=self.dev)
+            self.d_one = torch.ones(N, dtype=torch.int32, device=self.dev)
+            self.t = 0
+            return
         sel = lambda context: 1 if len(context) >= self.max_tokens else 0
         if self.readme:
             self.llm.clear_cache()
@@ -819,7 +838,13 @@ class ApiWorkload:
         if self.t >= self.max_tokens:
             self._reset()
 
-        if self.coro or self.readme:
+        if self.device_batch:  # README.md:82-91 on device tensors: one batched call, one bookkeeping launch, nothing on the host
+            P = len(self.prompt)
+            mask_ids = ((self.d_len - P) >= self.max_tokens).to(torch.int32)
+            len_eff = torch.where(self.d_act > 0, self.d_len, self.d_one)  # (a finished particle: its one-token stub)
+            logZ, tok = self.llm.batch_next_token_step_device(self.d_ctx, len_eff, mask_ids)
+            self.eng.particles_advance(self.d_ctx, self.d_len, self.d_act, self.d_lw, logZ, tok, self.eos, self.cap)
+        elif self.coro or self.readme:
             gather = self.llm.gather if self.llm_gather else aio.gather
 
             async def one_step():
@@ -840,7 +865,8 @@ class ApiWorkload:
         if self.world > 1:
             from genlm_backend_amd.sis import _gather_all
 
-            lw = torch.tensor([p.log_weight for p in self.particles], dtype=torch.float32, device=self.dev)
+            lw = self.d_lw if self.device_batch else \
+                torch.tensor([p.log_weight for p in self.particles], dtype=torch.float32, device=self.dev)
             _gather_all(self.dist, self.gathered, lw)
 
     def kernel_times_us(self):
@@ -858,6 +884,9 @@ class ApiWorkload:
         extra = {}
         if self.llm_gather and (self.coro or self.readme):
             what += "; the coroutines of a step run by AsyncAmdLM.gather (no asyncio Task per particle) instead of asyncio.gather"
+        if self.device_batch:
+            what += ("; the population lives on the device: a padded [N, cap] int32 matrix + lengths in, device tensors out "
+                     "(AsyncAmdLM.batch_next_token_step_device), bookkeeping by one glb_particles_advance launch")
         if self.auto_kv:
             what += "; KV rows follow the contexts (AsyncAmdLM(auto_kv_rows=...): beyond the reference)"
             extra["auto_kv"] = dict(self.llm._auto_kv.stats)

@@ -814,7 +814,7 @@ class AsyncAmdLM(AsyncLM):
         as NumPy arrays."""
         import itertools
 
-        eng, dev = self.engine, self.device
+        dev = self.device
         n = len(contexts)
         if n == 0:
             return np.zeros(0, np.float32), np.zeros(0, np.int32)
@@ -825,16 +825,47 @@ class AsyncAmdLM(AsyncLM):
         flat = np.fromiter(itertools.chain.from_iterable(contexts), np.int32, total)
         starts = np.zeros(n, np.int64)
         starts[1:] = np.cumsum(lens[:-1])
-        tok_d = torch.from_numpy(flat).to(dev)
-        st_d = torch.from_numpy(starts).to(dev)
-        ln_d = torch.from_numpy(lens).to(dev)
-        group_of, rep, ng = eng.group_contexts(tok_d, st_d, ln_d)
-        P = self._prefix_table()
-        base, pref = None, None
         mid_d = None
         if self._mask_kind != MASK_NONE:
             mid = np.zeros(n, np.int32) if mask_ids is None else np.ascontiguousarray(mask_ids, dtype=np.int32)
             mid_d = torch.from_numpy(mid).to(dev)
+        logZ, tok = self._batch_step(torch.from_numpy(flat).to(dev), torch.from_numpy(starts).to(dev),
+                                     torch.from_numpy(lens).to(dev), n, mid_d, l_max=int(lens.max()))
+        out = torch.stack([logZ, tok.to(torch.float32)]).cpu().numpy()  # token ids < 2^24: exact in float32
+        toks = out[1].astype(np.int32)
+        self.engine.raise_if_failed(tokens=toks)  # a finishing wave of the one-launch step gave up waiting (include/glb.h)
+        return out[0], toks
+
+    @torch.no_grad()
+    def batch_next_token_step_device(self, tokens, lengths, mask_ids=None):
+        """`batch_next_token_step` for a population that LIVES ON THE DEVICE: `tokens` int32 [n, cap] (row i's first
+        lengths[i] entries are context i - the padded particle matrix a device-resident loop keeps), `lengths` int32 [n],
+        `mask_ids` int32 [n] or None, all device tensors.  Returns (logZ float32 [n], token int32 [n]) as device tensors:
+        nothing of the population crosses the host in either direction (the call's only D2H copy is the handful of counts
+        the host needs to size the forward; a failed launch shows as token -2 and raises at the next call / `engine.check()`).
+        No counterpart in the reference (its API takes Python lists, hf.py:346-373); this is the same evaluation."""
+        if tokens.dim() != 2 or tokens.dtype != torch.int32 or lengths.dtype != torch.int32 or lengths.numel() != tokens.shape[0]:
+            raise ValueError("tokens must be int32 [n, cap] and lengths int32 [n]")
+        if not tokens.is_contiguous():
+            tokens = tokens.contiguous()
+        n, cap = tokens.shape
+        if n == 0:
+            return (torch.zeros(0, dtype=torch.float32, device=self.device), torch.zeros(0, dtype=torch.int32, device=self.device))
+        key = (n, cap)
+        if getattr(self, "_row_starts", (None,))[0] != key:
+            self._row_starts = (key, torch.arange(n, device=self.device, dtype=torch.int64) * cap)
+        mid_d = None
+        if self._mask_kind != MASK_NONE:
+            mid_d = torch.zeros(n, dtype=torch.int32, device=self.device) if mask_ids is None else mask_ids
+        return self._batch_step(tokens.view(-1), self._row_starts[1], lengths, n, mid_d, l_max=None)
+
+    def _batch_step(self, tok_d, st_d, ln_d, n, mid_d, l_max):
+        """The batched step on a ragged batch that is on the device already.  l_max: the longest context if the host
+        knows it (else it rides on the call's D2H copy).  Returns device tensors."""
+        eng, dev = self.engine, self.device
+        group_of, rep, ng = eng.group_contexts(tok_d, st_d, ln_d)
+        P = self._prefix_table()
+        base, pref = None, None
         head = [ng[0]]
         used_d = None
         auto = self._auto_kv if (self._auto_kv is not None and not P["n"]) else None
@@ -843,13 +874,18 @@ class AsyncAmdLM(AsyncLM):
             head.append((ln_d - base).max().to(torch.int32))
             # which cached prefixes this call uses (they count as recently used, like walk_cache's touch)
             used_d = torch.zeros(P["n"] + 1, dtype=torch.int32, device=dev).index_fill_(0, (pref + 1).long(), 1)[1:]
+        elif l_max is None and auto is None:
+            head.append(ln_d.max().to(torch.int32))
         if mid_d is not None:  # may the mask ids go per logits row? (they do when the mask is a function of the context)
             row_mid = mid_d[rep.long().clamp(0, n - 1)]  # entries of `rep` past the group count are unspecified
             head.append((row_mid[group_of.long()] == mid_d).all().to(torch.int32))
         if auto is not None:
-            # contexts find the KV rows of their first L - 1 tokens (autokv.AutoKV): one token per context is fed
-            logits, row_of_group, group_of_row, U, extra = auto.logits(tok_d, st_d, ln_d, group_of, rep, ng, head[1:])
-            by_row = bool(extra[-1]) if mid_d is not None else False
+            # contexts find the KV rows of their first L - 1 tokens (autokv.AutoKV): one token per context is fed; the error
+            # word of the calls so far rides on the call's one D2H copy
+            logits, row_of_group, group_of_row, U, extra = auto.logits(tok_d, st_d, ln_d, group_of, rep, ng,
+                                                                       head[1:] + [eng.error_word()[0]])
+            eng.raise_if_failed(extra[-1])
+            by_row = bool(extra[-2]) if mid_d is not None else False
             if mid_d is not None:
                 row_mid = row_mid[group_of_row]
             return self._finish_batch_step(logits, row_of_group[group_of.long()], group_of, U, n, mid_d,
@@ -863,7 +899,7 @@ class AsyncAmdLM(AsyncLM):
                     self._kv_lru.touch(node)
             head = head[:n_head]
         U = head[0]
-        l_max = head[1] if P["n"] else int(lens.max())
+        l_max = head[1] if (P["n"] or l_max is None) else l_max
         by_row = bool(head[-1]) if mid_d is not None else False
         p_max = P["p_max"] if P["n"] else 0
         pad_id = getattr(self.tokenizer, "pad_token_id", None) if self.tokenizer is not None else None
@@ -884,7 +920,7 @@ class AsyncAmdLM(AsyncLM):
 
     def _finish_batch_step(self, logits, row_of, group_of, U, n, mid_d, row_mid, by_row):
         """The fused step over a batch's logits rows (row_of: logits row of every context; group_of: its dedup group -
-        the order parity-mode noise is dealt in) and the call's one D2H copy of the results."""
+        the order parity-mode noise is dealt in).  Returns (logZ, token) device tensors."""
         eng, dev = self.engine, self.device
         V = logits.shape[-1]
         kw = self.step_masks(logits.dtype)
@@ -906,10 +942,7 @@ class AsyncAmdLM(AsyncLM):
         self.stats["queries"] += n
         self.stats["unique"] += U
         self.stats["rows"] += U
-        out = torch.stack([logZ, tok.to(torch.float32)]).cpu().numpy()  # token ids < 2^24: exact in float32
-        toks = out[1].astype(np.int32)
-        eng.raise_if_failed(tokens=toks)  # a finishing wave of the one-launch step gave up waiting (include/glb.h)
-        return out[0], toks
+        return logZ, tok
 
     async def batch_next_token_step(self, contexts, mask_ids=None):
         """Awaitable form of `batch_next_token_step_sync` (the evaluation itself blocks the loop, like

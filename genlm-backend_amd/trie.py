@@ -90,6 +90,8 @@ class TokenByteTrie:
         self._cdev = None
         self._plan = None
         self._pdev = None
+        self._tree_cache = None
+        self._sel_plans = {}
 
     def __len__(self):
         return len(self.children)
@@ -173,18 +175,35 @@ class TokenByteTrie:
         cap = int(cap or self.PLAN_CAP)
         if self._plan is not None and self._plan[0] == cap:
             return self._plan[1]
+        plan = self._build_plan(cap, None)
+        self._plan = (cap, plan)
+        return plan
+
+    def _tree(self):
+        """The folded trie as Python sees it: children of every slot, subtree sizes, the root's slot."""
+        if self._tree_cache is None:
+            c = self.compact()
+            n_slots = int(c["n_nodes"])
+            cp, ci = c["child_ptr"].astype(np.int64), c["child_idx"].astype(np.int64)
+            kids = [ci[cp[s]:cp[s + 1]] for s in range(n_slots)]
+            size = np.ones(n_slots, np.int64)
+            for s in range(n_slots):  # ascending slots = children first
+                if len(kids[s]):
+                    size[s] += size[kids[s]].sum()
+            self._tree_cache = (kids, size, int(c["slot_of"][self.root]))
+        return self._tree_cache
+
+    def _build_plan(self, cap, sel_roots):
+        """`plan()` for the forest below `sel_roots` (folded-trie slots, none an ancestor of another; None: the whole trie):
+        only those subtrees are cut into parts, read and reduced - what the masses of a SELECTION of nodes need (the
+        selection's maximal nodes are the roots).  Slots outside the forest get slot -1."""
         c = self.compact()
         n_slots = int(c["n_nodes"])
-        cp, ci = c["child_ptr"].astype(np.int64), c["child_idx"].astype(np.int64)
-        kids = [ci[cp[s]:cp[s + 1]] for s in range(n_slots)]
-        size = np.ones(n_slots, np.int64)
-        for s in range(n_slots):  # ascending slots = children first
-            if len(kids[s]):
-                size[s] += size[kids[s]].sum()
-        root = int(c["slot_of"][self.root])
-        # -- the cut: descend from the root while a subtree is too big for a part
+        kids, size, root = self._tree()
+        forest = [root] if sel_roots is None else sorted(int(r) for r in sel_roots)
+        # -- the cut: descend from the roots while a subtree is too big for a part
         top, cut = [], []
-        stack = [root]
+        stack = list(forest)
         while stack:
             s = stack.pop()
             if size[s] <= cap:
@@ -195,7 +214,6 @@ class TokenByteTrie:
         top.sort()
         cut.sort()
         if len(top) + len(cut) > cap or cap >= 65536:
-            self._plan = (cap, None)
             return None
         # -- parts: first fit, biggest subtrees first
         bins, room = [], []
@@ -262,7 +280,7 @@ class TokenByteTrie:
         n_top = len(top)
         toplocal = np.zeros(0, np.int64)
         if n_top:
-            order, cptr, depth_start = bfs([root], lambda s: s not in top_set)
+            order, cptr, depth_start = bfs([s for s in forest if s in top_set], lambda s: s not in top_set)
             order = np.asarray(order, np.int64)
             is_top = np.fromiter((s in top_set for s in order), bool, len(order))
             top_order = order[is_top]  # breadth first; new slots of the top follow this order
@@ -271,7 +289,7 @@ class TokenByteTrie:
             toplocal = np.nonzero(is_top)[0]
             local_of[top_order] = toplocal
             leaves = np.nonzero(~is_top)[0]
-            desc[T, 0], desc[T, 1], desc[T, 2], desc[T, 3] = slot_base, len(order), 1, len(depth_start) - 1
+            desc[T, 0], desc[T, 1], desc[T, 2], desc[T, 3] = slot_base, len(order), sum(s in top_set for s in forest), len(depth_start) - 1
             desc[T, 4], desc[T, 5] = sum(len(d) for d in depth_all), sum(len(x) for x in cptr_all)
             desc[T, 6], desc[T, 7] = sum(len(x) for x in leaf_src), len(leaves)
             depth_all.append(depth_start)
@@ -282,6 +300,8 @@ class TokenByteTrie:
         node_slot = c["slot_of"].astype(np.int64)
         slot_of_new = new_slot[node_slot]
         node_part = part_of[node_slot]
+        if sel_roots is not None:  # (a selection's plan writes selected nodes only: no node lists)
+            node_part = np.full_like(node_part, -1)
         pn_node, pn_local = [], []
         for p in range(n_parts + 1):
             nodes = np.nonzero(node_part == p)[0]
@@ -320,11 +340,11 @@ class TokenByteTrie:
             inode16.append(np.concatenate([ins, np.zeros(len(ins) & 1, np.int64)]))
             idepth.append(idp)
             if len(idp) > 31:  # (the kernel keeps a part's depth table in 32 words of LDS)
-                self._plan = (cap, None)
                 return None
             lds_bytes = max(lds_bytes, 4 * int(desc[p, 1]) + 2 * len(cptr16[-1]) + 2 * len(inode16[-1]) + 4 * 32)
         cat16 = lambda xs: np.concatenate(list(xs) + [np.zeros(2, np.int64)]).astype(np.uint16)  # (never empty: a device pointer)
-        plan = dict(n_parts=n_parts, n_top=n_top, n_slots=n_slots, n_cut=len(cut), cap=cap, vocab=len(self.decode),
+        plan = dict(n_parts=n_parts, n_top=n_top, n_slots=n_slots if sel_roots is None else slot_base + n_top, n_cut=len(cut), cap=cap,
+                    vocab=len(self.decode),
                     n_nodes=len(self.children), max_local=int(desc[:, 1].max()), top_base=slot_base,
                     lds_bytes=lds_bytes, cptr16=cat16(cptr16), inode16=cat16(inode16), idepth=cat(idepth),
                     desc=desc, depth_start=cat(depth_all), cptr=cat(cptr_all), leaf_src=cat(leaf_src),
@@ -332,8 +352,38 @@ class TokenByteTrie:
                     run_tab=np.asarray(run_tab, np.int32).reshape(-1, 2), pn_local16=cat(pn_local).astype(np.uint16),
                     top_local=toplocal.astype(np.int32), slot_of=slot_of_new.astype(np.int32),
                     slot_compact=np.argsort(new_slot).astype(np.int32))  # new slot -> compact() slot
-        self._plan = (cap, plan)
         return plan
+
+    def selection_plan(self, nodes):
+        """The plan of the sub-forest a selection of nodes needs (`_build_plan`), on the device, cached per selection tensor
+        (its storage and version).  None: use the whole trie's plan (the selection reaches the root, or has no plan)."""
+        key = (nodes.data_ptr(), nodes._version, nodes.numel())
+        ent = self._sel_plans.get(key)
+        if ent is None:
+            if len(self._sel_plans) >= 8:
+                self._sel_plans.pop(next(iter(self._sel_plans)))
+            c = self.compact()
+            kids, size, root = self._tree()
+            sel = np.unique(c["slot_of"].astype(np.int64)[nodes.cpu().numpy().astype(np.int64)])
+            # the maximal selected slots: drop every slot that lies below another selected one (slots ascend children first,
+            # so a subtree is the slot range (s - size[s], s])
+            sel_desc = sel[::-1]
+            roots, lo_bound = [], None
+            for s_ in sel_desc:
+                if lo_bound is not None and s_ > lo_bound:
+                    continue  # inside the last root's subtree
+                roots.append(int(s_))
+                lo_bound = int(s_) - int(size[s_])
+            pl = None
+            if sum(int(size[r]) for r in roots) < 0.5 * int(c["n_nodes"]) and root not in roots:
+                host = self._build_plan(self.PLAN_CAP, roots)
+                if host is not None:
+                    dev = self.engine.device
+                    signed = {np.dtype(np.uint16): np.int16, np.dtype(np.uint32): np.int32, np.dtype(np.uint64): np.int64}
+                    pl = {k: (torch.from_numpy(v.view(signed.get(v.dtype, v.dtype))).to(dev) if isinstance(v, np.ndarray) else v)
+                          for k, v in host.items()}
+            ent = self._sel_plans[key] = (pl, nodes)  # (holds the tensor: its address cannot be handed to another selection)
+        return ent[0]
 
     def plan_device_arrays(self, cap=None):
         """`plan()` on the device (None when the trie has no usable plan)."""
@@ -381,6 +431,7 @@ class TokenByteTrie:
 
     _COMPACT_ROWS = 32  # from here on the kernels keep the values node-major: the folded trie pays
 
+    prune_selection = True  # masses of selected nodes: plan only the sub-forest below them (selection_plan)
     resident = True  # glb_trie_rows (a row of a part of the trie in LDS) when the trie has a plan; False: the level-synchronous kernels
 
     def _batch(self, ws, op, from_logprobs):
@@ -416,6 +467,9 @@ class TokenByteTrie:
         if nodes is not None and nodes.dtype != torch.int32:
             raise TypeError("nodes must be int32")
         pl = self.plan_device_arrays() if self.resident and (layout in ("rows", "slot_rows")) else None
+        if pl is not None and nodes is not None and layout == "rows" and self.prune_selection:
+            # only the subtrees below the selected nodes are read and reduced (a plan of that sub-forest, cached per selection)
+            pl = self.selection_plan(nodes) or pl
         if pl is not None:
             return self.engine.trie_rows(logits, pl, op, True, lse=lse, logit_scale=logit_scale, nodes=nodes,
                                          layout="slots" if layout == "slot_rows" and nodes is None else "rows")

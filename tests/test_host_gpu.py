@@ -759,6 +759,54 @@ def test_trie_rows_in_lds_equal_the_level_kernels_and_the_oracle(engine, oracle,
             assert (own[:, trie.root] - 1.0).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("cap", [250, 20000])
+def test_selected_masses_read_only_the_selected_subtrees(engine, oracle, cap):
+    """Masses of SELECTED nodes (round 5): `TokenByteTrie.selection_plan` plans only the sub-forest below the selection's
+    maximal nodes, so glb_trie_rows reads those subtrees' tokens and reduces those nodes only - results bit-equal to the
+    whole trie's (and through it to the oracle) for random nodes, leaves, a depth-1 node with some of its descendants, and
+    - falling back to the whole plan - the root."""
+    from genlm_backend_amd.tokenization import Token
+    from genlm_backend_amd.trie import TokenByteTrie
+
+    rs = np.random.default_rng(23)
+    words, seen = [], set()
+    while len(words) < 4000:
+        w = bytes(rs.integers(97, 104, int(rs.integers(1, 7))).astype(np.uint8))
+        if w not in seen:
+            seen.add(w)
+            words.append(w)
+    trie = TokenByteTrie([Token(i, w) for i, w in enumerate(words)], engine=engine)
+    trie.PLAN_CAP = cap
+    dev = engine.device
+    V, nn = len(words), len(trie)
+    x = (rs.standard_normal((37, V)) * 3).astype(np.float32)
+    xd = torch.from_numpy(x).to(dev)
+    _, lse, _ = engine.step(xd, vocab=V, rng_mode=0)
+    trie.prune_selection = False
+    rows = trie.masses_from_logits(xd, lse)
+    want = oracle.trie_reduce(np.exp(x.astype(np.float64) - lse.cpu().numpy().astype(np.float64)[:, None]).astype(np.float32), trie.flat(), 0)
+    assert np.abs(rows.cpu().numpy() - want).max() < 1e-5
+    trie.prune_selection = True
+    d1 = sorted(trie.children[trie.root].values())
+    sels = {"random": rs.choice(nn, 256, replace=False), "leaves": trie.idx_to_leaf[rs.choice(V, 500, replace=False), 1],
+            "depth1": np.asarray([d1[0]] + [int(c) for c in trie.jump[d1[0]]]), "root": np.asarray([trie.root, 3, 5])}
+    for name, sel in sels.items():
+        sel_d = torch.from_numpy(np.asarray(sel, np.int32)).to(dev)
+        got = trie.masses_from_logits(xd, lse, nodes=sel_d)
+        assert torch.equal(got, rows[:, sel_d.long()]), name
+        pl = trie.selection_plan(sel_d)
+        assert (pl is None) == (name == "root"), name
+        if pl is not None:
+            assert pl["n_slots"] < trie.plan()["n_slots"] // 2
+        for dt in (torch.bfloat16,):
+            xb = xd.to(dt)
+            _, lb, _ = engine.step(xb, vocab=V, rng_mode=0)
+            trie.prune_selection = False
+            full = trie.masses_from_logits(xb, lb)
+            trie.prune_selection = True
+            assert torch.equal(trie.masses_from_logits(xb, lb, nodes=sel_d), full[:, sel_d.long()]), name
+
+
 def test_trie_rows_on_degenerate_vocabularies(engine, oracle):
     """One token, one chain, two leaves under the root: the plan has one part of one to five slots and no top."""
     from genlm_backend_amd.tokenization import Token
@@ -872,6 +920,65 @@ def test_prefix_kv_is_evicted_least_recently_used_first_on_gpu(llm):
     finally:
         m._kv_lru.budget = old_budget
         m.clear_cache()
+
+
+@pytest.mark.parametrize("auto_rows", [0, 20])
+def test_readme_sis_on_a_device_resident_population_on_gpu(engine, llm, auto_rows):
+    """`AsyncAmdLM.batch_next_token_step_device` on the hardware: the README loop with the population as device tensors (a
+    padded [N, cap] int32 matrix + lengths in, device tensors out, bookkeeping by glb_particles_advance - nothing of the
+    population on the host) reproduces the reference's golden tokens and weights; finished particles ride along as
+    one-token stubs the way DeviceSIS carries them."""
+    from transformers import GPT2Config, GPT2LMHeadModel
+
+    from genlm_backend_amd.llm import AsyncAmdLM
+
+    _, gold = llm
+    dev = engine.device
+    cfg = ast.literal_eval(bytes(gold["config_json"]).decode())
+    model = GPT2LMHeadModel(GPT2Config(**cfg)).eval()
+    model.load_state_dict({k[3:]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("w::")})
+    m = AsyncAmdLM(model.to(dev), None, batch_size=64, timeout=0.02, engine=engine, auto_kv_rows=auto_rows, auto_kv_cap=32)
+    m.tokenizer = Tok()
+    m.register_masks(torch.from_numpy(gold["sis_masks"]))
+    m.set_rng("torch", 1234)
+    prompt = [int(t) for t in gold["sis_prompt"]]
+    N, P, max_tokens = 16, len(prompt), 10
+    cap = P + max_tokens + 1
+    ctx = torch.zeros((N, cap), dtype=torch.int32, device=dev)
+    ctx[:, :P] = torch.tensor(prompt, dtype=torch.int32, device=dev)
+    ln = torch.full((N,), P, dtype=torch.int32, device=dev)
+    act = torch.ones(N, dtype=torch.int32, device=dev)
+    lw = torch.zeros(N, dtype=torch.float32, device=dev)
+    steps = 0
+    while int(act.sum().item()) > 0:
+        idx = torch.nonzero(act > 0).flatten()  # (the reference submits the active particles only: so do the parity draws)
+        mask_ids = ((ln[idx] - P) >= max_tokens).to(torch.int32)
+        logZ, tok = m.batch_next_token_step_device(ctx[idx].contiguous(), ln[idx].contiguous(), mask_ids)
+        assert logZ.is_cuda and tok.is_cuda
+        c, l, a, w = ctx[idx].contiguous(), ln[idx].contiguous(), act[idx].contiguous(), lw[idx].contiguous()
+        engine.particles_advance(c, l, a, w, logZ, tok, 0, cap)
+        ctx[idx], ln[idx], act[idx], lw[idx] = c, l, a, w
+        steps += 1
+    engine.check()
+    ctx_h, ln_h = ctx.cpu().numpy(), ln.cpu().numpy()
+    got = [[int(t) for t in ctx_h[i, P:ln_h[i]]] for i in range(N)]
+    assert got == [_strip(r) for r in gold["sis_contexts"]]
+    assert np.abs(lw.cpu().numpy() - gold["sis_log_weights"]).max() < TOL
+    assert steps == int(gold["sis_steps"][0])
+    # the whole population in every call, finished particles as one-token stubs, Philox draws: equal to the list entry point
+    m.clear_cache()
+    m.set_rng("philox", 7)
+    qs = [prompt + g[:3] for g in got[:6]] + [prompt[:1]]
+    ids = [0, 1, 0, 1, 0, 0, 1]
+    a1 = m.batch_next_token_step_sync(qs, ids)
+    m.clear_cache()
+    m.set_rng("philox", 7)
+    mat = torch.zeros((len(qs), cap), dtype=torch.int32)
+    for i, q in enumerate(qs):
+        mat[i, :len(q)] = torch.tensor(q, dtype=torch.int32)
+    a2 = m.batch_next_token_step_device(mat.to(dev), torch.tensor([len(q) for q in qs], dtype=torch.int32, device=dev),
+                                        torch.tensor(ids, dtype=torch.int32, device=dev))
+    assert np.array_equal(a1[0].view(np.uint32), a2[0].cpu().numpy().view(np.uint32)) and np.array_equal(a1[1], a2[1].cpu().numpy())
 
 
 def test_readme_sis_with_auto_kv_on_gpu(engine, llm):

@@ -263,11 +263,14 @@ def test_trie_accepts_plain_iterables_and_refuses_duplicates():
         TokenByteTrie([Token(0, b"test"), Token(1, b"other"), Token(0, b"test")])
 
 
-def _run_plan(pl, ws, op):
+def _run_plan(pl, ws, op, sel_nodes=None):
     """What glb_trie_rows does with a plan (glb_trie.hip), in numpy: per part the leaves, then depth by depth - children
-    consecutive, ascending, in double, stored as float32 -, then the top from the parts' roots.  Returns [B, n_nodes]."""
+    consecutive, ascending, in double, stored as float32 -, then the top from the parts' roots.  Returns [B, n_nodes], or
+    with `sel_nodes` the selected nodes' values [B, len(sel_nodes)] the way part_write finds them (by slot)."""
     B = ws.shape[0]
     out = np.full((B, pl["n_nodes"]), np.nan, np.float32)
+    sel_slot = None if sel_nodes is None else pl["slot_of"][np.asarray(sel_nodes, np.int64)].astype(np.int64)
+    out_sel = None if sel_nodes is None else np.full((B, len(sel_nodes)), np.nan, np.float32)
     cut = np.full((B, max(pl["n_cut"], 1)), np.nan, np.float32)
     parts = list(range(pl["n_parts"])) + ([pl["n_parts"]] if pl["n_top"] else [])
     for p in parts:
@@ -299,9 +302,62 @@ def _run_plan(pl, ws, op):
             nd = np.concatenate([np.arange(lo, lo + cnt) for lo, cnt in runs]) if len(runs) else np.zeros(0, np.int64)
             assert np.array_equal(nd, pl["pn_node"][d[9]:d[9] + d[10]]) and (top or len(runs) <= int(d[2]))  # (a run per subtree)
             out[r, nd] = val[nl]
+            if sel_slot is not None:
+                base = int(d[0])
+                if top:
+                    mine = sel_slot >= base
+                    out_sel[r, mine] = val[pl["top_local"][sel_slot[mine] - base]]
+                else:
+                    mine = (sel_slot >= base) & (sel_slot < base + n_local)
+                    out_sel[r, mine] = val[sel_slot[mine] - base]
             if not top:
                 cut[r, d[8]:d[8] + n_roots] = val[:n_roots]
-    return out
+    return out if sel_nodes is None else out_sel
+
+
+@pytest.mark.parametrize("cap", [60, 300, 20000])
+def test_selection_plans_give_the_reference_masses(oracle, cap):
+    """TokenByteTrie._build_plan for a SELECTION of nodes (round 5): only the subtrees below the selection's maximal nodes
+    are planned - fewer leaves read, fewer nodes reduced -, and the selected nodes' values are still the oracle's, bit for
+    bit: leaves only, nested selections, a selection whose subtrees need a top of their own (small caps), the root."""
+    from genlm_backend_amd.tokenization import Token
+    from genlm_backend_amd.trie import TokenByteTrie
+
+    rs = np.random.default_rng(8)
+    words, seen = [], set()
+    while len(words) < 1500:
+        w = bytes(rs.integers(97, 103, int(rs.integers(1, 7))).astype(np.uint8))
+        if w not in seen:
+            seen.add(w)
+            words.append(w)
+    trie = TokenByteTrie([Token(i, w) for i, w in enumerate(words)])
+    c = trie.compact()
+    kids, size, root = trie._tree()
+    ws = rs.random((3, len(words))).astype(np.float32)
+    n = len(trie)
+    depth1 = sorted(trie.children[trie.root].values())
+    for sel in (rs.choice(n, 200, replace=False), np.asarray(depth1[:2] + [int(trie.jump[depth1[0]][0])]),
+                trie.idx_to_leaf[:50, 1].astype(np.int64), np.asarray(depth1)):
+        sel = np.asarray(sel, np.int64)
+        slots = np.unique(c["slot_of"].astype(np.int64)[sel])
+        roots, lo = [], None
+        for s_ in slots[::-1]:
+            if lo is not None and s_ > lo:
+                continue
+            roots.append(int(s_))
+            lo = int(s_) - int(size[s_])
+        # no root below another
+        for a in roots:
+            assert not any(b != a and a - size[a] < b <= a for b in roots)
+        pl = trie._build_plan(cap, roots)
+        if pl is None:
+            continue
+        needed = sum(int(size[r]) for r in roots)
+        assert pl["n_slots"] == needed <= c["n_nodes"] and (pl["slot_of"][sel] >= 0).all()
+        for op in (0, 1):
+            want = oracle.trie_reduce(ws, trie.flat(), op)[:, sel]
+            got = _run_plan(pl, ws, op, sel_nodes=sel)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (cap, op)
 
 
 @pytest.mark.parametrize("cap", [40, 300, 20000])
