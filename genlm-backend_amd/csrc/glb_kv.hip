@@ -586,9 +586,27 @@ __global__ __launch_bounds__(64) void short_attention_rows_kernel(const ShortArg
       for (int k = 0; k < EPV; ++k) Ks[p * DH + c * EPV + k] = kf[k], Vs[p * DH + c * EPV + k] = vf[k];
     }
   }
+  // which keys a query position may see, one word per position, once per wave (a byte of the mask per (position, key):
+  // fetched per query group they were thirteen dependent trips to memory a group - half of the kernel's time)
+  const uint32_t all_keys = a.Lk >= 32 ? 0xffffffffu : ((1u << a.Lk) - 1u);
+  uint32_t *vis_t = reinterpret_cast<uint32_t *>(kv_lds + 2 * a.Lk * DH);
+  for (int t = lane; t < a.Lq; t += 64) {
+    uint32_t vis = 0;
+    if (a.mask) {
+      const uint8_t *mrow = a.mask + (int64_t)u * a.m_sr + (int64_t)t * a.m_sq;
+      uint8_t mb[KMAX];
+#pragma unroll
+      for (int p = 0; p < KMAX; ++p) mb[p] = p < a.Lk ? mrow[p] : (uint8_t)0;
+#pragma unroll
+      for (int p = 0; p < KMAX; ++p) vis |= (mb[p] != 0 ? 1u : 0u) << p;
+    } else {
+      const int last = t + a.Lk - a.Lq;  // causal: keys 0 .. last
+      vis = last >= 31 ? 0xffffffffu : ((2u << last) - 1u);
+    }
+    vis_t[t] = vis & all_keys;
+  }
   __syncthreads();
   const int nq = G * a.Lq;
-  const uint32_t all_keys = a.Lk >= 32 ? 0xffffffffu : ((1u << a.Lk) - 1u);
   for (int q0 = 0; q0 < nq; q0 += PP) {
     const int qi = q0 + j;
     const bool live = qi < nq;
@@ -596,15 +614,7 @@ __global__ __launch_bounds__(64) void short_attention_rows_kernel(const ShortArg
     const int g = qc / a.Lq, t = qc - g * a.Lq, h = hk * G + g;
     float qf[EPV];
     unpack16<DT>(*reinterpret_cast<const u32x4 *>(a.q + ((int64_t)u * a.q_sr + (int64_t)h * a.q_sh + (int64_t)t * a.q_sp + i * EPV) * ES), qf);
-    uint32_t vis = 0;  // bit p: query t may see key p
-    if (a.mask) {
-      const uint8_t *mrow = a.mask + (int64_t)u * a.m_sr + (int64_t)t * a.m_sq;
-      for (int p = 0; p < a.Lk; ++p) vis |= (mrow[p] != 0 ? 1u : 0u) << p;
-    } else {
-      const int last = t + a.Lk - a.Lq;  // causal: keys 0 .. last
-      vis = last >= 31 ? 0xffffffffu : ((2u << last) - 1u);
-    }
-    vis &= all_keys;
+    const uint32_t vis = vis_t[t];  // bit p: query t may see key p
     float sc[KMAX];
     float m = -__builtin_huge_valf();
 #pragma unroll
@@ -645,7 +655,7 @@ __global__ __launch_bounds__(64) void short_attention_rows_kernel(const ShortArg
 template <int DT, int DH>
 hipError_t launch_short_rows(const ShortArgs &a, hipStream_t s) {
   const dim3 grid((unsigned)((int64_t)a.U * a.Hkv)), block(64);
-  const size_t lds = (size_t)2 * a.Lk * DH * sizeof(float);
+  const size_t lds = (size_t)2 * a.Lk * DH * sizeof(float) + (size_t)a.Lq * sizeof(uint32_t);
   if (a.Lk <= 16) hipLaunchKernelGGL((short_attention_rows_kernel<DT, DH, 16>), grid, block, lds, s, a);
   else hipLaunchKernelGGL((short_attention_rows_kernel<DT, DH, 32>), grid, block, lds, s, a);
   return hipGetLastError();
@@ -653,7 +663,7 @@ hipError_t launch_short_rows(const ShortArgs &a, hipStream_t s) {
 
 template <int DT>
 hipError_t launch_short_attention(const ShortArgs &a, int head_dim, hipStream_t s) {
-  if (a.Lk <= 32 && (int64_t)a.U * a.Hkv <= 0x7fffffffll) {  // the (row, KV head) form: K / V in LDS once, slots are queries
+  if (a.Lk <= 32 && a.Lq <= 2048 && (int64_t)a.U * a.Hkv <= 0x7fffffffll) {  // the (row, KV head) form: K / V in LDS once, slots are queries
     if (head_dim == 64) return launch_short_rows<DT, 64>(a, s);
     if (head_dim == 128) return launch_short_rows<DT, 128>(a, s);
     if (head_dim == 32) return launch_short_rows<DT, 32>(a, s);
