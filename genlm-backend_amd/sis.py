@@ -265,8 +265,6 @@ class DeviceSIS:
         self._noise_groups = None  # parity draws: the dedup grouping the noise rows are dealt by (set per step)
         self._kv_stale = None  # bool [N]: rows whose KV has to be rebuilt from the context (ancestor on another rank)
         self._row_of_d = torch.full((self.N,), -1, dtype=torch.int32, device=self.dev)  # shared KV: particle -> slab row (-1: none)
-        self._spec_in_place = False  # shared KV: the last step ran on the slab in place (the next one's forward starts before its counts are read)
-        self._copy_stream = getattr(self, "_copy_stream", None)
         # active particles over all ranks as of the last exchange (device scalar; read with the step's one D2H copy)
         self._global_active = torch.tensor(self.N * self.world, dtype=torch.int32, device=self.dev)
         self.all_weights = None
@@ -348,39 +346,8 @@ class DeviceSIS:
         hashes_eff = torch.where(self.active > 0, self.hashes, self._hash_stub)
         group_of, rep, ng = eng.group_contexts(ctx_flat, self.starts, lengths_eff, hashes=hashes_eff)
         plan = eng.kv_plan(group_of, rep, ng, self._row_of_d, lengths_eff, R, self.cap, by_context=True)
-        head_d = torch.cat([plan["head"][:6], torch.stack([self.active.sum().to(torch.int32), self._global_active,
-                                                           eng.error_word()[0]])])
-        # The host needs nine words of the plan (how many rows of which kind) before it can size what follows.  When the
-        # last step ran on the slab in place, this one almost surely does too: its forward - copy-on-append copies, the
-        # graph replay, the output embedding on ALL slab rows (fixed shapes: nothing in it depends on the counts) - is
-        # enqueued BEFORE the host waits, and the nine words come back on a side stream behind the plan kernel only, so the
-        # GPU works through the forward while the host reads them and enqueues the rest of the step.
-        spec = (self._spec_in_place and self.pkv is not None and self.kv_in_place is not None and self.dev.type == "cuda")
-        logits_all = None
-        if spec:
-            if self._copy_stream is None:
-                self._copy_stream = torch.cuda.Stream(device=self.dev)
-                self._head_host = torch.empty(9, dtype=torch.int32, pin_memory=True)
-            ready = torch.cuda.Event()
-            ready.record()
-            with torch.cuda.stream(self._copy_stream):
-                self._copy_stream.wait_event(ready)
-                head_d.record_stream(self._copy_stream)
-                self._head_host.copy_(head_d, non_blocking=True)
-                done = torch.cuda.Event()
-                done.record()
-            self.pkv.copy_rows(plan["copy_src"], plan["copy_len"])  # (rows with nothing to copy: untouched)
-            pos_d = plan["pos_of_row"]
-            ids = self.contexts[plan["ctx_of_row"].clamp_min(0).long(), pos_d.long()].view(-1, 1).long()
-            if self._slab_fwd is None or self._slab_fwd.pkv is not self.pkv:
-                from .kv import SlabForward
-
-                self._slab_fwd = SlabForward(self.pkv, llm._body, graph=self.kv_graph)
-            logits_all = llm._lm_head(self._slab_fwd(ids, pos_d))  # [R, V]: logits row = slab row
-            done.synchronize()
-            head = self._head_host.tolist()
-        else:
-            head = head_d.cpu().tolist()  # the step's one D2H copy
+        head = torch.cat([plan["head"][:6], torch.stack([self.active.sum().to(torch.int32), self._global_active,
+                                                          eng.error_word()[0]])]).cpu().tolist()  # the step's one D2H copy
         U, nA, nB, n_copied, n_unkept, l_max_b, n_active, n_global = head[:8]
         eng.raise_if_failed(head[8])
         self._row_of_d = plan["row_of_context"]
@@ -392,12 +359,7 @@ class DeviceSIS:
         st["steps"] += 1
         logits_parts = []
         fed_a = 0  # tokens the one-token forward is fed: its live rows, or every slab row when it runs in place
-        self._spec_in_place = False
-        if nA and logits_all is not None:  # the forward has run already
-            st["in_place_steps"] += 1
-            fed_a = R
-            self._spec_in_place = True
-        elif nA:
+        if nA:
             if n_copied:
                 self.pkv.copy_rows(plan["copy_src"], plan["copy_len"])
             if self.kv_in_place is not None and nA >= self.kv_in_place * R:
@@ -413,7 +375,6 @@ class DeviceSIS:
                 logits_parts.append(llm._lm_head(hidden.index_select(0, plan["rows_a"][:nA].long())))
                 st["in_place_steps"] += 1
                 fed_a = R
-                self._spec_in_place = True
             else:
                 pos_a = plan["pos_a"][:nA].contiguous()
                 ids = self.contexts[plan["ctx_a"][:nA].long(), pos_a.long()].view(-1, 1).long()
@@ -443,21 +404,9 @@ class DeviceSIS:
                 src_full[R] = -1
                 self.pkv.fill_rows(src, src_full[:R].contiguous(), len_full[:R].contiguous())
         self._fwd_tokens = fed_a + nB * l_max_b
-        self._noise_groups = group_of  # parity draws follow the reference's resolution order: by dedup group
-        if nA and logits_all is not None:
-            # logits row = slab row for the contexts that hold one; the encoded contexts' rows follow behind the slab's
-            ctx_rows = plan["ctx_of_row"].clamp_min(0)
-            if nB == 0:
-                logits, row_of = logits_all, plan["row_of_context"]
-                self._rep = ctx_rows
-            else:
-                logits = torch.cat([logits_all, logits_parts[0]])
-                lr = plan["logits_row"][group_of.long()]  # index into [A rows in plan order; B rows]
-                row_of = torch.where(lr < nA, plan["rows_a"][lr.clamp(max=max(nA - 1, 0)).long()], lr - nA + R)
-                self._rep = torch.cat([ctx_rows, plan["ctx_b"][:nB]])
-            return self._finish_step(logits, row_of.contiguous(), U, n_active, n_global, time_kernel, l_max=1)
         logits = logits_parts[0] if len(logits_parts) == 1 else torch.cat(logits_parts)
         self._rep = torch.cat([plan["ctx_a"][:nA], plan["ctx_b"][:nB]])  # the context behind every logits row
+        self._noise_groups = group_of  # parity draws follow the reference's resolution order: by dedup group
         row_of = plan["logits_row"][group_of.long()]
         return self._finish_step(logits, row_of, U, n_active, n_global, time_kernel, l_max=1)
 

@@ -213,7 +213,7 @@ class TokenByteTrie:
                 stack.extend(kids[s].tolist())
         top.sort()
         cut.sort()
-        if len(top) + len(cut) > cap or cap >= 65536:
+        if cap >= 65536:
             return None
         # -- parts: first fit, biggest subtrees first
         bins, room = [], []
@@ -281,6 +281,8 @@ class TokenByteTrie:
         toplocal = np.zeros(0, np.int64)
         if n_top:
             order, cptr, depth_start = bfs([s for s in forest if s in top_set], lambda s: s not in top_set)
+            if len(order) > cap:  # the top and the cut roots below it have to fit a part
+                return None
             order = np.asarray(order, np.int64)
             is_top = np.fromiter((s in top_set for s in order), bool, len(order))
             top_order = order[is_top]  # breadth first; new slots of the top follow this order
