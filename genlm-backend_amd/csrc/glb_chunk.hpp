@@ -40,6 +40,7 @@
 #define GLB_STATS_WAVES_16 5  // stats waves per SIMD for 2-byte elements (6: 80 registers, 42 spilled: 43 us against 34)
 #endif
 
+#include "glb_diag.hpp"
 #include "glb_math.hpp"
 
 namespace glb {
@@ -91,10 +92,7 @@ struct StepParams {
   // fused launch (one-wave workgroups): blocks [0, stats_blocks) reduce one (unit, chunk) each, then fin_blocks
   // finishing waves (wave f takes particles f, f + fin_blocks, ...)
   int32_t stats_blocks, fin_blocks;
-  // diagnostic build only (GLB_STAMPS; tools/r4_kernel_ab.sh, DESIGN.md §5 - both placements measured slower and are not
-  // in the product): il_lag >= 0 deals the finishing blocks INSIDE the grid, il_lag units behind their rows' stats
-  // blocks; short_last deals every row's short last chunk after all full chunks
-  int32_t il_lag, short_last, dbg_mode;
+  GLB_DIAG(DiagParams diag;)  // diagnostic build only (glb_diag.hpp)
   uint32_t *err;      // nullable: word a wave that gave up waiting adds 1 to (glb_workspace_check)
   uint64_t spin_ticks;  // the watchdog of the waits inside the launch, in s_memrealtime ticks
 };
@@ -515,28 +513,22 @@ template <int DT, int MASK, bool SCALED>
 __device__ __forceinline__ void stats_item(const StepParams &p, int item, int lane) {
   constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC;
   const int nch = p.nch;
-#ifdef GLB_STAMPS  // diagnostic build (tools/dbg/stamps.py): wave start / end times in the record's padding
-  const uint64_t stamp0 = __builtin_amdgcn_s_memrealtime();
-#endif
+  GLB_DIAG(const uint64_t stamp0 = GLB_NOW();)
   int pr = item / nch, c = item - pr * nch;  // (dealt chunk-major instead - every row's chunk 0, then every row's chunk 1, ... - the launch is 2.5 us slower)
-#ifdef GLB_STAMPS
-  if (p.short_last) {  // every row's short last chunk after all the full ones: 2 us slower (profiles/r04/ab_short_last_v1.log)
-    const int nfull = nch - 1, split = p.n_pairs * nfull;
-    pr = item < split ? item / nfull : item - split;
-    c = item < split ? item - pr * nfull : nfull;
-  }
-#endif
+  GLB_DIAG(
+    if (p.diag.short_last) {
+      const int nfull = nch - 1, split = p.n_pairs * nfull;
+      pr = item < split ? item / nfull : item - split;
+      c = item < split ? item - pr * nfull : nfull;
+    }
+  )
   int row = p.pair_row ? as_const(p.pair_row)[pr] : pr;
-#ifdef GLB_STAMPS
-  if (p.dbg_mode == 2) row &= 7;  // (timing experiment: the rows come out of the caches)
-#endif
+  GLB_DIAG(if (p.diag.dbg_mode == 2) row &= 7;)
   const char *rowp = (const char *)p.logits + (int64_t)row * p.ld * ES;
   const int V = p.V, e_base = c * kChunk;
   int nv_valid = (V - e_base + 64 * EPV - 1) / (64 * EPV);
   nv_valid = nv_valid < NVC ? nv_valid : NVC;
-#ifdef GLB_STAMPS
-  if (p.dbg_mode == 1) nv_valid = 1;  // (timing experiment: one vector's worth of exponentials instead of sixteen / eight)
-#endif
+  GLB_DIAG(if (p.diag.dbg_mode == 1) nv_valid = 1;)
 
   // the chunk's loads go out first: everything below that has to wait for a scalar load (the mask id of the unit, then
   // the mask words) waits while they are in flight, not in front of them
@@ -578,13 +570,13 @@ __device__ __forceinline__ void stats_item(const StepParams &p, int item, int la
     }
   }
   store_rec(p.recs + ((int64_t)pr * nch + c) * kRecWords, p.epoch, lane, Nc, Nm, pA, pB, rA, rB);
-#ifdef GLB_STAMPS
-  if (lane == 0) {
-    uint64_t *r = p.recs + ((int64_t)pr * nch + c) * kRecWords;
-    r[12] = stamp0;
-    r[13] = __builtin_amdgcn_s_memrealtime();
-  }
-#endif
+  GLB_DIAG(
+    if (lane == 0) {
+      uint64_t *r = p.recs + ((int64_t)pr * nch + c) * kRecWords;
+      r[12] = stamp0;
+      r[13] = GLB_NOW();
+    }
+  )
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -604,9 +596,7 @@ __global__ __launch_bounds__(256) void chunk_stats_small_kernel(const StepParams
   __shared__ uint32_t s_pay[4][10];  // per wave: pA, pB, rA[4], rB[4]
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int item = blockIdx.x, nch = p.nch;
-#ifdef GLB_STAMPS
-  const uint64_t stamp0 = __builtin_amdgcn_s_memrealtime();
-#endif
+  GLB_DIAG(const uint64_t stamp0 = GLB_NOW();)
   const int pr = item / nch, c = item - pr * nch;
   const int row = p.pair_row ? as_const(p.pair_row)[pr] : pr;
   const char *rowp = (const char *)p.logits + (int64_t)row * p.ld * ES;
@@ -714,13 +704,13 @@ __global__ __launch_bounds__(256) void chunk_stats_small_kernel(const StepParams
     const uint32_t qa[4] = {t[2], t[3], t[4], t[5]}, qb[4] = {t[6], t[7], t[8], t[9]};
     store_rec(p.recs + ((int64_t)pr * nch + c) * kRecWords, p.epoch, lane, Nc, Nm, t[0], t[1], qa, qb);
   }
-#ifdef GLB_STAMPS
-  if (wave == 0 && lane == 0) {
-    uint64_t *r = p.recs + ((int64_t)pr * nch + c) * kRecWords;
-    r[12] = stamp0;
-    r[13] = __builtin_amdgcn_s_memrealtime();
-  }
-#endif
+  GLB_DIAG(
+    if (wave == 0 && lane == 0) {
+      uint64_t *r = p.recs + ((int64_t)pr * nch + c) * kRecWords;
+      r[12] = stamp0;
+      r[13] = GLB_NOW();
+    }
+  )
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -794,7 +784,7 @@ __device__ __forceinline__ bool recs_acquire(Recs &R, int nch, int lane, uint64_
   R.cached = nch <= 64;
   R.mine = ChunkRec{kNegInf, kNegInf, 0u, 0u, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, 0u, 0u};
   uint64_t t0 = 0;
-  if constexpr (POLL) t0 = __builtin_amdgcn_s_memrealtime();
+  if constexpr (POLL) t0 = GLB_NOW();
   for (int c0 = 0; c0 < nch; c0 += 64) {
     const int c = c0 + lane;
     for (;;) {
@@ -811,7 +801,7 @@ __device__ __forceinline__ bool recs_acquire(Recs &R, int nch, int lane, uint64_
         }
         if (__builtin_amdgcn_ballot_w64(!seen) != 0ull) {
           __builtin_amdgcn_s_sleep(2);
-          if (__builtin_amdgcn_s_memrealtime() - t0 > spin_ticks) return false;
+          if (GLB_NOW() - t0 > spin_ticks) return false;
           continue;
         }
       }
@@ -822,7 +812,7 @@ __device__ __forceinline__ bool recs_acquire(Recs &R, int nch, int lane, uint64_
       if constexpr (!POLL) break;
       if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
       __builtin_amdgcn_s_sleep(2);
-      if (__builtin_amdgcn_s_memrealtime() - t0 > spin_ticks) return false;
+      if (GLB_NOW() - t0 > spin_ticks) return false;
     }
   }
   return true;
@@ -994,10 +984,10 @@ __device__ __forceinline__ void finish_draw(const StepParams &p, int pidx, int l
   const int pr = p.pair_of ? as_const(p.pair_of)[pidx] : pidx;
   const int row = p.pair_row ? as_const(p.pair_row)[pr] : pr;
   const int mi = MASK == kMaskNone ? 0 : (p.pair_mask ? as_const(p.pair_mask)[pr] : (p.n_masks == 1 ? 0 : pr));
-#ifdef GLB_STAMPS  // diagnostic build: time stamps of every particle's finishing wave through out_margin (tools/dbg/stamps.py)
-  uint64_t *stamps = p.out_margin ? reinterpret_cast<uint64_t *>(p.out_margin) + (int64_t)pidx * 8 : nullptr;
-  if (stamps && lane == 0) stamps[0] = __builtin_amdgcn_s_memrealtime();
-#endif
+  GLB_DIAG(
+    uint64_t *stamps = p.out_margin ? reinterpret_cast<uint64_t *>(p.out_margin) + (int64_t)pidx * 8 : nullptr;
+    if (stamps && lane == 0) stamps[0] = GLB_NOW();
+  )
   uint64_t R1, R2;
   philox_pair(p, pidx, R1, R2);  // (before the wait: the draws need nothing from the records)
   Recs recs;
@@ -1013,9 +1003,7 @@ __device__ __forceinline__ void finish_draw(const StepParams &p, int pidx, int l
     }
     return;
   }
-#ifdef GLB_STAMPS
-  if (stamps && lane == 0) stamps[1] = __builtin_amdgcn_s_memrealtime();
-#endif
+  GLB_DIAG(if (stamps && lane == 0) stamps[1] = GLB_NOW();)
   PairState st;
   ChunkPick pick{-1, 0.f, R2, {0ull, 0ull, 0ull, 0ull}};
   const bool fast = recs.cached;  // rows of up to 64 chunks: lane c holds record c
@@ -1032,9 +1020,7 @@ __device__ __forceinline__ void finish_draw(const StepParams &p, int pidx, int l
     }
     const uint64_t incl = wave_scan_u64(sm);
     st.S_msk = readlane_u64(incl, 63);
-#ifdef GLB_STAMPS
-    if (stamps && lane == 0) stamps[4] = __builtin_amdgcn_s_memrealtime();
-#endif
+    GLB_DIAG(if (stamps && lane == 0) stamps[4] = GLB_NOW();)
     uint32_t nz = (uint32_t)st.S_msk | (uint32_t)(st.S_msk >> 32);
     opaque_u32(nz);
     if (nz != 0u) {
@@ -1049,14 +1035,10 @@ __device__ __forceinline__ void finish_draw(const StepParams &p, int pidx, int l
     }
   } else {
     pair_fold<MASK>(recs, nch, lane, st);
-#ifdef GLB_STAMPS
-    if (stamps && lane == 0) stamps[4] = __builtin_amdgcn_s_memrealtime();
-#endif
+    GLB_DIAG(if (stamps && lane == 0) stamps[4] = GLB_NOW();)
     pick = pair_pick_chunk(recs, st, R1, R2, nch, lane);
   }
-#ifdef GLB_STAMPS
-  if (stamps && lane == 0) stamps[5] = __builtin_amdgcn_s_memrealtime();
-#endif
+  GLB_DIAG(if (stamps && lane == 0) stamps[5] = GLB_NOW();)
   int32_t tok = -1;
   if (pick.csel >= 0) {
     // ---- the 16-lane row: four wave-uniform sums, picked in scalar registers
@@ -1099,9 +1081,7 @@ __device__ __forceinline__ void finish_draw(const StepParams &p, int pidx, int l
         }
       }
     }
-#ifdef GLB_STAMPS
-    if (stamps && lane == 0) stamps[6] = __builtin_amdgcn_s_memrealtime();
-#endif
+    GLB_DIAG(if (stamps && lane == 0) stamps[6] = GLB_NOW();)
     {  // while the quarter chunk is on its way: the sums of all elements and the two logarithms (outputs, not inputs of the draw)
       if (fast) {
         if constexpr (MASK == kMaskNone) st.N_all = st.N_msk, st.S_all = st.S_msk;
@@ -1114,11 +1094,11 @@ __device__ __forceinline__ void finish_draw(const StepParams &p, int pidx, int l
         if (p.out_logZ) p.out_logZ[pidx] = logZ;
       }
     }
-#ifdef GLB_STAMPS
-    if (stamps && lane == 0) stamps[7] = __builtin_amdgcn_s_memrealtime();
-    asm volatile("" ::"v"(y[15]));  // [3]: the quarter chunk has arrived (the wave waits for its last vector here)
-    if (stamps && lane == 0) stamps[3] = __builtin_amdgcn_s_memrealtime();
-#endif
+    GLB_DIAG(
+      if (stamps && lane == 0) stamps[7] = GLB_NOW();
+      asm volatile("" ::"v"(y[15]));
+      if (stamps && lane == 0) stamps[3] = GLB_NOW();
+    )
     float t[16], P = 0.0f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -1163,9 +1143,7 @@ __device__ __forceinline__ void finish_draw(const StepParams &p, int pidx, int l
     }
   }
   if (lane == 0) p.out_token[pidx] = tok;
-#ifdef GLB_STAMPS
-  if (stamps && lane == 0) stamps[2] = __builtin_amdgcn_s_memrealtime();
-#endif
+  GLB_DIAG(if (stamps && lane == 0) stamps[2] = GLB_NOW();)
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1190,18 +1168,18 @@ __global__ __launch_bounds__(64, (StatsWaves<DT, MASK>::value)) void fused_step_
   const int lane = threadIdx.x;
   const int blk = blockIdx.x;
   int item = blk < p.stats_blocks ? blk : -1, pfirst = blk - p.stats_blocks;
-#ifdef GLB_STAMPS
-  if (p.il_lag >= 0) {  // finishing blocks inside the grid (slower at every lag tried: profiles/r04/ab_fin_lag_v1.log)
-    const int head = p.il_lag * p.nch, b = blk - head;
-    item = blk;
-    if (b >= 0) {
-      const int per = p.nch + 1, n_mid = p.n_pairs - p.il_lag;
-      const int q = (int)((unsigned)b / (unsigned)per), r = b - q * per;
-      item = q < n_mid && r < p.nch ? (p.il_lag + q) * p.nch + r : -1;
-      pfirst = q < n_mid ? q : n_mid + (b - n_mid * per);
+  GLB_DIAG(
+    if (p.diag.il_lag >= 0) {
+      const int head = p.diag.il_lag * p.nch, b = blk - head;
+      item = blk;
+      if (b >= 0) {
+        const int per = p.nch + 1, n_mid = p.n_pairs - p.diag.il_lag;
+        const int q = (int)((unsigned)b / (unsigned)per), r = b - q * per;
+        item = q < n_mid && r < p.nch ? (p.diag.il_lag + q) * p.nch + r : -1;
+        pfirst = q < n_mid ? q : n_mid + (b - n_mid * per);
+      }
     }
-  }
-#endif
+  )
   if (item >= 0) {
     stats_item<DT, MASK, SCALED>(p, item, lane);
     return;
@@ -1541,9 +1519,7 @@ __global__ __launch_bounds__(64, WPS) void logprob_rows_waves_kernel(
   static_assert(CPW == 1 || DT != kDtF32, "a float32 chunk fills the registers by itself");
   constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC;
   const int lane = threadIdx.x;
-#ifdef GLB_STAMPS  // diagnostic build (tools/dbg/stamps_lsm.py): [start, record out, lse in, stores drained] in the record's padding
-  const uint64_t stamp0 = __builtin_amdgcn_s_memrealtime();
-#endif
+  GLB_DIAG(const uint64_t stamp0 = GLB_NOW();)
   const int r = (int)(blockIdx.x / (unsigned)wpr), w = (int)(blockIdx.x - (unsigned)r * (unsigned)wpr);
   const int c0 = w * CPW;
   const char *rowp = (const char *)logits + (int64_t)r * ld * ES;
@@ -1569,17 +1545,17 @@ __global__ __launch_bounds__(64, WPS) void logprob_rows_waves_kernel(
                            __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-#ifdef GLB_STAMPS
-  uint64_t *stamps = row_recs + (int64_t)c0 * kRecWords + 12;
-  if (lane == 0) stamps[0] = stamp0, stamps[1] = __builtin_amdgcn_s_memrealtime();
-#endif
+  GLB_DIAG(
+    uint64_t *stamps = row_recs + (int64_t)c0 * kRecWords + 12;
+    if (lane == 0) stamps[0] = stamp0, stamps[1] = GLB_NOW();
+  )
   // The row's FIRST wave (placed before its row-mates) sweeps the records - lane j takes record j: the three granules in
   // one sweep, so the sweep that finds every tag in place already holds the values -, folds lse and publishes it as one
   // more tagged granule (word 1 of chunk 0's record); the other waves of the row wait for that one granule: one 8-byte
   // poll per sweep instead of nch of them, and one pass through the double-precision logarithm per row instead of one per
   // wave (fp64 instructions issue at a fraction of the fp32 rate).
   float lse = __builtin_nanf("");
-  const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+  const uint64_t t0 = GLB_NOW();
   if (w != 0) {
     for (;;) {
       const uint64_t g = __hip_atomic_load(row_recs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1588,7 +1564,7 @@ __global__ __launch_bounds__(64, WPS) void logprob_rows_waves_kernel(
         break;
       }
       __builtin_amdgcn_s_sleep(8);
-      if (__builtin_amdgcn_s_memrealtime() - t0 > spin_ticks) {
+      if (GLB_NOW() - t0 > spin_ticks) {
         if (lane == 0 && err) atomicAdd(err, 1u);  // (the chunks come out as NaN: a failed launch, never a result)
         break;
       }
@@ -1610,7 +1586,7 @@ __global__ __launch_bounds__(64, WPS) void logprob_rows_waves_kernel(
       }
       if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
       __builtin_amdgcn_s_sleep(8);
-      if (__builtin_amdgcn_s_memrealtime() - t0 > spin_ticks) {
+      if (GLB_NOW() - t0 > spin_ticks) {
         have = false;
         break;
       }
@@ -1632,9 +1608,7 @@ __global__ __launch_bounds__(64, WPS) void logprob_rows_waves_kernel(
       if (out_lse) out_lse[r] = lse;
     }
   }
-#ifdef GLB_STAMPS
-  if (lane == 0) stamps[2] = __builtin_amdgcn_s_memrealtime();
-#endif
+  GLB_DIAG(if (lane == 0) stamps[2] = GLB_NOW();)
   if (out_v) {
     // (the lane index as a new value: element indices of the ragged last chunk's stores are otherwise computed next to
     // those of its loads, ahead of the wait, and spilled across it)
@@ -1645,10 +1619,10 @@ __global__ __launch_bounds__(64, WPS) void logprob_rows_waves_kernel(
       if (j == 0 || c0 + j < nch)
         chunk_store_logprobs<DT, SCALED, STORE, OUT16>(raw[j], scale, lse, out_v, (int64_t)r * out_ld, (c0 + j) * kChunk, V, lane_s);
   }
-#ifdef GLB_STAMPS
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the stores have left the wave's queue)
-  if (lane == 0) stamps[3] = __builtin_amdgcn_s_memrealtime();
-#endif
+  GLB_DIAG(
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) stamps[3] = GLB_NOW();
+  )
 }
 
 // ---------------------------------------------------------------------------------------------------------

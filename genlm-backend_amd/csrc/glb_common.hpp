@@ -4,6 +4,9 @@
 
 #include <atomic>
 
+// launch grids: blocks of t threads for n items
+inline unsigned blocks_for(int64_t n, int t) { return (unsigned)((n + t - 1) / t); }
+
 namespace glb {
 // set the calling thread's error message (glb_last_error) and return `code`
 int api_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));

@@ -569,27 +569,49 @@ template <int DT, int DH, int KMAX>
 __global__ __launch_bounds__(64) void short_attention_rows_kernel(const ShortArgs a) {
   constexpr int ES = DT == GLB_F32 ? 4 : 2, EPV = 16 / ES, LP = DH / EPV, PP = 64 / LP;
   static_assert(LP >= 1 && LP <= 64 && PP * LP == 64, "head_dim / vector width must divide the wave");
-  extern __shared__ float kv_lds[];  // K [Lk][DH], then V [Lk][DH], float32
+  // up to 16 keys: a lane keeps its chunk of every key in registers (K never passes through LDS: with K and V both read
+  // from LDS for every query group the LDS data path - 1 KB a read instruction - took as long as the arithmetic)
+  constexpr bool KREG = KMAX * EPV <= 128;
+  extern __shared__ float kv_lds[];  // V [Lk][DH] (and before it K [Lk][DH] when the keys do not fit registers), float32
   const int lane = threadIdx.x, j = lane / LP, i = lane - j * LP;
   const int G = a.H / a.Hkv;
   const int hk = blockIdx.x % a.Hkv, u = blockIdx.x / a.Hkv;
-  float *Ks = kv_lds, *Vs = kv_lds + a.Lk * DH;
-  {
-    const char *kb = a.k + ((int64_t)u * a.k_sr + (int64_t)hk * a.k_sh) * ES;
-    const char *vb = a.v + ((int64_t)u * a.v_sr + (int64_t)hk * a.v_sh) * ES;
-    for (int x = lane; x < a.Lk * LP; x += 64) {
-      const int p = x / LP, c = x - p * LP;
-      float kf[EPV], vf[EPV];
-      unpack16<DT>(*reinterpret_cast<const u32x4 *>(kb + ((int64_t)p * a.k_sp + c * EPV) * ES), kf);
-      unpack16<DT>(*reinterpret_cast<const u32x4 *>(vb + ((int64_t)p * a.v_sp + c * EPV) * ES), vf);
+  float *Ks = kv_lds, *Vs = KREG ? kv_lds : kv_lds + a.Lk * DH;
+  const char *kb = a.k + ((int64_t)u * a.k_sr + (int64_t)hk * a.k_sh) * ES;
+  const char *vb = a.v + ((int64_t)u * a.v_sr + (int64_t)hk * a.v_sh) * ES;
+  const int nq = G * a.Lq;
+  // the first query group's vectors go out with the keys
+  auto q_addr = [&](int qi) {
+    const int qc = qi < nq ? qi : nq - 1;
+    const int g = qc / a.Lq, t = qc - g * a.Lq;
+    return a.q + ((int64_t)u * a.q_sr + (int64_t)(hk * G + g) * a.q_sh + (int64_t)t * a.q_sp + i * EPV) * ES;
+  };
+  u32x4 q_raw = *reinterpret_cast<const u32x4 *>(q_addr(j));
+  float kr[KREG ? KMAX : 1][EPV];
+  if constexpr (KREG) {
+    u32x4 raw[KMAX];
 #pragma unroll
-      for (int k = 0; k < EPV; ++k) Ks[p * DH + c * EPV + k] = kf[k], Vs[p * DH + c * EPV + k] = vf[k];
+    for (int p = 0; p < KMAX; ++p)
+      raw[p] = *reinterpret_cast<const u32x4 *>(kb + ((int64_t)(p < a.Lk ? p : 0) * a.k_sp + i * EPV) * ES);
+#pragma unroll
+    for (int p = 0; p < KMAX; ++p) unpack16<DT>(raw[p], kr[p]);
+  }
+  for (int x = lane; x < a.Lk * LP; x += 64) {
+    const int p = x / LP, c = x - p * LP;
+    float vf[EPV];
+    unpack16<DT>(*reinterpret_cast<const u32x4 *>(vb + ((int64_t)p * a.v_sp + c * EPV) * ES), vf);
+#pragma unroll
+    for (int k = 0; k < EPV; ++k) Vs[p * DH + c * EPV + k] = vf[k];
+    if constexpr (!KREG) {
+      float kf[EPV];
+      unpack16<DT>(*reinterpret_cast<const u32x4 *>(kb + ((int64_t)p * a.k_sp + c * EPV) * ES), kf);
+#pragma unroll
+      for (int k = 0; k < EPV; ++k) Ks[p * DH + c * EPV + k] = kf[k];
     }
   }
-  // which keys a query position may see, one word per position, once per wave (a byte of the mask per (position, key):
-  // fetched per query group they were thirteen dependent trips to memory a group - half of the kernel's time)
+  // which keys a query position may see, one word per position, once per wave
   const uint32_t all_keys = a.Lk >= 32 ? 0xffffffffu : ((1u << a.Lk) - 1u);
-  uint32_t *vis_t = reinterpret_cast<uint32_t *>(kv_lds + 2 * a.Lk * DH);
+  uint32_t *vis_t = reinterpret_cast<uint32_t *>(kv_lds + (KREG ? 1 : 2) * a.Lk * DH);
   for (int t = lane; t < a.Lq; t += 64) {
     uint32_t vis = 0;
     if (a.mask) {
@@ -606,14 +628,14 @@ __global__ __launch_bounds__(64) void short_attention_rows_kernel(const ShortArg
     vis_t[t] = vis & all_keys;
   }
   __syncthreads();
-  const int nq = G * a.Lq;
   for (int q0 = 0; q0 < nq; q0 += PP) {
     const int qi = q0 + j;
     const bool live = qi < nq;
     const int qc = live ? qi : nq - 1;
     const int g = qc / a.Lq, t = qc - g * a.Lq, h = hk * G + g;
     float qf[EPV];
-    unpack16<DT>(*reinterpret_cast<const u32x4 *>(a.q + ((int64_t)u * a.q_sr + (int64_t)h * a.q_sh + (int64_t)t * a.q_sp + i * EPV) * ES), qf);
+    unpack16<DT>(q_raw, qf);
+    if (q0 + PP < nq) q_raw = *reinterpret_cast<const u32x4 *>(q_addr(qi + PP));  // the next group's vectors travel while this one is worked on
     const uint32_t vis = vis_t[t];  // bit p: query t may see key p
     float sc[KMAX];
     float m = -__builtin_huge_valf();
@@ -621,10 +643,15 @@ __global__ __launch_bounds__(64) void short_attention_rows_kernel(const ShortArg
     for (int p = 0; p < KMAX; ++p) {
       sc[p] = -__builtin_huge_valf();
       if (p < a.Lk) {  // (wave-uniform)
-        const float *kp = Ks + p * DH + i * EPV;
         float s = 0.0f;
+        if constexpr (KREG) {
 #pragma unroll
-        for (int k = 0; k < EPV; ++k) s = __builtin_fmaf(qf[k], kp[k], s);
+          for (int k = 0; k < EPV; ++k) s = __builtin_fmaf(qf[k], kr[p][k], s);
+        } else {
+          const float *kp = Ks + p * DH + i * EPV;
+#pragma unroll
+          for (int k = 0; k < EPV; ++k) s = __builtin_fmaf(qf[k], kp[k], s);
+        }
         s = slot_sum<LP>(s) * a.scale;
         sc[p] = ((vis >> p) & 1u) ? s : -__builtin_huge_valf();
         m = fmaxf(m, sc[p]);
@@ -679,9 +706,121 @@ hipError_t launch_short_attention(const ShortArgs &a, int head_dim, hipStream_t 
   return hipGetLastError();
 }
 
+// ---- KV slab rows: append, gather (moved here from glb_api.hip in round 5) ---------------------------------------------------
+
+// slab[row_of[i] (or i), h, pos[i], :] = rows[i, h, :]  (one new token per forward row; rows may be a strided view)
+template <typename VT>
+__global__ void kv_append_kernel(VT *slab, const VT *rows, const int32_t *pos, const int32_t *row_of, int64_t n_rows,
+                                 int64_t heads, int64_t cap, int64_t row_vecs, int64_t rows_stride_row,
+                                 int64_t rows_stride_head) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n_rows * heads * row_vecs) return;
+  const int64_t x = gid % row_vecs, h = (gid / row_vecs) % heads, i = gid / (row_vecs * heads);
+  const int64_t p = pos[i], r = row_of ? (int64_t)row_of[i] : i;
+  if (p < 0 || p >= cap || r < 0) return;
+  slab[((r * heads + h) * cap + p) * row_vecs + x] = rows[i * rows_stride_row + h * rows_stride_head + x];
+}
+
+// dst[t][i, h, p, :] = src[t][src_row_of[i], h, p, :] for p < len_of[i]; src_row_of[i] < 0 leaves row i alone.
+// One launch moves every layer's K and V (pointer tables): fan-out of prompt KV to particles, ancestor gather.
+template <typename VT>
+__global__ void kv_gather_rows_kernel(const VT *const *src, VT *const *dst, int64_t n_rows, int64_t heads,
+                                      int64_t row_vecs, int64_t src_cap, int64_t dst_cap, const int32_t *src_row_of,
+                                      const int32_t *len_of) {
+  const int t = blockIdx.y;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t per_row = heads * dst_cap * row_vecs;
+  if (gid >= n_rows * per_row) return;
+  const int64_t i = gid / per_row, r = gid % per_row;
+  const int64_t x = r % row_vecs, p = (r / row_vecs) % dst_cap, h = r / (row_vecs * dst_cap);
+  const int64_t sr = src_row_of[i];
+  if (sr < 0 || p >= len_of[i] || p >= src_cap) return;
+  dst[t][((i * heads + h) * dst_cap + p) * row_vecs + x] = src[t][((sr * heads + h) * src_cap + p) * row_vecs + x];
+}
+
+__global__ void gather_rows_i32_kernel(const int32_t *src, int64_t src_ld, const int32_t *row_of, int64_t n,
+                                       int64_t width, int32_t *dst, int64_t dst_ld) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n * width) return;
+  const int64_t i = gid / width, j = gid % width;
+  dst[i * dst_ld + j] = src[(int64_t)row_of[i] * src_ld + j];
+}
+
+
 }  // namespace
 
 extern "C" {
+
+int glb_kv_append(void *slab, const void *new_rows, const int32_t *pos, const int32_t *row_of, int64_t n_rows,
+                  int64_t heads, int64_t cap, int64_t head_dim, int64_t new_stride_row, int64_t new_stride_head,
+                  int32_t elem_bytes, void *stream) {
+  if (!slab || !new_rows || !pos) return glb::api_fail(GLB_EINVAL, "null pointer");
+  if (n_rows <= 0 || heads <= 0 || cap <= 0 || head_dim <= 0) return glb::api_fail(GLB_EINVAL, "bad sizes");
+  if (elem_bytes != 2 && elem_bytes != 4) return glb::api_fail(GLB_EINVAL, "elem_bytes must be 2 or 4");
+  const int64_t rowb = head_dim * elem_bytes;
+  hipStream_t s = (hipStream_t)stream;
+  const bool wide = rowb % 16 == 0 && ((uintptr_t)slab) % 16 == 0 && ((uintptr_t)new_rows) % 16 == 0 &&
+                    (new_stride_row * elem_bytes) % 16 == 0 && (new_stride_head * elem_bytes) % 16 == 0;
+  if (wide) {
+    const int64_t rv = rowb / 16, total = n_rows * heads * rv;
+    hipLaunchKernelGGL(kv_append_kernel<uint4>, dim3(blocks_for(total, 256)), dim3(256), 0, s, (uint4 *)slab,
+                       (const uint4 *)new_rows, pos, row_of, n_rows, heads, cap, rv, new_stride_row * elem_bytes / 16,
+                       new_stride_head * elem_bytes / 16);
+  } else if (elem_bytes == 4) {
+    const int64_t total = n_rows * heads * head_dim;
+    hipLaunchKernelGGL(kv_append_kernel<uint32_t>, dim3(blocks_for(total, 256)), dim3(256), 0, s, (uint32_t *)slab,
+                       (const uint32_t *)new_rows, pos, row_of, n_rows, heads, cap, head_dim, new_stride_row, new_stride_head);
+  } else {
+    const int64_t total = n_rows * heads * head_dim;
+    hipLaunchKernelGGL(kv_append_kernel<uint16_t>, dim3(blocks_for(total, 256)), dim3(256), 0, s, (uint16_t *)slab,
+                       (const uint16_t *)new_rows, pos, row_of, n_rows, heads, cap, head_dim, new_stride_row, new_stride_head);
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return glb::api_hip_fail(e, "kv_append launch");
+  return GLB_OK;
+}
+
+int glb_kv_gather_rows(const void *const *src, void *const *dst, int64_t n_tensors, int64_t n_rows, int64_t heads,
+                       int64_t head_dim, int64_t src_cap, int64_t dst_cap, const int32_t *src_row_of,
+                       const int32_t *len_of, int32_t elem_bytes, void *stream) {
+  if (!src || !dst || !src_row_of || !len_of) return glb::api_fail(GLB_EINVAL, "null pointer");
+  if (n_tensors <= 0 || n_tensors > 65535 || n_rows <= 0 || heads <= 0 || head_dim <= 0 || src_cap <= 0 || dst_cap <= 0)
+    return glb::api_fail(GLB_EINVAL, "bad sizes");
+  if (elem_bytes != 2 && elem_bytes != 4) return glb::api_fail(GLB_EINVAL, "elem_bytes must be 2 or 4");
+  const int64_t rowb = head_dim * elem_bytes;
+  hipStream_t s = (hipStream_t)stream;
+  if (rowb % 16 == 0) {  // slabs come from the allocator: 16-byte aligned
+    const int64_t rv = rowb / 16, total = n_rows * heads * dst_cap * rv;
+    hipLaunchKernelGGL(kv_gather_rows_kernel<uint4>, dim3(blocks_for(total, 256), (unsigned)n_tensors), dim3(256), 0, s,
+                       (const uint4 *const *)src, (uint4 *const *)dst, n_rows, heads, rv, src_cap, dst_cap,
+                       src_row_of, len_of);
+  } else if (elem_bytes == 4) {
+    const int64_t total = n_rows * heads * dst_cap * head_dim;
+    hipLaunchKernelGGL(kv_gather_rows_kernel<uint32_t>, dim3(blocks_for(total, 256), (unsigned)n_tensors), dim3(256), 0,
+                       s, (const uint32_t *const *)src, (uint32_t *const *)dst, n_rows, heads, head_dim, src_cap,
+                       dst_cap, src_row_of, len_of);
+  } else {
+    const int64_t total = n_rows * heads * dst_cap * head_dim;
+    hipLaunchKernelGGL(kv_gather_rows_kernel<uint16_t>, dim3(blocks_for(total, 256), (unsigned)n_tensors), dim3(256), 0,
+                       s, (const uint16_t *const *)src, (uint16_t *const *)dst, n_rows, heads, head_dim, src_cap,
+                       dst_cap, src_row_of, len_of);
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return glb::api_hip_fail(e, "kv_gather_rows launch");
+  return GLB_OK;
+}
+
+int glb_gather_rows_i32(const int32_t *src, int64_t src_ld, const int32_t *row_of, int64_t n, int64_t width,
+                        int32_t *dst, int64_t dst_ld, void *stream) {
+  if (!src || !row_of || !dst) return glb::api_fail(GLB_EINVAL, "null pointer");
+  if (n <= 0 || width <= 0 || src_ld < width || dst_ld < width) return glb::api_fail(GLB_EINVAL, "bad sizes");
+  hipLaunchKernelGGL(gather_rows_i32_kernel, dim3(blocks_for(n * width, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     src_ld, row_of, n, width, dst, dst_ld);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return glb::api_hip_fail(e, "gather_rows_i32 launch");
+  return GLB_OK;
+}
+
 
 int glb_slab_attention(const void *q, int64_t q_stride_row, int64_t q_stride_head, const void *k_new, int64_t k_stride_row,
                        int64_t k_stride_head, const void *v_new, int64_t v_stride_row, int64_t v_stride_head, void *k_slab,
