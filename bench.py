@@ -242,8 +242,10 @@ def main():
                     help="sis workloads with the prompt's KV cached (hf.py:155-164 cache_kv; BASELINE config 3)")
     ap.add_argument("--prompts", type=int, default=1, help="distinct shared prompts over the population (config 3: 1 / 8 / 64)")
     ap.add_argument("--resample", action="store_true", help="systematic resampling after every step (replicated, deterministic)")
-    ap.add_argument("--trie-out", choices=["rows", "slots", "selected"], default="rows",
-                    help="trie workload: all nodes row-major / the folded trie's slots row-major / 4096 selected nodes")
+    ap.add_argument("--trie-out", choices=["rows", "slots", "selected", "rowsel", "rowsel-root"], default="rows",
+                    help="trie workload: all nodes row-major / the folded trie's slots row-major / 4096 selected nodes / a selection "
+                         "per row: the children of every row's own depth-1 node (a particle inside a token) / of the root (a particle "
+                         "at a token boundary: every part of the trie)")
     ap.add_argument("--llm-gather", action="store_true",
                     help="api-coro / api-readme: run a step's coroutines with AsyncAmdLM.gather (advanced by hand, no asyncio Task per "
                          "particle) instead of asyncio.gather - the README's user code with ONE name changed")
@@ -437,7 +439,8 @@ def main():
         if kern_us is not None and len(kern_us):
             ach = runner.kernel_bytes / (np.mean(kern_us) * 1e-6) / 1e9
             outer = runner.outer_times_us()
-            traffic, traffic_src = pmc_traffic(workload + ("-rowmasks" if args.per_row_masks and workload.startswith("kernel") else ""))
+            traffic, traffic_src = pmc_traffic(workload + ("-rowmasks" if args.per_row_masks and workload.startswith("kernel") else "")
+                                               + (f"-{args.trie_out}" if workload == "trie" else ""))
             out["roofline"] = {
                 "bound": "hbm",
                 "achieved": ach,
@@ -562,7 +565,15 @@ class TrieWorkload:
         self.out_kind, self.B, self.V, self.eng = out, B, V, eng
         self.particles_per_step = B
         self.sel = torch.from_numpy(rs.choice(len(self.trie), 4096, replace=False).astype(np.int32)).to(dev)
-        width = {"rows": len(self.trie), "slots": self.plan["n_slots"], "selected": 4096}[out]
+        # a selection per row: the children (<= 256) of the row's current node - one of the root's children, or the root itself
+        d1 = sorted(self.trie.children[self.trie.root].values())
+        cur = [self.trie.root] * B if out == "rowsel-root" else [d1[int(k)] for k in rs.integers(0, len(d1), B)]
+        K = max(len(self.trie.jump[c]) for c in set(cur))
+        rowsel = np.full((B, K), -1, np.int32)
+        for r, c in enumerate(cur):
+            rowsel[r, :len(self.trie.jump[c])] = self.trie.jump[c]
+        self.rowsel = torch.from_numpy(rowsel).to(dev)
+        width = {"rows": len(self.trie), "slots": self.plan["n_slots"], "selected": 4096, "rowsel": K, "rowsel-root": K}[out]
         self.kernel_bytes = B * V * 4 + B * width * 4 + B * 4
         self.outer = []
         self.roofline_kernel = ("(anonymous)::trie_rows_kernel x 2 launches (glb_trie_rows: a workgroup per (row, part) of the "
@@ -573,7 +584,8 @@ class TrieWorkload:
 
     def step(self, i, timed):
         x, lse = self.bufs[i % len(self.bufs)], self.lse[i % len(self.bufs)]
-        kw = {"rows": dict(layout="rows"), "slots": dict(layout="slot_rows"), "selected": dict(nodes=self.sel)}[self.out_kind]
+        kw = {"rows": dict(layout="rows"), "slots": dict(layout="slot_rows"), "selected": dict(nodes=self.sel),
+              "rowsel": dict(nodes=self.rowsel), "rowsel-root": dict(nodes=self.rowsel)}[self.out_kind]
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -592,7 +604,7 @@ class TrieWorkload:
     def config(self):
         pl = self.plan
         return {"workload": f"token->byte trie masses of {self.B} rows of [{self.B}, {self.V}] fp32 logits + lse -> "
-                            f"{ {'rows': 'all nodes, row-major', 'slots': 'the folded trie slots, row-major', 'selected': '4096 selected nodes'}[self.out_kind] }"
+                            f"{ {'rows': 'all nodes, row-major', 'slots': 'the folded trie slots, row-major', 'selected': '4096 selected nodes (only the subtrees below them planned)', 'rowsel': 'a selection per row: the children of the row-s own depth-1 node', 'rowsel-root': 'a selection per row: the children of the root (every part)'}[self.out_kind] }"
                             f" (glb_trie_rows; {len(self.trie)} nodes, {pl['n_slots']} slots in {pl['n_parts']} parts of <= {pl['max_local']}; "
                             "synthetic vocabulary of 1-8 letter byte strings)",
                 "rows_per_gpu": self.B, "vocab": self.V}

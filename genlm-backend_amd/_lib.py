@@ -84,6 +84,7 @@ class TrieRowsArgs(C.Structure):
         ("out_sel_ld", C.c_int64),
         ("workspace", C.c_void_p),
         ("workspace_bytes", C.c_size_t),
+        ("sel_row_stride", C.c_int64),
     ]
 
 

@@ -45,7 +45,9 @@ struct TrieRowsParams {
   int64_t out_slots_ld;
   float *out_nodes;
   int64_t out_nodes_ld;
-  const int32_t *sel_slot;  // [n_sel]: the slots of the selected nodes (workspace)
+  const int32_t *sel_slot;  // [n_sel]: the slots of the selected nodes (workspace); per-row selections: [n_rows][n_sel]
+  int64_t sel_stride;       // 0: one selection for every row; n_sel: a selection per row
+  const uint64_t *need;     // per-row selections: bit p of need[r] = row r needs part p (bit 63: the top); else null
   int32_t n_sel;
   float *out_sel;
   int64_t out_sel_ld;
@@ -167,12 +169,13 @@ __device__ __forceinline__ void part_write(const TrieRowsParams &p, const PartVi
   if (p.out_sel) {
     float *o = p.out_sel + (int64_t)r * p.out_sel_ld;
     const int base = v.d[D_SLOT_BASE];
+    const int32_t *sel_slot = p.sel_slot + (int64_t)r * p.sel_stride;
     for (int j0 = tid; j0 < p.n_sel; j0 += nt * 4) {
       int sl[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int jj = j0 + j * nt;
-        sl[j] = jj < p.n_sel ? p.sel_slot[jj] : -1;
+        sl[j] = jj < p.n_sel ? sel_slot[jj] : -1;
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -210,6 +213,7 @@ __global__ __launch_bounds__(kMaxThreads, 6) void trie_rows_kernel(TrieRowsParam
     r = (q / p.n_parts) * 8 + xcd;
     if (r >= p.n_rows) return;
   }
+  if (p.need && !((p.need[r] >> (TOP ? 63 : part)) & 1ull)) return;  // (per-row selections: this row asks nothing of this part)
   const PartView v(p.desc + part * kDesc);
   const int tid = threadIdx.x, nt = blockDim.x;
 #ifdef GLB_STAMPS
@@ -284,16 +288,49 @@ __global__ __launch_bounds__(kMaxThreads, 6) void trie_rows_kernel(TrieRowsParam
 }
 
 // the selected nodes' slots, once per call (the same for every row)
-__global__ void trie_sel_slots_kernel(const int32_t *sel, int32_t n_sel, const int32_t *slot_of, int32_t *sel_slot) {
+__global__ void trie_sel_slots_kernel(const int32_t *sel, int32_t n_sel, int64_t n_nodes, const int32_t *slot_of, int32_t *sel_slot) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < n_sel) sel_slot[j] = slot_of[sel[j]];
+  if (j < n_sel) sel_slot[j] = (sel[j] >= 0 && sel[j] < n_nodes) ? slot_of[sel[j]] : -1;  // (a node outside the trie: no slot, its output stays untouched)
+}
+
+// per-row selections: every row's nodes -> slots (a node outside the trie, or negative: none - its output is 0), and the
+// parts the row needs: the part that holds a slot (a part is a union of whole subtrees, so a node's descendants are in its
+// own part), every part and the top for a slot above the cut
+__global__ __launch_bounds__(256) void trie_sel_rows_kernel(const int32_t *sel, int64_t sel_stride, int32_t n_sel, int64_t n_nodes,
+                                                            const int32_t *slot_of, const int32_t *desc, int32_t n_parts,
+                                                            int32_t top_base, int32_t has_top, int32_t *sel_slot, uint64_t *need,
+                                                            float *out_sel, int64_t out_sel_ld) {
+  __shared__ unsigned long long bits;
+  const int r = blockIdx.x;
+  if (threadIdx.x == 0) bits = 0ull;
+  __syncthreads();
+  unsigned long long mine = 0ull;
+  for (int k = threadIdx.x; k < n_sel; k += blockDim.x) {
+    const int32_t node = sel[(int64_t)r * sel_stride + k];
+    int32_t slot = (node >= 0 && node < n_nodes) ? slot_of[node] : -1;
+    sel_slot[(int64_t)r * n_sel + k] = slot;
+    if (slot < 0) {
+      out_sel[(int64_t)r * out_sel_ld + k] = 0.0f;
+    } else if (has_top && slot >= top_base) {
+      mine = ~0ull;
+    } else {
+      for (int p = 0; p < n_parts; ++p)
+        if (slot >= desc[p * kDesc + D_SLOT_BASE] && slot < desc[p * kDesc + D_SLOT_BASE] + desc[p * kDesc + D_N_LOCAL]) mine |= 1ull << p;
+    }
+  }
+  if (mine) atomicOr(&bits, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) need[r] = bits;
 }
 
 template <int DT, int kL>
 hipError_t launch_rows1(const TrieRowsParams &p, int n_top, size_t lds, int threads, hipStream_t s) {
   static std::atomic<uint64_t> big_lds{0}, big_lds_top{0};  // (more than 64 KB of dynamic LDS: allowed per kernel and device)
-  hipError_t e0 = glb::allow_dynamic_lds((const void *)trie_rows_kernel<DT, false, kL>, 160 * 1024, big_lds);
-  if (e0 == hipSuccess) e0 = glb::allow_dynamic_lds((const void *)trie_rows_kernel<DT, true, 8>, 160 * 1024, big_lds_top);
+  hipError_t e0 = hipSuccess;
+  if (lds > 64 * 1024) {  // (parts of up to 64 KB need no attribute: a build for a device with less LDS still serves them)
+    e0 = glb::allow_dynamic_lds((const void *)trie_rows_kernel<DT, false, kL>, 160 * 1024, big_lds);
+    if (e0 == hipSuccess) e0 = glb::allow_dynamic_lds((const void *)trie_rows_kernel<DT, true, 8>, 160 * 1024, big_lds_top);
+  }
   if (e0 != hipSuccess) return e0;
   const unsigned blocks = (unsigned)(((int64_t)p.n_rows + 7) / 8 * 8 * p.n_parts);
   hipLaunchKernelGGL((trie_rows_kernel<DT, false, kL>), dim3(blocks), dim3(threads), lds, s, p);
@@ -320,7 +357,7 @@ extern "C" {
 
 size_t glb_trie_rows_workspace(int64_t n_rows, const glb_trie_plan *plan) {
   if (!plan || n_rows <= 0) return 0;
-  return cut_bytes(n_rows, plan) + kMaxSel * sizeof(int32_t);
+  return cut_bytes(n_rows, plan) + kMaxSel * sizeof(int32_t) + (size_t)n_rows * sizeof(uint64_t);
 }
 
 int glb_trie_rows(const glb_trie_rows_args *a, const glb_trie_plan *pl, void *stream) {
@@ -351,6 +388,9 @@ int glb_trie_rows(const glb_trie_rows_args *a, const glb_trie_plan *pl, void *st
     return api_fail(GLB_EINVAL, "glb_trie_rows: output pitch below its width");
   if (a->n_sel < 0 || a->n_sel > kMaxSel || (a->out_sel && a->n_sel > 0 && !a->sel_nodes))
     return api_fail(GLB_EINVAL, "glb_trie_rows: bad selection");
+  const bool per_row = a->sel_row_stride != 0 && a->out_sel && a->n_sel > 0;
+  if (per_row && (a->sel_row_stride < a->n_sel || a->n_rows * a->n_sel > kMaxSel || pl->n_parts > 62))
+    return api_fail(GLB_EINVAL, "glb_trie_rows: per-row selections need sel_row_stride >= n_sel, n_rows * n_sel <= 2^20 and at most 62 parts");
   const size_t need = glb_trie_rows_workspace(a->n_rows, pl);
   if (need && (!a->workspace || a->workspace_bytes < need))
     return api_fail(GLB_ENOSPC, "glb_trie_rows: %zu bytes of workspace needed (glb_trie_rows_workspace)", need);
@@ -387,9 +427,17 @@ int glb_trie_rows(const glb_trie_rows_args *a, const glb_trie_plan *pl, void *st
   p.out_sel = a->n_sel > 0 ? a->out_sel : nullptr;
   p.out_sel_ld = a->out_sel_ld;
   hipStream_t s = (hipStream_t)stream;
-  if (p.out_sel)
+  if (per_row) {
+    uint64_t *need = (uint64_t *)((char *)a->workspace + cut_bytes(a->n_rows, pl) + kMaxSel * sizeof(int32_t));
+    p.sel_stride = p.n_sel;
+    p.need = need;
+    hipLaunchKernelGGL(trie_sel_rows_kernel, dim3((unsigned)p.n_rows), dim3(256), 0, s, a->sel_nodes, a->sel_row_stride, p.n_sel, pl->n_nodes,
+                       pl->slot_of, pl->desc, pl->n_parts, pl->top_base, pl->n_top > 0 ? 1 : 0, (int32_t *)p.sel_slot, need, p.out_sel,
+                       p.out_sel_ld);
+  } else if (p.out_sel) {
     hipLaunchKernelGGL(trie_sel_slots_kernel, dim3((unsigned)((p.n_sel + 255) / 256)), dim3(256), 0, s, a->sel_nodes, p.n_sel,
-                       pl->slot_of, (int32_t *)p.sel_slot);
+                       pl->n_nodes, pl->slot_of, (int32_t *)p.sel_slot);
+  }
   // threads per workgroup: as many workgroups as the LDS lets a CU hold.  (1024-thread workgroups were never seen two to
   // a CU, whatever their LDS - tools/dbg/stamps_trie.py; 512-thread ones are.)
   int threads = 512;

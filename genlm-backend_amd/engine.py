@@ -689,7 +689,9 @@ class HipEngine:
     def trie_rows(self, ws, plan, op=0, from_logprobs=False, lse=None, logit_scale=1.0, nodes=None, layout="rows", out=None):
         """Token -> byte trie masses with one row of a part of the trie resident in LDS (glb_trie_rows): the weights are
         read once, the result written once, row-major.  plan: `TokenByteTrie.plan_device_arrays()`.  ws as in
-        `trie_masses`.  Result: layout "rows" float32 [B, n_nodes]; nodes given (int32 device tensor) [B, len(nodes)];
+        `trie_masses`.  Result: layout "rows" float32 [B, n_nodes]; nodes given (int32 device tensor) [B, len(nodes)] - or,
+        `nodes` int32 [B, K], every row's OWN nodes (negative: none, 0 out): only the parts of the trie that hold a row's
+        nodes are read and reduced for that row;
         layout "slots" [B, n_slots] in the plan's slot numbering (plan["slot_of"]: node -> slot)."""
         if ws.dim() != 2 or ws.stride(1) != 1 or ws.dtype not in _DT:
             raise ValueError("weights must be [B, V] float32 / bfloat16 / float16 with unit inner stride")
@@ -717,10 +719,13 @@ class HipEngine:
             if self._trie_ws is None or self._trie_ws.numel() < need:
                 self._trie_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
             a.workspace, a.workspace_bytes = self._trie_ws.data_ptr(), self._trie_ws.numel()
+        per_row = nodes is not None and nodes.dim() == 2
         if nodes is not None:
             if nodes.dtype != torch.int32:
                 raise TypeError("nodes must be int32")
-            width = nodes.numel()
+            if per_row and (nodes.shape[0] != B or nodes.stride(1) != 1):
+                raise ValueError(f"per-row nodes must be int32 [{B}, K] with unit inner stride")
+            width = nodes.shape[1] if per_row else nodes.numel()
         elif layout == "rows":
             width = plan["n_nodes"]
         elif layout == "slots":
@@ -735,6 +740,7 @@ class HipEngine:
             return out
         if nodes is not None:
             a.sel_nodes, a.n_sel, a.out_sel, a.out_sel_ld = nodes.data_ptr(), width, out.data_ptr(), out.stride(0)
+            a.sel_row_stride = max(nodes.stride(0), width) if per_row else 0
         elif layout == "rows":
             a.out_nodes, a.out_nodes_ld = out.data_ptr(), out.stride(0)
         else:

@@ -458,7 +458,8 @@ class TokenByteTrie:
         the device) and the rows' lse (float32 [B]: the fused step's `lse` output; None: computed here, `HipEngine.row_lse`):
         what the reference gets from `batch_weight_sum(logprobs.exp())` (trie/parallel.py:92-103) without the [B, V]
         matrix of log-probabilities ever being written.  nodes: int32 device tensor - only these nodes' masses,
-        [B, len(nodes)]; layout "slots": node-major [n_slots, pitch] over the folded trie (`compact()`: the value of node
+        [B, len(nodes)] (only the subtrees below them are read and reduced: `selection_plan`) - or int32 [B, K]: every row's
+        OWN nodes, e.g. each particle's current node's children (negative entries: none), [B, K]; layout "slots": node-major [n_slots, pitch] over the folded trie (`compact()`: the value of node
         n for row r is at [slot_of[n], r] - nothing is transposed back); layout "nodes": the same over all nodes,
         [n_nodes, pitch] (see HipEngine.trie_masses); layout "slot_rows": row-major [B, n_slots] over the plan's slots
         (`plan()["slot_of"]`: node -> slot) - the cheapest form: the logits are read once and nothing else is written."""
@@ -469,7 +470,7 @@ class TokenByteTrie:
         if nodes is not None and nodes.dtype != torch.int32:
             raise TypeError("nodes must be int32")
         pl = self.plan_device_arrays() if self.resident and (layout in ("rows", "slot_rows")) else None
-        if pl is not None and nodes is not None and layout == "rows" and self.prune_selection:
+        if pl is not None and nodes is not None and nodes.dim() == 1 and layout == "rows" and self.prune_selection:
             # only the subtrees below the selected nodes are read and reduced (a plan of that sub-forest, cached per selection)
             pl = self.selection_plan(nodes) or pl
         if pl is not None:

@@ -500,8 +500,9 @@ int glb_trie_masses(const glb_trie_args *args, void *hip_stream);
  * Same arithmetic per node as glb_trie_reduce (children in ascending order, accumulated in double, stored as float32),
  * so the results are bit-equal to glb_trie_masses on the same folded trie.
  * Outputs (any subset): out_slots [n_rows, n_slots] in the plan's slot numbering; out_nodes [n_rows, n_nodes];
- * out_sel [n_rows, n_sel] = the nodes sel_nodes[0 .. n_sel), n_sel <= 2^20.  workspace: glb_trie_rows_workspace bytes
- * (the values of the parts' subtree roots, read by the top's launch; the slots of the selected nodes).
+ * out_sel [n_rows, n_sel] = the nodes sel_nodes[0 .. n_sel), n_sel <= 2^20 - or, with sel_row_stride, every row's own
+ * nodes.  workspace: glb_trie_rows_workspace bytes (the values of the parts' subtree roots, read by the top's launch; the
+ * slots of the selected nodes; a row's needed parts).
  */
 typedef struct glb_trie_plan {
   uint32_t struct_size;  /* sizeof(glb_trie_plan) - ABI guard */
@@ -529,6 +530,11 @@ typedef struct glb_trie_rows_args {
   int64_t out_sel_ld;
   void *workspace;
   size_t workspace_bytes;
+  int64_t sel_row_stride; /* 0: sel_nodes [n_sel] is one selection for every row.  > 0: a selection PER ROW - sel_nodes
+                             [n_rows, sel_row_stride], row r asks for its first n_sel entries (a negative entry: nothing,
+                             its output is 0; n_rows * n_sel <= 2^20) - e.g. every particle's current node's children, what a
+                             byte-level sampler reads after trie/base.py:147-213.  Only the parts of the trie that hold a row's
+                             nodes are read and reduced for that row (every part when a node sits above the cut). */
 } glb_trie_rows_args;
 size_t glb_trie_rows_workspace(int64_t n_rows, const glb_trie_plan *plan);
 int glb_trie_rows(const glb_trie_rows_args *args, const glb_trie_plan *plan, void *hip_stream);

@@ -807,6 +807,54 @@ def test_selected_masses_read_only_the_selected_subtrees(engine, oracle, cap):
             assert torch.equal(trie.masses_from_logits(xb, lb, nodes=sel_d), full[:, sel_d.long()]), name
 
 
+@pytest.mark.parametrize("cap", [250, 20000])
+def test_per_row_selections_read_only_the_parts_a_row_needs(engine, cap):
+    """A selection PER ROW (round 5: `nodes` int32 [B, K] - every particle's current node's children, what a byte-level
+    sampler reads after trie/base.py:147-213): row r's values are the whole trie's values of row r's nodes, bit for bit;
+    negative entries give 0; rows whose nodes sit above the cut (the root's children at a small cap) take every part."""
+    from genlm_backend_amd.tokenization import Token
+    from genlm_backend_amd.trie import TokenByteTrie
+
+    rs = np.random.default_rng(29)
+    words, seen = [], set()
+    while len(words) < 4000:
+        w = bytes(rs.integers(97, 104, int(rs.integers(1, 7))).astype(np.uint8))
+        if w not in seen:
+            seen.add(w)
+            words.append(w)
+    trie = TokenByteTrie([Token(i, w) for i, w in enumerate(words)], engine=engine)
+    trie.PLAN_CAP = cap
+    dev = engine.device
+    V, nn, B, K = len(words), len(trie), 41, 12
+    x = (rs.standard_normal((B, V)) * 3).astype(np.float32)
+    xd = torch.from_numpy(x).to(dev)
+    _, lse, _ = engine.step(xd, vocab=V, rng_mode=0)
+    rows = trie.masses_from_logits(xd, lse).cpu().numpy()
+    internal = [n for n in range(nn) if len(trie.jump[n]) >= 2]
+    sel = np.full((B, K), -1, np.int32)
+    for r in range(B):
+        node = trie.root if r % 7 == 0 else int(rs.choice(internal))
+        kids = trie.jump[node][:K]
+        sel[r, :len(kids)] = kids
+        if r % 5 == 0:
+            sel[r, 0] = -1  # a hole in the middle of a row
+        if r == 3:
+            sel[r] = -1     # a row that asks for nothing
+    got = trie.masses_from_logits(xd, lse, nodes=torch.from_numpy(sel).to(dev)).cpu().numpy()
+    for r in range(B):
+        for k in range(K):
+            want = rows[r, sel[r, k]] if sel[r, k] >= 0 else 0.0
+            assert got[r, k].view(np.uint32) == np.float32(want).view(np.uint32), (r, k)
+    xb = xd.to(torch.bfloat16)
+    _, lb, _ = engine.step(xb, vocab=V, rng_mode=0)
+    full = trie.masses_from_logits(xb, lb)
+    gb = trie.masses_from_logits(xb, lb, nodes=torch.from_numpy(sel).to(dev))
+    idx = torch.from_numpy(np.where(sel >= 0, sel, 0).astype(np.int64)).to(dev)
+    assert torch.equal(gb, torch.where(torch.from_numpy(sel >= 0).to(dev), torch.gather(full, 1, idx), torch.zeros_like(gb)))
+    with pytest.raises(Exception):
+        trie.masses_from_logits(xd, lse, nodes=torch.from_numpy(sel[:5]).to(dev))
+
+
 def test_trie_rows_on_degenerate_vocabularies(engine, oracle):
     """One token, one chain, two leaves under the root: the plan has one part of one to five slots and no top."""
     from genlm_backend_amd.tokenization import Token

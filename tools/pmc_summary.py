@@ -96,6 +96,52 @@ if trie:
                    "MI355X_MICROARCH.md (calibrated there for 16-byte-per-lane streaming reads; the level kernels read 16 bytes per lane)")
     json.dump(out, open(os.path.join(root, "trie_pmc_traffic.json"), "w"), indent=1)
     print("trie", json.dumps(out, indent=1))
+# the trie bench lines (bench.py --workload trie --trie-out X): HBM traffic of one call = every trie_* launch of the call
+for out_kind in ("rows", "slots", "selected", "rowsel", "rowsel-root"):
+    wl = f"trie-{out_kind}"
+    per_tag = {}
+    for tag, sub in (("FETCH_SIZE", f"pmc_fetch_{wl}"), ("WRITE_SIZE", f"pmc_write_{wl}")):
+        f = first(f"{sub}/**/*counter_collection.csv")
+        if not f:
+            continue
+        tot, calls = 0.0, 0
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if row.get("Counter_Name") != tag or "trie_" not in row["Kernel_Name"]:
+                    continue
+                tot += float(row["Counter_Value"])
+                if "trie_rows_kernel" in row["Kernel_Name"] and ", false," in row["Kernel_Name"].replace("<", ", ").replace(">", ","):
+                    calls += 1  # (one launch over the parts per call; the top, when the plan has one, is a second launch)
+        per_tag[tag] = (tot, calls)
+    if len(per_tag) == 2:
+        out = {"hbm_read_bytes_per_launch_corrected": per_tag["FETCH_SIZE"][0] / max(per_tag["FETCH_SIZE"][1], 1) * 1024 * 2,
+               "hbm_write_bytes_per_launch": per_tag["WRITE_SIZE"][0] / max(per_tag["WRITE_SIZE"][1], 1) * 1024,
+               "calls": per_tag["FETCH_SIZE"][1],
+               "note": (f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python3 bench.py --workload trie --trie-out "
+                        f"{out_kind} --steps 20 --warmup 2 --no-cpu`; per call = all trie_* launches of the call; FETCH_SIZE doubled per "
+                        "MI355X_MICROARCH.md")}
+        json.dump(out, open(os.path.join(root, f"{wl}_pmc_traffic.json"), "w"), indent=1)
+        print(wl, json.dumps(out, indent=1))
+# request counters of the trie kernel (TCP / TCC: is glb_trie_rows bound by requests, as DESIGN.md §10 says, or by bytes?)
+for f in sorted(glob.glob(os.path.join(root, "pmc_req_trie*", "**", "*counter_collection.csv"), recursive=True)):
+    agg = {}
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            if "trie_rows_kernel" not in row["Kernel_Name"]:
+                continue
+            k = row["Counter_Name"]
+            agg.setdefault(k, []).append(float(row["Counter_Value"]))
+    if agg:
+        tag = os.path.relpath(f, root).split(os.sep)[0][len("pmc_req_"):]
+        out = {k: {"launches": len(v), "mean_per_launch": sum(v) / len(v)} for k, v in sorted(agg.items())}
+        prev = {}
+        pth = os.path.join(root, f"{tag}_request_counters.json")
+        if os.path.exists(pth):
+            prev = json.load(open(pth))
+        prev.update(out)
+        json.dump(prev, open(pth, "w"), indent=1)
+        print(tag, json.dumps(out))
+
 def short_name(name, limit=150):
     """Kernel names of Tensile / ATen run to several hundred characters: keep the head that identifies them (macro-tile for
     Tensile, functor for ATen) - the NAME is cut, never the row's numbers (round 4 cut the line and lost them)."""
