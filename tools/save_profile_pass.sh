@@ -3,10 +3,10 @@
 # suffix: tools/save_profile_pass.sh r04 v2
 set -e
 cd "$(dirname "$0")/.."
-R=$1; V=$2; O=gpurun_out/prof; D=profiles/$R
+R=$1; V=$2; O=gpurun_out/${3:-prof}; D=profiles/$R
 mkdir -p $D
 for f in $O/bench_*.json; do b=$(basename $f .json); grep "^{" $f > $D/${b}_$V.json || true; done
-for f in $O/*_kernel_stats.csv $O/*_pmc_traffic.json $O/*_gpu_busy.txt; do
+for f in $O/*_kernel_stats.csv $O/*_pmc_traffic.json $O/*_gpu_busy.txt $O/*_step_table.txt $O/*_request_counters.json $O/rccl_info.log; do
   [ -f "$f" ] || continue
   b=$(basename $f); cp $f $D/${b%.*}_$V.${b##*.}
 done
