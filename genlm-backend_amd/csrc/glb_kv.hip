@@ -126,7 +126,7 @@ __global__ __launch_bounds__(kT) void kv_plan_kernel(const PlanArgs a) {
   __shared__ int s_lmax, s_unkept, s_copied;
   Scan scan{s_wave};
   const int tid = threadIdx.x, n = a.n, R = a.R;
-  const int U = *a.n_groups;
+  const int U = *a.n_groups < n ? (*a.n_groups < 0 ? 0 : *a.n_groups) : n;  // (never past the scratch sized for n groups)
   if (tid == 0) s_lmax = 0, s_unkept = 0, s_copied = 0;
   for (int r = tid; r < R; r += kT) {
     a.keeper[r] = INT_MAX;
@@ -139,7 +139,9 @@ __global__ __launch_bounds__(kT) void kv_plan_kernel(const PlanArgs a) {
   // ---- the row a group's prefix sits in; the first group (by id) of every live row keeps it
   for (int u = tid; u < U; u += kT) {
     int o = a.old_src[a.old_sel ? a.old_sel[u] : u];
-    o = o >= 0 && o < R ? o : -1;  // (a row index outside the table reads as "no row")
+    // (a row index outside the table reads as "no row"; so does the row of a context that has outgrown a row's cap
+    // positions: it is encoded from its tokens and its row goes back to the free ones - never a position past the row)
+    o = o >= 0 && o < R && a.lengths[a.rep[u]] <= a.cap ? o : -1;
     a.flags[u] = o;
     if (o >= 0) atomicMin(&a.keeper[o], u);
   }
@@ -396,7 +398,8 @@ __global__ __launch_bounds__(64) void slab_attention_kernel(const AttnArgs a) {
   const int r = blockIdx.x / a.H, h = blockIdx.x - r * a.H;
   const int G = a.H / a.Hkv, hk = h / G;
   int p_new = a.pos[r];  // the token being appended sits at p_new; positions 0 .. p_new are attended to
-  p_new = p_new < 0 ? 0 : (p_new < a.cap ? p_new : a.cap - 1);  // (a position outside the row is the caller's bug, not a fault)
+  const bool bad_pos = p_new < 0 || p_new >= a.cap;  // a position outside the row: the caller's bug - no fault, no plausible answer: NaN out, nothing appended
+  p_new = p_new < 0 ? 0 : (p_new < a.cap ? p_new : a.cap - 1);
   float qf[EPV], kn[EPV], vn[EPV];
   unpack16<DT>(*reinterpret_cast<const u32x4 *>(a.q + ((int64_t)r * a.q_sr + (int64_t)h * a.q_sh + i * EPV) * ES), qf);
   const u32x4 kn_raw = *reinterpret_cast<const u32x4 *>(a.k_new + ((int64_t)r * a.k_sr + (int64_t)hk * a.k_sh + i * EPV) * ES);
@@ -404,7 +407,7 @@ __global__ __launch_bounds__(64) void slab_attention_kernel(const AttnArgs a) {
   unpack16<DT>(kn_raw, kn);
   unpack16<DT>(vn_raw, vn);
   const int64_t slab_row = ((int64_t)r * a.Hkv + hk) * a.cap;
-  if (h == hk * G && j == 0 && p_new < a.cap) {  // the append: once per (row, KV head)
+  if (h == hk * G && j == 0 && !bad_pos) {  // the append: once per (row, KV head)
     *reinterpret_cast<u32x4 *>(a.k_slab + ((slab_row + p_new) * DH + i * EPV) * ES) = kn_raw;
     *reinterpret_cast<u32x4 *>(a.v_slab + ((slab_row + p_new) * DH + i * EPV) * ES) = vn_raw;
   }
@@ -447,7 +450,7 @@ __global__ __launch_bounds__(64) void slab_attention_kernel(const AttnArgs a) {
     m = m2;
   }
   if (j == 0) {
-    const float inv = 1.0f / l;
+    const float inv = bad_pos ? __builtin_nanf("") : 1.0f / l;
 #pragma unroll
     for (int k = 0; k < EPV; ++k) acc[k] *= inv;
     *reinterpret_cast<u32x4 *>(a.out + (((int64_t)r * a.H + h) * DH + i * EPV) * ES) = pack16v<DT>(acc);

@@ -748,7 +748,8 @@ class AsyncAmdLM(AsyncLM):
                 live = nxt
                 if not live:
                     break
-                if self.queries or self._sq is not None:
+                did_batch = bool(self.queries or self._sq is not None)
+                if did_batch:
                     if self.timer:
                         self.timer.cancel()
                         self.timer = None
@@ -756,13 +757,32 @@ class AsyncAmdLM(AsyncLM):
                 waiting = [blocked[i] for i in live if blocked[i] is not None and not blocked[i].done()]
                 if waiting and len(waiting) == len(live):
                     await asyncio.wait(waiting, return_when=asyncio.FIRST_COMPLETED)  # (foreign futures: the event loop's business)
-                elif not waiting and all(blocked[i] is None for i in live):
-                    await asyncio.sleep(0)  # (bare yields, e.g. asyncio.sleep(0): give the loop its turn)
-        except BaseException:
+                elif not did_batch:
+                    # nothing of this pass was this backend's to resolve - coroutines polling with bare yields, possibly
+                    # next to others blocked on foreign futures: the event loop (its timers, the futures' owners) gets its turn
+                    await asyncio.sleep(0)
+        except BaseException as exc:
             for i in live:
                 coros[i].close()
+            # what the closed coroutines had queued must not ride into somebody else's next batch: fail it (nobody is left
+            # waiting on a future that would never resolve)
+            self._fail_pending(exc if isinstance(exc, Exception) else asyncio.CancelledError())
             raise
         return results
+
+    def _fail_pending(self, exc):
+        """Drop everything queued and not yet evaluated; its futures get `exc`."""
+        sq, self._sq = self._sq, None
+        if sq is not None and not sq[2].done():
+            sq[2].set_exception(exc)
+            sq[2].exception()  # (marked retrieved: a gather that was abandoned has nobody left to read it)
+        queries, self.queries = self.queries, []
+        for q in queries:
+            if q.future is not None and not q.future.done():
+                q.future.set_exception(exc)
+        if self.timer:
+            self.timer.cancel()
+            self.timer = None
 
     def _fire_step_batch(self):
         """Evaluate the pending `next_token_step` requests (one vectorised call) and resolve their shared future."""

@@ -440,11 +440,26 @@ class TokenByteTrie:
         ws = self._rows(ws)
         pl = self.plan_device_arrays() if self.resident else None
         if pl is not None:
-            return self.engine.trie_rows(ws, pl, op, from_logprobs)
+            got = self._trie_rows(ws, pl, op, from_logprobs)
+            if got is not None:
+                return got
         if ws.shape[0] < self._COMPACT_ROWS or self.compact()["n_levels"] == 0:
             return self.engine.trie_reduce(ws, self.device_arrays(), op, from_logprobs)
         c = self.compact_device_arrays()
         return self.engine.trie_masses(ws, c, op, from_logprobs, nodes=c["slot_of"])
+
+    def _trie_rows(self, ws, pl, *args, **kw):
+        """glb_trie_rows, or None when the device cannot run it (a part of the plan needs more LDS than the device has - a
+        build for another architecture): the level-synchronous kernels serve the trie from then on."""
+        from ._lib import GLB_EHIP, GlbError
+
+        try:
+            return self.engine.trie_rows(ws, pl, *args, **kw)
+        except GlbError as e:
+            if e.code != GLB_EHIP:
+                raise
+            self.resident = False
+            return None
 
     def batch_weight_sum_device(self, ws, from_logprobs=False):
         """[B, V] weights (or log-probabilities) -> float32 [B, n_nodes] on the device."""
@@ -474,8 +489,12 @@ class TokenByteTrie:
             # only the subtrees below the selected nodes are read and reduced (a plan of that sub-forest, cached per selection)
             pl = self.selection_plan(nodes) or pl
         if pl is not None:
-            return self.engine.trie_rows(logits, pl, op, True, lse=lse, logit_scale=logit_scale, nodes=nodes,
-                                         layout="slots" if layout == "slot_rows" and nodes is None else "rows")
+            got = self._trie_rows(logits, pl, op, True, lse=lse, logit_scale=logit_scale, nodes=nodes,
+                                  layout="slots" if layout == "slot_rows" and nodes is None else "rows")
+            if got is not None:
+                return got
+            if nodes is not None and nodes.dim() == 2:
+                raise RuntimeError("per-row selections need glb_trie_rows, which this device refused")
         if layout == "slot_rows":
             raise ValueError("layout 'slot_rows' needs a plan (TokenByteTrie.plan() returned None, or resident is off)")
         if layout == "nodes" or self.compact()["n_levels"] == 0:

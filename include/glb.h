@@ -338,6 +338,9 @@ int glb_gather_rows_i32(const int32_t *src, int64_t src_ld, const int32_t *row_o
  *                             context to encode, free rows before the call, 0 - all the host has to read
  *   With row_tok != null the table rows of every group that holds a row now are rewritten (tokens zero-padded to cap,
  *   length, group_hash[g]).  workspace: glb_kv_plan_workspace(n, n_rows) bytes, 4-byte aligned.
+  *   A group whose context has outgrown a row (length > cap) holds no row from this step on, whatever old_row says: it is
+ *   encoded from its tokens and not kept, and the row it sat in is free again.  A position outside [0, cap) handed to
+ *   glb_slab_attention appends nothing and gives NaN outputs for that row.
  */
 int glb_match_rows(const int32_t *tokens, const int64_t *starts, const int32_t *lengths, const int32_t *rep,
                    const int32_t *n_groups, int64_t n, const int32_t *row_tok, const int32_t *row_len,

@@ -325,6 +325,8 @@ def kv_plan(group_of, rep, n_groups, old, lengths, n_rows, cap, stamps=None, cal
     int32 arrays with the library's output names; `stamps` (int64, optional) is updated in place."""
     n, U, R = len(group_of), int(n_groups), int(n_rows)
     L = np.array([int(lengths[rep[u]]) for u in range(U)], np.int64)
+    # a row index outside the table reads as "no row"; so does the row of a context that has outgrown a row's cap positions
+    old = np.array([int(old[u]) if 0 <= int(old[u]) < R and L[u] <= cap else -1 for u in range(U)], np.int64)
     keeper = {}
     for u in range(U):
         if old[u] >= 0:

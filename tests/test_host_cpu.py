@@ -416,6 +416,51 @@ def test_logits_include_the_models_post_head_transform(family):
     assert np.abs(asyncio.run(m.next_token_logprobs(ids)).numpy() - want).max() < TOL
 
 
+def test_gather_lets_the_event_loop_run_and_cleans_up_after_a_failure(llm):
+    """AsyncAmdLM.gather (no reference counterpart) next to foreign awaitables: a coroutine that polls with bare yields for
+    something only the event loop can deliver, beside one blocked on a foreign future, must not starve the loop; and when a
+    coroutine raises, what the closed ones had queued does not ride into the next batch."""
+    m = llm
+    ids = [3, 1, 4, 1, 5]
+
+    async def run():
+        loop = asyncio.get_running_loop()
+        flag = {"set": False}
+        loop.call_later(0.05, lambda: flag.__setitem__("set", True))
+        fut = loop.create_future()
+        loop.call_later(0.08, lambda: fut.set_result("late"))
+
+        async def poller():
+            n = 0
+            while not flag["set"]:
+                await asyncio.sleep(0)
+                n += 1
+            return n
+
+        async def foreign():
+            return await fut
+
+        async def ours():
+            return await m.next_token_step(ids, mask_id=0)
+
+        res = await asyncio.wait_for(m.gather(poller(), foreign(), ours()), timeout=5.0)
+        assert res[0] > 0 and res[1] == "late" and len(res[2]) == 2
+
+        async def boom():
+            await asyncio.sleep(0)
+            raise RuntimeError("boom")
+
+        with pytest.raises(RuntimeError):
+            await m.gather(ours(), boom(), ours())
+        assert m._sq is None and m.queries == [] and m.timer is None
+        logZ, tok = await m.next_token_step(ids, mask_id=0)  # the backend still works, alone in its batch
+        assert m.stats["queries"] >= 2
+        return logZ, tok
+
+    m.batch_size = 64
+    asyncio.run(run())
+
+
 def test_the_callers_model_is_never_modified(gold):
     """hf.py:114-140 leaves the model it is handed alone; so does this backend: fused activations / norms / rotary embedding
     and the attention entry live in a private shadow of the module tree that shares the weights (fuse.shadow_model).  Two

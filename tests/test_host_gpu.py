@@ -1392,6 +1392,14 @@ def test_slab_attention_matches_torch(engine, dtype, R, H, Hkv, cap, Dh):
     tol = 2e-5 if dtype == torch.float32 else (2e-2 if dtype == torch.bfloat16 else 3e-3)
     assert (out[:, 0].float() - want).abs().max().item() < tol
     assert torch.equal(ks, k_ref) and torch.equal(vs, v_ref)  # the append, and nothing else, happened to the slabs
+    # a position outside the row is the caller's bug: no fault, nothing appended, and no plausible answer either - NaN
+    bad = pos.clone()
+    bad[1], bad[2] = cap, -1
+    out2 = engine.slab_attention(q, kn, vn, ks, vs, bad, scale)
+    torch.cuda.synchronize()
+    assert torch.isnan(out2[1].float()).all() and torch.isnan(out2[2].float()).all()
+    assert not torch.isnan(out2[0].float()).any() and torch.equal(out2[3:], out[3:])
+    assert torch.equal(ks, k_ref) and torch.equal(vs, v_ref)
 
 
 @pytest.mark.parametrize("auto_kv", [False, True])
