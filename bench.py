@@ -663,6 +663,11 @@ class KernelWorkload:
         self._pool = []
         # the argument block of every buffer's call is filled once: a step's host work is then a few microseconds, so
         # the host stays ahead of the GPU and the event interval holds no wait for the next launch packet
+        # set-up, not measurement: what building the synthetic rows left in the allocator's cache goes back to the driver now
+        # (hundreds of MB of argsort / rand temporaries for the peaked rows: released lazily they cost one 65 ms stall
+        # somewhere in the timed region)
+        torch.cuda.synchronize(dev)
+        torch.cuda.empty_cache()
         draw = dict(rng_mode=2, noise=self.noise_buf) if self.parity else dict(rng_mode=1, seed=1234, offset=0)
         if per_row_masks:  # raw bit rows, one per particle (mask ids = identity): every call prepares them itself
             self.plans = [eng.step_plan(x, mask_kind=1, mask=self.bits, particle_base=rank * B, out=self.out, **draw)

@@ -17,7 +17,7 @@ for ln in open(line):
     if ln.startswith("{"):
         bench = json.loads(ln)
 groups = {"GEMM (Tensile)": lambda n: n.startswith("Cijk_") or n.startswith("Custom_Cijk_"),
-          "glb attention": lambda n: "short_attention_kernel" in n or "slab_attention_kernel" in n,
+          "glb attention": lambda n: "short_attention" in n or "slab_attention" in n,
           "library attention (attn_fwd / SDPA)": lambda n: "attn_fwd" in n or "fmha" in n.lower(),
           "fused step (glb)": lambda n: "fused_step_kernel" in n or "chunk_stats" in n or "finish_kernel" in n,
           "other glb kernels": lambda n: "glb::" in n or ("anonymous namespace)::" in n and "at::native" not in n),

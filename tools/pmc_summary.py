@@ -132,7 +132,7 @@ for f in sorted(glob.glob(os.path.join(root, "pmc_req_trie*", "**", "*counter_co
             k = row["Counter_Name"]
             agg.setdefault(k, []).append(float(row["Counter_Value"]))
     if agg:
-        tag = os.path.relpath(f, root).split(os.sep)[0][len("pmc_req_"):]
+        tag = os.path.relpath(f, root).split(os.sep)[0][len("pmc_req_"):].split("_")[0]  # pmc_req_<workload>_<counter>
         out = {k: {"launches": len(v), "mean_per_launch": sum(v) / len(v)} for k, v in sorted(agg.items())}
         prev = {}
         pth = os.path.join(root, f"{tag}_request_counters.json")
