@@ -272,6 +272,10 @@ def main():
     ap.add_argument("--mask", choices=["random", "eos-only"], default="random",
                     help="kernel workloads: two shared masks forbidding a random third of the vocabulary (default), or the README's "
                          "EOS-only mask (README.md:63-66: one allowed token) on every row")
+    ap.add_argument("--mask-churn", type=float, default=1.0,
+                    help="kernel workloads with --per-row-masks: the fraction of the particles whose mask changes between calls. 1 "
+                         "(default): every call brings all masks into the kernels' layout (handed over raw); below 1: the masks are "
+                         "prepared once and only that fraction is prepared again per call (glb_mask_prepare_rows)")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="--gpus N on a box with ONE GPU: every rank computes on cuda:0 and the exchange goes over gloo through "
                          "host memory (RCCL wants a GPU per rank) - a rehearsal of the multi-rank code, not a measurement")
@@ -340,7 +344,7 @@ def main():
         runner = TrieWorkload(eng, dev, rank, out=args.trie_out)
     elif workload in ("kernel", "kernel-llama"):
         runner = KernelWorkload(eng, dev, rank, world, dist, llama=workload == "kernel-llama", per_row_masks=args.per_row_masks,
-                                logits=args.logits, mask_mode=args.mask, rng=args.rng)
+                                logits=args.logits, mask_mode=args.mask, rng=args.rng, mask_churn=args.mask_churn)
     elif workload in ("api", "api-coro", "api-readme", "api-logprobs"):
         runner = ApiWorkload(eng, dev, rank, world, dist, logprobs=workload == "api-logprobs", coro=workload == "api-coro",
                              auto_kv=args.auto_kv, readme=workload == "api-readme", llm_gather=args.llm_gather,
@@ -615,7 +619,7 @@ class KernelWorkload:
     (like the README's two masks), mask ids per row, in-kernel Philox."""
 
     def __init__(self, eng, dev, rank, world, dist, llama=False, nbuf=4, per_row_masks=False, logits="gaussian",
-                 mask_mode="random", rng="philox"):
+                 mask_mode="random", rng="philox", mask_churn=1.0):
         self.eng, self.dev, self.rank, self.world, self.dist = eng, dev, rank, world, dist
         g = torch.Generator(device=dev)
         g.manual_seed(1234 + rank)
@@ -638,13 +642,18 @@ class KernelWorkload:
             self.bufs = [(torch.randn((B, V), device=dev, generator=g) * 3.0).to(dt) for _ in range(nbuf)]
         self.bits, _ = eng.mask_to_bits(maskf)
         del maskf
-        self.masks = None if per_row_masks else eng.prepare_masks(self.bits, V, dt)
+        self.churn = float(mask_churn) if per_row_masks else 1.0
+        self.incremental = per_row_masks and self.churn < 1.0
+        self.masks = eng.prepare_masks(self.bits, V, dt) if (self.incremental or not per_row_masks) else None
+        self.n_changed = int(round(self.churn * B)) if self.incremental else 0
+        self.changed = [torch.from_numpy(np.random.default_rng(5 + k).choice(B, self.n_changed, replace=False).astype(np.int32)).to(dev)
+                        for k in range(nbuf)] if self.n_changed else None
         self.mask_id = (torch.arange(B, device=dev) % 2).to(torch.int32)
         self.out = (torch.empty(B, device=dev), torch.empty(B, device=dev),
                     torch.empty(B, dtype=torch.int32, device=dev))
         self.lw = torch.zeros(B, device=dev)
         self.gathered = torch.empty(B * world, device=dev) if world > 1 else None
-        self.kernel_bytes = algorithmic_bytes(B, V, 2 if llama else 4, n_masks, (V + 31) // 32)
+        self.kernel_bytes = algorithmic_bytes(B, V, 2 if llama else 4, self.n_changed if self.incremental else n_masks, (V + 31) // 32)
         self.parity = rng == "parity"
         self.noise_src = self.noise_buf = None
         if self.parity:
@@ -669,7 +678,11 @@ class KernelWorkload:
         torch.cuda.synchronize(dev)
         torch.cuda.empty_cache()
         draw = dict(rng_mode=2, noise=self.noise_buf) if self.parity else dict(rng_mode=1, seed=1234, offset=0)
-        if per_row_masks:  # raw bit rows, one per particle (mask ids = identity): every call prepares them itself
+        if self.incremental:  # one mask per particle, prepared once: a call prepares again only the masks that changed
+            self.own_id = torch.arange(B, dtype=torch.int32, device=dev)
+            self.plans = [eng.step_plan(x, mask=self.masks, mask_id=self.own_id, particle_base=rank * B, out=self.out, **draw)
+                          for x in self.bufs]
+        elif per_row_masks:  # raw bit rows, one per particle (mask ids = identity): every call prepares them itself
             self.plans = [eng.step_plan(x, mask_kind=1, mask=self.bits, particle_base=rank * B, out=self.out, **draw)
                           for x in self.bufs]
         else:
@@ -707,6 +720,8 @@ class KernelWorkload:
             e0.record()
             if self.parity:
                 self.noise_src.rows(self.B, out=self.noise_buf)
+            if self.n_changed:
+                self.eng.update_prepared_masks(self.masks, self.bits, self.changed[i % len(self.changed)])
             plan.run_timed(inner, offset=i)
             e1.record()
             self.events.append(inner)
@@ -714,6 +729,8 @@ class KernelWorkload:
         else:
             if self.parity:
                 self.noise_src.rows(self.B, out=self.noise_buf)
+            if self.n_changed:
+                self.eng.update_prepared_masks(self.masks, self.bits, self.changed[i % len(self.changed)])
             plan.run(offset=i)
         self.lw += self.out[0]
         if self.world > 1:
@@ -723,7 +740,7 @@ class KernelWorkload:
             self.eng.normalize_weights(self.gathered)
 
     def kernel_times_us(self):
-        if self.parity:  # the span that holds the noise generation too
+        if self.parity or self.n_changed:  # the span that holds the noise generation / the masks' update too
             return self.outer_times_us()
         return np.array([a.elapsed_time(b) * 1e3 for a, b in self.events])
 
@@ -738,6 +755,9 @@ class KernelWorkload:
             "1024 particles x gpt2 vocab 50257, fp32 logits [1024,50257]"
         masks = (f"{self.B} bit masks, one per particle (GLB_MASK_BITS, handed over raw: the call's own mask_prepare launch is "
                  "inside the timed launch span)") if self.per_row_masks else "2 shared bit masks (prepared once)"
+        if self.incremental:
+            masks = (f"{self.B} bit masks, one per particle, prepared once; {self.n_changed} of them ({self.churn:.0%}) change and are "
+                     "prepared again before every call (glb_mask_prepare_rows, inside the timed span)")
         if self.mask_mode == "eos-only":
             masks += ", EOS-only (one allowed token, README.md:63-66) on every row"
         rows = ("N(0, 3^2) logits" if self.logits_kind == "gaussian" else

@@ -181,6 +181,7 @@ SYMBOLS = {
     "glb_set_spin_limit": (C.c_int, [C.c_uint64]),
     "glb_mask_prepared_bytes": (_sz, [_i64, _i64]),
     "glb_mask_prepare": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _vp, _sz, _vp]),
+    "glb_mask_prepare_rows": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp, _sz, _vp]),
     "glb_log_softmax_workspace_bytes": (_sz, [_i64, _i64]),
     "glb_log_softmax_rows": (C.c_int, [_vp, _i32, _i64, _i64, _i64, _f32, _vp, _i32, _i64, _vp, _vp, _sz, _vp]),
     "glb_mask_f32_to_bits": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp]),

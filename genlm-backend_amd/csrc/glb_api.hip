@@ -190,15 +190,18 @@ inline size_t step_fixed_bytes(int64_t units, int64_t vocab) { return step_recs_
 // start: an event the launch carries as its start stamp (glb_logprob_mask_sample_timed: a call that prepares its own masks
 // is timed from this launch on)
 hipError_t launch_mask_prepare(const uint32_t *bits, int64_t n_masks, int64_t vocab, int64_t mask_ld, int dtype,
-                               void *out, hipStream_t s, hipEvent_t start = nullptr) {
+                               void *out, hipStream_t s, hipEvent_t start = nullptr, const int32_t *which = nullptr,
+                               int64_t n_which = 0) {
   const int nch = (int)n_chunks(vocab);
   uint64_t *mt = (uint64_t *)out;
   uint64_t *many = (uint64_t *)((char *)out + prepared_words_bytes(n_masks, vocab));
-  const dim3 grid((unsigned)nch, (unsigned)n_masks), block(64);
+  const dim3 grid((unsigned)nch, (unsigned)(which ? n_which : n_masks)), block(64);
   if (dtype == GLB_F32)
-    hipExtLaunchKernelGGL((glb::mask_prepare_kernel<4>), grid, block, 0, s, start, nullptr, 0, bits, mask_ld, (int)vocab, nch, mt, many);
+    hipExtLaunchKernelGGL((glb::mask_prepare_kernel<4>), grid, block, 0, s, start, nullptr, 0, bits, mask_ld, (int)vocab, nch, mt, many,
+                          which, (int)n_masks);
   else
-    hipExtLaunchKernelGGL((glb::mask_prepare_kernel<8>), grid, block, 0, s, start, nullptr, 0, bits, mask_ld, (int)vocab, nch, mt, many);
+    hipExtLaunchKernelGGL((glb::mask_prepare_kernel<8>), grid, block, 0, s, start, nullptr, 0, bits, mask_ld, (int)vocab, nch, mt, many,
+                          which, (int)n_masks);
   return hipGetLastError();
 }
 
@@ -784,6 +787,21 @@ int glb_mask_prepare(const uint32_t *mask_bits, int64_t n_masks, int64_t vocab, 
     return fail(GLB_ENOSPC, "prepared buffer %zu < %zu bytes", out_bytes, prepared_bytes(n_masks, vocab));
   if (((uintptr_t)out_prepared) % 16 || ((uintptr_t)mask_bits) % 4) return fail(GLB_EINVAL, "misaligned pointer");
   const hipError_t e = launch_mask_prepare(mask_bits, n_masks, vocab, mask_ld, dtype, out_prepared, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "mask_prepare launch");
+  return GLB_OK;
+}
+
+int glb_mask_prepare_rows(const uint32_t *mask_bits, int64_t n_masks, int64_t vocab, int64_t mask_ld, int32_t dtype,
+                          const int32_t *rows, int64_t n_rows, void *prepared, size_t prepared_bytes_, void *stream) {
+  if (!mask_bits || !prepared || (n_rows > 0 && !rows)) return fail(GLB_EINVAL, "null pointer");
+  if (n_masks <= 0 || vocab <= 0 || mask_ld < (vocab + 31) / 32 || n_rows < 0) return fail(GLB_EINVAL, "bad sizes");
+  if (dtype < GLB_F32 || dtype > GLB_F16) return fail(GLB_EINVAL, "bad dtype %d", dtype);
+  if (vocab > 0x7fffff00ll || n_masks > 65535 || n_rows > 65535) return fail(GLB_EINVAL, "vocab / n_masks / n_rows out of range");
+  if (prepared_bytes_ < prepared_bytes(n_masks, vocab))
+    return fail(GLB_ENOSPC, "prepared buffer %zu < %zu bytes", prepared_bytes_, prepared_bytes(n_masks, vocab));
+  if (((uintptr_t)prepared) % 16 || ((uintptr_t)mask_bits) % 4) return fail(GLB_EINVAL, "misaligned pointer");
+  if (n_rows == 0) return GLB_OK;
+  const hipError_t e = launch_mask_prepare(mask_bits, n_masks, vocab, mask_ld, dtype, prepared, (hipStream_t)stream, nullptr, rows, n_rows);
   if (e != hipSuccess) return hip_fail(e, "mask_prepare launch");
   return GLB_OK;
 }

@@ -1646,9 +1646,11 @@ __device__ __forceinline__ uint64_t bit_transpose_step(uint64_t x, int lane) {
 
 template <int EPV>
 __global__ __launch_bounds__(64) void mask_prepare_kernel(const uint32_t *bits, int64_t mask_ld, int V, int nch,
-                                                         uint64_t *mask_t, uint64_t *mask_any) {
+                                                         uint64_t *mask_t, uint64_t *mask_any, const int32_t *which, int n_masks) {
   constexpr int NVC = 64 / EPV;
-  const int k = blockIdx.y, c = blockIdx.x, lane = threadIdx.x;
+  // which: the masks to (re)prepare - only the rows whose mask changed since the last call (glb_mask_prepare_rows); null: all
+  const int k = which ? as_const(which)[blockIdx.y] : (int)blockIdx.y, c = blockIdx.x, lane = threadIdx.x;
+  if (k < 0 || k >= n_masks) return;
   const uint32_t *row = bits + (int64_t)k * mask_ld;
   uint64_t *dst = mask_t + ((int64_t)k * nch + c) * 64;
   const int n_words = (V + 31) >> 5;

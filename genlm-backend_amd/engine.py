@@ -385,6 +385,21 @@ class HipEngine:
                                         _ptr(blob), need, self._stream()))
         return PreparedMasks(blob, K, vocab, dt)
 
+    def update_prepared_masks(self, prepared, bits, rows):
+        """Re-prepare only the masks `rows` (int32 device tensor) of `prepared` (a `PreparedMasks` made from `bits` before)
+        from their current bit rows (glb_mask_prepare_rows): masks that change a few at a time cost what changed."""
+        if bits.dim() == 1:
+            bits = bits[None]
+        self._check_dev(bits, rows)
+        if bits.dtype != torch.int32 or rows.dtype != torch.int32:
+            raise TypeError("bit masks and row indices must be int32")
+        if bits.shape[0] != prepared.n_masks:
+            raise ValueError("the bit rows are not the ones these masks were prepared from")
+        K = prepared.n_masks
+        check(self.lib.glb_mask_prepare_rows(_ptr(bits), K, prepared.vocab, bits.stride(0) if K > 1 else bits.shape[1], prepared.dtype,
+                                             _ptr(rows), rows.numel(), _ptr(prepared.blob), prepared.blob.numel(), self._stream()))
+        return prepared
+
     def log_softmax_rows(self, logits, vocab=None, logit_scale=1.0, out=None, want_lse=False, workspace=None,
                          out_dtype=torch.float32):
         """out[r] = logits[r] - logsumexp(logits[r]) (glb_log_softmax_rows).  `out_dtype`: float32 (default) or the

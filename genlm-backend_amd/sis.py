@@ -150,8 +150,8 @@ class DeviceSIS:
     kv_graph         the in-place forward is replayed from a hipGraph after its second call (kv.SlabForward)
     particle_masks   int32 bit rows [n_particles + 1, ceil(V / 32)] on the device: particle i's OWN mask (row i; what a
                      grammar gives: README.md:57-70 generalised) while it generates, row n_particles once
-                     `max_tokens` are out.  Handed to the fused step raw on every call (GLB_MASK_BITS: masks that change
-                     every step cannot be prepared ahead); every particle is its own reduction unit.
+                     `max_tokens` are out.  Prepared for the kernels once; `update_particle_masks(rows, bit_rows)` changes
+                     some of them and only those are prepared again; every particle is its own reduction unit.
     force_collectives  run the collectives of the multi-rank path (all-gather of log-weights / token matrices, the
                      set-up reductions) through `dist` even when world == 1: a one-rank "nccl" group exercises the RCCL
                      code of an 8-GPU run on a single GPU.
@@ -219,6 +219,7 @@ class DeviceSIS:
         if self.particle_kv:
             assert not use_prefix_kv
         self.particle_masks = particle_masks
+        self._pm_prepared, self._pm_dirty = None, None
         self.rows_moved = 0  # particles that changed ranks in the last resampling step (over all ranks)
         self.resample_ess = resample_ess
         self.n_resamples = 0
@@ -415,9 +416,16 @@ class DeviceSIS:
         V = logits.shape[-1]
         mask_id = ((self.lengths - self.prompt_len) >= self.max_tokens).to(torch.int32)
         kw = llm.step_masks(logits.dtype) if self.particle_masks is None else {}
-        if self.particle_masks is not None:  # one mask per particle, raw bit rows: per-particle ids, no dedup of the math
+        if self.particle_masks is not None:  # one mask per particle: per-particle ids, no dedup of the math
+            # the bit rows are brought into the kernels' layout once; afterwards only the rows `update_particle_masks` named
+            # are prepared again (a grammar moves a few particles' masks a step: glb_mask_prepare_rows)
             own = torch.arange(N, dtype=torch.int32, device=self.dev)
-            kw = dict(mask_kind=1, mask=self.particle_masks, mask_id=torch.where(mask_id > 0, torch.full_like(own, N), own))
+            if self._pm_prepared is None or self._pm_prepared[1] != logits.dtype:
+                self._pm_prepared = (eng.prepare_masks(self.particle_masks, V, logits.dtype), logits.dtype)
+            elif self._pm_dirty is not None:
+                eng.update_prepared_masks(self._pm_prepared[0], self.particle_masks, self._pm_dirty)
+            self._pm_dirty = None
+            kw = dict(mask=self._pm_prepared[0], mask_id=torch.where(mask_id > 0, torch.full_like(own, N), own))
         elif kw:
             # The mask depends on the number of generated tokens only; with prompts of one length that makes it a
             # function of the context, so identical contexts (one logits row) share it: ids go per ROW and a shared
@@ -456,6 +464,12 @@ class DeviceSIS:
         if self.resample_ess is not None:
             self._maybe_resample()
         return U, n_global
+
+    def update_particle_masks(self, rows, bit_rows):
+        """Particles `rows` (int32 device tensor) get new masks `bit_rows` (int32 [len(rows), ceil(V / 32)]): only these are
+        brought into the kernels' layout again before the next step."""
+        self.particle_masks[rows.long()] = bit_rows
+        self._pm_dirty = rows if self._pm_dirty is None else torch.unique(torch.cat([self._pm_dirty, rows]))
 
     def _exchange(self):
         """All-gather of the per-shard log-weights and active counts (RCCL over xGMI when the backend is nccl): every

@@ -176,6 +176,14 @@ int glb_set_spin_limit(uint64_t microseconds);
 size_t glb_mask_prepared_bytes(int64_t n_masks, int64_t vocab);
 int glb_mask_prepare(const uint32_t *mask_bits, int64_t n_masks, int64_t vocab, int64_t mask_ld, int32_t dtype,
                      void *out_prepared, size_t out_bytes, void *hip_stream);
+/*
+ * Masks that change a few at a time (a grammar moves one particle's mask per token, README.md:57-70 generalised): re-prepare
+ * ONLY the masks rows[0 .. n_rows) (device int32; entries outside [0, n_masks) are skipped) of a buffer glb_mask_prepare
+ * filled before - the other masks' lane words stay as they are, so a steady-state call pays for what changed, not for
+ * n_masks x ceil(V / 8) bytes in and out.
+ */
+int glb_mask_prepare_rows(const uint32_t *mask_bits, int64_t n_masks, int64_t vocab, int64_t mask_ld, int32_t dtype,
+                          const int32_t *rows, int64_t n_rows, void *prepared, size_t prepared_bytes, void *hip_stream);
 
 /*
  * Materialise log-probabilities: out[r, j] = x[r, j] - logsumexp(x[r, :]).  Replaces the

@@ -55,6 +55,10 @@ class CpuOracleEngine:
     def prepare_masks(self, bits, vocab, logits_dtype=torch.float32):
         return _Prepared(bits)
 
+    def update_prepared_masks(self, prepared, bits, rows):
+        prepared.bits = bits  # (the double keeps the plain bit rows)
+        return prepared
+
     def step(self, logits, vocab=None, row_of=None, mask_kind=0, mask=None, mask_id=None, rng_mode=0, noise=None,
              seed=0, offset=0, particle_base=0, logit_scale=1.0, want_lse=True, out=None, row_mask_id=None,
              out_margin=None):

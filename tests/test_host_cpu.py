@@ -276,6 +276,18 @@ def test_device_sis_with_one_mask_per_particle(llm, gold):
     sis.run()
     ctx, _ = sis.results()
     assert [list(map(int, c)) for c in ctx] == [[3 + i] * 3 for i in range(16)]
+    # masks that change between steps (a grammar moving some particles on): only those rows are prepared again
+    sis = DeviceSIS(llm, 16, prompt, max_tokens=3, eos_id=0, seed=1, particle_masks=pm2.clone())
+    sis.step()
+    moved = torch.tensor([2, 5], dtype=torch.int32)
+    other = torch.full((2, V), float("-inf"))
+    other[0, 40], other[1, 41] = 0.0, 0.0
+    sis.update_particle_masks(moved, llm.engine.mask_to_bits(other)[0])
+    sis.run()
+    ctx, _ = sis.results()
+    want = [[3 + i] * 3 for i in range(16)]
+    want[2], want[5] = [5, 40, 40], [8, 41, 41]
+    assert [list(map(int, c)) for c in ctx] == want
 
 
 @pytest.mark.parametrize("use_kv", [False, True])

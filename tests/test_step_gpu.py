@@ -641,3 +641,34 @@ def test_one_bit_mask_per_particle_bit_exact(engine, oracle, B, V, dtype):
     for a, b in zip(got, got_p):
         assert torch.equal(a, b)
     engine.check()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_masks_prepared_again_only_where_they_changed(engine, oracle, dtype):
+    """glb_mask_prepare_rows (round 5): of 96 per-particle masks prepared once, 17 change; preparing only those again gives
+    the same bytes as preparing all of them, and the step on the updated masks holds the oracle's bits.  Indices outside the
+    table are skipped."""
+    dev = engine.device
+    tdt = torch.float32 if dtype == "f32" else torch.bfloat16
+    B, V = 96, 50257
+    x = synth.logits(41, B, V)
+    x_t = torch.from_numpy(x).to(tdt)
+    x_o = x if dtype == "f32" else x_t.view(torch.int16).numpy().view(np.uint16)
+    bits0, _ = oracle.mask_f32_to_bits(synth.binary_masks(41, B, V))
+    bits1 = bits0.copy()
+    rs = np.random.default_rng(4)
+    rows = rs.choice(B, 17, replace=False).astype(np.int32)
+    bits1[rows] = oracle.mask_f32_to_bits(synth.binary_masks(42, 17, V))[0]
+    b0 = torch.from_numpy(bits0.view(np.int32)).to(dev)
+    b1 = torch.from_numpy(bits1.view(np.int32)).to(dev)
+    prep = engine.prepare_masks(b0, V, tdt)
+    rows_d = torch.from_numpy(np.concatenate([rows, [-1, B + 5]]).astype(np.int32)).to(dev)
+    engine.update_prepared_masks(prep, b1, rows_d)
+    fresh = engine.prepare_masks(b1, V, tdt)
+    torch.cuda.synchronize()
+    assert torch.equal(prep.blob, fresh.blob)
+    want = oracle.step(x_o, mask_kind=oracle.MASK_BITS, mask=bits1, rng_mode=oracle.RNG_PHILOX, seed=5, offset=9)
+    got = engine.step(x_t.to(dev), mask=prep, rng_mode=1, seed=5, offset=9)
+    torch.cuda.synchronize()
+    for w, g, name in zip(want, got, ("logZ", "lse", "token")):
+        assert np.array_equal(g.cpu().numpy().view(np.uint32), w.view(np.uint32)), name
