@@ -219,6 +219,10 @@ SYMBOLS = {
     "glb_mt19937_jump_host": (C.c_int, [_vp, _vp, _vp]),
     "glb_mt19937_rows_workspace": (_sz, [_i64, _i32]),
     "glb_mt19937_exponential_rows": (C.c_int, [C.POINTER(MtRowsArgs), _vp]),
+    "glb_comm_unique_id": (C.c_int, [_vp]),
+    "glb_comm_init": (C.c_int, [_vp, _i32, _i32, C.POINTER(C.c_void_p)]),
+    "glb_allgather_f32": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
+    "glb_comm_destroy": (C.c_int, [_vp]),
     "glb_philox4x32_10": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
 }
 

@@ -607,6 +607,21 @@ typedef struct glb_mt_rows_args {
 size_t glb_mt19937_rows_workspace(int64_t max_draw_rows, int32_t n_small);
 int glb_mt19937_exponential_rows(const glb_mt_rows_args *args, void *hip_stream);
 
+/*
+ * The path's one collective for a caller WITHOUT PyTorch (SURVEY.md §8(b) sketched glb_allgather_f32(comm, ...)): once the
+ * particles are split over GPUs, README.md:108-110's normalisation needs every shard's log-weights on every rank - an
+ * all-gather of n floats per rank over RCCL / xGMI (4 KiB at 1024 particles: latency-bound).  Rank 0 makes an id
+ * (glb_comm_unique_id, GLB_COMM_ID_BYTES bytes) and hands it to the other ranks by whatever channel the integrator has;
+ * every rank calls glb_comm_init with its device current; recv holds world * n floats, rank-major.  RCCL is taken from the
+ * process at run time (dlopen); GLB_EUNSUPPORTED when there is none.  The Python host uses torch.distributed ("nccl" is
+ * the same RCCL) and never calls these.
+ */
+#define GLB_COMM_ID_BYTES 128
+int glb_comm_unique_id(void *out_id);
+int glb_comm_init(const void *id, int32_t rank, int32_t world, void **out_comm);
+int glb_allgather_f32(void *comm, const float *send, int64_t n, float *recv, void *hip_stream);
+int glb_comm_destroy(void *comm);
+
 /* Philox4x32-10 block function, exposed so hosts can reproduce the device draws. */
 void glb_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 

@@ -510,6 +510,34 @@ def test_rccl_self_exchange_of_the_calls_a_multi_gpu_run_makes(nccl_single):
     assert torch.equal(out, lw)
 
 
+def test_c_abi_allgather_without_torch_distributed(engine):
+    """glb_comm_* / glb_allgather_f32: the path's one collective for a caller that binds the C ABI without PyTorch - a
+    one-rank RCCL communicator made from a unique id, the all-gather of 1025 floats (the shard's log-weights + its active
+    count), destroyed again.  (N > 1 needs a GPU per rank: the driver's 8-GPU node.)"""
+    import ctypes as C
+
+    from genlm_backend_amd import _lib
+
+    lib = engine.lib
+    uid = (C.c_char * 128)()
+    rc = lib.glb_comm_unique_id(C.cast(uid, C.c_void_p))
+    if rc == _lib.GLB_EUNSUPPORTED:
+        pytest.skip("no RCCL in this process: " + _lib.last_error())
+    assert rc == 0, _lib.last_error()
+    comm = C.c_void_p()
+    assert lib.glb_comm_init(C.cast(uid, C.c_void_p), 0, 1, C.byref(comm)) == 0, _lib.last_error()
+    dev = engine.device
+    lw = torch.randn(1025, device=dev)
+    out = torch.full((1025,), -1.0, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    assert lib.glb_allgather_f32(comm, C.c_void_p(lw.data_ptr()), 1025, C.c_void_p(out.data_ptr()), stream) == 0, _lib.last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(out, lw)
+    assert lib.glb_allgather_f32(None, C.c_void_p(lw.data_ptr()), 1025, C.c_void_p(out.data_ptr()), stream) == _lib.GLB_EINVAL
+    assert lib.glb_comm_init(C.cast(uid, C.c_void_p), 1, 1, C.byref(comm)) == _lib.GLB_EINVAL
+    assert lib.glb_comm_destroy(comm) == 0
+
+
 def test_engine_launches_on_its_own_device(engine, oracle):
     """HipEngine runs every entry point with ITS device current, whatever the calling thread has set (one process
     driving several GPUs).  With one visible GPU the guard is exercised through its bookkeeping: the proxy resolves and
