@@ -236,6 +236,7 @@ def main():
     ap.add_argument("--workload", default="sis", choices=WORKLOADS)
     ap.add_argument("--cpu-sample", type=int, default=1024, help="rows of the CPU baseline sample (upper bound)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--step-times", action="store_true", help="diagnostic: print the longest host-side steps of the timed region to stderr")
     ap.add_argument("--particle-kv", action="store_true",
                     help="sis workloads with device-resident per-particle KV (beyond the reference: one token per particle per step)")
     ap.add_argument("--prefix-kv", action="store_true",
@@ -378,9 +379,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        marks = []
         for i in range(args.steps):
             r.step(args.warmup + i, timed=True)
+            if args.step_times:
+                marks.append(time.perf_counter())
         torch.cuda.synchronize()
+        if args.step_times and marks:  # (diagnostic: where the host spent the timed region - enqueue times, not GPU times)
+            d = np.diff(np.array([t0] + marks)) * 1e3
+            worst = np.argsort(-d)[:5]
+            print("longest host steps (ms):", [(int(k), round(float(d[k]), 3)) for k in worst], "median", round(float(np.median(d)), 4),
+                  "sync tail", round((time.perf_counter() - marks[-1]) * 1e3, 3), file=sys.stderr)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -672,9 +681,8 @@ class KernelWorkload:
         self._pool = []
         # the argument block of every buffer's call is filled once: a step's host work is then a few microseconds, so
         # the host stays ahead of the GPU and the event interval holds no wait for the next launch packet
-        # set-up, not measurement: what building the synthetic rows left in the allocator's cache goes back to the driver now
-        # (hundreds of MB of argsort / rand temporaries for the peaked rows: released lazily they cost one 65 ms stall
-        # somewhere in the timed region)
+        # set-up, not measurement: what building the synthetic rows left in the allocator's cache (GBs of argsort / rand
+        # temporaries for the peaked rows) goes back to the driver before the clock starts
         torch.cuda.synchronize(dev)
         torch.cuda.empty_cache()
         draw = dict(rng_mode=2, noise=self.noise_buf) if self.parity else dict(rng_mode=1, seed=1234, offset=0)
