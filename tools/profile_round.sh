@@ -61,6 +61,11 @@ for o in rows slots selected; do
   python3 $R/bench.py --workload trie --trie-out $o --steps 50 --warmup 5 $([ $o = rows ] || echo --no-cpu) > $O/bench_trie_$o.json 2>> $O/bench_trie.err
 done
 python3 $R/tools/gbench.py > $O/gbench.log 2>&1
+# ---- round 5: per-step tables of the default lines (GEMM us / TFLOP/s / % of step) from the traces made above
+for n in sis sis-llama; do
+  tr=$(find $O/kstats_$n -name "*kernel_trace.csv" | head -1)
+  [ -n "$tr" ] && python3 $R/tools/gemm_table.py $tr $O/bench_$n.json > $O/${n}_step_table.txt 2>&1
+done
 python3 $R/tools/pmc_summary.py $O > $O/pmc_summary.log
 find $O -name "*.db" -delete 2>/dev/null || true
 find $O -name "*kernel_trace.csv" -delete 2>/dev/null || true
