@@ -21,6 +21,7 @@
 
 #include "../../include/glb.h"
 #include "glb_common.hpp"
+#include "glb_diag.hpp"
 #include "glb_trie.hpp"
 
 namespace {
@@ -51,9 +52,7 @@ struct TrieRowsParams {
   int32_t n_sel;
   float *out_sel;
   int64_t out_sel_ld;
-#ifdef GLB_STAMPS  // diagnostic build (tools/dbg/stamps_trie.py): per workgroup [start, leaves in flight, leaves in LDS, reduced, written]
-  uint64_t *stamps;
-#endif
+  GLB_DIAG(uint64_t *stamps;)  // diagnostic build (tools/dbg/stamps_trie.py): per workgroup [start, leaves in flight, leaves in LDS, reduced, written]
 };
 
 // LDS of a part: val[n_local] float32, then as 16-bit words (a part has fewer than 65536 slots) the part's child
@@ -216,13 +215,9 @@ __global__ __launch_bounds__(kMaxThreads, 6) void trie_rows_kernel(TrieRowsParam
   if (p.need && !((p.need[r] >> (TOP ? 63 : part)) & 1ull)) return;  // (per-row selections: this row asks nothing of this part)
   const PartView v(p.desc + part * kDesc);
   const int tid = threadIdx.x, nt = blockDim.x;
-#ifdef GLB_STAMPS
-  uint64_t *st = (!TOP && p.stamps && blockIdx.x < 65536u) ? p.stamps + (int64_t)blockIdx.x * 8 : nullptr;
-  if (st && tid == 0) st[0] = __builtin_amdgcn_s_memrealtime();
-#define GLB_TRIE_STAMP(k) if (st && tid == 0) st[k] = __builtin_amdgcn_s_memrealtime();
-#else
-#define GLB_TRIE_STAMP(k)
-#endif
+  GLB_DIAG(uint64_t *st = (!TOP && p.stamps && blockIdx.x < 65536u) ? p.stamps + (int64_t)blockIdx.x * 8 : nullptr;)
+#define GLB_TRIE_STAMP(k) GLB_DIAG(if (st && tid == 0) st[k] = GLB_NOW();)
+  GLB_TRIE_STAMP(0)
   uint32_t *tab = reinterpret_cast<uint32_t *>(val + v.n_local);
   // ---- tables and leaves, two memory latencies in all: the table words and the leaves' indices (token, local slot) go
   // out together; the weights the indices name follow; the table words go to LDS while those are on their way.  (One
@@ -280,11 +275,9 @@ __global__ __launch_bounds__(kMaxThreads, 6) void trie_rows_kernel(TrieRowsParam
       for (int i = tid; i < n_roots; i += nt) cv[i] = val[i];
     }
   }
-#ifdef GLB_STAMPS
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  GLB_DIAG(asm volatile("s_waitcnt vmcnt(0)" ::: "memory");)
   GLB_TRIE_STAMP(4)
-  if (st && tid == 0) st[5] = ((uint64_t)part << 32) | (uint32_t)r;
-#endif
+  GLB_DIAG(if (st && tid == 0) st[5] = ((uint64_t)part << 32) | (uint32_t)r;)
 }
 
 // the selected nodes' slots, once per call (the same for every row)
@@ -421,9 +414,7 @@ int glb_trie_rows(const glb_trie_rows_args *a, const glb_trie_plan *pl, void *st
   p.out_nodes_ld = a->out_nodes_ld;
   p.n_sel = a->out_sel ? (int32_t)a->n_sel : 0;
   p.sel_slot = (const int32_t *)((char *)a->workspace + cut_bytes(a->n_rows, pl));
-#ifdef GLB_STAMPS
-  p.stamps = p.n_sel == 0 ? (uint64_t *)p.sel_slot : nullptr;  // (the selection's area, when there is no selection)
-#endif
+  GLB_DIAG(p.stamps = p.n_sel == 0 ? (uint64_t *)p.sel_slot : nullptr;)  // (the selection's area, when there is no selection)
   p.out_sel = a->n_sel > 0 ? a->out_sel : nullptr;
   p.out_sel_ld = a->out_sel_ld;
   hipStream_t s = (hipStream_t)stream;
@@ -443,10 +434,8 @@ int glb_trie_rows(const glb_trie_rows_args *a, const glb_trie_plan *pl, void *st
   int threads = 512;
   if (lds * 8 <= 160 * 1024) threads = 256;
   bool deep = pl->max_local > 8 * threads;  // (a part's leaves - three slots in four - in one trip of twelve a thread)
-#ifdef GLB_STAMPS
-  if (const char *ev = getenv("GLB_TRIE_THREADS")) threads = atoi(ev);
-  if (const char *ev = getenv("GLB_TRIE_DEEP")) deep = atoi(ev) != 0;
-#endif
+  GLB_DIAG(if (const char *ev = getenv("GLB_TRIE_THREADS")) threads = atoi(ev);)
+  GLB_DIAG(if (const char *ev = getenv("GLB_TRIE_DEEP")) deep = atoi(ev) != 0;)
   hipError_t e;
   switch (a->dtype) {
     case GLB_F32: e = launch_rows<GLB_F32>(p, pl->n_top, lds, threads, deep, s); break;
