@@ -86,7 +86,8 @@ def _merged_qkv(attn):
         with torch.no_grad():
             w = torch.cat(ws, 0)
             b = torch.cat(bs, 0) if bs[0] is not None else None
-        ent = attn.__dict__["_glb_qkv"] = (key, w, b)
+        # (the entry holds the source tensors: their ids cannot be handed to other tensors while it lives)
+        ent = attn.__dict__["_glb_qkv"] = (key, w, b, ws + bs)
     return ent[1], ent[2]
 
 
