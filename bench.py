@@ -263,6 +263,9 @@ def main():
                     help="kernel workloads: one bit mask PER PARTICLE (GLB_MASK_BITS, n_masks == n_particles: what a grammar gives), "
                          "handed over raw every call - the call brings them into the kernels' layout itself; sis workloads: "
                          "one mask per particle, every particle its own reduction unit")
+    ap.add_argument("--llama", choices=["3.2-1b", "3-8b"], default="3.2-1b",
+                    help="sis-llama: the Llama-3.2-1B shape (config 4's per-GPU share, default) or the Llama-3-8B shape (config 5's model: "
+                         "16 GB of bf16 weights, 512 particles)")
     ap.add_argument("--rng", choices=["philox", "parity"], default="philox",
                     help="kernel / sis workloads: in-kernel Philox draws (default), or the reference's draws - torch.multinomial's CPU "
                          "MT19937 stream (README.md:87), generated on the device (glb_mt19937_exponential_rows) and raced against "
@@ -354,7 +357,7 @@ def main():
         from genlm_backend_amd.sis import SisBenchWorkload
 
         runner = SisBenchWorkload(eng, dev, rank, world, dist, prefix_kv=args.prefix_kv, particle_kv=args.particle_kv,
-                                  model="llama-3.2-1b" if workload == "sis-llama" else "gpt2",
+                                  model=("llama-3-8b" if args.llama == "3-8b" else "llama-3.2-1b") if workload == "sis-llama" else "gpt2",
                                   n_particles=512 if workload == "sis-llama" else 1024, n_prompts=args.prompts,
                                   resample=args.resample, force_collectives=force_coll,
                                   kv_in_place=None if args.kv_gather else 0.75, per_particle_masks=args.per_row_masks,

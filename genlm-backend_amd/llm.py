@@ -139,7 +139,20 @@ class AsyncAmdLM(AsyncLM):
         from transformers import AutoModelForCausalLM
 
         torch.manual_seed(seed)
-        mod = AutoModelForCausalLM.from_config(config).to(dtype).to(device)
+        n_params = getattr(config, "num_hidden_layers", 0) * getattr(config, "hidden_size", 0) ** 2 * 12
+        if n_params > 2e9 and torch.device(device).type == "cuda":
+            # a model of several billion parameters: made on the device in its own dtype (on the host it would first be
+            # tens of GB of float32 and minutes of initialisation)
+            old = torch.get_default_dtype()
+            torch.set_default_dtype(dtype)
+            try:
+                with torch.device(device):
+                    mod = AutoModelForCausalLM.from_config(config)
+            finally:
+                torch.set_default_dtype(old)
+            mod = mod.to(dtype)
+        else:
+            mod = AutoModelForCausalLM.from_config(config).to(dtype).to(device)
         return cls(mod, tokenizer, **kwargs)
 
     @staticmethod

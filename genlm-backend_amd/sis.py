@@ -761,6 +761,15 @@ class SisBenchWorkload:
 
             cfg, dtype = GPT2Config(), torch.float32  # gpt2 small: 12 layers, d=768, 12 heads, vocab 50257
             self.model_name = "gpt2-small shape (random init, fp32)"
+        elif model == "llama-3-8b":  # BASELINE config 5's model: 32 layers, d 4096, 32 heads / 8 KV heads of 128, MLP 14336, untied
+            from transformers import LlamaConfig
+
+            cfg = LlamaConfig(vocab_size=128256, hidden_size=4096, intermediate_size=14336, num_hidden_layers=32,
+                              num_attention_heads=32, num_key_value_heads=8, head_dim=128, max_position_embeddings=4096,
+                              rope_theta=500000.0, rms_norm_eps=1e-5, tie_word_embeddings=False, bos_token_id=128000,
+                              eos_token_id=128001)
+            dtype = torch.bfloat16
+            self.model_name = "Llama-3-8B shape (random init, bf16)"
         else:
             from transformers import LlamaConfig
 
