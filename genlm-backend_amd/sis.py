@@ -546,7 +546,10 @@ class DeviceSIS:
         stable sort of the group ids, the number of rows consumed a device scalar - nothing crosses the host."""
         N = self.N
         if self.noise_src is None:
-            self.noise_src = self.eng.noise_rng(self.seed, V)
+            # (the reference is ONE process, so its stream is defined for one shard; with several ranks every rank takes a
+            # stream of its own - the same rows on every rank would tie the shards' particles together.  Philox draws are
+            # the shard-invariant mode.)
+            self.noise_src = self.eng.noise_rng(self.seed + 7919 * self.rank, V)
         act = self.active > 0
         key = torch.where(act, group_of.to(torch.int64), torch.full((N,), 1 << 40, dtype=torch.int64, device=self.dev))
         order = torch.argsort(key, stable=True)
