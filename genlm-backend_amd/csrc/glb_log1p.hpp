@@ -9,6 +9,10 @@
 // correctly rounded), so host and device agree with each other and with glibc.  Pinned on the CPU against the C
 // library's log1p (tests/test_mt_cpu.py: tens of millions of arguments, every branch) and through it against torch
 // (tests/test_oracle.py).
+//
+// The algorithm and its constants are those of fdlibm's s_log1p.c (Copyright (C) 1993 by Sun Microsystems, Inc.; developed at
+// SunPro, a Sun Microsystems, Inc. business; permission to use, copy, modify, and distribute that software is freely
+// granted, provided that this notice is preserved), in the evaluation order glibc gives the polynomial.
 #pragma once
 #include <stdint.h>
 #include <string.h>
