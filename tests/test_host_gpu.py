@@ -510,6 +510,43 @@ def test_rccl_self_exchange_of_the_calls_a_multi_gpu_run_makes(nccl_single):
     assert torch.equal(out, lw)
 
 
+@pytest.mark.parametrize("dtype,head_dim", [(torch.float32, 64), (torch.bfloat16, 64), (torch.bfloat16, 128)])
+def test_llama_shadow_equals_the_callers_model_on_gpu(engine, dtype, head_dim):
+    """The shadow the backend runs (fuse.py: RMSNorm as rms_norm, q / k / v from one GEMM, the rotary embedding for queries
+    and keys in one pass, glb attention) against the caller's untouched HuggingFace model on the device: a padded batch
+    with a mask, and a prefill + one-token decode through transformers' own DynamicCache - float32 within rounding, bfloat16
+    within a few bf16 ulps of the logits; the caller's model gives bit-identical results before and after."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    from genlm_backend_amd.llm import AsyncAmdLM
+
+    torch.manual_seed(11)
+    dev = engine.device
+    cfg = LlamaConfig(vocab_size=1000, hidden_size=4 * head_dim, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=2, head_dim=head_dim, max_position_embeddings=64, bos_token_id=1, eos_token_id=2)
+    model = LlamaForCausalLM(cfg).to(dtype).to(dev).eval()
+    ids = torch.randint(3, 1000, (5, 9), device=dev)
+    am = torch.ones_like(ids)
+    am[1, 6:] = 0
+    am[3, 4:] = 0
+    with torch.no_grad():
+        want = model(input_ids=ids, attention_mask=am).logits
+        w1 = model(input_ids=ids[:, :6], use_cache=True)
+        want2 = model(input_ids=ids[:, 6:7], past_key_values=w1.past_key_values).logits
+    m = AsyncAmdLM(model, None, engine=engine)
+    assert m._net is not model and set(m.fused) == {"rms_norm", "rope"} and m.glb_attention
+    with torch.no_grad():
+        got = m._lm_head(m._body(input_ids=ids, attention_mask=am).last_hidden_state)
+        g1 = m._body(input_ids=ids[:, :6], use_cache=True)
+        got2 = m._lm_head(m._body(input_ids=ids[:, 6:7], past_key_values=g1.past_key_values).last_hidden_state)
+        again = model(input_ids=ids, attention_mask=am).logits
+    tol = 2e-4 if dtype == torch.float32 else 6e-2
+    real = am.bool()  # (padded positions of a row: whatever the model's own attention leaves there)
+    assert (got.float() - want.float())[real].abs().max().item() < tol
+    assert (got2.float() - want2.float()).abs().max().item() < tol
+    assert torch.equal(again, want)
+
+
 def test_c_abi_allgather_without_torch_distributed(engine):
     """glb_comm_* / glb_allgather_f32: the path's one collective for a caller that binds the C ABI without PyTorch - a
     one-rank RCCL communicator made from a unique id, the all-gather of 1025 floats (the shard's log-weights + its active
