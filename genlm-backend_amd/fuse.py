@@ -16,6 +16,8 @@ What the shadow swaps (PyTorch ops only - no kernels of this library inside the 
                                                              -> roll + mul + addcmul, queries and keys in one pass
   * the q / k / v projections (three GEMMs)                  -> one GEMM on a derived [q; k; v] weight (a copy of those
                                                                 rows, rebuilt when the caller's weights change)
+  * Llama's gate_proj + up_proj, for few-token forwards       -> one GEMM on a derived [gate; up] weight (a second copy of
+                                                                those two matrices: `merge_mlp=False` keeps the memory)
   * the attention interface                                  -> kv.py's "glb" entry (glb_short_attention /
                                                                 glb_slab_attention where they apply, SDPA otherwise)
 Same functions, different rounding (float32 inside the fused ops, one rounding at the end): the reference's goldens hold
@@ -91,6 +93,38 @@ def _merged_qkv(attn):
     return ent[1], ent[2]
 
 
+MERGE_MLP_MAX_TOKENS = 2048  # up to here one GEMM for gate + up wins (tools/dbg/gemm_merge_probe.py); beyond, two do
+
+
+def _merged_gate_up(mlp):
+    """One weight [gate; up] for a SwiGLU MLP's two input projections, as `_merged_qkv`: a derived copy (at Llama-3.2-1B's
+    shape 67 MB a layer), rebuilt when the caller's weights change."""
+    ws = (mlp.gate_proj.weight, mlp.up_proj.weight)
+    bs = (mlp.gate_proj.bias, mlp.up_proj.bias)
+    key = tuple((id(t), t._version, t.data_ptr()) for t in ws + bs if t is not None)
+    ent = mlp.__dict__.get("_glb_gate_up")
+    if ent is None or ent[0] != key:
+        with torch.no_grad():
+            w = torch.cat(ws, 0)
+            b = torch.cat(bs, 0) if bs[0] is not None else None
+        ent = mlp.__dict__["_glb_gate_up"] = (key, w, b, ws + bs)
+    return ent[1], ent[2]
+
+
+def _llama_mlp_forward(self, x):
+    """modeling_llama.py:174-176.  For the few-token forwards of the path (one token per KV row: M = 512 to 1024) gate_proj and
+    up_proj are ONE GEMM on a derived [gate; up] weight - at M = 512 two GEMMs of N = 8192 leave three quarters of the chip's
+    CUs without a tile (65.6 -> 48.3 us a layer at Llama-3.2-1B's shape, 135 -> 114 at Llama-3-8B's); the big re-encoding
+    batches keep two GEMMs (the strided halves cost the elementwise ops more than the GEMM gains there)."""
+    if (x.shape[:-1].numel() <= MERGE_MLP_MAX_TOKENS
+            and not (torch.is_grad_enabled() and (x.requires_grad or self.gate_proj.weight.requires_grad))):
+        w, b = _merged_gate_up(self)
+        n = self.gate_proj.weight.shape[0]
+        h = torch.nn.functional.linear(x, w, b)
+        return self.down_proj(self.act_fn(h[..., :n]) * h[..., n:])
+    return self.down_proj(self.act_fn(self.gate_proj(x)) * self.up_proj(x))
+
+
 def weights_version(net):
     """A number that changes when a weight the shadow keeps a derived copy of changes (SlabForward drops its hipGraphs then:
     a captured launch would keep reading the stale copy)."""
@@ -148,7 +182,7 @@ def _rotary_forward_signed(self, x, position_ids):
     return cos, sin
 
 
-def fuse_shadow(shadow, activations=True):
+def fuse_shadow(shadow, activations=True, merge_mlp=True):
     """Swap the decomposed activations / norms / rotary embedding of a SHADOW tree (never call this on a caller's model).
     Returns the names of what was swapped."""
     done = []
@@ -168,4 +202,7 @@ def fuse_shadow(shadow, activations=True):
                 done.append("rope")
             elif kind == "LlamaRotaryEmbedding":
                 child.forward = types.MethodType(_rotary_forward_signed, child)
+            elif kind == "LlamaMLP" and merge_mlp:
+                child.forward = types.MethodType(_llama_mlp_forward, child)
+                done.append("gate_up")
     return done

@@ -285,6 +285,8 @@ class SlabForward:
         # with, so the graphs are dropped when one of the sources changes
         self._watched = [t for mod in body.modules() if hasattr(mod, "q_proj") and hasattr(mod, "k_proj") and hasattr(mod, "v_proj")
                          for t in (mod.q_proj.weight, mod.k_proj.weight, mod.v_proj.weight)]
+        self._watched += [t for mod in body.modules() if hasattr(mod, "gate_proj") and hasattr(mod, "up_proj")
+                          for t in (mod.gate_proj.weight, mod.up_proj.weight)]
         self._watched_version = self._weights_version()
         # glb_slab_attention instead of two appends + a mask + a dense SDPA call per layer: for models whose attention
         # goes through transformers' attention interface with plain softmax(q k^T * scale) v semantics on a HIP device

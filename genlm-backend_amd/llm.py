@@ -187,13 +187,15 @@ class AsyncAmdLM(AsyncLM):
     @torch.no_grad()
     def __init__(self, hf_model, hf_tokenizer, batch_size=20, timeout=0.02, engine=None, fuse_activations=True,
                  kv_budget_bytes=8 << 30, logprob_budget_bytes=16 << 30, auto_kv_rows=0, auto_kv_cap=64,
-                 logprob_dtype="float32", glb_attention=True):
+                 logprob_dtype="float32", glb_attention=True, merge_mlp=True):
         """The caller's `hf_model` is never modified (hf.py:114-140 leaves it alone too): with `fuse_activations` or
         `glb_attention` the forwards of this backend run on a private SHADOW of its module tree that shares every weight
         (fuse.shadow_model); `self.model` stays the caller's object.
         fuse_activations: in the shadow, GPT-2's eight-op `gelu_new` becomes one GELU kernel, Llama-family RMSNorm one
         `rms_norm` call, the rotary embedding three elementwise ops per tensor instead of six (same functions, different
-        rounding).  glb_attention: the shadow's attention goes through this library's kernels where they apply (padded
+        rounding); `merge_mlp` (Llama family): for few-token forwards gate_proj and up_proj are one GEMM on a derived
+        [gate; up] weight - a second copy of those two matrices in device memory (False: not made).  glb_attention: the
+        shadow's attention goes through this library's kernels where they apply (padded
         batches of short contexts: glb_short_attention; the in-place one-token forward over KV rows: glb_slab_attention),
         everything else still runs the SDPA path.  Both False: the forwards run on `hf_model` itself.
         logprob_dtype: "float32" (default: every row `next_token_logprobs` returns is float32, whatever the checkpoint's
@@ -228,7 +230,7 @@ class AsyncAmdLM(AsyncLM):
             from .fuse import fuse_shadow, shadow_model
 
             self._net = shadow_model(self.model)
-            self.fused = fuse_shadow(self._net, activations=bool(fuse_activations))
+            self.fused = fuse_shadow(self._net, activations=bool(fuse_activations), merge_mlp=bool(merge_mlp))
             if want_attention:
                 from .kv import use_glb_attention
 

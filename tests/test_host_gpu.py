@@ -534,7 +534,7 @@ def test_llama_shadow_equals_the_callers_model_on_gpu(engine, dtype, head_dim):
         w1 = model(input_ids=ids[:, :6], use_cache=True)
         want2 = model(input_ids=ids[:, 6:7], past_key_values=w1.past_key_values).logits
     m = AsyncAmdLM(model, None, engine=engine)
-    assert m._net is not model and set(m.fused) == {"rms_norm", "rope"} and m.glb_attention
+    assert m._net is not model and set(m.fused) == {"rms_norm", "rope", "gate_up"} and m.glb_attention
     with torch.no_grad():
         got = m._lm_head(m._body(input_ids=ids, attention_mask=am).last_hidden_state)
         g1 = m._body(input_ids=ids[:, :6], use_cache=True)
