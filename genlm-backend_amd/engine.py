@@ -179,6 +179,7 @@ class HipEngine:
         self._trie_ws = None
         self._mt_ws = None
         self._mt_polys = {}
+        self._ptr_tables = {}
 
     def __del__(self):
         try:
@@ -563,17 +564,30 @@ class HipEngine:
                                            _DT[query.dtype], _ptr(out), self._stream()))
         return out
 
-    def kv_gather_rows(self, srcs, dsts, src_row_of, len_of):
+    def kv_gather_rows(self, srcs, dsts, src_row_of, len_of, srcs_stable=True):
         """dsts[t][i, h, p] = srcs[t][src_row_of[i], h, p] for p < len_of[i], for every tensor pair of the two lists
         (all [rows, heads, cap, head_dim], contiguous) in ONE launch through device pointer tables
         (glb_kv_gather_rows).  src_row_of[i] < 0 leaves row i untouched."""
         s0, d0 = srcs[0], dsts[0]
         assert all(t.is_contiguous() for t in srcs) and all(t.is_contiguous() for t in dsts)
-        sp = torch.tensor([t.data_ptr() for t in srcs], dtype=torch.int64, device=self.device)
-        dp = torch.tensor([t.data_ptr() for t in dsts], dtype=torch.int64, device=self.device)
+        # (srcs_stable=False: the sources are a one-off - the KV a forward has just returned: their table is not kept)
+        sp = self._ptr_table(srcs) if srcs_stable else torch.tensor([t.data_ptr() for t in srcs], dtype=torch.int64, device=self.device)
+        dp = self._ptr_table(dsts)
         check(self.lib.glb_kv_gather_rows(_ptr(sp), _ptr(dp), len(srcs), d0.shape[0], d0.shape[1], d0.shape[3],
                                           s0.shape[2], d0.shape[2], _ptr(src_row_of), _ptr(len_of), d0.element_size(),
                                           self._stream()))
+
+    def _ptr_table(self, tensors):
+        """Device table of the tensors' addresses.  Slab sets are handed over again and again: the table of a set is made
+        once (a host list -> device copy from pageable memory is a synchronous copy - one in every step kept the host from
+        running ahead of the GPU) and kept with the tensors it names, so an address cannot be reused under it."""
+        key = tuple(t.data_ptr() for t in tensors)
+        ent = self._ptr_tables.get(key)
+        if ent is None:
+            if len(self._ptr_tables) >= 64:
+                self._ptr_tables.pop(next(iter(self._ptr_tables)))
+            ent = self._ptr_tables[key] = (torch.tensor(key, dtype=torch.int64, device=self.device), list(tensors))
+        return ent[0]
 
     def gather_rows_i32(self, src, row_of, out=None):
         """out[i] = src[row_of[i]] for an int32 matrix (glb_gather_rows_i32)."""

@@ -163,7 +163,7 @@ class SlabKV(Cache):
         ([(K, V)] per layer, each [u, heads, l_src, head_dim], contiguous): fan-out of freshly encoded contexts."""
         self._alloc_like(src_layers)
         srcs = [t for kv in src_layers for t in kv]
-        self.engine.kv_gather_rows(srcs, self._tensors(self.layers), src_row_of, len_of)
+        self.engine.kv_gather_rows(srcs, self._tensors(self.layers), src_row_of, len_of, srcs_stable=False)
 
     def gather(self, src_row_of, len_of):
         """Resampling: row i becomes a copy of row src_row_of[i] (first len_of[i] positions); rows with

@@ -203,7 +203,7 @@ class CpuOracleEngine:
         r = torch.arange(n) if rows is None else rows.long()
         slab[r, :, pos.long()] = new_rows[:, :, 0]
 
-    def kv_gather_rows(self, srcs, dsts, src_row_of, len_of):
+    def kv_gather_rows(self, srcs, dsts, src_row_of, len_of, srcs_stable=True):
         sr, ln = _np(src_row_of), _np(len_of)
         for s_, d_ in zip(srcs, dsts):
             for i in range(d_.shape[0]):
