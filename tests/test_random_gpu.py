@@ -131,3 +131,108 @@ def test_random_case(engine, oracle, c):
         g16 = got16.cpu().view(torch.int16).numpy().view(np.uint16)
         assert np.array_equal(g16[~nan], want16.view(np.uint16)[~nan]), "log_softmax rows in the logits' dtype"
         assert np.array_equal(np.isnan(got16.float().cpu().numpy()), nan), "log_softmax NaN pattern (16-bit)"
+
+
+# ---- round 5: the attention of the padded batches and the trie selections, swept -----------------------------------------------
+def _attn_case(rng):
+    Dh = int(rng.choice([16, 32, 64, 128]))
+    Hkv = int(rng.choice([1, 2, 3, 8]))
+    G = int(rng.choice([1, 1, 2, 4]))
+    Lq = int(rng.integers(1, 20))
+    Lk = Lq + int(rng.choice([0, 0, 0, 1, 5, 13, 30]))  # (up to 32 keys: the (row, KV head) kernel; beyond: round 4's)
+    return dict(Dh=Dh, Hkv=Hkv, H=Hkv * G, Lq=Lq, Lk=Lk, U=int(rng.integers(1, 40)), dtype=str(rng.choice(["f32", "bf16", "f16"])),
+                seed=int(rng.integers(0, 2**31)), masked=bool(rng.random() < 0.7))
+
+
+ATTN_CASES = [_attn_case(np.random.default_rng(7000 + i)) for i in range(max(8, int(os.environ.get("GLB_RANDOM_CASES", "96")) // 3))]
+
+
+@pytest.mark.parametrize("c", ATTN_CASES, ids=lambda c: f"U{c['U']}-H{c['H']}/{c['Hkv']}-L{c['Lq']}/{c['Lk']}-D{c['Dh']}-{c['dtype']}-{'mask' if c['masked'] else 'causal'}")
+def test_random_short_attention(engine, c):
+    """glb_short_attention against scaled_dot_product_attention in float32 on random shapes: head widths, grouped heads, key
+    ranges on both sides of the 16 / 32-key kernels, ragged padding masks with fully padded queries, causal without a mask."""
+    dev = engine.device
+    tdt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[c["dtype"]]
+    U, H, Hkv, Lq, Lk, Dh = c["U"], c["H"], c["Hkv"], c["Lq"], c["Lk"], c["Dh"]
+    g = torch.Generator(device=dev)
+    g.manual_seed(c["seed"])
+    proj = torch.randn((U, Lq, (H + 2 * Hkv) * Dh), device=dev, generator=g).to(tdt)
+    q = proj[..., :H * Dh].view(U, Lq, H, Dh).transpose(1, 2)
+    k_new = proj[..., H * Dh:(H + Hkv) * Dh].view(U, Lq, Hkv, Dh).transpose(1, 2)
+    v_new = proj[..., (H + Hkv) * Dh:].view(U, Lq, Hkv, Dh).transpose(1, 2)
+    P = Lk - Lq
+    if P:
+        k = torch.cat([torch.randn((U, Hkv, P, Dh), device=dev, generator=g).to(tdt), k_new], dim=2)
+        v = torch.cat([torch.randn((U, Hkv, P, Dh), device=dev, generator=g).to(tdt), v_new], dim=2)
+    else:
+        k, v = k_new, v_new
+    ar = torch.arange(Lk, device=dev)
+    causal = ar[None, :] <= (torch.arange(Lq, device=dev)[:, None] + P)
+    mask = None
+    if c["masked"]:
+        lens = torch.randint(1, Lq + 1, (U,), device=dev, generator=g)
+        base = torch.randint(0, P + 1, (U,), device=dev, generator=g) if P else torch.zeros(U, dtype=torch.long, device=dev)
+        key_ok = (ar[None, :] < base[:, None]) | ((ar[None, :] >= P) & (ar[None, :] < P + lens[:, None]))
+        mask = (key_ok[:, None, None, :] & causal[None, None, :, :]).contiguous()
+    scale = Dh ** -0.5
+    out = engine.short_attention(q, k, v, mask, scale)
+    torch.cuda.synchronize()
+    ref_mask = mask if mask is not None else causal[None, None].expand(U, 1, Lq, Lk)
+    G = H // Hkv
+    want = torch.nn.functional.scaled_dot_product_attention(q.float(), k.float().repeat_interleave(G, 1), v.float().repeat_interleave(G, 1),
+                                                            attn_mask=ref_mask, scale=scale).transpose(1, 2)
+    live = ref_mask.any(-1)[:, 0]
+    tol = 5e-5 if tdt == torch.float32 else (2e-2 if tdt == torch.bfloat16 else 3e-3)
+    assert out.shape == (U, Lq, H, Dh) and out.dtype == tdt
+    assert (out.float() - want)[live].abs().max().item() < tol
+    assert not bool(out[~live].any())
+
+
+TRIE_CASES = [dict(seed=9000 + i) for i in range(max(4, int(os.environ.get("GLB_RANDOM_CASES", "96")) // 16))]
+
+
+@pytest.mark.parametrize("c", TRIE_CASES, ids=lambda c: f"trie{c['seed']}")
+def test_random_trie_selections(engine, oracle, c):
+    """Selections of trie nodes on random vocabularies and part sizes: one selection for every row (the sub-forest plan) and a
+    selection per row (parts a row does not need are skipped) give the whole trie's values of those nodes, bit for bit, and
+    the whole trie's values are the oracle's."""
+    from genlm_backend_amd.tokenization import Token
+    from genlm_backend_amd.trie import TokenByteTrie
+
+    rs = np.random.default_rng(c["seed"])
+    n_words, alpha, max_len = int(rs.integers(50, 3000)), int(rs.integers(2, 9)), int(rs.integers(2, 8))
+    words, seen = [], set()
+    tries = 0
+    while len(words) < n_words and tries < 50 * n_words:
+        tries += 1
+        w = bytes(rs.integers(97, 97 + alpha, int(rs.integers(1, max_len + 1))).astype(np.uint8))
+        if w not in seen:
+            seen.add(w)
+            words.append(w)
+    trie = TokenByteTrie([Token(i, w) for i, w in enumerate(words)], engine=engine)
+    trie.PLAN_CAP = int(rs.choice([60, 250, 1000, 20000]))
+    if trie.plan() is None:
+        pytest.skip("a node with more children than a part holds: the level kernels serve this trie")
+    dev = engine.device
+    V, nn, B = len(words), len(trie), int(rs.integers(1, 30))
+    w = rs.random((B, V)).astype(np.float32)
+    wd = torch.from_numpy(w).to(dev)
+    op = int(rs.integers(0, 2))
+    full = engine.trie_rows(wd, trie.plan_device_arrays(), op, False)
+    assert np.array_equal(full.cpu().numpy().view(np.uint32), oracle.trie_reduce(w, trie.flat(), op).view(np.uint32))
+    # one selection for all rows, through masses_from_logits' sub-forest plan (weights in as "log-probabilities" of themselves)
+    x = (rs.standard_normal((B, V)) * 2).astype(np.float32)
+    xd = torch.from_numpy(x).to(dev)
+    _, lse, _ = engine.step(xd, vocab=V, rng_mode=0)
+    trie.prune_selection = False
+    rows = trie.masses_from_logits(xd, lse)
+    trie.prune_selection = True
+    sel = torch.from_numpy(rs.choice(nn, int(rs.integers(1, min(nn, 300) + 1)), replace=False).astype(np.int32)).to(dev)
+    assert torch.equal(trie.masses_from_logits(xd, lse, nodes=sel), rows[:, sel.long()])
+    # a selection per row
+    K = int(rs.integers(1, 20))
+    per = rs.integers(-1, nn, size=(B, K)).astype(np.int32)
+    got = trie.masses_from_logits(xd, lse, nodes=torch.from_numpy(per).to(dev))
+    idx = torch.from_numpy(np.where(per >= 0, per, 0).astype(np.int64)).to(dev)
+    want = torch.where(torch.from_numpy(per >= 0).to(dev), torch.gather(rows, 1, idx), torch.zeros_like(got))
+    assert torch.equal(got, want)
