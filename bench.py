@@ -573,7 +573,7 @@ class TrieWorkload:
                 seen.add(w)
                 words.append(w)
         self.trie = TokenByteTrie([Token(i, w) for i, w in enumerate(words)], engine=eng)
-        self.plan = self.trie.plan()
+        self.plan = self.trie.slot_plan() if out in ("rows", "slots") else self.trie.plan()  # (the plan the timed call runs on)
         g = torch.Generator(device=dev)
         g.manual_seed(77 + rank)
         self.bufs = [torch.randn((B, V), device=dev, generator=g) * 3.0 for _ in range(nbuf)]
@@ -592,9 +592,15 @@ class TrieWorkload:
         width = {"rows": len(self.trie), "slots": self.plan["n_slots"], "selected": 4096, "rowsel": K, "rowsel-root": K}[out]
         self.kernel_bytes = B * V * 4 + B * width * 4 + B * 4
         self.outer = []
-        self.roofline_kernel = ("(anonymous)::trie_rows_kernel x 2 launches (glb_trie_rows: a workgroup per (row, part) of the "
-                                "folded trie - leaves gathered from the row, reduced depth by depth in LDS in the reference's order, "
-                                "the part's run of the output row written; then the few nodes above the parts)")
+        if self.plan.get("sweep"):
+            self.roofline_kernel = ("(anonymous)::trie_sweep_kernel + trie_rows_kernel<top> (glb_trie_rows: a persistent workgroup per part "
+                                    "of the folded trie reads row after row front to back, its tokens' slots and the part's internal "
+                                    "nodes in registers, the part's values in LDS - reduced depth by depth in the reference's order, "
+                                    "the part's run of the output row written; then the few nodes above the parts)")
+        else:
+            self.roofline_kernel = ("(anonymous)::trie_rows_kernel x 2 launches (glb_trie_rows: a workgroup per (row, part) of the "
+                                    "folded trie - leaves gathered from the row, reduced depth by depth in LDS in the reference's order, "
+                                    "the part's run of the output row written; then the few nodes above the parts)")
         self.roofline_timing = ("every call of the timed region between two hipEventRecord markers on the stream (both launches "
                                 "and, for selected nodes, the slot look-up launch inside the span)")
 

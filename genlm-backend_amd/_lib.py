@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libglb_hip.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 GLB_OK, GLB_EINVAL, GLB_EUNSUPPORTED, GLB_EHIP, GLB_ENOSPC = 0, 1, 2, 3, 4
 F32, BF16, F16 = 0, 1, 2
 MASK_NONE, MASK_BITS, MASK_F32, MASK_PREPARED = 0, 1, 2, 3
@@ -59,7 +59,8 @@ class TriePlan(C.Structure):
     _fields_ = [("struct_size", C.c_uint32)] + [(k, C.c_int32) for k in ("n_parts", "n_top", "n_cut", "n_slots", "max_local", "top_base",
                                                                           "lds_bytes")] + [
         ("n_nodes", C.c_int64)] + [(k, C.c_void_p) for k in ("desc", "idepth", "leaf_src", "leaf_local", "run_tab", "top_local", "slot_of",
-                                                             "cptr16", "inode16", "pn_local16")]
+                                                             "cptr16", "inode16", "pn_local16", "tok_local16", "inode64")] + [
+        ("lds_top_bytes", C.c_int32), ("vocab", C.c_int32)]
 
 
 class TrieRowsArgs(C.Structure):

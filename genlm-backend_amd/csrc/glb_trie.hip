@@ -39,6 +39,9 @@ struct TrieRowsParams {
   float scale;
   const int32_t *desc, *idepth, *leaf_src, *leaf_local, *run_tab, *top_local;
   const uint16_t *cptr16, *inode16, *pn_local16;
+  const uint16_t *tok_local16;  // sweep plans: [n_parts][vocab_pad] the token's local slot in the part (another part's: a word of the slack, n_local + 0..31)
+  const uint64_t *inode64;      // sweep plans: the internal nodes as inode16 lists them: slot | first child << 16 | children << 32
+  int32_t vocab, vocab_pad;
 
   int32_t top_base, n_cut;
   float *cut_vals;  // [n_rows][n_cut]: the values of the parts' subtree roots, the leaves of the top
@@ -120,8 +123,11 @@ __device__ __forceinline__ void part_reduce(const TrieRowsParams &p, const PartV
 }
 
 // the part's values out: its run of the slot-major row, the trie nodes it holds, the selected nodes that are its own
+// kW: 8-byte reads of node lists / selected slots a thread has in flight; OUT: the outputs compiled in (1 slots, 2 nodes,
+// 4 selected) - the sweep kernel has few registers to spare and is instantiated per kind of output
+template <int kW = 4, int OUT = 7>
 __device__ __forceinline__ void part_write(const TrieRowsParams &p, const PartView &v, const float *val, bool top, int r, int tid, int nt) {
-  if (p.out_slots) {
+  if ((OUT & 1) && p.out_slots) {
     float *o = p.out_slots + (int64_t)r * p.out_slots_ld;
     if (top) {
       const int n_top = v.n_local - v.n_leaves;
@@ -135,7 +141,7 @@ __device__ __forceinline__ void part_write(const TrieRowsParams &p, const PartVi
       for (int i = n4 + tid; i < v.n_local; i += nt) o[i] = val[i];
     }
   }
-  if (p.out_nodes) {
+  if ((OUT & 2) && p.out_nodes) {
     // the part's nodes are a few runs of consecutive ids (a subtree is an interval of the post-order numbering, the
     // one-child nodes folded into its root follow it): consecutive stores, one 16-bit local slot read per node
     float *o = p.out_nodes + (int64_t)r * p.out_nodes_ld;
@@ -148,12 +154,12 @@ __device__ __forceinline__ void part_write(const TrieRowsParams &p, const PartVi
     for (int k = 0; k < n_runs; ++k) {  // (workgroup-uniform)
       const int lo = runs[2 * k], cnt = runs[2 * k + 1], cnt4 = cnt & ~3;
       // four nodes a lane: one 8-byte read of local slots, one 16-byte store (1 KB of consecutive output a wave instruction)
-      for (int i0 = 4 * tid; i0 < cnt4; i0 += 4 * nt * 4) {
-        uint64_t q[4];
+      for (int i0 = 4 * tid; i0 < cnt4; i0 += 4 * nt * kW) {
+        uint64_t q[kW];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) q[j] = i0 + j * 4 * nt < cnt4 ? *reinterpret_cast<const u64_u *>(nl + at + i0 + j * 4 * nt) : 0ull;
+        for (int j = 0; j < kW; ++j) q[j] = i0 + j * 4 * nt < cnt4 ? *reinterpret_cast<const u64_u *>(nl + at + i0 + j * 4 * nt) : 0ull;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < kW; ++j) {
           const int i = i0 + j * 4 * nt;
           if (i < cnt4) {
             const f32x4_u x{val[q[j] & 0xffffu], val[(q[j] >> 16) & 0xffffu], val[(q[j] >> 32) & 0xffffu], val[q[j] >> 48]};
@@ -165,19 +171,19 @@ __device__ __forceinline__ void part_write(const TrieRowsParams &p, const PartVi
       at += cnt;
     }
   }
-  if (p.out_sel) {
+  if ((OUT & 4) && p.out_sel) {
     float *o = p.out_sel + (int64_t)r * p.out_sel_ld;
     const int base = v.d[D_SLOT_BASE];
     const int32_t *sel_slot = p.sel_slot + (int64_t)r * p.sel_stride;
-    for (int j0 = tid; j0 < p.n_sel; j0 += nt * 4) {
-      int sl[4];
+    for (int j0 = tid; j0 < p.n_sel; j0 += nt * kW) {
+      int sl[kW];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < kW; ++j) {
         const int jj = j0 + j * nt;
         sl[j] = jj < p.n_sel ? sel_slot[jj] : -1;
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < kW; ++j) {
         const int jj = j0 + j * nt, s = sl[j];
         if (top) {
           if (s >= base) o[jj] = val[p.top_local[s - base]];
@@ -280,6 +286,260 @@ __global__ __launch_bounds__(kMaxThreads, 6) void trie_rows_kernel(TrieRowsParam
   GLB_DIAG(if (st && tid == 0) st[5] = ((uint64_t)part << 32) | (uint32_t)r;)
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5: the same (row, part) workgroup, but the row is READ FRONT TO BACK instead of gathered.  A gathered part touches
+// nearly every 64-byte sector of the row for 1.8 of its tokens, so nine parts ask the L2 for the row nine times over, a
+// request per 1.8 tokens: 28 M sector requests a launch at 1024 x 50257, the rate that bounds the kernel above.  Here only
+// the part's VALUES live in LDS (4 bytes a slot: parts of 40 000 slots, two for the 66 k slots of a 50 k vocabulary, one
+// 1024-thread workgroup a CU); the workgroup streams the whole row in 16-byte loads next to `tok_local16[part]` (16 bytes
+// for 8 tokens: the token's slot in this part, or 0xffff), and drops its own tokens' weights into LDS; the internal nodes
+// come depth by depth from `inode64` in global memory (the same for every row: L2), a depth ahead of the reduction.
+// Requests per row: parts x (row + table) in 128-byte lines instead of a sector per 1.8 tokens per part.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int DT>
+struct RowVec;
+template <>
+struct RowVec<GLB_F32> {
+  typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));  // (a row starts on any word)
+  f32x4_u a, b;
+  __device__ __forceinline__ void load(const void *ws, int64_t idx) {
+    const float *q = reinterpret_cast<const float *>(ws) + idx;
+    a = *reinterpret_cast<const f32x4_u *>(q);  // (plain loads: the row's other parts read it from this XCD's L2)
+    b = *reinterpret_cast<const f32x4_u *>(q + 4);
+  }
+  __device__ __forceinline__ float get(int k) const { return k < 4 ? a[k] : b[k - 4]; }
+  __device__ __forceinline__ void none() { asm volatile("" : "=v"(a), "=v"(b)); }  // (any value: no tie to what the registers held)
+};
+template <int DT>
+struct RowVec {  // 16-bit rows: eight tokens in 16 bytes, on any 2-byte boundary
+  typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(2)));
+  u32x4_u a;
+  __device__ __forceinline__ void load(const void *ws, int64_t idx) {
+    a = *reinterpret_cast<const u32x4_u *>(reinterpret_cast<const uint16_t *>(ws) + idx);
+  }
+  __device__ __forceinline__ float get(int k) const { return glb::trie_upcast<DT>((uint16_t)(a[k >> 1] >> ((k & 1) * 16))); }
+  __device__ __forceinline__ void none() { asm volatile("" : "=v"(a)); }
+};
+
+// The reduction of a swept part.  A node: its children are consecutive in LDS, added one by one in ascending order in
+// double, the node stored as float32 - the arithmetic and the order of part_reduce.  A depth lists the nodes with the most
+// children first, so a wave's nodes have about the same number: the wave takes eight or four children a trip, whatever
+// its widest node needs (reading past a node's last child stays inside the part's LDS - 32 words follow the values - and
+// adds +0, which changes no bit of a sum that started from +0).  OP at compile time: no branch inside a node.
+template <int OP>
+__device__ __forceinline__ void sweep_node(float *val, uint64_t e) {
+  const int s = (int)(e & 0xffffu), c0 = (int)((e >> 16) & 0xffffu), cnt = (int)(e >> 32);
+  double acc = 0.0;
+  for (int base = 0; __any(base < cnt); base += 8) {
+    const float *q = val + c0 + base;
+    const int rem = cnt - base;
+    if (__any(rem > 4)) {
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = q[j];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if constexpr (OP == GLB_TRIE_SUM) acc += (double)(j < rem ? x[j] : 0.0f);
+        else acc = j < rem ? fmax(acc, (double)x[j]) : acc;
+      }
+    } else {
+      float x[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[j] = q[j];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (OP == GLB_TRIE_SUM) acc += (double)(j < rem ? x[j] : 0.0f);
+        else acc = j < rem ? fmax(acc, (double)x[j]) : acc;
+      }
+    }
+  }
+  val[s] = (float)acc;
+}
+
+// depth by depth, deepest internal depth first; trip t of the work list is ent[t] (in registers for the workgroup's life)
+template <int OP, int kNT, int kQ>
+__device__ __forceinline__ void sweep_reduce(float *val, const uint64_t (&ent)[kQ], int dv, int n_depths, int tid, const uint64_t *in64) {
+  constexpr int nt = kNT;
+  int k = n_depths - 2, j = 0;
+#pragma unroll
+  for (int t = 0; t < kQ; ++t) {
+    if (k >= 0) {
+      const int lo = __builtin_amdgcn_readlane(dv, k), hi = __builtin_amdgcn_readlane(dv, k + 1);
+      if (lo + tid + j * nt < hi) {
+        uint64_t e = ent[t];
+        asm volatile("" : "+v"(e));  // (unpacked here, row by row, not hoisted out of the rows' loop into three registers a node)
+        sweep_node<OP>(val, e);
+      }
+      if (lo + (j + 1) * nt < hi) {
+        ++j;
+      } else {
+        --k, j = 0;
+        __syncthreads();
+      }
+    }
+  }
+  while (k >= 0) {  // (a part with more than kQ trips: the rest straight from global memory)
+    const int lo = __builtin_amdgcn_readlane(dv, k), hi = __builtin_amdgcn_readlane(dv, k + 1);
+    for (int i = lo + tid + j * nt; i < hi; i += nt) sweep_node<OP>(val, in64[i]);
+    --k, j = 0;
+    __syncthreads();
+  }
+}
+
+// A PERSISTENT workgroup per (part, lane g of n_lanes): rows g, g + n_lanes, ... .  One workgroup fills a CU (the values
+// of 33 000 slots), so nothing else hides its trips to memory, and with every CU reading at once a row and its table
+// arrive at the chip's rate, 30 GB/s a CU - half a one-row workgroup's life.  What is the same for every row therefore
+// stays in registers for the workgroup's life - the tokens' slots (tok_local16: 4 registers an 8-token unit, kU units a
+// thread: a 50 k row over 1024 threads) and the first kQ trips of the reduction's work list - and the first kX units of
+// the NEXT row are on their way while the current one is reduced and written (128 registers a thread hold no more).
+template <int DT, int kNT, int OUT>
+__global__ __launch_bounds__(kNT) void trie_sweep_kernel(TrieRowsParams p, int n_lanes) {
+  extern __shared__ float val[];
+  const int b = blockIdx.x, xcd = b & 7, q = b >> 3;
+  const int part = q % p.n_parts;
+  const int g = (q / p.n_parts) * 8 + xcd;  // (the parts of a row on the same XCD, side by side in time: the row comes from HBM once)
+  if (g >= n_lanes) return;
+  const PartView v(p.desc + part * kDesc);
+  const int tid = threadIdx.x;
+  constexpr int nt = kNT;
+  constexpr int kU = 7;   // units whose slots a thread keeps in registers
+  constexpr int kX = DT == GLB_F32 ? 0 : 4;  // units of the next row a thread has in flight during the reduction (16-bit rows: 4
+                                             // registers a unit; a float32 row's 8 do not fit next to the slots and the work list)
+  constexpr int kB = 3;                      // units a trip for the rest
+  constexpr int kQ = 12;  // trips of the reduction's work list a thread keeps in registers (33 000 slots, 1024 threads: 11)
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  const uint16_t *tl = p.tok_local16 + (int64_t)part * p.vocab_pad;
+  const int full = p.vocab >> 3;  // units of 8 tokens that lie inside the row
+  // -- what every row shares
+  // the reduction's work list: depth k (deepest internal depth first), trip j -> node lo_k + tid + j * nt of the part's list;
+  // the depth table (<= 31 words) sits in a register, a word a lane, and the walk over (k, j) is scalar
+  const int32_t *gdp = p.idepth + v.d[D_IDEPTH_OFF];
+  const int lane = tid & 63;
+  const int dv = lane <= v.n_depths ? gdp[lane] : 0;
+  const uint64_t *in64 = p.inode64 + v.d[D_INODE_OFF];
+  uint64_t ent[kQ];
+  {
+    int k = v.n_depths - 2, j = 0;
+#pragma unroll
+    for (int t = 0; t < kQ; ++t) {
+      uint64_t e = 0ull;
+      if (k >= 0) {
+        const int lo = __builtin_amdgcn_readlane(dv, k), hi = __builtin_amdgcn_readlane(dv, k + 1);
+        const int i = lo + tid + j * nt;
+        if (i < hi) e = in64[i];
+        if (lo + (j + 1) * nt < hi) ++j;
+        else --k, j = 0;
+      }
+      ent[t] = e;
+    }
+  }
+  u32x4_t tk[kU];
+#pragma unroll
+  for (int j = 0; j < kU; ++j) {
+    const int u = tid + j * nt;
+    tk[j] = u < full ? *reinterpret_cast<const u32x4_t *>(tl + 8 * u) : u32x4_t{0u, 0u, 0u, 0u};  // (never used: guarded by u < full)
+  }
+  // every token is stored: another part's token names a word of the slack behind the values
+  auto put = [&](const u32x4_t &t, const RowVec<DT> &x, float lse) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t loc = (t[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
+      val[loc] = glb::trie_weight_value(x.get(k), p.from_logprobs, p.scale, lse);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // (a unit at a time: scheduled for latency, a trip's 32 weights and addresses take 64 registers)
+  };
+  // -- the rows
+  auto next_row = [&](int r) {  // (per-row selections: a row that asks nothing of this part is skipped)
+    while (r < p.n_rows && p.need && !((p.need[r] >> part) & 1ull)) r += n_lanes;
+    return r;
+  };
+  int r = next_row(g);
+  RowVec<DT> x[kX > 0 ? kX : 1];
+#pragma unroll
+  for (int j = 0; j < kX; ++j) {
+    if (r < p.n_rows && tid + j * nt < full) x[j].load(p.ws, (int64_t)r * p.ld + 8 * (tid + j * nt));
+    else x[j].none();
+  }
+  while (r < p.n_rows) {
+    const float lse = p.lse ? p.lse[r] : 0.0f;
+    const int64_t row = (int64_t)r * p.ld;
+    GLB_DIAG(uint64_t *st = (p.stamps && r < 8192) ? p.stamps + ((int64_t)r * p.n_parts + part) * 8 : nullptr;)
+    GLB_TRIE_STAMP(0)
+    // the units that came ahead go to LDS while the first trip of the others is on its way
+    // (the slots are unpacked here, row by row: hoisted out of the loop they would take two registers a token, not half a one)
+#pragma unroll
+    for (int j0 = kX; j0 < kU; j0 += kB) {
+      RowVec<DT> y[kB];
+#pragma unroll
+      for (int j = j0; j < j0 + kB && j < kU; ++j) {
+        if (tid + j * nt < full) y[j - j0].load(p.ws, row + 8 * (tid + j * nt));
+        else y[j - j0].none();
+      }
+      if (j0 == kX) {
+#pragma unroll
+        for (int j = 0; j < kX; ++j) {
+          if (tid + j * nt < full) {
+            u32x4_t tj = tk[j];
+            asm volatile("" : "+v"(tj));
+            put(tj, x[j], lse);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = j0; j < j0 + kB && j < kU; ++j) {
+        if (tid + j * nt < full) {
+          u32x4_t tj = tk[j];
+          asm volatile("" : "+v"(tj));
+          put(tj, y[j - j0], lse);
+        }
+      }
+    }
+    // ... the rest of a long row, two units a trip, slots and all ...
+    for (int u0 = tid + kU * nt; u0 < full; u0 += nt * 2) {
+      u32x4_t t[2];
+      RowVec<DT> z[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int u = u0 + j * nt;
+        if (u < full) {
+          t[j] = *reinterpret_cast<const u32x4_t *>(tl + 8 * u);
+          z[j].load(p.ws, row + 8 * u);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (u0 + j * nt < full) put(t[j], z[j], lse);
+    }
+    // ... and the last, partial unit element by element: nothing is read past the row
+    const int t_tail = 8 * full + tid;
+    if (t_tail < p.vocab) val[tl[t_tail]] = glb::trie_weight<DT>(p.ws, row + t_tail, p.from_logprobs, p.scale, lse);
+    GLB_TRIE_STAMP(1)
+    // the next row sets out - not before the registers of this one are free
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const int r2 = next_row(r + n_lanes);
+#pragma unroll
+    for (int j = 0; j < kX; ++j) {  // (a register that gets no load gets "any value": it must not stay tied to the row just used)
+      if (r2 < p.n_rows && tid + j * nt < full) x[j].load(p.ws, (int64_t)r2 * p.ld + 8 * (tid + j * nt));
+      else x[j].none();
+    }
+    __syncthreads();
+    GLB_TRIE_STAMP(2)
+    if (p.op == GLB_TRIE_SUM) sweep_reduce<GLB_TRIE_SUM, kNT, kQ>(val, ent, dv, v.n_depths, tid, in64);
+    else sweep_reduce<GLB_TRIE_MAX, kNT, kQ>(val, ent, dv, v.n_depths, tid, in64);
+    GLB_TRIE_STAMP(3)
+    part_write<1, OUT>(p, v, val, false, r, tid, nt);
+    if (p.cut_vals) {
+      float *cv = p.cut_vals + (int64_t)r * p.n_cut + v.d[D_CUT_BASE];
+      const int n_roots = v.d[D_N_ROOTS];
+      for (int i = tid; i < n_roots; i += nt) cv[i] = val[i];
+    }
+    GLB_TRIE_STAMP(4)
+    __syncthreads();  // (the values are read out before the next row lands on them)
+    r = r2;
+  }
+}
+
 // the selected nodes' slots, once per call (the same for every row)
 __global__ void trie_sel_slots_kernel(const int32_t *sel, int32_t n_sel, int64_t n_nodes, const int32_t *slot_of, int32_t *sel_slot) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -331,6 +591,44 @@ hipError_t launch_rows1(const TrieRowsParams &p, int n_top, size_t lds, int thre
   return hipGetLastError();
 }
 
+template <int DT, int kNT, int OUT>
+hipError_t launch_sweep1(const TrieRowsParams &p, int n_top, size_t lds, size_t lds_top, int wg_per_cu, hipStream_t s) {
+  static std::atomic<uint64_t> big_lds{0};
+  if (lds > 64 * 1024) {
+    hipError_t e0 = glb::allow_dynamic_lds((const void *)trie_sweep_kernel<DT, kNT, OUT>, 160 * 1024, big_lds);
+    if (e0 != hipSuccess) return e0;
+  }
+  // as many persistent workgroups as the chip holds at once, shared out over the parts: n_lanes rows in flight
+  static std::atomic<int> n_cus{0};
+  int cus = n_cus.load(std::memory_order_relaxed);
+  if (cus == 0) {
+    int dev = 0;
+    hipError_t e1 = hipGetDevice(&dev);
+    if (e1 == hipSuccess) e1 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e1 != hipSuccess) return e1;
+    if (cus < 8) cus = 8;
+    n_cus.store(cus, std::memory_order_relaxed);
+  }
+  int n_lanes = (cus * wg_per_cu / p.n_parts) & ~7;
+  if (n_lanes < 8) n_lanes = 8;
+  const int rows8 = (p.n_rows + 7) & ~7;
+  if (n_lanes > rows8) n_lanes = rows8;
+  const unsigned blocks = (unsigned)(n_lanes * p.n_parts);
+  hipLaunchKernelGGL((trie_sweep_kernel<DT, kNT, OUT>), dim3(blocks), dim3(kNT), lds, s, p, n_lanes);
+  if (n_top > 0) hipLaunchKernelGGL((trie_rows_kernel<DT, true, 8>), dim3((unsigned)p.n_rows), dim3(256), lds_top, s, p);
+  return hipGetLastError();
+}
+
+// a kernel per kind of output (1 slots, 2 all nodes, 4 selected nodes; several at once: the one that writes them all)
+template <int DT>
+hipError_t launch_sweep(const TrieRowsParams &p, int n_top, size_t lds, size_t lds_top, hipStream_t s) {
+  const int out = (p.out_slots ? 1 : 0) | (p.out_nodes ? 2 : 0) | (p.out_sel ? 4 : 0);
+  if (out == 1) return launch_sweep1<DT, 1024, 1>(p, n_top, lds, lds_top, 1, s);
+  if (out == 2) return launch_sweep1<DT, 1024, 2>(p, n_top, lds, lds_top, 1, s);
+  if (out == 4) return launch_sweep1<DT, 1024, 4>(p, n_top, lds, lds_top, 1, s);
+  return launch_sweep1<DT, 1024, 7>(p, n_top, lds, lds_top, 1, s);
+}
+
 // deep: twelve leaves a thread in flight (73 registers: three 512-thread workgroups a CU, what parts of 9 500 slots allow
 // by their LDS; the leaves of such a part in ONE trip); otherwise eight (53 registers).  Sixteen: 93 registers, two
 // workgroups a CU - 234 against 206 us at 1024 x 50257.
@@ -372,7 +670,11 @@ int glb_trie_rows(const glb_trie_rows_args *a, const glb_trie_plan *pl, void *st
       !pl->idepth || !pl->cptr16 || !pl->inode16 || !pl->leaf_src || !pl->leaf_local || !pl->slot_of)
     return api_fail(GLB_EINVAL, "glb_trie_rows: incomplete plan");
   const size_t lds = (size_t)pl->lds_bytes;
-  if (pl->lds_bytes < pl->max_local * 6 || lds > 160 * 1024 || pl->max_local >= 65536)
+  const bool sweep = pl->tok_local16 != nullptr;  // (a plan for the kernel that reads a row front to back)
+  if (sweep && (!pl->inode64 || pl->vocab != a->vocab || pl->lds_top_bytes < 0 || pl->lds_top_bytes > 64 * 1024 || pl->max_local > 65500))
+    return api_fail(GLB_EINVAL, "glb_trie_rows: sweep plan without inode64, for another vocabulary (%d, rows of %lld), or with a top over 64 KB",
+                    pl->vocab, (long long)a->vocab);
+  if (pl->lds_bytes < pl->max_local * (sweep ? 4 : 6) || lds > 160 * 1024 || pl->max_local >= 65536)
     return api_fail(GLB_EINVAL, "glb_trie_rows: a part of %d slots does not fit the LDS", pl->max_local);
   if (a->out_nodes && (!pl->run_tab || !pl->pn_local16)) return api_fail(GLB_EINVAL, "glb_trie_rows: plan without node lists");
   if (pl->n_top > 0 && !pl->top_local) return api_fail(GLB_EINVAL, "glb_trie_rows: plan without top_local");
@@ -405,6 +707,10 @@ int glb_trie_rows(const glb_trie_rows_args *a, const glb_trie_plan *pl, void *st
   p.run_tab = pl->run_tab;
   p.pn_local16 = pl->pn_local16;
   p.top_local = pl->top_local;
+  p.tok_local16 = pl->tok_local16;
+  p.inode64 = pl->inode64;
+  p.vocab = (int32_t)a->vocab;
+  p.vocab_pad = (int32_t)((a->vocab + 7) & ~(int64_t)7);
   p.top_base = pl->top_base;
   p.n_cut = pl->n_cut;
   p.cut_vals = pl->n_top > 0 ? (float *)a->workspace : nullptr;
@@ -437,6 +743,16 @@ int glb_trie_rows(const glb_trie_rows_args *a, const glb_trie_plan *pl, void *st
   GLB_DIAG(if (const char *ev = getenv("GLB_TRIE_THREADS")) threads = atoi(ev);)
   GLB_DIAG(if (const char *ev = getenv("GLB_TRIE_DEEP")) deep = atoi(ev) != 0;)
   hipError_t e;
+  if (sweep) {
+    const size_t lds_top = (size_t)pl->lds_top_bytes;
+    switch (a->dtype) {
+      case GLB_F32: e = launch_sweep<GLB_F32>(p, pl->n_top, lds, lds_top, s); break;
+      case GLB_BF16: e = launch_sweep<GLB_BF16>(p, pl->n_top, lds, lds_top, s); break;
+      default: e = launch_sweep<GLB_F16>(p, pl->n_top, lds, lds_top, s); break;
+    }
+    if (e != hipSuccess) return glb::api_hip_fail(e, "glb_trie_rows launch");
+    return GLB_OK;
+  }
   switch (a->dtype) {
     case GLB_F32: e = launch_rows<GLB_F32>(p, pl->n_top, lds, threads, deep, s); break;
     case GLB_BF16: e = launch_rows<GLB_BF16>(p, pl->n_top, lds, threads, deep, s); break;

@@ -715,13 +715,16 @@ class HipEngine:
         pitch = (B + 63) // 64 * 64
         return self._trie_ws[: n_nodes * pitch * 4].view(torch.float32).view(n_nodes, pitch)
 
-    def trie_rows(self, ws, plan, op=0, from_logprobs=False, lse=None, logit_scale=1.0, nodes=None, layout="rows", out=None):
+    def trie_rows(self, ws, plan, op=0, from_logprobs=False, lse=None, logit_scale=1.0, nodes=None, layout="rows", out=None,
+                  out_slots=None):
         """Token -> byte trie masses with one row of a part of the trie resident in LDS (glb_trie_rows): the weights are
         read once, the result written once, row-major.  plan: `TokenByteTrie.plan_device_arrays()`.  ws as in
         `trie_masses`.  Result: layout "rows" float32 [B, n_nodes]; nodes given (int32 device tensor) [B, len(nodes)] - or,
         `nodes` int32 [B, K], every row's OWN nodes (negative: none, 0 out): only the parts of the trie that hold a row's
         nodes are read and reduced for that row;
-        layout "slots" [B, n_slots] in the plan's slot numbering (plan["slot_of"]: node -> slot)."""
+        layout "slots" [B, n_slots] in the plan's slot numbering (plan["slot_of"]: node -> slot).  out_slots: float32
+        [B, n_slots] to be filled with the slots IN ADDITION to the requested output (one call, the C entry point's several
+        outputs at once)."""
         if ws.dim() != 2 or ws.stride(1) != 1 or ws.dtype not in _DT:
             raise ValueError("weights must be [B, V] float32 / bfloat16 / float16 with unit inner stride")
         B = ws.shape[0]
@@ -735,6 +738,9 @@ class HipEngine:
                 setattr(pl, k, int(plan[k]))
             for k in ("desc", "idepth", "leaf_src", "leaf_local", "run_tab", "top_local", "slot_of", "cptr16", "inode16", "pn_local16"):
                 setattr(pl, k, plan[k].data_ptr())
+            if plan.get("sweep"):  # (the kernel that reads a row front to back: TokenByteTrie.plan(sweep=True))
+                pl.tok_local16, pl.inode64 = plan["tok_local16"].data_ptr(), plan["inode64"].data_ptr()
+                pl.lds_top_bytes, pl.vocab = int(plan["lds_top_bytes"]), int(plan["vocab"])
             plan["_c"] = pl
         a = TrieRowsArgs()
         a.struct_size = C.sizeof(TrieRowsArgs)
@@ -774,6 +780,11 @@ class HipEngine:
             a.out_nodes, a.out_nodes_ld = out.data_ptr(), out.stride(0)
         else:
             a.out_slots, a.out_slots_ld = out.data_ptr(), out.stride(0)
+        if out_slots is not None:
+            if out_slots.shape != (B, plan["n_slots"]) or out_slots.dtype != torch.float32 or out_slots.stride(1) != 1:
+                raise ValueError(f"out_slots must be float32 [{B}, {plan['n_slots']}] with unit inner stride")
+            self._check_dev(out_slots)
+            a.out_slots, a.out_slots_ld = out_slots.data_ptr(), out_slots.stride(0)
         check(self.lib.glb_trie_rows(C.byref(a), C.byref(pl), self._stream()))
         return out
 

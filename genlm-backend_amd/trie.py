@@ -88,8 +88,8 @@ class TokenByteTrie:
         self._dev = None
         self._compact = None
         self._cdev = None
-        self._plan = None
-        self._pdev = None
+        self._plans = {}
+        self._pdevs = {}
         self._tree_cache = None
         self._sel_plans = {}
 
@@ -162,7 +162,16 @@ class TokenByteTrie:
     PLAN_CAP = 9500  # slots per part: ~6.5 bytes of LDS a slot (value, child pointer, list of internal nodes); three 512-thread workgroups a CU
     # (tools/dbg/stamps_trie.py at 1024 x 50257: parts of <= 5267 / 7875 / 10481 / 23440 slots: 232 / 206 / 225 / 225 us)
 
-    def plan(self, cap=None):
+    SWEEP_LOCAL_MAX = 40000  # slots per part of a sweep plan: 4 bytes of LDS a slot, one 1024-thread workgroup a CU (160 KB)
+
+    def sweep_cap(self):
+        """Slots per part for `plan(sweep=True)`: as few parts as the LDS allows (every part reads the whole row once), of
+        about equal size."""
+        n_slots = int(self.compact()["n_nodes"])
+        n_parts = max(1, -(-n_slots // (self.SWEEP_LOCAL_MAX - 2000)))
+        return min(self.SWEEP_LOCAL_MAX, -(-n_slots * 21 // (n_parts * 20)) + 64)
+
+    def plan(self, cap=None, sweep=False):
         """The folded trie (`compact()`) cut for glb_trie_rows, which keeps ONE ROW's values of a part of the trie in
         the LDS of a compute unit: subtrees of at most `cap` slots are packed into parts of at most `cap` slots; the few
         nodes above them (the root and what else is too big - `top`) form one more part whose leaves are the cut
@@ -171,13 +180,18 @@ class TokenByteTrie:
         and a depth is a range `depth_start[d] .. depth_start[d + 1]`; every sum still adds the same numbers in the same
         order as the reference's loop (base.py:346-393).  Slots are renumbered part by part (`slot_of`: node -> new
         slot; the top's nodes come last), so a part's values are one run of a row of the slot-major output.
-        Returns None when the top does not fit a part (a trie with a node of more than `cap` children)."""
-        cap = int(cap or self.PLAN_CAP)
-        if self._plan is not None and self._plan[0] == cap:
-            return self._plan[1]
-        plan = self._build_plan(cap, None)
-        self._plan = (cap, plan)
-        return plan
+        Returns None when the top does not fit a part (a trie with a node of more than `cap` children).
+        sweep=True: the plan of the kernel that reads a row front to back instead of gathering a part's tokens from it
+        (round 5): parts as big as the LDS holds when only the VALUES live there (`sweep_cap`), and two more tables -
+        `tok_local16[part, token]` (the token's local slot in that part; another part's token: one of the 32 slack words behind
+        the part's values, n_local + (token // 8) % 32; rows padded to 8 tokens)
+        and `inode64` (a part's internal nodes depth by depth as `inode16` lists them: slot | first child << 16 |
+        children << 32), which the kernel streams from global memory."""
+        cap = int(cap or (self.sweep_cap() if sweep else self.PLAN_CAP))
+        key = (cap, bool(sweep))
+        if key not in self._plans:
+            self._plans[key] = self._build_plan(cap, None, sweep=sweep)
+        return self._plans[key]
 
     def _tree(self):
         """The folded trie as Python sees it: children of every slot, subtree sizes, the root's slot."""
@@ -193,7 +207,7 @@ class TokenByteTrie:
             self._tree_cache = (kids, size, int(c["slot_of"][self.root]))
         return self._tree_cache
 
-    def _build_plan(self, cap, sel_roots):
+    def _build_plan(self, cap, sel_roots, sweep=False):
         """`plan()` for the forest below `sel_roots` (folded-trie slots, none an ancestor of another; None: the whole trie):
         only those subtrees are cut into parts, read and reduced - what the masses of a SELECTION of nodes need (the
         selection's maximal nodes are the roots).  Slots outside the forest get slot -1."""
@@ -323,8 +337,8 @@ class TokenByteTrie:
         # what the kernel keeps in LDS next to the values, as 16-bit words (a part has fewer than 65536 slots): the child
         # pointers, and the part's internal nodes depth by depth (within a depth the nodes with the most children first:
         # the lanes of a wave then run loops of about the same length)
-        cptr16, inode16, idepth = [], [], []
-        lds_bytes = 0
+        cptr16, inode16, idepth, inode64 = [], [], [], []
+        lds_bytes = lds_top = 0
         for p in range(len(cptr_all)):
             cp = np.asarray(cptr_all[p], np.int64)
             ds = np.asarray(depth_all[p], np.int64)
@@ -340,12 +354,30 @@ class TokenByteTrie:
             ins = np.concatenate(ins) if ins else np.zeros(0, np.int64)
             desc[p, 11], desc[p, 12], desc[p, 13] = sum(len(x) for x in inode16), len(ins), sum(len(x) for x in idepth)
             inode16.append(np.concatenate([ins, np.zeros(len(ins) & 1, np.int64)]))
+            inode64.append(np.concatenate([ins | (cp[ins] << 16) | (nch[ins] << 32), np.zeros(len(ins) & 1, np.int64)]))
             idepth.append(idp)
             if len(idp) > 31:  # (the kernel keeps a part's depth table in 32 words of LDS)
                 return None
-            lds_bytes = max(lds_bytes, 4 * int(desc[p, 1]) + 2 * len(cptr16[-1]) + 2 * len(inode16[-1]) + 4 * 32)
+            resident = 4 * int(desc[p, 1]) + 2 * len(cptr16[-1]) + 2 * len(inode16[-1]) + 4 * 32
+            if sweep and p < n_parts:  # (a swept part keeps its values and 32 words of slack)
+                lds_bytes = max(lds_bytes, 4 * int(desc[p, 1]) + 4 * 32)
+            else:
+                lds_bytes = max(lds_bytes, resident)
+            if p == n_parts:
+                lds_top = resident
         cat16 = lambda xs: np.concatenate(list(xs) + [np.zeros(2, np.int64)]).astype(np.uint16)  # (never empty: a device pointer)
-        plan = dict(n_parts=n_parts, n_top=n_top, n_slots=n_slots if sel_roots is None else slot_base + n_top, n_cut=len(cut), cap=cap,
+        extra = {}
+        if sweep and lds_bytes > 160 * 1024:
+            return None
+        if sweep:
+            V = len(self.decode)
+            vp = (V + 7) & ~7
+            tl = np.zeros((max(n_parts, 1), vp), np.uint16)
+            for p in range(n_parts):  # (another part's token: a word of the 32-word slack behind the values - the kernel stores every token)
+                tl[p] = (int(desc[p, 1]) + ((np.arange(vp) >> 3) & 31)).astype(np.uint16)
+                tl[p, leaf_src[p]] = np.asarray(leaf_local[p], np.int64).astype(np.uint16)
+            extra = dict(tok_local16=tl.reshape(-1), inode64=np.concatenate(inode64 + [np.zeros(2, np.int64)]).astype(np.uint64))
+        plan = dict(n_parts=n_parts, n_top=n_top, sweep=bool(sweep), lds_top_bytes=lds_top, **extra, n_slots=n_slots if sel_roots is None else slot_base + n_top, n_cut=len(cut), cap=cap,
                     vocab=len(self.decode),
                     n_nodes=len(self.children), max_local=int(desc[:, 1].max()), top_base=slot_base,
                     lds_bytes=lds_bytes, cptr16=cat16(cptr16), inode16=cat16(inode16), idepth=cat(idepth),
@@ -387,19 +419,20 @@ class TokenByteTrie:
             ent = self._sel_plans[key] = (pl, nodes)  # (holds the tensor: its address cannot be handed to another selection)
         return ent[0]
 
-    def plan_device_arrays(self, cap=None):
+    def plan_device_arrays(self, cap=None, sweep=False):
         """`plan()` on the device (None when the trie has no usable plan)."""
-        pl = self.plan(cap)
+        pl = self.plan(cap, sweep=sweep)
         if pl is None:
             return None
-        if self._pdev is None or self._pdev[0] != pl["cap"]:
+        key = (pl["cap"], bool(sweep))
+        if key not in self._pdevs:
             if self.engine is None:
                 raise RuntimeError("TokenByteTrie needs a HipEngine to compute masses (there is no CPU path)")
             dev = self.engine.device
             signed = {np.dtype(np.uint16): np.int16, np.dtype(np.uint32): np.int32, np.dtype(np.uint64): np.int64}
-            self._pdev = (pl["cap"], {k: (torch.from_numpy(v.view(signed.get(v.dtype, v.dtype))).to(dev)
-                                          if isinstance(v, np.ndarray) else v) for k, v in pl.items()})
-        return self._pdev[1]
+            self._pdevs[key] = {k: (torch.from_numpy(v.view(signed.get(v.dtype, v.dtype))).to(dev)
+                                    if isinstance(v, np.ndarray) else v) for k, v in pl.items()}
+        return self._pdevs[key]
 
     def _to_device(self, f):
         if self.engine is None:
@@ -434,11 +467,15 @@ class TokenByteTrie:
     _COMPACT_ROWS = 32  # from here on the kernels keep the values node-major: the folded trie pays
 
     prune_selection = True  # masses of selected nodes: plan only the sub-forest below them (selection_plan)
+    sweep = True  # whole-trie masses through the plan whose parts read a row front to back (plan(sweep=True)): the slots always
+    # (their numbering is that plan's: `slot_plan()`), all nodes from SWEEP_MIN_ROWS rows on (below, the gathered plan's
+    # many small workgroups fill the chip better: 1 row 18 against 30 us)
+    SWEEP_MIN_ROWS = 128
     resident = True  # glb_trie_rows (a row of a part of the trie in LDS) when the trie has a plan; False: the level-synchronous kernels
 
     def _batch(self, ws, op, from_logprobs):
         ws = self._rows(ws)
-        pl = self.plan_device_arrays() if self.resident else None
+        pl = self._whole_plan_device(ws.shape[0]) if self.resident else None
         if pl is not None:
             got = self._trie_rows(ws, pl, op, from_logprobs)
             if got is not None:
@@ -447,6 +484,20 @@ class TokenByteTrie:
             return self.engine.trie_reduce(ws, self.device_arrays(), op, from_logprobs)
         c = self.compact_device_arrays()
         return self.engine.trie_masses(ws, c, op, from_logprobs, nodes=c["slot_of"])
+
+    def slot_plan(self):
+        """The plan whose slot numbering layout "slot_rows" uses (`["slot_of"]`: node -> column): the sweep plan when the
+        trie has one and `sweep` is on, else `plan()`."""
+        return (self.plan(sweep=True) if self.sweep else None) or self.plan()
+
+    def _whole_plan_device(self, n_rows, slots=False):
+        """The device plan for masses of the whole trie: the sweep plan for the slots (one numbering whatever the batch) and
+        for big batches, the gathered plan otherwise."""
+        if self.sweep and (slots or n_rows >= self.SWEEP_MIN_ROWS):
+            pl = self.plan_device_arrays(sweep=True)
+            if pl is not None:
+                return pl
+        return self.plan_device_arrays()
 
     def _trie_rows(self, ws, pl, *args, **kw):
         """glb_trie_rows, or None when the device cannot run it (a part of the plan needs more LDS than the device has - a
@@ -477,14 +528,16 @@ class TokenByteTrie:
         OWN nodes, e.g. each particle's current node's children (negative entries: none), [B, K]; layout "slots": node-major [n_slots, pitch] over the folded trie (`compact()`: the value of node
         n for row r is at [slot_of[n], r] - nothing is transposed back); layout "nodes": the same over all nodes,
         [n_nodes, pitch] (see HipEngine.trie_masses); layout "slot_rows": row-major [B, n_slots] over the plan's slots
-        (`plan()["slot_of"]`: node -> slot) - the cheapest form: the logits are read once and nothing else is written."""
+        (`slot_plan()["slot_of"]`: node -> slot) - the cheapest form: the logits are read once and nothing else is written."""
         if logits.shape[1] < len(self.decode):
             raise ValueError(f"logits rows have {logits.shape[1]} columns, vocabulary has {len(self.decode)}")
         if lse is None:  # (one more reading of the rows: hand the fused step's lse over when there is one)
             lse = self.engine.row_lse(logits, vocab=len(self.decode), logit_scale=logit_scale)
         if nodes is not None and nodes.dtype != torch.int32:
             raise TypeError("nodes must be int32")
-        pl = self.plan_device_arrays() if self.resident and (layout in ("rows", "slot_rows")) else None
+        pl = None
+        if self.resident and layout in ("rows", "slot_rows"):
+            pl = self._whole_plan_device(logits.shape[0], slots=layout == "slot_rows") if nodes is None else self.plan_device_arrays()
         if pl is not None and nodes is not None and nodes.dim() == 1 and layout == "rows" and self.prune_selection:
             # only the subtrees below the selected nodes are read and reduced (a plan of that sub-forest, cached per selection)
             pl = self.selection_plan(nodes) or pl

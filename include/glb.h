@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GLB_ABI_VERSION 7
+#define GLB_ABI_VERSION 8
 
 /* status codes */
 enum {
@@ -521,6 +521,20 @@ typedef struct glb_trie_plan {
   int64_t n_nodes;
   const int32_t *desc, *idepth, *leaf_src, *leaf_local, *run_tab, *top_local, *slot_of;
   const uint16_t *cptr16, *inode16, *pn_local16;
+  /* ABI 8 - a SWEEP plan (tok_local16 non-null; TokenByteTrie.plan(sweep=True)): a (row, part) workgroup reads the whole
+   * row front to back instead of gathering the part's tokens; a persistent workgroup keeps a part's values in LDS
+   * (lds_bytes >= 4 * max_local + 128: parts of up to 40 000 slots), the tokens' slots and the part's internal nodes in
+   * registers, and has the head of the next row on its way while it reduces and writes the current one:
+   *   tok_local16 [n_parts][(vocab + 7) & ~7]: token -> its local slot in that part; another part's token -> a word of the
+   *            32-word slack behind the part's values, n_local + (token / 8) % 32 (the kernel stores every token's weight);
+   *   inode64: per part at desc[D_INODE_OFF], the part's internal nodes as inode16 lists them (depth by depth):
+   *            local slot | first child << 16 | number of children << 32;
+   *   lds_top_bytes: the LDS of the launch over the top (its values and 16-bit tables, as for a gathered part);
+   *   vocab: the vocabulary tok_local16 was made for (glb_trie_rows_args.vocab must equal it).
+   * All null / 0: the gathered plan of rounds 4-5. */
+  const uint16_t *tok_local16;
+  const uint64_t *inode64;
+  int32_t lds_top_bytes, vocab;
 } glb_trie_plan;
 typedef struct glb_trie_rows_args {
   uint32_t struct_size;  /* sizeof(glb_trie_rows_args) - ABI guard */

@@ -817,7 +817,7 @@ def test_trie_rows_in_lds_equal_the_level_kernels_and_the_oracle(engine, oracle,
             assert torch.equal(trie.masses_from_logits(xd, lse, nodes=sel), rows[:, sel.long()])
             sl = trie.masses_from_logits(xd, lse, layout="slot_rows")
             assert sl.shape == (B, pl["n_slots"])
-            assert torch.equal(sl[:, trie.plan_device_arrays()["slot_of"].long()], rows)
+            assert torch.equal(sl[:, torch.from_numpy(trie.slot_plan()["slot_of"].astype(np.int64)).to(dev)], rows)
             half = trie.masses_from_logits(xd, lse, logit_scale=0.5)
             assert torch.equal(half, old.masses_from_logits(xd, lse, logit_scale=0.5))
             own = trie.masses_from_logits(xd[:, :V].contiguous(), logit_scale=0.5)  # lse computed by the call itself (row_lse)
@@ -920,6 +920,89 @@ def test_per_row_selections_read_only_the_parts_a_row_needs(engine, cap):
         trie.masses_from_logits(xd, lse, nodes=torch.from_numpy(sel[:5]).to(dev))
 
 
+@pytest.mark.parametrize("cap", [300, 2000, None])
+def test_trie_sweep_kernel_equals_the_gathered_one_and_the_oracle(engine, oracle, cap):
+    """glb_trie_rows on a SWEEP plan (round 5: a persistent workgroup per part reads row after row front to back, the tokens'
+    slots and the part's internal nodes in registers): the bits of the gathered plan and of the oracle - several parts and a
+    top (small caps) or one part, 1 / 5 / 130 / 300 rows (more rows than persistent lanes: a workgroup takes several), every
+    element type, sums and maxima, weights with an odd pitch, all nodes / slots / one selection / a selection per row (rows
+    that ask nothing of a part skip it) / two outputs at once."""
+    from genlm_backend_amd.tokenization import Token
+    from genlm_backend_amd.trie import TokenByteTrie
+
+    rs = np.random.default_rng(23)
+    words, seen = [], set()
+    while len(words) < 3001:
+        w = bytes(rs.integers(97, 102, int(rs.integers(1, 7))).astype(np.uint8))
+        if w not in seen:
+            seen.add(w)
+            words.append(w)
+    trie = TokenByteTrie([Token(i, w) for i, w in enumerate(words)], engine=engine)
+    V, nn, dev = len(words), len(trie), engine.device
+    sw = trie.plan_device_arrays(cap, sweep=True)
+    ga = trie.plan_device_arrays()
+    host = trie.plan(cap, sweep=True)
+    assert sw is not None and sw["sweep"] and (host["n_parts"] > 1) == (cap is not None) and (host["n_top"] > 0) == (cap is not None)
+    slot_of = sw["slot_of"].long()
+    for B in (1, 5, 130, 300):
+        w = rs.random((B, V + 3)).astype(np.float32)
+        wd = torch.from_numpy(w).to(dev)[:, :V]  # (pitch V + 3: rows start on any word)
+        for op in (0, 1):
+            got = engine.trie_rows(wd, sw, op, False)
+            assert np.array_equal(got.cpu().numpy().view(np.uint32), oracle.trie_reduce(w[:, :V].copy(), trie.flat(), op).view(np.uint32)), (B, op)
+        x = rs.standard_normal((B, V)).astype(np.float32) * 3
+        for dt in (torch.float32, torch.bfloat16, torch.float16):
+            xd = torch.from_numpy(x).to(dev).to(dt)
+            _, lse, _ = engine.step(xd, vocab=V, rng_mode=0)
+            rows = engine.trie_rows(xd, ga, 0, True, lse=lse)
+            assert torch.equal(engine.trie_rows(xd, sw, 0, True, lse=lse), rows)
+            assert torch.equal(engine.trie_rows(xd, sw, 0, True, lse=lse, logit_scale=0.5), engine.trie_rows(xd, ga, 0, True, lse=lse, logit_scale=0.5))
+            sl = engine.trie_rows(xd, sw, 0, True, lse=lse, layout="slots")
+            assert sl.shape == (B, host["n_slots"]) and torch.equal(sl[:, slot_of], rows)
+            sel = torch.from_numpy(rs.choice(nn, 77, replace=True).astype(np.int32)).to(dev)
+            both = torch.full((B, host["n_slots"]), -1.0, device=dev)
+            assert torch.equal(engine.trie_rows(xd, sw, 0, True, lse=lse, nodes=sel, out_slots=both), rows[:, sel.long()])
+            assert torch.equal(both, sl)
+            # a selection per row: the children of one of the root's children, or nothing
+            d1 = sorted(trie.children[trie.root].values())
+            K = max(len(trie.jump[c]) for c in d1)
+            rowsel = np.full((B, K), -1, np.int32)
+            for r in range(B):
+                if r % 7 != 3:
+                    c = d1[int(rs.integers(0, len(d1)))]
+                    rowsel[r, :len(trie.jump[c])] = trie.jump[c]
+            rsd = torch.from_numpy(rowsel).to(dev)
+            got = engine.trie_rows(xd, sw, 0, True, lse=lse, nodes=rsd)
+            want = torch.where(rsd >= 0, torch.gather(rows, 1, rsd.clamp(min=0).long()), torch.zeros((), device=dev))
+            assert torch.equal(got, want)
+
+
+def test_trie_sweep_kernel_on_deep_and_tiny_tries(engine, oracle):
+    """Words of up to 24 letters over two symbols: more depths than the reduction's work list holds trips in registers (the
+    rest comes straight from global memory); and the degenerate vocabularies (one token, one chain, two leaves)."""
+    from genlm_backend_amd.tokenization import Token
+    from genlm_backend_amd.trie import TokenByteTrie
+
+    rs = np.random.default_rng(29)
+    words, seen = [], set()
+    while len(words) < 4000:
+        w = bytes(rs.integers(97, 99, int(rs.integers(1, 25))).astype(np.uint8))
+        if w not in seen:
+            seen.add(w)
+            words.append(w)
+    for vocab in (words, [b"a"], [b"abc"], [b"a", b"b"], [b"a", b"ab", b"abc"]):
+        trie = TokenByteTrie([Token(i, w) for i, w in enumerate(vocab)], engine=engine)
+        sw = trie.plan_device_arrays(sweep=True)
+        assert sw is not None
+        if len(vocab) > 10:
+            assert int(trie.plan(sweep=True)["desc"][0, 3]) > 14  # (depths of part 0)
+        ws = rs.random((9, len(vocab))).astype(np.float32)
+        for op in (0, 1):
+            got = engine.trie_rows(torch.from_numpy(ws).to(engine.device), sw, op, False).cpu().numpy()
+            assert np.array_equal(got.view(np.uint32), oracle.trie_reduce(ws, trie.flat(), op).view(np.uint32))
+
+
+
 def test_trie_rows_on_degenerate_vocabularies(engine, oracle):
     """One token, one chain, two leaves under the root: the plan has one part of one to five slots and no top."""
     from genlm_backend_amd.tokenization import Token
@@ -962,6 +1045,14 @@ def test_trie_rows_at_llama_vocabulary_size(engine, oracle):
     sel = torch.from_numpy(rs.choice(len(trie), 1000, replace=False).astype(np.int32)).to(dev)
     assert torch.equal(trie.masses_from_logits(x, lse, nodes=sel), rows[:, sel.long()])
     assert (rows[:, trie.root] - 1.0).abs().max().item() < 1e-3  # (bf16 logits against a float32 lse of the same values)
+    # the sweep plan (round 5): 5 parts of <= 40 000 slots, a row longer than what a thread keeps in registers
+    sw = trie.plan_device_arrays(sweep=True)
+    assert sw is not None and 4 <= trie.plan(sweep=True)["n_parts"] <= 6
+    assert torch.equal(engine.trie_rows(x, sw, 0, True, lse=lse), rows)
+    sl = trie.masses_from_logits(x, lse, layout="slot_rows")
+    assert torch.equal(sl[:, sw["slot_of"].long()], rows)
+    big = torch.cat([x] * 4)[:150]  # (from SWEEP_MIN_ROWS rows on, the rows go through the sweep plan too)
+    assert torch.equal(trie.masses_from_logits(big, torch.cat([lse] * 4)[:150]), torch.cat([rows] * 4)[:150])
 
 
 def test_async_trie_batches_concurrent_requests(engine, oracle):

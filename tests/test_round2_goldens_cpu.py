@@ -285,10 +285,31 @@ def _run_plan(pl, ws, op, sel_nodes=None):
         src, loc = pl["leaf_src"][d[6]:d[6] + d[7]], pl["leaf_local"][d[6]:d[6] + d[7]]
         assert ds[0] == 0 and ds[-1] == n_local and cp[-1] == n_local and (np.diff(cp) >= 0).all()
         assert idp[0] == 0 and idp[-1] == len(ins) == int((np.diff(cp) > 0).sum()) and len(set(ins)) == len(ins)
-        assert pl["lds_bytes"] >= 4 * n_local + 2 * (n_local + 1) + 2 * len(ins) + 4 * (n_depths + 1) and n_depths <= 30
+        swept = bool(pl.get("sweep")) and not top  # (the kernel that reads a row front to back: round 5)
+        if swept:
+            # its tables say what the gathered plan's do: every token has a slot (its own, or a word of the 32-word slack behind
+            # the values), the internal nodes are inode16's with their children's range
+            V = pl["vocab"]
+            vp = (V + 7) & ~7
+            tl = pl["tok_local16"][p * vp:(p + 1) * vp].astype(np.int64)
+            mine = np.zeros(vp, bool)
+            mine[src] = True
+            assert np.array_equal(tl[src], loc) and ((tl[~mine] >= n_local) & (tl[~mine] < n_local + 32)).all()
+            e = pl["inode64"][d[11]:d[11] + d[12]].astype(np.uint64)
+            assert np.array_equal((e & np.uint64(0xffff)).astype(np.int64), ins)
+            assert np.array_equal(((e >> np.uint64(16)) & np.uint64(0xffff)).astype(np.int64), cp[ins])
+            assert np.array_equal((e >> np.uint64(32)).astype(np.int64), cp[ins + 1] - cp[ins])
+            assert 4 * n_local + 128 <= pl["lds_bytes"] <= 160 * 1024 and n_depths <= 30 and n_local + 32 < 65536
+        else:
+            assert pl["lds_bytes" if not (top and pl.get("sweep")) else "lds_top_bytes"] >= 4 * n_local + 2 * (n_local + 1) + 2 * len(ins) + 4 * (n_depths + 1) and n_depths <= 30
         for r in range(B):
-            val = np.full(n_local, np.nan, np.float32)
-            val[loc] = cut[r, src] if top else ws[r, src]
+            if swept:
+                val = np.full(n_local + 32, np.nan, np.float32)
+                val[tl[:V]] = ws[r, :V]  # (every token is stored)
+                val = val[:n_local]
+            else:
+                val = np.full(n_local, np.nan, np.float32)
+                val[loc] = cut[r, src] if top else ws[r, src]
             for k in range(n_depths - 2, -1, -1):
                 for s in ins[idp[k]:idp[k + 1]]:
                     assert ds[k] <= s < ds[k + 1] and cp[s] >= ds[k + 1] and cp[s + 1] <= ds[k + 2]  # children sit one depth down
@@ -389,3 +410,10 @@ def test_trie_plan_gives_the_reference_masses(gold, oracle, cap):
         for op in (0, 1):
             got = _run_plan(pl, ws, op)
             assert np.array_equal(got.view(np.uint32), oracle.trie_reduce(ws, trie.flat(), op).view(np.uint32))
+        # the same cut for the kernel that reads a row front to back (round 5): its two tables restate the gathered plan's
+        sw = trie.plan(cap, sweep=True)
+        assert sw is not None and sw["sweep"] and sw["n_parts"] == pl["n_parts"] and np.array_equal(sw["slot_of"], pl["slot_of"])
+        for op in (0, 1):
+            got = _run_plan(sw, ws, op)
+            assert np.array_equal(got.view(np.uint32), oracle.trie_reduce(ws, trie.flat(), op).view(np.uint32))
+        assert trie.slot_plan() is trie.plan(sweep=True) and trie.plan(sweep=True)["n_parts"] == 1  # (small tries: one part, no top)

@@ -31,7 +31,10 @@ while len(words) < 50257:
 trie = TokenByteTrie([Token(i, w) for i, w in enumerate(words)], engine=eng)
 if os.environ.get("GLB_TRIE_CAP"):
     trie.PLAN_CAP = int(os.environ["GLB_TRIE_CAP"])
-pl = trie.plan()
+trie.sweep = os.environ.get("GLB_TRIE_SWEEP", "0") == "1"
+if trie.sweep and os.environ.get("GLB_TRIE_CAP"):
+    trie.sweep_cap = lambda: int(os.environ["GLB_TRIE_CAP"])
+pl = trie.plan(sweep=trie.sweep)
 x = torch.randn((B, len(words)), device=dev) * 3
 _, lse, _ = eng.step(x, rng_mode=0)
 for i in range(6):
@@ -39,7 +42,7 @@ for i in range(6):
         eng._trie_ws.zero_()  # (only the workgroups of the last call leave stamps)
     trie.masses_from_logits(x, lse, layout=layout)
 torch.cuda.synchronize()
-n_blocks = min(65536, (B + 7) // 8 * 8 * pl["n_parts"])
+n_blocks = min(65536, (B + 7) // 8 * 8 * pl["n_parts"]) if not trie.sweep else min(8192, B) * pl["n_parts"]  # (sweep: a record per (row, part))
 cut = 0 if pl["n_top"] == 0 else (B * pl["n_cut"] * 4 + 255) // 256 * 256
 st = eng._trie_ws[cut: cut + n_blocks * 64].view(torch.int64).view(n_blocks, 8).cpu().numpy()
 st = st[st[:, 0] > 0]
@@ -48,5 +51,9 @@ seg = np.diff(t, axis=1)
 print(f"{layout} B={B}: {pl['n_parts']} parts of <= {pl['max_local']} slots; {len(st)} workgroups, last one done at {t[:, 4].max():.1f} us")
 for name, col in zip(["start -> leaves in flight", "-> leaves in LDS (barrier)", "-> reduced", "-> written"], seg.T):
     print(f"  {name:32s} mean {col.mean():6.2f}  p10 {np.percentile(col, 10):6.2f}  p90 {np.percentile(col, 90):6.2f}  max {col.max():6.2f} us")
+if trie.sweep:
+    d = (st[:, 5:8] - st[:, 2:3]) / 100.0
+    print("  after the barrier, the three deepest internal depths done at", " / ".join(f"{x:.2f}" for x in d.mean(0)), "us")
+    print("  internal nodes per depth of part 0:", np.diff(pl["idepth"][:pl["desc"][0, 3] + 1]).tolist())
 life = t[:, 4] - t[:, 0]
 print(f"  workgroup lifetime mean {life.mean():.2f} us; resident on average {life.sum() / t[:, 4].max():.0f} workgroups")

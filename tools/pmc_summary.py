@@ -110,7 +110,8 @@ for out_kind in ("rows", "slots", "selected", "rowsel", "rowsel-root"):
                 if row.get("Counter_Name") != tag or "trie_" not in row["Kernel_Name"]:
                     continue
                 tot += float(row["Counter_Value"])
-                if "trie_rows_kernel" in row["Kernel_Name"] and ", false," in row["Kernel_Name"].replace("<", ", ").replace(">", ","):
+                if "trie_sweep_kernel" in row["Kernel_Name"] or (
+                        "trie_rows_kernel" in row["Kernel_Name"] and ", false," in row["Kernel_Name"].replace("<", ", ").replace(">", ",")):
                     calls += 1  # (one launch over the parts per call; the top, when the plan has one, is a second launch)
         per_tag[tag] = (tot, calls)
     if len(per_tag) == 2:
@@ -127,7 +128,7 @@ for f in sorted(glob.glob(os.path.join(root, "pmc_req_trie*", "**", "*counter_co
     agg = {}
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            if "trie_rows_kernel" not in row["Kernel_Name"]:
+            if "trie_rows_kernel" not in row["Kernel_Name"] and "trie_sweep_kernel" not in row["Kernel_Name"]:
                 continue
             k = row["Counter_Name"]
             agg.setdefault(k, []).append(float(row["Counter_Value"]))
