@@ -393,7 +393,7 @@ __device__ __forceinline__ void sweep_reduce(float *val, const uint64_t (&ent)[k
 // thread: a 50 k row over 1024 threads) and the first kQ trips of the reduction's work list - and the first kX units of
 // the NEXT row are on their way while the current one is reduced and written (128 registers a thread hold no more).
 template <int DT, int kNT, int OUT>
-__global__ __launch_bounds__(kNT) void trie_sweep_kernel(TrieRowsParams p, int n_lanes) {
+__global__ __launch_bounds__(kNT) void trie_sweep_kernel(TrieRowsParams p, int n_lanes, int stagger) {
   extern __shared__ float val[];
   const int b = blockIdx.x, xcd = b & 7, q = b >> 3;
   const int part = q % p.n_parts;
@@ -454,6 +454,12 @@ __global__ __launch_bounds__(kNT) void trie_sweep_kernel(TrieRowsParams p, int n
     return r;
   };
   int r = next_row(g);
+  // Every workgroup starts at once and takes the same time a row, so all of them would read at the same time and reduce at
+  // the same time: the reads at 30 GB/s a CU (the chip's rate over 256), the memory idle in between.  Every other group of
+  // eight lanes therefore waits half a row's time after its first row (once; `stagger`: the host asks for it when a lane
+  // has rows enough to win it back): from then on half the chip reads while the other half reduces - 50 GB/s a CU.
+  bool wait_half = stagger && ((g >> 3) & 1);
+  const uint64_t t_first = __builtin_amdgcn_s_memrealtime();
   RowVec<DT> x[kX > 0 ? kX : 1];
 #pragma unroll
   for (int j = 0; j < kX; ++j) {
@@ -536,6 +542,13 @@ __global__ __launch_bounds__(kNT) void trie_sweep_kernel(TrieRowsParams p, int n
     }
     GLB_TRIE_STAMP(4)
     __syncthreads();  // (the values are read out before the next row lands on them)
+    if (wait_half) {
+      wait_half = false;
+      const uint64_t now = __builtin_amdgcn_s_memrealtime();
+      uint64_t half = (now - t_first) >> 1;
+      if (half > 2000) half = 2000;  // (20 us at 100 MHz: never a long wait, whatever the clock read)
+      while (__builtin_amdgcn_s_memrealtime() - now < half) __builtin_amdgcn_s_sleep(8);
+    }
     r = r2;
   }
 }
@@ -614,7 +627,12 @@ hipError_t launch_sweep1(const TrieRowsParams &p, int n_top, size_t lds, size_t 
   const int rows8 = (p.n_rows + 7) & ~7;
   if (n_lanes > rows8) n_lanes = rows8;
   const unsigned blocks = (unsigned)(n_lanes * p.n_parts);
-  hipLaunchKernelGGL((trie_sweep_kernel<DT, kNT, OUT>), dim3(blocks), dim3(kNT), lds, s, p, n_lanes);
+  // (where the next row is not on its way during the reduction - float32 rows - and the output is short; five rows a lane and
+  // more; every workgroup resident.  Measured at 1024 x 50257: float32 slots 150 -> 142 us; 16-bit rows, whose reads overlap
+  // already, and all-nodes outputs, bound by their writes, lose 5-7 %)
+  int stagger = DT == GLB_F32 && OUT != 2 && OUT != 7 && p.n_rows >= 5 * n_lanes && blocks <= (unsigned)(cus * wg_per_cu) ? 1 : 0;
+  GLB_DIAG(if (const char *ev = getenv("GLB_TRIE_STAGGER")) stagger = atoi(ev);)
+  hipLaunchKernelGGL((trie_sweep_kernel<DT, kNT, OUT>), dim3(blocks), dim3(kNT), lds, s, p, n_lanes, stagger);
   if (n_top > 0) hipLaunchKernelGGL((trie_rows_kernel<DT, true, 8>), dim3((unsigned)p.n_rows), dim3(256), lds_top, s, p);
   return hipGetLastError();
 }

@@ -468,9 +468,10 @@ class TokenByteTrie:
 
     prune_selection = True  # masses of selected nodes: plan only the sub-forest below them (selection_plan)
     sweep = True  # whole-trie masses through the plan whose parts read a row front to back (plan(sweep=True)): the slots always
-    # (their numbering is that plan's: `slot_plan()`), all nodes from SWEEP_MIN_ROWS rows on (below, the gathered plan's
-    # many small workgroups fill the chip better: 1 row 18 against 30 us)
-    SWEEP_MIN_ROWS = 128
+    # (their numbering is that plan's: `slot_plan()`; 1024 rows 193 -> 140 us, 8 rows 17 -> 21), all nodes from SWEEP_MIN_ROWS
+    # rows on (1024: 309 -> 273 us, 512: 158 -> 146; below, the gathered plan's many small workgroups fill the chip better:
+    # 256 rows 63 against 68 us, one row 18 against 30 - tools/dbg/sweep_probe2.py)
+    SWEEP_MIN_ROWS = 512
     resident = True  # glb_trie_rows (a row of a part of the trie in LDS) when the trie has a plan; False: the level-synchronous kernels
 
     def _batch(self, ws, op, from_logprobs):

@@ -1051,7 +1051,8 @@ def test_trie_rows_at_llama_vocabulary_size(engine, oracle):
     assert torch.equal(engine.trie_rows(x, sw, 0, True, lse=lse), rows)
     sl = trie.masses_from_logits(x, lse, layout="slot_rows")
     assert torch.equal(sl[:, sw["slot_of"].long()], rows)
-    big = torch.cat([x] * 4)[:150]  # (from SWEEP_MIN_ROWS rows on, the rows go through the sweep plan too)
+    trie.SWEEP_MIN_ROWS = 100  # (from SWEEP_MIN_ROWS rows on, the rows go through the sweep plan too)
+    big = torch.cat([x] * 4)[:150]
     assert torch.equal(trie.masses_from_logits(big, torch.cat([lse] * 4)[:150]), torch.cat([rows] * 4)[:150])
 
 
