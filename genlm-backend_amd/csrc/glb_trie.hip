@@ -308,7 +308,7 @@ struct RowVec<GLB_F32> {
     b = *reinterpret_cast<const f32x4_u *>(q + 4);
   }
   __device__ __forceinline__ float get(int k) const { return k < 4 ? a[k] : b[k - 4]; }
-  __device__ __forceinline__ void none() { asm volatile("" : "=v"(a), "=v"(b)); }  // (any value: no tie to what the registers held)
+  __device__ __forceinline__ void keep() const { asm volatile("" ::"v"(a), "v"(b)); }  // (a use: the registers stay the vector's own up to here)
 };
 template <int DT>
 struct RowVec {  // 16-bit rows: eight tokens in 16 bytes, on any 2-byte boundary
@@ -318,7 +318,7 @@ struct RowVec {  // 16-bit rows: eight tokens in 16 bytes, on any 2-byte boundar
     a = *reinterpret_cast<const u32x4_u *>(reinterpret_cast<const uint16_t *>(ws) + idx);
   }
   __device__ __forceinline__ float get(int k) const { return glb::trie_upcast<DT>((uint16_t)(a[k >> 1] >> ((k & 1) * 16))); }
-  __device__ __forceinline__ void none() { asm volatile("" : "=v"(a)); }
+  __device__ __forceinline__ void keep() const { asm volatile("" ::"v"(a)); }
 };
 
 // The reduction of a swept part.  A node: its children are consecutive in LDS, added one by one in ascending order in
@@ -330,6 +330,9 @@ template <int OP>
 __device__ __forceinline__ void sweep_node(float *val, uint64_t e) {
   const int s = (int)(e & 0xffffu), c0 = (int)((e >> 16) & 0xffffu), cnt = (int)(e >> 32);
   double acc = 0.0;
+#if defined(GLB_TRIE_EXP) && GLB_TRIE_EXP == 1
+  float facc = 0.0f;
+#endif
   for (int base = 0; __any(base < cnt); base += 8) {
     const float *q = val + c0 + base;
     const int rem = cnt - base;
@@ -339,8 +342,12 @@ __device__ __forceinline__ void sweep_node(float *val, uint64_t e) {
       for (int j = 0; j < 8; ++j) x[j] = q[j];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
+#if defined(GLB_TRIE_EXP) && GLB_TRIE_EXP == 1
+        facc += (j < rem ? x[j] : 0.0f);
+#else
         if constexpr (OP == GLB_TRIE_SUM) acc += (double)(j < rem ? x[j] : 0.0f);
         else acc = j < rem ? fmax(acc, (double)x[j]) : acc;
+#endif
       }
     } else {
       float x[4];
@@ -348,17 +355,24 @@ __device__ __forceinline__ void sweep_node(float *val, uint64_t e) {
       for (int j = 0; j < 4; ++j) x[j] = q[j];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
+#if defined(GLB_TRIE_EXP) && GLB_TRIE_EXP == 1
+        facc += (j < rem ? x[j] : 0.0f);
+#else
         if constexpr (OP == GLB_TRIE_SUM) acc += (double)(j < rem ? x[j] : 0.0f);
         else acc = j < rem ? fmax(acc, (double)x[j]) : acc;
+#endif
       }
     }
   }
+#if defined(GLB_TRIE_EXP) && GLB_TRIE_EXP == 1
+  acc = facc;
+#endif
   val[s] = (float)acc;
 }
 
 // depth by depth, deepest internal depth first; trip t of the work list is ent[t] (in registers for the workgroup's life)
 template <int OP, int kNT, int kQ>
-__device__ __forceinline__ void sweep_reduce(float *val, const uint64_t (&ent)[kQ], int dv, int n_depths, int tid, const uint64_t *in64) {
+__device__ __forceinline__ void sweep_reduce(float *val, const uint64_t (&ent)[kQ], int dv, int n_depths, int tid, const uint64_t *in64 GLB_DIAG(, uint64_t *st)) {
   constexpr int nt = kNT;
   int k = n_depths - 2, j = 0;
 #pragma unroll
@@ -375,6 +389,7 @@ __device__ __forceinline__ void sweep_reduce(float *val, const uint64_t (&ent)[k
       } else {
         --k, j = 0;
         __syncthreads();
+        GLB_DIAG(if (st && tid == 0 && n_depths - 3 - k < 3) st[5 + n_depths - 3 - k] = GLB_NOW();)
       }
     }
   }
@@ -433,12 +448,18 @@ __global__ __launch_bounds__(kNT) void trie_sweep_kernel(TrieRowsParams p, int n
       ent[t] = e;
     }
   }
+  // A thread's units are tid + j * nt; one past the row's last whole unit becomes that last unit once more (the same
+  // weights to the same slots a second time): no load and no store of the rows' loop hangs on a per-lane condition, so the
+  // compiler sees straight code and waits for a load where it is used.  (A vocabulary under 8 tokens has no whole unit.)
+  const int last = full > 0 ? full - 1 : 0;
+  auto uo = [&](int j) { return 8 * (tid + j * nt < full ? tid + j * nt : last); };
   u32x4_t tk[kU];
 #pragma unroll
-  for (int j = 0; j < kU; ++j) {
-    const int u = tid + j * nt;
-    tk[j] = u < full ? *reinterpret_cast<const u32x4_t *>(tl + 8 * u) : u32x4_t{0u, 0u, 0u, 0u};  // (never used: guarded by u < full)
-  }
+  for (int j = 0; j < kU; ++j) tk[j] = *reinterpret_cast<const u32x4_t *>(tl + uo(j));  // (the table is padded to whole units)
+  // (everything above has arrived before the first row sets out: inside the rows' loop the compiler then waits for a row's
+  // loads where they are used, not - to be safe about these - for all of memory at every trip of the reduction, which
+  // would end the next row's head start)
+  __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
   // every token is stored: another part's token names a word of the slack behind the values
   auto put = [&](const u32x4_t &t, const RowVec<DT> &x, float lse) {
 #pragma unroll
@@ -453,47 +474,76 @@ __global__ __launch_bounds__(kNT) void trie_sweep_kernel(TrieRowsParams p, int n
     while (r < p.n_rows && p.need && !((p.need[r] >> part) & 1ull)) r += n_lanes;
     return r;
   };
-  int r = next_row(g);
   // Every workgroup starts at once and takes the same time a row, so all of them would read at the same time and reduce at
   // the same time: the reads at 30 GB/s a CU (the chip's rate over 256), the memory idle in between.  Every other group of
   // eight lanes therefore waits half a row's time after its first row (once; `stagger`: the host asks for it when a lane
   // has rows enough to win it back): from then on half the chip reads while the other half reduces - 50 GB/s a CU.
   bool wait_half = stagger && ((g >> 3) & 1);
   const uint64_t t_first = __builtin_amdgcn_s_memrealtime();
-  RowVec<DT> x[kX > 0 ? kX : 1];
+  // A trip of the loop: the head of row r sets out; the row BEFORE it, which is in LDS, is reduced and written; row r goes
+  // to LDS.  A load is issued and used in the same trip, with the reduction in between - nothing is carried round the loop
+  // in flight, which the compiler answers with waits for all of memory in the middle of the reduction.
+  int r = next_row(g), r_prev = -1;
+  for (;;) {
+    const bool have = r < p.n_rows;
+    if (!have && r_prev < 0) break;
+    const int64_t row = (int64_t)(have ? r : r_prev) * p.ld;  // (no row left: the loads below read the last one's head again, unused)
+    float lse = 0.0f;
+    RowVec<DT> x[kX > 0 ? kX : 1];
+    if (full > 0) {
+      if (p.lse) lse = p.lse[have ? r : r_prev];
 #pragma unroll
-  for (int j = 0; j < kX; ++j) {
-    if (r < p.n_rows && tid + j * nt < full) x[j].load(p.ws, (int64_t)r * p.ld + 8 * (tid + j * nt));
-    else x[j].none();
-  }
-  while (r < p.n_rows) {
-    const float lse = p.lse ? p.lse[r] : 0.0f;
-    const int64_t row = (int64_t)r * p.ld;
+      for (int j = 0; j < kX; ++j) x[j].load(p.ws, row + uo(j));
+    }
+    if (r_prev >= 0) {
+      GLB_DIAG(uint64_t *st = (p.stamps && r_prev < 8192) ? p.stamps + ((int64_t)r_prev * p.n_parts + part) * 8 : nullptr;)
+      GLB_TRIE_STAMP(2)
+      if (p.op == GLB_TRIE_SUM) sweep_reduce<GLB_TRIE_SUM, kNT, kQ>(val, ent, dv, v.n_depths, tid, in64 GLB_DIAG(, st));
+      else sweep_reduce<GLB_TRIE_MAX, kNT, kQ>(val, ent, dv, v.n_depths, tid, in64 GLB_DIAG(, st));
+      GLB_TRIE_STAMP(3)
+      part_write<1, OUT>(p, v, val, false, r_prev, tid, nt);
+      if (p.cut_vals) {
+        float *cv = p.cut_vals + (int64_t)r_prev * p.n_cut + v.d[D_CUT_BASE];
+        const int n_roots = v.d[D_N_ROOTS];
+        for (int i = tid; i < n_roots; i += nt) cv[i] = val[i];
+      }
+      GLB_TRIE_STAMP(4)
+      __syncthreads();  // (the values are read out before the next row lands on them)
+      if (wait_half) {
+        wait_half = false;
+        const uint64_t now = __builtin_amdgcn_s_memrealtime();
+        uint64_t half = (now - t_first) >> 1;
+        if (half > 2000) half = 2000;  // (20 us at 100 MHz: never a long wait, whatever the clock read)
+        while (__builtin_amdgcn_s_memrealtime() - now < half) __builtin_amdgcn_s_sleep(8);
+      }
+    }
+    // (the row's head and its lse own their registers through the reduction on every path: a register with a load out that
+    // the reduction could reuse would have to be waited for there)
+#pragma unroll
+    for (int j = 0; j < kX; ++j) x[j].keep();
+    asm volatile("" ::"v"(lse));
+    if (!have) break;
     GLB_DIAG(uint64_t *st = (p.stamps && r < 8192) ? p.stamps + ((int64_t)r * p.n_parts + part) * 8 : nullptr;)
     GLB_TRIE_STAMP(0)
+    if (full == 0 && p.lse) lse = p.lse[r];
     // the units that came ahead go to LDS while the first trip of the others is on its way
     // (the slots are unpacked here, row by row: hoisted out of the loop they would take two registers a token, not half a one)
+    if (full > 0) {
 #pragma unroll
-    for (int j0 = kX; j0 < kU; j0 += kB) {
-      RowVec<DT> y[kB];
+      for (int j0 = kX; j0 < kU; j0 += kB) {
+        RowVec<DT> y[kB];
 #pragma unroll
-      for (int j = j0; j < j0 + kB && j < kU; ++j) {
-        if (tid + j * nt < full) y[j - j0].load(p.ws, row + 8 * (tid + j * nt));
-        else y[j - j0].none();
-      }
-      if (j0 == kX) {
+        for (int j = j0; j < j0 + kB && j < kU; ++j) y[j - j0].load(p.ws, row + uo(j));
+        if (j0 == kX) {
 #pragma unroll
-        for (int j = 0; j < kX; ++j) {
-          if (tid + j * nt < full) {
+          for (int j = 0; j < kX; ++j) {
             u32x4_t tj = tk[j];
             asm volatile("" : "+v"(tj));
             put(tj, x[j], lse);
           }
         }
-      }
 #pragma unroll
-      for (int j = j0; j < j0 + kB && j < kU; ++j) {
-        if (tid + j * nt < full) {
+        for (int j = j0; j < j0 + kB && j < kU; ++j) {
           u32x4_t tj = tk[j];
           asm volatile("" : "+v"(tj));
           put(tj, y[j - j0], lse);
@@ -506,50 +556,20 @@ __global__ __launch_bounds__(kNT) void trie_sweep_kernel(TrieRowsParams p, int n
       RowVec<DT> z[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const int u = u0 + j * nt;
-        if (u < full) {
-          t[j] = *reinterpret_cast<const u32x4_t *>(tl + 8 * u);
-          z[j].load(p.ws, row + 8 * u);
-        }
+        const int u = u0 + j * nt < full ? u0 + j * nt : last;
+        t[j] = *reinterpret_cast<const u32x4_t *>(tl + 8 * u);
+        z[j].load(p.ws, row + 8 * u);
       }
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        if (u0 + j * nt < full) put(t[j], z[j], lse);
+      for (int j = 0; j < 2; ++j) put(t[j], z[j], lse);
     }
     // ... and the last, partial unit element by element: nothing is read past the row
     const int t_tail = 8 * full + tid;
     if (t_tail < p.vocab) val[tl[t_tail]] = glb::trie_weight<DT>(p.ws, row + t_tail, p.from_logprobs, p.scale, lse);
     GLB_TRIE_STAMP(1)
-    // the next row sets out - not before the registers of this one are free
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    const int r2 = next_row(r + n_lanes);
-#pragma unroll
-    for (int j = 0; j < kX; ++j) {  // (a register that gets no load gets "any value": it must not stay tied to the row just used)
-      if (r2 < p.n_rows && tid + j * nt < full) x[j].load(p.ws, (int64_t)r2 * p.ld + 8 * (tid + j * nt));
-      else x[j].none();
-    }
     __syncthreads();
-    GLB_TRIE_STAMP(2)
-    if (p.op == GLB_TRIE_SUM) sweep_reduce<GLB_TRIE_SUM, kNT, kQ>(val, ent, dv, v.n_depths, tid, in64);
-    else sweep_reduce<GLB_TRIE_MAX, kNT, kQ>(val, ent, dv, v.n_depths, tid, in64);
-    GLB_TRIE_STAMP(3)
-    part_write<1, OUT>(p, v, val, false, r, tid, nt);
-    if (p.cut_vals) {
-      float *cv = p.cut_vals + (int64_t)r * p.n_cut + v.d[D_CUT_BASE];
-      const int n_roots = v.d[D_N_ROOTS];
-      for (int i = tid; i < n_roots; i += nt) cv[i] = val[i];
-    }
-    GLB_TRIE_STAMP(4)
-    __syncthreads();  // (the values are read out before the next row lands on them)
-    if (wait_half) {
-      wait_half = false;
-      const uint64_t now = __builtin_amdgcn_s_memrealtime();
-      uint64_t half = (now - t_first) >> 1;
-      if (half > 2000) half = 2000;  // (20 us at 100 MHz: never a long wait, whatever the clock read)
-      while (__builtin_amdgcn_s_memrealtime() - now < half) __builtin_amdgcn_s_sleep(8);
-    }
-    r = r2;
+    r_prev = r;
+    r = next_row(r + n_lanes);
   }
 }
 

@@ -37,6 +37,8 @@ if trie.sweep and os.environ.get("GLB_TRIE_CAP"):
 pl = trie.plan(sweep=trie.sweep)
 x = torch.randn((B, len(words)), device=dev) * 3
 _, lse, _ = eng.step(x, rng_mode=0)
+if os.environ.get("GLB_TRIE_DT") == "bf16":
+    x = x.to(torch.bfloat16)
 for i in range(6):
     if i == 5:
         eng._trie_ws.zero_()  # (only the workgroups of the last call leave stamps)
