@@ -164,12 +164,38 @@ class TokenByteTrie:
 
     SWEEP_LOCAL_MAX = 40000  # slots per part of a sweep plan: 4 bytes of LDS a slot, one 1024-thread workgroup a CU (160 KB)
 
+    def _count_parts(self, cap):
+        """How many parts `_build_plan(cap, None)` would make (the cut and the first-fit packing alone)."""
+        kids, size, root = self._tree()
+        cut, stack = [], [root]
+        while stack:
+            s = stack.pop()
+            if size[s] <= cap:
+                cut.append(int(size[s]))
+            else:
+                stack.extend(kids[s].tolist())
+        room = []
+        for sz in sorted(cut, reverse=True):
+            for b in range(len(room)):
+                if room[b] >= sz:
+                    room[b] -= sz
+                    break
+            else:
+                room.append(cap - sz)
+        return len(room)
+
     def sweep_cap(self):
         """Slots per part for `plan(sweep=True)`: as few parts as the LDS allows (every part reads the whole row once), of
-        about equal size."""
+        about equal size - the smallest cap that packs the subtrees into that many parts."""
         n_slots = int(self.compact()["n_nodes"])
-        n_parts = max(1, -(-n_slots // (self.SWEEP_LOCAL_MAX - 2000)))
-        return min(self.SWEEP_LOCAL_MAX, -(-n_slots * 21 // (n_parts * 20)) + 64)
+        n_parts = max(1, -(-n_slots // self.SWEEP_LOCAL_MAX))
+        while True:
+            ideal = -(-n_slots // n_parts)
+            for num in (102, 105, 110, 120, 135):
+                cap = min(self.SWEEP_LOCAL_MAX, ideal * num // 100 + 64)
+                if self._count_parts(cap) <= n_parts:
+                    return cap
+            n_parts += 1
 
     def plan(self, cap=None, sweep=False):
         """The folded trie (`compact()`) cut for glb_trie_rows, which keeps ONE ROW's values of a part of the trie in

@@ -48,13 +48,15 @@ for B in (1, 8, 64, 1024):
     for xx, tag in ((xb, "f32"), (xb.to(torch.bfloat16), "bf16")):
         for name, kw in (("rows", dict(layout="rows")), ("slot_rows", dict(layout="slot_rows")), ("4096 selected nodes", dict(nodes=sel))):
             res = []
-            for resident in (True, False):
-                trie.resident = resident
+            for resident, sweep in ((True, True), (True, False), (False, False)):
+                trie.resident, trie.sweep = resident, sweep
                 if name == "slot_rows" and not resident:
                     res.append(timed(lambda: trie.masses_from_logits(xx, lb, layout="slots")))  # (node-major: the old path's cheapest form)
                 else:
                     res.append(timed(lambda: trie.masses_from_logits(xx, lb, **kw)))
-            print(f"masses_from_logits {tag} B={B} -> {name}: in LDS {res[0]:9.1f} us   level kernels {res[1]:9.1f} us", flush=True)
+            trie.sweep = True
+            print(f"masses_from_logits {tag} B={B} -> {name}: in LDS {res[0]:9.1f} us (sweep plan where it is the default) "
+                  f"{res[1]:9.1f} us (gathered plan)   level kernels {res[2]:9.1f} us", flush=True)
 trie.resident = False
 for B in (1, 8, 64, 1024):
     ws = torch.rand((B, len(words)), device=dev); ws /= ws.sum(-1, keepdim=True)
@@ -88,16 +90,20 @@ while len(words2) < 128256:
     if w not in seen2: seen2.add(w); words2.append(w)
 trie2 = TokenByteTrie([Token(i, w) for i, w in enumerate(words2)], engine=eng)
 pl2 = trie2.plan()
-print(f"128256 tokens: {len(trie2)} nodes, {pl2['n_slots']} slots, plan: {pl2['n_parts']} parts of at most {pl2['max_local']} slots, top of {pl2['n_top']}")
+sw2 = trie2.plan(sweep=True)
+print(f"128256 tokens: {len(trie2)} nodes, {pl2['n_slots']} slots, plan: {pl2['n_parts']} parts of at most {pl2['max_local']} slots, top of {pl2['n_top']}; "
+      f"sweep plan: {sw2['n_parts']} parts of at most {sw2['max_local']} slots, top of {sw2['n_top']}")
 x2 = (torch.randn((512, len(words2)), device=dev) * 3).to(torch.bfloat16)
 _, lse2, _ = eng.step(x2, rng_mode=0)
 sel2 = torch.from_numpy(rs.choice(len(trie2), 4096, replace=False).astype(np.int32)).to(dev)
 for name, kw in (("rows", dict(layout="rows")), ("slot_rows", dict(layout="slot_rows")), ("4096 selected nodes", dict(nodes=sel2))):
     res = []
-    for resident in (True, False):
-        trie2.resident = resident
+    for resident, sweep in ((True, True), (True, False), (False, False)):
+        trie2.resident, trie2.sweep = resident, sweep
         if name == "slot_rows" and not resident:
             res.append(timed(lambda: trie2.masses_from_logits(x2, lse2, layout="slots"), 5))
         else:
             res.append(timed(lambda: trie2.masses_from_logits(x2, lse2, **kw), 5))
-    print(f"masses_from_logits bf16 B=512 V=128256 -> {name}: in LDS {res[0]:9.1f} us   level kernels {res[1]:9.1f} us", flush=True)
+    trie2.sweep = True
+    print(f"masses_from_logits bf16 B=512 V=128256 -> {name}: in LDS {res[0]:9.1f} us (sweep plan where it is the default) "
+          f"{res[1]:9.1f} us (gathered plan)   level kernels {res[2]:9.1f} us", flush=True)
