@@ -63,8 +63,9 @@ GLB_HD static inline double log1p_neg(double x) {
     u = 1.0 + x;
     hu = hi_word(u);
     k = (hu >> 20) - 1023;
-    c = (k > 0) ? 1.0 - (u - x) : x - (u - 1.0);  // the rounding error of 1 + x
-    c /= u;
+    // (glibc: c = the rounding error of 1 + x, divided by u.  For the stream's arguments - x = -k 2^-53 - the sum 1 + x is
+    // exact, c is +0 and so is c / u: the division, a dozen double-precision instructions, is left out; tests/test_mt_cpu.py
+    // holds the result against the C library's bit for bit)
     hu &= 0x000fffff;
     if (hu < 0x6a09e) {
       u = with_hi_word(u, hu | 0x3ff00000);  // u in [1, sqrt 2)
@@ -102,6 +103,81 @@ GLB_HD static inline float exponential_from_words(uint32_t first, uint32_t secon
   const uint64_t r = ((uint64_t)first << 32) | second;
   const double u = (double)(r & ((1ull << 53) - 1)) * (1.0 / 9007199254740992.0);
   return (float)(-log1p_neg(-u));
+}
+
+// ---- the same float four times cheaper ---------------------------------------------------------------------------------
+// Only the FLOAT (float)(-log1p(-u)) is wanted, and glibc's double is within an ulp of the true logarithm.  Any other
+// double within 2^-49 of it (relative) rounds to the same float unless a rounding boundary - the midpoint of two
+// neighbouring floats - lies between the two, i.e. within 2^-46 |y| of either.  exponential_fast computes log1p(-u) by a
+// 128-entry table and a degree-9 series (20 double-precision operations where fdlibm's division and its polynomial take
+// 60; its error is the table's: 2^-46.5 |y| at worst, 2^-52 typically), rounds it, and REPORTS when the double lies within
+// 2^-41 |y| of a boundary - 45 times the bound: one value in 10^5 -, for which the caller runs log1p_neg itself.  Every
+// float it does not report is the float of the function above (tests/test_mt_cpu.py: 10^8 arguments against the C library).
+//     w = 1 - u (exact) = m 2^e, m in [1, 2);  i = the top seven bits of m's fraction;  1 / c_i ~ inv[i] (c_0 = 1)
+//     r = m inv[i] - 1 (one fma; |r| <= 2^-8);  log w = e ln2 + log(1 / inv[i]) + log1p(r)
+//     u < 2^-7: r = -u, e = 0, log(1 / inv) = 0 (w next to 1: the table form would cancel)
+constexpr int kLog1pEntries = 128;
+
+// entry i of the table: inv = 1 / c_i rounded (c_i = 1 + (i + 1/2) / 128 the middle of the i-th interval; c_0 = 1), and
+// hi = log(1 / inv) by log1p_neg itself (an ulp: 2^-53.5 absolute, 2^-46.5 of a result that is at least 2^-7) - host and
+// device build the same table with the same operations
+GLB_HD static inline void log1p_table_entry(int i, double *inv, double *hi) {
+  if (i == 0) {
+    *inv = 1.0, *hi = 0.0;
+    return;
+  }
+  const double c = 1.0 + ((double)i + 0.5) * 0.0078125;
+  *inv = 1.0 / c;
+  *hi = -log1p_neg(*inv - 1.0);  // (inv - 1 in (-1/2, 0): exact)
+}
+
+// y ~ log1p(-u) for u = k 2^-53, 0 < k < 2^53
+GLB_HD static inline double log1p_neg_fast(double u, const double *inv, const double *hi) {
+  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+  const double w = 1.0 - u;  // (exact)
+  uint64_t b;
+  memcpy(&b, &w, 8);
+  const int i = (int)((b >> 45) & 127);
+  const uint64_t mb = (b & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
+  double m;
+  memcpy(&m, &mb, 8);
+  const bool small = u < 0.0078125;
+  const double r = small ? -u : __builtin_fma(m, inv[i], -1.0);
+  const double e = small ? 0.0 : (double)((int)(b >> 52) - 1023);
+  const double lh = small ? 0.0 : hi[i];
+  double p = 1.0 / 9.0;
+  p = __builtin_fma(p, r, -1.0 / 8.0);
+  p = __builtin_fma(p, r, 1.0 / 7.0);
+  p = __builtin_fma(p, r, -1.0 / 6.0);
+  p = __builtin_fma(p, r, 1.0 / 5.0);
+  p = __builtin_fma(p, r, -1.0 / 4.0);
+  p = __builtin_fma(p, r, 1.0 / 3.0);
+  p = __builtin_fma(p, r, -0.5);
+  const double tail = __builtin_fma(p, r * r, e * ln2_lo);
+  const double head = __builtin_fma(e, ln2_hi, lh);
+  return head + (r + tail);
+}
+
+// the variate of exponential_from_words, or *redo = true when only log1p_neg can tell (then the return value is a guess)
+GLB_HD static inline float exponential_fast(uint32_t first, uint32_t second, const double *inv, const double *hi, bool *redo) {
+  const uint64_t k = (((uint64_t)first << 32) | second) & ((1ull << 53) - 1);
+  if (k == 0) {  // u = 0: -log1p(-0.0) = +0.0
+    *redo = false;
+    return 0.0f;
+  }
+  const double u = (double)k * (1.0 / 9007199254740992.0);
+  const double E = -log1p_neg_fast(u, inv, hi);  // in [2^-53, 37]: a normal float
+  const float f = (float)E;
+  uint32_t fb;
+  memcpy(&fb, &f, 4);
+  const uint32_t lb = fb - 1u, ub = fb + 1u;  // the neighbouring floats (f > 0)
+  float fl, fu;
+  memcpy(&fl, &lb, 4);
+  memcpy(&fu, &ub, 4);
+  const double lower = 0.5 * ((double)f + (double)fl), upper = 0.5 * ((double)f + (double)fu);  // the rounding boundaries round f
+  const double room = (E - lower) < (upper - E) ? (E - lower) : (upper - E);
+  *redo = !(room >= E * 4.547473508864641e-13);  // 2^-41 (NaN: redo)
+  return f;
 }
 
 }  // namespace glb

@@ -12,14 +12,15 @@
 //   * Host, once per vocabulary (glb_mt19937_jump_polys): phi by Berlekamp-Massey, g_{r s} for r < n_small and
 //     g_{m n_small s} for m < n_big, s = 2 V words = one particle's stride.
 //   * mt_jump_kernel: a workgroup runs the recurrence from its source window through a ring in LDS (227 words per step:
-//     the recurrence reaches back 227) up to the quarter of the sequence it convolves, and each of its four waves
-//     convolves that quarter with the matching quarter of one polynomial - lane l keeps 11 consecutive output words, a
-//     42-word sliding window of the sequence serves 32 coefficients; a window is the XOR of its four partial planes.  Two
-//     launches: the base window -> every n_small-th row's window, those -> every row's window.
+//     the recurrence reaches back 227) up to the part of the sequence it convolves (a quarter; a sixteenth in the first
+//     launch), and each of its four waves convolves that part with the matching part of one polynomial - lane l keeps 11
+//     consecutive output words, a 42-word sliding window of the sequence serves 32 coefficients; a window is the XOR of its
+//     partial planes.  Two launches: the base window -> every n_small-th row's window, those -> every row's window.
 //   * mt_rows_kernel: a workgroup per output row runs the recurrence from its window (454 words per round through a
-//     2048-word ring in LDS), tempers, pairs the words as random64() and turns them into E = (float)(-log1p(-u)) with
-//     glibc's log1p restated operation for operation (glb_log1p.hpp); one more block leaves the window after the last
-//     consumed row as the stream's new position.
+//     2048-word ring in LDS), tempers, pairs the words as random64() and turns them into E = (float)(-log1p(-u)): glibc's
+//     log1p restated operation for operation (glb_log1p.hpp) where a cheaper double cannot tell the float - one value in
+//     10^5 -, a table and a series everywhere else (the same float, by construction: exponential_fast); one more block
+//     leaves the window after the last consumed row as the stream's new position.
 // Everything is integer work except the logarithm; results are bit-identical to the host's serial
 // glb_mt19937_exponential_f32 (tests/test_mt_gpu.py), which is pinned against torch (tests/test_oracle.py).
 #include <hip/hip_runtime.h>
@@ -42,10 +43,20 @@ constexpr int kN = 624, kM = 397, kDeg = 19937;
 constexpr int kPW = GLB_MT_POLY_WORDS;  // 312 64-bit words: coefficients 0 .. 19967
 constexpr int kStep = kN - kM;          // 227: how many new words one step of the recurrence can make at once
 constexpr int kPerLane = 11;             // output words a lane of mt_jump_kernel keeps (57 lanes x 11 >= 624; stride 11: no bank conflicts)
-constexpr int kParts = 4;                // a polynomial's coefficients are applied in four parts by four workgroups
-constexpr int kPartWords = kN / kParts;  // 156 32-bit coefficient words (4992 coefficients) a part
-constexpr int kPartSeq = kPartWords * 32 + 56 * kPerLane + 32 + kPerLane - 1;  // sequence words a part reads: 5650
-constexpr int kJumpRing = 8192;          // words of LDS of a jumping workgroup (32 KB) >= kPartSeq + kN + kStep
+// A polynomial's coefficients are applied in PARTS parts by as many workgroups that never meet (a window is the XOR of the
+// PARTS planes they leave).  kParts = 4 for the launch that makes every row's window (a thousand windows: throughput - more
+// parts would run the recurrence up to their range more often than they save: 178 -> 240 us with 16); kPartsFew = 16 for the
+// launch before it, which makes the 32 windows of every n_small-th row from the stream's position (32 workgroups with four
+// parts: the latency of ONE workgroup's 156 coefficient words, 178 us; 128 workgroups of 39 words: 50 us).
+constexpr int kParts = 4, kPartsFew = 16;
+template <int PARTS>
+struct JumpShape {
+  static_assert(kN % PARTS == 0, "a part is a whole number of coefficient words");
+  static constexpr int kPartWords = kN / PARTS;  // 32-bit coefficient words a part: 156 (4992 coefficients) / 39
+  static constexpr int kPartSeq = kPartWords * 32 + 56 * kPerLane + 32 + kPerLane - 1;  // sequence words a part reads: 5650 / 1906
+  static constexpr int kRingWords = PARTS >= 16 ? 4096 : 8192;  // LDS words of a jumping workgroup
+  static_assert(kRingWords >= kPartSeq + kN + kStep, "the ring holds a part's sequence and the recurrence's reach");
+};
 constexpr int kRing = 2048;
 
 __host__ __device__ static inline uint32_t mt_twist(uint32_t a, uint32_t b, uint32_t c) {
@@ -203,23 +214,31 @@ static void jump_host(const uint32_t *win, const uint64_t *poly, uint32_t *out) 
 
 // ---- device ------------------------------------------------------------------------------------------------------------
 // Block (src, quad, part): waves 0..3 apply coefficients [part * 4992, (part + 1) * 4992) of polynomials 4 quad + wave to
-// source window src.  A window is kept as kParts PLANES whose XOR it is (dst[part][src * n_poly + p]): the four parts of a
-// polynomial are four workgroups that never meet, each with a quarter of the sequence in LDS (32 KB: five workgroups a CU,
+// source window src.  A window is kept as PARTS PLANES whose XOR it is (dst[part][src * n_poly + p]): the parts of a
+// polynomial are workgroups that never meet, each with its part of the sequence in LDS (PARTS = 4: 32 KB, five workgroups a CU,
 // so that one wave's LDS waits and taken branches are another's issue slots; the whole sequence in one workgroup - 82 KB,
 // one wave a SIMD - took 577 us a launch, VALU idle two thirds of the time).  The source window is the XOR of its own planes.
+template <int PARTS>
 __global__ __launch_bounds__(256) void mt_jump_kernel(const uint32_t *__restrict__ src, int src_planes, int64_t src_plane_stride,
                                                       const uint64_t *__restrict__ polys, int n_poly, uint32_t *__restrict__ dst,
                                                       int n_dst, int64_t dst_plane_stride) {
+  constexpr int kPartWords = JumpShape<PARTS>::kPartWords, kPartSeq = JumpShape<PARTS>::kPartSeq, kJumpRing = JumpShape<PARTS>::kRingWords;
   __shared__ uint32_t ring[kJumpRing];
   const int quads = (n_poly + 3) >> 2;
-  const int part = (int)blockIdx.x % kParts, sq = (int)blockIdx.x / kParts;
+  const int part = (int)blockIdx.x % PARTS, sq = (int)blockIdx.x / PARTS;
   const int s = sq / quads, q = sq % quads;
   const int t = (int)threadIdx.x;
   // word n of the sequence lives at ring[(n - lo) & (kJumpRing - 1)]: the part's range [lo, lo + kPartSeq) is contiguous
   const int lo = part * kPartWords * 32;
-  for (int i = t; i < kN; i += 256) {
+  for (int i = t; i < kN; i += 256) {  // (the planes' loads go out together: one after the other, sixteen planes are sixteen trips)
     uint32_t v = 0;
-    for (int pl = 0; pl < src_planes; ++pl) v ^= src[(size_t)pl * src_plane_stride + (size_t)s * kN + i];
+    for (int pl0 = 0; pl0 < src_planes; pl0 += 8) {
+      uint32_t x[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) x[k] = pl0 + k < src_planes ? src[(size_t)(pl0 + k) * src_plane_stride + (size_t)s * kN + i] : 0u;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v ^= x[k];
+    }
     ring[(i - lo) & (kJumpRing - 1)] = v;
   }
   __syncthreads();
@@ -269,6 +288,7 @@ __global__ __launch_bounds__(256) void mt_rows_kernel(const uint32_t *__restrict
                                                       int n_out, int64_t V, float *__restrict__ out, int64_t ld,
                                                       const int32_t *__restrict__ n_draw_dev, int n_draw_host, uint32_t *window_out) {
   __shared__ uint32_t st[kRing];
+  __shared__ double tab_inv[glb::kLog1pEntries], tab_hi[glb::kLog1pEntries];  // exponential_fast's table (glb_log1p.hpp)
   const int r = (int)blockIdx.x, t = (int)threadIdx.x;
   if (r == n_out) {
     int nd = n_draw_dev ? *n_draw_dev : n_draw_host;
@@ -296,6 +316,7 @@ __global__ __launch_bounds__(256) void mt_rows_kernel(const uint32_t *__restrict
     for (int pl = 0; pl < kParts; ++pl) v ^= w[(size_t)pl * plane_stride + i];
     st[i] = v;
   }
+  if (t < glb::kLog1pEntries) glb::log1p_table_entry(t, &tab_inv[t], &tab_hi[t]);
   __syncthreads();
   int pos = 0;  // st[(pos + i) & (kRing - 1)] = x[row start + consumed + i]
   for (int64_t v0 = 0; v0 < V; v0 += kStep) {
@@ -312,7 +333,16 @@ __global__ __launch_bounds__(256) void mt_rows_kernel(const uint32_t *__restrict
     if (t < kStep && v0 + t < V) {
       const int i = pos + kN + 2 * t;
       const uint32_t first = mt_temper(st[i & (kRing - 1)]), second = mt_temper(st[(i + 1) & (kRing - 1)]);
-      o[v0 + t] = glb::exponential_from_words(first, second);
+      // the float by the short form; the one value in 10^5 whose double lies too near a rounding boundary for it to tell (one
+      // wave in 1 500) by glibc's own form
+#ifdef GLB_MT_NOEXP  // (timing experiment: everything but the logarithm)
+      o[v0 + t] = (float)(first ^ second);
+#else
+      bool redo;
+      float e = glb::exponential_fast(first, second, tab_inv, tab_hi, &redo);
+      if (redo) e = glb::exponential_from_words(first, second);
+      o[v0 + t] = e;
+#endif
     }
     pos = (pos + 2 * kStep) & (kRing - 1);
     // (the next round writes ring positions pos + 624 + [0, 454) of the NEW pos - 454 past what this round's readers
@@ -320,10 +350,11 @@ __global__ __launch_bounds__(256) void mt_rows_kernel(const uint32_t *__restrict
   }
 }
 
+template <int PARTS>
 int launch_jump(const uint32_t *src, int src_planes, int64_t src_plane_stride, int n_src, const uint64_t *polys, int n_poly,
                 uint32_t *dst, int n_dst, int64_t dst_plane_stride, hipStream_t st) {
   const int quads = (n_poly + 3) / 4;
-  hipLaunchKernelGGL(mt_jump_kernel, dim3((unsigned)(n_src * quads * kParts)), dim3(256), 0, st, src, src_planes, src_plane_stride, polys,
+  hipLaunchKernelGGL(mt_jump_kernel<PARTS>, dim3((unsigned)(n_src * quads * PARTS)), dim3(256), 0, st, src, src_planes, src_plane_stride, polys,
                      n_poly, dst, n_dst, dst_plane_stride);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? GLB_OK : api_hip_fail(e, "mt_jump_kernel");
@@ -394,8 +425,8 @@ int glb_mt19937_jump_host(const uint32_t *window_in, const uint64_t *poly, uint3
 
 size_t glb_mt19937_rows_workspace(int64_t max_draw_rows, int32_t n_small) {
   if (max_draw_rows < 0 || n_small < 2) return 0;
-  const int64_t n_big = (max_draw_rows + 1 + n_small - 1) / n_small;  // windows are kept as kParts planes (csrc/glb_mt.hip)
-  return (size_t)(n_big + n_big * n_small) * kN * sizeof(uint32_t) * kParts;
+  const int64_t n_big = (max_draw_rows + 1 + n_small - 1) / n_small;  // windows are kept as planes: kPartsFew / kParts (csrc/glb_mt.hip)
+  return (size_t)(n_big * kPartsFew + n_big * n_small * kParts) * kN * sizeof(uint32_t);
 }
 
 int glb_mt19937_exponential_rows(const glb_mt_rows_args *a, void *hip_stream) {
@@ -414,19 +445,19 @@ int glb_mt19937_exponential_rows(const glb_mt_rows_args *a, void *hip_stream) {
   const int m_need = (n_win + a->n_small - 1) / a->n_small;
   // (window_out may be `window`: the launches below read `window` before the last one writes window_out)
   const int64_t big_plane = (int64_t)m_need * kN, all_plane = (int64_t)m_need * a->n_small * kN;
-  uint32_t *big = (uint32_t *)a->workspace, *all = big + big_plane * kParts;
+  uint32_t *big = (uint32_t *)a->workspace, *all = big + big_plane * kPartsFew;
   const uint32_t *lvl1 = a->window;
   int lvl1_planes = 1;
   int64_t lvl1_stride = 0;
   if (m_need > 1) {  // the base window -> the window of every n_small-th row
-    int rc = launch_jump(a->window, 1, 0, 1, a->polys + (size_t)a->n_small * kPW, m_need, big, m_need, big_plane, st);
+    int rc = launch_jump<kPartsFew>(a->window, 1, 0, 1, a->polys + (size_t)a->n_small * kPW, m_need, big, m_need, big_plane, st);
     if (rc) return rc;
     lvl1 = big;
-    lvl1_planes = kParts;
+    lvl1_planes = kPartsFew;
     lvl1_stride = big_plane;
   }
   // -> every row's window (and the one after the last)
-  int rc = launch_jump(lvl1, lvl1_planes, lvl1_stride, m_need, a->polys, a->n_small, all, n_win, all_plane, st);
+  int rc = launch_jump<kParts>(lvl1, lvl1_planes, lvl1_stride, m_need, a->polys, a->n_small, all, n_win, all_plane, st);
   if (rc) return rc;
   if (a->n_out_rows || a->window_out) {
     uint32_t *wo = a->window_out;

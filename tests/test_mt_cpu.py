@@ -35,6 +35,28 @@ def test_library_stream_equals_the_oracle_stream(oracle):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
+def test_short_form_of_the_exponential_gives_the_c_librarys_float(tmp_path):
+    """csrc/glb_log1p.hpp compiled with g++ against the C library's log1p (tests/native/log1p_check.cpp), 20 million
+    arguments and the edges: the exact form - glibc's algorithm without the division that is 0 / u for the stream's
+    arguments - gives the library's float every time; the short form (table + series: what the device runs for all but one
+    value in 10^5) gives the same float whenever it does not ask for the exact one, and asks rarely."""
+    import os
+    import shutil
+    import subprocess
+
+    if shutil.which("g++") is None:
+        import pytest
+
+        pytest.skip("no g++")
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "native", "log1p_check.cpp")
+    exe = str(tmp_path / "log1p_check")
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-o", exe, src, "-lm"], check=True)
+    n, redo, undetected, exact_bad = (int(x) for x in subprocess.run([exe, "20000000"], check=True, capture_output=True,
+                                                                     text=True).stdout.split())
+    assert n > 20_000_000 and undetected == 0 and exact_bad == 0
+    assert redo < n // 20_000  # (one in 10^5 expected)
+
+
 def test_window_is_the_seeded_state_and_jumps_equal_stepping():
     lib = _lib.load()
     V = 50257
@@ -77,4 +99,4 @@ def test_polys_of_another_stride_and_argument_errors():
     assert lib.glb_mt19937_jump_polys(0, 2, 1, polys.ctypes.data_as(C.c_void_p)) == _lib.GLB_EINVAL
     assert lib.glb_mt19937_jump_polys(7, 1, 1, polys.ctypes.data_as(C.c_void_p)) == _lib.GLB_EINVAL
     assert lib.glb_mt19937_jump_polys(7, 2, 1, None) == _lib.GLB_EINVAL
-    assert lib.glb_mt19937_rows_workspace(1024, 32) == (33 + 33 * 32) * 624 * 4 * 4  # (windows as four partial planes)
+    assert lib.glb_mt19937_rows_workspace(1024, 32) == (33 * 16 + 33 * 32 * 4) * 624 * 4  # (windows as partial planes: 16 / 4)
