@@ -162,6 +162,7 @@ class MtRowsArgs(C.Structure):
         ("row_slot", C.c_void_p),
         ("out", C.c_void_p), ("out_ld", C.c_int64),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("reuse_windows", C.c_int32), ("rows_from", C.c_void_p), ("rows_from_ld", C.c_int64),
     ]
 
 

@@ -350,6 +350,33 @@ __global__ __launch_bounds__(256) void mt_rows_kernel(const uint32_t *__restrict
   }
 }
 
+// out[i, 0..V) = src[row_slot[i], 0..V) (ones for a negative slot, NaN for one past the rows that exist): the rows were
+// generated ahead of time in stream order (glb_mt_rows_args.rows_from)
+__global__ __launch_bounds__(256) void mt_rows_copy_kernel(const float *__restrict__ src, int64_t src_ld, int n_src, const int32_t *__restrict__ row_slot,
+                                                           int64_t V, float *__restrict__ out, int64_t ld) {
+  typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));  // (a row starts on any word)
+  const int r = (int)blockIdx.x, t = (int)threadIdx.x;
+  const int slot = row_slot ? row_slot[r] : r;
+  float *o = out + (size_t)r * ld;
+  const int64_t v4 = V & ~(int64_t)3;
+  if (slot < 0 || slot >= n_src) {
+    const float fill = slot < 0 ? 1.0f : __builtin_nanf("");
+    for (int64_t v = t; v < V; v += 256) o[v] = fill;
+    return;
+  }
+  const float *s = src + (size_t)slot * src_ld;
+  for (int64_t v = 4 * (int64_t)t; v < v4; v += 4 * 256 * 4) {
+    f32x4_u x[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (v + k * 1024 < v4) x[k] = *reinterpret_cast<const f32x4_u *>(s + v + k * 1024);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (v + k * 1024 < v4) *reinterpret_cast<f32x4_u *>(o + v + k * 1024) = x[k];
+  }
+  for (int64_t v = v4 + t; v < V; v += 256) o[v] = s[v];
+}
+
 template <int PARTS>
 int launch_jump(const uint32_t *src, int src_planes, int64_t src_plane_stride, int n_src, const uint64_t *polys, int n_poly,
                 uint32_t *dst, int n_dst, int64_t dst_plane_stride, hipStream_t st) {
@@ -434,6 +461,7 @@ int glb_mt19937_exponential_rows(const glb_mt_rows_args *a, void *hip_stream) {
   if (!a->window || !a->polys || a->n_small < 2 || a->n_big < 1 || a->vocab <= 0 || a->max_draw_rows < 0 || a->n_out_rows < 0)
     return api_fail(GLB_EINVAL, "bad arguments");
   if (a->n_out_rows && (!a->out || a->out_ld < a->vocab)) return api_fail(GLB_EINVAL, "out / out_ld");
+  if (a->rows_from && a->rows_from_ld < a->vocab) return api_fail(GLB_EINVAL, "rows_from_ld");
   if (a->max_draw_rows + 1 > (int64_t)a->n_big * a->n_small)
     return api_fail(GLB_EINVAL, "max_draw_rows %lld needs more than the %d x %d polynomials handed over", (long long)a->max_draw_rows,
                     a->n_big, a->n_small);
@@ -449,16 +477,33 @@ int glb_mt19937_exponential_rows(const glb_mt_rows_args *a, void *hip_stream) {
   const uint32_t *lvl1 = a->window;
   int lvl1_planes = 1;
   int64_t lvl1_stride = 0;
-  if (m_need > 1) {  // the base window -> the window of every n_small-th row
-    int rc = launch_jump<kPartsFew>(a->window, 1, 0, 1, a->polys + (size_t)a->n_small * kPW, m_need, big, m_need, big_plane, st);
+  if (!a->reuse_windows) {  // (reuse_windows: the workspace holds them since the call that generated rows_from)
+    if (m_need > 1) {  // the base window -> the window of every n_small-th row
+      int rc = launch_jump<kPartsFew>(a->window, 1, 0, 1, a->polys + (size_t)a->n_small * kPW, m_need, big, m_need, big_plane, st);
+      if (rc) return rc;
+      lvl1 = big;
+      lvl1_planes = kPartsFew;
+      lvl1_stride = big_plane;
+    }
+    // -> every row's window (and the one after the last)
+    int rc = launch_jump<kParts>(lvl1, lvl1_planes, lvl1_stride, m_need, a->polys, a->n_small, all, n_win, all_plane, st);
     if (rc) return rc;
-    lvl1 = big;
-    lvl1_planes = kPartsFew;
-    lvl1_stride = big_plane;
   }
-  // -> every row's window (and the one after the last)
-  int rc = launch_jump<kParts>(lvl1, lvl1_planes, lvl1_stride, m_need, a->polys, a->n_small, all, n_win, all_plane, st);
-  if (rc) return rc;
+  if (a->rows_from) {  // the rows exist: copy them into place; the stream's new position by the rows kernel's last block alone
+    if (a->n_out_rows) {
+      hipLaunchKernelGGL(mt_rows_copy_kernel, dim3((unsigned)a->n_out_rows), dim3(256), 0, st, a->rows_from, a->rows_from_ld, (int)a->max_draw_rows,
+                         a->row_slot, a->vocab, a->out, a->out_ld);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return api_hip_fail(e, "mt_rows_copy_kernel");
+    }
+    if (a->window_out) {
+      hipLaunchKernelGGL(mt_rows_kernel, dim3(1), dim3(256), 0, st, all, all_plane, n_win, a->row_slot, 0, a->vocab, a->out, a->out_ld, a->n_draw,
+                         (int)a->max_draw_rows, a->window_out);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return api_hip_fail(e, "mt_rows_kernel");
+    }
+    return GLB_OK;
+  }
   if (a->n_out_rows || a->window_out) {
     uint32_t *wo = a->window_out;
     const int n_blocks = (int)a->n_out_rows + (wo ? 1 : 0);

@@ -39,6 +39,22 @@ class HostRng:
         return out
 
 
+def _low_priority_stream(device):
+    """A stream of the LOWEST priority HIP has (torch offers normal and high only): work queued on it fills what the
+    caller's stream leaves idle instead of competing with it.  Falls back to an ordinary torch stream."""
+    try:
+        hip = C.CDLL("libamdhip64.so")
+        least, greatest = C.c_int(0), C.c_int(0)
+        if hip.hipDeviceGetStreamPriorityRange(C.byref(least), C.byref(greatest)) == 0 and least.value > 0:
+            h = C.c_void_p()
+            with torch.cuda.device(device):
+                if hip.hipStreamCreateWithPriority(C.byref(h), C.c_uint(1), C.c_int(least.value)) == 0 and h.value:  # (1: hipStreamNonBlocking)
+                    return torch.cuda.ExternalStream(h.value, device=device)
+    except OSError:
+        pass
+    return torch.cuda.Stream(device=device)
+
+
 class DeviceRng:
     """torch's CPU generator for the parity draw, ON THE DEVICE (glb_mt19937_exponential_rows): the MT19937 stream of
     `torch.Generator().manual_seed(seed)` entered at every particle's row at once - no serial host loop, no noise tensor
@@ -46,19 +62,45 @@ class DeviceRng:
     would yield them one after the other, and moves the stream on by the rows consumed.
 
     The stream's position is a 624-word window on the device; the jump polynomials for stride 2 V are computed on the host
-    once per vocabulary (about 0.1 s) and cached on the engine."""
+    once per vocabulary (about 0.1 s) and cached on the engine.
+
+    `ahead=True` (what `DeviceSIS` uses): the rows of the NEXT call depend on nothing but where the stream stands after this
+    one, so `prefetch()` - called once the step that consumed the rows has been queued - generates them in stream order on a
+    side stream while the caller's stream runs the next forward; the next `rows(...)` then only copies the rows its
+    `row_slot` names into place and moves the position (the same rows, bit for bit: the same kernels made them)."""
 
     SMALL = 32
 
-    def __init__(self, engine, seed, vocab):
-        self.eng, self.seed, self.vocab = engine, int(seed), int(vocab)
+    def __init__(self, engine, seed, vocab, ahead=False):
+        self.eng, self.seed, self.vocab, self.ahead = engine, int(seed), int(vocab), bool(ahead)
+        self._side = None   # the side stream
+        self._pre = None    # (max_draw, rows buffer, done event): what prefetch() has queued
+        self._ws = None     # this stream's own windows (the engine's scratch is shared by every caller)
+        self._last = None   # max_draw of the last rows() call
         self.reset()
 
     def reset(self):
+        if self._pre is not None:  # (let the side stream finish with the window before it is replaced)
+            self._pre[2].synchronize()
+            self._pre = None
         w = np.zeros(624, np.uint32)
         check(self.eng.lib.glb_mt19937_window(C.c_uint64(self.seed & 0xFFFFFFFFFFFFFFFF), C.c_void_p(w.ctypes.data)))
         self.window = torch.from_numpy(w.view(np.int32)).to(self.eng.device)
         self.rows_drawn = 0  # host-side tally when the counts are known here (diagnostic)
+
+    def _args(self, max_draw, n_big, polys):
+        eng = self.eng
+        need = eng.lib.glb_mt19937_rows_workspace(max_draw, self.SMALL)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=eng.device)
+        a = MtRowsArgs()
+        a.struct_size = C.sizeof(MtRowsArgs)
+        a.window = self.window.data_ptr()
+        a.polys = polys.data_ptr()
+        a.n_small, a.n_big = self.SMALL, n_big
+        a.vocab, a.max_draw_rows = self.vocab, max_draw
+        a.workspace, a.workspace_bytes = self._ws.data_ptr(), self._ws.numel()
+        return a
 
     def rows(self, n_out, row_slot=None, n_draw=None, max_draw=None, out=None):
         """n_out rows; row_slot: int32 [n_out] device - the stream row every output row takes (negative: a row of ones),
@@ -74,24 +116,49 @@ class DeviceRng:
             raise ValueError("row_slot must be int32 [n_out]")
         if n_draw is not None and n_draw.dtype != torch.int32:
             raise TypeError("n_draw must be an int32 device scalar")
-        need = eng.lib.glb_mt19937_rows_workspace(max_draw, self.SMALL)
-        if eng._mt_ws is None or eng._mt_ws.numel() < need:
-            eng._mt_ws = torch.empty(need, dtype=torch.uint8, device=eng.device)
-        a = MtRowsArgs()
-        a.struct_size = C.sizeof(MtRowsArgs)
-        a.window = a.window_out = self.window.data_ptr()
-        a.polys = polys.data_ptr()
-        a.n_small, a.n_big = self.SMALL, n_big
-        a.vocab, a.max_draw_rows = V, max_draw
+        pre, self._pre = self._pre, None
+        if pre is not None and pre[0] != max_draw:  # (made for another shape: wait it out - it reads the window - and drop it)
+            pre[2].synchronize()
+            pre = None
+        a = self._args(max_draw, n_big, polys)
+        a.window_out = self.window.data_ptr()
         a.n_draw = None if n_draw is None else n_draw.data_ptr()
         a.n_out_rows = n_out
         a.row_slot = None if row_slot is None else row_slot.data_ptr()
         a.out, a.out_ld = out.data_ptr(), out.stride(0) if n_out > 1 else max(V, out.stride(0))
-        a.workspace, a.workspace_bytes = eng._mt_ws.data_ptr(), eng._mt_ws.numel()
+        if pre is not None:  # the rows stand in pre[1], the windows in the workspace: copy and move on
+            torch.cuda.current_stream(eng.device).wait_event(pre[2])
+            a.reuse_windows = 1
+            a.rows_from, a.rows_from_ld = pre[1].data_ptr(), pre[1].stride(0)
+            self._keep = pre[1]
         check(eng.lib.glb_mt19937_exponential_rows(C.byref(a), eng._stream()))
         if n_draw is None:
             self.rows_drawn += max_draw
+        self._last = max_draw
         return out
+
+    def prefetch(self):
+        """Queue the generation of the next call's rows (as many as the last call could draw, in stream order) on the side
+        stream; it starts when everything queued on the current stream so far is done - call it after the step that reads
+        the last rows() has been queued.  No-op unless `ahead`."""
+        if not self.ahead or self._last is None or self._pre is not None:
+            return
+        eng, V, max_draw = self.eng, self.vocab, self._last
+        if self._side is None:
+            self._side = _low_priority_stream(eng.device)
+            self._rows_buf = None
+        if self._rows_buf is None or self._rows_buf.shape[0] < max_draw:
+            self._rows_buf = torch.empty((max_draw, V), dtype=torch.float32, device=eng.device)
+        polys, n_big = eng.mt_polys(V, max_draw + 1)
+        a = self._args(max_draw, n_big, polys)
+        a.n_out_rows = max_draw
+        a.out, a.out_ld = self._rows_buf.data_ptr(), self._rows_buf.stride(0)
+        self._side.wait_stream(torch.cuda.current_stream(eng.device))
+        with torch.cuda.stream(self._side):
+            check(eng.lib.glb_mt19937_exponential_rows(C.byref(a), eng._stream()))
+            done = torch.cuda.Event()
+            done.record(self._side)
+        self._pre = (max_draw, self._rows_buf, done)
 
 
 class PreparedMasks:
@@ -177,7 +244,6 @@ class HipEngine:
         self._ws = None
         self._step_ws = None
         self._trie_ws = None
-        self._mt_ws = None
         self._mt_polys = {}
         self._ptr_tables = {}
 
@@ -352,10 +418,10 @@ class HipEngine:
         it (run() checks)."""
         return self.step(logits, _plan=True, **kw)
 
-    def noise_rng(self, seed, vocab):
+    def noise_rng(self, seed, vocab, ahead=False):
         """The parity draw's noise source: torch's CPU generator seeded with `seed`, rows of `vocab` exponentials, on the
-        device (DeviceRng)."""
-        return DeviceRng(self, seed, vocab)
+        device (DeviceRng; ahead: the next call's rows generated on a side stream once `prefetch()` is called)."""
+        return DeviceRng(self, seed, vocab, ahead=ahead)
 
     def mt_polys(self, vocab, n_windows):
         """Device table of the MT19937 jump polynomials for rows of `vocab` exponentials (stride 2 * vocab words), enough

@@ -14,6 +14,8 @@ Two drivers of the same per-step pipeline (reference: README.md:46-115):
 """
 import asyncio
 
+import os
+
 import numpy as np
 import torch
 
@@ -169,6 +171,12 @@ class DeviceSIS:
         self.seed = seed
         self.rng_mode = RNG_PHILOX if rng == "philox" else RNG_NOISE
         self.noise_src = None  # parity draws: torch's CPU generator on the device (engine.DeviceRng), made at the first step
+        # GLB_RNG_AHEAD=1: the next step's noise rows generated on a low-priority side stream under the next forward
+        # (DeviceRng.prefetch).  Off by default: measured on one box, 1024 x gpt2-small 4.05 / 4.04 ms a step with it against
+        # 4.12 / 3.98 without, 512 x Llama-3.2-1B 4.37 / 4.44 against 4.55 / 4.50 - the generation is issue-bound work (GF(2)
+        # convolutions, the recurrence, double-precision logarithms), not something idle cycles of the forward absorb, and it
+        # costs another [N, V] buffer.
+        self.noise_ahead = os.environ.get("GLB_RNG_AHEAD", "0") == "1"
         prompts = prompt_ids if isinstance(prompt_ids[0], (list, tuple)) else [prompt_ids] * n_particles
         assert len(prompts) == n_particles
         self._prompt_len0 = torch.tensor([len(p) for p in prompts], dtype=torch.int32, device=self.dev)
@@ -453,6 +461,8 @@ class DeviceSIS:
             e1.record()
             self.kernel_events.append(inner)
             self.outer_events.append((e0, e1))
+        if self.rng_mode == RNG_NOISE:  # the next step's rows set out on a side stream, under the next forward
+            self.noise_src.prefetch()
         eng.particles_advance(self.contexts, self.lengths, self.active, self.log_weights, logZ, tok, self.eos_id,
                               self.cap, hashes=self.hashes)
         self.t += 1
@@ -549,7 +559,7 @@ class DeviceSIS:
             # (the reference is ONE process, so its stream is defined for one shard; with several ranks every rank takes a
             # stream of its own - the same rows on every rank would tie the shards' particles together.  Philox draws are
             # the shard-invariant mode.)
-            self.noise_src = self.eng.noise_rng(self.seed + 7919 * self.rank, V)
+            self.noise_src = self.eng.noise_rng(self.seed + 7919 * self.rank, V, ahead=self.noise_ahead)
         act = self.active > 0
         key = torch.where(act, group_of.to(torch.int64), torch.full((N,), 1 << 40, dtype=torch.int64, device=self.dev))
         order = torch.argsort(key, stable=True)

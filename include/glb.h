@@ -617,6 +617,15 @@ typedef struct glb_mt_rows_args {
   int64_t out_ld;           /* >= vocab */
   void *workspace;          /* >= glb_mt19937_rows_workspace(max_draw_rows, n_small) bytes */
   size_t workspace_bytes;
+  /* Two-phase use (ABI 8), for a caller that generates the NEXT step's rows ahead of time on another stream - they do not
+   * depend on the step's data, only on where the stream stands -: call 1 (ahead): row_slot null, n_out_rows = the rows
+   * that may be needed, out = a buffer G, window_out null.  Call 2 (when the step knows its row_slot and n_draw), same
+   * window / polys / max_draw_rows / workspace: reuse_windows = 1 (the workspace still holds every row's window: the two
+   * jump launches are skipped), rows_from = G (out rows are COPIED from G[row_slot[i]], ones for a negative slot, instead of
+   * generated), window_out = the position after *n_draw rows.  Both 0 / null: one call does everything. */
+  int32_t reuse_windows;
+  const float *rows_from;   /* [>= max_draw_rows, rows_from_ld] */
+  int64_t rows_from_ld;
 } glb_mt_rows_args;
 size_t glb_mt19937_rows_workspace(int64_t max_draw_rows, int32_t n_small);
 int glb_mt19937_exponential_rows(const glb_mt_rows_args *args, void *hip_stream);

@@ -34,6 +34,9 @@ class _OracleNoise:
     def reset(self):
         self.state = None
 
+    def prefetch(self):  # (DeviceRng's side-stream generation: nothing to get ahead of here)
+        pass
+
     def rows(self, n_out, row_slot=None, n_draw=None, max_draw=None, out=None):
         V = self.vocab
         slot = np.arange(n_out) if row_slot is None else row_slot.cpu().numpy()
@@ -49,7 +52,7 @@ class _OracleNoise:
 class CpuOracleEngine:
     device = torch.device("cpu")
 
-    def noise_rng(self, seed, vocab):
+    def noise_rng(self, seed, vocab, ahead=False):
         return _OracleNoise(seed, vocab)
 
     def prepare_masks(self, bits, vocab, logits_dtype=torch.float32):

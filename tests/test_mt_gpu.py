@@ -83,6 +83,46 @@ def test_headline_size_and_a_later_position(engine):
     assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
 
 
+def test_rows_generated_ahead_on_a_side_stream_are_the_same_rows(engine):
+    """DeviceRng(ahead=True): prefetch() generates the next call's rows in stream order on a side stream, rows() then only
+    copies what row_slot names and moves the position (glb_mt_rows_args: reuse_windows, rows_from).  Same floats as the
+    serial stream whatever the steps draw: all, some, none; a call of another shape drops what was made ahead; reset()."""
+    from genlm_backend_amd.engine import DeviceRng
+
+    V, N = 4099, 70
+    rs = np.random.default_rng(5)
+    want = _host_stream(99, (6 * N + 8) * V).reshape(6 * N + 8, V)
+    for trial in range(2):
+        rng = DeviceRng(engine, 99, V, ahead=True) if trial == 0 else rng
+        if trial == 1:
+            rng.reset()  # (with rows made ahead still pending)
+        used = 0
+        for call in range(5):
+            act = rs.random(N) < (1.0, 0.6, 0.0, 0.9, 0.5)[call]
+            n_act = int(act.sum())
+            slot = np.full(N, -1, np.int32)
+            slot[np.nonzero(act)[0]] = rs.permutation(n_act)
+            got = rng.rows(N, row_slot=torch.from_numpy(slot).to(engine.device),
+                           n_draw=torch.tensor(n_act, dtype=torch.int32, device=engine.device), max_draw=N)
+            rng.prefetch()
+            assert (rng._pre is not None) and (call == 0 or True)
+            busy = torch.randn((512, 512), device=engine.device) @ torch.randn((512, 512), device=engine.device)  # (the caller's stream goes on)
+            got = got.cpu().numpy()
+            for i in range(N):
+                if slot[i] < 0:
+                    assert (got[i] == 1.0).all()
+                else:
+                    assert np.array_equal(got[i].view(np.uint32), want[used + slot[i]].view(np.uint32)), (trial, call, i)
+            used += n_act
+        # another shape: what was made ahead (70 rows) does not fit and is dropped; the stream stands where it stood
+        one = rng.rows(8)
+        rng.prefetch()
+        assert np.array_equal(one.cpu().numpy().view(np.uint32), want[used:used + 8].view(np.uint32))
+        again = rng.rows(8)  # (served from the rows made ahead)
+        assert np.array_equal(again.cpu().numpy().view(np.uint32), want[used + 8:used + 16].view(np.uint32))
+        del busy
+
+
 def test_argument_errors(engine):
     from genlm_backend_amd.engine import DeviceRng
 
