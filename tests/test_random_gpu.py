@@ -195,7 +195,7 @@ TRIE_CASES = [dict(seed=9000 + i) for i in range(max(4, int(os.environ.get("GLB_
 def test_random_trie_selections(engine, oracle, c):
     """Selections of trie nodes on random vocabularies and part sizes: one selection for every row (the sub-forest plan) and a
     selection per row (parts a row does not need are skipped) give the whole trie's values of those nodes, bit for bit, and
-    the whole trie's values are the oracle's."""
+    the whole trie's values are the oracle's - through the gathered plan and through the sweep plan."""
     from genlm_backend_amd.tokenization import Token
     from genlm_backend_amd.trie import TokenByteTrie
 
@@ -236,3 +236,11 @@ def test_random_trie_selections(engine, oracle, c):
     idx = torch.from_numpy(np.where(per >= 0, per, 0).astype(np.int64)).to(dev)
     want = torch.where(torch.from_numpy(per >= 0).to(dev), torch.gather(rows, 1, idx), torch.zeros_like(got))
     assert torch.equal(got, want)
+    # the sweep plan (persistent workgroups read the rows front to back) on a random cut: the same bits for all nodes, the
+    # slots, the per-row selection
+    sw = trie.plan_device_arrays(int(rs.choice([60, 250, 1000, 20000])), sweep=True)
+    if sw is not None:
+        assert torch.equal(engine.trie_rows(wd, sw, op, False), full)
+        assert torch.equal(engine.trie_rows(xd, sw, 0, True, lse=lse, layout="slots")[:, sw["slot_of"].long()], rows)
+        if sw["n_parts"] <= 62:
+            assert torch.equal(engine.trie_rows(xd, sw, 0, True, lse=lse, nodes=torch.from_numpy(per).to(dev)), want)
