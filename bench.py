@@ -286,7 +286,18 @@ def main():
     ap.add_argument("--no-kv-line", action="store_true", help="default sis workload: do not also time the shared-KV-rows variant (value_kv)")
     ap.add_argument("--no-rccl-single", action="store_true",
                     help="N = 1 sis workloads: do NOT route the per-step exchange through a one-rank RCCL group")
+    ap.add_argument("--tune-gemms", action="store_true",
+                    help="let PyTorch's TunableOp pick, per GEMM shape, the fastest of the library's own solutions (rocBLAS / hipBLASLt) "
+                         "during the warm-up steps: 10-30 s more wall time; measured 3.37 -> 3.22 ms (sis --particle-kv) and 3.48 -> "
+                         "3.39 ms (sis-llama --particle-kv) a step.  Off by default: the choice changes the order of the GEMMs' "
+                         "additions (last bits of the logits), and the shapes of the re-encoding loop change every step")
     args = ap.parse_args()
+    if args.tune_gemms:
+        import torch.cuda.tunable as tunable
+
+        tunable.enable(True)
+        tunable.tuning_enable(True)
+        tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), "glb_tunableop.csv"), insert_device_ordinal=True)
 
     world_env = os.environ.get("WORLD_SIZE")
     if world_env is None and args.gpus > 1:
