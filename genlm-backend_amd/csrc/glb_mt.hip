@@ -335,14 +335,10 @@ __global__ __launch_bounds__(256) void mt_rows_kernel(const uint32_t *__restrict
       const uint32_t first = mt_temper(st[i & (kRing - 1)]), second = mt_temper(st[(i + 1) & (kRing - 1)]);
       // the float by the short form; the one value in 10^5 whose double lies too near a rounding boundary for it to tell (one
       // wave in 1 500) by glibc's own form
-#ifdef GLB_MT_NOEXP  // (timing experiment: everything but the logarithm)
-      o[v0 + t] = (float)(first ^ second);
-#else
       bool redo;
       float e = glb::exponential_fast(first, second, tab_inv, tab_hi, &redo);
       if (redo) e = glb::exponential_from_words(first, second);
       o[v0 + t] = e;
-#endif
     }
     pos = (pos + 2 * kStep) & (kRing - 1);
     // (the next round writes ring positions pos + 624 + [0, 454) of the NEW pos - 454 past what this round's readers

@@ -330,9 +330,6 @@ template <int OP>
 __device__ __forceinline__ void sweep_node(float *val, uint64_t e) {
   const int s = (int)(e & 0xffffu), c0 = (int)((e >> 16) & 0xffffu), cnt = (int)(e >> 32);
   double acc = 0.0;
-#if defined(GLB_TRIE_EXP) && GLB_TRIE_EXP == 1
-  float facc = 0.0f;
-#endif
   for (int base = 0; __any(base < cnt); base += 8) {
     const float *q = val + c0 + base;
     const int rem = cnt - base;
@@ -342,12 +339,8 @@ __device__ __forceinline__ void sweep_node(float *val, uint64_t e) {
       for (int j = 0; j < 8; ++j) x[j] = q[j];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-#if defined(GLB_TRIE_EXP) && GLB_TRIE_EXP == 1
-        facc += (j < rem ? x[j] : 0.0f);
-#else
         if constexpr (OP == GLB_TRIE_SUM) acc += (double)(j < rem ? x[j] : 0.0f);
         else acc = j < rem ? fmax(acc, (double)x[j]) : acc;
-#endif
       }
     } else {
       float x[4];
@@ -355,18 +348,11 @@ __device__ __forceinline__ void sweep_node(float *val, uint64_t e) {
       for (int j = 0; j < 4; ++j) x[j] = q[j];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-#if defined(GLB_TRIE_EXP) && GLB_TRIE_EXP == 1
-        facc += (j < rem ? x[j] : 0.0f);
-#else
         if constexpr (OP == GLB_TRIE_SUM) acc += (double)(j < rem ? x[j] : 0.0f);
         else acc = j < rem ? fmax(acc, (double)x[j]) : acc;
-#endif
       }
     }
   }
-#if defined(GLB_TRIE_EXP) && GLB_TRIE_EXP == 1
-  acc = facc;
-#endif
   val[s] = (float)acc;
 }
 
