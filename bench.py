@@ -286,18 +286,22 @@ def main():
     ap.add_argument("--no-kv-line", action="store_true", help="default sis workload: do not also time the shared-KV-rows variant (value_kv)")
     ap.add_argument("--no-rccl-single", action="store_true",
                     help="N = 1 sis workloads: do NOT route the per-step exchange through a one-rank RCCL group")
-    ap.add_argument("--tune-gemms", action="store_true",
-                    help="let PyTorch's TunableOp pick, per GEMM shape, the fastest of the library's own solutions (rocBLAS / hipBLASLt) "
-                         "during the warm-up steps: 10-30 s more wall time; measured 3.37 -> 3.22 ms (sis --particle-kv) and 3.48 -> "
-                         "3.39 ms (sis-llama --particle-kv) a step.  Off by default: the choice changes the order of the GEMMs' "
-                         "additions (last bits of the logits), and the shapes of the re-encoding loop change every step")
+    ap.add_argument("--gemms", choices=["recorded", "library", "tune"], default="recorded",
+                    help="which of the GEMM library's own solutions PyTorch runs (genlm_backend_amd.gemm_tuning, torch.cuda.tunable): "
+                         "recorded (default) - the shapes in genlm-backend_amd/tuned/<arch>.csv by their recorded solution, everything "
+                         "else (and everything, if the file was made by another build of the libraries) by the library's default; "
+                         "library - the defaults; tune - time the solutions of every new shape during the warm-up (seconds a shape) "
+                         "and write --gemms-file at exit")
+    ap.add_argument("--gemms-file", default=None, help="--gemms tune: the file to extend (default: $TMPDIR/glb_tunableop.csv)")
     args = ap.parse_args()
-    if args.tune_gemms:
-        import torch.cuda.tunable as tunable
+    args.gemm_shapes = 0
+    if args.workload not in ("kernel", "kernel-llama", "trie", "plumbing"):
+        from genlm_backend_amd import gemm_tuning
 
-        tunable.enable(True)
-        tunable.tuning_enable(True)
-        tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), "glb_tunableop.csv"), insert_device_ordinal=True)
+        if args.gemms == "tune":
+            gemm_tuning.record(args.gemms_file or os.path.join(os.environ.get("TMPDIR", "/tmp"), "glb_tunableop.csv"))
+        elif args.gemms == "recorded":
+            args.gemm_shapes = gemm_tuning.use_recorded()
 
     world_env = os.environ.get("WORLD_SIZE")
     if world_env is None and args.gpus > 1:
@@ -453,6 +457,13 @@ def main():
             "data": "synthetic",
             "config": runner.config(),
         }
+        if args.workload not in ("kernel", "kernel-llama", "trie", "plumbing"):
+            out["config"]["gemms"] = {
+                "recorded": f"PyTorch TunableOp: {args.gemm_shapes} shapes of genlm-backend_amd/tuned/<arch>.csv run by their recorded "
+                            "rocBLAS / hipBLASLt solution, the rest by the library's default" if args.gemm_shapes else
+                            "the library's default solutions (no recorded file for this build of the libraries)",
+                "library": "the library's default solutions",
+                "tune": "PyTorch TunableOp, tuned during the warm-up"}[args.gemms]
         if rccl_ranks is not None:
             if args.rehearse_one_gpu and world > 1:  # every rank on cuda:0, exchange over gloo: NOT a measurement
                 out["rehearsal_one_gpu"] = True

@@ -1,0 +1,68 @@
+"""Which of the GEMM library's own solutions PyTorch runs for a shape (torch.cuda.tunable, "TunableOp").
+
+The transformer forward of this backend is PyTorch's; its time is GEMMs (82 % of a re-encoding GPT-2 step, two thirds of a
+KV-row step), and for every (transposes, m, n, k, leading dimensions) rocBLAS / hipBLASLt hold dozens of kernels of which
+the default heuristic picks one.  TunableOp times them once per shape and records the winner; a recorded file is tied to
+the build of PyTorch, HIP, rocBLAS, hipBLASLt and the GPU it was made on (the file's "Validator" lines - PyTorch refuses a
+file whose validators differ and runs the default solutions).
+
+    use_recorded()      run the shapes recorded in tuned/<arch>.csv with their recorded solution; every other shape, and
+                        every shape when the file does not fit this installation, by the library's default.  No tuning,
+                        no extra time.  Measured on the shapes of `bench.py` (1024 particles, GPT-2-small, fp32): 19.2
+                        -> 17.8 ms a re-encoding step, 3.37 -> 3.22 ms a KV-row step.
+    record(path)        tune every new shape this process meets (seconds a shape, once) and write `path` at exit:
+                        how tuned/<arch>.csv was made (tools/record_gemm_tuning.sh) and how to add an application's shapes.
+
+Process-wide switches of PyTorch, so nothing here is called by the backend itself: `bench.py` asks for the recorded
+solutions (--gemms recorded, its default), an application calls `use_recorded()` if it wants them.  The solutions are the
+library's kernels at the tensors' own precision; what changes is the order of a GEMM's additions (the last bits of the
+logits), as between any two library versions."""
+import os
+
+import torch
+
+_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned")
+
+
+def recorded_file(device=None):
+    """tuned/<arch>.csv for the device's architecture (gfx950: MI355X), or None."""
+    if not torch.cuda.is_available():
+        return None
+    arch = torch.cuda.get_device_properties(device if device is not None else torch.cuda.current_device()).gcnArchName.split(":")[0]
+    path = os.path.join(_DIR, f"{arch}.csv")
+    return path if os.path.exists(path) else None
+
+
+def use_recorded(path=None, device=None):
+    """Run recorded shapes with their recorded solutions.  Returns the number of shapes taken over (0: no file for this
+    architecture, or one made by another build of the libraries - the library's defaults stay in charge)."""
+    import torch.cuda.tunable as tunable
+
+    path = path or recorded_file(device)
+    if path is None:
+        return 0
+    tunable.enable(True)
+    tunable.tuning_enable(False)
+    tunable.record_untuned_enable(False)
+    ok = tunable.read_file(path)
+    n = len(tunable.get_results()) if ok else 0
+    if n == 0:
+        tunable.enable(False)
+    return n
+
+
+def record(path):
+    """Tune every shape this process meets that `path` does not hold yet; PyTorch writes `path` when the process ends."""
+    import torch.cuda.tunable as tunable
+
+    tunable.enable(True)
+    tunable.tuning_enable(True)
+    tunable.set_filename(path, insert_device_ordinal=False)
+    if os.path.exists(path):
+        tunable.read_file(path)
+
+
+def off():
+    import torch.cuda.tunable as tunable
+
+    tunable.enable(False)
