@@ -879,3 +879,21 @@ def test_load_model_by_name_end_to_end_offline(tmp_path):
     for bad in ("vllm", "mlx", "nonsense"):
         with pytest.raises(ValueError):
             load_model_by_name(str(tmp_path), backend=bad)
+
+
+def test_recorded_gemm_solutions_file_is_well_formed_and_optional():
+    """genlm_backend_amd.gemm_tuning: the shipped tuned/<arch>.csv is a TunableOp results file (validator lines, then one
+    line per GEMM shape: operation, shape key, solution name, time); without a GPU nothing is switched on."""
+    import os
+
+    from genlm_backend_amd import gemm_tuning
+
+    assert gemm_tuning.recorded_file() is None and gemm_tuning.use_recorded() == 0  # (no GPU here)
+    path = os.path.join(os.path.dirname(gemm_tuning.__file__), "tuned", "gfx950.csv")
+    lines = open(path).read().splitlines()
+    vals = [ln for ln in lines if ln.startswith("Validator,")]
+    assert {v.split(",")[1] for v in vals} >= {"PT_VERSION", "HIPBLASLT_VERSION", "ROCBLAS_VERSION", "GCN_ARCH_NAME"}
+    ents = [ln.split(",") for ln in lines if ln and not ln.startswith("Validator,")]
+    assert len(ents) > 100 and all(len(e) == 4 and e[0].startswith("Gemm") and float(e[3]) > 0 for e in ents)
+    assert len({(e[0], e[1]) for e in ents}) == len(ents)  # (a shape once)
+    assert any(e[1].startswith("tn_50257_1024_768") for e in ents)  # (BASELINE config 2's lm_head)

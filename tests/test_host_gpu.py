@@ -1867,3 +1867,26 @@ def test_short_attention_matches_torch(engine, dtype, U, H, Hkv, Lq, Lk, Dh):
         assert out.shape == (U, Lq, H, Dh) and out.dtype == dtype
         assert (out.float() - want)[live].abs().max().item() < tol
         assert not bool(out[~live].any())
+
+
+def test_recorded_gemm_solutions_give_the_librarys_results_within_rounding(engine):
+    """gemm_tuning.use_recorded(): on an MI355X with the libraries the file was recorded with, the recorded shapes run by
+    their recorded rocBLAS / hipBLASLt solution - the same product up to the order of the additions - and `off()` hands the
+    choice back; with other libraries PyTorch refuses the file and 0 shapes are taken over (still fine)."""
+    from genlm_backend_amd import gemm_tuning
+
+    dev = engine.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    a = torch.randn((1024, 768), device=dev, generator=g)
+    w = torch.randn((50257, 768), device=dev, generator=g)
+    ref = a @ w.t()
+    n = gemm_tuning.use_recorded()
+    try:
+        got = a @ w.t()
+        torch.cuda.synchronize()
+        assert n == 0 or n > 100
+        assert (got - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    finally:
+        gemm_tuning.off()
+    assert torch.equal(a @ w.t(), ref)
