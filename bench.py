@@ -295,13 +295,6 @@ def main():
     ap.add_argument("--gemms-file", default=None, help="--gemms tune: the file to extend (default: $TMPDIR/glb_tunableop.csv)")
     args = ap.parse_args()
     args.gemm_shapes = 0
-    if args.workload not in ("kernel", "kernel-llama", "trie", "plumbing"):
-        from genlm_backend_amd import gemm_tuning
-
-        if args.gemms == "tune":
-            gemm_tuning.record(args.gemms_file or os.path.join(os.environ.get("TMPDIR", "/tmp"), "glb_tunableop.csv"))
-        elif args.gemms == "recorded":
-            args.gemm_shapes = gemm_tuning.use_recorded()
 
     world_env = os.environ.get("WORLD_SIZE")
     if world_env is None and args.gpus > 1:
@@ -335,6 +328,13 @@ def main():
     if cpu_only:
         return plumbing(args, rank, world, dist)
     dev = torch.device("cuda", local_rank)
+    if args.workload not in ("kernel", "kernel-llama", "trie"):  # (here, in the rank's own process: the parent that starts the ranks never touches the GPU)
+        from genlm_backend_amd import gemm_tuning
+
+        if args.gemms == "tune":
+            gemm_tuning.record(args.gemms_file or os.path.join(os.environ.get("TMPDIR", "/tmp"), "glb_tunableop.csv"))
+        elif args.gemms == "recorded":
+            args.gemm_shapes = gemm_tuning.use_recorded(device=dev)
     torch.cuda.set_device(dev)
 
     import genlm_backend_amd  # noqa: F401
