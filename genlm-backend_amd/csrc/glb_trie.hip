@@ -287,14 +287,15 @@ __global__ __launch_bounds__(kMaxThreads, 6) void trie_rows_kernel(TrieRowsParam
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Round 5: the same (row, part) workgroup, but the row is READ FRONT TO BACK instead of gathered.  A gathered part touches
-// nearly every 64-byte sector of the row for 1.8 of its tokens, so nine parts ask the L2 for the row nine times over, a
-// request per 1.8 tokens: 28 M sector requests a launch at 1024 x 50257, the rate that bounds the kernel above.  Here only
-// the part's VALUES live in LDS (4 bytes a slot: parts of 40 000 slots, two for the 66 k slots of a 50 k vocabulary, one
-// 1024-thread workgroup a CU); the workgroup streams the whole row in 16-byte loads next to `tok_local16[part]` (16 bytes
-// for 8 tokens: the token's slot in this part, or 0xffff), and drops its own tokens' weights into LDS; the internal nodes
-// come depth by depth from `inode64` in global memory (the same for every row: L2), a depth ahead of the reduction.
-// Requests per row: parts x (row + table) in 128-byte lines instead of a sector per 1.8 tokens per part.
+// Round 5: a (row, part) is still one workgroup's, but the row is READ FRONT TO BACK instead of gathered.  A gathered part
+// touches nearly every 64-byte sector of the row for 1.8 of its tokens, so nine parts ask the L2 for the row nine times
+// over, a request per 1.8 tokens: 28 M sector requests a launch at 1024 x 50257, the rate that bounds the kernel above.
+// Here only the part's VALUES live in LDS (4 bytes a slot: parts of 40 000 slots, two for the 66 k slots of a 50 k
+// vocabulary, one 1024-thread workgroup a CU); the workgroup streams the whole row in 16-byte loads and stores EVERY
+// token's weight through `tok_local16[part]` (the token's slot in this part; another part's token: a word of the slack
+// behind the values); the part's internal nodes (`inode64`) and the tokens' slots stay in registers from row to row - the
+// workgroup is persistent (trie_sweep_kernel below).  Requests per row: parts x the row in 128-byte lines instead of a
+// sector per 1.8 tokens per part (20.8 M L1 accesses a call where the gathered kernel makes 103 M).
 // ---------------------------------------------------------------------------------------------------------------------
 template <int DT>
 struct RowVec;
