@@ -488,7 +488,7 @@ __global__ __launch_bounds__(kNT) void trie_sweep_kernel(TrieRowsParams p, int n
       if (p.op == GLB_TRIE_SUM) sweep_reduce<GLB_TRIE_SUM, kNT, kQ>(val, ent, dv, v.n_depths, tid, in64 GLB_DIAG(, st));
       else sweep_reduce<GLB_TRIE_MAX, kNT, kQ>(val, ent, dv, v.n_depths, tid, in64 GLB_DIAG(, st));
       GLB_TRIE_STAMP(3)
-      part_write<1, OUT>(p, v, val, false, r_prev, tid, nt);
+      part_write<(OUT == 2 ? 4 : 1), OUT>(p, v, val, false, r_prev, tid, nt);  // (all nodes: four node-list reads in flight - with one the write-out waits for the L2 24 times)
       if (p.cut_vals) {
         float *cv = p.cut_vals + (int64_t)r_prev * p.n_cut + v.d[D_CUT_BASE];
         const int n_roots = v.d[D_N_ROOTS];
