@@ -130,7 +130,6 @@ class DeviceRng:
             torch.cuda.current_stream(eng.device).wait_event(pre[2])
             a.reuse_windows = 1
             a.rows_from, a.rows_from_ld = pre[1].data_ptr(), pre[1].stride(0)
-            self._keep = pre[1]
         check(eng.lib.glb_mt19937_exponential_rows(C.byref(a), eng._stream()))
         if n_draw is None:
             self.rows_drawn += max_draw
