@@ -595,7 +595,7 @@ class TrieWorkload:
                 seen.add(w)
                 words.append(w)
         self.trie = TokenByteTrie([Token(i, w) for i, w in enumerate(words)], engine=eng)
-        self.plan = self.trie.slot_plan() if out in ("rows", "slots") else self.trie.plan()  # (the plan the timed call runs on)
+        self.plan = self.trie.slot_plan() if out in ("rows", "slots", "rowsel-root") else self.trie.plan()  # (the plan the timed call runs on)
         g = torch.Generator(device=dev)
         g.manual_seed(77 + rank)
         self.bufs = [torch.randn((B, V), device=dev, generator=g) * 3.0 for _ in range(nbuf)]
@@ -629,7 +629,7 @@ class TrieWorkload:
     def step(self, i, timed):
         x, lse = self.bufs[i % len(self.bufs)], self.lse[i % len(self.bufs)]
         kw = {"rows": dict(layout="rows"), "slots": dict(layout="slot_rows"), "selected": dict(nodes=self.sel),
-              "rowsel": dict(nodes=self.rowsel), "rowsel-root": dict(nodes=self.rowsel)}[self.out_kind]
+              "rowsel": dict(nodes=self.rowsel), "rowsel-root": dict(nodes=self.rowsel, wide_selections=True)}[self.out_kind]
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -648,7 +648,7 @@ class TrieWorkload:
     def config(self):
         pl = self.plan
         return {"workload": f"token->byte trie masses of {self.B} rows of [{self.B}, {self.V}] fp32 logits + lse -> "
-                            f"{ {'rows': 'all nodes, row-major', 'slots': 'the folded trie slots, row-major', 'selected': '4096 selected nodes (only the subtrees below them planned)', 'rowsel': 'a selection per row: the children of the row-s own depth-1 node', 'rowsel-root': 'a selection per row: the children of the root (every part)'}[self.out_kind] }"
+                            f"{ {'rows': 'all nodes, row-major', 'slots': 'the folded trie slots, row-major', 'selected': '4096 selected nodes (only the subtrees below them planned)', 'rowsel': 'a selection per row: the children of the row-s own depth-1 node', 'rowsel-root': 'a selection per row: the children of the root (every part; wide_selections: the sweep plan)'}[self.out_kind] }"
                             f" (glb_trie_rows; {len(self.trie)} nodes, {pl['n_slots']} slots in {pl['n_parts']} parts of <= {pl['max_local']}; "
                             "synthetic vocabulary of 1-8 letter byte strings)",
                 "rows_per_gpu": self.B, "vocab": self.V}

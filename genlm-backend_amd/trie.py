@@ -546,13 +546,16 @@ class TokenByteTrie:
     def batch_weight_max_device(self, ws, from_logprobs=False):
         return self._batch(ws, 1, from_logprobs)
 
-    def masses_from_logits(self, logits, lse=None, nodes=None, layout="rows", op=0, logit_scale=1.0):
+    def masses_from_logits(self, logits, lse=None, nodes=None, layout="rows", op=0, logit_scale=1.0, wide_selections=False):
         """Masses of softmax(logits * logit_scale) straight from the logits rows ([B, V] float32 / bfloat16 / float16 on
         the device) and the rows' lse (float32 [B]: the fused step's `lse` output; None: computed here, `HipEngine.row_lse`):
         what the reference gets from `batch_weight_sum(logprobs.exp())` (trie/parallel.py:92-103) without the [B, V]
         matrix of log-probabilities ever being written.  nodes: int32 device tensor - only these nodes' masses,
         [B, len(nodes)] (only the subtrees below them are read and reduced: `selection_plan`) - or int32 [B, K]: every row's
-        OWN nodes, e.g. each particle's current node's children (negative entries: none), [B, K]; layout "slots": node-major [n_slots, pitch] over the folded trie (`compact()`: the value of node
+        OWN nodes, e.g. each particle's current node's children (negative entries: none), [B, K] (wide_selections=True: most
+        rows' nodes lie above the parts - the root's children, after a token boundary -, so nearly every row needs nearly
+        every part: the sweep plan's two parts then beat the gathered plan's nine, 168 -> 100 us at 1024 x 50257; a row
+        that needs one part of nine is better off gathered: 58 against 99 us); layout "slots": node-major [n_slots, pitch] over the folded trie (`compact()`: the value of node
         n for row r is at [slot_of[n], r] - nothing is transposed back); layout "nodes": the same over all nodes,
         [n_nodes, pitch] (see HipEngine.trie_masses); layout "slot_rows": row-major [B, n_slots] over the plan's slots
         (`slot_plan()["slot_of"]`: node -> slot) - the cheapest form: the logits are read once and nothing else is written."""
@@ -564,7 +567,12 @@ class TokenByteTrie:
             raise TypeError("nodes must be int32")
         pl = None
         if self.resident and layout in ("rows", "slot_rows"):
-            pl = self._whole_plan_device(logits.shape[0], slots=layout == "slot_rows") if nodes is None else self.plan_device_arrays()
+            if nodes is None:
+                pl = self._whole_plan_device(logits.shape[0], slots=layout == "slot_rows")
+            elif nodes.dim() == 2 and wide_selections and self.sweep and (self.plan(sweep=True) or {}).get("n_parts", 99) <= 62:
+                pl = self.plan_device_arrays(sweep=True)
+            else:
+                pl = self.plan_device_arrays()
         if pl is not None and nodes is not None and nodes.dim() == 1 and layout == "rows" and self.prune_selection:
             # only the subtrees below the selected nodes are read and reduced (a plan of that sub-forest, cached per selection)
             pl = self.selection_plan(nodes) or pl

@@ -975,6 +975,9 @@ def test_trie_sweep_kernel_equals_the_gathered_one_and_the_oracle(engine, oracle
             got = engine.trie_rows(xd, sw, 0, True, lse=lse, nodes=rsd)
             want = torch.where(rsd >= 0, torch.gather(rows, 1, rsd.clamp(min=0).long()), torch.zeros((), device=dev))
             assert torch.equal(got, want)
+            if cap is None:  # (the host entry point's hint that the selections are wide: the default sweep plan)
+                assert torch.equal(trie.masses_from_logits(xd, lse, nodes=rsd, wide_selections=True), want)
+                assert torch.equal(trie.masses_from_logits(xd, lse, nodes=rsd), want)
 
 
 def test_trie_sweep_kernel_on_deep_and_tiny_tries(engine, oracle):
