@@ -500,6 +500,7 @@ __global__ __launch_bounds__(kNT) void trie_sweep_kernel(TrieRowsParams p, int n
         wait_half = false;
         const uint64_t now = __builtin_amdgcn_s_memrealtime();
         uint64_t half = (now - t_first) >> 1;
+        GLB_DIAG(if (stagger > 1) half = ((now - t_first) * (uint64_t)stagger) >> 4;)  // (diagnostic build: GLB_TRIE_STAGGER = sixteenths of a row's time)
         if (half > 2000) half = 2000;  // (20 us at 100 MHz: never a long wait, whatever the clock read)
         while (__builtin_amdgcn_s_memrealtime() - now < half) __builtin_amdgcn_s_sleep(8);
       }
