@@ -417,3 +417,30 @@ def test_trie_plan_gives_the_reference_masses(gold, oracle, cap):
             got = _run_plan(sw, ws, op)
             assert np.array_equal(got.view(np.uint32), oracle.trie_reduce(ws, trie.flat(), op).view(np.uint32))
         assert trie.slot_plan() is trie.plan(sweep=True) and trie.plan(sweep=True)["n_parts"] == 1  # (small tries: one part, no top)
+
+
+def test_sweep_cap_packs_the_trie_into_the_parts_it_promises():
+    """TokenByteTrie.sweep_cap / _count_parts (round 5): the part count predicted from the cut and the packing alone is the
+    one `_build_plan` makes, and the cap chosen for the sweep plan gives the fewest parts the LDS limit allows, each within
+    it - on a vocabulary big enough for several parts when the limit is lowered."""
+    from genlm_backend_amd.tokenization import Token
+    from genlm_backend_amd.trie import TokenByteTrie
+
+    rs = np.random.default_rng(12)
+    words, seen = [], set()
+    while len(words) < 6000:
+        w = bytes(rs.integers(97, 110, int(rs.integers(1, 7))).astype(np.uint8))
+        if w not in seen:
+            seen.add(w)
+            words.append(w)
+    trie = TokenByteTrie([Token(i, w) for i, w in enumerate(words)])
+    n_slots = int(trie.compact()["n_nodes"])
+    for cap in (500, 1500, 4000, n_slots):
+        pl = trie.plan(cap, sweep=True)
+        assert pl is not None and trie._count_parts(cap) == pl["n_parts"] and pl["max_local"] <= cap
+    trie.SWEEP_LOCAL_MAX = 3000  # (as if the LDS held 3000 slots)
+    cap = trie.sweep_cap()
+    pl = trie.plan(sweep=True)
+    assert cap <= 3000 and pl["cap"] == cap and pl["max_local"] <= cap
+    assert pl["n_parts"] <= -(-n_slots // 3000) + 1  # (the fewest parts, give or take one for the packing)
+    assert pl["lds_bytes"] == 4 * pl["max_local"] + 128 and pl["tok_local16"].shape == (pl["n_parts"] * ((len(words) + 7) & ~7),)
