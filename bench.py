@@ -292,6 +292,10 @@ def main():
                          "else (and everything, if the file was made by another build of the libraries) by the library's default; "
                          "library - the defaults; tune - time the solutions of every new shape during the warm-up (seconds a shape) "
                          "and write --gemms-file at exit")
+    ap.add_argument("--contract", choices=["poly", "hw", "auto"], default="poly",
+                    help="arithmetic of the fused step's terms (include/glb.h GLB_STEP_HW_EXP): poly - the polynomial exponential, "
+                         "bit for bit the oracle's; hw / auto - v_exp_f32 for 16-bit logits (checked against the oracle by tolerance), "
+                         "the polynomial for float32 rows")
     ap.add_argument("--gemms-file", default=None, help="--gemms tune: the file to extend (default: $TMPDIR/glb_tunableop.csv)")
     args = ap.parse_args()
     args.gemm_shapes = 0
@@ -340,7 +344,7 @@ def main():
     import genlm_backend_amd  # noqa: F401
     from genlm_backend_amd.engine import HipEngine
 
-    eng = HipEngine(dev)
+    eng = HipEngine(dev, contract=args.contract)
     workload = args.workload
     # N = 1: the SIS workloads still run the multi-rank code - a one-rank "nccl" group carries the per-step all-gather
     # of log-weights (and the resampling exchange) through RCCL, exactly the calls an 8-GPU run makes
@@ -807,7 +811,9 @@ class KernelWorkload:
         extra = {"us_race_only_mean": float(np.mean(self.race_times_us()))} if self.parity and self.events else {}
         return {"workload": f"fused step only: {shape} ld=V, {rows}, {masks}, {draw}, 4 rotating logits buffers",
                 "particles_per_gpu": self.B, "vocab": self.V, "rng": "parity (torch CPU generator on the device)" if self.parity else "philox",
-                "logits": self.logits_kind, "mask": self.mask_mode, **extra}
+                "logits": self.logits_kind, "mask": self.mask_mode,
+                "contract": ("hardware exponential (v_exp_f32; GLB_STEP_HW_EXP)" if self.llama and self.eng.contract != "poly"
+                             else "polynomial exponential (bit for bit the oracle's)"), **extra}
 
 
 class ApiWorkload:

@@ -9,11 +9,12 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libglb_hip.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 GLB_OK, GLB_EINVAL, GLB_EUNSUPPORTED, GLB_EHIP, GLB_ENOSPC = 0, 1, 2, 3, 4
 F32, BF16, F16 = 0, 1, 2
 MASK_NONE, MASK_BITS, MASK_F32, MASK_PREPARED = 0, 1, 2, 3
 RNG_NONE, RNG_PHILOX, RNG_NOISE = 0, 1, 2
+STEP_HW_EXP = 1  # glb_step_args.flags: the hardware-exponential contract of 16-bit rows
 
 
 class GlbError(RuntimeError):

@@ -21,9 +21,10 @@
 namespace glb {
 // launchers exported by the three glb_chunk_tu.hip translation units (one per element type)
 #define GLB_DECL(dt)                                                                                              \
-  hipError_t launch_stats_##dt(const StepParams &p, int mask_kind, bool scaled, hipStream_t s);                    \
-  hipError_t launch_fused_step_##dt(const StepParams &p, int mask_kind, int mode, bool scaled, hipStream_t s);     \
-  hipError_t launch_finish_##dt(const StepParams &p, int mask_kind, int mode, hipStream_t s);                     \
+  hipError_t launch_stats_##dt(const StepParams &p, int mask_kind, bool scaled, int expc, hipStream_t s);          \
+  hipError_t launch_fused_step_##dt(const StepParams &p, int mask_kind, int mode, bool scaled, int expc,          \
+                                    hipStream_t s);                                                               \
+  hipError_t launch_finish_##dt(const StepParams &p, int mask_kind, int mode, int expc, hipStream_t s);           \
   hipError_t launch_logprob_rows_##dt(const void *logits, int64_t ld, int V, float scale, const float *lse,       \
                                       void *out, bool out16, int64_t out_ld, int n_rows, hipStream_t s);           \
   hipError_t launch_logprob_waves_##dt(const void *logits, int64_t ld, int V, int nch, float scale, void *out,    \
@@ -69,20 +70,21 @@ int api_hip_fail(hipError_t e, const char *what) { return hip_fail(e, what); }
 
 namespace {
 
-hipError_t launch_stats(int dtype, const glb::StepParams &p, int mask_kind, bool scaled, hipStream_t s) {
+// expc: the term's arithmetic contract (glb::kExpPoly / glb::kExpHw, glb_math.hpp)
+hipError_t launch_stats(int dtype, const glb::StepParams &p, int mask_kind, bool scaled, int expc, hipStream_t s) {
   switch (dtype) {
-    case 0: return glb::launch_stats_0(p, mask_kind, scaled, s);
-    case 1: return glb::launch_stats_1(p, mask_kind, scaled, s);
-    case 2: return glb::launch_stats_2(p, mask_kind, scaled, s);
+    case 0: return glb::launch_stats_0(p, mask_kind, scaled, expc, s);
+    case 1: return glb::launch_stats_1(p, mask_kind, scaled, expc, s);
+    case 2: return glb::launch_stats_2(p, mask_kind, scaled, expc, s);
   }
   return hipErrorInvalidValue;
 }
 
-hipError_t launch_fused_step(int dtype, const glb::StepParams &p, int mask_kind, int mode, bool scaled, hipStream_t s) {
+hipError_t launch_fused_step(int dtype, const glb::StepParams &p, int mask_kind, int mode, bool scaled, int expc, hipStream_t s) {
   switch (dtype) {
-    case 0: return glb::launch_fused_step_0(p, mask_kind, mode, scaled, s);
-    case 1: return glb::launch_fused_step_1(p, mask_kind, mode, scaled, s);
-    case 2: return glb::launch_fused_step_2(p, mask_kind, mode, scaled, s);
+    case 0: return glb::launch_fused_step_0(p, mask_kind, mode, scaled, expc, s);
+    case 1: return glb::launch_fused_step_1(p, mask_kind, mode, scaled, expc, s);
+    case 2: return glb::launch_fused_step_2(p, mask_kind, mode, scaled, expc, s);
   }
   return hipErrorInvalidValue;
 }
@@ -162,11 +164,11 @@ int fin_wave_cap(bool float_mask) { return device_cus() * (float_mask ? 6 : 8); 
 
 
 
-hipError_t launch_finish(int dtype, const glb::StepParams &p, int mask_kind, int mode, hipStream_t s) {
+hipError_t launch_finish(int dtype, const glb::StepParams &p, int mask_kind, int mode, int expc, hipStream_t s) {
   switch (dtype) {
-    case 0: return glb::launch_finish_0(p, mask_kind, mode, s);
-    case 1: return glb::launch_finish_1(p, mask_kind, mode, s);
-    case 2: return glb::launch_finish_2(p, mask_kind, mode, s);
+    case 0: return glb::launch_finish_0(p, mask_kind, mode, expc, s);
+    case 1: return glb::launch_finish_1(p, mask_kind, mode, expc, s);
+    case 2: return glb::launch_finish_2(p, mask_kind, mode, expc, s);
   }
   return hipErrorInvalidValue;
 }
@@ -704,7 +706,10 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
   }
   if (a->rng_mode < GLB_RNG_NONE || a->rng_mode > GLB_RNG_NOISE)
     return fail(GLB_EINVAL, "bad rng_mode %d", a->rng_mode);
-  if (a->flags != 0) return fail(GLB_EINVAL, "flags must be 0 (no bits are defined)");
+  if (a->flags & ~GLB_STEP_HW_EXP) return fail(GLB_EINVAL, "flags %d: only GLB_STEP_HW_EXP is defined", a->flags);
+  if ((a->flags & GLB_STEP_HW_EXP) && a->dtype == GLB_F32)
+    return fail(GLB_EINVAL, "GLB_STEP_HW_EXP is a contract of 16-bit rows (float32 rows are bound by memory, not by the exponential)");
+  const int expc = (a->flags & GLB_STEP_HW_EXP) ? glb::kExpHw : glb::kExpPoly;
   if (a->rng_mode == GLB_RNG_NOISE && (!a->noise || (a->noise_ld < a->vocab && a->noise_ld != 0)))
     return fail(GLB_EINVAL, "noise tensor missing or noise_ld < vocab (0 = one row shared by every particle)");
   if (a->rng_mode != GLB_RNG_NONE && !a->out_token)
@@ -804,14 +809,14 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
     if (const char *e = getenv("GLB_SHORT_LAST"))
       p.diag.short_last = (atoi(e) && p.diag.il_lag < 0 && p.nch >= 2 && a->vocab - (int64_t)(p.nch - 1) * glb::kChunk <= glb::kChunk / 2) ? 1 : 0;
 #endif
-    const hipError_t e = launch_fused_step(a->dtype, p, kmask, a->rng_mode, scaled, s);
+    const hipError_t e = launch_fused_step(a->dtype, p, kmask, a->rng_mode, scaled, expc, s);
     if (e != hipSuccess) return hip_fail(e, "fused_step launch");
     return GLB_OK;
   }
   p.epoch = 0u;
-  hipError_t e = launch_stats(a->dtype, p, kmask, scaled, s);
+  hipError_t e = launch_stats(a->dtype, p, kmask, scaled, expc, s);
   if (e != hipSuccess) return hip_fail(e, "chunk_stats launch");
-  e = launch_finish(a->dtype, p, kmask, a->rng_mode, s);
+  e = launch_finish(a->dtype, p, kmask, a->rng_mode, expc, s);
   if (e != hipSuccess) return hip_fail(e, "finish launch");
   return GLB_OK;
 }
@@ -930,9 +935,9 @@ int glb_log_softmax_rows(const void *logits, int32_t dtype, int64_t n_rows, int6
   p.n_pairs = (int32_t)n_rows;
   p.recs = (uint64_t *)workspace;
   p.out_lse = lse;
-  hipError_t e = launch_stats(dtype, p, glb::kMaskNone, logit_scale != 1.0f, s);
+  hipError_t e = launch_stats(dtype, p, glb::kMaskNone, logit_scale != 1.0f, glb::kExpPoly, s);
   if (e != hipSuccess) return hip_fail(e, "chunk_stats launch");
-  e = launch_finish(dtype, p, glb::kMaskNone, glb::kModeStats, s);
+  e = launch_finish(dtype, p, glb::kMaskNone, glb::kModeStats, glb::kExpPoly, s);
   if (e != hipSuccess) return hip_fail(e, "finish launch");
   if (out) {
     switch (dtype) {

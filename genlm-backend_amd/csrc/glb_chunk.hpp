@@ -317,7 +317,7 @@ __device__ __forceinline__ void mask_ahead(cu64_t mt, MaskAhead &ma, int v0 = 0)
 // over the allowed ones.  (v0, VSTEP): this wave's vectors are v0, v0 + VSTEP, ... and x holds them densely - one wave
 // per chunk: (0, 1), four classes per lane; four waves per chunk: (wave, 4), every vector of a wave is of class `wave`
 // and the sums land in P[0] / Pm[0].
-template <int DT, bool MASKED, int VSTEP, bool FULL>
+template <int DT, bool MASKED, int VSTEP, bool FULL, int EXPC>
 __device__ __forceinline__ void class_partials_body(const float (&x)[64], float magicN, int nv_valid, cu64_t mt, int v0,
                                                     const MaskAhead &ahead, float (&P)[4], float (&Pm)[4]) {
   constexpr int EPV = ElemTraits<DT>::EPV, NVC = ElemTraits<DT>::NVC / VSTEP;
@@ -354,7 +354,7 @@ __device__ __forceinline__ void class_partials_body(const float (&x)[64], float 
       if (FULL || vi < nv_valid) {  // wave-uniform: vectors wholly past the row end are skipped (they would add +0)
         float t[EPV];
 #pragma unroll
-        for (int k = 0; k < EPV; ++k) t[k] = chunk_term(x[i * EPV + k], magicN);
+        for (int k = 0; k < EPV; ++k) t[k] = chunk_term<EXPC>(x[i * EPV + k], magicN);
 #pragma unroll
         for (int k = 0; k < EPV; ++k) P[cls] = P[cls] + t[k];
         if constexpr (MASKED) {
@@ -369,7 +369,8 @@ __device__ __forceinline__ void class_partials_body(const float (&x)[64], float 
   }
 }
 
-template <int DT, bool MASKED, int VSTEP = 1>
+// (magicN: term_bias<EXPC>(the scale) - the name is the polynomial contract's)
+template <int DT, bool MASKED, int VSTEP = 1, int EXPC = kExpPoly>
 __device__ __forceinline__ void class_partials(const float (&x)[64], float magicN, int nv_valid, cu64_t mt,
                                                const MaskAhead &ahead, float (&P)[4], float (&Pm)[4], int v0 = 0) {
 #pragma unroll
@@ -377,9 +378,9 @@ __device__ __forceinline__ void class_partials(const float (&x)[64], float magic
   // a full chunk (all but the last of a row) runs as one straight block: the scheduler can then start the scalar loads
   // of the mask words well ahead of the adds that use them; the last chunk tests every vector against the row end
   if (nv_valid == ElemTraits<DT>::NVC)
-    class_partials_body<DT, MASKED, VSTEP, true>(x, magicN, nv_valid, mt, v0, ahead, P, Pm);
+    class_partials_body<DT, MASKED, VSTEP, true, EXPC>(x, magicN, nv_valid, mt, v0, ahead, P, Pm);
   else
-    class_partials_body<DT, MASKED, VSTEP, false>(x, magicN, nv_valid, mt, v0, ahead, P, Pm);
+    class_partials_body<DT, MASKED, VSTEP, false, EXPC>(x, magicN, nv_valid, mt, v0, ahead, P, Pm);
 }
 
 // this lane's payload words: the sum over its NCLS class partials of floor(P * 2^36), h and l words apart
@@ -411,13 +412,13 @@ __device__ __forceinline__ float chunk_max(const float (&x)[64]) {
 // more (wave-uniform, rare, L1 / L2 serve it; not keeping x alive for this is what lets the common path run without
 // spills), its forbidden elements overwritten with -inf and the allowed ones summed again on their own maximum's
 // scale.  Out (wave-uniform): the totals of all elements, the allowed elements' sums by 16-lane row, and their scale Nm.
-template <int DT, bool SCALED>
+template <int DT, bool SCALED, int EXPC>
 __device__ __forceinline__ void chunk_reduce_bits(float (&x)[64], float Nc, int nv_valid, cu64_t mt,
                                                   const MaskAhead &ma, uint64_t allows_any, int lane, const char *rowp,
                                                   int e_base, int V, float scale, uint32_t &pA, uint32_t &pB,
                                                   uint32_t (&rA)[4], uint32_t (&rB)[4], float &Nm) {
   float P[4], Pm[4];
-  class_partials<DT, true>(x, kMagic - Nc, nv_valid, mt, ma, P, Pm);
+  class_partials<DT, true, 1, EXPC>(x, term_bias<EXPC>(Nc), nv_valid, mt, ma, P, Pm);
   uint32_t h, l, hm, lm;
   lane_payload<4>(P, h, l);
   lane_payload<4>(Pm, hm, lm);
@@ -437,7 +438,7 @@ __device__ __forceinline__ void chunk_reduce_bits(float (&x)[64], float Nc, int 
     for (int j = 0; j < 64; ++j)
       if (!((mt[j] >> lane) & 1ull)) y[j] = kNegInf;
     Nm = exp_n(chunk_max(y));
-    class_partials<DT, false>(y, kMagic - Nm, nv_valid, nullptr, MaskAhead{}, P, Pm);
+    class_partials<DT, false, 1, EXPC>(y, term_bias<EXPC>(Nm), nv_valid, nullptr, MaskAhead{}, P, Pm);
     lane_payload<4>(P, hm, lm);
     row_sums_u32(hm, rA);
     row_sums_u32(lm, rB);
@@ -509,7 +510,7 @@ __device__ __forceinline__ uint64_t chunk_pick_lane(uint32_t inclA, uint32_t inc
 // ---------------------------------------------------------------------------------------------------------
 // stats role: one wave per (reduction unit, chunk)
 // ---------------------------------------------------------------------------------------------------------
-template <int DT, int MASK, bool SCALED>
+template <int DT, int MASK, bool SCALED, int EXPC>
 __device__ __forceinline__ void stats_item(const StepParams &p, int item, int lane) {
   constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC;
   const int nch = p.nch;
@@ -548,11 +549,11 @@ __device__ __forceinline__ void stats_item(const StepParams &p, int item, int la
   uint32_t pA, pB, rA[4], rB[4];
   float Nm = Nc;
   if constexpr (MASK == kMaskBits) {
-    chunk_reduce_bits<DT, SCALED>(x, Nc, nv_valid, mt, ma, allows_any, lane, rowp, e_base, V, p.scale, pA, pB, rA, rB, Nm);
+    chunk_reduce_bits<DT, SCALED, EXPC>(x, Nc, nv_valid, mt, ma, allows_any, lane, rowp, e_base, V, p.scale, pA, pB, rA, rB, Nm);
   } else {
     float P[4], Pm[4];
     uint32_t h, l;
-    class_partials<DT, false>(x, kMagic - Nc, nv_valid, nullptr, ma, P, Pm);
+    class_partials<DT, false, 1, EXPC>(x, term_bias<EXPC>(Nc), nv_valid, nullptr, ma, P, Pm);
     lane_payload<4>(P, h, l);
     row_sums_u32(h, rA);
     row_sums_u32(l, rB);
@@ -563,7 +564,7 @@ __device__ __forceinline__ void stats_item(const StepParams &p, int item, int la
       float y[64];
       add_float_mask<DT>(x, mrow, e_base, V, lane, y);
       Nm = exp_n(chunk_max(y));
-      class_partials<DT, false>(y, kMagic - Nm, nv_valid, nullptr, ma, P, Pm);
+      class_partials<DT, false, 1, EXPC>(y, term_bias<EXPC>(Nm), nv_valid, nullptr, ma, P, Pm);
       lane_payload<4>(P, h, l);
       row_sums_u32(h, rA);
       row_sums_u32(l, rB);
@@ -588,7 +589,7 @@ __device__ __forceinline__ void stats_item(const StepParams &p, int item, int la
 // launch.  (As the tail of a big launch the quarters gain nothing: tools/dbg/stamps.py)  Bit masks / no
 // mask only (float masks use the one-wave form).
 // ---------------------------------------------------------------------------------------------------------
-template <int DT, int MASK, bool SCALED>
+template <int DT, int MASK, bool SCALED, int EXPC = kExpPoly>
 __global__ __launch_bounds__(256) void chunk_stats_small_kernel(const StepParams p) {
   constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC, NVW = NVC / 4;
   static_assert(MASK != kMaskF32, "float masks take the one-wave-per-chunk form");
@@ -631,11 +632,11 @@ __global__ __launch_bounds__(256) void chunk_stats_small_kernel(const StepParams
     const cu64_t mt = as_const(p.mask_t + ((int64_t)mi * nch + c) * 64);
     MaskAhead ma;
     mask_ahead<DT, 4>(mt, ma, wave);
-    class_partials<DT, true, 4>(x, kMagic - Nc, nv_valid, mt, ma, P, Pm, wave);
+    class_partials<DT, true, 4, EXPC>(x, term_bias<EXPC>(Nc), nv_valid, mt, ma, P, Pm, wave);
     lane_payload<1>(P, h, l);
     lane_payload<1>(Pm, hm, lm);
   } else {
-    class_partials<DT, false, 4>(x, kMagic - Nc, nv_valid, nullptr, MaskAhead{}, P, Pm, wave);
+    class_partials<DT, false, 4, EXPC>(x, term_bias<EXPC>(Nc), nv_valid, nullptr, MaskAhead{}, P, Pm, wave);
     lane_payload<1>(P, h, l);
     hm = h;
     lm = l;
@@ -687,7 +688,7 @@ __global__ __launch_bounds__(256) void chunk_stats_small_kernel(const StepParams
       if (lane == 0) s_max[wave] = mm;
       __syncthreads();
       Nm = exp_n(fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3])));
-      class_partials<DT, false, 4>(x, kMagic - Nm, nv_valid, nullptr, MaskAhead{}, P, Pm, wave);
+      class_partials<DT, false, 4, EXPC>(x, term_bias<EXPC>(Nm), nv_valid, nullptr, MaskAhead{}, P, Pm, wave);
       lane_payload<1>(P, hm, lm);
       row_sums_u32(hm, rA);
       row_sums_u32(lm, rB);
@@ -977,7 +978,7 @@ __device__ __forceinline__ void fold_all_fast(const ChunkRec &r, bool have, floa
   S_all = wave_sum_u64(sa);
 }
 
-template <int DT, int MASK, bool POLL>
+template <int DT, int MASK, bool POLL, int EXPC>
 __device__ __forceinline__ void finish_draw(const StepParams &p, int pidx, int lane) {
   constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC, NVW = NVC / 4;
   const int nch = p.nch, V = p.V;
@@ -1050,7 +1051,7 @@ __device__ __forceinline__ void finish_draw(const StepParams &p, int pidx, int l
     const int c = pick.csel, e_base = c * kChunk;
     const int w = lane & 3, sl = 16 * gsel + (lane >> 2);  // class, lane of the stats wave
     const char *rowp = (const char *)p.logits + (int64_t)row * p.ld * ES;
-    const float magicN = kMagic - pick.Nms;
+    const float magicN = term_bias<EXPC>(pick.Nms);
     float y[16];
     const bool whole = e_base + kChunk <= V;  // wave-uniform: every chunk of a row but its last - no per-lane guards
 #pragma unroll
@@ -1102,7 +1103,7 @@ __device__ __forceinline__ void finish_draw(const StepParams &p, int pidx, int l
     float t[16], P = 0.0f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      t[j] = chunk_term(y[j], magicN);
+      t[j] = chunk_term<EXPC>(y[j], magicN);
       P = P + t[j];
     }
     uint32_t h, l;
@@ -1157,13 +1158,14 @@ __device__ __forceinline__ void finish_draw(const StepParams &p, int pidx, int l
 // ---------------------------------------------------------------------------------------------------------
 // waves per SIMD the kernels are compiled for.  Float masks hold x[64] and y[64] in the stats role: three leave them
 // the registers.  16-bit rows are bound by VALU issue and gain from a fifth wave (96 registers fit without spills);
-// fp32 rows spill at five and stream as fast with four.
+// fp32 rows spill at five and stream as fast with four.  Under the hardware-exponential contract (kExpHw, 16-bit rows)
+// the stream is bound by memory, not issue: four and five waves measure the same, six spill (profiles/r06/ab_contract_*).
 template <int DT, int MASK>
 struct StatsWaves {
   static constexpr int value = MASK == kMaskF32 ? 3 : (DT == kDtF32 ? 4 : GLB_STATS_WAVES_16);
 };
 
-template <int DT, int MASK, bool SCALED, int MODE>
+template <int DT, int MASK, bool SCALED, int MODE, int EXPC = kExpPoly>
 __global__ __launch_bounds__(64, (StatsWaves<DT, MASK>::value)) void fused_step_kernel(const StepParams p) {
   const int lane = threadIdx.x;
   const int blk = blockIdx.x;
@@ -1181,18 +1183,18 @@ __global__ __launch_bounds__(64, (StatsWaves<DT, MASK>::value)) void fused_step_
     }
   )
   if (item >= 0) {
-    stats_item<DT, MASK, SCALED>(p, item, lane);
+    stats_item<DT, MASK, SCALED, EXPC>(p, item, lane);
     return;
   }
   for (int pidx = pfirst; pidx < p.n_particles; pidx += p.fin_blocks) {
-    if constexpr (MODE == kModePhilox) finish_draw<DT, MASK, true>(p, pidx, lane);
+    if constexpr (MODE == kModePhilox) finish_draw<DT, MASK, true, EXPC>(p, pidx, lane);
     else finish_stats<MASK, true>(p, pidx, lane);
   }
 }
 
-template <int DT, int MASK, bool SCALED>
+template <int DT, int MASK, bool SCALED, int EXPC = kExpPoly>
 __global__ __launch_bounds__(64, (StatsWaves<DT, MASK>::value)) void chunk_stats_kernel(const StepParams p) {
-  stats_item<DT, MASK, SCALED>(p, blockIdx.x, threadIdx.x);
+  stats_item<DT, MASK, SCALED, EXPC>(p, blockIdx.x, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1200,7 +1202,7 @@ __global__ __launch_bounds__(64, (StatsWaves<DT, MASK>::value)) void chunk_stats
 // wave for the statistics / Philox modes (launched with 64 threads), four for parity mode, which deals the row's vectors
 // to all of them.
 // ---------------------------------------------------------------------------------------------------------
-template <int DT, int MASK, int MODE>
+template <int DT, int MASK, int MODE, int EXPC = kExpPoly>
 __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
   constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC;
   __shared__ float s_bestg[4], s_secg[4];
@@ -1213,7 +1215,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
   }
   if constexpr (MODE == kModePhilox) {
     if (wave == 0) {
-      if (p.out_token) finish_draw<DT, MASK, false>(p, pidx, lane);
+      if (p.out_token) finish_draw<DT, MASK, false, EXPC>(p, pidx, lane);
       else finish_stats<MASK, false>(p, pidx, lane);
     }
     return;
@@ -1254,7 +1256,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
     //      robin to the four waves; ties resolve to the smallest index at every level ------------------------------
     int32_t tok = -1;
     if (st.S_msk != 0) {  // workgroup-uniform: every wave folded the same records
-      const float magicN = kMagic - st.N_msk;
+      const float magicN = term_bias<EXPC>(st.N_msk);
       const float *E = p.noise + (int64_t)pidx * p.noise_ld;
       float best = -1.0f, sec = -1.0f;  // sec: runner-up of the race (for the reported margin)
       int32_t bj = -1;
@@ -1283,7 +1285,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
           for (int k = 0; k < EPV; ++k) {
             const int j = e0[jv] + k;
             const bool ok = j < V && y[jv][k] > kNegInf;
-            const float e = chunk_term(y[jv][k], magicN);
+            const float e = chunk_term<EXPC>(y[jv][k], magicN);
             const uint32_t eb = k % 4 == 0 ? en[jv][k / 4].x : (k % 4 == 1 ? en[jv][k / 4].y : (k % 4 == 2 ? en[jv][k / 4].z : en[jv][k / 4].w));
             const float g = ok ? e / __uint_as_float(eb) : -1.0f;
             const bool better = g > best;  // strict: the first maximum in this lane's (increasing) order stays

@@ -30,79 +30,106 @@ static void launch_k(K kernel, dim3 grid, dim3 block, hipStream_t s, const StepP
 // two SIMDs the per-wave latency is the launch time)
 constexpr int64_t kSmallLaunchItems = 512;
 
-template <int MASK>
+// the term's arithmetic contract (glb_math.hpp): the hardware exponential exists for 16-bit rows only
+constexpr bool kHasHwExp = GLB_DT != kDtF32;
+
+template <int MASK, int EXPC>
 static hipError_t stats1(const StepParams &p, bool scaled, hipStream_t s) {
   const int64_t waves = (int64_t)p.n_pairs * p.nch;
   if constexpr (MASK != kMaskF32) {
     if (waves <= kSmallLaunchItems) {
       const dim3 grid((unsigned)waves), block(256);
-      if (scaled) launch_k(chunk_stats_small_kernel<GLB_DT, MASK, true>, grid, block, s, p, true, false);
-      else launch_k(chunk_stats_small_kernel<GLB_DT, MASK, false>, grid, block, s, p, true, false);
+      if (scaled) launch_k(chunk_stats_small_kernel<GLB_DT, MASK, true, EXPC>, grid, block, s, p, true, false);
+      else launch_k(chunk_stats_small_kernel<GLB_DT, MASK, false, EXPC>, grid, block, s, p, true, false);
       return hipGetLastError();
     }
   }
   const dim3 grid((unsigned)waves), block(64);  // one-wave workgroups: every wave slot refills on its own
-  if (scaled) launch_k(chunk_stats_kernel<GLB_DT, MASK, true>, grid, block, s, p, true, false);
-  else launch_k(chunk_stats_kernel<GLB_DT, MASK, false>, grid, block, s, p, true, false);
+  if (scaled) launch_k(chunk_stats_kernel<GLB_DT, MASK, true, EXPC>, grid, block, s, p, true, false);
+  else launch_k(chunk_stats_kernel<GLB_DT, MASK, false, EXPC>, grid, block, s, p, true, false);
   return hipGetLastError();
 }
 
-hipError_t GLB_CAT(launch_stats_, GLB_DT)(const StepParams &p, int mask_kind, bool scaled, hipStream_t s) {
+template <int EXPC>
+static hipError_t stats0(const StepParams &p, int mask_kind, bool scaled, hipStream_t s) {
   switch (mask_kind) {
-    case kMaskNone: return stats1<kMaskNone>(p, scaled, s);
-    case kMaskBits: return stats1<kMaskBits>(p, scaled, s);
-    case kMaskF32: return stats1<kMaskF32>(p, scaled, s);
+    case kMaskNone: return stats1<kMaskNone, EXPC>(p, scaled, s);
+    case kMaskBits: return stats1<kMaskBits, EXPC>(p, scaled, s);
+    case kMaskF32: return stats1<kMaskF32, EXPC>(p, scaled, s);
   }
   return hipErrorInvalidValue;
 }
 
+hipError_t GLB_CAT(launch_stats_, GLB_DT)(const StepParams &p, int mask_kind, bool scaled, int expc, hipStream_t s) {
+  if constexpr (kHasHwExp) {
+    if (expc == kExpHw) return stats0<kExpHw>(p, mask_kind, scaled, s);
+  }
+  return expc == kExpPoly ? stats0<kExpPoly>(p, mask_kind, scaled, s) : hipErrorInvalidValue;
+}
+
 // the step in one launch (statistics / Philox modes): the caller has set the grid's two parts in p
-template <int MASK, int MODE>
+template <int MASK, int MODE, int EXPC>
 static hipError_t fused2(const StepParams &p, bool scaled, hipStream_t s) {
   const dim3 grid((unsigned)(p.stats_blocks + p.fin_blocks)), block(64);
   // (dynamic LDS nobody touches: a cap on the workgroups a CU holds, for occupancy experiments; 0 in the product)
   const unsigned lds = (unsigned)g_lds_pad[GLB_DT];
-  if (scaled) launch_k(fused_step_kernel<GLB_DT, MASK, true, MODE>, grid, block, s, p, true, true, lds);
-  else launch_k(fused_step_kernel<GLB_DT, MASK, false, MODE>, grid, block, s, p, true, true, lds);
+  if (scaled) launch_k(fused_step_kernel<GLB_DT, MASK, true, MODE, EXPC>, grid, block, s, p, true, true, lds);
+  else launch_k(fused_step_kernel<GLB_DT, MASK, false, MODE, EXPC>, grid, block, s, p, true, true, lds);
   return hipGetLastError();
 }
 
-template <int MASK>
+template <int MASK, int EXPC>
 static hipError_t fused1(const StepParams &p, int mode, bool scaled, hipStream_t s) {
-  if (mode == kModeStats) return fused2<MASK, kModeStats>(p, scaled, s);
-  if (mode == kModePhilox) return fused2<MASK, kModePhilox>(p, scaled, s);
+  if (mode == kModeStats) return fused2<MASK, kModeStats, EXPC>(p, scaled, s);
+  if (mode == kModePhilox) return fused2<MASK, kModePhilox, EXPC>(p, scaled, s);
   return hipErrorInvalidValue;
 }
 
-hipError_t GLB_CAT(launch_fused_step_, GLB_DT)(const StepParams &p, int mask_kind, int mode, bool scaled, hipStream_t s) {
+template <int EXPC>
+static hipError_t fused0(const StepParams &p, int mask_kind, int mode, bool scaled, hipStream_t s) {
   switch (mask_kind) {
-    case kMaskNone: return fused1<kMaskNone>(p, mode, scaled, s);
-    case kMaskBits: return fused1<kMaskBits>(p, mode, scaled, s);
-    case kMaskF32: return fused1<kMaskF32>(p, mode, scaled, s);
+    case kMaskNone: return fused1<kMaskNone, EXPC>(p, mode, scaled, s);
+    case kMaskBits: return fused1<kMaskBits, EXPC>(p, mode, scaled, s);
+    case kMaskF32: return fused1<kMaskF32, EXPC>(p, mode, scaled, s);
   }
   return hipErrorInvalidValue;
 }
 
-template <int MASK>
+hipError_t GLB_CAT(launch_fused_step_, GLB_DT)(const StepParams &p, int mask_kind, int mode, bool scaled, int expc, hipStream_t s) {
+  if constexpr (kHasHwExp) {
+    if (expc == kExpHw) return fused0<kExpHw>(p, mask_kind, mode, scaled, s);
+  }
+  return expc == kExpPoly ? fused0<kExpPoly>(p, mask_kind, mode, scaled, s) : hipErrorInvalidValue;
+}
+
+template <int MASK, int EXPC>
 static hipError_t finish1(const StepParams &p, int mode, hipStream_t s) {
   // one workgroup per particle: one wave, four for the parity-mode race over the whole row
   const dim3 grid((unsigned)p.n_particles), block(mode == kModeNoise ? 256 : 64);
   switch (mode) {
-    case kModeStats: launch_k(finish_kernel<GLB_DT, MASK, kModeStats>, grid, block, s, p, false, true); break;
-    case kModePhilox: launch_k(finish_kernel<GLB_DT, MASK, kModePhilox>, grid, block, s, p, false, true); break;
-    case kModeNoise: launch_k(finish_kernel<GLB_DT, MASK, kModeNoise>, grid, block, s, p, false, true); break;
+    case kModeStats: launch_k(finish_kernel<GLB_DT, MASK, kModeStats, kExpPoly>, grid, block, s, p, false, true); break;
+    case kModePhilox: launch_k(finish_kernel<GLB_DT, MASK, kModePhilox, EXPC>, grid, block, s, p, false, true); break;
+    case kModeNoise: launch_k(finish_kernel<GLB_DT, MASK, kModeNoise, EXPC>, grid, block, s, p, false, true); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
 
-hipError_t GLB_CAT(launch_finish_, GLB_DT)(const StepParams &p, int mask_kind, int mode, hipStream_t s) {
+template <int EXPC>
+static hipError_t finish0(const StepParams &p, int mask_kind, int mode, hipStream_t s) {
   switch (mask_kind) {
-    case kMaskNone: return finish1<kMaskNone>(p, mode, s);
-    case kMaskBits: return finish1<kMaskBits>(p, mode, s);
-    case kMaskF32: return finish1<kMaskF32>(p, mode, s);
+    case kMaskNone: return finish1<kMaskNone, EXPC>(p, mode, s);
+    case kMaskBits: return finish1<kMaskBits, EXPC>(p, mode, s);
+    case kMaskF32: return finish1<kMaskF32, EXPC>(p, mode, s);
   }
   return hipErrorInvalidValue;
+}
+
+hipError_t GLB_CAT(launch_finish_, GLB_DT)(const StepParams &p, int mask_kind, int mode, int expc, hipStream_t s) {
+  if constexpr (kHasHwExp) {
+    if (expc == kExpHw) return finish0<kExpHw>(p, mask_kind, mode, s);
+  }
+  return expc == kExpPoly ? finish0<kExpPoly>(p, mask_kind, mode, s) : hipErrorInvalidValue;
 }
 
 hipError_t GLB_CAT(launch_logprob_rows_, GLB_DT)(const void *logits, int64_t ld, int V, float scale,

@@ -208,20 +208,45 @@ __device__ __forceinline__ float fma_clamp01(float a, float b, float c) {
   return r;
 }
 
-// t of one element against the chunk scale; magicN = kMagic - N_c (exact).  The exponent n - N_c sits in the
+// The two arithmetic contracts of a term.  kExpPoly (every element type): the polynomial above - every
+// step an IEEE operation, restated bit for bit by oracle/glb_oracle.c.  kExpHw (16-bit rows, glb_step_args.flags &
+// GLB_STEP_HW_EXP): t = v_exp_f32(fma(x, log2 e, -(N_c + 1))) - the hardware's 2^y, within one ulp of the true value
+// (more accurate than the polynomial's 2.7e-6) and deterministic on gfx950, but not correctly rounded, so no CPU
+// restatement reproduces its last bit: that contract is checked against the oracle's exp2f form by tolerance (logZ, lse)
+// and token by token with the draws' distances from the CDF's boundaries (tests/test_step_gpu.py).  Everything above the
+// term - chunks, (lane, class) sums in load order, integer sums, records, draws - is the same code.
+enum { kExpPoly = 0, kExpHw = 1 };
+
+// what chunk_term adds to x * log2(e): kMagic - N (exact; n - N lands in the low mantissa bits), or -(N + 1)
+template <int EXPC>
+__device__ __forceinline__ float term_bias(float N) {
+  if constexpr (EXPC == kExpHw) return -1.0f - N;
+  else return kMagic - N;
+}
+
+// t of one element against the chunk scale; bias = term_bias(N_c).  kExpPoly: the exponent n - N_c sits in the
 // low mantissa bits of tm; out-of-range inputs (-inf, NaN, more than 2^22 binades away) end as t = 0 or as a
-// harmless finite value because P is clamped and v_ldexp_f32 saturates.
-__device__ __forceinline__ float chunk_term(float x, float magicN) {
-  const float tm = __builtin_fmaf(x, kLog2e, magicN);
-  const float negn = magicN - tm;
-  const int np = (int)(__float_as_uint(tm) - kMagicBits);
-  const float f = __builtin_fmaf(x, kLog2e, negn);
-  float p = kD4;
-  p = __builtin_fmaf(p, f, kD3);
-  p = __builtin_fmaf(p, f, kD2);
-  p = __builtin_fmaf(p, f, kD1);
-  p = fma_clamp01(p, f, kD0);
-  return __builtin_amdgcn_ldexpf(p, np);
+// harmless finite value because P is clamped and v_ldexp_f32 saturates.  kExpHw: y <= -1/2 by construction of N_c, the
+// clamp modifier turns NaN (a NaN logit, -inf against an empty chunk's scale) into 0.
+template <int EXPC = kExpPoly>
+__device__ __forceinline__ float chunk_term(float x, float bias) {
+  if constexpr (EXPC == kExpHw) {
+    const float y = __builtin_fmaf(x, kLog2e, bias);
+    float r;
+    asm("v_exp_f32 %0, %1 clamp" : "=v"(r) : "v"(y));
+    return r;
+  } else {
+    const float tm = __builtin_fmaf(x, kLog2e, bias);
+    const float negn = bias - tm;
+    const int np = (int)(__float_as_uint(tm) - kMagicBits);
+    const float f = __builtin_fmaf(x, kLog2e, negn);
+    float p = kD4;
+    p = __builtin_fmaf(p, f, kD3);
+    p = __builtin_fmaf(p, f, kD2);
+    p = __builtin_fmaf(p, f, kD1);
+    p = fma_clamp01(p, f, kD0);
+    return __builtin_amdgcn_ldexpf(p, np);
+  }
 }
 
 // floor(P * 2^36) of a (lane, class) partial sum as two words: h = floor(P * 2^18) < 2^22, l < 2^18.  Every step

@@ -11,7 +11,7 @@ import torch
 from . import _lib
 from ._lib import GLB_EHIP, GlbError
 from ._lib import (F32, BF16, F16, MASK_NONE, MASK_BITS, MASK_F32, MASK_PREPARED, RNG_NONE, RNG_PHILOX, RNG_NOISE,
-                   KvPlanArgs, MtRowsArgs, StepArgs, TrieArgs, TriePlan, TrieRowsArgs, MT19937, MT_POLY_WORDS, check)
+                   STEP_HW_EXP, KvPlanArgs, MtRowsArgs, StepArgs, TrieArgs, TriePlan, TrieRowsArgs, MT19937, MT_POLY_WORDS, check)
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 
@@ -228,7 +228,16 @@ class _OnDevice:
 class HipEngine:
     """All device work of the hot path for one GPU."""
 
-    def __init__(self, device=None):
+    CONTRACTS = ("poly", "hw", "auto")
+
+    def __init__(self, device=None, contract="poly"):
+        """contract: the arithmetic of the fused step's terms (include/glb.h, GLB_STEP_HW_EXP) - "poly":
+        the polynomial exponential every element type has, restated bit for bit by the oracle; "hw" / "auto": the
+        hardware's v_exp_f32 for 16-bit logits (float32 rows have the polynomial only), checked against the oracle by
+        tolerance.  `step(contract=...)` overrides it per call."""
+        if contract not in self.CONTRACTS:
+            raise ValueError(f"contract must be one of {self.CONTRACTS}, got {contract!r}")
+        self.contract = contract
         lib = _lib.load()
         if not torch.cuda.is_available() or lib.glb_device_count() <= 0:
             raise RuntimeError(
@@ -283,13 +292,15 @@ class HipEngine:
 
     def step(self, logits, vocab=None, row_of=None, mask_kind=MASK_NONE, mask=None, mask_id=None,
              rng_mode=RNG_NONE, noise=None, seed=0, offset=0, particle_base=0, logit_scale=1.0,
-             want_lse=True, out=None, row_mask_id=None, out_margin=None, _plan=False, timing_events=None):
+             want_lse=True, out=None, row_mask_id=None, out_margin=None, _plan=False, timing_events=None,
+             contract=None):
         """Fused particle step (glb_logprob_mask_sample).  Returns (logZ, lse, token) device tensors.
 
         logits: [n_rows, ld] (last dim contiguous; rows may be strided), vocab <= ld.
         mask: int32 bit rows / float rows, or a `PreparedMasks` (prepare_masks).  `row_mask_id` gives the mask per
         logits row (the mask is a function of the context): shared rows are then reduced once.
         A launch whose waves gave up waiting shows as token -2 / NaN and in `error_word()`: `raise_if_failed`.
+        contract: "poly" / "hw" / "auto" (None: the engine's) - see __init__.
         """
         if logits.dim() != 2 or logits.stride(1) != 1:
             raise ValueError("logits must be 2-D with unit inner stride")
@@ -350,6 +361,10 @@ class HipEngine:
         a.out_lse = None if lse is None else lse.data_ptr()
         a.out_token = None if tok is None else tok.data_ptr()
         a.out_margin = None if out_margin is None else out_margin.data_ptr()  # parity mode: tie margin of every draw
+        contract = self.contract if contract is None else contract
+        if contract not in self.CONTRACTS:
+            raise ValueError(f"contract must be one of {self.CONTRACTS}, got {contract!r}")
+        a.flags = STEP_HW_EXP if contract != "poly" and a.dtype != F32 else 0
         ws = self._scratch(self.lib.glb_step_workspace_bytes(n, n_rows, V, n_masks))
         a.workspace = ws.data_ptr()
         a.workspace_bytes = ws.numel()

@@ -203,7 +203,21 @@ static const uint32_t GLB_EXP2_D[5] = {0x3f7ffff4u - (1u << 23), 0x3f31706eu - (
 #define GLB_FRAC 36
 #define GLB_LOW_MASS_BITS 32 /* a chunk's bit-masked sum below 2^32 on the chunk's scale is redone on its own scale */
 
+/* The second contract of a term (include/glb.h GLB_STEP_HW_EXP, 16-bit rows): t = 2^(fma(x, log2 e, -(N + 1))) by the
+ * GPU's v_exp_f32, clamped to [0, 1] with NaN -> 0.  v_exp_f32 is within one ulp of 2^y but not correctly rounded, so
+ * it has no bit-exact CPU restatement; the oracle states that contract with libm's exp2f (also within one ulp) and the
+ * tests compare by tolerance and by the draws' distance from the CDF's boundaries (orc_step2's out_edge).  Selected per
+ * call by orc_step2 (not thread safe: the oracle is called from one thread). */
+static int g_expc = 0;
+static float glb_bias(float N) { return g_expc ? -1.0f - N : GLB_MAGIC - N; }
+
 static float glb_chunk_term(float x, float magicN) {
+  if (g_expc) {
+    float r = exp2f(fmaf(x, GLB_LOG2E, magicN));
+    if (!(r > 0.0f)) r = 0.0f;
+    if (r > 1.0f) r = 1.0f;
+    return r;
+  }
   float tm = fmaf(x, GLB_LOG2E, magicN);
   float negn = magicN - tm;
   uint32_t tb;
@@ -271,7 +285,7 @@ static int64_t glb_chunk_stats(const float *y, int64_t V, int epv, chunk_stat *o
     for (int64_t j = lo; j < hi; ++j)
       if (y[j] > m) m = y[j];
     out[c].N = glb_exp_n(m);
-    out[c].S = glb_chunk_sum(y, lo, V, GLB_MAGIC - out[c].N, epv, NULL, NULL);
+    out[c].S = glb_chunk_sum(y, lo, V, glb_bias(out[c].N), epv, NULL, NULL);
   }
   return nch;
 }
@@ -288,14 +302,14 @@ static void glb_chunk_masked(const float *x, const uint32_t *mb, int64_t V, int 
     int64_t lo = c * GLB_CHUNK, hi = lo + GLB_CHUNK < V ? lo + GLB_CHUNK : V;
     int any = 0;
     for (int64_t j = lo; j < hi && !any; ++j) any = mask_allows(mb, j);
-    uint64_t S = glb_chunk_sum(x, lo, V, GLB_MAGIC - cs[c].N, epv, mb, NULL);
+    uint64_t S = glb_chunk_sum(x, lo, V, glb_bias(cs[c].N), epv, mb, NULL);
     out[c].N = cs[c].N;
     if (any && (S >> GLB_LOW_MASS_BITS) == 0) {
       float mk = -INFINITY;
       for (int64_t j = lo; j < hi; ++j)
         if (mask_allows(mb, j) && x[j] > mk) mk = x[j];
       out[c].N = glb_exp_n(mk);
-      S = glb_chunk_sum(x, lo, V, GLB_MAGIC - out[c].N, epv, mb, NULL);
+      S = glb_chunk_sum(x, lo, V, glb_bias(out[c].N), epv, mb, NULL);
     }
     out[c].S = S;
   }
@@ -309,11 +323,17 @@ static uint64_t shr_sat(uint64_t v, float d) { /* d >= 0, integer valued */
  * Layer B particle step (contract of glb_logprob_mask_sample, include/glb.h).
  * Mirrors README.md:82-91 / cache.py:96 / base.py:136-141 semantics.
  */
-int orc_step(const void *logits, int dtype, int64_t n_rows, int64_t V, int64_t ld,
+/* out_edge (nullable, Philox draws): how far the draw is from the nearest boundary of the inverse CDF it walks - the
+ * smaller of (target - lower end, upper end - target) of the chosen chunk's interval as a fraction of the row's allowed
+ * sum (first stage) and of the chosen element's interval as a fraction of the chunk's allowed sum (second stage; the
+ * lane's and the class's intervals contain it).  Two implementations whose terms differ in the last place can only
+ * disagree on a token whose edge is of that order. */
+static int step_impl(const void *logits, int dtype, int64_t n_rows, int64_t V, int64_t ld,
              float logit_scale, int64_t n_particles, const int32_t *row_of, int mask_kind,
              const void *mask, int64_t mask_ld, int64_t n_masks, const int32_t *mask_id,
              int rng_mode, const float *noise, int64_t noise_ld, uint64_t seed, uint64_t offset,
-             int64_t particle_base, float *out_logZ, float *out_lse, int32_t *out_token, float *out_margin) {
+             int64_t particle_base, float *out_logZ, float *out_lse, int32_t *out_token, float *out_margin,
+             float *out_edge) {
   int64_t nch = (V + GLB_CHUNK - 1) / GLB_CHUNK;
   const int epv = glb_epv(dtype);
   float *x = (float *)malloc(sizeof(float) * (size_t)V);
@@ -367,6 +387,7 @@ int orc_step(const void *logits, int dtype, int64_t n_rows, int64_t V, int64_t l
     if (out_logZ) out_logZ[i] = (float)(lse_mask - lse_all);
     if (rng_mode == ORC_RNG_NONE || !out_token) continue;
     int32_t tok = -1;
+    if (out_edge) out_edge[i] = 1.0f;
     if (S_msk != 0) {
       if (rng_mode == ORC_RNG_PHILOX) {
         uint64_t gp = (uint64_t)(particle_base + i);
@@ -377,6 +398,7 @@ int orc_step(const void *logits, int dtype, int64_t n_rows, int64_t V, int64_t l
         uint64_t R = ((uint64_t)rnd[1] << 32) | rnd[0];
         uint64_t R2 = ((uint64_t)rnd[3] << 32) | rnd[2];
         uint64_t T = mulhi64(R, S_msk); /* uniform integer in [0, S_msk) */
+        double edge = 1.0;
         {
           /* two stages, two independent 64-bit draws: the chunk by the shifted chunk sums (first draw), then inside
            * the chunk an inverse CDF on the chunk's own scale against its unshifted sum (second draw), level by level
@@ -389,7 +411,11 @@ int orc_step(const void *logits, int dtype, int64_t n_rows, int64_t V, int64_t l
             uint64_t sm = shr_sat(cm[c].S, d);
             if (T < sm) {
               uint64_t q[256];
-              const float magicN = GLB_MAGIC - cm[c].N;
+              const float magicN = glb_bias(cm[c].N);
+              {
+                double lo1 = (double)T, hi1 = (double)(sm - T);
+                edge = (lo1 < hi1 ? lo1 : hi1) / (double)S_msk;
+              }
               const int64_t lo = c * GLB_CHUNK;
               glb_chunk_sum(y, lo, V, magicN, epv, NULL, q); /* y carries the mask: forbidden = -inf = term 0 */
               uint64_t Tc = mulhi64(R2, cm[c].S), acc = 0;
@@ -400,11 +426,20 @@ int orc_step(const void *logits, int dtype, int64_t n_rows, int64_t V, int64_t l
                 for (int w = 0; w < 4 && tok < 0; ++w) {
                   if (Tl >= q[l * 4 + w]) { Tl -= q[l * 4 + w]; continue; }
                   float P = 0.0f;
+                  uint64_t qprev = 0;
                   for (int pos = 0; pos < 16; ++pos) {
                     int64_t j = glb_lane_elem(lo, epv, l, w, pos);
                     if (j >= V) continue;
                     P = P + glb_chunk_term(y[j], magicN);
-                    if (glb_partial_q(P) > Tl) { tok = (int32_t)j; break; }
+                    uint64_t qcur = glb_partial_q(P);
+                    if (qcur > Tl) {
+                      tok = (int32_t)j;
+                      double lo2 = (double)(Tl - qprev), hi2 = (double)(qcur - Tl);
+                      double e2 = (lo2 < hi2 ? lo2 : hi2) / (double)cm[c].S;
+                      if (e2 < edge) edge = e2;
+                      break;
+                    }
+                    qprev = qcur;
                   }
                   break;
                 }
@@ -415,12 +450,13 @@ int orc_step(const void *logits, int dtype, int64_t n_rows, int64_t V, int64_t l
             T -= sm;
           }
         }
+        if (out_edge) out_edge[i] = (float)edge;
       } else { /* exponential race against caller noise: first maximum of e_j / E_j, e_j on the masked row scale */
         const float *E = noise + i * noise_ld;
         float best = -1.0f, sec = -1.0f;
         for (int64_t j = 0; j < V; ++j) {
           if (!(y[j] > -INFINITY)) continue;
-          float e = glb_chunk_term(y[j], GLB_MAGIC - N_msk);
+          float e = glb_chunk_term(y[j], glb_bias(N_msk));
           float g = e / E[j];
           if (g > best) { sec = best; best = g; tok = (int32_t)j; }
           else if (g > sec) sec = g;
@@ -432,6 +468,32 @@ int orc_step(const void *logits, int dtype, int64_t n_rows, int64_t V, int64_t l
   }
   free(x); free(y); free(ca); free(cm);
   return 0;
+}
+
+int orc_step(const void *logits, int dtype, int64_t n_rows, int64_t V, int64_t ld,
+             float logit_scale, int64_t n_particles, const int32_t *row_of, int mask_kind,
+             const void *mask, int64_t mask_ld, int64_t n_masks, const int32_t *mask_id,
+             int rng_mode, const float *noise, int64_t noise_ld, uint64_t seed, uint64_t offset,
+             int64_t particle_base, float *out_logZ, float *out_lse, int32_t *out_token, float *out_margin) {
+  return step_impl(logits, dtype, n_rows, V, ld, logit_scale, n_particles, row_of, mask_kind, mask, mask_ld, n_masks,
+                   mask_id, rng_mode, noise, noise_ld, seed, offset, particle_base, out_logZ, out_lse, out_token,
+                   out_margin, NULL);
+}
+
+/* orc_step under either contract of the terms (contract: 0 = polynomial, 1 = hardware exponential restated with exp2f),
+ * with the draws' edge distances */
+int orc_step2(const void *logits, int dtype, int64_t n_rows, int64_t V, int64_t ld,
+              float logit_scale, int64_t n_particles, const int32_t *row_of, int mask_kind,
+              const void *mask, int64_t mask_ld, int64_t n_masks, const int32_t *mask_id,
+              int rng_mode, const float *noise, int64_t noise_ld, uint64_t seed, uint64_t offset,
+              int64_t particle_base, float *out_logZ, float *out_lse, int32_t *out_token, float *out_margin,
+              int contract, float *out_edge) {
+  g_expc = contract ? 1 : 0;
+  int rc = step_impl(logits, dtype, n_rows, V, ld, logit_scale, n_particles, row_of, mask_kind, mask, mask_ld, n_masks,
+                     mask_id, rng_mode, noise, noise_ld, seed, offset, particle_base, out_logZ, out_lse, out_token,
+                     out_margin, out_edge);
+  g_expc = 0;
+  return rc;
 }
 
 /* contract of glb_log_softmax_rows: out = x - (float)lse, lse from the chunked integer sums */

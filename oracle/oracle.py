@@ -62,8 +62,11 @@ def bf16_bits_to_f32(b):
 
 
 def step(logits, row_of=None, mask_kind=MASK_NONE, mask=None, mask_id=None, rng_mode=RNG_NONE,
-         noise=None, seed=0, offset=0, particle_base=0, logit_scale=1.0, n_particles=None, want_margin=False):
-    """Layer-B particle step.  Returns (logZ, lse, token) [+ the race's tie margin with want_margin]."""
+         noise=None, seed=0, offset=0, particle_base=0, logit_scale=1.0, n_particles=None, want_margin=False,
+         contract="poly", want_edge=False):
+    """Layer-B particle step.  Returns (logZ, lse, token) [+ the race's tie margin with want_margin] [+ the Philox
+    draws' distance from the nearest boundary of the inverse CDF with want_edge].  contract "hw": the terms of
+    GLB_STEP_HW_EXP restated with exp2f (not bit for bit what v_exp_f32 gives: glb_oracle.c)."""
     logits = np.ascontiguousarray(logits)
     n_rows, ld = logits.shape
     V = ld
@@ -86,15 +89,23 @@ def step(logits, row_of=None, mask_kind=MASK_NONE, mask=None, mask_id=None, rng_
     lse = np.empty(n, np.float32)
     tok = np.full(n, -2, np.int32)
     margin = np.ones(n, np.float32) if want_margin else None
-    rc = lib().orc_step(
+    if contract not in ("poly", "hw"):
+        raise ValueError(contract)
+    edge = np.ones(n, np.float32) if want_edge else None
+    rc = lib().orc_step2(
         _p(logits), _dtype_code(logits), C.c_int64(n_rows), C.c_int64(V), C.c_int64(ld),
         C.c_float(logit_scale), C.c_int64(n), _p(row_of), C.c_int(mask_kind), _p(mask),
         C.c_int64(mask_ld), C.c_int64(n_masks), _p(mask_id), C.c_int(rng_mode), _p(noise),
         C.c_int64(noise_ld), C.c_uint64(seed), C.c_uint64(offset), C.c_int64(particle_base),
-        _p(logZ), _p(lse), _p(tok), _p(margin))
+        _p(logZ), _p(lse), _p(tok), _p(margin), C.c_int(1 if contract == "hw" else 0), _p(edge))
     if rc:
         raise RuntimeError(f"orc_step rc={rc}")
-    return (logZ, lse, tok, margin) if want_margin else (logZ, lse, tok)
+    out = (logZ, lse, tok)
+    if want_margin:
+        out += (margin,)
+    if want_edge:
+        out += (edge,)
+    return out
 
 
 def log_softmax_rows(logits, logit_scale=1.0):

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     raw = C.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert lib.glb_abi_version() == 8
+    assert lib.glb_abi_version() == 9
     assert b"gfx950" in lib.glb_version()
     assert C.sizeof(_lib.StepArgs) == 224  # layout guard of glb_step_args
     # ... and of the other argument blocks (sizeof in C, include/glb.h compiled with gcc: 264 / 200 / 144 / 160 / 136)

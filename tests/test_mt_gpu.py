@@ -21,6 +21,32 @@ def _host_stream(seed, n):
     return out
 
 
+def test_device_rows_are_torchs_stream_directly(engine):
+    """The chain's last link closed ON the GPU box: rows made by the device generator, flattened, against the golden
+    torch itself produced (tests/golden/torch_kernel_ops.npz, mt::seed99_first4096 =
+    torch.empty(4096).exponential_(1, generator=manual_seed(99)), oracle/make_goldens.py) - no host stream of this
+    library in between - at three row widths (the stream is one sequence however it is cut into rows), and against torch
+    run here on the host for a seed and a position no fixture holds."""
+    import os
+
+    from genlm_backend_amd.engine import DeviceRng
+
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "torch_kernel_ops.npz"))["mt::seed99_first4096"]
+    for V, rows in ((4096, 1), (64, 64), (311, 13)):
+        got = DeviceRng(engine, 99, V).rows(rows)
+        torch.cuda.synchronize()
+        flat = got.cpu().numpy().reshape(-1)
+        assert np.array_equal(flat.view(np.uint32), gold[:flat.size].view(np.uint32)), (V, rows)
+    g = torch.Generator()
+    g.manual_seed(31337)
+    want = torch.empty(40 * 50257).exponential_(1, generator=g).numpy().reshape(40, 50257)
+    rng = DeviceRng(engine, 31337, 50257)
+    first, second = rng.rows(33), rng.rows(7)  # (33 rows: both jump launches; the second call starts where the first ended)
+    torch.cuda.synchronize()
+    assert np.array_equal(first.cpu().numpy().view(np.uint32), want[:33].view(np.uint32))
+    assert np.array_equal(second.cpu().numpy().view(np.uint32), want[33:].view(np.uint32))
+
+
 @pytest.mark.parametrize("V,rows", [(50257, 70), (4099, 33), (1, 40), (128256, 9), (311, 1)])
 def test_rows_equal_the_serial_stream(engine, V, rows):
     """Several calls in a row: the stream moves on by what each call consumed; rows beyond one polynomial level (rows > 32)

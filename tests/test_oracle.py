@@ -170,3 +170,46 @@ def test_host_ops(oracle):
     assert abs(stats[0] - t.logsumexp(0).item()) < 1e-6
     w = torch.softmax(t, 0)
     assert abs(stats[1] - (1.0 / (w * w).sum()).item()) < 1e-4
+
+
+def test_oracle_at_config5_full_size_against_the_torch_golden(oracle):
+    """512 x 128256 bf16 (BASELINE config 5) in parity mode against torch-CPU's log_softmax + mask + logsumexp + multinomial
+    on the upcast logits (tests/golden/ref_round6.npz, oracle/make_goldens_r6.py): every id identical, logZ / lse within
+    1e-4, margins as torch's race has them - under BOTH contracts of the terms (the polynomial, and the hardware
+    exponential as the oracle restates it with exp2f)."""
+    O = oracle
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_round6.npz"))
+    B, V = 512, 128256
+    x = torch.from_numpy(synth.logits(23, B, V)).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+    bits, _ = O.mask_f32_to_bits(synth.binary_masks(23, 2, V))
+    mid = (np.arange(B) % 2).astype(np.int32)
+    E, _ = O.mt_exponential(2025, B * V)
+    assert gold["parity512_llama::margin"].min() > 1e-3  # no golden draw is a near tie
+    for contract in ("poly", "hw"):
+        logZ, lse, tok, margin = O.step(x, mask_kind=O.MASK_BITS, mask=bits, mask_id=mid, rng_mode=O.RNG_NOISE,
+                                        noise=E.reshape(B, V), want_margin=True, contract=contract)
+        assert np.array_equal(tok, gold["parity512_llama::token"]), contract
+        assert np.abs(logZ - gold["parity512_llama::logZ"]).max() < TOL
+        assert np.abs(lse - gold["parity512_llama::lse"]).max() < TOL
+        assert np.abs(margin - gold["parity512_llama::margin"]).max() < 1e-3
+
+
+def test_hw_contract_of_the_oracle_is_the_polynomial_within_tolerance(oracle):
+    """The oracle's restatement of GLB_STEP_HW_EXP (exp2f terms) against its polynomial contract: lse / logZ within 1e-5,
+    Philox tokens identical except where a draw lies within 2^-16 of a boundary of the inverse CDF (the polynomial is
+    2.7e-6 off 2^f); -inf and NaN logits, masks of every kind."""
+    O = oracle
+    rs = np.random.default_rng(7)
+    for V, B in ((5000, 12), (40000, 6)):
+        x = synth.logits(V, B, V)
+        x[rs.random((B, V)) < 0.01] = -np.inf
+        x[0, rs.integers(0, V, 5)] = np.nan
+        xb = O.f32_to_bf16_bits(x)
+        bits, _ = O.mask_f32_to_bits(synth.binary_masks(V, 2, V))
+        mid = (np.arange(B) % 2).astype(np.int32)
+        for kw in (dict(), dict(mask_kind=O.MASK_BITS, mask=bits, mask_id=mid)):
+            a = O.step(xb, rng_mode=O.RNG_PHILOX, seed=5, offset=3, **kw)
+            b = O.step(xb, rng_mode=O.RNG_PHILOX, seed=5, offset=3, contract="hw", want_edge=True, **kw)
+            assert np.abs(a[0] - b[0]).max() < 1e-5 and np.abs(a[1] - b[1]).max() < 1e-5
+            differ = a[2] != b[2]
+            assert (b[3][differ] < 2.0 ** -16).all() and differ.sum() <= 1

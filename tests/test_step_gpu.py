@@ -254,13 +254,16 @@ def test_many_rows_per_workgroup(engine, oracle):
     assert np.array_equal(_np(lse).view(np.uint32), lse_o.view(np.uint32))
 
 
-def test_parity_mode_at_the_headline_size(engine, oracle):
+@pytest.mark.parametrize("noise_from", ["device", "host"])
+def test_parity_mode_at_the_headline_size(engine, oracle, noise_from):
     """1024 x 50257 fp32 in parity RNG mode against torch-CPU's log_softmax + mask + logsumexp + multinomial
     (tests/golden/ref_round2.npz, parity1024::*): every sampled id identical, logZ within 1e-4, and the kernel's own
-    report of how close each draw was to a tie agrees with torch's race."""
+    report of how close each draw was to a tie agrees with torch's race.  The noise comes from the DEVICE's MT19937
+    stream (DeviceRng(2024, V).rows(1024): what the product runs - the whole chain seed -> jump-ahead -> exponentials ->
+    race on the GPU box against a torch-made fixture), and once from the serial host stream (the form the reference runs)."""
     import os
 
-    from genlm_backend_amd.engine import HostRng
+    from genlm_backend_amd.engine import DeviceRng, HostRng
 
     gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_round2.npz"))
     B, V = 1024, 50257
@@ -269,7 +272,10 @@ def test_parity_mode_at_the_headline_size(engine, oracle):
     masks = synth.binary_masks(21, 2, V)
     bits, _ = oracle.mask_f32_to_bits(masks)
     mid = (np.arange(B) % 2).astype(np.int32)
-    noise = HostRng(2024).exponential(B * V).view(B, V).to(dev)
+    if noise_from == "device":
+        noise = DeviceRng(engine, 2024, V).rows(B)
+    else:
+        noise = HostRng(2024).exponential(B * V).view(B, V).to(dev)
     margin = torch.empty(B, device=dev)
     logZ, lse, tok = engine.step(torch.from_numpy(x).to(dev), mask_kind=1, mask=_bits_dev(bits, dev),
                                  mask_id=torch.from_numpy(mid).to(dev), rng_mode=2, noise=noise, out_margin=margin)

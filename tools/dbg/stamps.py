@@ -18,7 +18,7 @@ from genlm_backend_amd.engine import HipEngine  # noqa: E402
 shape = sys.argv[1] if len(sys.argv) > 1 else "gpt2"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 B, V, dt = (1024, 50257, torch.float32) if shape == "gpt2" else (512, 128256, torch.bfloat16)
-eng = HipEngine("cuda:0")
+eng = HipEngine("cuda:0", contract=os.environ.get("GLB_CONTRACT", "poly"))
 dev = eng.device
 g = torch.Generator(device=dev)
 g.manual_seed(0)
