@@ -292,10 +292,10 @@ def main():
                          "else (and everything, if the file was made by another build of the libraries) by the library's default; "
                          "library - the defaults; tune - time the solutions of every new shape during the warm-up (seconds a shape) "
                          "and write --gemms-file at exit")
-    ap.add_argument("--contract", choices=["poly", "hw", "auto"], default="poly",
-                    help="arithmetic of the fused step's terms (include/glb.h GLB_STEP_HW_EXP): poly - the polynomial exponential, "
-                         "bit for bit the oracle's; hw / auto - v_exp_f32 for 16-bit logits (checked against the oracle by tolerance), "
-                         "the polynomial for float32 rows")
+    ap.add_argument("--contract", choices=["poly", "hw", "auto"], default="auto",
+                    help="arithmetic of the fused step's terms (include/glb.h GLB_STEP_HW_EXP): auto (default, the product's) / hw - "
+                         "v_exp_f32 for 16-bit logits (checked against the oracle by tolerance), the polynomial for float32 rows; "
+                         "poly - the polynomial exponential for every element type, bit for bit the oracle's")
     ap.add_argument("--gemms-file", default=None, help="--gemms tune: the file to extend (default: $TMPDIR/glb_tunableop.csv)")
     args = ap.parse_args()
     args.gemm_shapes = 0
@@ -332,13 +332,13 @@ def main():
     if cpu_only:
         return plumbing(args, rank, world, dist)
     dev = torch.device("cuda", local_rank)
-    if args.workload not in ("kernel", "kernel-llama", "trie"):  # (here, in the rank's own process: the parent that starts the ranks never touches the GPU)
+    if args.workload not in ("kernel", "kernel-llama", "trie") and args.gemms == "tune":  # (here, in the rank's own process: the parent that starts the ranks never touches the GPU)
         from genlm_backend_amd import gemm_tuning
 
-        if args.gemms == "tune":
-            gemm_tuning.record(args.gemms_file or os.path.join(os.environ.get("TMPDIR", "/tmp"), "glb_tunableop.csv"))
-        elif args.gemms == "recorded":
-            args.gemm_shapes = gemm_tuning.use_recorded(device=dev)
+        gemm_tuning.record(args.gemms_file or os.path.join(os.environ.get("TMPDIR", "/tmp"), "glb_tunableop.csv"))
+    # --gemms recorded goes through the product's own option, AsyncAmdLM(gemms="recorded") (= load_model_by_name(name,
+    # llm_opts={"gemms": "recorded"})): what the line measures is what a user of the backend gets with that option
+    lm_gemms = "recorded" if args.gemms == "recorded" else "library"
     torch.cuda.set_device(dev)
 
     import genlm_backend_amd  # noqa: F401
@@ -371,7 +371,7 @@ def main():
     elif workload in ("api", "api-coro", "api-readme", "api-logprobs"):
         runner = ApiWorkload(eng, dev, rank, world, dist, logprobs=workload == "api-logprobs", coro=workload == "api-coro",
                              auto_kv=args.auto_kv, readme=workload == "api-readme", llm_gather=args.llm_gather,
-                             device_batch=args.device_batch)
+                             device_batch=args.device_batch, gemms=lm_gemms)
     else:
         from genlm_backend_amd.sis import SisBenchWorkload
 
@@ -380,7 +380,8 @@ def main():
                                   n_particles=512 if workload == "sis-llama" else 1024, n_prompts=args.prompts,
                                   resample=args.resample, force_collectives=force_coll,
                                   kv_in_place=None if args.kv_gather else 0.75, per_particle_masks=args.per_row_masks,
-                                  rng="torch" if args.rng == "parity" else "philox")
+                                  rng="torch" if args.rng == "parity" else "philox", gemms=lm_gemms)
+    args.gemm_shapes = getattr(getattr(runner, "llm", None), "gemm_shapes", 0)
 
     rccl_ranks = None
     if dist is not None:  # one collective before the clock starts: proves every rank is on the RCCL communicator
@@ -432,7 +433,7 @@ def main():
         from genlm_backend_amd.sis import SisBenchWorkload
 
         runner_kv = SisBenchWorkload(eng, dev, rank, world, dist, particle_kv=True, model="gpt2", n_particles=1024,
-                                     n_prompts=args.prompts, force_collectives=force_coll)
+                                     n_prompts=args.prompts, force_collectives=force_coll, gemms=lm_gemms)
         dt_kv = timed_run(runner_kv)
         kv_extra = {"value_kv": runner_kv.particles_per_step * world * args.steps / dt_kv,
                     "ms_per_step_kv": dt_kv / args.steps * 1e3,
@@ -441,7 +442,19 @@ def main():
                                  "from a hipGraph with glb_slab_attention): beyond the reference's re-encode-every-step algorithm; "
                                  "same tokens",
                     "kv_rows": dict(runner_kv.sis.kv_stats)}
+        runner_kv.llm.close()
         del runner_kv
+
+    # ... and `value` once more with the GEMM library's own choice of kernels (what AsyncAmdLM runs unless asked for the
+    # recorded solutions): the default line carries both, so that neither hides behind the other
+    lib_extra = None
+    if workload == "sis" and kv_extra is not None and args.gemm_shapes:
+        kern_first = runner.kernel_times_us()
+        runner.llm.close()  # TunableOp off: the library's defaults from here on
+        dt_lib = timed_run(runner)
+        lib_extra = {"value_library_gemms": runner.particles_per_step * world * args.steps / dt_lib,
+                     "ms_per_step_library_gemms": dt_lib / args.steps * 1e3}
+        runner.keep_kernel_times(len(kern_first))  # the roofline block stays the first run's launches
 
     kern_us = runner.kernel_times_us()
     if rank == 0:
@@ -463,8 +476,10 @@ def main():
         }
         if args.workload not in ("kernel", "kernel-llama", "trie", "plumbing"):
             out["config"]["gemms"] = {
-                "recorded": f"PyTorch TunableOp: {args.gemm_shapes} shapes of genlm-backend_amd/tuned/<arch>.csv run by their recorded "
-                            "rocBLAS / hipBLASLt solution, the rest by the library's default" if args.gemm_shapes else
+                "recorded": f"AsyncAmdLM(gemms=\"recorded\") = load_model_by_name(name, llm_opts={{\"gemms\": \"recorded\"}}): PyTorch "
+                            f"TunableOp, {args.gemm_shapes} shapes of genlm-backend_amd/tuned/<arch>.csv run by their recorded "
+                            "rocBLAS / hipBLASLt solution, the rest by the library's default; value_library_gemms = the same loop with "
+                            "the backend's default option (gemms=\"library\")" if args.gemm_shapes else
                             "the library's default solutions (no recorded file for this build of the libraries)",
                 "library": "the library's default solutions",
                 "tune": "PyTorch TunableOp, tuned during the warm-up"}[args.gemms]
@@ -478,8 +493,13 @@ def main():
             out["rccl_note"] = rccl_note
         if kv_extra is not None:
             out.update(kv_extra)
+        if lib_extra is not None:
+            out.update(lib_extra)
         if kern_us is not None and len(kern_us):
             ach = runner.kernel_bytes / (np.mean(kern_us) * 1e-6) / 1e9
+            each_bytes = getattr(runner, "kernel_bytes_each", None)
+            if each_bytes is None or len(each_bytes) != len(kern_us):
+                each_bytes = np.full(len(kern_us), float(runner.kernel_bytes))
             outer = runner.outer_times_us()
             traffic, traffic_src = pmc_traffic(workload + ("-rowmasks" if args.per_row_masks and workload.startswith("kernel") else "")
                                                + (f"-{args.trie_out}" if workload == "trie" else ""))
@@ -489,7 +509,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS,
-                "frac_median": runner.kernel_bytes / (np.median(kern_us) * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                # the median over the timed launches of (that launch's bytes / that launch's time): a loop's launches differ in
+                # size (SIS step 0 reads one shared row), so bytes and time are paired per launch, never a mean over a median
+                "frac_median": float(np.median(each_bytes / (kern_us * 1e-6))) / 1e9 / HBM_PEAK_GBS,
                 "traffic": traffic,
                 # (counters cannot be read from inside the process: NOT measured in this run, but by an earlier rocprofv3
                 # --pmc pass of this same command whose summary is committed under profiles/)
@@ -607,6 +629,8 @@ class TrieWorkload:
         self.out_kind, self.B, self.V, self.eng = out, B, V, eng
         self.particles_per_step = B
         self.sel = torch.from_numpy(rs.choice(len(self.trie), 4096, replace=False).astype(np.int32)).to(dev)
+        if out == "selected":  # one selection asked for again and again: its sub-forest is planned once, up front (host work)
+            self.trie.prepare_selection(self.sel)
         # a selection per row: the children (<= 256) of the row's current node - one of the root's children, or the root itself
         d1 = sorted(self.trie.children[self.trie.root].values())
         cur = [self.trie.root] * B if out == "rowsel-root" else [d1[int(k)] for k in rs.integers(0, len(d1), B)]
@@ -827,7 +851,7 @@ class ApiWorkload:
     dtype_name = "f32"
 
     def __init__(self, eng, dev, rank, world, dist, logprobs=False, coro=False, n_particles=1024, max_tokens=10,
-                 auto_kv=False, readme=False, llm_gather=False, device_batch=False):
+                 auto_kv=False, readme=False, llm_gather=False, device_batch=False, gemms="library"):
         import asyncio
 
         from transformers import GPT2Config
@@ -837,7 +861,7 @@ class ApiWorkload:
         self.asyncio = asyncio
         cfg = GPT2Config()
         self.llm = AsyncAmdLM.from_config(cfg, None, device=dev, dtype=torch.float32, seed=1234, engine=eng,
-                                          batch_size=n_particles, timeout=0.02,
+                                          batch_size=n_particles, timeout=0.02, gemms=gemms,
                                           auto_kv_rows=n_particles + n_particles // 4 if auto_kv else 0, auto_kv_cap=24)
         self.auto_kv = auto_kv
         self.llm_gather = llm_gather

@@ -78,7 +78,7 @@ class AutoKV:
                 if self._slab_fwd is None or self._slab_fwd.pkv is not self.pkv:
                     from .kv import SlabForward
 
-                    self._slab_fwd = SlabForward(self.pkv, llm._body, graph=self.graph)
+                    self._slab_fwd = SlabForward(self.pkv, llm._body, graph=self.graph, owner=llm)
                 hidden = self._slab_fwd(ids, pos_d)
                 parts.append(llm._lm_head(hidden.index_select(0, plan["rows_a"][:nA].long())))
                 st["in_place_calls"] += 1

@@ -223,7 +223,12 @@ __device__ __forceinline__ void load_chunk_raw(const char *rowp, int e_base, int
     // A/B (tools/ab.sh, tools/ab_sis.sh): fp32 step 45.4 -> 42.7 us on rotating buffers and 44.5 -> 36.8 us inside the
     // SIS loop, right behind the lm_head GEMM that wrote the logits; 16-bit rows (bound by VALU issue) unchanged.
     for (int i = 0; i < NVC; ++i)
+#if defined(GLB_PLAIN_LOADS_16)  // (experiment: default cache policy for 16-bit rows - the draw's reload may then hit the Infinity Cache)
+      raw[i] = DT != kDtF32 ? *reinterpret_cast<const u32x4_t *>(q + (int64_t)i * 64 * 16)
+                            : __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(q + (int64_t)i * 64 * 16));
+#else
       raw[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(q + (int64_t)i * 64 * 16));
+#endif
   } else {
 #pragma unroll
     for (int i = 0; i < NVC; ++i) raw[i] = load_vec_guarded<DT>(rowp, e_base + (i * 64 + lane) * EPV, V);

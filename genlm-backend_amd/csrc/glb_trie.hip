@@ -325,15 +325,17 @@ struct RowVec {  // 16-bit rows: eight tokens in 16 bytes, on any 2-byte boundar
 // The reduction of a swept part.  A node: its children are consecutive in LDS, added one by one in ascending order in
 // double, the node stored as float32 - the arithmetic and the order of part_reduce.  A depth lists the nodes with the most
 // children first, so a wave's nodes have about the same number: the wave takes eight or four children a trip, whatever
-// its widest node needs (reading past a node's last child stays inside the part's LDS - 32 words follow the values - and
-// adds +0, which changes no bit of a sum that started from +0).  OP at compile time: no branch inside a node.
+// its widest node needs.  A lane reads at most 7 words past its node's last child (inside the part's LDS: 32 words follow
+// the values; what it reads there is selected away and +0 added instead, which changes no bit of a sum that started from
+// +0); a lane whose node is finished while the wave's widest one is not reads its own first children again, not further
+// and further past its node.  OP at compile time: no branch inside a node.
 template <int OP>
 __device__ __forceinline__ void sweep_node(float *val, uint64_t e) {
   const int s = (int)(e & 0xffffu), c0 = (int)((e >> 16) & 0xffffu), cnt = (int)(e >> 32);
   double acc = 0.0;
   for (int base = 0; __any(base < cnt); base += 8) {
-    const float *q = val + c0 + base;
     const int rem = cnt - base;
+    const float *q = val + c0 + (rem > 0 ? base : 0);
     if (__any(rem > 4)) {
       float x[8];
 #pragma unroll

@@ -230,11 +230,13 @@ class HipEngine:
 
     CONTRACTS = ("poly", "hw", "auto")
 
-    def __init__(self, device=None, contract="poly"):
+    def __init__(self, device=None, contract="auto"):
         """contract: the arithmetic of the fused step's terms (include/glb.h, GLB_STEP_HW_EXP) - "poly":
-        the polynomial exponential every element type has, restated bit for bit by the oracle; "hw" / "auto": the
-        hardware's v_exp_f32 for 16-bit logits (float32 rows have the polynomial only), checked against the oracle by
-        tolerance.  `step(contract=...)` overrides it per call."""
+        the polynomial exponential every element type has, restated bit for bit by the oracle; "hw" / "auto" (the
+        default): the hardware's v_exp_f32 for 16-bit logits - a third less time on rows bound by instruction issue,
+        within one ulp of 2^y, deterministic and independent of launch geometry on gfx950, checked against the oracle by
+        tolerance and against torch's ids in parity mode (tests/test_step_hw_gpu.py) - and the polynomial for float32 rows,
+        which have nothing else.  `step(contract=...)` overrides it per call."""
         if contract not in self.CONTRACTS:
             raise ValueError(f"contract must be one of {self.CONTRACTS}, got {contract!r}")
         self.contract = contract
@@ -660,14 +662,24 @@ class HipEngine:
     def _ptr_table(self, tensors):
         """Device table of the tensors' addresses.  Slab sets are handed over again and again: the table of a set is made
         once (a host list -> device copy from pageable memory is a synchronous copy - one in every step kept the host from
-        running ahead of the GPU) and kept with the tensors it names, so an address cannot be reused under it."""
+        running ahead of the GPU).  An entry names its tensors by WEAK references: it never keeps a slab set alive (a set is
+        gigabytes at the Llama-3-8B shape, and an engine outlives many DeviceSIS / SlabKV objects), and it is only valid
+        while every one of them is the very object it was made for - an address the allocator hands out again after its
+        owner died does not pass for the old tensor.  Entries whose tensors are gone leave at the next miss."""
+        import weakref
+
         key = tuple(t.data_ptr() for t in tensors)
         ent = self._ptr_tables.get(key)
-        if ent is None:
-            if len(self._ptr_tables) >= 64:
-                self._ptr_tables.pop(next(iter(self._ptr_tables)))
-            ent = self._ptr_tables[key] = (torch.tensor(key, dtype=torch.int64, device=self.device), list(tensors))
-        return ent[0]
+        if ent is not None and all(r() is t for r, t in zip(ent[1], tensors)):
+            return ent[0]
+        dead = [k for k, (_, refs) in self._ptr_tables.items() if any(r() is None for r in refs)]
+        for k in dead:
+            del self._ptr_tables[k]
+        if len(self._ptr_tables) >= 64:
+            self._ptr_tables.pop(next(iter(self._ptr_tables)))
+        table = torch.tensor(key, dtype=torch.int64, device=self.device)
+        self._ptr_tables[key] = (table, [weakref.ref(t) for t in tensors])
+        return table
 
     def gather_rows_i32(self, src, row_of, out=None):
         """out[i] = src[row_of[i]] for an int32 matrix (glb_gather_rows_i32)."""

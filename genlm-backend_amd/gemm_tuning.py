@@ -13,10 +13,12 @@ file whose validators differ and runs the default solutions).
     record(path)        tune every new shape this process meets (seconds a shape, once) and write `path` at exit:
                         how tuned/<arch>.csv was made (tools/record_gemm_tuning.sh) and how to add an application's shapes.
 
-Process-wide switches of PyTorch, so nothing here is called by the backend itself: `bench.py` asks for the recorded
-solutions (--gemms recorded, its default), an application calls `use_recorded()` if it wants them.  The solutions are the
-library's kernels at the tensors' own precision; what changes is the order of a GEMM's additions (the last bits of the
-logits), as between any two library versions."""
+Process-wide switches of PyTorch, so the backend touches them only when asked: `AsyncAmdLM(gemms="recorded")` /
+`load_model_by_name(name, llm_opts={"gemms": "recorded"})` takes the recorded solutions (`acquire()`), `AsyncAmdLM.close()`
+gives them back (`release()`: the last holder switches TunableOp off again) - the option `bench.py --gemms recorded` goes
+through, so that a bench line's `value` is one a user of the backend reproduces with that option; the default
+(gemms="library") leaves PyTorch alone.  The solutions are the library's kernels at the tensors' own precision; what
+changes is the order of a GEMM's additions (the last bits of the logits), as between any two library versions."""
 import os
 
 import torch
@@ -56,6 +58,33 @@ def use_recorded(path=None, device=None):
         except Exception:
             pass
     return n
+
+
+_holders = 0
+_held_shapes = 0
+
+
+def acquire(device=None):
+    """use_recorded() for one more holder (AsyncAmdLM(gemms="recorded")); returns the number of shapes taken over."""
+    global _holders, _held_shapes
+    if _holders == 0:
+        _held_shapes = use_recorded(device=device)
+    _holders += 1
+    return _held_shapes
+
+
+def release():
+    """One holder less; the last one switches TunableOp off again (PyTorch's state as this module found it)."""
+    global _holders, _held_shapes
+    if _holders == 0:
+        return
+    _holders -= 1
+    if _holders == 0:
+        _held_shapes = 0
+        try:
+            off()
+        except Exception:
+            pass
 
 
 def record(path):

@@ -276,8 +276,10 @@ class SlabForward:
     rows: 10.4 -> 7.2 ms).  A graph belongs to the slab tensors it was captured over (a resampling `gather` swaps slab
     sets: one graph each).  `graph=False` (or a CPU device) keeps every call eager."""
 
-    def __init__(self, pkv, body, graph=True, fused_attention=True):
+    def __init__(self, pkv, body, graph=True, fused_attention=True, owner=None):
         self.pkv, self.body = pkv, body
+        self.owner = owner  # the AsyncAmdLM whose `refresh_weights()` drops the captured graphs (its weights_epoch moves)
+        self._owner_epoch = getattr(owner, "weights_epoch", 0)
         self.graph_ok = bool(graph) and torch.cuda.is_available()
         self.calls = 0
         self.graphs = {}  # identity of the slab set -> (graph, ids, pos, hidden, the slab tensors themselves)
@@ -335,6 +337,10 @@ class SlabForward:
             if ver != self._watched_version:  # the caller changed a weight in place: captured launches would read stale copies
                 self.graphs.clear()
                 self._watched_version = ver
+        ep = getattr(self.owner, "weights_epoch", 0)
+        if ep != self._owner_epoch:  # AsyncAmdLM.refresh_weights(): writes the version counters cannot see (param.data)
+            self.graphs.clear()
+            self._owner_epoch = ep
         # a graph belongs to the slab tensors it was captured over: every layer's addresses, shape and dtype make the key,
         # and the entry holds the tensors, so the allocator cannot hand their addresses to another slab set meanwhile
         slabs = self.pkv._tensors(self.pkv.layers)

@@ -187,7 +187,7 @@ class AsyncAmdLM(AsyncLM):
     @torch.no_grad()
     def __init__(self, hf_model, hf_tokenizer, batch_size=20, timeout=0.02, engine=None, fuse_activations=True,
                  kv_budget_bytes=8 << 30, logprob_budget_bytes=16 << 30, auto_kv_rows=0, auto_kv_cap=64,
-                 logprob_dtype="float32", glb_attention=True, merge_mlp=True):
+                 logprob_dtype="float32", glb_attention=True, merge_mlp=True, contract=None, gemms="library"):
         """The caller's `hf_model` is never modified (hf.py:114-140 leaves it alone too): with `fuse_activations` or
         `glb_attention` the forwards of this backend run on a private SHADOW of its module tree that shares every weight
         (fuse.shadow_model); `self.model` stays the caller's object.
@@ -203,14 +203,33 @@ class AsyncAmdLM(AsyncLM):
         bfloat16 checkpoint a third fewer bytes per materialised row: glb_log_softmax_rows' out_dtype).
         auto_kv_rows > 0: `batch_next_token_step` keeps the KV of the contexts it evaluates in that many slab rows of
         `auto_kv_cap` positions and feeds one token to every context whose first L - 1 tokens it finds there
-        (autokv.AutoKV; off by default: the reference re-encodes, hf.py:202-288)."""
+        (autokv.AutoKV; off by default: the reference re-encodes, hf.py:202-288).
+        contract: "poly" / "hw" / "auto" - the arithmetic of the fused step's terms (HipEngine; None: the engine's own, "auto"
+        for an engine made here: the hardware exponential for 16-bit logits, the polynomial for float32).
+        gemms: "library" (default: PyTorch picks the GEMM kernels as it always does) or "recorded" - the forward's GEMM
+        shapes run by the rocBLAS / hipBLASLt solution recorded for them in tuned/<arch>.csv (gemm_tuning: PyTorch TunableOp,
+        a PROCESS-WIDE switch that also reaches the caller's other GEMMs; 8-10 % of a step at 1024 particles; silently the
+        library's defaults when the file was made by another build of the libraries - `self.gemm_shapes` says how many
+        shapes were taken over).  `close()` gives the switch back."""
         self.model = hf_model
         self.tokenizer = hf_tokenizer
         self.device = hf_model.device
+        if gemms not in ("library", "recorded"):
+            raise ValueError(f"gemms must be 'library' or 'recorded', got {gemms!r}")
+        self.gemms, self.gemm_shapes = gemms, 0
+        if gemms == "recorded" and self.device.type == "cuda":
+            from . import gemm_tuning
+
+            self.gemm_shapes = gemm_tuning.acquire(self.device)
+            self._gemms_held = True
         if engine is None:
             from .engine import HipEngine  # raises without the library / a HIP device
 
-            engine = HipEngine(self.device)
+            engine = HipEngine(self.device, contract=contract or "auto")
+        elif contract is not None:
+            if contract not in engine.CONTRACTS:
+                raise ValueError(f"contract must be one of {engine.CONTRACTS}, got {contract!r}")
+            engine.contract = contract
         self.engine = engine
         if logprob_dtype not in ("float32", "model"):
             raise ValueError(f"logprob_dtype must be 'float32' or 'model', got {logprob_dtype!r}")
@@ -268,6 +287,36 @@ class AsyncAmdLM(AsyncLM):
             super().__init__(tokenizer=self.tokenizer)
         else:  # model-only use (synthetic benchmarks): no vocabulary to decode
             self.byte_vocab, self.str_vocab = None, None
+
+    def refresh_weights(self):
+        """Call after changing the model's weights in a way PyTorch's version counters do not see.  The shadow keeps derived
+        copies of some weights ([q; k; v] and [gate; up] as one matrix each: fuse.py) and captured hipGraphs of the
+        one-token forward read the copies they were captured with; both notice `param.copy_()` / `param.mul_()` and replaced
+        parameters by themselves (`Tensor._version`, identity, address), but NOT writes through `param.data` (EMA and
+        weight-merging code does that: `p.data.copy_(...)` bumps no counter and moves no address).  This drops every
+        derived copy and every captured graph - they are rebuilt from the current weights at the next forward - and the
+        cached log-prob rows and KV (made with the old weights: clear_cache())."""
+        for mod in self._net.modules():
+            mod.__dict__.pop("_glb_qkv", None)
+            mod.__dict__.pop("_glb_gate_up", None)
+        self.weights_epoch = getattr(self, "weights_epoch", 0) + 1  # SlabForward drops its graphs when this moves
+        self.clear_cache()
+
+    def close(self):
+        """Give back what this backend holds of the process's state: the recorded GEMM solutions (gemms="recorded").  The
+        object stays usable (its GEMMs then run by the library's defaults); safe to call more than once."""
+        if getattr(self, "_gemms_held", False):
+            from . import gemm_tuning
+
+            self._gemms_held = False
+            self.gemm_shapes = 0
+            gemm_tuning.release()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown
+            pass
 
     def _forget_prefix(self, node):
         self._kv_tokens.pop(id(node), None)

@@ -255,6 +255,7 @@ class DeviceSIS:
     def reset(self):
         if self.noise_src is not None:  # a run starts its seeded noise stream over
             self.noise_src.reset()
+        self._pm_prepared, self._pm_dirty = None, None  # (a new run may come with new masks: prepared again at its first step)
         self.contexts = self._ctx0.clone()
         self.prompt_len = self._prompt_len0.clone()
         self.lengths = self.prompt_len.clone()
@@ -333,7 +334,7 @@ class DeviceSIS:
         if self._slab_fwd is None or self._slab_fwd.pkv is not self.pkv:
             from .kv import SlabForward
 
-            self._slab_fwd = SlabForward(self.pkv, llm._body, graph=self.kv_graph)
+            self._slab_fwd = SlabForward(self.pkv, llm._body, graph=self.kv_graph, owner=llm)
         logits = llm._lm_head(self._slab_fwd(ids, pos))  # [N, V]
         self._noise_groups = None
         if self.rng_mode == RNG_NOISE:  # parity draws follow the reference's resolution order: by dedup group
@@ -379,7 +380,7 @@ class DeviceSIS:
                 if self._slab_fwd is None or self._slab_fwd.pkv is not self.pkv:
                     from .kv import SlabForward
 
-                    self._slab_fwd = SlabForward(self.pkv, llm._body, graph=self.kv_graph)
+                    self._slab_fwd = SlabForward(self.pkv, llm._body, graph=self.kv_graph, owner=llm)
                 hidden = self._slab_fwd(ids, pos_d)
                 logits_parts.append(llm._lm_head(hidden.index_select(0, plan["rows_a"][:nA].long())))
                 st["in_place_steps"] += 1
@@ -427,11 +428,16 @@ class DeviceSIS:
         if self.particle_masks is not None:  # one mask per particle: per-particle ids, no dedup of the math
             # the bit rows are brought into the kernels' layout once; afterwards only the rows `update_particle_masks` named
             # are prepared again (a grammar moves a few particles' masks a step: glb_mask_prepare_rows)
+            # The prepared form is valid for exactly the tensor state it was made from: `particle_masks` rebound to another
+            # tensor, or written in place by anyone but `update_particle_masks` (its version counter moves), is prepared
+            # again as a whole - a caller that edits the bit rows directly gets correct draws, just not the incremental path.
             own = torch.arange(N, dtype=torch.int32, device=self.dev)
-            if self._pm_prepared is None or self._pm_prepared[1] != logits.dtype:
-                self._pm_prepared = (eng.prepare_masks(self.particle_masks, V, logits.dtype), logits.dtype)
+            pm = self.particle_masks
+            state = (pm.data_ptr(), pm._version, logits.dtype)
+            if self._pm_prepared is None or self._pm_prepared[1] != state:
+                self._pm_prepared = (eng.prepare_masks(pm, V, logits.dtype), state)
             elif self._pm_dirty is not None:
-                eng.update_prepared_masks(self._pm_prepared[0], self.particle_masks, self._pm_dirty)
+                eng.update_prepared_masks(self._pm_prepared[0], pm, self._pm_dirty)
             self._pm_dirty = None
             kw = dict(mask=self._pm_prepared[0], mask_id=torch.where(mask_id > 0, torch.full_like(own, N), own))
         elif kw:
@@ -478,8 +484,12 @@ class DeviceSIS:
     def update_particle_masks(self, rows, bit_rows):
         """Particles `rows` (int32 device tensor) get new masks `bit_rows` (int32 [len(rows), ceil(V / 32)]): only these are
         brought into the kernels' layout again before the next step."""
-        self.particle_masks[rows.long()] = bit_rows
-        self._pm_dirty = rows if self._pm_dirty is None else torch.unique(torch.cat([self._pm_dirty, rows]))
+        pm = self.particle_masks
+        known = self._pm_prepared is not None and self._pm_prepared[1][:2] == (pm.data_ptr(), pm._version)
+        pm[rows.long()] = bit_rows
+        if known:  # the prepared form follows this write row by row; any other write makes the next step prepare everything
+            self._pm_prepared = (self._pm_prepared[0], (pm.data_ptr(), pm._version, self._pm_prepared[1][2]))
+            self._pm_dirty = rows if self._pm_dirty is None else torch.unique(torch.cat([self._pm_dirty, rows]))
 
     def _exchange(self):
         """All-gather of the per-shard log-weights and active counts (RCCL over xGMI when the backend is nccl): every
@@ -766,7 +776,7 @@ class SisBenchWorkload:
 
     def __init__(self, eng, dev, rank, world, dist, n_particles=1024, max_tokens=10, prefix_kv=False, particle_kv=False,
                  model="gpt2", n_prompts=1, resample=False, force_collectives=False, kv_in_place=0.75,
-                 per_particle_masks=False, rng="philox"):
+                 per_particle_masks=False, rng="philox", gemms="library"):
         from .llm import AsyncAmdLM
 
         if model == "gpt2":
@@ -795,7 +805,7 @@ class SisBenchWorkload:
         self.dtype_name = "f32" if dtype == torch.float32 else "bf16"
         self.elem = 4 if dtype == torch.float32 else 2
         self.llm = AsyncAmdLM.from_config(cfg, None, device=dev, dtype=dtype, seed=1234, engine=eng,
-                                          batch_size=n_particles)
+                                          batch_size=n_particles, gemms=gemms)
         V = cfg.vocab_size
         g = torch.Generator(device=dev)
         g.manual_seed(4321)
@@ -868,7 +878,15 @@ class SisBenchWorkload:
     def kernel_times_us(self):
         self._collect()
         self.kernel_bytes = float(np.mean(self._bytes)) if self._bytes else 0.0
+        self.kernel_bytes_each = np.array(self._bytes, dtype=np.float64)  # per timed launch, in the order of the times
         return np.array([a.elapsed_time(b) * 1e3 for a, b in self._events])
+
+    def keep_kernel_times(self, n):
+        """Forget the timed launches after the first n (bench.py runs the loop a second time for another line of the same
+        JSON object; the roofline block stays the first run's)."""
+        self._collect()
+        for name in ("_events", "_outer", "_bytes", "unique_hist", "fed_hist", "flops_hist"):
+            setattr(self, name, getattr(self, name)[:n])
 
     def outer_times_us(self):
         return np.array([a.elapsed_time(b) * 1e3 for a, b in self._outer])

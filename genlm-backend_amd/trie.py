@@ -414,17 +414,33 @@ class TokenByteTrie:
                     slot_compact=np.argsort(new_slot).astype(np.int32))  # new slot -> compact() slot
         return plan
 
-    def selection_plan(self, nodes):
+    def prepare_selection(self, nodes):
+        """Plan the sub-forest below a selection of nodes that will be asked for again and again (`masses_from_logits(nodes=
+        this tensor)` then reads and reduces only those subtrees: 4096 nodes of a 50 k-token trie 179 -> 78 us a call).  Host
+        work - a device-to-host copy of the ids (a stream synchronisation), a plan of the sub-forest in Python, some twenty
+        small uploads: tens of milliseconds - which is why it is asked for, not done behind a call's back: a selection that
+        changes every step (the children of each particle's current node) belongs to the per-row form (`nodes` [B, K]),
+        whose need mask is made on the device.  Returns True when a pruned plan is in place (False: the selection reaches
+        the root or covers half the trie - the whole trie's plan serves it)."""
+        return self.selection_plan(nodes, build=True) is not None
+
+    def selection_plan(self, nodes, build=False):
         """The plan of the sub-forest a selection of nodes needs (`_build_plan`), on the device, cached per selection tensor
-        (its storage and version).  None: use the whole trie's plan (the selection reaches the root, or has no plan)."""
+        (its storage and version).  None: use the whole trie's plan (the selection reaches the root, has no plan, or - unless
+        `build` - was never prepared: `prepare_selection`).  Ids outside the trie (negative: "none", as the kernel reads
+        them) select nothing."""
         key = (nodes.data_ptr(), nodes._version, nodes.numel())
         ent = self._sel_plans.get(key)
+        if ent is None and not build:
+            return None
         if ent is None:
             if len(self._sel_plans) >= 8:
                 self._sel_plans.pop(next(iter(self._sel_plans)))
             c = self.compact()
             kids, size, root = self._tree()
-            sel = np.unique(c["slot_of"].astype(np.int64)[nodes.cpu().numpy().astype(np.int64)])
+            ids = nodes.cpu().numpy().astype(np.int64).reshape(-1)
+            ids = ids[(ids >= 0) & (ids < len(c["slot_of"]))]
+            sel = np.unique(c["slot_of"].astype(np.int64)[ids])
             # the maximal selected slots: drop every slot that lies below another selected one (slots ascend children first,
             # so a subtree is the slot range (s - size[s], s])
             sel_desc = sel[::-1]
@@ -492,7 +508,11 @@ class TokenByteTrie:
 
     _COMPACT_ROWS = 32  # from here on the kernels keep the values node-major: the folded trie pays
 
-    prune_selection = True  # masses of selected nodes: plan only the sub-forest below them (selection_plan)
+    # masses of selected nodes ([len(nodes)] for every row) through a plan of only the sub-forest below them: "cached" (the
+    # default) - when the caller prepared this selection (`prepare_selection(nodes)`: the host work is asked for, never
+    # done behind a call's back), else the whole trie's plan; True - planned at the first call that meets a selection
+    # (synchronises the stream once per new selection tensor); False - never
+    prune_selection = "cached"
     sweep = True  # whole-trie masses through the plan whose parts read a row front to back (plan(sweep=True)): the slots always
     # (their numbering is that plan's: `slot_plan()`; 1024 rows 193 -> 140 us, 8 rows 17 -> 21), all nodes from SWEEP_MIN_ROWS
     # rows on (1024: 309 -> 273 us, 512: 158 -> 146; below, the gathered plan's many small workgroups fill the chip better:
@@ -575,7 +595,7 @@ class TokenByteTrie:
                 pl = self.plan_device_arrays()
         if pl is not None and nodes is not None and nodes.dim() == 1 and layout == "rows" and self.prune_selection:
             # only the subtrees below the selected nodes are read and reduced (a plan of that sub-forest, cached per selection)
-            pl = self.selection_plan(nodes) or pl
+            pl = self.selection_plan(nodes, build=self.prune_selection is True) or pl
         if pl is not None:
             got = self._trie_rows(logits, pl, op, True, lse=lse, logit_scale=logit_scale, nodes=nodes,
                                   layout="slots" if layout == "slot_rows" and nodes is None else "rows")

@@ -56,10 +56,12 @@ class CpuOracleEngine:
         return _OracleNoise(seed, vocab)
 
     def prepare_masks(self, bits, vocab, logits_dtype=torch.float32):
-        return _Prepared(bits)
+        return _Prepared(bits.clone())  # (a snapshot, as the device's prepared form is: later writes to `bits` do not reach it)
 
     def update_prepared_masks(self, prepared, bits, rows):
-        prepared.bits = bits  # (the double keeps the plain bit rows)
+        idx = rows.long()
+        idx = idx[(idx >= 0) & (idx < bits.shape[0])]
+        prepared.bits[idx] = bits[idx]  # (only the named rows, as glb_mask_prepare_rows)
         return prepared
 
     def step(self, logits, vocab=None, row_of=None, mask_kind=0, mask=None, mask_id=None, rng_mode=0, noise=None,

@@ -288,6 +288,23 @@ def test_device_sis_with_one_mask_per_particle(llm, gold):
     want = [[3 + i] * 3 for i in range(16)]
     want[2], want[5] = [5, 40, 40], [8, 41, 41]
     assert [list(map(int, c)) for c in ctx] == want
+    # ... and masks the caller edits IN PLACE, or replaces, without telling (the pattern that was supported before the
+    # prepared form existed): the next step sees the tensor's version / identity change and prepares everything again
+    sis = DeviceSIS(llm, 16, prompt, max_tokens=3, eos_id=0, seed=1, particle_masks=pm2.clone())
+    sis.step()
+    sis.particle_masks[7] = llm.engine.mask_to_bits(other)[0][0]  # particle 7 may only emit 40 from now on
+    sis.step()
+    fresh = pm2.clone()
+    fresh[9] = llm.engine.mask_to_bits(other)[0][1]
+    fresh[7] = llm.engine.mask_to_bits(other)[0][0]
+    sis.particle_masks = fresh                                     # a new tensor: particle 9 may only emit 41
+    sis.step()
+    ctx, _ = sis.results()
+    want = [[3 + i] * 3 for i in range(16)]
+    want[7], want[9] = [10, 40, 40], [12, 12, 41]
+    assert [list(map(int, c)) for c in ctx] == want
+    sis.reset()  # a new run prepares its masks again
+    assert sis._pm_prepared is None
 
 
 @pytest.mark.parametrize("use_kv", [False, True])
@@ -897,3 +914,18 @@ def test_recorded_gemm_solutions_file_is_well_formed_and_optional():
     assert len(ents) > 100 and all(len(e) == 4 and e[0].startswith("Gemm") and float(e[3]) > 0 for e in ents)
     assert len({(e[0], e[1]) for e in ents}) == len(ents)  # (a shape once)
     assert any(e[1].startswith("tn_50257_1024_768") for e in ents)  # (BASELINE config 2's lm_head)
+    # the product's handle on the process-wide switch (AsyncAmdLM(gemms="recorded") / close()): counted, the last holder
+    # switches TunableOp off again
+    calls = []
+    real_use, real_off = gemm_tuning.use_recorded, gemm_tuning.off
+    gemm_tuning.use_recorded = lambda path=None, device=None: calls.append("on") or 7
+    gemm_tuning.off = lambda: calls.append("off")
+    try:
+        assert gemm_tuning.acquire() == 7 and gemm_tuning.acquire() == 7 and calls == ["on"]
+        gemm_tuning.release()
+        assert calls == ["on"]
+        gemm_tuning.release()
+        gemm_tuning.release()  # (one too many: nothing happens)
+        assert calls == ["on", "off"]
+    finally:
+        gemm_tuning.use_recorded, gemm_tuning.off = real_use, real_off

@@ -188,6 +188,50 @@ def test_backend_sis_on_gpu_matches_reference(llm):
     assert ids == [int(t) for t in gold["sample_ids"]]
 
 
+def test_device_sis_per_particle_masks_follow_in_place_edits_on_gpu(llm):
+    """`DeviceSIS(particle_masks=...)` on the HIP engine: the bit rows are brought into the kernels' layout once and only the
+    rows `update_particle_masks` names are prepared again - but a caller that writes `sis.particle_masks` in place, or rebinds
+    it (the pattern the raw hand-over supported), must never sample under the stale prepared form: the tensor's version /
+    identity is checked every step.  Golden run first: every particle under the README's `valid` mask."""
+    from genlm_backend_amd.sis import DeviceSIS
+
+    m, gold = llm
+    masks = torch.from_numpy(gold["sis_masks"])
+    m.register_masks(masks)
+    prompt = [int(t) for t in gold["sis_prompt"]]
+    dev = m.device
+    bits, _ = m.engine.mask_to_bits(masks.to(dev))
+    pm = torch.cat([bits[:1].expand(16, -1), bits[1:2]]).contiguous()
+    sis = DeviceSIS(m, 16, prompt, max_tokens=10, eos_id=0, seed=1234, rng="torch", particle_masks=pm)
+    sis.run()
+    ctx, lw = sis.results()
+    assert [list(map(int, c)) for c in ctx] == [_strip(r) for r in gold["sis_contexts"]]
+    assert np.abs(lw - gold["sis_log_weights"]).max() < TOL
+    V = masks.shape[1]
+    only = torch.full((17, V), float("-inf"), device=dev)
+    for i in range(16):
+        only[i, 3 + i] = 0.0
+    only[16, 0] = 0.0
+    pm2, _ = m.engine.mask_to_bits(only)
+    other = torch.full((2, V), float("-inf"), device=dev)
+    other[0, 40], other[1, 41] = 0.0, 0.0
+    ob, _ = m.engine.mask_to_bits(other)
+    sis = DeviceSIS(m, 16, prompt, max_tokens=4, eos_id=0, seed=1, particle_masks=pm2.clone())
+    sis.step()
+    sis.update_particle_masks(torch.tensor([2], dtype=torch.int32, device=dev), ob[:1])  # told: row 2 prepared again
+    sis.step()
+    sis.particle_masks[7] = ob[0]          # not told: written in place
+    sis.step()
+    fresh = sis.particle_masks.clone()
+    fresh[9] = ob[1]
+    sis.particle_masks = fresh             # not told: another tensor
+    sis.step()
+    ctx, _ = sis.results()
+    want = [[3 + i] * 4 for i in range(16)]
+    want[2], want[7], want[9] = [5, 40, 40, 40], [10, 10, 40, 40], [12, 12, 12, 41]
+    assert [list(map(int, c)) for c in ctx] == want
+
+
 def test_device_sis_philox_is_shard_invariant(llm):
     """Sharding the population (particle_base) does not change any particle's draws or weights."""
     from genlm_backend_amd.sis import DeviceSIS
@@ -391,6 +435,41 @@ def test_llama_shaped_model_on_gpu_matches_reference(engine):
     assert gen == [_strip(r) for r in gold["llama::sis_contexts"]]
     assert np.abs(lw.astype(np.float32) - gold["llama::sis_log_weights"]).max() < TOL
     assert a._auto_kv.stats["encoded_rows"] == 3 and a._auto_kv.stats["in_place_calls"] >= 1
+
+
+def test_refresh_weights_after_a_write_the_version_counters_do_not_see(engine):
+    """the shadow's derived [q; k; v] / [gate; up] weights follow `param.mul_()` by themselves (Tensor._version)
+    but not `param.data.mul_()` (EMA / weight-merging code): `AsyncAmdLM.refresh_weights()` drops the derived copies, the
+    captured graphs and the caches, and the backend then computes what the caller's model computes."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    from genlm_backend_amd.llm import AsyncAmdLM
+
+    gold = np.load(G2)
+    cfg = ast.literal_eval(bytes(gold["llama::config_json"]).decode())
+    model = LlamaForCausalLM(LlamaConfig(**cfg)).eval()
+    model.load_state_dict({k[len("llama::w::"):]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("llama::w::")})
+    model = model.to(engine.device)
+    m = AsyncAmdLM(model, None, batch_size=64, engine=engine)
+    m.tokenizer = Tok()
+    prompts = [_strip(r) for r in gold["llama::lp_prompts"]]
+    ids = torch.tensor([prompts[0]], device=engine.device)
+
+    def own():
+        with torch.no_grad():
+            return torch.log_softmax(model(ids).logits[0, -1].float(), -1)
+
+    before = m.batch_next_token_logprobs_sync(prompts[:1])[0]
+    assert (before - own()).abs().max().item() < TOL
+    with torch.no_grad():  # a write PyTorch counts: followed without being told
+        model.model.layers[0].self_attn.q_proj.weight.mul_(1.5)
+    m.clear_cache()
+    assert (m.batch_next_token_logprobs_sync(prompts[:1])[0] - own()).abs().max().item() < TOL
+    model.model.layers[0].self_attn.k_proj.weight.data.mul_(1.7)  # a write it does not count
+    model.model.layers[1].mlp.up_proj.weight.data.mul_(0.6)
+    m.refresh_weights()
+    after = m.batch_next_token_logprobs_sync(prompts[:1])[0]
+    assert (after - own()).abs().max().item() < TOL and (after - before).abs().max().item() > 1e-3
 
 
 def test_batched_submit_on_gpu_matches_reference(llm):
@@ -870,6 +949,37 @@ def test_selected_masses_read_only_the_selected_subtrees(engine, oracle, cap):
             full = trie.masses_from_logits(xb, lb)
             trie.prune_selection = True
             assert torch.equal(trie.masses_from_logits(xb, lb, nodes=sel_d), full[:, sel_d.long()]), name
+
+
+def test_selection_plans_are_made_when_asked_for_not_behind_a_call(engine):
+    """a selection met for the first time used to cost a device-to-host copy of its ids, a Python plan of its
+    sub-forest and twenty uploads inside `masses_from_logits`.  The default now serves an unprepared selection from the whole
+    trie's plan (one launch, no synchronisation) and takes the pruned plan once `prepare_selection(nodes)` was called; ids
+    outside the trie ("none" to the kernel: negative, or past the last node) select nothing on the host either."""
+    from genlm_backend_amd.tokenization import Token
+    from genlm_backend_amd.trie import TokenByteTrie
+
+    rs = np.random.default_rng(5)
+    words = sorted({bytes(rs.integers(97, 104, int(rs.integers(1, 7))).astype(np.uint8)) for _ in range(3000)})
+    trie = TokenByteTrie([Token(i, w) for i, w in enumerate(words)], engine=engine)
+    trie.PLAN_CAP = 250
+    assert trie.prune_selection == "cached"
+    dev = engine.device
+    V, nn = len(words), len(trie)
+    xd = torch.from_numpy((rs.standard_normal((9, V)) * 3).astype(np.float32)).to(dev)
+    _, lse, _ = engine.step(xd, vocab=V, rng_mode=0)
+    rows = trie.masses_from_logits(xd, lse)
+    sel = rs.choice(nn, 200, replace=False).astype(np.int32)
+    sel[::17] = -1  # "none"
+    sel_d = torch.from_numpy(sel).to(dev)
+    want = torch.where(sel_d[None, :] >= 0, rows[:, sel_d.clamp_min(0).long()], torch.zeros((), device=dev))
+    assert trie.selection_plan(sel_d) is None  # nothing was planned ...
+    assert torch.equal(trie.masses_from_logits(xd, lse, nodes=sel_d), want)
+    assert trie.selection_plan(sel_d) is None and not trie._sel_plans  # ... by the call either
+    assert trie.prepare_selection(sel_d) and trie.selection_plan(sel_d) is not None
+    assert trie.selection_plan(sel_d)["n_slots"] < trie.plan()["n_slots"] // 2
+    assert torch.equal(trie.masses_from_logits(xd, lse, nodes=sel_d), want)
+    assert not trie.prepare_selection(torch.tensor([trie.root, 3], dtype=torch.int32, device=dev))  # the root: the whole plan
 
 
 @pytest.mark.parametrize("cap", [250, 20000])
@@ -1893,3 +2003,31 @@ def test_recorded_gemm_solutions_give_the_librarys_results_within_rounding(engin
     finally:
         gemm_tuning.off()
     assert torch.equal(a @ w.t(), ref)
+
+
+def test_gemms_option_of_the_backend_is_what_the_bench_switches(engine):
+    """AsyncAmdLM(gemms="recorded") (= load_model_by_name(name, llm_opts={"gemms": "recorded"}), the option `bench.py --gemms
+    recorded` goes through): TunableOp on with the recorded file while the backend lives, `close()` hands PyTorch's state back;
+    log-probs equal the library-default backend's within GEMM rounding; the default (gemms="library") touches nothing."""
+    import torch.cuda.tunable as tunable
+    from transformers import GPT2Config
+
+    from genlm_backend_amd.llm import AsyncAmdLM
+
+    cfg = GPT2Config(n_layer=2, n_embd=64, n_head=4, vocab_size=1000, n_positions=64)
+    assert not tunable.is_enabled()
+    plain = AsyncAmdLM.from_config(cfg, None, device=engine.device, seed=5, engine=engine)
+    assert plain.gemms == "library" and not tunable.is_enabled()
+    ctxs = [[1, 2, 3, 4], [5, 6], [7, 8, 9]]
+    want = plain.batch_next_token_logprobs_sync(ctxs)
+    tuned = AsyncAmdLM.from_config(cfg, None, device=engine.device, seed=5, engine=engine, gemms="recorded")
+    try:
+        assert tuned.gemm_shapes == 0 or (tuned.gemm_shapes > 100 and tunable.is_enabled())
+        got = tuned.batch_next_token_logprobs_sync(ctxs)
+        assert (got - want).abs().max().item() < 1e-4
+    finally:
+        tuned.close()
+    assert not tunable.is_enabled() and tuned.gemm_shapes == 0
+    tuned.close()  # (twice: nothing happens)
+    with pytest.raises(ValueError):
+        AsyncAmdLM.from_config(cfg, None, device=engine.device, seed=5, engine=engine, gemms="fastest")
