@@ -223,12 +223,7 @@ __device__ __forceinline__ void load_chunk_raw(const char *rowp, int e_base, int
     // A/B (tools/ab.sh, tools/ab_sis.sh): fp32 step 45.4 -> 42.7 us on rotating buffers and 44.5 -> 36.8 us inside the
     // SIS loop, right behind the lm_head GEMM that wrote the logits; 16-bit rows (bound by VALU issue) unchanged.
     for (int i = 0; i < NVC; ++i)
-#if defined(GLB_PLAIN_LOADS_16)  // (experiment: default cache policy for 16-bit rows - the draw's reload may then hit the Infinity Cache)
-      raw[i] = DT != kDtF32 ? *reinterpret_cast<const u32x4_t *>(q + (int64_t)i * 64 * 16)
-                            : __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(q + (int64_t)i * 64 * 16));
-#else
       raw[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(q + (int64_t)i * 64 * 16));
-#endif
   } else {
 #pragma unroll
     for (int i = 0; i < NVC; ++i) raw[i] = load_vec_guarded<DT>(rowp, e_base + (i * 64 + lane) * EPV, V);
@@ -1170,6 +1165,10 @@ struct StatsWaves {
   static constexpr int value = MASK == kMaskF32 ? 3 : (DT == kDtF32 ? 4 : GLB_STATS_WAVES_16);
 };
 
+// (Round 6, under the hardware-exponential contract, where the stream is bound by memory: workgroups of two and four waves
+// again - 27.2 / 27.3 us against 26.6 at 512 x 128256 bf16 -, two chunks per wave - 30 to 34 us: the doubled body spills -,
+// the chunk kept as loaded in 32 registers at six and eight waves a SIMD - no gain, spills at eight -, default-policy loads
+// - 28.7 us; EXPERIMENTS.md.)
 template <int DT, int MASK, bool SCALED, int MODE, int EXPC = kExpPoly>
 __global__ __launch_bounds__(64, (StatsWaves<DT, MASK>::value)) void fused_step_kernel(const StepParams p) {
   const int lane = threadIdx.x;
