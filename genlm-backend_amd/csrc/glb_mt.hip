@@ -218,16 +218,30 @@ static void jump_host(const uint32_t *win, const uint64_t *poly, uint32_t *out) 
 // polynomial are workgroups that never meet, each with its part of the sequence in LDS (PARTS = 4: 32 KB, five workgroups a CU,
 // so that one wave's LDS waits and taken branches are another's issue slots; the whole sequence in one workgroup - 82 KB,
 // one wave a SIMD - took 577 us a launch, VALU idle two thirds of the time).  The source window is the XOR of its own planes.
+// need (nullable): one word per destination window, nonzero = somebody reads it.  A sharded population enters ONE global
+// stream (every rank deals the whole population's rows, DeviceSIS._parity_noise) but reads only its own particles' rows:
+// a block none of whose four windows is needed leaves before it has done anything.
 template <int PARTS>
 __global__ __launch_bounds__(256) void mt_jump_kernel(const uint32_t *__restrict__ src, int src_planes, int64_t src_plane_stride,
                                                       const uint64_t *__restrict__ polys, int n_poly, uint32_t *__restrict__ dst,
-                                                      int n_dst, int64_t dst_plane_stride) {
+                                                      int n_dst, int64_t dst_plane_stride, const int32_t *__restrict__ need,
+                                                      int need_group) {
   constexpr int kPartWords = JumpShape<PARTS>::kPartWords, kPartSeq = JumpShape<PARTS>::kPartSeq, kJumpRing = JumpShape<PARTS>::kRingWords;
   __shared__ uint32_t ring[kJumpRing];
   const int quads = (n_poly + 3) >> 2;
   const int part = (int)blockIdx.x % PARTS, sq = (int)blockIdx.x / PARTS;
   const int s = sq / quads, q = sq % quads;
   const int t = (int)threadIdx.x;
+  if (need) {  // (block-uniform: decided before the first barrier)
+    // destination window d stands for the need_group consecutive rows [d * need_group, (d + 1) * need_group)
+    int any = 0;
+    for (int w = 0; w < 4; ++w) {
+      const int d = s * n_poly + q * 4 + w;
+      if (q * 4 + w >= n_poly || d >= n_dst) continue;
+      for (int g = 0; g < need_group; ++g) any |= need[(size_t)d * need_group + g];
+    }
+    if (!any) return;
+  }
   // word n of the sequence lives at ring[(n - lo) & (kJumpRing - 1)]: the part's range [lo, lo + kPartSeq) is contiguous
   const int lo = part * kPartWords * 32;
   for (int i = t; i < kN; i += 256) {  // (the planes' loads go out together: one after the other, sixteen planes are sixteen trips)
@@ -279,6 +293,21 @@ __global__ __launch_bounds__(256) void mt_jump_kernel(const uint32_t *__restrict
 #pragma unroll
   for (int k = 0; k < kPerLane; ++k)
     if (j0 + k < kN) o[j0 + k] = acc[k];
+}
+
+// need[k] = 1 for every stream row an output row takes, and for the row the stream stands at afterwards (window_out)
+__global__ __launch_bounds__(256) void mt_need_kernel(const int32_t *__restrict__ row_slot, int n_out, const int32_t *__restrict__ n_draw_dev,
+                                                      int n_draw_host, int want_window_out, int32_t *__restrict__ need, int n_need) {
+  const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (i < n_out) {
+    const int sl = row_slot[i];
+    if (sl >= 0 && sl < n_need) need[sl] = 1;
+  }
+  if (i == 0 && want_window_out) {
+    int nd = n_draw_dev ? *n_draw_dev : n_draw_host;
+    nd = nd < 0 ? 0 : (nd > n_draw_host ? n_draw_host : nd);
+    if (nd < n_need) need[nd] = 1;
+  }
 }
 
 // Block r < n_out: output row r = the V exponentials of stream row row_slot[r] (window windows[slot]); ones for slot < 0.
@@ -375,10 +404,10 @@ __global__ __launch_bounds__(256) void mt_rows_copy_kernel(const float *__restri
 
 template <int PARTS>
 int launch_jump(const uint32_t *src, int src_planes, int64_t src_plane_stride, int n_src, const uint64_t *polys, int n_poly,
-                uint32_t *dst, int n_dst, int64_t dst_plane_stride, hipStream_t st) {
+                uint32_t *dst, int n_dst, int64_t dst_plane_stride, hipStream_t st, const int32_t *need = nullptr, int need_group = 1) {
   const int quads = (n_poly + 3) / 4;
   hipLaunchKernelGGL(mt_jump_kernel<PARTS>, dim3((unsigned)(n_src * quads * PARTS)), dim3(256), 0, st, src, src_planes, src_plane_stride, polys,
-                     n_poly, dst, n_dst, dst_plane_stride);
+                     n_poly, dst, n_dst, dst_plane_stride, need, need_group);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? GLB_OK : api_hip_fail(e, "mt_jump_kernel");
 }
@@ -449,7 +478,8 @@ int glb_mt19937_jump_host(const uint32_t *window_in, const uint64_t *poly, uint3
 size_t glb_mt19937_rows_workspace(int64_t max_draw_rows, int32_t n_small) {
   if (max_draw_rows < 0 || n_small < 2) return 0;
   const int64_t n_big = (max_draw_rows + 1 + n_small - 1) / n_small;  // windows are kept as planes: kPartsFew / kParts (csrc/glb_mt.hip)
-  return (size_t)(n_big * kPartsFew + n_big * n_small * kParts) * kN * sizeof(uint32_t);
+  // ... and one word per row window behind them: which windows this call's output rows read (mt_need_kernel)
+  return (size_t)(n_big * kPartsFew + n_big * n_small * kParts) * kN * sizeof(uint32_t) + (size_t)(n_big * n_small) * sizeof(int32_t);
 }
 
 int glb_mt19937_exponential_rows(const glb_mt_rows_args *a, void *hip_stream) {
@@ -474,15 +504,29 @@ int glb_mt19937_exponential_rows(const glb_mt_rows_args *a, void *hip_stream) {
   int lvl1_planes = 1;
   int64_t lvl1_stride = 0;
   if (!a->reuse_windows) {  // (reuse_windows: the workspace holds them since the call that generated rows_from)
-    if (m_need > 1) {  // the base window -> the window of every n_small-th row
-      int rc = launch_jump<kPartsFew>(a->window, 1, 0, 1, a->polys + (size_t)a->n_small * kPW, m_need, big, m_need, big_plane, st);
+    // Output rows that take only SOME of the stream's rows (a rank's particles in a sharded population's one global
+    // stream: n_out_rows of max_draw_rows): the windows nobody reads are not made - a word per row says which are.
+    const int32_t *need = nullptr;
+    if (a->row_slot && !a->rows_from && a->n_out_rows * 2 <= a->max_draw_rows) {
+      int32_t *flags = (int32_t *)(all + all_plane * kParts);
+      const size_t n_flags = (size_t)m_need * a->n_small;
+      hipError_t e = hipMemsetAsync(flags, 0, n_flags * sizeof(int32_t), st);
+      if (e != hipSuccess) return api_hip_fail(e, "need flags");
+      hipLaunchKernelGGL(mt_need_kernel, dim3((unsigned)((a->n_out_rows + 255) / 256 + (a->n_out_rows ? 0 : 1))), dim3(256), 0, st, a->row_slot,
+                         (int)a->n_out_rows, a->n_draw, (int)a->max_draw_rows, a->window_out ? 1 : 0, flags, (int)n_flags);
+      e = hipGetLastError();
+      if (e != hipSuccess) return api_hip_fail(e, "mt_need_kernel");
+      need = flags;
+    }
+    if (m_need > 1) {  // the base window -> the window of every n_small-th row (of the groups of n_small rows that are read)
+      int rc = launch_jump<kPartsFew>(a->window, 1, 0, 1, a->polys + (size_t)a->n_small * kPW, m_need, big, m_need, big_plane, st, need, a->n_small);
       if (rc) return rc;
       lvl1 = big;
       lvl1_planes = kPartsFew;
       lvl1_stride = big_plane;
     }
     // -> every row's window (and the one after the last)
-    int rc = launch_jump<kParts>(lvl1, lvl1_planes, lvl1_stride, m_need, a->polys, a->n_small, all, n_win, all_plane, st);
+    int rc = launch_jump<kParts>(lvl1, lvl1_planes, lvl1_stride, m_need, a->polys, a->n_small, all, n_win, all_plane, st, need, 1);
     if (rc) return rc;
   }
   if (a->rows_from) {  // the rows exist: copy them into place; the stream's new position by the rows kernel's last block alone

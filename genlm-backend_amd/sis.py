@@ -278,6 +278,7 @@ class DeviceSIS:
         # active particles over all ranks as of the last exchange (device scalar; read with the step's one D2H copy)
         self._global_active = torch.tensor(self.N * self.world, dtype=torch.int32, device=self.dev)
         self.all_weights = None
+        self._all_stamp = None  # parity draws over several ranks: which (step, resampling) the gathered hashes belong to
         self._rehash()
 
     def _rehash(self):
@@ -497,11 +498,23 @@ class DeviceSIS:
         anywhere, is still generating - the loop's termination test is collective."""
         count = self.active.sum().to(torch.float32).view(1)
         if self.collective:
-            mine = torch.cat([self.log_weights, count])
-            out = torch.empty((self.world, self.N + 1), dtype=torch.float32, device=self.dev)
+            N = self.N
+            parts = [self.log_weights, count]
+            carry = self.rng_mode == RNG_NOISE and self.world > 1
+            if carry:
+                # parity draws of a sharded population: every rank deals the WHOLE population's rows of the one stream
+                # (_parity_noise), which takes every particle's context hash (64 bits, carried as two float32 words: the
+                # collective copies bytes) and whether it still draws - 12 bytes a particle beside the 4 of its weight
+                parts += [self.hashes.view(torch.float32), self.active.to(torch.float32)]
+            mine = torch.cat(parts)
+            out = torch.empty((self.world, mine.numel()), dtype=torch.float32, device=self.dev)
             _gather_all(self.dist, out.view(-1), mine)
-            self.all_weights = out[:, :self.N].reshape(-1)
-            self._global_active = out[:, self.N].sum().to(torch.int32)
+            self.all_weights = out[:, :N].reshape(-1)
+            self._global_active = out[:, N].sum().to(torch.int32)
+            if carry:
+                self._all_hashes = out[:, N + 1:3 * N + 1].contiguous().view(torch.int64).reshape(-1)
+                self._all_active = out[:, 3 * N + 1:].reshape(-1) > 0
+                self._all_stamp = (self.t, self.n_resamples)
         else:
             self.all_weights = self.log_weights
             self._global_active = count[0].to(torch.int32)
@@ -565,11 +578,10 @@ class DeviceSIS:
         generator, entered on the device at every particle's row at once (glb_mt19937_exponential_rows): the order is a
         stable sort of the group ids, the number of rows consumed a device scalar - nothing crosses the host."""
         N = self.N
-        if self.noise_src is None:
-            # (the reference is ONE process, so its stream is defined for one shard; with several ranks every rank takes a
-            # stream of its own - the same rows on every rank would tie the shards' particles together.  Philox draws are
-            # the shard-invariant mode.)
-            self.noise_src = self.eng.noise_rng(self.seed + 7919 * self.rank, V, ahead=self.noise_ahead)
+        if self.noise_src is None:  # ONE stream for the whole population, whatever the number of ranks: the reference's
+            self.noise_src = self.eng.noise_rng(self.seed, V, ahead=self.noise_ahead and self.world == 1)
+        if self.collective and self.world > 1:
+            return self._parity_noise_sharded(V)
         act = self.active > 0
         key = torch.where(act, group_of.to(torch.int64), torch.full((N,), 1 << 40, dtype=torch.int64, device=self.dev))
         order = torch.argsort(key, stable=True)
@@ -579,6 +591,40 @@ class DeviceSIS:
         if self._noise_buf is None or self._noise_buf.shape != (N, V):
             self._noise_buf = torch.empty((N, V), dtype=torch.float32, device=self.dev)
         return self.noise_src.rows(N, row_slot=slot, n_draw=act.sum().to(torch.int32), max_draw=N, out=self._noise_buf)
+
+    def _parity_noise_sharded(self, V):
+        """The reference is ONE process: particle g of the whole population (rank * N + i) draws from the stream row it would
+        draw from there - its place among the ACTIVE particles ordered by dedup group in first-appearance order over the
+        global particle index, duplicates contiguous (hf.py:214-220,285-288).  Every rank computes that order for everybody
+        (replicated, like resampling) from the all-gathered context hashes and active flags - equal hash = equal context,
+        up to a 64-bit collision, which would only swap two rows of noise -, generates the rows of ITS particles at their
+        global slots (the jump-ahead makes the offset free; windows nobody here reads are not made) and moves the stream on by
+        the population's active count: the same tokens and weights as one process with all the particles."""
+        N, dev = self.N, self.dev
+        if getattr(self, "_all_stamp", None) != (self.t, self.n_resamples):  # (a run's first step: no exchange has carried them yet)
+            mine = torch.cat([self.hashes.view(torch.float32), self.active.to(torch.float32)])
+            out = torch.empty((self.world, 3 * N), dtype=torch.float32, device=dev)
+            _gather_all(self.dist, out.view(-1), mine)
+            self._all_hashes = out[:, :2 * N].contiguous().view(torch.int64).reshape(-1)
+            self._all_active = out[:, 2 * N:].reshape(-1) > 0
+            self._all_stamp = (self.t, self.n_resamples)
+        h, act = self._all_hashes, self._all_active
+        NT = h.numel()
+        ar = torch.arange(NT, device=dev)
+        sh, perm = torch.sort(h, stable=True)  # equal contexts side by side, each run in particle order
+        start = torch.ones(NT, dtype=torch.bool, device=dev)
+        start[1:] = sh[1:] != sh[:-1]
+        first = perm[torch.cummax(torch.where(start, ar, torch.zeros_like(ar)), 0).values]  # a run's first = smallest particle index
+        key = torch.empty(NT, dtype=torch.int64, device=dev)
+        key[perm] = first
+        key = torch.where(act, key, torch.full_like(key, 1 << 40))
+        order = torch.argsort(key, stable=True)
+        place = torch.empty(NT, dtype=torch.int32, device=dev)
+        place[order] = torch.arange(NT, dtype=torch.int32, device=dev)
+        slot = torch.where(act, place, torch.full_like(place, -1))[self.rank * N:(self.rank + 1) * N].contiguous()
+        if self._noise_buf is None or self._noise_buf.shape != (N, V):
+            self._noise_buf = torch.empty((N, V), dtype=torch.float32, device=dev)
+        return self.noise_src.rows(N, row_slot=slot, n_draw=act.sum().to(torch.int32), max_draw=NT, out=self._noise_buf)
 
     # -------------------------------------------------------------------------------------------
     def gather_weights(self):

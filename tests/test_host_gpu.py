@@ -1401,7 +1401,12 @@ def _two_rank_worker(rank, world, port, out_dir, mode):
     kw = dict(use_particle_kv=True) if mode == "pkv" else (dict(use_prefix_kv=True) if mode == "prefix" else {})
     if mode == "private":  # per-particle KV slabs: the rows of a particle that changes ranks travel with it
         kw = dict(use_particle_kv=True, share_kv=False)
-    sis = DeviceSIS(m, 8, prompts, max_tokens=6, eos_id=-1, seed=21, rank=rank, world=world, dist=dist, resample_ess=1.0, **kw)
+    if mode in ("torch", "torch-pkv"):  # the reference's draws: ONE MT19937 stream entered by both ranks
+        kw = dict(rng="torch", use_particle_kv=mode == "torch-pkv")
+    if mode == "golden":  # the reference's own run (tests/golden/ref_hotpath_tiny.npz), its 16 particles cut in two
+        sis = DeviceSIS(m, 8, p, max_tokens=10, eos_id=0, seed=1234, rng="torch", rank=rank, world=world, dist=dist)
+    else:
+        sis = DeviceSIS(m, 8, prompts, max_tokens=6, eos_id=-1, seed=21, rank=rank, world=world, dist=dist, resample_ess=1.0, **kw)
     if mode == "private":
         sis.log_weights = sis.log_weights - 4.0 * rank  # (the first resampling step fills rank 1's slots from rank 0)
     sis.run()
@@ -1412,14 +1417,17 @@ def _two_rank_worker(rank, world, port, out_dir, mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["plain", "pkv", "prefix", "private"])
+@pytest.mark.parametrize("mode", ["plain", "pkv", "prefix", "private", "torch", "torch-pkv", "golden"])
 def test_two_ranks_on_one_gpu_equal_one_rank(llm, tmp_path, mode):
     """The multi-rank path through the HIP kernels: two processes share this GPU, each holds half of the population
     (rank-specific ragged prompts), draws by the global particle index, gathers the weights every step (over gloo here
     - RCCL needs a GPU per rank; `test_rccl_collectives_on_one_rank_change_nothing` covers the RCCL calls) and resamples
     across the ranks after every step: the union equals one process with the whole population - plain, with shared KV
     rows (contexts that migrate are encoded on their new rank), with cached prompt prefixes of all ranks, and with private
-    KV slabs whose rows travel with the particles that change ranks."""
+    KV slabs whose rows travel with the particles that change ranks.  "torch" / "torch-pkv": the same with the REFERENCE's
+    draws - both ranks enter ONE MT19937 stream at their particles' global rows (DeviceSIS._parity_noise_sharded: no
+    per-rank seed any more), so the union is again the one-process run; "golden": the reference's own run (README loop, 16
+    particles, torch.manual_seed: ref_hotpath_tiny.npz) reproduced by two ranks of 8 - tokens and weights."""
     import torch.multiprocessing as mp
 
     from genlm_backend_amd.sis import DeviceSIS
@@ -1427,13 +1435,20 @@ def test_two_ranks_on_one_gpu_equal_one_rank(llm, tmp_path, mode):
     world, port = 2, 29741 + os.getpid() % 200
     mp.start_processes(_two_rank_worker, args=(world, port, str(tmp_path), mode), nprocs=world, join=True, start_method="spawn")
     r = [np.load(tmp_path / f"rank{i}.npz") for i in range(world)]
-    assert np.array_equal(r[0]["all_lw"], r[1]["all_lw"]) and int(r[0]["n_resamples"]) >= 2
     m, gold = llm
+    if mode == "golden":
+        got = [[int(t) for t in row if t >= 0] for row in np.concatenate([r[0]["ctx"], r[1]["ctx"]])]
+        assert got == [_strip(row) for row in gold["sis_contexts"]]
+        assert np.abs(np.concatenate([r[0]["lw"], r[1]["lw"]]) - gold["sis_log_weights"]).max() < TOL
+        return
+    assert np.array_equal(r[0]["all_lw"], r[1]["all_lw"]) and int(r[0]["n_resamples"]) >= 2
     m.register_masks(torch.from_numpy(gold["sis_masks"]))
     p = [int(t) for t in gold["sis_prompt"]]
     kw = dict(use_particle_kv=True) if mode == "pkv" else (dict(use_prefix_kv=True) if mode == "prefix" else {})
     if mode == "private":
         kw = dict(use_particle_kv=True, share_kv=False)
+    if mode in ("torch", "torch-pkv"):
+        kw = dict(rng="torch", use_particle_kv=mode == "torch-pkv")
     one = DeviceSIS(m, 16, [p, p[:5], p[2:], p[1:]] * 4, max_tokens=6, eos_id=-1, seed=21, resample_ess=1.0, **kw)
     if mode == "private":
         one.log_weights[8:] -= 4.0
@@ -1724,7 +1739,7 @@ def _many_rank_prompts(n_total, vocab):
     return [pool[i] for i in rs.integers(0, len(pool), size=n_total)]
 
 
-def _many_rank_worker(rank, world, port, out_dir, per_rank):
+def _many_rank_worker(rank, world, port, out_dir, per_rank, rng="philox"):
     import torch.distributed as dist
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -1747,7 +1762,7 @@ def _many_rank_worker(rank, world, port, out_dir, per_rank):
     m.register_masks(torch.from_numpy(gold["sis_masks"]))
     prompts = _many_rank_prompts(world * per_rank, cfg["vocab_size"])[rank * per_rank:(rank + 1) * per_rank]
     sis = DeviceSIS(m, per_rank, prompts, max_tokens=4, eos_id=-1, seed=23, rank=rank, world=world, dist=dist, resample_ess=1.0,
-                    use_particle_kv=True)
+                    use_particle_kv=True, rng=rng)
     moved = []
     for _ in range(5):
         sis.step()
@@ -1759,16 +1774,19 @@ def _many_rank_worker(rank, world, port, out_dir, per_rank):
     dist.destroy_process_group()
 
 
-def test_four_ranks_of_512_on_one_gpu_equal_one_rank(llm, tmp_path):
+@pytest.mark.parametrize("rng", ["philox", "torch"])
+def test_four_ranks_of_512_on_one_gpu_equal_one_rank(llm, tmp_path, rng):
     """Config 4's per-rank population (512 particles) on four ranks sharing this GPU - HIP kernels, shared KV rows with the
     block table on the device, systematic resampling after every step, the rows that change ranks travelling in one
-    all-to-all (over gloo: RCCL wants a GPU per rank) - equals one process with all 2048 particles."""
+    all-to-all (over gloo: RCCL wants a GPU per rank) - equals one process with all 2048 particles; with Philox draws (keyed
+    by the global particle index) and with the reference's (one MT19937 stream, every rank generating its 512 rows of the
+    2048 at their global places)."""
     import torch.multiprocessing as mp
 
     from genlm_backend_amd.sis import DeviceSIS
 
     world, per_rank, port = 4, 512, 30341 + os.getpid() % 200
-    mp.start_processes(_many_rank_worker, args=(world, port, str(tmp_path), per_rank), nprocs=world, join=True, start_method="spawn")
+    mp.start_processes(_many_rank_worker, args=(world, port, str(tmp_path), per_rank, rng), nprocs=world, join=True, start_method="spawn")
     r = [np.load(tmp_path / f"rank{i}.npz") for i in range(world)]
     for x in r[1:]:
         assert np.array_equal(x["all_lw"], r[0]["all_lw"]) and np.array_equal(x["moved"], r[0]["moved"])
@@ -1777,7 +1795,7 @@ def test_four_ranks_of_512_on_one_gpu_equal_one_rank(llm, tmp_path):
     m.register_masks(torch.from_numpy(gold["sis_masks"]))
     cfg = ast.literal_eval(bytes(gold["config_json"]).decode())
     one = DeviceSIS(m, world * per_rank, _many_rank_prompts(world * per_rank, cfg["vocab_size"]), max_tokens=4, eos_id=-1, seed=23,
-                    resample_ess=1.0, use_particle_kv=True)
+                    resample_ess=1.0, use_particle_kv=True, rng=rng)
     for _ in range(5):
         one.step()
     ctx, lw = one.results()
