@@ -218,13 +218,13 @@ static void jump_host(const uint32_t *win, const uint64_t *poly, uint32_t *out) 
 // polynomial are workgroups that never meet, each with its part of the sequence in LDS (PARTS = 4: 32 KB, five workgroups a CU,
 // so that one wave's LDS waits and taken branches are another's issue slots; the whole sequence in one workgroup - 82 KB,
 // one wave a SIMD - took 577 us a launch, VALU idle two thirds of the time).  The source window is the XOR of its own planes.
-// need (nullable): one word per destination window, nonzero = somebody reads it.  A sharded population enters ONE global
+// need_rows (nullable): one word per destination window, nonzero = somebody reads it.  A sharded population enters ONE global
 // stream (every rank deals the whole population's rows, DeviceSIS._parity_noise) but reads only its own particles' rows:
 // a block none of whose four windows is needed leaves before it has done anything.
 template <int PARTS>
 __global__ __launch_bounds__(256) void mt_jump_kernel(const uint32_t *__restrict__ src, int src_planes, int64_t src_plane_stride,
                                                       const uint64_t *__restrict__ polys, int n_poly, uint32_t *__restrict__ dst,
-                                                      int n_dst, int64_t dst_plane_stride, const int32_t *__restrict__ need,
+                                                      int n_dst, int64_t dst_plane_stride, const int32_t *__restrict__ need_rows,
                                                       int need_group) {
   constexpr int kPartWords = JumpShape<PARTS>::kPartWords, kPartSeq = JumpShape<PARTS>::kPartSeq, kJumpRing = JumpShape<PARTS>::kRingWords;
   __shared__ uint32_t ring[kJumpRing];
@@ -232,13 +232,13 @@ __global__ __launch_bounds__(256) void mt_jump_kernel(const uint32_t *__restrict
   const int part = (int)blockIdx.x % PARTS, sq = (int)blockIdx.x / PARTS;
   const int s = sq / quads, q = sq % quads;
   const int t = (int)threadIdx.x;
-  if (need) {  // (block-uniform: decided before the first barrier)
+  if (need_rows) {  // (block-uniform: decided before the first barrier)
     // destination window d stands for the need_group consecutive rows [d * need_group, (d + 1) * need_group)
     int any = 0;
     for (int w = 0; w < 4; ++w) {
       const int d = s * n_poly + q * 4 + w;
       if (q * 4 + w >= n_poly || d >= n_dst) continue;
-      for (int g = 0; g < need_group; ++g) any |= need[(size_t)d * need_group + g];
+      for (int g = 0; g < need_group; ++g) any |= need_rows[(size_t)d * need_group + g];
     }
     if (!any) return;
   }
