@@ -61,6 +61,33 @@ def test_rows_equal_the_serial_stream(engine, V, rows):
         assert np.array_equal(got.cpu().numpy().view(np.uint32), want[call * rows:(call + 1) * rows].view(np.uint32)), call
 
 
+@pytest.mark.parametrize("V,total,mine", [(311, 200, 40), (50257, 130, 33), (4099, 64, 1)])
+def test_a_shard_reads_only_its_rows_of_the_global_stream(engine, V, total, mine):
+    """A sharded population's parity draws (DeviceSIS._parity_noise_sharded): `total` stream rows are dealt over all ranks,
+    this rank's `mine` output rows take scattered ones of them and the stream moves on by a count that lives on the device.
+    The jump launches make only the windows somebody here reads (mt_need_kernel's flags: the rows named, and the row the
+    stream stands at afterwards); the rows and the next call's start are the serial stream's."""
+    from genlm_backend_amd.engine import DeviceRng
+
+    rng = DeviceRng(engine, 4242, V)
+    rs = np.random.default_rng(V)
+    n_draw = [total - 7, total]
+    want = _host_stream(4242, (n_draw[0] + n_draw[1]) * V).reshape(-1, V)
+    base = 0
+    for call in range(2):
+        slot = rs.choice(n_draw[call], mine, replace=False).astype(np.int32)
+        if mine > 3:
+            slot[1] = -1  # a particle of this rank that draws nothing
+        got = rng.rows(mine, row_slot=torch.from_numpy(slot).to(engine.device),
+                       n_draw=torch.tensor(n_draw[call], dtype=torch.int32, device=engine.device), max_draw=total)
+        torch.cuda.synchronize()
+        got = got.cpu().numpy()
+        for i, sl in enumerate(slot):
+            exp = np.ones(V, np.float32) if sl < 0 else want[base + sl]
+            assert np.array_equal(got[i].view(np.uint32), exp.view(np.uint32)), (call, i)
+        base += n_draw[call]
+
+
 def test_slots_counts_on_the_device_and_rows_of_ones(engine):
     """Output rows take stream rows in any order (row_slot), particles that draw nothing get ones, and the stream moves on
     by a count that lives on the device - the resolution order of hf.py:285-288 with inactive particles skipped."""
