@@ -401,6 +401,10 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+        clock = getattr(getattr(r, "sis", None), "coll_clock", None)
+        if clock is not None and dist is not None:  # the run's collectives, timed (sis.CollectiveClock) from here on
+            clock.start()
+            r.sis.rows_moved_total = 0
         t0 = time.perf_counter()
         marks = []
         for i in range(args.steps):
@@ -408,6 +412,7 @@ def main():
             if args.step_times:
                 marks.append(time.perf_counter())
         torch.cuda.synchronize()
+        dt_own = time.perf_counter() - t0
         if args.step_times and marks:  # (diagnostic: where the host spent the timed region - enqueue times, not GPU times)
             d = np.diff(np.array([t0] + marks)) * 1e3
             worst = np.argsort(-d)[:5]
@@ -418,12 +423,36 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if dist is not None:
+            # every rank's own time of the timed region (its steps end when its last kernel ends; the closing barrier then
+            # waits for the slowest): the spread says whether one rank holds the others up
+            own = torch.tensor([dt_own], dtype=torch.float64, device=dev)
+            every = torch.empty(dist.get_world_size(), dtype=torch.float64, device=dev)
+            _gather_all(dist, every, own)
+            r.rank_ms = [float(x) / args.steps * 1e3 for x in every.cpu().tolist()]
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             _reduce_all(dist, t, dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
 
     dt = timed_run(runner)
+    # what a scaling curve needs to explain itself: the collectives' share of a step on rank 0 (RCCL: device
+    # time between two stream events around every call, waiting for the slowest rank included; the gloo rehearsal: host time
+    # of the synchronous calls), the particles that changed ranks, every rank's own step time
+    coll_info = None
+    clock = getattr(getattr(runner, "sis", None), "coll_clock", None)
+    if clock is not None and clock.on:
+        coll_info = {
+            "collective_us_per_step": clock.total_us() / args.steps,
+            "calls_per_step": clock.calls / args.steps,
+            "bytes_per_step": clock.bytes / args.steps,
+            "rows_moved_per_step": runner.sis.rows_moved_total / args.steps,
+            "timed_by": "stream events around each call (RCCL)" if clock._device_timed else "host clock around each call (gloo rehearsal)",
+            "what": "all-gather of log-weights + active count per step (+ context hashes in parity mode); with --resample one "
+                    "all_to_all_single of the particle rows that change ranks (+ one of their KV rows with private slabs)"}
+        if getattr(runner, "rank_ms", None):
+            coll_info["rank_ms_per_step"] = {"min": min(runner.rank_ms), "max": max(runner.rank_ms),
+                                             "mean": float(np.mean(runner.rank_ms)), "ranks": runner.rank_ms}
+        clock.on = False
     # The default line also carries the same loop with KV rows shared by equal contexts (`--particle-kv`: one new token
     # per distinct context per step instead of the reference's re-encoding; tokens proven equal to the reference's by
     # tests/test_host_gpu.py) as value_kv / ms_per_step_kv.  `value` itself stays BASELINE config 2's algorithm.
@@ -491,6 +520,8 @@ def main():
                 out["rccl_ranks"] = rccl_ranks
         if rccl_note is not None:
             out["rccl_note"] = rccl_note
+        if coll_info is not None:
+            out["collectives"] = coll_info
         if kv_extra is not None:
             out.update(kv_extra)
         if lib_extra is not None:

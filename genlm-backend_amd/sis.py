@@ -127,6 +127,46 @@ def _reduce_all(dist, t, op):
         dist.all_reduce(t, op=op)
 
 
+class CollectiveClock:
+    """What a run's collectives cost, for bench lines that have to explain a scaling curve: on an RCCL group the device
+    time between two events recorded on the stream around the call (it includes waiting for the slowest rank to arrive -
+    that IS the cost of a collective in a step), on a gloo group (the one-GPU rehearsal, CPU tests) the host time of the
+    call, which is synchronous there.  Off unless `start()` was called: nothing is recorded, nothing is timed."""
+
+    def __init__(self):
+        self.on = False
+        self.events, self.host_s, self.calls, self.bytes = [], 0.0, 0, 0
+
+    def start(self):
+        self.on = True
+        self.events, self.host_s, self.calls, self.bytes = [], 0.0, 0, 0
+
+    def run(self, fn, tensor, nbytes):
+        if not self.on:
+            return fn()
+        self.calls += 1
+        self.bytes += int(nbytes)
+        if tensor.is_cuda and self._device_timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn()
+            e1.record()
+            self.events.append((e0, e1))
+            return out
+        import time
+
+        t0 = time.perf_counter()
+        out = fn()
+        self.host_s += time.perf_counter() - t0
+        return out
+
+    _device_timed = True
+
+    def total_us(self):
+        """(the caller has synchronised the device)"""
+        return self.host_s * 1e6 + sum(a.elapsed_time(b) for a, b in self.events) * 1e3
+
+
 class DeviceSIS:
     """N particles over one prompt (or one prompt per particle, any lengths), masks[0] while fewer than `max_tokens`
     tokens were generated and masks[1] afterwards (README.md:57-70's masking function).
@@ -166,6 +206,10 @@ class DeviceSIS:
         self.N, self.max_tokens, self.eos_id = n_particles, max_tokens, eos_id
         self.rank, self.world, self.dist = rank, world, dist
         self.collective = world > 1 or (bool(force_collectives) and dist is not None)
+        self.coll_clock = CollectiveClock()  # (bench.py starts it: collective_us_per_step of the multi-rank lines)
+        if dist is not None:
+            self.coll_clock._device_timed = dist.get_backend() != "gloo"
+        self.rows_moved_total = 0
         self.migrate_kv = bool(migrate_kv)  # private KV slabs: a particle resampled from another rank brings its KV rows along
         self.kv_rows_moved = 0
         self.seed = seed
@@ -508,7 +552,7 @@ class DeviceSIS:
                 parts += [self.hashes.view(torch.float32), self.active.to(torch.float32)]
             mine = torch.cat(parts)
             out = torch.empty((self.world, mine.numel()), dtype=torch.float32, device=self.dev)
-            _gather_all(self.dist, out.view(-1), mine)
+            self.coll_clock.run(lambda: _gather_all(self.dist, out.view(-1), mine), mine, out.numel() * 4)
             self.all_weights = out[:, :N].reshape(-1)
             self._global_active = out[:, N].sum().to(torch.int32)
             if carry:
@@ -604,7 +648,7 @@ class DeviceSIS:
         if getattr(self, "_all_stamp", None) != (self.t, self.n_resamples):  # (a run's first step: no exchange has carried them yet)
             mine = torch.cat([self.hashes.view(torch.float32), self.active.to(torch.float32)])
             out = torch.empty((self.world, 3 * N), dtype=torch.float32, device=dev)
-            _gather_all(self.dist, out.view(-1), mine)
+            self.coll_clock.run(lambda: _gather_all(self.dist, out.view(-1), mine), mine, out.numel() * 4)
             self._all_hashes = out[:, :2 * N].contiguous().view(torch.int64).reshape(-1)
             self._all_active = out[:, 2 * N:].reshape(-1) > 0
             self._all_stamp = (self.t, self.n_resamples)
@@ -672,6 +716,7 @@ class DeviceSIS:
             mine_owner = owner[r * N:(r + 1) * N]
             recv_cnt = [int((mine_owner == src).sum()) if src != r else 0 for src in range(self.world)]
             self.rows_moved = int((owner != np.repeat(np.arange(self.world), N)).sum())  # over all ranks (replicated value)
+            self.rows_moved_total += self.rows_moved
             moved = None
             if self.rows_moved:
                 take = np.concatenate(send_idx).astype(np.int64)
@@ -679,7 +724,9 @@ class DeviceSIS:
                 send = state[take_d] if len(take) else state[:0]
                 recv = torch.empty((sum(recv_cnt), state.shape[1]), dtype=torch.int32, device=dev)
                 send_cnt = [len(x) for x in send_idx]
-                _all_to_all(self.dist, recv, send.contiguous(), recv_cnt, send_cnt)
+                send = send.contiguous()
+                self.coll_clock.run(lambda: _all_to_all(self.dist, recv, send, recv_cnt, send_cnt), send,
+                                    (send.numel() + recv.numel()) * 4)
                 slots_d = None
                 if sum(recv_cnt):
                     # rows arrive ordered by source rank, then by this rank's slot order - the order the senders used
@@ -728,7 +775,8 @@ class DeviceSIS:
                 raise ValueError("KV layers of different shapes: rows cannot travel in one message")
         send = torch.stack([t[take_d] for t in old], dim=1).contiguous() if n_send else new[0].new_zeros((0, len(new)) + shape)
         recv = new[0].new_empty((n_recv, len(new)) + shape)
-        _all_to_all_any(self.dist, recv, send, recv_cnt, send_cnt)
+        self.coll_clock.run(lambda: _all_to_all_any(self.dist, recv, send, recv_cnt, send_cnt), send,
+                            (send.numel() + recv.numel()) * send.element_size())
         if n_recv:
             for j, t in enumerate(new):
                 t[slots_d] = recv[:, j]

@@ -1479,6 +1479,10 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["gloo_ranks"] == 2 and out["rehearsal_one_gpu"] is True and "rccl_ranks" not in out
     assert out["steps"] == 12 and out["value"] > 0 and out["roofline"]["launches_timed"] == 12
+    # a multi-rank line explains itself: the collectives' time, what moved, every rank's own step time
+    c = out["collectives"]
+    assert c["collective_us_per_step"] > 0 and c["calls_per_step"] >= 2 and c["rows_moved_per_step"] > 0 and "gloo" in c["timed_by"]
+    assert len(c["rank_ms_per_step"]["ranks"]) == 2 and c["rank_ms_per_step"]["min"] <= out["ms_per_step"] * 1.001
 
 
 # ---- a failed one-launch call must reach every caller (vllm.py:396-400: nobody is left with a wrong answer)
@@ -1822,6 +1826,8 @@ def test_bench_four_ranks_rehearsal_of_config4_on_one_gpu():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 4 and out["gloo_ranks"] == 4 and out["rehearsal_one_gpu"] is True
     assert out["config"]["particles_per_gpu"] == 512 and out["config"]["vocab"] == 128256 and out["value"] > 0
+    c = out["collectives"]
+    assert c["collective_us_per_step"] > 0 and c["rows_moved_per_step"] > 0 and len(c["rank_ms_per_step"]["ranks"]) == 4
 
 
 @pytest.mark.parametrize("family", ["gpt2", "llama"])
