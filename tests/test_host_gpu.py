@@ -1827,7 +1827,9 @@ def test_bench_four_ranks_rehearsal_of_config4_on_one_gpu():
     assert out["n_gpus"] == 4 and out["gloo_ranks"] == 4 and out["rehearsal_one_gpu"] is True
     assert out["config"]["particles_per_gpu"] == 512 and out["config"]["vocab"] == 128256 and out["value"] > 0
     c = out["collectives"]
-    assert c["collective_us_per_step"] > 0 and c["rows_moved_per_step"] > 0 and len(c["rank_ms_per_step"]["ranks"]) == 4
+    # (rows_moved_per_step may be 0 here: a random-init model's weights stay near uniform, and systematic resampling of
+    # near-uniform weights keeps every particle where it is)
+    assert c["collective_us_per_step"] > 0 and c["rows_moved_per_step"] >= 0 and len(c["rank_ms_per_step"]["ranks"]) == 4
 
 
 @pytest.mark.parametrize("family", ["gpt2", "llama"])
