@@ -40,10 +40,6 @@
 #define GLB_STATS_WAVES_16 5  // stats waves per SIMD for 2-byte elements (6: 80 registers, 42 spilled: 43 us against 34)
 #endif
 
-#ifndef GLB_STEP_CANDIDATES
-#define GLB_STEP_CANDIDATES 1  // 0: the finishing wave always walks the chosen chunk itself (the form before round 6)
-#endif
-
 #include "glb_diag.hpp"
 #include "glb_math.hpp"
 
@@ -61,10 +57,7 @@ struct ChunkRec {  // one (row|particle, chunk) as the finish role holds it
   uint32_t rA[4], rB[4];  // allowed elements on the scale Nm, by 16-lane row g of the wave that held the chunk (lanes
                           // 16 g .. 16 g + 15: a quarter of the chunk): (rA[g] << 18) + rB[g]; S_c^m = their sum
   uint32_t pAm, pBm;   // the sums of rA / rB (not stored)
-  int32_t cand;        // (granule 12, one-launch Philox step only) the token the unit's ONE particle draws if the first stage
-                       // picks this chunk (chunk_candidate); kNoCand: not made - the finishing wave walks the chunk itself
 };
-constexpr int32_t kNoCand = -3;
 // In memory a record is 128 bytes: twelve 8-byte granules {low word = value, high word = the call's epoch} in the
 // order Nc, Nm, pA, pB, rA[0..3], rB[0..3] (+ 32 bytes of padding), each written by ONE agent-scope store and valid
 // exactly when its tag equals the epoch of the call - so a reader needs no flag, no fence and no ordering between the
@@ -258,10 +251,9 @@ __device__ __forceinline__ void load_chunk(const char *rowp, int e_base, int V, 
   for (int i = 0; i < NVC; ++i) unpack_scaled<DT, SCALED>(raw[i], scale, &x[i * EPV]);
 }
 
-// one record out: lanes 0..11 store one granule each (the values are wave-uniform); CAND: lane 12 the candidate token
-template <bool CAND = false>
+// one record out: lanes 0..11 store one granule each (the values are wave-uniform)
 __device__ __forceinline__ void store_rec(uint64_t *dst, uint32_t epoch, int lane, float Nc, float Nm, uint32_t pA,
-                                          uint32_t pB, const uint32_t (&rA)[4], const uint32_t (&rB)[4], int32_t cand = kNoCand) {
+                                          uint32_t pB, const uint32_t (&rA)[4], const uint32_t (&rB)[4]) {
   uint32_t v = __float_as_uint(Nc);
   v = lane == 1 ? __float_as_uint(Nm) : v;
   v = lane == 2 ? pA : v;
@@ -271,28 +263,24 @@ __device__ __forceinline__ void store_rec(uint64_t *dst, uint32_t epoch, int lan
     v = lane == 4 + g ? rA[g] : v;
     v = lane == 8 + g ? rB[g] : v;
   }
-  if constexpr (CAND) v = lane == 12 ? (uint32_t)cand : v;
-  if (lane < (CAND ? 13 : 12))
+  if (lane < 12)
     __hip_atomic_store(dst + lane, ((uint64_t)epoch << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // one record in; true when every granule carries `epoch`.  COHERENT: agent-scope loads (past the L1: the stats waves of
 // this very launch may still be writing); otherwise plain loads - records of an earlier launch, and when a thousand
 // particles share one row (SIS step 0) the CU's L1 serves all but the first sweep.
-template <bool COHERENT, bool CAND = false>
+template <bool COHERENT>
 __device__ __forceinline__ bool load_rec(const uint64_t *src, uint32_t epoch, ChunkRec &r) {
-  constexpr int NG = CAND ? 13 : 12;
-  uint64_t g[NG];
+  uint64_t g[12];
 #pragma unroll
-  for (int k = 0; k < NG; ++k) {
+  for (int k = 0; k < 12; ++k) {
     if constexpr (COHERENT) g[k] = __hip_atomic_load(const_cast<uint64_t *>(src) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else g[k] = src[k];
   }
   bool ok = true;
 #pragma unroll
-  for (int k = 0; k < NG; ++k) ok = ok && (uint32_t)(g[k] >> 32) == epoch;
-  r.cand = kNoCand;
-  if constexpr (CAND) r.cand = (int32_t)(uint32_t)g[12];
+  for (int k = 0; k < 12; ++k) ok = ok && (uint32_t)(g[k] >> 32) == epoch;
   r.Nc = __uint_as_float((uint32_t)g[0]);
   r.Nm = __uint_as_float((uint32_t)g[1]);
   r.pA = (uint32_t)g[2];
@@ -418,120 +406,18 @@ __device__ __forceinline__ float chunk_max(const float (&x)[64]) {
   return wave_max(m);
 }
 
-// the particle's two 64-bit draws (chunk stage, in-chunk stage): Philox4x32-10 keyed by the call's seed, counter =
-// (global particle index, call offset)
-__device__ __forceinline__ void philox_pair(const StepParams &p, int pidx, uint64_t &R1, uint64_t &R2) {
-  const uint64_t gp = (uint64_t)(p.particle_base + pidx);
-  const uint32_t ctr[4] = {(uint32_t)gp, (uint32_t)(gp >> 32), (uint32_t)p.offset, (uint32_t)(p.offset >> 32)};
-  const uint32_t key[2] = {(uint32_t)p.seed, (uint32_t)(p.seed >> 32)};
-  uint32_t rnd[4];
-  philox4x32_10(ctr, key, rnd);
-  R1 = ((uint64_t)rnd[1] << 32) | rnd[0];
-  R2 = ((uint64_t)rnd[3] << 32) | rnd[2];
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// The second stage of a Philox draw made by the STATS wave itself (round 6), for units with exactly one particle (no
-// dedup fan-out: particle = unit).  That stage - row, lane, class, element inside ONE chunk - depends on nothing but the
-// chunk's own allowed sums and the particle's second Philox word, so every chunk's wave can make it for the case that the
-// first stage will pick its chunk, from the values it still holds in registers, and leave the token in the record's
-// thirteenth granule: the finishing wave then folds, picks the chunk and reads the token - no reload of a quarter chunk
-// from memory (the row was streamed past every cache), no sixteen exponentials, no walk: 1.7 of its 2.7 us, which sit on
-// the launch's tail.  The same picks as finish_draw by construction: the same integers (the record's row sums, floor(P *
-// 2^36) of the same float32 partials, the running sum of the same terms in the same order); the whole -m gpu suite compares
-// the tokens with the oracle's.  Costs every stats wave a Philox block (scalar unit), two short DPP scans and sixteen
-// terms: + a fifth of its vector instructions - float32 rows are bound by memory and have them to spare.
-// Returns the token, -1 when the chunk allows nothing, kNoCand when the draw has to be walked by the finishing wave.
-// ---------------------------------------------------------------------------------------------------------
-template <int DT, int MASK, int EXPC, int W>
-__device__ __forceinline__ void candidate_walk(const float (&x)[64], float bias, cu64_t mt, int lane, double thr, int &pos) {
-  constexpr int EPV = ElemTraits<DT>::EPV, NVW = ElemTraits<DT>::NVC / 4;
-  float cs = 0.0f;
-  pos = -1;
-#pragma unroll
-  for (int j = 0; j < NVW; ++j) {
-    const int iv = W + 4 * j;
-#pragma unroll
-    for (int k = 0; k < EPV; ++k) {
-      const float t = chunk_term<EXPC>(x[iv * EPV + k], bias);
-      bool allowed = true;
-      if constexpr (MASK == kMaskBits) allowed = ((mt[iv * EPV + k] >> lane) & 1ull) != 0ull;
-      cs = allowed ? cs + t : cs;  // (a forbidden element is skipped = adds +0, as in the sums)
-      pos = (pos < 0 && (double)cs >= thr) ? j * EPV + k : pos;  // floor(cs * 2^36) > Tw  <=>  cs >= (Tw + 1) 2^-36, exact in double
-    }
-  }
-}
-
-template <int DT, int MASK, int EXPC>
-__device__ __forceinline__ int32_t chunk_candidate(const float (&x)[64], float bias, cu64_t mt, int lane, int e_base,
-                                                   const float (&Pm)[4], const uint32_t (&rA)[4], const uint32_t (&rB)[4],
-                                                   uint64_t R2) {
-  constexpr int EPV = ElemTraits<DT>::EPV;
-  // ---- the 16-lane row: the record's four sums (wave-uniform), as finish_draw picks it
-  const uint64_t q0 = ((uint64_t)rA[0] << kGridHi) + rB[0], q1 = ((uint64_t)rA[1] << kGridHi) + rB[1];
-  const uint64_t q2 = ((uint64_t)rA[2] << kGridHi) + rB[2], q3 = ((uint64_t)rA[3] << kGridHi) + rB[3];
-  const uint64_t i0 = q0, i1 = i0 + q1, i2 = i1 + q2, Sc = i2 + q3;
-  uint32_t nz = (uint32_t)Sc | (uint32_t)(Sc >> 32);
-  opaque_u32(nz);
-  if (nz == 0u) return -1;  // nothing allowed here: the first stage never picks this chunk
-  const uint64_t T2 = __umul64hi(R2, Sc);
-  const int gsel = T2 < i0 ? 0 : (T2 < i1 ? 1 : (T2 < i2 ? 2 : 3));
-  const uint64_t Tg = T2 - (gsel == 0 ? 0ull : (gsel == 1 ? i0 : (gsel == 2 ? i1 : i2)));
-  // ---- lane and class: the (lane, class) integers in summation order - lane by lane, class by class inside a lane
-  uint64_t c[4];
-#pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    uint32_t h, l;
-    partial_q(Pm[w], h, l);
-    c[w] = (w ? c[w - 1] : 0ull) + (((uint64_t)h << kGridHi) + l);
-  }
-  uint64_t incl = c[3];  // inclusive scan of the lane totals inside every 16-lane row (row_shr: zeros come in at a row's start)
-  incl += dpp_u64_or0<0x111, 0xf>(incl);
-  incl += dpp_u64_or0<0x112, 0xf>(incl);
-  incl += dpp_u64_or0<0x114, 0xf>(incl);
-  incl += dpp_u64_or0<0x118, 0xf>(incl);
-  const uint64_t excl = incl - c[3];
-  int fw = -1;
-  uint64_t before = 0;
-#pragma unroll
-  for (int w = 3; w >= 0; --w) {
-    const bool hit = excl + c[w] > Tg;
-    fw = hit ? w : fw;
-    before = hit ? excl + (w ? c[w - 1] : 0ull) : before;
-  }
-  const uint64_t votes = __ballot((lane >> 4) == gsel && fw >= 0);
-  uint32_t any = (uint32_t)votes | (uint32_t)(votes >> 32);
-  opaque_u32(any);
-  if (any == 0u) return kNoCand;  // (cannot happen: T2 < S_c)
-  const int lsel = __ffsll((long long)votes) - 1;  // the first lane of the row whose prefix passes the target
-  const int wsel = __builtin_amdgcn_readlane(fw, lsel);
-  const uint64_t Tw = Tg - readlane_u64(before, lsel);
-  // ---- the element: the class's sixteen terms again, their running sum in order
-  const double thr = (double)(Tw + 1ull) * 0x1p-36;
-  int pos;
-  if (wsel == 0) candidate_walk<DT, MASK, EXPC, 0>(x, bias, mt, lane, thr, pos);
-  else if (wsel == 1) candidate_walk<DT, MASK, EXPC, 1>(x, bias, mt, lane, thr, pos);
-  else if (wsel == 2) candidate_walk<DT, MASK, EXPC, 2>(x, bias, mt, lane, thr, pos);
-  else candidate_walk<DT, MASK, EXPC, 3>(x, bias, mt, lane, thr, pos);
-  const int psel = __builtin_amdgcn_readlane(pos, lsel);
-  if (psel < 0) return kNoCand;  // (cannot happen either: the class's sum passes the target)
-  return e_base + ((wsel + 4 * (psel / EPV)) * 64 + lsel) * EPV + (psel % EPV);
-}
-
 // Bit-masked chunk: both sums at the chunk scale Nc (one exponential per element); if the allowed sum comes out
 // below 2^32 although the mask allows something in this chunk (allows_any, from mask_prepare) - allowed mass under
 // about 2^-3.5 of the chunk's largest term, e.g. the one likely token is the forbidden one - the chunk is loaded once
 // more (wave-uniform, rare, L1 / L2 serve it; not keeping x alive for this is what lets the common path run without
 // spills), its forbidden elements overwritten with -inf and the allowed ones summed again on their own maximum's
 // scale.  Out (wave-uniform): the totals of all elements, the allowed elements' sums by 16-lane row, and their scale Nm.
-template <int DT, bool SCALED, int EXPC, bool CAND = false>
+template <int DT, bool SCALED, int EXPC>
 __device__ __forceinline__ void chunk_reduce_bits(float (&x)[64], float Nc, int nv_valid, cu64_t mt,
                                                   const MaskAhead &ma, uint64_t allows_any, int lane, const char *rowp,
                                                   int e_base, int V, float scale, uint32_t &pA, uint32_t &pB,
-                                                  uint32_t (&rA)[4], uint32_t (&rB)[4], float &Nm, bool want_cand, uint64_t R2,
-                                                  int32_t &cand) {
+                                                  uint32_t (&rA)[4], uint32_t (&rB)[4], float &Nm) {
   float P[4], Pm[4];
-  cand = kNoCand;
   class_partials<DT, true, 1, EXPC>(x, term_bias<EXPC>(Nc), nv_valid, mt, ma, P, Pm);
   uint32_t h, l, hm, lm;
   lane_payload<4>(P, h, l);
@@ -545,7 +431,7 @@ __device__ __forceinline__ void chunk_reduce_bits(float (&x)[64], float Nc, int 
   uint32_t top = (uint32_t)(Sm >> kLowMassBits), any = (uint32_t)allows_any;
   opaque_u32(top);
   opaque_u32(any);
-  if (top == 0u && any != 0u) {  // (no candidate for such a chunk: its allowed terms sit on another scale - and x is dead here)
+  if (top == 0u && any != 0u) {
     float y[64];
     load_chunk<DT, SCALED>(rowp, e_base, V, lane, scale, y);
 #pragma unroll
@@ -556,11 +442,19 @@ __device__ __forceinline__ void chunk_reduce_bits(float (&x)[64], float Nc, int 
     lane_payload<4>(P, hm, lm);
     row_sums_u32(hm, rA);
     row_sums_u32(lm, rB);
-  } else {
-    if constexpr (CAND) {
-      if (want_cand) cand = chunk_candidate<DT, kMaskBits, EXPC>(x, term_bias<EXPC>(Nc), mt, lane, e_base, Pm, rA, rB, R2);
-    }
   }
+}
+
+// the particle's two 64-bit draws (chunk stage, in-chunk stage): Philox4x32-10 keyed by the call's seed, counter =
+// (global particle index, call offset)
+__device__ __forceinline__ void philox_pair(const StepParams &p, int pidx, uint64_t &R1, uint64_t &R2) {
+  const uint64_t gp = (uint64_t)(p.particle_base + pidx);
+  const uint32_t ctr[4] = {(uint32_t)gp, (uint32_t)(gp >> 32), (uint32_t)p.offset, (uint32_t)(p.offset >> 32)};
+  const uint32_t key[2] = {(uint32_t)p.seed, (uint32_t)(p.seed >> 32)};
+  uint32_t rnd[4];
+  philox4x32_10(ctr, key, rnd);
+  R1 = ((uint64_t)rnd[1] << 32) | rnd[0];
+  R2 = ((uint64_t)rnd[3] << 32) | rnd[2];
 }
 
 // y = x + (float mask row) for the wave's chunk (same lane layout as x)
@@ -616,7 +510,7 @@ __device__ __forceinline__ uint64_t chunk_pick_lane(uint32_t inclA, uint32_t inc
 // ---------------------------------------------------------------------------------------------------------
 // stats role: one wave per (reduction unit, chunk)
 // ---------------------------------------------------------------------------------------------------------
-template <int DT, int MASK, bool SCALED, int EXPC, bool CAND = false>
+template <int DT, int MASK, bool SCALED, int EXPC>
 __device__ __forceinline__ void stats_item(const StepParams &p, int item, int lane) {
   constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC;
   const int nch = p.nch;
@@ -654,16 +548,8 @@ __device__ __forceinline__ void stats_item(const StepParams &p, int item, int la
   const float Nc = exp_n(chunk_max(x));
   uint32_t pA, pB, rA[4], rB[4];
   float Nm = Nc;
-  int32_t cand = kNoCand;
-  // the unit's ONE particle (no dedup fan-out: particle pr) gets its in-chunk draw made here: chunk_candidate
-  [[maybe_unused]] const bool want_cand = CAND && p.pair_of == nullptr;
   if constexpr (MASK == kMaskBits) {
-    uint64_t R1 = 0, R2 = 0;
-    if constexpr (CAND) {
-      if (want_cand) philox_pair(p, pr, R1, R2);
-    }
-    chunk_reduce_bits<DT, SCALED, EXPC, CAND>(x, Nc, nv_valid, mt, ma, allows_any, lane, rowp, e_base, V, p.scale, pA, pB, rA, rB, Nm,
-                                              want_cand, R2, cand);
+    chunk_reduce_bits<DT, SCALED, EXPC>(x, Nc, nv_valid, mt, ma, allows_any, lane, rowp, e_base, V, p.scale, pA, pB, rA, rB, Nm);
   } else {
     float P[4], Pm[4];
     uint32_t h, l;
@@ -673,13 +559,6 @@ __device__ __forceinline__ void stats_item(const StepParams &p, int item, int la
     row_sums_u32(l, rB);
     pA = rA[0] + rA[1] + rA[2] + rA[3];
     pB = rB[0] + rB[1] + rB[2] + rB[3];
-    if constexpr (CAND && MASK == kMaskNone) {
-      if (want_cand) {
-        uint64_t R1, R2;
-        philox_pair(p, pr, R1, R2);
-        cand = chunk_candidate<DT, MASK, EXPC>(x, term_bias<EXPC>(Nc), nullptr, lane, e_base, P, rA, rB, R2);
-      }
-    }
     if constexpr (MASK == kMaskF32) {  // general additive masks: y = x + m has its own maximum, scale and exp
       const char *mrow = (const char *)(p.mask_f + (int64_t)mi * p.mask_ld);
       float y[64];
@@ -691,12 +570,12 @@ __device__ __forceinline__ void stats_item(const StepParams &p, int item, int la
       row_sums_u32(l, rB);
     }
   }
-  store_rec<CAND>(p.recs + ((int64_t)pr * nch + c) * kRecWords, p.epoch, lane, Nc, Nm, pA, pB, rA, rB, cand);
+  store_rec(p.recs + ((int64_t)pr * nch + c) * kRecWords, p.epoch, lane, Nc, Nm, pA, pB, rA, rB);
   GLB_DIAG(
     if (lane == 0) {
       uint64_t *r = p.recs + ((int64_t)pr * nch + c) * kRecWords;
-      r[14] = stamp0;
-      r[15] = GLB_NOW();
+      r[12] = stamp0;
+      r[13] = GLB_NOW();
     }
   )
 }
@@ -829,8 +708,8 @@ __global__ __launch_bounds__(256) void chunk_stats_small_kernel(const StepParams
   GLB_DIAG(
     if (wave == 0 && lane == 0) {
       uint64_t *r = p.recs + ((int64_t)pr * nch + c) * kRecWords;
-      r[14] = stamp0;
-      r[15] = GLB_NOW();
+      r[12] = stamp0;
+      r[13] = GLB_NOW();
     }
   )
 }
@@ -889,13 +768,11 @@ struct Recs {
   const uint64_t *base;
   uint32_t epoch;
   bool cached;
-  bool has_cand = false;  // the records carry the thirteenth granule (chunk_candidate)
   ChunkRec mine;
   __device__ __forceinline__ ChunkRec get(int c) const {  // always called with c = c0 + lane
     if (cached) return mine;
     ChunkRec r;
-    if (has_cand) load_rec<true, true>(base + (int64_t)c * kRecWords, epoch, r);
-    else load_rec<true, false>(base + (int64_t)c * kRecWords, epoch, r);
+    load_rec<true>(base + (int64_t)c * kRecWords, epoch, r);
     return r;
   }
 };
@@ -903,11 +780,10 @@ struct Recs {
 // POLL: sweep the unit's granules until every tag is this call's epoch (the stats waves of the same launch are still
 // writing them; relaxed agent-scope loads, a short sleep between sweeps, a bounded wait).  Without POLL the records
 // come from an earlier launch on the stream and the tags are not looked at.
-template <bool POLL, bool CAND = false>
+template <bool POLL>
 __device__ __forceinline__ bool recs_acquire(Recs &R, int nch, int lane, uint64_t spin_ticks) {
   R.cached = nch <= 64;
-  R.has_cand = CAND;
-  R.mine = ChunkRec{kNegInf, kNegInf, 0u, 0u, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, 0u, 0u, kNoCand};
+  R.mine = ChunkRec{kNegInf, kNegInf, 0u, 0u, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, 0u, 0u};
   uint64_t t0 = 0;
   if constexpr (POLL) t0 = GLB_NOW();
   for (int c0 = 0; c0 < nch; c0 += 64) {
@@ -920,7 +796,7 @@ __device__ __forceinline__ bool recs_acquire(Recs &R, int nch, int lane, uint64_
         // reads of the still running stats waves queue behind
         bool seen = true;
         if (c < nch) {
-          const uint64_t g = __hip_atomic_load(const_cast<uint64_t *>(R.base) + (int64_t)c * kRecWords + (CAND ? 12 : 11), __ATOMIC_RELAXED,
+          const uint64_t g = __hip_atomic_load(const_cast<uint64_t *>(R.base) + (int64_t)c * kRecWords + 11, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_AGENT);
           seen = (uint32_t)(g >> 32) == R.epoch;
         }
@@ -931,8 +807,8 @@ __device__ __forceinline__ bool recs_acquire(Recs &R, int nch, int lane, uint64_
         }
       }
       bool ok = true;
-      ChunkRec r = ChunkRec{kNegInf, kNegInf, 0u, 0u, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, 0u, 0u, kNoCand};
-      if (c < nch) ok = load_rec<POLL, CAND>(R.base + (int64_t)c * kRecWords, R.epoch, r);
+      ChunkRec r = ChunkRec{kNegInf, kNegInf, 0u, 0u, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, 0u, 0u};
+      if (c < nch) ok = load_rec<POLL>(R.base + (int64_t)c * kRecWords, R.epoch, r);
       if (c0 == 0) R.mine = r;
       if constexpr (!POLL) break;
       if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
@@ -1011,7 +887,6 @@ struct ChunkPick {
   float Nms;       // the scale the chosen chunk's allowed terms sit on
   uint64_t R2;     // second Philox word
   uint64_t qg[4];  // the chosen chunk's allowed sums by 16-lane row
-  int32_t cand = kNoCand;  // the token the chunk's stats wave drew for this particle (chunk_candidate), or kNoCand
 };
 
 __device__ __forceinline__ ChunkPick pair_pick_chunk(const Recs &recs, const PairState &st, uint64_t R1, uint64_t R2,
@@ -1024,7 +899,7 @@ __device__ __forceinline__ ChunkPick pair_pick_chunk(const Recs &recs, const Pai
   for (int c0 = 0; c0 < nch && k.csel < 0; c0 += 64) {
     const int c = c0 + lane;
     uint64_t sm = 0;
-    ChunkRec r{kNegInf, kNegInf, 0u, 0u, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, 0u, 0u, kNoCand};
+    ChunkRec r{kNegInf, kNegInf, 0u, 0u, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, 0u, 0u};
     if (c < nch) {
       r = recs.get(c);
       const uint64_t m = ((uint64_t)r.pAm << kGridHi) + r.pBm;
@@ -1037,7 +912,6 @@ __device__ __forceinline__ ChunkPick pair_pick_chunk(const Recs &recs, const Pai
     const int lsel = first_lane_above(incl, T);
     if (lsel >= 0) {
       k.csel = c0 + lsel;
-      k.cand = __builtin_amdgcn_readlane(r.cand, lsel);
       k.Nms = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(r.Nm), lsel));
 #pragma unroll
       for (int g = 0; g < 4; ++g)
@@ -1104,7 +978,7 @@ __device__ __forceinline__ void fold_all_fast(const ChunkRec &r, bool have, floa
   S_all = wave_sum_u64(sa);
 }
 
-template <int DT, int MASK, bool POLL, int EXPC, bool CAND = false>
+template <int DT, int MASK, bool POLL, int EXPC>
 __device__ __forceinline__ void finish_draw(const StepParams &p, int pidx, int lane) {
   constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC, NVW = NVC / 4;
   const int nch = p.nch, V = p.V;
@@ -1120,7 +994,7 @@ __device__ __forceinline__ void finish_draw(const StepParams &p, int pidx, int l
   Recs recs;
   recs.base = p.recs + (int64_t)pr * nch * kRecWords;
   recs.epoch = p.epoch;
-  if (!recs_acquire<POLL, CAND>(recs, nch, lane, p.spin_ticks)) {  // never in a healthy launch: say so in the outputs and leave
+  if (!recs_acquire<POLL>(recs, nch, lane, p.spin_ticks)) {  // never in a healthy launch: say so in the outputs and leave
     if (lane == 0) {
       if (p.err) atomicAdd(p.err, 1u);
       const float nan = __uint_as_float(0x7fc00000u);
@@ -1154,7 +1028,6 @@ __device__ __forceinline__ void finish_draw(const StepParams &p, int pidx, int l
       const uint64_t T = __umul64hi(R1, st.S_msk);  // uniform integer in [0, S_msk)
       const int lsel = first_lane_above(incl, T);
       pick.csel = lsel;
-      pick.cand = __builtin_amdgcn_readlane(r.cand, lsel);
       pick.Nms = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(r.Nm), lsel));
 #pragma unroll
       for (int g = 0; g < 4; ++g)
@@ -1168,16 +1041,7 @@ __device__ __forceinline__ void finish_draw(const StepParams &p, int pidx, int l
   }
   GLB_DIAG(if (stamps && lane == 0) stamps[5] = GLB_NOW();)
   int32_t tok = -1;
-  bool drawn = false;
-  if constexpr (CAND) {
-    // the chunk's own stats wave made this particle's in-chunk draw (chunk_candidate: units of one particle): nothing to
-    // reload, nothing to walk - the token is in the record
-    if (pick.csel >= 0 && p.pair_of == nullptr && pick.cand != kNoCand) {
-      tok = pick.cand;
-      drawn = true;
-    }
-  }
-  if (pick.csel >= 0 && !drawn) {
+  if (pick.csel >= 0) {
     // ---- the 16-lane row: four wave-uniform sums, picked in scalar registers
     const uint64_t i0 = pick.qg[0], i1 = i0 + pick.qg[1], i2 = i1 + pick.qg[2], Sc = i2 + pick.qg[3];
     const uint64_t T2 = __umul64hi(pick.R2, Sc);  // uniform integer in [0, S_c)
@@ -1304,7 +1168,10 @@ struct StatsWaves {
 // (Round 6, under the hardware-exponential contract, where the stream is bound by memory: workgroups of two and four waves
 // again - 27.2 / 27.3 us against 26.6 at 512 x 128256 bf16 -, two chunks per wave - 30 to 34 us: the doubled body spills -,
 // the chunk kept as loaded in 32 registers at six and eight waves a SIMD - no gain, spills at eight -, default-policy loads
-// - 28.7 us; EXPERIMENTS.md.)
+// - 28.7 us; and VERDICT r5 #7's proposal, the stats wave making the in-chunk draw itself for units of one particle and
+// leaving the token in a thirteenth granule (commit 42bad02: bit-exact, the finishing wave 1.7 us shorter - and the launch
+// 4.4 us LONGER at 1024 x 50257 fp32, 5.7 us at 512 x 128256 bf16: every stats wave lives a Philox block, two scans and
+// sixteen terms longer, and the stream is bound by how many waves have loads in flight); EXPERIMENTS.md.)
 template <int DT, int MASK, bool SCALED, int MODE, int EXPC = kExpPoly>
 __global__ __launch_bounds__(64, (StatsWaves<DT, MASK>::value)) void fused_step_kernel(const StepParams p) {
   const int lane = threadIdx.x;
@@ -1322,14 +1189,12 @@ __global__ __launch_bounds__(64, (StatsWaves<DT, MASK>::value)) void fused_step_
       }
     }
   )
-  // the stats waves of a Philox step make every unit's in-chunk draw themselves (chunk_candidate) - GLB_STEP_CANDIDATES
-  constexpr bool CAND = MODE == kModePhilox && MASK != kMaskF32 && (GLB_STEP_CANDIDATES);
   if (item >= 0) {
-    stats_item<DT, MASK, SCALED, EXPC, CAND>(p, item, lane);
+    stats_item<DT, MASK, SCALED, EXPC>(p, item, lane);
     return;
   }
   for (int pidx = pfirst; pidx < p.n_particles; pidx += p.fin_blocks) {
-    if constexpr (MODE == kModePhilox) finish_draw<DT, MASK, true, EXPC, CAND>(p, pidx, lane);
+    if constexpr (MODE == kModePhilox) finish_draw<DT, MASK, true, EXPC>(p, pidx, lane);
     else finish_stats<MASK, true>(p, pidx, lane);
   }
 }

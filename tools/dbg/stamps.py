@@ -38,8 +38,8 @@ for i in range(iters):
         continue
     ws = eng._step_ws[: B * nch * 128].view(torch.int64).view(B, nch, 16).cpu().numpy()
     st = stamps.view(torch.int64).view(B, 8).cpu().numpy()
-    t0 = ws[:, :, 14].min()
-    s_start, s_end = (ws[:, :, 14] - t0) / 100.0, (ws[:, :, 15] - t0) / 100.0  # microseconds
+    t0 = ws[:, :, 12].min()
+    s_start, s_end = (ws[:, :, 12] - t0) / 100.0, (ws[:, :, 13] - t0) / 100.0  # microseconds
     f = (st[:, :3] - t0) / 100.0
     rows.append((s_start.max(), s_end.max(), np.percentile(s_end, 50), np.percentile(s_end, 90), f[:, 0].min(), f[:, 0].max(),
                  f[:, 2].max(), (f[:, 2] - f[:, 1]).mean(), (f[:, 2] - f[:, 1]).max(), (f[:, 2] - f[:, 1]).min(),
