@@ -293,9 +293,9 @@ def main():
                          "library - the defaults; tune - time the solutions of every new shape during the warm-up (seconds a shape) "
                          "and write --gemms-file at exit")
     ap.add_argument("--contract", choices=["poly", "hw", "auto"], default="auto",
-                    help="arithmetic of the fused step's terms (include/glb.h GLB_STEP_HW_EXP): auto (default, the product's) / hw - "
-                         "v_exp_f32 for 16-bit logits (checked against the oracle by tolerance), the polynomial for float32 rows; "
-                         "poly - the polynomial exponential for every element type, bit for bit the oracle's")
+                    help="arithmetic of the fused step's terms (include/glb.h GLB_STEP_HW_EXP): auto (default, the product's) - "
+                         "v_exp_f32 for 16-bit logits (checked against the oracle by tolerance), the polynomial for float32 rows; hw - "
+                         "v_exp_f32 for every element type; poly - the polynomial, bit for bit the oracle's")
     ap.add_argument("--gemms-file", default=None, help="--gemms tune: the file to extend (default: $TMPDIR/glb_tunableop.csv)")
     args = ap.parse_args()
     args.gemm_shapes = 0
@@ -867,7 +867,8 @@ class KernelWorkload:
         return {"workload": f"fused step only: {shape} ld=V, {rows}, {masks}, {draw}, 4 rotating logits buffers",
                 "particles_per_gpu": self.B, "vocab": self.V, "rng": "parity (torch CPU generator on the device)" if self.parity else "philox",
                 "logits": self.logits_kind, "mask": self.mask_mode,
-                "contract": ("hardware exponential (v_exp_f32; GLB_STEP_HW_EXP)" if self.llama and self.eng.contract != "poly"
+                "contract": ("hardware exponential (v_exp_f32; GLB_STEP_HW_EXP)"
+                             if self.eng.contract == "hw" or (self.llama and self.eng.contract == "auto")
                              else "polynomial exponential (bit for bit the oracle's)"), **extra}
 
 

@@ -707,8 +707,6 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
   if (a->rng_mode < GLB_RNG_NONE || a->rng_mode > GLB_RNG_NOISE)
     return fail(GLB_EINVAL, "bad rng_mode %d", a->rng_mode);
   if (a->flags & ~GLB_STEP_HW_EXP) return fail(GLB_EINVAL, "flags %d: only GLB_STEP_HW_EXP is defined", a->flags);
-  if ((a->flags & GLB_STEP_HW_EXP) && a->dtype == GLB_F32)
-    return fail(GLB_EINVAL, "GLB_STEP_HW_EXP is a contract of 16-bit rows (float32 rows are bound by memory, not by the exponential)");
   const int expc = (a->flags & GLB_STEP_HW_EXP) ? glb::kExpHw : glb::kExpPoly;
   if (a->rng_mode == GLB_RNG_NOISE && (!a->noise || (a->noise_ld < a->vocab && a->noise_ld != 0)))
     return fail(GLB_EINVAL, "noise tensor missing or noise_ld < vocab (0 = one row shared by every particle)");

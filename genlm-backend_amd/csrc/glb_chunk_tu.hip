@@ -30,8 +30,10 @@ static void launch_k(K kernel, dim3 grid, dim3 block, hipStream_t s, const StepP
 // two SIMDs the per-wave latency is the launch time)
 constexpr int64_t kSmallLaunchItems = 512;
 
-// the term's arithmetic contract (glb_math.hpp): the hardware exponential exists for 16-bit rows only
-constexpr bool kHasHwExp = GLB_DT != kDtF32;
+// the term's arithmetic contract (glb_math.hpp): both exist for every element type (round 6: float32 rows gain less from
+// the hardware exponential than 16-bit rows - they are bound by memory - but a wave that is done sooner frees its loads'
+// slots sooner: 38.0 -> 36.6 us at 1024 x 50257, profiles/r06/ab_contract_f32_v1.log)
+constexpr bool kHasHwExp = true;
 
 template <int MASK, int EXPC>
 static hipError_t stats1(const StepParams &p, bool scaled, hipStream_t s) {

@@ -232,11 +232,11 @@ class HipEngine:
 
     def __init__(self, device=None, contract="auto"):
         """contract: the arithmetic of the fused step's terms (include/glb.h, GLB_STEP_HW_EXP) - "poly":
-        the polynomial exponential every element type has, restated bit for bit by the oracle; "hw" / "auto" (the
-        default): the hardware's v_exp_f32 for 16-bit logits - a third less time on rows bound by instruction issue,
-        within one ulp of 2^y, deterministic and independent of launch geometry on gfx950, checked against the oracle by
-        tolerance and against torch's ids in parity mode (tests/test_step_hw_gpu.py) - and the polynomial for float32 rows,
-        which have nothing else.  `step(contract=...)` overrides it per call."""
+        the polynomial exponential, restated bit for bit by the oracle; "hw": the hardware's v_exp_f32 - within one ulp of
+        2^y, deterministic and independent of launch geometry on gfx950, checked against the oracle by tolerance and
+        against torch's ids in parity mode (tests/test_step_hw_gpu.py); "auto" (the default): "hw" for 16-bit logits (a
+        sixth less time on rows bound by instruction issue), "poly" for float32 rows (bound by memory: 4 % to gain, and
+        their results stay the oracle's bit for bit).  `step(contract=...)` overrides it per call."""
         if contract not in self.CONTRACTS:
             raise ValueError(f"contract must be one of {self.CONTRACTS}, got {contract!r}")
         self.contract = contract
@@ -366,7 +366,7 @@ class HipEngine:
         contract = self.contract if contract is None else contract
         if contract not in self.CONTRACTS:
             raise ValueError(f"contract must be one of {self.CONTRACTS}, got {contract!r}")
-        a.flags = STEP_HW_EXP if contract != "poly" and a.dtype != F32 else 0
+        a.flags = STEP_HW_EXP if contract == "hw" or (contract == "auto" and a.dtype != F32) else 0
         ws = self._scratch(self.lib.glb_step_workspace_bytes(n, n_rows, V, n_masks))
         a.workspace = ws.data_ptr()
         a.workspace_bytes = ws.numel()

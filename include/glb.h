@@ -54,16 +54,18 @@ enum {
 };
 
 /* glb_step_args.flags.
- * GLB_STEP_HW_EXP (GLB_BF16 / GLB_F16 rows; GLB_EINVAL with GLB_F32): the second arithmetic contract of the step - a
- * term is the hardware's 2^y, t = v_exp_f32(fma(x, log2 e, -(N_c + 1))), instead of the polynomial.  Same chunks, same
+ * GLB_STEP_HW_EXP: the second arithmetic contract of the step - a term is the hardware's 2^y,
+ * t = v_exp_f32(fma(x, log2 e, -(N_c + 1))), instead of the polynomial.  Same chunks, same
  * (lane, class) float32 sums in load order, same integer sums, records and draws, so results are still deterministic and
  * independent of launch geometry and particle sharding ON gfx950; v_exp_f32 is within one ulp of 2^y (the polynomial:
  * 2.7e-6) but not correctly rounded, so oracle/glb_oracle.c restates this contract with exp2f and the comparison is by
  * tolerance: logZ / lse within 1e-4 of the reference (observed 1e-6), parity-mode tokens identical on every golden,
  * Philox tokens equal to the oracle's except where a draw lands within 2^-20 of a boundary of the inverse CDF
  * (tests/test_step_gpu.py counts them).  What it buys: the exponential is 9 of the 13 vector instructions per element of
- * the polynomial contract and 16-bit rows are bound by instruction issue; cache.py:96 keeps the
- * logits' dtype, so 16-bit rows are every Llama-class checkpoint's case. */
+ * the polynomial contract and 16-bit rows are bound by instruction issue (512 x 128256 bf16 31.5 ->
+ * 27 us); cache.py:96 keeps the logits' dtype, so 16-bit rows are every Llama-class checkpoint's case.  float32 rows are
+ * bound by memory and gain less (1024 x 50257: 38.0 -> 36.6 us): the Python host sets the flag for 16-bit rows by default
+ * ("auto") and for float32 rows only when asked ("hw"), so that float32 results stay the oracle's bit for bit. */
 enum { GLB_STEP_HW_EXP = 1 };
 
 /* RNG modes of the categorical draw */
@@ -133,7 +135,7 @@ typedef struct glb_step_args {
                         finishing wave gave up waiting for its row's records - a failed launch, never a result) */
   float *out_margin; /* [n_particles] GLB_RNG_NOISE only: (winner - runner-up) / winner of the race e_j / E_j, i.e. how
                         far the draw is from a tie that float rounding could flip (1 if there is no runner-up) */
-  int32_t flags;     /* 0, or GLB_STEP_HW_EXP (16-bit logits only); any other bit: GLB_EINVAL */
+  int32_t flags;     /* 0 or GLB_STEP_HW_EXP; any other bit: GLB_EINVAL */
   /* device scratch of >= glb_step_workspace_bytes(...) bytes, 32-byte aligned: the per-chunk records (64 bytes per
      row and 4096-token chunk) the reducing waves hand to the per-particle waves (and, for GLB_MASK_BITS, the prepared
      masks).  See glb_workspace_init. */

@@ -25,6 +25,8 @@ def _np(t):
 
 
 def _mk16(x, dtype):
+    if dtype == "f32":
+        return x, torch.from_numpy(x)
     if dtype == "bf16":
         t = torch.from_numpy(x).to(torch.bfloat16)
         return t.view(torch.int16).numpy().view(np.uint16), t
@@ -66,6 +68,8 @@ CASES = [
     (3, 777, "bf16", 3),
     (300, 4097, "bf16", 2),   # more than 512 chunks: the one-launch kernel
     (40, 70001, "f16", 1),
+    (16, 50257, "f32", 2),    # float32 rows have the contract too (the host asks for it with contract="hw" only)
+    (200, 8191, "f32", 3),
 ]
 
 
@@ -95,12 +99,15 @@ def test_hw_contract_against_the_oracle(engine, oracle, B, V, dtype, K, mask_kin
     res = engine.step(x_t.to(dev), rng_mode=1, seed=1234, offset=7, particle_base=11, contract="hw", **kw_g)
     dz, dl, n_diff = check_hw(res, want_hw, want_poly, edge)
     assert dz < 2e-5 and dl < 2e-5  # (the bar is 1e-4; the two exponentials are an ulp apart)
-    # float32 rows have the polynomial only: the engine's "hw" / "auto" leave them on it, bit for bit
+    # "auto" leaves float32 rows on the polynomial, bit for bit, and puts 16-bit rows on the hardware exponential
     if B <= 4:
         x32 = torch.from_numpy(x).to(dev)
-        a = engine.step(x32, rng_mode=1, seed=1, contract="hw")
+        a = engine.step(x32, rng_mode=1, seed=1, contract="auto")
         b = engine.step(x32, rng_mode=1, seed=1, contract="poly")
         assert all(torch.equal(p, q) for p, q in zip(a, b))
+        if dtype != "f32":
+            c = engine.step(x_t.to(dev), rng_mode=1, seed=1234, offset=7, particle_base=11, contract="auto", **kw_g)
+            assert all(torch.equal(p, q) for p, q in zip(c, res))
 
 
 def test_hw_contract_at_config5_full_size(engine, oracle):
@@ -171,7 +178,8 @@ def test_hw_contract_parity_at_config5_full_size_is_torchs(engine, oracle):
         assert np.abs(_np(margin) - gold["parity512_llama::margin"]).max() < 1e-3
 
 
-def test_hw_contract_does_not_depend_on_launch_geometry(engine):
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_hw_contract_does_not_depend_on_launch_geometry(engine, dtype):
     """Deterministic and shard-invariant on the GPU: one row alone (four waves per chunk, two launches), the same row
     among 300 (one-wave statistics, one launch), shared by 700 particles, and a population cut into shards with
     particle_base give the same bits for logZ / lse / tokens."""
@@ -179,10 +187,10 @@ def test_hw_contract_does_not_depend_on_launch_geometry(engine):
     V = 50257
     g = torch.Generator(device=dev)
     g.manual_seed(3)
-    x = (torch.randn((300, V), device=dev, generator=g) * 3).to(torch.bfloat16)
+    x = (torch.randn((300, V), device=dev, generator=g) * 3).to(torch.bfloat16 if dtype == "bf16" else torch.float32)
     maskf = torch.where(torch.rand((2, V), device=dev, generator=g) < 1 / 3, float("-inf"), 0.0)
     bits, _ = engine.mask_to_bits(maskf)
-    prep = engine.prepare_masks(bits, V, torch.bfloat16)
+    prep = engine.prepare_masks(bits, V, x.dtype)
     rid = (torch.arange(300, device=dev) % 2).to(torch.int32)
     kw = dict(rng_mode=1, seed=77, offset=3, contract="hw")
     full = [t.clone() for t in engine.step(x, mask=prep, row_mask_id=rid, **kw)]
@@ -201,16 +209,37 @@ def test_hw_contract_does_not_depend_on_launch_geometry(engine):
     assert torch.equal(shared[0], full[0][row_of.long()]) and torch.equal(shared[1], full[1][row_of.long()])
 
 
-def test_hw_flag_through_the_c_abi_is_refused_for_float32(engine):
-    """GLB_STEP_HW_EXP with GLB_F32 rows, and undefined flag bits: GLB_EINVAL (include/glb.h)."""
+def test_undefined_flag_bits_are_refused_through_the_c_abi(engine):
+    """glb_step_args.flags: GLB_STEP_HW_EXP or nothing; any other bit is GLB_EINVAL (include/glb.h)."""
     import ctypes as C
 
     from genlm_backend_amd._lib import GLB_EINVAL, STEP_HW_EXP
 
     x = torch.zeros((2, 100), device=engine.device)
     plan = engine.step_plan(x, rng_mode=1, seed=1)
-    for flags in (STEP_HW_EXP, 2, 4 | STEP_HW_EXP):
+    for flags in (2, 4 | STEP_HW_EXP, -1):
         plan.args.flags = flags
         assert engine.lib.glb_logprob_mask_sample(C.byref(plan.args), engine._stream()) == GLB_EINVAL
-    plan.args.flags = 0
-    assert engine.lib.glb_logprob_mask_sample(C.byref(plan.args), engine._stream()) == 0
+    for flags in (0, STEP_HW_EXP):
+        plan.args.flags = flags
+        assert engine.lib.glb_logprob_mask_sample(C.byref(plan.args), engine._stream()) == 0
+
+
+def test_hw_contract_parity_at_the_fp32_headline_size_is_torchs(engine, oracle):
+    """(ii) for float32 rows: 1024 x 50257 in parity mode under the hardware exponential against the torch-made golden
+    (ref_round2.npz, parity1024::*): every id torch.multinomial's, logZ within 1e-4, the race's margins as torch has them."""
+    from genlm_backend_amd.engine import DeviceRng
+
+    gold = np.load(os.path.join(GOLD, "ref_round2.npz"))
+    B, V = 1024, 50257
+    dev = engine.device
+    bits, _ = oracle.mask_f32_to_bits(synth.binary_masks(21, 2, V))
+    mid = torch.from_numpy((np.arange(B) % 2).astype(np.int32)).to(dev)
+    margin = torch.empty(B, device=dev)
+    logZ, lse, tok = engine.step(torch.from_numpy(synth.logits(21, B, V)).to(dev), mask_kind=1,
+                                 mask=torch.from_numpy(bits.view(np.int32)).to(dev), mask_id=mid, rng_mode=2,
+                                 noise=DeviceRng(engine, 2024, V).rows(B), out_margin=margin, contract="hw")
+    torch.cuda.synchronize()
+    assert np.array_equal(_np(tok), gold["parity1024::token"])
+    assert np.abs(_np(logZ) - gold["parity1024::logZ"]).max() < 1e-4
+    assert np.abs(_np(margin) - gold["parity1024::margin"]).max() < 1e-3

@@ -57,5 +57,7 @@ if __name__ == "__main__":
     for _ in range(2):
         run(eng, 512, 128256, torch.bfloat16, a.iters)
         run(eng, 1024, 50257, torch.bfloat16, a.iters)
+    run(eng, 1024, 50257, torch.float32, a.iters)
+    run(eng, 1024, 50257, torch.float32, a.iters)
     run(eng, 512, 128256, torch.float16, a.iters)
     run(eng, 512, 128256, torch.bfloat16, a.iters, rng_mode=0)
