@@ -1,5 +1,5 @@
 // glb_diag.hpp - the DIAGNOSTIC build's hooks (make dbg: -DGLB_STAMPS -> tools/dbg/libglb_hip_dbg.so; tools/dbg/stamps*.py,
-// tools/r4_kernel_ab*.sh).  In the product build GLB_DIAG(...) is nothing and none of this exists: no field of a kernel's
+// tools/ab.sh).  In the product build GLB_DIAG(...) is nothing and none of this exists: no field of a kernel's
 // parameters, no instruction, no getenv.  The experiments these hooks served are written up in DESIGN.md §5.
 #pragma once
 #include <stdint.h>

@@ -2,12 +2,12 @@
 # Round 5 additions to tools/profile_round.sh (run as a second gpurun call: each stays under the 20-minute limit): the parity
 # (torch CPU generator on the device) lines, real-shaped logits, the Llama-shaped steps with their per-step GEMM tables and
 # GPU-busy, the device-resident API batch, the trie's selected / per-row forms with their HBM traffic and request counters,
-# RCCL's own account of the one-rank group.  Output: gpurun_out/prof5/ (tools/save_profile_pass.sh r05 vN prof5 copies the
+# RCCL's own account of the one-rank group.  Output: gpurun_out/prof2/ (tools/save_profile_pass.sh r05 vN prof2 copies the
 # judged summaries into profiles/r05/).
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 cd /tmp
 export TMPDIR=/tmp
-O=$R/gpurun_out/prof5
+O=$R/gpurun_out/prof2
 rm -rf $O && mkdir -p $O
 b() { n=$1; shift; timeout -k 10 400 python3 $R/bench.py "$@" > $O/bench_$n.json 2> $O/bench_$n.err; echo "$n rc=$?"; }
 b kernel_parity --workload kernel --rng parity --steps 100 --warmup 5

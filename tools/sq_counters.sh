@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ / GRBM counters of the fused step on the two headline shapes: separate --pmc passes (8 SQ slots per
+# SQ / GRBM counters of the fused step on the two headline shapes (extra bench.py arguments, e.g. --contract poly, as $@): separate --pmc passes (8 SQ slots per
 # pass; no trace domains beside --pmc), condensed by tools/sq_summary.py.  Output: gpurun_out/sq/.
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 cd /tmp
@@ -15,7 +15,7 @@ for w in kernel kernel-llama; do
   i=0
   for p in "${PASSES[@]}"; do
     i=$((i + 1))
-    rocprofv3 --pmc $p --output-format csv -d $O/${w}_p$i -o c -- python3 $R/bench.py --workload $w --steps 20 --warmup 2 --no-cpu > $O/${w}_p$i.log 2>&1 || echo "pass $i of $w failed" >> $O/failed.txt
+    rocprofv3 --pmc $p --output-format csv -d $O/${w}_p$i -o c -- python3 $R/bench.py --workload $w --steps 20 --warmup 2 --no-cpu "$@" > $O/${w}_p$i.log 2>&1 || echo "pass $i of $w failed" >> $O/failed.txt
   done
 done
 python3 $R/tools/sq_summary.py $O > $O/sq_summary.log 2>&1

@@ -1,4 +1,4 @@
-"""Condense the rocprofv3 --pmc passes of tools/r4_sq.sh under <dir> into <workload>_sq_counters.json: per kernel of this
+"""Condense the rocprofv3 --pmc passes of tools/sq_counters.sh under <dir> into <workload>_sq_counters.json: per kernel of this
 library, the mean of every counter per launch (launches of the dominant grid only) and the ratios the guide reads from
 them (MI355X_MICROARCH.md: SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves;
 SQ_BUSY_CYCLES per SE/XCD instance; GRBM_GUI_ACTIVE summed over the 8 XCDs)."""
