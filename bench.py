@@ -921,7 +921,10 @@ class ApiWorkload:
         self._reset()
         rs = np.random.default_rng(7 + rank)
         self.ctx_pool = [[int(t) for t in rs.integers(0, V, 13)] for _ in range(n_particles)]
-        for i in range(2):  # set-up: allocator growth, GEMM selection
+        # set-up, not measurement: allocator growth, GEMM selection - and, with KV rows, the hipGraph captures of the in-place
+        # forward (kv.SlabForward captures a slab set's launch sequence at its third call; the second set's capture used to land
+        # in the middle of the timed region: one 41 ms host step in thirty, `--step-times`, 4.9 instead of 3.5 ms a step)
+        for i in range(3 * (max_tokens + 1) if auto_kv else 2):
             self.step(i, False)
         self._reset()
 
