@@ -741,25 +741,6 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
     p.pair_of = nullptr;
   }
   p.recs = (uint64_t *)a->workspace;
-  int kmask = glb::kMaskNone;
-  if (a->mask_kind == GLB_MASK_F32) {
-    kmask = glb::kMaskF32;
-    p.mask_f = (const float *)a->mask;
-    p.mask_ld = a->mask_ld;
-  } else if (a->mask_kind != GLB_MASK_NONE) {
-    kmask = glb::kMaskBits;
-    const char *prep = (const char *)a->mask;
-    if (own_prep) {  // transposed form into the workspace, on the same stream
-      char *dst = (char *)a->workspace + fixed_bytes;
-      const hipError_t e = launch_mask_prepare((const uint32_t *)a->mask, a->n_masks, a->vocab, a->mask_ld, a->dtype, dst, s,
-                                               glb::g_step_ev_start);
-      glb::g_step_ev_start = nullptr;  // (a timed call starts with this launch)
-      if (e != hipSuccess) return hip_fail(e, "mask_prepare launch");
-      prep = dst;
-    }
-    p.mask_t = (const uint64_t *)prep;
-    p.mask_any = (const uint64_t *)(prep + prepared_words_bytes(a->n_masks, a->vocab));
-  }
   p.noise = a->noise;
   p.noise_ld = a->noise_ld;
   p.seed = a->seed;
@@ -779,7 +760,7 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
   // launch is big enough to be dealt one wave per chunk (smaller ones: four waves per chunk, then the finish launch);
   // two launches otherwise.
   const int64_t items = n_units * (int64_t)p.nch;
-  const bool fmask = kmask == glb::kMaskF32;
+  const bool fmask = a->mask_kind == GLB_MASK_F32;
   bool fused = a->rng_mode != GLB_RNG_NOISE && items > 512 && a->n_particles <= 16 * (int64_t)fin_wave_cap(fmask);
   p.spin_ticks = g_spin_ticks.load(std::memory_order_relaxed);
 #ifdef GLB_STAMPS  // diagnostic build: occupancy cap of the one-launch step from the environment (bytes of unused LDS)
@@ -790,6 +771,31 @@ int glb_logprob_mask_sample(const glb_step_args *a, void *stream) {
     const int rc = ws_next_epoch(a->workspace, fixed_bytes, need_ws, s, &p.epoch, &p.err);
     if (rc < 0) return hip_fail(hipGetLastError(), "workspace re-zero");
     fused = rc > 0;
+  }
+  int kmask = glb::kMaskNone;
+  if (a->mask_kind == GLB_MASK_F32) {
+    kmask = glb::kMaskF32;
+    p.mask_f = (const float *)a->mask;
+    p.mask_ld = a->mask_ld;
+  } else if (own_prep && fused) {
+    // raw bit rows and the one-launch step: the stats waves read the rows themselves (kMaskRaw) - no mask_prepare launch,
+    // no lane words written to the workspace and read back
+    kmask = glb::kMaskRaw;
+    p.mask_bits = (const uint32_t *)a->mask;
+    p.mask_bits_ld = a->mask_ld;
+  } else if (a->mask_kind != GLB_MASK_NONE) {
+    kmask = glb::kMaskBits;
+    const char *prep = (const char *)a->mask;
+    if (own_prep) {  // transposed form into the workspace, on the same stream
+      char *dst = (char *)a->workspace + fixed_bytes;
+      const hipError_t e = launch_mask_prepare((const uint32_t *)a->mask, a->n_masks, a->vocab, a->mask_ld, a->dtype, dst, s,
+                                               glb::g_step_ev_start);
+      glb::g_step_ev_start = nullptr;  // (a timed call starts with this launch)
+      if (e != hipSuccess) return hip_fail(e, "mask_prepare launch");
+      prep = dst;
+    }
+    p.mask_t = (const uint64_t *)prep;
+    p.mask_any = (const uint64_t *)(prep + prepared_words_bytes(a->n_masks, a->vocab));
   }
   if (fused) {
     p.stats_blocks = (int32_t)items;

@@ -46,7 +46,13 @@
 namespace glb {
 
 enum { kDtF32 = 0, kDtBf16 = 1, kDtF16 = 2 };
-enum { kMaskNone = 0, kMaskBits = 1, kMaskF32 = 2 };
+enum { kMaskNone = 0, kMaskBits = 1, kMaskF32 = 2, kMaskRaw = 3 };
+// kMaskRaw (round 6; the one-launch step only): GLB_MASK_BITS rows as the caller holds them - bit j % 32 of word j / 32 -,
+// read by the stats waves themselves: a lane fetches the words that hold ITS elements' bits with the chunk's loads, keeps
+// them as one 64-bit value (bit i * EPV + k = element (i, k)) and ANDs every term with 0 / ~0 before the allowed sum.  No
+// mask_prepare launch, no lane words written and read back: what a grammar that changes every particle's mask every step
+// pays (kMaskBits' prepared lane words select by EXEC from scalar registers - two operations an element fewer - and stay the
+// form for masks that are prepared once).  Same sums: a forbidden term enters as +0.
 enum { kModeStats = 0, kModePhilox = 1, kModeNoise = 2 };
 
 struct ChunkRec {  // one (row|particle, chunk) as the finish role holds it
@@ -80,6 +86,8 @@ struct StepParams {
   const uint64_t *mask_any;  // [n_masks][nch]: nonzero when the mask allows any token of the chunk
   const float *mask_f;       // float masks [n_masks][mask_ld]
   int64_t mask_ld;
+  const uint32_t *mask_bits; // kMaskRaw: the caller's bit rows [n_masks][mask_bits_ld]
+  int64_t mask_bits_ld;
   const float *noise;
   int64_t noise_ld;
   uint64_t seed, offset;
@@ -383,6 +391,55 @@ __device__ __forceinline__ void class_partials(const float (&x)[64], float magic
     class_partials_body<DT, MASKED, VSTEP, false, EXPC>(x, magicN, nv_valid, mt, v0, ahead, P, Pm);
 }
 
+// kMaskRaw: bit i * EPV + k of the result = this lane's element (vector i, component k) of chunk c is allowed.  The EPV bits
+// of a vector sit in one word of the row (fp32: 4 bits at a multiple of 4; 16-bit: one byte); elements past the row's end
+// read as forbidden.
+template <int DT>
+__device__ __forceinline__ uint64_t lane_mask_bits(const uint32_t *brow, int e_base, int V, int lane) {
+  constexpr int EPV = ElemTraits<DT>::EPV, NVC = ElemTraits<DT>::NVC;
+  const int n_words = (V + 31) >> 5;
+  uint32_t w[NVC];
+#pragma unroll
+  for (int i = 0; i < NVC; ++i) {  // (loads first)
+    const int wi = (e_base + (i * 64 + lane) * EPV) >> 5;
+    w[i] = wi < n_words ? brow[wi] : 0u;
+  }
+  uint64_t X = 0;
+#pragma unroll
+  for (int i = 0; i < NVC; ++i) {
+    const int e0 = e_base + (i * 64 + lane) * EPV;
+    uint32_t v = (w[i] >> (e0 & 31)) & ((1u << EPV) - 1u);
+    const int valid = V - e0;
+    if (valid < EPV) v &= valid > 0 ? ((1u << valid) - 1u) : 0u;
+    X |= (uint64_t)v << (i * EPV);
+  }
+  return X;
+}
+
+// class_partials on per-lane bits: P over all elements, Pm over the allowed ones - a term ANDed with 0 / ~0 by its bit
+// (v_bfe_i32: a one-bit field, sign-extended), so a forbidden term enters the allowed sum as +0
+template <int DT, int EXPC, bool ONLY_MASKED = false>
+__device__ __forceinline__ void class_partials_raw(const float (&x)[64], float bias, int nv_valid, uint64_t X, float (&P)[4],
+                                                   float (&Pm)[4]) {
+  constexpr int EPV = ElemTraits<DT>::EPV, NVC = ElemTraits<DT>::NVC;
+  const uint32_t Xlo = (uint32_t)X, Xhi = (uint32_t)(X >> 32);
+#pragma unroll
+  for (int w = 0; w < 4; ++w) P[w] = Pm[w] = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NVC; ++i) {
+    if (i < nv_valid) {  // wave-uniform: vectors wholly past the row's end would add +0
+#pragma unroll
+      for (int k = 0; k < EPV; ++k) {
+        const int j = i * EPV + k;  // (compile-time after unrolling)
+        const float t = chunk_term<EXPC>(x[j], bias);
+        if constexpr (!ONLY_MASKED) P[i & 3] = P[i & 3] + t;
+        const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)(j < 32 ? Xlo : Xhi), (unsigned)(j & 31), 1u);
+        Pm[i & 3] = Pm[i & 3] + __uint_as_float(__float_as_uint(t) & m);
+      }
+    }
+  }
+}
+
 // this lane's payload words: the sum over its NCLS class partials of floor(P * 2^36), h and l words apart
 template <int NCLS>
 __device__ __forceinline__ void lane_payload(const float (&P)[4], uint32_t &h, uint32_t &l) {
@@ -545,11 +602,42 @@ __device__ __forceinline__ void stats_item(const StepParams &p, int item, int la
     mask_ahead<DT>(mt, ma);
     allows_any = as_const(p.mask_any)[(int64_t)mi * nch + c];
   }
+  uint64_t X = 0;  // kMaskRaw: this lane's 64 allowed bits (their words travel with the chunk's loads)
+  if constexpr (MASK == kMaskRaw) X = lane_mask_bits<DT>(p.mask_bits + (int64_t)mi * p.mask_bits_ld, e_base, V, lane);
   const float Nc = exp_n(chunk_max(x));
   uint32_t pA, pB, rA[4], rB[4];
   float Nm = Nc;
   if constexpr (MASK == kMaskBits) {
     chunk_reduce_bits<DT, SCALED, EXPC>(x, Nc, nv_valid, mt, ma, allows_any, lane, rowp, e_base, V, p.scale, pA, pB, rA, rB, Nm);
+  } else if constexpr (MASK == kMaskRaw) {
+    // chunk_reduce_bits on per-lane bits: both sums on the chunk's scale; a chunk that allows something but whose allowed
+    // sum comes out below 2^32 sums its allowed values again on their own maximum's scale
+    float P[4], Pm[4];
+    class_partials_raw<DT, EXPC>(x, term_bias<EXPC>(Nc), nv_valid, X, P, Pm);
+    uint32_t h, l, hm, lm;
+    lane_payload<4>(P, h, l);
+    lane_payload<4>(Pm, hm, lm);
+    pA = last_lane(wave_sum_u32_l63(h));
+    pB = last_lane(wave_sum_u32_l63(l));
+    row_sums_u32(hm, rA);
+    row_sums_u32(lm, rB);
+    const uint64_t Sm = ((uint64_t)(rA[0] + rA[1] + rA[2] + rA[3]) << kGridHi) + (rB[0] + rB[1] + rB[2] + rB[3]);
+    const uint64_t votes = __ballot(X != 0ull);
+    uint32_t top = (uint32_t)(Sm >> kLowMassBits), any = (uint32_t)votes | (uint32_t)(votes >> 32);
+    opaque_u32(top);
+    opaque_u32(any);
+    if (top == 0u && any != 0u) {
+      float y[64];  // (loaded once more, as chunk_reduce_bits does: x is not kept alive for this rare branch)
+      load_chunk<DT, SCALED>(rowp, e_base, V, lane, p.scale, y);
+      float mm = kNegInf;
+#pragma unroll
+      for (int j = 0; j < 64; ++j) mm = fmaxf(mm, ((X >> j) & 1ull) ? y[j] : kNegInf);
+      Nm = exp_n(wave_max(mm));
+      class_partials_raw<DT, EXPC, true>(y, term_bias<EXPC>(Nm), nv_valid, X, P, Pm);
+      lane_payload<4>(Pm, hm, lm);
+      row_sums_u32(hm, rA);
+      row_sums_u32(lm, rB);
+    }
   } else {
     float P[4], Pm[4];
     uint32_t h, l;
@@ -1069,6 +1157,12 @@ __device__ __forceinline__ void finish_draw(const StepParams &p, int pidx, int l
 #pragma unroll
         for (int k = 0; k < EPV; ++k)
           if (!((mw[2 * k] >> (sl & 31)) & 1u)) y[j * EPV + k] = kNegInf;
+      } else if constexpr (MASK == kMaskRaw) {  // the caller's bit row: the vector's EPV bits sit in one word
+        const int wi = e0 >> 5;
+        const uint32_t wbits = wi < ((V + 31) >> 5) ? (p.mask_bits + (int64_t)mi * p.mask_bits_ld)[wi] : 0u;
+#pragma unroll
+        for (int k = 0; k < EPV; ++k)
+          if (!((wbits >> ((e0 & 31) + k)) & 1u)) y[j * EPV + k] = kNegInf;
       } else if constexpr (MASK == kMaskF32) {
         const char *mrow = (const char *)(p.mask_f + (int64_t)mi * p.mask_ld);
 #pragma unroll

@@ -93,6 +93,7 @@ static hipError_t fused0(const StepParams &p, int mask_kind, int mode, bool scal
     case kMaskNone: return fused1<kMaskNone, EXPC>(p, mode, scaled, s);
     case kMaskBits: return fused1<kMaskBits, EXPC>(p, mode, scaled, s);
     case kMaskF32: return fused1<kMaskF32, EXPC>(p, mode, scaled, s);
+    case kMaskRaw: return fused1<kMaskRaw, EXPC>(p, mode, scaled, s);  // (the one-launch step only: glb_chunk.hpp)
   }
   return hipErrorInvalidValue;
 }
