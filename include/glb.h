@@ -46,7 +46,10 @@ enum { GLB_F32 = 0, GLB_BF16 = 1, GLB_F16 = 2 };
 enum {
   GLB_MASK_NONE = 0, /* no mask: logZ == 0 up to rounding, sample from the full distribution      */
   GLB_MASK_BITS = 1, /* table [n_masks, mask_ld] of uint32 words, bit j%32 of word j/32 == 1 ⇔
-                        token j allowed (log-mask 0), 0 ⇔ forbidden (log-mask -inf)                */
+                        token j allowed (log-mask 0), 0 ⇔ forbidden (log-mask -inf).  The one-launch step
+                        reads these rows as they are (every lane the words that hold its elements' bits:
+                        what a grammar that changes every particle's mask every step hands over); the
+                        two-launch forms bring them into GLB_MASK_PREPARED's layout in the workspace first */
   GLB_MASK_F32 = 2,  /* table [n_masks, mask_ld] of float additive log-masks (any value, -inf ok) */
   GLB_MASK_PREPARED = 3 /* bit masks already brought into the kernels' layout by glb_mask_prepare (same
                         meaning as GLB_MASK_BITS; saves one small launch per call for masks that are
@@ -615,7 +618,9 @@ int glb_mt19937_jump_host(const uint32_t *window_in, const uint64_t *poly, uint3
  * `window`); row_slot[i] < 0: a row of ones (a particle that draws nothing this step); row_slot null: identity.  Then
  * window_out (nullable; may be `window` itself) = the position after *n_draw rows (n_draw: device scalar <= max_draw_rows,
  * null: max_draw_rows) - the stream moves on by what was consumed, decided on the device.  Three launches, no host
- * synchronisation.  All pointers device pointers.
+ * synchronisation.  All pointers device pointers.  When the output rows take at most half of the stream's rows (a rank of a
+ * sharded population that enters ONE global stream: n_out_rows of max_draw_rows), only the windows some output row - or
+ * window_out - reads are made (a word per row in the workspace says which).
  */
 typedef struct glb_mt_rows_args {
   uint32_t struct_size;
