@@ -662,6 +662,8 @@ class TrieWorkload:
         self.sel = torch.from_numpy(rs.choice(len(self.trie), 4096, replace=False).astype(np.int32)).to(dev)
         if out == "selected":  # one selection asked for again and again: its sub-forest is planned once, up front (host work)
             self.trie.prepare_selection(self.sel)
+            sp = self.trie.selection_plan(self.sel, sweep=True) if B >= self.trie.SWEEP_MIN_ROWS else None
+            self.plan = sp or self.trie.selection_plan(self.sel) or self.plan  # (the plan the timed call runs on)
         # a selection per row: the children (<= 256) of the row's current node - one of the root's children, or the root itself
         d1 = sorted(self.trie.children[self.trie.root].values())
         cur = [self.trie.root] * B if out == "rowsel-root" else [d1[int(k)] for k in rs.integers(0, len(d1), B)]

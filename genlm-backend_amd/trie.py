@@ -422,19 +422,22 @@ class TokenByteTrie:
         changes every step (the children of each particle's current node) belongs to the per-row form (`nodes` [B, K]),
         whose need mask is made on the device.  Returns True when a pruned plan is in place (False: the selection reaches
         the root or covers half the trie - the whole trie's plan serves it)."""
-        return self.selection_plan(nodes, build=True) is not None
+        got = self.selection_plan(nodes, build=True) is not None
+        if got and self.sweep:  # big batches read the rows front to back: the sub-forest's sweep plan beside the gathered one
+            self.selection_plan(nodes, build=True, sweep=True)
+        return got
 
-    def selection_plan(self, nodes, build=False):
+    def selection_plan(self, nodes, build=False, sweep=False):
         """The plan of the sub-forest a selection of nodes needs (`_build_plan`), on the device, cached per selection tensor
         (its storage and version).  None: use the whole trie's plan (the selection reaches the root, has no plan, or - unless
         `build` - was never prepared: `prepare_selection`).  Ids outside the trie (negative: "none", as the kernel reads
         them) select nothing."""
-        key = (nodes.data_ptr(), nodes._version, nodes.numel())
+        key = (nodes.data_ptr(), nodes._version, nodes.numel(), bool(sweep))
         ent = self._sel_plans.get(key)
         if ent is None and not build:
             return None
         if ent is None:
-            if len(self._sel_plans) >= 8:
+            if len(self._sel_plans) >= 16:
                 self._sel_plans.pop(next(iter(self._sel_plans)))
             c = self.compact()
             kids, size, root = self._tree()
@@ -452,7 +455,7 @@ class TokenByteTrie:
                 lo_bound = int(s_) - int(size[s_])
             pl = None
             if sum(int(size[r]) for r in roots) < 0.5 * int(c["n_nodes"]) and root not in roots:
-                host = self._build_plan(self.PLAN_CAP, roots)
+                host = self._build_plan(self.sweep_cap() if sweep else self.PLAN_CAP, roots, sweep=sweep)
                 if host is not None:
                     dev = self.engine.device
                     signed = {np.dtype(np.uint16): np.int16, np.dtype(np.uint32): np.int32, np.dtype(np.uint64): np.int64}
@@ -595,7 +598,11 @@ class TokenByteTrie:
                 pl = self.plan_device_arrays()
         if pl is not None and nodes is not None and nodes.dim() == 1 and layout == "rows" and self.prune_selection:
             # only the subtrees below the selected nodes are read and reduced (a plan of that sub-forest, cached per selection)
-            pl = self.selection_plan(nodes, build=self.prune_selection is True) or pl
+            # (SWEEP_MIN_ROWS rows and more: the sub-forest's sweep plan - persistent workgroups read every row front to back
+            # once, where the gathered plan's parts each touch most of a row's sectors for their tokens)
+            want_sweep = self.sweep and logits.shape[0] >= self.SWEEP_MIN_ROWS
+            pl = ((self.selection_plan(nodes, build=self.prune_selection is True, sweep=True) if want_sweep else None)
+                  or self.selection_plan(nodes, build=self.prune_selection is True) or pl)
         if pl is not None:
             got = self._trie_rows(logits, pl, op, True, lse=lse, logit_scale=logit_scale, nodes=nodes,
                                   layout="slots" if layout == "slot_rows" and nodes is None else "rows")
