@@ -572,7 +572,9 @@ __device__ __forceinline__ void stats_item(const StepParams &p, int item, int la
   constexpr int EPV = ElemTraits<DT>::EPV, ES = ElemTraits<DT>::ES, NVC = ElemTraits<DT>::NVC;
   const int nch = p.nch;
   GLB_DIAG(const uint64_t stamp0 = GLB_NOW();)
-  int pr = item / nch, c = item - pr * nch;  // (dealt chunk-major instead - every row's chunk 0, then every row's chunk 1, ... - the launch is 2.5 us slower)
+  // (the quotient of two scalars comes out of the vector unit's reciprocal: told to be a scalar, or it - and the row's and the
+  // record's addresses made from it - live in vector registers for the whole wave)
+  int pr = __builtin_amdgcn_readfirstlane(item / nch), c = item - pr * nch;  // (dealt chunk-major instead - every row's chunk 0, then every row's chunk 1, ... - the launch is 2.5 us slower)
   GLB_DIAG(
     if (p.diag.short_last) {
       const int nfull = nch - 1, split = p.n_pairs * nfull;
@@ -658,7 +660,11 @@ __device__ __forceinline__ void stats_item(const StepParams &p, int item, int la
       row_sums_u32(l, rB);
     }
   }
-  store_rec(p.recs + ((int64_t)pr * nch + c) * kRecWords, p.epoch, lane, Nc, Nm, pA, pB, rA, rB);
+  // (the record's address is made here, from scalars the compiler cannot see through: hoisted to the top of the wave, a
+  // lane's 64-bit address is two registers held - or spilled: the raw-mask kernel did - across the whole reduction)
+  int pr_s = __builtin_amdgcn_readfirstlane(pr), c_s = __builtin_amdgcn_readfirstlane(c);
+  asm volatile("" : "+s"(pr_s), "+s"(c_s));
+  store_rec(p.recs + ((int64_t)pr_s * nch + c_s) * kRecWords, p.epoch, lane, Nc, Nm, pA, pB, rA, rB);
   GLB_DIAG(
     if (lane == 0) {
       uint64_t *r = p.recs + ((int64_t)pr * nch + c) * kRecWords;
