@@ -553,8 +553,9 @@ def main():
                           "stream the rows chunk by chunk, finishing waves at the end of the grid fold the tagged records "
                           "and draw); the few calls too small for it (one shared row: SIS step 0) run "
                           "glb::chunk_stats_small_kernel + glb::finish_kernel and are timed first start to last stop"
-                          + ("; with one raw bit mask per particle the call's glb::mask_prepare_kernel launch comes first and is "
-                             "inside the span" if args.per_row_masks else "")),
+                          + ("; one raw bit mask per particle: the stats waves of that launch read the caller's bit rows themselves "
+                             "(no glb::mask_prepare_kernel launch; the parity draw's two-launch form still prepares them, inside "
+                             "the span)" if args.per_row_masks else "")),
                 "timing": getattr(runner, "roofline_timing", None) or (
                           "every fused call of the timed region, none left out: HIP events carried by the launch itself as "
                           "its start / stop stamps (hipExtLaunchKernel through glb_logprob_mask_sample_timed) = the launch "
@@ -782,7 +783,7 @@ class KernelWorkload:
             self.own_id = torch.arange(B, dtype=torch.int32, device=dev)
             self.plans = [eng.step_plan(x, mask=self.masks, mask_id=self.own_id, particle_base=rank * B, out=self.out, **draw)
                           for x in self.bufs]
-        elif per_row_masks:  # raw bit rows, one per particle (mask ids = identity): every call prepares them itself
+        elif per_row_masks:  # raw bit rows, one per particle (mask ids = identity): the fused launch reads them as they are
             self.plans = [eng.step_plan(x, mask_kind=1, mask=self.bits, particle_base=rank * B, out=self.out, **draw)
                           for x in self.bufs]
         else:
@@ -853,8 +854,9 @@ class KernelWorkload:
     def config(self):
         shape = "512 particles x Llama vocab 128256, bf16 logits [512,128256]" if self.llama else \
             "1024 particles x gpt2 vocab 50257, fp32 logits [1024,50257]"
-        masks = (f"{self.B} bit masks, one per particle (GLB_MASK_BITS, handed over raw: the call's own mask_prepare launch is "
-                 "inside the timed launch span)") if self.per_row_masks else "2 shared bit masks (prepared once)"
+        masks = (f"{self.B} bit masks, one per particle (GLB_MASK_BITS, handed over raw: read by the fused launch's stats waves "
+                 "as they are; the parity draw's two-launch form prepares them first, inside the timed span)") \
+            if self.per_row_masks else "2 shared bit masks (prepared once)"
         if self.incremental:
             masks = (f"{self.B} bit masks, one per particle, prepared once; {self.n_changed} of them ({self.churn:.0%}) change and are "
                      "prepared again before every call (glb_mask_prepare_rows, inside the timed span)")

@@ -275,6 +275,39 @@ __device__ __forceinline__ void store_rec(uint64_t *dst, uint32_t epoch, int lan
     __hip_atomic_store(dst + lane, ((uint64_t)epoch << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// the same record from the lanes that hold its words already.  F1 / F2: wave scans of the all-element words (lane 63 =
+// pA / pB); R1 / R2: row scans of the allowed-element words (lanes 15, 31, 47, 63 = rA[0..3] / rB[0..3]).  Five DPP moves
+// gather the twelve words in one register - R1's where they are, R2's one lane to the left (row_shl:1 writes lanes 0..14
+// of a row, :2 lanes 0..13, ...: each move leaves the words already placed alone), pB / pA in lanes 61 / 60, Nm / Nc in
+// 59 / 58 - and each of those twelve lanes stores its granule.  (Through scalar registers - eight v_readlane, then a
+// compare, a move and a select per granule - the record cost the wave 50 vector instructions of its ~530.)
+__device__ __forceinline__ void store_rec_lanes(uint64_t *dst, uint32_t epoch, int lane, float Nc, float Nm, uint32_t F1,
+                                                uint32_t F2, uint32_t R1, uint32_t R2) {
+  uint32_t v = R1;
+  v = dpp_u32<0x101, 0xf>(v, R2);
+  v = dpp_u32<0x102, 0xf>(v, F2);
+  v = dpp_u32<0x103, 0xf>(v, F1);
+  v = dpp_u32<0x104, 0xf>(v, __float_as_uint(Nm));
+  v = dpp_u32<0x105, 0xf>(v, __float_as_uint(Nc));
+  // granule of the lane: 58 -> 0 (Nc), 59 -> 1 (Nm), 60 -> 2 (pA), 61 -> 3 (pB), 16 r + 15 -> 4 + r, 16 r + 14 -> 8 + r
+  const int t = lane & 15, hi = lane >> 4;
+  const int slot = t >= 14 ? 4 + hi + ((15 - t) << 2) : t - 10;
+  const uint32_t off = (uint32_t)slot << 3;
+  const uint64_t val = ((uint64_t)epoch << 32) | v;
+  uint64_t saved, keep = 0xFC00C000C000C000ull;
+  // the twelve lanes store under an EXEC set from a constant, off a scalar base (agent-scope relaxed store: sc1, as
+  // __hip_atomic_store makes it).  s_nop 3: with the two scalar instructions before it, the five wait states a VMEM read
+  // of an SGPR needs after a VALU write of it (v_readfirstlane) - the compiler does not look inside an asm block
+  asm volatile("s_mov_b64 %0, exec\n\t"
+               "s_and_b64 exec, %0, %4\n\t"
+               "s_nop 3\n\t"
+               "global_store_dwordx2 %1, %2, %3 sc1\n\t"
+               "s_mov_b64 exec, %0"
+               : "=&s"(saved)
+               : "v"(off), "v"(val), "s"(dst), "s"(keep)
+               : "memory", "scc");
+}
+
 // one record in; true when every granule carries `epoch`.  COHERENT: agent-scope loads (past the L1: the stats waves of
 // this very launch may still be writing); otherwise plain loads - records of an earlier launch, and when a thousand
 // particles share one row (SIS step 0) the CU's L1 serves all but the first sweep.
@@ -397,37 +430,44 @@ __device__ __forceinline__ void class_partials(const float (&x)[64], float magic
 template <int DT>
 __device__ __forceinline__ uint64_t lane_mask_bits(const uint32_t *brow, int e_base, int V, int lane) {
   constexpr int EPV = ElemTraits<DT>::EPV, NVC = ElemTraits<DT>::NVC;
-  const int n_words = (V + 31) >> 5;
+  const uint32_t last_word = (uint32_t)((V + 31) >> 5) - 1u;
+  // e_base is a multiple of 4096: the vector's word is (e_base >> 5) + i * (2 * EPV) + ((lane * EPV) >> 5), its bits start
+  // at (lane * EPV) & 31 in every one of them.  Words past the row's end are not read (the index is clamped; their bits
+  // are cleared below) - a load under a branch per vector cost the 16-bit launch 8 scalar branches a wave
+  const uint32_t w0 = (uint32_t)(e_base >> 5) + ((uint32_t)(lane * EPV) >> 5), sh = (uint32_t)(lane * EPV) & 31u;
   uint32_t w[NVC];
 #pragma unroll
   for (int i = 0; i < NVC; ++i) {  // (loads first)
-    const int wi = (e_base + (i * 64 + lane) * EPV) >> 5;
-    w[i] = wi < n_words ? brow[wi] : 0u;
+    uint32_t wi = w0 + (uint32_t)(i * 2 * EPV);
+    wi = wi < last_word ? wi : last_word;
+    w[i] = *(const uint32_t *)((const char *)brow + (wi << 2));
   }
   uint64_t X = 0;
+  if (e_base + kChunk <= V) {  // wave-uniform: all but the last chunk of a row
 #pragma unroll
-  for (int i = 0; i < NVC; ++i) {
-    const int e0 = e_base + (i * 64 + lane) * EPV;
-    uint32_t v = (w[i] >> (e0 & 31)) & ((1u << EPV) - 1u);
-    const int valid = V - e0;
-    if (valid < EPV) v &= valid > 0 ? ((1u << valid) - 1u) : 0u;
-    X |= (uint64_t)v << (i * EPV);
+    for (int i = 0; i < NVC; ++i) X |= (uint64_t)((w[i] >> sh) & ((1u << EPV) - 1u)) << (i * EPV);
+  } else {
+#pragma unroll
+    for (int i = 0; i < NVC; ++i) {
+      const int valid = V - (e_base + (i * 64 + lane) * EPV);
+      uint32_t v = (w[i] >> sh) & ((1u << EPV) - 1u);
+      if (valid < EPV) v &= valid > 0 ? ((1u << valid) - 1u) : 0u;
+      X |= (uint64_t)v << (i * EPV);
+    }
   }
   return X;
 }
 
 // class_partials on per-lane bits: P over all elements, Pm over the allowed ones - a term ANDed with 0 / ~0 by its bit
 // (v_bfe_i32: a one-bit field, sign-extended), so a forbidden term enters the allowed sum as +0
-template <int DT, int EXPC, bool ONLY_MASKED = false>
-__device__ __forceinline__ void class_partials_raw(const float (&x)[64], float bias, int nv_valid, uint64_t X, float (&P)[4],
-                                                   float (&Pm)[4]) {
+template <int DT, int EXPC, bool ONLY_MASKED, bool FULL>
+__device__ __forceinline__ void class_partials_raw_body(const float (&x)[64], float bias, int nv_valid, uint64_t X,
+                                                        float (&P)[4], float (&Pm)[4]) {
   constexpr int EPV = ElemTraits<DT>::EPV, NVC = ElemTraits<DT>::NVC;
   const uint32_t Xlo = (uint32_t)X, Xhi = (uint32_t)(X >> 32);
 #pragma unroll
-  for (int w = 0; w < 4; ++w) P[w] = Pm[w] = 0.0f;
-#pragma unroll
   for (int i = 0; i < NVC; ++i) {
-    if (i < nv_valid) {  // wave-uniform: vectors wholly past the row's end would add +0
+    if (FULL || i < nv_valid) {  // wave-uniform: vectors wholly past the row's end would add +0
 #pragma unroll
       for (int k = 0; k < EPV; ++k) {
         const int j = i * EPV + k;  // (compile-time after unrolling)
@@ -438,6 +478,17 @@ __device__ __forceinline__ void class_partials_raw(const float (&x)[64], float b
       }
     }
   }
+}
+
+template <int DT, int EXPC, bool ONLY_MASKED = false>
+__device__ __forceinline__ void class_partials_raw(const float (&x)[64], float bias, int nv_valid, uint64_t X, float (&P)[4],
+                                                   float (&Pm)[4]) {
+#pragma unroll
+  for (int w = 0; w < 4; ++w) P[w] = Pm[w] = 0.0f;
+  if (nv_valid == ElemTraits<DT>::NVC)  // (a full chunk runs as one straight block, as in class_partials)
+    class_partials_raw_body<DT, EXPC, ONLY_MASKED, true>(x, bias, nv_valid, X, P, Pm);
+  else
+    class_partials_raw_body<DT, EXPC, ONLY_MASKED, false>(x, bias, nv_valid, X, P, Pm);
 }
 
 // this lane's payload words: the sum over its NCLS class partials of floor(P * 2^36), h and l words apart
@@ -472,33 +523,35 @@ __device__ __forceinline__ float chunk_max(const float (&x)[64]) {
 template <int DT, bool SCALED, int EXPC>
 __device__ __forceinline__ void chunk_reduce_bits(float (&x)[64], float Nc, int nv_valid, cu64_t mt,
                                                   const MaskAhead &ma, uint64_t allows_any, int lane, const char *rowp,
-                                                  int e_base, int V, float scale, uint32_t &pA, uint32_t &pB,
-                                                  uint32_t (&rA)[4], uint32_t (&rB)[4], float &Nm) {
+                                                  int e_base, int V, float scale, uint32_t &F1, uint32_t &F2,
+                                                  uint32_t &R1, uint32_t &R2, float &Nm) {
   float P[4], Pm[4];
   class_partials<DT, true, 1, EXPC>(x, term_bias<EXPC>(Nc), nv_valid, mt, ma, P, Pm);
   uint32_t h, l, hm, lm;
   lane_payload<4>(P, h, l);
   lane_payload<4>(Pm, hm, lm);
-  pA = last_lane(wave_sum_u32_l63(h));
-  pB = last_lane(wave_sum_u32_l63(l));
-  row_sums_u32(hm, rA);
-  row_sums_u32(lm, rB);
+  F1 = wave_sum_u32_l63(h);
+  F2 = wave_sum_u32_l63(l);
+  R1 = row_scan_u32(hm);
+  R2 = row_scan_u32(lm);
   Nm = Nc;
-  const uint64_t Sm = ((uint64_t)(rA[0] + rA[1] + rA[2] + rA[3]) << kGridHi) + (rB[0] + rB[1] + rB[2] + rB[3]);
+  const uint64_t Sm = ((uint64_t)rows_total(R1) << kGridHi) + rows_total(R2);
   uint32_t top = (uint32_t)(Sm >> kLowMassBits), any = (uint32_t)allows_any;
   opaque_u32(top);
   opaque_u32(any);
   if (top == 0u && any != 0u) {
     float y[64];
-    load_chunk<DT, SCALED>(rowp, e_base, V, lane, scale, y);
+    int lane_again = lane;  // (the lane's address is made again, from a lane id the compiler cannot match with the first:
+    asm volatile("" : "+v"(lane_again));  // not held - or spilled - across the reduction for this rare branch)
+    load_chunk<DT, SCALED>(rowp, e_base, V, lane_again, scale, y);
 #pragma unroll
     for (int j = 0; j < 64; ++j)
       if (!((mt[j] >> lane) & 1ull)) y[j] = kNegInf;
     Nm = exp_n(chunk_max(y));
     class_partials<DT, false, 1, EXPC>(y, term_bias<EXPC>(Nm), nv_valid, nullptr, MaskAhead{}, P, Pm);
     lane_payload<4>(P, hm, lm);
-    row_sums_u32(hm, rA);
-    row_sums_u32(lm, rB);
+    R1 = row_scan_u32(hm);
+    R2 = row_scan_u32(lm);
   }
 }
 
@@ -607,10 +660,10 @@ __device__ __forceinline__ void stats_item(const StepParams &p, int item, int la
   uint64_t X = 0;  // kMaskRaw: this lane's 64 allowed bits (their words travel with the chunk's loads)
   if constexpr (MASK == kMaskRaw) X = lane_mask_bits<DT>(p.mask_bits + (int64_t)mi * p.mask_bits_ld, e_base, V, lane);
   const float Nc = exp_n(chunk_max(x));
-  uint32_t pA, pB, rA[4], rB[4];
+  uint32_t F1, F2, R1, R2;  // the record's words as the scans leave them in the lanes (store_rec_lanes)
   float Nm = Nc;
   if constexpr (MASK == kMaskBits) {
-    chunk_reduce_bits<DT, SCALED, EXPC>(x, Nc, nv_valid, mt, ma, allows_any, lane, rowp, e_base, V, p.scale, pA, pB, rA, rB, Nm);
+    chunk_reduce_bits<DT, SCALED, EXPC>(x, Nc, nv_valid, mt, ma, allows_any, lane, rowp, e_base, V, p.scale, F1, F2, R1, R2, Nm);
   } else if constexpr (MASK == kMaskRaw) {
     // chunk_reduce_bits on per-lane bits: both sums on the chunk's scale; a chunk that allows something but whose allowed
     // sum comes out below 2^32 sums its allowed values again on their own maximum's scale
@@ -619,36 +672,38 @@ __device__ __forceinline__ void stats_item(const StepParams &p, int item, int la
     uint32_t h, l, hm, lm;
     lane_payload<4>(P, h, l);
     lane_payload<4>(Pm, hm, lm);
-    pA = last_lane(wave_sum_u32_l63(h));
-    pB = last_lane(wave_sum_u32_l63(l));
-    row_sums_u32(hm, rA);
-    row_sums_u32(lm, rB);
-    const uint64_t Sm = ((uint64_t)(rA[0] + rA[1] + rA[2] + rA[3]) << kGridHi) + (rB[0] + rB[1] + rB[2] + rB[3]);
+    F1 = wave_sum_u32_l63(h);
+    F2 = wave_sum_u32_l63(l);
+    R1 = row_scan_u32(hm);
+    R2 = row_scan_u32(lm);
+    const uint64_t Sm = ((uint64_t)rows_total(R1) << kGridHi) + rows_total(R2);
     const uint64_t votes = __ballot(X != 0ull);
     uint32_t top = (uint32_t)(Sm >> kLowMassBits), any = (uint32_t)votes | (uint32_t)(votes >> 32);
     opaque_u32(top);
     opaque_u32(any);
     if (top == 0u && any != 0u) {
-      float y[64];  // (loaded once more, as chunk_reduce_bits does: x is not kept alive for this rare branch)
-      load_chunk<DT, SCALED>(rowp, e_base, V, lane, p.scale, y);
+      float y[64];  // (loaded once more, as chunk_reduce_bits does: x is not kept alive for this rare branch - and neither
+      int lane_again = lane;  // is the lane's address: made again from a lane id the compiler cannot match with the first)
+      asm volatile("" : "+v"(lane_again));
+      load_chunk<DT, SCALED>(rowp, e_base, V, lane_again, p.scale, y);
       float mm = kNegInf;
 #pragma unroll
       for (int j = 0; j < 64; ++j) mm = fmaxf(mm, ((X >> j) & 1ull) ? y[j] : kNegInf);
       Nm = exp_n(wave_max(mm));
       class_partials_raw<DT, EXPC, true>(y, term_bias<EXPC>(Nm), nv_valid, X, P, Pm);
       lane_payload<4>(Pm, hm, lm);
-      row_sums_u32(hm, rA);
-      row_sums_u32(lm, rB);
+      R1 = row_scan_u32(hm);
+      R2 = row_scan_u32(lm);
     }
   } else {
     float P[4], Pm[4];
     uint32_t h, l;
     class_partials<DT, false, 1, EXPC>(x, term_bias<EXPC>(Nc), nv_valid, nullptr, ma, P, Pm);
     lane_payload<4>(P, h, l);
-    row_sums_u32(h, rA);
-    row_sums_u32(l, rB);
-    pA = rA[0] + rA[1] + rA[2] + rA[3];
-    pB = rB[0] + rB[1] + rB[2] + rB[3];
+    R1 = row_scan_u32(h);
+    R2 = row_scan_u32(l);
+    F1 = rows_scan_to_wave(R1);  // (pA / pB: the row scans taken on to lane 63)
+    F2 = rows_scan_to_wave(R2);
     if constexpr (MASK == kMaskF32) {  // general additive masks: y = x + m has its own maximum, scale and exp
       const char *mrow = (const char *)(p.mask_f + (int64_t)mi * p.mask_ld);
       float y[64];
@@ -656,15 +711,18 @@ __device__ __forceinline__ void stats_item(const StepParams &p, int item, int la
       Nm = exp_n(chunk_max(y));
       class_partials<DT, false, 1, EXPC>(y, term_bias<EXPC>(Nm), nv_valid, nullptr, ma, P, Pm);
       lane_payload<4>(P, h, l);
-      row_sums_u32(h, rA);
-      row_sums_u32(l, rB);
+      R1 = row_scan_u32(h);
+      R2 = row_scan_u32(l);
     }
   }
   // (the record's address is made here, from scalars the compiler cannot see through: hoisted to the top of the wave, a
   // lane's 64-bit address is two registers held - or spilled: the raw-mask kernel did - across the whole reduction)
   int pr_s = __builtin_amdgcn_readfirstlane(pr), c_s = __builtin_amdgcn_readfirstlane(c);
-  asm volatile("" : "+s"(pr_s), "+s"(c_s));
-  store_rec(p.recs + ((int64_t)pr_s * nch + c_s) * kRecWords, p.epoch, lane, Nc, Nm, pA, pB, rA, rB);
+  int lane_s = lane;
+  asm volatile("" : "+s"(pr_s), "+s"(c_s), "+v"(lane_s));
+  int rec = pr_s * nch + c_s;  // (< 2^31: a record is 128 bytes; as one scalar, so that its address is made by the scalar unit)
+  asm volatile("" : "+s"(rec));
+  store_rec_lanes(p.recs + (int64_t)rec * kRecWords, p.epoch, lane_s, Nc, Nm, F1, F2, R1, R2);
   GLB_DIAG(
     if (lane == 0) {
       uint64_t *r = p.recs + ((int64_t)pr * nch + c) * kRecWords;

@@ -156,21 +156,27 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane) {
 // wave total, broadcast to every lane (wave-uniform value)
 __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) { return readlane_u64(wave_scan_u64(v), 63); }
 
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_max_step(float v) {
-  const uint32_t ninf = 0xff800000u;
-  const float o = __uint_as_float(dpp_u32<CTRL, ROW_MASK>(ninf, __float_as_uint(v)));
-  return fmaxf(v, o);
-}
-
-// wave maximum, broadcast to every lane
+// wave maximum, broadcast to every lane.  One v_max_f32 with a DPP operand per step (a lane without a source keeps its
+// value); written out because fmaxf() on a DPP move costs four instructions a step - the move, its -inf filler and a
+// canonicalising max of either operand.  The input is canonicalised once (a signalling NaN would otherwise come out of
+// v_max_f32 as a quiet NaN instead of being ignored), every later value is a v_max_f32 result.  s_nop 1: the two wait
+// states a DPP read needs after the VALU write of its source (the compiler does not look inside an asm block).
 __device__ __forceinline__ float wave_max(float v) {
-  v = dpp_max_step<0x111, 0xf>(v);
-  v = dpp_max_step<0x112, 0xf>(v);
-  v = dpp_max_step<0x114, 0xf>(v);
-  v = dpp_max_step<0x118, 0xf>(v);
-  v = dpp_max_step<0x142, 0xa>(v);
-  v = dpp_max_step<0x143, 0xc>(v);
+  v = __builtin_canonicalizef(v);
+  asm("s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 0"
+      : "+v"(v));
   return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
 }
 
@@ -291,6 +297,28 @@ __device__ __forceinline__ uint32_t wave_sum_u32_l63(uint32_t v) {
   v += dpp_u32<0x142, 0xa>(0u, v);
   v += dpp_u32<0x143, 0xc>(0u, v);
   return v;
+}
+
+// the first four steps of the DPP scan: inclusive sums within each 16-lane row (lanes 15, 31, 47, 63 = the rows' totals)
+__device__ __forceinline__ uint32_t row_scan_u32(uint32_t v) {
+  v += dpp_u32<0x111, 0xf>(0u, v);
+  v += dpp_u32<0x112, 0xf>(0u, v);
+  v += dpp_u32<0x114, 0xf>(0u, v);
+  v += dpp_u32<0x118, 0xf>(0u, v);
+  return v;
+}
+
+// its last two: a row scan taken on to the wave scan (lane 63 = the wave's total)
+__device__ __forceinline__ uint32_t rows_scan_to_wave(uint32_t v) {
+  v += dpp_u32<0x142, 0xa>(0u, v);
+  v += dpp_u32<0x143, 0xc>(0u, v);
+  return v;
+}
+
+// the four rows' totals of a row scan, added (wave-uniform)
+__device__ __forceinline__ uint32_t rows_total(uint32_t rs) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)rs, 15) + (uint32_t)__builtin_amdgcn_readlane((int)rs, 31) +
+         (uint32_t)__builtin_amdgcn_readlane((int)rs, 47) + (uint32_t)__builtin_amdgcn_readlane((int)rs, 63);
 }
 
 // sums of v over the four 16-lane rows of the wave (wave-uniform results): the first four steps of the DPP scan leave

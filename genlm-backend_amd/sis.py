@@ -19,6 +19,7 @@ import os
 import numpy as np
 import torch
 
+from ._lib import MASK_BITS
 from .cache import KVPrefix
 
 RNG_PHILOX, RNG_NOISE = 1, 2
@@ -271,7 +272,9 @@ class DeviceSIS:
         if self.particle_kv:
             assert not use_prefix_kv
         self.particle_masks = particle_masks
-        self._pm_prepared, self._pm_dirty = None, None
+        self._pm_prepared, self._pm_dirty, self._pm_seen, self._pm_moved = None, None, None, False
+        self.pm_raw_above = None  # fraction of changed rows above which a step hands the bit rows over raw (None: by dtype)
+        self.pm_raw_steps = 0
         self.rows_moved = 0  # particles that changed ranks in the last resampling step (over all ranks)
         self.resample_ess = resample_ess
         self.n_resamples = 0
@@ -299,7 +302,7 @@ class DeviceSIS:
     def reset(self):
         if self.noise_src is not None:  # a run starts its seeded noise stream over
             self.noise_src.reset()
-        self._pm_prepared, self._pm_dirty = None, None  # (a new run may come with new masks: prepared again at its first step)
+        self._pm_prepared, self._pm_dirty, self._pm_seen, self._pm_moved = None, None, None, False  # (a new run may come with new masks)
         self.contexts = self._ctx0.clone()
         self.prompt_len = self._prompt_len0.clone()
         self.lengths = self.prompt_len.clone()
@@ -471,20 +474,36 @@ class DeviceSIS:
         mask_id = ((self.lengths - self.prompt_len) >= self.max_tokens).to(torch.int32)
         kw = llm.step_masks(logits.dtype) if self.particle_masks is None else {}
         if self.particle_masks is not None:  # one mask per particle: per-particle ids, no dedup of the math
-            # the bit rows are brought into the kernels' layout once; afterwards only the rows `update_particle_masks` named
-            # are prepared again (a grammar moves a few particles' masks a step: glb_mask_prepare_rows)
-            # The prepared form is valid for exactly the tensor state it was made from: `particle_masks` rebound to another
-            # tensor, or written in place by anyone but `update_particle_masks` (its version counter moves), is prepared
-            # again as a whole - a caller that edits the bit rows directly gets correct draws, just not the incremental path.
+            # Two ways to hand the bit rows over.  RAW: the fused launch's stats waves read the caller's rows themselves
+            # (kMaskRaw: + 2 us a step on float32 rows, + 5 us on 16-bit ones, nothing to prepare).  PREPARED: the rows
+            # transposed into the kernels' layout (glb_mask_prepare: 11 us for 1025 rows of 50257), afterwards only the rows
+            # `update_particle_masks` named again (glb_mask_prepare_rows).  A grammar that moves every particle's mask every
+            # token is served raw; masks that stand still, or of which a few move a step, prepared.  A step goes raw
+            #  * when more than `pm_raw_above` of the rows changed since the prepared form was last brought up to date and
+            #    some did since the last step (their names are kept: a step before which nothing moved brings it up to date);
+            #  * when the tensor is in a state this object has not seen - rebound, or written in place by anyone but
+            #    `update_particle_masks` (its version counter moves); seen twice in a row, that state is prepared.
+            # The parity draw is two launches (no raw form): always prepared.
             own = torch.arange(N, dtype=torch.int32, device=self.dev)
             pm = self.particle_masks
+            ids = torch.where(mask_id > 0, torch.full_like(own, N), own)
             state = (pm.data_ptr(), pm._version, logits.dtype)
+            frac = self.pm_raw_above if self.pm_raw_above is not None else (0.25 if logits.dtype == torch.float32 else 0.5)
+            raw = False
             if self._pm_prepared is None or self._pm_prepared[1] != state:
-                self._pm_prepared = (eng.prepare_masks(pm, V, logits.dtype), state)
+                if self.rng_mode != RNG_NOISE and frac < 1.0 and self._pm_seen != state:
+                    raw, self._pm_prepared, self._pm_dirty = True, None, None
+                else:
+                    self._pm_prepared, self._pm_dirty = (eng.prepare_masks(pm, V, logits.dtype), state), None
             elif self._pm_dirty is not None:
-                eng.update_prepared_masks(self._pm_prepared[0], pm, self._pm_dirty)
-            self._pm_dirty = None
-            kw = dict(mask=self._pm_prepared[0], mask_id=torch.where(mask_id > 0, torch.full_like(own, N), own))
+                if self.rng_mode != RNG_NOISE and self._pm_moved and self._pm_dirty.numel() > frac * N:
+                    raw = True  # (the prepared form stays behind by the rows named in _pm_dirty, until the masks stand still)
+                else:
+                    eng.update_prepared_masks(self._pm_prepared[0], pm, self._pm_dirty)
+                    self._pm_dirty = None
+            self._pm_seen, self._pm_moved = state, False
+            self.pm_raw_steps += int(raw)
+            kw = dict(mask_kind=MASK_BITS, mask=pm, mask_id=ids) if raw else dict(mask=self._pm_prepared[0], mask_id=ids)
         elif kw:
             # The mask depends on the number of generated tokens only; with prompts of one length that makes it a
             # function of the context, so identical contexts (one logits row) share it: ids go per ROW and a shared
@@ -535,6 +554,7 @@ class DeviceSIS:
         if known:  # the prepared form follows this write row by row; any other write makes the next step prepare everything
             self._pm_prepared = (self._pm_prepared[0], (pm.data_ptr(), pm._version, self._pm_prepared[1][2]))
             self._pm_dirty = rows if self._pm_dirty is None else torch.unique(torch.cat([self._pm_dirty, rows]))
+            self._pm_moved = True
 
     def _exchange(self):
         """All-gather of the per-shard log-weights and active counts (RCCL over xGMI when the backend is nccl): every
@@ -987,7 +1007,7 @@ class SisBenchWorkload:
 
     def config(self):
         return {"workload": f"SIS step: {self.N} particles/GPU, {self.model_name}, prompt len 8, <=10 new "
-                            "tokens, " + (f"{self.N} per-particle bit masks handed over raw every step" if self.per_particle_masks
+                            "tokens, " + (f"{self.N} per-particle bit masks (standing still: handed over raw at the first step, prepared from the second on)" if self.per_particle_masks
                                           else "2 shared bit masks") + ", device-resident population, "
                             + ("Philox draws" if self.rng == "philox" else "the reference's draws (torch.multinomial's CPU MT19937 stream, "
                                "generated on the device: ids identical to torch's under the seed)")

@@ -232,6 +232,60 @@ def test_device_sis_per_particle_masks_follow_in_place_edits_on_gpu(llm):
     assert [list(map(int, c)) for c in ctx] == want
 
 
+def test_device_sis_per_particle_masks_raw_or_prepared_same_run_on_gpu(llm):
+    """Round 6: a step hands the per-particle bit rows over RAW (the fused launch reads them itself) when the tensor is in a
+    state not seen before or more than `pm_raw_above` of its rows changed since the prepared form was last brought up to date,
+    and PREPARED otherwise (the rows named since are prepared again, all of them - the prepared form may lag several steps,
+    until one passes in which no mask moved).
+    Whatever the mix, the run is the run of the always-prepared form: same contexts, same weights (600 particles: more than
+    512 (unit, chunk) items, so the raw steps do take the one-launch form)."""
+    from genlm_backend_amd.sis import DeviceSIS
+
+    m, gold = llm
+    masks = torch.from_numpy(gold["sis_masks"])
+    m.register_masks(masks)
+    prompt = [int(t) for t in gold["sis_prompt"]]
+    dev, V, N = m.device, masks.shape[1], 600
+    g = torch.Generator(device="cpu")
+    g.manual_seed(5)
+
+    def rows(n):
+        f = torch.where(torch.rand((n, V), generator=g) < 0.5, float("-inf"), 0.0)
+        f[:, 1:4] = 0.0  # (something other than EOS is always allowed)
+        return m.engine.mask_to_bits(f.to(dev))[0]
+
+    eos_only, _ = m.engine.mask_to_bits(masks[1:2].to(dev))
+    pm0 = torch.cat([rows(N), eos_only]).contiguous()
+    script = [None, None, ("few", 40), ("many", 400), ("few", 30), None, ("all", N), ("few", 10)]
+    edits = []
+    for e in script:
+        if e is None:
+            edits.append(None)
+        else:
+            idx = torch.randperm(N, generator=g)[:e[1]].to(torch.int32)
+            edits.append((idx.to(dev), rows(e[1])))
+    runs = []
+    for above in (None, 1.0):
+        sis = DeviceSIS(m, N, prompt, max_tokens=len(script), eos_id=0, seed=77, particle_masks=pm0.clone())
+        sis.pm_raw_above = above
+        kinds = []
+        for e in edits:
+            if e is not None:
+                sis.update_particle_masks(*e)
+            before = sis.pm_raw_steps
+            sis.step()
+            kinds.append(sis.pm_raw_steps > before)
+        ctx, lw = sis.results()
+        runs.append(([list(map(int, c)) for c in ctx], lw, kinds))
+    # first sight of the tensor raw, the second prepared; 40 of 600 changed: those rows prepared again; 400: raw (the prepared
+    # form lags), 30 more: 430 behind - raw; nothing moved: the 430 prepared; all: raw; 10 more: raw (float32: above a quarter)
+    assert runs[0][2] == [True, False, False, True, True, False, True, True]
+    assert runs[1][2] == [False] * len(script)
+    assert runs[0][0] == runs[1][0]
+    assert np.array_equal(runs[0][1], runs[1][1])
+    assert len({tuple(c) for c in runs[0][0]}) > 100  # (the masks do steer the particles apart)
+
+
 def test_device_sis_philox_is_shard_invariant(llm):
     """Sharding the population (particle_base) does not change any particle's draws or weights."""
     from genlm_backend_amd.sis import DeviceSIS

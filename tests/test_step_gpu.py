@@ -649,6 +649,37 @@ def test_one_bit_mask_per_particle_bit_exact(engine, oracle, B, V, dtype):
     engine.check()
 
 
+@pytest.mark.parametrize("B,V", [(520, 1), (520, 31), (520, 33), (520, 4096), (300, 4097), (200, 8191), (180, 12289)])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_raw_masks_read_by_the_fused_launch_at_row_ends(engine, oracle, B, V, dtype):
+    """Raw per-particle bit masks inside the ONE-launch form (more than 512 (unit, chunk) items: the stats waves read the
+    caller's bit rows themselves, kMaskRaw) on rows that end inside a mask word, inside a 16-byte vector, on a chunk's
+    last element and one past it: words past a row's end are never read (the index is clamped), their bits count as
+    forbidden - the oracle's bits."""
+    O = oracle
+    x_np, x_t = _mk(O, B, V, dtype, seed=7 * V + B)
+    dev = engine.device
+    rng = np.random.default_rng(V)
+    masks = np.where(rng.random((B, V)) < 0.4, -np.inf, 0.0).astype(np.float32)
+    masks[1, :] = -np.inf
+    masks[2, :] = -np.inf
+    masks[2, V - 1] = 0.0
+    masks[3, :] = 0.0
+    bits, _ = O.mask_f32_to_bits(masks)
+    want = O.step(x_np, mask_kind=O.MASK_BITS, mask=bits, mask_id=np.arange(B, dtype=np.int32), rng_mode=O.RNG_PHILOX, seed=3,
+                  offset=1)
+    # the bit rows sit at the very end of an allocation: a read past a row's last word would leave it
+    pad = torch.zeros(bits.size + 4096, dtype=torch.int32, device=dev)
+    bits_d = pad[pad.numel() - bits.size:].view(B, -1)
+    bits_d.copy_(_bits_dev(bits, dev))
+    got = engine.step(x_t.to(dev), mask_kind=1, mask=bits_d, rng_mode=1, seed=3, offset=1)
+    torch.cuda.synchronize()
+    for w, g, name in zip(want, got, ("logZ", "lse", "token")):
+        assert np.array_equal(_np(g).view(np.uint32), w.view(np.uint32)), name
+    assert _np(got[2])[1] == -1 and _np(got[2])[2] == V - 1
+    engine.check()
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_masks_prepared_again_only_where_they_changed(engine, oracle, dtype):
     """glb_mask_prepare_rows (round 5): of 96 per-particle masks prepared once, 17 change; preparing only those again gives
