@@ -1315,9 +1315,10 @@ __device__ __forceinline__ void finish_draw(const StepParams &p, int pidx, int l
 // (kSpinTicks).
 // ---------------------------------------------------------------------------------------------------------
 // waves per SIMD the kernels are compiled for.  Float masks hold x[64] and y[64] in the stats role: three leave them
-// the registers.  16-bit rows are bound by VALU issue and gain from a fifth wave (96 registers fit without spills);
-// fp32 rows spill at five and stream as fast with four.  Under the hardware-exponential contract (kExpHw, 16-bit rows)
-// the stream is bound by memory, not issue: four and five waves measure the same, six spill (profiles/r06/ab_contract_*).
+// the registers.  16-bit rows under the polynomial contract are bound by VALU issue and gain from a fifth wave (96
+// registers fit without spills); fp32 rows spill at five and stream as fast with four.  Under the hardware-exponential
+// contract (kExpHw) 16-bit rows are bound by memory, not issue: four and five waves measure the same, six spill
+// (profiles/r06/ab_contract_*), and a tenth fewer vector instructions a wave change nothing (ab_libs_valu_v5.log).
 template <int DT, int MASK>
 struct StatsWaves {
   static constexpr int value = MASK == kMaskF32 ? 3 : (DT == kDtF32 ? 4 : GLB_STATS_WAVES_16);
@@ -1329,7 +1330,10 @@ struct StatsWaves {
 // - 28.7 us; and VERDICT r5 #7's proposal, the stats wave making the in-chunk draw itself for units of one particle and
 // leaving the token in a thirteenth granule (commit 42bad02: bit-exact, the finishing wave 1.7 us shorter - and the launch
 // 4.4 us LONGER at 1024 x 50257 fp32, 5.7 us at 512 x 128256 bf16: every stats wave lives a Philox block, two scans and
-// sixteen terms longer, and the stream is bound by how many waves have loads in flight); EXPERIMENTS.md.)
+// sixteen terms longer, and the stream is bound by how many waves have loads in flight); EXPERIMENTS.md.
+// Kept at the end of the round: the (unit, chunk) quotient as a scalar, the record gathered in the lanes by DPP moves and
+// stored off a scalar base, the wave maximum as DPP v_max_f32 - no spill in the hot path of any form, ~50 vector
+// instructions a wave fewer; raw bit rows read by the stats waves themselves (kMaskRaw).)
 template <int DT, int MASK, bool SCALED, int MODE, int EXPC = kExpPoly>
 __global__ __launch_bounds__(64, (StatsWaves<DT, MASK>::value)) void fused_step_kernel(const StepParams p) {
   const int lane = threadIdx.x;
