@@ -114,6 +114,17 @@ def test_random_case(engine, oracle, c):
             assert np.array_equal(tok.cpu().numpy(), tok_o), f"token ({what})"
 
     check(call(), "auto")
+    # ... and under the second arithmetic contract (GLB_STEP_HW_EXP, round 6: the hardware's v_exp_f32): the same case against
+    # the oracle's exp2f restatement by tolerance - logZ / lse within 1e-4 of both restatements, NaN / infinity patterns equal,
+    # tokens equal except where the draw lies within 2^-20 of a boundary of the inverse CDF (tests/test_step_hw_gpu.py)
+    if c["rng_mode"] != "noise":
+        from tests.test_step_hw_gpu import check_hw
+
+        *want_hw, edge = O.step(x_np, row_of=row_of, rng_mode=mode, seed=seed, offset=offset, particle_base=base,
+                                logit_scale=c["scale"], n_particles=N if row_of is None else None, contract="hw",
+                                want_edge=True, **kw_o)
+        res = call(contract="hw")
+        check_hw(res if c["rng_mode"] != "none" else (res[0], res[1], None), want_hw, (logZ_o, lse_o, tok_o), edge, "hw contract")
     # the same rows through glb_log_softmax_rows (the one-launch kernel of independent waves; -inf and NaN logits, odd
     # sizes, misaligned and padded rows): lse and every finite log-probability bit for bit, NaN where the logit is NaN
     want, lse_w = O.log_softmax_rows(x_np, c["scale"])
