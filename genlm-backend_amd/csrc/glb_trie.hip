@@ -333,27 +333,37 @@ template <int OP>
 __device__ __forceinline__ void sweep_node(float *val, uint64_t e) {
   const int s = (int)(e & 0xffffu), c0 = (int)((e >> 16) & 0xffffu), cnt = (int)(e >> 32);
   double acc = 0.0;
-  for (int base = 0; __any(base < cnt); base += 8) {
-    const int rem = cnt - base;
-    const float *q = val + c0 + (rem > 0 ? base : 0);
-    if (__any(rem > 4)) {
-      float x[8];
+  auto add = [&](float x, bool in) {
+    if constexpr (OP == GLB_TRIE_SUM) acc += (double)(in ? x : 0.0f);
+    else acc = in ? fmax(acc, (double)x) : acc;
+  };
+  if (!__any(cnt > 4)) {  // the wave's widest node has at most four children: one trip of four
+    float x[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) x[j] = q[j];
+    for (int j = 0; j < 4; ++j) x[j] = val[c0 + j];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if constexpr (OP == GLB_TRIE_SUM) acc += (double)(j < rem ? x[j] : 0.0f);
-        else acc = j < rem ? fmax(acc, (double)x[j]) : acc;
+    for (int j = 0; j < 4; ++j) add(x[j], j < cnt);
+  } else {
+    // eight children a trip; the NEXT trip's eight are read before this trip's are added (round 6): a trip was an LDS round
+    // trip and then a chain of eight dependent double additions, one after the other - for the 256 children of a node near
+    // the root 32 times over, and a depth takes as long as its widest node
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = val[c0 + j];
+    for (int base = 0;; base += 8) {
+      const int rem = cnt - base;
+      const bool more = __any(rem > 8);
+      float nx[8];
+      if (more) {
+        const float *q = val + c0 + (rem > 8 ? base + 8 : 0);  // (a finished lane reads its own first children again)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) nx[j] = q[j];
       }
-    } else {
-      float x[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) x[j] = q[j];
+      for (int j = 0; j < 8; ++j) add(x[j], j < rem);
+      if (!more) break;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if constexpr (OP == GLB_TRIE_SUM) acc += (double)(j < rem ? x[j] : 0.0f);
-        else acc = j < rem ? fmax(acc, (double)x[j]) : acc;
-      }
+      for (int j = 0; j < 8; ++j) x[j] = nx[j];
     }
   }
   val[s] = (float)acc;
