@@ -307,6 +307,47 @@ def test_device_sis_with_one_mask_per_particle(llm, gold):
     assert sis._pm_prepared is None
 
 
+def test_device_sis_hands_moving_masks_over_raw_and_standing_ones_prepared(llm, gold):
+    """Round 6: the policy of `DeviceSIS._finish_step` for per-particle bit masks, on the CPU engine (host logic: the hand-over
+    kind of every step is counted in `pm_raw_steps`) - a tensor state seen for the first time goes RAW, seen again it is
+    prepared; few changed rows (`update_particle_masks`) are prepared again, many make the step raw while the prepared form
+    lags, a step before which nothing moved brings it up to date; `pm_raw_above = 1.0` never goes raw; the parity draw (two
+    launches) never does either.  Whatever the mix, the same run."""
+    from genlm_backend_amd.sis import DeviceSIS
+
+    masks = torch.from_numpy(gold["sis_masks"])
+    llm.register_masks(masks)
+    prompt = [int(t) for t in gold["sis_prompt"]]
+    V, N = masks.shape[1], 40
+    g = torch.Generator()
+    g.manual_seed(11)
+
+    def rows(n):
+        f = torch.where(torch.rand((n, V), generator=g) < 0.5, float("-inf"), 0.0)
+        f[:, 1:4] = 0.0
+        return llm.engine.mask_to_bits(f)[0]
+
+    pm0 = torch.cat([rows(N), llm.engine.mask_to_bits(masks[1:2])[0]]).contiguous()
+    script = [None, None, 3, 30, 2, None, N, 1]  # rows moved before each step (float32 rows: raw above a quarter = 10)
+    edits = [None if e is None else (torch.randperm(N, generator=g)[:e].to(torch.int32), rows(e)) for e in script]
+    runs = []
+    for above, rng in ((None, "philox"), (1.0, "philox"), (None, "torch")):
+        sis = DeviceSIS(llm, N, prompt, max_tokens=len(script), eos_id=0, seed=5, rng=rng, particle_masks=pm0.clone())
+        sis.pm_raw_above = above
+        kinds = []
+        for e in edits:
+            if e is not None:
+                sis.update_particle_masks(*e)
+            before = sis.pm_raw_steps
+            sis.step()
+            kinds.append(sis.pm_raw_steps > before)
+        ctx, lw = sis.results()
+        runs.append(([list(map(int, c)) for c in ctx], lw, kinds))
+    assert runs[0][2] == [True, False, False, True, True, False, True, True]
+    assert runs[1][2] == [False] * len(script) and runs[2][2] == [False] * len(script)
+    assert runs[0][0] == runs[1][0] and np.array_equal(runs[0][1], runs[1][1])
+
+
 @pytest.mark.parametrize("use_kv", [False, True])
 def test_device_sis_matches_reference(llm, gold, use_kv):
     from genlm_backend_amd.sis import DeviceSIS
